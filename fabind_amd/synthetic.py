@@ -1,0 +1,269 @@
+"""Seeded synthetic protein/ligand complexes with the reference's data-field contract.
+
+Two granularities:
+
+* :func:`make_stack_batch` -- the arguments of ``EfficientMCAttModel.forward``
+  (reference: FABind/fabind/models/att_model.py:170) for B complexes.
+* :func:`make_hetero_batch` -- a dict-like stand-in for the collated PyG ``HeteroData`` batch the
+  reference's ``IaBNet...forward(data, stage, train)`` consumes (field contract: SURVEY.md A.10,
+  built by FABind/fabind/utils/utils.py:231-442 in the reference).
+
+Geometry follows SURVEY.md section 8(d): protein C-alpha uniform in a sphere of 135 A^3/residue,
+ligand = 1.5 A random walk centred at 0.5 R, bonds = chain, LAS = index distance <= 2,
+node features 0.1*N(0,1).  Pure host-side torch; no reference code involved.
+"""
+import math
+
+import torch
+
+
+class Store(dict):
+    """Attribute-style dict (one PyG node/edge store)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+class HeteroBatch:
+    """Minimal stand-in for a collated ``torch_geometric.data.HeteroData`` batch.
+
+    ``data['compound'].batch``, ``data['complex', 'c2c', 'complex'].edge_index`` and graph-level
+    attributes (``data.coords``) behave as the reference expects; ``.to(device)`` moves tensors."""
+
+    def __init__(self):
+        object.__setattr__(self, "_stores", {})
+        object.__setattr__(self, "_glob", Store())
+
+    def __getitem__(self, key):
+        st = self._stores
+        if key not in st:
+            st[key] = Store()
+        return st[key]
+
+    def __getattr__(self, k):
+        try:
+            return self._glob[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self._glob[k] = v
+
+    def to(self, device):
+        for st in list(self._stores.values()) + [self._glob]:
+            for k, v in list(st.items()):
+                if torch.is_tensor(v):
+                    st[k] = v.to(device)
+        return self
+
+    def clone(self):
+        out = HeteroBatch()
+        for key, st in self._stores.items():
+            for k, v in st.items():
+                out[key][k] = v.clone() if torch.is_tensor(v) else v
+        for k, v in self._glob.items():
+            out._glob[k] = v.clone() if torch.is_tensor(v) else v
+        return out
+
+
+def _protein_coords(n, g):
+    """n points uniform in a sphere of volume 135*n A^3 (not centred yet)."""
+    R = (3.0 * 135.0 * n / (4.0 * math.pi)) ** (1.0 / 3.0)
+    pts = torch.empty(0, 3)
+    while pts.shape[0] < n:
+        c = (torch.rand(2 * n + 16, 3, generator=g) * 2 - 1) * R
+        c = c[(c ** 2).sum(-1) <= R * R]
+        pts = torch.cat([pts, c], 0)
+    return pts[:n], R
+
+
+def _ligand_walk(n, g):
+    steps = torch.randn(n, 3, generator=g)
+    steps = 1.5 * steps / steps.norm(dim=-1, keepdim=True)
+    walk = torch.cumsum(steps, 0)
+    return walk - walk.mean(0, keepdim=True)
+
+
+def _chain_bonds(n):
+    i = torch.arange(n - 1)
+    return torch.cat([torch.stack([i, i + 1]), torch.stack([i + 1, i])], 1)  # [2, 2(n-1)]
+
+
+def _las_edges(n):
+    i = torch.arange(n)
+    d = (i[:, None] - i[None, :]).abs()
+    r, c = torch.nonzero((d <= 2) & (d > 0)).T
+    return torch.stack([r, c])
+
+
+def _snap_off_cutoffs(x_norm, cutoffs, margin=2e-4):
+    """Nudge coordinates (normalised units) so no pair distance lies within `margin` of a cutoff.
+
+    Edge sets are thresholded distances; a 1-ulp difference at the cutoff changes the graph
+    discontinuously (hard parts), so parity inputs avoid the knife edge."""
+    for _ in range(20):
+        d = torch.cdist(x_norm.double(), x_norm.double())
+        bad = torch.zeros_like(d, dtype=torch.bool)
+        for c in cutoffs:
+            bad |= (d - c).abs() < margin
+        bad.fill_diagonal_(False)
+        if not bad.any():
+            break
+        rows = torch.nonzero(bad.any(1)).flatten()
+        x_norm[rows] += 1e-3 * (torch.arange(rows.numel(), dtype=x_norm.dtype)[:, None] % 7 + 1) * \
+            torch.tensor([[1.0, -0.7, 0.3]], dtype=x_norm.dtype)
+    return x_norm
+
+
+def make_complex(n_prot, n_lig, seed, scale=5.0):
+    """One complex: protein coords (centred), ligand pose, ligand reference conformer, bonds, LAS."""
+    g = torch.Generator().manual_seed(seed)
+    prot, R = _protein_coords(n_prot, g)
+    prot = prot - prot.mean(0, keepdim=True)
+    conf = _ligand_walk(n_lig, g)  # "rdkit" conformer, centred at 0
+    lig = conf + torch.tensor([[0.5 * R, 0.0, 0.0]])
+    return dict(prot=prot, lig=lig, conf=conf, R=R, bonds=_chain_bonds(n_lig), las=_las_edges(n_lig), g=g)
+
+
+def make_stack_batch(sizes, hidden, seed=0, scale=5.0, snap=True, dtype=torch.float32):
+    """Arguments of ``EfficientMCAttModel.forward`` for complexes of ``sizes=[(n_prot, n_lig), ...]``.
+
+    Node order inside a complex is ``[glb_c, ligand..., glb_p, protein...]`` (utils/utils.py:328-335).
+    Returns a dict: X [N,1,3] (A/scale), H [N,hidden], batch_id, segment_id (float 0/1), mask,
+    is_global, compound_edge_index [2,Eb], LAS_edge_index [2,El], coord_LAS [N,1,3]."""
+    Xs, Xl, Hs, bid, seg, msk, glb, bonds, las = [], [], [], [], [], [], [], [], []
+    off = 0
+    for b, (npr, nl) in enumerate(sizes):
+        c = make_complex(npr, nl, seed * 1000 + b, scale)
+        g = c["g"]
+        x = torch.cat([torch.zeros(1, 3), c["lig"], torch.zeros(1, 3), c["prot"]], 0) / scale
+        if snap:
+            x = _snap_off_cutoffs(x, (8.0 / scale, 10.0 / scale))
+        xl = torch.cat([torch.zeros(1, 3), c["conf"], torch.zeros(1, 3), torch.zeros(npr, 3)], 0) / scale
+        n = npr + nl + 2
+        Xs.append(x)
+        Xl.append(xl)
+        Hs.append(0.1 * torch.randn(n, hidden, generator=g))
+        bid.append(torch.full((n,), b, dtype=torch.long))
+        s = torch.zeros(n)
+        s[nl + 1:] = 1
+        seg.append(s)
+        m = torch.zeros(n, dtype=torch.bool)
+        m[:nl + 2] = True
+        msk.append(m)
+        gl = torch.zeros(n, dtype=torch.bool)
+        gl[0] = True
+        gl[nl + 1] = True
+        glb.append(gl)
+        bonds.append(c["bonds"] + 1 + off)
+        las.append(c["las"] + 1 + off)
+        off += n
+    return dict(
+        X=torch.cat(Xs).unsqueeze(1).to(dtype), H=torch.cat(Hs).to(dtype), batch_id=torch.cat(bid),
+        segment_id=torch.cat(seg), mask=torch.cat(msk), is_global=torch.cat(glb),
+        compound_edge_index=torch.cat(bonds, 1), LAS_edge_index=torch.cat(las, 1),
+        coord_LAS=torch.cat(Xl).unsqueeze(1).to(dtype), sizes=list(sizes))
+
+
+def make_hetero_batch(sizes, seed=0, pocket_radius=20.0, feat_scale=0.1, prot_feat=1280, lig_feat=56):
+    """A collated batch with every field ``IaBNet...forward`` / ``.inference`` reads.
+
+    ``sizes=[(n_prot_whole, n_lig), ...]``.  The pocket is the residues within `pocket_radius` of the
+    ligand centroid (what the reference's dataset builder does, utils/utils.py:121-144)."""
+    data = HeteroBatch()
+    acc = {k: [] for k in (
+        "c_feats", "c_coords", "c_rdkit", "c_batch", "p_feats", "p_batch", "keep", "pocket_batch",
+        "cx", "cx_las", "cx_seg", "cx_mask", "cx_glb", "cx_batch", "cx_c2c", "cx_LAS",
+        "wx", "wx_las", "wx_seg", "wx_mask", "wx_glb", "wx_batch", "wx_c2c", "wx_LAS",
+        "bond_x", "bond_batch", "las_x", "las_batch", "node_xyz", "node_xyz_whole", "coords",
+        "coords_center", "pocket_idx", "dis_map")}
+    off_c = off_w = 0
+    for b, (npr, nl) in enumerate(sizes):
+        c = make_complex(npr, nl, seed * 1000 + b)
+        g = c["g"]
+        prot, lig_true, conf = c["prot"], c["lig"], c["conf"]
+        com = lig_true.mean(0)
+        keep = ((prot - com) ** 2).sum(-1).sqrt() < pocket_radius
+        if keep.sum() < 5:
+            keep[:100] = True
+        pocket = prot[keep]
+        npk = int(keep.sum())
+        # initial ligand pose: conformer moved to the pocket centre (utils/utils.py:320-322 analogue)
+        rot = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+        init = conf @ rot.T
+        init = init - init.mean(0, keepdim=True) + pocket.mean(0, keepdim=True)
+        acc["c_feats"].append(feat_scale * torch.randn(nl, lig_feat, generator=g))
+        acc["p_feats"].append(feat_scale * torch.randn(npr, prot_feat, generator=g))
+        acc["c_coords"].append(init)
+        acc["c_rdkit"].append(conf)
+        acc["c_batch"].append(torch.full((nl,), b, dtype=torch.long))
+        acc["p_batch"].append(torch.full((npr,), b, dtype=torch.long))
+        acc["keep"].append(keep)
+        acc["pocket_batch"].append(torch.full((npk,), b, dtype=torch.long))
+        z1 = torch.zeros(1, 3)
+        for pre, pr, li, offn in (("cx", pocket, init, off_c), ("wx", prot, init - init.mean(0, keepdim=True), off_w)):
+            n = pr.shape[0] + nl + 2
+            acc[pre].append(torch.cat([z1, li, z1, pr], 0))
+            acc[pre + "_las"].append(torch.cat([z1, conf, z1, torch.zeros_like(pr)], 0))
+            s = torch.zeros(n)
+            s[nl + 1:] = 1
+            acc[pre + "_seg"].append(s)
+            m = torch.zeros(n, dtype=torch.bool)
+            m[:nl + 2] = True
+            acc[pre + "_mask"].append(m)
+            gl = torch.zeros(n, dtype=torch.bool)
+            gl[0] = True
+            gl[nl + 1] = True
+            acc[pre + "_glb"].append(gl)
+            acc[pre + "_batch"].append(torch.full((n,), b, dtype=torch.long))
+            acc[pre + "_c2c"].append(c["bonds"] + 1 + offn)
+            acc[pre + "_LAS"].append(c["las"] + 1 + offn)
+        off_c += npk + nl + 2
+        off_w += npr + nl + 2
+        acc["bond_x"].append((c["bonds"] + 1).T.contiguous())
+        acc["bond_batch"].append(torch.full((c["bonds"].shape[1],), b, dtype=torch.long))
+        acc["las_x"].append((c["las"] + 1).T.contiguous())
+        acc["las_batch"].append(torch.full((c["las"].shape[1],), b, dtype=torch.long))
+        acc["node_xyz"].append(pocket)
+        acc["node_xyz_whole"].append(prot)
+        acc["coords"].append(lig_true)
+        acc["coords_center"].append(com[None])
+        acc["pocket_idx"].append(keep.int())
+        dm = torch.cdist(pocket, lig_true).clamp(max=10.0)
+        acc["dis_map"].append(dm.flatten())
+    cat = lambda k, d=0: torch.cat(acc[k], d)
+    data["compound"].node_feats = cat("c_feats")
+    data["compound"].node_coords = cat("c_coords")
+    data["compound"].rdkit_coords = cat("c_rdkit")
+    data["compound"].batch = cat("c_batch")
+    data["protein_whole"].node_feats = cat("p_feats")
+    data["protein_whole"].batch = cat("p_batch")
+    data["pocket"].keepNode = cat("keep")
+    data["pocket"].batch = cat("pocket_batch")
+    for pre, name in (("cx", "complex"), ("wx", "complex_whole_protein")):
+        data[name].node_coords = cat(pre)
+        data[name].node_coords_LAS = cat(pre + "_las")
+        data[name].segment = cat(pre + "_seg")
+        data[name].mask = cat(pre + "_mask")
+        data[name].is_global = cat(pre + "_glb")
+        data[name].batch = cat(pre + "_batch")
+        data[name, "c2c", name].edge_index = cat(pre + "_c2c", 1)
+        data[name, "LAS", name].edge_index = cat(pre + "_LAS", 1)
+    data["compound_atom_edge_list"].x = cat("bond_x")
+    data["compound_atom_edge_list"].batch = cat("bond_batch")
+    data["LAS_edge_list"].x = cat("las_x")
+    data["LAS_edge_list"].batch = cat("las_batch")
+    data.node_xyz = cat("node_xyz")
+    data.node_xyz_whole = cat("node_xyz_whole")
+    data.coords = cat("coords")
+    data.coords_center = cat("coords_center")
+    data.pocket_idx = cat("pocket_idx")
+    data.dis_map = cat("dis_map")
+    data.pdb = ["syn%d_%d" % (seed, b) for b in range(len(sizes))]
+    return data

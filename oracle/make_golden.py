@@ -1,0 +1,222 @@
+"""TEST INFRASTRUCTURE -- generates tests/golden/*.npz by EXECUTING THE REFERENCE in this container.
+
+Run:  python oracle/make_golden.py           (needs /root/reference; it is absent on the GPU box)
+
+The reference's own python (FABind/fabind/models/*.py) is imported from where it lies under
+/root/reference with the stand-ins of oracle/refshim.py; seeded random weights (reference init, then
+the last coord-MLP layers scaled up so that atoms really move -- SURVEY.md section 7 "discriminating
+goldens") and seeded synthetic inputs (fabind_amd/synthetic.py) go in, and inputs + weights + outputs
+come out as small .npz fixtures.  Only data is written; no reference source is copied.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import refshim  # noqa: E402
+from fabind_amd import synthetic  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+COORD_GAIN = 300.0  # multiplies every *.coord_mlp.2.weight (reference init gain is 1e-3)
+
+
+class _Logger:
+    def log_message(self, s):
+        pass
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _boost(module):
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if n.endswith("coord_mlp.2.weight"):
+                p.mul_(COORD_GAIN)
+            # reference input/shrink/enlarge/distmap linears are xavier(gain=1e-3): lift them so the
+            # heads carry signal through to the outputs being compared
+            if n in ("protein_linear_whole_protein.weight", "compound_linear_whole_protein.weight",
+                     "embedding_shrink.weight", "embedding_enlarge.weight", "distmap_mlp.0.weight",
+                     "distmap_mlp.2.weight", "protein_to_pocket.linear1.weight",
+                     "protein_to_pocket.linear2.weight"):
+                p.mul_(300.0)
+
+
+def _hetero_to_ref(d):
+    """Copy a fabind_amd.synthetic.HeteroBatch into the shim's FakeHeteroData (same fields)."""
+    out = refshim.FakeHeteroData()
+    for key, st in d._stores.items():
+        for k, v in st.items():
+            out[key][k] = v.clone() if torch.is_tensor(v) else v
+    for k, v in d._glob.items():
+        setattr(out, k, v.clone() if torch.is_tensor(v) else v)
+    return out
+
+
+def golden_stack(mods, name, sizes, hidden, layers, n_iter, seed):
+    torch.manual_seed(seed)
+    args = refshim.production_args(hidden_size=hidden, mean_layers=layers, n_iter=n_iter)
+    norm = lambda x: x / 5.0
+    unnorm = lambda x: x * 5.0
+    model = mods["models.att_model"].EfficientMCAttModel(
+        args, hidden, hidden, 1, n_edge_feats=0, n_layers=layers, n_iter=n_iter, inter_cutoff=10.0,
+        intra_cutoff=8.0, normalize_coord=norm, unnormalize_coord=unnorm).eval()
+    _boost(model)
+    batch = synthetic.make_stack_batch(sizes, hidden, seed=seed)
+    cap = {}
+
+    def hook(label):
+        def f(mod, inp, out):
+            cap[label + ".h"] = _np(out[0])
+            cap[label + ".x"] = _np(out[1].reshape(-1, 3))
+            if len(out) > 2:
+                cap[label + ".alpha"] = _np(out[2])
+        return f
+
+    def edge_hook(mod, inp, out):
+        if "ctx_edges_noBond" not in cap:
+            cap["ctx_edges_noBond"], cap["inter_edges"] = _np(out[0]), _np(out[1])
+
+    hs = [model.extract_edges.register_forward_hook(edge_hook)]
+    res = {}
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        m = model.to(dt)
+        if tag == "f32":
+            for i in range(layers):
+                hs.append(getattr(m.gnn, "gcl_%d" % i).register_forward_hook(hook("gcl_%d" % i)))
+                hs.append(getattr(m.gnn, "att_%d" % i).register_forward_hook(hook("att_%d" % i)))
+        with torch.no_grad():
+            X, H = m(batch["X"].clone().to(dt), batch["H"].clone().to(dt), batch["batch_id"], batch["segment_id"],
+                     batch["mask"], batch["is_global"], batch["compound_edge_index"], batch["LAS_edge_index"],
+                     batch["coord_LAS"].clone().to(dt))
+        res["out_X_" + tag], res["out_H_" + tag] = _np(X), _np(H)
+        if tag == "f32":
+            for h in hs:
+                h.remove()
+    model.to(torch.float32)
+    moved = np.sqrt(((res["out_X_f32"] - _np(batch["X"])) ** 2).sum(-1)).max() * 5
+    noise = np.sqrt(((res["out_X_f32"] - res["out_X_f64"]) ** 2).sum(-1)).max() * 5
+    print("%s: max displacement %.3f A, f32-vs-f64 %.2e A, E_ctx %d E_inter %d" % (
+        name, moved, noise, cap["ctx_edges_noBond"].shape[1], cap["inter_edges"].shape[1]))
+    save = {("in_" + k): _np(v) for k, v in batch.items() if torch.is_tensor(v)}
+    save["sizes"] = np.array(sizes)
+    save["cfg"] = np.array([hidden, layers, n_iter, seed])
+    save.update({"w_" + k: _np(v) for k, v in model.state_dict().items()})
+    save.update(res)
+    save.update({"cap_" + k: v for k, v in cap.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
+def golden_model(mods, name, sizes, hidden, pocket_hidden, layers, n_iter, seed):
+    torch.manual_seed(seed)
+    args = refshim.production_args(hidden_size=hidden, pocket_pred_hidden_size=pocket_hidden, mean_layers=layers,
+                                   n_iter=n_iter, random_n_iter=False)
+    model = mods["models.model"].get_model(args, _Logger(), None).eval()
+    _boost(model)
+    data = synthetic.make_hetero_batch(sizes, seed=seed)
+    save = {"sizes": np.array(sizes), "cfg": np.array([hidden, pocket_hidden, layers, n_iter, seed])}
+    save.update({"w_" + k: _np(v) for k, v in model.state_dict().items()})
+    names = ["coords", "compound_batch", "y_pred", "y_pred_by_coords", "pocket_cls_pred", "pocket_cls",
+             "protein_out_mask_whole", "protein_coords_batched_whole", "pred_pocket_center", "dis_map"]
+    for stage in (1, 2):
+        with torch.no_grad():
+            out = model(_hetero_to_ref(data), stage=stage, train=False)
+        for n, o in zip(names, out[:10]):
+            save["s%d_%s" % (stage, n)] = _np(o)
+        save["s%d_keepNode_less_5" % stage] = np.array(out[10])
+        moved = (out[0] - data["compound"].node_coords).norm(dim=-1).max()
+        print("%s stage %d: ligand moved up to %.3f A, center %s" % (name, stage, moved, _np(out[8][0])))
+    with torch.no_grad():
+        out = model.inference(_hetero_to_ref(data))
+    save["inf_coords"] = _np(out[0])
+    # train-step loss + gradients (eval-mode modules: dropout off, no Gumbel noise; stage fixed)
+    for stage in (1, 2):
+        model.zero_grad()
+        d = _hetero_to_ref(data)
+        out = model(d, stage=stage, train=False)
+        F = torch.nn.functional
+        coords, c_batch, y_pred, y_by, logits, pocket_cls, p_mask, _, center, dis_map, _ = out
+        terms = dict(
+            pocket_cls=F.binary_cross_entropy_with_logits(logits, pocket_cls.float()) * (p_mask.numel() / p_mask.sum()),
+            pocket_center=0.05 * torch.nn.HuberLoss(delta=3.0)(center, d.coords_center),
+            contact=F.mse_loss(y_pred, dis_map), contact_by_pred=F.mse_loss(y_by, dis_map),
+            distill=F.mse_loss(y_by, y_pred), coord=F.smooth_l1_loss(coords, d.coords))
+        loss = sum(terms.values())
+        loss.backward()
+        save["s%d_loss" % stage] = _np(loss)
+        for k, v in terms.items():
+            save["s%d_loss_%s" % (stage, k)] = _np(v)
+        for n, p in model.named_parameters():
+            if p.grad is not None:  # norm + 16 evenly spaced entries per tensor keeps the fixture small
+                gflat = p.grad.flatten()
+                idx = torch.linspace(0, gflat.numel() - 1, 16).long()
+                save["s%d_gradnorm_%s" % (stage, n)] = _np(gflat.norm())
+                save["s%d_gradsmp_%s" % (stage, n)] = _np(gflat[idx])
+        print("%s stage %d: loss %.6f" % (name, stage, float(loss)), {k: round(float(v), 5) for k, v in terms.items()})
+    hd = {}
+    for key, st in data._stores.items():
+        kname = key if isinstance(key, str) else "|".join(key)
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                hd["d_%s::%s" % (kname, k)] = _np(v)
+    for k, v in data._glob.items():
+        if torch.is_tensor(v):
+            hd["d_::%s" % k] = _np(v)
+    save.update(hd)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
+def golden_stack_grad(mods, name, sizes, hidden, layers, seed):
+    """Gradients of a scalar of the stack outputs w.r.t. every parameter and the input H (n_iter=1)."""
+    torch.manual_seed(seed)
+    args = refshim.production_args(hidden_size=hidden, mean_layers=layers, n_iter=1)
+    model = mods["models.att_model"].EfficientMCAttModel(
+        args, hidden, hidden, 1, n_edge_feats=0, n_layers=layers, n_iter=1, inter_cutoff=10.0, intra_cutoff=8.0,
+        normalize_coord=lambda x: x / 5.0, unnormalize_coord=lambda x: x * 5.0).eval()
+    _boost(model)
+    batch = synthetic.make_stack_batch(sizes, hidden, seed=seed)
+    Hin = batch["H"].clone().requires_grad_(True)
+    g = torch.Generator().manual_seed(seed + 77)
+    N = Hin.shape[0]
+    cx, ch = torch.randn(N, 1, 3, generator=g), torch.randn(N, hidden, generator=g)
+    X, H = model(batch["X"].clone(), Hin, batch["batch_id"], batch["segment_id"], batch["mask"], batch["is_global"],
+                 batch["compound_edge_index"], batch["LAS_edge_index"], batch["coord_LAS"].clone())
+    loss = (X * cx).sum() + (H * ch).sum()
+    loss.backward()
+    save = {("in_" + k): _np(v) for k, v in batch.items() if torch.is_tensor(v)}
+    save["sizes"], save["cfg"] = np.array(sizes), np.array([hidden, layers, 1, seed])
+    save.update({"w_" + k: _np(v) for k, v in model.state_dict().items()})
+    save["cot_X"], save["cot_H"], save["loss"] = _np(cx), _np(ch), _np(loss)
+    save["out_X_f32"], save["out_H_f32"] = _np(X), _np(H)
+    save["grad_in_H"] = _np(Hin.grad)
+    nograd = []
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            nograd.append(n)
+        else:
+            save["grad_" + n] = _np(p.grad)
+    save["nograd"] = np.array(nograd)
+    print("%s: loss %.5f, %d params without grad" % (name, float(loss), len(nograd)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
+def main():
+    torch.set_num_threads(1)
+    os.makedirs(OUT, exist_ok=True)
+    mods = refshim.load_reference("FABind")
+    golden_stack(mods, "stack_tiny_it1", [(24, 7), (31, 5)], 32, 2, 1, seed=0)
+    golden_stack(mods, "stack_tiny_it3", [(24, 7), (31, 5)], 32, 2, 3, seed=1)
+    golden_stack(mods, "stack_mid_it2", [(100, 40), (90, 22)], 64, 2, 2, seed=2)
+    golden_stack_grad(mods, "stack_tiny_grad", [(24, 7), (31, 5)], 32, 2, seed=3)
+    golden_model(mods, "model_tiny", [(70, 8), (85, 6)], 64, 32, 2, 2, seed=4)
+
+
+if __name__ == "__main__":
+    main()

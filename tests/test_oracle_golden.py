@@ -1,0 +1,131 @@
+"""CPU: pins the oracle (oracle/fabind_oracle.py) to outputs of the reference itself
+(fixtures captured by oracle/make_golden.py from /root/reference)."""
+import numpy as np
+import pytest
+import torch
+
+import fabind_oracle as orc
+from helpers import hetero_from_npz, load_npz, rmsd, stack_inputs, weights
+
+STACKS = ["stack_tiny_it1", "stack_tiny_it3", "stack_mid_it2"]
+
+
+def _run_stack(g, dtype, capture=None):
+    sd, inp = weights(g, dtype), stack_inputs(g, dtype)
+    hidden, layers, n_iter, _ = [int(v) for v in g["cfg"]]
+    return orc.stack_forward(sd, "", inp["X"], inp["H"], inp["batch_id"], inp["segment_id"], inp["mask"],
+                             inp["is_global"], inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"],
+                             layers, n_iter, capture=capture)
+
+
+@pytest.mark.parametrize("name", STACKS)
+def test_stack_forward_matches_reference(name):
+    g = load_npz(name)
+    cap = {}
+    X, H = _run_stack(g, torch.float32, cap)
+    # coordinates are normalised (A/5): RMSD in Angstrom must be far below the 1e-4 gate
+    assert rmsd(X.numpy() * 5, g["out_X_f32"] * 5) < 2e-5
+    assert np.abs(H.numpy() - g["out_H_f32"]).max() <= 2e-5 * max(1.0, np.abs(g["out_H_f32"]).max())
+    # edge sets (first iteration) are identical including order
+    nb = g["in_compound_edge_index"].shape[1]
+    assert np.array_equal(cap["ctx_edges"][:, nb:].numpy(), g["cap_ctx_edges_noBond"])
+    assert np.array_equal(cap["inter_edges"].numpy(), g["cap_inter_edges"])
+
+
+@pytest.mark.parametrize("name", STACKS)
+def test_stack_forward_fp64_twin(name):
+    g = load_npz(name)
+    X, H = _run_stack(g, torch.float64)
+    assert rmsd(X.numpy() * 5, g["out_X_f64"] * 5) < 1e-9
+    assert np.abs(H.numpy() - g["out_H_f64"]).max() < 1e-8
+
+
+def test_per_layer_intermediates():
+    g = load_npz("stack_tiny_it1")
+    cap = {}
+    _run_stack(g, torch.float32, cap)
+    for k in ("gcl_0.h", "gcl_0.x", "att_0.h", "att_0.x", "att_0.alpha", "gcl_1.h", "att_1.x"):
+        ref = g["cap_" + k]
+        got = cap[k].numpy().reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
+
+
+def test_stack_gradients_match_reference():
+    g = load_npz("stack_tiny_grad")
+    sd, inp = weights(g), stack_inputs(g)
+    for v in sd.values():
+        v.requires_grad_(True)
+    Hin = inp["H"].clone().requires_grad_(True)
+    hidden, layers, n_iter, _ = [int(v) for v in g["cfg"]]
+    X, H = orc.stack_forward(sd, "", inp["X"], Hin, inp["batch_id"], inp["segment_id"], inp["mask"], inp["is_global"],
+                             inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"], layers, n_iter)
+    loss = (X * torch.from_numpy(g["cot_X"])).sum() + (H * torch.from_numpy(g["cot_H"])).sum()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    assert np.abs(Hin.grad.numpy() - g["grad_in_H"]).max() <= 1e-4 * np.abs(g["grad_in_H"]).max()
+    nograd = set(str(s) for s in g["nograd"])
+    for k, v in sd.items():
+        if k in nograd:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+        else:
+            ref = g["grad_" + k]
+            assert np.abs(v.grad.numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, k
+
+
+CFG = dict(orc.DEFAULT_CFG)
+
+
+def _model_cfg(g):
+    hidden, pocket_hidden, layers, n_iter, _ = [int(v) for v in g["cfg"]]
+    cfg = dict(CFG)
+    cfg.update(mean_layers=layers, n_iter=n_iter)
+    return cfg
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_model_forward_and_loss(stage):
+    g = load_npz("model_tiny")
+    sd, data = weights(g), hetero_from_npz(g)
+    out = orc.model_forward(sd, _model_cfg(g), data, stage=stage)
+    p = "s%d_" % stage
+    assert rmsd(out[0].numpy(), g[p + "coords"]) < 2e-5
+    for i, n in ((2, "y_pred"), (3, "y_pred_by_coords"), (4, "pocket_cls_pred"), (8, "pred_pocket_center"),
+                 (9, "dis_map")):
+        ref = g[p + n]
+        assert np.abs(out[i].numpy() - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), n
+    assert np.array_equal(out[5].numpy(), g[p + "pocket_cls"])
+    assert np.array_equal(out[6].numpy(), g[p + "protein_out_mask_whole"])
+    total, terms = orc.compute_loss(out, data)
+    assert abs(float(total) - float(g[p + "loss"])) <= 1e-5 * abs(float(g[p + "loss"]))
+    for k, v in terms.items():
+        assert abs(float(v) - float(g[p + "loss_" + k])) <= 1e-5 * max(abs(float(g[p + "loss_" + k])), 1e-3), k
+
+
+def test_model_inference():
+    g = load_npz("model_tiny")
+    coords, batch = orc.model_inference(weights(g), _model_cfg(g), hetero_from_npz(g))
+    assert rmsd(coords.numpy(), g["inf_coords"]) < 2e-5
+
+
+def test_model_gradients_sampled():
+    g = load_npz("model_tiny")
+    sd, data = weights(g), hetero_from_npz(g)
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    out = orc.model_forward(sd, _model_cfg(g), data, stage=1)
+    total, _ = orc.compute_loss(out, data)
+    total.backward()
+    checked = 0
+    for k, v in sd.items():
+        key = "s1_gradnorm_" + k
+        if key not in g:
+            continue
+        ref_n = float(g[key])
+        got = v.grad.flatten()
+        assert abs(float(got.norm()) - ref_n) <= 2e-3 * ref_n + 1e-6, k
+        idx = torch.linspace(0, got.numel() - 1, 16).long()
+        smp = g["s1_gradsmp_" + k]
+        assert np.abs(got[idx].numpy() - smp).max() <= 2e-3 * max(np.abs(smp).max(), ref_n / max(got.numel(), 1) ** 0.5) + 1e-7, k
+        checked += 1
+    assert checked > 300
