@@ -1,0 +1,97 @@
+"""ctypes binding of libfabind_hip.so (the C ABI declared in include/fabind_hip.h).
+
+The library is the product: there is NO fallback.  If it cannot be loaded, or a tensor handed to a
+kernel wrapper is not on a HIP device, the call raises."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfabind_hip.so")
+
+DT_F32, DT_BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+
+_vp, _i, _f, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long
+
+
+class GemmArgs(ctypes.Structure):
+    _fields_ = [(n, _vp) for n in ("A", "A2", "W", "C", "bias", "R", "r_index", "dotvec", "dot_out", "aux", "groups")] + \
+               [(n, _i) for n in ("M", "N", "K", "K1", "lda", "lda2", "ldw", "ldc", "ldr", "ldaux", "dot_ld",
+                                  "a_dtype", "w_dtype", "c_dtype", "aux_dtype", "act_pro", "act_epi", "dact_epi",
+                                  "accumulate", "store_preact", "n_groups", "max_m", "max_n")] + [("alpha", _f)]
+
+
+# name -> argtypes (every function returns int and takes the stream last)
+SIGNATURES = {
+    "fabind_gemm": [ctypes.POINTER(GemmArgs), _vp],
+    "fabind_transpose_act": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "fabind_colsum": [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp],
+    "fabind_edges_count": [_vp, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp],
+    "fabind_edges_fill": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "fabind_exclusive_scan": [_vp, _vp, _i, _vp],
+    "fabind_inter_meta": [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "fabind_edge_geom": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "fabind_gcl_pre": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "fabind_segment_sum": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp],
+    "fabind_coord_update": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
+    "fabind_cross_attn_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _vp],
+    "fabind_pair_bmat": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp],
+    "fabind_pair_hadamard": [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
+    "fabind_inter_attn_fwd": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
+                              _vp, _f, _i, _vp, _vp, _vp, _vp, _vp],
+    "fabind_las_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp],
+    "fabind_select_rows": [_vp, _vp, _vp, _i, _i, _vp, _vp],
+    "fabind_add": [_vp, _vp, _vp, _l, _vp],
+    "fabind_layernorm_fwd": [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp],
+    "fabind_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library; raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "fabind_amd: %s is missing -- build it with `python -m fabind_amd.build` (hipcc, gfx950). "
+            "There is no CPU/eager fallback for the hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.fabind_last_error.restype = ctypes.c_char_p
+    lib.fabind_abi_version.restype = ctypes.c_int
+    for name, argt in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.argtypes = argt
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, load().fabind_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  Refuses CPU tensors: no silent fallback."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("fabind_amd kernels need HIP device tensors; got a %s tensor" % t.device)
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return DT_F32
+    if dtype == torch.bfloat16:
+        return DT_BF16
+    raise TypeError("unsupported dtype %s" % dtype)

@@ -1,0 +1,343 @@
+// Attention-type kernels of the FABind layer for gfx950:
+//   * protein<->ligand cross attention with gated pair bias (RowAttentionBlock, reference
+//     models/cross_att.py:118-134 + models/model_utils.py:21-38,96-133), ragged (no padding);
+//   * inter-graph edge attention + coordinate update (MC_Att_L, models/egnn.py:186-252), one wave per
+//     aggregating node with an online segment softmax;
+//   * pair-embedding helpers, LAS geometry step (models/egnn.py:433-449), row select.
+#include "common.h"
+#include "fabind_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// cross attention forward: 64 queries x 4 heads per work-group, keys streamed through LDS in tiles
+// ------------------------------------------------------------------------------------------------
+#define CA_KT 32
+__global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __restrict__ q, int ldq,
+                                                             const float* __restrict__ k, const float* __restrict__ v,
+                                                             int ldkv, const float* __restrict__ gpre, int ldg,
+                                                             const float* __restrict__ bias, int bias_ld, int lin_col,
+                                                             int gate_col, const int* desc, float scale, float* out,
+                                                             int ldo, float* lse) {
+    __shared__ __attribute__((aligned(16))) float sK[CA_KT * 128];
+    __shared__ __attribute__((aligned(16))) float sV[CA_KT * 128];
+    const int* ds = desc + blockIdx.y * 8;
+    const int q_off = ds[0], nq = ds[1], k_off = ds[2], nk = ds[3];
+    const long pair_off = (long)(unsigned)ds[4] | ((long)ds[5] << 32);
+    const int sq = ds[6], sk = ds[7];
+    if ((int)(blockIdx.x * 64) >= nq) return;
+    const int tid = threadIdx.x, ql = tid >> 2, h = tid & 3;
+    const int qi = blockIdx.x * 64 + ql;
+    const bool valid = qi < nq;
+    float qr[32], o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) { qr[d] = 0.f; o[d] = 0.f; }
+    if (valid) {
+        const float* qp = q + (size_t)(q_off + qi) * ldq + h * 32;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) {
+            float4 t = *(const float4*)(qp + d);
+            qr[d] = t.x * scale; qr[d + 1] = t.y * scale; qr[d + 2] = t.z * scale; qr[d + 3] = t.w * scale;
+        }
+    }
+    float m = -INFINITY, l = 0.f;
+    for (int j0 = 0; j0 < nk; j0 += CA_KT) {
+        __syncthreads();
+        for (int i = tid; i < CA_KT * 32; i += 256) {  // 32 float4 per key row
+            int jr = i >> 5, c4 = (i & 31) * 4;
+            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+            if (j0 + jr < nk) {
+                kk = *(const float4*)(k + (size_t)(k_off + j0 + jr) * ldkv + c4);
+                vv = *(const float4*)(v + (size_t)(k_off + j0 + jr) * ldkv + c4);
+            }
+            *(float4*)(&sK[jr * 128 + c4]) = kk;
+            *(float4*)(&sV[jr * 128 + c4]) = vv;
+        }
+        __syncthreads();
+        if (!valid) continue;
+        const int jn = min(CA_KT, nk - j0);
+        for (int j = 0; j < jn; ++j) {
+            const float* kp = &sK[j * 128 + h * 32];
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; d += 4) {
+                float4 t = *(const float4*)(kp + d);
+                s += qr[d] * t.x + qr[d + 1] * t.y + qr[d + 2] * t.z + qr[d + 3] * t.w;
+            }
+            const size_t bi = (size_t)(pair_off + (long)qi * sq + (long)(j0 + j) * sk) * bias_ld;
+            s += bias[bi + lin_col + h] * sigmoid_f(bias[bi + gate_col + h]);
+            const float mn = fmaxf(m, s);
+            const float corr = __expf(m - mn), pj = __expf(s - mn);
+            l = l * corr + pj;
+            const float* vp = &sV[j * 128 + h * 32];
+#pragma unroll
+            for (int d = 0; d < 32; d += 4) {
+                float4 t = *(const float4*)(vp + d);
+                o[d] = o[d] * corr + pj * t.x; o[d + 1] = o[d + 1] * corr + pj * t.y;
+                o[d + 2] = o[d + 2] * corr + pj * t.z; o[d + 3] = o[d + 3] * corr + pj * t.w;
+            }
+            m = mn;
+        }
+    }
+    if (!valid) return;
+    const float inv = 1.f / l;
+    const float* gp = gpre + (size_t)(q_off + qi) * ldg + h * 32;
+    float* op = out + (size_t)(q_off + qi) * ldo + h * 32;
+#pragma unroll
+    for (int d = 0; d < 32; d += 4) {
+        float4 g = *(const float4*)(gp + d);
+        *(float4*)(op + d) = make_float4(o[d] * inv * sigmoid_f(g.x), o[d + 1] * inv * sigmoid_f(g.y),
+                                         o[d + 2] * inv * sigmoid_f(g.z), o[d + 3] * inv * sigmoid_f(g.w));
+    }
+    if (lse) lse[(size_t)(q_off + qi) * 4 + h] = m + __logf(l);
+}
+
+extern "C" int fabind_cross_attn_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv,
+                                     const float* gpre, int ldg, const float* bias, int bias_ld, int lin_col,
+                                     int gate_col, const int* desc, int B, int max_nq, float scale, float* out, int ldo,
+                                     float* lse, hipStream_t stream) {
+    FB_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0, "fabind_cross_attn_fwd: strides % 4");
+    if (B <= 0 || max_nq <= 0) return 0;
+    dim3 grid((max_nq + 63) / 64, B);
+    hipLaunchKernelGGL(cross_attn_fwd_kernel, grid, dim3(256), 0, stream, q, ldq, k, v, ldkv, gpre, ldg, bias, bias_ld,
+                       lin_col, gate_col, desc, scale, out, ldo, lse);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair helpers
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_bmat_kernel(const float* __restrict__ b0, int ldb,
+                                                        const float* __restrict__ wcomp, int NO, int H,
+                                                        const int* c_node, int n_rows, void* bmat, int bmat_dt) {
+    const int lane = threadIdx.x & 63;
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int j = r / NO, o = r % NO;
+    const float* bp = b0 + (size_t)c_node[j] * ldb;
+    const float* wp = wcomp + (size_t)o * H;
+    for (int c = lane * 4; c < H; c += 256) {
+        float4 a = *(const float4*)(bp + c), w = *(const float4*)(wp + c);
+        st4_any(bmat, bmat_dt, (size_t)r * H + c, make_float4(a.x * w.x, a.y * w.y, a.z * w.z, a.w * w.w));
+    }
+}
+
+extern "C" int fabind_pair_bmat(const float* b0, int ldb, const float* wcomp, int NO, int H, const int* c_node, int n_c,
+                                void* bmat, int bmat_dt, hipStream_t stream) {
+    FB_REQUIRE(H % 4 == 0 && ldb % 4 == 0, "fabind_pair_bmat: H/ldb % 4");
+    int n_rows = n_c * NO;
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(pair_bmat_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, b0, ldb, wcomp, NO, H, c_node,
+                       n_rows, bmat, bmat_dt);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void pair_hadamard_kernel(const float* __restrict__ a0, const float* __restrict__ b0,
+                                                            int ld0, int H, const float* __restrict__ a1,
+                                                            const float* __restrict__ b1, int ld1, int H2,
+                                                            const int* red_p, const int* red_c, int n_red, void* hd,
+                                                            int hd_dt, int ldh) {
+    const int lane = threadIdx.x & 63;
+    int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= n_red) return;
+    const int pn = red_p[e], cn = red_c[e];
+    for (int c = lane * 4; c < H; c += 256) {
+        float4 a = *(const float4*)(a0 + (size_t)pn * ld0 + c), b = *(const float4*)(b0 + (size_t)cn * ld0 + c);
+        st4_any(hd, hd_dt, (size_t)e * ldh + c, make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w));
+    }
+    for (int c = lane * 4; c < H2; c += 256) {
+        float4 a = *(const float4*)(a1 + (size_t)pn * ld1 + c), b = *(const float4*)(b1 + (size_t)cn * ld1 + c);
+        st4_any(hd, hd_dt, (size_t)e * ldh + H + c, make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w));
+    }
+}
+
+extern "C" int fabind_pair_hadamard(const float* a0, const float* b0, int ld0, int H, const float* a1, const float* b1,
+                                    int ld1, int H2, const int* red_p, const int* red_c, int n_red, void* hd, int hd_dt,
+                                    int ldh, hipStream_t stream) {
+    FB_REQUIRE(H % 4 == 0 && H2 % 4 == 0 && ld0 % 4 == 0 && ld1 % 4 == 0 && ldh % 4 == 0, "fabind_pair_hadamard: % 4");
+    if (n_red <= 0) return 0;
+    hipLaunchKernelGGL(pair_hadamard_kernel, dim3((n_red + 3) / 4), dim3(256), 0, stream, a0, b0, ld0, H, a1, b1, ld1,
+                       H2, red_p, red_c, n_red, hd, hd_dt, ldh);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// inter-graph edge attention, forward.  One wave per aggregating node.
+// ------------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(256) void inter_attn_fwd_kernel(
+    const float* __restrict__ qkv, int ldqkv, const float* __restrict__ cv, int ldcv, int H, const float* __restrict__ h,
+    int ldh, const float* __restrict__ x, const float* __restrict__ d, const float* __restrict__ rhohat,
+    const int* rowptr, const int* col, const int* red_idx, const float* bias_red, int bias_np,
+    const float* __restrict__ w_rk, const float* __restrict__ w_rv, const float* __restrict__ wcr,
+    const float* __restrict__ w3, float clampv, int n_rows, float* h_out, float* x_out, float* alpha, float* cvs) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    float4 qv[NS], acc[NS], wk[NS], wc[NS], w3v[NS];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float qw = 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        int c = s * 256 + lane * 4;
+        qv[s] = z4; acc[s] = z4; wk[s] = z4; wc[s] = z4; w3v[s] = z4;
+        if (c < H) {
+            qv[s] = *(const float4*)(qkv + (size_t)r * ldqkv + c);
+            wk[s] = *(const float4*)(w_rk + c);
+            wc[s] = *(const float4*)(wcr + c);
+            w3v[s] = *(const float4*)(w3 + c);
+            qw += qv[s].x * wk[s].x + qv[s].y * wk[s].y + qv[s].z * wk[s].z + qv[s].w * wk[s].w;
+        }
+    }
+    qw = wave_sum(qw);
+    float m = -INFINITY, l = 0.f, sar = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
+    for (int e = e0; e < e1; ++e) {
+        const int cn = col[e];
+        const float rh = rhohat[e];
+        float lp = 0.f, cp = 0.f;
+        float4 vv[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            int c = s * 256 + lane * 4;
+            vv[s] = z4;
+            if (c < H) {
+                float4 kk = *(const float4*)(qkv + (size_t)cn * ldqkv + H + c);
+                vv[s] = *(const float4*)(qkv + (size_t)cn * ldqkv + 2 * H + c);
+                float4 cc = *(const float4*)(cv + (size_t)cn * ldcv + c);
+                lp += qv[s].x * kk.x + qv[s].y * kk.y + qv[s].z * kk.z + qv[s].w * kk.w;
+                cp += w3v[s].x * silu_f(cc.x + rh * wc[s].x) + w3v[s].y * silu_f(cc.y + rh * wc[s].y) +
+                      w3v[s].z * silu_f(cc.z + rh * wc[s].z) + w3v[s].w * silu_f(cc.w + rh * wc[s].w);
+            }
+        }
+        lp = wave_sum(lp);
+        cp = wave_sum(cp);
+        float bsum = 0.f;
+        for (int kb = 0; kb < bias_np; ++kb) bsum += bias_red[(size_t)red_idx[e] * bias_np + kb];
+        const float logit = lp + rh * qw + bsum;
+        const float mn = fmaxf(m, logit);
+        const float corr = __expf(m - mn), pj = __expf(logit - mn);
+        l = l * corr + pj;
+        sar = sar * corr + pj * rh;
+        const float t = pj * cp;
+        ax = ax * corr + t * d[(size_t)e * 3]; ay = ay * corr + t * d[(size_t)e * 3 + 1]; az = az * corr + t * d[(size_t)e * 3 + 2];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            acc[s].x = acc[s].x * corr + pj * vv[s].x; acc[s].y = acc[s].y * corr + pj * vv[s].y;
+            acc[s].z = acc[s].z * corr + pj * vv[s].z; acc[s].w = acc[s].w * corr + pj * vv[s].w;
+        }
+        m = mn;
+        if (lane == 0) { alpha[e] = logit; cvs[e] = cp; }
+    }
+    const float inv = (e1 > e0) ? 1.f / l : 0.f;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        int c = s * 256 + lane * 4;
+        if (c < H) {
+            float4 hv = *(const float4*)(h + (size_t)r * ldh + c);
+            float4 wv = *(const float4*)(w_rv + c);
+            float4 o = make_float4(hv.x + (acc[s].x + sar * wv.x) * inv, hv.y + (acc[s].y + sar * wv.y) * inv,
+                                   hv.z + (acc[s].z + sar * wv.z) * inv, hv.w + (acc[s].w + sar * wv.w) * inv);
+            *(float4*)(h_out + (size_t)r * ldh + c) = o;
+        }
+    }
+    if (lane == 0) {
+        float tx = fminf(fmaxf(ax * inv, -clampv), clampv), ty = fminf(fmaxf(ay * inv, -clampv), clampv),
+              tz = fminf(fmaxf(az * inv, -clampv), clampv);
+        x_out[(size_t)r * 3] = x[(size_t)r * 3] + tx;
+        x_out[(size_t)r * 3 + 1] = x[(size_t)r * 3 + 1] + ty;
+        x_out[(size_t)r * 3 + 2] = x[(size_t)r * 3 + 2] + tz;
+    }
+    // the wave's own stores to alpha[] above are visible to it after this barrier-free fence
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int e = e0 + lane; e < e1; e += 64) alpha[e] = __expf(alpha[e] - m) * inv;
+}
+
+extern "C" int fabind_inter_attn_fwd(const float* qkv, int ldqkv, const float* cv, int ldcv, int H, const float* h,
+                                     int ldh, const float* x, const float* d, const float* rhohat, const int* rowptr,
+                                     const int* col, const int* red_idx, const float* bias_red, int bias_np,
+                                     const float* w_rk, const float* w_rv, const float* wcr, const float* w3,
+                                     float clampv, int n_rows, float* h_out, float* x_out, float* alpha, float* cvs,
+                                     hipStream_t stream) {
+    FB_REQUIRE(H % 4 == 0 && ldqkv % 4 == 0 && ldcv % 4 == 0 && ldh % 4 == 0, "fabind_inter_attn_fwd: % 4");
+    FB_REQUIRE(H <= 1024, "fabind_inter_attn_fwd: H <= 1024");
+    if (n_rows <= 0) return 0;
+    dim3 grid((n_rows + 3) / 4), block(256);
+#define LAUNCH(NS)                                                                                                   \
+    hipLaunchKernelGGL((inter_attn_fwd_kernel<NS>), grid, block, 0, stream, qkv, ldqkv, cv, ldcv, H, h, ldh, x, d,    \
+                       rhohat, rowptr, col, red_idx, bias_red, bias_np, w_rk, w_rv, wcr, w3, clampv, n_rows, h_out, \
+                       x_out, alpha, cvs)
+    if (H <= 256) LAUNCH(1); else if (H <= 512) LAUNCH(2); else LAUNCH(4);
+#undef LAUNCH
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LAS geometry step, row select, add
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void las_step_kernel(const float* __restrict__ x, const float* __restrict__ x0,
+                                                       const int* las_i, const int* las_j, const int* las_off,
+                                                       const int* node_off, const int* c_cnt, float step, float clampv,
+                                                       float* x_out) {
+    const int b = blockIdx.y;
+    const int off = node_off[b], n = node_off[b + 1] - off, C = c_cnt[b];
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n) return;
+    const int gu = off + u;
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (u >= 1 && u < C) {
+        for (int e = las_off[b]; e < las_off[b + 1]; ++e) {
+            if (las_j[e] != gu) continue;
+            const int i = las_i[e];
+            float dx = x[i * 3] - x[gu * 3], dy = x[i * 3 + 1] - x[gu * 3 + 1], dz = x[i * 3 + 2] - x[gu * 3 + 2];
+            float ex = x0[i * 3] - x0[gu * 3], ey = x0[i * 3 + 1] - x0[gu * 3 + 1], ez = x0[i * 3 + 2] - x0[gu * 3 + 2];
+            float cur = dx * dx + dy * dy + dz * dz, tru = ex * ex + ey * ey + ez * ez;
+            float f = 2.f * (cur - tru);
+            fx += f * (2.f * dx); fy += f * (2.f * dy); fz += f * (2.f * dz);
+        }
+    }
+    x_out[(size_t)gu * 3] = x[(size_t)gu * 3] + fminf(fmaxf(fx * step, -clampv), clampv);
+    x_out[(size_t)gu * 3 + 1] = x[(size_t)gu * 3 + 1] + fminf(fmaxf(fy * step, -clampv), clampv);
+    x_out[(size_t)gu * 3 + 2] = x[(size_t)gu * 3 + 2] + fminf(fmaxf(fz * step, -clampv), clampv);
+}
+
+extern "C" int fabind_las_step(const float* x, const float* x0, const int* las_i, const int* las_j, const int* las_off,
+                               const int* node_off, const int* c_cnt, int B, int max_n, float step, float clampv,
+                               float* x_out, hipStream_t stream) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(las_step_kernel, dim3((max_n + 255) / 256, B), dim3(256), 0, stream, x, x0, las_i, las_j, las_off,
+                       node_off, c_cnt, step, clampv, x_out);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void select_rows_kernel(const float* x, const float* z, const uint8_t* mask, int n, int width, float* out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n * width) return;
+    out[i] = mask[i / width] ? z[i] : x[i];
+}
+
+extern "C" int fabind_select_rows(const float* x, const float* z, const uint8_t* mask, int n, int width, float* x_out,
+                                  hipStream_t stream) {
+    long tot = (long)n * width;
+    if (tot <= 0) return 0;
+    hipLaunchKernelGGL(select_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, x, z, mask, n, width,
+                       x_out);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ void add_kernel(const float* a, const float* b, float* out, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+extern "C" int fabind_add(const float* a, const float* b, float* out, long n, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, b, out, n);
+    FB_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,13 @@
+// Error plumbing + ABI version for libfabind_hip.so
+#include "common.h"
+#include "fabind_hip.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+extern "C" void fabind_set_error(const char* msg) {
+    strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+    g_err[sizeof(g_err) - 1] = 0;
+}
+extern "C" const char* fabind_last_error(void) { return g_err; }
+extern "C" int fabind_abi_version(void) { return 1; }

@@ -1,0 +1,316 @@
+"""Host orchestration of the FABind layer stack on the HIP kernels (one process per GPU).
+
+Mirrors, call for call, what the reference's `EfficientMCAttModel.forward` -> `MCAttEGNN.forward`
+-> `MC_E_GCL` / `MC_Att_L` / `CrossAttentionModule` do (FABind/fabind/models/att_model.py:170-246,
+egnn.py:130-144,308-333,392-466, cross_att.py:24-54) but on the MI355X-first data layout:
+
+* nodes stay in the reference's complex-contiguous order, so the "dense" protein/ligand views are
+  contiguous slices (no to_dense_batch / un-batch copies);
+* graphs are int32 row-sorted CSR rebuilt on device every refinement iteration;
+* the first Linear of every edge MLP is split column-wise and evaluated per NODE, then gathered;
+* the [B,P,C,H] pair tensor is never materialised in FABind-v1 mode: every layer consumes the same
+  z0 = W_o(a_i*b_j)+b_o (att_model.py:198-206; egnn.py:413-418 discards the update), so the
+  RowAttention pair biases are one K=H contraction per forward, and `pair_transition` is only
+  evaluated at the (ligand, protein) pairs that carry an inter edge (egnn.py:286-304 gathers nothing else).
+
+Only parameter-only preprocessing (weight slicing / composition, O(H^2)) uses torch ops; everything that
+touches activations runs in libfabind_hip.so.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from . import ops
+
+from .config import get_precision, set_precision  # noqa: F401
+
+
+DEBUG_CAPTURE = None  # set to a dict to record per-layer outputs of the LAST egnn_forward call (tests)
+
+
+def _wd():
+    return torch.float32 if get_precision() == "fp32" else torch.bfloat16
+
+
+# ------------------------------------------------------------------------------------------------
+# layout of a batch of complexes
+# ------------------------------------------------------------------------------------------------
+class Layout:
+    """Per-batch index arrays.  One host sync (reading per-complex node counts) per construction."""
+
+    def __init__(self, batch_id, segment_id, n_pair_out=8):
+        dev = batch_id.device
+        B = int(batch_id[-1].item()) + 1
+        seg = (segment_id > 0.5) if segment_id.is_floating_point() else segment_id.bool()
+        cnt = torch.stack([torch.bincount(batch_id, minlength=B),
+                           torch.bincount(batch_id, weights=seg.to(torch.float64), minlength=B).long()]).cpu().numpy()
+        n, P = cnt[0].astype(np.int64), cnt[1].astype(np.int64)
+        C = n - P
+        off = np.concatenate([[0], np.cumsum(n)])
+        self.B, self.N = B, int(off[-1])
+        self.n, self.P, self.C, self.off = n, P, C, off
+        self.max_n, self.max_P, self.max_C = int(n.max()), int(P.max()), int(C.max())
+        coff = np.concatenate([[0], np.cumsum(C)])
+        poff = np.concatenate([[0], np.cumsum(P)])
+        pair_off = np.concatenate([[0], np.cumsum(P * C)])
+        self.n_pairs = int(pair_off[-1])
+        self.sumC, self.sumP = int(coff[-1]), int(poff[-1])
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+        self.node_off = i32(off)
+        self.c_cnt = i32(C)
+        c_index = np.concatenate([np.arange(off[b], off[b] + C[b]) for b in range(B)])
+        p_index = np.concatenate([np.arange(off[b] + C[b], off[b + 1]) for b in range(B)])
+        self.c_index, self.p_index = i32(c_index), i32(p_index)
+        self.c_index64, self.p_index64 = self.c_index.long(), self.p_index.long()
+        inv = np.empty(self.N, dtype=np.int64)
+        inv[c_index] = np.arange(self.sumC)
+        inv[p_index] = self.sumC + np.arange(self.sumP)
+        self.inv_perm = torch.from_numpy(inv).to(dev)
+
+        def desc(rows):
+            return i32(np.array(rows, dtype=np.int64).astype(np.int32).reshape(-1, 8))
+
+        lo = lambda v: int(v) & 0xFFFFFFFF
+        hi = lambda v: int(v) >> 32
+        s32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v
+        self.desc_p = desc([[poff[b], P[b], coff[b], C[b], s32(lo(pair_off[b])), hi(pair_off[b]), C[b], 1] for b in range(B)])
+        self.desc_c = desc([[coff[b], C[b], poff[b], P[b], s32(lo(pair_off[b])), hi(pair_off[b]), 1, C[b]] for b in range(B)])
+        NO = n_pair_out
+        self.NO = NO
+        self.pb_groups = desc([[off[b] + C[b], P[b], coff[b] * NO, C[b] * NO, s32(lo(pair_off[b] * NO)),
+                                hi(pair_off[b] * NO), C[b] * NO, 0] for b in range(B)])
+        self.pb_max_n = int((C * NO).max())
+
+    def ranges(self, idx_first):
+        """Per-complex [start,end) offsets of a complex-contiguous edge list given its first-node ids."""
+        which = torch.bucketize(idx_first, self.node_off[1:].to(idx_first.dtype), right=True)
+        cnt = torch.bincount(which, minlength=self.B)
+        out = torch.zeros(self.B + 1, dtype=torch.int32, device=idx_first.device)
+        out[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+        return out
+
+
+class Graph:
+    """ctx + inter CSR of the current coordinates (rebuilt each refinement iteration, no grad)."""
+
+    @torch.no_grad()
+    def __init__(self, lay, x, bond_row, bond_col, bond_off, cut_intra, cut_inter):
+        deg_ctx, deg_int = K.edges_count(x, lay.node_off, lay.c_cnt, lay.B, lay.max_n, bond_row, bond_off, cut_intra,
+                                         cut_inter)
+        rp_ctx, rp_int = K.exclusive_scan(deg_ctx), K.exclusive_scan(deg_int)
+        E_ctx, E_int = int(rp_ctx[-1].item()), int(rp_int[-1].item())
+        if E_int == 0:
+            # reference fallback (att_model.py:85-86): one fake symmetric pair from the first candidate,
+            # i.e. first ligand atom of complex 0 <-> its first protein residue.
+            u, v = 1, int(lay.C[0]) + 1
+            deg_int[u] = 1
+            deg_int[v] = 1
+            rp_int = K.exclusive_scan(deg_int)
+            E_int = 2
+            self.col_ctx, self.row_ctx, _, _ = K.edges_fill(x, lay.node_off, lay.c_cnt, lay.B, lay.max_n, bond_row,
+                                                            bond_col, bond_off, cut_intra, -1.0, rp_ctx, rp_ctx * 0,
+                                                            E_ctx, 0)
+            self.col_int = torch.tensor([v, u], dtype=torch.int32, device=x.device)
+            self.row_int = torch.tensor([u, v], dtype=torch.int32, device=x.device)
+        else:
+            self.col_ctx, self.row_ctx, self.col_int, self.row_int = K.edges_fill(
+                x, lay.node_off, lay.c_cnt, lay.B, lay.max_n, bond_row, bond_col, bond_off, cut_intra, cut_inter, rp_ctx,
+                rp_int, E_ctx, E_int)
+        self.rp_ctx, self.rp_int, self.E_ctx, self.E_int = rp_ctx, rp_int, E_ctx, E_int
+        self.red_off, self.red_idx, self.red_c, self.red_p = K.inter_meta(lay.node_off, lay.c_cnt, lay.B, rp_int,
+                                                                          self.col_int, self.row_int)
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter preparation (weight slicing / composition; differentiable torch ops on parameters only)
+# ------------------------------------------------------------------------------------------------
+def _cat(ts, d=0):
+    return torch.cat(list(ts), d)
+
+
+def prepare_stack_params(model):
+    """Pack the parameters of an EfficientMCAttModel for the kernels (see module docstring)."""
+    wd = _wd()
+    gnn = model.gnn
+    H = gnn.hidden_nf
+    L = gnn.n_layers
+    il = model.inter_layer
+    P = {"H": H, "L": L}
+    W = lambda t: t.to(wd).contiguous()
+    P["W_ab0"] = W(_cat([il.linear_p.weight, il.linear_c.weight]))
+    P["b_ab0"] = _cat([il.linear_p.bias, il.linear_c.bias]).contiguous()
+    Wo0, bo0 = il.linear_out.weight, il.linear_out.bias
+    rows, rb = [], []
+    for i in range(L):
+        cam = getattr(gnn, "att_%d" % i).cross_attn_module
+        for blk in (cam.p_attention_block, cam.c_attention_block):
+            rows.append(_cat([blk.linear.weight, blk.linear_g.weight]))       # [8, H]: lin heads 0-3, gate heads 4-7
+            rb.append(_cat([blk.linear.bias, blk.linear_g.bias]))
+    rows, rb = torch.stack(rows), torch.stack(rb)                            # [2L, 8, H], [2L, 8]
+    P["pb_wcomp"] = (rows @ Wo0).contiguous()                                # z0 = Wo0 (a*b) + bo0 folded in
+    P["pb_bconst"] = (rows @ bo0 + rb).contiguous()
+    P["W_in"], P["b_in"] = W(gnn.linear_in.weight), gnn.linear_in.bias
+    P["W_out"], P["b_out"] = W(gnn.linear_out.weight), gnn.linear_out.bias
+
+    def gcl(m):
+        W1 = m.edge_mlp[0].weight
+        Hh = m.edge_mlp[2].weight.shape[1]
+        Hin = (W1.shape[1] - 1) // 2
+        return dict(
+            W_ab=W(_cat([W1[:, :Hin], W1[:, Hin:2 * Hin]])),
+            b_ab=_cat([m.edge_mlp[0].bias, torch.zeros_like(m.edge_mlp[0].bias)]).contiguous(),
+            w_r=W1[:, 2 * Hin].contiguous(), W2=W(m.edge_mlp[2].weight), b2=m.edge_mlp[2].bias,
+            Wc=W(m.coord_mlp[0].weight), bc=m.coord_mlp[0].bias, w3=m.coord_mlp[2].weight[0].contiguous(),
+            Wn1=W(m.node_mlp[0].weight), bn1=m.node_mlp[0].bias, Wn2=W(m.node_mlp[2].weight), bn2=m.node_mlp[2].bias)
+
+    P["gcl"] = [gcl(getattr(gnn, "gcl_%d" % i)) for i in range(L)]
+    P["out_layer"] = gcl(gnn.out_layer)
+    att = []
+    for i in range(L):
+        m = getattr(gnn, "att_%d" % i)
+        cam = m.cross_attn_module
+        d = {}
+        for tag, blk in (("p", cam.p_attention_block), ("c", cam.c_attention_block)):
+            a = blk.mha
+            d["Wqg_" + tag] = W(_cat([a.linear_q.weight, a.linear_g.weight]))
+            d["bqg_" + tag] = _cat([torch.zeros_like(a.linear_g.bias), a.linear_g.bias]).contiguous()
+            d["Wkv_" + tag] = W(_cat([a.linear_k.weight, a.linear_v.weight]))
+            d["Wo_" + tag], d["bo_" + tag] = W(a.linear_o.weight), a.linear_o.bias
+        for tag, tr in (("p", cam.p_transition), ("c", cam.c_transition)):
+            d["Wt1_" + tag], d["bt1_" + tag] = W(tr.linear_1.weight), tr.linear_1.bias
+            d["Wt2_" + tag], d["bt2_" + tag] = W(tr.linear_2.weight), tr.linear_2.bias
+        i32 = cam.inter_layer
+        d["W_ab32"] = W(_cat([i32.linear_p.weight, i32.linear_c.weight]))
+        d["b_ab32"] = _cat([i32.linear_p.bias, i32.linear_c.bias]).contiguous()
+        pt = cam.pair_transition
+        Woo = _cat([Wo0, i32.linear_out.weight], 1)                  # [H, H+32]
+        d["Wcomp1"] = W(pt.linear_1.weight @ Woo)                    # [2H, H+32]
+        d["bcomp1"] = (pt.linear_1.weight @ (bo0 + i32.linear_out.bias) + pt.linear_1.bias).contiguous()
+        d["u"] = (pt.linear_2.weight.t() @ m.attn_bias_proj.weight[0]).contiguous()   # [2H]
+        Wkv, bkv = m.linear_kv.weight, m.linear_kv.bias
+        d["Wqkv"] = W(_cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]]))
+        d["bqkv"] = _cat([m.linear_q.bias, bkv[0::2], bkv[1::2]]).contiguous()
+        d["w_rk"], d["w_rv"] = Wkv[0::2, 0].contiguous(), Wkv[1::2, 0].contiguous()
+        d["Wc"], d["bc"] = W(m.coord_mlp[0].weight), m.coord_mlp[0].bias
+        d["w3"] = m.coord_mlp[2].weight[0].contiguous()
+        d["wcr"] = (m.coord_mlp[0].weight @ d["w_rv"]).contiguous()
+        att.append(d)
+    P["att"] = att
+    return P
+
+
+# ------------------------------------------------------------------------------------------------
+# layers
+# ------------------------------------------------------------------------------------------------
+def gcl_layer(p, h, x, lay, g, clampv):
+    """MC_E_GCL.forward (egnn.py:130-144): edge -> coord -> node, all from the layer's input h, x."""
+    H = h.shape[1]
+    AB = ops.linear(h, p["W_ab"], p["b_ab"])                                           # [N,2H] node-level
+    d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
+    pre = ops.gcl_pre(AB, H, g.row_ctx, g.col_ctx, rhohat, p["w_r"])                    # [E,H]  pre-activation
+    Z2 = ops.linear(pre, p["W2"], p["b2"], act_pro=K.ACT_SILU, out_dtype=ops.act_dtype())  # [E,H]  pre-activation
+    s = ops.linear_rowdot(Z2, p["Wc"], p["bc"], p["w3"], act_pro=K.ACT_SILU, act_epi=K.ACT_SILU)   # [E,nt]
+    x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
+    agg = ops.segment_sum(Z2, g.rp_ctx, g.row_ctx, h.shape[0], act=K.ACT_SILU)
+    t = ops.linear(h, p["Wn1"], p["bn1"], x2=agg)
+    h_new = ops.linear(t, p["Wn2"], p["bn2"], act_pro=K.ACT_SILU, residual=h)
+    return h_new, x_new
+
+
+def cross_attention(p, h, lay, pairbias, layer):
+    """CrossAttentionModule node path (cross_att.py:38-49) on compact protein / ligand arrays."""
+    hp, hc = ops.take_rows(h, lay.p_index64), ops.take_rows(h, lay.c_index64)
+    scale = 1.0 / math.sqrt(32.0)
+    bias_p, bias_c = pairbias[2 * layer], pairbias[2 * layer + 1]
+    qg = ops.linear(hp, p["Wqg_p"], p["bqg_p"])
+    kv = ops.linear(hc, p["Wkv_p"])
+    og = ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_p, lay.B, lay.max_P, scale)
+    hp = ops.linear(og, p["Wo_p"], p["bo_p"], residual=hp)
+    qg = ops.linear(hc, p["Wqg_c"], p["bqg_c"])
+    kv = ops.linear(hp, p["Wkv_c"])
+    og = ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_c, lay.B, lay.max_C, scale)
+    hc = ops.linear(og, p["Wo_c"], p["bo_c"], residual=hc)
+    t = ops.linear(hp, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU)
+    hp = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp)
+    t = ops.linear(hc, p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU)
+    hc = ops.linear(t, p["Wt2_c"], p["bt2_c"], residual=hc)
+    return ops.take_rows(torch.cat([hc, hp], 0), lay.inv_perm)
+
+
+def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv):
+    """MC_Att_L.forward (egnn.py:308-333)."""
+    H = h.shape[1]
+    h = cross_attention(p, h, lay, pairbias, layer)
+    # pair embedding at the inter-edge pairs only -> scalar attention bias (egnn.py:208, 286-304)
+    ab32 = ops.linear(h, p["W_ab32"], p["b_ab32"])                                     # [N,64]
+    hd = ops.pair_hadamard(a0b0, H, ab32, 32, g.red_p, g.red_c)                        # [n_red, H+32]
+    bias_part = ops.linear_rowdot(hd, p["Wcomp1"], p["bcomp1"], p["u"], act_epi=K.ACT_RELU)
+    qkv = ops.linear(h, p["Wqkv"], p["bqkv"])                                          # [N,3H]
+    cv = ops.linear(qkv[:, 2 * H:], p["Wc"], p["bc"])                                  # [N,H]
+    d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay)
+    h_new, x_new, alpha = ops.inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["wcr"],
+                                         p["w3"], clampv)
+    return h_new, x_new, alpha
+
+
+def egnn_forward(P, h, x, lay, g, las, x_las, a0b0, pairbias, scale, step):
+    """MCAttEGNN.forward (egnn.py:392-466), eval-mode dropout."""
+    clampv = 10.0 / scale
+    h = ops.linear(h, P["W_in"], P["b_in"])
+    cap = DEBUG_CAPTURE
+    for i in range(P["L"]):
+        h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv)
+        if cap is not None:
+            cap["gcl_%d.h" % i], cap["gcl_%d.x" % i] = h.detach().clone(), x.detach().clone()
+        h, x, alpha = att_layer(P["att"][i], h, x, lay, g, a0b0, pairbias, i, clampv)
+        if cap is not None:
+            cap["att_%d.h" % i], cap["att_%d.x" % i], cap["att_%d.alpha" % i] = h.detach().clone(), x.detach().clone(), alpha.detach().clone()
+        x = ops.las_step(x, x_las, las, lay, step, 15.0 / scale)
+    h, x = gcl_layer(P["out_layer"], h, x, lay, g, clampv)
+    return ops.linear(h, P["W_out"], P["b_out"]), x
+
+
+def pair_bias_all(P, a0b0, lay):
+    """RowAttention pair biases of every layer from z0 in one ragged-batched K=H contraction."""
+    H = P["H"]
+    return ops.pair_bias(a0b0, H, P["pb_wcomp"], P["pb_bconst"], lay)
+
+
+def stack_forward(model, X, Hin, batch_id, segment_id, mask, is_global, compound_edge_index, LAS_edge_index,
+                  coord_LAS, n_iter):
+    """EfficientMCAttModel.forward with refine='refine_coord' (att_model.py:198-246).
+
+    Mutates X in place like the reference (X[mask] = Z[mask]) and returns (X, H)."""
+    if not X.is_cuda:
+        raise RuntimeError("fabind_amd: the docking stack runs on a HIP device only (no CPU fallback); got " + str(X.device))
+    args = model.args
+    scale = float(args.coordinate_scale)
+    P = prepare_stack_params(model)
+    lay = Layout(batch_id, segment_id)
+    bond_row = compound_edge_index[0].to(torch.int32).contiguous()
+    bond_col = compound_edge_index[1].to(torch.int32).contiguous()
+    bond_off = lay.ranges(bond_row)
+    las = (LAS_edge_index[0].to(torch.int32).contiguous(), LAS_edge_index[1].to(torch.int32).contiguous())
+    las = las + (lay.ranges(las[0]),)
+    x = X.reshape(-1, 3).float().contiguous()
+    x_las = coord_LAS.reshape(-1, 3).float().contiguous()
+    mask_u8 = mask.to(torch.uint8).contiguous()
+    Hin = Hin.float().contiguous()
+    a0b0 = ops.linear(Hin, P["W_ab0"], P["b_ab0"])
+    pairbias = pair_bias_all(P, a0b0, lay)
+    cut_intra, cut_inter = float(model.extract_edges.intra_cutoff), float(model.extract_edges.inter_cutoff)
+    Hout = None
+    for r in range(n_iter):
+        last = r == n_iter - 1
+        g = Graph(lay, x.detach(), bond_row, bond_col, bond_off, cut_intra, cut_inter)
+        with torch.set_grad_enabled(last and torch.is_grad_enabled()):
+            Hout, z = egnn_forward(P, Hin, x, lay, g, las, x_las, a0b0, pairbias, scale,
+                                   float(args.geometry_reg_step_size))
+            x = ops.select_rows(x, z, mask_u8)
+    model.last_graph = g
+    with torch.no_grad():
+        X.copy_(x.reshape(X.shape).to(X.dtype))
+    Xout = x.reshape(X.shape)
+    return (Xout if Xout.requires_grad else X), Hout

@@ -1,0 +1,213 @@
+"""Thin Python wrappers over the C ABI (include/fabind_hip.h): allocate outputs with torch, pass raw
+device pointers + the current HIP stream.  No math happens here."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, GemmArgs, check, dt_code, ptr, stream
+
+__all__ = ["gemm", "transpose_act", "colsum", "edges_count", "edges_fill", "exclusive_scan", "inter_meta",
+           "edge_geom", "gcl_pre", "segment_sum", "coord_update", "cross_attn_fwd", "pair_bmat", "pair_hadamard",
+           "inter_attn_fwd", "las_step", "select_rows", "ACT_NONE", "ACT_SILU", "ACT_RELU", "ACT_SIGMOID"]
+
+GEMM_BN = 128
+
+
+def _ld(t):
+    assert t.stride(-1) == 1, "innermost dimension must be contiguous"
+    return t.stride(0) if t.dim() == 2 else t.shape[-1]
+
+
+def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=None, r_index=None,
+         out=None, out_dtype=torch.float32, want_out=True, dotvec=None, aux=None, dact=ACT_NONE, alpha=1.0,
+         accumulate=False, groups=None, n_groups=0, max_m=0, max_n=0, M=None, N=None, ldc=None):
+    """C = epi(pro([A|A2]) @ W^T); see FabindGemmArgs.  Returns (C or None, dot_partials or None).
+
+    `groups` (int32 [G,8] device tensor) selects the ragged-batched mode; then `out` must be given."""
+    lib = _lib.load()
+    a = GemmArgs()
+    K1 = A.shape[1]
+    K = K1 + (A2.shape[1] if A2 is not None else 0)
+    M = A.shape[0] if M is None else M
+    N = W.shape[0] if N is None else N
+    assert W.shape[1] == K, "gemm: K mismatch %s vs %s" % (tuple(W.shape), K)
+    if want_out and out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+    dot_out = None
+    if dotvec is not None:
+        nt = (N + GEMM_BN - 1) // GEMM_BN
+        dot_out = torch.empty((A.shape[0], nt), dtype=torch.float32, device=A.device)
+        a.dot_ld = nt
+    a.A, a.A2, a.W, a.C = ptr(A), ptr(A2), ptr(W), ptr(out) if want_out else None
+    a.bias, a.R, a.r_index = ptr(bias), ptr(residual), ptr(r_index)
+    a.dotvec, a.dot_out, a.aux, a.groups = ptr(dotvec), ptr(dot_out), ptr(aux), ptr(groups)
+    a.M, a.N, a.K, a.K1 = M, N, K, K1
+    a.lda, a.lda2, a.ldw = _ld(A), (_ld(A2) if A2 is not None else 0), _ld(W)
+    a.ldc = (ldc if ldc is not None else (_ld(out) if want_out else 0))
+    a.ldr = _ld(residual) if residual is not None else 0
+    a.ldaux = _ld(aux) if aux is not None else 0
+    a.a_dtype, a.w_dtype = dt_code(A.dtype), dt_code(W.dtype)
+    a.c_dtype = dt_code(out.dtype) if want_out else 0
+    a.aux_dtype = dt_code(aux.dtype) if aux is not None else 0
+    if A2 is not None:
+        assert A2.dtype == A.dtype
+    a.act_pro, a.act_epi, a.dact_epi = act_pro, act_epi, dact
+    a.accumulate = 1 if accumulate else 0
+    a.n_groups, a.max_m, a.max_n = n_groups, max_m, max_n
+    a.alpha = alpha
+    check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm")
+    return (out if want_out else None), dot_out
+
+
+def transpose_act(x, act=ACT_NONE, out_dtype=None):
+    R, C = x.shape
+    out = torch.empty((C, R), dtype=out_dtype or x.dtype, device=x.device)
+    check(_lib.load().fabind_transpose_act(ptr(x), dt_code(x.dtype), _ld(x), ptr(out), dt_code(out.dtype), R, R, C, act,
+                                           stream()), "fabind_transpose_act")
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    R, C = x.shape
+    nchunk = max(1, min(256, (R + 1023) // 1024))
+    scratch = torch.empty((nchunk, C), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((C,), dtype=torch.float32, device=x.device)
+        accumulate = False
+    check(_lib.load().fabind_colsum(ptr(x), dt_code(x.dtype), _ld(x), ptr(out), R, C, 1 if accumulate else 0,
+                                    ptr(scratch), nchunk, stream()), "fabind_colsum")
+    return out
+
+
+def edges_count(x, node_off, c_cnt, B, max_n, bond_row, bond_off, cut_intra, cut_inter):
+    N = x.shape[0]
+    deg_ctx = torch.empty(N, dtype=torch.int32, device=x.device)
+    deg_int = torch.empty(N, dtype=torch.int32, device=x.device)
+    check(_lib.load().fabind_edges_count(ptr(x), ptr(node_off), ptr(c_cnt), B, max_n, ptr(bond_row), ptr(bond_off),
+                                         cut_intra, cut_inter, ptr(deg_ctx), ptr(deg_int), stream()), "fabind_edges_count")
+    return deg_ctx, deg_int
+
+
+def exclusive_scan(deg):
+    out = torch.empty(deg.shape[0] + 1, dtype=torch.int32, device=deg.device)
+    check(_lib.load().fabind_exclusive_scan(ptr(deg), ptr(out), deg.shape[0], stream()), "fabind_exclusive_scan")
+    return out
+
+
+def edges_fill(x, node_off, c_cnt, B, max_n, bond_row, bond_col, bond_off, cut_intra, cut_inter, rowptr_ctx, rowptr_int,
+               E_ctx, E_int):
+    dev = x.device
+    col_ctx = torch.empty(max(E_ctx, 1), dtype=torch.int32, device=dev)
+    row_ctx = torch.empty(max(E_ctx, 1), dtype=torch.int32, device=dev)
+    col_int = torch.empty(max(E_int, 1), dtype=torch.int32, device=dev)
+    row_int = torch.empty(max(E_int, 1), dtype=torch.int32, device=dev)
+    check(_lib.load().fabind_edges_fill(ptr(x), ptr(node_off), ptr(c_cnt), B, max_n, ptr(bond_row), ptr(bond_col),
+                                        ptr(bond_off), cut_intra, cut_inter, ptr(rowptr_ctx), ptr(rowptr_int),
+                                        ptr(col_ctx), ptr(row_ctx), ptr(col_int), ptr(row_int), stream()),
+          "fabind_edges_fill")
+    return col_ctx[:E_ctx], row_ctx[:E_ctx], col_int[:E_int], row_int[:E_int]
+
+
+def inter_meta(node_off, c_cnt, B, rowptr_int, col_int, row_int):
+    dev = col_int.device
+    E = col_int.shape[0]
+    red_off = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    red_idx = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    n_red = E // 2
+    red_c = torch.empty(max(n_red, 1), dtype=torch.int32, device=dev)
+    red_p = torch.empty(max(n_red, 1), dtype=torch.int32, device=dev)
+    check(_lib.load().fabind_inter_meta(ptr(node_off), ptr(c_cnt), B, ptr(rowptr_int), ptr(col_int), ptr(row_int), E,
+                                        ptr(red_off), ptr(red_idx), ptr(red_c), ptr(red_p), stream()), "fabind_inter_meta")
+    return red_off, red_idx[:E], red_c[:n_red], red_p[:n_red]
+
+
+def edge_geom(x, row, col, rowptr, node_off, B):
+    E, dev = row.shape[0], x.device
+    d = torch.empty((max(E, 1), 3), dtype=torch.float32, device=dev)
+    rho = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+    rhohat = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+    norm = torch.empty(B, dtype=torch.float32, device=dev)
+    check(_lib.load().fabind_edge_geom(ptr(x), ptr(row), ptr(col), ptr(rowptr), ptr(node_off), B, ptr(d), ptr(rho),
+                                       ptr(rhohat), ptr(norm), stream()), "fabind_edge_geom")
+    return d[:E], rho[:E], rhohat[:E], norm
+
+
+def gcl_pre(AB, H, row, col, rhohat, w_r, out_dtype):
+    E = row.shape[0]
+    pre = torch.empty((E, H), dtype=out_dtype, device=AB.device)
+    check(_lib.load().fabind_gcl_pre(ptr(AB), _ld(AB), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r), ptr(pre),
+                                     dt_code(out_dtype), E, stream()), "fabind_gcl_pre")
+    return pre
+
+
+def segment_sum(Z, rowptr, n_rows, act=ACT_NONE):
+    H = Z.shape[1]
+    out = torch.empty((n_rows, H), dtype=torch.float32, device=Z.device)
+    check(_lib.load().fabind_segment_sum(ptr(Z), dt_code(Z.dtype), _ld(Z), H, ptr(rowptr), n_rows, act, ptr(out), H,
+                                         stream()), "fabind_segment_sum")
+    return out
+
+
+def coord_update(x, d, s_part, rowptr, mean, clampv, weight=None, want_s=False):
+    n_rows = x.shape[0]
+    x_out = torch.empty_like(x)
+    s_out = torch.empty(s_part.shape[0], dtype=torch.float32, device=x.device) if want_s else None
+    check(_lib.load().fabind_coord_update(ptr(x), ptr(d), ptr(s_part), s_part.shape[1], ptr(weight), ptr(rowptr), n_rows,
+                                          1 if mean else 0, clampv, ptr(x_out), ptr(s_out), stream()), "fabind_coord_update")
+    return x_out, s_out
+
+
+def cross_attn_fwd(q, k, v, gpre, bias, lin_col, gate_col, desc, B, max_nq, scale, out, want_lse=False):
+    lse = torch.empty((q.shape[0], 4), dtype=torch.float32, device=q.device) if want_lse else None
+    assert k.stride(0) == v.stride(0)
+    check(_lib.load().fabind_cross_attn_fwd(ptr(q), _ld(q), ptr(k), ptr(v), _ld(k), ptr(gpre), _ld(gpre), ptr(bias),
+                                            _ld(bias), lin_col, gate_col, ptr(desc), B, max_nq, scale, ptr(out), _ld(out),
+                                            ptr(lse), stream()), "fabind_cross_attn_fwd")
+    return out, lse
+
+
+def pair_bmat(b0, wcomp, c_node, out_dtype):
+    NO, H = wcomp.shape
+    n_c = c_node.shape[0]
+    out = torch.empty((n_c * NO, H), dtype=out_dtype, device=b0.device)
+    check(_lib.load().fabind_pair_bmat(ptr(b0), _ld(b0), ptr(wcomp), NO, H, ptr(c_node), n_c, ptr(out),
+                                       dt_code(out_dtype), stream()), "fabind_pair_bmat")
+    return out
+
+
+def pair_hadamard(a0, b0, a1, b1, red_p, red_c, out_dtype):
+    H, H2 = a0.shape[1], a1.shape[1]
+    n_red = red_p.shape[0]
+    hd = torch.empty((n_red, H + H2), dtype=out_dtype, device=a0.device)
+    assert a0.stride(0) == b0.stride(0) and a1.stride(0) == b1.stride(0)
+    check(_lib.load().fabind_pair_hadamard(ptr(a0), ptr(b0), _ld(a0), H, ptr(a1), ptr(b1), _ld(a1), H2, ptr(red_p),
+                                           ptr(red_c), n_red, ptr(hd), dt_code(out_dtype), H + H2, stream()),
+          "fabind_pair_hadamard")
+    return hd
+
+
+def inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, rowptr, col, red_idx, bias_part, w_rk, w_rv, wcr, w3, clampv):
+    n_rows, E = h.shape[0], col.shape[0]
+    h_out, x_out = torch.empty_like(h), torch.empty_like(x)
+    alpha = torch.empty(max(E, 1), dtype=torch.float32, device=h.device)
+    cvs = torch.empty(max(E, 1), dtype=torch.float32, device=h.device)
+    check(_lib.load().fabind_inter_attn_fwd(ptr(qkv), _ld(qkv), ptr(cv), _ld(cv), H, ptr(h), _ld(h), ptr(x), ptr(d),
+                                            ptr(rhohat), ptr(rowptr), ptr(col), ptr(red_idx), ptr(bias_part),
+                                            bias_part.shape[1], ptr(w_rk), ptr(w_rv), ptr(wcr), ptr(w3), clampv, n_rows,
+                                            ptr(h_out), ptr(x_out), ptr(alpha), ptr(cvs), stream()), "fabind_inter_attn_fwd")
+    return h_out, x_out, alpha[:E], cvs[:E]
+
+
+def las_step(x, x0, las_i, las_j, las_off, node_off, c_cnt, B, max_n, step, clampv):
+    x_out = torch.empty_like(x)
+    check(_lib.load().fabind_las_step(ptr(x), ptr(x0), ptr(las_i), ptr(las_j), ptr(las_off), ptr(node_off), ptr(c_cnt), B,
+                                      max_n, step, clampv, ptr(x_out), stream()), "fabind_las_step")
+    return x_out
+
+
+def select_rows(x, z, mask_u8):
+    out = torch.empty_like(x)
+    check(_lib.load().fabind_select_rows(ptr(x), ptr(z), ptr(mask_u8), x.shape[0], x.shape[1], ptr(out), stream()),
+          "fabind_select_rows")
+    return out

@@ -1,0 +1,319 @@
+"""IaBNet_mean_and_pocket_prediction_cls_coords_dependent / get_model on the HIP engine.
+
+Same constructor, parameter names (394 state_dict keys at the production sizes), forward / inference
+signatures and return tuples as the reference (FABind/fabind/models/model.py:26-586).  The reference's
+per-sample python loops (model.py:104-115, 195-288, 308-319) are replaced by vectorised index
+arithmetic (pure data movement); every contraction runs in libfabind_hip.so."""
+import random
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn import Linear
+
+from .. import kernels as K
+from .. import ops
+from ..utils.utils import get_keepNode_tensor, gumbel_softmax_no_random  # noqa: F401
+from .att_model import EfficientMCAttModel
+
+
+class Transition_diff_out_dim(nn.Module):
+    """LayerNorm -> Linear(C, n*C) -> ReLU -> Linear(n*C, out) (reference model.py:11-24)."""
+
+    def __init__(self, embedding_channels=256, out_channels=256, n=4):
+        super().__init__()
+        self.layernorm = nn.LayerNorm(embedding_channels)
+        self.linear1 = Linear(embedding_channels, n * embedding_channels)
+        self.linear2 = Linear(n * embedding_channels, out_channels)
+        torch.nn.init.xavier_uniform_(self.linear1.weight, gain=0.001)
+        torch.nn.init.xavier_uniform_(self.linear2.weight, gain=0.001)
+
+    def forward(self, z):
+        shp = z.shape
+        wd = ops.mm_dtype()
+        t = ops.layernorm(z.reshape(-1, shp[-1]).float().contiguous(), self.layernorm.weight, self.layernorm.bias,
+                          self.layernorm.eps)
+        t = ops.linear(t, self.linear1.weight.to(wd), self.linear1.bias, act_epi=K.ACT_RELU)
+        w2 = self.linear2.weight
+        y = ops.linear(t, w2.to(wd), self.linear2.bias)
+        return y.reshape(shp[:-1] + (w2.shape[0],))
+
+
+def _offsets(counts):
+    return torch.cumsum(counts, 0) - counts
+
+
+class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
+    def __init__(self, args, embedding_channels=128, pocket_pred_embedding_channels=128):
+        super().__init__()
+        self.layernorm = nn.LayerNorm(embedding_channels)
+        self.args = args
+        self.coordinate_scale = args.coordinate_scale
+        self.normalize_coord = lambda x: x / self.coordinate_scale
+        self.unnormalize_coord = lambda x: x * self.coordinate_scale
+        self.stage_prob = args.stage_prob
+        n_channel = 1
+        self.complex_model = EfficientMCAttModel(
+            args, embedding_channels, embedding_channels, n_channel, n_edge_feats=0, n_layers=args.mean_layers,
+            n_iter=args.n_iter, inter_cutoff=args.inter_cutoff, intra_cutoff=args.intra_cutoff,
+            normalize_coord=self.normalize_coord, unnormalize_coord=self.unnormalize_coord)
+        self.pocket_pred_model = EfficientMCAttModel(
+            args, pocket_pred_embedding_channels, pocket_pred_embedding_channels, n_channel, n_edge_feats=0,
+            n_layers=args.pocket_pred_layers, n_iter=args.pocket_pred_n_iter, inter_cutoff=args.inter_cutoff,
+            intra_cutoff=args.intra_cutoff, normalize_coord=self.normalize_coord,
+            unnormalize_coord=self.unnormalize_coord)
+        self.protein_to_pocket = Transition_diff_out_dim(embedding_channels=embedding_channels, n=4, out_channels=1)
+        self.glb_c = nn.Parameter(torch.ones(1, embedding_channels))
+        self.glb_p = nn.Parameter(torch.ones(1, embedding_channels))
+        protein_hidden = 1280 if args.use_esm2_feat else 15
+        if args.esm2_concat_raw:
+            protein_hidden = 1295
+        self.protein_linear_whole_protein = nn.Linear(protein_hidden, embedding_channels)
+        self.compound_linear_whole_protein = nn.Linear(56, embedding_channels)
+        self.embedding_shrink = nn.Linear(embedding_channels, pocket_pred_embedding_channels)
+        self.embedding_enlarge = nn.Linear(pocket_pred_embedding_channels, embedding_channels)
+        self.distmap_mlp = nn.Sequential(nn.Linear(embedding_channels, embedding_channels), nn.ReLU(),
+                                         nn.Linear(embedding_channels, 1))
+        for lin in (self.protein_linear_whole_protein, self.compound_linear_whole_protein, self.embedding_shrink,
+                    self.embedding_enlarge, self.distmap_mlp[0], self.distmap_mlp[2]):
+            torch.nn.init.xavier_uniform_(lin.weight, gain=0.001)
+
+    # ---- helpers ------------------------------------------------------------------------------
+    def _lin(self, lin, x, **kw):
+        return ops.linear(x.float().contiguous(), lin.weight.to(ops.mm_dtype()), lin.bias, **kw)
+
+    def _assemble(self, segment, is_global, c_emb, p_emb):
+        """[glb_c | ligand | glb_p | protein] per complex as one gather (replaces model.py:104-115)."""
+        seg1 = segment.bool() if not segment.is_floating_point() else segment > 0.5
+        N = seg1.shape[0]
+        idx = torch.empty(N, dtype=torch.long, device=seg1.device)
+        idx[is_global & ~seg1] = 0
+        idx[is_global & seg1] = 1
+        cf, pf = ~seg1 & ~is_global, seg1 & ~is_global
+        idx[cf] = 2 + torch.arange(c_emb.shape[0], device=idx.device)
+        idx[pf] = 2 + c_emb.shape[0] + torch.arange(p_emb.shape[0], device=idx.device)
+        return torch.cat([self.glb_c, self.glb_p, c_emb, p_emb], 0).index_select(0, idx), cf, pf
+
+    def _pocket_head(self, data):
+        """Whole-protein pocket model + classifier (model.py:98-141)."""
+        w = data['complex_whole_protein']
+        c_emb = self._lin(self.compound_linear_whole_protein, data['compound'].node_feats)
+        p_emb = self._lin(self.protein_linear_whole_protein, data['protein_whole'].node_feats)
+        h0, cf, pf = self._assemble(w.segment, w.is_global, c_emb, p_emb)
+        h0 = self._lin(self.embedding_shrink, h0)
+        Xw = self.normalize_coord(w.node_coords.unsqueeze(-2)).float()
+        Xl = self.normalize_coord(w.node_coords_LAS.unsqueeze(-2)).float()
+        _, hw = self.pocket_pred_model(
+            Xw, h0, batch_id=w.batch, segment_id=w.segment, mask=w.mask, is_global=w.is_global,
+            compound_edge_index=data['complex_whole_protein', 'c2c', 'complex_whole_protein'].edge_index,
+            LAS_edge_index=data['complex_whole_protein', 'LAS', 'complex_whole_protein'].edge_index,
+            batched_complex_coord_LAS=Xl, LAS_mask=None)
+        hw = self._lin(self.embedding_enlarge, hw)
+        c_out, p_out = hw[cf], hw[pf]
+        logits_flat = self.protein_to_pocket(p_out).squeeze(-1)                      # [sum L]
+        pb = data['protein_whole'].batch
+        B = int(pb[-1].item()) + 1
+        cnt = torch.bincount(pb, minlength=B)
+        loc = torch.arange(pb.shape[0], device=pb.device) - _offsets(cnt)[pb]
+        Lmax = int(cnt.max().item())
+        mask = torch.zeros(B, Lmax, dtype=torch.bool, device=pb.device)
+        mask[pb, loc] = True
+        logits = torch.zeros(B, Lmax, dtype=logits_flat.dtype, device=pb.device).index_put((pb, loc), logits_flat)
+        xyz = torch.zeros(B, Lmax, 3, dtype=data.node_xyz_whole.dtype, device=pb.device)
+        xyz[pb, loc] = data.node_xyz_whole
+        return dict(B=B, c_out=c_out, p_out=p_out, logits=logits, mask=mask, xyz=xyz, pb=pb, loc=loc, cnt=cnt,
+                    logits_flat=logits_flat)
+
+    def _soft_center(self, logits, mask, xyz, noise):
+        pt = logits.sigmoid().unsqueeze(-1)
+        prob = torch.clamp(torch.cat([1. - pt, pt], dim=-1), min=1e-6, max=1 - 1e-6)
+        logp = torch.log(prob)
+        if noise:
+            y = F.gumbel_softmax(logp, tau=self.args.gs_tau, hard=self.args.gs_hard)
+        else:
+            y = gumbel_softmax_no_random(logp, tau=self.args.gs_tau, hard=self.args.gs_hard)
+        wgt = (y[:, :, 1] * mask).unsqueeze(-1)
+        return (wgt * xyz).sum(dim=1) / wgt.sum(dim=1)
+
+    @torch.no_grad()
+    def _stage2_indices(self, data, head, center):
+        """Pocket crop + re-batch as index arithmetic (replaces the python loop model.py:195-288)."""
+        dev = center.device
+        pb, B = head['pb'], head['B']
+        cb = data['compound'].batch
+        keep = get_keepNode_tensor(data.node_xyz_whole, self.args.pocket_radius, None, center.detach()[pb])
+        kcnt = torch.bincount(pb[keep], minlength=B)
+        bad = kcnt < 5
+        less5 = int(bad.sum().item())
+        if less5:
+            keep = keep | (bad[pb] & (head['loc'] < 100))
+            kcnt = torch.bincount(pb[keep], minlength=B)
+        ncnt = torch.bincount(cb, minlength=B)
+        n = ncnt + kcnt + 2
+        off = _offsets(n)
+        N = int(n.sum().item())
+        pocket_batch = pb[keep]
+        lig_pos = off[cb] + 1 + (torch.arange(cb.shape[0], device=dev) - _offsets(ncnt)[cb])
+        prot_pos = off[pocket_batch] + ncnt[pocket_batch] + 2 + \
+            (torch.arange(pocket_batch.shape[0], device=dev) - _offsets(kcnt)[pocket_batch])
+        glbc_pos, glbp_pos = off, off + ncnt + 1
+        segment = torch.zeros(N, dtype=torch.bool, device=dev)
+        segment[prot_pos] = True
+        segment[glbp_pos] = True
+        is_global = torch.zeros(N, dtype=torch.bool, device=dev)
+        is_global[glbc_pos] = True
+        is_global[glbp_pos] = True
+        mask = ~segment | is_global
+        batch = torch.repeat_interleave(torch.arange(B, device=dev), n)
+        return dict(keep=keep, less5=less5, n=n, off=off, N=N, pocket_batch=pocket_batch, lig_pos=lig_pos,
+                    prot_pos=prot_pos, segment=segment, is_global=is_global, mask=mask, batch=batch, ncnt=ncnt, kcnt=kcnt)
+
+    def _stage2(self, data, head, center):
+        ix = self._stage2_indices(data, head, center)
+        dev = center.device
+        cb = data['compound'].batch
+        B = head['B']
+        pocket_xyz = data.node_xyz_whole[ix['keep']]
+        pemb = head['p_out'][ix['keep']]
+        H, _, _ = self._assemble(ix['segment'], ix['is_global'], head['c_out'], pemb)
+        with torch.no_grad():
+            li = data['compound'].node_coords.float()
+            mean_l = torch.zeros(B, 3, device=dev).index_add_(0, cb, li) / ix['ncnt'][:, None]
+            mean_p = torch.zeros(B, 3, device=dev).index_add_(0, ix['pocket_batch'], pocket_xyz.float()) / ix['kcnt'][:, None]
+            X = torch.zeros(ix['N'], 3, device=dev)
+            X[ix['lig_pos']] = li - mean_l[cb] + mean_p[cb]
+            X[ix['prot_pos']] = pocket_xyz.float()
+            XL = torch.zeros(ix['N'], 3, device=dev)
+            if self.args.compound_coords_init_mode in ('redocking', 'redocking_no_rotate'):
+                XL[ix['lig_pos']] = li
+            else:
+                XL[ix['lig_pos']] = data['compound'].rdkit_coords.float()
+            el, ll = data['compound_atom_edge_list'], data['LAS_edge_list']
+            c2c = (el.x + ix['off'][el.batch][:, None]).t().contiguous().long()
+            las = (ll.x + ix['off'][ll.batch][:, None]).t().contiguous().long()
+            # distance map against the INITIAL ligand pose (model.py:286-287), protein-major per complex
+            pi, ci = self._pair_lists(ix['pocket_batch'], cb, ix['kcnt'], ix['ncnt'])
+            dis_map = (pocket_xyz.float()[pi] - li[ci]).norm(dim=-1).clamp(max=10.0)
+        # the reference overwrites the batch's `complex` stores (model.py:291-300)
+        cx = data['complex']
+        cx.node_coords, cx.node_coords_LAS, cx.segment, cx.mask, cx.is_global = X, XL, ix['segment'], ix['mask'], ix['is_global']
+        data['complex', 'c2c', 'complex'].edge_index = c2c
+        data['complex', 'LAS', 'complex'].edge_index = las
+        return dict(H=H, X=X, XL=XL, segment=ix['segment'], mask=ix['mask'], is_global=ix['is_global'], batch=ix['batch'],
+                    c2c=c2c, LAS=las, pocket_xyz=pocket_xyz, pocket_batch=ix['pocket_batch'], dis_map=dis_map,
+                    less5=ix['less5'], pairs=(pi, ci))
+
+    @staticmethod
+    def _pair_lists(pocket_batch, cb, kcnt, ncnt):
+        """(pocket index, ligand index) of every valid pair, protein-major inside each complex."""
+        dev = pocket_batch.device
+        reps = ncnt[pocket_batch]                                   # each pocket residue pairs with Nc_b atoms
+        pi = torch.repeat_interleave(torch.arange(pocket_batch.shape[0], device=dev), reps)
+        start = _offsets(reps)
+        j = torch.arange(pi.shape[0], device=dev) - start[pi]
+        ci = _offsets(ncnt)[pocket_batch][pi] + j
+        return pi, ci
+
+    def _complex_and_heads(self, data, g):
+        scale = self.coordinate_scale
+        cb = data['compound'].batch
+        Xn = self.normalize_coord(g['X'].unsqueeze(-2)).float()
+        Xl = self.normalize_coord(g['XL'].unsqueeze(-2)).float()
+        Xo, Ho = self.complex_model(Xn, g['H'], batch_id=g['batch'], segment_id=g['segment'], mask=g['mask'],
+                                    is_global=g['is_global'], compound_edge_index=g['c2c'], LAS_edge_index=g['LAS'],
+                                    batched_complex_coord_LAS=Xl, LAS_mask=None)
+        seg1 = g['segment'].bool() if not g['segment'].is_floating_point() else g['segment'] > 0.5
+        cflag, pflag = ~seg1 & ~g['is_global'], seg1 & ~g['is_global']
+        coords_n = Xo[cflag].squeeze(-2)
+        return Ho, cflag, pflag, coords_n
+
+    def _dist_heads(self, data, g, Ho, cflag, pflag, coords_n):
+        cb = data['compound'].batch
+        B = int(cb[-1].item()) + 1
+        pi, ci = g.get('pairs') or self._pair_lists(g['pocket_batch'], cb, torch.bincount(g['pocket_batch'], minlength=B),
+                                                   torch.bincount(cb, minlength=B))
+        ln = ops.layernorm(torch.cat([Ho[pflag], Ho[cflag]], 0).contiguous(), self.layernorm.weight, self.layernorm.bias,
+                           self.layernorm.eps)
+        npk = int(pflag.sum().item())
+        hd = ops.rows_hadamard(ln, pi, npk + ci)                                       # LN(p_i) * LN(c_j)
+        wd = ops.mm_dtype()
+        part = ops.linear_rowdot(hd, self.distmap_mlp[0].weight.to(wd), self.distmap_mlp[0].bias,
+                                 self.distmap_mlp[2].weight[0].contiguous(), act_epi=K.ACT_RELU)
+        y_pred = (part.sum(1) + self.distmap_mlp[2].bias).sigmoid() * 10
+        xp = self.normalize_coord(g['pocket_xyz']).float()
+        y_by = self.unnormalize_coord((xp[pi] - coords_n[ci]).norm(dim=-1)).clamp(0, 10)
+        return y_pred, y_by
+
+    # ---- reference API ------------------------------------------------------------------------
+    def forward(self, data, stage=1, train=False):
+        cb = data['compound'].batch
+        head = self._pocket_head(data)
+        training = self.pocket_pred_model.training
+        center = self._soft_center(head['logits'], head['mask'], head['xyz'], noise=training)
+        pocket_cls = torch.zeros_like(head['mask'], dtype=data.pocket_idx.dtype)
+        pocket_cls[head['pb'], head['loc']] = data.pocket_idx
+        if training:
+            dist = torch.norm(data.coords_center - center, p=2, dim=-1).mean(dim=-1)
+            final_stage = 2 if (dist < self.args.center_dist_threshold and random.random() < self.stage_prob) else 1
+        else:
+            final_stage = stage
+        if final_stage == 2:
+            c2 = center
+            if self.args.local_eval or (self.args.train_pred_pocket_noise and train):
+                c2 = center + self.args.train_pred_pocket_noise * (2 * torch.rand_like(center) - 1)
+            g = self._stage2(data, head, c2)
+        else:
+            cx = data['complex']
+            pemb = head['p_out'][data['pocket'].keepNode]
+            H, _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], pemb)
+            g = dict(H=H, X=cx.node_coords, XL=cx.node_coords_LAS, segment=cx.segment, mask=cx.mask,
+                     is_global=cx.is_global, batch=cx.batch, c2c=data['complex', 'c2c', 'complex'].edge_index,
+                     LAS=data['complex', 'LAS', 'complex'].edge_index, pocket_xyz=data.node_xyz,
+                     pocket_batch=data['pocket'].batch, dis_map=data.dis_map, less5=0)
+        Ho, cflag, pflag, coords_n = self._complex_and_heads(data, g)
+        y_pred, y_by = self._dist_heads(data, g, Ho, cflag, pflag, coords_n)
+        return (self.unnormalize_coord(coords_n), cb, y_pred, y_by, head['logits'] * head['mask'], pocket_cls,
+                head['mask'], head['xyz'], center, g['dis_map'], g['less5'])
+
+    def inference(self, data):
+        head = self._pocket_head(data)
+        with torch.no_grad():
+            lg, m = head['logits'].detach(), head['mask']
+            hard = (lg.sigmoid().round() == 1) & m
+            nh = hard.sum(1)
+            hard_c = (hard.unsqueeze(-1) * head['xyz']).sum(1) / nh.clamp(min=1).unsqueeze(-1)
+            pt = lg.sigmoid().unsqueeze(-1)
+            y = gumbel_softmax_no_random(torch.log(torch.cat([1. - pt, pt], -1)), tau=self.args.gs_tau,
+                                         hard=self.args.gs_hard)
+            wgt = (y[..., 1] * m).unsqueeze(-1)
+            soft_c = (wgt * head['xyz']).sum(1) / wgt.sum(1)
+            center = torch.where((nh > 0).unsqueeze(-1), hard_c, soft_c)
+        g = self._stage2(data, head, center)
+        data['complex'].batch = g['batch']
+        _, _, _, coords_n = self._complex_and_heads(data, g)
+        return self.unnormalize_coord(coords_n), data['compound'].batch
+
+
+def get_model(args, logger, device=None):
+    if args.mode == 5:
+        logger.log_message("FABind")
+        return IaBNet_mean_and_pocket_prediction_cls_coords_dependent(args, args.hidden_size, args.pocket_pred_hidden_size)
+    raise NotImplementedError("only args.mode == 5 exists in the reference (model.py:582-586)")
+
+
+def compute_loss(out, data, args=None):
+    """The reference's train-step loss (main_fabind.py:398-417) as a function of the forward's 11-tuple.
+
+    Returns (loss, dict of the six terms).  Small vector reductions: plain torch on the device."""
+    w = dict(coord=1.0, pair=1.0, distill=1.0, cls=1.0, center=0.05, delta=3.0)
+    if args is not None:
+        w.update(coord=args.coord_loss_weight, pair=args.pair_distance_loss_weight,
+                 distill=args.pair_distance_distill_loss_weight, cls=args.pocket_cls_loss_weight,
+                 center=args.pocket_distance_loss_weight, delta=args.pocket_coord_huber_delta)
+    coords, cb, y_pred, y_by, logits, pocket_cls, p_mask, _, center, dis_map, _ = out
+    terms = dict(
+        pocket_cls=w['cls'] * F.binary_cross_entropy_with_logits(logits, pocket_cls.float()) * (p_mask.numel() / p_mask.sum()),
+        pocket_center=w['center'] * F.huber_loss(center, data.coords_center, delta=w['delta']),
+        contact=w['pair'] * F.mse_loss(y_pred, dis_map), contact_by_pred=w['pair'] * F.mse_loss(y_by, dis_map),
+        distill=w['distill'] * F.mse_loss(y_by, y_pred), coord=w['coord'] * F.smooth_l1_loss(coords, data.coords))
+    return sum(terms.values()), terms

@@ -1,0 +1,510 @@
+"""Differentiable operators of the FABind hot path, each backed by kernels of libfabind_hip.so.
+
+Forward-only calls (torch.no_grad(), 7 of the 8 refinement iterations) go straight to the kernels;
+when a gradient is required the same kernels run inside torch.autograd.Function wrappers whose
+backward passes are HIP kernels as well (fabind_amd/csrc/bwd.hip + the GEMM family)."""
+import torch
+
+from . import config as _engine
+from . import kernels as K
+
+
+def act_dtype():
+    """Storage type of the large edge-/pair-level intermediates."""
+    return torch.float32 if _engine.get_precision() == "fp32" else torch.bfloat16
+
+
+def mm_dtype():
+    return torch.float32 if _engine.get_precision() == "fp32" else torch.bfloat16
+
+
+def _needs_grad(*ts):
+    return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in ts)
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _transposed(x, act=K.ACT_NONE):
+    """act(x)^T as an mm-dtype [C, pad8(R)] matrix (zero padded) for K=R contractions."""
+    R, C = x.shape
+    Rp = _pad8(R)
+    out = torch.empty((C, Rp), dtype=mm_dtype(), device=x.device)
+    if Rp != R:
+        out[:, R:].zero_()
+    from ._lib import check, dt_code, load, ptr, stream
+    check(load().fabind_transpose_act(ptr(x), dt_code(x.dtype), x.stride(0), ptr(out), dt_code(out.dtype), Rp, R, C, act,
+                                      stream()), "fabind_transpose_act")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# linear:  y = act_epi( act_pro([x|x2]) W^T + b ) (+ residual)
+# ------------------------------------------------------------------------------------------------
+class _Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, x2, residual, act_pro, act_epi, out_dtype):
+        y, _ = K.gemm(x, W, bias=b, A2=x2, act_pro=act_pro, act_epi=act_epi, residual=residual, out_dtype=out_dtype)
+        ctx.act_pro, ctx.act_epi = act_pro, act_epi
+        ctx.has_b, ctx.has_res, ctx.has_x2 = b is not None, residual is not None, x2 is not None
+        assert act_epi in (K.ACT_NONE, K.ACT_RELU), "linear: only ReLU may be fused as an output activation under autograd"
+        assert not (act_epi != K.ACT_NONE and residual is not None)
+        ctx.save_for_backward(x, W, x2, y if act_epi == K.ACT_RELU else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, x2, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.act_epi == K.ACT_RELU:   # dPre = dy * (y > 0): ReLU'(pre) == ReLU'(y)
+            dpre = torch.empty_like(dy)
+            from ._lib import check, load, ptr, stream, dt_code
+            check(load().fabind_mul_dact(ptr(dy), dt_code(dy.dtype), ptr(y), dt_code(y.dtype), K.ACT_RELU, ptr(dpre),
+                                         dt_code(dpre.dtype), dy.numel(), stream()), "fabind_mul_dact")
+        else:
+            dpre = dy
+        K1 = x.shape[1]
+        dx = dx2 = dW = db = None
+        need_x = ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[3])
+        if need_x:
+            Wt = W.t().contiguous()                                     # [K, N] (parameter-only transpose)
+            if ctx.has_x2:
+                dfull, _ = K.gemm(dpre, Wt)
+                dx, dx2 = dfull[:, :K1], dfull[:, K1:]
+            else:
+                dx, _ = K.gemm(dpre, Wt, aux=x if ctx.act_pro != K.ACT_NONE else None, dact=ctx.act_pro,
+                               out_dtype=torch.float32 if x.dtype == torch.float32 else x.dtype)
+        if ctx.needs_input_grad[1]:
+            dpt = _transposed(dpre)                                     # [N, Mp]
+            xt = _transposed(x, ctx.act_pro)                            # [K1, Mp]
+            if ctx.has_x2:
+                xt = torch.cat([xt, _transposed(x2)], 0)
+            dW, _ = K.gemm(dpt, xt)                                     # [N, K] fp32
+            dW = dW.to(W.dtype)
+        if ctx.has_b and ctx.needs_input_grad[2]:
+            db = K.colsum(dpre)
+        dres = dy.float() if (ctx.has_res and ctx.needs_input_grad[4]) else None
+        return dx, dW, db, dx2, dres, None, None, None
+
+
+def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, x2=None, out_dtype=torch.float32):
+    if not x.is_contiguous() and x.stride(-1) != 1:
+        x = x.contiguous()
+    if _needs_grad(x, W, b, x2, residual):
+        return _Linear.apply(x, W, b, x2, residual, act_pro, act_epi, out_dtype)
+    y, _ = K.gemm(x, W, bias=b, A2=x2, act_pro=act_pro, act_epi=act_epi, residual=residual, out_dtype=out_dtype)
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# linear + row-dot:  s_part[m, t] = sum_{n in tile t} act_epi(act_pro(x) W^T + b)[m,n] * u[n]
+# ------------------------------------------------------------------------------------------------
+class _LinearRowdot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, u, act_pro, act_epi):
+        from ._lib import GemmArgs  # noqa: F401
+        z, part = _gemm_rowdot(x, W, b, u, act_pro, act_epi, store=True)
+        ctx.act_pro, ctx.act_epi = act_pro, act_epi
+        ctx.save_for_backward(x, W, u, z)
+        return part
+
+    @staticmethod
+    def backward(ctx, dpart):
+        x, W, u, z = ctx.saved_tensors
+        from ._lib import check, load, ptr, stream, dt_code
+        dpart = dpart.contiguous()
+        M, N = z.shape
+        dz = torch.empty_like(z)
+        nchunk = max(1, min(256, (M + 1023) // 1024))
+        scratch = torch.empty((nchunk, N), dtype=torch.float32, device=z.device)
+        du = torch.empty(N, dtype=torch.float32, device=z.device)
+        check(load().fabind_rowdot_bwd(ptr(z), dt_code(z.dtype), ptr(dpart), dpart.shape[1], ptr(u), ctx.act_epi, M, N,
+                                       ptr(dz), ptr(du), ptr(scratch), nchunk, stream()), "fabind_rowdot_bwd")
+        Wt = W.t().contiguous()
+        dx, _ = K.gemm(dz, Wt, aux=x if ctx.act_pro != K.ACT_NONE else None, dact=ctx.act_pro, out_dtype=x.dtype)
+        dW, _ = K.gemm(_transposed(dz), _transposed(x, ctx.act_pro))
+        db = K.colsum(dz)
+        return dx, dW.to(W.dtype), db, du, None, None
+
+
+def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store):
+    """GEMM with row-dot epilogue; store=True keeps the pre-activation matrix (training)."""
+    import ctypes
+    from ._lib import GemmArgs, check, dt_code, load, ptr, stream
+    M, Kd = x.shape
+    N = W.shape[0]
+    nt = (N + K.GEMM_BN - 1) // K.GEMM_BN
+    part = torch.empty((M, nt), dtype=torch.float32, device=x.device)
+    z = torch.empty((M, N), dtype=act_dtype(), device=x.device) if store else None
+    a = GemmArgs()
+    a.A, a.W, a.C, a.bias, a.dotvec, a.dot_out = ptr(x), ptr(W), ptr(z), ptr(b), ptr(u), ptr(part)
+    a.M, a.N, a.K, a.K1 = M, N, Kd, Kd
+    a.lda, a.ldw, a.ldc, a.dot_ld = x.stride(0), W.stride(0), N, nt
+    a.a_dtype, a.w_dtype, a.c_dtype = dt_code(x.dtype), dt_code(W.dtype), dt_code(z.dtype) if store else 0
+    a.act_pro, a.act_epi, a.store_preact, a.alpha = act_pro, act_epi, 1, 1.0
+    check(load().fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm(rowdot)")
+    return z, part
+
+
+def linear_rowdot(x, W, b, u, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE):
+    if _needs_grad(x, W, b, u):
+        return _LinearRowdot.apply(x, W, b, u, act_pro, act_epi)
+    return _gemm_rowdot(x, W, b, u, act_pro, act_epi, store=False)[1]
+
+
+# ------------------------------------------------------------------------------------------------
+# geometry / gathers / segmented reductions
+# ------------------------------------------------------------------------------------------------
+class _EdgeGeom(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, row, col, rowptr, lay):
+        d, rho, rhohat, norm = K.edge_geom(x, row, col, rowptr, lay.node_off, lay.B)
+        ctx.lay, ctx.n = lay, x.shape[0]
+        ctx.save_for_backward(row, col, rowptr, d, rho, norm)
+        ctx.mark_non_differentiable(rho)
+        return d, rhohat
+
+    @staticmethod
+    def backward(ctx, dd, drhohat):
+        row, col, rowptr, d, rho, norm = ctx.saved_tensors
+        from ._lib import check, load, ptr, stream
+        lay = ctx.lay
+        dx = torch.zeros((ctx.n, 3), dtype=torch.float32, device=d.device)
+        dd = dd.contiguous() if dd is not None else torch.zeros_like(d)
+        drhohat = drhohat.contiguous() if drhohat is not None else torch.zeros_like(rho)
+        check(load().fabind_edge_geom_bwd(ptr(d), ptr(rho), ptr(norm), ptr(dd), ptr(drhohat), ptr(row), ptr(col),
+                                          ptr(rowptr), ptr(lay.node_off), lay.B, row.shape[0], ptr(dx), stream()),
+              "fabind_edge_geom_bwd")
+        return dx, None, None, None, None
+
+
+def edge_geom(x, row, col, rowptr, lay):
+    if _needs_grad(x):
+        return _EdgeGeom.apply(x, row, col, rowptr, lay)
+    d, _, rhohat, _ = K.edge_geom(x, row, col, rowptr, lay.node_off, lay.B)
+    return d, rhohat
+
+
+class _GclPre(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, AB, rhohat, w_r, H, row, col):
+        ctx.H = H
+        ctx.save_for_backward(AB, rhohat, w_r, row, col)
+        return K.gcl_pre(AB, H, row, col, rhohat, w_r, act_dtype())
+
+    @staticmethod
+    def backward(ctx, dpre):
+        AB, rhohat, w_r, row, col = ctx.saved_tensors
+        from ._lib import check, load, ptr, stream, dt_code
+        H, E, N = ctx.H, row.shape[0], AB.shape[0]
+        dpre = dpre.contiguous()
+        dAB = torch.zeros((N, 2 * H), dtype=torch.float32, device=AB.device)
+        drh = torch.empty(E, dtype=torch.float32, device=AB.device)
+        nchunk = max(1, min(256, (E + 1023) // 1024))
+        scratch = torch.empty((nchunk, H), dtype=torch.float32, device=AB.device)
+        dw = torch.empty(H, dtype=torch.float32, device=AB.device)
+        check(load().fabind_gcl_pre_bwd(ptr(dpre), dt_code(dpre.dtype), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r), E,
+                                        ptr(dAB), 2 * H, ptr(drh), ptr(dw), ptr(scratch), nchunk, stream()),
+              "fabind_gcl_pre_bwd")
+        return dAB, drh, dw, None, None, None
+
+
+def gcl_pre(AB, H, row, col, rhohat, w_r):
+    if _needs_grad(AB, rhohat, w_r):
+        return _GclPre.apply(AB, rhohat, w_r, H, row, col)
+    return K.gcl_pre(AB, H, row, col, rhohat, w_r, act_dtype())
+
+
+class _SegmentSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Z, rowptr, row, n_rows, act):
+        ctx.act = act
+        ctx.save_for_backward(Z, row)
+        return K.segment_sum(Z, rowptr, n_rows, act)
+
+    @staticmethod
+    def backward(ctx, dout):
+        Z, row = ctx.saved_tensors
+        from ._lib import check, load, ptr, stream, dt_code
+        dout = dout.contiguous()
+        dZ = torch.empty_like(Z)
+        check(load().fabind_gather_dact(ptr(dout), dout.stride(0), ptr(row), ptr(Z), dt_code(Z.dtype), ctx.act, ptr(dZ),
+                                        dt_code(dZ.dtype), Z.shape[0], Z.shape[1], stream()), "fabind_gather_dact")
+        return dZ, None, None, None, None
+
+
+def segment_sum(Z, rowptr, row, n_rows, act=K.ACT_NONE):
+    if _needs_grad(Z):
+        return _SegmentSum.apply(Z, rowptr, row, n_rows, act)
+    return K.segment_sum(Z, rowptr, n_rows, act)
+
+
+class _CoordUpdate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, d, s_part, rowptr, mean, clampv):
+        x_out, s = K.coord_update(x, d, s_part, rowptr, mean, clampv, want_s=True)
+        ctx.mean, ctx.clampv, ctx.np = mean, clampv, s_part.shape[1]
+        ctx.save_for_backward(x, x_out, d, s, rowptr)
+        return x_out
+
+    @staticmethod
+    def backward(ctx, dxo):
+        x, x_out, d, s, rowptr = ctx.saved_tensors
+        from ._lib import check, load, ptr, stream
+        dxo = dxo.contiguous()
+        E = s.shape[0]
+        dd = torch.empty((E, 3), dtype=torch.float32, device=x.device)
+        ds = torch.empty(E, dtype=torch.float32, device=x.device)
+        check(load().fabind_coord_update_bwd(ptr(x), ptr(x_out), ptr(d), ptr(s), ptr(rowptr), x.shape[0],
+                                             1 if ctx.mean else 0, ctx.clampv, ptr(dxo), ptr(dd), ptr(ds), stream()),
+              "fabind_coord_update_bwd")
+        return dxo, dd, ds[:, None].expand(E, ctx.np), None, None, None
+
+
+def coord_update(x, d, s_part, rowptr, mean, clampv):
+    if _needs_grad(x, d, s_part):
+        return _CoordUpdate.apply(x, d, s_part, rowptr, mean, clampv)
+    return K.coord_update(x, d, s_part, rowptr, mean, clampv)[0]
+
+
+def take_rows(x, index64):
+    """Row gather (torch index_select: pure data movement, autograd-native)."""
+    return x.index_select(0, index64)
+
+
+def select_rows(x, z, mask_u8):
+    if _needs_grad(x, z):
+        return torch.where(mask_u8.bool()[:, None], z, x)
+    return K.select_rows(x, z, mask_u8)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention ops
+# ------------------------------------------------------------------------------------------------
+class _CrossAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qg, kv, bias, lin_col, gate_col, desc, B, max_nq, scale):
+        out = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
+        _, lse = K.cross_attn_fwd(qg[:, :128], kv[:, :128], kv[:, 128:], qg[:, 128:], bias, lin_col, gate_col, desc, B,
+                                  max_nq, scale, out, want_lse=True)
+        ctx.args = (lin_col, gate_col, desc, B, max_nq, scale)
+        ctx.save_for_backward(qg, kv, bias, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qg, kv, bias, out, lse = ctx.saved_tensors
+        lin_col, gate_col, desc, B, max_nq, scale = ctx.args
+        from ._lib import check, load, ptr, stream
+        dout = dout.contiguous()
+        dqg = torch.empty_like(qg)
+        dkv = torch.zeros_like(kv)
+        dbias = torch.empty_like(bias)
+        check(load().fabind_cross_attn_bwd(ptr(qg), qg.stride(0), ptr(kv), kv.stride(0), ptr(bias), bias.stride(0), lin_col,
+                                           gate_col, ptr(desc), B, max_nq, scale, ptr(out), ptr(lse), ptr(dout), ptr(dqg),
+                                           ptr(dkv), ptr(dbias), stream()), "fabind_cross_attn_bwd")
+        return dqg, dkv, dbias, None, None, None, None, None, None
+
+
+def cross_attn(qg, kv, bias, lin_col, gate_col, desc, B, max_nq, scale):
+    if _needs_grad(qg, kv, bias):
+        return _CrossAttn.apply(qg, kv, bias, lin_col, gate_col, desc, B, max_nq, scale)
+    out = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
+    K.cross_attn_fwd(qg[:, :128], kv[:, :128], kv[:, 128:], qg[:, 128:], bias, lin_col, gate_col, desc, B, max_nq, scale, out)
+    return out
+
+
+def pair_hadamard(a0b0, H, ab32, H2, red_p, red_c):
+    if _needs_grad(a0b0, ab32):
+        return _PairHadamard.apply(a0b0, ab32, H, H2, red_p, red_c)
+    return K.pair_hadamard(a0b0[:, :H], a0b0[:, H:], ab32[:, :H2], ab32[:, H2:], red_p, red_c, act_dtype())
+
+
+class _PairHadamard(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a0b0, ab32, H, H2, red_p, red_c):
+        ctx.dims = (H, H2)
+        ctx.save_for_backward(a0b0, ab32, red_p, red_c)
+        return K.pair_hadamard(a0b0[:, :H], a0b0[:, H:], ab32[:, :H2], ab32[:, H2:], red_p, red_c, act_dtype())
+
+    @staticmethod
+    def backward(ctx, dhd):
+        a0b0, ab32, red_p, red_c = ctx.saved_tensors
+        H, H2 = ctx.dims
+        from ._lib import check, load, ptr, stream, dt_code
+        dhd = dhd.contiguous()
+        d0, d1 = torch.zeros_like(a0b0), torch.zeros_like(ab32)
+        check(load().fabind_pair_hadamard_bwd(ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(a0b0), a0b0.stride(0), H,
+                                              ptr(ab32), ab32.stride(0), H2, ptr(red_p), ptr(red_c), red_p.shape[0],
+                                              ptr(d0), ptr(d1), stream()), "fabind_pair_hadamard_bwd")
+        return d0, d1, None, None, None, None
+
+
+class _InterAttn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv):
+        h_out, x_out, alpha, cvs = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx,
+                                                    bias_part, w_rk, w_rv, wcr, w3, clampv)
+        ctx.g, ctx.H, ctx.clampv, ctx.np = g, H, clampv, bias_part.shape[1]
+        ctx.save_for_backward(qkv, cv, x, x_out, d, rhohat, w_rk, w_rv, wcr, w3, alpha, cvs)
+        ctx.mark_non_differentiable(alpha)
+        return h_out, x_out, alpha
+
+    @staticmethod
+    def backward(ctx, dh_out, dx_out, _dalpha):
+        qkv, cv, x, x_out, d, rhohat, w_rk, w_rv, wcr, w3, alpha, cvs = ctx.saved_tensors
+        from ._lib import check, load, ptr, stream
+        g, H = ctx.g, ctx.H
+        N, E = qkv.shape[0], g.col_int.shape[0]
+        dev = qkv.device
+        dh_out = dh_out.contiguous() if dh_out is not None else torch.zeros((N, H), device=dev)
+        dx_out = dx_out.contiguous() if dx_out is not None else torch.zeros((N, 3), device=dev)
+        dqkv = torch.zeros_like(qkv)
+        dcv = torch.zeros_like(cv)
+        dd = torch.empty((max(E, 1), 3), dtype=torch.float32, device=dev)
+        drh = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+        dbias_red = torch.zeros(max(E // 2, 1), dtype=torch.float32, device=dev)
+        nrb = (N + 3) // 4
+        wpart = torch.zeros((4, nrb, H), dtype=torch.float32, device=dev)   # per-block partials of dw_rk,dw_rv,dwcr,dw3
+        check(load().fabind_inter_attn_bwd(ptr(qkv), qkv.stride(0), ptr(cv), cv.stride(0), H, ptr(x), ptr(x_out), ptr(d),
+                                           ptr(rhohat), ptr(g.rp_int), ptr(g.col_int), ptr(g.red_idx), ptr(w_rk),
+                                           ptr(w_rv), ptr(wcr), ptr(w3), ptr(alpha), ptr(cvs), ctx.clampv, N,
+                                           ptr(dh_out), ptr(dx_out), ptr(dqkv), ptr(dcv), ptr(dd), ptr(drh),
+                                           ptr(dbias_red), ptr(wpart), stream()), "fabind_inter_attn_bwd")
+        dw = [K.colsum(wpart[i]) for i in range(4)]
+        n_red = E // 2
+        return (dqkv, dcv, dh_out, dx_out, dd[:E], drh[:E], dbias_red[:n_red, None].expand(n_red, ctx.np), dw[0], dw[1],
+                dw[2], dw[3], None, None, None)
+
+
+def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, clampv):
+    if _needs_grad(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3):
+        return _InterAttn.apply(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv)
+    h_out, x_out, alpha, _ = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx, bias_part,
+                                              w_rk, w_rv, wcr, w3, clampv)
+    return h_out, x_out, alpha
+
+
+class _LasStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, x0, las, lay, step, clampv):
+        out = K.las_step(x, x0, las[0], las[1], las[2], lay.node_off, lay.c_cnt, lay.B, lay.max_n, step, clampv)
+        ctx.las, ctx.lay, ctx.step, ctx.clampv = las, lay, step, clampv
+        ctx.save_for_backward(x, x0, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, x0, out = ctx.saved_tensors
+        from ._lib import check, load, ptr, stream
+        las, lay = ctx.las, ctx.lay
+        dout = dout.contiguous()
+        dx = torch.empty_like(x)
+        check(load().fabind_las_step_bwd(ptr(x), ptr(x0), ptr(out), ptr(las[0]), ptr(las[1]), ptr(las[2]),
+                                         ptr(lay.node_off), ptr(lay.c_cnt), lay.B, lay.max_n, ctx.step, ctx.clampv,
+                                         ptr(dout), ptr(dx), stream()), "fabind_las_step_bwd")
+        return dx, None, None, None, None, None
+
+
+def las_step(x, x0, las, lay, step, clampv):
+    if _needs_grad(x):
+        return _LasStep.apply(x, x0, las, lay, step, clampv)
+    return K.las_step(x, x0, las[0], las[1], las[2], lay.node_off, lay.c_cnt, lay.B, lay.max_n, step, clampv)
+
+
+# ------------------------------------------------------------------------------------------------
+# pair biases of all layers/blocks:  out[k][pair(b,i,j), o] = sum_h a0[i,h] b0[j,h] wcomp[k,o,h] + bconst[k,o]
+# (k = 2*layer + {0: protein-query block, 1: ligand-query block}; o = 4 "linear" heads then 4 "gate" heads)
+# ------------------------------------------------------------------------------------------------
+def _pair_bias_fwd(a0b0, H, wcomp, bconst, lay):
+    nblk, NO, _ = wcomp.shape
+    outs = []
+    for k in range(nblk):
+        bmat = K.pair_bmat(a0b0[:, H:], wcomp[k], lay.c_index, mm_dtype())       # [(sumC*NO), H]
+        out = torch.empty((lay.n_pairs, NO), dtype=torch.float32, device=a0b0.device)
+        K.gemm(a0b0[:, :H], bmat, bias=bconst[k].repeat(lay.sumC), out=out, groups=lay.pb_groups, n_groups=lay.B,
+               max_m=lay.max_P, max_n=lay.pb_max_n, M=lay.N, N=bmat.shape[0], ldc=NO)
+        outs.append(out)
+    return outs
+
+
+class _PairBias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a0b0, wcomp, bconst, H, lay):
+        ctx.H, ctx.lay = H, lay
+        ctx.save_for_backward(a0b0, wcomp)
+        return tuple(_pair_bias_fwd(a0b0, H, wcomp, bconst, lay))
+
+    @staticmethod
+    def backward(ctx, *douts):
+        a0b0, wcomp = ctx.saved_tensors
+        from ._lib import check, load, ptr, stream
+        H, lay = ctx.H, ctx.lay
+        nblk, NO, _ = wcomp.shape
+        da0b0 = torch.zeros_like(a0b0)
+        dwcomp = torch.zeros_like(wcomp)
+        dbconst = torch.zeros((nblk, NO), dtype=torch.float32, device=a0b0.device)
+        for k, dout in enumerate(douts):
+            if dout is None:
+                continue
+            dout = dout.contiguous()
+            dwk = torch.zeros((lay.B, NO, H), dtype=torch.float32, device=a0b0.device)
+            check(load().fabind_pair_bias_bwd(ptr(dout), NO, ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.desc_p),
+                                              lay.B, lay.max_P, ptr(lay.p_index), ptr(lay.c_index), ptr(da0b0), ptr(dwk),
+                                              stream()), "fabind_pair_bias_bwd")
+            dwcomp[k] = K.colsum(dwk.reshape(lay.B, NO * H)).reshape(NO, H)
+            dbconst[k] = K.colsum(dout)
+        return da0b0, dwcomp, dbconst, None, None
+
+
+def pair_bias(a0b0, H, wcomp, bconst, lay):
+    if _needs_grad(a0b0, wcomp, bconst):
+        return list(_PairBias.apply(a0b0, wcomp, bconst, H, lay))
+    return _pair_bias_fwd(a0b0, H, wcomp, bconst, lay)
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm, row-pair Hadamard (dist-map head)
+# ------------------------------------------------------------------------------------------------
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        from ._lib import check, load, ptr, stream
+        R, C = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(R, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+        check(load().fabind_layernorm_fwd(ptr(x), ptr(w), ptr(b), eps, R, C, ptr(y), ptr(mean), ptr(rstd), stream()),
+              "fabind_layernorm_fwd")
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ._lib import check, load, ptr, stream
+        x, w, mean, rstd = ctx.saved_tensors
+        R, C = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        nb = (R + 3) // 4
+        dwp = torch.empty((nb, C), dtype=torch.float32, device=x.device)
+        dbp = torch.empty((nb, C), dtype=torch.float32, device=x.device)
+        check(load().fabind_layernorm_bwd(ptr(x), ptr(w), ptr(dy), ptr(mean), ptr(rstd), R, C, ptr(dx), ptr(dwp), ptr(dbp),
+                                          stream()), "fabind_layernorm_bwd")
+        return dx, K.colsum(dwp), K.colsum(dbp), None
+
+
+def layernorm(x, w, b, eps=1e-5):
+    return _LayerNorm.apply(x.float().contiguous(), w, b, eps)
+
+
+def rows_hadamard(t, idx_a, idx_b):
+    """out[e,:] = t[idx_a[e],:] * t[idx_b[e],:]  (einsum('bik,bjk->bijk') on the valid pairs only, model.py:355)."""
+    ia, ib = idx_a.to(torch.int32).contiguous(), idx_b.to(torch.int32).contiguous()
+    W = t.shape[1]
+    dummy = t[:, :0]
+    if _needs_grad(t):
+        zero2 = torch.zeros((t.shape[0], 8), dtype=torch.float32, device=t.device)
+        return _PairHadamard.apply(torch.cat([t, t], 1), zero2, W, 4, ia, ib)[:, :W]
+    return K.pair_hadamard(t, t, dummy, dummy, ia, ib, act_dtype())

@@ -1,0 +1,185 @@
+/* fabind_hip.h -- C ABI of libfabind_hip.so: the MI355X (gfx950) kernels behind the FABind docking hot path.
+ *
+ * The reference (QizhiPei/FABind) is 100 % Python; its "native layer" is ATen + torch_scatter +
+ * torch_geometric ops called from fabind/models/*.py.  Each entry point below replaces the group of
+ * those ops named in its comment (paths relative to the reference's FABind/fabind directory).  Plain pointers
+ * and sizes only: every pointer is a DEVICE pointer unless stated otherwise, `stream` is a
+ * hipStream_t, dtype codes are FB_DT_F32 = 0 / FB_DT_BF16 = 1 (raw bfloat16 bits), activation
+ * codes FB_ACT_NONE/SILU/RELU/SIGMOID = 0..3.  Every function returns 0 on success, non-zero on
+ * error (message via fabind_last_error()); none of them synchronises or allocates.
+ *
+ * Node layout contract: nodes are complex-contiguous in the fixed order
+ * [glb_c, ligand atoms..., glb_p, protein residues...]; node_off[b] is the first node of complex b
+ * (node_off[B] = N) and c_cnt[b] = Nc_b + 1 the size of the ligand-side block (global node included).
+ */
+#ifndef FABIND_HIP_H
+#define FABIND_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef __HIP_PLATFORM_AMD__
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+const char* fabind_last_error(void);
+int fabind_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense contractions.  Replaces every nn.Linear / torch.cat+Linear / einsum+Linear on the path:
+ * models/egnn.py:40-60,81,104,119,160-170,197-208; models/model_utils.py:83-92,103-131,168-174,
+ * 196-222; models/model.py:100-101,117,132,139,358.
+ *   C[M,N] = epi( pro(A|A2)[M,K] * W[N,K]^T )
+ *   pro: act_pro applied to A while staging; columns [0,K1) come from A, [K1,K) from A2.
+ *   epi: v = alpha*acc + bias[n]; v = act_epi(v); v *= d(act)/dx (dact_epi) at aux[m,n];
+ *        v += R[r_index ? r_index[m] : m, n]; v += C_old (accumulate); C = v;
+ *        dot_out[m, n_tile] = sum_n v * dotvec[n]   (n_tile = column block of 128)
+ *   groups != NULL: ragged batched mode, blockIdx.z picks int32[8] {a_row0, M, w_row0, N, c_off_lo,
+ *        c_off_hi, ldc, 0}; bias is indexed by w_row0 + n.
+ * -------------------------------------------------------------------------------------------*/
+typedef struct FabindGemmArgs {
+    const void* A;
+    const void* A2;
+    const void* W;
+    void* C;
+    const float* bias;
+    const void* R;
+    const int* r_index;
+    const float* dotvec;
+    float* dot_out;
+    const void* aux;
+    const int* groups;
+    int M, N, K, K1;
+    int lda, lda2, ldw, ldc, ldr, ldaux, dot_ld;
+    int a_dtype, w_dtype, c_dtype, aux_dtype;
+    int act_pro, act_epi, dact_epi;
+    int accumulate;
+    int store_preact; /* C receives the value BEFORE act_epi (row-dot still sees act_epi(v)) */
+    int n_groups, max_m, max_n;
+    float alpha;
+} FabindGemmArgs;
+
+int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream);
+
+/* out[C,R] = act(in[R,C])^T -- feeds weight-gradient contractions (autograd of the ops above). */
+int fabind_transpose_act(const void* in, int in_dt, int ldi, void* out, int out_dt, int ldo, int R, int C, int act,
+                         hipStream_t stream);
+/* out[c] (+)= sum_r in[r,c]; scratch = float[nchunk*C] (bias gradients, deterministic two-pass). */
+int fabind_colsum(const void* in, int in_dt, int ldi, float* out, int R, int C, int accumulate, float* scratch,
+                  int nchunk, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Edge construction.  Replaces ComplexGraph.construct_edges + _radial_edges (models/att_model.py:
+ * 37-128: dense [N,max_n] mask + nonzero) with direct row-sorted CSR emission.
+ *   ctx graph  (row aggregates): ligand bonds (as given), protein-protein pairs with |xu-xv| <= cut_intra
+ *              (normalised units), star edges to the segment's global node, glb_c<->glb_p.
+ *   inter graph: ligand-atom <-> protein-residue pairs with |xu-xv| <= cut_inter, both directions.
+ * count: fills deg_ctx[N], deg_int[N].  The caller scans them into rowptr (fabind_exclusive_scan).
+ * fill : writes col / row (COO row per edge) arrays for both graphs.
+ * bond_row/bond_col: ligand bonds (global node ids), complex-contiguous; bond_off[B+1] their ranges.
+ * -------------------------------------------------------------------------------------------*/
+int fabind_edges_count(const float* x, const int* node_off, const int* c_cnt, int B, int max_n, const int* bond_row,
+                       const int* bond_off, float cut_intra, float cut_inter, int* deg_ctx, int* deg_int,
+                       hipStream_t stream);
+int fabind_edges_fill(const float* x, const int* node_off, const int* c_cnt, int B, int max_n, const int* bond_row,
+                      const int* bond_col, const int* bond_off, float cut_intra, float cut_inter,
+                      const int* rowptr_ctx, const int* rowptr_int, int* col_ctx, int* row_ctx, int* col_int,
+                      int* row_int, hipStream_t stream);
+/* out[0]=0, out[i+1]=out[i]+in[i], i<n (single work-group scan; n up to a few million). */
+int fabind_exclusive_scan(const int* in, int* out, int n, hipStream_t stream);
+/* Inter-edge pair bookkeeping (replaces trio_encoder's index arithmetic, models/egnn.py:286-304):
+ * red_off[B+1] = prefix of ligand-row inter edges per complex; for every inter edge e, red_idx[e] =
+ * index of its unordered (ligand, protein) pair in the reduced list; red_c/red_p = the pair's nodes. */
+int fabind_inter_meta(const int* node_off, const int* c_cnt, int B, const int* rowptr_int, const int* col_int,
+                      const int* row_int, int E_int, int* red_off, int* red_idx, int* red_c, int* red_p,
+                      hipStream_t stream);
+/* If the batch has no inter edge the reference inserts one fake symmetric pair (att_model.py:85-86);
+ * host-side logic handles that case by calling fill with a forced pair -- see fabind_amd/graph.py. */
+
+/* coord2radial with norm_type='per_sample' (models/egnn.py:767-787): d[e]=x[row]-x[col],
+ * rho=|d|^2, rhohat = rho / sqrt(sum_{e in complex} rho^2).  Edges of a complex are contiguous:
+ * [rowptr[node_off[b]], rowptr[node_off[b+1]]).  Also writes rho (un-normalised) and norm[b]. */
+int fabind_edge_geom(const float* x, const int* row, const int* col, const int* rowptr, const int* node_off, int B,
+                     float* d, float* rho, float* rhohat, float* norm, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * MC_E_GCL pieces (models/egnn.py:68-144).
+ * gcl_pre:  pre[e,:] = AB[row[e], 0:H] + AB[col[e], H:2H] + rhohat[e]*w_r[:]
+ *           (first edge_mlp Linear split column-wise: node-level projections gathered per edge).
+ * segment_sum: out[r,:] = sum_{e in row r} act(Z[e,:])   (unsorted_segment_sum on a row-sorted CSR)
+ * coord_mean: x_out[r] = x[r] + clamp( (1/max(deg,1)) * sum_e d[e]*s[e], +-clampv ),
+ *           s[e] = sum_k s_part[e,k] (row-dot partials written by fabind_gemm).
+ * -------------------------------------------------------------------------------------------*/
+int fabind_gcl_pre(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
+                   const float* w_r, void* pre, int pre_dt, int E, hipStream_t stream);
+int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, int n_rows, int act, float* out,
+                       int ldo, hipStream_t stream);
+int fabind_coord_update(const float* x, const float* d, const float* s_part, int n_part, const float* weight,
+                        const int* rowptr, int n_rows, int mean, float clampv, float* x_out, float* s_out,
+                        hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Cross attention (RowAttentionBlock / Attention._attention, models/cross_att.py:118-134,
+ * models/model_utils.py:21-38,96-133).  Ragged: no padding, so the -1e9 mask bias never applies.
+ *   for complex b, query i, key j, head h (4 heads x 32):
+ *     s = scale * q[i,h,:].k[j,h,:] + lin*sigmoid(gate)   with (lin,gate) read from
+ *         bias[(pair_off[b] + i*sq[b] + j*sk[b]) * bias_ld + {lin_col, gate_col} + h]
+ *     out[i,h,:] = sigmoid(gpre[i,h,:]) * sum_j softmax_j(s) v[j,h,:]
+ * desc: int32[B][8] = {q_off, nq, k_off, nk, pair_off_lo, pair_off_hi, sq, sk}.
+ * -------------------------------------------------------------------------------------------*/
+int fabind_cross_attn_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* gpre,
+                          int ldg, const float* bias, int bias_ld, int lin_col, int gate_col, const int* desc, int B,
+                          int max_nq, float scale, float* out, int ldo, float* lse, hipStream_t stream);
+
+/* pair-bias precompute helpers (RowAttentionBlock.linear/linear_g applied to the initial pair
+ * embedding z0 = W_o (a_i * b_j) + b_o; models/cross_att.py:125, models/att_model.py:198-206):
+ * bmat[(j*NO + o), k] = b0[c_node(j), k] * wcomp[o, k]  for the ligand-side rows of one batch. */
+int fabind_pair_bmat(const float* b0, int ldb, const float* wcomp, int NO, int H, const int* c_node, int n_c,
+                     void* bmat, int bmat_dt, hipStream_t stream);
+/* hd[e, 0:H] = a0[red_p[e]]*b0[red_c[e]],  hd[e, H:H+H2] = a1[red_p[e]]*b1[red_c[e]]  */
+int fabind_pair_hadamard(const float* a0, const float* b0, int ld0, int H, const float* a1, const float* b1, int ld1,
+                         int H2, const int* red_p, const int* red_c, int n_red, void* hd, int hd_dt, int ldh,
+                         hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Inter-graph attention layer (MC_Att_L.att_model/node_model/coord_model, models/egnn.py:186-252)
+ * on node-level projections qkv[N,3H] = [q | k | v] and cv[N,H] = coord_mlp.0(v) :
+ *   logit_e = q[r].(k[c] + rhohat_e w_rk) + sum_k bias_red[red_idx[e], k]   (row-dot partials; any
+ *             per-layer constant offset cancels in the softmax and is dropped)
+ *   alpha   = segment softmax over the row
+ *   h_out[r] = h[r] + sum_e alpha_e (v[c] + rhohat_e w_rv)
+ *   x_out[r] = x[r] + clamp( sum_e d_e alpha_e * w3.silu(cv[c] + rhohat_e wcr), +-clampv )
+ * -------------------------------------------------------------------------------------------*/
+int fabind_inter_attn_fwd(const float* qkv, int ldqkv, const float* cv, int ldcv, int H, const float* h, int ldh,
+                          const float* x, const float* d, const float* rhohat, const int* rowptr, const int* col,
+                          const int* red_idx, const float* bias_red, int bias_np, const float* w_rk,
+                          const float* w_rv, const float* wcr, const float* w3, float clampv, int n_rows,
+                          float* h_out, float* x_out, float* alpha, float* cvs, hipStream_t stream);
+
+/* LAS geometry step (models/egnn.py:433-449): x_out = x + clamp(step * sum_{(i,j): j=node} 4(|xi-xj|^2-|x0i-x0j|^2)(xi-xj)).
+ * las_off[B+1]: per-complex ranges of the (complex-contiguous) LAS edge list. */
+int fabind_las_step(const float* x, const float* x0, const int* las_i, const int* las_j, const int* las_off,
+                    const int* node_off, const int* c_cnt, int B, int max_n, float step, float clampv, float* x_out,
+                    hipStream_t stream);
+
+/* x_out[i] = mask[i] ? z[i] : x[i]   (X[mask] = Z[mask], models/att_model.py:236,245) */
+int fabind_select_rows(const float* x, const float* z, const uint8_t* mask, int n, int width, float* x_out,
+                       hipStream_t stream);
+
+/* LayerNorm over the last dim (models/model.py:15,29): y = (x-mean)*rstd*w + b; backward returns dx and
+ * per-block partial sums of dw/db ([ceil(R/4), C] each, reduce with fabind_colsum). */
+int fabind_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int R, int C, float* y, float* mean,
+                         float* rstd, hipStream_t stream);
+int fabind_layernorm_bwd(const float* x, const float* w, const float* dy, const float* mean, const float* rstd, int R,
+                         int C, float* dx, float* dw_part, float* db_part, hipStream_t stream);
+
+/* elementwise: out = a + b (fp32), n elements */
+int fabind_add(const float* a, const float* b, float* out, long n, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

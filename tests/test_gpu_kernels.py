@@ -1,0 +1,78 @@
+"""GPU: unit parity of the HIP kernels (through the C ABI) against plain torch fp32 on the CPU."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(300, 96, 64), (129, 130, 56), (1000, 512, 544), (17, 1, 2048), (5, 256, 128)])
+def test_gemm_epilogues(mode, shape):
+    from fabind_amd import kernels as K
+    dev = _dev()
+    M, N, Kd = shape
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, Kd, generator=g)
+    W = torch.randn(N, Kd, generator=g) / Kd ** 0.5
+    b = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    u = torch.randn(N, generator=g)
+    wd = torch.float32 if mode == "fp32" else torch.bfloat16
+    tol = 2e-5 if mode == "fp32" else 3e-2
+    Ad, Wd = A.to(dev), W.to(dev).to(wd)
+    # plain + bias + silu prologue + residual
+    ref = torch.nn.functional.silu(A) @ W.T + b + R
+    out, _ = K.gemm(Ad, Wd, bias=b.to(dev), act_pro=K.ACT_SILU, residual=R.to(dev))
+    assert (out.cpu() - ref).abs().max() <= tol * max(1.0, ref.abs().max())
+    # relu epilogue + rowdot, no C
+    pre = A @ W.T + b
+    ref_dot = (torch.relu(pre) * u).sum(1)
+    _, part = K.gemm(Ad, Wd, bias=b.to(dev), act_epi=K.ACT_RELU, dotvec=u.to(dev), want_out=False)
+    assert (part.sum(1).cpu() - ref_dot).abs().max() <= tol * max(1.0, ref_dot.abs().max()) * 4
+    # bf16 output + K-split operand
+    if Kd % 64 == 0:
+        out, _ = K.gemm(Ad[:, :Kd // 2].contiguous(), Wd, A2=Ad[:, Kd // 2:].contiguous(), out_dtype=torch.bfloat16)
+        assert (out.float().cpu() - A @ W.T).abs().max() <= 3e-2 * max(1.0, (A @ W.T).abs().max())
+
+
+def test_gemm_transpose_detecting():
+    from fabind_amd import kernels as K
+    dev = _dev()
+    A = torch.eye(64, 64)
+    W = torch.arange(64 * 64, dtype=torch.float32).reshape(64, 64) / 100.0   # asymmetric
+    out, _ = K.gemm(A.to(dev), W.to(dev))
+    assert torch.equal(out.cpu(), W.T.contiguous())
+
+
+def test_segment_sum_and_scan():
+    from fabind_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    deg = torch.randint(0, 40, (3000,), generator=g, dtype=torch.int32)
+    deg[5] = 1700
+    rp = K.exclusive_scan(deg.to(dev))
+    ref_rp = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(deg.long(), 0)])
+    assert torch.equal(rp.cpu().long(), ref_rp)
+    E = int(ref_rp[-1])
+    for H in (32, 128, 512):
+        Z = torch.randn(E, H, generator=g)
+        out = K.segment_sum(Z.to(dev), rp, 3000, K.ACT_SILU)
+        row = torch.repeat_interleave(torch.arange(3000), deg.long())
+        ref = torch.zeros(3000, H).index_add_(0, row, torch.nn.functional.silu(Z))
+        assert (out.cpu() - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max())
+
+
+def test_layernorm():
+    from fabind_amd import ops
+    dev = _dev()
+    x = torch.randn(77, 512)
+    w, b = torch.randn(512), torch.randn(512)
+    y = ops.layernorm(x.to(dev), w.to(dev), b.to(dev))
+    ref = torch.nn.functional.layer_norm(x, (512,), w, b)
+    assert (y.cpu() - ref).abs().max() < 1e-4
