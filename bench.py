@@ -1,0 +1,200 @@
+"""bench.py -- throughput of the FABind docking hot path on N MI355X GPUs (one process per GPU).
+
+python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" = one pass of the hot path (EfficientMCAttModel: 4 FABind layers + out layer, hidden 512,
+refinement iterations = --n-iter) over one resident synthetic batch of --batch complexes of
+1500 protein / 40 ligand nodes per GPU (BASELINE.json configs[1]/[2]).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}
+
+
+def stack_args(hidden, layers, n_iter):
+    from argparse import Namespace
+    return Namespace(
+        mode=5, n_iter=n_iter, mean_layers=layers, hidden_size=hidden, pocket_pred_hidden_size=128,
+        pocket_pred_layers=1, pocket_pred_n_iter=1, refine="refine_coord", coordinate_scale=5.0,
+        geometry_reg_step_size=0.001, rm_layernorm=True, add_attn_pair_bias=True, explicit_pair_embed=True,
+        add_cross_attn_layer=True, norm_type="per_sample", random_n_iter=False, center_dist_threshold=4.0,
+        stage_prob=0.25, distmap_pred="mlp", use_esm2_feat=True, esm2_concat_raw=False, inter_cutoff=10.0,
+        intra_cutoff=8.0, pocket_radius=20.0, gs_tau=1.0, gs_hard=False, local_eval=False,
+        train_pred_pocket_noise=0.0, compound_coords_init_mode="pocket_center_rdkit", ablation_no_attention=False,
+        ablation_no_attention_with_cross_attn=False, keep_trig_attn=False, opm=False, rm_F_norm=False,
+        fix_pocket=False, rm_LAS_constrained_optim=False)
+
+
+def build_model(hidden, layers, n_iter, seed=0):
+    from fabind_amd.models.att_model import EfficientMCAttModel
+    torch.manual_seed(seed)
+    m = EfficientMCAttModel(stack_args(hidden, layers, n_iter), hidden, hidden, 1, n_layers=layers, n_iter=n_iter,
+                            dropout=0.0, normalize_coord=lambda x: x / 5.0, unnormalize_coord=lambda x: x * 5.0)
+    return m
+
+
+def make_batch(batch, n_prot, n_lig, hidden, seed):
+    """Seeded synthetic complexes; 4 distinct geometries tiled to `batch` (host generation cost)."""
+    from fabind_amd import synthetic
+    uniq = min(batch, 4)
+    base = synthetic.make_stack_batch([(n_prot, n_lig)] * uniq, hidden, seed=seed, snap=False)
+    if batch == uniq:
+        return base
+    reps = (batch + uniq - 1) // uniq
+    n = base["X"].shape[0]
+    out = {}
+    for k in ("X", "H", "segment_id", "mask", "is_global", "coord_LAS"):
+        out[k] = torch.cat([base[k]] * reps)[: n // uniq * batch]
+    per = n // uniq
+    out["batch_id"] = torch.repeat_interleave(torch.arange(batch), per)
+    shift = lambda e: torch.cat([e + i * n for i in range(reps)], 1)
+    ce, le = shift(base["compound_edge_index"]), shift(base["LAS_edge_index"])
+    out["compound_edge_index"] = ce[:, ce[0] < per * batch]
+    out["LAS_edge_index"] = le[:, le[0] < per * batch]
+    return out
+
+
+def cpu_baseline(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0):
+    """The oracle (CPU restatement of the reference algorithm, `kind: port`) timed on the host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fabind_oracle as orc
+    m = build_model(hidden, layers, n_iter)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    inp = make_batch(1, n_prot, n_lig, hidden, seed=0)
+    run = lambda: orc.stack_forward(sd, "", inp["X"], inp["H"], inp["batch_id"], inp["segment_id"], inp["mask"],
+                                    inp["is_global"], inp["compound_edge_index"], inp["LAS_edge_index"],
+                                    inp["coord_LAS"], layers, n_iter)
+    with torch.no_grad():
+        t0 = time.time()
+        run()
+        first = time.time() - t0
+        reps = max(1, min(5, int(budget_s / max(first, 1e-3)) - 1))
+        t0 = time.time()
+        for _ in range(reps):
+            run()
+        dt = (time.time() - t0) / reps
+    return dict(value=1.0 / dt, unit="complexes/s", cores=torch.get_num_threads(), kind="port",
+                sample="oracle stack forward, B=1, %d/%d nodes, hidden %d, %d layers, n_iter=%d, fp32, %d timed runs"
+                       % (n_prot, n_lig, hidden, layers, n_iter, reps))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="complexes per GPU")
+    ap.add_argument("--n-prot", type=int, default=1500)
+    ap.add_argument("--n-lig", type=int, default=40)
+    ap.add_argument("--hidden", type=int, default=512)
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--n-iter", type=int, default=1)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "fwdbwd"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fabind_amd import engine
+    from fabind_amd import kernels as K
+    engine.set_precision(a.precision)
+    model = build_model(a.hidden, a.layers, a.n_iter).to(dev)
+    model.eval()
+    inp = make_batch(a.batch, a.n_prot, a.n_lig, a.hidden, seed=rank)
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    params = [p for p in model.parameters()]
+    cot = None
+
+    def step():
+        X0 = t["X"].clone()
+        if a.mode == "fwd":
+            with torch.no_grad():
+                model(X0, t["H"], t["batch_id"], t["segment_id"], t["mask"], t["is_global"], t["compound_edge_index"],
+                      t["LAS_edge_index"], t["coord_LAS"])
+        else:
+            for p in params:
+                p.grad = None
+            X, Hh = model(X0, t["H"], t["batch_id"], t["segment_id"], t["mask"], t["is_global"],
+                          t["compound_edge_index"], t["LAS_edge_index"], t["coord_LAS"])
+            loss = (X * X).mean() + (Hh * Hh).mean() * 1e-6
+            loss.backward()
+            if world > 1:
+                from fabind_amd import parallel
+                parallel.allreduce_gradients(params, world)
+
+    def sync():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    K.PROFILE = {} if rank == 0 else None
+    t0 = time.time()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.time() - t0
+    prof = K.PROFILE
+    K.PROFILE = None
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        return
+    value = a.batch * world * a.steps / dt
+    out = {
+        "metric": "complexes/sec %s (1500p/40l nodes), one stack pass per refinement iteration" % (
+            "fwd+bwd" if a.mode == "fwdbwd" else "fwd"),
+        "value": value, "unit": "complexes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.precision, "data": "synthetic",
+        "config": {"workload": "synthetic batch=%d/GPU, %d protein / %d ligand nodes, %d-layer FABind stack + out layer, "
+                               "hidden %d, n_iter=%d, %s" % (a.batch, a.n_prot, a.n_lig, a.layers, a.hidden, a.n_iter,
+                                                             a.mode),
+                   "global_batch": a.batch * world, "n_iter": a.n_iter, "pass": a.mode},
+    }
+    # ---- roofline of the dominant kernel (live HIP-event timing of every GEMM launch in the timed region)
+    if prof:
+        best = None
+        for key, evs in prof.items():
+            ms = sum(s.elapsed_time(e) for s, e in evs)
+            if best is None or ms > best[1]:
+                best = (key, ms, len(evs))
+        (M, N, Kd, adt, wdt), ms, cnt = best
+        avg_s = ms / cnt * 1e-3
+        flops = 2.0 * M * N * Kd
+        peak = MFMA_PEAK_TFLOPS[a.precision]
+        out["roofline"] = {"bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": peak, "unit": "TFLOP/s",
+                           "frac": flops / avg_s / 1e12 / peak, "traffic": None,
+                           "kernel": "gemm_nt_kernel<%s,%s> M=%d N=%d K=%d (edge MLP)" % (adt, wdt, M, N, Kd),
+                           "launches": cnt, "avg_us": avg_s * 1e6,
+                           "share_of_step": ms / (1e3 * dt)}
+    if not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.hidden, a.layers, a.n_iter, a.n_prot, a.n_lig)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -7,7 +7,7 @@
 // pre[e,:] = AB[row[e], 0:H] + AB[col[e], H:2H] + rhohat[e] * w_r[:]       (one wave per edge)
 __global__ __launch_bounds__(256) void gcl_pre_kernel(const float* __restrict__ AB, int ldab, int H, const int* row,
                                                       const int* col, const float* rhohat, const float* __restrict__ w_r,
-                                                      void* pre, int pre_dt, int E) {
+                                                      void* pre, int pre_dt, int E, int act) {
     const int lane = threadIdx.x & 63;
     int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= E) return;
@@ -16,18 +16,18 @@ __global__ __launch_bounds__(256) void gcl_pre_kernel(const float* __restrict__ 
     const float rh = rhohat[e];
     for (int c = lane * 4; c < H; c += 256) {
         float4 va = *(const float4*)(a + c), vb = *(const float4*)(b + c), w = *(const float4*)(w_r + c);
-        float4 o = make_float4(va.x + vb.x + rh * w.x, va.y + vb.y + rh * w.y, va.z + vb.z + rh * w.z,
-                               va.w + vb.w + rh * w.w);
+        float4 o = make_float4(apply_act(va.x + vb.x + rh * w.x, act), apply_act(va.y + vb.y + rh * w.y, act),
+                               apply_act(va.z + vb.z + rh * w.z, act), apply_act(va.w + vb.w + rh * w.w, act));
         st4_any(pre, pre_dt, (size_t)e * H + c, o);
     }
 }
 
 extern "C" int fabind_gcl_pre(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
-                              const float* w_r, void* pre, int pre_dt, int E, hipStream_t stream) {
+                              const float* w_r, void* pre, int pre_dt, int E, int act, hipStream_t stream) {
     FB_REQUIRE(H % 4 == 0 && ldab % 4 == 0, "fabind_gcl_pre: H and ldab must be multiples of 4");
     if (E <= 0) return 0;
     hipLaunchKernelGGL(gcl_pre_kernel, dim3((E + 3) / 4), dim3(256), 0, stream, AB, ldab, H, row, col, rhohat, w_r, pre,
-                       pre_dt, E);
+                       pre_dt, E, act);
     FB_CHECK_LAUNCH();
     return 0;
 }

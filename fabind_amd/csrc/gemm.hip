@@ -75,6 +75,92 @@ template <> __device__ __forceinline__ void mma_k32<float>(f32x4_t& acc, const f
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc, 0, 0, 0);
 }
 
+// ---- shared epilogue: C/D layout of mfma 16x16: col = lane&15, row = (lane>>4)*4 + reg.
+// BM_ = rows of the block tile (64 per wave-row).  sDot: float[2][BM_].  sOut (optional): bf16 staging
+// tile [BM_][BN+8] in LDS so that bf16 outputs leave as whole 16-B chunks of a row instead of 2-B scalars.
+#define OUT_LD (BN + 8)
+template <int BM_>
+__device__ __forceinline__ void gemm_epilogue(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sDot, bf16_t* sOut,
+                                              int M, int N, int ldc, long a_row0, long w_row0, long c_off, int m0,
+                                              int n0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 15;
+    const int cq = lane >> 4;
+    const bool want_dot = p.dotvec != nullptr;
+    const bool staged = sOut != nullptr && p.C != nullptr && p.c_dtype == FB_DT_BF16 && !p.accumulate;
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 4; ++i) {
+        float ds0 = 0.f, ds1 = 0.f, ds2 = 0.f, ds3 = 0.f;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 4; ++j) {
+            const f32x4_t a4 = acc[i][j];
+            const float av[4] = {a4[0], a4[1], a4[2], a4[3]};
+            const int coll = wn * 64 + j * 16 + fr;
+            const int col = n0 + coll;
+            const float dv = (want_dot && col < N) ? p.dotvec[col] : 0.f;
+            const float bv = (p.bias && col < N) ? p.bias[w_row0 + col] : 0.f;
+#pragma clang loop unroll(full)
+            for (int r = 0; r < 4; ++r) {
+                const int rowl = wm * 64 + i * 16 + cq * 4 + r;
+                const int row = m0 + rowl;
+                float v = 0.f;
+                if (row < M && col < N) {
+                    v = av[r] * p.alpha + bv;
+                    const float vpre = v;
+                    v = apply_act(v, p.act_epi);
+                    if (p.aux) v *= apply_dact(ld_any(p.aux, p.aux_dtype, (size_t)(a_row0 + row) * p.ldaux + col), p.dact_epi);
+                    if (p.R) {
+                        long rr = p.r_index ? (long)p.r_index[a_row0 + row] : (a_row0 + row);
+                        v += ((const float*)p.R)[(size_t)rr * p.ldr + col];
+                    }
+                    if (staged) {
+                        sOut[rowl * OUT_LD + coll] = f32_to_bf16(p.store_preact ? vpre : v);
+                    } else if (p.C) {
+                        size_t ci = (size_t)c_off + (size_t)row * ldc + col;
+                        if (p.accumulate) v += ld_any(p.C, p.c_dtype, ci);
+                        st_any(p.C, p.c_dtype, ci, p.store_preact ? vpre : v);
+                    }
+                }
+                const float t = v * dv;
+                if (r == 0) ds0 += t; else if (r == 1) ds1 += t; else if (r == 2) ds2 += t; else ds3 += t;
+            }
+        }
+        if (want_dot) {
+            float dsr[4] = {ds0, ds1, ds2, ds3};
+#pragma clang loop unroll(full)
+            for (int r = 0; r < 4; ++r) {
+                float dsum = dsr[r];
+                dsum += __shfl_xor(dsum, 1, 64);
+                dsum += __shfl_xor(dsum, 2, 64);
+                dsum += __shfl_xor(dsum, 4, 64);
+                dsum += __shfl_xor(dsum, 8, 64);
+                if (fr == 0) sDot[wn * BM_ + wm * 64 + i * 16 + cq * 4 + r] = dsum;
+            }
+        }
+    }
+    if (want_dot || staged) __syncthreads();
+    if (want_dot) {
+        for (int t = tid; t < BM_; t += blockDim.x)
+            if (m0 + t < M) p.dot_out[(size_t)(a_row0 + m0 + t) * p.dot_ld + n0 / BN] = sDot[t] + sDot[BM_ + t];
+    }
+    if (staged) {
+        bf16_t* C = (bf16_t*)p.C + c_off;
+        const bool vec_ok = (ldc % 8 == 0) && (((uintptr_t)C & 15) == 0);
+        for (int idx = tid; idx < BM_ * (BN / 8); idx += blockDim.x) {
+            const int rowl = idx / (BN / 8), ch = idx % (BN / 8);
+            const int row = m0 + rowl, col = n0 + ch * 8;
+            if (row >= M || col >= N) continue;
+            const bf16_t* sp = &sOut[rowl * OUT_LD + ch * 8];
+            if (vec_ok && col + 8 <= N) {
+                *(uint4*)(C + (size_t)row * ldc + col) = *(const uint4*)sp;
+            } else {
+                for (int e = 0; e < 8 && col + e < N; ++e) C[(size_t)row * ldc + col + e] = sp[e];
+            }
+        }
+    }
+}
+
 template <typename TA, typename TM>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(FabindGemmArgs p) {
     constexpr int LS = LdsStride<TM>::v;
@@ -159,60 +245,226 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(FabindGemmArgs p) {
         }
     }
 
-    // ---- epilogue: C/D layout of mfma 16x16: col = lane&15, row = (lane>>4)*4 + reg
-    const int cq = lane >> 4;
-    const bool want_dot = p.dotvec != nullptr;
-#pragma clang loop unroll(full)
-    for (int i = 0; i < 4; ++i) {
-        float ds0 = 0.f, ds1 = 0.f, ds2 = 0.f, ds3 = 0.f;
-#pragma clang loop unroll(full)
+    gemm_epilogue<BM>(p, acc, &sDot[0][0], nullptr, M, N, ldc, a_row0, w_row0, c_off, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fast path: bf16 A and W, no prologue activation, K % 64 == 0.  Both operand tiles go HBM -> LDS with
+// global_load_lds_dwordx4 (no VGPR round trip), double-buffered, BK = 64 (32 MFMAs per wave between
+// barriers).  LDS rows are 128 B; the 16-B chunk index is XOR-swizzled with (row & 7) on the SOURCE
+// address (the LDS image of an LDS-DMA is lane-linear) and on the fragment read.
+// ------------------------------------------------------------------------------------------------
+#define FBK 64
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__global__ __launch_bounds__(256) void gemm_bf16_glds_kernel(FabindGemmArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16_t sT[2][2][BM * FBK];   // [buf][A|B][128 rows x 64]
+    __shared__ float sDot[2][BM];
+    int M = p.M, N = p.N, ldc = p.ldc;
+    long a_row0 = 0, w_row0 = 0, c_off = 0;
+    if (p.groups) {
+        const int* g = p.groups + (size_t)blockIdx.z * 8;
+        a_row0 = g[0]; M = g[1]; w_row0 = g[2]; N = g[3];
+        c_off = (long)(unsigned)g[4] | ((long)g[5] << 32);
+        if (g[6] > 0) ldc = g[6];
+    }
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    if (m0 >= M || n0 >= N) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const bf16_t* A = (const bf16_t*)p.A + a_row0 * p.lda;
+    const bf16_t* W = (const bf16_t*)p.W + w_row0 * p.ldw;
+    const int K = p.K;
+
+    // per-lane source rows/chunks of this wave's 4 LDS-DMA pieces per operand (8 rows x 128 B each)
+    const int lrow = lane >> 3, lchunk = lane & 7;
+    const bf16_t* srcA[4];
+    const bf16_t* srcB[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (wave * 4 + j) * 8 + lrow;
+        const int chunk = lchunk ^ (row & 7);
+        const int gm = min(m0 + row, M - 1), gn = min(n0 + row, N - 1);   // clamp: out-of-range rows are never stored
+        srcA[j] = A + (size_t)gm * p.lda + chunk * 8;
+        srcB[j] = W + (size_t)gn * p.ldw + chunk * 8;
+    }
+    auto stage = [&](int buf, int k0) {
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4_t a4 = acc[i][j];
-            const float av[4] = {a4[0], a4[1], a4[2], a4[3]};
-            const int col = n0 + wn * 64 + j * 16 + fr;
-            const float dv = (want_dot && col < N) ? p.dotvec[col] : 0.f;
-            const float bv = (p.bias && col < N) ? p.bias[w_row0 + col] : 0.f;
-#pragma clang loop unroll(full)
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + cq * 4 + r;
-                float v = 0.f;
-                if (row < M && col < N) {
-                    v = av[r] * p.alpha + bv;
-                    const float vpre = v;
-                    v = apply_act(v, p.act_epi);
-                    if (p.aux) v *= apply_dact(ld_any(p.aux, p.aux_dtype, (size_t)(a_row0 + row) * p.ldaux + col), p.dact_epi);
-                    if (p.R) {
-                        long rr = p.r_index ? (long)p.r_index[a_row0 + row] : (a_row0 + row);
-                        v += ((const float*)p.R)[(size_t)rr * p.ldr + col];
-                    }
-                    if (p.C) {
-                        size_t ci = (size_t)c_off + (size_t)row * ldc + col;
-                        if (p.accumulate) v += ld_any(p.C, p.c_dtype, ci);
-                        st_any(p.C, p.c_dtype, ci, p.store_preact ? vpre : v);
-                    }
-                }
-                const float t = v * dv;
-                if (r == 0) ds0 += t; else if (r == 1) ds1 += t; else if (r == 2) ds2 += t; else ds3 += t;
-            }
+            const int q = wave * 4 + j;
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcA[j] + k0), (lptr_t)&sT[buf][0][q * 8 * FBK], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(srcB[j] + k0), (lptr_t)&sT[buf][1][q * 8 * FBK], 16, 0, 0);
         }
-        if (want_dot) {
-            float dsr[4] = {ds0, ds1, ds2, ds3};
-#pragma clang loop unroll(full)
-            for (int r = 0; r < 4; ++r) {
-                float dsum = dsr[r];
-                dsum += __shfl_xor(dsum, 1, 64);
-                dsum += __shfl_xor(dsum, 2, 64);
-                dsum += __shfl_xor(dsum, 4, 64);
-                dsum += __shfl_xor(dsum, 8, 64);
-                if (fr == 0) sDot[wn][wm * 64 + i * 16 + cq * 4 + r] = dsum;
-            }
-        }
-    }
-    if (want_dot) {
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / FBK;
+    const int fr = lane & 15, fq = lane >> 4;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid < BM && m0 + tid < M)
-            p.dot_out[(size_t)(a_row0 + m0 + tid) * p.dot_ld + blockIdx.x] = sDot[0][tid] + sDot[1][tid];
+        if (kt + 1 < nk) stage(buf ^ 1, (kt + 1) * FBK);
+        const bf16_t* tA = sT[buf][0];
+        const bf16_t* tB = sT[buf][1];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wm * 64 + i * 16 + fr, rb = wn * 64 + i * 16 + fr;
+                af[i] = *(const bf16x8_t*)&tA[ra * FBK + (((kk * 4 + fq) ^ (ra & 7)) * 8)];
+                bfr[i] = *(const bf16x8_t*)&tB[rb * FBK + (((kk * 4 + fq) ^ (rb & 7)) * 8)];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
     }
+    __syncthreads();
+    gemm_epilogue<BM>(p, acc, &sDot[0][0], &sT[0][0][0], M, N, ldc, a_row0, w_row0, c_off, m0, n0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pipelined LDS-DMA variant: NSTAGE-deep ring of (A|W) k-tiles, counted s_waitcnt vmcnt(N) so that
+// NSTAGE-2 tiles stay in flight across the (raw) barrier -- the HBM latency of this short-K, long-M
+// edge GEMM (K = 512: 8-16 k-steps per block) is what bounds it, not the matrix pipe.
+// ------------------------------------------------------------------------------------------------
+// bytes of the tile ring; at least one bf16 output staging tile [BM_][BN+8] must fit in it
+template <int WM, int BK_, int NSTAGE> __host__ __device__ constexpr size_t lds_tile_bytes() {
+    size_t ring = (size_t)NSTAGE * (WM * 64 + BN) * BK_ * 2, out = (size_t)WM * 64 * (BN + 8) * 2;
+    return ring > out ? ring : out;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int WM, int BK_, int NSTAGE>
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_pipe_kernel(FabindGemmArgs p) {
+    constexpr int BM_ = WM * 64, NW = WM * 2, NT = NW * 64;
+    constexpr int ROWS = BM_ + BN;                    // A rows then W rows share one row space per stage
+    constexpr int RPP = 1024 / (BK_ * 2);             // rows per 1-KiB LDS-DMA piece
+    constexpr int PT = ROWS / RPP, PPW = PT / NW;     // pieces per stage / per wave
+    constexpr int LPR = 64 / RPP;                     // lanes (16-B chunks) per row
+    static_assert(PT % NW == 0, "pieces must divide evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sT = (bf16_t*)smem;                       // [NSTAGE][ROWS][BK_]
+    float* sDot = (float*)(smem + lds_tile_bytes<WM, BK_, NSTAGE>());
+    int M = p.M, N = p.N, ldc = p.ldc;
+    long a_row0 = 0, w_row0 = 0, c_off = 0;
+    if (p.groups) {
+        const int* g = p.groups + (size_t)blockIdx.z * 8;
+        a_row0 = g[0]; M = g[1]; w_row0 = g[2]; N = g[3];
+        c_off = (long)(unsigned)g[4] | ((long)g[5] << 32);
+        if (g[6] > 0) ldc = g[6];
+    }
+    // XCD-aware tile order (non-grouped launches are 1-D): block L runs on XCD L % 8, so give every XCD a
+    // contiguous run of tiles -- the N-tiles of one M-panel then share that XCD's L2 copy of the A panel.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (!p.groups) {
+        const int nbx = (N + BN - 1) / BN, total = gridDim.x;
+        const int L = blockIdx.x, q = total / 8, r = total % 8, xcd = L % 8;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + L / 8;
+        bx = t % nbx; by = t / nbx;
+    }
+    const int m0 = by * BM_, n0 = bx * BN;
+    if (m0 >= M || n0 >= N) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const bf16_t* A = (const bf16_t*)p.A + a_row0 * p.lda;
+    const bf16_t* W = (const bf16_t*)p.W + w_row0 * p.ldw;
+    const int K = p.K;
+
+    const bf16_t* src[PPW];
+    const bf16_t* src2[PPW];   // second K-segment of A (K-concatenated operand); W rows keep one segment
+    const int K1 = p.K1;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int row = (wave * PPW + j) * RPP + lane / LPR;      // row in the combined (A|W) space
+        const int cl = lane % LPR;                                 // LDS chunk slot
+        const int chunk = (BK_ == 64) ? (cl ^ (row & 7)) : (cl ^ ((row >> 2) & 3));
+        if (row < BM_) {
+            const size_t gm = (size_t)min(m0 + row, M - 1);
+            src[j] = A + gm * p.lda + chunk * 8;
+            src2[j] = p.A2 ? (const bf16_t*)p.A2 + (a_row0 + gm) * p.lda2 + chunk * 8 - K1 : src[j];
+        } else {
+            src[j] = W + (size_t)min(n0 + row - BM_, N - 1) * p.ldw + chunk * 8;
+            src2[j] = src[j];
+        }
+    }
+    auto stage = [&](int st, int k0) {
+        bf16_t* base = sT + (size_t)st * ROWS * BK_;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)((k0 < K1 ? src[j] : src2[j]) + k0),
+                                             (lptr_t)(base + (size_t)(wave * PPW + j) * RPP * BK_), 16, 0, 0);
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK_;
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < NSTAGE - 1; ++s)
+        if (s < nk) stage(s, s * BK_);
+    for (int kt = 0; kt < nk; ++kt) {
+        // tiles kt+1 .. kt+NSTAGE-2 may stay in flight
+        const int ahead = min(NSTAGE - 2, nk - 1 - kt);
+        if (ahead >= 2) wait_vmcnt<2 * PPW>(); else if (ahead == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, (kt + NSTAGE - 1) * BK_);
+        const bf16_t* tA = sT + (size_t)(kt % NSTAGE) * ROWS * BK_;
+        const bf16_t* tB = tA + BM_ * BK_;
+#pragma unroll
+        for (int kk = 0; kk < BK_ / 32; ++kk) {
+            bf16x8_t af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wm * 64 + i * 16 + fr, rb = wn * 64 + i * 16 + fr;
+                const int ca = (BK_ == 64) ? ((kk * 4 + fq) ^ (ra & 7)) : (fq ^ ((ra >> 2) & 3));
+                const int cb = (BK_ == 64) ? ((kk * 4 + fq) ^ (rb & 7)) : (fq ^ ((rb >> 2) & 3));
+                af[i] = *(const bf16x8_t*)&tA[ra * BK_ + ca * 8];
+                bfr[i] = *(const bf16x8_t*)&tB[rb * BK_ + cb * 8];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    gemm_epilogue<BM_>(p, acc, sDot, sT, M, N, ldc, a_row0, w_row0, c_off, m0, n0);
+}
+
+static int g_gemm_cfg = 3;   // 256x128 tile, BK = 32, 3-stage ring (best of the measured set, see tools/gemm_bench.py)
+extern "C" void fabind_gemm_set_config(int cfg) { g_gemm_cfg = cfg; }
+
+template <int WM, int BK_, int NSTAGE>
+static int launch_pipe(const FabindGemmArgs& p, int maxM, int maxN, hipStream_t stream) {
+    constexpr int BM_ = WM * 64;
+    const size_t lds = lds_tile_bytes<WM, BK_, NSTAGE>() + 2 * BM_ * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pipe_kernel<WM, BK_, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((maxN + BN - 1) / BN, (maxM + BM_ - 1) / BM_, p.groups ? p.n_groups : 1);
+    if (!p.groups) grid = dim3(grid.x * grid.y, 1, 1);
+    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<WM, BK_, NSTAGE>), grid, dim3(WM * 128), lds, stream, p);
+    return 0;
 }
 
 extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
@@ -231,6 +483,21 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
         hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, stream, p);
     } else if (p.a_dtype == FB_DT_F32) {
         hipLaunchKernelGGL((gemm_nt_kernel<float, bf16_t>), grid, dim3(256), 0, stream, p);
+    } else if (p.act_pro == FB_ACT_NONE && p.K % FBK == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 &&
+               ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) &&
+               (p.A2 == nullptr || (g_gemm_cfg != 0 && p.K1 % FBK == 0 && p.lda2 % 8 == 0 && ((uintptr_t)p.A2 % 16 == 0)))) {
+        switch (g_gemm_cfg) {
+            case 1: launch_pipe<2, 32, 4>(p, maxM, maxN, stream); break;
+            case 2: launch_pipe<2, 64, 3>(p, maxM, maxN, stream); break;
+            case 3: launch_pipe<4, 32, 3>(p, maxM, maxN, stream); break;
+            case 4: launch_pipe<4, 64, 3>(p, maxM, maxN, stream); break;
+            case 5: launch_pipe<4, 32, 4>(p, maxM, maxN, stream); break;
+            case 6: launch_pipe<2, 32, 3>(p, maxM, maxN, stream); break;
+            case 7: launch_pipe<4, 32, 2>(p, maxM, maxN, stream); break;
+            case 8: launch_pipe<2, 32, 2>(p, maxM, maxN, stream); break;
+            case 9: launch_pipe<4, 64, 2>(p, maxM, maxN, stream); break;
+            default: hipLaunchKernelGGL(gemm_bf16_glds_kernel, grid, dim3(256), 0, stream, p);
+        }
     } else {
         hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, stream, p);
     }

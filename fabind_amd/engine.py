@@ -204,37 +204,64 @@ def prepare_stack_params(model):
 # ------------------------------------------------------------------------------------------------
 # layers
 # ------------------------------------------------------------------------------------------------
+def _fast(*ts):
+    """Forward-only bf16 mode: producers apply the activations, node tensors are fed to the GEMMs as bf16."""
+    return get_precision() == "bf16" and not ops.needs_grad(*ts)
+
+
+def _b16(t):
+    return t.to(torch.bfloat16)
+
+
 def gcl_layer(p, h, x, lay, g, clampv):
     """MC_E_GCL.forward (egnn.py:130-144): edge -> coord -> node, all from the layer's input h, x."""
     H = h.shape[1]
-    AB = ops.linear(h, p["W_ab"], p["b_ab"])                                           # [N,2H] node-level
+    fast = _fast(h, x, p["W2"])
+    hin = _b16(h) if fast else h
+    AB = ops.linear(hin, p["W_ab"], p["b_ab"])                                         # [N,2H] node-level
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
-    pre = ops.gcl_pre(AB, H, g.row_ctx, g.col_ctx, rhohat, p["w_r"])                    # [E,H]  pre-activation
-    Z2 = ops.linear(pre, p["W2"], p["b2"], act_pro=K.ACT_SILU, out_dtype=ops.act_dtype())  # [E,H]  pre-activation
-    s = ops.linear_rowdot(Z2, p["Wc"], p["bc"], p["w3"], act_pro=K.ACT_SILU, act_epi=K.ACT_SILU)   # [E,nt]
+    if ops.needs_grad(h, x, p["W2"]):
+        # training form: keep pre-activations (the consumers apply SiLU while staging their operand)
+        pre = ops.gcl_pre(AB, H, g.row_ctx, g.col_ctx, rhohat, p["w_r"])                # [E,H]
+        Z2 = ops.linear(pre, p["W2"], p["b2"], act_pro=K.ACT_SILU, out_dtype=ops.act_dtype())
+        s = ops.linear_rowdot(Z2, p["Wc"], p["bc"], p["w3"], act_pro=K.ACT_SILU, act_epi=K.ACT_SILU)   # [E,nt]
+        agg = ops.segment_sum(Z2, g.rp_ctx, g.row_ctx, h.shape[0], act=K.ACT_SILU)
+    else:
+        # forward-only form: producers apply SiLU once, the edge GEMMs stream bf16 operands HBM->LDS directly
+        S1 = ops.gcl_pre(AB, H, g.row_ctx, g.col_ctx, rhohat, p["w_r"], act=K.ACT_SILU)
+        Mm = ops.linear(S1, p["W2"], p["b2"], act_epi=K.ACT_SILU, out_dtype=ops.act_dtype())
+        s = ops.linear_rowdot(Mm, p["Wc"], p["bc"], p["w3"], act_epi=K.ACT_SILU)
+        agg = ops.segment_sum(Mm, g.rp_ctx, g.row_ctx, h.shape[0], act=K.ACT_NONE)
     x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
-    agg = ops.segment_sum(Z2, g.rp_ctx, g.row_ctx, h.shape[0], act=K.ACT_SILU)
-    t = ops.linear(h, p["Wn1"], p["bn1"], x2=agg)
-    h_new = ops.linear(t, p["Wn2"], p["bn2"], act_pro=K.ACT_SILU, residual=h)
+    if fast:
+        t = ops.linear(hin, p["Wn1"], p["bn1"], x2=_b16(agg), act_epi=K.ACT_SILU, out_dtype=torch.bfloat16)
+        h_new = ops.linear(t, p["Wn2"], p["bn2"], residual=h)
+    else:
+        t = ops.linear(h, p["Wn1"], p["bn1"], x2=agg)
+        h_new = ops.linear(t, p["Wn2"], p["bn2"], act_pro=K.ACT_SILU, residual=h)
     return h_new, x_new
 
 
 def cross_attention(p, h, lay, pairbias, layer):
     """CrossAttentionModule node path (cross_att.py:38-49) on compact protein / ligand arrays."""
+    fast = _fast(h, p["Wo_p"])
+    od = torch.bfloat16 if fast else torch.float32
+    c16 = (lambda t: _b16(t)) if fast else (lambda t: t)
     hp, hc = ops.take_rows(h, lay.p_index64), ops.take_rows(h, lay.c_index64)
     scale = 1.0 / math.sqrt(32.0)
     bias_p, bias_c = pairbias[2 * layer], pairbias[2 * layer + 1]
-    qg = ops.linear(hp, p["Wqg_p"], p["bqg_p"])
-    kv = ops.linear(hc, p["Wkv_p"])
+    qg = ops.linear(c16(hp), p["Wqg_p"], p["bqg_p"])
+    kv = ops.linear(c16(hc), p["Wkv_p"])
     og = ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_p, lay.B, lay.max_P, scale)
-    hp = ops.linear(og, p["Wo_p"], p["bo_p"], residual=hp)
-    qg = ops.linear(hc, p["Wqg_c"], p["bqg_c"])
-    kv = ops.linear(hp, p["Wkv_c"])
+    hp = ops.linear(c16(og), p["Wo_p"], p["bo_p"], residual=hp)
+    hp16 = c16(hp)
+    qg = ops.linear(c16(hc), p["Wqg_c"], p["bqg_c"])
+    kv = ops.linear(hp16, p["Wkv_c"])
     og = ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_c, lay.B, lay.max_C, scale)
-    hc = ops.linear(og, p["Wo_c"], p["bo_c"], residual=hc)
-    t = ops.linear(hp, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU)
+    hc = ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc)
+    t = ops.linear(hp16, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU, out_dtype=od)
     hp = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp)
-    t = ops.linear(hc, p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU)
+    t = ops.linear(c16(hc), p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU, out_dtype=od)
     hc = ops.linear(t, p["Wt2_c"], p["bt2_c"], residual=hc)
     return ops.take_rows(torch.cat([hc, hp], 0), lay.inv_perm)
 
@@ -244,10 +271,11 @@ def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv):
     H = h.shape[1]
     h = cross_attention(p, h, lay, pairbias, layer)
     # pair embedding at the inter-edge pairs only -> scalar attention bias (egnn.py:208, 286-304)
-    ab32 = ops.linear(h, p["W_ab32"], p["b_ab32"])                                     # [N,64]
+    h16 = _b16(h) if _fast(h, x, p["Wqkv"]) else h
+    ab32 = ops.linear(h16, p["W_ab32"], p["b_ab32"])                                   # [N,64]
     hd = ops.pair_hadamard(a0b0, H, ab32, 32, g.red_p, g.red_c)                        # [n_red, H+32]
     bias_part = ops.linear_rowdot(hd, p["Wcomp1"], p["bcomp1"], p["u"], act_epi=K.ACT_RELU)
-    qkv = ops.linear(h, p["Wqkv"], p["bqkv"])                                          # [N,3H]
+    qkv = ops.linear(h16, p["Wqkv"], p["bqkv"])                                        # [N,3H]
     cv = ops.linear(qkv[:, 2 * H:], p["Wc"], p["bc"])                                  # [N,H]
     d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay)
     h_new, x_new, alpha = ops.inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["wcr"],

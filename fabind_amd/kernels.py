@@ -12,6 +12,7 @@ __all__ = ["gemm", "transpose_act", "colsum", "edges_count", "edges_fill", "excl
            "inter_attn_fwd", "las_step", "select_rows", "ACT_NONE", "ACT_SILU", "ACT_RELU", "ACT_SIGMOID"]
 
 GEMM_BN = 128
+PROFILE = None  # dict -> per-(M,N,K,dtypes) list of (start,end) HIP events around every GEMM launch (bench.py)
 
 
 def _ld(t):
@@ -56,7 +57,14 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     a.accumulate = 1 if accumulate else 0
     a.n_groups, a.max_m, a.max_n = n_groups, max_m, max_n
     a.alpha = alpha
-    check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm")
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm")
+        e1.record()
+        PROFILE.setdefault((M, N, K, str(A.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", "")), []).append((e0, e1))
+    else:
+        check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm")
     return (out if want_out else None), dot_out
 
 
@@ -133,11 +141,11 @@ def edge_geom(x, row, col, rowptr, node_off, B):
     return d[:E], rho[:E], rhohat[:E], norm
 
 
-def gcl_pre(AB, H, row, col, rhohat, w_r, out_dtype):
+def gcl_pre(AB, H, row, col, rhohat, w_r, out_dtype, act=ACT_NONE):
     E = row.shape[0]
     pre = torch.empty((E, H), dtype=out_dtype, device=AB.device)
     check(_lib.load().fabind_gcl_pre(ptr(AB), _ld(AB), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r), ptr(pre),
-                                     dt_code(out_dtype), E, stream()), "fabind_gcl_pre")
+                                     dt_code(out_dtype), E, act, stream()), "fabind_gcl_pre")
     return pre
 
 

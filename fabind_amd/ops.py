@@ -143,7 +143,14 @@ def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store):
     a.lda, a.ldw, a.ldc, a.dot_ld = x.stride(0), W.stride(0), N, nt
     a.a_dtype, a.w_dtype, a.c_dtype = dt_code(x.dtype), dt_code(W.dtype), dt_code(z.dtype) if store else 0
     a.act_pro, a.act_epi, a.store_preact, a.alpha = act_pro, act_epi, 1, 1.0
-    check(load().fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm(rowdot)")
+    if K.PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(load().fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm(rowdot)")
+        e1.record()
+        K.PROFILE.setdefault((M, N, Kd, str(x.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", "")), []).append((e0, e1))
+    else:
+        check(load().fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm(rowdot)")
     return z, part
 
 
@@ -210,10 +217,15 @@ class _GclPre(torch.autograd.Function):
         return dAB, drh, dw, None, None, None
 
 
-def gcl_pre(AB, H, row, col, rhohat, w_r):
+def gcl_pre(AB, H, row, col, rhohat, w_r, act=K.ACT_NONE):
     if _needs_grad(AB, rhohat, w_r):
+        assert act == K.ACT_NONE
         return _GclPre.apply(AB, rhohat, w_r, H, row, col)
-    return K.gcl_pre(AB, H, row, col, rhohat, w_r, act_dtype())
+    return K.gcl_pre(AB, H, row, col, rhohat, w_r, act_dtype(), act)
+
+
+def needs_grad(*ts):
+    return _needs_grad(*ts)
 
 
 class _SegmentSum(torch.autograd.Function):

@@ -107,14 +107,15 @@ int fabind_edge_geom(const float* x, const int* row, const int* col, const int* 
 
 /* ---------------------------------------------------------------------------------------------
  * MC_E_GCL pieces (models/egnn.py:68-144).
- * gcl_pre:  pre[e,:] = AB[row[e], 0:H] + AB[col[e], H:2H] + rhohat[e]*w_r[:]
+ * gcl_pre:  pre[e,:] = act( AB[row[e], 0:H] + AB[col[e], H:2H] + rhohat[e]*w_r[:] )   (act = NONE keeps the
+ *           pre-activation for training; SILU is the forward-only form)
  *           (first edge_mlp Linear split column-wise: node-level projections gathered per edge).
  * segment_sum: out[r,:] = sum_{e in row r} act(Z[e,:])   (unsorted_segment_sum on a row-sorted CSR)
  * coord_mean: x_out[r] = x[r] + clamp( (1/max(deg,1)) * sum_e d[e]*s[e], +-clampv ),
  *           s[e] = sum_k s_part[e,k] (row-dot partials written by fabind_gemm).
  * -------------------------------------------------------------------------------------------*/
 int fabind_gcl_pre(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
-                   const float* w_r, void* pre, int pre_dt, int E, hipStream_t stream);
+                   const float* w_r, void* pre, int pre_dt, int E, int act, hipStream_t stream);
 int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, int n_rows, int act, float* out,
                        int ldo, hipStream_t stream);
 int fabind_coord_update(const float* x, const float* d, const float* s_part, int n_part, const float* weight,

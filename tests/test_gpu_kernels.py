@@ -76,3 +76,31 @@ def test_layernorm():
     y = ops.layernorm(x.to(dev), w.to(dev), b.to(dev))
     ref = torch.nn.functional.layer_norm(x, (512,), w, b)
     assert (y.cpu() - ref).abs().max() < 1e-4
+
+
+@pytest.mark.parametrize("cfg", [0, 3, 6, 7])
+@pytest.mark.parametrize("shape", [(1000, 512, 512), (257, 200, 128), (4096, 1024, 576), (130, 64, 64)])
+def test_gemm_bf16_lds_dma_fast_path(shape, cfg):
+    """bf16 A and W, K % 64 == 0 -> global_load_lds pipelined kernels (swizzled LDS image), every tile config."""
+    from fabind_amd import kernels as K, _lib
+    dev = _dev()
+    _lib.load().fabind_gemm_set_config(cfg)
+    M, N, Kd = shape
+    g = torch.Generator().manual_seed(M + N + Kd)
+    A = torch.randn(M, Kd, generator=g).bfloat16()
+    W = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).bfloat16()
+    b = torch.randn(N, generator=g)
+    u = torch.randn(N, generator=g)
+    ref = torch.nn.functional.silu(A.float() @ W.float().T + b)
+    out, part = K.gemm(A.to(dev), W.to(dev), bias=b.to(dev), act_epi=K.ACT_SILU, dotvec=u.to(dev), out_dtype=torch.bfloat16)
+    assert (out.float().cpu() - ref).abs().max() <= 2e-2 * max(1.0, ref.abs().max())
+    rd = (ref * u).sum(1)
+    assert (part.sum(1).cpu() - rd).abs().max() <= 2e-2 * max(1.0, rd.abs().max())
+    # transposition check with an asymmetric operand
+    eye = torch.eye(128, 128).bfloat16()
+    Wa = (torch.arange(128 * 128, dtype=torch.float32).reshape(128, 128) % 251 / 256.0).bfloat16()
+    o2, _ = K.gemm(eye.to(dev), Wa.to(dev))
+    o3, _ = K.gemm(eye.to(dev), Wa.to(dev), out_dtype=torch.bfloat16)
+    _lib.load().fabind_gemm_set_config(3)
+    assert torch.equal(o2.cpu(), Wa.float().T.contiguous())
+    assert torch.equal(o3.float().cpu(), Wa.float().T.contiguous())
