@@ -31,10 +31,10 @@ SIGNATURES = {
     "fabind_edges_count": [_vp, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp],
     "fabind_edges_fill": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "fabind_exclusive_scan": [_vp, _vp, _i, _vp],
-    "fabind_inter_meta": [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "fabind_inter_meta": [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fabind_edge_geom": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "fabind_gcl_pre": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "fabind_segment_sum": [_vp, _i, _i, _i, _vp, _i, _i, _vp, _i, _vp],
+    "fabind_segment_sum": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp],
     "fabind_coord_update": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
     "fabind_cross_attn_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _vp],
     "fabind_pair_bmat": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp],
@@ -44,6 +44,20 @@ SIGNATURES = {
     "fabind_las_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp],
     "fabind_select_rows": [_vp, _vp, _vp, _i, _i, _vp, _vp],
     "fabind_add": [_vp, _vp, _vp, _l, _vp],
+    "fabind_mul_dact": [_vp, _i, _vp, _i, _i, _vp, _i, _l, _vp],
+    "fabind_rowdot_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "fabind_edge_geom_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
+    "fabind_gcl_pre_bwd": [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],
+    "fabind_gather_dact": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "fabind_coord_update_bwd": [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
+    "fabind_cross_attn_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                              _vp, _vp],
+    "fabind_pair_hadamard_bwd": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
+                                 _vp],
+    "fabind_inter_attn_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i,
+                              _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "fabind_las_step_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp],
+    "fabind_pair_bias_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fabind_layernorm_fwd": [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp],
     "fabind_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
 }
@@ -63,6 +77,8 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.fabind_last_error.restype = ctypes.c_char_p
     lib.fabind_abi_version.restype = ctypes.c_int
+    lib.fabind_gemm_set_config.argtypes = [ctypes.c_int]
+    lib.fabind_gemm_set_config.restype = None
     for name, argt in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = argt

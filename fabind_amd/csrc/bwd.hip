@@ -1,0 +1,748 @@
+// Backward kernels of the FABind layer ops (gfx950).  Each kernel is the hand-written adjoint of a
+// forward kernel in gcl.hip / attn.hip / graph.hip; contractions in backward passes reuse the GEMM family.
+// Reductions over a CSR row, a key tile or a chunk of rows are done in fixed order (no float atomics)
+// unless stated in the kernel's comment.
+#include "common.h"
+#include "fabind_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// out = dy * act'(y)   (elementwise; for ReLU the derivative can be taken at the output)
+// ------------------------------------------------------------------------------------------------
+__global__ void mul_dact_kernel(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) st_any(out, out_dt, i, ld_any(dy, dy_dt, i) * apply_dact(ld_any(y, y_dt, i), act));
+}
+extern "C" int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, long n,
+                               hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mul_dact_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, dy_dt, y, y_dt, act,
+                       out, out_dt, n);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adjoint of the row-dot epilogue:  part[m,t] = sum_{n in tile t} act(z[m,n]) u[n]
+//   dz[m,n] = dpart[m, n/128] * u[n] * act'(z[m,n]);   du[n] = sum_m dpart[m, n/128] * act(z[m,n])
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const void* z, int z_dt, const float* dpart, int np,
+                                                         const float* u, int act, int M, int N, void* dz,
+                                                         float* scratch, int rows_per) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float s = 0.f;
+    if (c < N) {
+        const float uc = u[c];
+        const int t = c / 128;
+        for (int r = r0 + q; r < r1; r += 4) {
+            const float zv = ld_any(z, z_dt, (size_t)r * N + c), g = dpart[(size_t)r * np + t];
+            st_any(dz, z_dt, (size_t)r * N + c, g * uc * apply_dact(zv, act));
+            s += g * apply_act(zv, act);
+        }
+    }
+    part[q][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (q == 0 && c < N) {
+        const int l = threadIdx.x;
+        scratch[(size_t)blockIdx.y * N + c] = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
+    }
+}
+__global__ void sum_chunks_kernel(const float* scratch, float* out, int C, int nchunk) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunk; ++k) s += scratch[(size_t)k * C + c];
+    out[c] = s;
+}
+extern "C" int fabind_rowdot_bwd(const void* z, int z_dt, const float* dpart, int np, const float* u, int act, int M,
+                                 int N, void* dz, float* du, float* scratch, int nchunk, hipStream_t stream) {
+    if (M <= 0 || N <= 0) return 0;
+    int rows_per = (M + nchunk - 1) / nchunk;
+    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((N + 63) / 64, nchunk), dim3(256), 0, stream, z, z_dt, dpart, np, u, act,
+                       M, N, dz, scratch, rows_per);
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, scratch, du, N, nchunk);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adjoint of edge_geom:  d=x[r]-x[c], rho=|d|^2, rhohat=rho/sqrt(sum_b rho^2)
+//   drho_e = drhohat_e/nrm - T_b rho_e / nrm^3,  T_b = sum_e drhohat_e rho_e;   g_e = dd_e + 2 drho_e d_e
+//   dx[r] += g_e, dx[c] -= g_e   (float atomics on [N,3]: order-insensitive to rounding only)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void edge_geom_bwd_kernel(const float* d, const float* rho, const float* norm,
+                                                             const float* dd, const float* drhohat, const int* row,
+                                                             const int* col, const int* rowptr, const int* node_off,
+                                                             float* dx) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    const int e0 = rowptr[node_off[b]], e1 = rowptr[node_off[b + 1]];
+    float acc = 0.f;
+    for (int e = e0 + threadIdx.x; e < e1; e += 1024) acc += drhohat[e] * rho[e];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    float T = 0.f;
+    for (int k = 0; k < 16; ++k) T += red[k];
+    const float nrm = norm[b], inv = 1.f / nrm, inv3 = inv * inv * inv;
+    for (int e = e0 + threadIdx.x; e < e1; e += 1024) {
+        const float drho = drhohat[e] * inv - T * rho[e] * inv3;
+        const int r = row[e], c = col[e];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float g = dd[(size_t)e * 3 + k] + 2.f * drho * d[(size_t)e * 3 + k];
+            atomicAdd(&dx[(size_t)r * 3 + k], g);
+            atomicAdd(&dx[(size_t)c * 3 + k], -g);
+        }
+    }
+}
+extern "C" int fabind_edge_geom_bwd(const float* d, const float* rho, const float* norm, const float* dd,
+                                    const float* drhohat, const int* row, const int* col, const int* rowptr,
+                                    const int* node_off, int B, int E, float* dx, hipStream_t stream) {
+    if (B <= 0 || E <= 0) return 0;
+    hipLaunchKernelGGL(edge_geom_bwd_kernel, dim3(B), dim3(1024), 0, stream, d, rho, norm, dd, drhohat, row, col, rowptr,
+                       node_off, dx);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adjoint of gcl_pre w.r.t. rhohat and w_r:  drh[e] = dpre[e,:].w_r ;  dw[c] = sum_e rhohat[e] dpre[e,c]
+// (dAB comes from two segment_sum launches: by row, and by column through a permutation)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gcl_pre_bwd_kernel(const void* dpre, int dt, int H, const float* rhohat,
+                                                          const float* w_r, int E, float* drh, float* scratch,
+                                                          int edges_per) {
+    extern __shared__ float sh[];  // [4][H]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e0 = blockIdx.x * edges_per, e1 = min(E, e0 + edges_per);
+    for (int c = lane; c < H; c += 64) sh[w * H + c] = 0.f;
+    for (int e = e0 + w; e < e1; e += 4) {
+        const float rh = rhohat[e];
+        float dot = 0.f;
+        for (int c = lane; c < H; c += 64) {
+            const float g = ld_any(dpre, dt, (size_t)e * H + c);
+            dot += g * w_r[c];
+            sh[w * H + c] += rh * g;
+        }
+        dot = wave_sum(dot);
+        if (lane == 0) drh[e] = dot;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256)
+        scratch[(size_t)blockIdx.x * H + c] = (sh[c] + sh[H + c]) + (sh[2 * H + c] + sh[3 * H + c]);
+}
+extern "C" int fabind_gcl_pre_bwd(const void* dpre, int dt, int H, const float* rhohat, const float* w_r, int E,
+                                  float* drh, float* dw, float* scratch, int nchunk, hipStream_t stream) {
+    if (E <= 0) return 0;
+    int edges_per = (E + nchunk - 1) / nchunk;
+    hipLaunchKernelGGL(gcl_pre_bwd_kernel, dim3(nchunk), dim3(256), 4 * H * sizeof(float), stream, dpre, dt, H, rhohat,
+                       w_r, E, drh, scratch, edges_per);
+    hipLaunchKernelGGL(sum_chunks_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, scratch, dw, H, nchunk);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// adjoint of segment_sum: dZ[e,:] = dout[row[e],:] * act'(Z[e,:])     (one wave per edge)
+__global__ __launch_bounds__(256) void gather_dact_kernel(const float* dout, int ldo, const int* row, const void* Z,
+                                                          int z_dt, int act, void* dZ, int dz_dt, int E, int H) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;
+    const float* g = dout + (size_t)row[e] * ldo;
+    for (int c = lane * 4; c < H; c += 256) {
+        float4 gv = *(const float4*)(g + c), zv = ld4_any(Z, z_dt, (size_t)e * H + c);
+        st4_any(dZ, dz_dt, (size_t)e * H + c,
+                make_float4(gv.x * apply_dact(zv.x, act), gv.y * apply_dact(zv.y, act), gv.z * apply_dact(zv.z, act),
+                            gv.w * apply_dact(zv.w, act)));
+    }
+}
+extern "C" int fabind_gather_dact(const float* dout, int ldo, const int* row, const void* Z, int z_dt, int act, void* dZ,
+                                  int dz_dt, int E, int H, hipStream_t stream) {
+    if (E <= 0) return 0;
+    hipLaunchKernelGGL(gather_dact_kernel, dim3((E + 3) / 4), dim3(256), 0, stream, dout, ldo, row, Z, z_dt, act, dZ,
+                       dz_dt, E, H);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adjoint of coord_update (one wave per row): t = sum_e d_e s_e / den; x_out = x + clamp(t)
+//   g = dxo * [|t| <= clampv];  dd_e = g s_e / den;  ds_e = (g . d_e) / den
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void coord_update_bwd_kernel(const float* d, const float* s, const int* rowptr,
+                                                               int n_rows, int mean, float clampv, const float* dxo,
+                                                               float* dd, float* ds) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int e = e0 + lane; e < e1; e += 64) {
+        const float sv = s[e];
+        ax += d[(size_t)e * 3] * sv; ay += d[(size_t)e * 3 + 1] * sv; az += d[(size_t)e * 3 + 2] * sv;
+    }
+    ax = wave_sum(ax); ay = wave_sum(ay); az = wave_sum(az);
+    const int deg = e1 - e0;
+    const float den = mean ? (float)(deg < 1 ? 1 : deg) : 1.f;
+    const float gx = (fabsf(ax / den) <= clampv ? dxo[(size_t)r * 3] : 0.f) / den;
+    const float gy = (fabsf(ay / den) <= clampv ? dxo[(size_t)r * 3 + 1] : 0.f) / den;
+    const float gz = (fabsf(az / den) <= clampv ? dxo[(size_t)r * 3 + 2] : 0.f) / den;
+    for (int e = e0 + lane; e < e1; e += 64) {
+        const float sv = s[e];
+        dd[(size_t)e * 3] = gx * sv; dd[(size_t)e * 3 + 1] = gy * sv; dd[(size_t)e * 3 + 2] = gz * sv;
+        ds[e] = gx * d[(size_t)e * 3] + gy * d[(size_t)e * 3 + 1] + gz * d[(size_t)e * 3 + 2];
+    }
+}
+extern "C" int fabind_coord_update_bwd(const float* d, const float* s, const int* rowptr, int n_rows, int mean,
+                                       float clampv, const float* dxo, float* dd, float* ds, hipStream_t stream) {
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(coord_update_bwd_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, d, s, rowptr, n_rows, mean,
+                       clampv, dxo, dd, ds);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// cross attention backward.  Pass Q (thread = query x head): dq, dgpre, dbias(lin,gate), and the per-query
+// helpers dO = dout*sigmoid(gpre) and D = dout.out for pass KV.  Pass KV (thread = key x head): dk, dv.
+// Probabilities are recomputed from the saved log-sum-exp.
+// ------------------------------------------------------------------------------------------------
+#define CB_KT 32
+__global__ __launch_bounds__(256) void cross_attn_bwd_q_kernel(const float* __restrict__ qg, int ldq,
+                                                               const float* __restrict__ kv, int ldkv,
+                                                               const float* __restrict__ bias, int bias_ld, int lin_col,
+                                                               int gate_col, const int* desc, float scale,
+                                                               const float* __restrict__ out, const float* lse,
+                                                               const float* __restrict__ dout, float* dqg, float* dbias,
+                                                               float* dO, float* Dv) {
+    __shared__ __attribute__((aligned(16))) float sK[CB_KT * 128];
+    __shared__ __attribute__((aligned(16))) float sV[CB_KT * 128];
+    const int* ds = desc + blockIdx.y * 8;
+    const int q_off = ds[0], nq = ds[1], k_off = ds[2], nk = ds[3];
+    const long pair_off = (long)(unsigned)ds[4] | ((long)ds[5] << 32);
+    const int sq = ds[6], sk = ds[7];
+    if ((int)(blockIdx.x * 64) >= nq) return;
+    const int tid = threadIdx.x, ql = tid >> 2, h = tid & 3;
+    const int qi = blockIdx.x * 64 + ql;
+    const bool valid = qi < nq;
+    float qr[32], dor[32], dq[32];
+    float D = 0.f, L = 0.f;
+#pragma unroll
+    for (int dd_ = 0; dd_ < 32; ++dd_) { qr[dd_] = 0.f; dor[dd_] = 0.f; dq[dd_] = 0.f; }
+    if (valid) {
+        const size_t ro = (size_t)(q_off + qi);
+        const float* qp = qg + ro * ldq + h * 32;
+        const float* gp = qg + ro * ldq + 128 + h * 32;
+        const float* op = out + ro * 128 + h * 32;
+        const float* dp = dout + ro * 128 + h * 32;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {
+            qr[c] = qp[c] * scale;
+            const float sg = sigmoid_f(gp[c]);
+            dor[c] = dp[c] * sg;
+            D += dp[c] * op[c];
+            dqg[ro * ldq + 128 + h * 32 + c] = dp[c] * op[c] * (1.f - sg);   // d gpre
+            dO[ro * 128 + h * 32 + c] = dor[c];
+        }
+        L = lse[ro * 4 + h];
+        Dv[ro * 4 + h] = D;
+    }
+    for (int j0 = 0; j0 < nk; j0 += CB_KT) {
+        __syncthreads();
+        for (int i = tid; i < CB_KT * 32; i += 256) {
+            int jr = i >> 5, c4 = (i & 31) * 4;
+            float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
+            if (j0 + jr < nk) {
+                kk = *(const float4*)(kv + (size_t)(k_off + j0 + jr) * ldkv + c4);
+                vv = *(const float4*)(kv + (size_t)(k_off + j0 + jr) * ldkv + 128 + c4);
+            }
+            *(float4*)(&sK[jr * 128 + c4]) = kk;
+            *(float4*)(&sV[jr * 128 + c4]) = vv;
+        }
+        __syncthreads();
+        if (!valid) continue;
+        const int jn = min(CB_KT, nk - j0);
+        for (int j = 0; j < jn; ++j) {
+            const float* kp = &sK[j * 128 + h * 32];
+            const float* vp = &sV[j * 128 + h * 32];
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) { s += qr[c] * kp[c]; dp += dor[c] * vp[c]; }
+            const size_t bi = (size_t)(pair_off + (long)qi * sq + (long)(j0 + j) * sk) * bias_ld;
+            const float lin = bias[bi + lin_col + h], gate = bias[bi + gate_col + h];
+            const float sg = sigmoid_f(gate);
+            s += lin * sg;
+            const float p = __expf(s - L);
+            const float dsj = p * (dp - D);
+            dbias[bi + lin_col + h] = dsj * sg;
+            dbias[bi + gate_col + h] = dsj * lin * sg * (1.f - sg);
+#pragma unroll
+            for (int c = 0; c < 32; ++c) dq[c] += dsj * kp[c];
+        }
+    }
+    if (!valid) return;
+    float* dqp = dqg + (size_t)(q_off + qi) * ldq + h * 32;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) dqp[c] = dq[c] * scale;
+}
+
+__global__ __launch_bounds__(256) void cross_attn_bwd_kv_kernel(const float* __restrict__ qg, int ldq,
+                                                                const float* __restrict__ kv, int ldkv,
+                                                                const float* __restrict__ bias, int bias_ld, int lin_col,
+                                                                int gate_col, const int* desc, float scale,
+                                                                const float* lse, const float* __restrict__ dO,
+                                                                const float* Dv, float* dkv) {
+    __shared__ __attribute__((aligned(16))) float sQ[CB_KT * 128];
+    __shared__ __attribute__((aligned(16))) float sDO[CB_KT * 128];
+    __shared__ float sL[CB_KT * 4], sD[CB_KT * 4];
+    const int* ds = desc + blockIdx.y * 8;
+    const int q_off = ds[0], nq = ds[1], k_off = ds[2], nk = ds[3];
+    const long pair_off = (long)(unsigned)ds[4] | ((long)ds[5] << 32);
+    const int sq = ds[6], sk = ds[7];
+    if ((int)(blockIdx.x * 64) >= nk) return;
+    const int tid = threadIdx.x, kl = tid >> 2, h = tid & 3;
+    const int kj = blockIdx.x * 64 + kl;
+    const bool valid = kj < nk;
+    float kr[32], vr[32], dk[32], dv[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { kr[c] = 0.f; vr[c] = 0.f; dk[c] = 0.f; dv[c] = 0.f; }
+    if (valid) {
+        const float* kp = kv + (size_t)(k_off + kj) * ldkv + h * 32;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) { kr[c] = kp[c]; vr[c] = kp[128 + c]; }
+    }
+    for (int i0 = 0; i0 < nq; i0 += CB_KT) {
+        __syncthreads();
+        for (int i = tid; i < CB_KT * 32; i += 256) {
+            int ir = i >> 5, c4 = (i & 31) * 4;
+            float4 qq = make_float4(0.f, 0.f, 0.f, 0.f), dd_ = qq;
+            if (i0 + ir < nq) {
+                qq = *(const float4*)(qg + (size_t)(q_off + i0 + ir) * ldq + c4);
+                dd_ = *(const float4*)(dO + (size_t)(q_off + i0 + ir) * 128 + c4);
+            }
+            *(float4*)(&sQ[ir * 128 + c4]) = qq;
+            *(float4*)(&sDO[ir * 128 + c4]) = dd_;
+        }
+        if (tid < CB_KT * 4) {
+            int ir = tid >> 2;
+            sL[tid] = (i0 + ir < nq) ? lse[(size_t)(q_off + i0 + ir) * 4 + (tid & 3)] : 0.f;
+            sD[tid] = (i0 + ir < nq) ? Dv[(size_t)(q_off + i0 + ir) * 4 + (tid & 3)] : 0.f;
+        }
+        __syncthreads();
+        if (!valid) continue;
+        const int in_ = min(CB_KT, nq - i0);
+        for (int i = 0; i < in_; ++i) {
+            const float* qp = &sQ[i * 128 + h * 32];
+            const float* dp_ = &sDO[i * 128 + h * 32];
+            float s = 0.f, dp = 0.f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) { s += qp[c] * kr[c]; dp += dp_[c] * vr[c]; }
+            s *= scale;
+            const size_t bi = (size_t)(pair_off + (long)(i0 + i) * sq + (long)kj * sk) * bias_ld;
+            s += bias[bi + lin_col + h] * sigmoid_f(bias[bi + gate_col + h]);
+            const float p = __expf(s - sL[i * 4 + h]);
+            const float dsj = p * (dp - sD[i * 4 + h]) * scale;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) { dk[c] += dsj * qp[c]; dv[c] += p * dp_[c]; }
+        }
+    }
+    if (!valid) return;
+    float* o = dkv + (size_t)(k_off + kj) * ldkv + h * 32;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { o[c] = dk[c]; o[128 + c] = dv[c]; }
+}
+
+extern "C" int fabind_cross_attn_bwd(const float* qg, int ldq, const float* kv, int ldkv, const float* bias, int bias_ld,
+                                     int lin_col, int gate_col, const int* desc, int B, int max_nq, int max_nk,
+                                     float scale, const float* out, const float* lse, const float* dout, float* dqg,
+                                     float* dkv, float* dbias, float* dO, float* Dv, hipStream_t stream) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(cross_attn_bwd_q_kernel, dim3((max_nq + 63) / 64, B), dim3(256), 0, stream, qg, ldq, kv, ldkv, bias,
+                       bias_ld, lin_col, gate_col, desc, scale, out, lse, dout, dqg, dbias, dO, Dv);
+    hipLaunchKernelGGL(cross_attn_bwd_kv_kernel, dim3((max_nk + 63) / 64, B), dim3(256), 0, stream, qg, ldq, kv, ldkv,
+                       bias, bias_ld, lin_col, gate_col, desc, scale, lse, dO, Dv, dkv);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adjoint of pair_hadamard: hd[e, 0:H] = a0[p]*b0[c], hd[e, H:H+H2] = a1[p]*b1[c]
+// (float atomics: every node collects the few pairs it belongs to)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_hadamard_bwd_kernel(const void* dhd, int dt, int ldh, const float* a0,
+                                                                const float* b0, int ld0, int H, const float* a1,
+                                                                const float* b1, int ld1, int H2, const int* red_p,
+                                                                const int* red_c, int n, float* da0, float* db0,
+                                                                int ldd0, float* da1, float* db1, int ldd1) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= n) return;
+    const int pn = red_p[e], cn = red_c[e];
+    for (int c = lane; c < H; c += 64) {
+        const float g = ld_any(dhd, dt, (size_t)e * ldh + c);
+        atomicAdd(&da0[(size_t)pn * ldd0 + c], g * b0[(size_t)cn * ld0 + c]);
+        atomicAdd(&db0[(size_t)cn * ldd0 + c], g * a0[(size_t)pn * ld0 + c]);
+    }
+    for (int c = lane; c < H2; c += 64) {
+        const float g = ld_any(dhd, dt, (size_t)e * ldh + H + c);
+        atomicAdd(&da1[(size_t)pn * ldd1 + c], g * b1[(size_t)cn * ld1 + c]);
+        atomicAdd(&db1[(size_t)cn * ldd1 + c], g * a1[(size_t)pn * ld1 + c]);
+    }
+}
+extern "C" int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const float* a0, const float* b0, int ld0,
+                                        int H, const float* a1, const float* b1, int ld1, int H2, const int* red_p,
+                                        const int* red_c, int n, float* da0, float* db0, int ldd0, float* da1,
+                                        float* db1, int ldd1, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(pair_hadamard_bwd_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, dhd, dt, ldh, a0, b0, ld0, H, a1,
+                       b1, ld1, H2, red_p, red_c, n, da0, db0, ldd0, da1, db1, ldd1);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// inter-graph attention backward.
+// Pass A (waves stride over rows): softmax adjoint per row -> dlogit[e], dcp[e], dd[e], drh[e], dq[r],
+//   per-block partials of dw_rk, dw_rv, dwcr, dw3.
+// Pass B (one wave per node n): the inter graph is symmetric, so "scatter by sending node" is a gather
+//   over the node's own row through mirror[]: dk[n], dv[n], dcv[n]; dbias_red[pair] = dlogit[e]+dlogit[mirror].
+// ------------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(256) void inter_attn_bwd_a_kernel(
+    const float* __restrict__ qkv, int ldqkv, const float* __restrict__ cv, int ldcv, int H, const float* __restrict__ d,
+    const float* __restrict__ rhohat, const int* rowptr, const int* col, const float* __restrict__ w_rk,
+    const float* __restrict__ w_rv, const float* __restrict__ wcr, const float* __restrict__ w3, const float* alpha,
+    const float* cvs, float clampv, int n_rows, const float* __restrict__ dh_out, const float* __restrict__ dx_out,
+    float* dqkv, float* dd, float* drh, float* dlogit, float* dcp, float* wpart) {
+    extern __shared__ float4 shp[];   // [4 quantities][4 waves][NS*64] float4
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 a_wrk[NS], a_wrv[NS], a_wcr[NS], a_w3[NS], wk[NS], wvv[NS], wc[NS], w3v[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int c = s * 256 + lane * 4;
+        a_wrk[s] = z4; a_wrv[s] = z4; a_wcr[s] = z4; a_w3[s] = z4; wk[s] = z4; wvv[s] = z4; wc[s] = z4; w3v[s] = z4;
+        if (c < H) {
+            wk[s] = *(const float4*)(w_rk + c); wvv[s] = *(const float4*)(w_rv + c);
+            wc[s] = *(const float4*)(wcr + c); w3v[s] = *(const float4*)(w3 + c);
+        }
+    }
+    for (int r = blockIdx.x * 4 + wv; r < n_rows; r += gridDim.x * 4) {
+        const int e0 = rowptr[r], e1 = rowptr[r + 1];
+        if (e1 == e0) continue;
+        float4 qv[NS], gh[NS], dq[NS];
+        float qw = 0.f, gwv = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = s * 256 + lane * 4;
+            qv[s] = z4; gh[s] = z4; dq[s] = z4;
+            if (c < H) {
+                qv[s] = *(const float4*)(qkv + (size_t)r * ldqkv + c);
+                gh[s] = *(const float4*)(dh_out + (size_t)r * H + c);
+                qw += qv[s].x * wk[s].x + qv[s].y * wk[s].y + qv[s].z * wk[s].z + qv[s].w * wk[s].w;
+                gwv += gh[s].x * wvv[s].x + gh[s].y * wvv[s].y + gh[s].z * wvv[s].z + gh[s].w * wvv[s].w;
+            }
+        }
+        qw = wave_sum(qw); gwv = wave_sum(gwv);
+        // recompute t_r for the clamp mask
+        float tx = 0.f, ty = 0.f, tz = 0.f;
+        for (int e = e0 + lane; e < e1; e += 64) {
+            const float w = alpha[e] * cvs[e];
+            tx += w * d[(size_t)e * 3]; ty += w * d[(size_t)e * 3 + 1]; tz += w * d[(size_t)e * 3 + 2];
+        }
+        tx = wave_sum(tx); ty = wave_sum(ty); tz = wave_sum(tz);
+        const float gx = fabsf(tx) <= clampv ? dx_out[(size_t)r * 3] : 0.f;
+        const float gy = fabsf(ty) <= clampv ? dx_out[(size_t)r * 3 + 1] : 0.f;
+        const float gz = fabsf(tz) <= clampv ? dx_out[(size_t)r * 3 + 2] : 0.f;
+        // pass 1: dalpha_e, stored in dlogit[]; S = sum alpha dalpha
+        float S = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            const int cn = col[e];
+            const float rh = rhohat[e];
+            float hp = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int c = s * 256 + lane * 4;
+                if (c < H) {
+                    const float4 vv = *(const float4*)(qkv + (size_t)cn * ldqkv + 2 * H + c);
+                    hp += gh[s].x * vv.x + gh[s].y * vv.y + gh[s].z * vv.z + gh[s].w * vv.w;
+                }
+            }
+            hp = wave_sum(hp) + rh * gwv;
+            const float gd = gx * d[(size_t)e * 3] + gy * d[(size_t)e * 3 + 1] + gz * d[(size_t)e * 3 + 2];
+            const float da = hp + cvs[e] * gd;
+            S += alpha[e] * da;
+            if (lane == 0) dlogit[e] = da;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // pass 2
+        float s_lrh = 0.f, s_arh = 0.f;
+        for (int e = e0; e < e1; ++e) {
+            const int cn = col[e];
+            const float rh = rhohat[e], al = alpha[e];
+            const float dl = al * (dlogit[e] - S);
+            const float gd = gx * d[(size_t)e * 3] + gy * d[(size_t)e * 3 + 1] + gz * d[(size_t)e * 3 + 2];
+            const float dc = al * gd;
+            float dsum = 0.f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int c = s * 256 + lane * 4;
+                if (c < H) {
+                    const float4 kk = *(const float4*)(qkv + (size_t)cn * ldqkv + H + c);
+                    const float4 cc = *(const float4*)(cv + (size_t)cn * ldcv + c);
+                    dq[s].x += dl * (kk.x + rh * wk[s].x); dq[s].y += dl * (kk.y + rh * wk[s].y);
+                    dq[s].z += dl * (kk.z + rh * wk[s].z); dq[s].w += dl * (kk.w + rh * wk[s].w);
+                    const float ux = cc.x + rh * wc[s].x, uy = cc.y + rh * wc[s].y, uz = cc.z + rh * wc[s].z, uw = cc.w + rh * wc[s].w;
+                    const float px = w3v[s].x * dsilu_f(ux), py = w3v[s].y * dsilu_f(uy), pz = w3v[s].z * dsilu_f(uz), pw = w3v[s].w * dsilu_f(uw);
+                    dsum += px * wc[s].x + py * wc[s].y + pz * wc[s].z + pw * wc[s].w;
+                    a_wcr[s].x += dc * rh * px; a_wcr[s].y += dc * rh * py; a_wcr[s].z += dc * rh * pz; a_wcr[s].w += dc * rh * pw;
+                    a_w3[s].x += dc * silu_f(ux); a_w3[s].y += dc * silu_f(uy); a_w3[s].z += dc * silu_f(uz); a_w3[s].w += dc * silu_f(uw);
+                }
+            }
+            dsum = wave_sum(dsum);
+            s_lrh += dl * rh; s_arh += al * rh;
+            if (lane == 0) {
+                dlogit[e] = dl;
+                dcp[e] = dc;
+                drh[e] = dl * qw + al * gwv + dc * dsum;
+                const float w = al * cvs[e];
+                dd[(size_t)e * 3] = w * gx; dd[(size_t)e * 3 + 1] = w * gy; dd[(size_t)e * 3 + 2] = w * gz;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = s * 256 + lane * 4;
+            if (c < H) {
+                *(float4*)(dqkv + (size_t)r * ldqkv + c) = dq[s];
+                a_wrk[s].x += s_lrh * qv[s].x; a_wrk[s].y += s_lrh * qv[s].y; a_wrk[s].z += s_lrh * qv[s].z; a_wrk[s].w += s_lrh * qv[s].w;
+                a_wrv[s].x += s_arh * gh[s].x; a_wrv[s].y += s_arh * gh[s].y; a_wrv[s].z += s_arh * gh[s].z; a_wrv[s].w += s_arh * gh[s].w;
+            }
+        }
+    }
+    // block partials of the four vector gradients: [4][gridDim.x][H]
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        shp[(0 * 4 + wv) * NS * 64 + s * 64 + lane] = a_wrk[s];
+        shp[(1 * 4 + wv) * NS * 64 + s * 64 + lane] = a_wrv[s];
+        shp[(2 * 4 + wv) * NS * 64 + s * 64 + lane] = a_wcr[s];
+        shp[(3 * 4 + wv) * NS * 64 + s * 64 + lane] = a_w3[s];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 4 * NS * 64; idx += 256) {
+        const int qn = idx / (NS * 64), rem = idx % (NS * 64);
+        const int c = (rem / 64) * 256 + (rem % 64) * 4;
+        if (c >= H) continue;
+        float4 t = shp[(qn * 4 + 0) * NS * 64 + rem];
+#pragma unroll
+        for (int w2 = 1; w2 < 4; ++w2) {
+            const float4 o = shp[(qn * 4 + w2) * NS * 64 + rem];
+            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        *(float4*)(wpart + ((size_t)qn * gridDim.x + blockIdx.x) * H + c) = t;
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void inter_attn_bwd_b_kernel(
+    const float* __restrict__ qkv, int ldqkv, const float* __restrict__ cv, int ldcv, int H, const float* rhohat,
+    const int* rowptr, const int* col, const int* mirror, const int* red_idx, const float* __restrict__ wcr,
+    const float* __restrict__ w3, const float* alpha, const float* dlogit, const float* dcp, int n_rows, int n_lig_flag,
+    const float* __restrict__ dh_out, float* dqkv, float* dcv, float* dbias_red, const int* node_is_lig) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_rows) return;
+    const int e0 = rowptr[n], e1 = rowptr[n + 1];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 dk[NS], dv[NS], dc[NS], cvn[NS], wc[NS], w3v[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int c = s * 256 + lane * 4;
+        dk[s] = z4; dv[s] = z4; dc[s] = z4; cvn[s] = z4; wc[s] = z4; w3v[s] = z4;
+        if (c < H) {
+            cvn[s] = *(const float4*)(cv + (size_t)n * ldcv + c);
+            wc[s] = *(const float4*)(wcr + c); w3v[s] = *(const float4*)(w3 + c);
+        }
+    }
+    for (int e = e0; e < e1; ++e) {
+        const int m = col[e], me = mirror[e];          // edge me = (m <- n)
+        const float dl = dlogit[me], al = alpha[me], dcm = dcp[me], rh = rhohat[me];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = s * 256 + lane * 4;
+            if (c < H) {
+                const float4 qm = *(const float4*)(qkv + (size_t)m * ldqkv + c);
+                const float4 gm = *(const float4*)(dh_out + (size_t)m * H + c);
+                dk[s].x += dl * qm.x; dk[s].y += dl * qm.y; dk[s].z += dl * qm.z; dk[s].w += dl * qm.w;
+                dv[s].x += al * gm.x; dv[s].y += al * gm.y; dv[s].z += al * gm.z; dv[s].w += al * gm.w;
+                dc[s].x += dcm * w3v[s].x * dsilu_f(cvn[s].x + rh * wc[s].x);
+                dc[s].y += dcm * w3v[s].y * dsilu_f(cvn[s].y + rh * wc[s].y);
+                dc[s].z += dcm * w3v[s].z * dsilu_f(cvn[s].z + rh * wc[s].z);
+                dc[s].w += dcm * w3v[s].w * dsilu_f(cvn[s].w + rh * wc[s].w);
+            }
+        }
+        if (lane == 0 && n < m) dbias_red[red_idx[e]] = dlogit[e] + dl;   // ligand rows precede their proteins
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int c = s * 256 + lane * 4;
+        if (c < H) {
+            *(float4*)(dqkv + (size_t)n * ldqkv + H + c) = dk[s];
+            *(float4*)(dqkv + (size_t)n * ldqkv + 2 * H + c) = dv[s];
+            *(float4*)(dcv + (size_t)n * ldcv + c) = dc[s];
+        }
+    }
+}
+
+extern "C" int fabind_inter_attn_bwd(const float* qkv, int ldqkv, const float* cv, int ldcv, int H, const float* d,
+                                     const float* rhohat, const int* rowptr, const int* col, const int* mirror,
+                                     const int* red_idx, const float* w_rk, const float* w_rv, const float* wcr,
+                                     const float* w3, const float* alpha, const float* cvs, float clampv, int n_rows,
+                                     const float* dh_out, const float* dx_out, float* dqkv, float* dcv, float* dd,
+                                     float* drh, float* dbias_red, float* dlogit, float* dcp, float* wpart, int nblk,
+                                     hipStream_t stream) {
+    if (n_rows <= 0) return 0;
+    FB_REQUIRE(H % 4 == 0 && H <= 1024, "fabind_inter_attn_bwd: H % 4, H <= 1024");
+    dim3 gb((n_rows + 3) / 4);
+#define LA(NS) do {                                                                                                    \
+        size_t lds = (size_t)16 * NS * 64 * sizeof(float4);                                                            \
+        hipLaunchKernelGGL((inter_attn_bwd_a_kernel<NS>), dim3(nblk), dim3(256), lds, stream, qkv, ldqkv, cv, ldcv, H, d, \
+                           rhohat, rowptr, col, w_rk, w_rv, wcr, w3, alpha, cvs, clampv, n_rows, dh_out, dx_out, dqkv, dd, \
+                           drh, dlogit, dcp, wpart);                                                                    \
+        hipLaunchKernelGGL((inter_attn_bwd_b_kernel<NS>), gb, dim3(256), 0, stream, qkv, ldqkv, cv, ldcv, H, rhohat, rowptr, \
+                           col, mirror, red_idx, wcr, w3, alpha, dlogit, dcp, n_rows, 0, dh_out, dqkv, dcv, dbias_red,   \
+                           (const int*)nullptr);                                                                        \
+    } while (0)
+    if (H <= 256) LA(1); else if (H <= 512) LA(2); else LA(4);
+#undef LA
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LAS step backward: x_out_j = x_j + clamp(step F_j), F_j = sum_{(i,j)} 4(|d|^2 - |d0|^2) d, d = x_i - x_j
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void las_step_bwd_kernel(const float* __restrict__ x, const float* __restrict__ x0,
+                                                           const float* __restrict__ xo, const int* las_i,
+                                                           const int* las_j, const int* las_off, const int* node_off,
+                                                           const int* c_cnt, float step, float clampv,
+                                                           const float* __restrict__ dout, float* dx) {
+    const int b = blockIdx.y;
+    const int off = node_off[b], n = node_off[b + 1] - off, C = c_cnt[b];
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n) return;
+    const int gu = off + u;
+    float ax = dout[(size_t)gu * 3], ay = dout[(size_t)gu * 3 + 1], az = dout[(size_t)gu * 3 + 2];
+    if (u >= 1 && u < C) {
+        for (int e = las_off[b]; e < las_off[b + 1]; ++e) {
+            const int i = las_i[e], j = las_j[e];
+            if (i != gu && j != gu) continue;
+            // dF_j = step * dout_j * [clamp inactive]
+            float gF[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float delta = xo[(size_t)j * 3 + k] - x[(size_t)j * 3 + k];
+                gF[k] = fabsf(delta) < clampv ? step * dout[(size_t)j * 3 + k] : 0.f;
+            }
+            const float dx_ = x[i * 3] - x[j * 3], dy_ = x[i * 3 + 1] - x[j * 3 + 1], dz_ = x[i * 3 + 2] - x[j * 3 + 2];
+            const float ex = x0[i * 3] - x0[j * 3], ey = x0[i * 3 + 1] - x0[j * 3 + 1], ez = x0[i * 3 + 2] - x0[j * 3 + 2];
+            const float diff = (dx_ * dx_ + dy_ * dy_ + dz_ * dz_) - (ex * ex + ey * ey + ez * ez);
+            const float dg = dx_ * gF[0] + dy_ * gF[1] + dz_ * gF[2];
+            const float vx = 4.f * (diff * gF[0] + 2.f * dx_ * dg), vy = 4.f * (diff * gF[1] + 2.f * dy_ * dg),
+                        vz = 4.f * (diff * gF[2] + 2.f * dz_ * dg);
+            if (i == gu) { ax += vx; ay += vy; az += vz; }
+            if (j == gu) { ax -= vx; ay -= vy; az -= vz; }
+        }
+    }
+    dx[(size_t)gu * 3] = ax; dx[(size_t)gu * 3 + 1] = ay; dx[(size_t)gu * 3 + 2] = az;
+}
+extern "C" int fabind_las_step_bwd(const float* x, const float* x0, const float* xo, const int* las_i, const int* las_j,
+                                   const int* las_off, const int* node_off, const int* c_cnt, int B, int max_n,
+                                   float step, float clampv, const float* dout, float* dx, hipStream_t stream) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(las_step_bwd_kernel, dim3((max_n + 255) / 256, B), dim3(256), 0, stream, x, x0, xo, las_i, las_j,
+                       las_off, node_off, c_cnt, step, clampv, dout, dx);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// pair-bias backward (one attention block): out[(b,i,j), o] = sum_h a0[i,h] b0[j,h] w[o,h]
+//   kernel A: da0[i,h] += sum_{j,o} D[i,j,o] w[o,h] b0[j,h]          (block = 8 protein rows, threads over h)
+//   kernel B: T[o] = sum_i D[i,j,o] a0[i,h];  db0[j,h] += sum_o w[o,h] T[o];  dw[b][o,h] += b0[j,h] T[o]
+// a0 = a0b0[:, 0:H] at protein-side nodes, b0 = a0b0[:, H:2H] at ligand-side nodes. NO == 8.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_bias_bwd_a_kernel(const float* __restrict__ dout, const float* __restrict__ ab,
+                                                              int ld, int H, const float* __restrict__ w, const int* desc,
+                                                              const int* p_index, const int* c_index, float* dab) {
+    const int* ds = desc + blockIdx.y * 8;
+    const int p_off = ds[0], P = ds[1], c_off = ds[2], C = ds[3];
+    const long pair_off = (long)(unsigned)ds[4] | ((long)ds[5] << 32);
+    const int i0 = blockIdx.x * 8;
+    if (i0 >= P) return;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        float wv[8], acc[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) { wv[o] = w[o * H + h]; acc[o] = 0.f; }
+        for (int j = 0; j < C; ++j) {
+            const float bj = ab[(size_t)c_index[c_off + j] * ld + H + h];
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+                if (i0 + ii >= P) break;
+                const float* Dp = dout + ((size_t)pair_off + (size_t)(i0 + ii) * C + j) * 8;
+                float t = 0.f;
+#pragma unroll
+                for (int o = 0; o < 8; ++o) t += Dp[o] * wv[o];
+                acc[ii] += t * bj;
+            }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii)
+            if (i0 + ii < P) dab[(size_t)p_index[p_off + i0 + ii] * ld + h] += acc[ii];
+    }
+}
+__global__ __launch_bounds__(256) void pair_bias_bwd_b_kernel(const float* __restrict__ dout, const float* __restrict__ ab,
+                                                              int ld, int H, const float* __restrict__ w, const int* desc,
+                                                              const int* p_index, const int* c_index, float* dab,
+                                                              float* dwk) {
+    const int b = blockIdx.y;
+    const int* ds = desc + b * 8;
+    const int p_off = ds[0], P = ds[1], c_off = ds[2], C = ds[3];
+    const long pair_off = (long)(unsigned)ds[4] | ((long)ds[5] << 32);
+    const int j = blockIdx.x;
+    if (j >= C) return;
+    const int cn = c_index[c_off + j];
+    for (int h = threadIdx.x; h < H; h += 256) {
+        float T[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) T[o] = 0.f;
+        for (int i = 0; i < P; ++i) {
+            const float ai = ab[(size_t)p_index[p_off + i] * ld + h];
+            const float* Dp = dout + ((size_t)pair_off + (size_t)i * C + j) * 8;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) T[o] += Dp[o] * ai;
+        }
+        const float bj = ab[(size_t)cn * ld + H + h];
+        float db = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            db += w[o * H + h] * T[o];
+            atomicAdd(&dwk[((size_t)b * 8 + o) * H + h], bj * T[o]);   // C adds per element (order-insensitive to rounding)
+        }
+        dab[(size_t)cn * ld + H + h] += db;
+    }
+}
+extern "C" int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, int ld, int H, const float* w,
+                                    const int* desc_p, int B, int max_P, int max_C, const int* p_index,
+                                    const int* c_index, float* dab, float* dwk, hipStream_t stream) {
+    FB_REQUIRE(NO == 8, "fabind_pair_bias_bwd: NO must be 8");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(pair_bias_bwd_a_kernel, dim3((max_P + 7) / 8, B), dim3(256), 0, stream, dout, ab, ld, H, w, desc_p,
+                       p_index, c_index, dab);
+    hipLaunchKernelGGL(pair_bias_bwd_b_kernel, dim3(max_C, B), dim3(256), 0, stream, dout, ab, ld, H, w, desc_p, p_index,
+                       c_index, dab, dwk);
+    FB_CHECK_LAUNCH();
+    return 0;
+}

@@ -37,14 +37,16 @@ extern "C" int fabind_gcl_pre(const float* AB, int ldab, int H, const int* row, 
 // per 256-column slab; partials are combined through LDS in fixed wave order (bit-reproducible).
 template <int NSLAB>
 __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict__ Z, int z_dt, int ldz, int H,
-                                                          const int* rowptr, int act, float* out, int ldo) {
+                                                          const int* rowptr, const int* eidx, int act, float* out,
+                                                          int ldo) {
     __shared__ float4 part[3][NSLAB * 64];
     const int r = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
     float4 acc[NSLAB];
 #pragma unroll
     for (int s = 0; s < NSLAB; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int e = e0 + w; e < e1; e += 4) {
+    for (int ee = e0 + w; ee < e1; ee += 4) {
+        const int e = eidx ? eidx[ee] : ee;
 #pragma unroll
         for (int s = 0; s < NSLAB; ++s) {
             int c = s * 256 + lane * 4;
@@ -77,17 +79,17 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict
     }
 }
 
-extern "C" int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, int n_rows, int act,
-                                  float* out, int ldo, hipStream_t stream) {
+extern "C" int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, const int* eidx,
+                                  int n_rows, int act, float* out, int ldo, hipStream_t stream) {
     FB_REQUIRE(H % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0, "fabind_segment_sum: H/ldz/ldo must be multiples of 4");
     FB_REQUIRE(H <= 1024, "fabind_segment_sum: H <= 1024");
     if (n_rows <= 0) return 0;
     if (H <= 256)
-        hipLaunchKernelGGL((segment_sum_kernel<1>), dim3(n_rows), dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, act, out, ldo);
+        hipLaunchKernelGGL((segment_sum_kernel<1>), dim3(n_rows), dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo);
     else if (H <= 512)
-        hipLaunchKernelGGL((segment_sum_kernel<2>), dim3(n_rows), dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, act, out, ldo);
+        hipLaunchKernelGGL((segment_sum_kernel<2>), dim3(n_rows), dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo);
     else
-        hipLaunchKernelGGL((segment_sum_kernel<4>), dim3(n_rows), dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, act, out, ldo);
+        hipLaunchKernelGGL((segment_sum_kernel<4>), dim3(n_rows), dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo);
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -146,7 +146,7 @@ __global__ void red_off_kernel(const int* node_off, const int* c_cnt, int B, con
 
 __global__ void inter_meta_kernel(const int* node_off, const int* c_cnt, int B, const int* rowptr_int,
                                   const int* col_int, const int* row_int, int E, const int* red_off, int* red_idx,
-                                  int* red_c, int* red_p) {
+                                  int* red_c, int* red_p, int* mirror) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E) return;
     int r = row_int[e], c = col_int[e];
@@ -162,16 +162,18 @@ __global__ void inter_meta_kernel(const int* node_off, const int* c_cnt, int B, 
         int s = rowptr_int[c], t = rowptr_int[c + 1];
         while (t - s > 1) { int mid = (s + t) >> 1; if (col_int[mid] <= r) s = mid; else t = mid; }
         red_idx[e] = red_off[b] + (s - base);
+        mirror[e] = s;
+        mirror[s] = e;
     }
 }
 
 extern "C" int fabind_inter_meta(const int* node_off, const int* c_cnt, int B, const int* rowptr_int,
                                  const int* col_int, const int* row_int, int E_int, int* red_off, int* red_idx,
-                                 int* red_c, int* red_p, hipStream_t stream) {
+                                 int* red_c, int* red_p, int* mirror, hipStream_t stream) {
     hipLaunchKernelGGL(red_off_kernel, dim3(1), dim3(64), 0, stream, node_off, c_cnt, B, rowptr_int, red_off);
     if (E_int > 0)
         hipLaunchKernelGGL(inter_meta_kernel, dim3((E_int + 255) / 256), dim3(256), 0, stream, node_off, c_cnt, B,
-                           rowptr_int, col_int, row_int, E_int, red_off, red_idx, red_c, red_p);
+                           rowptr_int, col_int, row_int, E_int, red_off, red_idx, red_c, red_p, mirror);
     FB_CHECK_LAUNCH();
     return 0;
 }

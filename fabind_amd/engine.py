@@ -119,8 +119,20 @@ class Graph:
                 x, lay.node_off, lay.c_cnt, lay.B, lay.max_n, bond_row, bond_col, bond_off, cut_intra, cut_inter, rp_ctx,
                 rp_int, E_ctx, E_int)
         self.rp_ctx, self.rp_int, self.E_ctx, self.E_int = rp_ctx, rp_int, E_ctx, E_int
-        self.red_off, self.red_idx, self.red_c, self.red_p = K.inter_meta(lay.node_off, lay.c_cnt, lay.B, rp_int,
-                                                                          self.col_int, self.row_int)
+        self.red_off, self.red_idx, self.red_c, self.red_p, self.mirror = K.inter_meta(
+            lay.node_off, lay.c_cnt, lay.B, rp_int, self.col_int, self.row_int)
+        self._ctx_bycol = None
+        self.N = lay.N
+
+    def ctx_by_col(self):
+        """(colptr, perm): ctx edges grouped by their SENDING node (for column-wise reductions in backward)."""
+        if self._ctx_bycol is None:
+            colsorted, perm = torch.sort(self.col_ctx.long(), stable=True)
+            cnt = torch.bincount(colsorted, minlength=self.N)
+            colptr = torch.zeros(self.N + 1, dtype=torch.int32, device=perm.device)
+            colptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
+            self._ctx_bycol = (colptr, perm.to(torch.int32).contiguous())
+        return self._ctx_bycol
 
 
 # ------------------------------------------------------------------------------------------------
@@ -222,13 +234,13 @@ def gcl_layer(p, h, x, lay, g, clampv):
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
     if ops.needs_grad(h, x, p["W2"]):
         # training form: keep pre-activations (the consumers apply SiLU while staging their operand)
-        pre = ops.gcl_pre(AB, H, g.row_ctx, g.col_ctx, rhohat, p["w_r"])                # [E,H]
+        pre = ops.gcl_pre(AB, H, g, rhohat, p["w_r"])                                   # [E,H]
         Z2 = ops.linear(pre, p["W2"], p["b2"], act_pro=K.ACT_SILU, out_dtype=ops.act_dtype())
         s = ops.linear_rowdot(Z2, p["Wc"], p["bc"], p["w3"], act_pro=K.ACT_SILU, act_epi=K.ACT_SILU)   # [E,nt]
         agg = ops.segment_sum(Z2, g.rp_ctx, g.row_ctx, h.shape[0], act=K.ACT_SILU)
     else:
         # forward-only form: producers apply SiLU once, the edge GEMMs stream bf16 operands HBM->LDS directly
-        S1 = ops.gcl_pre(AB, H, g.row_ctx, g.col_ctx, rhohat, p["w_r"], act=K.ACT_SILU)
+        S1 = ops.gcl_pre(AB, H, g, rhohat, p["w_r"], act=K.ACT_SILU)
         Mm = ops.linear(S1, p["W2"], p["b2"], act_epi=K.ACT_SILU, out_dtype=ops.act_dtype())
         s = ops.linear_rowdot(Mm, p["Wc"], p["bc"], p["w3"], act_epi=K.ACT_SILU)
         agg = ops.segment_sum(Mm, g.rp_ctx, g.row_ctx, h.shape[0], act=K.ACT_NONE)
@@ -252,12 +264,12 @@ def cross_attention(p, h, lay, pairbias, layer):
     bias_p, bias_c = pairbias[2 * layer], pairbias[2 * layer + 1]
     qg = ops.linear(c16(hp), p["Wqg_p"], p["bqg_p"])
     kv = ops.linear(c16(hc), p["Wkv_p"])
-    og = ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_p, lay.B, lay.max_P, scale)
+    og = ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_p, lay.B, lay.max_P, lay.max_C, scale)
     hp = ops.linear(c16(og), p["Wo_p"], p["bo_p"], residual=hp)
     hp16 = c16(hp)
     qg = ops.linear(c16(hc), p["Wqg_c"], p["bqg_c"])
     kv = ops.linear(hp16, p["Wkv_c"])
-    og = ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_c, lay.B, lay.max_C, scale)
+    og = ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_c, lay.B, lay.max_C, lay.max_P, scale)
     hc = ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc)
     t = ops.linear(hp16, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU, out_dtype=od)
     hp = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp)

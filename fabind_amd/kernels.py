@@ -125,9 +125,11 @@ def inter_meta(node_off, c_cnt, B, rowptr_int, col_int, row_int):
     n_red = E // 2
     red_c = torch.empty(max(n_red, 1), dtype=torch.int32, device=dev)
     red_p = torch.empty(max(n_red, 1), dtype=torch.int32, device=dev)
+    mirror = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     check(_lib.load().fabind_inter_meta(ptr(node_off), ptr(c_cnt), B, ptr(rowptr_int), ptr(col_int), ptr(row_int), E,
-                                        ptr(red_off), ptr(red_idx), ptr(red_c), ptr(red_p), stream()), "fabind_inter_meta")
-    return red_off, red_idx[:E], red_c[:n_red], red_p[:n_red]
+                                        ptr(red_off), ptr(red_idx), ptr(red_c), ptr(red_p), ptr(mirror), stream()),
+          "fabind_inter_meta")
+    return red_off, red_idx[:E], red_c[:n_red], red_p[:n_red], mirror[:E]
 
 
 def edge_geom(x, row, col, rowptr, node_off, B):
@@ -149,11 +151,12 @@ def gcl_pre(AB, H, row, col, rhohat, w_r, out_dtype, act=ACT_NONE):
     return pre
 
 
-def segment_sum(Z, rowptr, n_rows, act=ACT_NONE):
+def segment_sum(Z, rowptr, n_rows, act=ACT_NONE, eidx=None, out=None):
     H = Z.shape[1]
-    out = torch.empty((n_rows, H), dtype=torch.float32, device=Z.device)
-    check(_lib.load().fabind_segment_sum(ptr(Z), dt_code(Z.dtype), _ld(Z), H, ptr(rowptr), n_rows, act, ptr(out), H,
-                                         stream()), "fabind_segment_sum")
+    if out is None:
+        out = torch.empty((n_rows, H), dtype=torch.float32, device=Z.device)
+    check(_lib.load().fabind_segment_sum(ptr(Z), dt_code(Z.dtype), _ld(Z), H, ptr(rowptr), ptr(eidx), n_rows, act,
+                                         ptr(out), _ld(out), stream()), "fabind_segment_sum")
     return out
 
 

@@ -3,27 +3,38 @@
 Forward-only calls (torch.no_grad(), 7 of the 8 refinement iterations) go straight to the kernels;
 when a gradient is required the same kernels run inside torch.autograd.Function wrappers whose
 backward passes are HIP kernels as well (fabind_amd/csrc/bwd.hip + the GEMM family)."""
+import ctypes
+
 import torch
 
-from . import config as _engine
+from . import config as _cfg
 from . import kernels as K
+from ._lib import GemmArgs, check, dt_code, load, ptr, stream
 
 
 def act_dtype():
     """Storage type of the large edge-/pair-level intermediates."""
-    return torch.float32 if _engine.get_precision() == "fp32" else torch.bfloat16
+    return torch.float32 if _cfg.get_precision() == "fp32" else torch.bfloat16
 
 
 def mm_dtype():
-    return torch.float32 if _engine.get_precision() == "fp32" else torch.bfloat16
+    return torch.float32 if _cfg.get_precision() == "fp32" else torch.bfloat16
 
 
 def _needs_grad(*ts):
     return torch.is_grad_enabled() and any(torch.is_tensor(t) and t.requires_grad for t in ts)
 
 
+def needs_grad(*ts):
+    return _needs_grad(*ts)
+
+
 def _pad8(n):
-    return (n + 7) // 8 * 8
+    return (n + 63) // 64 * 64      # K of the weight-gradient GEMMs: multiple of 64 keeps them on the LDS-DMA path
+
+
+def _nchunk(rows):
+    return max(1, min(256, (rows + 1023) // 1024))
 
 
 def _transposed(x, act=K.ACT_NONE):
@@ -33,10 +44,19 @@ def _transposed(x, act=K.ACT_NONE):
     out = torch.empty((C, Rp), dtype=mm_dtype(), device=x.device)
     if Rp != R:
         out[:, R:].zero_()
-    from ._lib import check, dt_code, load, ptr, stream
     check(load().fabind_transpose_act(ptr(x), dt_code(x.dtype), x.stride(0), ptr(out), dt_code(out.dtype), Rp, R, C, act,
                                       stream()), "fabind_transpose_act")
     return out
+
+
+def _weight_grad(dpre, x, act_pro, x2=None):
+    """dW = dpre^T [act(x) | x2]  as NT GEMMs over the (padded) row dimension."""
+    dpt = _transposed(dpre)
+    xt = _transposed(x, act_pro)
+    if x2 is not None:
+        xt = torch.cat([xt, _transposed(x2)], 0)
+    dW, _ = K.gemm(dpt, xt)
+    return dW
 
 
 # ------------------------------------------------------------------------------------------------
@@ -50,6 +70,7 @@ class _Linear(torch.autograd.Function):
         ctx.has_b, ctx.has_res, ctx.has_x2 = b is not None, residual is not None, x2 is not None
         assert act_epi in (K.ACT_NONE, K.ACT_RELU), "linear: only ReLU may be fused as an output activation under autograd"
         assert not (act_epi != K.ACT_NONE and residual is not None)
+        assert not (act_pro != K.ACT_NONE and x2 is not None)
         ctx.save_for_backward(x, W, x2, y if act_epi == K.ACT_RELU else None)
         return y
 
@@ -59,29 +80,21 @@ class _Linear(torch.autograd.Function):
         dy = dy.contiguous()
         if ctx.act_epi == K.ACT_RELU:   # dPre = dy * (y > 0): ReLU'(pre) == ReLU'(y)
             dpre = torch.empty_like(dy)
-            from ._lib import check, load, ptr, stream, dt_code
             check(load().fabind_mul_dact(ptr(dy), dt_code(dy.dtype), ptr(y), dt_code(y.dtype), K.ACT_RELU, ptr(dpre),
                                          dt_code(dpre.dtype), dy.numel(), stream()), "fabind_mul_dact")
         else:
             dpre = dy
         K1 = x.shape[1]
         dx = dx2 = dW = db = None
-        need_x = ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[3])
-        if need_x:
+        if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[3]):
             Wt = W.t().contiguous()                                     # [K, N] (parameter-only transpose)
             if ctx.has_x2:
                 dfull, _ = K.gemm(dpre, Wt)
                 dx, dx2 = dfull[:, :K1], dfull[:, K1:]
             else:
-                dx, _ = K.gemm(dpre, Wt, aux=x if ctx.act_pro != K.ACT_NONE else None, dact=ctx.act_pro,
-                               out_dtype=torch.float32 if x.dtype == torch.float32 else x.dtype)
+                dx, _ = K.gemm(dpre, Wt, aux=x if ctx.act_pro != K.ACT_NONE else None, dact=ctx.act_pro, out_dtype=x.dtype)
         if ctx.needs_input_grad[1]:
-            dpt = _transposed(dpre)                                     # [N, Mp]
-            xt = _transposed(x, ctx.act_pro)                            # [K1, Mp]
-            if ctx.has_x2:
-                xt = torch.cat([xt, _transposed(x2)], 0)
-            dW, _ = K.gemm(dpt, xt)                                     # [N, K] fp32
-            dW = dW.to(W.dtype)
+            dW = _weight_grad(dpre, x, ctx.act_pro, x2).to(W.dtype)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = K.colsum(dpre)
         dres = dy.float() if (ctx.has_res and ctx.needs_input_grad[4]) else None
@@ -89,7 +102,7 @@ class _Linear(torch.autograd.Function):
 
 
 def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, x2=None, out_dtype=torch.float32):
-    if not x.is_contiguous() and x.stride(-1) != 1:
+    if x.stride(-1) != 1:
         x = x.contiguous()
     if _needs_grad(x, W, b, x2, residual):
         return _Linear.apply(x, W, b, x2, residual, act_pro, act_epi, out_dtype)
@@ -100,38 +113,8 @@ def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, 
 # ------------------------------------------------------------------------------------------------
 # linear + row-dot:  s_part[m, t] = sum_{n in tile t} act_epi(act_pro(x) W^T + b)[m,n] * u[n]
 # ------------------------------------------------------------------------------------------------
-class _LinearRowdot(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, W, b, u, act_pro, act_epi):
-        from ._lib import GemmArgs  # noqa: F401
-        z, part = _gemm_rowdot(x, W, b, u, act_pro, act_epi, store=True)
-        ctx.act_pro, ctx.act_epi = act_pro, act_epi
-        ctx.save_for_backward(x, W, u, z)
-        return part
-
-    @staticmethod
-    def backward(ctx, dpart):
-        x, W, u, z = ctx.saved_tensors
-        from ._lib import check, load, ptr, stream, dt_code
-        dpart = dpart.contiguous()
-        M, N = z.shape
-        dz = torch.empty_like(z)
-        nchunk = max(1, min(256, (M + 1023) // 1024))
-        scratch = torch.empty((nchunk, N), dtype=torch.float32, device=z.device)
-        du = torch.empty(N, dtype=torch.float32, device=z.device)
-        check(load().fabind_rowdot_bwd(ptr(z), dt_code(z.dtype), ptr(dpart), dpart.shape[1], ptr(u), ctx.act_epi, M, N,
-                                       ptr(dz), ptr(du), ptr(scratch), nchunk, stream()), "fabind_rowdot_bwd")
-        Wt = W.t().contiguous()
-        dx, _ = K.gemm(dz, Wt, aux=x if ctx.act_pro != K.ACT_NONE else None, dact=ctx.act_pro, out_dtype=x.dtype)
-        dW, _ = K.gemm(_transposed(dz), _transposed(x, ctx.act_pro))
-        db = K.colsum(dz)
-        return dx, dW.to(W.dtype), db, du, None, None
-
-
 def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store):
     """GEMM with row-dot epilogue; store=True keeps the pre-activation matrix (training)."""
-    import ctypes
-    from ._lib import GemmArgs, check, dt_code, load, ptr, stream
     M, Kd = x.shape
     N = W.shape[0]
     nt = (N + K.GEMM_BN - 1) // K.GEMM_BN
@@ -154,6 +137,32 @@ def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store):
     return z, part
 
 
+class _LinearRowdot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W, b, u, act_pro, act_epi):
+        z, part = _gemm_rowdot(x, W, b, u, act_pro, act_epi, store=True)
+        ctx.act_pro, ctx.act_epi = act_pro, act_epi
+        ctx.save_for_backward(x, W, u, z)
+        return part
+
+    @staticmethod
+    def backward(ctx, dpart):
+        x, W, u, z = ctx.saved_tensors
+        dpart = dpart.contiguous()
+        M, N = z.shape
+        dz = torch.empty_like(z)
+        nchunk = _nchunk(M)
+        scratch = torch.empty((nchunk, N), dtype=torch.float32, device=z.device)
+        du = torch.empty(N, dtype=torch.float32, device=z.device)
+        check(load().fabind_rowdot_bwd(ptr(z), dt_code(z.dtype), ptr(dpart), dpart.shape[1], ptr(u), ctx.act_epi, M, N,
+                                       ptr(dz), ptr(du), ptr(scratch), nchunk, stream()), "fabind_rowdot_bwd")
+        Wt = W.t().contiguous()
+        dx, _ = K.gemm(dz, Wt, aux=x if ctx.act_pro != K.ACT_NONE else None, dact=ctx.act_pro, out_dtype=x.dtype)
+        dW = _weight_grad(dz, x, ctx.act_pro).to(W.dtype)
+        db = K.colsum(dz)
+        return dx, dW, db, du, None, None
+
+
 def linear_rowdot(x, W, b, u, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE):
     if _needs_grad(x, W, b, u):
         return _LinearRowdot.apply(x, W, b, u, act_pro, act_epi)
@@ -169,13 +178,11 @@ class _EdgeGeom(torch.autograd.Function):
         d, rho, rhohat, norm = K.edge_geom(x, row, col, rowptr, lay.node_off, lay.B)
         ctx.lay, ctx.n = lay, x.shape[0]
         ctx.save_for_backward(row, col, rowptr, d, rho, norm)
-        ctx.mark_non_differentiable(rho)
         return d, rhohat
 
     @staticmethod
     def backward(ctx, dd, drhohat):
         row, col, rowptr, d, rho, norm = ctx.saved_tensors
-        from ._lib import check, load, ptr, stream
         lay = ctx.lay
         dx = torch.zeros((ctx.n, 3), dtype=torch.float32, device=d.device)
         dd = dd.contiguous() if dd is not None else torch.zeros_like(d)
@@ -195,37 +202,35 @@ def edge_geom(x, row, col, rowptr, lay):
 
 class _GclPre(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, AB, rhohat, w_r, H, row, col):
-        ctx.H = H
-        ctx.save_for_backward(AB, rhohat, w_r, row, col)
-        return K.gcl_pre(AB, H, row, col, rhohat, w_r, act_dtype())
+    def forward(ctx, AB, rhohat, w_r, H, g):
+        ctx.H, ctx.g = H, g
+        ctx.save_for_backward(AB, rhohat, w_r)
+        return K.gcl_pre(AB, H, g.row_ctx, g.col_ctx, rhohat, w_r, act_dtype())
 
     @staticmethod
     def backward(ctx, dpre):
-        AB, rhohat, w_r, row, col = ctx.saved_tensors
-        from ._lib import check, load, ptr, stream, dt_code
-        H, E, N = ctx.H, row.shape[0], AB.shape[0]
+        AB, rhohat, w_r = ctx.saved_tensors
+        H, g = ctx.H, ctx.g
+        E, N = g.row_ctx.shape[0], AB.shape[0]
         dpre = dpre.contiguous()
-        dAB = torch.zeros((N, 2 * H), dtype=torch.float32, device=AB.device)
+        dAB = torch.empty((N, 2 * H), dtype=torch.float32, device=AB.device)
+        K.segment_sum(dpre, g.rp_ctx, N, out=dAB[:, :H])                      # receiving side: rows are CSR segments
+        colptr, perm = g.ctx_by_col()
+        K.segment_sum(dpre, colptr, N, eidx=perm, out=dAB[:, H:])             # sending side: permuted segments
         drh = torch.empty(E, dtype=torch.float32, device=AB.device)
-        nchunk = max(1, min(256, (E + 1023) // 1024))
+        nchunk = _nchunk(E)
         scratch = torch.empty((nchunk, H), dtype=torch.float32, device=AB.device)
         dw = torch.empty(H, dtype=torch.float32, device=AB.device)
-        check(load().fabind_gcl_pre_bwd(ptr(dpre), dt_code(dpre.dtype), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r), E,
-                                        ptr(dAB), 2 * H, ptr(drh), ptr(dw), ptr(scratch), nchunk, stream()),
-              "fabind_gcl_pre_bwd")
-        return dAB, drh, dw, None, None, None
+        check(load().fabind_gcl_pre_bwd(ptr(dpre), dt_code(dpre.dtype), H, ptr(rhohat), ptr(w_r), E, ptr(drh), ptr(dw),
+                                        ptr(scratch), nchunk, stream()), "fabind_gcl_pre_bwd")
+        return dAB, drh, dw, None, None
 
 
-def gcl_pre(AB, H, row, col, rhohat, w_r, act=K.ACT_NONE):
+def gcl_pre(AB, H, g, rhohat, w_r, act=K.ACT_NONE):
     if _needs_grad(AB, rhohat, w_r):
         assert act == K.ACT_NONE
-        return _GclPre.apply(AB, rhohat, w_r, H, row, col)
-    return K.gcl_pre(AB, H, row, col, rhohat, w_r, act_dtype(), act)
-
-
-def needs_grad(*ts):
-    return _needs_grad(*ts)
+        return _GclPre.apply(AB, rhohat, w_r, H, g)
+    return K.gcl_pre(AB, H, g.row_ctx, g.col_ctx, rhohat, w_r, act_dtype(), act)
 
 
 class _SegmentSum(torch.autograd.Function):
@@ -238,7 +243,6 @@ class _SegmentSum(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         Z, row = ctx.saved_tensors
-        from ._lib import check, load, ptr, stream, dt_code
         dout = dout.contiguous()
         dZ = torch.empty_like(Z)
         check(load().fabind_gather_dact(ptr(dout), dout.stride(0), ptr(row), ptr(Z), dt_code(Z.dtype), ctx.act, ptr(dZ),
@@ -257,20 +261,18 @@ class _CoordUpdate(torch.autograd.Function):
     def forward(ctx, x, d, s_part, rowptr, mean, clampv):
         x_out, s = K.coord_update(x, d, s_part, rowptr, mean, clampv, want_s=True)
         ctx.mean, ctx.clampv, ctx.np = mean, clampv, s_part.shape[1]
-        ctx.save_for_backward(x, x_out, d, s, rowptr)
+        ctx.save_for_backward(d, s, rowptr)
         return x_out
 
     @staticmethod
     def backward(ctx, dxo):
-        x, x_out, d, s, rowptr = ctx.saved_tensors
-        from ._lib import check, load, ptr, stream
+        d, s, rowptr = ctx.saved_tensors
         dxo = dxo.contiguous()
         E = s.shape[0]
-        dd = torch.empty((E, 3), dtype=torch.float32, device=x.device)
-        ds = torch.empty(E, dtype=torch.float32, device=x.device)
-        check(load().fabind_coord_update_bwd(ptr(x), ptr(x_out), ptr(d), ptr(s), ptr(rowptr), x.shape[0],
-                                             1 if ctx.mean else 0, ctx.clampv, ptr(dxo), ptr(dd), ptr(ds), stream()),
-              "fabind_coord_update_bwd")
+        dd = torch.empty((E, 3), dtype=torch.float32, device=d.device)
+        ds = torch.empty(E, dtype=torch.float32, device=d.device)
+        check(load().fabind_coord_update_bwd(ptr(d), ptr(s), ptr(rowptr), dxo.shape[0], 1 if ctx.mean else 0, ctx.clampv,
+                                             ptr(dxo), ptr(dd), ptr(ds), stream()), "fabind_coord_update_bwd")
         return dxo, dd, ds[:, None].expand(E, ctx.np), None, None, None
 
 
@@ -296,35 +298,57 @@ def select_rows(x, z, mask_u8):
 # ------------------------------------------------------------------------------------------------
 class _CrossAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qg, kv, bias, lin_col, gate_col, desc, B, max_nq, scale):
+    def forward(ctx, qg, kv, bias, lin_col, gate_col, desc, B, max_nq, max_nk, scale):
         out = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
         _, lse = K.cross_attn_fwd(qg[:, :128], kv[:, :128], kv[:, 128:], qg[:, 128:], bias, lin_col, gate_col, desc, B,
                                   max_nq, scale, out, want_lse=True)
-        ctx.args = (lin_col, gate_col, desc, B, max_nq, scale)
+        ctx.args = (lin_col, gate_col, desc, B, max_nq, max_nk, scale)
         ctx.save_for_backward(qg, kv, bias, out, lse)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qg, kv, bias, out, lse = ctx.saved_tensors
-        lin_col, gate_col, desc, B, max_nq, scale = ctx.args
-        from ._lib import check, load, ptr, stream
+        lin_col, gate_col, desc, B, max_nq, max_nk, scale = ctx.args
         dout = dout.contiguous()
-        dqg = torch.empty_like(qg)
-        dkv = torch.zeros_like(kv)
-        dbias = torch.empty_like(bias)
+        dqg, dkv, dbias = torch.empty_like(qg), torch.empty_like(kv), torch.empty_like(bias)
+        dO = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
+        Dv = torch.empty((qg.shape[0], 4), dtype=torch.float32, device=qg.device)
         check(load().fabind_cross_attn_bwd(ptr(qg), qg.stride(0), ptr(kv), kv.stride(0), ptr(bias), bias.stride(0), lin_col,
-                                           gate_col, ptr(desc), B, max_nq, scale, ptr(out), ptr(lse), ptr(dout), ptr(dqg),
-                                           ptr(dkv), ptr(dbias), stream()), "fabind_cross_attn_bwd")
-        return dqg, dkv, dbias, None, None, None, None, None, None
+                                           gate_col, ptr(desc), B, max_nq, max_nk, scale, ptr(out), ptr(lse), ptr(dout),
+                                           ptr(dqg), ptr(dkv), ptr(dbias), ptr(dO), ptr(Dv), stream()),
+              "fabind_cross_attn_bwd")
+        return dqg, dkv, dbias, None, None, None, None, None, None, None
 
 
-def cross_attn(qg, kv, bias, lin_col, gate_col, desc, B, max_nq, scale):
+def cross_attn(qg, kv, bias, lin_col, gate_col, desc, B, max_nq, max_nk, scale):
     if _needs_grad(qg, kv, bias):
-        return _CrossAttn.apply(qg, kv, bias, lin_col, gate_col, desc, B, max_nq, scale)
+        return _CrossAttn.apply(qg, kv, bias, lin_col, gate_col, desc, B, max_nq, max_nk, scale)
     out = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
     K.cross_attn_fwd(qg[:, :128], kv[:, :128], kv[:, 128:], qg[:, 128:], bias, lin_col, gate_col, desc, B, max_nq, scale, out)
     return out
+
+
+class _PairHadamard(torch.autograd.Function):
+    """hd[e, :H] = T0[p, :H] * T0[c, H:2H];  hd[e, H:H+H2] = T1[p, :H2] * T1[c, H2:2*H2]"""
+
+    @staticmethod
+    def forward(ctx, T0, T1, H, H2, red_p, red_c):
+        ctx.dims = (H, H2)
+        ctx.save_for_backward(T0, T1, red_p, red_c)
+        return K.pair_hadamard(T0[:, :H], T0[:, H:], T1[:, :H2], T1[:, H2:], red_p, red_c, act_dtype())
+
+    @staticmethod
+    def backward(ctx, dhd):
+        T0, T1, red_p, red_c = ctx.saved_tensors
+        H, H2 = ctx.dims
+        dhd = dhd.contiguous()
+        d0, d1 = torch.zeros_like(T0), torch.zeros_like(T1)
+        check(load().fabind_pair_hadamard_bwd(
+            ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(T0[:, :H]), ptr(T0[:, H:]), T0.stride(0), H, ptr(T1[:, :H2]),
+            ptr(T1[:, H2:]), T1.stride(0), H2, ptr(red_p), ptr(red_c), red_p.shape[0], ptr(d0[:, :H]), ptr(d0[:, H:]),
+            d0.stride(0), ptr(d1[:, :H2]), ptr(d1[:, H2:]), d1.stride(0), stream()), "fabind_pair_hadamard_bwd")
+        return d0, d1, None, None, None, None
 
 
 def pair_hadamard(a0b0, H, ab32, H2, red_p, red_c):
@@ -333,24 +357,34 @@ def pair_hadamard(a0b0, H, ab32, H2, red_p, red_c):
     return K.pair_hadamard(a0b0[:, :H], a0b0[:, H:], ab32[:, :H2], ab32[:, H2:], red_p, red_c, act_dtype())
 
 
-class _PairHadamard(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, a0b0, ab32, H, H2, red_p, red_c):
-        ctx.dims = (H, H2)
-        ctx.save_for_backward(a0b0, ab32, red_p, red_c)
-        return K.pair_hadamard(a0b0[:, :H], a0b0[:, H:], ab32[:, :H2], ab32[:, H2:], red_p, red_c, act_dtype())
+class _RowsHadamard(torch.autograd.Function):
+    """out[e,:] = t[ia[e],:] * t[ib[e],:]"""
 
     @staticmethod
-    def backward(ctx, dhd):
-        a0b0, ab32, red_p, red_c = ctx.saved_tensors
-        H, H2 = ctx.dims
-        from ._lib import check, load, ptr, stream, dt_code
-        dhd = dhd.contiguous()
-        d0, d1 = torch.zeros_like(a0b0), torch.zeros_like(ab32)
-        check(load().fabind_pair_hadamard_bwd(ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(a0b0), a0b0.stride(0), H,
-                                              ptr(ab32), ab32.stride(0), H2, ptr(red_p), ptr(red_c), red_p.shape[0],
-                                              ptr(d0), ptr(d1), stream()), "fabind_pair_hadamard_bwd")
-        return d0, d1, None, None, None, None
+    def forward(ctx, t, ia, ib):
+        ctx.save_for_backward(t, ia, ib)
+        dummy = t[:, :0]
+        return K.pair_hadamard(t, t, dummy, dummy, ia, ib, act_dtype())
+
+    @staticmethod
+    def backward(ctx, dout):
+        t, ia, ib = ctx.saved_tensors
+        dout = dout.contiguous()
+        dt_ = torch.zeros_like(t)
+        W = t.shape[1]
+        check(load().fabind_pair_hadamard_bwd(ptr(dout), dt_code(dout.dtype), dout.stride(0), ptr(t), ptr(t), t.stride(0), W,
+                                              None, None, 0, 0, ptr(ia), ptr(ib), ia.shape[0], ptr(dt_), ptr(dt_),
+                                              dt_.stride(0), None, None, 0, stream()), "fabind_pair_hadamard_bwd")
+        return dt_, None, None
+
+
+def rows_hadamard(t, idx_a, idx_b):
+    """einsum('bik,bjk->bijk') restricted to the valid pairs (reference model.py:355)."""
+    ia, ib = idx_a.to(torch.int32).contiguous(), idx_b.to(torch.int32).contiguous()
+    if _needs_grad(t):
+        return _RowsHadamard.apply(t, ia, ib)
+    dummy = t[:, :0]
+    return K.pair_hadamard(t, t, dummy, dummy, ia, ib, act_dtype())
 
 
 class _InterAttn(torch.autograd.Function):
@@ -359,33 +393,33 @@ class _InterAttn(torch.autograd.Function):
         h_out, x_out, alpha, cvs = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx,
                                                     bias_part, w_rk, w_rv, wcr, w3, clampv)
         ctx.g, ctx.H, ctx.clampv, ctx.np = g, H, clampv, bias_part.shape[1]
-        ctx.save_for_backward(qkv, cv, x, x_out, d, rhohat, w_rk, w_rv, wcr, w3, alpha, cvs)
+        ctx.save_for_backward(qkv, cv, d, rhohat, w_rk, w_rv, wcr, w3, alpha, cvs)
         ctx.mark_non_differentiable(alpha)
         return h_out, x_out, alpha
 
     @staticmethod
     def backward(ctx, dh_out, dx_out, _dalpha):
-        qkv, cv, x, x_out, d, rhohat, w_rk, w_rv, wcr, w3, alpha, cvs = ctx.saved_tensors
-        from ._lib import check, load, ptr, stream
+        qkv, cv, d, rhohat, w_rk, w_rv, wcr, w3, alpha, cvs = ctx.saved_tensors
         g, H = ctx.g, ctx.H
         N, E = qkv.shape[0], g.col_int.shape[0]
         dev = qkv.device
-        dh_out = dh_out.contiguous() if dh_out is not None else torch.zeros((N, H), device=dev)
-        dx_out = dx_out.contiguous() if dx_out is not None else torch.zeros((N, 3), device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        dh_out = dh_out.contiguous() if dh_out is not None else torch.zeros((N, H), **f32)
+        dx_out = dx_out.contiguous() if dx_out is not None else torch.zeros((N, 3), **f32)
         dqkv = torch.zeros_like(qkv)
-        dcv = torch.zeros_like(cv)
-        dd = torch.empty((max(E, 1), 3), dtype=torch.float32, device=dev)
-        drh = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
-        dbias_red = torch.zeros(max(E // 2, 1), dtype=torch.float32, device=dev)
-        nrb = (N + 3) // 4
-        wpart = torch.zeros((4, nrb, H), dtype=torch.float32, device=dev)   # per-block partials of dw_rk,dw_rv,dwcr,dw3
-        check(load().fabind_inter_attn_bwd(ptr(qkv), qkv.stride(0), ptr(cv), cv.stride(0), H, ptr(x), ptr(x_out), ptr(d),
-                                           ptr(rhohat), ptr(g.rp_int), ptr(g.col_int), ptr(g.red_idx), ptr(w_rk),
-                                           ptr(w_rv), ptr(wcr), ptr(w3), ptr(alpha), ptr(cvs), ctx.clampv, N,
-                                           ptr(dh_out), ptr(dx_out), ptr(dqkv), ptr(dcv), ptr(dd), ptr(drh),
-                                           ptr(dbias_red), ptr(wpart), stream()), "fabind_inter_attn_bwd")
-        dw = [K.colsum(wpart[i]) for i in range(4)]
+        dcv = torch.empty_like(cv)
+        dd, drh = torch.zeros((max(E, 1), 3), **f32), torch.zeros(max(E, 1), **f32)
         n_red = E // 2
+        dbias_red = torch.zeros(max(n_red, 1), **f32)
+        dlogit, dcp = torch.zeros(max(E, 1), **f32), torch.zeros(max(E, 1), **f32)
+        nblk = min((N + 3) // 4, 1024)
+        wpart = torch.empty((4, nblk, H), **f32)
+        check(load().fabind_inter_attn_bwd(ptr(qkv), qkv.stride(0), ptr(cv), cv.stride(0), H, ptr(d), ptr(rhohat),
+                                           ptr(g.rp_int), ptr(g.col_int), ptr(g.mirror), ptr(g.red_idx), ptr(w_rk),
+                                           ptr(w_rv), ptr(wcr), ptr(w3), ptr(alpha), ptr(cvs), ctx.clampv, N, ptr(dh_out),
+                                           ptr(dx_out), ptr(dqkv), ptr(dcv), ptr(dd), ptr(drh), ptr(dbias_red), ptr(dlogit),
+                                           ptr(dcp), ptr(wpart), nblk, stream()), "fabind_inter_attn_bwd")
+        dw = [K.colsum(wpart[i]) for i in range(4)]
         return (dqkv, dcv, dh_out, dx_out, dd[:E], drh[:E], dbias_red[:n_red, None].expand(n_red, ctx.np), dw[0], dw[1],
                 dw[2], dw[3], None, None, None)
 
@@ -409,7 +443,6 @@ class _LasStep(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         x, x0, out = ctx.saved_tensors
-        from ._lib import check, load, ptr, stream
         las, lay = ctx.las, ctx.lay
         dout = dout.contiguous()
         dx = torch.empty_like(x)
@@ -446,12 +479,11 @@ class _PairBias(torch.autograd.Function):
     def forward(ctx, a0b0, wcomp, bconst, H, lay):
         ctx.H, ctx.lay = H, lay
         ctx.save_for_backward(a0b0, wcomp)
-        return tuple(_pair_bias_fwd(a0b0, H, wcomp, bconst, lay))
+        return tuple(_pair_bias_fwd(a0b0.detach(), H, wcomp.detach(), bconst.detach(), lay))
 
     @staticmethod
     def backward(ctx, *douts):
         a0b0, wcomp = ctx.saved_tensors
-        from ._lib import check, load, ptr, stream
         H, lay = ctx.H, ctx.lay
         nblk, NO, _ = wcomp.shape
         da0b0 = torch.zeros_like(a0b0)
@@ -461,11 +493,11 @@ class _PairBias(torch.autograd.Function):
             if dout is None:
                 continue
             dout = dout.contiguous()
-            dwk = torch.zeros((lay.B, NO, H), dtype=torch.float32, device=a0b0.device)
+            dwk = torch.zeros((lay.B, NO * H), dtype=torch.float32, device=a0b0.device)
             check(load().fabind_pair_bias_bwd(ptr(dout), NO, ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.desc_p),
-                                              lay.B, lay.max_P, ptr(lay.p_index), ptr(lay.c_index), ptr(da0b0), ptr(dwk),
-                                              stream()), "fabind_pair_bias_bwd")
-            dwcomp[k] = K.colsum(dwk.reshape(lay.B, NO * H)).reshape(NO, H)
+                                              lay.B, lay.max_P, lay.max_C, ptr(lay.p_index), ptr(lay.c_index), ptr(da0b0),
+                                              ptr(dwk), stream()), "fabind_pair_bias_bwd")
+            dwcomp[k] = K.colsum(dwk).reshape(NO, H)
             dbconst[k] = K.colsum(dout)
         return da0b0, dwcomp, dbconst, None, None
 
@@ -477,12 +509,11 @@ def pair_bias(a0b0, H, wcomp, bconst, lay):
 
 
 # ------------------------------------------------------------------------------------------------
-# LayerNorm, row-pair Hadamard (dist-map head)
+# LayerNorm
 # ------------------------------------------------------------------------------------------------
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps):
-        from ._lib import check, load, ptr, stream
         R, C = x.shape
         y = torch.empty_like(x)
         mean = torch.empty(R, dtype=torch.float32, device=x.device)
@@ -494,7 +525,6 @@ class _LayerNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        from ._lib import check, load, ptr, stream
         x, w, mean, rstd = ctx.saved_tensors
         R, C = x.shape
         dy = dy.contiguous()
@@ -509,14 +539,3 @@ class _LayerNorm(torch.autograd.Function):
 
 def layernorm(x, w, b, eps=1e-5):
     return _LayerNorm.apply(x.float().contiguous(), w, b, eps)
-
-
-def rows_hadamard(t, idx_a, idx_b):
-    """out[e,:] = t[idx_a[e],:] * t[idx_b[e],:]  (einsum('bik,bjk->bijk') on the valid pairs only, model.py:355)."""
-    ia, ib = idx_a.to(torch.int32).contiguous(), idx_b.to(torch.int32).contiguous()
-    W = t.shape[1]
-    dummy = t[:, :0]
-    if _needs_grad(t):
-        zero2 = torch.zeros((t.shape[0], 8), dtype=torch.float32, device=t.device)
-        return _PairHadamard.apply(torch.cat([t, t], 1), zero2, W, 4, ia, ib)[:, :W]
-    return K.pair_hadamard(t, t, dummy, dummy, ia, ib, act_dtype())

@@ -92,9 +92,10 @@ int fabind_edges_fill(const float* x, const int* node_off, const int* c_cnt, int
 int fabind_exclusive_scan(const int* in, int* out, int n, hipStream_t stream);
 /* Inter-edge pair bookkeeping (replaces trio_encoder's index arithmetic, models/egnn.py:286-304):
  * red_off[B+1] = prefix of ligand-row inter edges per complex; for every inter edge e, red_idx[e] =
- * index of its unordered (ligand, protein) pair in the reduced list; red_c/red_p = the pair's nodes. */
+ * index of its unordered (ligand, protein) pair in the reduced list; red_c/red_p = the pair's nodes;
+ * mirror[e] = index of the reversed edge (the inter graph is symmetric). */
 int fabind_inter_meta(const int* node_off, const int* c_cnt, int B, const int* rowptr_int, const int* col_int,
-                      const int* row_int, int E_int, int* red_off, int* red_idx, int* red_c, int* red_p,
+                      const int* row_int, int E_int, int* red_off, int* red_idx, int* red_c, int* red_p, int* mirror,
                       hipStream_t stream);
 /* If the batch has no inter edge the reference inserts one fake symmetric pair (att_model.py:85-86);
  * host-side logic handles that case by calling fill with a forced pair -- see fabind_amd/graph.py. */
@@ -110,14 +111,15 @@ int fabind_edge_geom(const float* x, const int* row, const int* col, const int* 
  * gcl_pre:  pre[e,:] = act( AB[row[e], 0:H] + AB[col[e], H:2H] + rhohat[e]*w_r[:] )   (act = NONE keeps the
  *           pre-activation for training; SILU is the forward-only form)
  *           (first edge_mlp Linear split column-wise: node-level projections gathered per edge).
- * segment_sum: out[r,:] = sum_{e in row r} act(Z[e,:])   (unsorted_segment_sum on a row-sorted CSR)
+ * segment_sum: out[r,:] = sum_{e in row r} act(Z[eidx ? eidx[e] : e,:])   (unsorted_segment_sum on a row-sorted
+ *           CSR; eidx = permutation for reductions over the column index, used by backward passes)
  * coord_mean: x_out[r] = x[r] + clamp( (1/max(deg,1)) * sum_e d[e]*s[e], +-clampv ),
  *           s[e] = sum_k s_part[e,k] (row-dot partials written by fabind_gemm).
  * -------------------------------------------------------------------------------------------*/
 int fabind_gcl_pre(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
                    const float* w_r, void* pre, int pre_dt, int E, int act, hipStream_t stream);
-int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, int n_rows, int act, float* out,
-                       int ldo, hipStream_t stream);
+int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, const int* eidx, int n_rows, int act,
+                       float* out, int ldo, hipStream_t stream);
 int fabind_coord_update(const float* x, const float* d, const float* s_part, int n_part, const float* weight,
                         const int* rowptr, int n_rows, int mean, float clampv, float* x_out, float* s_out,
                         hipStream_t stream);
@@ -179,6 +181,45 @@ int fabind_layernorm_bwd(const float* x, const float* w, const float* dy, const 
 
 /* elementwise: out = a + b (fp32), n elements */
 int fabind_add(const float* a, const float* b, float* out, long n, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward passes (adjoints of the kernels above; they replace torch autograd's traversal of the
+ * reference's ATen/torch_scatter graph for the same ops).  Contractions in backward passes go through
+ * fabind_gemm / fabind_transpose_act / fabind_colsum.
+ * -------------------------------------------------------------------------------------------*/
+int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, long n,
+                    hipStream_t stream);
+int fabind_rowdot_bwd(const void* z, int z_dt, const float* dpart, int np, const float* u, int act, int M, int N,
+                      void* dz, float* du, float* scratch, int nchunk, hipStream_t stream);
+int fabind_edge_geom_bwd(const float* d, const float* rho, const float* norm, const float* dd, const float* drhohat,
+                         const int* row, const int* col, const int* rowptr, const int* node_off, int B, int E, float* dx,
+                         hipStream_t stream);
+int fabind_gcl_pre_bwd(const void* dpre, int dt, int H, const float* rhohat, const float* w_r, int E, float* drh,
+                       float* dw, float* scratch, int nchunk, hipStream_t stream);
+int fabind_gather_dact(const float* dout, int ldo, const int* row, const void* Z, int z_dt, int act, void* dZ, int dz_dt,
+                       int E, int H, hipStream_t stream);
+int fabind_coord_update_bwd(const float* d, const float* s, const int* rowptr, int n_rows, int mean, float clampv,
+                            const float* dxo, float* dd, float* ds, hipStream_t stream);
+int fabind_cross_attn_bwd(const float* qg, int ldq, const float* kv, int ldkv, const float* bias, int bias_ld,
+                          int lin_col, int gate_col, const int* desc, int B, int max_nq, int max_nk, float scale,
+                          const float* out, const float* lse, const float* dout, float* dqg, float* dkv, float* dbias,
+                          float* dO, float* Dv, hipStream_t stream);
+int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const float* a0, const float* b0, int ld0, int H,
+                             const float* a1, const float* b1, int ld1, int H2, const int* red_p, const int* red_c, int n,
+                             float* da0, float* db0, int ldd0, float* da1, float* db1, int ldd1, hipStream_t stream);
+int fabind_inter_attn_bwd(const float* qkv, int ldqkv, const float* cv, int ldcv, int H, const float* d,
+                          const float* rhohat, const int* rowptr, const int* col, const int* mirror, const int* red_idx,
+                          const float* w_rk, const float* w_rv, const float* wcr, const float* w3, const float* alpha,
+                          const float* cvs, float clampv, int n_rows, const float* dh_out, const float* dx_out,
+                          float* dqkv, float* dcv, float* dd, float* drh, float* dbias_red, float* dlogit, float* dcp,
+                          float* wpart, int nblk, hipStream_t stream);
+int fabind_las_step_bwd(const float* x, const float* x0, const float* xo, const int* las_i, const int* las_j,
+                        const int* las_off, const int* node_off, const int* c_cnt, int B, int max_n, float step,
+                        float clampv, const float* dout, float* dx, hipStream_t stream);
+int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, int ld, int H, const float* w, const int* desc_p,
+                         int B, int max_P, int max_C, const int* p_index, const int* c_index, float* dab, float* dwk,
+                         hipStream_t stream);
+void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of the bf16 LDS-DMA GEMM */
 
 #ifdef __cplusplus
 }
