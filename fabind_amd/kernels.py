@@ -16,7 +16,7 @@ PROFILE = None  # dict -> per-(M,N,K,dtypes) list of (start,end) HIP events arou
 
 
 def _ld(t):
-    assert t.stride(-1) == 1, "innermost dimension must be contiguous"
+    assert t.stride(-1) == 1 or t.shape[-1] == 1, "innermost dimension must be contiguous"
     return t.stride(0) if t.dim() == 2 else t.shape[-1]
 
 

@@ -87,12 +87,22 @@ class _Linear(torch.autograd.Function):
         K1 = x.shape[1]
         dx = dx2 = dW = db = None
         if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[3]):
-            Wt = W.t().contiguous()                                     # [K, N] (parameter-only transpose)
+            N = W.shape[0]
+            if N % 8 == 0:
+                Wt = W.t().contiguous()                                 # [K, N] (parameter-only transpose)
+            else:                                                       # tiny heads (N = 1): pad the contraction dim to 8
+                Np = (N + 7) // 8 * 8
+                Wt = torch.zeros((W.shape[1], Np), dtype=W.dtype, device=W.device)
+                Wt[:, :N] = W.t()
+                dpad = torch.zeros((dpre.shape[0], Np), dtype=dpre.dtype, device=dpre.device)
+                dpad[:, :N] = dpre
+                dpre_mm = dpad
+            dpre_mm = dpre if N % 8 == 0 else dpre_mm
             if ctx.has_x2:
-                dfull, _ = K.gemm(dpre, Wt)
+                dfull, _ = K.gemm(dpre_mm, Wt)
                 dx, dx2 = dfull[:, :K1], dfull[:, K1:]
             else:
-                dx, _ = K.gemm(dpre, Wt, aux=x if ctx.act_pro != K.ACT_NONE else None, dact=ctx.act_pro, out_dtype=x.dtype)
+                dx, _ = K.gemm(dpre_mm, Wt, aux=x if ctx.act_pro != K.ACT_NONE else None, dact=ctx.act_pro, out_dtype=x.dtype)
         if ctx.needs_input_grad[1]:
             dW = _weight_grad(dpre, x, ctx.act_pro, x2).to(W.dtype)
         if ctx.has_b and ctx.needs_input_grad[2]:

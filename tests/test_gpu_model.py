@@ -1,0 +1,76 @@
+"""GPU: full IaBNet model (get_model / forward / inference / compute_loss) against reference-captured goldens."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import hetero_from_npz, load_npz, rmsd, weights
+from test_gpu_stack import _args
+
+pytestmark = pytest.mark.gpu
+
+
+class _Logger:
+    def log_message(self, s):
+        pass
+
+
+def _model(g, dev):
+    from fabind_amd.models import get_model
+    hidden, pocket_hidden, layers, n_iter, _ = [int(v) for v in g["cfg"]]
+    a = _args(hidden, layers, n_iter)
+    a.pocket_pred_hidden_size = pocket_hidden
+    a.random_n_iter = False
+    m = get_model(a, _Logger(), dev)
+    m.load_state_dict(weights(g), strict=True)
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_model_forward_loss_and_gradients(stage):
+    from fabind_amd import engine
+    from fabind_amd.models.model import compute_loss
+    dev = torch.device("cuda:0")
+    engine.set_precision("fp32")
+    g = load_npz("model_tiny")
+    m = _model(g, dev)
+    data = hetero_from_npz(g).to(dev)
+    out = m(data, stage=stage, train=False)
+    p = "s%d_" % stage
+    assert rmsd(out[0].detach().cpu().numpy(), g[p + "coords"]) < 1e-4           # north_star: 1e-4 A RMSD
+    for i, n in ((2, "y_pred"), (3, "y_pred_by_coords"), (4, "pocket_cls_pred"), (8, "pred_pocket_center"), (9, "dis_map")):
+        ref = g[p + n]
+        got = out[i].detach().cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), n
+    assert np.array_equal(out[5].cpu().numpy(), g[p + "pocket_cls"])
+    assert np.array_equal(out[6].cpu().numpy(), g[p + "protein_out_mask_whole"])
+    loss, terms = compute_loss(out, data)
+    assert abs(float(loss.detach()) - float(g[p + "loss"])) <= 1e-5 * abs(float(g[p + "loss"]))    # north_star: 1e-5 rel
+    for k, v in terms.items():
+        assert abs(float(v.detach()) - float(g[p + "loss_" + k])) <= 1e-5 * max(abs(float(g[p + "loss_" + k])), 1e-2), k
+    loss.backward()
+    checked, bad = 0, []
+    for n, prm in m.named_parameters():
+        key = p + "gradnorm_" + n
+        if key not in g or prm.grad is None:
+            continue
+        ref_n = float(g[key])
+        got = prm.grad.flatten().cpu()
+        idx = torch.linspace(0, got.numel() - 1, 16).long()
+        smp = g[p + "gradsmp_" + n]
+        e1 = abs(float(got.norm()) - ref_n)
+        e2 = np.abs(got[idx].numpy() - smp).max()
+        if e1 > 5e-3 * ref_n + 1e-6 or e2 > 5e-3 * max(np.abs(smp).max(), ref_n / max(got.numel(), 1) ** 0.5) + 1e-7:
+            bad.append((n, e1, ref_n, float(e2)))
+        checked += 1
+    assert checked > 200 and not bad, bad[:8]
+
+
+def test_model_inference():
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision("fp32")
+    g = load_npz("model_tiny")
+    m = _model(g, dev)
+    with torch.no_grad():
+        coords, batch = m.inference(hetero_from_npz(g).to(dev))
+    assert rmsd(coords.cpu().numpy(), g["inf_coords"]) < 1e-4
