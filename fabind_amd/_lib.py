@@ -11,16 +11,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfabind_hip.so")
 
 DT_F32, DT_BF16 = 0, 1
-ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
 _vp, _i, _f, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_long
 
 
 class GemmArgs(ctypes.Structure):
-    _fields_ = [(n, _vp) for n in ("A", "A2", "W", "C", "bias", "R", "r_index", "dotvec", "dot_out", "aux", "groups")] + \
+    _fields_ = [(n, _vp) for n in ("A", "A2", "W", "C", "bias", "R", "r_index", "dotvec", "dot_out", "aux", "groups", "C2")] + \
                [(n, _i) for n in ("M", "N", "K", "K1", "lda", "lda2", "ldw", "ldc", "ldr", "ldaux", "dot_ld",
                                   "a_dtype", "w_dtype", "c_dtype", "aux_dtype", "act_pro", "act_epi", "dact_epi",
-                                  "accumulate", "store_preact", "n_groups", "max_m", "max_n")] + [("alpha", _f)]
+                                  "accumulate", "store_preact", "n_groups", "max_m", "max_n", "k_splits")] + [("alpha", _f)]
 
 
 # name -> argtypes (every function returns int and takes the stream last)
@@ -33,7 +33,7 @@ SIGNATURES = {
     "fabind_exclusive_scan": [_vp, _vp, _i, _vp],
     "fabind_inter_meta": [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fabind_edge_geom": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
-    "fabind_gcl_pre": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "fabind_gcl_pre": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "fabind_segment_sum": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp],
     "fabind_coord_update": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
     "fabind_cross_attn_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _vp],

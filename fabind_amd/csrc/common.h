@@ -10,6 +10,7 @@
 #define FB_ACT_SILU 1
 #define FB_ACT_RELU 2
 #define FB_ACT_SIGMOID 3
+#define FB_ACT_STORED_DERIV 4  // "derivative" operand already holds act'(pre): apply_dact(x) = x
 
 typedef uint16_t bf16_t;  // raw bfloat16 storage
 
@@ -74,6 +75,7 @@ __device__ __forceinline__ float apply_dact(float x, int act) {
         case FB_ACT_SILU: return dsilu_f(x);
         case FB_ACT_RELU: return x > 0.f ? 1.f : 0.f;
         case FB_ACT_SIGMOID: { float s = sigmoid_f(x); return s * (1.f - s); }
+        case FB_ACT_STORED_DERIV: return x;
         default: return 1.f;
     }
 }

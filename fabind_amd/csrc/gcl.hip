@@ -7,7 +7,7 @@
 // pre[e,:] = AB[row[e], 0:H] + AB[col[e], H:2H] + rhohat[e] * w_r[:]       (one wave per edge)
 __global__ __launch_bounds__(256) void gcl_pre_kernel(const float* __restrict__ AB, int ldab, int H, const int* row,
                                                       const int* col, const float* rhohat, const float* __restrict__ w_r,
-                                                      void* pre, int pre_dt, int E, int act) {
+                                                      void* pre, int pre_dt, int E, int act, void* dact_out) {
     const int lane = threadIdx.x & 63;
     int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= E) return;
@@ -16,18 +16,22 @@ __global__ __launch_bounds__(256) void gcl_pre_kernel(const float* __restrict__ 
     const float rh = rhohat[e];
     for (int c = lane * 4; c < H; c += 256) {
         float4 va = *(const float4*)(a + c), vb = *(const float4*)(b + c), w = *(const float4*)(w_r + c);
-        float4 o = make_float4(apply_act(va.x + vb.x + rh * w.x, act), apply_act(va.y + vb.y + rh * w.y, act),
-                               apply_act(va.z + vb.z + rh * w.z, act), apply_act(va.w + vb.w + rh * w.w, act));
-        st4_any(pre, pre_dt, (size_t)e * H + c, o);
+        const float4 z = make_float4(va.x + vb.x + rh * w.x, va.y + vb.y + rh * w.y, va.z + vb.z + rh * w.z,
+                                     va.w + vb.w + rh * w.w);
+        st4_any(pre, pre_dt, (size_t)e * H + c,
+                make_float4(apply_act(z.x, act), apply_act(z.y, act), apply_act(z.z, act), apply_act(z.w, act)));
+        if (dact_out)
+            st4_any(dact_out, pre_dt, (size_t)e * H + c,
+                    make_float4(apply_dact(z.x, act), apply_dact(z.y, act), apply_dact(z.z, act), apply_dact(z.w, act)));
     }
 }
 
 extern "C" int fabind_gcl_pre(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
-                              const float* w_r, void* pre, int pre_dt, int E, int act, hipStream_t stream) {
+                              const float* w_r, void* pre, int pre_dt, int E, int act, void* dact_out, hipStream_t stream) {
     FB_REQUIRE(H % 4 == 0 && ldab % 4 == 0, "fabind_gcl_pre: H and ldab must be multiples of 4");
     if (E <= 0) return 0;
     hipLaunchKernelGGL(gcl_pre_kernel, dim3((E + 3) / 4), dim3(256), 0, stream, AB, ldab, H, row, col, rhohat, w_r, pre,
-                       pre_dt, E, act);
+                       pre_dt, E, act, dact_out);
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -114,6 +114,7 @@ __device__ __forceinline__ void gemm_epilogue(const FabindGemmArgs& p, f32x4_t (
                         long rr = p.r_index ? (long)p.r_index[a_row0 + row] : (a_row0 + row);
                         v += ((const float*)p.R)[(size_t)rr * p.ldr + col];
                     }
+                    if (p.C2) st_any(p.C2, p.c_dtype, (size_t)c_off + (size_t)row * ldc + col, apply_dact(vpre, p.act_epi));
                     if (staged) {
                         sOut[rowl * OUT_LD + coll] = f32_to_bf16(p.store_preact ? vpre : v);
                     } else if (p.C) {
@@ -184,7 +185,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(FabindGemmArgs p) {
     const TA* A = (const TA*)p.A + a_row0 * p.lda;
     const TA* A2 = p.A2 ? (const TA*)p.A2 + a_row0 * p.lda2 : nullptr;
     const TM* W = (const TM*)p.W + w_row0 * p.ldw;
-    const int K = p.K, K1 = p.K1;
+    int K = p.K;
+    const int K1 = p.K1;
+    int kbeg = 0;
+    if (!p.groups && p.k_splits > 1) {      // split-K: this work-group owns K range [kbeg, K)
+        const int per = ((p.K / p.k_splits + BK - 1) / BK) * BK;
+        kbeg = blockIdx.z * per;
+        K = min(p.K, kbeg + per);
+        c_off = (long)blockIdx.z * M * ldc;
+    }
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -226,14 +235,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(FabindGemmArgs p) {
         }
     };
 
-    const int nk = (K + BK - 1) / BK;
-    fetch(0);
+    const int nk = (K - kbeg + BK - 1) / BK;
+    fetch(kbeg);
     const int fr = lane & 15, fk = (lane >> 4) * 8;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();
         stash();
         __syncthreads();
-        if (kt + 1 < nk) fetch((kt + 1) * BK);
+        if (kt + 1 < nk) fetch(kbeg + (kt + 1) * BK);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const TM* ap = &sA[(wm * 64 + i * 16 + fr) * LS + fk];
@@ -381,7 +390,13 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_pipe_kernel(FabindGemmArgs
     const int wm = wave >> 1, wn = wave & 1;
     const bf16_t* A = (const bf16_t*)p.A + a_row0 * p.lda;
     const bf16_t* W = (const bf16_t*)p.W + w_row0 * p.ldw;
-    const int K = p.K;
+    int K = p.K, kbeg = 0;
+    if (!p.groups && p.k_splits > 1) {      // split-K over blockIdx.y (non-grouped launches are 1-D in x)
+        const int per = ((p.K / p.k_splits + BK_ - 1) / BK_) * BK_;
+        kbeg = blockIdx.y * per;
+        K = min(p.K, kbeg + per);
+        c_off = (long)blockIdx.y * M * ldc;
+    }
 
     const bf16_t* src[PPW];
     const bf16_t* src2[PPW];   // second K-segment of A (K-concatenated operand); W rows keep one segment
@@ -414,17 +429,17 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_pipe_kernel(FabindGemmArgs
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK_;
+    const int nk = max(0, (K - kbeg) / BK_);
     const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nk) stage(s, s * BK_);
+        if (s < nk) stage(s, kbeg + s * BK_);
     for (int kt = 0; kt < nk; ++kt) {
         // tiles kt+1 .. kt+NSTAGE-2 may stay in flight
         const int ahead = min(NSTAGE - 2, nk - 1 - kt);
         if (ahead >= 2) wait_vmcnt<2 * PPW>(); else if (ahead == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, (kt + NSTAGE - 1) * BK_);
+        if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, kbeg + (kt + NSTAGE - 1) * BK_);
         const bf16_t* tA = sT + (size_t)(kt % NSTAGE) * ROWS * BK_;
         const bf16_t* tB = tA + BM_ * BK_;
 #pragma unroll
@@ -462,7 +477,7 @@ static int launch_pipe(const FabindGemmArgs& p, int maxM, int maxN, hipStream_t 
         attr_set = true;
     }
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM_ - 1) / BM_, p.groups ? p.n_groups : 1);
-    if (!p.groups) grid = dim3(grid.x * grid.y, 1, 1);
+    if (!p.groups) grid = dim3(grid.x * grid.y, p.k_splits > 1 ? p.k_splits : 1, 1);
     hipLaunchKernelGGL((gemm_bf16_pipe_kernel<WM, BK_, NSTAGE>), grid, dim3(WM * 128), lds, stream, p);
     return 0;
 }
@@ -477,7 +492,13 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     FB_REQUIRE(!(p.w_dtype == FB_DT_BF16 && (p.ldw % 8 != 0)), "fabind_gemm: bf16 W needs ldw % 8 == 0");
     int maxM = p.groups ? p.max_m : p.M, maxN = p.groups ? p.max_n : p.N;
     if (maxM <= 0 || maxN <= 0) return 0;
-    dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, p.groups ? p.n_groups : 1);
+    dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, p.groups ? p.n_groups : (p.k_splits > 1 ? p.k_splits : 1));
+    if (p.k_splits > 1) {
+        FB_REQUIRE(!p.groups && p.c_dtype == FB_DT_F32 && !p.bias && !p.R && !p.dotvec && !p.aux && !p.accumulate &&
+                       p.act_epi == FB_ACT_NONE && p.A2 == nullptr,
+                   "fabind_gemm: split-K needs a plain fp32 epilogue");
+        FB_REQUIRE(p.K % 64 == 0, "fabind_gemm: split-K needs K % 64 == 0");
+    }
     if (p.w_dtype == FB_DT_F32) {
         FB_REQUIRE(p.a_dtype == FB_DT_F32, "fabind_gemm: fp32 MMA needs fp32 A");
         hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, stream, p);
@@ -486,7 +507,7 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     } else if (p.act_pro == FB_ACT_NONE && p.K % FBK == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 &&
                ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) &&
                (p.A2 == nullptr || (g_gemm_cfg != 0 && p.K1 % FBK == 0 && p.lda2 % 8 == 0 && ((uintptr_t)p.A2 % 16 == 0)))) {
-        switch (g_gemm_cfg) {
+        switch ((p.k_splits > 1 && g_gemm_cfg == 0) ? 3 : g_gemm_cfg) {
             case 1: launch_pipe<2, 32, 4>(p, maxM, maxN, stream); break;
             case 2: launch_pipe<2, 64, 3>(p, maxM, maxN, stream); break;
             case 3: launch_pipe<4, 32, 3>(p, maxM, maxN, stream); break;

@@ -226,31 +226,23 @@ def _b16(t):
 
 
 def gcl_layer(p, h, x, lay, g, clampv):
-    """MC_E_GCL.forward (egnn.py:130-144): edge -> coord -> node, all from the layer's input h, x."""
+    """MC_E_GCL.forward (egnn.py:130-144): edge -> coord -> node, all from the layer's input h, x.
+
+    Producers apply the activations once (gcl_pre -> SiLU, GEMM epilogue -> SiLU); under autograd the same
+    kernels additionally emit the activation derivative, so every edge-level GEMM (forward and backward)
+    streams plain bf16 operands HBM -> LDS."""
     H = h.shape[1]
-    fast = _fast(h, x, p["W2"])
-    hin = _b16(h) if fast else h
+    ad = ops.act_dtype()
+    hin = _b16(h) if _fast(h, x, p["W2"]) else h
     AB = ops.linear(hin, p["W_ab"], p["b_ab"])                                         # [N,2H] node-level
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
-    if ops.needs_grad(h, x, p["W2"]):
-        # training form: keep pre-activations (the consumers apply SiLU while staging their operand)
-        pre = ops.gcl_pre(AB, H, g, rhohat, p["w_r"])                                   # [E,H]
-        Z2 = ops.linear(pre, p["W2"], p["b2"], act_pro=K.ACT_SILU, out_dtype=ops.act_dtype())
-        s = ops.linear_rowdot(Z2, p["Wc"], p["bc"], p["w3"], act_pro=K.ACT_SILU, act_epi=K.ACT_SILU)   # [E,nt]
-        agg = ops.segment_sum(Z2, g.rp_ctx, g.row_ctx, h.shape[0], act=K.ACT_SILU)
-    else:
-        # forward-only form: producers apply SiLU once, the edge GEMMs stream bf16 operands HBM->LDS directly
-        S1 = ops.gcl_pre(AB, H, g, rhohat, p["w_r"], act=K.ACT_SILU)
-        Mm = ops.linear(S1, p["W2"], p["b2"], act_epi=K.ACT_SILU, out_dtype=ops.act_dtype())
-        s = ops.linear_rowdot(Mm, p["Wc"], p["bc"], p["w3"], act_epi=K.ACT_SILU)
-        agg = ops.segment_sum(Mm, g.rp_ctx, g.row_ctx, h.shape[0], act=K.ACT_NONE)
+    S1 = ops.gcl_pre(AB, H, g, rhohat, p["w_r"], act=K.ACT_SILU)                        # [E,H] silu(first edge Linear)
+    Mm = ops.linear(S1, p["W2"], p["b2"], act_epi=K.ACT_SILU, out_dtype=ad)             # [E,H] messages m_e
+    s = ops.linear_rowdot(Mm, p["Wc"], p["bc"], p["w3"], act_epi=K.ACT_SILU)            # [E,nt] coord_mlp
     x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
-    if fast:
-        t = ops.linear(hin, p["Wn1"], p["bn1"], x2=_b16(agg), act_epi=K.ACT_SILU, out_dtype=torch.bfloat16)
-        h_new = ops.linear(t, p["Wn2"], p["bn2"], residual=h)
-    else:
-        t = ops.linear(h, p["Wn1"], p["bn1"], x2=agg)
-        h_new = ops.linear(t, p["Wn2"], p["bn2"], act_pro=K.ACT_SILU, residual=h)
+    agg = ops.segment_sum(Mm, g.rp_ctx, g.row_ctx, h.shape[0], act=K.ACT_NONE)
+    t = ops.linear(hin, p["Wn1"], p["bn1"], x2=agg, act_epi=K.ACT_SILU, out_dtype=ad)
+    h_new = ops.linear(t, p["Wn2"], p["bn2"], residual=h)
     return h_new, x_new
 
 

@@ -5,11 +5,11 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, GemmArgs, check, dt_code, ptr, stream
+from ._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SILU, ACT_STORED_DERIV, GemmArgs, check, dt_code, ptr, stream
 
 __all__ = ["gemm", "transpose_act", "colsum", "edges_count", "edges_fill", "exclusive_scan", "inter_meta",
            "edge_geom", "gcl_pre", "segment_sum", "coord_update", "cross_attn_fwd", "pair_bmat", "pair_hadamard",
-           "inter_attn_fwd", "las_step", "select_rows", "ACT_NONE", "ACT_SILU", "ACT_RELU", "ACT_SIGMOID"]
+           "inter_attn_fwd", "las_step", "select_rows", "ACT_NONE", "ACT_SILU", "ACT_RELU", "ACT_SIGMOID", "ACT_STORED_DERIV"]
 
 GEMM_BN = 128
 PROFILE = None  # dict -> per-(M,N,K,dtypes) list of (start,end) HIP events around every GEMM launch (bench.py)
@@ -22,7 +22,8 @@ def _ld(t):
 
 def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=None, r_index=None,
          out=None, out_dtype=torch.float32, want_out=True, dotvec=None, aux=None, dact=ACT_NONE, alpha=1.0,
-         accumulate=False, groups=None, n_groups=0, max_m=0, max_n=0, M=None, N=None, ldc=None):
+         accumulate=False, groups=None, n_groups=0, max_m=0, max_n=0, M=None, N=None, ldc=None, k_splits=1,
+         out2=None):
     """C = epi(pro([A|A2]) @ W^T); see FabindGemmArgs.  Returns (C or None, dot_partials or None).
 
     `groups` (int32 [G,8] device tensor) selects the ragged-batched mode; then `out` must be given."""
@@ -34,7 +35,9 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     N = W.shape[0] if N is None else N
     assert W.shape[1] == K, "gemm: K mismatch %s vs %s" % (tuple(W.shape), K)
     if want_out and out is None:
-        out = torch.empty((M, N), dtype=out_dtype, device=A.device)
+        out = torch.empty((k_splits, M, N) if k_splits > 1 else (M, N), dtype=out_dtype, device=A.device)
+        if k_splits > 1:
+            ldc = N
     dot_out = None
     if dotvec is not None:
         nt = (N + GEMM_BN - 1) // GEMM_BN
@@ -43,6 +46,7 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     a.A, a.A2, a.W, a.C = ptr(A), ptr(A2), ptr(W), ptr(out) if want_out else None
     a.bias, a.R, a.r_index = ptr(bias), ptr(residual), ptr(r_index)
     a.dotvec, a.dot_out, a.aux, a.groups = ptr(dotvec), ptr(dot_out), ptr(aux), ptr(groups)
+    a.C2 = ptr(out2)
     a.M, a.N, a.K, a.K1 = M, N, K, K1
     a.lda, a.lda2, a.ldw = _ld(A), (_ld(A2) if A2 is not None else 0), _ld(W)
     a.ldc = (ldc if ldc is not None else (_ld(out) if want_out else 0))
@@ -56,6 +60,7 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     a.act_pro, a.act_epi, a.dact_epi = act_pro, act_epi, dact
     a.accumulate = 1 if accumulate else 0
     a.n_groups, a.max_m, a.max_n = n_groups, max_m, max_n
+    a.k_splits = k_splits
     a.alpha = alpha
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -143,12 +148,13 @@ def edge_geom(x, row, col, rowptr, node_off, B):
     return d[:E], rho[:E], rhohat[:E], norm
 
 
-def gcl_pre(AB, H, row, col, rhohat, w_r, out_dtype, act=ACT_NONE):
+def gcl_pre(AB, H, row, col, rhohat, w_r, out_dtype, act=ACT_NONE, want_dact=False):
     E = row.shape[0]
     pre = torch.empty((E, H), dtype=out_dtype, device=AB.device)
+    dact = torch.empty((E, H), dtype=out_dtype, device=AB.device) if want_dact else None
     check(_lib.load().fabind_gcl_pre(ptr(AB), _ld(AB), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r), ptr(pre),
-                                     dt_code(out_dtype), E, act, stream()), "fabind_gcl_pre")
-    return pre
+                                     dt_code(out_dtype), E, act, ptr(dact), stream()), "fabind_gcl_pre")
+    return (pre, dact) if want_dact else pre
 
 
 def segment_sum(Z, rowptr, n_rows, act=ACT_NONE, eidx=None, out=None):

@@ -29,18 +29,21 @@ def needs_grad(*ts):
     return _needs_grad(*ts)
 
 
-def _pad8(n):
-    return (n + 63) // 64 * 64      # K of the weight-gradient GEMMs: multiple of 64 keeps them on the LDS-DMA path
-
-
 def _nchunk(rows):
     return max(1, min(256, (rows + 1023) // 1024))
 
 
-def _transposed(x, act=K.ACT_NONE):
-    """act(x)^T as an mm-dtype [C, pad8(R)] matrix (zero padded) for K=R contractions."""
+def _ksplit(R):
+    """(splits, padded K) for a contraction over R rows (weight gradients: tiny M x N, huge K)."""
+    S = max(1, min(128, R // 4096))
+    unit = 64 * S
+    return S, (R + unit - 1) // unit * unit
+
+
+def _transposed(x, act=K.ACT_NONE, Rp=None):
+    """act(x)^T as an mm-dtype [C, Rp] matrix (zero padded) for K=R contractions."""
     R, C = x.shape
-    Rp = _pad8(R)
+    Rp = Rp or _ksplit(R)[1]
     out = torch.empty((C, Rp), dtype=mm_dtype(), device=x.device)
     if Rp != R:
         out[:, R:].zero_()
@@ -50,73 +53,102 @@ def _transposed(x, act=K.ACT_NONE):
 
 
 def _weight_grad(dpre, x, act_pro, x2=None):
-    """dW = dpre^T [act(x) | x2]  as NT GEMMs over the (padded) row dimension."""
-    dpt = _transposed(dpre)
-    xt = _transposed(x, act_pro)
+    """dW = dpre^T [act(x) | x2]  as split-K NT GEMMs over the (padded) row dimension."""
+    S, Rp = _ksplit(dpre.shape[0])
+    dpt = _transposed(dpre, Rp=Rp)
+    xt = _transposed(x, act_pro, Rp=Rp)
     if x2 is not None:
-        xt = torch.cat([xt, _transposed(x2)], 0)
-    dW, _ = K.gemm(dpt, xt)
-    return dW
+        xt = torch.cat([xt, _transposed(x2, Rp=Rp)], 0)
+    if S == 1:
+        return K.gemm(dpt, xt)[0]
+    part, _ = K.gemm(dpt, xt, k_splits=S)                                  # [S, N, K] fp32 partials
+    return K.colsum(part.reshape(S, -1)).reshape(part.shape[1], part.shape[2])
 
 
 # ------------------------------------------------------------------------------------------------
-# linear:  y = act_epi( act_pro([x|x2]) W^T + b ) (+ residual)
+# linear:  y = act_epi( [x|x2] W^T + b ) (+ residual)
+# Under autograd the kernel also emits act_epi'(pre-activation) (SiLU) so that backward is a plain multiply,
+# and fp32 activations are fed to the MFMA kernels as bf16 copies in bf16 mode (also what is saved).
 # ------------------------------------------------------------------------------------------------
+def _mul_dact(dy, aux, act, out_dtype):
+    out = torch.empty(dy.shape, dtype=out_dtype, device=dy.device)
+    a = aux if aux is not None else dy
+    check(load().fabind_mul_dact(ptr(dy), dt_code(dy.dtype), ptr(a), dt_code(a.dtype), act, ptr(out), dt_code(out_dtype),
+                                 dy.numel(), stream()), "fabind_mul_dact")
+    return out
+
+
+def _mm_in(x):
+    """Operand as the GEMM wants it: bf16 copy of an fp32 activation in bf16 mode."""
+    if x is not None and _cfg.get_precision() == "bf16" and x.dtype == torch.float32:
+        return x.to(torch.bfloat16)
+    return x
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, x2, residual, act_pro, act_epi, out_dtype):
-        y, _ = K.gemm(x, W, bias=b, A2=x2, act_pro=act_pro, act_epi=act_epi, residual=residual, out_dtype=out_dtype)
-        ctx.act_pro, ctx.act_epi = act_pro, act_epi
+    def forward(ctx, x, W, b, x2, residual, act_epi, out_dtype):
+        assert act_epi in (K.ACT_NONE, K.ACT_RELU, K.ACT_SILU)
+        xin, x2in = _mm_in(x), _mm_in(x2)
+        D = None
+        M, N = x.shape[0], W.shape[0]
+        y = torch.empty((M, N), dtype=out_dtype, device=x.device)
+        if act_epi == K.ACT_SILU:
+            D = torch.empty((M, N), dtype=out_dtype, device=x.device)
+        K.gemm(xin, W, bias=b, A2=x2in, act_epi=act_epi, residual=residual, out=y, out2=D)
+        ctx.act_epi, ctx.x_dtype = act_epi, x.dtype
+        ctx.x2_dtype = x2.dtype if x2 is not None else None
         ctx.has_b, ctx.has_res, ctx.has_x2 = b is not None, residual is not None, x2 is not None
-        assert act_epi in (K.ACT_NONE, K.ACT_RELU), "linear: only ReLU may be fused as an output activation under autograd"
-        assert not (act_epi != K.ACT_NONE and residual is not None)
-        assert not (act_pro != K.ACT_NONE and x2 is not None)
-        ctx.save_for_backward(x, W, x2, y if act_epi == K.ACT_RELU else None)
+        ctx.save_for_backward(xin, W, x2in, y if act_epi == K.ACT_RELU else None, D)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W, x2, y = ctx.saved_tensors
+        x, W, x2, y, D = ctx.saved_tensors
         dy = dy.contiguous()
-        if ctx.act_epi == K.ACT_RELU:   # dPre = dy * (y > 0): ReLU'(pre) == ReLU'(y)
-            dpre = torch.empty_like(dy)
-            check(load().fabind_mul_dact(ptr(dy), dt_code(dy.dtype), ptr(y), dt_code(y.dtype), K.ACT_RELU, ptr(dpre),
-                                         dt_code(dpre.dtype), dy.numel(), stream()), "fabind_mul_dact")
+        md = mm_dtype()
+        if ctx.act_epi == K.ACT_RELU:
+            dpre = _mul_dact(dy, y, K.ACT_RELU, md)
+        elif ctx.act_epi == K.ACT_SILU:
+            dpre = _mul_dact(dy, D, K.ACT_STORED_DERIV, md)
+        elif dy.dtype != md:
+            dpre = _mul_dact(dy, None, K.ACT_NONE, md)            # dtype conversion only
         else:
             dpre = dy
-        K1 = x.shape[1]
+        K1, N = x.shape[1], W.shape[0]
         dx = dx2 = dW = db = None
         if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[3]):
-            N = W.shape[0]
             if N % 8 == 0:
-                Wt = W.t().contiguous()                                 # [K, N] (parameter-only transpose)
+                Wt, dmm = W.t().contiguous(), dpre                      # [K, N] (parameter-only transpose)
             else:                                                       # tiny heads (N = 1): pad the contraction dim to 8
                 Np = (N + 7) // 8 * 8
                 Wt = torch.zeros((W.shape[1], Np), dtype=W.dtype, device=W.device)
                 Wt[:, :N] = W.t()
-                dpad = torch.zeros((dpre.shape[0], Np), dtype=dpre.dtype, device=dpre.device)
-                dpad[:, :N] = dpre
-                dpre_mm = dpad
-            dpre_mm = dpre if N % 8 == 0 else dpre_mm
+                dmm = torch.zeros((dpre.shape[0], Np), dtype=dpre.dtype, device=dpre.device)
+                dmm[:, :N] = dpre
+            dfull, _ = K.gemm(dmm, Wt, out_dtype=torch.float32 if ctx.x_dtype == torch.float32 else ctx.x_dtype)
             if ctx.has_x2:
-                dfull, _ = K.gemm(dpre_mm, Wt)
                 dx, dx2 = dfull[:, :K1], dfull[:, K1:]
+                if ctx.x2_dtype != dx2.dtype:
+                    dx2 = dx2.to(ctx.x2_dtype)
             else:
-                dx, _ = K.gemm(dpre_mm, Wt, aux=x if ctx.act_pro != K.ACT_NONE else None, dact=ctx.act_pro, out_dtype=x.dtype)
+                dx = dfull
         if ctx.needs_input_grad[1]:
-            dW = _weight_grad(dpre, x, ctx.act_pro, x2).to(W.dtype)
+            dW = _weight_grad(dpre, x, K.ACT_NONE, x2).to(W.dtype)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = K.colsum(dpre)
         dres = dy.float() if (ctx.has_res and ctx.needs_input_grad[4]) else None
-        return dx, dW, db, dx2, dres, None, None, None
+        return dx, dW, db, dx2, dres, None, None
 
 
 def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, x2=None, out_dtype=torch.float32):
     if x.stride(-1) != 1:
         x = x.contiguous()
     if _needs_grad(x, W, b, x2, residual):
-        return _Linear.apply(x, W, b, x2, residual, act_pro, act_epi, out_dtype)
-    y, _ = K.gemm(x, W, bias=b, A2=x2, act_pro=act_pro, act_epi=act_epi, residual=residual, out_dtype=out_dtype)
+        assert act_pro == K.ACT_NONE, "producer-side activations only under autograd"
+        return _Linear.apply(x, W, b, x2, residual, act_epi, out_dtype)
+    y, _ = K.gemm(_mm_in(x), W, bias=b, A2=_mm_in(x2), act_pro=act_pro, act_epi=act_epi, residual=residual,
+                  out_dtype=out_dtype)
     return y
 
 
@@ -166,9 +198,10 @@ class _LinearRowdot(torch.autograd.Function):
         du = torch.empty(N, dtype=torch.float32, device=z.device)
         check(load().fabind_rowdot_bwd(ptr(z), dt_code(z.dtype), ptr(dpart), dpart.shape[1], ptr(u), ctx.act_epi, M, N,
                                        ptr(dz), ptr(du), ptr(scratch), nchunk, stream()), "fabind_rowdot_bwd")
+        assert ctx.act_pro == K.ACT_NONE
         Wt = W.t().contiguous()
-        dx, _ = K.gemm(dz, Wt, aux=x if ctx.act_pro != K.ACT_NONE else None, dact=ctx.act_pro, out_dtype=x.dtype)
-        dW = _weight_grad(dz, x, ctx.act_pro).to(W.dtype)
+        dx, _ = K.gemm(dz, Wt, out_dtype=x.dtype)
+        dW = _weight_grad(dz, x, K.ACT_NONE).to(W.dtype)
         db = K.colsum(dz)
         return dx, dW, db, du, None, None
 
@@ -212,34 +245,38 @@ def edge_geom(x, row, col, rowptr, lay):
 
 class _GclPre(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, AB, rhohat, w_r, H, g):
-        ctx.H, ctx.g = H, g
-        ctx.save_for_backward(AB, rhohat, w_r)
-        return K.gcl_pre(AB, H, g.row_ctx, g.col_ctx, rhohat, w_r, act_dtype())
+    def forward(ctx, AB, rhohat, w_r, H, g, act):
+        ctx.H, ctx.g, ctx.act = H, g, act
+        if act == K.ACT_NONE:
+            out, D = K.gcl_pre(AB, H, g.row_ctx, g.col_ctx, rhohat, w_r, act_dtype()), None
+        else:
+            out, D = K.gcl_pre(AB, H, g.row_ctx, g.col_ctx, rhohat, w_r, act_dtype(), act, want_dact=True)
+        ctx.save_for_backward(AB, rhohat, w_r, D)
+        return out
 
     @staticmethod
-    def backward(ctx, dpre):
-        AB, rhohat, w_r = ctx.saved_tensors
+    def backward(ctx, dout):
+        AB, rhohat, w_r, D = ctx.saved_tensors
         H, g = ctx.H, ctx.g
         E, N = g.row_ctx.shape[0], AB.shape[0]
-        dpre = dpre.contiguous()
+        dout = dout.contiguous()
+        dpre = dout if D is None else _mul_dact(dout, D, K.ACT_STORED_DERIV, dout.dtype)
         dAB = torch.empty((N, 2 * H), dtype=torch.float32, device=AB.device)
         K.segment_sum(dpre, g.rp_ctx, N, out=dAB[:, :H])                      # receiving side: rows are CSR segments
         colptr, perm = g.ctx_by_col()
         K.segment_sum(dpre, colptr, N, eidx=perm, out=dAB[:, H:])             # sending side: permuted segments
         drh = torch.empty(E, dtype=torch.float32, device=AB.device)
-        nchunk = _nchunk(E)
+        nchunk = max(1, min(2048, (E + 255) // 256))
         scratch = torch.empty((nchunk, H), dtype=torch.float32, device=AB.device)
         dw = torch.empty(H, dtype=torch.float32, device=AB.device)
         check(load().fabind_gcl_pre_bwd(ptr(dpre), dt_code(dpre.dtype), H, ptr(rhohat), ptr(w_r), E, ptr(drh), ptr(dw),
                                         ptr(scratch), nchunk, stream()), "fabind_gcl_pre_bwd")
-        return dAB, drh, dw, None, None
+        return dAB, drh, dw, None, None, None
 
 
 def gcl_pre(AB, H, g, rhohat, w_r, act=K.ACT_NONE):
     if _needs_grad(AB, rhohat, w_r):
-        assert act == K.ACT_NONE
-        return _GclPre.apply(AB, rhohat, w_r, H, g)
+        return _GclPre.apply(AB, rhohat, w_r, H, g, act)
     return K.gcl_pre(AB, H, g.row_ctx, g.col_ctx, rhohat, w_r, act_dtype(), act)
 
 

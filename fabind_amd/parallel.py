@@ -1,0 +1,92 @@
+"""Data-parallel training step: one process per GPU, complexes sharded across ranks, one gradient
+all-reduce per step over RCCL/xGMI (torch.distributed backend "nccl" is RCCL on ROCm).
+
+Replaces accelerate -> torch DDP (reference main_fabind.py:194-195, 289-296, 419-423):
+  * DDP semantics are kept: the result is the MEAN over ranks of the per-rank gradients (each rank's loss
+    is a mean over its own atoms / pairs / residues -- SURVEY.md section 4, 8(e)); do not "fix" this.
+  * 33 parameter tensors never receive a gradient (att_i.inter_layer.*, pocket model out_layer.coord_mlp.*;
+    the reference needs find_unused_parameters=True).  Here every rank packs the SAME flat buffer over
+    all trainable parameters and fills missing gradients with zeros, so no graph inspection is needed.
+  * xGMI is point-to-point (7 links x ~153 GB/s): the 145 MB fp32 gradient is sent as a few large buckets
+    (default 64 MB) so that RCCL can use reduce-scatter + all-gather across all links; the collective is
+    issued on RCCL's own stream and overlaps with the packing of the next bucket.
+  * gradient clipping (max_norm 1.0) happens after the all-reduce on the full gradient (main_fabind.py:420-423).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_complexes(n_complexes, rank, world):
+    """Contiguous, balanced shard [lo, hi) of a global batch of complexes for `rank`."""
+    base, rem = divmod(n_complexes, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _buckets(params, bucket_bytes):
+    cur, size = [], 0
+    for p in params:
+        n = p.numel() * 4
+        if cur and size + n > bucket_bytes:
+            yield cur
+            cur, size = [], 0
+        cur.append(p)
+        size += n
+    if cur:
+        yield cur
+
+
+def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, group=None):
+    """Average .grad of `params` over all ranks (flat fp32 buckets; missing grads count as zeros)."""
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    params = [p for p in params if p.requires_grad]
+    if world == 1:
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        return
+    pending = []
+    for bucket in _buckets(params, bucket_bytes):
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        pending.append((bucket, flat, work))
+    for bucket, flat, work in pending:
+        work.wait()
+        flat.div_(world)
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+
+
+def clip_grad_norm_(params, max_norm=1.0):
+    """torch.nn.utils.clip_grad_norm_ semantics on the (already all-reduced) gradients."""
+    grads = [p.grad for p in params if p.grad is not None]
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g.float()) for g in grads]))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for g in grads:
+        g.mul_(coef.to(g.dtype))
+    return total
+
+
+def train_step(model, data, optimizer, compute_loss, world=1, clip=1.0, stage=1):
+    """One DP step with the reference's order: forward, NaN guard, 6-term loss, backward, all-reduce,
+    clip, optimizer step (main_fabind.py:392-426).  Returns (loss, terms) or None when the batch is skipped."""
+    out = model(data, stage=stage, train=True)
+    if any(torch.isnan(t).any() for t in (out[0], out[2], out[3], out[4], out[8])):
+        return None
+    loss, terms = compute_loss(out, data)
+    optimizer.zero_grad(set_to_none=True)
+    loss.backward()
+    params = [p for p in model.parameters() if p.requires_grad]
+    allreduce_gradients(params, world)
+    if clip:
+        clip_grad_norm_(params, clip)
+    optimizer.step()
+    return loss.detach(), {k: v.detach() for k, v in terms.items()}

@@ -5,7 +5,7 @@
  * those ops named in its comment (paths relative to the reference's FABind/fabind directory).  Plain pointers
  * and sizes only: every pointer is a DEVICE pointer unless stated otherwise, `stream` is a
  * hipStream_t, dtype codes are FB_DT_F32 = 0 / FB_DT_BF16 = 1 (raw bfloat16 bits), activation
- * codes FB_ACT_NONE/SILU/RELU/SIGMOID = 0..3.  Every function returns 0 on success, non-zero on
+ * codes FB_ACT_NONE/SILU/RELU/SIGMOID = 0..3 (4 = FB_ACT_STORED_DERIV: the aux operand already is the derivative).  Every function returns 0 on success, non-zero on
  * error (message via fabind_last_error()); none of them synchronises or allocates.
  *
  * Node layout contract: nodes are complex-contiguous in the fixed order
@@ -52,6 +52,7 @@ typedef struct FabindGemmArgs {
     float* dot_out;
     const void* aux;
     const int* groups;
+    void* C2; /* optional second output: act_epi'(pre-activation), same dtype/ld as C (saved for backward) */
     int M, N, K, K1;
     int lda, lda2, ldw, ldc, ldr, ldaux, dot_ld;
     int a_dtype, w_dtype, c_dtype, aux_dtype;
@@ -59,6 +60,7 @@ typedef struct FabindGemmArgs {
     int accumulate;
     int store_preact; /* C receives the value BEFORE act_epi (row-dot still sees act_epi(v)) */
     int n_groups, max_m, max_n;
+    int k_splits; /* >1: split the K loop over k_splits work-groups; C must be fp32 [k_splits, M, N] partials */
     float alpha;
 } FabindGemmArgs;
 
@@ -117,7 +119,7 @@ int fabind_edge_geom(const float* x, const int* row, const int* col, const int* 
  *           s[e] = sum_k s_part[e,k] (row-dot partials written by fabind_gemm).
  * -------------------------------------------------------------------------------------------*/
 int fabind_gcl_pre(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
-                   const float* w_r, void* pre, int pre_dt, int E, int act, hipStream_t stream);
+                   const float* w_r, void* pre, int pre_dt, int E, int act, void* dact_out, hipStream_t stream);
 int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, const int* eidx, int n_rows, int act,
                        float* out, int ldo, hipStream_t stream);
 int fabind_coord_update(const float* x, const float* d, const float* s_part, int n_part, const float* weight,
