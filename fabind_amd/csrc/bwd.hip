@@ -9,13 +9,21 @@
 // out = dy * act'(y)   (elementwise; for ReLU the derivative can be taken at the output)
 // ------------------------------------------------------------------------------------------------
 __global__ void mul_dact_kernel(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, long n) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) st_any(out, out_dt, i, ld_any(dy, dy_dt, i) * apply_dact(ld_any(y, y_dt, i), act));
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) {   // 4 elements per thread (8/16-byte accesses)
+        float4 g = ld4_any(dy, dy_dt, i), v = ld4_any(y, y_dt, i);
+        st4_any(out, out_dt, i, make_float4(g.x * apply_dact(v.x, act), g.y * apply_dact(v.y, act),
+                                            g.z * apply_dact(v.z, act), g.w * apply_dact(v.w, act)));
+    } else {
+        for (; i < n; ++i) st_any(out, out_dt, i, ld_any(dy, dy_dt, i) * apply_dact(ld_any(y, y_dt, i), act));
+    }
 }
 extern "C" int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, long n,
                                hipStream_t stream) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(mul_dact_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, dy, dy_dt, y, y_dt, act,
+    FB_REQUIRE(((uintptr_t)dy % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)out % 16 == 0), "fabind_mul_dact: 16-byte alignment");
+    long nt = (n + 3) / 4;
+    hipLaunchKernelGGL(mul_dact_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, stream, dy, dy_dt, y, y_dt, act,
                        out, out_dt, n);
     FB_CHECK_LAUNCH();
     return 0;

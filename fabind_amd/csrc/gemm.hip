@@ -555,18 +555,34 @@ extern "C" int fabind_transpose_act(const void* in, int in_dt, int ldi, void* ou
 }
 
 // column sums of a [R,C] matrix (bias gradients): deterministic two-pass (chunk partials, then fixed-order sum)
-__global__ void colsum_part_kernel(const void* in, int in_dt, int ldi, float* scratch, int R, int C, int rows_per) {
-    __shared__ float part[4][64];
-    int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
-    int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
-    float s = 0.f;
-    if (c < C)
-        for (int r = r0 + q; r < r1; r += 4) s += ld_any(in, in_dt, (size_t)r * ldi + c);
-    part[q][threadIdx.x & 63] = s;
+__global__ __launch_bounds__(256) void colsum_part_kernel(const void* in, int in_dt, int ldi, float* scratch, int R, int C,
+                                                          int rows_per) {
+    // one block = 256 columns (64 lanes x 4 consecutive columns) x 4 row-lanes; fixed-order combine in LDS
+    __shared__ float4 part[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool vec = (c + 3 < C) && (ldi % 4 == 0);
+    if (vec) {
+        for (int r = r0 + q; r < r1; r += 4) {
+            float4 v = ld4_any(in, in_dt, (size_t)r * ldi + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    } else if (c < C) {
+        for (int r = r0 + q; r < r1; r += 4) {
+            s.x += ld_any(in, in_dt, (size_t)r * ldi + c);
+            if (c + 1 < C) s.y += ld_any(in, in_dt, (size_t)r * ldi + c + 1);
+            if (c + 2 < C) s.z += ld_any(in, in_dt, (size_t)r * ldi + c + 2);
+            if (c + 3 < C) s.w += ld_any(in, in_dt, (size_t)r * ldi + c + 3);
+        }
+    }
+    part[q][lane] = s;
     __syncthreads();
     if (q == 0 && c < C) {
-        int l = threadIdx.x;
-        scratch[(size_t)blockIdx.y * C + c] = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
+        float4 a = part[0][lane], b = part[1][lane], d = part[2][lane], e = part[3][lane];
+        float o[4] = {(a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w)};
+        for (int k = 0; k < 4 && c + k < C; ++k) scratch[(size_t)blockIdx.y * C + c + k] = o[k];
     }
 }
 __global__ void colsum_final_kernel(const float* scratch, float* out, int C, int nchunk, int accumulate) {
@@ -583,7 +599,7 @@ extern "C" int fabind_colsum(const void* in, int in_dt, int ldi, float* out, int
     FB_REQUIRE(nchunk >= 1, "fabind_colsum: nchunk >= 1");
     int rows_per = (R + nchunk - 1) / nchunk;
     if (rows_per < 1) rows_per = 1;
-    hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 63) / 64, nchunk), dim3(256), 0, stream, in, in_dt, ldi, scratch, R,
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 255) / 256, nchunk), dim3(256), 0, stream, in, in_dt, ldi, scratch, R,
                        C, rows_per);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, out, C, nchunk,
                        accumulate);
