@@ -188,7 +188,7 @@ def main():
         peak = MFMA_PEAK_TFLOPS[a.precision]
         out["roofline"] = {"bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": peak, "unit": "TFLOP/s",
                            "frac": flops / avg_s / 1e12 / peak, "traffic": None,
-                           "kernel": "gemm_nt_kernel<%s,%s> M=%d N=%d K=%d (edge MLP)" % (adt, wdt, M, N, Kd),
+                           "kernel": "fabind_gemm <%s,%s> M=%d N=%d K=%d (edge-MLP contraction; bf16 -> gemm_bf16_pipe_kernel<4,32,3>)" % (adt, wdt, M, N, Kd),
                            "launches": cnt, "avg_us": avg_s * 1e6,
                            "share_of_step": ms / (1e3 * dt)}
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
