@@ -20,7 +20,7 @@ class GemmArgs(ctypes.Structure):
     _fields_ = [(n, _vp) for n in ("A", "A2", "W", "C", "bias", "R", "r_index", "dotvec", "dot_out", "aux", "groups", "C2")] + \
                [(n, _i) for n in ("M", "N", "K", "K1", "lda", "lda2", "ldw", "ldc", "ldr", "ldaux", "dot_ld",
                                   "a_dtype", "w_dtype", "c_dtype", "aux_dtype", "act_pro", "act_epi", "dact_epi",
-                                  "accumulate", "store_preact", "n_groups", "max_m", "max_n", "k_splits")] + [("alpha", _f)]
+                                  "accumulate", "store_preact", "n_groups", "max_m", "max_n", "epi_fast", "k_splits")] + [("alpha", _f)]
 
 
 # name -> argtypes (every function returns int and takes the stream last)
@@ -79,6 +79,8 @@ def load():
     lib.fabind_abi_version.restype = ctypes.c_int
     lib.fabind_gemm_set_config.argtypes = [ctypes.c_int]
     lib.fabind_gemm_set_config.restype = None
+    lib.fabind_gemm_set_persistent.argtypes = [ctypes.c_int]
+    lib.fabind_gemm_set_persistent.restype = None
     for name, argt in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = argt

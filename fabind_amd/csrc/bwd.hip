@@ -711,35 +711,51 @@ __global__ __launch_bounds__(256) void pair_bias_bwd_a_kernel(const float* __res
             if (i0 + ii < P) dab[(size_t)p_index[p_off + i0 + ii] * ld + h] += acc[ii];
     }
 }
+#define PB_JT 4
 __global__ __launch_bounds__(256) void pair_bias_bwd_b_kernel(const float* __restrict__ dout, const float* __restrict__ ab,
                                                               int ld, int H, const float* __restrict__ w, const int* desc,
                                                               const int* p_index, const int* c_index, float* dab,
                                                               float* dwk) {
+    // block = PB_JT ligand-side nodes of one complex; threads over h; a0[i,h] is read once per PB_JT columns
     const int b = blockIdx.y;
     const int* ds = desc + b * 8;
     const int p_off = ds[0], P = ds[1], c_off = ds[2], C = ds[3];
     const long pair_off = (long)(unsigned)ds[4] | ((long)ds[5] << 32);
-    const int j = blockIdx.x;
-    if (j >= C) return;
-    const int cn = c_index[c_off + j];
+    const int j0 = blockIdx.x * PB_JT;
+    if (j0 >= C) return;
     for (int h = threadIdx.x; h < H; h += 256) {
-        float T[8];
+        float T[PB_JT][8];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) T[o] = 0.f;
+        for (int jj = 0; jj < PB_JT; ++jj)
+#pragma unroll
+            for (int o = 0; o < 8; ++o) T[jj][o] = 0.f;
         for (int i = 0; i < P; ++i) {
             const float ai = ab[(size_t)p_index[p_off + i] * ld + h];
-            const float* Dp = dout + ((size_t)pair_off + (size_t)i * C + j) * 8;
+            const float* Dp = dout + ((size_t)pair_off + (size_t)i * C + j0) * 8;
 #pragma unroll
-            for (int o = 0; o < 8; ++o) T[o] += Dp[o] * ai;
+            for (int jj = 0; jj < PB_JT; ++jj) {
+                if (j0 + jj < C) {
+                    const float4 d0 = *(const float4*)(Dp + jj * 8), d1 = *(const float4*)(Dp + jj * 8 + 4);
+                    T[jj][0] += d0.x * ai; T[jj][1] += d0.y * ai; T[jj][2] += d0.z * ai; T[jj][3] += d0.w * ai;
+                    T[jj][4] += d1.x * ai; T[jj][5] += d1.y * ai; T[jj][6] += d1.z * ai; T[jj][7] += d1.w * ai;
+                }
+            }
         }
-        const float bj = ab[(size_t)cn * ld + H + h];
-        float db = 0.f;
+        float wv[8], dwa[8];
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            db += w[o * H + h] * T[o];
-            atomicAdd(&dwk[((size_t)b * 8 + o) * H + h], bj * T[o]);   // C adds per element (order-insensitive to rounding)
+        for (int o = 0; o < 8; ++o) { wv[o] = w[o * H + h]; dwa[o] = 0.f; }
+#pragma unroll
+        for (int jj = 0; jj < PB_JT; ++jj) {
+            if (j0 + jj >= C) break;
+            const int cn = c_index[c_off + j0 + jj];
+            const float bj = ab[(size_t)cn * ld + H + h];
+            float db = 0.f;
+#pragma unroll
+            for (int o = 0; o < 8; ++o) { db += wv[o] * T[jj][o]; dwa[o] += bj * T[jj][o]; }
+            dab[(size_t)cn * ld + H + h] += db;
         }
-        dab[(size_t)cn * ld + H + h] += db;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) atomicAdd(&dwk[((size_t)b * 8 + o) * H + h], dwa[o]);   // C/PB_JT adds per element
     }
 }
 extern "C" int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, int ld, int H, const float* w,
@@ -749,7 +765,7 @@ extern "C" int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, 
     if (B <= 0) return 0;
     hipLaunchKernelGGL(pair_bias_bwd_a_kernel, dim3((max_P + 7) / 8, B), dim3(256), 0, stream, dout, ab, ld, H, w, desc_p,
                        p_index, c_index, dab);
-    hipLaunchKernelGGL(pair_bias_bwd_b_kernel, dim3(max_C, B), dim3(256), 0, stream, dout, ab, ld, H, w, desc_p, p_index,
+    hipLaunchKernelGGL(pair_bias_bwd_b_kernel, dim3((max_C + PB_JT - 1) / PB_JT, B), dim3(256), 0, stream, dout, ab, ld, H, w, desc_p, p_index,
                        c_index, dab, dwk);
     FB_CHECK_LAUNCH();
     return 0;

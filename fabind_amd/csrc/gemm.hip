@@ -79,7 +79,7 @@ template <> __device__ __forceinline__ void mma_k32<float>(f32x4_t& acc, const f
 // BM_ = rows of the block tile (64 per wave-row).  sDot: float[2][BM_].  sOut (optional): bf16 staging
 // tile [BM_][BN+8] in LDS so that bf16 outputs leave as whole 16-B chunks of a row instead of 2-B scalars.
 #define OUT_LD (BN + 8)
-template <int BM_>
+template <int BM_, bool RAW_BARRIER = false>
 __device__ __forceinline__ void gemm_epilogue(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sDot, bf16_t* sOut,
                                               int M, int N, int ldc, long a_row0, long w_row0, long c_off, int m0,
                                               int n0) {
@@ -140,10 +140,21 @@ __device__ __forceinline__ void gemm_epilogue(const FabindGemmArgs& p, f32x4_t (
             }
         }
     }
-    if (want_dot || staged) __syncthreads();
+    if (want_dot || staged) {
+        if (RAW_BARRIER) {   // do not drain in-flight LDS-DMA (a plain __syncthreads would wait vmcnt(0))
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        } else {
+            __syncthreads();
+        }
+    }
     if (want_dot) {
         for (int t = tid; t < BM_; t += blockDim.x)
             if (m0 + t < M) p.dot_out[(size_t)(a_row0 + m0 + t) * p.dot_ld + n0 / BN] = sDot[t] + sDot[BM_ + t];
+        if (RAW_BARRIER) {   // sDot is rewritten by the next tile's epilogue
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
     }
     if (staged) {
         bf16_t* C = (bf16_t*)p.C + c_off;
@@ -160,6 +171,109 @@ __device__ __forceinline__ void gemm_epilogue(const FabindGemmArgs& p, f32x4_t (
             }
         }
     }
+}
+
+// ---- specialised epilogue for the hot configurations (alpha = 1; no aux / residual / accumulate / gather):
+// compile-time activation and outputs, bf16 tile staged through LDS and stored as 16-B chunks.
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
+template <int ACT> __device__ __forceinline__ float fast_act(float x) {
+    if (ACT == FB_ACT_SILU) return x * fast_sigmoid(x);
+    if (ACT == FB_ACT_RELU) return x > 0.f ? x : 0.f;
+    return x;
+}
+template <int ACT> __device__ __forceinline__ float fast_dact(float x) {
+    if (ACT == FB_ACT_SILU) { const float sg = fast_sigmoid(x); return sg * (1.0f + x * (1.0f - sg)); }
+    if (ACT == FB_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    return 1.f;
+}
+
+template <int BM_, int ACT, bool HAS_C, bool HAS_C2, bool HAS_DOT, bool RAW_BARRIER, bool STORE_PRE = false>
+__device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sDot, bf16_t* sOut,
+                                                   int M, int N, int ldc, int m0, int n0) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, cq = lane >> 4;
+    bf16_t* C = (bf16_t*)p.C;
+    bf16_t* C2 = (bf16_t*)p.C2;
+    auto barrier = [&]() {
+        if (RAW_BARRIER) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        else __syncthreads();
+    };
+    auto flush = [&](bf16_t* dst) {       // LDS tile -> global, 16-B chunks of a row
+        const bool vec_ok = (ldc % 8 == 0) && (((uintptr_t)dst & 15) == 0);
+        for (int idx = tid; idx < BM_ * (BN / 8); idx += blockDim.x) {
+            const int rowl = idx / (BN / 8), ch = idx % (BN / 8);
+            const int row = m0 + rowl, col = n0 + ch * 8;
+            if (row >= M || col >= N) continue;
+            const bf16_t* sp = &sOut[rowl * OUT_LD + ch * 8];
+            if (vec_ok && col + 8 <= N) *(uint4*)(dst + (size_t)row * ldc + col) = *(const uint4*)sp;
+            else for (int e = 0; e < 8 && col + e < N; ++e) dst[(size_t)row * ldc + col + e] = sp[e];
+        }
+    };
+    float bv[4], dv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + fr;
+        bv[j] = (p.bias && col < N) ? p.bias[col] : 0.f;
+        dv[j] = (HAS_DOT && col < N) ? p.dotvec[col] : 0.f;
+    }
+    if (HAS_C2) {                          // derivative tile first (uses the staging buffer), then the value tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    sOut[(wm * 64 + i * 16 + cq * 4 + r) * OUT_LD + wn * 64 + j * 16 + fr] = f32_to_bf16(fast_dact<ACT>(acc[i][j][r] + bv[j]));
+        barrier();
+        flush(C2);
+        barrier();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float ds[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float vp = acc[i][j][r] + bv[j];
+                const float v = fast_act<ACT>(vp);
+                if (HAS_C) sOut[(wm * 64 + i * 16 + cq * 4 + r) * OUT_LD + wn * 64 + j * 16 + fr] = f32_to_bf16(STORE_PRE ? vp : v);
+                if (HAS_DOT) ds[r] += v * dv[j];
+            }
+        if (HAS_DOT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = ds[r];
+                t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                if (fr == 0) sDot[wn * BM_ + wm * 64 + i * 16 + cq * 4 + r] = t;
+            }
+        }
+    }
+    barrier();
+    if (HAS_DOT)
+        for (int t = tid; t < BM_; t += blockDim.x)
+            if (m0 + t < M) p.dot_out[(size_t)(m0 + t) * p.dot_ld + n0 / BN] = sDot[t] + sDot[BM_ + t];
+    if (HAS_C) flush(C);
+    if (RAW_BARRIER) barrier();            // the staging tile / sDot are reused by the next tile
+}
+
+// returns true when the fast epilogue applies (decided per launch on the host -> p.epi_fast)
+template <int BM_, bool RAW_BARRIER>
+__device__ __forceinline__ bool gemm_epilogue_dispatch(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sDot, bf16_t* sOut,
+                                                       int M, int N, int ldc, int m0, int n0) {
+#define EPI(ACT, HC, HC2, HD) gemm_epilogue_fast<BM_, ACT, HC, HC2, HD, RAW_BARRIER>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true
+    switch (p.epi_fast) {
+        case 1: EPI(FB_ACT_NONE, true, false, false);
+        case 2: EPI(FB_ACT_SILU, true, false, false);
+        case 3: EPI(FB_ACT_SILU, true, true, false);
+        case 4: EPI(FB_ACT_SILU, false, false, true);
+        case 5: EPI(FB_ACT_RELU, true, false, false);
+        case 6: EPI(FB_ACT_RELU, false, false, true);
+        case 7: gemm_epilogue_fast<BM_, FB_ACT_SILU, true, false, true, RAW_BARRIER, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
+        case 8: gemm_epilogue_fast<BM_, FB_ACT_RELU, true, false, true, RAW_BARRIER, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
+        default: return false;
+    }
+#undef EPI
 }
 
 template <typename TA, typename TM>
@@ -461,9 +575,135 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_pipe_kernel(FabindGemmArgs
         }
     }
     __syncthreads();
+    if (p.epi_fast && gemm_epilogue_dispatch<BM_, false>(p, acc, sDot, sT, M, N, ldc, m0, n0)) return;
     gemm_epilogue<BM_>(p, acc, sDot, sT, M, N, ldc, a_row0, w_row0, c_off, m0, n0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent variant for long-M / short-K problems (edge MLPs: K = 512 = 16 k-steps): every work-group
+// walks a contiguous range of output tiles (the N-tiles of its M-panels, so the A panel stays in its own
+// L1/L2) and keeps ONE continuous LDS-DMA ring across tile boundaries -- no pipeline fill/drain per
+// tile, and the epilogue of tile t runs while the operands of tile t+1 are already landing.
+// ------------------------------------------------------------------------------------------------
+template <int WM, int BK_, int NSTAGE>
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_persist_kernel(FabindGemmArgs p, int tiles_total, int nbx) {
+    constexpr int BM_ = WM * 64, NW = WM * 2;
+    constexpr int ROWS = BM_ + BN;
+    constexpr int RPP = 1024 / (BK_ * 2);
+    constexpr int PT = ROWS / RPP, PPW = PT / NW;
+    constexpr int LPR = 64 / RPP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sT = (bf16_t*)smem;
+    float* sDot = (float*)(smem + (size_t)NSTAGE * ROWS * BK_ * 2);
+    bf16_t* sOutP = (bf16_t*)(smem + (size_t)NSTAGE * ROWS * BK_ * 2 + 2 * BM_ * sizeof(float));   // own staging tile
+    const int M = p.M, N = p.N, ldc = p.ldc, K = p.K, K1 = p.K1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const bf16_t* A = (const bf16_t*)p.A;
+    const bf16_t* W = (const bf16_t*)p.W;
+    const int t0 = (int)((long)blockIdx.x * tiles_total / gridDim.x), t1 = (int)((long)(blockIdx.x + 1) * tiles_total / gridDim.x);
+    const int nk = K / BK_;
+    const int G = (t1 - t0) * nk;               // k-steps this work-group executes
+    if (G <= 0) return;
+
+    const bf16_t* src[PPW];
+    const bf16_t* src2[PPW];
+    auto set_src = [&](int tile) {
+        const int m0 = (tile / nbx) * BM_, n0 = (tile % nbx) * BN;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int row = (wave * PPW + j) * RPP + lane / LPR;
+            const int cl = lane % LPR;
+            const int chunk = (BK_ == 64) ? (cl ^ (row & 7)) : (cl ^ ((row >> 2) & 3));
+            if (row < BM_) {
+                const size_t gm = (size_t)min(m0 + row, M - 1);
+                src[j] = A + gm * p.lda + chunk * 8;
+                src2[j] = p.A2 ? (const bf16_t*)p.A2 + gm * p.lda2 + chunk * 8 - K1 : src[j];
+            } else {
+                src[j] = W + (size_t)min(n0 + row - BM_, N - 1) * p.ldw + chunk * 8;
+                src2[j] = src[j];
+            }
+        }
+    };
+    int s_tile = t0, s_kt = 0, s_g = 0;          // staging cursor (runs NSTAGE-1 steps ahead of compute)
+    set_src(s_tile);
+    auto stage_next = [&]() {
+        bf16_t* base = sT + (size_t)(s_g % NSTAGE) * ROWS * BK_;
+        const int k0 = s_kt * BK_;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t)((k0 < K1 ? src[j] : src2[j]) + k0),
+                                             (lptr_t)(base + (size_t)(wave * PPW + j) * RPP * BK_), 16, 0, 0);
+        ++s_g;
+        if (++s_kt == nk) { s_kt = 0; ++s_tile; if (s_tile < t1) set_src(s_tile); }
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
+        if (s_g < G) stage_next();
+    int c_tile = t0, c_kt = 0;
+    for (int g = 0; g < G; ++g) {
+        const int ahead = min(NSTAGE - 2, G - 1 - g);
+        if (ahead >= 2) wait_vmcnt<2 * PPW>(); else if (ahead == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (s_g < G) stage_next();
+        const bf16_t* tA = sT + (size_t)(g % NSTAGE) * ROWS * BK_;
+        const bf16_t* tB = tA + BM_ * BK_;
+#pragma unroll
+        for (int kk = 0; kk < BK_ / 32; ++kk) {
+            bf16x8_t af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wm * 64 + i * 16 + fr, rb = wn * 64 + i * 16 + fr;
+                const int ca = (BK_ == 64) ? ((kk * 4 + fq) ^ (ra & 7)) : (fq ^ ((ra >> 2) & 3));
+                const int cb = (BK_ == 64) ? ((kk * 4 + fq) ^ (rb & 7)) : (fq ^ ((rb >> 2) & 3));
+                af[i] = *(const bf16x8_t*)&tA[ra * BK_ + ca * 8];
+                bfr[i] = *(const bf16x8_t*)&tB[rb * BK_ + cb * 8];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (++c_kt == nk) {
+            if (!(p.epi_fast && gemm_epilogue_dispatch<BM_, true>(p, acc, sDot, sOutP, M, N, ldc, (c_tile / nbx) * BM_, (c_tile % nbx) * BN)))
+                gemm_epilogue<BM_, true>(p, acc, sDot, nullptr, M, N, ldc, 0, 0, 0, (c_tile / nbx) * BM_, (c_tile % nbx) * BN);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            c_kt = 0;
+            ++c_tile;
+        }
+    }
+}
+
+template <int WM, int BK_, int NSTAGE>
+static int launch_persist(const FabindGemmArgs& p, hipStream_t stream) {
+    constexpr int BM_ = WM * 64;
+    const size_t lds = (size_t)NSTAGE * (BM_ + BN) * BK_ * 2 + 2 * BM_ * sizeof(float) + (size_t)BM_ * OUT_LD * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_persist_kernel<WM, BK_, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int nbx = (p.N + BN - 1) / BN, nby = (p.M + BM_ - 1) / BM_;
+    const int tiles = nbx * nby;
+    int grid = 256;                              // 144 KiB of LDS per work-group: one per CU
+    if (grid > tiles) grid = tiles;
+    hipLaunchKernelGGL((gemm_bf16_persist_kernel<WM, BK_, NSTAGE>), dim3(grid), dim3(WM * 128), lds, stream, p, tiles, nbx);
+    return 0;
+}
+
+static int g_gemm_persist = 0;   // measured slower than 2 work-groups/CU of the tile-per-block kernel (see tools/gemm_bench.py)
+extern "C" void fabind_gemm_set_persistent(int on) { g_gemm_persist = on; }
 static int g_gemm_cfg = 3;   // 256x128 tile, BK = 32, 3-stage ring (best of the measured set, see tools/gemm_bench.py)
 extern "C" void fabind_gemm_set_config(int cfg) { g_gemm_cfg = cfg; }
 
@@ -490,6 +730,20 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     FB_REQUIRE(p.lda % 4 == 0 && p.ldw % 4 == 0, "fabind_gemm: lda/ldw must be multiples of 4");
     FB_REQUIRE(!(p.a_dtype == FB_DT_BF16 && (p.lda % 8 != 0)), "fabind_gemm: bf16 A needs lda % 8 == 0");
     FB_REQUIRE(!(p.w_dtype == FB_DT_BF16 && (p.ldw % 8 != 0)), "fabind_gemm: bf16 W needs ldw % 8 == 0");
+    p.epi_fast = 0;
+    if (!p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.R && !p.accumulate && !p.r_index &&
+        (p.C == nullptr || p.c_dtype == FB_DT_BF16) && (p.C2 == nullptr || p.C != nullptr)) {
+        const bool hc = p.C != nullptr, hc2 = p.C2 != nullptr, hd = p.dotvec != nullptr;
+        const bool pre = p.store_preact != 0;
+        if (p.act_epi == FB_ACT_NONE && hc && !hc2 && !hd) p.epi_fast = 1;
+        else if (p.act_epi == FB_ACT_SILU && hc && !hc2 && !hd && !pre) p.epi_fast = 2;
+        else if (p.act_epi == FB_ACT_SILU && hc && hc2 && !hd && !pre) p.epi_fast = 3;
+        else if (p.act_epi == FB_ACT_SILU && !hc && !hc2 && hd) p.epi_fast = 4;
+        else if (p.act_epi == FB_ACT_RELU && hc && !hc2 && !hd && !pre) p.epi_fast = 5;
+        else if (p.act_epi == FB_ACT_RELU && !hc && !hc2 && hd) p.epi_fast = 6;
+        else if (p.act_epi == FB_ACT_SILU && hc && !hc2 && hd && pre) p.epi_fast = 7;
+        else if (p.act_epi == FB_ACT_RELU && hc && !hc2 && hd && pre) p.epi_fast = 8;
+    }
     int maxM = p.groups ? p.max_m : p.M, maxN = p.groups ? p.max_n : p.N;
     if (maxM <= 0 || maxN <= 0) return 0;
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, p.groups ? p.n_groups : (p.k_splits > 1 ? p.k_splits : 1));
@@ -507,6 +761,12 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     } else if (p.act_pro == FB_ACT_NONE && p.K % FBK == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 &&
                ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) &&
                (p.A2 == nullptr || (g_gemm_cfg != 0 && p.K1 % FBK == 0 && p.lda2 % 8 == 0 && ((uintptr_t)p.A2 % 16 == 0)))) {
+        const long n_tiles = (long)((maxM + 255) / 256) * ((maxN + BN - 1) / BN);
+        if (g_gemm_persist && !p.groups && p.k_splits <= 1 && n_tiles >= 2048 && p.K <= 2048) {
+            launch_persist<4, 32, 3>(p, stream);
+            FB_CHECK_LAUNCH();
+            return 0;
+        }
         switch ((p.k_splits > 1 && g_gemm_cfg == 0) ? 3 : g_gemm_cfg) {
             case 1: launch_pipe<2, 32, 4>(p, maxM, maxN, stream); break;
             case 2: launch_pipe<2, 64, 3>(p, maxM, maxN, stream); break;
@@ -529,26 +789,53 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // out[C,R] = act(in[R,C])^T   (used to turn dW = dY^T X into NT GEMMs; fused activation on read)
 // ------------------------------------------------------------------------------------------------
-__global__ void transpose_act_kernel(const void* in, int in_dt, int ldi, void* out, int out_dt, int ldo, int R, int C,
-                                     int act) {
-    __shared__ float tile[32][33];
-    int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
-    for (int i = ty; i < 32; i += 8) {
-        int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < R && c < C) ? apply_act(ld_any(in, in_dt, (size_t)r * ldi + c), act) : 0.f;
+// 64x64 tiles through LDS; 16 contiguous elements per thread on both the read and the write side
+__global__ __launch_bounds__(256) void transpose_act_kernel(const void* in, int in_dt, int ldi, void* out, int out_dt,
+                                                            int ldo, int R, int C, int act) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tr = threadIdx.x >> 2, tc = (threadIdx.x & 3) * 16;
+    {
+        const int r = r0 + tr;
+        const bool vec = (r < R) && (c0 + tc + 16 <= C) && (ldi % 4 == 0);
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 v = ld4_any(in, in_dt, (size_t)r * ldi + c0 + tc + q * 4);
+                tile[tr][tc + q * 4 + 0] = apply_act(v.x, act); tile[tr][tc + q * 4 + 1] = apply_act(v.y, act);
+                tile[tr][tc + q * 4 + 2] = apply_act(v.z, act); tile[tr][tc + q * 4 + 3] = apply_act(v.w, act);
+            }
+        } else {
+            for (int q = 0; q < 16; ++q) {
+                const int c = c0 + tc + q;
+                tile[tr][tc + q] = (r < R && c < C) ? apply_act(ld_any(in, in_dt, (size_t)r * ldi + c), act) : 0.f;
+            }
+        }
     }
     __syncthreads();
-    for (int i = ty; i < 32; i += 8) {
-        int c = c0 + i, r = r0 + tx;
-        if (c < C && r < R) st_any(out, out_dt, (size_t)c * ldo + r, tile[tx][i]);
+    {
+        const int c = c0 + tr;                 // output row
+        if (c >= C) return;
+        const bool vec = (r0 + tc + 16 <= R) && (ldo % 4 == 0);
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                st4_any(out, out_dt, (size_t)c * ldo + r0 + tc + q * 4,
+                        make_float4(tile[tc + q * 4 + 0][tr], tile[tc + q * 4 + 1][tr], tile[tc + q * 4 + 2][tr],
+                                    tile[tc + q * 4 + 3][tr]));
+        } else {
+            for (int q = 0; q < 16; ++q) {
+                const int r = r0 + tc + q;
+                if (r < R) st_any(out, out_dt, (size_t)c * ldo + r, tile[tc + q][tr]);
+            }
+        }
     }
 }
 
 extern "C" int fabind_transpose_act(const void* in, int in_dt, int ldi, void* out, int out_dt, int ldo, int R, int C,
                                     int act, hipStream_t stream) {
     if (R <= 0 || C <= 0) return 0;
-    dim3 grid((C + 31) / 32, (R + 31) / 32);
+    dim3 grid((C + 63) / 64, (R + 63) / 64);
     hipLaunchKernelGGL(transpose_act_kernel, grid, dim3(256), 0, stream, in, in_dt, ldi, out, out_dt, ldo, R, C, act);
     FB_CHECK_LAUNCH();
     return 0;
@@ -565,7 +852,14 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const void* in, int in
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool vec = (c + 3 < C) && (ldi % 4 == 0);
     if (vec) {
-        for (int r = r0 + q; r < r1; r += 4) {
+        int r = r0 + q;
+        for (; r + 12 < r1; r += 16) {          // 4 independent loads in flight per lane
+            float4 v0 = ld4_any(in, in_dt, (size_t)r * ldi + c), v1 = ld4_any(in, in_dt, (size_t)(r + 4) * ldi + c);
+            float4 v2 = ld4_any(in, in_dt, (size_t)(r + 8) * ldi + c), v3 = ld4_any(in, in_dt, (size_t)(r + 12) * ldi + c);
+            s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+            s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; r < r1; r += 4) {
             float4 v = ld4_any(in, in_dt, (size_t)r * ldi + c);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }

@@ -83,7 +83,7 @@ def transpose_act(x, act=ACT_NONE, out_dtype=None):
 
 def colsum(x, out=None, accumulate=False):
     R, C = x.shape
-    nchunk = max(1, min(256, (R + 1023) // 1024))
+    nchunk = max(1, min(2048, (R + 255) // 256))
     scratch = torch.empty((nchunk, C), dtype=torch.float32, device=x.device)
     if out is None:
         out = torch.empty((C,), dtype=torch.float32, device=x.device)

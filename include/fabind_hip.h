@@ -60,6 +60,7 @@ typedef struct FabindGemmArgs {
     int accumulate;
     int store_preact; /* C receives the value BEFORE act_epi (row-dot still sees act_epi(v)) */
     int n_groups, max_m, max_n;
+    int epi_fast; /* set by fabind_gemm itself: index of a specialised epilogue (0 = generic) */
     int k_splits; /* >1: split the K loop over k_splits work-groups; C must be fp32 [k_splits, M, N] partials */
     float alpha;
 } FabindGemmArgs;
@@ -222,6 +223,7 @@ int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, int ld, int
                          int B, int max_P, int max_C, const int* p_index, const int* c_index, float* dab, float* dwk,
                          hipStream_t stream);
 void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of the bf16 LDS-DMA GEMM */
+void fabind_gemm_set_persistent(int on); /* development knob: persistent tile walk for long-M/short-K GEMMs */
 
 #ifdef __cplusplus
 }

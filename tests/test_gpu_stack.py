@@ -156,3 +156,67 @@ def test_stack_gradients_match_reference():
         if not err <= 3e-3 * np.abs(ref).max() + 1e-7:
             bad.append((n, float(err), float(np.abs(ref).max())))
     assert not bad, bad
+
+
+def _random_stack(H, L, it, seed):
+    from fabind_amd.models.att_model import EfficientMCAttModel
+    torch.manual_seed(seed)
+    m = EfficientMCAttModel(_args(H, L, it), H, H, 1, n_layers=L, n_iter=it, normalize_coord=lambda x: x / 5.0,
+                            unnormalize_coord=lambda x: x * 5.0).eval()
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("coord_mlp.2.weight"):
+                p.mul_(300.0)
+    return m
+
+
+def _vs_oracle(m, inp, L, it, tol=1e-4):
+    dev = torch.device("cuda:0")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    Xr, Hr = orc.stack_forward(sd, "", inp["X"], inp["H"], inp["batch_id"], inp["segment_id"], inp["mask"],
+                               inp["is_global"], inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"], L, it)
+    X, Hh = _run(m.to(dev), inp, dev)
+    assert rmsd(X.cpu().numpy() * 5, Xr.numpy() * 5) < tol
+    assert (Hh.cpu() - Hr).abs().max() <= tol * max(1.0, float(Hr.abs().max()))
+    return m
+
+
+def test_edge_case_no_inter_edges_uses_reference_fallback():
+    """Ligand far from the protein: the batch has no inter edge -> one fake symmetric pair (att_model.py:85-86)."""
+    from fabind_amd import engine, synthetic
+    engine.set_precision("fp32")
+    inp = synthetic.make_stack_batch([(40, 6), (35, 5)], 32, seed=9)
+    lig = (inp["segment_id"] == 0) & ~inp["is_global"]
+    inp["X"][lig] += 50.0                                   # 250 A away
+    m = _vs_oracle(_random_stack(32, 2, 2, 21), inp, 2, 2)
+    assert m.last_graph.E_int == 2
+
+
+def test_edge_case_single_complex_pocket_model_shape():
+    """B = 1 and the pocket-prediction configuration (hidden 128, 1 layer, 1 iteration)."""
+    from fabind_amd import engine, synthetic
+    engine.set_precision("fp32")
+    _vs_oracle(_random_stack(128, 1, 1, 22), synthetic.make_stack_batch([(260, 31)], 128, seed=10), 1, 1)
+
+
+def test_edge_case_tiny_and_ragged_complexes():
+    """Very ragged batch incl. a 2-atom ligand and a 6-residue protein."""
+    from fabind_amd import engine, synthetic
+    engine.set_precision("fp32")
+    _vs_oracle(_random_stack(64, 2, 3, 23), synthetic.make_stack_batch([(6, 2), (200, 45), (17, 3), (64, 64)], 64, seed=11), 2, 3)
+
+
+def test_construct_edges_api_matches_reference_sets():
+    """ComplexGraph.construct_edges keeps the reference's signature and edge sets."""
+    from fabind_amd import engine
+    from fabind_amd.models.att_model import ComplexGraph
+    dev = torch.device("cuda:0")
+    g = load_npz("stack_tiny_it1")
+    inp = stack_inputs(g)
+    cg = ComplexGraph(_args(32, 2, 1), normalize_coord=lambda x: x / 5.0)
+    ctx, inter, (rb, ro) = cg.construct_edges(inp["X"].to(dev), inp["batch_id"].to(dev), inp["segment_id"].to(dev),
+                                              inp["is_global"].to(dev))
+    key = lambda e: sorted(map(tuple, np.asarray(e).T.tolist()))
+    assert key(ctx.cpu().numpy()) == key(g["cap_ctx_edges_noBond"])
+    assert np.array_equal(inter.cpu().numpy(), g["cap_inter_edges"])
+    assert rb.shape[0] == inter.shape[1] // 2

@@ -45,8 +45,9 @@ def main():
     from fabind_amd import _lib
     lib = _lib.load()
     ref = (A16[:512].float() @ W16.float().T)
-    for cfg in (3, 6, 7):
-        lib.fabind_gemm_set_config(cfg)
+    for cfg in (3, 103):
+        lib.fabind_gemm_set_config(3)
+        lib.fabind_gemm_set_persistent(1 if cfg > 100 else 0)
         K.gemm(A16, W16, out=o16)
         err = float((o16[:512].float() - ref).abs().max())
         for name in ("bf16A plain -> bf16", "bf16A bias+silu -> bf16", "bf16A bias+silu rowdot only"):
