@@ -27,6 +27,7 @@ from . import ops
 from .config import get_precision, set_precision  # noqa: F401
 
 
+FUSED_EDGE = True     # forward-only bf16: fused gather->GEMM->GEMM->segment-sum edge kernel
 DEBUG_CAPTURE = None  # set to a dict to record per-layer outputs of the LAST egnn_forward call (tests)
 
 
@@ -233,7 +234,17 @@ def gcl_layer(p, h, x, lay, g, clampv):
     streams plain bf16 operands HBM -> LDS."""
     H = h.shape[1]
     ad = ops.act_dtype()
-    hin = _b16(h) if _fast(h, x, p["W2"]) else h
+    fast = _fast(h, x, p["W2"])
+    hin = _b16(h) if fast else h
+    if fast and FUSED_EDGE and H in (64, 128, 256, 512):
+        # forward-only: the whole edge pipeline in one kernel, edge tensors stay in LDS (csrc/fused_edge.hip)
+        AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=torch.bfloat16)
+        d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
+        agg, s = K.gcl_edge_fused(AB, H, g.row_ctx, g.col_ctx, rhohat, p["w_r"], K.pack_frag(p["W2"]), p["b2"],
+                                  K.pack_frag(p["Wc"]), p["bc"], p["w3"], h.shape[0])
+        x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
+        t = ops.linear(hin, p["Wn1"], p["bn1"], x2=agg, act_epi=K.ACT_SILU, out_dtype=ad)
+        return ops.linear(t, p["Wn2"], p["bn2"], residual=h), x_new
     AB = ops.linear(hin, p["W_ab"], p["b_ab"])                                         # [N,2H] node-level
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
     S1 = ops.gcl_pre(AB, H, g, rhohat, p["w_r"], act=K.ACT_SILU)                        # [E,H] silu(first edge Linear)

@@ -228,3 +228,19 @@ def select_rows(x, z, mask_u8):
     check(_lib.load().fabind_select_rows(ptr(x), ptr(z), ptr(mask_u8), x.shape[0], x.shape[1], ptr(out), stream()),
           "fabind_select_rows")
     return out
+
+
+def pack_frag(W):
+    """[N,K] weight -> bf16 MFMA-fragment order [K/32][N/16][4][16][8] (one contiguous 1 KiB block per wave load)."""
+    N, Kd = W.shape
+    return W.to(torch.bfloat16).view(N // 16, 16, Kd // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
+
+
+def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows):
+    E = row.shape[0]
+    agg = torch.zeros((n_rows, H), dtype=torch.float32, device=AB16.device)
+    s = torch.empty((max(E, 1), 1), dtype=torch.float32, device=AB16.device)
+    check(_lib.load().fabind_gcl_edge_fused(ptr(AB16), _ld(AB16), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r), ptr(W2p),
+                                            ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s), stream()),
+          "fabind_gcl_edge_fused")
+    return agg, s[:E]

@@ -127,6 +127,14 @@ int fabind_coord_update(const float* x, const float* d, const float* s_part, int
                         const int* rowptr, int n_rows, int mean, float clampv, float* x_out, float* s_out,
                         hipStream_t stream);
 
+/* Fused forward edge pipeline of MC_E_GCL (models/egnn.py:68-128) for 64-edge tiles, bf16:
+ *   s_out[e] = w3 . silu( silu( silu(A[row]+Bc[col]+rhohat*w_r) W2^T + b2 ) Wc^T + bc ),  agg[row] += silu(.. W2^T + b2)
+ * AB = bf16 [N, 2H] (A | Bc); W2p / Wcp = bf16 weights packed in MFMA fragment order [H/32][H/16][4][16][8];
+ * agg must be zero-initialised (float atomics per row run).  H in {64,128,256,512}. */
+int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
+                          const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
+                          const float* w3, int E, float* agg, float* s_out, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Cross attention (RowAttentionBlock / Attention._attention, models/cross_att.py:118-134,
  * models/model_utils.py:21-38,96-133).  Ragged: no padding, so the -1e9 mask bias never applies.

@@ -104,3 +104,31 @@ def test_gemm_bf16_lds_dma_fast_path(shape, cfg):
     _lib.load().fabind_gemm_set_config(3)
     assert torch.equal(o2.cpu(), Wa.float().T.contiguous())
     assert torch.equal(o3.float().cpu(), Wa.float().T.contiguous())
+
+
+@pytest.mark.parametrize("H", [64, 128, 512])
+def test_fused_edge_pipeline_matches_unfused(H):
+    """csrc/fused_edge.hip (gather -> GEMM -> SiLU -> {segment-sum, GEMM -> row-dot}) vs fp32 torch on the CPU."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(H)
+    N, deg = 300, torch.randint(0, 40, (300,), generator=g)
+    deg[7] = 333                                                        # a heavy row spanning several 64-edge tiles
+    row = torch.repeat_interleave(torch.arange(N), deg)
+    E = row.shape[0]
+    col = torch.randint(0, N, (E,), generator=g)
+    AB = torch.randn(N, 2 * H, generator=g).bfloat16()
+    rh = torch.rand(E, generator=g)
+    w_r, b2, bc, w3 = [torch.randn(H, generator=g) * 0.5 for _ in range(4)]
+    W2 = (torch.randn(H, H, generator=g) / H ** 0.5).bfloat16()
+    Wc = (torch.randn(H, H, generator=g) / H ** 0.5).bfloat16()
+    silu = torch.nn.functional.silu
+    S1 = silu(AB[row, :H].float() + AB[col, H:].float() + rh[:, None] * w_r).bfloat16().float()
+    M = silu(S1 @ W2.float().T + b2).bfloat16().float()
+    agg_ref = torch.zeros(N, H).index_add_(0, row, M)
+    s_ref = (silu(M @ Wc.float().T + bc) * w3).sum(1)
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    agg, s = K.gcl_edge_fused(AB.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), K.pack_frag(W2.to(dev)),
+                              b2.to(dev), K.pack_frag(Wc.to(dev)), bc.to(dev), w3.to(dev), N)
+    assert (agg.cpu() - agg_ref).abs().max() <= 2e-2 * max(1.0, float(agg_ref.abs().max()))
+    assert (s[:, 0].cpu() - s_ref).abs().max() <= 2e-2 * max(1.0, float(s_ref.abs().max()))
