@@ -178,25 +178,26 @@ def main():
     # ---- roofline of the dominant kernel (live HIP-event timing of every GEMM launch in the timed region)
     if prof:
         best = None
-        for key, evs in prof.items():
-            ms = sum(s.elapsed_time(e) for s, e in evs)
+        for label, evs in prof.items():
+            ms = sum(s_.elapsed_time(e_) for s_, e_, _ in evs)
             if best is None or ms > best[1]:
-                best = (key, ms, len(evs))
-        (M, N, Kd, adt, wdt), ms, cnt = best
+                best = (label, ms, len(evs), evs[0][2])
+        label, ms, cnt, flops = best
         avg_s = ms / cnt * 1e-3
-        flops = 2.0 * M * N * Kd
         peak = MFMA_PEAK_TFLOPS[a.precision]
         out["roofline"] = {"bound": "mfma", "achieved": flops / avg_s / 1e12, "peak": peak, "unit": "TFLOP/s",
-                           "frac": flops / avg_s / 1e12 / peak, "traffic": None,
-                           "kernel": "fabind_gemm <%s,%s> M=%d N=%d K=%d (edge-MLP contraction; bf16 -> gemm_bf16_pipe_kernel<4,32,3>)" % (adt, wdt, M, N, Kd),
-                           "launches": cnt, "avg_us": avg_s * 1e6,
+                           "frac": flops / avg_s / 1e12 / peak, "traffic": None, "kernel": label,
+                           "flop_per_launch": flops, "launches": cnt, "avg_us": avg_s * 1e6,
                            "share_of_step": ms / (1e3 * dt)}
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
     # FETCH_SIZE doubled per MI355X_MICROARCH.md "HBM"), per launch; null when no PMC summary is available
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_gemm.json")
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
     if "roofline" in out and os.path.exists(pmc):
         try:
-            out["roofline"]["traffic"] = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            tr = json.load(open(pmc))
+            for key, val in tr.get("per_kernel", {}).items():
+                if key in out["roofline"]["kernel"]:
+                    out["roofline"]["traffic"] = val
         except Exception:
             pass
     if not a.no_cpu_baseline:

@@ -37,7 +37,8 @@ SIGNATURES = {
     "fabind_gcl_edge_fused": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
     "fabind_segment_sum": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp],
     "fabind_coord_update": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
-    "fabind_cross_attn_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _vp],
+    "fabind_cross_attn_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i,
+                              _vp],
     "fabind_pair_bmat": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp],
     "fabind_pair_hadamard": [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
     "fabind_inter_attn_fwd": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
@@ -52,7 +53,7 @@ SIGNATURES = {
     "fabind_gather_dact": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "fabind_coord_update_bwd": [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
     "fabind_cross_attn_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                              _vp, _vp],
+                              _vp, _i, _i, _vp],
     "fabind_pair_hadamard_bwd": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
                                  _vp],
     "fabind_inter_attn_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i,

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
                                                              int ldkv, const float* __restrict__ gpre, int ldg,
                                                              const float* __restrict__ bias, int bias_ld, int lin_col,
                                                              int gate_col, const int* desc, float scale, float* out,
-                                                             int ldo, float* lse) {
+                                                             int ldo, float* lse, int ksplit, float* part) {
     __shared__ __attribute__((aligned(16))) float sK[CA_KT * 128];
     __shared__ __attribute__((aligned(16))) float sV[CA_KT * 128];
     const int* ds = desc + blockIdx.y * 8;
@@ -39,12 +39,18 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
         }
     }
     float m = -INFINITY, l = 0.f;
-    for (int j0 = 0; j0 < nk; j0 += CA_KT) {
+    // key range of this work-group (ksplit > 1: flash-decoding style split over the keys, merged by a second kernel)
+    int kb = 0, ke = nk;
+    if (ksplit > 1) {
+        const int per = ((nk + ksplit - 1) / ksplit + CA_KT - 1) / CA_KT * CA_KT;
+        kb = blockIdx.z * per; ke = min(nk, kb + per);
+    }
+    for (int j0 = kb; j0 < ke; j0 += CA_KT) {
         __syncthreads();
         for (int i = tid; i < CA_KT * 32; i += 256) {  // 32 float4 per key row
             int jr = i >> 5, c4 = (i & 31) * 4;
             float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
-            if (j0 + jr < nk) {
+            if (j0 + jr < ke) {
                 kk = *(const float4*)(k + (size_t)(k_off + j0 + jr) * ldkv + c4);
                 vv = *(const float4*)(v + (size_t)(k_off + j0 + jr) * ldkv + c4);
             }
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
         }
         __syncthreads();
         if (!valid) continue;
-        const int jn = min(CA_KT, nk - j0);
+        const int jn = min(CA_KT, ke - j0);
         for (int j = 0; j < jn; ++j) {
             const float* kp = &sK[j * 128 + h * 32];
             float s = 0.f;
@@ -78,6 +84,13 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
         }
     }
     if (!valid) return;
+    if (ksplit > 1) {      // un-normalised partial: [row][split][head][34] = o[32], m, l
+        float* pp = part + (((size_t)(q_off + qi) * ksplit + blockIdx.z) * 4 + h) * 34;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) pp[d] = o[d];
+        pp[32] = m; pp[33] = l;
+        return;
+    }
     const float inv = 1.f / l;
     const float* gp = gpre + (size_t)(q_off + qi) * ldg + h * 32;
     float* op = out + (size_t)(q_off + qi) * ldo + h * 32;
@@ -90,15 +103,44 @@ __global__ __launch_bounds__(256) void cross_attn_fwd_kernel(const float* __rest
     if (lse) lse[(size_t)(q_off + qi) * 4 + h] = m + __logf(l);
 }
 
+__global__ __launch_bounds__(256) void cross_attn_combine_kernel(const float* __restrict__ part, int ksplit,
+                                                                 const float* __restrict__ gpre, int ldg, int n_rows,
+                                                                 float* out, int ldo, float* lse) {
+    const int t = blockIdx.x * 256 + threadIdx.x;          // (row, head)
+    if (t >= n_rows * 4) return;
+    const int rowi = t >> 2, h = t & 3;
+    float M = -INFINITY;
+    for (int s_ = 0; s_ < ksplit; ++s_) M = fmaxf(M, part[(((size_t)rowi * ksplit + s_) * 4 + h) * 34 + 32]);
+    float L = 0.f, o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+    for (int s_ = 0; s_ < ksplit; ++s_) {
+        const float* pp = part + (((size_t)rowi * ksplit + s_) * 4 + h) * 34;
+        const float w = (pp[33] > 0.f) ? __expf(pp[32] - M) : 0.f;
+        L += pp[33] * w;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] += pp[d] * w;
+    }
+    const float inv = 1.f / L;
+#pragma unroll
+    for (int d = 0; d < 32; ++d)
+        out[(size_t)rowi * ldo + h * 32 + d] = o[d] * inv * sigmoid_f(gpre[(size_t)rowi * ldg + h * 32 + d]);
+    if (lse) lse[(size_t)rowi * 4 + h] = M + __logf(L);
+}
+
 extern "C" int fabind_cross_attn_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv,
                                      const float* gpre, int ldg, const float* bias, int bias_ld, int lin_col,
                                      int gate_col, const int* desc, int B, int max_nq, float scale, float* out, int ldo,
-                                     float* lse, hipStream_t stream) {
+                                     float* lse, int ksplit, float* part, int n_rows, hipStream_t stream) {
     FB_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0, "fabind_cross_attn_fwd: strides % 4");
     if (B <= 0 || max_nq <= 0) return 0;
-    dim3 grid((max_nq + 63) / 64, B);
+    if (ksplit < 1) ksplit = 1;
+    dim3 grid((max_nq + 63) / 64, B, ksplit);
     hipLaunchKernelGGL(cross_attn_fwd_kernel, grid, dim3(256), 0, stream, q, ldq, k, v, ldkv, gpre, ldg, bias, bias_ld,
-                       lin_col, gate_col, desc, scale, out, ldo, lse);
+                       lin_col, gate_col, desc, scale, out, ldo, lse, ksplit, part);
+    if (ksplit > 1)
+        hipLaunchKernelGGL(cross_attn_combine_kernel, dim3((n_rows * 4 + 255) / 256), dim3(256), 0, stream, part, ksplit,
+                           gpre, ldg, n_rows, out, ldo, lse);
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_q_kernel(const float* __re
                                                                int gate_col, const int* desc, float scale,
                                                                const float* __restrict__ out, const float* lse,
                                                                const float* __restrict__ dout, float* dqg, float* dbias,
-                                                               float* dO, float* Dv) {
+                                                               float* dO, float* Dv, int ksplit) {
     __shared__ __attribute__((aligned(16))) float sK[CB_KT * 128];
     __shared__ __attribute__((aligned(16))) float sV[CB_KT * 128];
     const int* ds = desc + blockIdx.y * 8;
@@ -257,12 +257,17 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_q_kernel(const float* __re
         L = lse[ro * 4 + h];
         Dv[ro * 4 + h] = D;
     }
-    for (int j0 = 0; j0 < nk; j0 += CB_KT) {
+    int kb = 0, ke = nk;
+    if (ksplit > 1) {
+        const int per = ((nk + ksplit - 1) / ksplit + CB_KT - 1) / CB_KT * CB_KT;
+        kb = blockIdx.z * per; ke = min(nk, kb + per);
+    }
+    for (int j0 = kb; j0 < ke; j0 += CB_KT) {
         __syncthreads();
         for (int i = tid; i < CB_KT * 32; i += 256) {
             int jr = i >> 5, c4 = (i & 31) * 4;
             float4 kk = make_float4(0.f, 0.f, 0.f, 0.f), vv = kk;
-            if (j0 + jr < nk) {
+            if (j0 + jr < ke) {
                 kk = *(const float4*)(kv + (size_t)(k_off + j0 + jr) * ldkv + c4);
                 vv = *(const float4*)(kv + (size_t)(k_off + j0 + jr) * ldkv + 128 + c4);
             }
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_q_kernel(const float* __re
         }
         __syncthreads();
         if (!valid) continue;
-        const int jn = min(CB_KT, nk - j0);
+        const int jn = min(CB_KT, ke - j0);
         for (int j = 0; j < jn; ++j) {
             const float* kp = &sK[j * 128 + h * 32];
             const float* vp = &sV[j * 128 + h * 32];
@@ -292,8 +297,13 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_q_kernel(const float* __re
     }
     if (!valid) return;
     float* dqp = dqg + (size_t)(q_off + qi) * ldq + h * 32;
+    if (ksplit > 1) {      // partial over this key range: dq columns were zeroed by the host
 #pragma unroll
-    for (int c = 0; c < 32; ++c) dqp[c] = dq[c] * scale;
+        for (int c = 0; c < 32; ++c) atomicAdd(&dqp[c], dq[c] * scale);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) dqp[c] = dq[c] * scale;
+    }
 }
 
 __global__ __launch_bounds__(256) void cross_attn_bwd_kv_kernel(const float* __restrict__ qg, int ldq,
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kv_kernel(const float* __r
                                                                 const float* __restrict__ bias, int bias_ld, int lin_col,
                                                                 int gate_col, const int* desc, float scale,
                                                                 const float* lse, const float* __restrict__ dO,
-                                                                const float* Dv, float* dkv) {
+                                                                const float* Dv, float* dkv, int qsplit) {
     __shared__ __attribute__((aligned(16))) float sQ[CB_KT * 128];
     __shared__ __attribute__((aligned(16))) float sDO[CB_KT * 128];
     __shared__ float sL[CB_KT * 4], sD[CB_KT * 4];
@@ -321,12 +331,17 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kv_kernel(const float* __r
 #pragma unroll
         for (int c = 0; c < 32; ++c) { kr[c] = kp[c]; vr[c] = kp[128 + c]; }
     }
-    for (int i0 = 0; i0 < nq; i0 += CB_KT) {
+    int qb = 0, qe = nq;
+    if (qsplit > 1) {
+        const int per = ((nq + qsplit - 1) / qsplit + CB_KT - 1) / CB_KT * CB_KT;
+        qb = blockIdx.z * per; qe = min(nq, qb + per);
+    }
+    for (int i0 = qb; i0 < qe; i0 += CB_KT) {
         __syncthreads();
         for (int i = tid; i < CB_KT * 32; i += 256) {
             int ir = i >> 5, c4 = (i & 31) * 4;
             float4 qq = make_float4(0.f, 0.f, 0.f, 0.f), dd_ = qq;
-            if (i0 + ir < nq) {
+            if (i0 + ir < qe) {
                 qq = *(const float4*)(qg + (size_t)(q_off + i0 + ir) * ldq + c4);
                 dd_ = *(const float4*)(dO + (size_t)(q_off + i0 + ir) * 128 + c4);
             }
@@ -335,12 +350,12 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kv_kernel(const float* __r
         }
         if (tid < CB_KT * 4) {
             int ir = tid >> 2;
-            sL[tid] = (i0 + ir < nq) ? lse[(size_t)(q_off + i0 + ir) * 4 + (tid & 3)] : 0.f;
-            sD[tid] = (i0 + ir < nq) ? Dv[(size_t)(q_off + i0 + ir) * 4 + (tid & 3)] : 0.f;
+            sL[tid] = (i0 + ir < qe) ? lse[(size_t)(q_off + i0 + ir) * 4 + (tid & 3)] : 0.f;
+            sD[tid] = (i0 + ir < qe) ? Dv[(size_t)(q_off + i0 + ir) * 4 + (tid & 3)] : 0.f;
         }
         __syncthreads();
         if (!valid) continue;
-        const int in_ = min(CB_KT, nq - i0);
+        const int in_ = min(CB_KT, qe - i0);
         for (int i = 0; i < in_; ++i) {
             const float* qp = &sQ[i * 128 + h * 32];
             const float* dp_ = &sDO[i * 128 + h * 32];
@@ -358,19 +373,32 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kv_kernel(const float* __r
     }
     if (!valid) return;
     float* o = dkv + (size_t)(k_off + kj) * ldkv + h * 32;
+    if (qsplit > 1) {      // partial over this query range: dkv was zeroed by the host
 #pragma unroll
-    for (int c = 0; c < 32; ++c) { o[c] = dk[c]; o[128 + c] = dv[c]; }
+        for (int c = 0; c < 32; ++c) { atomicAdd(&o[c], dk[c]); atomicAdd(&o[128 + c], dv[c]); }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 32; ++c) { o[c] = dk[c]; o[128 + c] = dv[c]; }
+    }
 }
 
 extern "C" int fabind_cross_attn_bwd(const float* qg, int ldq, const float* kv, int ldkv, const float* bias, int bias_ld,
                                      int lin_col, int gate_col, const int* desc, int B, int max_nq, int max_nk,
                                      float scale, const float* out, const float* lse, const float* dout, float* dqg,
-                                     float* dkv, float* dbias, float* dO, float* Dv, hipStream_t stream) {
+                                     float* dkv, float* dbias, float* dO, float* Dv, int n_q_rows, int n_k_rows,
+                                     hipStream_t stream) {
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(cross_attn_bwd_q_kernel, dim3((max_nq + 63) / 64, B), dim3(256), 0, stream, qg, ldq, kv, ldkv, bias,
-                       bias_ld, lin_col, gate_col, desc, scale, out, lse, dout, dqg, dbias, dO, Dv);
-    hipLaunchKernelGGL(cross_attn_bwd_kv_kernel, dim3((max_nk + 63) / 64, B), dim3(256), 0, stream, qg, ldq, kv, ldkv,
-                       bias, bias_ld, lin_col, gate_col, desc, scale, lse, dO, Dv, dkv);
+    // few queries / many keys -> split the keys in pass Q; few keys / many queries -> split the queries in pass KV
+    int ksplit = (max_nq <= 256 && max_nk >= 512) ? max_nk / 128 : 1;
+    int qsplit = (max_nk <= 256 && max_nq >= 512) ? max_nq / 128 : 1;
+    if (ksplit > 32) ksplit = 32;
+    if (qsplit > 32) qsplit = 32;
+    if (ksplit > 1) (void)hipMemsetAsync(dqg, 0, (size_t)n_q_rows * ldq * sizeof(float), stream);
+    if (qsplit > 1) (void)hipMemsetAsync(dkv, 0, (size_t)n_k_rows * ldkv * sizeof(float), stream);
+    hipLaunchKernelGGL(cross_attn_bwd_q_kernel, dim3((max_nq + 63) / 64, B, ksplit), dim3(256), 0, stream, qg, ldq, kv,
+                       ldkv, bias, bias_ld, lin_col, gate_col, desc, scale, out, lse, dout, dqg, dbias, dO, Dv, ksplit);
+    hipLaunchKernelGGL(cross_attn_bwd_kv_kernel, dim3((max_nk + 63) / 64, B, qsplit), dim3(256), 0, stream, qg, ldq, kv,
+                       ldkv, bias, bias_ld, lin_col, gate_col, desc, scale, lse, dO, Dv, dkv, qsplit);
     FB_CHECK_LAUNCH();
     return 0;
 }

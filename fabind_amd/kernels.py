@@ -12,7 +12,18 @@ __all__ = ["gemm", "transpose_act", "colsum", "edges_count", "edges_fill", "excl
            "inter_attn_fwd", "las_step", "select_rows", "ACT_NONE", "ACT_SILU", "ACT_RELU", "ACT_SIGMOID", "ACT_STORED_DERIV"]
 
 GEMM_BN = 128
-PROFILE = None  # dict -> per-(M,N,K,dtypes) list of (start,end) HIP events around every GEMM launch (bench.py)
+PROFILE = None  # dict: label -> list of (start_event, end_event, flops) around every MFMA-kernel launch (bench.py)
+
+
+def _profiled(label, flops, fn):
+    if PROFILE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    PROFILE.setdefault(label, []).append((e0, e1, flops))
+    return r
 
 
 def _ld(t):
@@ -62,14 +73,8 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     a.n_groups, a.max_m, a.max_n = n_groups, max_m, max_n
     a.k_splits = k_splits
     a.alpha = alpha
-    if PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm")
-        e1.record()
-        PROFILE.setdefault((M, N, K, str(A.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", "")), []).append((e0, e1))
-    else:
-        check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm")
+    label = "fabind_gemm <%s,%s> M=%d N=%d K=%d" % (str(A.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""), M, N, K)
+    _profiled(label, 2.0 * M * N * K, lambda: check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm"))
     return (out if want_out else None), dot_out
 
 
@@ -175,12 +180,15 @@ def coord_update(x, d, s_part, rowptr, mean, clampv, weight=None, want_s=False):
     return x_out, s_out
 
 
-def cross_attn_fwd(q, k, v, gpre, bias, lin_col, gate_col, desc, B, max_nq, scale, out, want_lse=False):
+def cross_attn_fwd(q, k, v, gpre, bias, lin_col, gate_col, desc, B, max_nq, scale, out, want_lse=False, max_nk=0):
     lse = torch.empty((q.shape[0], 4), dtype=torch.float32, device=q.device) if want_lse else None
     assert k.stride(0) == v.stride(0)
+    # few queries / many keys (ligand-query block): split the keys so that the launch fills the chip
+    ksplit = max(1, min(32, max_nk // 128)) if (max_nq <= 256 and max_nk >= 512) else 1
+    part = torch.empty(q.shape[0] * ksplit * 4 * 34, dtype=torch.float32, device=q.device) if ksplit > 1 else None
     check(_lib.load().fabind_cross_attn_fwd(ptr(q), _ld(q), ptr(k), ptr(v), _ld(k), ptr(gpre), _ld(gpre), ptr(bias),
                                             _ld(bias), lin_col, gate_col, ptr(desc), B, max_nq, scale, ptr(out), _ld(out),
-                                            ptr(lse), stream()), "fabind_cross_attn_fwd")
+                                            ptr(lse), ksplit, ptr(part), q.shape[0], stream()), "fabind_cross_attn_fwd")
     return out, lse
 
 
@@ -240,7 +248,8 @@ def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows)
     E = row.shape[0]
     agg = torch.zeros((n_rows, H), dtype=torch.float32, device=AB16.device)
     s = torch.empty((max(E, 1), 1), dtype=torch.float32, device=AB16.device)
-    check(_lib.load().fabind_gcl_edge_fused(ptr(AB16), _ld(AB16), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r), ptr(W2p),
-                                            ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s), stream()),
-          "fabind_gcl_edge_fused")
+    _profiled("gcl_edge_fused_kernel<%d> E=%d (gather + 2 chained H x H contractions + segment-sum per edge)" % (H, E), 4.0 * E * H * H,
+              lambda: check(_lib.load().fabind_gcl_edge_fused(ptr(AB16), _ld(AB16), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
+                                                              ptr(W2p), ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s),
+                                                              stream()), "fabind_gcl_edge_fused"))
     return agg, s[:E]

@@ -168,14 +168,8 @@ def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store):
     a.lda, a.ldw, a.ldc, a.dot_ld = x.stride(0), W.stride(0), N, nt
     a.a_dtype, a.w_dtype, a.c_dtype = dt_code(x.dtype), dt_code(W.dtype), dt_code(z.dtype) if store else 0
     a.act_pro, a.act_epi, a.store_preact, a.alpha = act_pro, act_epi, 1, 1.0
-    if K.PROFILE is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        check(load().fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm(rowdot)")
-        e1.record()
-        K.PROFILE.setdefault((M, N, Kd, str(x.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", "")), []).append((e0, e1))
-    else:
-        check(load().fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm(rowdot)")
+    label = "fabind_gemm <%s,%s> M=%d N=%d K=%d" % (str(x.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""), M, N, Kd)
+    K._profiled(label, 2.0 * M * N * Kd, lambda: check(load().fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm(rowdot)"))
     return z, part
 
 
@@ -348,7 +342,7 @@ class _CrossAttn(torch.autograd.Function):
     def forward(ctx, qg, kv, bias, lin_col, gate_col, desc, B, max_nq, max_nk, scale):
         out = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
         _, lse = K.cross_attn_fwd(qg[:, :128], kv[:, :128], kv[:, 128:], qg[:, 128:], bias, lin_col, gate_col, desc, B,
-                                  max_nq, scale, out, want_lse=True)
+                                  max_nq, scale, out, want_lse=True, max_nk=max_nk)
         ctx.args = (lin_col, gate_col, desc, B, max_nq, max_nk, scale)
         ctx.save_for_backward(qg, kv, bias, out, lse)
         return out
@@ -363,8 +357,8 @@ class _CrossAttn(torch.autograd.Function):
         Dv = torch.empty((qg.shape[0], 4), dtype=torch.float32, device=qg.device)
         check(load().fabind_cross_attn_bwd(ptr(qg), qg.stride(0), ptr(kv), kv.stride(0), ptr(bias), bias.stride(0), lin_col,
                                            gate_col, ptr(desc), B, max_nq, max_nk, scale, ptr(out), ptr(lse), ptr(dout),
-                                           ptr(dqg), ptr(dkv), ptr(dbias), ptr(dO), ptr(Dv), stream()),
-              "fabind_cross_attn_bwd")
+                                           ptr(dqg), ptr(dkv), ptr(dbias), ptr(dO), ptr(Dv), qg.shape[0], kv.shape[0],
+                                           stream()), "fabind_cross_attn_bwd")
         return dqg, dkv, dbias, None, None, None, None, None, None, None
 
 
@@ -372,7 +366,8 @@ def cross_attn(qg, kv, bias, lin_col, gate_col, desc, B, max_nq, max_nk, scale):
     if _needs_grad(qg, kv, bias):
         return _CrossAttn.apply(qg, kv, bias, lin_col, gate_col, desc, B, max_nq, max_nk, scale)
     out = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
-    K.cross_attn_fwd(qg[:, :128], kv[:, :128], kv[:, 128:], qg[:, 128:], bias, lin_col, gate_col, desc, B, max_nq, scale, out)
+    K.cross_attn_fwd(qg[:, :128], kv[:, :128], kv[:, 128:], qg[:, 128:], bias, lin_col, gate_col, desc, B, max_nq, scale, out,
+                     max_nk=max_nk)
     return out
 
 

@@ -143,10 +143,13 @@ int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int* row, const
  *         bias[(pair_off[b] + i*sq[b] + j*sk[b]) * bias_ld + {lin_col, gate_col} + h]
  *     out[i,h,:] = sigmoid(gpre[i,h,:]) * sum_j softmax_j(s) v[j,h,:]
  * desc: int32[B][8] = {q_off, nq, k_off, nk, pair_off_lo, pair_off_hi, sq, sk}.
+ * ksplit > 1 splits the keys over work-groups (few queries, many keys: the ligand-query block); `part` =
+ * float[n_rows * ksplit * 4 * 34] scratch, merged by a second kernel (out/lse rows are the first n_rows of q).
  * -------------------------------------------------------------------------------------------*/
 int fabind_cross_attn_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* gpre,
                           int ldg, const float* bias, int bias_ld, int lin_col, int gate_col, const int* desc, int B,
-                          int max_nq, float scale, float* out, int ldo, float* lse, hipStream_t stream);
+                          int max_nq, float scale, float* out, int ldo, float* lse, int ksplit, float* part, int n_rows,
+                          hipStream_t stream);
 
 /* pair-bias precompute helpers (RowAttentionBlock.linear/linear_g applied to the initial pair
  * embedding z0 = W_o (a_i * b_j) + b_o; models/cross_att.py:125, models/att_model.py:198-206):
@@ -214,7 +217,7 @@ int fabind_coord_update_bwd(const float* d, const float* s, const int* rowptr, i
 int fabind_cross_attn_bwd(const float* qg, int ldq, const float* kv, int ldkv, const float* bias, int bias_ld,
                           int lin_col, int gate_col, const int* desc, int B, int max_nq, int max_nk, float scale,
                           const float* out, const float* lse, const float* dout, float* dqg, float* dkv, float* dbias,
-                          float* dO, float* Dv, hipStream_t stream);
+                          float* dO, float* Dv, int n_q_rows, int n_k_rows, hipStream_t stream);
 int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const float* a0, const float* b0, int ld0, int H,
                              const float* a1, const float* b1, int ld1, int H2, const int* red_p, const int* red_c, int n,
                              float* da0, float* db0, int ldd0, float* da1, float* db1, int ldd1, hipStream_t stream);
