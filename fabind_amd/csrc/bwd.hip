@@ -757,15 +757,36 @@ __global__ __launch_bounds__(256) void pair_bias_bwd_b_kernel(const float* __res
         for (int jj = 0; jj < PB_JT; ++jj)
 #pragma unroll
             for (int o = 0; o < 8; ++o) T[jj][o] = 0.f;
-        for (int i = 0; i < P; ++i) {
-            const float ai = ab[(size_t)p_index[p_off + i] * ld + h];
+        // protein-side rows of a complex are contiguous nodes: p_index[p_off + i] = p_index[p_off] + i
+        const float* a0 = ab + (size_t)p_index[p_off] * ld + h;
+        const int jn = min(PB_JT, C - j0);
+        int i = 0;
+        for (; i + 4 <= P; i += 4) {              // 4 independent a0 loads in flight per lane
+            float ai[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ai[u] = a0[(size_t)(i + u) * ld];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float* Dp = dout + ((size_t)pair_off + (size_t)(i + u) * C + j0) * 8;
+#pragma unroll
+                for (int jj = 0; jj < PB_JT; ++jj) {
+                    if (jj < jn) {
+                        const float4 d0 = *(const float4*)(Dp + jj * 8), d1 = *(const float4*)(Dp + jj * 8 + 4);
+                        T[jj][0] += d0.x * ai[u]; T[jj][1] += d0.y * ai[u]; T[jj][2] += d0.z * ai[u]; T[jj][3] += d0.w * ai[u];
+                        T[jj][4] += d1.x * ai[u]; T[jj][5] += d1.y * ai[u]; T[jj][6] += d1.z * ai[u]; T[jj][7] += d1.w * ai[u];
+                    }
+                }
+            }
+        }
+        for (; i < P; ++i) {
+            const float av = a0[(size_t)i * ld];
             const float* Dp = dout + ((size_t)pair_off + (size_t)i * C + j0) * 8;
 #pragma unroll
             for (int jj = 0; jj < PB_JT; ++jj) {
-                if (j0 + jj < C) {
+                if (jj < jn) {
                     const float4 d0 = *(const float4*)(Dp + jj * 8), d1 = *(const float4*)(Dp + jj * 8 + 4);
-                    T[jj][0] += d0.x * ai; T[jj][1] += d0.y * ai; T[jj][2] += d0.z * ai; T[jj][3] += d0.w * ai;
-                    T[jj][4] += d1.x * ai; T[jj][5] += d1.y * ai; T[jj][6] += d1.z * ai; T[jj][7] += d1.w * ai;
+                    T[jj][0] += d0.x * av; T[jj][1] += d0.y * av; T[jj][2] += d0.z * av; T[jj][3] += d0.w * av;
+                    T[jj][4] += d1.x * av; T[jj][5] += d1.y * av; T[jj][6] += d1.z * av; T[jj][7] += d1.w * av;
                 }
             }
         }

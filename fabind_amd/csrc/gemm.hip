@@ -257,6 +257,33 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
     if (RAW_BARRIER) barrier();            // the staging tile / sDot are reused by the next tile
 }
 
+// fp32 output (node-level residual stream): bias (+ residual) and direct 4-byte stores, no runtime switches
+template <int BM_, bool HAS_R>
+__device__ __forceinline__ void gemm_epilogue_f32(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], int M, int N, int ldc, int m0,
+                                                  int n0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, cq = lane >> 4;
+    float* C = (float*)p.C;
+    const float* R = (const float*)p.R;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + fr;
+        if (col >= N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + cq * 4 + r;
+                if (row < M) {
+                    float v = acc[i][j][r] + bv;
+                    if (HAS_R) v += R[(size_t)row * p.ldr + col];
+                    C[(size_t)row * ldc + col] = v;
+                }
+            }
+    }
+}
+
 // returns true when the fast epilogue applies (decided per launch on the host -> p.epi_fast)
 template <int BM_, bool RAW_BARRIER>
 __device__ __forceinline__ bool gemm_epilogue_dispatch(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sDot, bf16_t* sOut,
@@ -271,6 +298,8 @@ __device__ __forceinline__ bool gemm_epilogue_dispatch(const FabindGemmArgs& p, 
         case 6: EPI(FB_ACT_RELU, false, false, true);
         case 7: gemm_epilogue_fast<BM_, FB_ACT_SILU, true, false, true, RAW_BARRIER, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 8: gemm_epilogue_fast<BM_, FB_ACT_RELU, true, false, true, RAW_BARRIER, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
+        case 9: gemm_epilogue_f32<BM_, false>(p, acc, M, N, ldc, m0, n0); return true;
+        case 10: gemm_epilogue_f32<BM_, true>(p, acc, M, N, ldc, m0, n0); return true;
         default: return false;
     }
 #undef EPI
@@ -731,6 +760,10 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     FB_REQUIRE(!(p.a_dtype == FB_DT_BF16 && (p.lda % 8 != 0)), "fabind_gemm: bf16 A needs lda % 8 == 0");
     FB_REQUIRE(!(p.w_dtype == FB_DT_BF16 && (p.ldw % 8 != 0)), "fabind_gemm: bf16 W needs ldw % 8 == 0");
     p.epi_fast = 0;
+    if (!p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && !p.r_index && p.C != nullptr &&
+        p.c_dtype == FB_DT_F32 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
+        p.epi_fast = p.R ? 10 : 9;
+    } else
     if (!p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.R && !p.accumulate && !p.r_index &&
         (p.C == nullptr || p.c_dtype == FB_DT_BF16) && (p.C2 == nullptr || p.C != nullptr)) {
         const bool hc = p.C != nullptr, hc2 = p.C2 != nullptr, hd = p.dotvec != nullptr;

@@ -260,7 +260,7 @@ def gcl_layer(p, h, x, lay, g, clampv):
 def cross_attention(p, h, lay, pairbias, layer):
     """CrossAttentionModule node path (cross_att.py:38-49) on compact protein / ligand arrays."""
     fast = _fast(h, p["Wo_p"])
-    od = torch.bfloat16 if fast else torch.float32
+    od = ops.act_dtype()
     c16 = (lambda t: _b16(t)) if fast else (lambda t: t)
     hp, hc = ops.take_rows(h, lay.p_index64), ops.take_rows(h, lay.c_index64)
     scale = 1.0 / math.sqrt(32.0)
