@@ -195,11 +195,15 @@ def prepare_stack_params(model):
             d["Wt1_" + tag], d["bt1_" + tag] = W(tr.linear_1.weight), tr.linear_1.bias
             d["Wt2_" + tag], d["bt2_" + tag] = W(tr.linear_2.weight), tr.linear_2.bias
         i32 = cam.inter_layer
-        d["W_ab32"] = W(_cat([i32.linear_p.weight, i32.linear_c.weight]))
-        d["b_ab32"] = _cat([i32.linear_p.bias, i32.linear_c.bias]).contiguous()
+        # the 32-wide Hadamard block is zero-padded to 64 columns so that K = H + 64 stays a multiple of 64
+        # (LDS-DMA GEMM path); the padded rows/columns are exact zeros and do not change the result
+        z32w = torch.zeros_like(i32.linear_p.weight)
+        z32b = torch.zeros_like(i32.linear_p.bias)
+        d["W_ab32"] = W(_cat([i32.linear_p.weight, z32w, i32.linear_c.weight, z32w]))
+        d["b_ab32"] = _cat([i32.linear_p.bias, z32b, i32.linear_c.bias, z32b]).contiguous()
         pt = cam.pair_transition
-        Woo = _cat([Wo0, i32.linear_out.weight], 1)                  # [H, H+32]
-        d["Wcomp1"] = W(pt.linear_1.weight @ Woo)                    # [2H, H+32]
+        Woo = _cat([Wo0, i32.linear_out.weight, torch.zeros_like(i32.linear_out.weight)], 1)   # [H, H+64]
+        d["Wcomp1"] = W(pt.linear_1.weight @ Woo)                    # [2H, H+64]
         d["bcomp1"] = (pt.linear_1.weight @ (bo0 + i32.linear_out.bias) + pt.linear_1.bias).contiguous()
         d["u"] = (pt.linear_2.weight.t() @ m.attn_bias_proj.weight[0]).contiguous()   # [2H]
         Wkv, bkv = m.linear_kv.weight, m.linear_kv.bias
@@ -287,8 +291,8 @@ def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv):
     h = cross_attention(p, h, lay, pairbias, layer)
     # pair embedding at the inter-edge pairs only -> scalar attention bias (egnn.py:208, 286-304)
     h16 = _b16(h) if _fast(h, x, p["Wqkv"]) else h
-    ab32 = ops.linear(h16, p["W_ab32"], p["b_ab32"])                                   # [N,64]
-    hd = ops.pair_hadamard(a0b0, H, ab32, 32, g.red_p, g.red_c)                        # [n_red, H+32]
+    ab32 = ops.linear(h16, p["W_ab32"], p["b_ab32"])                                   # [N,128] (a32|0|b32|0)
+    hd = ops.pair_hadamard(a0b0, H, ab32, 64, g.red_p, g.red_c)                        # [n_red, H+64]
     bias_part = ops.linear_rowdot(hd, p["Wcomp1"], p["bcomp1"], p["u"], act_epi=K.ACT_RELU)
     qkv = ops.linear(h16, p["Wqkv"], p["bqkv"])                                        # [N,3H]
     cv = ops.linear(qkv[:, 2 * H:], p["Wc"], p["bc"])                                  # [N,H]
