@@ -731,6 +731,132 @@ static int launch_persist(const FabindGemmArgs& p, hipStream_t stream) {
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN contraction for weight gradients:  C[m, n] = sum_e Y[e, m] * X[e, n]   (Y, X row-major bf16, e = rows)
+// Both operands have the contraction index as their SLOW dimension, so the MFMA fragments (8 consecutive e per
+// lane) are formed with the LDS transpose read ds_read_b64_tr_b16: in every 16-lane group, lane l receives
+// element (l % 4) of the 8-byte pieces addressed by lanes {l/4, 4 + l/4, 8 + l/4, 12 + l/4} (probe:
+// tools/probes/tr_probe.hip).  Tiles [32 e][256 m] and [32 e][128 n] arrive by LDS-DMA; their 32-byte granules
+// are XOR-swizzled per row on the source side so that the transpose reads are bank-conflict free.
+// Split over e across blockIdx.y; fp32 partials C[split][M][N].
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* p_lo, const bf16_t* p_hi) {
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    u32x2 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"((unsigned)(uintptr_t)p_lo) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"((unsigned)(uintptr_t)p_hi) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi)::"memory");
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(bf16x8_t, r);
+}
+__device__ __forceinline__ int tn_swz(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+
+template <int NSTAGE>
+__global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ X,
+                                                           int ldx, float* C, int M, int N, int E, int e_per,
+                                                           const bf16_t* __restrict__ zero_page) {
+    constexpr int TM = 256, TN_ = 128, BKE = 32, NW = 8;
+    constexpr int PY = (BKE * TM * 2) / 1024, PX = (BKE * TN_ * 2) / 1024, PPW = (PY + PX) / NW;   // 16 + 8 pieces -> 3 per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sT = (bf16_t*)smem;                                  // [NSTAGE][ Y tile 32x256 | X tile 32x128 ]
+    constexpr int STAGE_ELEMS = BKE * (TM + TN_);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nbx = (N + TN_ - 1) / TN_;
+    const int m0 = (blockIdx.x / nbx) * TM, n0 = (blockIdx.x % nbx) * TN_;
+    const int ebeg = blockIdx.y * e_per, eend = min(E, ebeg + e_per);
+    const int nk = (eend - ebeg + BKE - 1) / BKE;
+
+    // per-lane source descriptors of this wave's PPW pieces: (is_y, row-in-tile, element offset in the row)
+    int p_isy[PPW], p_row[PPW], p_col[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int q = wave * PPW + j;
+        if (q < PY) {                        // Y piece: 2 rows of 512 B
+            const int r = q * 2 + (lane >> 5), p = lane & 31;          // 16-B chunk position in the LDS row
+            const int src = (((p >> 1) ^ tn_swz(r)) << 1) | (p & 1);
+            p_isy[j] = 1; p_row[j] = r; p_col[j] = m0 + src * 8;
+        } else {                             // X piece: 4 rows of 256 B
+            const int r = (q - PY) * 4 + (lane >> 4), p = lane & 15;
+            const int src = (((p >> 1) ^ tn_swz(r)) << 1) | (p & 1);
+            p_isy[j] = 0; p_row[j] = r; p_col[j] = n0 + src * 8;
+        }
+    }
+    auto stage = [&](int st, int e0) {
+        bf16_t* base = sT + (size_t)st * STAGE_ELEMS;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int q = wave * PPW + j;
+            const int e = e0 + p_row[j];
+            const bf16_t* src;
+            if (p_isy[j]) src = (e < eend && p_col[j] < M) ? Y + (size_t)e * ldy + p_col[j] : zero_page;
+            else src = (e < eend && p_col[j] < N) ? X + (size_t)e * ldx + p_col[j] : zero_page;
+            bf16_t* dst = p_isy[j] ? base + (size_t)q * 512 : base + BKE * TM + (size_t)(q - PY) * 512;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+        }
+    };
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
+        if (s_ < nk) stage(s_, ebeg + s_ * BKE);
+    const int g = lane >> 4, sl = lane & 15;
+    const int r1 = g * 8 + (sl >> 2), r2 = r1 + 4, co = (sl & 3) * 4;
+    const int z1 = tn_swz(r1), z2 = tn_swz(r2);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int ahead = min(NSTAGE - 2, nk - 1 - kt);
+        if (ahead >= 2) wait_vmcnt<2 * PPW>(); else if (ahead == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, ebeg + (kt + NSTAGE - 1) * BKE);
+        const bf16_t* tY = sT + (size_t)(kt % NSTAGE) * STAGE_ELEMS;
+        const bf16_t* tX = tY + BKE * TM;
+        bf16x8_t af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = wm * 4 + i;                           // 16-column granule of the Y tile
+            af[i] = tr_frag(tY + r1 * TM + ((gm ^ z1) * 16) + co, tY + r2 * TM + ((gm ^ z2) * 16) + co);
+            const int gn = wn * 4 + i;
+            bfr[i] = tr_frag(tX + r1 * TN_ + ((gn ^ z1) * 16) + co, tX + r2 * TN_ + ((gn ^ z2) * 16) + co);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    float* Cs = C + (size_t)blockIdx.y * M * N;
+    const int fr = lane & 15, cq = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + cq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
+                if (row < M && col < N) Cs[(size_t)row * N + col] = acc[i][j][r];
+            }
+}
+
+extern "C" int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_part, int M, int N, int E, int splits,
+                              const void* zero_page, hipStream_t stream) {
+    FB_REQUIRE(M % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "fabind_gemm_tn: M, N, ldy, ldx must be multiples of 8");
+    FB_REQUIRE(((uintptr_t)Y % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)zero_page % 16 == 0), "fabind_gemm_tn: alignment");
+    if (M <= 0 || N <= 0 || splits <= 0) return 0;
+    constexpr int NST = 3;
+    const size_t lds = (size_t)NST * 32 * (256 + 128) * 2;
+    static bool set_ = false;
+    if (!set_) { (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; }
+    int e_per = ((E + splits - 1) / splits + 31) / 32 * 32;
+    dim3 grid(((M + 255) / 256) * ((N + 127) / 128), splits);
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<NST>), grid, dim3(512), lds, stream, (const bf16_t*)Y, ldy, (const bf16_t*)X, ldx,
+                       C_part, M, N, E, e_per, (const bf16_t*)zero_page);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
 static int g_gemm_persist = 0;   // measured slower than 2 work-groups/CU of the tile-per-block kernel (see tools/gemm_bench.py)
 extern "C" void fabind_gemm_set_persistent(int on) { g_gemm_persist = on; }
 static int g_gemm_cfg = 3;   // 256x128 tile, BK = 32, 3-stage ring (best of the measured set, see tools/gemm_bench.py)

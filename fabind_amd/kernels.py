@@ -253,3 +253,27 @@ def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows)
                                                               ptr(W2p), ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s),
                                                               stream()), "fabind_gcl_edge_fused"))
     return agg, s[:E]
+
+
+_ZERO_PAGE = {}
+
+
+def gemm_tn(Y, X, splits=None):
+    """sum_e Y[e,:]^T X[e,:] -> [M, N] fp32 (bf16 operands, LDS transpose reads; no materialised transposes)."""
+    E, M = Y.shape
+    N = X.shape[1]
+    assert X.shape[0] == E and Y.dtype == torch.bfloat16 and X.dtype == torch.bfloat16
+    dev = Y.device
+    zp = _ZERO_PAGE.get(dev)
+    if zp is None:
+        zp = _ZERO_PAGE[dev] = torch.zeros(256, dtype=torch.bfloat16, device=dev)
+    if splits is None:
+        tiles = ((M + 255) // 256) * ((N + 127) // 128)
+        splits = max(1, min(256, (E // 2048), max(1, 1024 // tiles)))
+    part = torch.empty((splits, M, N), dtype=torch.float32, device=dev)
+    _profiled("fabind_gemm_tn M=%d N=%d E=%d" % (M, N, E), 2.0 * M * N * E,
+              lambda: check(_lib.load().fabind_gemm_tn(ptr(Y), _ld(Y), ptr(X), _ld(X), ptr(part), M, N, E, splits, ptr(zp),
+                                                       stream()), "fabind_gemm_tn"))
+    if splits == 1:
+        return part[0]
+    return colsum(part.reshape(splits, M * N)).reshape(M, N)

@@ -53,7 +53,16 @@ def _transposed(x, act=K.ACT_NONE, Rp=None):
 
 
 def _weight_grad(dpre, x, act_pro, x2=None):
-    """dW = dpre^T [act(x) | x2]  as split-K NT GEMMs over the (padded) row dimension."""
+    """dW = dpre^T [act(x) | x2].  bf16: TN contraction with LDS transpose reads (no transposed copies);
+    fp32 parity mode / odd widths: explicit transposes + split-K NT GEMMs over the (padded) row dimension."""
+    bf = torch.bfloat16
+    if (act_pro == K.ACT_NONE and dpre.dtype == bf and x.dtype == bf and (x2 is None or x2.dtype == bf)
+            and dpre.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and (x2 is None or x2.shape[1] % 8 == 0)
+            and dpre.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dpre.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
+        dW = K.gemm_tn(dpre, x)
+        if x2 is not None:
+            dW = torch.cat([dW, K.gemm_tn(dpre, x2)], 1)
+        return dW
     S, Rp = _ksplit(dpre.shape[0])
     dpt = _transposed(dpre, Rp=Rp)
     xt = _transposed(x, act_pro, Rp=Rp)

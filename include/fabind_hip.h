@@ -67,6 +67,11 @@ typedef struct FabindGemmArgs {
 
 int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream);
 
+/* Weight-gradient contraction without transposes: C_part[s][m][n] = sum_{e in split s} Y[e,m] * X[e,n]
+ * (bf16 row-major operands, fp32 partials [splits, M, N]; zero_page = >= 16 zero bytes in device memory). */
+int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_part, int M, int N, int E, int splits,
+                   const void* zero_page, hipStream_t stream);
+
 /* out[C,R] = act(in[R,C])^T -- feeds weight-gradient contractions (autograd of the ops above). */
 int fabind_transpose_act(const void* in, int in_dt, int ldi, void* out, int out_dt, int ldo, int R, int C, int act,
                          hipStream_t stream);

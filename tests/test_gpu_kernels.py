@@ -132,3 +132,22 @@ def test_fused_edge_pipeline_matches_unfused(H):
                               b2.to(dev), K.pack_frag(Wc.to(dev)), bc.to(dev), w3.to(dev), N)
     assert (agg.cpu() - agg_ref).abs().max() <= 2e-2 * max(1.0, float(agg_ref.abs().max()))
     assert (s[:, 0].cpu() - s_ref).abs().max() <= 2e-2 * max(1.0, float(s_ref.abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(5000, 512, 512), (777, 256, 128), (100000, 512, 1024), (33, 64, 64)])
+def test_gemm_tn_transpose_reads(shape):
+    """Weight-gradient contraction sum_e Y[e,m] X[e,n] with ds_read_b64_tr_b16 fragments (no transposes)."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    E, M, N = shape
+    g = torch.Generator().manual_seed(E)
+    Y = torch.randn(E, M, generator=g).bfloat16()
+    X = torch.randn(E, N, generator=g).bfloat16()
+    ref = Y.double().T @ X.double()
+    out = K.gemm_tn(Y.to(dev), X.to(dev))
+    assert (out.cpu().double() - ref).abs().max() <= 2e-3 * float(ref.abs().max()) + 1e-3 * E ** 0.5
+    # strided views (column slices of wider tensors) and a forced odd split count
+    Yw = torch.randn(E, M + 64, generator=g).bfloat16().to(dev)
+    out2 = K.gemm_tn(Yw[:, 64:], X.to(dev), splits=3)
+    ref2 = Yw[:, 64:].cpu().double().T @ X.double()
+    assert (out2.cpu().double() - ref2).abs().max() <= 2e-3 * float(ref2.abs().max()) + 1e-3 * E ** 0.5
