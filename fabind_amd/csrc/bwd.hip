@@ -36,24 +36,32 @@ extern "C" int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_d
 __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const void* z, int z_dt, const float* dpart, int np,
                                                          const float* u, int act, int M, int N, void* dz,
                                                          float* scratch, int rows_per) {
-    __shared__ float part[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), q = threadIdx.x >> 6;
+    // 256 columns per block (4 consecutive per lane), 4 row-lanes, fixed-order combine of the du partials
+    __shared__ float4 part[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
     const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
-    float s = 0.f;
-    if (c < N) {
-        const float uc = u[c];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c + 3 < N) {
+        const float4 uc = *(const float4*)(u + c);
         const int t = c / 128;
         for (int r = r0 + q; r < r1; r += 4) {
-            const float zv = ld_any(z, z_dt, (size_t)r * N + c), g = dpart[(size_t)r * np + t];
-            st_any(dz, z_dt, (size_t)r * N + c, g * uc * apply_dact(zv, act));
-            s += g * apply_act(zv, act);
+            const float4 zv = ld4_any(z, z_dt, (size_t)r * N + c);
+            const float g = dpart[(size_t)r * np + t];
+            st4_any(dz, z_dt, (size_t)r * N + c,
+                    make_float4(g * uc.x * apply_dact(zv.x, act), g * uc.y * apply_dact(zv.y, act),
+                                g * uc.z * apply_dact(zv.z, act), g * uc.w * apply_dact(zv.w, act)));
+            s.x += g * apply_act(zv.x, act); s.y += g * apply_act(zv.y, act);
+            s.z += g * apply_act(zv.z, act); s.w += g * apply_act(zv.w, act);
         }
     }
-    part[q][threadIdx.x & 63] = s;
+    part[q][lane] = s;
     __syncthreads();
-    if (q == 0 && c < N) {
-        const int l = threadIdx.x;
-        scratch[(size_t)blockIdx.y * N + c] = (part[0][l] + part[1][l]) + (part[2][l] + part[3][l]);
+    if (q == 0 && c + 3 < N) {
+        const float4 a = part[0][lane], b = part[1][lane], d_ = part[2][lane], e = part[3][lane];
+        float* o = scratch + (size_t)blockIdx.y * N + c;
+        o[0] = (a.x + b.x) + (d_.x + e.x); o[1] = (a.y + b.y) + (d_.y + e.y);
+        o[2] = (a.z + b.z) + (d_.z + e.z); o[3] = (a.w + b.w) + (d_.w + e.w);
     }
 }
 __global__ void sum_chunks_kernel(const float* scratch, float* out, int C, int nchunk) {
@@ -66,8 +74,9 @@ __global__ void sum_chunks_kernel(const float* scratch, float* out, int C, int n
 extern "C" int fabind_rowdot_bwd(const void* z, int z_dt, const float* dpart, int np, const float* u, int act, int M,
                                  int N, void* dz, float* du, float* scratch, int nchunk, hipStream_t stream) {
     if (M <= 0 || N <= 0) return 0;
+    FB_REQUIRE(N % 4 == 0, "fabind_rowdot_bwd: N % 4");
     int rows_per = (M + nchunk - 1) / nchunk;
-    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((N + 63) / 64, nchunk), dim3(256), 0, stream, z, z_dt, dpart, np, u, act,
+    hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((N + 255) / 256, nchunk), dim3(256), 0, stream, z, z_dt, dpart, np, u, act,
                        M, N, dz, scratch, rows_per);
     hipLaunchKernelGGL(sum_chunks_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, scratch, du, N, nchunk);
     FB_CHECK_LAUNCH();

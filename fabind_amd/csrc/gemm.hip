@@ -1038,12 +1038,20 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const void* in, int in
         for (int k = 0; k < 4 && c + k < C; ++k) scratch[(size_t)blockIdx.y * C + c + k] = o[k];
     }
 }
-__global__ void colsum_final_kernel(const float* scratch, float* out, int C, int nchunk, int accumulate) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* scratch, float* out, int C, int nchunk, int accumulate) {
+    // 64 columns per block, the chunk rows split over 4 row-lanes, fixed-order combine
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
     float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += scratch[(size_t)k * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C)
+        for (int k = q; k < nchunk; k += 4) s += scratch[(size_t)k * C + c];
+    part[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        const float t = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 extern "C" int fabind_colsum(const void* in, int in_dt, int ldi, float* out, int R, int C, int accumulate,
@@ -1054,7 +1062,7 @@ extern "C" int fabind_colsum(const void* in, int in_dt, int ldi, float* out, int
     if (rows_per < 1) rows_per = 1;
     hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 255) / 256, nchunk), dim3(256), 0, stream, in, in_dt, ldi, scratch, R,
                        C, rows_per);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, scratch, out, C, nchunk,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, scratch, out, C, nchunk,
                        accumulate);
     FB_CHECK_LAUNCH();
     return 0;

@@ -88,7 +88,7 @@ def transpose_act(x, act=ACT_NONE, out_dtype=None):
 
 def colsum(x, out=None, accumulate=False):
     R, C = x.shape
-    nchunk = max(1, min(2048, (R + 255) // 256))
+    nchunk = max(1, min(1024, (R + 255) // 256))
     scratch = torch.empty((nchunk, C), dtype=torch.float32, device=x.device)
     if out is None:
         out = torch.empty((C,), dtype=torch.float32, device=x.device)

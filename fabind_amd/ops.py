@@ -30,7 +30,7 @@ def needs_grad(*ts):
 
 
 def _nchunk(rows):
-    return max(1, min(256, (rows + 1023) // 1024))
+    return max(1, min(1024, (rows + 255) // 256))
 
 
 def _ksplit(R):
