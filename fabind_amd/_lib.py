@@ -20,13 +20,13 @@ class GemmArgs(ctypes.Structure):
     _fields_ = [(n, _vp) for n in ("A", "A2", "W", "C", "bias", "R", "r_index", "dotvec", "dot_out", "aux", "groups", "C2")] + \
                [(n, _i) for n in ("M", "N", "K", "K1", "lda", "lda2", "ldw", "ldc", "ldr", "ldaux", "dot_ld",
                                   "a_dtype", "w_dtype", "c_dtype", "aux_dtype", "act_pro", "act_epi", "dact_epi",
-                                  "accumulate", "store_preact", "n_groups", "max_m", "max_n", "epi_fast", "k_splits")] + [("alpha", _f)]
+                                  "accumulate", "store_preact", "n_groups", "max_m", "max_n", "groups_ext", "epi_fast", "k_splits")] + [("alpha", _f)]
 
 
 # name -> argtypes (every function returns int and takes the stream last)
 SIGNATURES = {
     "fabind_gemm": [ctypes.POINTER(GemmArgs), _vp],
-    "fabind_gemm_tn": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp],
+    "fabind_gemm_tn": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "fabind_transpose_act": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fabind_colsum": [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp],
     "fabind_edges_count": [_vp, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp],
@@ -61,6 +61,7 @@ SIGNATURES = {
                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "fabind_las_step_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp],
     "fabind_pair_bias_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "fabind_pair_bias_finish": [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "fabind_layernorm_fwd": [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp],
     "fabind_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
 }

@@ -828,3 +828,31 @@ extern "C" int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, 
     FB_CHECK_LAUNCH();
     return 0;
 }
+
+// finishing pass of the GEMM formulation of the pair-bias adjoint:  T[(jc,o), h] = sum_i D[i,(j,o)] a0[i,h]
+//   db0[node(jc), h] += sum_o w[o,h] T[(jc,o),h];   dw[o,h] += sum_jc b0[node(jc),h] T[(jc,o),h]   (float atomics, sumC adds)
+__global__ __launch_bounds__(256) void pair_bias_finish_kernel(const float* __restrict__ T, const float* __restrict__ ab, int ld,
+                                                               int H, const float* __restrict__ w, const int* c_index, int n_c,
+                                                               float* dab, float* dw) {
+    const int jc = blockIdx.x;
+    if (jc >= n_c) return;
+    const int cn = c_index[jc];
+    for (int h = threadIdx.x; h < H; h += 256) {
+        const float bj = ab[(size_t)cn * ld + H + h];
+        float db = 0.f;
+#pragma unroll
+        for (int o = 0; o < 8; ++o) {
+            const float t = T[((size_t)jc * 8 + o) * H + h];
+            db += w[o * H + h] * t;
+            atomicAdd(&dw[o * H + h], bj * t);
+        }
+        dab[(size_t)cn * ld + H + h] += db;
+    }
+}
+extern "C" int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, const float* w, const int* c_index,
+                                       int n_c, float* dab, float* dw, hipStream_t stream) {
+    if (n_c <= 0) return 0;
+    hipLaunchKernelGGL(pair_bias_finish_kernel, dim3(n_c), dim3(256), 0, stream, T, ab, ld, H, w, c_index, n_c, dab, dw);
+    FB_CHECK_LAUNCH();
+    return 0;
+}

@@ -314,7 +314,18 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(FabindGemmArgs p) {
 
     int M = p.M, N = p.N, ldc = p.ldc;
     long a_row0 = 0, w_row0 = 0, c_off = 0;
-    if (p.groups) {
+    int Kg = p.K, lda_g = p.lda, K1g = p.K1;
+    long a_eoff = 0, w_eoff = 0;
+    if (p.groups && p.groups_ext) {
+        // extended descriptor int32[16]: {M, N, K, lda, a_off lo/hi, w_off lo/hi, c_off lo/hi, ldc}: fully ragged operands
+        const int* g = p.groups + (size_t)blockIdx.z * 16;
+        M = g[0]; N = g[1]; Kg = g[2]; lda_g = g[3];
+        a_eoff = (long)(unsigned)g[4] | ((long)g[5] << 32);
+        w_eoff = (long)(unsigned)g[6] | ((long)g[7] << 32);
+        c_off = (long)(unsigned)g[8] | ((long)g[9] << 32);
+        ldc = g[10];
+        K1g = Kg;
+    } else if (p.groups) {
         const int* g = p.groups + (size_t)blockIdx.z * 8;
         a_row0 = g[0]; M = g[1]; w_row0 = g[2]; N = g[3];
         c_off = (long)(unsigned)g[4] | ((long)g[5] << 32);
@@ -325,11 +336,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(FabindGemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const TA* A = (const TA*)p.A + a_row0 * p.lda;
+    const TA* A = (const TA*)p.A + a_row0 * lda_g + a_eoff;
     const TA* A2 = p.A2 ? (const TA*)p.A2 + a_row0 * p.lda2 : nullptr;
-    const TM* W = (const TM*)p.W + w_row0 * p.ldw;
-    int K = p.K;
-    const int K1 = p.K1;
+    const TM* W = (const TM*)p.W + w_row0 * p.ldw + w_eoff;
+    int K = Kg;
+    const int K1 = K1g;
     int kbeg = 0;
     if (!p.groups && p.k_splits > 1) {      // split-K: this work-group owns K range [kbeg, K)
         const int per = ((p.K / p.k_splits + BK - 1) / BK) * BK;
@@ -337,6 +348,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(FabindGemmArgs p) {
         K = min(p.K, kbeg + per);
         c_off = (long)blockIdx.z * M * ldc;
     }
+    if (p.groups_ext) { a_row0 = 0; w_row0 = 0; }
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -358,7 +370,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(FabindGemmArgs p) {
             ra[i] = z;
             rb[i] = z;
             if (gm < M && gk < K) {
-                const TA* src = (gk < K1) ? A + (size_t)gm * p.lda + gk : A2 + (size_t)gm * p.lda2 + (gk - K1);
+                const TA* src = (gk < K1) ? A + (size_t)gm * lda_g + gk : A2 + (size_t)gm * p.lda2 + (gk - K1);
                 ra[i] = load8<TA>(src);
                 if (p.act_pro != FB_ACT_NONE) {
 #pragma unroll
@@ -755,7 +767,7 @@ __device__ __forceinline__ int tn_swz(int r) { return (r & 3) | (((r >> 3) & 1) 
 template <int NSTAGE>
 __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ X,
                                                            int ldx, float* C, int M, int N, int E, int e_per,
-                                                           const bf16_t* __restrict__ zero_page) {
+                                                           const bf16_t* __restrict__ zero_page, const int* groups) {
     constexpr int TM = 256, TN_ = 128, BKE = 32, NW = 8;
     constexpr int PY = (BKE * TM * 2) / 1024, PX = (BKE * TN_ * 2) / 1024, PPW = (PY + PX) / NW;   // 16 + 8 pieces -> 3 per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -763,8 +775,18 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const bf16_t* __restr
     constexpr int STAGE_ELEMS = BKE * (TM + TN_);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    long c_goff = 0;
+    if (groups) {   // ragged batch: int32[8] = {y_off lo/hi (elements), ldy, M, x_row0, E, c_off lo/hi (elements)}
+        const int* g = groups + (size_t)blockIdx.z * 8;
+        Y += (long)(unsigned)g[0] | ((long)g[1] << 32);
+        ldy = g[2]; M = g[3];
+        X += (size_t)g[4] * ldx;
+        E = g[5];
+        c_goff = (long)(unsigned)g[6] | ((long)g[7] << 32);
+    }
     const int nbx = (N + TN_ - 1) / TN_;
     const int m0 = (blockIdx.x / nbx) * TM, n0 = (blockIdx.x % nbx) * TN_;
+    if (m0 >= M) return;
     const int ebeg = blockIdx.y * e_per, eend = min(E, ebeg + e_per);
     const int nk = (eend - ebeg + BKE - 1) / BKE;
 
@@ -827,7 +849,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const bf16_t* __restr
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    float* Cs = C + (size_t)blockIdx.y * M * N;
+    float* Cs = C + c_goff + (size_t)blockIdx.y * M * N;
     const int fr = lane & 15, cq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -841,18 +863,19 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const bf16_t* __restr
 }
 
 extern "C" int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_part, int M, int N, int E, int splits,
-                              const void* zero_page, hipStream_t stream) {
+                              const void* zero_page, const int* groups, int n_groups, hipStream_t stream) {
     FB_REQUIRE(M % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "fabind_gemm_tn: M, N, ldy, ldx must be multiples of 8");
     FB_REQUIRE(((uintptr_t)Y % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)zero_page % 16 == 0), "fabind_gemm_tn: alignment");
+    FB_REQUIRE(!(groups && splits != 1), "fabind_gemm_tn: grouped launches are not split");
     if (M <= 0 || N <= 0 || splits <= 0) return 0;
     constexpr int NST = 3;
     const size_t lds = (size_t)NST * 32 * (256 + 128) * 2;
     static bool set_ = false;
     if (!set_) { (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; }
     int e_per = ((E + splits - 1) / splits + 31) / 32 * 32;
-    dim3 grid(((M + 255) / 256) * ((N + 127) / 128), splits);
+    dim3 grid(((M + 255) / 256) * ((N + 127) / 128), splits, groups ? n_groups : 1);
     hipLaunchKernelGGL((gemm_tn_bf16_kernel<NST>), grid, dim3(512), lds, stream, (const bf16_t*)Y, ldy, (const bf16_t*)X, ldx,
-                       C_part, M, N, E, e_per, (const bf16_t*)zero_page);
+                       C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups);
     FB_CHECK_LAUNCH();
     return 0;
 }
@@ -879,7 +902,7 @@ static int launch_pipe(const FabindGemmArgs& p, int maxM, int maxN, hipStream_t 
 
 extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     FabindGemmArgs p = *args;
-    FB_REQUIRE(p.K % 8 == 0, "fabind_gemm: K must be a multiple of 8");
+    FB_REQUIRE(p.groups_ext || p.K % 8 == 0, "fabind_gemm: K must be a multiple of 8");
     FB_REQUIRE(p.A2 == nullptr || (p.K1 % BK == 0), "fabind_gemm: K1 must be a multiple of 32 when A2 is given");
     if (p.A2 == nullptr) p.K1 = p.K;
     FB_REQUIRE(p.lda % 4 == 0 && p.ldw % 4 == 0, "fabind_gemm: lda/ldw must be multiples of 4");
@@ -917,7 +940,7 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
         hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, stream, p);
     } else if (p.a_dtype == FB_DT_F32) {
         hipLaunchKernelGGL((gemm_nt_kernel<float, bf16_t>), grid, dim3(256), 0, stream, p);
-    } else if (p.act_pro == FB_ACT_NONE && p.K % FBK == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 &&
+    } else if (!p.groups_ext && p.act_pro == FB_ACT_NONE && p.K % FBK == 0 && p.lda % 8 == 0 && p.ldw % 8 == 0 &&
                ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) &&
                (p.A2 == nullptr || (g_gemm_cfg != 0 && p.K1 % FBK == 0 && p.lda2 % 8 == 0 && ((uintptr_t)p.A2 % 16 == 0)))) {
         const long n_tiles = (long)((maxM + 255) / 256) * ((maxN + BN - 1) / BN);

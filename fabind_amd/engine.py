@@ -83,6 +83,10 @@ class Layout:
         self.pb_groups = desc([[off[b] + C[b], P[b], coff[b] * NO, C[b] * NO, s32(lo(pair_off[b] * NO)),
                                 hi(pair_off[b] * NO), C[b] * NO, 0] for b in range(B)])
         self.pb_max_n = int((C * NO).max())
+        # adjoint of the pair bias as two ragged batched contractions per attention block (ops._PairBias.backward)
+        self.pb_tn_groups = desc([[s32(lo(pair_off[b] * NO)), hi(pair_off[b] * NO), C[b] * NO, C[b] * NO, off[b] + C[b], P[b],
+                                   0, 0] for b in range(B)])          # c_off filled per H in ops
+        self.coff, self.pair_off_np = coff, pair_off
 
     def ranges(self, idx_first):
         """Per-complex [start,end) offsets of a complex-contiguous edge list given its first-node ids."""

@@ -34,7 +34,7 @@ def _ld(t):
 def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=None, r_index=None,
          out=None, out_dtype=torch.float32, want_out=True, dotvec=None, aux=None, dact=ACT_NONE, alpha=1.0,
          accumulate=False, groups=None, n_groups=0, max_m=0, max_n=0, M=None, N=None, ldc=None, k_splits=1,
-         out2=None):
+         out2=None, groups_ext=False):
     """C = epi(pro([A|A2]) @ W^T); see FabindGemmArgs.  Returns (C or None, dot_partials or None).
 
     `groups` (int32 [G,8] device tensor) selects the ragged-batched mode; then `out` must be given."""
@@ -44,7 +44,7 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     K = K1 + (A2.shape[1] if A2 is not None else 0)
     M = A.shape[0] if M is None else M
     N = W.shape[0] if N is None else N
-    assert W.shape[1] == K, "gemm: K mismatch %s vs %s" % (tuple(W.shape), K)
+    assert groups_ext or W.shape[1] == K, "gemm: K mismatch %s vs %s" % (tuple(W.shape), K)
     if want_out and out is None:
         out = torch.empty((k_splits, M, N) if k_splits > 1 else (M, N), dtype=out_dtype, device=A.device)
         if k_splits > 1:
@@ -72,6 +72,7 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     a.accumulate = 1 if accumulate else 0
     a.n_groups, a.max_m, a.max_n = n_groups, max_m, max_n
     a.k_splits = k_splits
+    a.groups_ext = 1 if groups_ext else 0
     a.alpha = alpha
     label = "fabind_gemm <%s,%s> M=%d N=%d K=%d" % (str(A.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""), M, N, K)
     _profiled(label, 2.0 * M * N * K, lambda: check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm"))
@@ -273,7 +274,18 @@ def gemm_tn(Y, X, splits=None):
     part = torch.empty((splits, M, N), dtype=torch.float32, device=dev)
     _profiled("fabind_gemm_tn M=%d N=%d E=%d" % (M, N, E), 2.0 * M * N * E,
               lambda: check(_lib.load().fabind_gemm_tn(ptr(Y), _ld(Y), ptr(X), _ld(X), ptr(part), M, N, E, splits, ptr(zp),
-                                                       stream()), "fabind_gemm_tn"))
+                                                       None, 0, stream()), "fabind_gemm_tn"))
     if splits == 1:
         return part[0]
     return colsum(part.reshape(splits, M * N)).reshape(M, N)
+
+
+def gemm_tn_grouped(Y, X, groups, n_groups, max_M, N, out, max_E):
+    """Ragged batch of TN contractions (one per complex); descriptors as in fabind_gemm_tn."""
+    dev = Y.device
+    zp = _ZERO_PAGE.get(dev)
+    if zp is None:
+        zp = _ZERO_PAGE[dev] = torch.zeros(256, dtype=torch.bfloat16, device=dev)
+    check(_lib.load().fabind_gemm_tn(ptr(Y), 8, ptr(X), _ld(X), ptr(out), max_M, N, max_E, 1, ptr(zp), ptr(groups), n_groups,
+                                     stream()), "fabind_gemm_tn(grouped)")
+    return out

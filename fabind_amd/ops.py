@@ -525,6 +525,29 @@ def _pair_bias_fwd(a0b0, H, wcomp, bconst, lay):
     return outs
 
 
+def _pair_bias_groups(lay, H, ld_ab):
+    """Ragged-batch descriptors of the two adjoint contractions (cached on the layout)."""
+    key = ("pbg", H, ld_ab)
+    if getattr(lay, "_pbg_key", None) != key:
+        import numpy as np
+        B, NO = lay.B, 8
+        lo = lambda v: int(v) & 0xFFFFFFFF
+        hi = lambda v: int(v) >> 32
+        s32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v
+        dev = lay.node_off.device
+        tn, nn = [], []
+        for b in range(B):
+            C_, P_ = int(lay.C[b]), int(lay.P[b])
+            yoff, coff8 = int(lay.pair_off_np[b]) * NO, int(lay.coff[b]) * NO
+            tn.append([s32(lo(yoff)), hi(yoff), C_ * NO, C_ * NO, int(lay.off[b]) + C_, P_, s32(lo(coff8 * H)), hi(coff8 * H)])
+            co = (int(lay.off[b]) + C_) * ld_ab
+            nn.append([P_, H, C_ * NO, C_ * NO, s32(lo(yoff)), hi(yoff), s32(lo(coff8)), hi(coff8), s32(lo(co)), hi(co), ld_ab,
+                       0, 0, 0, 0, 0])
+        lay._pbg = (torch.tensor(tn, dtype=torch.int32, device=dev), torch.tensor(nn, dtype=torch.int32, device=dev))
+        lay._pbg_key = key
+    return lay._pbg
+
+
 class _PairBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a0b0, wcomp, bconst, H, lay):
@@ -537,19 +560,36 @@ class _PairBias(torch.autograd.Function):
         a0b0, wcomp = ctx.saved_tensors
         H, lay = ctx.H, ctx.lay
         nblk, NO, _ = wcomp.shape
+        dev = a0b0.device
         da0b0 = torch.zeros_like(a0b0)
         dwcomp = torch.zeros_like(wcomp)
-        dbconst = torch.zeros((nblk, NO), dtype=torch.float32, device=a0b0.device)
+        dbconst = torch.zeros((nblk, NO), dtype=torch.float32, device=dev)
+        bf16 = _cfg.get_precision() == "bf16" and NO == 8 and H % 8 == 0
+        if bf16:
+            tn_g, nn_g = _pair_bias_groups(lay, H, a0b0.stride(0))
+            a16 = a0b0.to(torch.bfloat16)
+            T = torch.empty((lay.sumC * NO, H), dtype=torch.float32, device=dev)
         for k, dout in enumerate(douts):
             if dout is None:
                 continue
             dout = dout.contiguous()
-            dwk = torch.zeros((lay.B, NO * H), dtype=torch.float32, device=a0b0.device)
-            check(load().fabind_pair_bias_bwd(ptr(dout), NO, ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.desc_p),
-                                              lay.B, lay.max_P, lay.max_C, ptr(lay.p_index), ptr(lay.c_index), ptr(da0b0),
-                                              ptr(dwk), stream()), "fabind_pair_bias_bwd")
-            dwcomp[k] = K.colsum(dwk).reshape(NO, H)
             dbconst[k] = K.colsum(dout)
+            if bf16:
+                # da0[i,:] += D[i,(j,o)] Bmat[(j,o),:]  and  T = D^T a0  as ragged-batched MFMA contractions
+                D16 = dout.to(torch.bfloat16)
+                bmat = K.pair_bmat(a0b0[:, H:], wcomp[k], lay.c_index, torch.bfloat16)          # [(sumC*8), H]
+                bmT = _transposed(bmat, Rp=(bmat.shape[0] + 63) // 64 * 64)                      # [H, sumC*8 (padded)]
+                K.gemm(D16, bmT, out=da0b0, accumulate=True, groups=nn_g, groups_ext=True, n_groups=lay.B,
+                       max_m=lay.max_P, max_n=H, M=lay.max_P, N=H, ldc=a0b0.stride(0))
+                K.gemm_tn_grouped(D16, a16[:, :H], tn_g, lay.B, lay.max_C * NO, H, T, lay.max_P)
+                check(load().fabind_pair_bias_finish(ptr(T), ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.c_index),
+                                                     lay.sumC, ptr(da0b0), ptr(dwcomp[k]), stream()), "fabind_pair_bias_finish")
+            else:
+                dwk = torch.zeros((lay.B, NO * H), dtype=torch.float32, device=dev)
+                check(load().fabind_pair_bias_bwd(ptr(dout), NO, ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.desc_p),
+                                                  lay.B, lay.max_P, lay.max_C, ptr(lay.p_index), ptr(lay.c_index), ptr(da0b0),
+                                                  ptr(dwk), stream()), "fabind_pair_bias_bwd")
+                dwcomp[k] = K.colsum(dwk).reshape(NO, H)
         return da0b0, dwcomp, dbconst, None, None
 
 

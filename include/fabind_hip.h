@@ -60,6 +60,7 @@ typedef struct FabindGemmArgs {
     int accumulate;
     int store_preact; /* C receives the value BEFORE act_epi (row-dot still sees act_epi(v)) */
     int n_groups, max_m, max_n;
+    int groups_ext; /* groups are int32[16] {M, N, K, lda, a_off lo/hi, w_off lo/hi, c_off lo/hi, ldc}: ragged A/W/C */
     int epi_fast; /* set by fabind_gemm itself: index of a specialised epilogue (0 = generic) */
     int k_splits; /* >1: split the K loop over k_splits work-groups; C must be fp32 [k_splits, M, N] partials */
     float alpha;
@@ -70,7 +71,8 @@ int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream);
 /* Weight-gradient contraction without transposes: C_part[s][m][n] = sum_{e in split s} Y[e,m] * X[e,n]
  * (bf16 row-major operands, fp32 partials [splits, M, N]; zero_page = >= 16 zero bytes in device memory). */
 int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_part, int M, int N, int E, int splits,
-                   const void* zero_page, hipStream_t stream);
+                   const void* zero_page, const int* groups, int n_groups, hipStream_t stream);
+/* groups (optional, splits == 1): int32[8] per group {y_off lo/hi (elements), ldy, M, x_row0, E, c_off lo/hi}. */
 
 /* out[C,R] = act(in[R,C])^T -- feeds weight-gradient contractions (autograd of the ops above). */
 int fabind_transpose_act(const void* in, int in_dt, int ldi, void* out, int out_dt, int ldo, int R, int C, int act,
@@ -238,6 +240,8 @@ int fabind_las_step_bwd(const float* x, const float* x0, const float* xo, const 
 int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, int ld, int H, const float* w, const int* desc_p,
                          int B, int max_P, int max_C, const int* p_index, const int* c_index, float* dab, float* dwk,
                          hipStream_t stream);
+int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, const float* w, const int* c_index, int n_c,
+                            float* dab, float* dw, hipStream_t stream);
 void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of the bf16 LDS-DMA GEMM */
 void fabind_gemm_set_persistent(int on); /* development knob: persistent tile walk for long-M/short-K GEMMs */
 

@@ -151,3 +151,42 @@ def test_gemm_tn_transpose_reads(shape):
     out2 = K.gemm_tn(Yw[:, 64:], X.to(dev), splits=3)
     ref2 = Yw[:, 64:].cpu().double().T @ X.double()
     assert (out2.cpu().double() - ref2).abs().max() <= 2e-3 * float(ref2.abs().max()) + 1e-3 * E ** 0.5
+
+
+def test_pair_bias_adjoint_gemm_path_matches_valu_path():
+    """ops.pair_bias backward: ragged-batched MFMA formulation (bf16 mode) vs the fp32 VALU kernels vs torch autograd."""
+    from fabind_amd import engine, ops, synthetic
+    dev = _dev()
+    H = 64
+    inp = synthetic.make_stack_batch([(70, 9), (33, 17), (120, 5)], H, seed=3)
+    lay = engine.Layout(inp["batch_id"].to(dev), inp["segment_id"].to(dev))
+    g = torch.Generator().manual_seed(1)
+    a0b0 = torch.randn(lay.N, 2 * H, generator=g)
+    wcomp = torch.randn(4, 8, H, generator=g) / H ** 0.5
+    bconst = torch.randn(4, 8, generator=g)
+    cots = [torch.randn(lay.n_pairs, 8, generator=g) for _ in range(4)]
+    # torch reference on the CPU
+    a_ref = a0b0.clone().requires_grad_(True); w_ref = wcomp.clone().requires_grad_(True); b_ref = bconst.clone().requires_grad_(True)
+    loss = 0
+    pi = lay.p_index64.cpu(); ci = lay.c_index64.cpu()
+    po, co = 0, 0
+    for b in range(lay.B):
+        P_, C_ = int(lay.P[b]), int(lay.C[b])
+        a = a_ref[pi[po:po + P_], :H]; bb = a_ref[ci[co:co + C_], H:]
+        for k in range(4):
+            out = torch.einsum("ih,jh,oh->ijo", a, bb, w_ref[k]) + b_ref[k]
+            off = int(lay.pair_off_np[b])
+            loss = loss + (out.reshape(-1, 8) * cots[k][off:off + P_ * C_]).sum()
+        po += P_; co += C_
+    loss.backward()
+    res = {}
+    for mode in ("fp32", "bf16"):
+        engine.set_precision(mode)
+        a = a0b0.to(dev).requires_grad_(True); w = wcomp.to(dev).requires_grad_(True); bc_ = bconst.to(dev).requires_grad_(True)
+        outs = ops.pair_bias(a, H, w, bc_, lay)
+        sum((o * c.to(dev)).sum() for o, c in zip(outs, cots)).backward()
+        res[mode] = (a.grad.cpu(), w.grad.cpu(), bc_.grad.cpu())
+    engine.set_precision("fp32")
+    for mode, tol in (("fp32", 2e-4), ("bf16", 3e-2)):
+        for got, ref in zip(res[mode], (a_ref.grad, w_ref.grad, b_ref.grad)):
+            assert (got - ref).abs().max() <= tol * float(ref.abs().max()), mode

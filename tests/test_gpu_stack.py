@@ -220,3 +220,37 @@ def test_construct_edges_api_matches_reference_sets():
     assert key(ctx.cpu().numpy()) == key(g["cap_ctx_edges_noBond"])
     assert np.array_equal(inter.cpu().numpy(), g["cap_inter_edges"])
     assert rb.shape[0] == inter.shape[1] // 2
+
+
+def test_stack_gradients_bf16_close():
+    """bf16 training path (stored activation derivatives, TN weight-gradient GEMM, ragged pair-bias adjoint):
+    gradients stay close to the reference's fp32 autograd (loose bound; bf16 operands)."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision("bf16")
+    try:
+        g = load_npz("stack_tiny_grad")
+        m = _build_stack(g, dev)
+        inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in stack_inputs(g).items()}
+        Hin = inp["H"].clone().requires_grad_(True)
+        X, H = m(inp["X"].clone(), Hin, inp["batch_id"], inp["segment_id"], inp["mask"], inp["is_global"],
+                 inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"])
+        loss = (X * torch.from_numpy(g["cot_X"]).to(dev)).sum() + (H * torch.from_numpy(g["cot_H"]).to(dev)).sum()
+        loss.backward()
+    finally:
+        engine.set_precision("fp32")
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 2e-2 * abs(float(g["loss"]))
+    ref = g["grad_in_H"]
+    assert np.abs(Hin.grad.cpu().numpy() - ref).max() <= 6e-2 * np.abs(ref).max()
+    nograd = set(str(s) for s in g["nograd"])
+    gmax = max(float(np.abs(g["grad_" + n]).max()) for n, _ in m.named_parameters() if n not in nograd)
+    bad = []
+    for n, p in m.named_parameters():
+        if n in nograd or p.grad is None:
+            continue
+        ref = g["grad_" + n]
+        err = np.abs(p.grad.float().cpu().numpy() - ref).max()
+        # tensors whose whole gradient is tiny (second-order paths through the attention bias) sit at bf16 noise level
+        if not err <= 8e-2 * np.abs(ref).max() + 1e-4 * gmax:
+            bad.append((n, float(err), float(np.abs(ref).max())))
+    assert not bad, (gmax, bad[:10])
