@@ -131,30 +131,59 @@ extern "C" int fabind_edge_geom_bwd(const float* d, const float* rho, const floa
 __global__ __launch_bounds__(256) void gcl_pre_bwd_kernel(const void* dpre, int dt, int H, const float* rhohat,
                                                           const float* w_r, int E, float* drh, float* scratch,
                                                           int edges_per) {
-    extern __shared__ float sh[];  // [4][H]
+    // register accumulators: lane owns 4 consecutive columns per 256-column slab (H <= 1024)
+    __shared__ float4 sh[3][256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int e0 = blockIdx.x * edges_per, e1 = min(E, e0 + edges_per);
-    for (int c = lane; c < H; c += 64) sh[w * H + c] = 0.f;
+    float4 acc[4], wr[4];
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        acc[sidx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c = sidx * 256 + lane * 4;
+        wr[sidx] = (c < H) ? *(const float4*)(w_r + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     for (int e = e0 + w; e < e1; e += 4) {
         const float rh = rhohat[e];
         float dot = 0.f;
-        for (int c = lane; c < H; c += 64) {
-            const float g = ld_any(dpre, dt, (size_t)e * H + c);
-            dot += g * w_r[c];
-            sh[w * H + c] += rh * g;
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int c = sidx * 256 + lane * 4;
+            if (c < H) {
+                const float4 g = ld4_any(dpre, dt, (size_t)e * H + c);
+                dot += g.x * wr[sidx].x + g.y * wr[sidx].y + g.z * wr[sidx].z + g.w * wr[sidx].w;
+                acc[sidx].x += rh * g.x; acc[sidx].y += rh * g.y; acc[sidx].z += rh * g.z; acc[sidx].w += rh * g.w;
+            }
         }
         dot = wave_sum(dot);
         if (lane == 0) drh[e] = dot;
     }
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        if (w > 0) sh[w - 1][sidx * 64 + lane] = acc[sidx];
+    }
     __syncthreads();
-    for (int c = threadIdx.x; c < H; c += 256)
-        scratch[(size_t)blockIdx.x * H + c] = (sh[c] + sh[H + c]) + (sh[2 * H + c] + sh[3 * H + c]);
+    if (w == 0) {
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int c = sidx * 256 + lane * 4;
+            if (c < H) {
+                float4 a = acc[sidx];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float4 o = sh[k][sidx * 64 + lane];
+                    a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+                }
+                *(float4*)(scratch + (size_t)blockIdx.x * H + c) = a;
+            }
+        }
+    }
 }
 extern "C" int fabind_gcl_pre_bwd(const void* dpre, int dt, int H, const float* rhohat, const float* w_r, int E,
                                   float* drh, float* dw, float* scratch, int nchunk, hipStream_t stream) {
     if (E <= 0) return 0;
     int edges_per = (E + nchunk - 1) / nchunk;
-    hipLaunchKernelGGL(gcl_pre_bwd_kernel, dim3(nchunk), dim3(256), 4 * H * sizeof(float), stream, dpre, dt, H, rhohat,
+    FB_REQUIRE(H % 4 == 0 && H <= 1024, "fabind_gcl_pre_bwd: H % 4, H <= 1024");
+    hipLaunchKernelGGL(gcl_pre_bwd_kernel, dim3(nchunk), dim3(256), 0, stream, dpre, dt, H, rhohat,
                        w_r, E, drh, scratch, edges_per);
     hipLaunchKernelGGL(sum_chunks_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, scratch, dw, H, nchunk);
     FB_CHECK_LAUNCH();

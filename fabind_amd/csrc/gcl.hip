@@ -36,28 +36,46 @@ extern "C" int fabind_gcl_pre(const float* AB, int ldab, int H, const int* row, 
     return 0;
 }
 
-// out[r,:] = sum_{e in [rowptr[r], rowptr[r+1])} act(Z[e,:])
-// One 256-thread work-group per row: its 4 waves take edges round-robin, each lane owns 4 columns
-// per 256-column slab; partials are combined through LDS in fixed wave order (bit-reproducible).
+// out[r,:] = sum_{e in [rowptr[r], rowptr[r+1])} act(Z[eidx ? eidx[e] : e,:])
+// One 256-thread work-group per row: its 4 waves take edges round-robin, each lane owns 8 consecutive columns
+// per 512-column slab (16-byte loads for bf16); partials are combined through LDS in fixed wave order.
+struct F8 { float v[8]; };
+__device__ __forceinline__ F8 ld8_any(const void* p, int dt, size_t i) {
+    F8 r;
+    if (dt == FB_DT_F32) {
+        const float4 a = *(const float4*)((const float*)p + i), b = *(const float4*)((const float*)p + i + 4);
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    } else {
+        const uint4 u = *(const uint4*)((const bf16_t*)p + i);
+        r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+        r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+        r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+        r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+    return r;
+}
+
 template <int NSLAB>
 __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict__ Z, int z_dt, int ldz, int H,
                                                           const int* rowptr, const int* eidx, int act, float* out,
                                                           int ldo) {
-    __shared__ float4 part[3][NSLAB * 64];
+    __shared__ F8 part[3][NSLAB * 64];
     const int r = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
-    float4 acc[NSLAB];
+    F8 acc[NSLAB];
 #pragma unroll
-    for (int s = 0; s < NSLAB; ++s) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < NSLAB; ++s)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[s].v[k] = 0.f;
     for (int ee = e0 + w; ee < e1; ee += 4) {
         const int e = eidx ? eidx[ee] : ee;
 #pragma unroll
         for (int s = 0; s < NSLAB; ++s) {
-            int c = s * 256 + lane * 4;
+            const int c = s * 512 + lane * 8;
             if (c < H) {
-                float4 v = ld4_any(Z, z_dt, (size_t)e * ldz + c);
-                acc[s].x += apply_act(v.x, act); acc[s].y += apply_act(v.y, act);
-                acc[s].z += apply_act(v.z, act); acc[s].w += apply_act(v.w, act);
+                const F8 v = ld8_any(Z, z_dt, (size_t)e * ldz + c);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[s].v[k] += apply_act(v.v[k], act);
             }
         }
     }
@@ -69,15 +87,17 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict
     if (w == 0) {
 #pragma unroll
         for (int s = 0; s < NSLAB; ++s) {
-            int c = s * 256 + lane * 4;
+            const int c = s * 512 + lane * 8;
             if (c < H) {
-                float4 a = acc[s];
+                F8 a = acc[s];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    float4 p = part[k][s * 64 + lane];
-                    a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+                    const F8 p = part[k][s * 64 + lane];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a.v[q] += p.v[q];
                 }
-                *(float4*)(out + (size_t)r * ldo + c) = a;
+                *(float4*)(out + (size_t)r * ldo + c) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+                *(float4*)(out + (size_t)r * ldo + c + 4) = make_float4(a.v[4], a.v[5], a.v[6], a.v[7]);
             }
         }
     }
@@ -85,15 +105,14 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict
 
 extern "C" int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, const int* eidx,
                                   int n_rows, int act, float* out, int ldo, hipStream_t stream) {
-    FB_REQUIRE(H % 4 == 0 && ldz % 4 == 0 && ldo % 4 == 0, "fabind_segment_sum: H/ldz/ldo must be multiples of 4");
+    FB_REQUIRE(H % 8 == 0 && ldz % 8 == 0 && ldo % 4 == 0, "fabind_segment_sum: H/ldz must be multiples of 8, ldo of 4");
     FB_REQUIRE(H <= 1024, "fabind_segment_sum: H <= 1024");
+    FB_REQUIRE(((uintptr_t)Z % 16 == 0) && ((uintptr_t)out % 16 == 0), "fabind_segment_sum: 16-byte alignment");
     if (n_rows <= 0) return 0;
-    if (H <= 256)
+    if (H <= 512)
         hipLaunchKernelGGL((segment_sum_kernel<1>), dim3(n_rows), dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo);
-    else if (H <= 512)
-        hipLaunchKernelGGL((segment_sum_kernel<2>), dim3(n_rows), dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo);
     else
-        hipLaunchKernelGGL((segment_sum_kernel<4>), dim3(n_rows), dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo);
+        hipLaunchKernelGGL((segment_sum_kernel<2>), dim3(n_rows), dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo);
     FB_CHECK_LAUNCH();
     return 0;
 }

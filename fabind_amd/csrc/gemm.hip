@@ -187,7 +187,7 @@ template <int ACT> __device__ __forceinline__ float fast_dact(float x) {
     return 1.f;
 }
 
-template <int BM_, int ACT, bool HAS_C, bool HAS_C2, bool HAS_DOT, bool RAW_BARRIER, bool STORE_PRE = false>
+template <int BM_, int ACT, bool HAS_C, bool HAS_C2, bool HAS_DOT, bool RAW_BARRIER, bool STORE_PRE = false, bool HAS_RG = false>
 __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sDot, bf16_t* sOut,
                                                    int M, int N, int ldc, int m0, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -235,7 +235,11 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float vp = acc[i][j][r] + bv[j];
+                float vp = acc[i][j][r] + bv[j];
+                if (HAS_RG) {          // + residual row gathered through r_index (adjoint of a segment-sum consumer)
+                    const int rowg = m0 + wm * 64 + i * 16 + cq * 4 + r, colg = n0 + wn * 64 + j * 16 + fr;
+                    if (rowg < M && colg < N) vp += ((const float*)p.R)[(size_t)p.r_index[rowg] * p.ldr + colg];
+                }
                 const float v = fast_act<ACT>(vp);
                 if (HAS_C) sOut[(wm * 64 + i * 16 + cq * 4 + r) * OUT_LD + wn * 64 + j * 16 + fr] = f32_to_bf16(STORE_PRE ? vp : v);
                 if (HAS_DOT) ds[r] += v * dv[j];
@@ -298,6 +302,7 @@ __device__ __forceinline__ bool gemm_epilogue_dispatch(const FabindGemmArgs& p, 
         case 6: EPI(FB_ACT_RELU, false, false, true);
         case 7: gemm_epilogue_fast<BM_, FB_ACT_SILU, true, false, true, RAW_BARRIER, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 8: gemm_epilogue_fast<BM_, FB_ACT_RELU, true, false, true, RAW_BARRIER, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
+        case 11: gemm_epilogue_fast<BM_, FB_ACT_NONE, true, false, false, RAW_BARRIER, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 9: gemm_epilogue_f32<BM_, false>(p, acc, M, N, ldc, m0, n0); return true;
         case 10: gemm_epilogue_f32<BM_, true>(p, acc, M, N, ldc, m0, n0); return true;
         default: return false;
@@ -912,6 +917,9 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     if (!p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && !p.r_index && p.C != nullptr &&
         p.c_dtype == FB_DT_F32 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
         p.epi_fast = p.R ? 10 : 9;
+    } else if (!p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && p.R && p.r_index && p.C &&
+               p.c_dtype == FB_DT_BF16 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
+        p.epi_fast = 11;
     } else
     if (!p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.R && !p.accumulate && !p.r_index &&
         (p.C == nullptr || p.c_dtype == FB_DT_BF16) && (p.C2 == nullptr || p.C != nullptr)) {

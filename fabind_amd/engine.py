@@ -257,9 +257,8 @@ def gcl_layer(p, h, x, lay, g, clampv):
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
     S1 = ops.gcl_pre(AB, H, g, rhohat, p["w_r"], act=K.ACT_SILU)                        # [E,H] silu(first edge Linear)
     Mm = ops.linear(S1, p["W2"], p["b2"], act_epi=K.ACT_SILU, out_dtype=ad)             # [E,H] messages m_e
-    s = ops.linear_rowdot(Mm, p["Wc"], p["bc"], p["w3"], act_epi=K.ACT_SILU)            # [E,nt] coord_mlp
+    s, agg = ops.edge_tail(Mm, p["Wc"], p["bc"], p["w3"], g.rp_ctx, g.row_ctx, h.shape[0])   # coord_mlp row-dot, sum_e m_e
     x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
-    agg = ops.segment_sum(Mm, g.rp_ctx, g.row_ctx, h.shape[0], act=K.ACT_NONE)
     t = ops.linear(hin, p["Wn1"], p["bn1"], x2=agg, act_epi=K.ACT_SILU, out_dtype=ad)
     h_new = ops.linear(t, p["Wn2"], p["bn2"], residual=h)
     return h_new, x_new

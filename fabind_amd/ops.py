@@ -216,6 +216,50 @@ def linear_rowdot(x, W, b, u, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE):
 
 
 # ------------------------------------------------------------------------------------------------
+# edge tail of MC_E_GCL under autograd: (row-dot of coord_mlp, segment-sum of the messages) as ONE node, so
+# that the two gradient contributions to the messages meet inside one GEMM epilogue
+#   dM = dz Wc + dagg[row]      (residual gathered through `row`) instead of a gather kernel + an add pass
+# ------------------------------------------------------------------------------------------------
+class _EdgeTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, Mm, Wc, bc, w3, rowptr, row, n_rows, act_epi):
+        z, part = _gemm_rowdot(Mm, Wc, bc, w3, K.ACT_NONE, act_epi, store=True)
+        agg = K.segment_sum(Mm, rowptr, n_rows)
+        ctx.act_epi = act_epi
+        ctx.save_for_backward(Mm, Wc, w3, z, row)
+        return part, agg
+
+    @staticmethod
+    def backward(ctx, dpart, dagg):
+        Mm, Wc, w3, z, row = ctx.saved_tensors
+        M, N = z.shape
+        dz = torch.empty_like(z)
+        nchunk = _nchunk(M)
+        scratch = torch.empty((nchunk, N), dtype=torch.float32, device=z.device)
+        du = torch.empty(N, dtype=torch.float32, device=z.device)
+        if dpart is None:
+            dpart = torch.zeros((M, (N + K.GEMM_BN - 1) // K.GEMM_BN), dtype=torch.float32, device=z.device)
+        dpart = dpart.contiguous()
+        check(load().fabind_rowdot_bwd(ptr(z), dt_code(z.dtype), ptr(dpart), dpart.shape[1], ptr(w3), ctx.act_epi, M, N,
+                                       ptr(dz), ptr(du), ptr(scratch), nchunk, stream()), "fabind_rowdot_bwd")
+        Wt = Wc.t().contiguous()
+        if dagg is not None:
+            dM, _ = K.gemm(dz, Wt, residual=dagg.contiguous(), r_index=row, out_dtype=Mm.dtype)
+        else:
+            dM, _ = K.gemm(dz, Wt, out_dtype=Mm.dtype)
+        dW = _weight_grad(dz, Mm, K.ACT_NONE).to(Wc.dtype)
+        return dM, dW, K.colsum(dz), du, None, None, None, None
+
+
+def edge_tail(Mm, Wc, bc, w3, rowptr, row, n_rows, act_epi=K.ACT_SILU):
+    """(s_part [E, nt], agg [n_rows, H]) = (row-dot(act(Mm Wc^T + bc), w3), segment_sum(Mm))"""
+    if _needs_grad(Mm, Wc, bc, w3):
+        return _EdgeTail.apply(Mm, Wc, bc, w3, rowptr, row, n_rows, act_epi)
+    part = _gemm_rowdot(Mm, Wc, bc, w3, K.ACT_NONE, act_epi, store=False)[1]
+    return part, K.segment_sum(Mm, rowptr, n_rows)
+
+
+# ------------------------------------------------------------------------------------------------
 # geometry / gathers / segmented reductions
 # ------------------------------------------------------------------------------------------------
 class _EdgeGeom(torch.autograd.Function):
