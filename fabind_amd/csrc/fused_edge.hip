@@ -141,12 +141,17 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
         const int c = tid;                          // H threads <-> H columns
         float run = 0.f;
         int cur = sRow[0];
+        bool first = true;                          // a run that starts at the tile's first row may continue a neighbour tile's
         for (int rw = 0; rw < ne; ++rw) {
             const int rr = sRow[rw];
-            if (rr != cur) { atomicAdd(&agg[(size_t)cur * H + c], run); run = 0.f; cur = rr; }
+            if (rr != cur) {
+                // interior runs cover ALL edges of their node (rows are node-contiguous): plain store, no read-modify-write
+                if (first) atomicAdd(&agg[(size_t)cur * H + c], run); else agg[(size_t)cur * H + c] = run;
+                run = 0.f; cur = rr; first = false;
+            }
             run += bf16_to_f32(sX[rw * H + (((c >> 3) ^ (rw & 7)) * 8) + (c & 7)]);
         }
-        if (ne > 0) atomicAdd(&agg[(size_t)cur * H + c], run);
+        if (ne > 0) atomicAdd(&agg[(size_t)cur * H + c], run);   // last run may continue in the next tile
     }
 
     // ---- phase 3: s = w3 . silu(M Wc^T + bc)
