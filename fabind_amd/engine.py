@@ -234,17 +234,24 @@ def _b16(t):
     return t.to(torch.bfloat16)
 
 
-def gcl_layer(p, h, x, lay, g, clampv):
+def _drop(t, pr):
+    """nn.Dropout of the reference modules (train mode only).  Bernoulli mask + scale: element-wise RNG plumbing
+    (torch's generator, so seeds behave as in the reference); identity in eval mode and for p = 0."""
+    return torch.nn.functional.dropout(t, pr, True) if pr > 0.0 else t
+
+
+def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
     """MC_E_GCL.forward (egnn.py:130-144): edge -> coord -> node, all from the layer's input h, x.
 
     Producers apply the activations once (gcl_pre -> SiLU, GEMM epilogue -> SiLU); under autograd the same
     kernels additionally emit the activation derivative, so every edge-level GEMM (forward and backward)
-    streams plain bf16 operands HBM -> LDS."""
+    streams plain bf16 operands HBM -> LDS.  pdrop > 0 (train mode): dropout on the messages before both
+    consumers and on the node-MLP output before the residual (egnn.py:82,106)."""
     H = h.shape[1]
     ad = ops.act_dtype()
     fast = _fast(h, x, p["W2"])
     hin = _b16(h) if fast else h
-    if fast and FUSED_EDGE and H in (64, 128, 256, 512):
+    if fast and FUSED_EDGE and pdrop == 0.0 and H in (64, 128, 256, 512):
         # forward-only: the whole edge pipeline in one kernel, edge tensors stay in LDS (csrc/fused_edge.hip)
         AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=torch.bfloat16)
         d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
@@ -257,15 +264,20 @@ def gcl_layer(p, h, x, lay, g, clampv):
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
     S1 = ops.gcl_pre(AB, H, g, rhohat, p["w_r"], act=K.ACT_SILU)                        # [E,H] silu(first edge Linear)
     Mm = ops.linear(S1, p["W2"], p["b2"], act_epi=K.ACT_SILU, out_dtype=ad)             # [E,H] messages m_e
+    Mm = _drop(Mm, pdrop)
     s, agg = ops.edge_tail(Mm, p["Wc"], p["bc"], p["w3"], g.rp_ctx, g.row_ctx, h.shape[0])   # coord_mlp row-dot, sum_e m_e
     x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
     t = ops.linear(hin, p["Wn1"], p["bn1"], x2=agg, act_epi=K.ACT_SILU, out_dtype=ad)
-    h_new = ops.linear(t, p["Wn2"], p["bn2"], residual=h)
+    if pdrop > 0.0:
+        h_new = h + _drop(ops.linear(t, p["Wn2"], p["bn2"]), pdrop)
+    else:
+        h_new = ops.linear(t, p["Wn2"], p["bn2"], residual=h)
     return h_new, x_new
 
 
-def cross_attention(p, h, lay, pairbias, layer):
-    """CrossAttentionModule node path (cross_att.py:38-49) on compact protein / ligand arrays."""
+def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
+    """CrossAttentionModule node path (cross_att.py:38-49) on compact protein / ligand arrays.
+    pdrop: RowAttentionBlock.dropout on the attention update before the residual (cross_att.py:128)."""
     fast = _fast(h, p["Wo_p"])
     od = ops.act_dtype()
     c16 = (lambda t: _b16(t)) if fast else (lambda t: t)
@@ -275,12 +287,14 @@ def cross_attention(p, h, lay, pairbias, layer):
     qg = ops.linear(c16(hp), p["Wqg_p"], p["bqg_p"])
     kv = ops.linear(c16(hc), p["Wkv_p"])
     og = ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_p, lay.B, lay.max_P, lay.max_C, scale)
-    hp = ops.linear(c16(og), p["Wo_p"], p["bo_p"], residual=hp)
+    hp = (hp + _drop(ops.linear(c16(og), p["Wo_p"], p["bo_p"]), pdrop)) if pdrop > 0.0 else \
+        ops.linear(c16(og), p["Wo_p"], p["bo_p"], residual=hp)
     hp16 = c16(hp)
     qg = ops.linear(c16(hc), p["Wqg_c"], p["bqg_c"])
     kv = ops.linear(hp16, p["Wkv_c"])
     og = ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_c, lay.B, lay.max_C, lay.max_P, scale)
-    hc = ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc)
+    hc = (hc + _drop(ops.linear(c16(og), p["Wo_c"], p["bo_c"]), pdrop)) if pdrop > 0.0 else \
+        ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc)
     t = ops.linear(hp16, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU, out_dtype=od)
     hp = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp)
     t = ops.linear(c16(hc), p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU, out_dtype=od)
@@ -288,10 +302,10 @@ def cross_attention(p, h, lay, pairbias, layer):
     return ops.take_rows(torch.cat([hc, hp], 0), lay.inv_perm)
 
 
-def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv):
-    """MC_Att_L.forward (egnn.py:308-333)."""
+def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv, pdrop=0.0, pdrop_row=0.0):
+    """MC_Att_L.forward (egnn.py:308-333).  pdrop: dropout on the aggregated attention message (egnn.py:236)."""
     H = h.shape[1]
-    h = cross_attention(p, h, lay, pairbias, layer)
+    h = cross_attention(p, h, lay, pairbias, layer, pdrop_row)
     # pair embedding at the inter-edge pairs only -> scalar attention bias (egnn.py:208, 286-304)
     h16 = _b16(h) if _fast(h, x, p["Wqkv"]) else h
     ab32 = ops.linear(h16, p["W_ab32"], p["b_ab32"])                                   # [N,128] (a32|0|b32|0)
@@ -302,24 +316,27 @@ def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv):
     d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay)
     h_new, x_new, alpha = ops.inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["wcr"],
                                          p["w3"], clampv)
+    if pdrop > 0.0:
+        h_new = h + _drop(h_new - h, pdrop)
     return h_new, x_new, alpha
 
 
-def egnn_forward(P, h, x, lay, g, las, x_las, a0b0, pairbias, scale, step):
-    """MCAttEGNN.forward (egnn.py:392-466), eval-mode dropout."""
+def egnn_forward(P, h, x, lay, g, las, x_las, a0b0, pairbias, scale, step, drop=None):
+    """MCAttEGNN.forward (egnn.py:392-466).  drop = dict of dropout probabilities (train mode) or None (eval)."""
     clampv = 10.0 / scale
-    h = ops.linear(h, P["W_in"], P["b_in"])
+    dp = drop or {}
+    h = _drop(ops.linear(h, P["W_in"], P["b_in"]), dp.get("gnn", 0.0))
     cap = DEBUG_CAPTURE
     for i in range(P["L"]):
-        h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv)
+        h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv, dp.get("gcl", 0.0))
         if cap is not None:
             cap["gcl_%d.h" % i], cap["gcl_%d.x" % i] = h.detach().clone(), x.detach().clone()
-        h, x, alpha = att_layer(P["att"][i], h, x, lay, g, a0b0, pairbias, i, clampv)
+        h, x, alpha = att_layer(P["att"][i], h, x, lay, g, a0b0, pairbias, i, clampv, dp.get("att", 0.0), dp.get("row", 0.0))
         if cap is not None:
             cap["att_%d.h" % i], cap["att_%d.x" % i], cap["att_%d.alpha" % i] = h.detach().clone(), x.detach().clone(), alpha.detach().clone()
         x = ops.las_step(x, x_las, las, lay, step, 15.0 / scale)
-    h, x = gcl_layer(P["out_layer"], h, x, lay, g, clampv)
-    return ops.linear(h, P["W_out"], P["b_out"]), x
+    h, x = gcl_layer(P["out_layer"], h, x, lay, g, clampv, dp.get("out", 0.0))
+    return ops.linear(_drop(h, dp.get("gnn", 0.0)), P["W_out"], P["b_out"]), x
 
 
 def pair_bias_all(P, a0b0, lay):
@@ -351,13 +368,20 @@ def stack_forward(model, X, Hin, batch_id, segment_id, mask, is_global, compound
     a0b0 = ops.linear(Hin, P["W_ab0"], P["b_ab0"])
     pairbias = pair_bias_all(P, a0b0, lay)
     cut_intra, cut_inter = float(model.extract_edges.intra_cutoff), float(model.extract_edges.inter_cutoff)
+    drop = None
+    if model.training:   # the reference's nn.Dropout modules are active in every refinement iteration (also under no_grad)
+        gnn = model.gnn
+        drop = dict(gnn=gnn.dropout.p, gcl=gnn.gcl_0.dropout.p, att=gnn.att_0.dropout.p, out=gnn.out_layer.dropout.p,
+                    row=gnn.att_0.cross_attn_module.p_attention_block.dropout.p)
+        if not any(v > 0 for v in drop.values()):
+            drop = None
     Hout = None
     for r in range(n_iter):
         last = r == n_iter - 1
         g = Graph(lay, x.detach(), bond_row, bond_col, bond_off, cut_intra, cut_inter)
         with torch.set_grad_enabled(last and torch.is_grad_enabled()):
             Hout, z = egnn_forward(P, Hin, x, lay, g, las, x_las, a0b0, pairbias, scale,
-                                   float(args.geometry_reg_step_size))
+                                   float(args.geometry_reg_step_size), drop)
             x = ops.select_rows(x, z, mask_u8)
     model.last_graph = g
     with torch.no_grad():

@@ -61,10 +61,6 @@ class EfficientMCAttModel(nn.Module):
                 batched_complex_coord_LAS, LAS_mask=None):
         """Same contract as the reference (att_model.py:170): X [N,1,3] is updated in place for the
         `mask`ed nodes and returned together with the last iteration's H."""
-        if self.training and self.dropout_p > 0:
-            raise NotImplementedError(
-                "train-mode dropout inside the fused kernels is not built yet: call .eval() (parity/benchmarks) or "
-                "construct with dropout=0")
         if self.training and self.random_n_iter:
             iter_i = random.randint(1, self.n_iter)
         else:

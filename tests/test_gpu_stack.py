@@ -254,3 +254,41 @@ def test_stack_gradients_bf16_close():
         if not err <= 8e-2 * np.abs(ref).max() + 1e-4 * gmax:
             bad.append((n, float(err), float(np.abs(ref).max())))
     assert not bad, (gmax, bad[:10])
+
+
+def test_train_mode_dropout_statistics():
+    """Train mode: dropout (p = 0.1, reference module defaults) is active, seeded, and vanishes for p = 0."""
+    from fabind_amd import engine, synthetic
+    from fabind_amd.models.att_model import EfficientMCAttModel
+    dev = torch.device("cuda:0")
+    engine.set_precision("fp32")
+    H, L = 64, 2
+    inp = synthetic.make_stack_batch([(50, 9), (64, 12)], H, seed=4)
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    a = _args(H, L, 1)
+    a.random_n_iter = False
+
+    def run(m, seed):
+        torch.manual_seed(seed)
+        X, Hh = m(t["X"].clone(), t["H"], t["batch_id"], t["segment_id"], t["mask"], t["is_global"], t["compound_edge_index"],
+                  t["LAS_edge_index"], t["coord_LAS"])
+        return X.detach(), Hh
+    torch.manual_seed(0)
+    m = EfficientMCAttModel(a, H, H, 1, n_layers=L, n_iter=1, normalize_coord=lambda x: x / 5.0,
+                            unnormalize_coord=lambda x: x * 5.0).to(dev)
+    m.eval()
+    Xe, He = run(m, 1)
+    m.train()
+    X1, H1 = run(m, 1)
+    X1b, H1b = run(m, 1)
+    X2, H2 = run(m, 2)
+    assert torch.equal(H1, H1b)                                   # same seed -> same masks
+    assert (H1 - H2).abs().max() > 1e-4 and (H1 - He).abs().max() > 1e-4
+    H1.sum().backward()                                           # gradients flow through the dropout path
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    # dropout probability 0 in train mode == eval mode
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    X0, H0 = run(m, 3)
+    assert torch.allclose(H0, He, rtol=1e-5, atol=1e-5) and torch.allclose(X0, Xe, rtol=1e-5, atol=1e-6)
