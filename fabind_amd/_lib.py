@@ -34,9 +34,9 @@ SIGNATURES = {
     "fabind_exclusive_scan": [_vp, _vp, _i, _vp],
     "fabind_inter_meta": [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fabind_edge_geom": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
-    "fabind_gcl_pre": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "fabind_gcl_pre": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "fabind_gcl_edge_fused": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
-    "fabind_segment_sum": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp],
+    "fabind_segment_sum": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
     "fabind_coord_update": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
     "fabind_cross_attn_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i,
                               _vp],

@@ -38,12 +38,15 @@ extern "C" void fabind_set_error(const char* msg);
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN kept quiet
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even through gfx950's v_cvt_pk_bf16_f32 (two floats -> one packed dword)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ uint32_t pack2_bf16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return *(const uint32_t*)&b;
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(pack2_bf16(f, 0.f) & 0xffffu); }
 
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
@@ -53,8 +56,9 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return f32_to_bf16(v); }
 
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each); an IEEE division here made the gather / epilogue kernels VALU-bound
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 // d/dx silu(x) = s(x) * (1 + x * (1 - s(x)))
 __device__ __forceinline__ float dsilu_f(float x) {
     float s = sigmoid_f(x);
@@ -107,6 +111,34 @@ __device__ __forceinline__ float4 ld4_any(const void* p, int dt, size_t i) {
 }
 __device__ __forceinline__ void st4_any(void* p, int dt, size_t i, float4 v) {
     if (dt == FB_DT_F32) { *(float4*)((float*)p + i) = v; return; }
-    ushort4 u; u.x = f32_to_bf16(v.x); u.y = f32_to_bf16(v.y); u.z = f32_to_bf16(v.z); u.w = f32_to_bf16(v.w);
-    *(ushort4*)((bf16_t*)p + i) = u;
+    *(uint2*)((bf16_t*)p + i) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+}
+// 8 consecutive elements per lane (16-byte bf16 / 2 x 16-byte fp32 accesses)
+struct F8 { float v[8]; };
+__device__ __forceinline__ F8 ld8_any(const void* p, int dt, size_t i) {
+    F8 r;
+    if (dt == FB_DT_F32) {
+        const float4 a = *(const float4*)((const float*)p + i), b = *(const float4*)((const float*)p + i + 4);
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    } else {
+        const uint4 u = *(const uint4*)((const bf16_t*)p + i);
+        r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
+        r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
+        r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
+        r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+    return r;
+}
+__device__ __forceinline__ void st8_any(void* p, int dt, size_t i, const F8& v) {
+    if (dt == FB_DT_F32) {
+        *(float4*)((float*)p + i) = make_float4(v.v[0], v.v[1], v.v[2], v.v[3]);
+        *(float4*)((float*)p + i + 4) = make_float4(v.v[4], v.v[5], v.v[6], v.v[7]);
+        return;
+    }
+    uint4 u;
+    u.x = pack2_bf16(v.v[0], v.v[1]);
+    u.y = pack2_bf16(v.v[2], v.v[3]);
+    u.z = pack2_bf16(v.v[4], v.v[5]);
+    u.w = pack2_bf16(v.v[6], v.v[7]);
+    *(uint4*)((bf16_t*)p + i) = u;
 }

@@ -27,10 +27,10 @@ __device__ __forceinline__ void unpack8(const uint4 u, float* f) {
 }
 __device__ __forceinline__ uint4 pack8(const float* f) {
     uint4 u;
-    u.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
-    u.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
-    u.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
-    u.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+    u.x = pack2_bf16(f[0], f[1]);
+    u.y = pack2_bf16(f[2], f[3]);
+    u.z = pack2_bf16(f[4], f[5]);
+    u.w = pack2_bf16(f[6], f[7]);
     return u;
 }
 

@@ -4,18 +4,19 @@
 #include "common.h"
 #include "fabind_hip.h"
 
-// pre[e,:] = AB[row[e], 0:H] + AB[col[e], H:2H] + rhohat[e] * w_r[:]       (one wave per edge)
-__global__ __launch_bounds__(256) void gcl_pre_kernel(const float* __restrict__ AB, int ldab, int H, const int* row,
-                                                      const int* col, const float* rhohat, const float* __restrict__ w_r,
-                                                      void* pre, int pre_dt, int E, int act, void* dact_out) {
+// pre[e,:] = act(AB[row[e], 0:H] + AB[col[e], H:2H] + rhohat[e] * w_r[:]),  dact_out[e,:] = act'(...)  (optional)
+// Generic shape: one wave per edge, 4 columns per lane.
+__global__ __launch_bounds__(256) void gcl_pre_kernel(const void* __restrict__ AB, int ab_dt, int ldab, int H,
+                                                      const int* row, const int* col, const float* rhohat,
+                                                      const float* __restrict__ w_r, void* pre, int pre_dt, int E, int act,
+                                                      void* dact_out) {
     const int lane = threadIdx.x & 63;
     int e = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (e >= E) return;
-    const float* a = AB + (size_t)row[e] * ldab;
-    const float* b = AB + (size_t)col[e] * ldab + H;
+    const size_t a = (size_t)row[e] * ldab, b = (size_t)col[e] * ldab + H;
     const float rh = rhohat[e];
     for (int c = lane * 4; c < H; c += 256) {
-        float4 va = *(const float4*)(a + c), vb = *(const float4*)(b + c), w = *(const float4*)(w_r + c);
+        float4 va = ld4_any(AB, ab_dt, a + c), vb = ld4_any(AB, ab_dt, b + c), w = *(const float4*)(w_r + c);
         const float4 z = make_float4(va.x + vb.x + rh * w.x, va.y + vb.y + rh * w.y, va.z + vb.z + rh * w.z,
                                      va.w + vb.w + rh * w.w);
         st4_any(pre, pre_dt, (size_t)e * H + c,
@@ -26,12 +27,68 @@ __global__ __launch_bounds__(256) void gcl_pre_kernel(const float* __restrict__ 
     }
 }
 
-extern "C" int fabind_gcl_pre(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
-                              const float* w_r, void* pre, int pre_dt, int E, int act, void* dact_out, hipStream_t stream) {
+// H = 8 * LPE <= 512: LPE lanes cover one edge with 8 columns each (16-byte bf16 loads and stores), a wave covers
+// 64/LPE edges per pass and GP_PASSES passes with every gather of all passes issued before the first use.
+#define GP_PASSES 4
+template <int LPE>
+__global__ __launch_bounds__(256) void gcl_pre8_kernel(const void* __restrict__ AB, int ab_dt, int ldab,
+                                                       const int* __restrict__ row, const int* __restrict__ col,
+                                                       const float* __restrict__ rhohat, const float* __restrict__ w_r,
+                                                       void* pre, int pre_dt, int E, int act, void* dact_out) {
+    constexpr int H = LPE * 8, EPP = 64 / LPE;
+    const int lane = threadIdx.x & 63, sub = lane / LPE, c = (lane % LPE) * 8;
+    const int ebase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (EPP * GP_PASSES) + sub;
+    if (ebase - sub >= E) return;
+    F8 va[GP_PASSES], vb[GP_PASSES];
+    float rh[GP_PASSES];
+#pragma unroll
+    for (int i = 0; i < GP_PASSES; ++i) {
+        const int e = min(ebase + i * EPP, E - 1);
+        const int r = row[e], q = col[e];
+        rh[i] = rhohat[e];
+        va[i] = ld8_any(AB, ab_dt, (size_t)r * ldab + c);
+        vb[i] = ld8_any(AB, ab_dt, (size_t)q * ldab + H + c);
+    }
+    const float4 w0 = *(const float4*)(w_r + c), w1 = *(const float4*)(w_r + c + 4);
+    const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+    for (int i = 0; i < GP_PASSES; ++i) {
+        const int e = ebase + i * EPP;
+        if (e < E) {
+            F8 z, y;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                z.v[k] = va[i].v[k] + vb[i].v[k] + rh[i] * w[k];
+                y.v[k] = apply_act(z.v[k], act);
+            }
+            st8_any(pre, pre_dt, (size_t)e * H + c, y);
+            if (dact_out) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) y.v[k] = apply_dact(z.v[k], act);
+                st8_any(dact_out, pre_dt, (size_t)e * H + c, y);
+            }
+        }
+    }
+}
+
+extern "C" int fabind_gcl_pre(const void* AB, int ab_dt, int ldab, int H, const int* row, const int* col,
+                              const float* rhohat, const float* w_r, void* pre, int pre_dt, int E, int act,
+                              void* dact_out, hipStream_t stream) {
     FB_REQUIRE(H % 4 == 0 && ldab % 4 == 0, "fabind_gcl_pre: H and ldab must be multiples of 4");
     if (E <= 0) return 0;
-    hipLaunchKernelGGL(gcl_pre_kernel, dim3((E + 3) / 4), dim3(256), 0, stream, AB, ldab, H, row, col, rhohat, w_r, pre,
-                       pre_dt, E, act, dact_out);
+    const bool vec8 = ldab % 8 == 0 && ((uintptr_t)AB % 16 == 0) && ((uintptr_t)pre % 16 == 0) &&
+                      (!dact_out || (uintptr_t)dact_out % 16 == 0) && ((uintptr_t)w_r % 16 == 0);
+#define GP_LAUNCH(LPE_)                                                                                              \
+    hipLaunchKernelGGL((gcl_pre8_kernel<LPE_>), dim3((E + 4 * (64 / LPE_) * GP_PASSES - 1) / (4 * (64 / LPE_) * GP_PASSES)), \
+                       dim3(256), 0, stream, AB, ab_dt, ldab, row, col, rhohat, w_r, pre, pre_dt, E, act, dact_out)
+    if (vec8 && H == 512) GP_LAUNCH(64);
+    else if (vec8 && H == 256) GP_LAUNCH(32);
+    else if (vec8 && H == 128) GP_LAUNCH(16);
+    else if (vec8 && H == 64) GP_LAUNCH(8);
+    else
+        hipLaunchKernelGGL(gcl_pre_kernel, dim3((E + 3) / 4), dim3(256), 0, stream, AB, ab_dt, ldab, H, row, col, rhohat,
+                           w_r, pre, pre_dt, E, act, dact_out);
+#undef GP_LAUNCH
     FB_CHECK_LAUNCH();
     return 0;
 }
@@ -39,80 +96,152 @@ extern "C" int fabind_gcl_pre(const float* AB, int ldab, int H, const int* row, 
 // out[r,:] = sum_{e in [rowptr[r], rowptr[r+1])} act(Z[eidx ? eidx[e] : e,:])
 // One 256-thread work-group per row: its 4 waves take edges round-robin, each lane owns 8 consecutive columns
 // per 512-column slab (16-byte loads for bf16); partials are combined through LDS in fixed wave order.
-struct F8 { float v[8]; };
-__device__ __forceinline__ F8 ld8_any(const void* p, int dt, size_t i) {
-    F8 r;
-    if (dt == FB_DT_F32) {
-        const float4 a = *(const float4*)((const float*)p + i), b = *(const float4*)((const float*)p + i + 4);
-        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    } else {
-        const uint4 u = *(const uint4*)((const bf16_t*)p + i);
-        r.v[0] = __uint_as_float(u.x << 16); r.v[1] = __uint_as_float(u.x & 0xffff0000u);
-        r.v[2] = __uint_as_float(u.y << 16); r.v[3] = __uint_as_float(u.y & 0xffff0000u);
-        r.v[4] = __uint_as_float(u.z << 16); r.v[5] = __uint_as_float(u.z & 0xffff0000u);
-        r.v[6] = __uint_as_float(u.w << 16); r.v[7] = __uint_as_float(u.w & 0xffff0000u);
+
+// One wave per CSR row (4 rows per work-group): no LDS, no barrier, few registers (8 waves/SIMD).  Each lane owns 8
+// consecutive columns per 512-column slab (16-byte bf16 loads), 4 independent row loads in flight per lane.
+#define SS_HEAVY 128
+template <int NSLAB, int U>
+__device__ __forceinline__ void ss_accum(const void* __restrict__ Z, int z_dt, int ldz, int H, const int* eidx, int act,
+                                         int lane, int e0, int e1, int estep, F8 (&acc)[NSLAB]) {
+    int ee = e0;
+    for (; ee + (U - 1) * estep < e1; ee += U * estep) {
+        int e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) e[u] = eidx ? eidx[ee + u * estep] : ee + u * estep;
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s) {
+            const int c = s * 512 + lane * 8;
+            if (c < H) {
+                F8 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) v[u] = ld8_any(Z, z_dt, (size_t)e[u] * ldz + c);
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[s].v[k] += apply_act(v[u].v[k], act);
+            }
+        }
     }
-    return r;
+    if (ee < e1) {                                  // ragged last group, predicated (wave-uniform) -- one round trip
+        int e[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            ok[u] = ee + u * estep < e1;
+            e[u] = ok[u] ? (eidx ? eidx[ee + u * estep] : ee + u * estep) : 0;
+        }
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s) {
+            const int c = s * 512 + lane * 8;
+            if (c < H) {
+                F8 v[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (ok[u]) v[u] = ld8_any(Z, z_dt, (size_t)e[u] * ldz + c);
+                    else
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[u].v[k] = 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc[s].v[k] += apply_act(v[u].v[k], act);
+            }
+        }
+    }
 }
 
 template <int NSLAB>
 __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict__ Z, int z_dt, int ldz, int H,
                                                           const int* rowptr, const int* eidx, int act, float* out,
-                                                          int ldo) {
-    __shared__ F8 part[3][NSLAB * 64];
-    const int r = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+                                                          int ldo, int n_rows) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    if (e1 - e0 > SS_HEAVY) return;                // left to segment_sum_heavy_kernel
     F8 acc[NSLAB];
 #pragma unroll
     for (int s = 0; s < NSLAB; ++s)
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[s].v[k] = 0.f;
-    for (int ee = e0 + w; ee < e1; ee += 4) {
-        const int e = eidx ? eidx[ee] : ee;
+    ss_accum<NSLAB, 4>(Z, z_dt, ldz, H, eidx, act, lane, e0, e1, 1, acc);
 #pragma unroll
-        for (int s = 0; s < NSLAB; ++s) {
-            const int c = s * 512 + lane * 8;
-            if (c < H) {
-                const F8 v = ld8_any(Z, z_dt, (size_t)e * ldz + c);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[s].v[k] += apply_act(v.v[k], act);
-            }
-        }
-    }
-    if (w > 0) {
-#pragma unroll
-        for (int s = 0; s < NSLAB; ++s) part[w - 1][s * 64 + lane] = acc[s];
-    }
-    __syncthreads();
-    if (w == 0) {
-#pragma unroll
-        for (int s = 0; s < NSLAB; ++s) {
-            const int c = s * 512 + lane * 8;
-            if (c < H) {
-                F8 a = acc[s];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const F8 p = part[k][s * 64 + lane];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) a.v[q] += p.v[q];
-                }
-                *(float4*)(out + (size_t)r * ldo + c) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
-                *(float4*)(out + (size_t)r * ldo + c + 4) = make_float4(a.v[4], a.v[5], a.v[6], a.v[7]);
-            }
+    for (int s = 0; s < NSLAB; ++s) {
+        const int c = s * 512 + lane * 8;
+        if (c < H) {
+            float* o = out + (size_t)r * ldo + c;
+            *(float4*)o = make_float4(acc[s].v[0], acc[s].v[1], acc[s].v[2], acc[s].v[3]);
+            *(float4*)(o + 4) = make_float4(acc[s].v[4], acc[s].v[5], acc[s].v[6], acc[s].v[7]);
         }
     }
 }
 
+// Rows longer than SS_HEAVY edges (the global nodes of a complex: ~1500 star edges): each 1024-thread work-group scans
+// 1024 row lengths, then its 16 waves reduce every heavy row among them cooperatively (8 row loads in flight per
+// wave), partials combined through LDS in fixed wave order.
+template <int NSLAB>
+__global__ __launch_bounds__(1024) void segment_sum_heavy_kernel(const void* __restrict__ Z, int z_dt, int ldz, int H,
+                                                                 const int* rowptr, const int* eidx, int act, float* out,
+                                                                 int ldo, int n_rows) {
+    __shared__ F8 part[15][NSLAB * 64];
+    __shared__ int heavy[1024];
+    __shared__ int n_heavy;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) n_heavy = 0;
+    __syncthreads();
+    const int rr = blockIdx.x * 1024 + threadIdx.x;
+    if (rr < n_rows && rowptr[rr + 1] - rowptr[rr] > SS_HEAVY) heavy[atomicAdd(&n_heavy, 1)] = rr;
+    __syncthreads();
+    const int nh = n_heavy;
+    for (int q = 0; q < nh; ++q) {
+        const int r = heavy[q];
+        F8 acc[NSLAB];
+#pragma unroll
+        for (int s = 0; s < NSLAB; ++s)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[s].v[k] = 0.f;
+        ss_accum<NSLAB, 8 / NSLAB>(Z, z_dt, ldz, H, eidx, act, lane, rowptr[r] + w, rowptr[r + 1], 16, acc);
+        if (w > 0) {
+#pragma unroll
+            for (int s = 0; s < NSLAB; ++s) part[w - 1][s * 64 + lane] = acc[s];
+        }
+        __syncthreads();
+        if (w == 0) {
+#pragma unroll
+            for (int s = 0; s < NSLAB; ++s) {
+                for (int k = 0; k < 15; ++k) {
+                    const F8 p = part[k][s * 64 + lane];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) acc[s].v[t] += p.v[t];
+                }
+                const int c = s * 512 + lane * 8;
+                if (c < H) {
+                    float* o = out + (size_t)r * ldo + c;
+                    *(float4*)o = make_float4(acc[s].v[0], acc[s].v[1], acc[s].v[2], acc[s].v[3]);
+                    *(float4*)(o + 4) = make_float4(acc[s].v[4], acc[s].v[5], acc[s].v[6], acc[s].v[7]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, const int* eidx,
-                                  int n_rows, int act, float* out, int ldo, hipStream_t stream) {
+                                  int n_rows, int n_edges, int act, float* out, int ldo, hipStream_t stream) {
     FB_REQUIRE(H % 8 == 0 && ldz % 8 == 0 && ldo % 4 == 0, "fabind_segment_sum: H/ldz must be multiples of 8, ldo of 4");
     FB_REQUIRE(H <= 1024, "fabind_segment_sum: H <= 1024");
     FB_REQUIRE(((uintptr_t)Z % 16 == 0) && ((uintptr_t)out % 16 == 0), "fabind_segment_sum: 16-byte alignment");
     if (n_rows <= 0) return 0;
-    if (H <= 512)
-        hipLaunchKernelGGL((segment_sum_kernel<1>), dim3(n_rows), dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo);
-    else
-        hipLaunchKernelGGL((segment_sum_kernel<2>), dim3(n_rows), dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo);
+    (void)n_edges;
+    const dim3 g((n_rows + 3) / 4), gh((n_rows + 1023) / 1024);
+    if (H <= 512) {
+        hipLaunchKernelGGL((segment_sum_kernel<1>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows);
+        hipLaunchKernelGGL((segment_sum_heavy_kernel<1>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows);
+    } else {
+        hipLaunchKernelGGL((segment_sum_kernel<2>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows);
+        hipLaunchKernelGGL((segment_sum_heavy_kernel<2>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows);
+    }
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -47,10 +47,10 @@ template <> __device__ __forceinline__ void store8_lds<float>(float* p, const Ve
 }
 template <> __device__ __forceinline__ void store8_lds<bf16_t>(bf16_t* p, const Vec8& r) {
     uint4 u;
-    u.x = (uint32_t)f32_to_bf16(r.v[0]) | ((uint32_t)f32_to_bf16(r.v[1]) << 16);
-    u.y = (uint32_t)f32_to_bf16(r.v[2]) | ((uint32_t)f32_to_bf16(r.v[3]) << 16);
-    u.z = (uint32_t)f32_to_bf16(r.v[4]) | ((uint32_t)f32_to_bf16(r.v[5]) << 16);
-    u.w = (uint32_t)f32_to_bf16(r.v[6]) | ((uint32_t)f32_to_bf16(r.v[7]) << 16);
+    u.x = pack2_bf16(r.v[0], r.v[1]);
+    u.y = pack2_bf16(r.v[2], r.v[3]);
+    u.z = pack2_bf16(r.v[4], r.v[5]);
+    u.w = pack2_bf16(r.v[6], r.v[7]);
     *(uint4*)p = u;
 }
 

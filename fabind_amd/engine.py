@@ -260,7 +260,7 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
         x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
         t = ops.linear(hin, p["Wn1"], p["bn1"], x2=agg, act_epi=K.ACT_SILU, out_dtype=ad)
         return ops.linear(t, p["Wn2"], p["bn2"], residual=h), x_new
-    AB = ops.linear(hin, p["W_ab"], p["b_ab"])                                         # [N,2H] node-level
+    AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=ad)                           # [N,2H] node-level
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
     S1 = ops.gcl_pre(AB, H, g, rhohat, p["w_r"], act=K.ACT_SILU)                        # [E,H] silu(first edge Linear)
     Mm = ops.linear(S1, p["W2"], p["b2"], act_epi=K.ACT_SILU, out_dtype=ad)             # [E,H] messages m_e

@@ -158,7 +158,7 @@ def gcl_pre(AB, H, row, col, rhohat, w_r, out_dtype, act=ACT_NONE, want_dact=Fal
     E = row.shape[0]
     pre = torch.empty((E, H), dtype=out_dtype, device=AB.device)
     dact = torch.empty((E, H), dtype=out_dtype, device=AB.device) if want_dact else None
-    check(_lib.load().fabind_gcl_pre(ptr(AB), _ld(AB), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r), ptr(pre),
+    check(_lib.load().fabind_gcl_pre(ptr(AB), dt_code(AB.dtype), _ld(AB), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r), ptr(pre),
                                      dt_code(out_dtype), E, act, ptr(dact), stream()), "fabind_gcl_pre")
     return (pre, dact) if want_dact else pre
 
@@ -167,8 +167,9 @@ def segment_sum(Z, rowptr, n_rows, act=ACT_NONE, eidx=None, out=None):
     H = Z.shape[1]
     if out is None:
         out = torch.empty((n_rows, H), dtype=torch.float32, device=Z.device)
-    check(_lib.load().fabind_segment_sum(ptr(Z), dt_code(Z.dtype), _ld(Z), H, ptr(rowptr), ptr(eidx), n_rows, act,
-                                         ptr(out), _ld(out), stream()), "fabind_segment_sum")
+    check(_lib.load().fabind_segment_sum(ptr(Z), dt_code(Z.dtype), _ld(Z), H, ptr(rowptr), ptr(eidx), n_rows,
+                                         Z.shape[0] if eidx is None else eidx.numel(), act, ptr(out), _ld(out),
+                                         stream()), "fabind_segment_sum")
     return out
 
 

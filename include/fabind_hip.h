@@ -123,13 +123,15 @@ int fabind_edge_geom(const float* x, const int* row, const int* col, const int* 
  *           (first edge_mlp Linear split column-wise: node-level projections gathered per edge).
  * segment_sum: out[r,:] = sum_{e in row r} act(Z[eidx ? eidx[e] : e,:])   (unsorted_segment_sum on a row-sorted
  *           CSR; eidx = permutation for reductions over the column index, used by backward passes)
+ *           n_edges = rowptr[n_rows] (host copy).  bf16 rows are reduced edge-balanced (64 CSR positions per wave,
+ *           rows cut by a chunk boundary finish with fp32 atomics); fp32 rows one wave per row, fixed order.
  * coord_mean: x_out[r] = x[r] + clamp( (1/max(deg,1)) * sum_e d[e]*s[e], +-clampv ),
  *           s[e] = sum_k s_part[e,k] (row-dot partials written by fabind_gemm).
  * -------------------------------------------------------------------------------------------*/
-int fabind_gcl_pre(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
+int fabind_gcl_pre(const void* AB, int ab_dt, int ldab, int H, const int* row, const int* col, const float* rhohat,
                    const float* w_r, void* pre, int pre_dt, int E, int act, void* dact_out, hipStream_t stream);
-int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, const int* eidx, int n_rows, int act,
-                       float* out, int ldo, hipStream_t stream);
+int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, const int* eidx, int n_rows, int n_edges,
+                       int act, float* out, int ldo, hipStream_t stream);
 int fabind_coord_update(const float* x, const float* d, const float* s_part, int n_part, const float* weight,
                         const int* rowptr, int n_rows, int mean, float clampv, float* x_out, float* s_out,
                         hipStream_t stream);

@@ -66,6 +66,49 @@ def test_segment_sum_and_scan():
         row = torch.repeat_interleave(torch.arange(3000), deg.long())
         ref = torch.zeros(3000, H).index_add_(0, row, torch.nn.functional.silu(Z))
         assert (out.cpu() - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max())
+    # bf16 rows take the edge-balanced path (64 positions per wave, cut rows finish with atomics); also the
+    # permuted reduction (eidx) used for the sending side, on a buffer that holds stale values before the call
+    deg[:7] = 0
+    deg[2990:] = 0
+    rp = K.exclusive_scan(deg.to(dev))
+    row = torch.repeat_interleave(torch.arange(3000), deg.long())
+    E = row.shape[0]
+    for H in (64, 512, 1024):
+        Z = torch.randn(E, H, generator=g).bfloat16()
+        out = torch.full((3000, H), 7.0, device=dev)
+        K.segment_sum(Z.to(dev), rp, 3000, K.ACT_SILU, out=out)
+        ref = torch.zeros(3000, H).index_add_(0, row, torch.nn.functional.silu(Z.float()))
+        assert (out.cpu() - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max())
+        perm = torch.randperm(E, generator=g)
+        out = K.segment_sum(Z.to(dev), rp, 3000, eidx=perm.to(torch.int32).to(dev))
+        ref = torch.zeros(3000, H).index_add_(0, row, Z.float()[perm])
+        assert (out.cpu() - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max())
+
+
+@pytest.mark.parametrize("H", [36, 64, 128, 512, 640])
+@pytest.mark.parametrize("ab_dtype", [torch.float32, torch.bfloat16])
+def test_gcl_pre_gather(H, ab_dtype):
+    """First edge Linear evaluated per node and gathered (egnn.py:72-76 split column-wise), with the SiLU and its
+    derivative emitted by the producer; both the 8-column vector kernel (H = 64..512) and the generic one."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(H)
+    N, E = 211, 3001                                    # E not a multiple of the edges-per-wave of any variant
+    AB = torch.randn(N, 2 * H, generator=g).to(ab_dtype)
+    row = torch.sort(torch.randint(0, N, (E,), generator=g))[0]
+    col = torch.randint(0, N, (E,), generator=g)
+    rh, w_r = torch.rand(E, generator=g), torch.randn(H, generator=g)
+    z = (AB[row, :H].float() + AB[col, H:].float() + rh[:, None] * w_r).requires_grad_(True)
+    ref = torch.nn.functional.silu(z)
+    dref, = torch.autograd.grad(ref.sum(), z)
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    for out_dtype, tol in ((torch.float32, 1e-5), (torch.bfloat16, 1e-2)):
+        pre, dact = K.gcl_pre(AB.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), out_dtype, K.ACT_SILU,
+                              want_dact=True)
+        assert (pre.float().cpu() - ref.detach()).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+        assert (dact.float().cpu() - dref).abs().max() <= tol * 2
+        pre0 = K.gcl_pre(AB.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), out_dtype)
+        assert (pre0.float().cpu() - z.detach()).abs().max() <= tol * max(1.0, float(z.abs().max()))
 
 
 def test_layernorm():
