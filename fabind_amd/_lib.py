@@ -23,6 +23,13 @@ class GemmArgs(ctypes.Structure):
                                   "accumulate", "store_preact", "n_groups", "max_m", "max_n", "groups_ext", "epi_fast", "k_splits")] + [("alpha", _f)]
 
 
+class EdgeBwdArgs(ctypes.Structure):
+    """Mirror of FabindEdgeBwdArgs (include/fabind_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("AB", "row", "col", "rhohat", "w_r", "W2p", "Wcp", "W2Tp", "WcTp", "b2", "bc", "w3", "ds",
+                                  "dagg", "S1", "Mm", "dT", "dP2", "dP1", "drh", "dABrow", "part", "dbg")] + \
+               [(n, _i) for n in ("ldab", "lddagg", "lddab", "E")]
+
+
 # name -> argtypes (every function returns int and takes the stream last)
 SIGNATURES = {
     "fabind_gemm": [ctypes.POINTER(GemmArgs), _vp],
@@ -36,6 +43,9 @@ SIGNATURES = {
     "fabind_edge_geom": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "fabind_gcl_pre": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "fabind_gcl_edge_fused": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp],
+    "fabind_gcl_edge_fused_bwd": [ctypes.POINTER(EdgeBwdArgs), _i, _i, _vp],
+    "fabind_gcl_edge_fused_bwd_set_tile": [_i],
+    "fabind_gcl_edge_fused_bwd_tile": [],
     "fabind_segment_sum": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
     "fabind_coord_update": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
     "fabind_cross_attn_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i,

@@ -65,6 +65,48 @@ __device__ __forceinline__ void fe_gemm(const bf16_t* sX, const bf16_t* __restri
     }
 }
 
+// Same contraction with the k-loop kept rolled (two k-steps per trip, B fragments ping-pong): the backward kernel
+// holds more live state (silu'(pre2), partial column sums) and a fully unrolled loop lets the scheduler hoist every
+// B-fragment load of the contraction at once.
+template <int H, int MI>
+__device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* __restrict__ Wp, int wave, int lane,
+                                               f32x4_t (&acc)[MI][4]) {
+    constexpr int NKS = H / 32, NG = H / 16;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16x8_t* wp = (const bf16x8_t*)Wp + ((size_t)wave * 4) * 64 + lane;
+    bf16x8_t b0[4], b1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0[j] = wp[(size_t)j * 64];
+#pragma unroll 1
+    for (int ks = 0; ks < NKS; ks += 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[j] = wp[((size_t)(ks + 1) * NG + j) * 64];
+        bf16x8_t a[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = i * 16 + fr;
+            a[i] = *(const bf16x8_t*)&sX[r * H + (((ks * 4 + fq) ^ (r & 7)) * 8)];
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0[j], acc[i][j], 0, 0, 0);
+        if (ks + 2 < NKS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b0[j] = wp[((size_t)(ks + 2) * NG + j) * 64];
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = i * 16 + fr;
+            a[i] = *(const bf16x8_t*)&sX[r * H + ((((ks + 1) * 4 + fq) ^ (r & 7)) * 8)];
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1[j], acc[i][j], 0, 0, 0);
+    }
+}
+
 template <int H>
 __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __restrict__ AB, int ldab, const int* __restrict__ row,
                                                            const int* __restrict__ col, const float* __restrict__ rhohat,
@@ -203,6 +245,372 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
     } while (0)
     if (H == 512) FE_LAUNCH(512); else if (H == 256) FE_LAUNCH(256); else if (H == 128) FE_LAUNCH(128); else FE_LAUNCH(64);
 #undef FE_LAUNCH
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// =====================================================================================================
+// Backward of the same pipeline (training, bf16): nothing per-edge was saved by the forward kernel.
+// Per 64-edge tile the work-group recomputes S1, pre2, M, pre3 and chains the four H x H contractions
+//
+//   S1 -> pre2 = S1 W2^T + b2 -> M = silu(pre2)            (recompute, keeps silu'(pre2) in registers)
+//   pre3 = M Wc^T + bc;  dT  = ds * w3 * silu'(pre3)        (ds = gradient of the per-edge scalar s)
+//   dM   = dT Wc + dagg[row];   dP2 = dM * silu'(pre2)      (dagg = gradient of the segment sum)
+//   dS1  = dP2 W2;              dP1 = dS1 * silu'(pre1)
+//
+// with S1 / dT / dS1 / dP1 passing through one LDS tile and M / dP2 through a second one.  It writes the
+// bf16 operands of the two weight-gradient contractions (S1, M, dT, dP2: consumed by fabind_gemm_tn) and
+// dP1 (sending-side segment sum) once each -- 5 [E,H] writes and no [E,H] read, instead of the ~20 round
+// trips of the unfused backward -- plus d rhohat, the receiving-side segment sum of dP1 (run-length scan,
+// boundary runs finish with atomics) and per-work-group partial column sums for d b2, d bc, d w3, d w_r.
+// Persistent work-groups (one per CU: 2 x 64 KiB LDS tiles at H = 512) walk the tiles grid-stride.
+template <int H>
+__device__ __forceinline__ void fe_tile_store(const bf16_t* sB, bf16_t* __restrict__ g, int e0, int ne, int tid) {
+    constexpr int CH = H / 8;
+    bf16_t* gt = g + (size_t)e0 * H;                      // uniform tile base (SGPRs) + 32-bit lane offsets below
+    for (unsigned q = tid; q < (unsigned)ne * CH; q += H) {
+        const unsigned rw = q / CH, ch = q % CH;
+        *(uint4*)&gt[rw * H + ch * 8] = *(const uint4*)&sB[rw * H + ((ch ^ (rw & 7)) * 8)];
+    }
+}
+
+template <int MI>
+__device__ __forceinline__ void fe_zero(f32x4_t (&acc)[MI][4]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int H, int BM>
+__global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kernel(const FabindEdgeBwdArgs p) {
+    constexpr int TPE = H / BM;                                   // threads per edge in the gather layout
+    constexpr int CPT = BM / 8;                                   // 16-byte chunks per thread there
+    constexpr int MI = BM / 16;                                   // 16-row MFMA fragments per wave
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sX = (bf16_t*)smem;                                   // [64][H] swizzled: S1 -> dT -> dS1 -> dP1
+    bf16_t* sY = sX + BM * H;                                  // [64][H] swizzled: M -> dP2
+    int* sRow = (int*)(sY + BM * H);
+    float* sDs = (float*)(sRow + BM);
+    float* sRh = sDs + BM;
+    const bf16_t* __restrict__ AB = (const bf16_t*)p.AB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, cq = lane >> 4;
+    const int el = tid / TPE, cth = tid % TPE;
+    const int n_tiles = (p.E + BM - 1) / BM;
+    // LDS element offset of C-fragment element (i, j, r) of this lane in a swizzled [64][H] tile, as one of four
+    // lane-dependent bases plus a compile-time constant (so the 64 stores of an epilogue need 4 address registers):
+    //   row = i*16 + cq*4 + r, col = wave*64 + j*16 + fr, chunk = (col>>3) ^ (row&7); bit0 flips with r&1, bit2 with j>>1
+    int cbase[2][2];
+#pragma unroll
+    for (int f0 = 0; f0 < 2; ++f0)
+#pragma unroll
+        for (int f2 = 0; f2 < 2; ++f2)
+            cbase[f0][f2] = cq * 4 * H + (wave * 8 + (((cq & 1) ^ f2) << 2) + ((fr >> 3) ^ f0)) * 8 + (fr & 7);
+#define FE_COFF(i, j, r) (cbase[(r) & 1][(j) >> 1] + ((i) * 16 + (r)) * H + ((((j) & 1) ^ ((r) >> 1)) * 16))
+    long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // optional per-phase cycle counts (p.dbg != NULL)
+    long long tlast = 0;
+#define FE_TICK(k_)                                                   \
+    if (p.dbg) {                                                      \
+        const long long now_ = __builtin_readcyclecounter();         \
+        tph[k_] += now_ - tlast;                                      \
+        tlast = now_;                                                 \
+    }
+    float pb2[4] = {0.f, 0.f, 0.f, 0.f}, pbc[4] = {0.f, 0.f, 0.f, 0.f}, pw3[4] = {0.f, 0.f, 0.f, 0.f}, pwr = 0.f;
+
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int e0 = tile * BM;
+        const int ne = min(BM, p.E - e0);
+        // Loop-invariant operands (weights, biases, w_r) must be re-read from L2 per tile, not hoisted into ~140
+        // registers that stay live across the whole tile loop: launder their base offsets once per trip.
+        int lz = 0;
+        asm volatile("" : "+s"(lz));
+        const float* w_r = p.w_r + lz;
+        const float* b2 = p.b2 + lz;
+        const float* bc = p.bc + lz;
+        const float* w3 = p.w3 + lz;
+        const bf16_t* W2p = (const bf16_t*)p.W2p + lz;
+        const bf16_t* Wcp = (const bf16_t*)p.Wcp + lz;
+        const bf16_t* W2Tp = (const bf16_t*)p.W2Tp + lz;
+        const bf16_t* WcTp = (const bf16_t*)p.WcTp + lz;
+        if (p.dbg) tlast = __builtin_readcyclecounter();
+        // ---- P0: gather + first Linear + SiLU -> sX
+        // every global access below is (uniform base in SGPRs) + (32-bit lane offset): 64-bit per-lane pointers
+        // are loop-invariant per access site, get hoisted out of the tile loop and spill by the hundred
+        const int* grow = p.row + e0;
+        const int* gcol = p.col + e0;
+        const float* grh = p.rhohat + e0;
+        const float* gds = p.ds + e0;
+        const unsigned uld = (unsigned)p.ldab;
+        if (tid < BM) {
+            const bool ok = tid < ne;
+            sRow[tid] = ok ? grow[(unsigned)tid] : -1;
+            sDs[tid] = ok ? gds[(unsigned)tid] : 0.f;
+            sRh[tid] = ok ? grh[(unsigned)tid] : 0.f;
+        }
+        if (el < ne) {
+            const unsigned r = (unsigned)grow[(unsigned)el], c = (unsigned)gcol[(unsigned)el];
+            const float rh = grh[(unsigned)el];
+            const unsigned aoff = r * uld + cth * (CPT * 8), boff = c * uld + H + cth * (CPT * 8);
+            const float* wp = w_r + (unsigned)(cth * (CPT * 8));
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                float fa[8], fb[8], o[8];
+                unpack8(*(const uint4*)(AB + (aoff + q * 8)), fa);
+                unpack8(*(const uint4*)(AB + (boff + q * 8)), fb);
+                const float4 w0 = *(const float4*)(wp + q * 8), w1 = *(const float4*)(wp + q * 8 + 4);
+                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = fe_silu(fa[k] + fb[k] + rh * wv[k]);
+                *(uint4*)&sX[el * H + (((cth * CPT + q) ^ (el & 7)) * 8)] = pack8(o);
+            }
+        } else {
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) *(uint4*)&sX[el * H + (((cth * CPT + q) ^ (el & 7)) * 8)] = z;
+        }
+        __syncthreads();
+        FE_TICK(0)
+        fe_tile_store<H>(sX, (bf16_t*)p.S1, e0, ne, tid);
+        FE_TICK(1)
+
+        // Epilogues run as ROLLED loops over the wave's four 16-column blocks: slot 0 of acc / d2 / the partial sums
+        // is processed, then every array rotates left by one block (a full turn after four trips).  A fully
+        // unrolled epilogue lets the scheduler interleave all 64 exp/rcp chains of a lane and spill by the hundred.
+#define FE_ROT4(a_) { auto t_ = a_[0]; a_[0] = a_[1]; a_[1] = a_[2]; a_[2] = a_[3]; a_[3] = t_; }
+#define FE_ROT_ACC() _Pragma("unroll") for (int i = 0; i < MI; ++i) FE_ROT4(acc[i])
+#define FE_ROT_D2() _Pragma("unroll") for (int i = 0; i < MI; ++i) { FE_ROT4(d2a[i]); FE_ROT4(d2b[i]); }
+        // LDS offset of element (i, block j, r): cb[r&1] + (i*16 + r)*H + o2[r>>1], cb / o2 recomputed per block
+#define FE_JADDR(j_)                                                                          \
+        const int cb[2] = {((j_) >> 1) ? cbase[0][1] : cbase[0][0], ((j_) >> 1) ? cbase[1][1] : cbase[1][0]}; \
+        const int o2[2] = {((j_) & 1) * 16, 16 - ((j_) & 1) * 16};
+#define FE_LOFF(i, r) (cb[(r) & 1] + ((i) * 16 + (r)) * H + o2[(r) >> 1])
+
+        // ---- P1: pre2 = S1 W2^T + b2;  M -> sY;  silu'(pre2) stays in registers (packed bf16)
+        f32x4_t acc[MI][4];
+        uint32_t d2a[MI][4], d2b[MI][4];
+        fe_zero(acc);
+        fe_gemm_rolled<H, MI>(sX, W2p, wave, lane, acc);
+        FE_TICK(2)
+        {
+            float bj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bj[j] = b2[wave * 64 + j * 16 + fr];
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                FE_JADDR(j)
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    float dd[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = acc[i][0][r] + bj[0], sg = fe_sigmoid(z);
+                        dd[r] = sg * (1.0f + z * (1.0f - sg));
+                        sY[FE_LOFF(i, r)] = f32_to_bf16(z * sg);
+                    }
+                    d2a[i][0] = pack2_bf16(dd[0], dd[1]);
+                    d2b[i][0] = pack2_bf16(dd[2], dd[3]);
+                }
+                FE_ROT_ACC() FE_ROT_D2() FE_ROT4(bj)
+            }
+        }
+        __syncthreads();
+        FE_TICK(3)
+        fe_tile_store<H>(sY, (bf16_t*)p.Mm, e0, ne, tid);
+        FE_TICK(1)
+
+        // ---- P2: pre3 = M Wc^T + bc;  dT = ds * w3 * silu'(pre3) -> sX
+        fe_zero(acc);
+        fe_gemm_rolled<H, MI>(sY, Wcp, wave, lane, acc);
+        FE_TICK(2)
+        {
+            float bj[4], wj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bj[j] = bc[wave * 64 + j * 16 + fr]; wj[j] = w3[wave * 64 + j * 16 + fr]; }
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                FE_JADDR(j)
+                float a3 = 0.f, ac = 0.f;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = acc[i][0][r] + bj[0], sg = fe_sigmoid(z), dsr = sDs[i * 16 + cq * 4 + r];
+                        const float dt = dsr * wj[0] * (sg * (1.0f + z * (1.0f - sg)));
+                        a3 += dsr * (z * sg);
+                        ac += dt;
+                        sX[FE_LOFF(i, r)] = f32_to_bf16(dt);
+                    }
+                pw3[0] += a3;
+                pbc[0] += ac;
+                FE_ROT_ACC() FE_ROT4(bj) FE_ROT4(wj) FE_ROT4(pw3) FE_ROT4(pbc)
+            }
+        }
+        __syncthreads();
+        FE_TICK(4)
+        fe_tile_store<H>(sX, (bf16_t*)p.dT, e0, ne, tid);
+        FE_TICK(1)
+
+        // ---- P3: dM = dT Wc + dagg[row];  dP2 = dM * silu'(pre2) -> sY
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = sRow[i * 16 + cq * 4 + r];
+                const unsigned doff = (unsigned)max(rr, 0) * (unsigned)p.lddagg + wave * 64 + fr;   // + j*16: immediates
+                const float keep = rr >= 0 ? 1.f : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j][r] = p.dagg[doff + j * 16] * keep;
+            }
+        FE_TICK(5)
+        fe_gemm_rolled<H, MI>(sX, WcTp, wave, lane, acc);
+        FE_TICK(2)
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            FE_JADDR(j)
+            float a2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t pk = (r >> 1) ? d2b[i][0] : d2a[i][0];
+                    const float dd = __uint_as_float((r & 1) ? (pk & 0xffff0000u) : (pk << 16));
+                    const float dp = acc[i][0][r] * dd;
+                    a2 += dp;
+                    sY[FE_LOFF(i, r)] = f32_to_bf16(dp);
+                }
+            pb2[0] += a2;
+            FE_ROT_ACC() FE_ROT_D2() FE_ROT4(pb2)
+        }
+        __syncthreads();
+        FE_TICK(6)
+        fe_tile_store<H>(sY, (bf16_t*)p.dP2, e0, ne, tid);
+        FE_TICK(1)
+
+        // ---- P4: dS1 = dP2 W2 -> sX
+        fe_zero(acc);
+        fe_gemm_rolled<H, MI>(sY, W2Tp, wave, lane, acc);
+        FE_TICK(2)
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            FE_JADDR(j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sX[FE_LOFF(i, r)] = f32_to_bf16(acc[i][0][r]);
+            FE_ROT_ACC()
+        }
+        __syncthreads();
+        FE_TICK(7)
+
+        // ---- P5 (gather layout): dP1 = dS1 * silu'(pre1) in place;  d rhohat = dP1 . w_r
+        if (el < ne) {
+            const unsigned r = (unsigned)sRow[el], c = (unsigned)gcol[(unsigned)el];
+            const float rh = sRh[el];
+            const unsigned aoff = r * uld + cth * (CPT * 8), boff = c * uld + H + cth * (CPT * 8);
+            const float* wp = w_r + (unsigned)(cth * (CPT * 8));
+            float dot = 0.f;
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) {
+                float fa[8], fb[8], g[8];
+                unpack8(*(const uint4*)(AB + (aoff + q * 8)), fa);
+                unpack8(*(const uint4*)(AB + (boff + q * 8)), fb);
+                uint4* sp = (uint4*)&sX[el * H + (((cth * CPT + q) ^ (el & 7)) * 8)];
+                unpack8(*sp, g);
+                const float4 w0 = *(const float4*)(wp + q * 8), w1 = *(const float4*)(wp + q * 8 + 4);
+                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float z = fa[k] + fb[k] + rh * wv[k], sg = fe_sigmoid(z);
+                    g[k] *= sg * (1.0f + z * (1.0f - sg));
+                    dot += g[k] * wv[k];
+                }
+                *sp = pack8(g);
+            }
+#pragma unroll
+            for (int o = 1; o < TPE; o <<= 1) dot += __shfl_xor(dot, o, 64);
+            if (cth == 0) (p.drh + e0)[(unsigned)el] = dot;
+        }
+        __syncthreads();
+        FE_TICK(8)
+        fe_tile_store<H>(sX, (bf16_t*)p.dP1, e0, ne, tid);
+        FE_TICK(1)
+
+        // ---- P6 (one column per thread): receiving-side segment sum of dP1 and the d w_r column sum
+        {
+            const int c = tid;
+            float run = 0.f;
+            int cur = sRow[0];
+            bool first = true;
+            for (int rw = 0; rw < ne; ++rw) {
+                const int rr = sRow[rw];
+                if (rr != cur) {
+                    const unsigned o = (unsigned)cur * (unsigned)p.lddab + c;
+                    if (first) atomicAdd(&p.dABrow[o], run); else p.dABrow[o] = run;
+                    run = 0.f; cur = rr; first = false;
+                }
+                const float v = bf16_to_f32(sX[rw * H + (((c >> 3) ^ (rw & 7)) * 8) + (c & 7)]);
+                run += v;
+                pwr += sRh[rw] * v;
+            }
+            if (ne > 0) atomicAdd(&p.dABrow[(unsigned)cur * (unsigned)p.lddab + c], run);
+        }
+        __syncthreads();                                          // the next tile overwrites sX / sRow
+        FE_TICK(9)
+    }
+    if (p.dbg && blockIdx.x == 0 && tid == 0)
+        for (int k = 0; k < 12; ++k) ((long long*)p.dbg)[k] = tph[k];
+
+    // per-work-group partial column sums: part[blockIdx.x][{b2, bc, w3, w_r}][H]
+    float* part = p.part + (size_t)blockIdx.x * 4 * H;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a = pb2[j], b = pbc[j], c = pw3[j];
+        a += __shfl_xor(a, 16, 64); a += __shfl_xor(a, 32, 64);
+        b += __shfl_xor(b, 16, 64); b += __shfl_xor(b, 32, 64);
+        c += __shfl_xor(c, 16, 64); c += __shfl_xor(c, 32, 64);
+        if (cq == 0) {
+            const int colj = wave * 64 + j * 16 + fr;
+            part[colj] = a; part[H + colj] = b; part[2 * H + colj] = c;
+        }
+    }
+    part[3 * H + tid] = pwr;
+}
+
+static int g_fe_bwd_bm = 32;
+extern "C" int fabind_gcl_edge_fused_bwd_set_tile(int bm) {
+    FB_REQUIRE(bm == 32 || bm == 64, "fabind_gcl_edge_fused_bwd_set_tile: 32 or 64 edges per tile");
+    g_fe_bwd_bm = bm;
+    return 0;
+}
+extern "C" int fabind_gcl_edge_fused_bwd_tile(void) { return g_fe_bwd_bm; }
+
+extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a, int H, int n_groups, hipStream_t stream) {
+    if (a->E <= 0 || n_groups <= 0) return 0;
+    FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_gcl_edge_fused_bwd: H must be 64, 128, 256 or 512");
+    FB_REQUIRE(a->ldab % 8 == 0, "fabind_gcl_edge_fused_bwd: ldab % 8");
+    const int BMr = g_fe_bwd_bm;
+    const size_t lds = (size_t)2 * BMr * H * 2 + BMr * (sizeof(int) + 2 * sizeof(float));
+#define FE_LAUNCH2(HH, BB)                                                                                         \
+    do {                                                                                                           \
+        static bool set_ = false;                                                                                  \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_bwd_kernel<HH, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        hipLaunchKernelGGL((gcl_edge_fused_bwd_kernel<HH, BB>), dim3(n_groups), dim3(HH), lds, stream, *a);         \
+    } while (0)
+#define FE_LAUNCH(HH)                                                                                              \
+    do {                                                                                                           \
+        if (BMr == 32) FE_LAUNCH2(HH, 32); else FE_LAUNCH2(HH, 64);                                                \
+    } while (0)
+    if (H == 512) FE_LAUNCH(512); else if (H == 256) FE_LAUNCH(256); else if (H == 128) FE_LAUNCH(128); else FE_LAUNCH(64);
+#undef FE_LAUNCH
+#undef FE_LAUNCH2
+#undef FE_COFF
+#undef FE_ROT4
+#undef FE_ROT_ACC
+#undef FE_ROT_D2
+#undef FE_JADDR
+#undef FE_LOFF
+#undef FE_TICK
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -30,24 +30,46 @@ __global__ __launch_bounds__(256) void gcl_pre_kernel(const void* __restrict__ A
 // H = 8 * LPE <= 512: LPE lanes cover one edge with 8 columns each (16-byte bf16 loads and stores), a wave covers
 // 64/LPE edges per pass and GP_PASSES passes with every gather of all passes issued before the first use.
 #define GP_PASSES 4
-template <int LPE>
-__global__ __launch_bounds__(256) void gcl_pre8_kernel(const void* __restrict__ AB, int ab_dt, int ldab,
+template <bool BF16> struct GpRaw;
+template <> struct GpRaw<true> {
+    uint4 u;
+    __device__ __forceinline__ void load(const void* p, size_t i) { u = *(const uint4*)((const bf16_t*)p + i); }
+    __device__ __forceinline__ void get(float* f) const {
+        f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+        f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+        f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+        f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+};
+template <> struct GpRaw<false> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const void* p, size_t i) {
+        a = *(const float4*)((const float*)p + i);
+        b = *(const float4*)((const float*)p + i + 4);
+    }
+    __device__ __forceinline__ void get(float* f) const {
+        f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+    }
+};
+template <int LPE, bool AB16, bool OUT16, bool DACT>
+__global__ __launch_bounds__(256) void gcl_pre8_kernel(const void* __restrict__ AB, int ldab,
                                                        const int* __restrict__ row, const int* __restrict__ col,
                                                        const float* __restrict__ rhohat, const float* __restrict__ w_r,
-                                                       void* pre, int pre_dt, int E, int act, void* dact_out) {
+                                                       void* pre, int E, int act, void* dact_out) {
     constexpr int H = LPE * 8, EPP = 64 / LPE;
+    constexpr int odt = OUT16 ? FB_DT_BF16 : FB_DT_F32;
     const int lane = threadIdx.x & 63, sub = lane / LPE, c = (lane % LPE) * 8;
     const int ebase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (EPP * GP_PASSES) + sub;
     if (ebase - sub >= E) return;
-    F8 va[GP_PASSES], vb[GP_PASSES];
+    GpRaw<AB16> va[GP_PASSES], vb[GP_PASSES];
     float rh[GP_PASSES];
 #pragma unroll
     for (int i = 0; i < GP_PASSES; ++i) {
         const int e = min(ebase + i * EPP, E - 1);
         const int r = row[e], q = col[e];
         rh[i] = rhohat[e];
-        va[i] = ld8_any(AB, ab_dt, (size_t)r * ldab + c);
-        vb[i] = ld8_any(AB, ab_dt, (size_t)q * ldab + H + c);
+        va[i].load(AB, (size_t)r * ldab + c);
+        vb[i].load(AB, (size_t)q * ldab + H + c);
     }
     const float4 w0 = *(const float4*)(w_r + c), w1 = *(const float4*)(w_r + c + 4);
     const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
@@ -55,18 +77,28 @@ __global__ __launch_bounds__(256) void gcl_pre8_kernel(const void* __restrict__ 
     for (int i = 0; i < GP_PASSES; ++i) {
         const int e = ebase + i * EPP;
         if (e < E) {
-            F8 z, y;
+            float fa[8], fb[8];
+            va[i].get(fa);
+            vb[i].get(fb);
+            F8 y, dy;
+            if (act == FB_ACT_SILU) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                z.v[k] = va[i].v[k] + vb[i].v[k] + rh[i] * w[k];
-                y.v[k] = apply_act(z.v[k], act);
-            }
-            st8_any(pre, pre_dt, (size_t)e * H + c, y);
-            if (dact_out) {
+                for (int k = 0; k < 8; ++k) {
+                    const float z = fa[k] + fb[k] + rh[i] * w[k];
+                    const float sg = sigmoid_f(z);
+                    y.v[k] = z * sg;
+                    if (DACT) dy.v[k] = sg * (1.0f + z * (1.0f - sg));
+                }
+            } else {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) y.v[k] = apply_dact(z.v[k], act);
-                st8_any(dact_out, pre_dt, (size_t)e * H + c, y);
+                for (int k = 0; k < 8; ++k) {
+                    const float z = fa[k] + fb[k] + rh[i] * w[k];
+                    y.v[k] = apply_act(z, act);
+                    if (DACT) dy.v[k] = apply_dact(z, act);
+                }
             }
+            st8_any(pre, odt, (size_t)e * H + c, y);
+            if (DACT) st8_any(dact_out, odt, (size_t)e * H + c, dy);
         }
     }
 }
@@ -78,9 +110,22 @@ extern "C" int fabind_gcl_pre(const void* AB, int ab_dt, int ldab, int H, const 
     if (E <= 0) return 0;
     const bool vec8 = ldab % 8 == 0 && ((uintptr_t)AB % 16 == 0) && ((uintptr_t)pre % 16 == 0) &&
                       (!dact_out || (uintptr_t)dact_out % 16 == 0) && ((uintptr_t)w_r % 16 == 0);
+#define GP_LAUNCH4(LPE_, A16_, O16_, D_)                                                                             \
+    hipLaunchKernelGGL((gcl_pre8_kernel<LPE_, A16_, O16_, D_>),                                                      \
+                       dim3((E + 4 * (64 / LPE_) * GP_PASSES - 1) / (4 * (64 / LPE_) * GP_PASSES)), dim3(256), 0, stream, \
+                       AB, ldab, row, col, rhohat, w_r, pre, E, act, dact_out)
 #define GP_LAUNCH(LPE_)                                                                                              \
-    hipLaunchKernelGGL((gcl_pre8_kernel<LPE_>), dim3((E + 4 * (64 / LPE_) * GP_PASSES - 1) / (4 * (64 / LPE_) * GP_PASSES)), \
-                       dim3(256), 0, stream, AB, ab_dt, ldab, row, col, rhohat, w_r, pre, pre_dt, E, act, dact_out)
+    do {                                                                                                             \
+        const bool a16 = ab_dt == FB_DT_BF16, o16 = pre_dt == FB_DT_BF16;                                            \
+        if (a16 && o16 && dact_out) GP_LAUNCH4(LPE_, true, true, true);                                              \
+        else if (a16 && o16) GP_LAUNCH4(LPE_, true, true, false);                                                    \
+        else if (!a16 && o16 && dact_out) GP_LAUNCH4(LPE_, false, true, true);                                       \
+        else if (!a16 && o16) GP_LAUNCH4(LPE_, false, true, false);                                                  \
+        else if (!a16 && !o16 && dact_out) GP_LAUNCH4(LPE_, false, false, true);                                     \
+        else if (!a16 && !o16) GP_LAUNCH4(LPE_, false, false, false);                                                \
+        else if (dact_out) GP_LAUNCH4(LPE_, true, false, true);                                                      \
+        else GP_LAUNCH4(LPE_, true, false, false);                                                                   \
+    } while (0)
     if (vec8 && H == 512) GP_LAUNCH(64);
     else if (vec8 && H == 256) GP_LAUNCH(32);
     else if (vec8 && H == 128) GP_LAUNCH(16);
@@ -89,6 +134,7 @@ extern "C" int fabind_gcl_pre(const void* AB, int ab_dt, int ldab, int H, const 
         hipLaunchKernelGGL(gcl_pre_kernel, dim3((E + 3) / 4), dim3(256), 0, stream, AB, ab_dt, ldab, H, row, col, rhohat,
                            w_r, pre, pre_dt, E, act, dact_out);
 #undef GP_LAUNCH
+#undef GP_LAUNCH4
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -251,12 +251,12 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
     ad = ops.act_dtype()
     fast = _fast(h, x, p["W2"])
     hin = _b16(h) if fast else h
-    if fast and FUSED_EDGE and pdrop == 0.0 and H in (64, 128, 256, 512):
-        # forward-only: the whole edge pipeline in one kernel, edge tensors stay in LDS (csrc/fused_edge.hip)
+    if get_precision() == "bf16" and FUSED_EDGE and pdrop == 0.0 and H in (64, 128, 256, 512):
+        # the whole edge pipeline in one kernel each way, edge tensors stay in LDS (csrc/fused_edge.hip); under
+        # autograd nothing per-edge is saved, the backward kernel recomputes tile by tile
         AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=torch.bfloat16)
         d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
-        agg, s = K.gcl_edge_fused(AB, H, g.row_ctx, g.col_ctx, rhohat, p["w_r"], K.pack_frag(p["W2"]), p["b2"],
-                                  K.pack_frag(p["Wc"]), p["bc"], p["w3"], h.shape[0])
+        agg, s = ops.fused_edge(AB, rhohat, p["w_r"], p["W2"], p["b2"], p["Wc"], p["bc"], p["w3"], H, g)
         x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
         t = ops.linear(hin, p["Wn1"], p["bn1"], x2=agg, act_epi=K.ACT_SILU, out_dtype=ad)
         return ops.linear(t, p["Wn2"], p["bn2"], residual=h), x_new

@@ -257,6 +257,53 @@ def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows)
     return agg, s[:E]
 
 
+_N_CU = {}
+EDGE_BWD_TIMES = None   # set to an int64[12] device tensor to collect per-phase cycle counts (tools/edge_bwd_phases.py)
+
+
+def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, dagg, colptr, perm):
+    """Adjoint of gcl_edge_fused (csrc/fused_edge.hip): returns dAB [N,2H] fp32, drh [E], dw_r, dW2, db2, dWc, dbc, dw3.
+    The five [E,H] bf16 operands it writes (S1, M, dT, dP2 for the weight gradients, dP1 for the sending-side
+    reduction) are scratch that is released on return."""
+    E, N, dev = row.shape[0], AB16.shape[0], AB16.device
+    ng = _N_CU.get(dev)
+    if ng is None:
+        ng = _N_CU[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    bm = _lib.load().fabind_gcl_edge_fused_bwd_tile()
+    ng = max(1, min(ng * (2 if bm == 32 else 1), (E + bm - 1) // bm))
+    buf = torch.empty((5, max(E, 1), H), dtype=torch.bfloat16, device=dev)
+    S1, Mm, dT, dP2, dP1 = buf[0], buf[1], buf[2], buf[3], buf[4]
+    dAB = torch.zeros((N, 2 * H), dtype=torch.float32, device=dev)
+    drh = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+    part = torch.zeros((ng, 4, H), dtype=torch.float32, device=dev)
+    dagg = dagg.contiguous()
+    ds = ds.contiguous()
+    a = _lib.EdgeBwdArgs()
+    W2p, Wcp, W2Tp, WcTp = pack_frag(W2), pack_frag(Wc), pack_frag(W2.t()), pack_frag(Wc.t())
+    keep = (W2p, Wcp, W2Tp, WcTp)
+    for name, t in (("AB", AB16), ("row", row), ("col", col), ("rhohat", rhohat), ("w_r", w_r), ("W2p", W2p), ("Wcp", Wcp),
+                    ("W2Tp", W2Tp), ("WcTp", WcTp), ("b2", b2), ("bc", bc), ("w3", w3), ("ds", ds), ("dagg", dagg),
+                    ("S1", S1), ("Mm", Mm), ("dT", dT), ("dP2", dP2), ("dP1", dP1), ("drh", drh), ("dABrow", dAB),
+                    ("part", part)):
+        setattr(a, name, ptr(t))
+    a.ldab, a.lddagg, a.lddab, a.E = _ld(AB16), _ld(dagg), _ld(dAB), E
+    a.dbg = ptr(EDGE_BWD_TIMES) if EDGE_BWD_TIMES is not None else None
+    _profiled("gcl_edge_fused_bwd_kernel<%d> E=%d (recompute + 4 chained H x H contractions per edge)" % (H, E),
+              8.0 * E * H * H,
+              lambda: check(_lib.load().fabind_gcl_edge_fused_bwd(ctypes.byref(a), H, ng, stream()),
+                            "fabind_gcl_edge_fused_bwd"))
+    del keep
+    if E > 0:
+        segment_sum(dP1[:E], colptr, N, eidx=perm, out=dAB[:, H:])
+        dW2 = gemm_tn(dP2[:E], S1[:E])
+        dWc = gemm_tn(dT[:E], Mm[:E])
+    else:
+        dW2 = torch.zeros((H, H), dtype=torch.float32, device=dev)
+        dWc = torch.zeros((H, H), dtype=torch.float32, device=dev)
+    ps = part.sum(0)
+    return dAB, drh[:E], ps[3], dW2, ps[0], dWc, ps[1], ps[2]
+
+
 _ZERO_PAGE = {}
 
 

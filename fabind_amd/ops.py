@@ -259,6 +259,41 @@ def edge_tail(Mm, Wc, bc, w3, rowptr, row, n_rows, act_epi=K.ACT_SILU):
     return part, K.segment_sum(Mm, rowptr, n_rows)
 
 
+class _FusedEdge(torch.autograd.Function):
+    """Whole intra-graph edge pipeline of MC_E_GCL as one kernel each way (csrc/fused_edge.hip): the forward keeps
+    no per-edge tensor, the backward recomputes them tile by tile in LDS."""
+
+    @staticmethod
+    def forward(ctx, AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g):
+        ctx.H, ctx.g = H, g
+        ctx.save_for_backward(AB16, rhohat, w_r, W2, b2, Wc, bc, w3)
+        agg, s = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3,
+                                  AB16.shape[0])
+        return agg, s
+
+    @staticmethod
+    def backward(ctx, dagg, ds):
+        AB16, rhohat, w_r, W2, b2, Wc, bc, w3 = ctx.saved_tensors
+        g = ctx.g
+        colptr, perm = g.ctx_by_col()
+        if dagg is None:
+            dagg = torch.zeros((AB16.shape[0], ctx.H), dtype=torch.float32, device=AB16.device)
+        if ds is None:
+            ds = torch.zeros(g.row_ctx.shape[0], dtype=torch.float32, device=AB16.device)
+        dAB, drh, dwr, dW2, db2, dWc, dbc, dw3 = K.gcl_edge_fused_bwd(
+            AB16, ctx.H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, ds.reshape(-1).float(), dagg.float(),
+            colptr, perm)
+        return (dAB.to(AB16.dtype), drh, dwr, dW2.to(W2.dtype), db2, dWc.to(Wc.dtype), dbc, dw3, None, None)
+
+
+def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g):
+    """(agg [N,H], s [E,1]) of the fused bf16 edge pipeline; differentiable."""
+    if _needs_grad(AB16, rhohat, w_r, W2, b2, Wc, bc, w3):
+        return _FusedEdge.apply(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g)
+    return K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3,
+                            AB16.shape[0])
+
+
 # ------------------------------------------------------------------------------------------------
 # geometry / gathers / segmented reductions
 # ------------------------------------------------------------------------------------------------

@@ -144,6 +144,28 @@ int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int* row, const
                           const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
                           const float* w3, int E, float* agg, float* s_out, hipStream_t stream);
 
+/* Backward of the fused edge pipeline (training, bf16): recomputes the forward per 64-edge tile and chains the four
+ * H x H contractions of the adjoint (autograd of models/egnn.py:68-128).  Inputs: the forward's operands, ds [E]
+ * (gradient of s), dagg [n_rows, lddagg] fp32 (gradient of agg); W2p/Wcp = fragment-packed W2 / Wc, W2Tp/WcTp =
+ * fragment-packed W2^T / Wc^T.  Outputs: S1, Mm, dT, dP2 [E,H] bf16 = operands of the weight gradients
+ * (dW2 = dP2^T S1, dWc = dT^T Mm via fabind_gemm_tn), dP1 [E,H] bf16 (gradient at the first Linear's output; the
+ * caller reduces it over the sending node), drh [E], dABrow [n_rows, lddab] fp32 (zero-initialised by the caller:
+ * receiving-side segment sum of dP1) and part [n_groups][4][H] fp32 partial column sums {d b2, d bc, d w3, d w_r}
+ * (the caller adds the n_groups rows).  n_groups = number of persistent work-groups (<= number of CUs). */
+typedef struct FabindEdgeBwdArgs {
+    const void* AB; const int* row; const int* col; const float* rhohat; const float* w_r;
+    const void* W2p; const void* Wcp; const void* W2Tp; const void* WcTp;
+    const float* b2; const float* bc; const float* w3; const float* ds; const float* dagg;
+    void* S1; void* Mm; void* dT; void* dP2; void* dP1;
+    float* drh; float* dABrow; float* part;
+    void* dbg;               /* NULL, or 12 x int64: cycle counts per phase of work-group 0 (profiling aid) */
+    int ldab, lddagg, lddab, E;
+} FabindEdgeBwdArgs;
+int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* args, int H, int n_groups, hipStream_t stream);
+/* Edges per tile of the backward kernel: 32 (two work-groups per CU, default) or 64 (one per CU). */
+int fabind_gcl_edge_fused_bwd_set_tile(int bm);
+int fabind_gcl_edge_fused_bwd_tile(void);
+
 /* ---------------------------------------------------------------------------------------------
  * Cross attention (RowAttentionBlock / Attention._attention, models/cross_att.py:118-134,
  * models/model_utils.py:21-38,96-133).  Ragged: no padding, so the -1e9 mask bias never applies.

@@ -85,6 +85,55 @@ def test_segment_sum_and_scan():
         assert (out.cpu() - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max())
 
 
+@pytest.mark.parametrize("bm", [32, 64])
+@pytest.mark.parametrize("H", [64, 128, 512])
+def test_fused_edge_backward_matches_autograd(H, bm):
+    """csrc/fused_edge.hip backward (recompute + 4 chained contractions) vs torch autograd of the same bf16-rounded
+    forward on the CPU: every gradient the kernel produces, including the partial column sums and both halves of dAB."""
+    from fabind_amd import kernels as K, _lib
+    dev = _dev()
+    _lib.load().fabind_gcl_edge_fused_bwd_set_tile(bm)
+    g = torch.Generator().manual_seed(100 + H)
+    N = 300
+    deg = torch.randint(0, 12, (N,), generator=g)
+    deg[7] = 333
+    deg[250:] = 0
+    row = torch.repeat_interleave(torch.arange(N), deg)
+    E = row.shape[0]
+    col = torch.randint(0, N, (E,), generator=g)
+    AB16 = torch.randn(N, 2 * H, generator=g).bfloat16()
+    rh = torch.rand(E, generator=g)
+    w_r, b2, bc, w3 = [torch.randn(H, generator=g) * 0.5 for _ in range(4)]
+    W2 = (torch.randn(H, H, generator=g) / H ** 0.5).bfloat16()
+    Wc = (torch.randn(H, H, generator=g) / H ** 0.5).bfloat16()
+    ds = torch.randn(E, generator=g)
+    dagg = torch.randn(N, H, generator=g)
+    silu = torch.nn.functional.silu
+    leaf = lambda t: t.float().clone().requires_grad_(True)
+    ABf, rhf, wrf, W2f, b2f, Wcf, bcf, w3f = map(leaf, (AB16, rh, w_r, W2, b2, Wc, bc, w3))
+    rb = lambda t: t + (t.bfloat16().float() - t).detach()           # bf16 rounding, straight-through
+    S1 = rb(silu(ABf[row, :H] + ABf[col, H:] + rhf[:, None] * wrf))
+    M = rb(silu(S1 @ W2f.T + b2f))
+    agg = torch.zeros(N, H).index_add(0, row, M)
+    sv = (silu(M @ Wcf.T + bcf) * w3f).sum(1)
+    ((agg * dagg).sum() + (sv * ds).sum()).backward()
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    colsorted, perm = torch.sort(col, stable=True)
+    colptr = torch.zeros(N + 1, dtype=torch.int32)
+    colptr[1:] = torch.cumsum(torch.bincount(colsorted, minlength=N), 0)
+    out = K.gcl_edge_fused_bwd(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev),
+                               Wc.to(dev), bc.to(dev), w3.to(dev), ds.to(dev), dagg.to(dev), colptr.to(dev), i32(perm))
+    _lib.load().fabind_gcl_edge_fused_bwd_set_tile(32)
+    names = ("dAB", "drh", "dw_r", "dW2", "db2", "dWc", "dbc", "dw3")
+    refs = (ABf.grad, rhf.grad, wrf.grad, W2f.grad, b2f.grad, Wcf.grad, bcf.grad, w3f.grad)
+    for name, got, ref in zip(names, out, refs):
+        err = (got.float().cpu() - ref).abs().max().item()
+        scale = max(1.0, ref.abs().max().item())
+        assert err <= 3e-2 * scale, (name, err, scale)
+        rel = ((got.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-6)).item()
+        assert rel <= 2e-2, (name, rel)
+
+
 @pytest.mark.parametrize("H", [36, 64, 128, 512, 640])
 @pytest.mark.parametrize("ab_dtype", [torch.float32, torch.bfloat16])
 def test_gcl_pre_gather(H, ab_dtype):
