@@ -318,6 +318,29 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
     }
     float pb2[4] = {0.f, 0.f, 0.f, 0.f}, pbc[4] = {0.f, 0.f, 0.f, 0.f}, pw3[4] = {0.f, 0.f, 0.f, 0.f}, pwr = 0.f;
 
+    // Gathered AB rows are prefetched into registers one phase ahead of their use: the rows of the NEXT tile while
+    // this tile finishes (dP1 store + P6), and this tile's rows again (for silu'(pre1)) while contraction 4 runs.
+    uint4 pfa[CPT], pfb[CPT];
+    const unsigned uld = (unsigned)p.ldab;
+    auto fe_prefetch = [&](unsigned r, unsigned c) {
+        const unsigned aoff = r * uld + cth * (CPT * 8), boff = c * uld + H + cth * (CPT * 8);
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) {
+            pfa[q] = *(const uint4*)(AB + (aoff + q * 8));
+            pfb[q] = *(const uint4*)(AB + (boff + q * 8));
+        }
+    };
+    unsigned ur = 0, uc = 0;                                      // this lane's edge of the current tile
+    if ((int)blockIdx.x < n_tiles) {
+        const int e0 = blockIdx.x * BM;
+        if (el < min(BM, p.E - e0)) {
+            ur = (unsigned)(p.row + e0)[(unsigned)el];
+            uc = (unsigned)(p.col + e0)[(unsigned)el];
+        }
+    }
+    fe_prefetch(ur, uc);                                          // unconditional (row 0 for idle lanes): a guarded
+                                                                  // load would keep the old registers live instead
+
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int e0 = tile * BM;
         const int ne = min(BM, p.E - e0);
@@ -341,23 +364,28 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
         const int* gcol = p.col + e0;
         const float* grh = p.rhohat + e0;
         const float* gds = p.ds + e0;
-        const unsigned uld = (unsigned)p.ldab;
         if (tid < BM) {
             const bool ok = tid < ne;
             sRow[tid] = ok ? grow[(unsigned)tid] : -1;
             sDs[tid] = ok ? gds[(unsigned)tid] : 0.f;
             sRh[tid] = ok ? grh[(unsigned)tid] : 0.f;
         }
+        // indices of this lane's edge in the next tile (their rows are fetched after P5)
+        unsigned nr = 0, nc = 0;
+        const int e0n = e0 + (int)gridDim.x * BM;
+        const bool has_next = tile + (int)gridDim.x < n_tiles && el < min(BM, p.E - e0n);
+        if (has_next) {
+            nr = (unsigned)(p.row + e0n)[(unsigned)el];
+            nc = (unsigned)(p.col + e0n)[(unsigned)el];
+        }
         if (el < ne) {
-            const unsigned r = (unsigned)grow[(unsigned)el], c = (unsigned)gcol[(unsigned)el];
             const float rh = grh[(unsigned)el];
-            const unsigned aoff = r * uld + cth * (CPT * 8), boff = c * uld + H + cth * (CPT * 8);
             const float* wp = w_r + (unsigned)(cth * (CPT * 8));
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
                 float fa[8], fb[8], o[8];
-                unpack8(*(const uint4*)(AB + (aoff + q * 8)), fa);
-                unpack8(*(const uint4*)(AB + (boff + q * 8)), fb);
+                unpack8(pfa[q], fa);
+                unpack8(pfb[q], fb);
                 const float4 w0 = *(const float4*)(wp + q * 8), w1 = *(const float4*)(wp + q * 8 + 4);
                 const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
@@ -487,7 +515,8 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
         fe_tile_store<H>(sY, (bf16_t*)p.dP2, e0, ne, tid);
         FE_TICK(1)
 
-        // ---- P4: dS1 = dP2 W2 -> sX
+        // ---- P4: dS1 = dP2 W2 -> sX   (this tile's AB rows are fetched again underneath it, for P5)
+        fe_prefetch(ur, uc);
         fe_zero(acc);
         fe_gemm_rolled<H, MI>(sY, W2Tp, wave, lane, acc);
         FE_TICK(2)
@@ -505,16 +534,14 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
 
         // ---- P5 (gather layout): dP1 = dS1 * silu'(pre1) in place;  d rhohat = dP1 . w_r
         if (el < ne) {
-            const unsigned r = (unsigned)sRow[el], c = (unsigned)gcol[(unsigned)el];
             const float rh = sRh[el];
-            const unsigned aoff = r * uld + cth * (CPT * 8), boff = c * uld + H + cth * (CPT * 8);
             const float* wp = w_r + (unsigned)(cth * (CPT * 8));
             float dot = 0.f;
 #pragma unroll
             for (int q = 0; q < CPT; ++q) {
                 float fa[8], fb[8], g[8];
-                unpack8(*(const uint4*)(AB + (aoff + q * 8)), fa);
-                unpack8(*(const uint4*)(AB + (boff + q * 8)), fb);
+                unpack8(pfa[q], fa);
+                unpack8(pfb[q], fb);
                 uint4* sp = (uint4*)&sX[el * H + (((cth * CPT + q) ^ (el & 7)) * 8)];
                 unpack8(*sp, g);
                 const float4 w0 = *(const float4*)(wp + q * 8), w1 = *(const float4*)(wp + q * 8 + 4);
@@ -531,27 +558,42 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
             for (int o = 1; o < TPE; o <<= 1) dot += __shfl_xor(dot, o, 64);
             if (cth == 0) (p.drh + e0)[(unsigned)el] = dot;
         }
+        ur = nr; uc = nc;
+        fe_prefetch(ur, uc);
         __syncthreads();
         FE_TICK(8)
         fe_tile_store<H>(sX, (bf16_t*)p.dP1, e0, ne, tid);
         FE_TICK(1)
 
-        // ---- P6 (one column per thread): receiving-side segment sum of dP1 and the d w_r column sum
+        // ---- P6 (one column per thread): receiving-side segment sum of dP1 and the d w_r column sum;
+        //      LDS reads batched 8 rows at a time, the run logic consumes them from registers
         {
             const int c = tid;
             float run = 0.f;
             int cur = sRow[0];
             bool first = true;
-            for (int rw = 0; rw < ne; ++rw) {
-                const int rr = sRow[rw];
-                if (rr != cur) {
-                    const unsigned o = (unsigned)cur * (unsigned)p.lddab + c;
-                    if (first) atomicAdd(&p.dABrow[o], run); else p.dABrow[o] = run;
-                    run = 0.f; cur = rr; first = false;
+            for (int rw0 = 0; rw0 < ne; rw0 += 8) {
+                int rr[8];
+                float v[8], rhv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int rw = rw0 + u;                       // < BM: BM is a multiple of 8
+                    rr[u] = sRow[rw];
+                    rhv[u] = sRh[rw];
+                    v[u] = bf16_to_f32(sX[rw * H + (((c >> 3) ^ (rw & 7)) * 8) + (c & 7)]);
                 }
-                const float v = bf16_to_f32(sX[rw * H + (((c >> 3) ^ (rw & 7)) * 8) + (c & 7)]);
-                run += v;
-                pwr += sRh[rw] * v;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (rw0 + u < ne) {
+                        if (rr[u] != cur) {
+                            const unsigned o = (unsigned)cur * (unsigned)p.lddab + c;
+                            if (first) atomicAdd(&p.dABrow[o], run); else p.dABrow[o] = run;
+                            run = 0.f; cur = rr[u]; first = false;
+                        }
+                        run += v[u];
+                        pwr += rhv[u] * v[u];
+                    }
+                }
             }
             if (ne > 0) atomicAdd(&p.dABrow[(unsigned)cur * (unsigned)p.lddab + c], run);
         }
@@ -577,7 +619,7 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
     part[3 * H + tid] = pwr;
 }
 
-static int g_fe_bwd_bm = 32;
+static int g_fe_bwd_bm = 64;
 extern "C" int fabind_gcl_edge_fused_bwd_set_tile(int bm) {
     FB_REQUIRE(bm == 32 || bm == 64, "fabind_gcl_edge_fused_bwd_set_tile: 32 or 64 edges per tile");
     g_fe_bwd_bm = bm;

@@ -162,7 +162,7 @@ typedef struct FabindEdgeBwdArgs {
     int ldab, lddagg, lddab, E;
 } FabindEdgeBwdArgs;
 int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* args, int H, int n_groups, hipStream_t stream);
-/* Edges per tile of the backward kernel: 32 (two work-groups per CU, default) or 64 (one per CU). */
+/* Edges per tile of the backward kernel: 64 (one work-group per CU, default) or 32 (two per CU). */
 int fabind_gcl_edge_fused_bwd_set_tile(int bm);
 int fabind_gcl_edge_fused_bwd_tile(void);
 

@@ -123,7 +123,7 @@ def test_fused_edge_backward_matches_autograd(H, bm):
     colptr[1:] = torch.cumsum(torch.bincount(colsorted, minlength=N), 0)
     out = K.gcl_edge_fused_bwd(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev),
                                Wc.to(dev), bc.to(dev), w3.to(dev), ds.to(dev), dagg.to(dev), colptr.to(dev), i32(perm))
-    _lib.load().fabind_gcl_edge_fused_bwd_set_tile(32)
+    _lib.load().fabind_gcl_edge_fused_bwd_set_tile(64)
     names = ("dAB", "drh", "dw_r", "dW2", "db2", "dWc", "dbc", "dw3")
     refs = (ABf.grad, rhf.grad, wrf.grad, W2f.grad, b2f.grad, Wcf.grad, bcf.grad, w3f.grad)
     for name, got, ref in zip(names, out, refs):
