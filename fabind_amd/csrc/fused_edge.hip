@@ -19,6 +19,18 @@
 __device__ __forceinline__ float fe_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
 __device__ __forceinline__ float fe_silu(float x) { return x * fe_sigmoid(x); }
 
+// Counter-based dropout mask of the messages (train mode, egnn.py:82): one 32-bit hash per (edge pair, column)
+// gives two 16-bit uniforms, element (e, c) is kept iff its half is >= thr16 = round(p * 65536).  Forward and
+// backward kernels (and tests/helpers.py) evaluate the same function, nothing is stored.
+__device__ __forceinline__ uint32_t fe_hash(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float fe_keep(uint32_t seed, uint32_t e, uint32_t c, uint32_t H, uint32_t thr16, float scale) {
+    const uint32_t h = fe_hash(seed + (e >> 1) * H + c);
+    return (((e & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr16) ? scale : 0.f;
+}
+
 __device__ __forceinline__ void unpack8(const uint4 u, float* f) {
     f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
     f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
@@ -113,7 +125,8 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
                                                            const float* __restrict__ w_r, const bf16_t* __restrict__ W2p,
                                                            const float* __restrict__ b2, const bf16_t* __restrict__ Wcp,
                                                            const float* __restrict__ bc, const float* __restrict__ w3, int E,
-                                                           float* agg, float* s_out) {
+                                                           float* agg, float* s_out, uint32_t thr16, float dscale,
+                                                           uint32_t seed) {
     constexpr int NW = H / 64;                      // waves; wave w owns output columns [64w, 64w+64)
     constexpr int CPT = FE_BM * H / H;              // gather: elements per thread = 64 (one 64-column chunk of one edge)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
             const bf16_t* ap = AB + (size_t)r * ldab + c64 * 64;
             const bf16_t* bp = AB + (size_t)c * ldab + H + c64 * 64;
             const float* wp = w_r + c64 * 64;
-#pragma unroll
+#pragma unroll 4
             for (int q = 0; q < 8; ++q) {
                 float fa[8], fb[8], o[8];
                 unpack8(*(const uint4*)(ap + q * 8), fa);
@@ -161,20 +174,31 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    fe_gemm<H>(sX, W2p, wave, lane, acc);
+    fe_gemm_rolled<H, 4>(sX, W2p, wave, lane, acc);
     __syncthreads();                                // every wave has finished reading S1
     const int fr = lane & 15, cq = lane >> 4;
+    // rolled over the wave's four 16-column blocks (slot 0 processed, arrays rotate): bounds the live ranges
+#define FE_ROT4(a_) { auto t_ = a_[0]; a_[0] = a_[1]; a_[1] = a_[2]; a_[2] = a_[3]; a_[3] = t_; }
+    {
+        float bj[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int colj = wave * 64 + j * 16 + fr;
-        const float bj = b2[colj];
+        for (int j = 0; j < 4; ++j) bj[j] = b2[wave * 64 + j * 16 + fr];
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            const int colj = wave * 64 + j * 16 + fr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rw = i * 16 + cq * 4 + r;
-                sX[rw * H + (((colj >> 3) ^ (rw & 7)) * 8) + (colj & 7)] = f32_to_bf16(fe_silu(acc[i][j][r] + bj));
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int rw = i * 16 + cq * 4 + r;
+                    float m = fe_silu(acc[i][0][r] + bj[0]);
+                    if (thr16) m *= fe_keep(seed, (uint32_t)(e0 + rw), (uint32_t)colj, H, thr16, dscale);
+                    sX[rw * H + (((colj >> 3) ^ (rw & 7)) * 8) + (colj & 7)] = f32_to_bf16(m);
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) FE_ROT4(acc[i])
+            FE_ROT4(bj)
+        }
     }
     __syncthreads();
 
@@ -201,24 +225,35 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    fe_gemm<H>(sX, Wcp, wave, lane, acc);
+    fe_gemm_rolled<H, 4>(sX, Wcp, wave, lane, acc);
+    {
+        float dsum[4][4], bj[4], wj[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float ds[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
+            for (int r = 0; r < 4; ++r) dsum[i][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { bj[j] = bc[wave * 64 + j * 16 + fr]; wj[j] = w3[wave * 64 + j * 16 + fr]; }
+#pragma unroll 1
         for (int j = 0; j < 4; ++j) {
-            const int colj = wave * 64 + j * 16 + fr;
-            const float bj = bc[colj], wj = w3[colj];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ds[r] += fe_silu(acc[i][j][r] + bj) * wj;
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsum[i][r] += fe_silu(acc[i][0][r] + bj[0]) * wj[0];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) FE_ROT4(acc[i])
+            FE_ROT4(bj) FE_ROT4(wj)
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float t = ds[r];
-            t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
-            if (fr == 0) sDot[wave * FE_BM + i * 16 + cq * 4 + r] = t;
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = dsum[i][r];
+                t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+                if (fr == 0) sDot[wave * FE_BM + i * 16 + cq * 4 + r] = t;
+            }
     }
+#undef FE_ROT4
     __syncthreads();
     if (tid < ne) {
         float s = 0.f;
@@ -230,8 +265,12 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
 
 extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
                                      const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
-                                     const float* w3, int E, float* agg, float* s_out, hipStream_t stream) {
+                                     const float* w3, int E, float* agg, float* s_out, float p_drop, unsigned seed,
+                                     hipStream_t stream) {
     if (E <= 0) return 0;
+    FB_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "fabind_gcl_edge_fused: p_drop in [0, 1)");
+    const uint32_t thr16 = (uint32_t)(p_drop * 65536.0f + 0.5f);
+    const float dscale = 1.0f / (1.0f - (float)thr16 / 65536.0f);
     FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_gcl_edge_fused: H must be 64, 128, 256 or 512");
     FB_REQUIRE(ldab % 8 == 0, "fabind_gcl_edge_fused: ldab % 8");
     const dim3 grid((E + FE_BM - 1) / FE_BM);
@@ -241,7 +280,8 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
         static bool set_ = false;                                                                                  \
         if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
         hipLaunchKernelGGL((gcl_edge_fused_kernel<HH>), grid, dim3(HH), lds, stream, (const bf16_t*)AB, ldab, row, col, rhohat, \
-                           w_r, (const bf16_t*)W2p, b2, (const bf16_t*)Wcp, bc, w3, E, agg, s_out);                 \
+                           w_r, (const bf16_t*)W2p, b2, (const bf16_t*)Wcp, bc, w3, E, agg, s_out, thr16, dscale, \
+                           (uint32_t)seed);                                                                        \
     } while (0)
     if (H == 512) FE_LAUNCH(512); else if (H == 256) FE_LAUNCH(256); else if (H == 128) FE_LAUNCH(128); else FE_LAUNCH(64);
 #undef FE_LAUNCH
@@ -298,6 +338,8 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
     const int fr = lane & 15, cq = lane >> 4;
     const int el = tid / TPE, cth = tid % TPE;
     const int n_tiles = (p.E + BM - 1) / BM;
+    const uint32_t thr16 = (uint32_t)(p.p_drop * 65536.0f + 0.5f);
+    const float dscale = 1.0f / (1.0f - (float)thr16 / 65536.0f);
     // LDS element offset of C-fragment element (i, j, r) of this lane in a swizzled [64][H] tile, as one of four
     // lane-dependent bases plus a compile-time constant (so the 64 stores of an epilogue need 4 address registers):
     //   row = i*16 + cq*4 + r, col = wave*64 + j*16 + fr, chunk = (col>>3) ^ (row&7); bit0 flips with r&1, bit2 with j>>1
@@ -433,8 +475,12 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float z = acc[i][0][r] + bj[0], sg = fe_sigmoid(z);
-                        dd[r] = sg * (1.0f + z * (1.0f - sg));
-                        sY[FE_LOFF(i, r)] = f32_to_bf16(z * sg);
+                        float kp = 1.0f;
+                        if (thr16)
+                            kp = fe_keep(p.seed, (uint32_t)(e0 + i * 16 + cq * 4 + r), (uint32_t)(wave * 64 + j * 16 + fr), H,
+                                         thr16, dscale);
+                        dd[r] = kp * (sg * (1.0f + z * (1.0f - sg)));
+                        sY[FE_LOFF(i, r)] = f32_to_bf16(kp * (z * sg));
                     }
                     d2a[i][0] = pack2_bf16(dd[0], dd[1]);
                     d2b[i][0] = pack2_bf16(dd[2], dd[3]);
@@ -631,6 +677,7 @@ extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a, int H, int 
     if (a->E <= 0 || n_groups <= 0) return 0;
     FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_gcl_edge_fused_bwd: H must be 64, 128, 256 or 512");
     FB_REQUIRE(a->ldab % 8 == 0, "fabind_gcl_edge_fused_bwd: ldab % 8");
+    FB_REQUIRE(a->p_drop >= 0.f && a->p_drop < 1.f, "fabind_gcl_edge_fused_bwd: p_drop in [0, 1)");
     const int BMr = g_fe_bwd_bm;
     const size_t lds = (size_t)2 * BMr * H * 2 + BMr * (sizeof(int) + 2 * sizeof(float));
 #define FE_LAUNCH2(HH, BB)                                                                                         \

@@ -251,14 +251,17 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
     ad = ops.act_dtype()
     fast = _fast(h, x, p["W2"])
     hin = _b16(h) if fast else h
-    if get_precision() == "bf16" and FUSED_EDGE and pdrop == 0.0 and H in (64, 128, 256, 512):
+    if get_precision() == "bf16" and FUSED_EDGE and H in (64, 128, 256, 512):
         # the whole edge pipeline in one kernel each way, edge tensors stay in LDS (csrc/fused_edge.hip); under
-        # autograd nothing per-edge is saved, the backward kernel recomputes tile by tile
+        # autograd nothing per-edge is saved, the backward kernel recomputes tile by tile.  Train-mode dropout on the
+        # messages is a counter-based mask evaluated inside both kernels.
         AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=torch.bfloat16)
         d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
-        agg, s = ops.fused_edge(AB, rhohat, p["w_r"], p["W2"], p["b2"], p["Wc"], p["bc"], p["w3"], H, g)
+        agg, s = ops.fused_edge(AB, rhohat, p["w_r"], p["W2"], p["b2"], p["Wc"], p["bc"], p["w3"], H, g, pdrop)
         x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
         t = ops.linear(hin, p["Wn1"], p["bn1"], x2=agg, act_epi=K.ACT_SILU, out_dtype=ad)
+        if pdrop > 0.0:
+            return h + _drop(ops.linear(t, p["Wn2"], p["bn2"]), pdrop), x_new
         return ops.linear(t, p["Wn2"], p["bn2"], residual=h), x_new
     AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=ad)                           # [N,2H] node-level
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)

@@ -246,14 +246,15 @@ def pack_frag(W):
     return W.to(torch.bfloat16).view(N // 16, 16, Kd // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
 
 
-def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows):
+def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows, p_drop=0.0, seed=0):
     E = row.shape[0]
     agg = torch.zeros((n_rows, H), dtype=torch.float32, device=AB16.device)
     s = torch.empty((max(E, 1), 1), dtype=torch.float32, device=AB16.device)
     _profiled("gcl_edge_fused_kernel<%d> E=%d (gather + 2 chained H x H contractions + segment-sum per edge)" % (H, E), 4.0 * E * H * H,
               lambda: check(_lib.load().fabind_gcl_edge_fused(ptr(AB16), _ld(AB16), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
                                                               ptr(W2p), ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s),
-                                                              stream()), "fabind_gcl_edge_fused"))
+                                                              float(p_drop), int(seed) & 0xFFFFFFFF, stream()),
+                            "fabind_gcl_edge_fused"))
     return agg, s[:E]
 
 
@@ -261,7 +262,8 @@ _N_CU = {}
 EDGE_BWD_TIMES = None   # set to an int64[12] device tensor to collect per-phase cycle counts (tools/edge_bwd_phases.py)
 
 
-def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, dagg, colptr, perm):
+def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, dagg, colptr, perm, p_drop=0.0, seed=0,
+                       want_edges=False):
     """Adjoint of gcl_edge_fused (csrc/fused_edge.hip): returns dAB [N,2H] fp32, drh [E], dw_r, dW2, db2, dWc, dbc, dw3.
     The five [E,H] bf16 operands it writes (S1, M, dT, dP2 for the weight gradients, dP1 for the sending-side
     reduction) are scratch that is released on return."""
@@ -287,6 +289,7 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
                     ("part", part)):
         setattr(a, name, ptr(t))
     a.ldab, a.lddagg, a.lddab, a.E = _ld(AB16), _ld(dagg), _ld(dAB), E
+    a.p_drop, a.seed = float(p_drop), int(seed) & 0xFFFFFFFF
     a.dbg = ptr(EDGE_BWD_TIMES) if EDGE_BWD_TIMES is not None else None
     _profiled("gcl_edge_fused_bwd_kernel<%d> E=%d (recompute + 4 chained H x H contractions per edge)" % (H, E),
               8.0 * E * H * H,
@@ -301,7 +304,8 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
         dW2 = torch.zeros((H, H), dtype=torch.float32, device=dev)
         dWc = torch.zeros((H, H), dtype=torch.float32, device=dev)
     ps = part.sum(0)
-    return dAB, drh[:E], ps[3], dW2, ps[0], dWc, ps[1], ps[2]
+    out = (dAB, drh[:E], ps[3], dW2, ps[0], dWc, ps[1], ps[2])
+    return out + (Mm[:E].clone(),) if want_edges else out
 
 
 _ZERO_PAGE = {}

@@ -264,11 +264,11 @@ class _FusedEdge(torch.autograd.Function):
     no per-edge tensor, the backward recomputes them tile by tile in LDS."""
 
     @staticmethod
-    def forward(ctx, AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g):
-        ctx.H, ctx.g = H, g
+    def forward(ctx, AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed):
+        ctx.H, ctx.g, ctx.p_drop, ctx.seed = H, g, p_drop, seed
         ctx.save_for_backward(AB16, rhohat, w_r, W2, b2, Wc, bc, w3)
         agg, s = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3,
-                                  AB16.shape[0])
+                                  AB16.shape[0], p_drop, seed)
         return agg, s
 
     @staticmethod
@@ -282,16 +282,18 @@ class _FusedEdge(torch.autograd.Function):
             ds = torch.zeros(g.row_ctx.shape[0], dtype=torch.float32, device=AB16.device)
         dAB, drh, dwr, dW2, db2, dWc, dbc, dw3 = K.gcl_edge_fused_bwd(
             AB16, ctx.H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, ds.reshape(-1).float(), dagg.float(),
-            colptr, perm)
-        return (dAB.to(AB16.dtype), drh, dwr, dW2.to(W2.dtype), db2, dWc.to(Wc.dtype), dbc, dw3, None, None)
+            colptr, perm, ctx.p_drop, ctx.seed)
+        return (dAB.to(AB16.dtype), drh, dwr, dW2.to(W2.dtype), db2, dWc.to(Wc.dtype), dbc, dw3, None, None, None, None)
 
 
-def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g):
-    """(agg [N,H], s [E,1]) of the fused bf16 edge pipeline; differentiable."""
+def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop=0.0):
+    """(agg [N,H], s [E,1]) of the fused bf16 edge pipeline; differentiable.  p_drop > 0: dropout on the messages
+    (egnn.py:82) from a counter-based mask keyed by a seed drawn from torch's CPU generator (no device sync)."""
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
     if _needs_grad(AB16, rhohat, w_r, W2, b2, Wc, bc, w3):
-        return _FusedEdge.apply(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g)
+        return _FusedEdge.apply(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed)
     return K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3,
-                            AB16.shape[0])
+                            AB16.shape[0], p_drop, seed)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -139,10 +139,14 @@ int fabind_coord_update(const float* x, const float* d, const float* s_part, int
 /* Fused forward edge pipeline of MC_E_GCL (models/egnn.py:68-128) for 64-edge tiles, bf16:
  *   s_out[e] = w3 . silu( silu( silu(A[row]+Bc[col]+rhohat*w_r) W2^T + b2 ) Wc^T + bc ),  agg[row] += silu(.. W2^T + b2)
  * AB = bf16 [N, 2H] (A | Bc); W2p / Wcp = bf16 weights packed in MFMA fragment order [H/32][H/16][4][16][8];
- * agg must be zero-initialised (float atomics per row run).  H in {64,128,256,512}. */
+ * agg must be zero-initialised (float atomics per row run).  H in {64,128,256,512}.
+ * p_drop > 0 (train mode, egnn.py:82): the messages are multiplied by keep(e,c)/(1-p) before both consumers, with
+ *   keep(e,c) = [ half_{e&1}( hash32(seed + (e>>1)*H + c) ) >= round(p*65536) ],
+ *   hash32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16   (evaluated again by the backward). */
 int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
                           const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
-                          const float* w3, int E, float* agg, float* s_out, hipStream_t stream);
+                          const float* w3, int E, float* agg, float* s_out, float p_drop, unsigned seed,
+                          hipStream_t stream);
 
 /* Backward of the fused edge pipeline (training, bf16): recomputes the forward per 64-edge tile and chains the four
  * H x H contractions of the adjoint (autograd of models/egnn.py:68-128).  Inputs: the forward's operands, ds [E]
@@ -160,6 +164,8 @@ typedef struct FabindEdgeBwdArgs {
     float* drh; float* dABrow; float* part;
     void* dbg;               /* NULL, or 12 x int64: cycle counts per phase of work-group 0 (profiling aid) */
     int ldab, lddagg, lddab, E;
+    float p_drop;            /* dropout probability of the messages (egnn.py:82); 0 = eval */
+    unsigned seed;           /* the seed the forward call used */
 } FabindEdgeBwdArgs;
 int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* args, int H, int n_groups, hipStream_t stream);
 /* Edges per tile of the backward kernel: 64 (one work-group per CU, default) or 32 (two per CU). */

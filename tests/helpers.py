@@ -44,3 +44,19 @@ def hetero_from_npz(g):
 
 def rmsd(a, b):
     return float(np.sqrt(((np.asarray(a) - np.asarray(b)) ** 2).sum(-1).mean()))
+
+
+def fused_edge_keep_mask(seed, E, H, p_drop):
+    """The counter-based dropout mask of csrc/fused_edge.hip (include/fabind_hip.h: fabind_gcl_edge_fused), as a
+    float [E, H] tensor of keep/(1-p) factors."""
+    import torch
+    thr = int(p_drop * 65536.0 + 0.5)
+    e = torch.arange(E, dtype=torch.int64)[:, None]
+    c = torch.arange(H, dtype=torch.int64)[None, :]
+    M = 0xFFFFFFFF
+    x = (seed + (e >> 1) * H + c) & M
+    x = x ^ (x >> 16); x = (x * 0x7feb352d) & M
+    x = x ^ (x >> 15); x = (x * 0x846ca68b) & M
+    x = x ^ (x >> 16)
+    half = torch.where((e & 1) == 1, x >> 16, x & 0xFFFF)
+    return (half >= thr).float() / (1.0 - thr / 65536.0)

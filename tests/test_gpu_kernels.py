@@ -85,9 +85,9 @@ def test_segment_sum_and_scan():
         assert (out.cpu() - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max())
 
 
-@pytest.mark.parametrize("bm", [32, 64])
+@pytest.mark.parametrize("bm,p_drop", [(32, 0.0), (64, 0.0), (64, 0.25)])
 @pytest.mark.parametrize("H", [64, 128, 512])
-def test_fused_edge_backward_matches_autograd(H, bm):
+def test_fused_edge_backward_matches_autograd(H, bm, p_drop):
     """csrc/fused_edge.hip backward (recompute + 4 chained contractions) vs torch autograd of the same bf16-rounded
     forward on the CPU: every gradient the kernel produces, including the partial column sums and both halves of dAB."""
     from fabind_amd import kernels as K, _lib
@@ -112,8 +112,13 @@ def test_fused_edge_backward_matches_autograd(H, bm):
     leaf = lambda t: t.float().clone().requires_grad_(True)
     ABf, rhf, wrf, W2f, b2f, Wcf, bcf, w3f = map(leaf, (AB16, rh, w_r, W2, b2, Wc, bc, w3))
     rb = lambda t: t + (t.bfloat16().float() - t).detach()           # bf16 rounding, straight-through
+    from helpers import fused_edge_keep_mask
+    seed = 123457
+    keep = fused_edge_keep_mask(seed, E, H, p_drop)
+    if p_drop > 0:
+        assert abs(float((keep == 0).float().mean()) - p_drop) < 0.02      # Bernoulli(p) zeros, survivors scaled 1/(1-p)
     S1 = rb(silu(ABf[row, :H] + ABf[col, H:] + rhf[:, None] * wrf))
-    M = rb(silu(S1 @ W2f.T + b2f))
+    M = rb(silu(S1 @ W2f.T + b2f) * keep)
     agg = torch.zeros(N, H).index_add(0, row, M)
     sv = (silu(M @ Wcf.T + bcf) * w3f).sum(1)
     ((agg * dagg).sum() + (sv * ds).sum()).backward()
@@ -122,7 +127,13 @@ def test_fused_edge_backward_matches_autograd(H, bm):
     colptr = torch.zeros(N + 1, dtype=torch.int32)
     colptr[1:] = torch.cumsum(torch.bincount(colsorted, minlength=N), 0)
     out = K.gcl_edge_fused_bwd(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev),
-                               Wc.to(dev), bc.to(dev), w3.to(dev), ds.to(dev), dagg.to(dev), colptr.to(dev), i32(perm))
+                               Wc.to(dev), bc.to(dev), w3.to(dev), ds.to(dev), dagg.to(dev), colptr.to(dev), i32(perm),
+                               p_drop, seed)
+    # the forward kernel evaluates the same mask
+    agg_k, s_k = K.gcl_edge_fused(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), K.pack_frag(W2.to(dev)),
+                                  b2.to(dev), K.pack_frag(Wc.to(dev)), bc.to(dev), w3.to(dev), N, p_drop, seed)
+    assert (agg_k.cpu() - agg.detach()).abs().max() <= 2e-2 * max(1.0, float(agg.abs().max()))
+    assert (s_k[:, 0].cpu() - sv.detach()).abs().max() <= 2e-2 * max(1.0, float(sv.abs().max()))
     _lib.load().fabind_gcl_edge_fused_bwd_set_tile(64)
     names = ("dAB", "drh", "dw_r", "dW2", "db2", "dWc", "dbc", "dw3")
     refs = (ABf.grad, rhf.grad, wrf.grad, W2f.grad, b2f.grad, Wcf.grad, bcf.grad, w3f.grad)
