@@ -88,10 +88,9 @@ extern "C" int fabind_rowdot_bwd(const void* z, int z_dt, const float* dpart, in
 //   drho_e = drhohat_e/nrm - T_b rho_e / nrm^3,  T_b = sum_e drhohat_e rho_e;   g_e = dd_e + 2 drho_e d_e
 //   dx[r] += g_e, dx[c] -= g_e   (float atomics on [N,3]: order-insensitive to rounding only)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void edge_geom_bwd_kernel(const float* d, const float* rho, const float* norm,
-                                                             const float* dd, const float* drhohat, const int* row,
-                                                             const int* col, const int* rowptr, const int* node_off,
-                                                             float* dx) {
+// pass 1: T_b per complex (one 1024-thread work-group per complex, contiguous edge range)
+__global__ __launch_bounds__(1024) void edge_geom_bwd_t_kernel(const float* __restrict__ rho, const float* __restrict__ drhohat,
+                                                               const int* rowptr, const int* node_off, float* T) {
     __shared__ float red[16];
     const int b = blockIdx.x;
     const int e0 = rowptr[node_off[b]], e1 = rowptr[node_off[b + 1]];
@@ -100,26 +99,63 @@ __global__ __launch_bounds__(1024) void edge_geom_bwd_kernel(const float* d, con
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    float T = 0.f;
-    for (int k = 0; k < 16; ++k) T += red[k];
-    const float nrm = norm[b], inv = 1.f / nrm, inv3 = inv * inv * inv;
-    for (int e = e0 + threadIdx.x; e < e1; e += 1024) {
-        const float drho = drhohat[e] * inv - T * rho[e] * inv3;
-        const int r = row[e], c = col[e];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float g = dd[(size_t)e * 3 + k] + 2.f * drho * d[(size_t)e * 3 + k];
-            atomicAdd(&dx[(size_t)r * 3 + k], g);
-            atomicAdd(&dx[(size_t)c * 3 + k], -g);
-        }
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        T[b] = t;
     }
 }
+// pass 2: one thread per edge over the whole batch: g_e -> scratch (no atomics: a global node would take ~3000
+// same-address atomics per complex)
+__global__ __launch_bounds__(256) void edge_geom_bwd_g_kernel(const float* __restrict__ d, const float* __restrict__ rho,
+                                                              const float* __restrict__ norm, const float* __restrict__ dd,
+                                                              const float* __restrict__ drhohat, const int* __restrict__ row,
+                                                              const int* __restrict__ node_off, const float* __restrict__ T,
+                                                              int B, int E, float* __restrict__ g) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    const int r = row[e];
+    int lo = 0, hi = B;                              // complex of node r: last b with node_off[b] <= r
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (node_off[mid] <= r) lo = mid; else hi = mid;
+    }
+    const float inv = 1.f / norm[lo], inv3 = inv * inv * inv;
+    const float drho = drhohat[e] * inv - T[lo] * rho[e] * inv3;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) g[(size_t)e * 3 + k] = dd[(size_t)e * 3 + k] + 2.f * drho * d[(size_t)e * 3 + k];
+}
+// pass 3: one wave per node: dx[n] = sum_{e in row n} g_e - sum_{e : col(e) = n} g_e, the second sum walks the edges
+// grouped by sending node (colptr, perm)
+__global__ __launch_bounds__(256) void edge_geom_bwd_reduce_kernel(const float* __restrict__ g, const int* __restrict__ rowptr,
+                                                                   const int* __restrict__ colptr,
+                                                                   const int* __restrict__ perm, int n_nodes, float* dx) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_nodes) return;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int e = rowptr[n] + lane; e < rowptr[n + 1]; e += 64) {
+        ax += g[(size_t)e * 3]; ay += g[(size_t)e * 3 + 1]; az += g[(size_t)e * 3 + 2];
+    }
+    for (int q = colptr[n] + lane; q < colptr[n + 1]; q += 64) {
+        const int e = perm[q];
+        ax -= g[(size_t)e * 3]; ay -= g[(size_t)e * 3 + 1]; az -= g[(size_t)e * 3 + 2];
+    }
+    ax = wave_sum(ax); ay = wave_sum(ay); az = wave_sum(az);
+    if (lane == 0) { dx[(size_t)n * 3] = ax; dx[(size_t)n * 3 + 1] = ay; dx[(size_t)n * 3 + 2] = az; }
+}
 extern "C" int fabind_edge_geom_bwd(const float* d, const float* rho, const float* norm, const float* dd,
-                                    const float* drhohat, const int* row, const int* col, const int* rowptr,
-                                    const int* node_off, int B, int E, float* dx, hipStream_t stream) {
-    if (B <= 0 || E <= 0) return 0;
-    hipLaunchKernelGGL(edge_geom_bwd_kernel, dim3(B), dim3(1024), 0, stream, d, rho, norm, dd, drhohat, row, col, rowptr,
-                       node_off, dx);
+                                    const float* drhohat, const int* row, const int* rowptr, const int* colptr,
+                                    const int* perm, const int* node_off, int B, int E, int n_nodes, float* dx,
+                                    float* g_scratch, float* T_scratch, hipStream_t stream) {
+    if (B <= 0 || n_nodes <= 0) return 0;
+    if (E > 0) {
+        hipLaunchKernelGGL(edge_geom_bwd_t_kernel, dim3(B), dim3(1024), 0, stream, rho, drhohat, rowptr, node_off, T_scratch);
+        hipLaunchKernelGGL(edge_geom_bwd_g_kernel, dim3((E + 255) / 256), dim3(256), 0, stream, d, rho, norm, dd, drhohat, row,
+                           node_off, T_scratch, B, E, g_scratch);
+    }
+    hipLaunchKernelGGL(edge_geom_bwd_reduce_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, stream, g_scratch, rowptr, colptr,
+                       perm, n_nodes, dx);
     FB_CHECK_LAUNCH();
     return 0;
 }
@@ -315,22 +351,36 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_q_kernel(const float* __re
         __syncthreads();
         if (!valid) continue;
         const int jn = min(CB_KT, ke - j0);
-        for (int j = 0; j < jn; ++j) {
-            const float* kp = &sK[j * 128 + h * 32];
-            const float* vp = &sV[j * 128 + h * 32];
-            float s = 0.f, dp = 0.f;
+        // pair-bias loads (the only HBM traffic of the loop) are issued 8 keys ahead of their use
+        for (int jg = 0; jg < jn; jg += 8) {
+            float lin8[8], gate8[8];
 #pragma unroll
-            for (int c = 0; c < 32; ++c) { s += qr[c] * kp[c]; dp += dor[c] * vp[c]; }
-            const size_t bi = (size_t)(pair_off + (long)qi * sq + (long)(j0 + j) * sk) * bias_ld;
-            const float lin = bias[bi + lin_col + h], gate = bias[bi + gate_col + h];
-            const float sg = sigmoid_f(gate);
-            s += lin * sg;
-            const float p = __expf(s - L);
-            const float dsj = p * (dp - D);
-            dbias[bi + lin_col + h] = dsj * sg;
-            dbias[bi + gate_col + h] = dsj * lin * sg * (1.f - sg);
+            for (int u = 0; u < 8; ++u) {
+                const int jj = min(jg + u, jn - 1);
+                const size_t bi = (size_t)(pair_off + (long)qi * sq + (long)(j0 + jj) * sk) * bias_ld;
+                lin8[u] = bias[bi + lin_col + h];
+                gate8[u] = bias[bi + gate_col + h];
+            }
 #pragma unroll
-            for (int c = 0; c < 32; ++c) dq[c] += dsj * kp[c];
+            for (int u = 0; u < 8; ++u) {
+                const int j = jg + u;
+                if (j < jn) {
+                    const float* kp = &sK[j * 128 + h * 32];
+                    const float* vp = &sV[j * 128 + h * 32];
+                    float s = 0.f, dp = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) { s += qr[c] * kp[c]; dp += dor[c] * vp[c]; }
+                    const size_t bi = (size_t)(pair_off + (long)qi * sq + (long)(j0 + j) * sk) * bias_ld;
+                    const float lin = lin8[u], sg = sigmoid_f(gate8[u]);
+                    s += lin * sg;
+                    const float p = __expf(s - L);
+                    const float dsj = p * (dp - D);
+                    dbias[bi + lin_col + h] = dsj * sg;
+                    dbias[bi + gate_col + h] = dsj * lin * sg * (1.f - sg);
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) dq[c] += dsj * kp[c];
+                }
+            }
         }
     }
     if (!valid) return;
@@ -394,19 +444,31 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kv_kernel(const float* __r
         __syncthreads();
         if (!valid) continue;
         const int in_ = min(CB_KT, qe - i0);
-        for (int i = 0; i < in_; ++i) {
-            const float* qp = &sQ[i * 128 + h * 32];
-            const float* dp_ = &sDO[i * 128 + h * 32];
-            float s = 0.f, dp = 0.f;
+        for (int ig = 0; ig < in_; ig += 8) {
+            float lin8[8], gate8[8];
 #pragma unroll
-            for (int c = 0; c < 32; ++c) { s += qp[c] * kr[c]; dp += dp_[c] * vr[c]; }
-            s *= scale;
-            const size_t bi = (size_t)(pair_off + (long)(i0 + i) * sq + (long)kj * sk) * bias_ld;
-            s += bias[bi + lin_col + h] * sigmoid_f(bias[bi + gate_col + h]);
-            const float p = __expf(s - sL[i * 4 + h]);
-            const float dsj = p * (dp - sD[i * 4 + h]) * scale;
+            for (int u = 0; u < 8; ++u) {
+                const int ii = min(ig + u, in_ - 1);
+                const size_t bi = (size_t)(pair_off + (long)(i0 + ii) * sq + (long)kj * sk) * bias_ld;
+                lin8[u] = bias[bi + lin_col + h];
+                gate8[u] = bias[bi + gate_col + h];
+            }
 #pragma unroll
-            for (int c = 0; c < 32; ++c) { dk[c] += dsj * qp[c]; dv[c] += p * dp_[c]; }
+            for (int u = 0; u < 8; ++u) {
+                const int i = ig + u;
+                if (i < in_) {
+                    const float* qp = &sQ[i * 128 + h * 32];
+                    const float* dp_ = &sDO[i * 128 + h * 32];
+                    float s = 0.f, dp = 0.f;
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) { s += qp[c] * kr[c]; dp += dp_[c] * vr[c]; }
+                    s = s * scale + lin8[u] * sigmoid_f(gate8[u]);
+                    const float p = __expf(s - sL[i * 4 + h]);
+                    const float dsj = p * (dp - sD[i * 4 + h]) * scale;
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) { dk[c] += dsj * qp[c]; dv[c] += p * dp_[c]; }
+                }
+            }
         }
     }
     if (!valid) return;

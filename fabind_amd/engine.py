@@ -129,6 +129,11 @@ class Graph:
         self._ctx_bycol = None
         self.N = lay.N
 
+    def int_by_col(self):
+        """Inter edges grouped by sending node: the graph is symmetric, so node n's incoming edges are the mirrors of
+        its own CSR row."""
+        return self.rp_int, self.mirror
+
     def ctx_by_col(self):
         """(colptr, perm): ctx edges grouped by their SENDING node (for column-wise reductions in backward)."""
         if self._ctx_bycol is None:
@@ -256,7 +261,7 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
         # autograd nothing per-edge is saved, the backward kernel recomputes tile by tile.  Train-mode dropout on the
         # messages is a counter-based mask evaluated inside both kernels.
         AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=torch.bfloat16)
-        d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
+        d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay, g.ctx_by_col)
         agg, s = ops.fused_edge(AB, rhohat, p["w_r"], p["W2"], p["b2"], p["Wc"], p["bc"], p["w3"], H, g, pdrop)
         x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
         t = ops.linear(hin, p["Wn1"], p["bn1"], x2=agg, act_epi=K.ACT_SILU, out_dtype=ad)
@@ -264,7 +269,7 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
             return h + _drop(ops.linear(t, p["Wn2"], p["bn2"]), pdrop), x_new
         return ops.linear(t, p["Wn2"], p["bn2"], residual=h), x_new
     AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=ad)                           # [N,2H] node-level
-    d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
+    d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay, g.ctx_by_col)
     S1 = ops.gcl_pre(AB, H, g, rhohat, p["w_r"], act=K.ACT_SILU)                        # [E,H] silu(first edge Linear)
     Mm = ops.linear(S1, p["W2"], p["b2"], act_epi=K.ACT_SILU, out_dtype=ad)             # [E,H] messages m_e
     Mm = _drop(Mm, pdrop)
@@ -316,7 +321,7 @@ def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv, pdrop=0.0, pdrop_r
     bias_part = ops.linear_rowdot(hd, p["Wcomp1"], p["bcomp1"], p["u"], act_epi=K.ACT_RELU)
     qkv = ops.linear(h16, p["Wqkv"], p["bqkv"])                                        # [N,3H]
     cv = ops.linear(qkv[:, 2 * H:], p["Wc"], p["bc"])                                  # [N,H]
-    d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay)
+    d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay, g.int_by_col)
     h_new, x_new, alpha = ops.inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["wcr"],
                                          p["w3"], clampv)
     if pdrop > 0.0:

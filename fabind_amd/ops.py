@@ -301,28 +301,39 @@ def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop=0.0):
 # ------------------------------------------------------------------------------------------------
 class _EdgeGeom(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, row, col, rowptr, lay):
+    def forward(ctx, x, row, col, rowptr, lay, bycol):
         d, rho, rhohat, norm = K.edge_geom(x, row, col, rowptr, lay.node_off, lay.B)
-        ctx.lay, ctx.n = lay, x.shape[0]
+        ctx.lay, ctx.n, ctx.bycol = lay, x.shape[0], bycol
         ctx.save_for_backward(row, col, rowptr, d, rho, norm)
         return d, rhohat
 
     @staticmethod
     def backward(ctx, dd, drhohat):
         row, col, rowptr, d, rho, norm = ctx.saved_tensors
-        lay = ctx.lay
-        dx = torch.zeros((ctx.n, 3), dtype=torch.float32, device=d.device)
+        lay, E, dev = ctx.lay, row.shape[0], d.device
+        if ctx.bycol is not None:
+            colptr, perm = ctx.bycol()
+        else:                                     # edges grouped by sending node (index glue, no activations)
+            colsorted, perm64 = torch.sort(col.long(), stable=True)
+            colptr = torch.zeros(ctx.n + 1, dtype=torch.int32, device=dev)
+            colptr[1:] = torch.cumsum(torch.bincount(colsorted, minlength=ctx.n), 0).to(torch.int32)
+            perm = perm64.to(torch.int32)
+        dx = torch.empty((ctx.n, 3), dtype=torch.float32, device=dev)
         dd = dd.contiguous() if dd is not None else torch.zeros_like(d)
         drhohat = drhohat.contiguous() if drhohat is not None else torch.zeros_like(rho)
-        check(load().fabind_edge_geom_bwd(ptr(d), ptr(rho), ptr(norm), ptr(dd), ptr(drhohat), ptr(row), ptr(col),
-                                          ptr(rowptr), ptr(lay.node_off), lay.B, row.shape[0], ptr(dx), stream()),
+        gbuf = torch.empty((max(E, 1), 3), dtype=torch.float32, device=dev)
+        check(load().fabind_edge_geom_bwd(ptr(d), ptr(rho), ptr(norm), ptr(dd), ptr(drhohat), ptr(row), ptr(rowptr),
+                                          ptr(colptr), ptr(perm), ptr(lay.node_off), lay.B, E, ctx.n, ptr(dx), ptr(gbuf),
+                                          ptr(torch.empty(lay.B, dtype=torch.float32, device=dev)), stream()),
               "fabind_edge_geom_bwd")
-        return dx, None, None, None, None
+        return dx, None, None, None, None, None
 
 
-def edge_geom(x, row, col, rowptr, lay):
+def edge_geom(x, row, col, rowptr, lay, bycol=None):
+    """bycol: callable returning (colptr, perm) = the edges grouped by their sending node (Graph.ctx_by_col; for the
+    symmetric inter graph (rowptr, mirror)); derived by a sort in backward when omitted."""
     if _needs_grad(x):
-        return _EdgeGeom.apply(x, row, col, rowptr, lay)
+        return _EdgeGeom.apply(x, row, col, rowptr, lay, bycol)
     d, _, rhohat, _ = K.edge_geom(x, row, col, rowptr, lay.node_off, lay.B)
     return d, rhohat
 

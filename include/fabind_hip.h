@@ -243,8 +243,9 @@ int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_dt, int act,
 int fabind_rowdot_bwd(const void* z, int z_dt, const float* dpart, int np, const float* u, int act, int M, int N,
                       void* dz, float* du, float* scratch, int nchunk, hipStream_t stream);
 int fabind_edge_geom_bwd(const float* d, const float* rho, const float* norm, const float* dd, const float* drhohat,
-                         const int* row, const int* col, const int* rowptr, const int* node_off, int B, int E, float* dx,
-                         hipStream_t stream);
+                         const int* row, const int* rowptr, const int* colptr /* edges grouped by sending node */,
+                         const int* perm /* their edge ids */, const int* node_off, int B, int E, int n_nodes, float* dx,
+                         float* g_scratch /* [E,3] */, float* T_scratch /* [B] */, hipStream_t stream);
 int fabind_gcl_pre_bwd(const void* dpre, int dt, int H, const float* rhohat, const float* w_r, int E, float* drh,
                        float* dw, float* scratch, int nchunk, hipStream_t stream);
 int fabind_gather_dact(const float* dout, int ldo, const int* row, const void* Z, int z_dt, int act, void* dZ, int dz_dt,
