@@ -29,6 +29,68 @@ extern "C" int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_d
     return 0;
 }
 
+// out = dy * act'(y) AND its column sums (the bias gradient) in the same pass over dy: one block = 256 columns x a
+// chunk of rows, 4 row-lanes with 4 independent row loads in flight, fixed-order combine (deterministic).
+__global__ __launch_bounds__(256) void mul_dact_colsum_kernel(const void* __restrict__ dy, int dy_dt, const void* __restrict__ y,
+                                                              int y_dt, int act, void* __restrict__ out, int out_dt, int R, int C,
+                                                              float* scratch, int rows_per) {
+    __shared__ float4 part[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + lane * 4;
+    const int r0 = blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) {                                     // C % 4 == 0: the lane's 4 columns are all inside
+        int r = r0 + q;
+        for (; r + 12 < r1; r += 16) {
+            float4 g[4], v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                g[u] = ld4_any(dy, dy_dt, (size_t)(r + 4 * u) * C + c);
+                v[u] = y ? ld4_any(y, y_dt, (size_t)(r + 4 * u) * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 o = make_float4(g[u].x * apply_dact(v[u].x, act), g[u].y * apply_dact(v[u].y, act),
+                                             g[u].z * apply_dact(v[u].z, act), g[u].w * apply_dact(v[u].w, act));
+                st4_any(out, out_dt, (size_t)(r + 4 * u) * C + c, o);
+                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            }
+        }
+        for (; r < r1; r += 4) {
+            const float4 g = ld4_any(dy, dy_dt, (size_t)r * C + c);
+            const float4 v = y ? ld4_any(y, y_dt, (size_t)r * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 o = make_float4(g.x * apply_dact(v.x, act), g.y * apply_dact(v.y, act), g.z * apply_dact(v.z, act),
+                                         g.w * apply_dact(v.w, act));
+            st4_any(out, out_dt, (size_t)r * C + c, o);
+            s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+        }
+    }
+    part[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && c < C) {
+        const float4 a = part[0][lane], b = part[1][lane], d_ = part[2][lane], e = part[3][lane];
+        float* o = scratch + (size_t)blockIdx.y * C + c;
+        o[0] = (a.x + b.x) + (d_.x + e.x); o[1] = (a.y + b.y) + (d_.y + e.y);
+        o[2] = (a.z + b.z) + (d_.z + e.z); o[3] = (a.w + b.w) + (d_.w + e.w);
+    }
+}
+#define SUMC_BLOCK 1024
+#define SUMC_GRID(C_) dim3(((C_) + 63) / 64)
+__global__ void sum_chunks_kernel(const float* __restrict__ scratch, float* out, int C, int nchunk);
+extern "C" int fabind_mul_dact_colsum(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt,
+                                      int R, int C, float* colsum, float* scratch, int nchunk, hipStream_t stream) {
+    if (R <= 0 || C <= 0) return 0;
+    FB_REQUIRE(C % 4 == 0 && nchunk >= 1, "fabind_mul_dact_colsum: C % 4 == 0, nchunk >= 1");
+    FB_REQUIRE(((uintptr_t)dy % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)out % 16 == 0),
+               "fabind_mul_dact_colsum: 16-byte alignment");
+    const int rows_per = (R + nchunk - 1) / nchunk;
+    hipLaunchKernelGGL(mul_dact_colsum_kernel, dim3((C + 255) / 256, nchunk), dim3(256), 0, stream, dy, dy_dt, y, y_dt, act, out,
+                       out_dt, R, C, scratch, rows_per);
+    hipLaunchKernelGGL(sum_chunks_kernel, SUMC_GRID(C), dim3(SUMC_BLOCK), 0, stream, scratch, colsum, C, nchunk);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // adjoint of the row-dot epilogue:  part[m,t] = sum_{n in tile t} act(z[m,n]) u[n]
 //   dz[m,n] = dpart[m, n/128] * u[n] * act'(z[m,n]);   du[n] = sum_m dpart[m, n/128] * act(z[m,n])
@@ -64,12 +126,29 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const void* z, int z_dt
         o[2] = (a.z + b.z) + (d_.z + e.z); o[3] = (a.w + b.w) + (d_.w + e.w);
     }
 }
-__global__ void sum_chunks_kernel(const float* scratch, float* out, int C, int nchunk) {
-    int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s = 0.f;
-    for (int k = 0; k < nchunk; ++k) s += scratch[(size_t)k * C + c];
-    out[c] = s;
+// out[c] = sum_k scratch[k, c]: 64 columns per 1024-thread block, the chunk rows over 16 row-lanes with 4
+// independent loads in flight, fixed-order combine through LDS (deterministic).  Launch with SUMC_GRID / SUMC_BLOCK.
+__global__ __launch_bounds__(1024) void sum_chunks_kernel(const float* __restrict__ scratch, float* out, int C, int nchunk) {
+    __shared__ float part[16][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < C) {
+        int k = q;
+        for (; k + 48 < nchunk; k += 64) {
+            s0 += scratch[(size_t)k * C + c]; s1 += scratch[(size_t)(k + 16) * C + c];
+            s2 += scratch[(size_t)(k + 32) * C + c]; s3 += scratch[(size_t)(k + 48) * C + c];
+        }
+        for (; k < nchunk; k += 16) s0 += scratch[(size_t)k * C + c];
+    }
+    part[q][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (q == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += part[k][lane];
+        out[c] = t;
+    }
 }
 extern "C" int fabind_rowdot_bwd(const void* z, int z_dt, const float* dpart, int np, const float* u, int act, int M,
                                  int N, void* dz, float* du, float* scratch, int nchunk, hipStream_t stream) {
@@ -78,7 +157,7 @@ extern "C" int fabind_rowdot_bwd(const void* z, int z_dt, const float* dpart, in
     int rows_per = (M + nchunk - 1) / nchunk;
     hipLaunchKernelGGL(rowdot_bwd_kernel, dim3((N + 255) / 256, nchunk), dim3(256), 0, stream, z, z_dt, dpart, np, u, act,
                        M, N, dz, scratch, rows_per);
-    hipLaunchKernelGGL(sum_chunks_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, scratch, du, N, nchunk);
+    hipLaunchKernelGGL(sum_chunks_kernel, SUMC_GRID(N), dim3(SUMC_BLOCK), 0, stream, scratch, du, N, nchunk);
     FB_CHECK_LAUNCH();
     return 0;
 }
@@ -221,7 +300,7 @@ extern "C" int fabind_gcl_pre_bwd(const void* dpre, int dt, int H, const float* 
     FB_REQUIRE(H % 4 == 0 && H <= 1024, "fabind_gcl_pre_bwd: H % 4, H <= 1024");
     hipLaunchKernelGGL(gcl_pre_bwd_kernel, dim3(nchunk), dim3(256), 0, stream, dpre, dt, H, rhohat,
                        w_r, E, drh, scratch, edges_per);
-    hipLaunchKernelGGL(sum_chunks_kernel, dim3((H + 255) / 256), dim3(256), 0, stream, scratch, dw, H, nchunk);
+    hipLaunchKernelGGL(sum_chunks_kernel, SUMC_GRID(H), dim3(SUMC_BLOCK), 0, stream, scratch, dw, H, nchunk);
     FB_CHECK_LAUNCH();
     return 0;
 }

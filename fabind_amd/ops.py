@@ -5,6 +5,8 @@ when a gradient is required the same kernels run inside torch.autograd.Function 
 backward passes are HIP kernels as well (fabind_amd/csrc/bwd.hip + the GEMM family)."""
 import ctypes
 
+import os
+
 import torch
 
 from . import config as _cfg
@@ -87,6 +89,22 @@ def _mul_dact(dy, aux, act, out_dtype):
     return out
 
 
+FUSE_DB = os.environ.get("FABIND_FUSE_DB", "1") == "1"
+
+
+def _mul_dact_colsum(dy, aux, act, out_dtype):
+    """(dy * act'(aux), its column sums) in one pass (bias gradient fused into the activation adjoint / cast)."""
+    R, C = dy.shape
+    out = torch.empty((R, C), dtype=out_dtype, device=dy.device)
+    nchunk = max(1, min(4096, (R + 63) // 64))           # >= 2 blocks per SIMD at C = 512: the pass is latency-bound
+    scratch = torch.empty((nchunk, C), dtype=torch.float32, device=dy.device)
+    db = torch.empty(C, dtype=torch.float32, device=dy.device)
+    check(load().fabind_mul_dact_colsum(ptr(dy), dt_code(dy.dtype), ptr(aux), dt_code(aux.dtype) if aux is not None else 0,
+                                        act, ptr(out), dt_code(out_dtype), R, C, ptr(db), ptr(scratch), nchunk, stream()),
+          "fabind_mul_dact_colsum")
+    return out, db
+
+
 def _mm_in(x):
     """Operand as the GEMM wants it: bf16 copy of an fp32 activation in bf16 mode."""
     if x is not None and _cfg.get_precision() == "bf16" and x.dtype == torch.float32:
@@ -116,16 +134,20 @@ class _Linear(torch.autograd.Function):
         x, W, x2, y, D = ctx.saved_tensors
         dy = dy.contiguous()
         md = mm_dtype()
+        db = None
+        want_db = ctx.has_b and ctx.needs_input_grad[2]
+        fuse_db = FUSE_DB and want_db and dy.dim() == 2 and dy.shape[1] % 4 == 0   # bias gradient in the same pass over dy
+        md_op = _mul_dact_colsum if fuse_db else (lambda *a: (_mul_dact(*a), None))
         if ctx.act_epi == K.ACT_RELU:
-            dpre = _mul_dact(dy, y, K.ACT_RELU, md)
+            dpre, db = md_op(dy, y, K.ACT_RELU, md)
         elif ctx.act_epi == K.ACT_SILU:
-            dpre = _mul_dact(dy, D, K.ACT_STORED_DERIV, md)
+            dpre, db = md_op(dy, D, K.ACT_STORED_DERIV, md)
         elif dy.dtype != md:
-            dpre = _mul_dact(dy, None, K.ACT_NONE, md)            # dtype conversion only
+            dpre, db = md_op(dy, None, K.ACT_NONE, md)           # dtype conversion only
         else:
             dpre = dy
         K1, N = x.shape[1], W.shape[0]
-        dx = dx2 = dW = db = None
+        dx = dx2 = dW = None
         if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[3]):
             if N % 8 == 0:
                 Wt, dmm = W.t().contiguous(), dpre                      # [K, N] (parameter-only transpose)
@@ -144,7 +166,7 @@ class _Linear(torch.autograd.Function):
                 dx = dfull
         if ctx.needs_input_grad[1]:
             dW = _weight_grad(dpre, x, K.ACT_NONE, x2).to(W.dtype)
-        if ctx.has_b and ctx.needs_input_grad[2]:
+        if want_db and db is None:
             db = K.colsum(dpre)
         dres = dy.float() if (ctx.has_res and ctx.needs_input_grad[4]) else None
         return dx, dW, db, dx2, dres, None, None

@@ -240,6 +240,10 @@ int fabind_add(const float* a, const float* b, float* out, long n, hipStream_t s
  * -------------------------------------------------------------------------------------------*/
 int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, long n,
                     hipStream_t stream);
+/* out = dy * act'(y) (y = NULL with FB_ACT_NONE: dtype conversion) and colsum[c] = sum_r out[r,c] in one pass
+ * (bias gradient of the Linear whose activation is being undone); [R,C] contiguous, scratch [nchunk, C]. */
+int fabind_mul_dact_colsum(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, int R, int C,
+                           float* colsum, float* scratch, int nchunk, hipStream_t stream);
 int fabind_rowdot_bwd(const void* z, int z_dt, const float* dpart, int np, const float* u, int act, int M, int N,
                       void* dz, float* du, float* scratch, int nchunk, hipStream_t stream);
 int fabind_edge_geom_bwd(const float* d, const float* rho, const float* norm, const float* dd, const float* drhohat,
