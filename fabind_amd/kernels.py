@@ -272,7 +272,9 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     if ng is None:
         ng = _N_CU[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
     bm = _lib.load().fabind_gcl_edge_fused_bwd_tile()
-    ng = max(1, min(ng * (2 if bm == 32 else 1), (E + bm - 1) // bm))
+    # persistent work-groups per CU: as many as the two LDS tiles (2 * bm * H * 2 B of 160 KiB) and 2 waves/SIMD allow
+    per_cu = max(1, min(8, (160 * 1024) // (4 * bm * H + 1024), (1024 if bm == 32 else 512) // H))
+    ng = max(1, min(ng * per_cu, (E + bm - 1) // bm))
     buf = torch.empty((5, max(E, 1), H), dtype=torch.bfloat16, device=dev)
     S1, Mm, dT, dP2, dP1 = buf[0], buf[1], buf[2], buf[3], buf[4]
     dAB = torch.zeros((N, 2 * H), dtype=torch.float32, device=dev)
