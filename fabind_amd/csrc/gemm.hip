@@ -772,7 +772,8 @@ __device__ __forceinline__ int tn_swz(int r) { return (r & 3) | (((r >> 3) & 1) 
 template <int NSTAGE>
 __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ X,
                                                            int ldx, float* C, int M, int N, int E, int e_per,
-                                                           const bf16_t* __restrict__ zero_page, const int* groups) {
+                                                           const bf16_t* __restrict__ zero_page, const int* groups,
+                                                           int n_tiles, int n_splits) {
     constexpr int TM = 256, TN_ = 128, BKE = 32, NW = 8;
     constexpr int PY = (BKE * TM * 2) / 1024, PX = (BKE * TN_ * 2) / 1024, PPW = (PY + PX) / NW;   // 16 + 8 pieces -> 3 per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -790,9 +791,15 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const bf16_t* __restr
         c_goff = (long)(unsigned)g[6] | ((long)g[7] << 32);
     }
     const int nbx = (N + TN_ - 1) / TN_;
-    const int m0 = (blockIdx.x / nbx) * TM, n0 = (blockIdx.x % nbx) * TN_;
+    // XCD-aware order: consecutive work-group ids go round-robin to the 8 XCDs, so id = (split_hi, tile, split_lo)
+    // puts every output tile of one e-range on the SAME XCD -- its Y / X slabs are fetched into that L2 once
+    // instead of once per tile (measured 3x the algorithmic HBM reads with tile-major order).
+    const int tile = (blockIdx.x >> 3) % n_tiles;
+    const int split = ((blockIdx.x >> 3) / n_tiles) * 8 + (blockIdx.x & 7);
+    if (split >= n_splits) return;
+    const int m0 = (tile / nbx) * TM, n0 = (tile % nbx) * TN_;
     if (m0 >= M) return;
-    const int ebeg = blockIdx.y * e_per, eend = min(E, ebeg + e_per);
+    const int ebeg = split * e_per, eend = min(E, ebeg + e_per);
     const int nk = (eend - ebeg + BKE - 1) / BKE;
 
     // per-lane source descriptors of this wave's PPW pieces: (is_y, row-in-tile, element offset in the row)
@@ -841,20 +848,36 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const bf16_t* __restr
         if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, ebeg + (kt + NSTAGE - 1) * BKE);
         const bf16_t* tY = sT + (size_t)(kt % NSTAGE) * STAGE_ELEMS;
         const bf16_t* tX = tY + BKE * TM;
+        // all 16 transpose reads of the k-step are issued before ONE wait (a wait per fragment serialised 8 LDS
+        // round trips per k-step)
+        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        u32x2 ya[4], yb[4], xa[4], xb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gm = wm * 4 + i, gn = wn * 4 + i;          // 16-column granules of the Y / X tiles
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ya[i]) : "v"((unsigned)(uintptr_t)(tY + r1 * TM + ((gm ^ z1) * 16) + co)) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(yb[i]) : "v"((unsigned)(uintptr_t)(tY + r2 * TM + ((gm ^ z2) * 16) + co)) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xa[i]) : "v"((unsigned)(uintptr_t)(tX + r1 * TN_ + ((gn ^ z1) * 16) + co)) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xb[i]) : "v"((unsigned)(uintptr_t)(tX + r2 * TN_ + ((gn ^ z2) * 16) + co)) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3]),
+                       "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])
+                     :: "memory");
         bf16x8_t af[4], bfr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int gm = wm * 4 + i;                           // 16-column granule of the Y tile
-            af[i] = tr_frag(tY + r1 * TM + ((gm ^ z1) * 16) + co, tY + r2 * TM + ((gm ^ z2) * 16) + co);
-            const int gn = wn * 4 + i;
-            bfr[i] = tr_frag(tX + r1 * TN_ + ((gn ^ z1) * 16) + co, tX + r2 * TN_ + ((gn ^ z2) * 16) + co);
+            const u32x4 ra = {ya[i][0], ya[i][1], yb[i][0], yb[i][1]}, rb = {xa[i][0], xa[i][1], xb[i][0], xb[i][1]};
+            af[i] = __builtin_bit_cast(bf16x8_t, ra);
+            bfr[i] = __builtin_bit_cast(bf16x8_t, rb);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    float* Cs = C + c_goff + (size_t)blockIdx.y * M * N;
+    float* Cs = C + c_goff + (size_t)split * M * N;
     const int fr = lane & 15, cq = lane >> 4;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -878,9 +901,10 @@ extern "C" int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, fl
     static bool set_ = false;
     if (!set_) { (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; }
     int e_per = ((E + splits - 1) / splits + 31) / 32 * 32;
-    dim3 grid(((M + 255) / 256) * ((N + 127) / 128), splits, groups ? n_groups : 1);
+    const int n_tiles = ((M + 255) / 256) * ((N + 127) / 128);
+    dim3 grid(n_tiles * ((splits + 7) / 8 * 8), 1, groups ? n_groups : 1);
     hipLaunchKernelGGL((gemm_tn_bf16_kernel<NST>), grid, dim3(512), lds, stream, (const bf16_t*)Y, ldy, (const bf16_t*)X, ldx,
-                       C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups);
+                       C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups, n_tiles, splits);
     FB_CHECK_LAUNCH();
     return 0;
 }
