@@ -235,7 +235,7 @@ def main():
                     out["roofline"]["traffic"] = val
         except Exception:
             pass
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
         out["cpu_baseline"] = cpu_baseline(a.hidden, a.layers, a.n_iter, a.n_prot, a.n_lig)
     print(json.dumps(out))
 

@@ -152,6 +152,20 @@ def _cat(ts, d=0):
     return torch.cat(list(ts), d)
 
 
+def gcl_params(m):
+    """Kernel-side parameter pack of one MC_E_GCL module (first edge Linear split per node, see module docstring)."""
+    wd = _wd()
+    W = lambda t: t.to(wd).contiguous()
+    W1 = m.edge_mlp[0].weight
+    Hin = (W1.shape[1] - 1) // 2
+    return dict(
+        W_ab=W(_cat([W1[:, :Hin], W1[:, Hin:2 * Hin]])),
+        b_ab=_cat([m.edge_mlp[0].bias, torch.zeros_like(m.edge_mlp[0].bias)]).contiguous(),
+        w_r=W1[:, 2 * Hin].contiguous(), W2=W(m.edge_mlp[2].weight), b2=m.edge_mlp[2].bias,
+        Wc=W(m.coord_mlp[0].weight), bc=m.coord_mlp[0].bias, w3=m.coord_mlp[2].weight[0].contiguous(),
+        Wn1=W(m.node_mlp[0].weight), bn1=m.node_mlp[0].bias, Wn2=W(m.node_mlp[2].weight), bn2=m.node_mlp[2].bias)
+
+
 def prepare_stack_params(model):
     """Pack the parameters of an EfficientMCAttModel for the kernels (see module docstring)."""
     wd = _wd()
@@ -176,17 +190,7 @@ def prepare_stack_params(model):
     P["W_in"], P["b_in"] = W(gnn.linear_in.weight), gnn.linear_in.bias
     P["W_out"], P["b_out"] = W(gnn.linear_out.weight), gnn.linear_out.bias
 
-    def gcl(m):
-        W1 = m.edge_mlp[0].weight
-        Hh = m.edge_mlp[2].weight.shape[1]
-        Hin = (W1.shape[1] - 1) // 2
-        return dict(
-            W_ab=W(_cat([W1[:, :Hin], W1[:, Hin:2 * Hin]])),
-            b_ab=_cat([m.edge_mlp[0].bias, torch.zeros_like(m.edge_mlp[0].bias)]).contiguous(),
-            w_r=W1[:, 2 * Hin].contiguous(), W2=W(m.edge_mlp[2].weight), b2=m.edge_mlp[2].bias,
-            Wc=W(m.coord_mlp[0].weight), bc=m.coord_mlp[0].bias, w3=m.coord_mlp[2].weight[0].contiguous(),
-            Wn1=W(m.node_mlp[0].weight), bn1=m.node_mlp[0].bias, Wn2=W(m.node_mlp[2].weight), bn2=m.node_mlp[2].bias)
-
+    gcl = gcl_params
     P["gcl"] = [gcl(getattr(gnn, "gcl_%d" % i)) for i in range(L)]
     P["out_layer"] = gcl(gnn.out_layer)
     att = []
@@ -353,46 +357,111 @@ def pair_bias_all(P, a0b0, lay):
     return ops.pair_bias(a0b0, H, P["pb_wcomp"], P["pb_bconst"], lay)
 
 
+class StackContext:
+    """Per-batch state shared by every FABind layer of one EfficientMCAttModel call: packed parameters, the batch
+    layout, the constant pair-embedding factors (a0 | b0) with the pair biases of every layer, LAS data and -- after
+    `rebuild_graph(x)` -- the ctx / inter CSR of the current coordinates.  `EfficientMCAttModel.context(...)` builds
+    one; `FABindLayer.forward(h, x, ctx)` / `MCAttEGNN.forward(h, x, ctx=ctx)` consume it."""
+
+    def __init__(self, model, X, Hin, batch_id, segment_id, mask, is_global, compound_edge_index, LAS_edge_index, coord_LAS):
+        if not X.is_cuda:
+            raise RuntimeError("fabind_amd: the docking stack runs on a HIP device only (no CPU fallback); got "
+                               + str(X.device))
+        args = model.args
+        self.model = model
+        self.scale = float(args.coordinate_scale)
+        self.step = float(args.geometry_reg_step_size)
+        self.clampv = 10.0 / self.scale
+        self.P = prepare_stack_params(model)
+        self.lay = lay = Layout(batch_id, segment_id)
+        self.bond_row = compound_edge_index[0].to(torch.int32).contiguous()
+        self.bond_col = compound_edge_index[1].to(torch.int32).contiguous()
+        self.bond_off = lay.ranges(self.bond_row)
+        las = (LAS_edge_index[0].to(torch.int32).contiguous(), LAS_edge_index[1].to(torch.int32).contiguous())
+        self.las = las + (lay.ranges(las[0]),)
+        self.x_las = coord_LAS.reshape(-1, 3).float().contiguous()
+        self.mask_u8 = mask.to(torch.uint8).contiguous()
+        self.Hin = Hin.float().contiguous()
+        self.a0b0 = ops.linear(self.Hin, self.P["W_ab0"], self.P["b_ab0"])
+        self.pairbias = pair_bias_all(self.P, self.a0b0, lay)
+        self.cut_intra = float(model.extract_edges.intra_cutoff)
+        self.cut_inter = float(model.extract_edges.inter_cutoff)
+        self.drop = None
+        if model.training:   # the reference's nn.Dropout modules are active in every refinement iteration (also under no_grad)
+            gnn = model.gnn
+            drop = dict(gnn=gnn.dropout.p, gcl=gnn.gcl_0.dropout.p, att=gnn.att_0.dropout.p, out=gnn.out_layer.dropout.p,
+                        row=gnn.att_0.cross_attn_module.p_attention_block.dropout.p)
+            self.drop = drop if any(v > 0 for v in drop.values()) else None
+        self.g = None
+
+    def rebuild_graph(self, x):
+        """ctx + inter edges of the coordinates x [N,3] (normalised), att_model.py:209-214."""
+        self.g = Graph(self.lay, x.detach().reshape(-1, 3).float().contiguous(), self.bond_row, self.bond_col, self.bond_off,
+                       self.cut_intra, self.cut_inter)
+        return self.g
+
+    # -- one loop body of MCAttEGNN.forward (egnn.py:402-449): gcl_i -> att_i -> LAS step
+    def layer(self, i, h, x):
+        dp = self.drop or {}
+        h, x = gcl_layer(self.P["gcl"][i], h, x, self.lay, self.g, self.clampv, dp.get("gcl", 0.0))
+        h, x, alpha = att_layer(self.P["att"][i], h, x, self.lay, self.g, self.a0b0, self.pairbias, i, self.clampv,
+                                dp.get("att", 0.0), dp.get("row", 0.0))
+        x = ops.las_step(x, self.x_las, self.las, self.lay, self.step, 15.0 / self.scale)
+        return h, x, alpha
+
+    def gnn(self, h, x):
+        return egnn_forward(self.P, h, x, self.lay, self.g, self.las, self.x_las, self.a0b0, self.pairbias, self.scale,
+                            self.step, self.drop)
+
+
 def stack_forward(model, X, Hin, batch_id, segment_id, mask, is_global, compound_edge_index, LAS_edge_index,
                   coord_LAS, n_iter):
     """EfficientMCAttModel.forward with refine='refine_coord' (att_model.py:198-246).
 
     Mutates X in place like the reference (X[mask] = Z[mask]) and returns (X, H)."""
-    if not X.is_cuda:
-        raise RuntimeError("fabind_amd: the docking stack runs on a HIP device only (no CPU fallback); got " + str(X.device))
-    args = model.args
-    scale = float(args.coordinate_scale)
-    P = prepare_stack_params(model)
-    lay = Layout(batch_id, segment_id)
-    bond_row = compound_edge_index[0].to(torch.int32).contiguous()
-    bond_col = compound_edge_index[1].to(torch.int32).contiguous()
-    bond_off = lay.ranges(bond_row)
-    las = (LAS_edge_index[0].to(torch.int32).contiguous(), LAS_edge_index[1].to(torch.int32).contiguous())
-    las = las + (lay.ranges(las[0]),)
+    ctx = StackContext(model, X, Hin, batch_id, segment_id, mask, is_global, compound_edge_index, LAS_edge_index, coord_LAS)
     x = X.reshape(-1, 3).float().contiguous()
-    x_las = coord_LAS.reshape(-1, 3).float().contiguous()
-    mask_u8 = mask.to(torch.uint8).contiguous()
-    Hin = Hin.float().contiguous()
-    a0b0 = ops.linear(Hin, P["W_ab0"], P["b_ab0"])
-    pairbias = pair_bias_all(P, a0b0, lay)
-    cut_intra, cut_inter = float(model.extract_edges.intra_cutoff), float(model.extract_edges.inter_cutoff)
-    drop = None
-    if model.training:   # the reference's nn.Dropout modules are active in every refinement iteration (also under no_grad)
-        gnn = model.gnn
-        drop = dict(gnn=gnn.dropout.p, gcl=gnn.gcl_0.dropout.p, att=gnn.att_0.dropout.p, out=gnn.out_layer.dropout.p,
-                    row=gnn.att_0.cross_attn_module.p_attention_block.dropout.p)
-        if not any(v > 0 for v in drop.values()):
-            drop = None
     Hout = None
     for r in range(n_iter):
         last = r == n_iter - 1
-        g = Graph(lay, x.detach(), bond_row, bond_col, bond_off, cut_intra, cut_inter)
+        g = ctx.rebuild_graph(x)
         with torch.set_grad_enabled(last and torch.is_grad_enabled()):
-            Hout, z = egnn_forward(P, Hin, x, lay, g, las, x_las, a0b0, pairbias, scale,
-                                   float(args.geometry_reg_step_size), drop)
-            x = ops.select_rows(x, z, mask_u8)
+            Hout, z = ctx.gnn(ctx.Hin, x)
+            x = ops.select_rows(x, z, ctx.mask_u8)
     model.last_graph = g
     with torch.no_grad():
         X.copy_(x.reshape(X.shape).to(X.dtype))
     Xout = x.reshape(X.shape)
     return (Xout if Xout.requires_grad else X), Hout
+
+
+class EdgeListGraph:
+    """CSR view of a caller-supplied ctx edge list (MC_E_GCL.forward with the reference's signature): edges sorted by
+    receiving node (index glue on the device), exposing what gcl_layer reads from a Graph."""
+
+    def __init__(self, edge_index, n_nodes):
+        row, col = edge_index[0].long(), edge_index[1].long()
+        srow, order = torch.sort(row, stable=True)
+        self.row_ctx = srow.to(torch.int32).contiguous()
+        self.col_ctx = col[order].to(torch.int32).contiguous()
+        rp = torch.zeros(n_nodes + 1, dtype=torch.int32, device=row.device)
+        rp[1:] = torch.cumsum(torch.bincount(srow, minlength=n_nodes), 0).to(torch.int32)
+        self.rp_ctx, self.N, self.E_ctx, self._bycol = rp, n_nodes, int(row.shape[0]), None
+
+    def ctx_by_col(self):
+        if self._bycol is None:
+            cs, perm = torch.sort(self.col_ctx.long(), stable=True)
+            cp = torch.zeros(self.N + 1, dtype=torch.int32, device=perm.device)
+            cp[1:] = torch.cumsum(torch.bincount(cs, minlength=self.N), 0).to(torch.int32)
+            self._bycol = (cp, perm.to(torch.int32).contiguous())
+        return self._bycol
+
+
+class BatchOnlyLayout:
+    """node_off / B of a complex-contiguous batch vector: all coord2radial's per-sample norm needs."""
+
+    def __init__(self, batch_id):
+        B = int(batch_id[-1].item()) + 1
+        off = torch.zeros(B + 1, dtype=torch.int32, device=batch_id.device)
+        off[1:] = torch.cumsum(torch.bincount(batch_id, minlength=B), 0).to(torch.int32)
+        self.node_off, self.B, self.N = off, B, int(batch_id.shape[0])

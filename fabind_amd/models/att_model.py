@@ -57,6 +57,16 @@ class EfficientMCAttModel(nn.Module):
         self.inter_layer = InteractionModule(hidden_size, hidden_size, hidden_size, rm_layernorm=args.rm_layernorm)
         self.dropout_p = dropout
 
+    def context(self, X, H, batch_id, segment_id, mask, is_global, compound_edge_index, LAS_edge_index,
+                batched_complex_coord_LAS, LAS_mask=None):
+        """Per-batch state for `FABindLayer.forward` / `MCAttEGNN.forward` (same arguments as `forward`): batch
+        layout, pair-embedding factors of the input H (att_model.py:198-206), and the ctx / inter graphs of X
+        (att_model.py:209-214; call `ctx.rebuild_graph(x)` again after moving the coordinates)."""
+        ctx = engine.StackContext(self, X, H, batch_id, segment_id, mask, is_global, compound_edge_index, LAS_edge_index,
+                                  batched_complex_coord_LAS)
+        ctx.rebuild_graph(X.reshape(-1, 3))
+        return ctx
+
     def forward(self, X, H, batch_id, segment_id, mask, is_global, compound_edge_index, LAS_edge_index,
                 batched_complex_coord_LAS, LAS_mask=None):
         """Same contract as the reference (att_model.py:170): X [N,1,3] is updated in place for the

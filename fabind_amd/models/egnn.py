@@ -26,7 +26,19 @@ class MC_E_GCL(nn.Module):
         self.coord_change_maximum = coord_change_maximum
 
     def forward(self, h, edge_index, coord, edge_attr=None, node_attr=None, batch_id=None):
-        raise NotImplementedError("MC_E_GCL runs inside the fused stack (fabind_amd.engine.gcl_layer)")
+        """Reference signature (egnn.py:130-144): h [N,H], edge_index [2,E] (any order), coord [N,1,3], batch_id [N]
+        (complex-contiguous) -> (h', coord').  Runs the same kernels as the stack (engine.gcl_layer) on a CSR built
+        from the given edge list."""
+        assert edge_attr is None and node_attr is None and batch_id is not None
+        if not h.is_cuda:
+            raise RuntimeError("fabind_amd: MC_E_GCL runs on a HIP device only (no CPU fallback)")
+        n = h.shape[0]
+        g = engine.EdgeListGraph(edge_index, n)
+        lay = engine.BatchOnlyLayout(batch_id)
+        pd = self.dropout.p if self.training else 0.0
+        h2, x2 = engine.gcl_layer(engine.gcl_params(self), h.float().contiguous(), coord.reshape(n, 3).float().contiguous(),
+                                  lay, g, float(self.coord_change_maximum), pd)
+        return h2, x2.reshape(coord.shape)
 
 
 class MC_Att_L(nn.Module):
@@ -65,6 +77,15 @@ class FABindLayer(nn.Module):
         super().__init__()
         self.gcl, self.att, self.index = getattr(gnn, "gcl_%d" % i), getattr(gnn, "att_%d" % i), i
 
+    def forward(self, h, x, ctx, return_attention=False):
+        """(h [N,H], x [N,3] or [N,1,3]) -> (h', x') through layer `index`: intra-graph message passing (MC_E_GCL),
+        cross attention + inter-graph attention (MC_Att_L), LAS geometry step -- reference egnn.py:402-449.
+        `ctx` = `EfficientMCAttModel.context(...)` (batch layout, current graph, pair-embedding factors)."""
+        shp = x.shape
+        h2, x2, alpha = ctx.layer(self.index, h, x.reshape(-1, 3))
+        out = (h2, x2.reshape(shp))
+        return out + (alpha,) if return_attention else out
+
 
 class MCAttEGNN(nn.Module):
     def __init__(self, args, in_node_nf, hidden_nf, out_node_nf, n_channel, in_edge_nf=0, act_fn=nn.SiLU(), n_layers=4,
@@ -97,5 +118,14 @@ class MCAttEGNN(nn.Module):
     def layers(self):
         return [FABindLayer(self, i) for i in range(self.n_layers)]
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("MCAttEGNN is driven by EfficientMCAttModel.forward (fabind_amd.engine.stack_forward)")
+    def forward(self, h, x, *reference_args, ctx=None, **reference_kwargs):
+        """linear_in -> n_layers x FABindLayer -> out_layer -> linear_out (egnn.py:392-466) -> (h_out, x_out).
+
+        The reference passes edge lists and the dense pair tensor positionally; here that state lives in `ctx`
+        (`EfficientMCAttModel.context(...)`: CSR graphs, factored pair embedding), so `ctx` is required."""
+        if ctx is None:
+            raise NotImplementedError("MCAttEGNN.forward needs ctx=EfficientMCAttModel.context(...): the dense "
+                                      "[B,P,C,H] pair tensor of the reference signature is never materialised")
+        shp = x.shape
+        h2, x2 = ctx.gnn(h, x.reshape(-1, 3))
+        return h2, x2.reshape(shp)

@@ -292,3 +292,83 @@ def test_train_mode_dropout_statistics():
             mod.p = 0.0
     X0, H0 = run(m, 3)
     assert torch.allclose(H0, He, rtol=1e-5, atol=1e-5) and torch.allclose(X0, Xe, rtol=1e-5, atol=1e-6)
+
+
+def test_fabind_layer_forward_composes_to_the_stack():
+    """north_star API: `FABindLayer.forward(h, x, ctx)` (one loop body of MCAttEGNN.forward, egnn.py:402-449).
+    Layer 0 reproduces the reference captures; all layers + out_layer (through MC_E_GCL.forward with the reference's
+    signature) + linear_out reproduce the stack output, and so does MCAttEGNN.forward(h, x, ctx=ctx)."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision("fp32")
+    g = load_npz("stack_tiny_it1")
+    m = _build_stack(g, dev)
+    inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in stack_inputs(g).items()}
+    args9 = (inp["H"], inp["batch_id"], inp["segment_id"], inp["mask"], inp["is_global"], inp["compound_edge_index"],
+             inp["LAS_edge_index"], inp["coord_LAS"])
+    with torch.no_grad():
+        ctx = m.context(inp["X"].clone(), *args9)
+        h = torch.nn.functional.linear(inp["H"], m.gnn.linear_in.weight, m.gnn.linear_in.bias)
+        x = inp["X"].clone()                                                  # [N,1,3]
+        layers = m.gnn.layers()
+        assert len(layers) == m.gnn.n_layers
+        h, x, alpha = layers[0](h, x, ctx, return_attention=True)
+        for k, got in (("att_0.h", h), ("att_0.alpha", alpha)):
+            ref = g["cap_" + k]
+            assert np.abs(got.cpu().numpy().reshape(ref.shape) - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
+        for layer in layers[1:]:
+            h, x = layer(h, x, ctx)
+        ei = torch.stack([ctx.g.row_ctx.long(), ctx.g.col_ctx.long()])
+        ei = ei[:, torch.randperm(ei.shape[1], device=dev)]                   # the reference signature takes any edge order
+        h, x = m.gnn.out_layer(h, ei, x, batch_id=inp["batch_id"])
+        Hout = torch.nn.functional.linear(h, m.gnn.linear_out.weight, m.gnn.linear_out.bias)
+        lig = g["in_mask"]
+        assert rmsd(x.cpu().numpy()[lig] * 5, g["out_X_f32"][lig] * 5) < 1e-4
+        assert np.abs(Hout.cpu().numpy() - g["out_H_f32"]).max() <= 1e-4 * max(1.0, np.abs(g["out_H_f32"]).max())
+        H2, x2 = m.gnn(inp["H"], inp["X"].clone(), ctx=ctx)
+        assert rmsd(x2.cpu().numpy()[lig] * 5, g["out_X_f32"][lig] * 5) < 1e-4
+        assert np.abs(H2.cpu().numpy() - g["out_H_f32"]).max() <= 1e-4 * max(1.0, np.abs(g["out_H_f32"]).max())
+        with pytest.raises(NotImplementedError):
+            m.gnn(inp["H"], inp["X"].clone(), None, None)
+
+
+def test_mc_e_gcl_forward_reference_signature_vs_oracle():
+    """MC_E_GCL.forward(h, edge_index, coord, batch_id=...) on an arbitrary (unsorted, asymmetric) edge list against the
+    CPU oracle's restatement of egnn.py:130-144, fp32 and bf16."""
+    from argparse import Namespace
+    from fabind_amd import engine
+    from fabind_amd.models.egnn import MC_E_GCL
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(11)
+    H, sizes = 64, [37, 5, 90]
+    N = sum(sizes)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    rows, cols = [], []
+    for b, n in enumerate(sizes):
+        e = n * 6
+        rows.append(torch.randint(0, n, (e,), generator=gen) + int(off[b]))
+        cols.append(torch.randint(0, n, (e,), generator=gen) + int(off[b]))
+    row, col = torch.cat(rows), torch.cat(cols)
+    keep = row != col
+    row, col = row[keep], col[keep]
+    h = torch.randn(N, H, generator=gen)
+    x = torch.randn(N, 1, 3, generator=gen)
+    torch.manual_seed(5)
+    mod = MC_E_GCL(Namespace(rm_F_norm=False, norm_type="per_sample"), H, H, H, 1, coord_change_maximum=2.0, dropout=0.1)
+    with torch.no_grad():
+        mod.coord_mlp[2].weight.mul_(300.0)                                    # xavier gain 0.001 would hide coordinate errors
+    sd = {k: v.detach().clone() for k, v in mod.state_dict().items()}
+    with torch.no_grad():
+        h_ref, x_ref = orc.gcl_forward(sd, "", h, row, col, x[:, 0], batch, len(sizes), 2.0)
+    mod = mod.to(dev).eval()
+    for prec, tol in (("fp32", 1e-4), ("bf16", 3e-2)):
+        engine.set_precision(prec)
+        try:
+            with torch.no_grad():
+                h2, x2 = mod(h.to(dev), torch.stack([row, col]).to(dev), x.to(dev), batch_id=batch.to(dev))
+        finally:
+            engine.set_precision("fp32")
+        assert x2.shape == x.shape
+        assert (h2.cpu() - h_ref).abs().max() <= tol * max(1.0, float(h_ref.abs().max())), prec
+        assert (x2[:, 0].cpu() - x_ref).abs().max() <= tol * max(1.0, float(x_ref.abs().max())), prec
