@@ -74,3 +74,38 @@ def test_model_inference():
     with torch.no_grad():
         coords, batch = m.inference(hetero_from_npz(g).to(dev))
     assert rmsd(coords.cpu().numpy(), g["inf_coords"]) < 1e-4
+
+
+def test_training_loop_reduces_the_loss():
+    """End-to-end training sanity on the HIP path (bf16, train mode: fused edge kernels with in-kernel message dropout,
+    node-level dropout, Gumbel noise): 40 AdamW steps on one fixed synthetic batch must cut the 6-term loss."""
+    from fabind_amd import engine, synthetic
+    from fabind_amd.models import get_model
+    from fabind_amd.models.model import compute_loss
+    dev = torch.device("cuda:0")
+    a = _args(64, 2, 1)
+    a.pocket_pred_hidden_size = 32
+    a.random_n_iter = False
+    torch.manual_seed(0)
+    engine.set_precision("bf16")
+    try:
+        m = get_model(a, _Logger(), dev).to(dev)
+        m.train()
+        base = synthetic.make_hetero_batch([(60, 9), (45, 14), (80, 6), (52, 11)], seed=3).to(dev)
+        opt = torch.optim.AdamW(m.parameters(), lr=2e-3, weight_decay=0.01)
+        losses = []
+        for step in range(40):
+            data = base.clone()
+            out = m(data, stage=1, train=True)
+            loss, _ = compute_loss(out, data)
+            assert torch.isfinite(loss)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_([p for p in m.parameters() if p.grad is not None], 1.0)
+            opt.step()
+            losses.append(float(loss.detach()))
+    finally:
+        engine.set_precision("fp32")
+    first, last = np.mean(losses[:5]), np.mean(losses[-5:])
+    print("training sanity: loss %.4f -> %.4f" % (first, last))
+    assert last < 0.8 * first, losses
