@@ -78,6 +78,12 @@ class Layout:
         s32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v
         self.desc_p = desc([[poff[b], P[b], coff[b], C[b], s32(lo(pair_off[b])), hi(pair_off[b]), C[b], 1] for b in range(B)])
         self.desc_c = desc([[coff[b], C[b], poff[b], P[b], s32(lo(pair_off[b])), hi(pair_off[b]), 1, C[b]] for b in range(B)])
+        # the same blocks with the protein side addressed IN PLACE in the node layout (rows off[b]+C[b] ...): protein-side
+        # arrays of the cross attention stay [N, .] and never get gathered / scattered (ligand rows are don't-care)
+        self.desc_pf = desc([[off[b] + C[b], P[b], coff[b], C[b], s32(lo(pair_off[b])), hi(pair_off[b]), C[b], 1]
+                             for b in range(B)])
+        self.desc_cf = desc([[coff[b], C[b], off[b] + C[b], P[b], s32(lo(pair_off[b])), hi(pair_off[b]), 1, C[b]]
+                             for b in range(B)])
         NO = n_pair_out
         self.NO = NO
         self.pb_groups = desc([[off[b] + C[b], P[b], coff[b] * NO, C[b] * NO, s32(lo(pair_off[b] * NO)),
@@ -288,30 +294,32 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
 
 
 def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
-    """CrossAttentionModule node path (cross_att.py:38-49) on compact protein / ligand arrays.
+    """CrossAttentionModule node path (cross_att.py:38-49).  The protein side (97 % of the nodes) is processed IN PLACE
+    in the node layout -- its ligand rows are don't-care (finite, zero gradient) -- only the ligand side is a compact
+    [sum C, H] array; the attention kernels address protein rows through the block descriptors.
     pdrop: RowAttentionBlock.dropout on the attention update before the residual (cross_att.py:128)."""
     fast = _fast(h, p["Wo_p"])
     od = ops.act_dtype()
     c16 = (lambda t: _b16(t)) if fast else (lambda t: t)
-    hp, hc = ops.take_rows(h, lay.p_index64), ops.take_rows(h, lay.c_index64)
+    hc = ops.take_rows(h, lay.c_index64)
     scale = 1.0 / math.sqrt(32.0)
     bias_p, bias_c = pairbias[2 * layer], pairbias[2 * layer + 1]
-    qg = ops.linear(c16(hp), p["Wqg_p"], p["bqg_p"])
-    kv = ops.linear(c16(hc), p["Wkv_p"])
-    og = ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_p, lay.B, lay.max_P, lay.max_C, scale)
-    hp = (hp + _drop(ops.linear(c16(og), p["Wo_p"], p["bo_p"]), pdrop)) if pdrop > 0.0 else \
-        ops.linear(c16(og), p["Wo_p"], p["bo_p"], residual=hp)
+    qg = ops.linear(c16(h), p["Wqg_p"], p["bqg_p"])                                     # [N, 256]
+    kv = ops.linear(c16(hc), p["Wkv_p"])                                                # [sum C, 256]
+    og = ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_pf, lay.B, lay.max_P, lay.max_C, scale)
+    hp = (h + _drop(ops.linear(c16(og), p["Wo_p"], p["bo_p"]), pdrop)) if pdrop > 0.0 else \
+        ops.linear(c16(og), p["Wo_p"], p["bo_p"], residual=h)
     hp16 = c16(hp)
     qg = ops.linear(c16(hc), p["Wqg_c"], p["bqg_c"])
-    kv = ops.linear(hp16, p["Wkv_c"])
-    og = ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_c, lay.B, lay.max_C, lay.max_P, scale)
+    kv = ops.linear(hp16, p["Wkv_c"])                                                   # [N, 256], protein rows used
+    og = ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
     hc = (hc + _drop(ops.linear(c16(og), p["Wo_c"], p["bo_c"]), pdrop)) if pdrop > 0.0 else \
         ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc)
     t = ops.linear(hp16, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU, out_dtype=od)
     hp = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp)
     t = ops.linear(c16(hc), p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU, out_dtype=od)
     hc = ops.linear(t, p["Wt2_c"], p["bt2_c"], residual=hc)
-    return ops.take_rows(torch.cat([hc, hp], 0), lay.inv_perm)
+    return ops.put_rows(hp, hc, lay.c_index64)
 
 
 def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv, pdrop=0.0, pdrop_row=0.0):

@@ -451,6 +451,34 @@ def take_rows(x, index64):
     return x.index_select(0, index64)
 
 
+class _PutRows(torch.autograd.Function):
+    """base[idx] = rows, in place on `base` (a fresh intermediate); gradients: d rows = dout[idx], d base = dout with
+    those rows zeroed."""
+
+    @staticmethod
+    def forward(ctx, base, rows, idx):
+        ctx.save_for_backward(idx)
+        base.index_copy_(0, idx, rows.to(base.dtype))
+        ctx.mark_dirty(base)
+        return base
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, = ctx.saved_tensors
+        d_rows = dout.index_select(0, idx)
+        d_base = dout.clone()
+        d_base.index_fill_(0, idx, 0.0)
+        return d_base, d_rows, None
+
+
+def put_rows(base, rows, index64):
+    """Row scatter of a small compact array into a node-layout array (index glue: pure data movement)."""
+    if _needs_grad(base, rows):
+        return _PutRows.apply(base, rows, index64)
+    base.index_copy_(0, index64, rows.to(base.dtype))
+    return base
+
+
 def select_rows(x, z, mask_u8):
     if _needs_grad(x, z):
         return torch.where(mask_u8.bool()[:, None], z, x)
@@ -463,7 +491,7 @@ def select_rows(x, z, mask_u8):
 class _CrossAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qg, kv, bias, lin_col, gate_col, desc, B, max_nq, max_nk, scale):
-        out = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
+        out = torch.zeros((qg.shape[0], 128), dtype=torch.float32, device=qg.device)   # rows outside every block: 0
         _, lse = K.cross_attn_fwd(qg[:, :128], kv[:, :128], kv[:, 128:], qg[:, 128:], bias, lin_col, gate_col, desc, B,
                                   max_nq, scale, out, want_lse=True, max_nk=max_nk)
         ctx.args = (lin_col, gate_col, desc, B, max_nq, max_nk, scale)
@@ -475,7 +503,7 @@ class _CrossAttn(torch.autograd.Function):
         qg, kv, bias, out, lse = ctx.saved_tensors
         lin_col, gate_col, desc, B, max_nq, max_nk, scale = ctx.args
         dout = dout.contiguous()
-        dqg, dkv, dbias = torch.empty_like(qg), torch.empty_like(kv), torch.empty_like(bias)
+        dqg, dkv, dbias = torch.zeros_like(qg), torch.zeros_like(kv), torch.empty_like(bias)   # uncovered rows: zero gradient
         dO = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
         Dv = torch.empty((qg.shape[0], 4), dtype=torch.float32, device=qg.device)
         check(load().fabind_cross_attn_bwd(ptr(qg), qg.stride(0), ptr(kv), kv.stride(0), ptr(bias), bias.stride(0), lin_col,
@@ -488,7 +516,7 @@ class _CrossAttn(torch.autograd.Function):
 def cross_attn(qg, kv, bias, lin_col, gate_col, desc, B, max_nq, max_nk, scale):
     if _needs_grad(qg, kv, bias):
         return _CrossAttn.apply(qg, kv, bias, lin_col, gate_col, desc, B, max_nq, max_nk, scale)
-    out = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
+    out = torch.zeros((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
     K.cross_attn_fwd(qg[:, :128], kv[:, :128], kv[:, 128:], qg[:, 128:], bias, lin_col, gate_col, desc, B, max_nq, scale, out,
                      max_nk=max_nk)
     return out
