@@ -261,37 +261,79 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
     if (RAW_BARRIER) barrier();            // the staging tile / sDot are reused by the next tile
 }
 
-// fp32 output (node-level residual stream): bias (+ residual) and direct 4-byte stores, no runtime switches
+// fp32 output (node-level residual stream): bias (+ residual).  The C fragments hold 16 consecutive columns per 16 lanes
+// (64-B pieces of 4 different rows per store); each wave therefore transposes its 64 x 64 sub-tile through a PRIVATE
+// LDS slab in two 32-row halves and writes 256-B row segments with 16-B lanes (residual rows are read the same way).
+// The slabs live in the (finished) pipeline stages; no work-group barrier is needed, LDS ops of one wave are in order.
+#define F32_SLAB_LD 68
 template <int BM_, bool HAS_R>
-__device__ __forceinline__ void gemm_epilogue_f32(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], int M, int N, int ldc, int m0,
-                                                  int n0) {
+__device__ __forceinline__ void gemm_epilogue_f32(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sStage, int stage_bytes,
+                                                  int M, int N, int ldc, int m0, int n0) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, cq = lane >> 4;
     float* C = (float*)p.C;
     const float* R = (const float*)p.R;
+    const bool vec = (ldc % 4 == 0) && (N % 4 == 0) && (((uintptr_t)C & 15) == 0) &&
+                     (!HAS_R || ((p.ldr % 4 == 0) && (((uintptr_t)R & 15) == 0))) &&
+                     stage_bytes >= (int)(blockDim.x / 64) * 32 * F32_SLAB_LD * 4;
+    if (!vec) {                                          // odd shapes: direct stores from the fragments
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + fr;
+            if (col >= N) continue;
+            const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm * 64 + i * 16 + cq * 4 + r;
+                    if (row < M) {
+                        float v = acc[i][j][r] + bv;
+                        if (HAS_R) v += R[(size_t)row * p.ldr + col];
+                        C[(size_t)row * ldc + col] = v;
+                    }
+                }
+        }
+        return;
+    }
+    float* my = sStage + (size_t)wave * (32 * F32_SLAB_LD);
+    float bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + wn * 64 + j * 16 + fr;
-        if (col >= N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
+        bv[j] = (p.bias && col < N) ? p.bias[col] : 0.f;
+    }
+    const int rr = lane >> 4, c4 = (lane & 15) * 4;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + cq * 4 + r;
-                if (row < M) {
-                    float v = acc[i][j][r] + bv;
-                    if (HAS_R) v += R[(size_t)row * p.ldr + col];
-                    C[(size_t)row * ldc + col] = v;
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    my[(ii * 16 + cq * 4 + r) * F32_SLAB_LD + j * 16 + fr] = acc[half * 2 + ii][j][r] + bv[j];
+        const int col = n0 + wn * 64 + c4;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int rl = k * 4 + rr;
+            const int row = m0 + wm * 64 + half * 32 + rl;
+            float4 v = *(const float4*)&my[rl * F32_SLAB_LD + c4];
+            if (row < M && col < N) {
+                if (HAS_R) {
+                    const float4 q = *(const float4*)&R[(size_t)row * p.ldr + col];
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                 }
+                *(float4*)&C[(size_t)row * ldc + col] = v;
             }
+        }
     }
 }
 
 // returns true when the fast epilogue applies (decided per launch on the host -> p.epi_fast)
 template <int BM_, bool RAW_BARRIER>
 __device__ __forceinline__ bool gemm_epilogue_dispatch(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sDot, bf16_t* sOut,
-                                                       int M, int N, int ldc, int m0, int n0) {
+                                                       int M, int N, int ldc, int m0, int n0, int stage_bytes = 0) {
 #define EPI(ACT, HC, HC2, HD) gemm_epilogue_fast<BM_, ACT, HC, HC2, HD, RAW_BARRIER>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true
     switch (p.epi_fast) {
         case 1: EPI(FB_ACT_NONE, true, false, false);
@@ -303,8 +345,8 @@ __device__ __forceinline__ bool gemm_epilogue_dispatch(const FabindGemmArgs& p, 
         case 7: gemm_epilogue_fast<BM_, FB_ACT_SILU, true, false, true, RAW_BARRIER, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 8: gemm_epilogue_fast<BM_, FB_ACT_RELU, true, false, true, RAW_BARRIER, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 11: gemm_epilogue_fast<BM_, FB_ACT_NONE, true, false, false, RAW_BARRIER, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
-        case 9: gemm_epilogue_f32<BM_, false>(p, acc, M, N, ldc, m0, n0); return true;
-        case 10: gemm_epilogue_f32<BM_, true>(p, acc, M, N, ldc, m0, n0); return true;
+        case 9: gemm_epilogue_f32<BM_, false>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0); return true;
+        case 10: gemm_epilogue_f32<BM_, true>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0); return true;
         default: return false;
     }
 #undef EPI
@@ -621,7 +663,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_pipe_kernel(FabindGemmArgs
         }
     }
     __syncthreads();
-    if (p.epi_fast && gemm_epilogue_dispatch<BM_, false>(p, acc, sDot, sT, M, N, ldc, m0, n0)) return;
+    if (p.epi_fast && gemm_epilogue_dispatch<BM_, false>(p, acc, sDot, sT, M, N, ldc, m0, n0, (int)lds_tile_bytes<WM, BK_, NSTAGE>())) return;
     gemm_epilogue<BM_>(p, acc, sDot, sT, M, N, ldc, a_row0, w_row0, c_off, m0, n0);
 }
 
@@ -719,7 +761,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_persist_kernel(FabindGemmA
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         if (++c_kt == nk) {
-            if (!(p.epi_fast && gemm_epilogue_dispatch<BM_, true>(p, acc, sDot, sOutP, M, N, ldc, (c_tile / nbx) * BM_, (c_tile % nbx) * BN)))
+            if (!(p.epi_fast && gemm_epilogue_dispatch<BM_, true>(p, acc, sDot, sOutP, M, N, ldc, (c_tile / nbx) * BM_, (c_tile % nbx) * BN, BM_ * OUT_LD * 2)))
                 gemm_epilogue<BM_, true>(p, acc, sDot, nullptr, M, N, ldc, 0, 0, 0, (c_tile / nbx) * BM_, (c_tile % nbx) * BN);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
