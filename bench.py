@@ -111,11 +111,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    # test hooks (one-GPU boxes): FABIND_BENCH_DEVICE pins every rank to one device, FABIND_BENCH_BACKEND=gloo swaps RCCL
+    # for gloo (gradients are then staged through the host) so that the N>1 control flow can be exercised anywhere
+    local = int(os.environ.get("FABIND_BENCH_DEVICE", local))
+    backend = os.environ.get("FABIND_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from fabind_amd import engine
     from fabind_amd import kernels as K
@@ -191,7 +198,7 @@ def main():
     prof = K.PROFILE
     K.PROFILE = None
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
     if world > 1:

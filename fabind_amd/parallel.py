@@ -49,10 +49,14 @@ def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, group=None):
     pending = []
     for bucket in _buckets(params, bucket_bytes):
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
+        dev = flat.device
+        if flat.is_cuda and dist.get_backend(group) == "gloo":      # CPU-only collective backend (tests): stage through the host
+            flat = flat.cpu()
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
-        pending.append((bucket, flat, work))
-    for bucket, flat, work in pending:
+        pending.append((bucket, flat, work, dev))
+    for bucket, flat, work, dev in pending:
         work.wait()
+        flat = flat.to(dev)
         flat.div_(world)
         off = 0
         for p in bucket:

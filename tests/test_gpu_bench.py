@@ -1,0 +1,45 @@
+"""GPU: bench.py's N>1 control flow (torch.distributed.run, per-rank batches, gradient all-reduce, barrier + MAX timing,
+one JSON line from rank 0) exercised with two ranks on ONE device through the gloo test hook (RCCL needs one GPU per rank)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+SMALL = ["--steps", "2", "--warmup", "1", "--batch", "3", "--n-prot", "70", "--n-lig", "9", "--hidden", "64", "--layers", "2",
+         "--no-cpu-baseline"]
+
+
+def test_bench_json_contract_single_rank():
+    r = _run([sys.executable, "bench.py"] + SMALL)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["steps"] == 2 and r["warmup"] == 1 and r["scaling"] == "weak" and r["vs_baseline"] is None
+    assert r["unit"] == "complexes/s" and r["higher_is_better"] is True and r["data"] == "synthetic"
+    assert abs(r["value"] - 3 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]
+    rf = r["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+
+
+def test_bench_two_ranks_control_flow():
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", "29533", "bench.py", "--gpus", "2"] + SMALL,
+             env={"FABIND_BENCH_DEVICE": "0", "FABIND_BENCH_BACKEND": "gloo"})
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 6
+    assert abs(r["value"] - 6 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]      # whole-job aggregate over both ranks
