@@ -1,4 +1,5 @@
-// Fused intra-graph edge pipeline of MC_E_GCL (reference models/egnn.py:68-128), forward-only bf16 path:
+// Fused intra-graph edge pipeline of MC_E_GCL (reference models/egnn.py:68-128), bf16 path -- forward kernel (its
+// adjoint, which recomputes these tensors tile by tile, follows below):
 //
 //   S1  = silu( A[row] + Bc[col] + rhohat * w_r )            (first edge_mlp Linear, evaluated per node: AB = h W1'^T)
 //   M   = silu( S1 W2^T + b2 )                               (second edge_mlp Linear)      -> messages m_e
@@ -46,40 +47,9 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return u;
 }
 
-// acc[i][j] (+)= X[64 x H] (LDS, swizzled) * Wp (packed [H/32][H/16][64 lanes][8]) for this wave's 64 columns
-template <int H>
-__device__ __forceinline__ void fe_gemm(const bf16_t* sX, const bf16_t* __restrict__ Wp, int wave, int lane,
-                                        f32x4_t (&acc)[4][4]) {
-    constexpr int NKS = H / 32, NG = H / 16;
-    const int fr = lane & 15, fq = lane >> 4;
-    const bf16x8_t* wp = (const bf16x8_t*)Wp + ((size_t)wave * 4) * 64 + lane;    // + (ks*NG + j)*64
-    bf16x8_t b0[4], b1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b0[j] = wp[(size_t)j * 64];
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        if (ks + 1 < NKS) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b1[j] = wp[((size_t)(ks + 1) * NG + j) * 64];
-        }
-        bf16x8_t a[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = i * 16 + fr;
-            a[i] = *(const bf16x8_t*)&sX[r * H + (((ks * 4 + fq) ^ (r & 7)) * 8)];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b0[j] = b1[j];
-    }
-}
-
-// Same contraction with the k-loop kept rolled (two k-steps per trip, B fragments ping-pong): the backward kernel
-// holds more live state (silu'(pre2), partial column sums) and a fully unrolled loop lets the scheduler hoist every
-// B-fragment load of the contraction at once.
+// acc[i][j] (+)= X[BM x H] (LDS, swizzled) * Wp (packed [H/32][H/16][64 lanes][8]) for this wave's 64 columns.
+// The k-loop is kept rolled (two k-steps per trip, B fragments ping-pong in registers): a fully unrolled loop lets
+// the scheduler hoist every B-fragment load of the contraction at once and spill.
 template <int H, int MI>
 __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* __restrict__ Wp, int wave, int lane,
                                                f32x4_t (&acc)[MI][4]) {
