@@ -207,7 +207,67 @@ def golden_stack_grad(mods, name, sizes, hidden, layers, seed):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def golden_stack_plus(mods, name, sizes, hidden, layers, n_iter, seed):
+    """FABind+ stack (FABind_plus/fabind/models/att_model.py:131-223): (X, H, pair_embed) + per-layer captures."""
+    torch.manual_seed(seed)
+    args = refshim.production_args_plus(hidden_size=hidden, mean_layers=layers, n_iter=n_iter)
+    model = mods["models.att_model"].EfficientMCAttModel(
+        args, hidden, hidden, 1, n_edge_feats=0, n_layers=layers, n_iter=n_iter, inter_cutoff=10.0, intra_cutoff=8.0,
+        normalize_coord=lambda x: x / 5.0, unnormalize_coord=lambda x: x * 5.0).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("coord_mlp.linear2.weight"):          # xavier gain 1e-3 in the reference: lift it so atoms move
+                p.mul_(COORD_GAIN)
+    batch = synthetic.make_stack_batch(sizes, hidden, seed=seed)
+    cap, hs = {}, []
+
+    def hook(label):
+        def f(mod, inp, out):
+            cap[label + ".h"] = _np(out[0])
+            cap[label + ".x"] = _np(out[1].reshape(-1, 3))
+            if len(out) > 2:
+                cap[label + ".alpha"] = _np(out[2])
+        return f
+
+    res = {}
+    for dt, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
+        m = model.to(dt)
+        if tag == "f32":
+            for i in range(layers):
+                hs.append(getattr(m.gnn, "gcl_%d" % i).register_forward_hook(hook("gcl_%d" % i)))
+                hs.append(getattr(m.gnn, "att_%d" % i).register_forward_hook(hook("att_%d" % i)))
+        with torch.no_grad():
+            X, H, Z = m(batch["X"].clone().to(dt), batch["H"].clone().to(dt), batch["batch_id"], batch["segment_id"],
+                        batch["mask"], batch["is_global"], batch["compound_edge_index"], batch["LAS_edge_index"],
+                        batch["coord_LAS"].clone().to(dt))
+        res["out_X_" + tag], res["out_H_" + tag], res["out_Z_" + tag] = _np(X), _np(H), _np(Z)
+        for h in hs:
+            h.remove()
+        hs = []
+    model.to(torch.float32)
+    moved = np.sqrt(((res["out_X_f32"] - _np(batch["X"])) ** 2).sum(-1)).max() * 5
+    noise = np.sqrt(((res["out_X_f32"] - res["out_X_f64"]) ** 2).sum(-1)).max() * 5
+    print("%s: max displacement %.3f A, f32-vs-f64 %.2e A, |Z| max %.3f" % (name, moved, noise, np.abs(res["out_Z_f32"]).max()))
+    save = {("in_" + k): _np(v) for k, v in batch.items() if torch.is_tensor(v)}
+    save["sizes"] = np.array(sizes)
+    save["cfg"] = np.array([hidden, layers, n_iter, seed])
+    save.update({"w_" + k: _np(v) for k, v in model.state_dict().items()})
+    save.update(res)
+    save.update({"cap_" + k: v for k, v in cap.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
+def main_plus():
+    torch.set_num_threads(1)
+    os.makedirs(OUT, exist_ok=True)
+    mods = refshim.load_reference("FABind_plus")
+    golden_stack_plus(mods, "plus_stack_tiny_it1", [(24, 7), (31, 5)], 32, 2, 1, seed=10)
+    golden_stack_plus(mods, "plus_stack_tiny_it2", [(40, 9), (26, 6), (33, 12)], 64, 3, 2, seed=11)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "plus":
+        return main_plus()
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
     mods = refshim.load_reference("FABind")

@@ -184,12 +184,14 @@ def _install_stubs():
     tg.utils, tg.data = tgu, tgd
     sys.modules.update({"torch_geometric": tg, "torch_geometric.utils": tgu, "torch_geometric.data": tgd})
 
-    for name in ("torchmetrics", "rdkit", "rdkit.Chem", "rdkit.Chem.rdMolTransforms"):
+    for name in ("torchmetrics", "rdkit", "rdkit.Chem", "rdkit.Chem.rdMolTransforms", "rdkit.Geometry"):
         if name not in sys.modules:
             m = types.ModuleType(name)
             sys.modules[name] = m
     sys.modules["rdkit"].Chem = sys.modules["rdkit.Chem"]
     sys.modules["rdkit.Chem"].rdMolTransforms = sys.modules["rdkit.Chem.rdMolTransforms"]
+    sys.modules["rdkit"].Geometry = sys.modules["rdkit.Geometry"]
+    sys.modules["rdkit.Geometry"].Point3D = object
 
     class _Any:
         def __init__(self, *a, **k):
@@ -243,4 +245,21 @@ def production_args(**over):
         rm_F_norm=False, fix_pocket=False, rm_LAS_constrained_optim=False,
     )
     a.update(over)
+    return Namespace(**a)
+
+
+def production_args_plus(**over):
+    """FABind+ (FABind_plus/fabind/test_regression_fabind.py:42; SURVEY.md App. C) on top of the v1 production flags;
+    every field FABind_plus/fabind/utils/parsing.py defines that the model constructors read."""
+    a = vars(production_args(mean_layers=5))
+    a.update(dict(
+        use_ln_mlp=True, mlp_hidden_scale=1, dropout=0.1, mha_heads=4, rel_dis_pair_bias="no",
+        inter_additional_mlp=False, only_last_LAS=False, geom_reg_steps=1, permutation_invariant=True,
+        use_for_radius_pred="ligand", dis_map_thres=15.0, pocket_radius_buffer=5.0, min_pocket_radius=20.0,
+        force_fix_radius=False, use_clustering=False, dbscan_eps=9.0, dbscan_min_samples=2, choose_cluster_prob=0.5,
+        stack_mlp=False, confidence_dropout=0.1, confidence_use_ln_mlp=False, confidence_mlp_hidden_scale=2,
+        train_ligand_torsion_noise=False, train_pred_pocket_noise=0.0, infer_dropout=False, confidence_training=False,
+        ranking_loss="logsigmoid", wandb=False, num_copies=1, keep_cls_2A=False, symmetric_rmsd=None))
+    a.update(over)
+    from argparse import Namespace
     return Namespace(**a)

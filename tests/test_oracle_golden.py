@@ -129,3 +129,44 @@ def test_model_gradients_sampled():
         assert np.abs(got[idx].numpy() - smp).max() <= 2e-3 * max(np.abs(smp).max(), ref_n / max(got.numel(), 1) ** 0.5) + 1e-7, k
         checked += 1
     assert checked > 200
+
+
+# ------------------------------------------------------------------------------------------------
+# FABind+ stack: oracle/fabind_plus_oracle.py against reference-run goldens
+# ------------------------------------------------------------------------------------------------
+import fabind_plus_oracle as porc  # noqa: E402
+
+PLUS = ["plus_stack_tiny_it1", "plus_stack_tiny_it2"]
+
+
+def _run_plus(g, dtype, cap=None):
+    sd, inp = weights(g, dtype), stack_inputs(g, dtype)
+    hidden, layers, n_iter, _ = [int(v) for v in g["cfg"]]
+    with torch.no_grad():
+        return porc.stack_forward(sd, "", inp["X"], inp["H"], inp["batch_id"], inp["segment_id"], inp["mask"],
+                                  inp["is_global"], inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"],
+                                  layers, n_iter, capture=cap)
+
+
+@pytest.mark.parametrize("name", PLUS)
+def test_plus_stack_forward_matches_reference(name):
+    g = load_npz(name)
+    cap = {}
+    X, H, Z = _run_plus(g, torch.float32, cap)
+    assert rmsd(X.numpy() * 5, g["out_X_f32"] * 5) < 2e-5
+    assert np.abs(H.numpy() - g["out_H_f32"]).max() <= 2e-5 * max(1.0, np.abs(g["out_H_f32"]).max())
+    assert Z.shape == g["out_Z_f32"].shape                                   # [B, Pmax, Cmax, H] pair embedding, threaded
+    assert np.abs(Z.numpy() - g["out_Z_f32"]).max() <= 2e-5 * max(1.0, np.abs(g["out_Z_f32"]).max())
+    for k in ("gcl_0.h", "gcl_0.x", "att_0.h", "att_0.x", "att_0.alpha", "gcl_1.h", "att_1.x"):
+        ref = g["cap_" + k]
+        got = cap[k].numpy().reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
+
+
+@pytest.mark.parametrize("name", PLUS)
+def test_plus_stack_forward_fp64_twin(name):
+    g = load_npz(name)
+    X, H, Z = _run_plus(g, torch.float64)
+    assert rmsd(X.numpy() * 5, g["out_X_f64"] * 5) < 1e-9
+    assert np.abs(H.numpy() - g["out_H_f64"]).max() < 1e-8
+    assert np.abs(Z.numpy() - g["out_Z_f64"]).max() < 1e-8
