@@ -72,3 +72,74 @@ extern "C" int fabind_layernorm_bwd(const float* x, const float* w, const float*
     FB_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// FABind+ LN-MLPs (FABind_plus/fabind/models/model_utils.py:10-74): LayerNorm in front of every MLP.
+// Row LayerNorm with free input / output types and strides; columns [C, pad_to) of the output are zero-filled so that the
+// result can feed a GEMM whose contraction dimension is padded to a multiple of 8.  One wave per row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const void* __restrict__ x, int x_dt, int ldx,
+                                                             const float* __restrict__ w, const float* __restrict__ b,
+                                                             float eps, int R, int C, void* y, int y_dt, int ldy, int pad_to) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const size_t xo = (size_t)r * ldx, yo = (size_t)r * ldy;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += ld_any(x, x_dt, xo + c);
+    const float mu = wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) { const float t = ld_any(x, x_dt, xo + c) - mu; v += t * t; }
+    const float rs = rsqrtf(wave_sum(v) / (float)C + eps);
+    for (int c = lane; c < C; c += 64) st_any(y, y_dt, yo + c, (ld_any(x, x_dt, xo + c) - mu) * rs * w[c] + b[c]);
+    for (int c = C + lane; c < pad_to; c += 64) st_any(y, y_dt, yo + c, 0.f);
+}
+extern "C" int fabind_layernorm_rows(const void* x, int x_dt, int ldx, const float* w, const float* b, float eps, int R, int C,
+                                     void* y, int y_dt, int ldy, int pad_to, hipStream_t stream) {
+    if (R <= 0) return 0;
+    FB_REQUIRE(pad_to <= ldy && C <= ldx, "fabind_layernorm_rows: pad_to <= ldy, C <= ldx");
+    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, x, x_dt, ldx, w, b, eps, R, C, y, y_dt,
+                       ldy, pad_to);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// LayerNorm of the concatenated edge input of MC_E_GCL, [h[row] | h[col] | rhohat] (2H+1 columns,
+// FABind_plus/fabind/models/egnn.py:52-58 + model_utils.py:44-46), evaluated while gathering: the concatenation is
+// never written un-normalised.  One wave per edge; output columns [2H+1, pad_to) are zero.
+__global__ __launch_bounds__(256) void edge_ln_concat_kernel(const float* __restrict__ h, int ldh, int H,
+                                                             const int* __restrict__ row, const int* __restrict__ col,
+                                                             const float* __restrict__ rhohat, const float* __restrict__ w,
+                                                             const float* __restrict__ b, float eps, int E, void* y, int y_dt,
+                                                             int ldy, int pad_to) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;
+    const float* hr = h + (size_t)row[e] * ldh;
+    const float* hc = h + (size_t)col[e] * ldh;
+    const float rh = rhohat[e];
+    const int C = 2 * H + 1;
+    float s = 0.f;
+    for (int c = lane; c < H; c += 64) s += hr[c] + hc[c];
+    const float mu = (wave_sum(s) + rh) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < H; c += 64) { const float t0 = hr[c] - mu, t1 = hc[c] - mu; v += t0 * t0 + t1 * t1; }
+    const float rs = rsqrtf((wave_sum(v) + (rh - mu) * (rh - mu)) / (float)C + eps);
+    const size_t yo = (size_t)e * ldy;
+    for (int c = lane; c < H; c += 64) {
+        st_any(y, y_dt, yo + c, (hr[c] - mu) * rs * w[c] + b[c]);
+        st_any(y, y_dt, yo + H + c, (hc[c] - mu) * rs * w[H + c] + b[H + c]);
+    }
+    if (lane == 0) st_any(y, y_dt, yo + 2 * H, (rh - mu) * rs * w[2 * H] + b[2 * H]);
+    for (int c = C + lane; c < pad_to; c += 64) st_any(y, y_dt, yo + c, 0.f);
+}
+extern "C" int fabind_edge_ln_concat(const float* h, int ldh, int H, const int* row, const int* col, const float* rhohat,
+                                     const float* w, const float* b, float eps, int E, void* y, int y_dt, int ldy, int pad_to,
+                                     hipStream_t stream) {
+    if (E <= 0) return 0;
+    FB_REQUIRE(pad_to <= ldy && 2 * H + 1 <= pad_to, "fabind_edge_ln_concat: 2H+1 <= pad_to <= ldy");
+    hipLaunchKernelGGL(edge_ln_concat_kernel, dim3((E + 3) / 4), dim3(256), 0, stream, h, ldh, H, row, col, rhohat, w, b, eps, E,
+                       y, y_dt, ldy, pad_to);
+    FB_CHECK_LAUNCH();
+    return 0;
+}

@@ -163,6 +163,25 @@ def gcl_pre(AB, H, row, col, rhohat, w_r, out_dtype, act=ACT_NONE, want_dact=Fal
     return (pre, dact) if want_dact else pre
 
 
+def layernorm_rows(x, w, b, out_dtype, pad_to=None, eps=1e-5):
+    """Row LayerNorm -> [R, pad_to] (columns beyond C zero): FABind+ LN-MLP front end."""
+    R, C = x.shape
+    pad_to = pad_to or C
+    y = torch.empty((R, pad_to), dtype=out_dtype, device=x.device)
+    check(_lib.load().fabind_layernorm_rows(ptr(x), dt_code(x.dtype), _ld(x), ptr(w), ptr(b), eps, R, C, ptr(y),
+                                            dt_code(out_dtype), pad_to, pad_to, stream()), "fabind_layernorm_rows")
+    return y
+
+
+def edge_ln_concat(h, row, col, rhohat, w, b, out_dtype, pad_to, eps=1e-5):
+    """LayerNorm([h[row] | h[col] | rhohat]) -> [E, pad_to] without materialising the concatenation."""
+    E, H = row.shape[0], h.shape[1]
+    y = torch.empty((E, pad_to), dtype=out_dtype, device=h.device)
+    check(_lib.load().fabind_edge_ln_concat(ptr(h), _ld(h), H, ptr(row), ptr(col), ptr(rhohat), ptr(w), ptr(b), eps, E, ptr(y),
+                                            dt_code(out_dtype), pad_to, pad_to, stream()), "fabind_edge_ln_concat")
+    return y
+
+
 def segment_sum(Z, rowptr, n_rows, act=ACT_NONE, eidx=None, out=None):
     H = Z.shape[1]
     if out is None:

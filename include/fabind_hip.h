@@ -225,6 +225,14 @@ int fabind_select_rows(const float* x, const float* z, const uint8_t* mask, int 
 
 /* LayerNorm over the last dim (models/model.py:15,29): y = (x-mean)*rstd*w + b; backward returns dx and
  * per-block partial sums of dw/db ([ceil(R/4), C] each, reduce with fabind_colsum). */
+/* FABind+ LN-MLPs (FABind_plus/fabind/models/model_utils.py:10-74).  fabind_layernorm_rows: row LayerNorm with free
+ * input / output dtypes (FB_DT_*) and strides; output columns [C, pad_to) are zero-filled (GEMM K padding).
+ * fabind_edge_ln_concat: LayerNorm over the concatenated edge input [h[row] | h[col] | rhohat] (2H+1 columns,
+ * FABind_plus/fabind/models/egnn.py:52-58) evaluated while gathering. */
+int fabind_layernorm_rows(const void* x, int x_dt, int ldx, const float* w, const float* b, float eps, int R, int C, void* y,
+                          int y_dt, int ldy, int pad_to, hipStream_t stream);
+int fabind_edge_ln_concat(const float* h, int ldh, int H, const int* row, const int* col, const float* rhohat, const float* w,
+                          const float* b, float eps, int E, void* y, int y_dt, int ldy, int pad_to, hipStream_t stream);
 int fabind_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int R, int C, float* y, float* mean,
                          float* rstd, hipStream_t stream);
 int fabind_layernorm_bwd(const float* x, const float* w, const float* dy, const float* mean, const float* rstd, int R,

@@ -1,0 +1,78 @@
+"""GPU: the FABind+ layer stack (fabind_amd.plus) against golden vectors captured from the reference
+FABind_plus tree (oracle/make_golden.py plus) -- coordinates, node features and the threaded pair embedding."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_npz, rmsd, stack_inputs, weights
+
+pytestmark = pytest.mark.gpu
+PLUS = ["plus_stack_tiny_it1", "plus_stack_tiny_it2"]
+
+
+def _args(hidden, layers, n_iter):
+    from argparse import Namespace
+    return Namespace(
+        mode=5, n_iter=n_iter, mean_layers=layers, hidden_size=hidden, refine="refine_coord", coordinate_scale=5.0,
+        geometry_reg_step_size=0.001, rm_layernorm=True, add_attn_pair_bias=True, explicit_pair_embed=True,
+        add_cross_attn_layer=True, norm_type="per_sample", random_n_iter=True, inter_cutoff=10.0, intra_cutoff=8.0,
+        ablation_no_attention=False, ablation_no_attention_with_cross_attn=False, keep_trig_attn=False, opm=False,
+        rm_F_norm=False, fix_pocket=False, rm_LAS_constrained_optim=False, use_ln_mlp=True, mlp_hidden_scale=1, dropout=0.1,
+        mha_heads=4, rel_dis_pair_bias="no", inter_additional_mlp=False, only_last_LAS=False, geom_reg_steps=1)
+
+
+def _build(g, dev):
+    from fabind_amd.plus.models.att_model import EfficientMCAttModel
+    hidden, layers, n_iter, _ = [int(v) for v in g["cfg"]]
+    m = EfficientMCAttModel(_args(hidden, layers, n_iter), hidden, hidden, 1, n_layers=layers, n_iter=n_iter,
+                            normalize_coord=lambda x: x / 5.0, unnormalize_coord=lambda x: x * 5.0)
+    m.load_state_dict(weights(g), strict=True)                 # reference parameter names and shapes
+    return m.to(dev).eval()
+
+
+def _run(m, inp, dev):
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    return m(t["X"].clone(), t["H"], t["batch_id"], t["segment_id"], t["mask"], t["is_global"], t["compound_edge_index"],
+             t["LAS_edge_index"], t["coord_LAS"])
+
+
+@pytest.mark.parametrize("name", PLUS)
+def test_plus_stack_forward_fp32_matches_reference(name):
+    from fabind_amd import engine
+    from fabind_amd.plus import engine as pengine
+    dev = torch.device("cuda:0")
+    engine.set_precision("fp32")
+    g = load_npz(name)
+    m = _build(g, dev)
+    cap = {}
+    pengine.DEBUG_CAPTURE = cap
+    try:
+        X, H, Z = _run(m, stack_inputs(g), dev)
+    finally:
+        pengine.DEBUG_CAPTURE = None
+    for k in ("gcl_0.h", "gcl_0.x", "att_0.h", "att_0.x", "att_0.alpha", "gcl_1.h", "att_1.x"):
+        ref = g["cap_" + k]
+        got = cap[k].cpu().numpy().reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
+    lig = g["in_mask"]
+    assert rmsd(X.cpu().numpy()[lig] * 5, g["out_X_f32"][lig] * 5) < 1e-4            # north_star gate: 1e-4 A RMSD
+    assert np.abs(H.cpu().numpy() - g["out_H_f32"]).max() <= 1e-4 * max(1.0, np.abs(g["out_H_f32"]).max())
+    assert Z.shape == g["out_Z_f32"].shape
+    assert np.abs(Z.cpu().numpy() - g["out_Z_f32"]).max() <= 1e-4 * max(1.0, np.abs(g["out_Z_f32"]).max())
+
+
+@pytest.mark.parametrize("name", PLUS)
+def test_plus_stack_forward_bf16_close(name):
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision("bf16")
+    try:
+        g = load_npz(name)
+        X, H, Z = _run(_build(g, dev), stack_inputs(g), dev)
+    finally:
+        engine.set_precision("fp32")
+    lig = g["in_mask"]
+    gap = rmsd(X.cpu().numpy()[lig] * 5, g["out_X_f32"][lig] * 5)
+    print("FABind+ bf16 ligand RMSD gap vs reference [A]:", name, gap)
+    assert gap < 5e-2
+    assert np.abs(Z.cpu().numpy() - g["out_Z_f32"]).max() <= 5e-2 * max(1.0, np.abs(g["out_Z_f32"]).max())
