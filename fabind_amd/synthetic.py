@@ -182,7 +182,7 @@ def make_hetero_batch(sizes, seed=0, pocket_radius=20.0, feat_scale=0.1, prot_fe
         "cx", "cx_las", "cx_seg", "cx_mask", "cx_glb", "cx_batch", "cx_c2c", "cx_LAS",
         "wx", "wx_las", "wx_seg", "wx_mask", "wx_glb", "wx_batch", "wx_c2c", "wx_LAS",
         "bond_x", "bond_batch", "las_x", "las_batch", "node_xyz", "node_xyz_whole", "coords",
-        "coords_center", "pocket_idx", "dis_map")}
+        "coords_center", "pocket_idx", "dis_map", "pocket_residue_center")}
     off_c = off_w = 0
     for b, (npr, nl) in enumerate(sizes):
         c = make_complex(npr, nl, seed * 1000 + b)
@@ -234,6 +234,7 @@ def make_hetero_batch(sizes, seed=0, pocket_radius=20.0, feat_scale=0.1, prot_fe
         acc["node_xyz_whole"].append(prot)
         acc["coords"].append(lig_true)
         acc["coords_center"].append(com[None])
+        acc["pocket_residue_center"].append(pocket.mean(0, keepdim=True))      # FABind+ pocket-centred frame (model.py:176-183)
         acc["pocket_idx"].append(keep.int())
         dm = torch.cdist(pocket, lig_true).clamp(max=10.0)
         acc["dis_map"].append(dm.flatten())
@@ -263,6 +264,7 @@ def make_hetero_batch(sizes, seed=0, pocket_radius=20.0, feat_scale=0.1, prot_fe
     data.node_xyz_whole = cat("node_xyz_whole")
     data.coords = cat("coords")
     data.coords_center = cat("coords_center")
+    data.pocket_residue_center = cat("pocket_residue_center")
     data.pocket_idx = cat("pocket_idx")
     data.dis_map = cat("dis_map")
     data.pdb = ["syn%d_%d" % (seed, b) for b in range(len(sizes))]

@@ -126,3 +126,150 @@ def stack_forward(sd, pre, X, H, batch_id, segment_id, mask, is_global, compound
                                          n_layers, scale, step, capture if last else None)
             x = torch.where(mask[:, None], z, x)
     return x[:, None], Hout, zout
+
+
+# ------------------------------------------------------------------------------------------------
+# full model: FABindPlus.forward / .inference (FABind_plus/fabind/models/model.py:63-670), eval mode,
+# use_for_radius_pred='ligand', no clustering, no confidence head
+# ------------------------------------------------------------------------------------------------
+from fabind_oracle import _assemble, _soft_center, _to_dense, get_keepNode_tensor, gumbel_softmax_no_random  # noqa: E402
+
+PLUS_CFG = dict(coordinate_scale=5.0, mean_layers=5, n_iter=8, pocket_pred_layers=1, pocket_pred_n_iter=1, inter_cutoff=10.0,
+                intra_cutoff=8.0, gs_tau=1.0, gs_hard=False, geometry_reg_step_size=1e-3, pocket_radius_buffer=5.0,
+                min_pocket_radius=20.0, dis_map_thres=15.0)
+
+
+def _pocket_head(sd, cfg, data):
+    """model.py:72-146: whole-protein pocket model, classifier (LN-MLP), radius head, soft Gumbel centre."""
+    scale = cfg["coordinate_scale"]
+    c_batch, pw_batch = data["compound"].batch, data["protein_whole"].batch
+    w = data["complex_whole_protein"]
+    B = int(w.batch.max()) + 1
+    c_emb = _lin(sd, "compound_linear_whole_protein", data["compound"].node_feats)
+    p_emb = _lin(sd, "protein_linear_whole_protein", data["protein_whole"].node_feats)
+    h0 = _lin(sd, "embedding_shrink", _assemble(sd["glb_c"], sd["glb_p"], c_emb, c_batch, p_emb, pw_batch, B))
+    _, hw, _ = stack_forward(sd, "pocket_pred_model.", (w.node_coords / scale)[:, None], h0, w.batch, w.segment, w.mask,
+                             w.is_global, data["complex_whole_protein", "c2c", "complex_whole_protein"].edge_index,
+                             data["complex_whole_protein", "LAS", "complex_whole_protein"].edge_index,
+                             (w.node_coords_LAS / scale)[:, None], cfg["pocket_pred_layers"], cfg["pocket_pred_n_iter"], scale,
+                             cfg["inter_cutoff"], cfg["intra_cutoff"], cfg["geometry_reg_step_size"])
+    hw = _lin(sd, "embedding_enlarge", hw)
+    segw = w.segment.to(torch.long)
+    c_out = hw[(segw == 0) & ~w.is_global]
+    p_out = hw[(segw == 1) & ~w.is_global]
+    c_dense, _ = _to_dense(c_out, c_batch, B)
+    radius = torch.relu(ln_mlp(sd, "pocket_radius_head.", c_dense.sum(1), False))            # [B,1]
+    p_dense, p_mask = _to_dense(p_out, pw_batch, B)
+    logits = ln_mlp(sd, "protein_to_pocket.", p_dense, False)[..., 0] * p_mask
+    xyz_dense, _ = _to_dense(data.node_xyz_whole, pw_batch, B)
+    return dict(B=B, c_out=c_out, p_out=p_out, p_dense=p_dense, p_mask=p_mask, logits=logits, xyz_dense=xyz_dense,
+                radius=radius)
+
+
+def _stage2_graph(sd, cfg, data, head, center, shift_coords):
+    """model.py:212-330 (and inference 518-600): radius-based crop, pocket-centred frame."""
+    B = head["B"]
+    c_batch, pw_batch = data["compound"].batch, data["protein_whole"].batch
+    hs, xs, xl, seg, msk, glb, bid, c2c, las, pk, pkb, dm, bias = [], [], [], [], [], [], [], [], [], [], [], [], []
+    off, less5 = 0, 0
+    coords = data.coords.clone()
+    for b in range(B):
+        prot = data.node_xyz_whole[pw_batch == b]
+        buf = cfg["pocket_radius_buffer"]
+        r = float(head["radius"][b] * buf) if buf <= 2.0 else float(head["radius"][b] + buf)
+        r = max(r, cfg["min_pocket_radius"])
+        keep = get_keepNode_tensor(prot, r, center[b].detach())
+        if keep.sum() < 5:
+            keep[:100] = True
+            less5 += 1
+        pemb = head["p_dense"][b][head["p_mask"][b]][keep]
+        cemb = head["c_out"][c_batch == b]
+        pc = prot[keep]
+        ctr = pc.mean(0, keepdim=True)
+        pc = pc - ctr
+        bias.append(ctr[0])
+        if shift_coords:
+            coords[c_batch == b] = coords[c_batch == b] - ctr
+        li = data["compound"].node_coords[c_batch == b]
+        nl, npk = li.shape[0], pc.shape[0]
+        n = nl + npk + 2
+        hs += [sd["glb_c"], cemb, sd["glb_p"], pemb]
+        z1 = torch.zeros(1, 3, dtype=pc.dtype)
+        xs += [z1, li - li.mean(0, keepdim=True) + pc.mean(0, keepdim=True), z1, pc]
+        xl += [z1, data["compound"].rdkit_coords[c_batch == b], z1, torch.zeros_like(pc)]
+        s = torch.zeros(n); s[nl + 1:] = 1
+        m = torch.zeros(n, dtype=torch.bool); m[:nl + 2] = True
+        g = torch.zeros(n, dtype=torch.bool); g[0] = True; g[nl + 1] = True
+        seg.append(s), msk.append(m), glb.append(g), bid.append(torch.full((n,), b, dtype=torch.long))
+        c2c.append(data["compound_atom_edge_list"].x[data["compound_atom_edge_list"].batch == b].T + off)
+        las.append(data["LAS_edge_list"].x[data["LAS_edge_list"].batch == b].T + off)
+        pk.append(pc), pkb.append(torch.full((npk,), b, dtype=torch.long))
+        dm.append(torch.cdist(pc, li.to(torch.float32) - ctr).flatten().clamp(max=cfg["dis_map_thres"]))
+        off += n
+    return dict(H=torch.cat(hs), X=torch.cat(xs).float(), XL=torch.cat(xl).float(), segment=torch.cat(seg),
+                mask=torch.cat(msk), is_global=torch.cat(glb), batch=torch.cat(bid), c2c=torch.cat(c2c, 1),
+                LAS=torch.cat(las, 1), pocket_xyz=torch.cat(pk), pocket_batch=torch.cat(pkb), dis_map=torch.cat(dm),
+                less5=less5, bias=torch.stack(bias), coords=coords)
+
+
+def _complex(sd, cfg, g):
+    scale = cfg["coordinate_scale"]
+    Xo, Ho, Z = stack_forward(sd, "complex_model.", (g["X"] / scale)[:, None], g["H"], g["batch"], g["segment"], g["mask"],
+                              g["is_global"], g["c2c"], g["LAS"], (g["XL"] / scale)[:, None], cfg["mean_layers"], cfg["n_iter"],
+                              scale, cfg["inter_cutoff"], cfg["intra_cutoff"], cfg["geometry_reg_step_size"])
+    segl = g["segment"].to(torch.long)
+    cflag, pflag = (segl == 0) & ~g["is_global"], (segl == 1) & ~g["is_global"]
+    return Xo, Ho, Z, cflag, pflag, Xo[cflag][:, 0]
+
+
+def model_forward(sd, cfg, data, stage=2):
+    """FABindPlus.forward(data, stage, train=False), eval mode -> the reference's 13-tuple plus the shifted data.coords
+    (the reference shifts `data.coords` in place and the caller's loss reads it afterwards, utils/training.py:55-60)."""
+    scale, thres = cfg["coordinate_scale"], cfg["dis_map_thres"]
+    head = _pocket_head(sd, cfg, data)
+    B = head["B"]
+    c_batch = data["compound"].batch
+    center = _soft_center(head["logits"], head["p_mask"], head["xyz_dense"], cfg["gs_tau"], cfg["gs_hard"])
+    pocket_cls, _ = _to_dense(data.pocket_idx, data["protein_whole"].batch, B)
+    if stage == 1:
+        cx = data["complex"]
+        X = cx.node_coords.clone()
+        coords = data.coords.clone()
+        nl = torch.bincount(c_batch, minlength=B)
+        for b in range(B):
+            idx = torch.nonzero(cx.batch == b)[:, 0]
+            n = int(nl[b])
+            lig, poc = idx[1:n + 1], idx[n + 2:]
+            X[lig] = X[lig] - X[lig].mean(0)
+            X[poc] = X[poc] - data.pocket_residue_center[b][None]
+            coords[c_batch == b] = coords[c_batch == b] - data.pocket_residue_center[b][None]
+        pemb = head["p_out"][data["pocket"].keepNode]
+        g = dict(H=_assemble(sd["glb_c"], sd["glb_p"], head["c_out"], c_batch, pemb, data["pocket"].batch, B), X=X,
+                 XL=cx.node_coords_LAS, segment=cx.segment, mask=cx.mask, is_global=cx.is_global, batch=cx.batch,
+                 c2c=data["complex", "c2c", "complex"].edge_index, LAS=data["complex", "LAS", "complex"].edge_index,
+                 pocket_xyz=data.node_xyz, pocket_batch=data["pocket"].batch, dis_map=data.dis_map, less5=0,
+                 bias=torch.zeros(B, 3), coords=coords)
+    else:
+        g = _stage2_graph(sd, cfg, data, head, center, shift_coords=True)
+    Xo, Ho, Z, cflag, pflag, coords_n = _complex(sd, cfg, g)
+    _, p_m = _to_dense(Ho[pflag], g["pocket_batch"], B)
+    _, c_m = _to_dense(Ho[cflag], c_batch, B)
+    xc_d, _ = _to_dense(coords_n, c_batch, B)
+    xp_d, _ = _to_dense(g["pocket_xyz"] / scale, g["pocket_batch"], B)
+    zm = p_m[:, :, None] & c_m[:, None, :]
+    bmap = ln_mlp(sd, "distmap_mlp.", Z[:, 1:, 1:], False)[..., 0]
+    y_pred = torch.sigmoid(bmap[zm]) * thres
+    y_by = (torch.cdist(xp_d, xc_d)[zm] * scale).clamp(0, thres)
+    return (coords_n * scale, c_batch, y_pred, y_by, head["logits"], pocket_cls, head["p_mask"], head["xyz_dense"], center,
+            g["dis_map"], g["less5"], head["radius"], g["bias"]), g["coords"]
+
+
+def model_inference(sd, cfg, data):
+    """FABindPlus.inference(data), model.py:403-670 -> (coords in the whole-protein frame [sum Nc, 3] A, compound_batch)."""
+    scale = cfg["coordinate_scale"]
+    head = _pocket_head(sd, cfg, data)
+    center = _soft_center(head["logits"], head["p_mask"], head["xyz_dense"], cfg["gs_tau"], cfg["gs_hard"])
+    g = _stage2_graph(sd, cfg, data, head, center, shift_coords=False)
+    _, _, _, _, _, coords_n = _complex(sd, cfg, g)
+    c_batch = data["compound"].batch
+    return coords_n * scale + g["bias"][c_batch], c_batch

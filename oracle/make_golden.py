@@ -257,12 +257,61 @@ def golden_stack_plus(mods, name, sizes, hidden, layers, n_iter, seed):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def golden_model_plus(mods, name, sizes, hidden, pocket_hidden, layers, n_iter, seed):
+    """FABindPlus.forward (stage 1 and 2, eval) and .inference; 13-tuples + the in-place shifted data.coords."""
+    torch.manual_seed(seed)
+    # min_pocket_radius 10 A (production: 20) so that the radius crop of these small synthetic proteins is partial and the
+    # pocket-centred frame / pocket_center_bias are non-trivial
+    args = refshim.production_args_plus(hidden_size=hidden, pocket_pred_hidden_size=pocket_hidden, mean_layers=layers,
+                                        n_iter=n_iter, random_n_iter=False, min_pocket_radius=10.0)
+    model = mods["models.model"].get_model(args, _Logger()).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("coord_mlp.linear2.weight"):
+                p.mul_(COORD_GAIN)
+            if n in ("protein_linear_whole_protein.weight", "compound_linear_whole_protein.weight", "embedding_shrink.weight",
+                     "embedding_enlarge.weight"):
+                p.mul_(300.0)                   # xavier gain 1e-3 in the reference: lift so the heads carry signal
+    data = synthetic.make_hetero_batch(sizes, seed=seed)
+    save = {"sizes": np.array(sizes), "cfg": np.array([hidden, pocket_hidden, layers, n_iter, seed]),
+            "min_pocket_radius": np.array(10.0)}
+    save.update({"w_" + k: _np(v) for k, v in model.state_dict().items()})
+    names = ["coords", "compound_batch", "y_pred", "y_pred_by_coords", "pocket_cls_pred", "pocket_cls",
+             "protein_out_mask_whole", "protein_coords_batched_whole", "pred_pocket_center", "dis_map", "keepNode_less_5",
+             "pocket_radius_pred", "pocket_center_bias"]
+    for stage in (1, 2):
+        d = _hetero_to_ref(data)
+        with torch.no_grad():
+            out = model(d, stage=stage, train=False)
+        for n, o in zip(names, out):
+            save["s%d_%s" % (stage, n)] = _np(o) if torch.is_tensor(o) else np.array(o)
+        save["s%d_data_coords" % stage] = _np(d.coords)
+        print("%s stage %d: radius %s, bias %s, |y_pred| %.3f" % (name, stage, _np(out[11]).ravel(), _np(out[12][0]),
+                                                               float(out[2].abs().max())))
+    d = _hetero_to_ref(data)
+    with torch.no_grad():
+        out = model.inference(d)
+    save["inf_coords"] = _np(out[0])
+    hd = {}
+    for key, st in data._stores.items():
+        kname = key if isinstance(key, str) else "|".join(key)
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                hd["d_%s::%s" % (kname, k)] = _np(v)
+    for k, v in data._glob.items():
+        if torch.is_tensor(v):
+            hd["d_::%s" % k] = _np(v)
+    save.update(hd)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def main_plus():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
     mods = refshim.load_reference("FABind_plus")
     golden_stack_plus(mods, "plus_stack_tiny_it1", [(24, 7), (31, 5)], 32, 2, 1, seed=10)
     golden_stack_plus(mods, "plus_stack_tiny_it2", [(40, 9), (26, 6), (33, 12)], 64, 3, 2, seed=11)
+    golden_model_plus(mods, "plus_model_tiny", [(70, 8), (85, 6)], 64, 32, 2, 2, seed=12)
 
 
 def main():

@@ -170,3 +170,43 @@ def test_plus_stack_forward_fp64_twin(name):
     assert rmsd(X.numpy() * 5, g["out_X_f64"] * 5) < 1e-9
     assert np.abs(H.numpy() - g["out_H_f64"]).max() < 1e-8
     assert np.abs(Z.numpy() - g["out_Z_f64"]).max() < 1e-8
+
+
+def _plus_model_cfg(g):
+    hidden, pocket_hidden, layers, n_iter, _ = [int(v) for v in g["cfg"]]
+    cfg = dict(porc.PLUS_CFG)
+    cfg.update(mean_layers=layers, n_iter=n_iter, min_pocket_radius=float(g["min_pocket_radius"]))
+    return cfg
+
+
+PLUS_NAMES = ["coords", "compound_batch", "y_pred", "y_pred_by_coords", "pocket_cls_pred", "pocket_cls",
+              "protein_out_mask_whole", "protein_coords_batched_whole", "pred_pocket_center", "dis_map", "keepNode_less_5",
+              "pocket_radius_pred", "pocket_center_bias"]
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_plus_model_forward_matches_reference(stage):
+    g = load_npz("plus_model_tiny")
+    sd, data = weights(g), hetero_from_npz(g)
+    with torch.no_grad():
+        out, coords_shifted = porc.model_forward(sd, _plus_model_cfg(g), data, stage=stage)
+    p = "s%d_" % stage
+    assert rmsd(out[0].numpy(), g[p + "coords"]) < 2e-5
+    for i, n in enumerate(PLUS_NAMES):
+        if n in ("coords", "keepNode_less_5"):
+            continue
+        ref, got = g[p + n], out[i].numpy()
+        assert got.shape == ref.shape, n
+        if ref.dtype.kind in "biu":
+            assert np.array_equal(got, ref), n
+        else:
+            assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), n
+    assert int(out[10]) == int(g[p + "keepNode_less_5"])
+    assert np.abs(coords_shifted.numpy() - g[p + "data_coords"]).max() < 1e-5        # data.coords shifted in place
+
+
+def test_plus_model_inference_matches_reference():
+    g = load_npz("plus_model_tiny")
+    with torch.no_grad():
+        coords, _ = porc.model_inference(weights(g), _plus_model_cfg(g), hetero_from_npz(g))
+    assert rmsd(coords.numpy(), g["inf_coords"]) < 2e-5
