@@ -250,10 +250,18 @@ def egnn_forward(P, h, x, z0, lay, g, las, x_las, pairs, batch_id, scale, step, 
 DEBUG_CAPTURE = None
 
 
+def mlp_module(m, x, last_act=False, out_dtype=torch.float32):
+    """Apply one of the reference's LN-MLP modules (MLP / MLPwithLastAct / MLPwoBias parameter containers) to rows x."""
+    wd = _wd()
+    return ln_mlp(_mlp(m, lambda t: t.to(wd).contiguous()), x.contiguous(), last_act, out_dtype=out_dtype)
+
+
 @torch.no_grad()
 def stack_forward(model, X, Hin, batch_id, segment_id, mask, is_global, compound_edge_index, LAS_edge_index, coord_LAS,
-                  n_iter):
-    """EfficientMCAttModel.forward of FABind+ (refine_coord): mutates X in place, returns (X, H, pair_embed_batched)."""
+                  n_iter, pair="dense"):
+    """EfficientMCAttModel.forward of FABind+ (refine_coord): mutates X in place, returns (X, H, pair_embed).
+    pair = "dense": the reference's [B, Pmax, Cmax, H] tensor; "ragged": (z [pairs, H], PairList, Layout) without the
+    padded copy (what the model's own heads consume); "none": None."""
     if not X.is_cuda:
         raise RuntimeError("fabind_amd: the FABind+ stack runs on a HIP device only (no CPU fallback); got " + str(X.device))
     args = model.args
@@ -284,4 +292,6 @@ def stack_forward(model, X, Hin, batch_id, segment_id, mask, is_global, compound
         x = ops.select_rows(x, xz, mask_u8)
     model.last_graph = g
     X.copy_(x.reshape(X.shape).to(X.dtype))
-    return X, Hout, pairs.dense(z, lay)
+    if pair == "dense":
+        return X, Hout, pairs.dense(z, lay)
+    return X, Hout, ((z, pairs, lay) if pair == "ragged" else None)

@@ -27,8 +27,9 @@ class EfficientMCAttModel(nn.Module):
         self.inter_layer = InteractionModule(hidden_size, hidden_size, hidden_size, rm_layernorm=args.rm_layernorm)
 
     def forward(self, X, H, batch_id, segment_id, mask, is_global, compound_edge_index, LAS_edge_index,
-                batched_complex_coord_LAS, LAS_mask=None):
-        """Same contract as the reference: mutates X in place, returns (X, H_out, pair_embed_batched)."""
+                batched_complex_coord_LAS, LAS_mask=None, pair="dense"):
+        """Same contract as the reference: mutates X in place, returns (X, H_out, pair_embed_batched).
+        pair="ragged" / "none" skip the padded [B, P, C, H] copy (see engine.stack_forward)."""
         iter_i = random.randint(1, self.n_iter) if (self.training and self.random_n_iter) else self.n_iter
         return engine.stack_forward(self, X, H, batch_id, segment_id, mask, is_global, compound_edge_index, LAS_edge_index,
-                                    batched_complex_coord_LAS, iter_i)
+                                    batched_complex_coord_LAS, iter_i, pair=pair)

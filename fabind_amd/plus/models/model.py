@@ -1,0 +1,231 @@
+"""FABindPlus / get_model on the HIP engine (reference FABind_plus/fabind/models/model.py:13-675).
+
+Same constructor, parameter names and return tuples as the reference (forward -> 13-tuple, inference -> 2-tuple); the
+per-sample python loops (model.py:84-97, 176-197, 225-330) are vectorised index arithmetic.  Round 1: eval / inference
+path (the stack has no autograd yet); the confidence head, DBSCAN centre sampling and dropout sampling are not built."""
+import torch
+import torch.nn as nn
+
+from ... import kernels as K
+from ... import ops
+from ...models.model import IaBNet_mean_and_pocket_prediction_cls_coords_dependent as _V1
+from ...models.model import _offsets
+from ...utils.utils import gumbel_softmax_no_random  # noqa: F401
+from .. import engine as pengine
+from .att_model import EfficientMCAttModel
+from .model_utils import MLP
+
+
+class FABindPlus(nn.Module):
+    def __init__(self, args, embedding_channels=128, pocket_pred_embedding_channels=128):
+        super().__init__()
+        if getattr(args, "confidence_training", False) or args.use_clustering:
+            raise NotImplementedError("confidence head / DBSCAN centre sampling (sampling mode) are not built yet")
+        if args.use_for_radius_pred != "ligand" or args.force_fix_radius:
+            raise NotImplementedError("only --use-for-radius-pred ligand (production) is built")
+        self.args = args
+        self.coordinate_scale = args.coordinate_scale
+        self.normalize_coord = lambda x: x / self.coordinate_scale
+        self.unnormalize_coord = lambda x: x * self.coordinate_scale
+        self.glb_c = nn.Parameter(torch.ones(1, embedding_channels))
+        self.glb_p = nn.Parameter(torch.ones(1, embedding_channels))
+        self.protein_linear_whole_protein = nn.Linear(1280, embedding_channels)
+        self.compound_linear_whole_protein = nn.Linear(56, embedding_channels)
+        self.embedding_shrink = nn.Linear(embedding_channels, pocket_pred_embedding_channels)
+        self.embedding_enlarge = nn.Linear(pocket_pred_embedding_channels, embedding_channels)
+        n_channel = 1
+        self.pocket_pred_model = EfficientMCAttModel(
+            args, pocket_pred_embedding_channels, pocket_pred_embedding_channels, n_channel, n_edge_feats=0,
+            n_layers=args.pocket_pred_layers, n_iter=args.pocket_pred_n_iter, inter_cutoff=args.inter_cutoff,
+            intra_cutoff=args.intra_cutoff, normalize_coord=self.normalize_coord, unnormalize_coord=self.unnormalize_coord)
+        n = args.mlp_hidden_scale
+        self.pocket_radius_head = MLP(args, embedding_channels=embedding_channels, n=n, out_channels=1)
+        self.protein_to_pocket = MLP(args, embedding_channels=embedding_channels, n=n, out_channels=1)
+        self.complex_model = EfficientMCAttModel(
+            args, embedding_channels, embedding_channels, n_channel, n_edge_feats=0, n_layers=args.mean_layers,
+            n_iter=args.n_iter, inter_cutoff=args.inter_cutoff, intra_cutoff=args.intra_cutoff,
+            normalize_coord=self.normalize_coord, unnormalize_coord=self.unnormalize_coord)
+        self.distmap_mlp = MLP(args, embedding_channels=embedding_channels, n=n, out_channels=1)
+        for lin in (self.protein_linear_whole_protein, self.compound_linear_whole_protein, self.embedding_shrink,
+                    self.embedding_enlarge):
+            torch.nn.init.xavier_uniform_(lin.weight, gain=0.001)
+        self.confidence_training = False
+
+    _lin = _V1._lin
+    _assemble = _V1._assemble
+    _soft_center = _V1._soft_center
+    _pair_lists = staticmethod(_V1._pair_lists)
+
+    # ---- whole-protein pocket model, classifier, radius head (model.py:72-146) -------------------------------------
+    def _pocket_head(self, data):
+        w = data['complex_whole_protein']
+        c_emb = self._lin(self.compound_linear_whole_protein, data['compound'].node_feats)
+        p_emb = self._lin(self.protein_linear_whole_protein, data['protein_whole'].node_feats)
+        h0, cf, pf = self._assemble(w.segment, w.is_global, c_emb, p_emb)
+        h0 = self._lin(self.embedding_shrink, h0)
+        Xw = self.normalize_coord(w.node_coords.unsqueeze(-2)).float()
+        Xl = self.normalize_coord(w.node_coords_LAS.unsqueeze(-2)).float()
+        _, hw, _ = self.pocket_pred_model(
+            Xw, h0, batch_id=w.batch, segment_id=w.segment, mask=w.mask, is_global=w.is_global,
+            compound_edge_index=data['complex_whole_protein', 'c2c', 'complex_whole_protein'].edge_index,
+            LAS_edge_index=data['complex_whole_protein', 'LAS', 'complex_whole_protein'].edge_index,
+            batched_complex_coord_LAS=Xl, LAS_mask=None, pair="none")
+        hw = self._lin(self.embedding_enlarge, hw)
+        c_out, p_out = hw[cf], hw[pf]
+        cb, pb = data['compound'].batch, data['protein_whole'].batch
+        B = int(pb[-1].item()) + 1
+        csum = torch.zeros(B, c_out.shape[1], dtype=torch.float32, device=hw.device).index_add_(0, cb, c_out.float())
+        radius = pengine.mlp_module(self.pocket_radius_head, csum).relu()                      # [B,1]
+        logits_flat = pengine.mlp_module(self.protein_to_pocket, p_out).squeeze(-1)            # [sum L]
+        cnt = torch.bincount(pb, minlength=B)
+        loc = torch.arange(pb.shape[0], device=pb.device) - _offsets(cnt)[pb]
+        Lmax = int(cnt.max().item())
+        mask = torch.zeros(B, Lmax, dtype=torch.bool, device=pb.device)
+        mask[pb, loc] = True
+        logits = torch.zeros(B, Lmax, dtype=logits_flat.dtype, device=pb.device).index_put((pb, loc), logits_flat)
+        xyz = torch.zeros(B, Lmax, 3, dtype=data.node_xyz_whole.dtype, device=pb.device)
+        xyz[pb, loc] = data.node_xyz_whole
+        return dict(B=B, c_out=c_out, p_out=p_out, logits=logits, mask=mask, xyz=xyz, pb=pb, loc=loc, cnt=cnt, radius=radius)
+
+    # ---- radius crop around the predicted centre, pocket-centred frame (model.py:212-330) --------------------------
+    @torch.no_grad()
+    def _stage2(self, data, head, center, shift_coords):
+        a, dev = self.args, center.device
+        pb, B, cb = head['pb'], head['B'], data['compound'].batch
+        r = head['radius'][:, 0].detach()
+        r = r * a.pocket_radius_buffer if a.pocket_radius_buffer <= 2.0 else r + a.pocket_radius_buffer
+        r = r.clamp(min=a.min_pocket_radius)
+        d = (data.node_xyz_whole.float() - center.detach()[pb]).norm(dim=-1)
+        keep = d < r[pb]
+        kcnt = torch.bincount(pb[keep], minlength=B)
+        bad = kcnt < 5
+        less5 = int(bad.sum().item())
+        if less5:
+            keep = keep | (bad[pb] & (head['loc'] < 100))
+            kcnt = torch.bincount(pb[keep], minlength=B)
+        ncnt = torch.bincount(cb, minlength=B)
+        n = ncnt + kcnt + 2
+        off = _offsets(n)
+        N = int(n.sum().item())
+        pocket_batch = pb[keep]
+        lig_pos = off[cb] + 1 + (torch.arange(cb.shape[0], device=dev) - _offsets(ncnt)[cb])
+        prot_pos = off[pocket_batch] + ncnt[pocket_batch] + 2 + \
+            (torch.arange(pocket_batch.shape[0], device=dev) - _offsets(kcnt)[pocket_batch])
+        segment = torch.zeros(N, dtype=torch.bool, device=dev)
+        segment[prot_pos] = True
+        segment[off + ncnt + 1] = True
+        is_global = torch.zeros(N, dtype=torch.bool, device=dev)
+        is_global[off] = True
+        is_global[off + ncnt + 1] = True
+        mask = ~segment | is_global
+        batch = torch.repeat_interleave(torch.arange(B, device=dev), n)
+        pocket_xyz = data.node_xyz_whole[keep].float()
+        bias = torch.zeros(B, 3, device=dev).index_add_(0, pocket_batch, pocket_xyz) / kcnt[:, None]   # pocket centre
+        pocket_xyz = pocket_xyz - bias[pocket_batch]
+        if shift_coords:                                            # the caller's loss reads data.coords after forward
+            data.coords = data.coords - bias[cb].to(data.coords.dtype)
+        li = data['compound'].node_coords.float()
+        mean_l = torch.zeros(B, 3, device=dev).index_add_(0, cb, li) / ncnt[:, None]
+        mean_p = torch.zeros(B, 3, device=dev).index_add_(0, pocket_batch, pocket_xyz) / kcnt[:, None]
+        X = torch.zeros(N, 3, device=dev)
+        X[lig_pos] = li - mean_l[cb] + mean_p[cb]
+        X[prot_pos] = pocket_xyz
+        XL = torch.zeros(N, 3, device=dev)
+        XL[lig_pos] = data['compound'].rdkit_coords.float()
+        el, ll = data['compound_atom_edge_list'], data['LAS_edge_list']
+        c2c = (el.x + off[el.batch][:, None]).t().contiguous().long()
+        las = (ll.x + off[ll.batch][:, None]).t().contiguous().long()
+        pi, ci = self._pair_lists(pocket_batch, cb, kcnt, ncnt)
+        dis_map = (pocket_xyz[pi] - (li - bias[cb])[ci]).norm(dim=-1).clamp(max=a.dis_map_thres)
+        pemb = head['p_out'][keep]
+        H, _, _ = self._assemble(segment, is_global, head['c_out'], pemb)
+        cx = data['complex']
+        cx.node_coords, cx.node_coords_LAS, cx.segment, cx.mask, cx.is_global = X, XL, segment, mask, is_global
+        data['complex', 'c2c', 'complex'].edge_index = c2c
+        data['complex', 'LAS', 'complex'].edge_index = las
+        return dict(H=H, X=X, XL=XL, segment=segment, mask=mask, is_global=is_global, batch=batch, c2c=c2c, LAS=las,
+                    pocket_xyz=pocket_xyz, pocket_batch=pocket_batch, dis_map=dis_map, less5=less5, pairs=(pi, ci), bias=bias)
+
+    @torch.no_grad()
+    def _stage1(self, data, head):
+        """Teacher-forced pocket, moved into the pocket frame IN PLACE like the reference (model.py:170-201)."""
+        cx, cb = data['complex'], data['compound'].batch
+        B, dev = head['B'], cb.device
+        seg1 = cx.segment.bool() if not cx.segment.is_floating_point() else cx.segment > 0.5
+        lig = ~seg1 & ~cx.is_global
+        poc = seg1 & ~cx.is_global
+        X = cx.node_coords.clone()
+        ncnt = torch.bincount(cb, minlength=B)
+        mean_l = torch.zeros(B, 3, device=dev, dtype=X.dtype).index_add_(0, cb, X[lig]) / ncnt[:, None]
+        X[lig] = X[lig] - mean_l[cx.batch[lig]]
+        X[poc] = X[poc] - data.pocket_residue_center[cx.batch[poc]].to(X.dtype)
+        cx.node_coords = X
+        data.coords = data.coords - data.pocket_residue_center[cb].to(data.coords.dtype)
+        pemb = head['p_out'][data['pocket'].keepNode]
+        H, _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], pemb)
+        return dict(H=H, X=X, XL=cx.node_coords_LAS, segment=cx.segment, mask=cx.mask, is_global=cx.is_global, batch=cx.batch,
+                    c2c=data['complex', 'c2c', 'complex'].edge_index, LAS=data['complex', 'LAS', 'complex'].edge_index,
+                    pocket_xyz=data.node_xyz, pocket_batch=data['pocket'].batch, dis_map=data.dis_map, less5=0,
+                    bias=torch.zeros(B, 3, device=dev))
+
+    def _complex(self, g, pair):
+        Xn = self.normalize_coord(g['X'].unsqueeze(-2)).float()
+        Xl = self.normalize_coord(g['XL'].unsqueeze(-2)).float()
+        Xo, Ho, Z = self.complex_model(Xn, g['H'], batch_id=g['batch'], segment_id=g['segment'], mask=g['mask'],
+                                       is_global=g['is_global'], compound_edge_index=g['c2c'], LAS_edge_index=g['LAS'],
+                                       batched_complex_coord_LAS=Xl, LAS_mask=None, pair=pair)
+        seg1 = g['segment'].bool() if not g['segment'].is_floating_point() else g['segment'] > 0.5
+        cflag, pflag = ~seg1 & ~g['is_global'], seg1 & ~g['is_global']
+        return Ho, Z, cflag, pflag, Xo[cflag].squeeze(-2)
+
+    def _dist_heads(self, data, g, Z, coords_n):
+        """distmap_mlp on the threaded pair embedding without its global rows (model.py:379-388) + coordinate distances."""
+        z, pairs, _ = Z
+        sel = (pairs.i >= 1) & (pairs.j >= 1)                                   # z[:, 1:, 1:] in (b, i, j) order
+        zz = z[sel].contiguous()
+        m = self.distmap_mlp
+        wd = ops.mm_dtype()
+        y = K.layernorm_rows(zz, m.layernorm.weight.float(), m.layernorm.bias.float(), ops.act_dtype())
+        part = ops.linear_rowdot(y, m.linear1.weight.to(wd).contiguous(), m.linear1.bias, m.linear2.weight[0].float().contiguous(),
+                                 act_epi=K.ACT_RELU)
+        thres = self.args.dis_map_thres
+        y_pred = (part.sum(1) + m.linear2.bias).sigmoid() * thres
+        cb = data['compound'].batch
+        B = int(cb[-1].item()) + 1
+        pi, ci = g.get('pairs') or self._pair_lists(g['pocket_batch'], cb, torch.bincount(g['pocket_batch'], minlength=B),
+                                                   torch.bincount(cb, minlength=B))
+        xp = self.normalize_coord(g['pocket_xyz']).float()
+        y_by = self.unnormalize_coord((xp[pi] - coords_n[ci]).norm(dim=-1)).clamp(0, thres)
+        return y_pred, y_by
+
+    # ---- reference API ---------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, data, stage=2, train=False):
+        if self.training or train:
+            raise NotImplementedError("FABind+ training (autograd through the stack, dropout, permutation loss) is not "
+                                      "built yet: eval / inference only")
+        cb = data['compound'].batch
+        head = self._pocket_head(data)
+        center = self._soft_center(head['logits'], head['mask'], head['xyz'], noise=False)
+        pocket_cls = torch.zeros_like(head['mask'], dtype=data.pocket_idx.dtype)
+        pocket_cls[head['pb'], head['loc']] = data.pocket_idx
+        g = self._stage1(data, head) if stage == 1 else self._stage2(data, head, center, shift_coords=True)
+        Ho, Z, cflag, pflag, coords_n = self._complex(g, "ragged")
+        y_pred, y_by = self._dist_heads(data, g, Z, coords_n)
+        return (self.unnormalize_coord(coords_n), cb, y_pred, y_by, head['logits'] * head['mask'], pocket_cls, head['mask'],
+                head['xyz'], center, g['dis_map'], g['less5'], head['radius'], g['bias'])
+
+    @torch.no_grad()
+    def inference(self, data):
+        head = self._pocket_head(data)
+        center = self._soft_center(head['logits'], head['mask'], head['xyz'], noise=False)
+        g = self._stage2(data, head, center, shift_coords=False)
+        data['complex'].batch = g['batch']
+        _, _, _, _, coords_n = self._complex(g, "none")
+        cb = data['compound'].batch
+        return self.unnormalize_coord(coords_n) + g['bias'][cb], cb          # back in the whole-protein frame
+
+
+def get_model(args, logger):
+    logger.log_message("FABind plus")
+    return FABindPlus(args, args.hidden_size, args.pocket_pred_hidden_size)

@@ -76,3 +76,70 @@ def test_plus_stack_forward_bf16_close(name):
     print("FABind+ bf16 ligand RMSD gap vs reference [A]:", name, gap)
     assert gap < 5e-2
     assert np.abs(Z.cpu().numpy() - g["out_Z_f32"]).max() <= 5e-2 * max(1.0, np.abs(g["out_Z_f32"]).max())
+
+
+# ------------------------------------------------------------------------------------------------
+# full model: FABindPlus forward (13-tuple, stage 1 and 2) and inference
+# ------------------------------------------------------------------------------------------------
+from helpers import hetero_from_npz  # noqa: E402
+
+
+class _Logger:
+    def log_message(self, s):
+        pass
+
+
+def _plus_model(g, dev):
+    from fabind_amd.plus.models import get_model
+    hidden, pocket_hidden, layers, n_iter, _ = [int(v) for v in g["cfg"]]
+    a = _args(hidden, layers, n_iter)
+    for k, v in dict(pocket_pred_hidden_size=pocket_hidden, pocket_pred_layers=1, pocket_pred_n_iter=1, random_n_iter=False,
+                     use_for_radius_pred="ligand", dis_map_thres=15.0, pocket_radius_buffer=5.0,
+                     min_pocket_radius=float(g["min_pocket_radius"]), force_fix_radius=False, use_clustering=False, gs_tau=1.0,
+                     gs_hard=False, pocket_radius=20.0, train_pred_pocket_noise=0.0, local_eval=False).items():
+        setattr(a, k, v)
+    m = get_model(a, _Logger())
+    m.load_state_dict(weights(g), strict=True)
+    return m.to(dev).eval()
+
+
+NAMES = ["coords", "compound_batch", "y_pred", "y_pred_by_coords", "pocket_cls_pred", "pocket_cls", "protein_out_mask_whole",
+         "protein_coords_batched_whole", "pred_pocket_center", "dis_map", "keepNode_less_5", "pocket_radius_pred",
+         "pocket_center_bias"]
+
+
+@pytest.mark.parametrize("stage", [1, 2])
+def test_plus_model_forward_matches_reference(stage):
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision("fp32")
+    g = load_npz("plus_model_tiny")
+    m = _plus_model(g, dev)
+    data = hetero_from_npz(g).to(dev)
+    out = m(data, stage=stage, train=False)
+    assert len(out) == 13
+    p = "s%d_" % stage
+    assert rmsd(out[0].cpu().numpy(), g[p + "coords"]) < 1e-4                         # north_star gate: 1e-4 A RMSD
+    for i, n in enumerate(NAMES):
+        if n in ("coords", "keepNode_less_5"):
+            continue
+        ref, got = g[p + n], out[i].cpu().numpy()
+        assert got.shape == ref.shape, n
+        if ref.dtype.kind in "biu":
+            assert np.array_equal(got, ref), n
+        else:
+            assert np.abs(got - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), n
+    assert int(out[10]) == int(g[p + "keepNode_less_5"])
+    # the reference moves data.coords into the pocket frame in place; the caller's loss reads it after forward
+    assert np.abs(data.coords.cpu().numpy() - g[p + "data_coords"]).max() < 1e-4
+
+
+def test_plus_model_inference_matches_reference():
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision("fp32")
+    g = load_npz("plus_model_tiny")
+    m = _plus_model(g, dev)
+    coords, batch = m.inference(hetero_from_npz(g).to(dev))
+    assert rmsd(coords.cpu().numpy(), g["inf_coords"]) < 1e-4                         # whole-protein frame
+    assert np.array_equal(batch.cpu().numpy(), g["s2_compound_batch"])
