@@ -80,3 +80,45 @@ def test_synthetic_generator_matches_survey_counts():
     n_star = 2 * (300 + 30) + 2
     assert ctx.shape[1] > n_star and inter.shape[1] % 2 == 0 and inter.shape[1] > 0
     assert torch.all(inter[0][1:] >= inter[0][:-1])          # row-sorted
+
+
+def _plus_args(hidden, pocket_hidden, layers, n_iter, min_radius=20.0):
+    a = _args(hidden, layers, n_iter)
+    for k, v in dict(pocket_pred_hidden_size=pocket_hidden, use_ln_mlp=True, mlp_hidden_scale=1, dropout=0.1, mha_heads=4,
+                     rel_dis_pair_bias="no", inter_additional_mlp=False, only_last_LAS=False, geom_reg_steps=1,
+                     use_for_radius_pred="ligand", dis_map_thres=15.0, pocket_radius_buffer=5.0, min_pocket_radius=min_radius,
+                     force_fix_radius=False, use_clustering=False).items():
+        setattr(a, k, v)
+    return a
+
+
+def test_plus_state_dict_keys_match_reference_capture():
+    """FABind+: the host mirror loads the reference FABindPlus state_dict strictly."""
+    from fabind_amd.plus.models import get_model
+    g = load_npz("plus_model_tiny")
+    hidden, pocket_hidden, layers, n_iter, _ = [int(v) for v in g["cfg"]]
+    lg = _Logger()
+    m = get_model(_plus_args(hidden, pocket_hidden, layers, n_iter), lg)
+    assert lg.msg == "FABind plus"
+    ref, mine = weights(g), m.state_dict()
+    assert set(ref) == set(mine)
+    assert all(tuple(ref[k].shape) == tuple(mine[k].shape) for k in ref)
+    m.load_state_dict(ref, strict=True)
+
+
+def test_plus_production_stack_parameter_count():
+    """the FABind+ production stack (L=5, use_ln_mlp, mlp_hidden_scale=1, H=512) has 42,507,437 parameters."""
+    from fabind_amd.plus.models.att_model import EfficientMCAttModel
+    m = EfficientMCAttModel(_plus_args(512, 128, 5, 8), 512, 512, 1, n_layers=5, n_iter=8, normalize_coord=lambda x: x / 5.0,
+                            unnormalize_coord=lambda x: x * 5.0)
+    assert sum(p.numel() for p in m.parameters()) == 42507437
+
+
+def test_plus_refuses_cpu_and_training():
+    from fabind_amd.plus.models.att_model import EfficientMCAttModel
+    m = EfficientMCAttModel(_plus_args(32, 32, 1, 1), 32, 32, 1, n_layers=1, n_iter=1, normalize_coord=lambda x: x / 5.0,
+                            unnormalize_coord=lambda x: x * 5.0).eval()
+    X, H = torch.zeros(6, 1, 3), torch.zeros(6, 32)
+    z = torch.zeros(6, dtype=torch.long)
+    with pytest.raises(RuntimeError):
+        m(X, H, z, z.bool(), z.bool(), z.bool(), torch.zeros(2, 0, dtype=torch.long), torch.zeros(2, 0, dtype=torch.long), X)
