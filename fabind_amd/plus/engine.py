@@ -53,7 +53,9 @@ def _mlp(m, W, k_pad=None, n_pad=None):
     w1, w2 = m.linear1.weight, m.linear2.weight
     k_pad = k_pad or w1.shape[1]
     n_pad = n_pad or w1.shape[0]
-    return dict(ln_w=m.layernorm.weight.float().contiguous(), ln_b=m.layernorm.bias.float().contiguous(),
+    has_ln = hasattr(m, "layernorm")
+    return dict(ln_w=m.layernorm.weight.float().contiguous() if has_ln else None,
+                ln_b=m.layernorm.bias.float().contiguous() if has_ln else None,
                 C=w1.shape[1], k_pad=k_pad,
                 W1=W(_padded(w1, n_pad, k_pad)), b1=_padvec(m.linear1.bias, n_pad).float().contiguous(),
                 W2=W(_padded(w2, w2.shape[0], n_pad)),
@@ -164,34 +166,48 @@ def _pair_hadamard_call(T, Hh, p_node, c_node, out_dtype):
 # ------------------------------------------------------------------------------------------------
 # layers
 # ------------------------------------------------------------------------------------------------
-def ln_mlp(m, x, last_act, residual=None, out_dtype=torch.float32):
-    """LN -> linear1 -> relu -> linear2 (-> relu) (+ residual after the activation)."""
+def _drop(t, pr):
+    """nn.Dropout of the reference modules (train mode = FABind+ sampling inference): element-wise mask + scale between
+    kernels, torch's generator."""
+    return torch.nn.functional.dropout(t, pr, True) if pr > 0.0 else t
+
+
+def ln_mlp(m, x, last_act, residual=None, out_dtype=torch.float32, pdrop=0.0):
+    """LN -> linear1 -> relu -> [dropout] -> linear2 (-> relu -> [dropout]) (+ residual).  model_utils.py:10-74."""
     ad = ops.act_dtype()
-    y = K.layernorm_rows(x, m["ln_w"], m["ln_b"], ad, m["k_pad"])
-    t = ops.linear(y, m["W1"], m["b1"], act_epi=K.ACT_RELU, out_dtype=ad)
-    return ops.linear(t, m["W2"], m["b2"], act_epi=K.ACT_RELU if last_act else K.ACT_NONE, residual=residual,
-                      out_dtype=out_dtype)
+    y = K.layernorm_rows(x, m["ln_w"], m["ln_b"], ad, m["k_pad"]) if m["ln_w"] is not None else x
+    t = _drop(ops.linear(y, m["W1"], m["b1"], act_epi=K.ACT_RELU, out_dtype=ad), pdrop)
+    act2 = K.ACT_RELU if last_act else K.ACT_NONE
+    if pdrop > 0.0 and last_act:
+        y2 = _drop(ops.linear(t, m["W2"], m["b2"], act_epi=act2, out_dtype=torch.float32), pdrop)
+        return (y2 if residual is None else residual + y2).to(out_dtype)
+    return ops.linear(t, m["W2"], m["b2"], act_epi=act2, residual=residual, out_dtype=out_dtype)
 
 
-def gcl_layer(p, h, x, lay, g, clampv):
-    """MC_E_GCL.forward of FABind+ (egnn.py:104-118)."""
+def gcl_layer(p, h, x, lay, g, clampv, pd=0.0):
+    """MC_E_GCL.forward of FABind+ (egnn.py:104-118).  pd: dropout inside the three LN-MLPs (train / sampling mode)."""
     ad = ops.act_dtype()
     e = p["edge"]
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
     y = K.edge_ln_concat(h, g.row_ctx, g.col_ctx, rhohat, e["ln_w"], e["ln_b"], ad, e["k_pad"])     # [E, K8]
-    t = ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad)                           # [E, K8]
-    m = ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad)                           # [E, H] messages
+    t = _drop(ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad), pd)              # [E, K8]
+    m = _drop(ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad), pd)              # [E, H] messages
     c = p["coord"]
     yc = K.layernorm_rows(m, c["ln_w"], c["ln_b"], ad, c["k_pad"])
-    s = ops.linear_rowdot(yc, c["W1"], c["b1"], c["w3"], act_epi=K.ACT_RELU)                        # [E, nt]
+    if pd > 0.0:                                                # dropout sits between relu(linear1) and the bias-free linear2
+        tc = _drop(ops.linear(yc, c["W1"], c["b1"], act_epi=K.ACT_RELU, out_dtype=torch.float32), pd)
+        s = (tc * c["w3"]).sum(1, keepdim=True)
+    else:
+        s = ops.linear_rowdot(yc, c["W1"], c["b1"], c["w3"], act_epi=K.ACT_RELU)                    # [E, nt]
     x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
     agg = K.segment_sum(m, g.rp_ctx, h.shape[0])
-    h_new = ln_mlp(p["node"], torch.cat([h, agg], 1), True, residual=h)
+    h_new = ln_mlp(p["node"], torch.cat([h, agg], 1), True, residual=h, pdrop=pd)
     return h_new, x_new
 
 
-def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv):
-    """MC_Att_L.forward of FABind+ (egnn.py:277-300) -> (h, x, alpha, z_updated); z is the ragged pair list."""
+def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0):
+    """MC_Att_L.forward of FABind+ (egnn.py:277-300) -> (h, x, alpha, z_updated); z is the ragged pair list.
+    pd: dropout of every nn.Dropout on the path (all constructed with args.dropout) in train / sampling mode."""
     H = h.shape[1]
     ad = ops.act_dtype()
     scale = 1.0 / math.sqrt(32.0)
@@ -201,19 +217,19 @@ def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv):
     qg = ops.linear(h, p["Wqg_p"], p["bqg_p"])
     kv = ops.linear(hc, p["Wkv_p"])
     og = ops.cross_attn(qg, kv, bias, 0, 4, lay.desc_pf, lay.B, lay.max_P, lay.max_C, scale)
-    hp = ops.linear(og, p["Wo_p"], p["bo_p"], residual=h)
+    hp = ops.linear(og, p["Wo_p"], p["bo_p"], residual=h) if pd == 0.0 else h + _drop(ops.linear(og, p["Wo_p"], p["bo_p"]), pd)
     qg = ops.linear(hc, p["Wqg_c"], p["bqg_c"])
     kv = ops.linear(hp, p["Wkv_c"])
     og = ops.cross_attn(qg, kv, bias, 8, 12, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
-    hc = ops.linear(og, p["Wo_c"], p["bo_c"], residual=hc)
-    hp = ln_mlp(p["tr_p"], hp, True, residual=hp)
-    hc = ln_mlp(p["tr_c"], hc, True, residual=hc)
+    hc = ops.linear(og, p["Wo_c"], p["bo_c"], residual=hc) if pd == 0.0 else hc + _drop(ops.linear(og, p["Wo_c"], p["bo_c"]), pd)
+    hp = ln_mlp(p["tr_p"], hp, True, residual=hp, pdrop=pd)
+    hc = ln_mlp(p["tr_c"], hc, True, residual=hc, pdrop=pd)
     h = ops.put_rows(hp, hc, lay.c_index64)
     # ---- pair update: z <- relu-MLP(LN(z + W_o32 (a32 * b32) + b_o32))   (no residual around pair_transition)
     ab32 = ops.linear(h, p["W_ab32"], p["b_ab32"])                                                   # [N, 64]
     hd32 = _pair_hadamard_call(ab32, 32, pairs.p_node, pairs.c_node, ad)                             # [pairs, 32]
     z1 = ops.linear(hd32, p["W_o32"], p["b_o32"], residual=z.float() if z.dtype != torch.float32 else z, out_dtype=ad)
-    z = ln_mlp(p["tr_z"], z1, True, out_dtype=ad)
+    z = ln_mlp(p["tr_z"], z1, True, out_dtype=ad, pdrop=pd)
     # ---- inter-edge attention (att_model / node_model identical to v1; coord_mlp is an LN-MLP on v_e)
     zr = ops.take_rows(z, pairs.index_of(g.red_p, g.red_c, batch_id))                                # [n_red, H]
     bias_part = ops.linear(zr, p["W_bias"], p["b_bias"])                                             # [n_red, 8]: col 0
@@ -222,38 +238,45 @@ def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv):
     zero_cv = torch.zeros((h.shape[0], H), dtype=torch.float32, device=h.device)
     h_new, _, alpha = ops.inter_attn(qkv, zero_cv, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["zeroH"],
                                      p["zeroH"], clampv)
+    if pd > 0.0:
+        h_new = h + _drop(h_new - h, pd)                                                             # egnn.py:207 dropout(agg)
     AB = torch.cat([zero_cv, qkv[:, 2 * H:].float()], 1)                                             # v_e = V[col] + rho w_rv
     v_e = K.gcl_pre(AB, H, g.row_int, g.col_int, rhohat, p["w_rv"], ad)
     c = p["coord"]
     yc = K.layernorm_rows(v_e, c["ln_w"], c["ln_b"], ad, c["k_pad"])
-    s = ops.linear_rowdot(yc, c["W1"], c["b1"], c["w3"], act_epi=K.ACT_RELU)
+    if pd > 0.0:
+        tc = _drop(ops.linear(yc, c["W1"], c["b1"], act_epi=K.ACT_RELU, out_dtype=torch.float32), pd)
+        s = (tc * c["w3"]).sum(1, keepdim=True)
+    else:
+        s = ops.linear_rowdot(yc, c["W1"], c["b1"], c["w3"], act_epi=K.ACT_RELU)
     x_new, _ = K.coord_update(x, d, s, g.rp_int, False, clampv, weight=alpha)
     return h_new, x_new, alpha, z
 
 
-def egnn_forward(P, h, x, z0, lay, g, las, x_las, pairs, batch_id, scale, step, capture=None):
+def egnn_forward(P, h, x, z0, lay, g, las, x_las, pairs, batch_id, scale, step, capture=None, pd=0.0):
     clampv = 10.0 / scale
-    h = ops.linear(h, P["W_in"], P["b_in"])
+    h = _drop(ops.linear(h, P["W_in"], P["b_in"]), pd)
     z = z0
     for i in range(P["L"]):
-        h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv)
+        h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv, pd)
         if capture is not None:
             capture["gcl_%d.h" % i], capture["gcl_%d.x" % i] = h.clone(), x.clone()
-        h, x, alpha, z = att_layer(P["att"][i], h, x, z, lay, g, pairs, batch_id, clampv)
+        h, x, alpha, z = att_layer(P["att"][i], h, x, z, lay, g, pairs, batch_id, clampv, pd)
         if capture is not None:
             capture["att_%d.h" % i], capture["att_%d.x" % i], capture["att_%d.alpha" % i] = h.clone(), x.clone(), alpha.clone()
         x = ops.las_step(x, x_las, las, lay, step, 15.0 / scale)
-    h, x = gcl_layer(P["out_layer"], h, x, lay, g, clampv)
-    return ops.linear(h, P["W_out"], P["b_out"]), x, z
+    h, x = gcl_layer(P["out_layer"], h, x, lay, g, clampv, pd)
+    return ops.linear(_drop(h, pd), P["W_out"], P["b_out"]), x, z
 
 
 DEBUG_CAPTURE = None
 
 
-def mlp_module(m, x, last_act=False, out_dtype=torch.float32):
-    """Apply one of the reference's LN-MLP modules (MLP / MLPwithLastAct / MLPwoBias parameter containers) to rows x."""
+def mlp_module(m, x, last_act=False, out_dtype=torch.float32, pdrop=0.0):
+    """Apply one of the reference's MLP modules (MLP / MLPwithLastAct / MLPwoBias / MLP4Confidence parameter containers)
+    to rows x."""
     wd = _wd()
-    return ln_mlp(_mlp(m, lambda t: t.to(wd).contiguous()), x.contiguous(), last_act, out_dtype=out_dtype)
+    return ln_mlp(_mlp(m, lambda t: t.to(wd).contiguous()), x.contiguous(), last_act, out_dtype=out_dtype, pdrop=pdrop)
 
 
 @torch.no_grad()
@@ -285,10 +308,11 @@ def stack_forward(model, X, Hin, batch_id, segment_id, mask, is_global, compound
     z0 = ops.linear(hd0, P["W_o0"], P["b_o0"], out_dtype=ad)                                         # [pairs, H]
     cut_intra, cut_inter = float(model.extract_edges.intra_cutoff), float(model.extract_edges.inter_cutoff)
     Hout = z = None
+    pd = float(args.dropout) if model.training else 0.0     # train mode at inference = FABind+ dropout sampling
     for r in range(n_iter):
         g = Graph(lay, x, bond_row, bond_col, bond_off, cut_intra, cut_inter)
         Hout, xz, z = egnn_forward(P, Hin, x, z0, lay, g, las, x_las, pairs, batch_id, scale,
-                                   float(args.geometry_reg_step_size), DEBUG_CAPTURE if r == n_iter - 1 else None)
+                                   float(args.geometry_reg_step_size), DEBUG_CAPTURE if r == n_iter - 1 else None, pd)
         x = ops.select_rows(x, xz, mask_u8)
     model.last_graph = g
     X.copy_(x.reshape(X.shape).to(X.dtype))

@@ -13,14 +13,12 @@ from ...models.model import _offsets
 from ...utils.utils import gumbel_softmax_no_random  # noqa: F401
 from .. import engine as pengine
 from .att_model import EfficientMCAttModel
-from .model_utils import MLP
+from .model_utils import MLP, MLP4Confidence
 
 
 class FABindPlus(nn.Module):
     def __init__(self, args, embedding_channels=128, pocket_pred_embedding_channels=128):
         super().__init__()
-        if getattr(args, "confidence_training", False) or args.use_clustering:
-            raise NotImplementedError("confidence head / DBSCAN centre sampling (sampling mode) are not built yet")
         if args.use_for_radius_pred != "ligand" or args.force_fix_radius:
             raise NotImplementedError("only --use-for-radius-pred ligand (production) is built")
         self.args = args
@@ -49,7 +47,50 @@ class FABindPlus(nn.Module):
         for lin in (self.protein_linear_whole_protein, self.compound_linear_whole_protein, self.embedding_shrink,
                     self.embedding_enlarge):
             torch.nn.init.xavier_uniform_(lin.weight, gain=0.001)
-        self.confidence_training = False
+        # sampling mode (inference_sampling_fabind.py:148-187): ranking head on the summed complex embedding and, with
+        # --use-clustering, a host-side DBSCAN choice of the pocket centre (model.py:50-61, 147-167)
+        self.confidence_training = getattr(args, 'confidence_training', False)
+        if self.confidence_training:
+            if args.stack_mlp:
+                self.ranking_mlp_pre = MLP4Confidence(args, embedding_channels=embedding_channels,
+                                                      n=args.confidence_mlp_hidden_scale, out_channels=embedding_channels)
+            self.ranking_score_mlp = MLP4Confidence(args, embedding_channels=embedding_channels,
+                                                    n=args.confidence_mlp_hidden_scale, out_channels=1)
+        if args.use_clustering:
+            from sklearn.cluster import DBSCAN
+            self.dbscan_module = DBSCAN(eps=args.dbscan_eps, min_samples=args.dbscan_min_samples)
+
+    def _pd(self):
+        return float(self.args.dropout) if self.training else 0.0
+
+    def _cluster_centers(self, head, center):
+        """DBSCAN over the residues predicted to be pocket (host-side sklearn, like the reference: model.py:147-167);
+        consumes python's `random` exactly as the reference does (one randint + one random per complex)."""
+        import random
+        centers = torch.zeros_like(center)
+        prob = head['logits'].sigmoid()
+        for i in range(center.shape[0]):
+            pp = prob[i]
+            sel = pp > 0.5
+            if int(sel.sum()) < 50:
+                top = torch.argsort(pp)[-50:]
+                sel = torch.zeros_like(sel)
+                sel[top] = True
+            pts = head['xyz'][i][sel].detach().cpu().numpy()
+            clustering = self.dbscan_module.fit(pts)
+            cid = random.randint(0, clustering.labels_.max())
+            if random.random() < self.args.choose_cluster_prob:
+                centers[i] = torch.tensor(pts[clustering.labels_ == cid].mean(axis=0), device=center.device)
+            else:
+                centers[i] = center[i]
+        return centers
+
+    def _confidence(self, Ho, batch, B):
+        pooled = torch.zeros(B, Ho.shape[1], dtype=torch.float32, device=Ho.device).index_add_(0, batch, Ho.float())
+        cd = float(self.args.confidence_dropout) if (self.ranking_score_mlp.training) else 0.0
+        if self.args.stack_mlp:
+            pooled = pengine.mlp_module(self.ranking_mlp_pre, pooled, pdrop=cd).relu()
+        return pengine.mlp_module(self.ranking_score_mlp, pooled, pdrop=cd).squeeze(-1)
 
     _lin = _V1._lin
     _assemble = _V1._assemble
@@ -75,8 +116,8 @@ class FABindPlus(nn.Module):
         cb, pb = data['compound'].batch, data['protein_whole'].batch
         B = int(pb[-1].item()) + 1
         csum = torch.zeros(B, c_out.shape[1], dtype=torch.float32, device=hw.device).index_add_(0, cb, c_out.float())
-        radius = pengine.mlp_module(self.pocket_radius_head, csum).relu()                      # [B,1]
-        logits_flat = pengine.mlp_module(self.protein_to_pocket, p_out).squeeze(-1)            # [sum L]
+        radius = pengine.mlp_module(self.pocket_radius_head, csum, pdrop=self._pd()).relu()                      # [B,1]
+        logits_flat = pengine.mlp_module(self.protein_to_pocket, p_out, pdrop=self._pd()).squeeze(-1)            # [sum L]
         cnt = torch.bincount(pb, minlength=B)
         loc = torch.arange(pb.shape[0], device=pb.device) - _offsets(cnt)[pb]
         Lmax = int(cnt.max().item())
@@ -201,9 +242,9 @@ class FABindPlus(nn.Module):
     # ---- reference API ---------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, data, stage=2, train=False):
-        if self.training or train:
-            raise NotImplementedError("FABind+ training (autograd through the stack, dropout, permutation loss) is not "
-                                      "built yet: eval / inference only")
+        if self.training or train or self.confidence_training:
+            raise NotImplementedError("FABind+ training (autograd through the stack, Gumbel noise, permutation loss, "
+                                      "confidence training) is not built yet: eval forward / inference / sampling only")
         cb = data['compound'].batch
         head = self._pocket_head(data)
         center = self._soft_center(head['logits'], head['mask'], head['xyz'], noise=False)
@@ -217,13 +258,20 @@ class FABindPlus(nn.Module):
 
     @torch.no_grad()
     def inference(self, data):
+        """model.py:403-670.  In train mode (`--infer-dropout` sampling, inference_sampling_fabind.py:148-152) every dropout
+        of the stack and heads is active; with `confidence_training` the 3-tuple carries the ranking score."""
         head = self._pocket_head(data)
         center = self._soft_center(head['logits'], head['mask'], head['xyz'], noise=False)
+        if self.args.use_clustering:
+            center = self._cluster_centers(head, center)
         g = self._stage2(data, head, center, shift_coords=False)
         data['complex'].batch = g['batch']
-        _, _, _, _, coords_n = self._complex(g, "none")
+        Ho, _, _, _, coords_n = self._complex(g, "none")
         cb = data['compound'].batch
-        return self.unnormalize_coord(coords_n) + g['bias'][cb], cb          # back in the whole-protein frame
+        coords = self.unnormalize_coord(coords_n) + g['bias'][cb]            # back in the whole-protein frame
+        if self.confidence_training:
+            return coords, cb, self._confidence(Ho, g['batch'], head['B'])
+        return coords, cb
 
 
 def get_model(args, logger):

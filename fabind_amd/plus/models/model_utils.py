@@ -56,6 +56,23 @@ class MLPwoBias(_LnMlp):
         _fused("MLPwoBias")
 
 
+class MLP4Confidence(nn.Module):
+    """Confidence / ranking head MLP: [LN] -> linear1 -> relu -> [dropout] -> linear2 (model_utils.py:77-98)."""
+
+    def __init__(self, args, embedding_channels=256, out_channels=256, n=4):
+        super().__init__()
+        self.args = args
+        if args.confidence_use_ln_mlp:
+            self.layernorm = nn.LayerNorm(embedding_channels)
+        if args.confidence_dropout > 0:
+            self.dropout = nn.Dropout(args.confidence_dropout)
+        self.linear1 = Linear(embedding_channels, n * embedding_channels)
+        self.linear2 = Linear(n * embedding_channels, out_channels)
+
+    def forward(self, z):
+        _fused("MLP4Confidence")
+
+
 class Attention(nn.Module):
     """Gated multi-head attention parameters (model_utils.py:150-270)."""
 

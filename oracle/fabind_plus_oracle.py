@@ -264,12 +264,54 @@ def model_forward(sd, cfg, data, stage=2):
             g["dis_map"], g["less5"], head["radius"], g["bias"]), g["coords"]
 
 
-def model_inference(sd, cfg, data):
-    """FABindPlus.inference(data), model.py:403-670 -> (coords in the whole-protein frame [sum Nc, 3] A, compound_batch)."""
+def _mlp4conf(sd, pre, x):
+    """MLP4Confidence (model_utils.py:77-98), eval: [LN] -> linear1 -> relu -> linear2."""
+    if pre + "layernorm.weight" in sd:
+        w = sd[pre + "layernorm.weight"]
+        x = F.layer_norm(x, (w.shape[0],), w, sd[pre + "layernorm.bias"], 1e-5)
+    return _lin(sd, pre + "linear2", torch.relu(_lin(sd, pre + "linear1", x)))
+
+
+def cluster_centers(head, center, eps, min_samples, choose_prob):
+    """model.py:147-167 / 487-507: DBSCAN (scikit-learn, the reference's own dependency) over the residues predicted to
+    be pocket; python's `random` decides which cluster / whether to keep the soft centre."""
+    import random
+    from sklearn.cluster import DBSCAN
+    db = DBSCAN(eps=eps, min_samples=min_samples)
+    centers = torch.zeros_like(center)
+    prob = torch.sigmoid(head["logits"])
+    for i in range(center.shape[0]):
+        pp = prob[i]
+        sel = pp > 0.5
+        if int(sel.sum()) < 50:
+            top = torch.argsort(pp)[-50:]
+            sel = torch.zeros_like(sel)
+            sel[top] = True
+        pts = head["xyz_dense"][i][sel].numpy()
+        cl = db.fit(pts)
+        cid = random.randint(0, cl.labels_.max())
+        if random.random() < choose_prob:
+            centers[i] = torch.tensor(pts[cl.labels_ == cid].mean(axis=0))
+        else:
+            centers[i] = center[i]
+    return centers
+
+
+def model_inference(sd, cfg, data, confidence=False, stack_mlp=False, clustering=None):
+    """FABindPlus.inference(data), model.py:403-670 -> (coords in the whole-protein frame [sum Nc, 3] A, compound_batch
+    [, confidence score per complex]).  clustering = (eps, min_samples, choose_cluster_prob) or None."""
     scale = cfg["coordinate_scale"]
     head = _pocket_head(sd, cfg, data)
     center = _soft_center(head["logits"], head["p_mask"], head["xyz_dense"], cfg["gs_tau"], cfg["gs_hard"])
+    if clustering is not None:
+        center = cluster_centers(head, center, *clustering)
     g = _stage2_graph(sd, cfg, data, head, center, shift_coords=False)
-    _, _, _, _, _, coords_n = _complex(sd, cfg, g)
+    _, Ho, _, _, _, coords_n = _complex(sd, cfg, g)
     c_batch = data["compound"].batch
-    return coords_n * scale + g["bias"][c_batch], c_batch
+    coords = coords_n * scale + g["bias"][c_batch]
+    if not confidence:
+        return coords, c_batch
+    pooled = torch.zeros(head["B"], Ho.shape[1]).index_add_(0, g["batch"], Ho)
+    if stack_mlp:
+        pooled = torch.relu(_mlp4conf(sd, "ranking_mlp_pre.", pooled))
+    return coords, c_batch, _mlp4conf(sd, "ranking_score_mlp.", pooled)[:, 0]

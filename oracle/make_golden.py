@@ -305,6 +305,44 @@ def golden_model_plus(mods, name, sizes, hidden, pocket_hidden, layers, n_iter, 
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def golden_model_plus_sampling(mods, name, sizes, hidden, pocket_hidden, layers, n_iter, seed):
+    """FABind+ sampling-mode pieces in eval (deterministic) form: confidence / ranking head (stack_mlp) and the DBSCAN
+    centre choice (python `random` seeded) -> inference 3-tuple."""
+    import random
+    torch.manual_seed(seed)
+    args = refshim.production_args_plus(hidden_size=hidden, pocket_pred_hidden_size=pocket_hidden, mean_layers=layers,
+                                        n_iter=n_iter, random_n_iter=False, min_pocket_radius=10.0, confidence_training=True,
+                                        stack_mlp=True, confidence_use_ln_mlp=True, confidence_dropout=0.2,
+                                        confidence_mlp_hidden_scale=1, use_clustering=True, dbscan_eps=9.0,
+                                        dbscan_min_samples=2, choose_cluster_prob=0.5)
+    model = mods["models.model"].get_model(args, _Logger()).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("coord_mlp.linear2.weight"):
+                p.mul_(COORD_GAIN)
+            if n in ("protein_linear_whole_protein.weight", "compound_linear_whole_protein.weight", "embedding_shrink.weight",
+                     "embedding_enlarge.weight"):
+                p.mul_(300.0)
+    data = synthetic.make_hetero_batch(sizes, seed=seed)
+    save = {"sizes": np.array(sizes), "cfg": np.array([hidden, pocket_hidden, layers, n_iter, seed]),
+            "min_pocket_radius": np.array(10.0), "py_seed": np.array(4321)}
+    save.update({"w_" + k: _np(v) for k, v in model.state_dict().items()})
+    random.seed(4321)
+    with torch.no_grad():
+        out = model.inference(_hetero_to_ref(data))
+    save["inf_coords"], save["inf_batch"], save["inf_conf"] = _np(out[0]), _np(out[1]), _np(out[2])
+    print("%s: confidence %s" % (name, _np(out[2])))
+    for key, st in data._stores.items():
+        kname = key if isinstance(key, str) else "|".join(key)
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                save["d_%s::%s" % (kname, k)] = _np(v)
+    for k, v in data._glob.items():
+        if torch.is_tensor(v):
+            save["d_::%s" % k] = _np(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def main_plus():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
@@ -312,6 +350,7 @@ def main_plus():
     golden_stack_plus(mods, "plus_stack_tiny_it1", [(24, 7), (31, 5)], 32, 2, 1, seed=10)
     golden_stack_plus(mods, "plus_stack_tiny_it2", [(40, 9), (26, 6), (33, 12)], 64, 3, 2, seed=11)
     golden_model_plus(mods, "plus_model_tiny", [(70, 8), (85, 6)], 64, 32, 2, 2, seed=12)
+    golden_model_plus_sampling(mods, "plus_model_sampling_tiny", [(120, 8), (140, 11)], 64, 32, 2, 1, seed=13)
 
 
 def main():

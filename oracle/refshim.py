@@ -184,7 +184,8 @@ def _install_stubs():
     tg.utils, tg.data = tgu, tgd
     sys.modules.update({"torch_geometric": tg, "torch_geometric.utils": tgu, "torch_geometric.data": tgd})
 
-    for name in ("torchmetrics", "rdkit", "rdkit.Chem", "rdkit.Chem.rdMolTransforms", "rdkit.Geometry"):
+    for name in ("torchmetrics", "rdkit", "rdkit.Chem", "rdkit.Chem.rdMolTransforms", "rdkit.Geometry", "mlflow",
+                 "mlflow.sklearn"):
         if name not in sys.modules:
             m = types.ModuleType(name)
             sys.modules[name] = m
@@ -192,6 +193,8 @@ def _install_stubs():
     sys.modules["rdkit.Chem"].rdMolTransforms = sys.modules["rdkit.Chem.rdMolTransforms"]
     sys.modules["rdkit"].Geometry = sys.modules["rdkit.Geometry"]
     sys.modules["rdkit.Geometry"].Point3D = object
+    sys.modules["mlflow"].sklearn = sys.modules["mlflow.sklearn"]
+    sys.modules["mlflow.sklearn"].autolog = lambda *a, **k: None
 
     class _Any:
         def __init__(self, *a, **k):

@@ -143,3 +143,69 @@ def test_plus_model_inference_matches_reference():
     coords, batch = m.inference(hetero_from_npz(g).to(dev))
     assert rmsd(coords.cpu().numpy(), g["inf_coords"]) < 1e-4                         # whole-protein frame
     assert np.array_equal(batch.cpu().numpy(), g["s2_compound_batch"])
+
+
+def _sampling_model(g, dev):
+    from fabind_amd.plus.models import get_model
+    hidden, pocket_hidden, layers, n_iter, _ = [int(v) for v in g["cfg"]]
+    a = _args(hidden, layers, n_iter)
+    for k, v in dict(pocket_pred_hidden_size=pocket_hidden, pocket_pred_layers=1, pocket_pred_n_iter=1, random_n_iter=False,
+                     use_for_radius_pred="ligand", dis_map_thres=15.0, pocket_radius_buffer=5.0,
+                     min_pocket_radius=float(g["min_pocket_radius"]), force_fix_radius=False, gs_tau=1.0, gs_hard=False,
+                     pocket_radius=20.0, train_pred_pocket_noise=0.0, local_eval=False, confidence_training=True, stack_mlp=True,
+                     confidence_use_ln_mlp=True, confidence_dropout=0.2, confidence_mlp_hidden_scale=1, use_clustering=True,
+                     dbscan_eps=9.0, dbscan_min_samples=2, choose_cluster_prob=0.5).items():
+        setattr(a, k, v)
+    m = get_model(a, _Logger())
+    m.load_state_dict(weights(g), strict=True)
+    return m.to(dev)
+
+
+def test_plus_sampling_inference_eval_matches_reference():
+    """BASELINE config 5 building blocks, deterministic form: DBSCAN pocket-centre choice (python `random` seeded like the
+    reference run) + confidence / ranking head -> inference 3-tuple."""
+    import random
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision("fp32")
+    g = load_npz("plus_model_sampling_tiny")
+    m = _sampling_model(g, dev).eval()
+    random.seed(int(g["py_seed"]))
+    coords, batch, conf = m.inference(hetero_from_npz(g).to(dev))
+    assert rmsd(coords.cpu().numpy(), g["inf_coords"]) < 1e-4
+    assert np.abs(conf.cpu().numpy() - g["inf_conf"]).max() <= 1e-4 * max(1.0, np.abs(g["inf_conf"]).max())
+
+
+def test_plus_dropout_sampling_produces_a_pose_distribution():
+    """`--infer-dropout` sampling (inference_sampling_fabind.py:148-152): model.train() with the ranking head in eval; poses
+    differ between passes, stay finite and close to the deterministic pose; eval passes are reproducible."""
+    import random
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision("bf16")
+    try:
+        g = load_npz("plus_model_sampling_tiny")
+        m = _sampling_model(g, dev)
+        m.eval()
+        random.seed(1)
+        ref, _, _ = m.inference(hetero_from_npz(g).to(dev))
+        random.seed(1)
+        ref2, _, _ = m.inference(hetero_from_npz(g).to(dev))
+        assert torch.equal(ref, ref2)
+        m.train()
+        for name, sub in m.named_modules():
+            if name.startswith("confidence") or name.startswith("ranking"):
+                sub.eval()
+        torch.manual_seed(0)
+        poses = []
+        for _ in range(4):
+            random.seed(1)
+            c, _, conf = m.inference(hetero_from_npz(g).to(dev))
+            assert torch.isfinite(c).all() and torch.isfinite(conf).all()
+            poses.append(c)
+        spread = torch.stack(poses).std(0).mean().item()
+        drift = (torch.stack(poses).mean(0) - ref).norm(dim=-1).mean().item()
+        print("dropout sampling: mean per-atom std %.3f A, mean drift from the eval pose %.3f A" % (spread, drift))
+        assert spread > 1e-3 and drift < 5.0
+    finally:
+        engine.set_precision("fp32")

@@ -210,3 +210,15 @@ def test_plus_model_inference_matches_reference():
     with torch.no_grad():
         coords, _ = porc.model_inference(weights(g), _plus_model_cfg(g), hetero_from_npz(g))
     assert rmsd(coords.numpy(), g["inf_coords"]) < 2e-5
+
+
+def test_plus_sampling_inference_matches_reference():
+    """Confidence / ranking head (stack_mlp) + DBSCAN centre choice: FABindPlus.inference 3-tuple, eval mode, seeded."""
+    import random
+    g = load_npz("plus_model_sampling_tiny")
+    random.seed(int(g["py_seed"]))
+    with torch.no_grad():
+        coords, batch, conf = porc.model_inference(weights(g), _plus_model_cfg(g), hetero_from_npz(g), confidence=True,
+                                                   stack_mlp=True, clustering=(9.0, 2, 0.5))
+    assert rmsd(coords.numpy(), g["inf_coords"]) < 2e-5
+    assert np.abs(conf.numpy() - g["inf_conf"]).max() <= 2e-5 * max(1.0, np.abs(g["inf_conf"]).max())
