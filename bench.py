@@ -100,10 +100,13 @@ def main():
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--n-iter", type=int, default=1)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--mode", default="fwdbwd", choices=["fwd", "fwdbwd", "model"],
+    ap.add_argument("--poses", type=int, default=20, help="plus_sampling: poses sampled per complex and step")
+    ap.add_argument("--mode", default="fwdbwd", choices=["fwd", "fwdbwd", "model", "plus_sampling"],
                     help="fwd / fwdbwd: the layer stack on the whole graph (SURVEY 8(d), the headline); model: the full "
                          "IaBNet (pocket model on the whole protein -> pocket crop -> complex model -> heads) with the "
-                         "pocket-cls + coord + distmap losses, fwd+bwd (BASELINE configs[2] read literally)")
+                         "pocket-cls + coord + distmap losses, fwd+bwd (BASELINE configs[2] read literally); plus_sampling: "
+                         "FABind+ sampling-mode inference (BASELINE configs[4]: dropout sampling, DBSCAN centre choice, "
+                         "confidence head, --poses per complex)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -127,7 +130,33 @@ def main():
     from fabind_amd import engine
     from fabind_amd import kernels as K
     engine.set_precision(a.precision)
-    if a.mode == "model":
+    if a.mode == "plus_sampling":
+        from fabind_amd import synthetic
+        from fabind_amd.plus.models import get_model as get_model_plus
+
+        class _Log:
+            def log_message(self, m):
+                pass
+        margs = stack_args(a.hidden, a.layers if a.layers != 4 else 5, a.n_iter)
+        for k_, v_ in dict(use_ln_mlp=True, mlp_hidden_scale=1, dropout=0.1, mha_heads=4, rel_dis_pair_bias="no",
+                           inter_additional_mlp=False, only_last_LAS=False, geom_reg_steps=1, use_for_radius_pred="ligand",
+                           dis_map_thres=15.0, pocket_radius_buffer=5.0, min_pocket_radius=20.0, force_fix_radius=False,
+                           use_clustering=True, dbscan_eps=9.0, dbscan_min_samples=2, choose_cluster_prob=0.5,
+                           confidence_training=True, stack_mlp=True, confidence_use_ln_mlp=True, confidence_dropout=0.2,
+                           confidence_mlp_hidden_scale=1).items():
+            setattr(margs, k_, v_)
+        torch.manual_seed(0)
+        model = get_model_plus(margs, _Log()).to(dev)
+        model.train()                                              # --infer-dropout: dropout on, ranking head in eval
+        for name_, sub_ in model.named_modules():
+            if name_.startswith("confidence") or name_.startswith("ranking"):
+                sub_.eval()
+        uniq = min(a.batch, 4)
+        hb = synthetic.make_hetero_batch([(a.n_prot, a.n_lig)] * a.batch if a.batch <= 8 else
+                                         [(a.n_prot, a.n_lig)] * uniq * ((a.batch + uniq - 1) // uniq), seed=rank).to(dev)
+        a.batch = int(hb["compound"].batch.max().item()) + 1
+        t = None
+    elif a.mode == "model":
         from fabind_amd import synthetic
         from fabind_amd.models import get_model
         from fabind_amd.models.model import compute_loss
@@ -154,6 +183,10 @@ def main():
     cot = None
 
     def step():
+        if a.mode == "plus_sampling":
+            for _ in range(a.poses):
+                model.inference(hb.clone())
+            return
         if a.mode == "model":
             for p in params:
                 p.grad = None
@@ -206,18 +239,23 @@ def main():
         torch.distributed.destroy_process_group()
     if rank != 0:
         return
-    value = a.batch * world * a.steps / dt
+    value = a.batch * world * a.steps / dt * (a.poses if a.mode == "plus_sampling" else 1)
     out = {
-        "metric": ("complexes/sec fwd+bwd, full IaBNet (pocket model + pocket crop + complex model + heads) with "
+        "metric": ("poses/sec, FABind+ sampling-mode inference (dropout sampling + DBSCAN centre + confidence head)"
+                   if a.mode == "plus_sampling" else
+                   "complexes/sec fwd+bwd, full IaBNet (pocket model + pocket crop + complex model + heads) with "
                    "pocket-cls + coord + distmap losses" if a.mode == "model" else
                    "complexes/sec %s (1500p/40l nodes), one stack pass per refinement iteration" % (
                        "fwd+bwd" if a.mode == "fwdbwd" else "fwd")),
-        "value": value, "unit": "complexes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "value": value, "unit": "poses/s" if a.mode == "plus_sampling" else "complexes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": a.precision, "data": "synthetic",
-        "config": {"workload": "synthetic batch=%d/GPU, %d protein / %d ligand nodes, %d-layer FABind stack + out layer, "
-                               "hidden %d, n_iter=%d, %s" % (a.batch, a.n_prot, a.n_lig, a.layers, a.hidden, a.n_iter,
-                                                             a.mode),
+        "config": {"workload": ("synthetic batch=%d/GPU, %d protein / %d ligand nodes, FABind+ model (5-layer LN-MLP stack, hidden "
+                                "%d, n_iter=%d), %d poses per complex and step" % (a.batch, a.n_prot, a.n_lig, a.hidden,
+                                                                                    a.n_iter, a.poses))
+                   if a.mode == "plus_sampling" else
+                   "synthetic batch=%d/GPU, %d protein / %d ligand nodes, %d-layer FABind stack + out layer, "
+                   "hidden %d, n_iter=%d, %s" % (a.batch, a.n_prot, a.n_lig, a.layers, a.hidden, a.n_iter, a.mode),
                    "global_batch": a.batch * world, "n_iter": a.n_iter, "pass": a.mode},
     }
     # ---- roofline of the dominant kernel (live HIP-event timing of every GEMM launch in the timed region)

@@ -106,9 +106,16 @@ def load():
     return lib
 
 
+_DEBUG_SYNC = os.environ.get("FABIND_DEBUG_SYNC", "0") == "1"     # development aid: surface a device fault at its launch
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, load().fabind_last_error().decode()))
+    if _DEBUG_SYNC:
+        import torch
+        print("[fabind] " + what, flush=True)
+        torch.cuda.synchronize()
 
 
 def ptr(t):

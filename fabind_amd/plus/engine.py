@@ -30,7 +30,9 @@ def _wd():
 
 
 def _pad8(n):
-    return (n + 7) // 8 * 8
+    """Contraction dims are padded to a multiple of 64 (zero weights / zero columns): the LDS-DMA pipelined GEMM needs
+    K % 64 == 0, the 2H+1 = 1025-wide edge MLP would otherwise fall back to the register-staged kernel."""
+    return (n + 63) // 64 * 64
 
 
 def _padded(w, rows, cols):
