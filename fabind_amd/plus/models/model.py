@@ -274,6 +274,54 @@ class FABindPlus(nn.Module):
         return coords, cb
 
 
+def best_isomorphism_index(pos_x, pos_y, num_atoms, isomorphisms):
+    """Per ligand, the precomputed automorphism (index list) with the smallest mean SmoothL1 to the target
+    (reference utils/permutation_loss.py:4-33).  Small per-ligand index work on the device, no gradient."""
+    import torch.nn.functional as F
+    idx, pre = [], 0
+    with torch.no_grad():
+        for n, isos in zip(num_atoms, isomorphisms):
+            n = int(n)
+            isos = torch.as_tensor(isos, dtype=torch.long, device=pos_x.device).reshape(-1, n)
+            if isos.shape[0] == 1:
+                idx.append(isos[0] + pre)
+            else:
+                x, y = pos_x[pre:pre + n], pos_y[pre:pre + n]
+                losses = F.smooth_l1_loss(x[isos], y[None].expand(isos.shape[0], -1, -1), reduction="none").mean(dim=(1, 2))
+                idx.append(isos[int(torch.argmin(losses))] + pre)
+            pre += n
+    return torch.cat(idx)
+
+
+def compute_loss(out, data, args=None):
+    """FABind+ train-step loss (reference utils/training.py:55-97 with the criteria of main_fabind.py:151-158) as a function
+    of the forward's 13-tuple; reads `data.coords` AFTER forward (pocket frame), `data.coords_center`, `data.ligand_radius`,
+    and -- with --permutation-invariant -- `data.num_atoms` / `data.isomorphisms`.  Returns (loss, dict of the 7 terms)."""
+    import torch.nn.functional as F
+    w = dict(coord=1.5, pair=1.0, distill=1.0, cls=1.0, center=0.05, radius=0.05, delta=3.0, perm=True)
+    if args is not None:
+        w.update(coord=args.coord_loss_weight, pair=args.pair_distance_loss_weight,
+                 distill=args.pair_distance_distill_loss_weight, cls=args.pocket_cls_loss_weight,
+                 center=args.pocket_distance_loss_weight, radius=args.pocket_radius_loss_weight,
+                 delta=args.pocket_coord_huber_delta, perm=args.permutation_invariant)
+    coords, cb, y_pred, y_by, logits, pocket_cls, p_mask, _, center, dis_map, _, radius, _ = out
+    cls = w["cls"] * F.binary_cross_entropy_with_logits(logits, pocket_cls.float()) * (p_mask.numel() / p_mask.sum())
+    cen = w["center"] * F.huber_loss(center, data.coords_center, delta=w["delta"])
+    contact = w["pair"] * F.mse_loss(y_pred, dis_map)
+    contact_by = w["pair"] * F.mse_loss(y_by, dis_map)
+    distill = w["distill"] * F.mse_loss(y_by, y_pred)
+    rad = w["radius"] * F.huber_loss(radius.squeeze(1), data.ligand_radius.to(radius.dtype), delta=w["delta"])
+    target = data.coords
+    if w["perm"]:
+        new_idx = best_isomorphism_index(coords, target, data.num_atoms, data.isomorphisms)
+        coord = w["coord"] * F.smooth_l1_loss(coords[new_idx], target, reduction="none").mean()
+    else:
+        coord = w["coord"] * F.smooth_l1_loss(coords, target)
+    total = coord + contact + contact_by + distill + cls + rad + cen
+    return total, dict(coord=coord, contact=contact, contact_by_pred=contact_by, distill=distill, pocket_cls=cls,
+                       pocket_radius=rad, pocket_center=cen)
+
+
 def get_model(args, logger):
     logger.log_message("FABind plus")
     return FABindPlus(args, args.hidden_size, args.pocket_pred_hidden_size)

@@ -315,3 +315,40 @@ def model_inference(sd, cfg, data, confidence=False, stack_mlp=False, clustering
     if stack_mlp:
         pooled = torch.relu(_mlp4conf(sd, "ranking_mlp_pre.", pooled))
     return coords, c_batch, _mlp4conf(sd, "ranking_score_mlp.", pooled)[:, 0]
+
+
+# ------------------------------------------------------------------------------------------------
+# train-step loss of FABind+ (FABind_plus/fabind/utils/training.py:55-97, utils/permutation_loss.py:4-38,
+# main_fabind.py:151-158): permutation-invariant SmoothL1 over precomputed ligand automorphisms + 6 further terms
+# ------------------------------------------------------------------------------------------------
+def best_isomorphism_index(pos_x, pos_y, num_atoms, isomorphisms):
+    """permutation_loss.py:4-33: per ligand, the automorphism (index list) minimising the mean SmoothL1 to the target."""
+    idx, pre = [], 0
+    with torch.no_grad():
+        for n, isos in zip(num_atoms, isomorphisms):
+            isos = [torch.as_tensor(i, dtype=torch.long) for i in isos]
+            if len(isos) == 1:
+                idx.append(isos[0] + pre)
+            else:
+                x, y = pos_x[pre:pre + n], pos_y[pre:pre + n]
+                losses = torch.stack([F.smooth_l1_loss(x[i], y, reduction="none").mean() for i in isos])
+                idx.append(isos[int(torch.argmin(losses))] + pre)
+            pre += n
+    return torch.cat(idx)
+
+
+def compute_loss(out, coords_true, data, num_atoms, isomorphisms, ligand_radius, w=None):
+    """-> (total, dict of the 7 terms).  `coords_true` = data.coords AFTER forward (pocket frame)."""
+    w = dict(coord=1.5, pair=1.0, distill=1.0, cls=1.0, center=0.05, radius=0.05, huber_delta=3.0) if w is None else w
+    coords, c_batch, y_pred, y_by, logits, pocket_cls, p_mask, _, center, dis_map, _, radius, _ = out
+    cls = w["cls"] * F.binary_cross_entropy_with_logits(logits, pocket_cls.float()) * (p_mask.numel() / p_mask.sum())
+    cen = w["center"] * F.huber_loss(center, data.coords_center, delta=w["huber_delta"])
+    contact = w["pair"] * F.mse_loss(y_pred, dis_map)
+    contact_by = w["pair"] * F.mse_loss(y_by, dis_map)
+    distill = w["distill"] * F.mse_loss(y_by, y_pred)
+    rad = w["radius"] * F.huber_loss(radius[:, 0], ligand_radius.to(radius.dtype), delta=w["huber_delta"])
+    new_idx = best_isomorphism_index(coords, coords_true, num_atoms, isomorphisms)
+    coord = w["coord"] * F.smooth_l1_loss(coords[new_idx], coords_true, reduction="none").mean()
+    total = coord + contact + contact_by + distill + cls + rad + cen
+    return total, dict(coord=coord, contact=contact, contact_by_pred=contact_by, distill=distill, pocket_cls=cls,
+                       pocket_radius=rad, pocket_center=cen)

@@ -343,6 +343,64 @@ def golden_model_plus_sampling(mods, name, sizes, hidden, pocket_hidden, layers,
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def golden_plus_loss(mods, name, seed):
+    """The reference's own compute_permutation_loss (utils/permutation_loss.py) + the other train-step terms
+    (utils/training.py:61-97) on the stage-2 outputs stored in plus_model_tiny, with synthetic automorphism lists."""
+    import importlib
+    sys.path.insert(0, os.path.join(refshim.REFERENCE_ROOT, "FABind_plus", "fabind"))
+    try:
+        perm = importlib.import_module("utils.permutation_loss")
+    finally:
+        sys.path.pop(0)
+    g = dict(np.load(os.path.join(OUT, "plus_model_tiny.npz")))
+    gen = torch.Generator().manual_seed(seed)
+    t = lambda k: torch.from_numpy(g[k])
+    coords, cb = t("s2_coords"), t("s2_compound_batch")
+    B = int(cb.max()) + 1
+    num_atoms = torch.bincount(cb, minlength=B).tolist()
+    isos = []
+    for n in num_atoms:                                   # identity + 3 random permutations (2 for odd complexes)
+        cur = [list(range(n))]
+        for _ in range(3):
+            cur.append(torch.randperm(n, generator=gen).tolist())
+        isos.append(cur)
+    isos[-1] = [list(range(num_atoms[-1]))]               # a ligand without symmetry: single automorphism
+    target = t("s2_data_coords") + 0.3 * torch.randn(coords.shape, generator=gen)
+    # make a non-identity automorphism the best one for complex 0
+    n0 = num_atoms[0]
+    target[:n0] = coords[:n0][torch.tensor(isos[0][2])] + 0.05 * torch.randn(n0, 3, generator=gen)
+
+    class _D:
+        pass
+    d = _D()
+    d.num_atoms, d.isomorphisms = num_atoms, isos
+    d.__len__ = lambda self=None: B
+    _D.__len__ = lambda self: B
+    crit = torch.nn.SmoothL1Loss(reduction="none")
+    new_idx = perm.update_best_isomorphism_idx(coords, target, d, crit)
+    coord_loss = 1.5 * perm.compute_permutation_loss(coords, target, d, crit).mean()
+    F = torch.nn.functional
+    logits, pocket_cls, p_mask = t("s2_pocket_cls_pred"), t("s2_pocket_cls"), t("s2_protein_out_mask_whole")
+    ligand_radius = torch.tensor([6.0, 4.5])
+    center_true = torch.from_numpy(g["d_::coords_center"])
+    terms = dict(
+        coord=coord_loss,
+        pocket_cls=F.binary_cross_entropy_with_logits(logits, pocket_cls.float()) * (p_mask.numel() / p_mask.sum()),
+        pocket_center=0.05 * torch.nn.HuberLoss(delta=3.0)(t("s2_pred_pocket_center"), center_true),
+        contact=F.mse_loss(t("s2_y_pred"), t("s2_dis_map")), contact_by_pred=F.mse_loss(t("s2_y_pred_by_coords"), t("s2_dis_map")),
+        distill=F.mse_loss(t("s2_y_pred_by_coords"), t("s2_y_pred")),
+        pocket_radius=0.05 * torch.nn.HuberLoss(delta=3.0)(t("s2_pocket_radius_pred").squeeze(1), ligand_radius))
+    save = {"target": _np(target), "new_idx": _np(new_idx), "ligand_radius": _np(ligand_radius), "loss": _np(sum(terms.values())),
+            "n_iso": np.array([len(i) for i in isos])}
+    for b, cur in enumerate(isos):
+        save["iso_%d" % b] = np.array(cur)
+    for k, v in terms.items():
+        save["loss_" + k] = _np(v)
+    print(name, {k: round(float(v), 5) for k, v in terms.items()}, "best iso of complex 0 non-identity:",
+          bool((new_idx[:n0] != torch.arange(n0)).any()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def main_plus():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
@@ -351,6 +409,7 @@ def main_plus():
     golden_stack_plus(mods, "plus_stack_tiny_it2", [(40, 9), (26, 6), (33, 12)], 64, 3, 2, seed=11)
     golden_model_plus(mods, "plus_model_tiny", [(70, 8), (85, 6)], 64, 32, 2, 2, seed=12)
     golden_model_plus_sampling(mods, "plus_model_sampling_tiny", [(120, 8), (140, 11)], 64, 32, 2, 1, seed=13)
+    golden_plus_loss(mods, "plus_loss_tiny", seed=14)
 
 
 def main():
