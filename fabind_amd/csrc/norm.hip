@@ -78,6 +78,9 @@ extern "C" int fabind_layernorm_bwd(const float* x, const float* w, const float*
 // Row LayerNorm with free input / output types and strides; columns [C, pad_to) of the output are zero-filled so that the
 // result can feed a GEMM whose contraction dimension is padded to a multiple of 8.  One wave per row.
 // ------------------------------------------------------------------------------------------------
+// NPL = ceil(C / 64) values per lane are kept in registers: the row is read once (2-byte / 4-byte scalar loads, 64
+// consecutive columns per wave instruction), statistics by wave reductions, one write.
+template <int NPL>
 __global__ __launch_bounds__(256) void layernorm_rows_kernel(const void* __restrict__ x, int x_dt, int ldx,
                                                              const float* __restrict__ w, const float* __restrict__ b,
                                                              float eps, int R, int C, void* y, int y_dt, int ldy, int pad_to) {
@@ -85,21 +88,43 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const void* __restr
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
     const size_t xo = (size_t)r * ldx, yo = (size_t)r * ldy;
+    float v[NPL];
     float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += ld_any(x, x_dt, xo + c);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int c = k * 64 + lane;
+        v[k] = c < C ? ld_any(x, x_dt, xo + c) : 0.f;
+        s += v[k];
+    }
     const float mu = wave_sum(s) / (float)C;
-    float v = 0.f;
-    for (int c = lane; c < C; c += 64) { const float t = ld_any(x, x_dt, xo + c) - mu; v += t * t; }
-    const float rs = rsqrtf(wave_sum(v) / (float)C + eps);
-    for (int c = lane; c < C; c += 64) st_any(y, y_dt, yo + c, (ld_any(x, x_dt, xo + c) - mu) * rs * w[c] + b[c]);
-    for (int c = C + lane; c < pad_to; c += 64) st_any(y, y_dt, yo + c, 0.f);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int c = k * 64 + lane;
+        const float t = c < C ? v[k] - mu : 0.f;
+        q += t * t;
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int c = k * 64 + lane;
+        if (c < C) st_any(y, y_dt, yo + c, (v[k] - mu) * rs * w[c] + b[c]);
+        else if (c < pad_to) st_any(y, y_dt, yo + c, 0.f);
+    }
+    for (int c = NPL * 64 + lane; c < pad_to; c += 64) st_any(y, y_dt, yo + c, 0.f);
 }
 extern "C" int fabind_layernorm_rows(const void* x, int x_dt, int ldx, const float* w, const float* b, float eps, int R, int C,
                                      void* y, int y_dt, int ldy, int pad_to, hipStream_t stream) {
     if (R <= 0) return 0;
     FB_REQUIRE(pad_to <= ldy && C <= ldx, "fabind_layernorm_rows: pad_to <= ldy, C <= ldx");
-    hipLaunchKernelGGL(layernorm_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, x, x_dt, ldx, w, b, eps, R, C, y, y_dt,
-                       ldy, pad_to);
+    FB_REQUIRE(C <= 2048, "fabind_layernorm_rows: C <= 2048");
+#define LNR_LAUNCH(NPL_) hipLaunchKernelGGL((layernorm_rows_kernel<NPL_>), dim3((R + 3) / 4), dim3(256), 0, stream, x, x_dt, ldx, \
+                                            w, b, eps, R, C, y, y_dt, ldy, pad_to)
+    if (C <= 128) LNR_LAUNCH(2);
+    else if (C <= 512) LNR_LAUNCH(8);
+    else if (C <= 1024) LNR_LAUNCH(16);
+    else LNR_LAUNCH(32);
+#undef LNR_LAUNCH
     FB_CHECK_LAUNCH();
     return 0;
 }

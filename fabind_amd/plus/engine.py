@@ -103,9 +103,13 @@ def prepare_stack_params(model):
         d["tr_p"], d["tr_c"] = _mlp(cam.p_transition, W), _mlp(cam.c_transition, W)
         d["tr_z"] = _mlp(cam.pair_transition, W)
         i32 = cam.inter_layer
-        d["W_ab32"] = W(_cat([i32.linear_p.weight, i32.linear_c.weight]))             # [64, H]: a32 | b32
-        d["b_ab32"] = _cat([i32.linear_p.bias, i32.linear_c.bias]).contiguous()
-        d["W_o32"], d["b_o32"] = W(i32.linear_out.weight), i32.linear_out.bias        # [H, 32]
+        # the 32-wide Hadamard block is zero-padded to 64 (a32 | 0 | b32 | 0) so that the contraction with W_o32 runs on the
+        # LDS-DMA GEMM path (K % 64 == 0); the padded columns are exact zeros
+        z32w, z32b = torch.zeros_like(i32.linear_p.weight), torch.zeros_like(i32.linear_p.bias)
+        d["W_ab32"] = W(_cat([i32.linear_p.weight, z32w, i32.linear_c.weight, z32w]))  # [128, H]
+        d["b_ab32"] = _cat([i32.linear_p.bias, z32b, i32.linear_c.bias, z32b]).contiguous()
+        d["W_o32"] = W(_cat([i32.linear_out.weight, torch.zeros_like(i32.linear_out.weight)], 1))   # [H, 64]
+        d["b_o32"] = i32.linear_out.bias
         Wkv, bkv = m.linear_kv.weight, m.linear_kv.bias
         d["Wqkv"] = W(_cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]]))
         d["bqkv"] = _cat([m.linear_q.bias, bkv[0::2], bkv[1::2]]).contiguous()
@@ -228,8 +232,8 @@ def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0):
     hc = ln_mlp(p["tr_c"], hc, True, residual=hc, pdrop=pd)
     h = ops.put_rows(hp, hc, lay.c_index64)
     # ---- pair update: z <- relu-MLP(LN(z + W_o32 (a32 * b32) + b_o32))   (no residual around pair_transition)
-    ab32 = ops.linear(h, p["W_ab32"], p["b_ab32"])                                                   # [N, 64]
-    hd32 = _pair_hadamard_call(ab32, 32, pairs.p_node, pairs.c_node, ad)                             # [pairs, 32]
+    ab32 = ops.linear(h, p["W_ab32"], p["b_ab32"])                                                   # [N, 128]
+    hd32 = _pair_hadamard_call(ab32, 64, pairs.p_node, pairs.c_node, ad)                             # [pairs, 64]
     z1 = ops.linear(hd32, p["W_o32"], p["b_o32"], residual=z.float() if z.dtype != torch.float32 else z, out_dtype=ad)
     z = ln_mlp(p["tr_z"], z1, True, out_dtype=ad, pdrop=pd)
     # ---- inter-edge attention (att_model / node_model identical to v1; coord_mlp is an LN-MLP on v_e)
