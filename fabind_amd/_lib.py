@@ -20,7 +20,8 @@ class GemmArgs(ctypes.Structure):
     _fields_ = [(n, _vp) for n in ("A", "A2", "W", "C", "bias", "R", "r_index", "dotvec", "dot_out", "aux", "groups", "C2")] + \
                [(n, _i) for n in ("M", "N", "K", "K1", "lda", "lda2", "ldw", "ldc", "ldr", "ldaux", "dot_ld",
                                   "a_dtype", "w_dtype", "c_dtype", "aux_dtype", "act_pro", "act_epi", "dact_epi",
-                                  "accumulate", "store_preact", "n_groups", "max_m", "max_n", "groups_ext", "epi_fast", "k_splits")] + [("alpha", _f)]
+                                  "accumulate", "store_preact", "n_groups", "max_m", "max_n", "groups_ext", "epi_fast", "k_splits")] + \
+               [("alpha", _f), ("p_drop", _f), ("drop_seed", ctypes.c_uint)]
 
 
 class EdgeBwdArgs(ctypes.Structure):

@@ -84,6 +84,12 @@ __device__ __forceinline__ float apply_dact(float x, int act) {
     }
 }
 
+// counter-based 32-bit hash (dropout masks evaluated in kernels: fused edge kernels, GEMM epilogue)
+__device__ __forceinline__ uint32_t fb_hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {  // all 64 lanes get the total
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -89,6 +89,8 @@ __device__ __forceinline__ void gemm_epilogue(const FabindGemmArgs& p, f32x4_t (
     const int cq = lane >> 4;
     const bool want_dot = p.dotvec != nullptr;
     const bool staged = sOut != nullptr && p.C != nullptr && p.c_dtype == FB_DT_BF16 && !p.accumulate;
+    const uint32_t drop_thr = (uint32_t)(p.p_drop * 65536.0f + 0.5f);
+    const float drop_scale = 1.0f / (1.0f - (float)drop_thr / 65536.0f);
 #pragma clang loop unroll(full)
     for (int i = 0; i < 4; ++i) {
         float ds0 = 0.f, ds1 = 0.f, ds2 = 0.f, ds3 = 0.f;
@@ -110,6 +112,7 @@ __device__ __forceinline__ void gemm_epilogue(const FabindGemmArgs& p, f32x4_t (
                     const float vpre = v;
                     v = apply_act(v, p.act_epi);
                     if (p.aux) v *= apply_dact(ld_any(p.aux, p.aux_dtype, (size_t)(a_row0 + row) * p.ldaux + col), p.dact_epi);
+                    if (drop_thr) v *= ((fb_hash32(p.drop_seed + (uint32_t)row * (uint32_t)N + (uint32_t)col) & 0xffffu) >= drop_thr) ? drop_scale : 0.f;
                     if (p.R) {
                         long rr = p.r_index ? (long)p.r_index[a_row0 + row] : (a_row0 + row);
                         v += ((const float*)p.R)[(size_t)rr * p.ldr + col];
@@ -980,6 +983,10 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     FB_REQUIRE(!(p.a_dtype == FB_DT_BF16 && (p.lda % 8 != 0)), "fabind_gemm: bf16 A needs lda % 8 == 0");
     FB_REQUIRE(!(p.w_dtype == FB_DT_BF16 && (p.ldw % 8 != 0)), "fabind_gemm: bf16 W needs ldw % 8 == 0");
     p.epi_fast = 0;
+    FB_REQUIRE(p.p_drop >= 0.f && p.p_drop < 1.f, "fabind_gemm: p_drop in [0, 1)");
+    if (p.p_drop > 0.f) {
+        /* dropout lives in the generic epilogue only */
+    } else
     if (!p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && !p.r_index && p.C != nullptr &&
         p.c_dtype == FB_DT_F32 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
         p.epi_fast = p.R ? 10 : 9;

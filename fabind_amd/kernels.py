@@ -34,7 +34,7 @@ def _ld(t):
 def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=None, r_index=None,
          out=None, out_dtype=torch.float32, want_out=True, dotvec=None, aux=None, dact=ACT_NONE, alpha=1.0,
          accumulate=False, groups=None, n_groups=0, max_m=0, max_n=0, M=None, N=None, ldc=None, k_splits=1,
-         out2=None, groups_ext=False):
+         out2=None, groups_ext=False, p_drop=0.0, seed=0):
     """C = epi(pro([A|A2]) @ W^T); see FabindGemmArgs.  Returns (C or None, dot_partials or None).
 
     `groups` (int32 [G,8] device tensor) selects the ragged-batched mode; then `out` must be given."""
@@ -74,6 +74,7 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     a.k_splits = k_splits
     a.groups_ext = 1 if groups_ext else 0
     a.alpha = alpha
+    a.p_drop, a.drop_seed = float(p_drop), int(seed) & 0xFFFFFFFF
     label = "fabind_gemm <%s,%s> M=%d N=%d K=%d" % (str(A.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""), M, N, K)
     _profiled(label, 2.0 * M * N * K, lambda: check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm"))
     return (out if want_out else None), dot_out

@@ -172,21 +172,26 @@ class _Linear(torch.autograd.Function):
         return dx, dW, db, dx2, dres, None, None
 
 
-def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, x2=None, out_dtype=torch.float32):
+def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, x2=None, out_dtype=torch.float32,
+           p_drop=0.0):
+    """p_drop > 0 (no-grad paths only): dropout on act(x W^T + b) inside the GEMM epilogue, before the residual; the mask is
+    a counter-based hash keyed by a seed drawn from torch's CPU generator."""
     if x.stride(-1) != 1:
         x = x.contiguous()
     if _needs_grad(x, W, b, x2, residual):
         assert act_pro == K.ACT_NONE, "producer-side activations only under autograd"
+        assert p_drop == 0.0, "epilogue dropout has no autograd path yet"
         return _Linear.apply(x, W, b, x2, residual, act_epi, out_dtype)
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
     y, _ = K.gemm(_mm_in(x), W, bias=b, A2=_mm_in(x2), act_pro=act_pro, act_epi=act_epi, residual=residual,
-                  out_dtype=out_dtype)
+                  out_dtype=out_dtype, p_drop=p_drop, seed=seed)
     return y
 
 
 # ------------------------------------------------------------------------------------------------
 # linear + row-dot:  s_part[m, t] = sum_{n in tile t} act_epi(act_pro(x) W^T + b)[m,n] * u[n]
 # ------------------------------------------------------------------------------------------------
-def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store):
+def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store, p_drop=0.0, seed=0):
     """GEMM with row-dot epilogue; store=True keeps the pre-activation matrix (training)."""
     M, Kd = x.shape
     N = W.shape[0]
@@ -199,6 +204,7 @@ def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store):
     a.lda, a.ldw, a.ldc, a.dot_ld = x.stride(0), W.stride(0), N, nt
     a.a_dtype, a.w_dtype, a.c_dtype = dt_code(x.dtype), dt_code(W.dtype), dt_code(z.dtype) if store else 0
     a.act_pro, a.act_epi, a.store_preact, a.alpha = act_pro, act_epi, 1, 1.0
+    a.p_drop, a.drop_seed = float(p_drop), int(seed) & 0xFFFFFFFF
     label = "fabind_gemm <%s,%s> M=%d N=%d K=%d" % (str(x.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""), M, N, Kd)
     K._profiled(label, 2.0 * M * N * Kd, lambda: check(load().fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm(rowdot)"))
     return z, part
@@ -231,10 +237,13 @@ class _LinearRowdot(torch.autograd.Function):
         return dx, dW, db, du, None, None
 
 
-def linear_rowdot(x, W, b, u, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE):
+def linear_rowdot(x, W, b, u, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, p_drop=0.0):
+    """p_drop > 0 (no-grad paths only): dropout on act(x W^T + b) before the row-dot with u, inside the epilogue."""
     if _needs_grad(x, W, b, u):
+        assert p_drop == 0.0, "epilogue dropout has no autograd path yet"
         return _LinearRowdot.apply(x, W, b, u, act_pro, act_epi)
-    return _gemm_rowdot(x, W, b, u, act_pro, act_epi, store=False)[1]
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
+    return _gemm_rowdot(x, W, b, u, act_pro, act_epi, store=False, p_drop=p_drop, seed=seed)[1]
 
 
 # ------------------------------------------------------------------------------------------------

@@ -179,15 +179,13 @@ def _drop(t, pr):
 
 
 def ln_mlp(m, x, last_act, residual=None, out_dtype=torch.float32, pdrop=0.0):
-    """LN -> linear1 -> relu -> [dropout] -> linear2 (-> relu -> [dropout]) (+ residual).  model_utils.py:10-74."""
+    """LN -> linear1 -> relu -> [dropout] -> linear2 (-> relu -> [dropout]) (+ residual).  model_utils.py:10-74; the
+    dropouts run inside the GEMM epilogues (before the residual)."""
     ad = ops.act_dtype()
     y = K.layernorm_rows(x, m["ln_w"], m["ln_b"], ad, m["k_pad"]) if m["ln_w"] is not None else x
-    t = _drop(ops.linear(y, m["W1"], m["b1"], act_epi=K.ACT_RELU, out_dtype=ad), pdrop)
-    act2 = K.ACT_RELU if last_act else K.ACT_NONE
-    if pdrop > 0.0 and last_act:
-        y2 = _drop(ops.linear(t, m["W2"], m["b2"], act_epi=act2, out_dtype=torch.float32), pdrop)
-        return (y2 if residual is None else residual + y2).to(out_dtype)
-    return ops.linear(t, m["W2"], m["b2"], act_epi=act2, residual=residual, out_dtype=out_dtype)
+    t = ops.linear(y, m["W1"], m["b1"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pdrop)
+    return ops.linear(t, m["W2"], m["b2"], act_epi=K.ACT_RELU if last_act else K.ACT_NONE, residual=residual,
+                      out_dtype=out_dtype, p_drop=pdrop if last_act else 0.0)
 
 
 def gcl_layer(p, h, x, lay, g, clampv, pd=0.0):
@@ -196,15 +194,12 @@ def gcl_layer(p, h, x, lay, g, clampv, pd=0.0):
     e = p["edge"]
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
     y = K.edge_ln_concat(h, g.row_ctx, g.col_ctx, rhohat, e["ln_w"], e["ln_b"], ad, e["k_pad"])     # [E, K8]
-    t = _drop(ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad), pd)              # [E, K8]
-    m = _drop(ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad), pd)              # [E, H] messages
+    t = ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)               # [E, K8]
+    m = ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)               # [E, H] messages
     c = p["coord"]
     yc = K.layernorm_rows(m, c["ln_w"], c["ln_b"], ad, c["k_pad"])
-    if pd > 0.0:                                                # dropout sits between relu(linear1) and the bias-free linear2
-        tc = _drop(ops.linear(yc, c["W1"], c["b1"], act_epi=K.ACT_RELU, out_dtype=torch.float32), pd)
-        s = (tc * c["w3"]).sum(1, keepdim=True)
-    else:
-        s = ops.linear_rowdot(yc, c["W1"], c["b1"], c["w3"], act_epi=K.ACT_RELU)                    # [E, nt]
+    # coord_mlp: dropout sits between relu(linear1) and the bias-free linear2 = the row-dot of the epilogue
+    s = ops.linear_rowdot(yc, c["W1"], c["b1"], c["w3"], act_epi=K.ACT_RELU, p_drop=pd)             # [E, nt]
     x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
     agg = K.segment_sum(m, g.rp_ctx, h.shape[0])
     h_new = ln_mlp(p["node"], torch.cat([h, agg], 1), True, residual=h, pdrop=pd)
@@ -223,11 +218,11 @@ def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0):
     qg = ops.linear(h, p["Wqg_p"], p["bqg_p"])
     kv = ops.linear(hc, p["Wkv_p"])
     og = ops.cross_attn(qg, kv, bias, 0, 4, lay.desc_pf, lay.B, lay.max_P, lay.max_C, scale)
-    hp = ops.linear(og, p["Wo_p"], p["bo_p"], residual=h) if pd == 0.0 else h + _drop(ops.linear(og, p["Wo_p"], p["bo_p"]), pd)
+    hp = ops.linear(og, p["Wo_p"], p["bo_p"], residual=h, p_drop=pd)
     qg = ops.linear(hc, p["Wqg_c"], p["bqg_c"])
     kv = ops.linear(hp, p["Wkv_c"])
     og = ops.cross_attn(qg, kv, bias, 8, 12, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
-    hc = ops.linear(og, p["Wo_c"], p["bo_c"], residual=hc) if pd == 0.0 else hc + _drop(ops.linear(og, p["Wo_c"], p["bo_c"]), pd)
+    hc = ops.linear(og, p["Wo_c"], p["bo_c"], residual=hc, p_drop=pd)
     hp = ln_mlp(p["tr_p"], hp, True, residual=hp, pdrop=pd)
     hc = ln_mlp(p["tr_c"], hc, True, residual=hc, pdrop=pd)
     h = ops.put_rows(hp, hc, lay.c_index64)
@@ -250,18 +245,14 @@ def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0):
     v_e = K.gcl_pre(AB, H, g.row_int, g.col_int, rhohat, p["w_rv"], ad)
     c = p["coord"]
     yc = K.layernorm_rows(v_e, c["ln_w"], c["ln_b"], ad, c["k_pad"])
-    if pd > 0.0:
-        tc = _drop(ops.linear(yc, c["W1"], c["b1"], act_epi=K.ACT_RELU, out_dtype=torch.float32), pd)
-        s = (tc * c["w3"]).sum(1, keepdim=True)
-    else:
-        s = ops.linear_rowdot(yc, c["W1"], c["b1"], c["w3"], act_epi=K.ACT_RELU)
+    s = ops.linear_rowdot(yc, c["W1"], c["b1"], c["w3"], act_epi=K.ACT_RELU, p_drop=pd)
     x_new, _ = K.coord_update(x, d, s, g.rp_int, False, clampv, weight=alpha)
     return h_new, x_new, alpha, z
 
 
 def egnn_forward(P, h, x, z0, lay, g, las, x_las, pairs, batch_id, scale, step, capture=None, pd=0.0):
     clampv = 10.0 / scale
-    h = _drop(ops.linear(h, P["W_in"], P["b_in"]), pd)
+    h = ops.linear(h, P["W_in"], P["b_in"], p_drop=pd)
     z = z0
     for i in range(P["L"]):
         h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv, pd)

@@ -64,6 +64,9 @@ typedef struct FabindGemmArgs {
     int epi_fast; /* set by fabind_gemm itself: index of a specialised epilogue (0 = generic) */
     int k_splits; /* >1: split the K loop over k_splits work-groups; C must be fp32 [k_splits, M, N] partials */
     float alpha;
+    float p_drop;       /* > 0: epilogue dropout (train / sampling mode): after bias + activation, before the residual, the value is
+                           multiplied by keep/(1-p) with keep = [hash32(drop_seed + row*N + col) & 0xffff >= round(p*65536)] */
+    unsigned drop_seed;
 } FabindGemmArgs;
 
 int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream);

@@ -293,3 +293,31 @@ def test_pair_bias_adjoint_gemm_path_matches_valu_path():
     for mode, tol in (("fp32", 2e-4), ("bf16", 3e-2)):
         for got, ref in zip(res[mode], (a_ref.grad, w_ref.grad, b_ref.grad)):
             assert (got - ref).abs().max() <= tol * float(ref.abs().max()), mode
+
+
+def test_gemm_epilogue_dropout_statistics_and_order():
+    """FabindGemmArgs.p_drop: Bernoulli(p) zeros on act(x W^T + b), survivors scaled by 1/(1-p), applied BEFORE the residual;
+    the same seed reproduces the mask, the row-dot epilogue sees the dropped values."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    M, N, Kd, p = 3000, 256, 128, 0.25
+    A = torch.randn(M, Kd, generator=g).bfloat16().to(dev)
+    W = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).bfloat16().to(dev)
+    b = (torch.rand(N, generator=g) + 3.0).to(dev)                       # keeps relu(.) > 0: zeros come from dropout only
+    R = torch.randn(M, N, generator=g).to(dev)
+    base, _ = K.gemm(A, W, bias=b, act_epi=K.ACT_RELU)
+    y1, _ = K.gemm(A, W, bias=b, act_epi=K.ACT_RELU, residual=R, p_drop=p, seed=77)
+    y2, _ = K.gemm(A, W, bias=b, act_epi=K.ACT_RELU, residual=R, p_drop=p, seed=77)
+    y3, _ = K.gemm(A, W, bias=b, act_epi=K.ACT_RELU, residual=R, p_drop=p, seed=78)
+    assert torch.equal(y1, y2) and not torch.equal(y1, y3)
+    v = y1 - R                                                          # dropped rows equal the residual exactly
+    dropped = v.abs() < 1e-6
+    assert abs(float(dropped.float().mean()) - p) < 0.01
+    thr = round(p * 65536) / 65536.0
+    kept = ~dropped
+    assert ((v[kept] - base[kept] / (1 - thr)).abs() <= 1e-3 * base[kept].abs() + 1e-3).all()
+    u = torch.randn(N, generator=g).to(dev)
+    _, part = K.gemm(A, W, bias=b, act_epi=K.ACT_RELU, dotvec=u, want_out=False, p_drop=p, seed=77)
+    ref = ((y1 - R) * u).sum(1)
+    assert (part.sum(1) - ref).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max()))
