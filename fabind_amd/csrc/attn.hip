@@ -213,7 +213,8 @@ __global__ __launch_bounds__(256) void inter_attn_fwd_kernel(
     int ldh, const float* __restrict__ x, const float* __restrict__ d, const float* __restrict__ rhohat,
     const int* rowptr, const int* col, const int* red_idx, const float* bias_red, int bias_np,
     const float* __restrict__ w_rk, const float* __restrict__ w_rv, const float* __restrict__ wcr,
-    const float* __restrict__ w3, float clampv, int n_rows, float* h_out, float* x_out, float* alpha, float* cvs) {
+    const float* __restrict__ w3, float clampv, int n_rows, float* h_out, float* x_out, float* alpha, float* cvs,
+    const float* __restrict__ s_ext) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256) void inter_attn_fwd_kernel(
         }
         lp = wave_sum(lp);
         cp = wave_sum(cp);
+        if (s_ext) cp += s_ext[e];                 // FABind+: the coord_mlp is an LN-MLP evaluated outside (per-edge scalar)
         float bsum = 0.f;
         for (int kb = 0; kb < bias_np; ++kb) bsum += bias_red[(size_t)red_idx[e] * bias_np + kb];
         const float logit = lp + rh * qw + bsum;
@@ -302,7 +304,7 @@ extern "C" int fabind_inter_attn_fwd(const float* qkv, int ldqkv, const float* c
                                      const int* col, const int* red_idx, const float* bias_red, int bias_np,
                                      const float* w_rk, const float* w_rv, const float* wcr, const float* w3,
                                      float clampv, int n_rows, float* h_out, float* x_out, float* alpha, float* cvs,
-                                     hipStream_t stream) {
+                                     const float* s_ext, hipStream_t stream) {
     FB_REQUIRE(H % 4 == 0 && ldqkv % 4 == 0 && ldcv % 4 == 0 && ldh % 4 == 0, "fabind_inter_attn_fwd: % 4");
     FB_REQUIRE(H <= 1024, "fabind_inter_attn_fwd: H <= 1024");
     if (n_rows <= 0) return 0;
@@ -310,7 +312,7 @@ extern "C" int fabind_inter_attn_fwd(const float* qkv, int ldqkv, const float* c
 #define LAUNCH(NS)                                                                                                   \
     hipLaunchKernelGGL((inter_attn_fwd_kernel<NS>), grid, block, 0, stream, qkv, ldqkv, cv, ldcv, H, h, ldh, x, d,    \
                        rhohat, rowptr, col, red_idx, bias_red, bias_np, w_rk, w_rv, wcr, w3, clampv, n_rows, h_out, \
-                       x_out, alpha, cvs)
+                       x_out, alpha, cvs, s_ext)
     if (H <= 256) LAUNCH(1); else if (H <= 512) LAUNCH(2); else LAUNCH(4);
 #undef LAUNCH
     FB_CHECK_LAUNCH();

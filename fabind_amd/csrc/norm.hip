@@ -168,3 +168,104 @@ extern "C" int fabind_edge_ln_concat(const float* h, int ldh, int H, const int* 
     FB_CHECK_LAUNCH();
     return 0;
 }
+
+// adjoint of layernorm_rows: one wave per row, row values in registers; dw / db partials per work-group through LDS
+template <int NPL>
+__global__ __launch_bounds__(256) void layernorm_rows_bwd_kernel(const void* __restrict__ x, int x_dt, int ldx,
+                                                                 const float* __restrict__ w, const void* __restrict__ dy,
+                                                                 int dy_dt, int lddy, float eps, int R, int C, void* dx,
+                                                                 int dx_dt, int lddx, float* dwp, float* dbp) {
+    extern __shared__ float sh[];                   // [2][C]
+    const int lane = threadIdx.x & 63;
+    for (int c = threadIdx.x; c < 2 * C; c += 256) sh[c] = 0.f;
+    __syncthreads();
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r < R) {
+        const size_t xo = (size_t)r * ldx, go = (size_t)r * lddy, o = (size_t)r * lddx;
+        float v[NPL], g[NPL];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int c = k * 64 + lane;
+            v[k] = c < C ? ld_any(x, x_dt, xo + c) : 0.f;
+            g[k] = c < C ? ld_any(dy, dy_dt, go + c) : 0.f;
+            s += v[k];
+        }
+        const float mu = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int c = k * 64 + lane;
+            const float t = c < C ? v[k] - mu : 0.f;
+            q += t * t;
+        }
+        const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int c = k * 64 + lane;
+            if (c < C) {
+                const float xh = (v[k] - mu) * rs, gw = g[k] * w[c];
+                s1 += gw; s2 += gw * xh;
+            }
+        }
+        s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int c = k * 64 + lane;
+            if (c < C) {
+                const float xh = (v[k] - mu) * rs, gw = g[k] * w[c];
+                st_any(dx, dx_dt, o + c, rs * (gw - s1 - xh * s2));
+                atomicAdd(&sh[c], g[k] * xh);
+                atomicAdd(&sh[C + c], g[k]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        dwp[(size_t)blockIdx.x * C + c] = sh[c];
+        dbp[(size_t)blockIdx.x * C + c] = sh[C + c];
+    }
+}
+extern "C" int fabind_layernorm_rows_bwd(const void* x, int x_dt, int ldx, const float* w, const void* dy, int dy_dt, int lddy,
+                                         float eps, int R, int C, void* dx, int dx_dt, int lddx, float* dw_part, float* db_part,
+                                         hipStream_t stream) {
+    if (R <= 0) return 0;
+    FB_REQUIRE(C <= 2048, "fabind_layernorm_rows_bwd: C <= 2048");
+    const size_t lds = (size_t)2 * C * sizeof(float);
+#define LNB_LAUNCH(NPL_) hipLaunchKernelGGL((layernorm_rows_bwd_kernel<NPL_>), dim3((R + 3) / 4), dim3(256), lds, stream, x, x_dt, \
+                                            ldx, w, dy, dy_dt, lddy, eps, R, C, dx, dx_dt, lddx, dw_part, db_part)
+    if (C <= 128) LNB_LAUNCH(2);
+    else if (C <= 512) LNB_LAUNCH(8);
+    else if (C <= 1024) LNB_LAUNCH(16);
+    else LNB_LAUNCH(32);
+#undef LNB_LAUNCH
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void edge_concat_kernel(const float* __restrict__ h, int ldh, int H, const int* __restrict__ row,
+                                                          const int* __restrict__ col, const float* __restrict__ rhohat, int E,
+                                                          void* y, int y_dt, int ldy, int pad_to) {
+    const int lane = threadIdx.x & 63;
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= E) return;
+    const float* hr = h + (size_t)row[e] * ldh;
+    const float* hc = h + (size_t)col[e] * ldh;
+    const size_t yo = (size_t)e * ldy;
+    for (int c = lane; c < H; c += 64) {
+        st_any(y, y_dt, yo + c, hr[c]);
+        st_any(y, y_dt, yo + H + c, hc[c]);
+    }
+    if (lane == 0) st_any(y, y_dt, yo + 2 * H, rhohat[e]);
+    for (int c = 2 * H + 1 + lane; c < pad_to; c += 64) st_any(y, y_dt, yo + c, 0.f);
+}
+extern "C" int fabind_edge_concat(const float* h, int ldh, int H, const int* row, const int* col, const float* rhohat, int E,
+                                  void* y, int y_dt, int ldy, int pad_to, hipStream_t stream) {
+    if (E <= 0) return 0;
+    FB_REQUIRE(pad_to <= ldy && 2 * H + 1 <= pad_to, "fabind_edge_concat: 2H+1 <= pad_to <= ldy");
+    hipLaunchKernelGGL(edge_concat_kernel, dim3((E + 3) / 4), dim3(256), 0, stream, h, ldh, H, row, col, rhohat, E, y, y_dt, ldy,
+                       pad_to);
+    FB_CHECK_LAUNCH();
+    return 0;
+}

@@ -120,13 +120,16 @@ class _Linear(torch.autograd.Function):
         D = None
         M, N = x.shape[0], W.shape[0]
         y = torch.empty((M, N), dtype=out_dtype, device=x.device)
-        if act_epi == K.ACT_SILU:
+        # ReLU followed by a residual (FABind+ MLPwithLastAct): y = relu(pre) + R no longer tells where pre > 0, so
+        # the derivative is stored like for SiLU
+        relu_res = act_epi == K.ACT_RELU and residual is not None
+        if act_epi == K.ACT_SILU or relu_res:
             D = torch.empty((M, N), dtype=out_dtype, device=x.device)
         K.gemm(xin, W, bias=b, A2=x2in, act_epi=act_epi, residual=residual, out=y, out2=D)
-        ctx.act_epi, ctx.x_dtype = act_epi, x.dtype
+        ctx.act_epi, ctx.x_dtype = (K.ACT_SILU if relu_res else act_epi), x.dtype       # backward: stored derivative
         ctx.x2_dtype = x2.dtype if x2 is not None else None
         ctx.has_b, ctx.has_res, ctx.has_x2 = b is not None, residual is not None, x2 is not None
-        ctx.save_for_backward(xin, W, x2in, y if act_epi == K.ACT_RELU else None, D)
+        ctx.save_for_backward(xin, W, x2in, y if (act_epi == K.ACT_RELU and not relu_res) else None, D)
         return y
 
     @staticmethod
@@ -465,8 +468,12 @@ class _PutRows(torch.autograd.Function):
     those rows zeroed."""
 
     @staticmethod
-    def forward(ctx, base, rows, idx):
+    def forward(ctx, base, rows, idx, inplace):
         ctx.save_for_backward(idx)
+        if not inplace:                      # `base` is saved by its producer (e.g. a ReLU epilogue): leave it untouched
+            out = base.clone()
+            out.index_copy_(0, idx, rows.to(base.dtype))
+            return out
         base.index_copy_(0, idx, rows.to(base.dtype))
         ctx.mark_dirty(base)
         return base
@@ -477,13 +484,13 @@ class _PutRows(torch.autograd.Function):
         d_rows = dout.index_select(0, idx)
         d_base = dout.clone()
         d_base.index_fill_(0, idx, 0.0)
-        return d_base, d_rows, None
+        return d_base, d_rows, None, None
 
 
-def put_rows(base, rows, index64):
+def put_rows(base, rows, index64, inplace=True):
     """Row scatter of a small compact array into a node-layout array (index glue: pure data movement)."""
     if _needs_grad(base, rows):
-        return _PutRows.apply(base, rows, index64)
+        return _PutRows.apply(base, rows, index64, inplace)
     base.index_copy_(0, index64, rows.to(base.dtype))
     return base
 
@@ -512,7 +519,7 @@ class _CrossAttn(torch.autograd.Function):
         qg, kv, bias, out, lse = ctx.saved_tensors
         lin_col, gate_col, desc, B, max_nq, max_nk, scale = ctx.args
         dout = dout.contiguous()
-        dqg, dkv, dbias = torch.zeros_like(qg), torch.zeros_like(kv), torch.empty_like(bias)   # uncovered rows: zero gradient
+        dqg, dkv, dbias = torch.zeros_like(qg), torch.zeros_like(kv), torch.zeros_like(bias)   # uncovered rows / columns: 0
         dO = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
         Dv = torch.empty((qg.shape[0], 4), dtype=torch.float32, device=qg.device)
         check(load().fabind_cross_attn_bwd(ptr(qg), qg.stride(0), ptr(kv), kv.stride(0), ptr(bias), bias.stride(0), lin_col,
@@ -591,10 +598,11 @@ def rows_hadamard(t, idx_a, idx_b):
 
 class _InterAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv):
+    def forward(ctx, qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext=None):
         h_out, x_out, alpha, cvs = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx,
-                                                    bias_part, w_rk, w_rv, wcr, w3, clampv)
+                                                    bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext)
         ctx.g, ctx.H, ctx.clampv, ctx.np = g, H, clampv, bias_part.shape[1]
+        ctx.has_ext = s_ext is not None
         ctx.save_for_backward(qkv, cv, d, rhohat, w_rk, w_rv, wcr, w3, alpha, cvs)
         ctx.mark_non_differentiable(alpha)
         return h_out, x_out, alpha
@@ -623,14 +631,16 @@ class _InterAttn(torch.autograd.Function):
                                            ptr(dcp), ptr(wpart), nblk, stream()), "fabind_inter_attn_bwd")
         dw = [K.colsum(wpart[i]) for i in range(4)]
         return (dqkv, dcv, dh_out, dx_out, dd[:E], drh[:E], dbias_red[:n_red, None].expand(n_red, ctx.np), dw[0], dw[1],
-                dw[2], dw[3], None, None, None)
+                dw[2], dw[3], None, None, None, dcp[:E] if ctx.has_ext else None)
 
 
-def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, clampv):
-    if _needs_grad(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3):
-        return _InterAttn.apply(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv)
+def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None):
+    """s_ext [E] (optional): per-edge scalar added to the coordinate-MLP value inside the kernel (FABind+ evaluates its
+    LN-MLP coord_mlp outside); differentiable."""
+    if _needs_grad(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, s_ext):
+        return _InterAttn.apply(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext)
     h_out, x_out, alpha, _ = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx, bias_part,
-                                              w_rk, w_rv, wcr, w3, clampv)
+                                              w_rk, w_rv, wcr, w3, clampv, s_ext)
     return h_out, x_out, alpha
 
 

@@ -170,6 +170,104 @@ def _pair_hadamard_call(T, Hh, p_node, c_node, out_dtype):
 
 
 # ------------------------------------------------------------------------------------------------
+# differentiable pieces specific to the FABind+ data path (the rest comes from fabind_amd.ops)
+# ------------------------------------------------------------------------------------------------
+class _LnRows(torch.autograd.Function):
+    """Row LayerNorm (any dtype / leading dimension, zero padding to pad_to) with a HIP adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, out_dtype, pad_to):
+        ctx.save_for_backward(x, w)
+        return K.layernorm_rows(x, w, b, out_dtype, pad_to)
+
+    @staticmethod
+    def backward(ctx, dy):
+        from .._lib import check, dt_code, load, ptr, stream
+        x, w = ctx.saved_tensors
+        R, C = x.shape
+        dy = dy if dy.stride(-1) == 1 else dy.contiguous()
+        dx = torch.empty((R, C), dtype=x.dtype, device=x.device)
+        nblk = (R + 3) // 4
+        dwp = torch.empty((nblk, C), dtype=torch.float32, device=x.device)
+        dbp = torch.empty((nblk, C), dtype=torch.float32, device=x.device)
+        check(load().fabind_layernorm_rows_bwd(ptr(x), dt_code(x.dtype), x.stride(0), ptr(w), ptr(dy), dt_code(dy.dtype),
+                                               dy.stride(0), 1e-5, R, C, ptr(dx), dt_code(dx.dtype), C, ptr(dwp), ptr(dbp),
+                                               stream()), "fabind_layernorm_rows_bwd")
+        return dx, K.colsum(dwp), K.colsum(dbp), None, None
+
+
+def ln_rows(x, w, b, out_dtype, pad_to=None):
+    pad_to = pad_to or x.shape[1]
+    if ops.needs_grad(x, w, b):
+        return _LnRows.apply(x, w, b, out_dtype, pad_to)
+    return K.layernorm_rows(x, w, b, out_dtype, pad_to)
+
+
+class _EdgeConcat(torch.autograd.Function):
+    """[h[row] | h[col] | rhohat | 0...] per edge; adjoint = two CSR segment sums (by receiving node, by sending node
+    through the by-sender permutation) + a column read."""
+
+    @staticmethod
+    def forward(ctx, h, rhohat, row, col, rowptr, bycol, out_dtype, pad_to):
+        from .._lib import check, dt_code, load, ptr, stream
+        E, H = row.shape[0], h.shape[1]
+        y = torch.empty((E, pad_to), dtype=out_dtype, device=h.device)
+        check(load().fabind_edge_concat(ptr(h), h.stride(0), H, ptr(row), ptr(col), ptr(rhohat), E, ptr(y), dt_code(out_dtype),
+                                        pad_to, pad_to, stream()), "fabind_edge_concat")
+        ctx.n, ctx.H, ctx.bycol = h.shape[0], H, bycol
+        ctx.save_for_backward(rowptr)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rowptr, = ctx.saved_tensors
+        H, n = ctx.H, ctx.n
+        dy = dy.contiguous()
+        colptr, perm = ctx.bycol()
+        dh = K.segment_sum(dy[:, :H], rowptr, n)
+        dh = dh + K.segment_sum(dy[:, H:2 * H], colptr, n, eidx=perm)
+        return dh, dy[:, 2 * H].float(), None, None, None, None, None, None
+
+
+class _PairHad1(torch.autograd.Function):
+    """hd[e] = T[p_node[e], :Hh] * T[c_node[e], Hh:2Hh] with the atomic adjoint kernel of the v1 path."""
+
+    @staticmethod
+    def forward(ctx, T, Hh, p_node, c_node, out_dtype):
+        ctx.Hh = Hh
+        ctx.save_for_backward(T, p_node, c_node)
+        return _pair_hadamard_call(T, Hh, p_node, c_node, out_dtype)
+
+    @staticmethod
+    def backward(ctx, dhd):
+        from .._lib import check, dt_code, load, ptr, stream
+        T, p_node, c_node = ctx.saved_tensors
+        Hh = ctx.Hh
+        dhd = dhd.contiguous()
+        dT = torch.zeros_like(T)
+        a0, b0 = T[:, :Hh], T[:, Hh:2 * Hh]
+        da, db = dT[:, :Hh], dT[:, Hh:2 * Hh]
+        check(load().fabind_pair_hadamard_bwd(ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(a0), ptr(b0), T.stride(0), Hh,
+                                              ptr(a0), ptr(b0), T.stride(0), 0, ptr(p_node), ptr(c_node), p_node.shape[0], ptr(da),
+                                              ptr(db), dT.stride(0), ptr(da), ptr(db), dT.stride(0), stream()),
+              "fabind_pair_hadamard_bwd")
+        return dT, None, None, None, None
+
+
+def pair_had(T, Hh, p_node, c_node, out_dtype):
+    if ops.needs_grad(T):
+        return _PairHad1.apply(T, Hh, p_node, c_node, out_dtype)
+    return _pair_hadamard_call(T, Hh, p_node, c_node, out_dtype)
+
+
+class _InterView:
+    """The inter graph under the attribute names ops.gcl_pre reads (row_ctx / col_ctx / rp_ctx / ctx_by_col)."""
+
+    def __init__(self, g):
+        self.row_ctx, self.col_ctx, self.rp_ctx, self.ctx_by_col = g.row_int, g.col_int, g.rp_int, g.int_by_col
+
+
+# ------------------------------------------------------------------------------------------------
 # layers
 # ------------------------------------------------------------------------------------------------
 def _drop(t, pr):
@@ -179,29 +277,59 @@ def _drop(t, pr):
 
 
 def ln_mlp(m, x, last_act, residual=None, out_dtype=torch.float32, pdrop=0.0):
-    """LN -> linear1 -> relu -> [dropout] -> linear2 (-> relu -> [dropout]) (+ residual).  model_utils.py:10-74; the
-    dropouts run inside the GEMM epilogues (before the residual)."""
+    """LN -> linear1 -> relu -> [dropout] -> linear2 (-> relu -> [dropout]) (+ residual).  model_utils.py:10-74.
+    No-grad: the dropouts run inside the GEMM epilogues (before the residual); under autograd they are torch masks."""
     ad = ops.act_dtype()
-    y = K.layernorm_rows(x, m["ln_w"], m["ln_b"], ad, m["k_pad"]) if m["ln_w"] is not None else x
+    y = ln_rows(x, m["ln_w"], m["ln_b"], ad, m["k_pad"]) if m["ln_w"] is not None else x
+    act2 = K.ACT_RELU if last_act else K.ACT_NONE
+    if pdrop > 0.0 and ops.needs_grad(y, m["W1"], m["W2"], residual):
+        t = _drop(ops.linear(y, m["W1"], m["b1"], act_epi=K.ACT_RELU, out_dtype=ad), pdrop)
+        if last_act:
+            y2 = _drop(ops.linear(t, m["W2"], m["b2"], act_epi=act2), pdrop)
+            return (y2 if residual is None else residual + y2).to(out_dtype)
+        return ops.linear(t, m["W2"], m["b2"], act_epi=act2, residual=residual, out_dtype=out_dtype)
     t = ops.linear(y, m["W1"], m["b1"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pdrop)
-    return ops.linear(t, m["W2"], m["b2"], act_epi=K.ACT_RELU if last_act else K.ACT_NONE, residual=residual,
-                      out_dtype=out_dtype, p_drop=pdrop if last_act else 0.0)
+    return ops.linear(t, m["W2"], m["b2"], act_epi=act2, residual=residual, out_dtype=out_dtype,
+                      p_drop=pdrop if last_act else 0.0)
+
+
+def lin_drop(x, W, b, residual, pd):
+    """residual + dropout(x W^T + b): epilogue dropout without autograd, torch mask under autograd."""
+    if pd > 0.0 and ops.needs_grad(x, W, b, residual):
+        return residual + _drop(ops.linear(x, W, b), pd)
+    return ops.linear(x, W, b, residual=residual, p_drop=pd)
+
+
+def _coord_scalar(c, v, pd):
+    """MLPwoBias coord_mlp on per-edge rows v [E,H] -> per-edge scalar partials [E, nt]: LN -> linear1 -> relu ->
+    [dropout] -> bias-free linear2 as the row-dot of the GEMM epilogue."""
+    ad = ops.act_dtype()
+    yc = ln_rows(v, c["ln_w"], c["ln_b"], ad, c["k_pad"])
+    if pd > 0.0 and ops.needs_grad(yc, c["W1"], c["w3"]):
+        tc = _drop(ops.linear(yc, c["W1"], c["b1"], act_epi=K.ACT_RELU), pd)
+        return (tc * c["w3"]).sum(1, keepdim=True)
+    return ops.linear_rowdot(yc, c["W1"], c["b1"], c["w3"], act_epi=K.ACT_RELU, p_drop=pd)
 
 
 def gcl_layer(p, h, x, lay, g, clampv, pd=0.0):
     """MC_E_GCL.forward of FABind+ (egnn.py:104-118).  pd: dropout inside the three LN-MLPs (train / sampling mode)."""
     ad = ops.act_dtype()
     e = p["edge"]
-    d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay)
-    y = K.edge_ln_concat(h, g.row_ctx, g.col_ctx, rhohat, e["ln_w"], e["ln_b"], ad, e["k_pad"])     # [E, K8]
-    t = ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)               # [E, K8]
-    m = ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)               # [E, H] messages
-    c = p["coord"]
-    yc = K.layernorm_rows(m, c["ln_w"], c["ln_b"], ad, c["k_pad"])
-    # coord_mlp: dropout sits between relu(linear1) and the bias-free linear2 = the row-dot of the epilogue
-    s = ops.linear_rowdot(yc, c["W1"], c["b1"], c["w3"], act_epi=K.ACT_RELU, p_drop=pd)             # [E, nt]
+    H = h.shape[1]
+    d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay, g.ctx_by_col)
+    grad = ops.needs_grad(h, x, e["W1"])
+    if grad:       # the concatenation is materialised so that LayerNorm is a separate differentiable step
+        cat = _EdgeConcat.apply(h, rhohat, g.row_ctx, g.col_ctx, g.rp_ctx, g.ctx_by_col, ad, e["k_pad"])
+        y = ln_rows(cat[:, :2 * H + 1], e["ln_w"], e["ln_b"], ad, e["k_pad"])
+        t = _drop(ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad), pd)
+        m = _drop(ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad), pd)
+    else:
+        y = K.edge_ln_concat(h, g.row_ctx, g.col_ctx, rhohat, e["ln_w"], e["ln_b"], ad, e["k_pad"])  # [E, K8]
+        t = ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)            # [E, K8]
+        m = ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)            # [E, H] messages
+    s = _coord_scalar(p["coord"], m, pd)                                                            # [E, nt]
     x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
-    agg = K.segment_sum(m, g.rp_ctx, h.shape[0])
+    agg = ops.segment_sum(m, g.rp_ctx, g.row_ctx, h.shape[0])
     h_new = ln_mlp(p["node"], torch.cat([h, agg], 1), True, residual=h, pdrop=pd)
     return h_new, x_new
 
@@ -218,49 +346,49 @@ def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0):
     qg = ops.linear(h, p["Wqg_p"], p["bqg_p"])
     kv = ops.linear(hc, p["Wkv_p"])
     og = ops.cross_attn(qg, kv, bias, 0, 4, lay.desc_pf, lay.B, lay.max_P, lay.max_C, scale)
-    hp = ops.linear(og, p["Wo_p"], p["bo_p"], residual=h, p_drop=pd)
+    hp = lin_drop(og, p["Wo_p"], p["bo_p"], h, pd)
     qg = ops.linear(hc, p["Wqg_c"], p["bqg_c"])
     kv = ops.linear(hp, p["Wkv_c"])
     og = ops.cross_attn(qg, kv, bias, 8, 12, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
-    hc = ops.linear(og, p["Wo_c"], p["bo_c"], residual=hc, p_drop=pd)
+    hc = lin_drop(og, p["Wo_c"], p["bo_c"], hc, pd)
     hp = ln_mlp(p["tr_p"], hp, True, residual=hp, pdrop=pd)
     hc = ln_mlp(p["tr_c"], hc, True, residual=hc, pdrop=pd)
-    h = ops.put_rows(hp, hc, lay.c_index64)
+    h = ops.put_rows(hp, hc, lay.c_index64, inplace=False)     # hp is saved by its ReLU epilogue under autograd
     # ---- pair update: z <- relu-MLP(LN(z + W_o32 (a32 * b32) + b_o32))   (no residual around pair_transition)
     ab32 = ops.linear(h, p["W_ab32"], p["b_ab32"])                                                   # [N, 128]
-    hd32 = _pair_hadamard_call(ab32, 64, pairs.p_node, pairs.c_node, ad)                             # [pairs, 64]
+    hd32 = pair_had(ab32, 64, pairs.p_node, pairs.c_node, ad)                                        # [pairs, 64]
     z1 = ops.linear(hd32, p["W_o32"], p["b_o32"], residual=z.float() if z.dtype != torch.float32 else z, out_dtype=ad)
     z = ln_mlp(p["tr_z"], z1, True, out_dtype=ad, pdrop=pd)
-    # ---- inter-edge attention (att_model / node_model identical to v1; coord_mlp is an LN-MLP on v_e)
+    # ---- inter-edge attention (att_model / node_model identical to v1; coord_mlp is an LN-MLP on v_e, handed to the
+    #      fused kernel as a per-edge scalar)
     zr = ops.take_rows(z, pairs.index_of(g.red_p, g.red_c, batch_id))                                # [n_red, H]
     bias_part = ops.linear(zr, p["W_bias"], p["b_bias"])                                             # [n_red, 8]: col 0
     qkv = ops.linear(h, p["Wqkv"], p["bqkv"])                                                        # [N, 3H]
-    d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay)
+    d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay, g.int_by_col)
     zero_cv = torch.zeros((h.shape[0], H), dtype=torch.float32, device=h.device)
-    h_new, _, alpha = ops.inter_attn(qkv, zero_cv, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["zeroH"],
-                                     p["zeroH"], clampv)
+    AB = torch.cat([zero_cv, qkv[:, 2 * H:].float()], 1)                                             # v_e = V[col] + rho w_rv
+    v_e = ops.gcl_pre(AB, H, _InterView(g), rhohat, p["w_rv"])
+    s_ext = _coord_scalar(p["coord"], v_e, pd).sum(1)                                                # [E_int]
+    h_new, x_new, alpha = ops.inter_attn(qkv, zero_cv, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["zeroH"],
+                                         p["zeroH"], clampv, s_ext=s_ext.contiguous())
     if pd > 0.0:
         h_new = h + _drop(h_new - h, pd)                                                             # egnn.py:207 dropout(agg)
-    AB = torch.cat([zero_cv, qkv[:, 2 * H:].float()], 1)                                             # v_e = V[col] + rho w_rv
-    v_e = K.gcl_pre(AB, H, g.row_int, g.col_int, rhohat, p["w_rv"], ad)
-    c = p["coord"]
-    yc = K.layernorm_rows(v_e, c["ln_w"], c["ln_b"], ad, c["k_pad"])
-    s = ops.linear_rowdot(yc, c["W1"], c["b1"], c["w3"], act_epi=K.ACT_RELU, p_drop=pd)
-    x_new, _ = K.coord_update(x, d, s, g.rp_int, False, clampv, weight=alpha)
     return h_new, x_new, alpha, z
 
 
 def egnn_forward(P, h, x, z0, lay, g, las, x_las, pairs, batch_id, scale, step, capture=None, pd=0.0):
     clampv = 10.0 / scale
-    h = ops.linear(h, P["W_in"], P["b_in"], p_drop=pd)
+    h = _drop(ops.linear(h, P["W_in"], P["b_in"]), pd) if (pd > 0.0 and ops.needs_grad(h, P["W_in"])) else \
+        ops.linear(h, P["W_in"], P["b_in"], p_drop=pd)
     z = z0
     for i in range(P["L"]):
         h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv, pd)
         if capture is not None:
-            capture["gcl_%d.h" % i], capture["gcl_%d.x" % i] = h.clone(), x.clone()
+            capture["gcl_%d.h" % i], capture["gcl_%d.x" % i] = h.detach().clone(), x.detach().clone()
         h, x, alpha, z = att_layer(P["att"][i], h, x, z, lay, g, pairs, batch_id, clampv, pd)
         if capture is not None:
-            capture["att_%d.h" % i], capture["att_%d.x" % i], capture["att_%d.alpha" % i] = h.clone(), x.clone(), alpha.clone()
+            capture["att_%d.h" % i], capture["att_%d.x" % i], capture["att_%d.alpha" % i] = \
+                h.detach().clone(), x.detach().clone(), alpha.detach().clone()
         x = ops.las_step(x, x_las, las, lay, step, 15.0 / scale)
     h, x = gcl_layer(P["out_layer"], h, x, lay, g, clampv, pd)
     return ops.linear(_drop(h, pd), P["W_out"], P["b_out"]), x, z
@@ -276,7 +404,6 @@ def mlp_module(m, x, last_act=False, out_dtype=torch.float32, pdrop=0.0):
     return ln_mlp(_mlp(m, lambda t: t.to(wd).contiguous()), x.contiguous(), last_act, out_dtype=out_dtype, pdrop=pdrop)
 
 
-@torch.no_grad()
 def stack_forward(model, X, Hin, batch_id, segment_id, mask, is_global, compound_edge_index, LAS_edge_index, coord_LAS,
                   n_iter, pair="dense"):
     """EfficientMCAttModel.forward of FABind+ (refine_coord): mutates X in place, returns (X, H, pair_embed).
@@ -301,18 +428,23 @@ def stack_forward(model, X, Hin, batch_id, segment_id, mask, is_global, compound
     Hin = Hin.float().contiguous()
     ad = ops.act_dtype()
     a0b0 = ops.linear(Hin, P["W_ab0"], P["b_ab0"])                                                   # [N, 2H]
-    hd0 = _pair_hadamard_call(a0b0, H, pairs.p_node, pairs.c_node, ad)
+    hd0 = pair_had(a0b0, H, pairs.p_node, pairs.c_node, ad)
     z0 = ops.linear(hd0, P["W_o0"], P["b_o0"], out_dtype=ad)                                         # [pairs, H]
     cut_intra, cut_inter = float(model.extract_edges.intra_cutoff), float(model.extract_edges.inter_cutoff)
     Hout = z = None
     pd = float(args.dropout) if model.training else 0.0     # train mode at inference = FABind+ dropout sampling
     for r in range(n_iter):
-        g = Graph(lay, x, bond_row, bond_col, bond_off, cut_intra, cut_inter)
-        Hout, xz, z = egnn_forward(P, Hin, x, z0, lay, g, las, x_las, pairs, batch_id, scale,
-                                   float(args.geometry_reg_step_size), DEBUG_CAPTURE if r == n_iter - 1 else None, pd)
-        x = ops.select_rows(x, xz, mask_u8)
+        last = r == n_iter - 1
+        g = Graph(lay, x.detach(), bond_row, bond_col, bond_off, cut_intra, cut_inter)
+        with torch.set_grad_enabled(last and torch.is_grad_enabled()):      # att_model.py:199-221: only the last pass has grad
+            Hout, xz, z = egnn_forward(P, Hin, x, z0, lay, g, las, x_las, pairs, batch_id, scale,
+                                       float(args.geometry_reg_step_size), DEBUG_CAPTURE if last else None, pd)
+            x = ops.select_rows(x, xz, mask_u8)
     model.last_graph = g
-    X.copy_(x.reshape(X.shape).to(X.dtype))
+    with torch.no_grad():
+        X.copy_(x.reshape(X.shape).to(X.dtype))
+    Xout = x.reshape(X.shape)
+    Xout = Xout if Xout.requires_grad else X
     if pair == "dense":
-        return X, Hout, pairs.dense(z, lay)
-    return X, Hout, ((z, pairs, lay) if pair == "ragged" else None)
+        return Xout, Hout, pairs.dense(z, lay)
+    return Xout, Hout, ((z, pairs, lay) if pair == "ragged" else None)

@@ -129,8 +129,13 @@ class FABindPlus(nn.Module):
         return dict(B=B, c_out=c_out, p_out=p_out, logits=logits, mask=mask, xyz=xyz, pb=pb, loc=loc, cnt=cnt, radius=radius)
 
     # ---- radius crop around the predicted centre, pocket-centred frame (model.py:212-330) --------------------------
-    @torch.no_grad()
     def _stage2(self, data, head, center, shift_coords):
+        g = self._stage2_nograd(data, head, center, shift_coords)
+        g['H'], _, _ = self._assemble(g['segment'], g['is_global'], head['c_out'], head['p_out'][g.pop('keep')])
+        return g
+
+    @torch.no_grad()
+    def _stage2_nograd(self, data, head, center, shift_coords):
         a, dev = self.args, center.device
         pb, B, cb = head['pb'], head['B'], data['compound'].batch
         r = head['radius'][:, 0].detach()
@@ -178,18 +183,22 @@ class FABindPlus(nn.Module):
         las = (ll.x + off[ll.batch][:, None]).t().contiguous().long()
         pi, ci = self._pair_lists(pocket_batch, cb, kcnt, ncnt)
         dis_map = (pocket_xyz[pi] - (li - bias[cb])[ci]).norm(dim=-1).clamp(max=a.dis_map_thres)
-        pemb = head['p_out'][keep]
-        H, _, _ = self._assemble(segment, is_global, head['c_out'], pemb)
         cx = data['complex']
         cx.node_coords, cx.node_coords_LAS, cx.segment, cx.mask, cx.is_global = X, XL, segment, mask, is_global
         data['complex', 'c2c', 'complex'].edge_index = c2c
         data['complex', 'LAS', 'complex'].edge_index = las
-        return dict(H=H, X=X, XL=XL, segment=segment, mask=mask, is_global=is_global, batch=batch, c2c=c2c, LAS=las,
+        return dict(keep=keep, X=X, XL=XL, segment=segment, mask=mask, is_global=is_global, batch=batch, c2c=c2c, LAS=las,
                     pocket_xyz=pocket_xyz, pocket_batch=pocket_batch, dis_map=dis_map, less5=less5, pairs=(pi, ci), bias=bias)
 
-    @torch.no_grad()
     def _stage1(self, data, head):
         """Teacher-forced pocket, moved into the pocket frame IN PLACE like the reference (model.py:170-201)."""
+        with torch.no_grad():
+            g = self._stage1_nograd(data, head)
+        cx = data['complex']
+        g['H'], _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], head['p_out'][data['pocket'].keepNode])
+        return g
+
+    def _stage1_nograd(self, data, head):
         cx, cb = data['complex'], data['compound'].batch
         B, dev = head['B'], cb.device
         seg1 = cx.segment.bool() if not cx.segment.is_floating_point() else cx.segment > 0.5
@@ -202,9 +211,7 @@ class FABindPlus(nn.Module):
         X[poc] = X[poc] - data.pocket_residue_center[cx.batch[poc]].to(X.dtype)
         cx.node_coords = X
         data.coords = data.coords - data.pocket_residue_center[cb].to(data.coords.dtype)
-        pemb = head['p_out'][data['pocket'].keepNode]
-        H, _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], pemb)
-        return dict(H=H, X=X, XL=cx.node_coords_LAS, segment=cx.segment, mask=cx.mask, is_global=cx.is_global, batch=cx.batch,
+        return dict(X=X, XL=cx.node_coords_LAS, segment=cx.segment, mask=cx.mask, is_global=cx.is_global, batch=cx.batch,
                     c2c=data['complex', 'c2c', 'complex'].edge_index, LAS=data['complex', 'LAS', 'complex'].edge_index,
                     pocket_xyz=data.node_xyz, pocket_batch=data['pocket'].batch, dis_map=data.dis_map, less5=0,
                     bias=torch.zeros(B, 3, device=dev))
@@ -226,9 +233,14 @@ class FABindPlus(nn.Module):
         zz = z[sel].contiguous()
         m = self.distmap_mlp
         wd = ops.mm_dtype()
-        y = K.layernorm_rows(zz, m.layernorm.weight.float(), m.layernorm.bias.float(), ops.act_dtype())
-        part = ops.linear_rowdot(y, m.linear1.weight.to(wd).contiguous(), m.linear1.bias, m.linear2.weight[0].float().contiguous(),
-                                 act_epi=K.ACT_RELU)
+        y = pengine.ln_rows(zz, m.layernorm.weight.float(), m.layernorm.bias.float(), ops.act_dtype())
+        pd = self._pd()
+        if pd > 0.0 and ops.needs_grad(y):
+            t = pengine._drop(ops.linear(y, m.linear1.weight.to(wd).contiguous(), m.linear1.bias, act_epi=K.ACT_RELU), pd)
+            part = (t * m.linear2.weight[0].float()).sum(1, keepdim=True)
+        else:
+            part = ops.linear_rowdot(y, m.linear1.weight.to(wd).contiguous(), m.linear1.bias,
+                                     m.linear2.weight[0].float().contiguous(), act_epi=K.ACT_RELU, p_drop=pd)
         thres = self.args.dis_map_thres
         y_pred = (part.sum(1) + m.linear2.bias).sigmoid() * thres
         cb = data['compound'].batch
@@ -240,17 +252,25 @@ class FABindPlus(nn.Module):
         return y_pred, y_by
 
     # ---- reference API ---------------------------------------------------------------------------------------------
-    @torch.no_grad()
     def forward(self, data, stage=2, train=False):
-        if self.training or train or self.confidence_training:
-            raise NotImplementedError("FABind+ training (autograd through the stack, Gumbel noise, permutation loss, "
-                                      "confidence training) is not built yet: eval forward / inference / sampling only")
+        """model.py:63-401.  train=True (or stage 1): teacher forcing with the native pocket; module.train(): Gumbel noise
+        on the centre, dropout, random n_iter.  Differentiable (autograd through the HIP stack)."""
+        if self.confidence_training:
+            raise NotImplementedError("confidence training (7-tuple forward on a frozen backbone) is not built")
+        if self.args.use_clustering:
+            raise NotImplementedError("use_clustering is a sampling-mode option: call inference()")
         cb = data['compound'].batch
         head = self._pocket_head(data)
-        center = self._soft_center(head['logits'], head['mask'], head['xyz'], noise=False)
+        center = self._soft_center(head['logits'], head['mask'], head['xyz'], noise=self.pocket_pred_model.training)
         pocket_cls = torch.zeros_like(head['mask'], dtype=data.pocket_idx.dtype)
         pocket_cls[head['pb'], head['loc']] = data.pocket_idx
-        g = self._stage1(data, head) if stage == 1 else self._stage2(data, head, center, shift_coords=True)
+        if train or stage == 1:
+            g = self._stage1(data, head)
+        else:
+            c2 = center
+            if self.args.train_pred_pocket_noise and train:
+                c2 = center + self.args.train_pred_pocket_noise * (2 * torch.rand_like(center) - 1)
+            g = self._stage2(data, head, c2, shift_coords=True)
         Ho, Z, cflag, pflag, coords_n = self._complex(g, "ragged")
         y_pred, y_by = self._dist_heads(data, g, Z, coords_n)
         return (self.unnormalize_coord(coords_n), cb, y_pred, y_by, head['logits'] * head['mask'], pocket_cls, head['mask'],

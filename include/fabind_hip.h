@@ -214,7 +214,10 @@ int fabind_inter_attn_fwd(const float* qkv, int ldqkv, const float* cv, int ldcv
                           const float* x, const float* d, const float* rhohat, const int* rowptr, const int* col,
                           const int* red_idx, const float* bias_red, int bias_np, const float* w_rk,
                           const float* w_rv, const float* wcr, const float* w3, float clampv, int n_rows,
-                          float* h_out, float* x_out, float* alpha, float* cvs, hipStream_t stream);
+                          float* h_out, float* x_out, float* alpha, float* cvs,
+                          const float* s_ext /* optional per-edge scalar added to the coord_mlp value (FABind+: its coord_mlp is an
+                                                LN-MLP evaluated outside); its gradient is the backward's dcp[] */,
+                          hipStream_t stream);
 
 /* LAS geometry step (models/egnn.py:433-449): x_out = x + clamp(step * sum_{(i,j): j=node} 4(|xi-xj|^2-|x0i-x0j|^2)(xi-xj)).
  * las_off[B+1]: per-complex ranges of the (complex-contiguous) LAS edge list. */
@@ -236,6 +239,13 @@ int fabind_layernorm_rows(const void* x, int x_dt, int ldx, const float* w, cons
                           int y_dt, int ldy, int pad_to, hipStream_t stream);
 int fabind_edge_ln_concat(const float* h, int ldh, int H, const int* row, const int* col, const float* rhohat, const float* w,
                           const float* b, float eps, int E, void* y, int y_dt, int ldy, int pad_to, hipStream_t stream);
+/* adjoint of fabind_layernorm_rows: dx (dtype dx_dt, leading dim lddx) and per-block partials of dw, db ([nblk][C] each,
+ * nblk = ceil(R/4); the caller adds the rows).  fabind_edge_concat: y[e] = [h[row[e]] | h[col[e]] | rhohat[e] | 0...]
+ * (the un-normalised edge input of MC_E_GCL, used under autograd where LayerNorm is a separate differentiable step). */
+int fabind_layernorm_rows_bwd(const void* x, int x_dt, int ldx, const float* w, const void* dy, int dy_dt, int lddy, float eps,
+                              int R, int C, void* dx, int dx_dt, int lddx, float* dw_part, float* db_part, hipStream_t stream);
+int fabind_edge_concat(const float* h, int ldh, int H, const int* row, const int* col, const float* rhohat, int E, void* y,
+                       int y_dt, int ldy, int pad_to, hipStream_t stream);
 int fabind_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int R, int C, float* y, float* mean,
                          float* rstd, hipStream_t stream);
 int fabind_layernorm_bwd(const float* x, const float* w, const float* dy, const float* mean, const float* rstd, int R,

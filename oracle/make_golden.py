@@ -401,6 +401,44 @@ def golden_plus_loss(mods, name, seed):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def golden_stack_plus_grad(mods, name, sizes, hidden, layers, seed):
+    """Gradients of a scalar of the FABind+ stack outputs (X, H, pair_embed) w.r.t. every parameter and the input H."""
+    torch.manual_seed(seed)
+    args = refshim.production_args_plus(hidden_size=hidden, mean_layers=layers, n_iter=1)
+    model = mods["models.att_model"].EfficientMCAttModel(
+        args, hidden, hidden, 1, n_edge_feats=0, n_layers=layers, n_iter=1, inter_cutoff=10.0, intra_cutoff=8.0,
+        normalize_coord=lambda x: x / 5.0, unnormalize_coord=lambda x: x * 5.0).eval()
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith("coord_mlp.linear2.weight"):
+                p.mul_(COORD_GAIN)
+    batch = synthetic.make_stack_batch(sizes, hidden, seed=seed)
+    Hin = batch["H"].clone().requires_grad_(True)
+    g = torch.Generator().manual_seed(seed + 77)
+    N = Hin.shape[0]
+    cx, ch = torch.randn(N, 1, 3, generator=g), torch.randn(N, hidden, generator=g)
+    X, H, Z = model(batch["X"].clone(), Hin, batch["batch_id"], batch["segment_id"], batch["mask"], batch["is_global"],
+                    batch["compound_edge_index"], batch["LAS_edge_index"], batch["coord_LAS"].clone())
+    cz = torch.randn(Z.shape, generator=g)
+    loss = (X * cx).sum() + (H * ch).sum() + (Z * cz).sum()
+    loss.backward()
+    save = {("in_" + k): _np(v) for k, v in batch.items() if torch.is_tensor(v)}
+    save["sizes"], save["cfg"] = np.array(sizes), np.array([hidden, layers, 1, seed])
+    save.update({"w_" + k: _np(v) for k, v in model.state_dict().items()})
+    save["cot_X"], save["cot_H"], save["cot_Z"], save["loss"] = _np(cx), _np(ch), _np(cz), _np(loss)
+    save["out_X_f32"], save["out_H_f32"] = _np(X), _np(H)
+    save["grad_in_H"] = _np(Hin.grad)
+    nograd = []
+    for n, p in model.named_parameters():
+        if p.grad is None:
+            nograd.append(n)
+        else:
+            save["grad_" + n] = _np(p.grad)
+    save["nograd"] = np.array(nograd)
+    print("%s: loss %.5f, %d params without grad" % (name, float(loss), len(nograd)))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def main_plus():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
@@ -410,6 +448,7 @@ def main_plus():
     golden_model_plus(mods, "plus_model_tiny", [(70, 8), (85, 6)], 64, 32, 2, 2, seed=12)
     golden_model_plus_sampling(mods, "plus_model_sampling_tiny", [(120, 8), (140, 11)], 64, 32, 2, 1, seed=13)
     golden_plus_loss(mods, "plus_loss_tiny", seed=14)
+    golden_stack_plus_grad(mods, "plus_stack_tiny_grad", [(24, 7), (31, 5)], 32, 2, seed=15)
 
 
 def main():

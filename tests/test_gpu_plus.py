@@ -32,8 +32,9 @@ def _build(g, dev):
 
 def _run(m, inp, dev):
     t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
-    return m(t["X"].clone(), t["H"], t["batch_id"], t["segment_id"], t["mask"], t["is_global"], t["compound_edge_index"],
-             t["LAS_edge_index"], t["coord_LAS"])
+    with torch.no_grad():
+        return m(t["X"].clone(), t["H"], t["batch_id"], t["segment_id"], t["mask"], t["is_global"], t["compound_edge_index"],
+                 t["LAS_edge_index"], t["coord_LAS"])
 
 
 @pytest.mark.parametrize("name", PLUS)
@@ -116,7 +117,8 @@ def test_plus_model_forward_matches_reference(stage):
     g = load_npz("plus_model_tiny")
     m = _plus_model(g, dev)
     data = hetero_from_npz(g).to(dev)
-    out = m(data, stage=stage, train=False)
+    with torch.no_grad():
+        out = m(data, stage=stage, train=False)
     assert len(out) == 13
     p = "s%d_" % stage
     assert rmsd(out[0].cpu().numpy(), g[p + "coords"]) < 1e-4                         # north_star gate: 1e-4 A RMSD
@@ -209,3 +211,38 @@ def test_plus_dropout_sampling_produces_a_pose_distribution():
         assert spread > 1e-3 and drift < 5.0
     finally:
         engine.set_precision("fp32")
+
+
+def test_plus_stack_gradients_match_reference():
+    """Autograd through the FABind+ stack on the HIP path (fp32 mode) against gradients captured from the reference:
+    every parameter, the input H; cotangents on X, H and the returned pair embedding."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision("fp32")
+    g = load_npz("plus_stack_tiny_grad")
+    m = _build(g, dev)
+    inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in stack_inputs(g).items()}
+    Hin = inp["H"].clone().requires_grad_(True)
+    X, H, Z = m(inp["X"].clone(), Hin, inp["batch_id"], inp["segment_id"], inp["mask"], inp["is_global"],
+                inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"])
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    loss = (X * t("cot_X")).sum() + (H * t("cot_H")).sum() + (Z * t("cot_Z")).sum()
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    loss.backward()
+    ref = g["grad_in_H"]
+    assert np.abs(Hin.grad.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+    nograd = set(str(s) for s in g["nograd"])
+    bad = []
+    for k, prm in m.named_parameters():
+        if k in nograd:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k
+            continue
+        ref = g["grad_" + k]
+        if prm.grad is None:
+            if np.abs(ref).max() > 1e-6:
+                bad.append((k, "missing", float(np.abs(ref).max())))
+            continue
+        err = np.abs(prm.grad.cpu().numpy() - ref).max()
+        if err > 5e-3 * np.abs(ref).max() + 1e-6:
+            bad.append((k, float(err), float(np.abs(ref).max())))
+    assert not bad, bad[:10]

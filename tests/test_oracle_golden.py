@@ -257,3 +257,26 @@ def test_plus_permutation_invariant_loss_matches_reference():
     assert abs(float(total2) - float(L["loss"])) <= 1e-6 * abs(float(L["loss"]))
     for k, v in terms2.items():
         assert abs(float(v) - float(L["loss_" + k])) <= 1e-6 * max(abs(float(L["loss_" + k])), 1e-3), k
+
+
+def test_plus_stack_gradients_match_reference():
+    g = load_npz("plus_stack_tiny_grad")
+    sd, inp = weights(g), stack_inputs(g)
+    for v in sd.values():
+        v.requires_grad_(True)
+    Hin = inp["H"].clone().requires_grad_(True)
+    hidden, layers, n_iter, _ = [int(v) for v in g["cfg"]]
+    X, H, Z = porc.stack_forward(sd, "", inp["X"], Hin, inp["batch_id"], inp["segment_id"], inp["mask"], inp["is_global"],
+                                 inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"], layers, n_iter)
+    loss = (X * torch.from_numpy(g["cot_X"])).sum() + (H * torch.from_numpy(g["cot_H"])).sum() + \
+        (Z * torch.from_numpy(g["cot_Z"])).sum()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    loss.backward()
+    assert np.abs(Hin.grad.numpy() - g["grad_in_H"]).max() <= 1e-4 * np.abs(g["grad_in_H"]).max()
+    nograd = set(str(s) for s in g["nograd"])
+    for k, v in sd.items():
+        if k in nograd:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+        else:
+            ref = g["grad_" + k]
+            assert np.abs(v.grad.numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, k
