@@ -31,6 +31,13 @@ class EdgeBwdArgs(ctypes.Structure):
                [(n, _i) for n in ("ldab", "lddagg", "lddab", "E")] + [("p_drop", _f), ("seed", ctypes.c_uint)]
 
 
+class PairUpdateArgs(ctypes.Structure):
+    """Mirror of FabindPairUpdateArgs (include/fabind_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("T", "p_node", "c_node", "z_in", "z_out", "Wop", "bo", "ln_w", "ln_b", "W1p", "b1", "W2p", "b2",
+                                  "Wbp", "bb", "bias_out")] + \
+               [(n, _i) for n in ("ldt", "b_off", "n_pairs")] + [("eps", _f), ("p_drop", _f), ("seed", ctypes.c_uint)]
+
+
 # name -> argtypes (every function returns int and takes the stream last)
 SIGNATURES = {
     "fabind_gemm": [ctypes.POINTER(GemmArgs), _vp],
@@ -45,6 +52,7 @@ SIGNATURES = {
     "fabind_gcl_pre": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "fabind_gcl_edge_fused": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp],
     "fabind_gcl_edge_fused_bwd": [ctypes.POINTER(EdgeBwdArgs), _i, _i, _vp],
+    "fabind_pair_update_fused": [ctypes.POINTER(PairUpdateArgs), _i, _vp],
     "fabind_gcl_edge_fused_bwd_set_tile": [_i],
     "fabind_gcl_edge_fused_bwd_tile": [],
     "fabind_layernorm_rows": [_vp, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _i, _i, _vp],

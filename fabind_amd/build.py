@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libfabind_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "graph.hip", "gcl.hip", "fused_edge.hip", "attn.hip", "norm.hip", "bwd.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "graph.hip", "gcl.hip", "fused_edge.hip", "pair_fused.hip", "attn.hip", "norm.hip", "bwd.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-comment", "-I" + INCLUDE, "-I" + CSRC]
 
@@ -23,7 +23,7 @@ def _stale(out, deps):
 
 def build(force=False, verbose=True):
     objs = []
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "fabind_hip.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fused_common.h"), os.path.join(INCLUDE, "fabind_hip.h")]
     procs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)

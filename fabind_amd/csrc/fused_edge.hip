@@ -14,80 +14,7 @@
 // [E,H] round trips.  Two work-groups are resident per CU (66 KiB LDS, <= 128 VGPRs).
 #include "common.h"
 #include "fabind_hip.h"
-
-#define FE_BM 64
-
-__device__ __forceinline__ float fe_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
-__device__ __forceinline__ float fe_silu(float x) { return x * fe_sigmoid(x); }
-
-// Counter-based dropout mask of the messages (train mode, egnn.py:82): one 32-bit hash per (edge pair, column)
-// gives two 16-bit uniforms, element (e, c) is kept iff its half is >= thr16 = round(p * 65536).  Forward and
-// backward kernels (and tests/helpers.py) evaluate the same function, nothing is stored.
-__device__ __forceinline__ uint32_t fe_hash(uint32_t x) {
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
-}
-__device__ __forceinline__ float fe_keep(uint32_t seed, uint32_t e, uint32_t c, uint32_t H, uint32_t thr16, float scale) {
-    const uint32_t h = fe_hash(seed + (e >> 1) * H + c);
-    return (((e & 1u) ? (h >> 16) : (h & 0xffffu)) >= thr16) ? scale : 0.f;
-}
-
-__device__ __forceinline__ void unpack8(const uint4 u, float* f) {
-    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
-    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
-    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
-    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
-}
-__device__ __forceinline__ uint4 pack8(const float* f) {
-    uint4 u;
-    u.x = pack2_bf16(f[0], f[1]);
-    u.y = pack2_bf16(f[2], f[3]);
-    u.z = pack2_bf16(f[4], f[5]);
-    u.w = pack2_bf16(f[6], f[7]);
-    return u;
-}
-
-// acc[i][j] (+)= X[BM x H] (LDS, swizzled) * Wp (packed [H/32][H/16][64 lanes][8]) for this wave's 64 columns.
-// The k-loop is kept rolled (two k-steps per trip, B fragments ping-pong in registers): a fully unrolled loop lets
-// the scheduler hoist every B-fragment load of the contraction at once and spill.
-template <int H, int MI>
-__device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* __restrict__ Wp, int wave, int lane,
-                                               f32x4_t (&acc)[MI][4]) {
-    constexpr int NKS = H / 32, NG = H / 16;
-    const int fr = lane & 15, fq = lane >> 4;
-    const bf16x8_t* wp = (const bf16x8_t*)Wp + ((size_t)wave * 4) * 64 + lane;
-    bf16x8_t b0[4], b1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b0[j] = wp[(size_t)j * 64];
-#pragma unroll 1
-    for (int ks = 0; ks < NKS; ks += 2) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b1[j] = wp[((size_t)(ks + 1) * NG + j) * 64];
-        bf16x8_t a[MI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int r = i * 16 + fr;
-            a[i] = *(const bf16x8_t*)&sX[r * H + (((ks * 4 + fq) ^ (r & 7)) * 8)];
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0[j], acc[i][j], 0, 0, 0);
-        if (ks + 2 < NKS) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) b0[j] = wp[((size_t)(ks + 2) * NG + j) * 64];
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int r = i * 16 + fr;
-            a[i] = *(const bf16x8_t*)&sX[r * H + ((((ks + 1) * 4 + fq) ^ (r & 7)) * 8)];
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1[j], acc[i][j], 0, 0, 0);
-    }
-}
+#include "fused_common.h"
 
 template <int H>
 __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __restrict__ AB, int ldab, const int* __restrict__ row,
@@ -274,24 +201,6 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
 // trips of the unfused backward -- plus d rhohat, the receiving-side segment sum of dP1 (run-length scan,
 // boundary runs finish with atomics) and per-work-group partial column sums for d b2, d bc, d w3, d w_r.
 // Persistent work-groups (one per CU: 2 x 64 KiB LDS tiles at H = 512) walk the tiles grid-stride.
-template <int H>
-__device__ __forceinline__ void fe_tile_store(const bf16_t* sB, bf16_t* __restrict__ g, int e0, int ne, int tid) {
-    constexpr int CH = H / 8;
-    bf16_t* gt = g + (size_t)e0 * H;                      // uniform tile base (SGPRs) + 32-bit lane offsets below
-    for (unsigned q = tid; q < (unsigned)ne * CH; q += H) {
-        const unsigned rw = q / CH, ch = q % CH;
-        *(uint4*)&gt[rw * H + ch * 8] = *(const uint4*)&sB[rw * H + ((ch ^ (rw & 7)) * 8)];
-    }
-}
-
-template <int MI>
-__device__ __forceinline__ void fe_zero(f32x4_t (&acc)[MI][4]) {
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-}
-
 template <int H, int BM>
 __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kernel(const FabindEdgeBwdArgs p) {
     constexpr int TPE = H / BM;                                   // threads per edge in the gather layout

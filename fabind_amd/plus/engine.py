@@ -12,9 +12,11 @@ What differs from FABind v1 (fabind_amd/engine.py) and why the data path differs
 * the RowAttention pair biases of a layer are one N=16 GEMM over that list (4 linear + 4 gate heads for each of the two
   blocks); the attention-bias of the inter-edge attention gathers z at the edge pairs.
 
-Round 1: inference path (no autograd), the kernels are the generic ones (GEMM, row LayerNorm, cross attention, inter-edge
-attention, CSR reductions); the pair MLP is three GEMM launches per layer, not yet one fused kernel."""
+The kernels are the generic ones (GEMM, row LayerNorm, cross attention, inter-edge attention, CSR reductions) plus, in
+bf16 inference / sampling, one fused pair-update kernel per layer (csrc/pair_fused.hip); under autograd the pair update
+runs as separate Hadamard / GEMM / LayerNorm launches."""
 import math
+import os
 
 import numpy as np
 import torch
@@ -110,6 +112,15 @@ def prepare_stack_params(model):
         d["b_ab32"] = _cat([i32.linear_p.bias, z32b, i32.linear_c.bias, z32b]).contiguous()
         d["W_o32"] = W(_cat([i32.linear_out.weight, torch.zeros_like(i32.linear_out.weight)], 1))   # [H, 64]
         d["b_o32"] = i32.linear_out.bias
+        if wd == torch.bfloat16 and H in (64, 128, 256, 512):
+            # fragment-packed operands of the fused pair-update kernel (csrc/pair_fused.hip, inference)
+            tz = cam.pair_transition
+            d["pair_fused"] = dict(Wop=K.pack_frag(i32.linear_out.weight), bo=i32.linear_out.bias.float().contiguous(),
+                                   ln_w=tz.layernorm.weight.float().contiguous(), ln_b=tz.layernorm.bias.float().contiguous(),
+                                   eps=float(tz.layernorm.eps),
+                                   W1p=K.pack_frag(tz.linear1.weight), b1=tz.linear1.bias.float().contiguous(),
+                                   W2p=K.pack_frag(tz.linear2.weight), b2=tz.linear2.bias.float().contiguous(),
+                                   Wbp=K.pack_frag(d["W_pb"]), bb=d["b_pb"].float().contiguous())
         Wkv, bkv = m.linear_kv.weight, m.linear_kv.bias
         d["Wqkv"] = W(_cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]]))
         d["bqkv"] = _cat([m.linear_q.bias, bkv[0::2], bkv[1::2]]).contiguous()
@@ -334,14 +345,20 @@ def gcl_layer(p, h, x, lay, g, clampv, pd=0.0):
     return h_new, x_new
 
 
-def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0):
-    """MC_Att_L.forward of FABind+ (egnn.py:277-300) -> (h, x, alpha, z_updated); z is the ragged pair list.
-    pd: dropout of every nn.Dropout on the path (all constructed with args.dropout) in train / sampling mode."""
+FUSE_PAIR = os.environ.get("FABIND_PLUS_FUSE_PAIR", "1") == "1"
+
+
+def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0, bias=None, p_next=None):
+    """MC_Att_L.forward of FABind+ (egnn.py:277-300) -> (h, x, alpha, z_updated, bias_next); z is the ragged pair list.
+    pd: dropout of every nn.Dropout on the path (all constructed with args.dropout) in train / sampling mode.
+    bias: this layer's [pairs, 16] row-attention biases when the previous layer's fused pair update already produced
+    them; bias_next: the same for layer p_next (None unless the fused kernel ran)."""
     H = h.shape[1]
     ad = ops.act_dtype()
     scale = 1.0 / math.sqrt(32.0)
     # ---- CrossAttentionModule (cross_att.py:20-47), protein side in place in the node layout
-    bias = ops.linear(z, p["W_pb"], p["b_pb"])                                                       # [pairs, 16] fp32
+    if bias is None:
+        bias = ops.linear(z, p["W_pb"], p["b_pb"])                                                   # [pairs, 16] fp32
     hc = ops.take_rows(h, lay.c_index64)
     qg = ops.linear(h, p["Wqg_p"], p["bqg_p"])
     kv = ops.linear(hc, p["Wkv_p"])
@@ -356,9 +373,19 @@ def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0):
     h = ops.put_rows(hp, hc, lay.c_index64, inplace=False)     # hp is saved by its ReLU epilogue under autograd
     # ---- pair update: z <- relu-MLP(LN(z + W_o32 (a32 * b32) + b_o32))   (no residual around pair_transition)
     ab32 = ops.linear(h, p["W_ab32"], p["b_ab32"])                                                   # [N, 128]
-    hd32 = pair_had(ab32, 64, pairs.p_node, pairs.c_node, ad)                                        # [pairs, 64]
-    z1 = ops.linear(hd32, p["W_o32"], p["b_o32"], residual=z.float() if z.dtype != torch.float32 else z, out_dtype=ad)
-    z = ln_mlp(p["tr_z"], z1, True, out_dtype=ad, pdrop=pd)
+    bias_next = None
+    pf = p.get("pair_fused")
+    if FUSE_PAIR and pf is not None and z.dtype == torch.bfloat16 and not ops.needs_grad(z, ab32, p["W_o32"]):
+        # one kernel per 64-pair tile: Hadamard + linear_out + residual + LN + both transition Linears (+ next biases)
+        nf = p_next.get("pair_fused") if p_next is not None else None
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if pd > 0.0 else 0
+        z, bias_next = K.pair_update_fused(ab32, 64, pairs.p_node, pairs.c_node, z.contiguous(), pf["Wop"], pf["bo"], pf["ln_w"],
+                                           pf["ln_b"], pf["eps"], pf["W1p"], pf["b1"], pf["W2p"], pf["b2"],
+                                           nf["Wbp"] if nf else None, nf["bb"] if nf else None, pd, seed)
+    else:
+        hd32 = pair_had(ab32, 64, pairs.p_node, pairs.c_node, ad)                                    # [pairs, 64]
+        z1 = ops.linear(hd32, p["W_o32"], p["b_o32"], residual=z.float() if z.dtype != torch.float32 else z, out_dtype=ad)
+        z = ln_mlp(p["tr_z"], z1, True, out_dtype=ad, pdrop=pd)
     # ---- inter-edge attention (att_model / node_model identical to v1; coord_mlp is an LN-MLP on v_e, handed to the
     #      fused kernel as a per-edge scalar)
     zr = ops.take_rows(z, pairs.index_of(g.red_p, g.red_c, batch_id))                                # [n_red, H]
@@ -373,19 +400,20 @@ def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0):
                                          p["zeroH"], clampv, s_ext=s_ext.contiguous())
     if pd > 0.0:
         h_new = h + _drop(h_new - h, pd)                                                             # egnn.py:207 dropout(agg)
-    return h_new, x_new, alpha, z
+    return h_new, x_new, alpha, z, bias_next
 
 
 def egnn_forward(P, h, x, z0, lay, g, las, x_las, pairs, batch_id, scale, step, capture=None, pd=0.0):
     clampv = 10.0 / scale
     h = _drop(ops.linear(h, P["W_in"], P["b_in"]), pd) if (pd > 0.0 and ops.needs_grad(h, P["W_in"])) else \
         ops.linear(h, P["W_in"], P["b_in"], p_drop=pd)
-    z = z0
+    z, bias = z0, None
     for i in range(P["L"]):
         h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv, pd)
         if capture is not None:
             capture["gcl_%d.h" % i], capture["gcl_%d.x" % i] = h.detach().clone(), x.detach().clone()
-        h, x, alpha, z = att_layer(P["att"][i], h, x, z, lay, g, pairs, batch_id, clampv, pd)
+        h, x, alpha, z, bias = att_layer(P["att"][i], h, x, z, lay, g, pairs, batch_id, clampv, pd, bias,
+                                         P["att"][i + 1] if i + 1 < P["L"] else None)
         if capture is not None:
             capture["att_%d.h" % i], capture["att_%d.x" % i], capture["att_%d.alpha" % i] = \
                 h.detach().clone(), x.detach().clone(), alpha.detach().clone()

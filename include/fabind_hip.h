@@ -175,6 +175,25 @@ int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* args, int H, int n_groups
 int fabind_gcl_edge_fused_bwd_set_tile(int bm);
 int fabind_gcl_edge_fused_bwd_tile(void);
 
+/* Fused pair-embedding update of FABind+'s CrossAttentionModule (FABind_plus/fabind/models/cross_att.py:42-44 with
+ * model_utils.py InteractionModule / MLPwithLastAct), bf16, inference (no adjoint: training runs the separate launches):
+ *   z1 = z_in + (T[p_node, 0:32] * T[c_node, b_off:b_off+32]) Wo^T + bo;   y = LayerNorm(z1; ln_w, ln_b, eps)
+ *   z_out = drop(relu( drop(relu(y W1^T + b1)) W2^T + b2 ));   bias_out = z_out Wb^T + bb   (when Wbp != NULL)
+ * z_in / z_out: bf16 [n_pairs, H] (may alias); T: fp32 [nodes, ldt]; p_node / c_node: int32 [n_pairs].
+ * Wop = [H,32], W1p / W2p = [H,H], Wbp = [16,H], all bf16 packed in MFMA fragment order [K/32][N/16][4][16][8].
+ * Dropout (sampling mode): keep(e,c) of fabind_gcl_edge_fused with seed (first) and seed + 0x9e3779b9 (second). */
+typedef struct FabindPairUpdateArgs {
+    const float* T; const int* p_node; const int* c_node;
+    const void* z_in; void* z_out;
+    const void* Wop; const float* bo; const float* ln_w; const float* ln_b;
+    const void* W1p; const float* b1; const void* W2p; const float* b2;
+    const void* Wbp; const float* bb; float* bias_out;
+    int ldt, b_off, n_pairs;
+    float eps, p_drop;
+    unsigned seed;
+} FabindPairUpdateArgs;
+int fabind_pair_update_fused(const FabindPairUpdateArgs* args, int H, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Cross attention (RowAttentionBlock / Attention._attention, models/cross_att.py:118-134,
  * models/model_utils.py:21-38,96-133).  Ragged: no padding, so the -1e9 mask bias never applies.

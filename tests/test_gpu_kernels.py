@@ -321,3 +321,56 @@ def test_gemm_epilogue_dropout_statistics_and_order():
     _, part = K.gemm(A, W, bias=b, act_epi=K.ACT_RELU, dotvec=u, want_out=False, p_drop=p, seed=77)
     ref = ((y1 - R) * u).sum(1)
     assert (part.sum(1) - ref).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("H,n_pairs,p_drop", [(512, 1000, 0.0), (512, 4133, 0.1), (128, 257, 0.0), (64, 63, 0.25), (256, 640, 0.1)])
+def test_pair_update_fused_matches_torch(H, n_pairs, p_drop):
+    """fabind_pair_update_fused (FABind+ cross_att.py:42-44): Hadamard + linear_out + residual + LayerNorm + the two
+    transition Linears (+ the next layer's 16 bias columns) per 64-pair tile, against fp32 torch on the same bf16-rounded
+    operands; the dropout masks are the counter-based ones of include/fabind_hip.h."""
+    from fabind_amd import kernels as K
+    from helpers import fused_edge_keep_mask
+    dev = _dev()
+    g = torch.Generator().manual_seed(H + n_pairs)
+    n_nodes = 200
+    T = torch.randn(n_nodes, 128, generator=g)
+    pn = torch.randint(0, n_nodes, (n_pairs,), generator=g, dtype=torch.int32)
+    cn = torch.randint(0, n_nodes, (n_pairs,), generator=g, dtype=torch.int32)
+    z = torch.randn(n_pairs, H, generator=g).bfloat16()
+    r16 = lambda t: t.bfloat16().float()
+    Wo = r16(torch.randn(H, 32, generator=g) / 32 ** 0.5)
+    W1, W2 = r16(torch.randn(H, H, generator=g) / H ** 0.5), r16(torch.randn(H, H, generator=g) / H ** 0.5)
+    Wb = r16(torch.randn(16, H, generator=g) / H ** 0.5)
+    bo, b1, b2, bb = (torch.randn(n, generator=g) * 0.3 for n in (H, H, H, 16))
+    lw, lb = torch.rand(H, generator=g) + 0.5, torch.randn(H, generator=g) * 0.2
+    seed = 1234
+    # fp32 reference (bf16 rounding at the points where the kernel stores bf16 tiles)
+    hd = r16(T[pn.long(), :32] * T[cn.long(), 64:96])
+    z1 = z.float() + hd @ Wo.T + bo
+    y = r16(torch.nn.functional.layer_norm(z1, (H,), lw, lb, 1e-5))
+    t = torch.relu(y @ W1.T + b1)
+    if p_drop > 0:
+        t = t * fused_edge_keep_mask(seed, n_pairs, H, p_drop)
+    t = r16(t)
+    zn = torch.relu(t @ W2.T + b2)
+    if p_drop > 0:
+        zn = zn * fused_edge_keep_mask((seed + 0x9e3779b9) & 0xFFFFFFFF, n_pairs, H, p_drop)
+    zn = r16(zn)
+    bias_ref = zn @ Wb.T + bb
+    d = lambda t_: t_.to(dev)
+    z_out, bias = K.pair_update_fused(d(T), 64, d(pn), d(cn), d(z), K.pack_frag(d(Wo)), d(bo), d(lw), d(lb), 1e-5,
+                                      K.pack_frag(d(W1)), d(b1), K.pack_frag(d(W2)), d(b2), K.pack_frag(d(Wb)), d(bb), p_drop, seed)
+    torch.cuda.synchronize()
+    scale = max(1.0, float(zn.abs().max()))
+    err = (z_out.float().cpu() - zn).abs()
+    # bf16 tiles between the contractions: a rounding flip moves an element by one bf16 ulp of the intermediate
+    assert float(err.max()) <= 4e-2 * scale, float(err.max())
+    assert float(err.mean()) <= 2e-3 * scale
+    assert (bias.cpu() - bias_ref).abs().max() <= 4e-2 * max(1.0, float(bias_ref.abs().max()))
+    if p_drop > 0:
+        assert abs(float((z_out == 0).float().mean()) - float((zn == 0).float().mean())) < 5e-3
+    # without the bias projection, and in place
+    z_in = d(z).clone()
+    a = K.pair_update_fused(d(T), 64, d(pn), d(cn), z_in, K.pack_frag(d(Wo)), d(bo), d(lw), d(lb), 1e-5,
+                            K.pack_frag(d(W1)), d(b1), K.pack_frag(d(W2)), d(b2), None, None, p_drop, seed)
+    assert a[1] is None and torch.equal(a[0], z_out)
