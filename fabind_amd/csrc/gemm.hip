@@ -219,6 +219,8 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
         bv[j] = (p.bias && col < N) ? p.bias[col] : 0.f;
         dv[j] = (HAS_DOT && col < N) ? p.dotvec[col] : 0.f;
     }
+    const uint32_t drop_thr = (uint32_t)(p.p_drop * 65536.0f + 0.5f);
+    const float drop_scale = 1.0f / (1.0f - (float)drop_thr / 65536.0f);
     if (HAS_C2) {                          // derivative tile first (uses the staging buffer), then the value tile
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -243,7 +245,11 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
                     const int rowg = m0 + wm * 64 + i * 16 + cq * 4 + r, colg = n0 + wn * 64 + j * 16 + fr;
                     if (rowg < M && colg < N) vp += ((const float*)p.R)[(size_t)p.r_index[rowg] * p.ldr + colg];
                 }
-                const float v = fast_act<ACT>(vp);
+                float v = fast_act<ACT>(vp);
+                if (drop_thr) {            // uniform branch: epilogue dropout (same counter-based mask as the generic epilogue)
+                    const uint32_t rowg = m0 + wm * 64 + i * 16 + cq * 4 + r, colg = n0 + wn * 64 + j * 16 + fr;
+                    v *= ((fb_hash32(p.drop_seed + rowg * (uint32_t)N + colg) & 0xffffu) >= drop_thr) ? drop_scale : 0.f;
+                }
                 if (HAS_C) sOut[(wm * 64 + i * 16 + cq * 4 + r) * OUT_LD + wn * 64 + j * 16 + fr] = f32_to_bf16(STORE_PRE ? vp : v);
                 if (HAS_DOT) ds[r] += v * dv[j];
             }
@@ -984,18 +990,17 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     FB_REQUIRE(!(p.w_dtype == FB_DT_BF16 && (p.ldw % 8 != 0)), "fabind_gemm: bf16 W needs ldw % 8 == 0");
     p.epi_fast = 0;
     FB_REQUIRE(p.p_drop >= 0.f && p.p_drop < 1.f, "fabind_gemm: p_drop in [0, 1)");
-    if (p.p_drop > 0.f) {
-        /* dropout lives in the generic epilogue only */
-    } else
-    if (!p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && !p.r_index && p.C != nullptr &&
+    const bool drop = p.p_drop > 0.f;    /* dropout: generic epilogue, or the fast ones without a second / pre-activation tile */
+    if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && !p.r_index && p.C != nullptr &&
         p.c_dtype == FB_DT_F32 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
         p.epi_fast = p.R ? 10 : 9;
-    } else if (!p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && p.R && p.r_index && p.C &&
+    } else if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && p.R && p.r_index && p.C &&
                p.c_dtype == FB_DT_BF16 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
         p.epi_fast = 11;
     } else
     if (!p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.R && !p.accumulate && !p.r_index &&
-        (p.C == nullptr || p.c_dtype == FB_DT_BF16) && (p.C2 == nullptr || p.C != nullptr)) {
+        (p.C == nullptr || p.c_dtype == FB_DT_BF16) && (p.C2 == nullptr || p.C != nullptr) &&
+        !(drop && (p.C2 != nullptr || p.store_preact))) {
         const bool hc = p.C != nullptr, hc2 = p.C2 != nullptr, hd = p.dotvec != nullptr;
         const bool pre = p.store_preact != 0;
         if (p.act_epi == FB_ACT_NONE && hc && !hc2 && !hd) p.epi_fast = 1;

@@ -58,40 +58,42 @@ class Layout:
         pair_off = np.concatenate([[0], np.cumsum(P * C)])
         self.n_pairs = int(pair_off[-1])
         self.sumC, self.sumP = int(coff[-1]), int(poff[-1])
-        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
-        self.node_off = i32(off)
-        self.c_cnt = i32(C)
-        c_index = np.concatenate([np.arange(off[b], off[b] + C[b]) for b in range(B)])
-        p_index = np.concatenate([np.arange(off[b] + C[b], off[b + 1]) for b in range(B)])
-        self.c_index, self.p_index = i32(c_index), i32(p_index)
-        self.c_index64, self.p_index64 = self.c_index.long(), self.p_index.long()
+        # every index array is assembled with numpy vector ops into ONE int32 buffer and uploaded once
+        bidx = np.repeat(np.arange(B), n)
+        loc = np.arange(self.N) - off[:-1][bidx]
+        is_c = loc < C[bidx]
+        c_index, p_index = np.nonzero(is_c)[0], np.nonzero(~is_c)[0]
         inv = np.empty(self.N, dtype=np.int64)
         inv[c_index] = np.arange(self.sumC)
         inv[p_index] = self.sumC + np.arange(self.sumP)
-        self.inv_perm = torch.from_numpy(inv).to(dev)
-
-        def desc(rows):
-            return i32(np.array(rows, dtype=np.int64).astype(np.int32).reshape(-1, 8))
-
-        lo = lambda v: int(v) & 0xFFFFFFFF
-        hi = lambda v: int(v) >> 32
-        s32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v
-        self.desc_p = desc([[poff[b], P[b], coff[b], C[b], s32(lo(pair_off[b])), hi(pair_off[b]), C[b], 1] for b in range(B)])
-        self.desc_c = desc([[coff[b], C[b], poff[b], P[b], s32(lo(pair_off[b])), hi(pair_off[b]), 1, C[b]] for b in range(B)])
-        # the same blocks with the protein side addressed IN PLACE in the node layout (rows off[b]+C[b] ...): protein-side
-        # arrays of the cross attention stay [N, .] and never get gathered / scattered (ligand rows are don't-care)
-        self.desc_pf = desc([[off[b] + C[b], P[b], coff[b], C[b], s32(lo(pair_off[b])), hi(pair_off[b]), C[b], 1]
-                             for b in range(B)])
-        self.desc_cf = desc([[coff[b], C[b], off[b] + C[b], P[b], s32(lo(pair_off[b])), hi(pair_off[b]), 1, C[b]]
-                             for b in range(B)])
+        lo = lambda v: (v & 0xFFFFFFFF).astype(np.uint32).astype(np.int64)     # low word, reinterpreted as int32 on upload
+        hi = lambda v: v >> 32
+        one, zero = np.ones(B, dtype=np.int64), np.zeros(B, dtype=np.int64)
+        o, cf, pf, po = off[:-1], coff[:-1], poff[:-1], pair_off[:-1]
         NO = n_pair_out
         self.NO = NO
-        self.pb_groups = desc([[off[b] + C[b], P[b], coff[b] * NO, C[b] * NO, s32(lo(pair_off[b] * NO)),
-                                hi(pair_off[b] * NO), C[b] * NO, 0] for b in range(B)])
+        desc = lambda cols: np.stack(cols, 1).reshape(-1)
+        parts = dict(
+            node_off=off, c_cnt=C, c_index=c_index, p_index=p_index, inv_perm=inv,
+            desc_p=desc([pf, P, cf, C, lo(po), hi(po), C, one]),
+            desc_c=desc([cf, C, pf, P, lo(po), hi(po), one, C]),
+            # the same blocks with the protein side addressed IN PLACE in the node layout (rows off[b]+C[b] ...): protein-side
+            # arrays of the cross attention stay [N, .] and never get gathered / scattered (ligand rows are don't-care)
+            desc_pf=desc([o + C, P, cf, C, lo(po), hi(po), C, one]),
+            desc_cf=desc([cf, C, o + C, P, lo(po), hi(po), one, C]),
+            pb_groups=desc([o + C, P, cf * NO, C * NO, lo(po * NO), hi(po * NO), C * NO, zero]),
+            # adjoint of the pair bias as two ragged batched contractions per attention block (ops._PairBias.backward)
+            pb_tn_groups=desc([lo(po * NO), hi(po * NO), C * NO, C * NO, o + C, P, zero, zero]))   # c_off filled per H in ops
+        flat = np.concatenate([np.asarray(v, dtype=np.int64) for v in parts.values()])
+        flat = torch.from_numpy((flat & 0xFFFFFFFF).astype(np.uint32).view(np.int32)).to(dev)
+        pos = 0
+        for name, v in parts.items():
+            t = flat[pos:pos + len(v)]
+            pos += len(v)
+            setattr(self, name, t.view(-1, 8) if name.startswith(("desc", "pb_")) else t)
+        self.c_index64, self.p_index64 = self.c_index.long(), self.p_index.long()
+        self.inv_perm = self.inv_perm.long()
         self.pb_max_n = int((C * NO).max())
-        # adjoint of the pair bias as two ragged batched contractions per attention block (ops._PairBias.backward)
-        self.pb_tn_groups = desc([[s32(lo(pair_off[b] * NO)), hi(pair_off[b] * NO), C[b] * NO, C[b] * NO, off[b] + C[b], P[b],
-                                   0, 0] for b in range(B)])          # c_off filled per H in ops
         self.coff, self.pair_off_np = coff, pair_off
 
     def ranges(self, idx_first):
@@ -172,8 +174,33 @@ def gcl_params(m):
         Wn1=W(m.node_mlp[0].weight), bn1=m.node_mlp[0].bias, Wn2=W(m.node_mlp[2].weight), bn2=m.node_mlp[2].bias)
 
 
+_PACK_CACHE = {}
+
+
+def cached_pack(model, builder):
+    """Kernel-side parameter pack of `model`.  Without autograd (inference / sampling: the same weights serve many
+    calls) the pack is built once and reused until a parameter is modified or replaced or the precision mode changes;
+    under autograd it is rebuilt every call, because it must be a differentiable function of the parameters."""
+    params = list(model.parameters())
+    if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        return builder(model)
+    key = (get_precision(), tuple((p.data_ptr(), p._version) for p in params))
+    ent = _PACK_CACHE.get(id(model))
+    if ent is not None and ent[0] == key and ent[2]() is model:
+        return ent[1]
+    import weakref
+    with torch.no_grad():
+        P = builder(model)
+    _PACK_CACHE[id(model)] = (key, P, weakref.ref(model, lambda _r, k=id(model): _PACK_CACHE.pop(k, None)))
+    return P
+
+
 def prepare_stack_params(model):
     """Pack the parameters of an EfficientMCAttModel for the kernels (see module docstring)."""
+    return cached_pack(model, _build_stack_params)
+
+
+def _build_stack_params(model):
     wd = _wd()
     gnn = model.gnn
     H = gnn.hidden_nf

@@ -24,7 +24,7 @@ import torch
 from .. import kernels as K
 from .. import ops
 from ..config import get_precision
-from ..engine import Graph, Layout, _cat
+from ..engine import Graph, Layout, _cat, cached_pack
 
 
 def _wd():
@@ -67,6 +67,10 @@ def _mlp(m, W, k_pad=None, n_pad=None):
 
 
 def prepare_stack_params(model):
+    return cached_pack(model, _build_stack_params)
+
+
+def _build_stack_params(model):
     wd = _wd()
     W = lambda t: t.to(wd).contiguous()
     gnn = model.gnn
@@ -142,20 +146,20 @@ def prepare_stack_params(model):
 # the order the block descriptors of the attention kernels use (pair = pair_off[b] + p_local * C_b + c_local)
 # ------------------------------------------------------------------------------------------------
 class PairList:
+    """Built with device index arithmetic (no per-complex host loop, no large upload)."""
+
     def __init__(self, lay, device):
-        pp, cc, bb, ii, jj = [], [], [], [], []
-        for b in range(lay.B):
-            Pb, Cb, o = int(lay.P[b]), int(lay.C[b]), int(lay.off[b])
-            i, j = np.meshgrid(np.arange(Pb), np.arange(Cb), indexing="ij")
-            pp.append((o + Cb + i).ravel()); cc.append((o + j).ravel())
-            bb.append(np.full(Pb * Cb, b)); ii.append(i.ravel()); jj.append(j.ravel())
-        t = lambda a, dt: torch.from_numpy(np.concatenate(a)).to(dt).to(device)
-        self.p_node, self.c_node = t(pp, torch.int32), t(cc, torch.int32)
-        self.b, self.i, self.j = t(bb, torch.int64), t(ii, torch.int64), t(jj, torch.int64)
-        self.n = int(self.p_node.shape[0])
-        self.off = torch.from_numpy(lay.off[:-1].astype(np.int64)).to(device)
-        self.C = torch.from_numpy(lay.C.astype(np.int64)).to(device)
-        self.pair_off = torch.from_numpy(lay.pair_off_np[:-1].astype(np.int64)).to(device)
+        i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(device)
+        packed = i64(np.stack([lay.off[:-1], lay.C, lay.pair_off_np[:-1], lay.P * lay.C]))       # one small upload
+        self.off, self.C, self.pair_off, npair = packed[0], packed[1], packed[2], packed[3]
+        self.n = int(lay.n_pairs)
+        self.b = torch.repeat_interleave(torch.arange(lay.B, device=device), npair, output_size=self.n)
+        loc = torch.arange(self.n, device=device) - self.pair_off[self.b]
+        Cb, ob = self.C[self.b], self.off[self.b]
+        self.i = torch.div(loc, Cb, rounding_mode="floor")
+        self.j = loc - self.i * Cb
+        self.p_node = (ob + Cb + self.i).to(torch.int32)
+        self.c_node = (ob + self.j).to(torch.int32)
 
     def index_of(self, p_node, c_node, batch_id):
         """Row of the pair list for (protein node, ligand node) ids (index arithmetic on small integer arrays)."""
@@ -429,7 +433,8 @@ def mlp_module(m, x, last_act=False, out_dtype=torch.float32, pdrop=0.0):
     """Apply one of the reference's MLP modules (MLP / MLPwithLastAct / MLPwoBias / MLP4Confidence parameter containers)
     to rows x."""
     wd = _wd()
-    return ln_mlp(_mlp(m, lambda t: t.to(wd).contiguous()), x.contiguous(), last_act, out_dtype=out_dtype, pdrop=pdrop)
+    pack = cached_pack(m, lambda mm: _mlp(mm, lambda t: t.to(wd).contiguous()))
+    return ln_mlp(pack, x.contiguous(), last_act, out_dtype=out_dtype, pdrop=pdrop)
 
 
 def stack_forward(model, X, Hin, batch_id, segment_id, mask, is_global, compound_edge_index, LAS_edge_index, coord_LAS,

@@ -3,6 +3,7 @@
 Same constructor, parameter names and return tuples as the reference (forward -> 13-tuple, inference -> 2-tuple); the
 per-sample python loops (model.py:84-97, 176-197, 225-330) are vectorised index arithmetic.  Round 1: eval / inference
 path (the stack has no autograd yet); the confidence head, DBSCAN centre sampling and dropout sampling are not built."""
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -67,23 +68,23 @@ class FABindPlus(nn.Module):
         """DBSCAN over the residues predicted to be pocket (host-side sklearn, like the reference: model.py:147-167);
         consumes python's `random` exactly as the reference does (one randint + one random per complex)."""
         import random
-        centers = torch.zeros_like(center)
         prob = head['logits'].sigmoid()
-        for i in range(center.shape[0]):
-            pp = prob[i]
-            sel = pp > 0.5
-            if int(sel.sum()) < 50:
-                top = torch.argsort(pp)[-50:]
-                sel = torch.zeros_like(sel)
-                sel[top] = True
-            pts = head['xyz'][i][sel].detach().cpu().numpy()
+        sel = prob > 0.5
+        for i in (sel.sum(1) < 50).nonzero().flatten().tolist():                # rare: too few predicted pocket residues
+            sel[i] = False
+            sel[i, torch.argsort(prob[i])[-50:]] = True
+        sel_h, xyz_h = sel.cpu().numpy(), head['xyz'].detach().float().cpu().numpy()   # one download for the whole batch
+        B = center.shape[0]
+        picked = np.zeros((B, 3), dtype=np.float32)
+        use = np.zeros(B, dtype=bool)
+        for i in range(B):
+            pts = xyz_h[i][sel_h[i]]
             clustering = self.dbscan_module.fit(pts)
             cid = random.randint(0, clustering.labels_.max())
             if random.random() < self.args.choose_cluster_prob:
-                centers[i] = torch.tensor(pts[clustering.labels_ == cid].mean(axis=0), device=center.device)
-            else:
-                centers[i] = center[i]
-        return centers
+                picked[i], use[i] = pts[clustering.labels_ == cid].mean(axis=0), True
+        picked_d = torch.from_numpy(picked).to(center.device).to(center.dtype)
+        return torch.where(torch.from_numpy(use).to(center.device)[:, None], picked_d, center)
 
     def _confidence(self, Ho, batch, B):
         pooled = torch.zeros(B, Ho.shape[1], dtype=torch.float32, device=Ho.device).index_add_(0, batch, Ho.float())

@@ -321,6 +321,10 @@ def test_gemm_epilogue_dropout_statistics_and_order():
     _, part = K.gemm(A, W, bias=b, act_epi=K.ACT_RELU, dotvec=u, want_out=False, p_drop=p, seed=77)
     ref = ((y1 - R) * u).sum(1)
     assert (part.sum(1) - ref).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max()))
+    # the staged bf16 epilogue (fast path) draws the same mask as the generic fp32 one
+    y16, _ = K.gemm(A, W, bias=b, act_epi=K.ACT_RELU, out_dtype=torch.bfloat16, p_drop=p, seed=77)
+    assert torch.equal(y16 == 0, dropped)
+    assert ((y16.float() - v).abs() <= 1e-2 * v.abs() + 1e-3).all()
 
 
 @pytest.mark.parametrize("H,n_pairs,p_drop", [(512, 1000, 0.0), (512, 4133, 0.1), (128, 257, 0.0), (64, 63, 0.25), (256, 640, 0.1)])
