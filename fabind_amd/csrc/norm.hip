@@ -1,6 +1,7 @@
 // LayerNorm over the last dimension (one wave per row), forward and backward.
 // Replaces torch.nn.LayerNorm in Transition_diff_out_dim and the dist-map head
 // (reference models/model.py:15,22,29,352-353).
+#include <algorithm>
 #include "common.h"
 #include "fabind_hip.h"
 
@@ -165,6 +166,148 @@ extern "C" int fabind_edge_ln_concat(const float* h, int ldh, int H, const int* 
     FB_REQUIRE(pad_to <= ldy && 2 * H + 1 <= pad_to, "fabind_edge_ln_concat: 2H+1 <= pad_to <= ldy");
     hipLaunchKernelGGL(edge_ln_concat_kernel, dim3((E + 3) / 4), dim3(256), 0, stream, h, ldh, H, row, col, rhohat, w, b, eps, E,
                        y, y_dt, ldy, pad_to);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// First Linear of FABind+'s LN-MLP edge model with the LayerNorm FOLDED into per-node projections (bf16 inference):
+//   relu( W1 LN([h_r | h_c | rho]) + b1 )
+//     = relu( rs_e * (A[row] + B[col] + (m_r - mu_e) c_r + (m_c - mu_e) c_c + (rho - mu_e) w_r) + dvec )
+// with W1w = W1 diag(ln_w), [A | B] = (h - m 1^T) [W1w_r | W1w_c]^T evaluated once per NODE on the node-CENTRED
+// features (m = per-node feature mean: every term is a deviation, so the bf16 projections are never cancelled against
+// a large mean), c_r = W1w_r 1, c_c = W1w_c 1, w_r = W1w[:, 2H], dvec = W1 ln_b + b1.  The row statistics of the
+// concatenation come from per-node (mean, centred sum of squares) pairs, combined exactly (parallel-variance formula),
+// so the [E, 2H+1] LayerNorm input is never formed and the E x (2H+1) x (2H+1) contraction becomes a gather.  One thread per (edge, 8-column chunk); optional dropout with
+// the GEMM epilogue's counter-based mask.
+__global__ __launch_bounds__(256) void edge_lnfold_kernel(const bf16_t* __restrict__ AB, int ldab, int Kp, int H,
+                                                          const int* __restrict__ row, const int* __restrict__ col,
+                                                          const float* __restrict__ rho, const float2* __restrict__ stat,
+                                                          float eps, const float* __restrict__ w_r,
+                                                          const float* __restrict__ c_r, const float* __restrict__ c_c,
+                                                          const float* __restrict__ dvec, int E,
+                                                          bf16_t* __restrict__ out, uint32_t thr, float dscale, uint32_t seed) {
+    const int CH = Kp >> 3;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)E * CH) return;
+    const int e = (int)(idx / CH), ch = (int)(idx % CH);
+    const int r = row[e], c = col[e];
+    const float rh = rho[e];
+    const float2 sr = stat[r], sc = stat[c];
+    const float Cn = (float)(2 * H + 1), Hf = (float)H;
+    const float mu = (Hf * (sr.x + sc.x) + rh) / Cn;
+    const float dr = sr.x - mu, dc = sc.x - mu, dq = rh - mu;
+    const float rs = rsqrtf((sr.y + sc.y + Hf * (dr * dr + dc * dc) + dq * dq) / Cn + eps);
+    const uint4 ua = *(const uint4*)(AB + (size_t)r * ldab + ch * 8);
+    const uint4 ub = *(const uint4*)(AB + (size_t)c * ldab + Kp + ch * 8);
+    const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w}, wb[4] = {ub.x, ub.y, ub.z, ub.w};
+    float o[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float a = __uint_as_float((k & 1) ? (wa[k >> 1] & 0xffff0000u) : (wa[k >> 1] << 16));
+        const float b = __uint_as_float((k & 1) ? (wb[k >> 1] & 0xffff0000u) : (wb[k >> 1] << 16));
+        const int cc = ch * 8 + k;
+        float v = fmaxf(rs * (a + b + dr * c_r[cc] + dc * c_c[cc] + dq * w_r[cc]) + dvec[cc], 0.f);
+        if (thr) v *= ((fb_hash32(seed + (uint32_t)e * (uint32_t)Kp + (uint32_t)cc) & 0xffffu) >= thr) ? dscale : 0.f;
+        o[k] = v;
+    }
+    uint4 u;
+    u.x = pack2_bf16(o[0], o[1]); u.y = pack2_bf16(o[2], o[3]); u.z = pack2_bf16(o[4], o[5]); u.w = pack2_bf16(o[6], o[7]);
+    *(uint4*)(out + idx * 8) = u;
+}
+// H a multiple of 256 (the production width, H = 512): one wave per edge, lane l owns the 8-column chunks l, l + 64, ...
+// of the 2H leading columns with their four per-column vectors held in registers across the wave's grid-stride walk over
+// the edges (per edge and lane: 2 NPL gathered 16-B loads, NPL 16-B stores); the Kp - 2H tail columns (rho's column and
+// the zero padding) go through the first lanes.  The per-edge scalars are wave-uniform.
+template <int NPL>
+__global__ __launch_bounds__(256) void edge_lnfold_wave_kernel(const bf16_t* __restrict__ AB, int ldab, int Kp, int H,
+                                                               const int* __restrict__ row, const int* __restrict__ col,
+                                                               const float* __restrict__ rho, const float2* __restrict__ stat,
+                                                               float eps, const float* __restrict__ w_r,
+                                                               const float* __restrict__ c_r, const float* __restrict__ c_c,
+                                                               const float* __restrict__ dvec, int E, bf16_t* __restrict__ out,
+                                                               uint32_t thr, float dscale, uint32_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4;
+    float wr[NPL][8], cr[NPL][8], cc[NPL][8], dv[NPL][8];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        const int b = (k * 64 + lane) * 8;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { wr[k][q] = w_r[b + q]; cr[k][q] = c_r[b + q]; cc[k][q] = c_c[b + q]; dv[k][q] = dvec[b + q]; }
+    }
+    const int tail0 = NPL * 64, n_tail = (Kp >> 3) - tail0;          // chunks past the 2H leading columns
+    const float Cn = (float)(2 * H + 1), Hf = (float)H;
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < E; e += nw) {
+        const int r = row[e], c = col[e];
+        const float rh = rho[e];
+        const float2 sr = stat[r], sc = stat[c];
+        const float mu = (Hf * (sr.x + sc.x) + rh) / Cn;
+        const float dr = sr.x - mu, dc = sc.x - mu, dq = rh - mu;
+        const float rs = rsqrtf((sr.y + sc.y + Hf * (dr * dr + dc * dc) + dq * dq) / Cn + eps);
+        const bf16_t* ar = AB + (size_t)r * ldab;
+        const bf16_t* bc = AB + (size_t)c * ldab + Kp;
+        bf16_t* oe = out + (size_t)e * Kp;
+        uint4 ua[NPL], ub[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) { ua[k] = *(const uint4*)(ar + (k * 64 + lane) * 8); ub[k] = *(const uint4*)(bc + (k * 64 + lane) * 8); }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const uint32_t wa[4] = {ua[k].x, ua[k].y, ua[k].z, ua[k].w}, wb[4] = {ub[k].x, ub[k].y, ub[k].z, ub[k].w};
+            float o[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float a = __uint_as_float((q & 1) ? (wa[q >> 1] & 0xffff0000u) : (wa[q >> 1] << 16));
+                const float b = __uint_as_float((q & 1) ? (wb[q >> 1] & 0xffff0000u) : (wb[q >> 1] << 16));
+                float v = fmaxf(rs * (a + b + dr * cr[k][q] + dc * cc[k][q] + dq * wr[k][q]) + dv[k][q], 0.f);
+                if (thr) v *= ((fb_hash32(seed + (uint32_t)e * (uint32_t)Kp + (uint32_t)((k * 64 + lane) * 8 + q)) & 0xffffu) >= thr) ? dscale : 0.f;
+                o[q] = v;
+            }
+            uint4 u;
+            u.x = pack2_bf16(o[0], o[1]); u.y = pack2_bf16(o[2], o[3]); u.z = pack2_bf16(o[4], o[5]); u.w = pack2_bf16(o[6], o[7]);
+            *(uint4*)(oe + (k * 64 + lane) * 8) = u;
+        }
+        if (lane < n_tail) {
+            const int ch = tail0 + lane;
+            const uint4 ta = *(const uint4*)(ar + ch * 8), tb = *(const uint4*)(bc + ch * 8);
+            const uint32_t wa[4] = {ta.x, ta.y, ta.z, ta.w}, wb[4] = {tb.x, tb.y, tb.z, tb.w};
+            float o[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int cq = ch * 8 + q;
+                const float a = __uint_as_float((q & 1) ? (wa[q >> 1] & 0xffff0000u) : (wa[q >> 1] << 16));
+                const float b = __uint_as_float((q & 1) ? (wb[q >> 1] & 0xffff0000u) : (wb[q >> 1] << 16));
+                float v = fmaxf(rs * (a + b + dr * c_r[cq] + dc * c_c[cq] + dq * w_r[cq]) + dvec[cq], 0.f);
+                if (thr) v *= ((fb_hash32(seed + (uint32_t)e * (uint32_t)Kp + (uint32_t)cq) & 0xffffu) >= thr) ? dscale : 0.f;
+                o[q] = v;
+            }
+            uint4 u;
+            u.x = pack2_bf16(o[0], o[1]); u.y = pack2_bf16(o[2], o[3]); u.z = pack2_bf16(o[4], o[5]); u.w = pack2_bf16(o[6], o[7]);
+            *(uint4*)(oe + ch * 8) = u;
+        }
+    }
+}
+extern "C" int fabind_edge_lnfold(const void* AB, int ldab, int Kp, int H, const int* row, const int* col, const float* rho,
+                                  const float* stat, float eps, const float* w_r, const float* c_r, const float* c_c,
+                                  const float* dvec, int E, void* out, float p_drop, unsigned seed, hipStream_t stream) {
+    if (E <= 0) return 0;
+    FB_REQUIRE(Kp % 8 == 0 && ldab % 8 == 0 && ldab >= 2 * Kp, "fabind_edge_lnfold: Kp % 8, ldab % 8, ldab >= 2 Kp");
+    FB_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "fabind_edge_lnfold: p_drop in [0, 1)");
+    const uint32_t thr = (uint32_t)(p_drop * 65536.0f + 0.5f);
+    const float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
+    if (H % 256 == 0 && H <= 512 && Kp / 8 - H / 4 <= 64) {
+        const int blocks = (int)std::min<size_t>(((size_t)E + 3) / 4, (size_t)256 * 8);
+        if (H == 512)
+            hipLaunchKernelGGL(edge_lnfold_wave_kernel<2>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)AB, ldab, Kp, H, row,
+                               col, rho, (const float2*)stat, eps, w_r, c_r, c_c, dvec, E, (bf16_t*)out, thr, dscale, (uint32_t)seed);
+        else
+            hipLaunchKernelGGL(edge_lnfold_wave_kernel<1>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)AB, ldab, Kp, H, row,
+                               col, rho, (const float2*)stat, eps, w_r, c_r, c_c, dvec, E, (bf16_t*)out, thr, dscale, (uint32_t)seed);
+        FB_CHECK_LAUNCH();
+        return 0;
+    }
+    const size_t total = (size_t)E * (Kp / 8);
+    hipLaunchKernelGGL(edge_lnfold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)AB, ldab, Kp,
+                       H, row, col, rho, (const float2*)stat, eps, w_r, c_r, c_c, dvec, E, (bf16_t*)out, thr, dscale, (uint32_t)seed);
     FB_CHECK_LAUNCH();
     return 0;
 }

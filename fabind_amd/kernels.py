@@ -279,6 +279,17 @@ def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows,
     return agg, s[:E]
 
 
+def edge_lnfold(AB16, Kp, H, row, col, rho, stat, eps, w_r, c_r, c_c, dvec, p_drop=0.0, seed=0):
+    """relu(W1 LN([h_r|h_c|rho]) + b1) from per-node projections (csrc/norm.hip: edge_lnfold_kernel) -> bf16 [E, Kp]."""
+    E = row.shape[0]
+    out = torch.empty((E, Kp), dtype=torch.bfloat16, device=AB16.device)
+    assert AB16.dtype == torch.bfloat16 and stat.dtype == torch.float32 and stat.is_contiguous()
+    check(_lib.load().fabind_edge_lnfold(ptr(AB16), _ld(AB16), Kp, H, ptr(row), ptr(col), ptr(rho), ptr(stat), float(eps),
+                                         ptr(w_r), ptr(c_r), ptr(c_c), ptr(dvec), E, ptr(out), float(p_drop), int(seed) & 0xFFFFFFFF,
+                                         stream()), "fabind_edge_lnfold")
+    return out
+
+
 def pair_update_fused(T, b_off, p_node, c_node, z, Wop, bo, ln_w, ln_b, eps, W1p, b1, W2p, b2, Wbp=None, bb=None, p_drop=0.0,
                       seed=0):
     """FABind+ pair update for a ragged pair list (csrc/pair_fused.hip): z [pairs,H] bf16 -> (z' bf16, bias' [pairs,16] fp32

@@ -87,6 +87,14 @@ def _build_stack_params(model):
     def gcl(m):
         d = dict(edge=_mlp(m.edge_mlp, W, K8, K8), node=_mlp(m.node_mlp, W), coord=_mlp(m.coord_mlp, W))
         d["coord"]["w3"] = m.coord_mlp.linear2.weight[0].float().contiguous()
+        if wd == torch.bfloat16:
+            # LayerNorm folded into per-node projections of the first edge Linear (csrc/norm.hip: edge_lnfold_kernel)
+            em = m.edge_mlp
+            W1w = _padded(em.linear1.weight.float() * em.layernorm.weight.float()[None, :], K8, 2 * H + 1)
+            d["fold"] = dict(W_ab=W(_cat([W1w[:, :H], W1w[:, H:2 * H]])), w_r=W1w[:, 2 * H].contiguous(),
+                             c_r=W1w[:, :H].sum(1).contiguous(), c_c=W1w[:, H:2 * H].sum(1).contiguous(),
+                             eps=float(em.layernorm.eps),
+                             dvec=_padvec(em.linear1.weight.float() @ em.layernorm.bias.float() + em.linear1.bias.float(), K8))
         return d
 
     P["gcl"] = [gcl(getattr(gnn, "gcl_%d" % i)) for i in range(L)]
@@ -338,6 +346,19 @@ def gcl_layer(p, h, x, lay, g, clampv, pd=0.0):
         y = ln_rows(cat[:, :2 * H + 1], e["ln_w"], e["ln_b"], ad, e["k_pad"])
         t = _drop(ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad), pd)
         m = _drop(ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad), pd)
+    elif FOLD_EDGE_LN and "fold" in p:
+        # inference, bf16: W1 LN([h_r | h_c | rho]) from per-node projections and per-node statistics -- the
+        # [E, 2H+1] x [2H+1, 2H+1] contraction becomes one [N, H] x [H, 2(2H+1)] contraction and a gather
+        f = p["fold"]
+        hf = h.float()
+        mean = hf.mean(1)
+        hcen = hf - mean[:, None]
+        stat = torch.stack([mean, (hcen * hcen).sum(1)], 1).contiguous()                            # [N, 2]
+        AB = ops.linear(hcen, f["W_ab"], None, out_dtype=torch.bfloat16)                             # [N, 2 K8]
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if pd > 0.0 else 0
+        t = K.edge_lnfold(AB, e["k_pad"], H, g.row_ctx, g.col_ctx, rhohat, stat, f["eps"], f["w_r"], f["c_r"], f["c_c"], f["dvec"],
+                          pd, seed)                                                                  # [E, K8]
+        m = ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)            # [E, H] messages
     else:
         y = K.edge_ln_concat(h, g.row_ctx, g.col_ctx, rhohat, e["ln_w"], e["ln_b"], ad, e["k_pad"])  # [E, K8]
         t = ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)            # [E, K8]
@@ -350,6 +371,7 @@ def gcl_layer(p, h, x, lay, g, clampv, pd=0.0):
 
 
 FUSE_PAIR = os.environ.get("FABIND_PLUS_FUSE_PAIR", "1") == "1"
+FOLD_EDGE_LN = os.environ.get("FABIND_PLUS_FOLD_EDGE_LN", "1") == "1"
 
 
 def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0, bias=None, p_next=None):

@@ -258,6 +258,17 @@ int fabind_layernorm_rows(const void* x, int x_dt, int ldx, const float* w, cons
                           int y_dt, int ldy, int pad_to, hipStream_t stream);
 int fabind_edge_ln_concat(const float* h, int ldh, int H, const int* row, const int* col, const float* rhohat, const float* w,
                           const float* b, float eps, int E, void* y, int y_dt, int ldy, int pad_to, hipStream_t stream);
+
+/* First Linear of FABind+'s LN-MLP edge model (egnn.py:52-58, model_utils.py:44-46) with the LayerNorm folded into
+ * per-node projections, bf16 inference:
+ *   out[e,:] = drop(relu( rs_e * (AB[row[e], 0:Kp] + AB[col[e], Kp:2Kp] + (m_r-mu_e) c_r + (m_c-mu_e) c_c + (rho[e]-mu_e) w_r) + dvec ))
+ * AB = bf16 [nodes, ldab] = (h - m 1^T) [W1 diag(ln_w)]_{r|c}^T (node-centred features), stat = fp32 [nodes][2] =
+ * (mean m, centred sum of squares) of each node's H features; (mu_e, rs_e) are the LayerNorm statistics of
+ * [h_r | h_c | rho] (2H+1 values) combined from them; c_r / c_c = row sums of the two weight blocks.  out = bf16 [E, Kp].
+ * Dropout mask: hash32(seed + e*Kp + c) & 0xffff >= round(p*65536). */
+int fabind_edge_lnfold(const void* AB, int ldab, int Kp, int H, const int* row, const int* col, const float* rho,
+                       const float* stat, float eps, const float* w_r, const float* c_r, const float* c_c, const float* dvec,
+                       int E, void* out, float p_drop, unsigned seed, hipStream_t stream);
 /* adjoint of fabind_layernorm_rows: dx (dtype dx_dt, leading dim lddx) and per-block partials of dw, db ([nblk][C] each,
  * nblk = ceil(R/4); the caller adds the rows).  fabind_edge_concat: y[e] = [h[row[e]] | h[col[e]] | rhohat[e] | 0...]
  * (the un-normalised edge input of MC_E_GCL, used under autograd where LayerNorm is a separate differentiable step). */

@@ -378,3 +378,41 @@ def test_pair_update_fused_matches_torch(H, n_pairs, p_drop):
     a = K.pair_update_fused(d(T), 64, d(pn), d(cn), z_in, K.pack_frag(d(Wo)), d(bo), d(lw), d(lb), 1e-5,
                             K.pack_frag(d(W1)), d(b1), K.pack_frag(d(W2)), d(b2), None, None, p_drop, seed)
     assert a[1] is None and torch.equal(a[0], z_out)
+
+
+@pytest.mark.parametrize("H,E,p_drop", [(512, 3000, 0.0), (128, 777, 0.0), (64, 500, 0.2)])
+def test_edge_lnfold_matches_layernorm_then_linear(H, E, p_drop):
+    """fabind_edge_lnfold: relu(W1 LN([h_r | h_c | rho]) + b1) from per-node projections + per-node statistics equals
+    the straightforward LayerNorm -> Linear -> relu on the concatenated edge input (egnn.py:52-58 of FABind+)."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(H + E)
+    N, Cn = 300, 2 * H + 1
+    Kp = (Cn + 63) // 64 * 64
+    h = torch.randn(N, H, generator=g) * 1.5 + 4.0                      # large feature mean: the centred form must not cancel
+    row = torch.randint(0, N, (E,), generator=g, dtype=torch.int32)
+    col = torch.randint(0, N, (E,), generator=g, dtype=torch.int32)
+    rho = torch.rand(E, generator=g) * 3.0
+    lw, lb = torch.rand(Cn, generator=g) + 0.5, torch.randn(Cn, generator=g) * 0.2
+    W1, b1 = torch.randn(Cn, Cn, generator=g) / Cn ** 0.5, torch.randn(Cn, generator=g) * 0.3
+    x = torch.cat([h[row.long()], h[col.long()], rho[:, None]], 1)
+    ref = torch.relu(torch.nn.functional.layer_norm(x, (Cn,), lw, lb, 1e-5) @ W1.T + b1)         # [E, Cn]
+    W1w = torch.zeros(Kp, Cn); W1w[:Cn] = W1 * lw[None, :]
+    mean = h.mean(1)
+    hcen = h - mean[:, None]
+    AB = (hcen @ torch.cat([W1w[:, :H], W1w[:, H:2 * H]]).T).bfloat16()                          # [N, 2 Kp]
+    stat = torch.stack([mean, (hcen * hcen).sum(1)], 1).contiguous()
+    dvec = torch.zeros(Kp); dvec[:Cn] = W1 @ lb + b1
+    d = lambda t: t.to(dev)
+    out = K.edge_lnfold(d(AB), Kp, H, d(row), d(col), d(rho), d(stat), 1e-5, d(W1w[:, 2 * H].contiguous()),
+                        d(W1w[:, :H].sum(1).contiguous()), d(W1w[:, H:2 * H].sum(1).contiguous()), d(dvec), p_drop, 99).float().cpu()
+    assert out.shape == (E, Kp) and float(out[:, Cn:].abs().max()) == 0.0
+    if p_drop == 0.0:
+        assert (out[:, :Cn] - ref).abs().max() <= 3e-2 * max(1.0, float(ref.abs().max()))
+        assert (out[:, :Cn] - ref).abs().mean() <= 3e-3 * max(1.0, float(ref.abs().mean()))
+    else:
+        kept = out[:, :Cn] != 0
+        thr = round(p_drop * 65536) / 65536.0
+        live = ref > 1e-3
+        assert abs(float((~kept)[live].float().mean()) - p_drop) < 0.01
+        assert ((out[:, :Cn] * (1 - thr) - ref)[kept].abs() <= 3e-2 * max(1.0, float(ref.abs().max()))).all()
