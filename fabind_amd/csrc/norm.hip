@@ -312,6 +312,62 @@ extern "C" int fabind_edge_lnfold(const void* AB, int ldab, int Kp, int H, const
     return 0;
 }
 
+// coord_mlp of FABind+'s inter-edge attention (egnn.py:277-300: LN -> Linear -> relu -> [dropout] -> bias-free Linear to
+// one scalar) on v_e = V[col] + rho * w_rv, with the LayerNorm folded into a per-node projection (bf16 inference):
+//   s[e] = sum_k w3[k] * drop(relu( rs_e * (P[col[e], k] + rho[e] * u[k]) + d[k] ))
+// P = (V - mean(V) 1^T) (W1 diag(ln_w))^T per NODE, u = W1 diag(ln_w) (w_rv - mean(w_rv)), d = W1 ln_b + b1, and
+//   rs_e = rsqrt( (q_V[col] + 2 rho (Vc[col] . wc) + rho^2 q_w) / H + eps )      (stat[n] = (q_V[n], Vc[n] . wc))
+// so the per-edge [E, H] value rows, their LayerNorm and the E x H x H contraction are never formed.  Wave per edge.
+__global__ __launch_bounds__(256) void inter_coord_fold_kernel(const bf16_t* __restrict__ P, int ldp, int H,
+                                                               const int* __restrict__ col, const float* __restrict__ rho,
+                                                               const float2* __restrict__ stat, float q_w, float eps,
+                                                               const float* __restrict__ u, const float* __restrict__ d,
+                                                               const float* __restrict__ w3, int E, float* __restrict__ s_out,
+                                                               uint32_t thr, float dscale, uint32_t seed) {
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4;
+    const bool act = lane * 8 < H;                              // H <= 512: one 8-column chunk per lane
+    float uu[8], dd[8], ww[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        uu[q] = act ? u[lane * 8 + q] : 0.f; dd[q] = act ? d[lane * 8 + q] : 0.f; ww[q] = act ? w3[lane * 8 + q] : 0.f;
+    }
+    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < E; e += nw) {
+        const int c = col[e];
+        const float rh = rho[e];
+        const float2 st = stat[c];
+        const float rs = rsqrtf(fmaxf(st.x + 2.f * rh * st.y + rh * rh * q_w, 0.f) / (float)H + eps);
+        float acc = 0.f;
+        if (act) {
+            const uint4 up = *(const uint4*)(P + (size_t)c * ldp + lane * 8);
+            const uint32_t wp[4] = {up.x, up.y, up.z, up.w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float pv = __uint_as_float((q & 1) ? (wp[q >> 1] & 0xffff0000u) : (wp[q >> 1] << 16));
+                float v = fmaxf(rs * (pv + rh * uu[q]) + dd[q], 0.f);
+                if (thr) v *= ((fb_hash32(seed + (uint32_t)e * (uint32_t)H + (uint32_t)(lane * 8 + q)) & 0xffffu) >= thr) ? dscale : 0.f;
+                acc += v * ww[q];
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) s_out[e] = acc;
+    }
+}
+extern "C" int fabind_inter_coord_fold(const void* P, int ldp, int H, const int* col, const float* rho, const float* stat,
+                                       float q_w, float eps, const float* u, const float* d, const float* w3, int E,
+                                       float* s_out, float p_drop, unsigned seed, hipStream_t stream) {
+    if (E <= 0) return 0;
+    FB_REQUIRE(H % 8 == 0 && H <= 512 && ldp % 8 == 0, "fabind_inter_coord_fold: H % 8 == 0, H <= 512, ldp % 8 == 0");
+    FB_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "fabind_inter_coord_fold: p_drop in [0, 1)");
+    const uint32_t thr = (uint32_t)(p_drop * 65536.0f + 0.5f);
+    const float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
+    const int blocks = (int)std::min<size_t>(((size_t)E + 3) / 4, (size_t)256 * 8);
+    hipLaunchKernelGGL(inter_coord_fold_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)P, ldp, H, col, rho,
+                       (const float2*)stat, q_w, eps, u, d, w3, E, s_out, thr, dscale, (uint32_t)seed);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
 // adjoint of layernorm_rows: one wave per row, row values in registers; dw / db partials per work-group through LDS
 template <int NPL>
 __global__ __launch_bounds__(256) void layernorm_rows_bwd_kernel(const void* __restrict__ x, int x_dt, int ldx,

@@ -290,6 +290,17 @@ def edge_lnfold(AB16, Kp, H, row, col, rho, stat, eps, w_r, c_r, c_c, dvec, p_dr
     return out
 
 
+def inter_coord_fold(P16, H, col, rho, stat, q_w, eps, u, d, w3, p_drop=0.0, seed=0):
+    """Per-edge coordinate scalar of FABind+'s inter-edge layer from per-node projections (csrc/norm.hip) -> fp32 [E]."""
+    E = col.shape[0]
+    out = torch.empty(max(E, 1), dtype=torch.float32, device=P16.device)
+    assert P16.dtype == torch.bfloat16 and stat.dtype == torch.float32 and stat.is_contiguous()
+    check(_lib.load().fabind_inter_coord_fold(ptr(P16), _ld(P16), H, ptr(col), ptr(rho), ptr(stat), float(q_w), float(eps),
+                                              ptr(u), ptr(d), ptr(w3), E, ptr(out), float(p_drop), int(seed) & 0xFFFFFFFF,
+                                              stream()), "fabind_inter_coord_fold")
+    return out[:E]
+
+
 def pair_update_fused(T, b_off, p_node, c_node, z, Wop, bo, ln_w, ln_b, eps, W1p, b1, W2p, b2, Wbp=None, bb=None, p_drop=0.0,
                       seed=0):
     """FABind+ pair update for a ragged pair list (csrc/pair_fused.hip): z [pairs,H] bf16 -> (z' bf16, bias' [pairs,16] fp32

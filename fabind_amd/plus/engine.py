@@ -143,6 +143,14 @@ def _build_stack_params(model):
         d["b_bias"] = _padvec(m.attn_bias_proj.bias, 8).float().contiguous()
         d["coord"] = _mlp(m.coord_mlp, W)
         d["coord"]["w3"] = m.coord_mlp.linear2.weight[0].float().contiguous()
+        if wd == torch.bfloat16 and H % 8 == 0 and H <= 512:
+            # coord_mlp's LayerNorm folded into a per-node projection of V (csrc/norm.hip: inter_coord_fold_kernel)
+            cm = m.coord_mlp
+            W1w = cm.linear1.weight.float() * cm.layernorm.weight.float()[None, :]
+            wc = d["w_rv"] - d["w_rv"].mean()
+            d["coord_fold"] = dict(W1w=W(W1w), wc=wc.contiguous(), q_w=float((wc * wc).sum()), u=(W1w @ wc).contiguous(),
+                                   d=(cm.linear1.weight.float() @ cm.layernorm.bias.float() + cm.linear1.bias.float()).contiguous(),
+                                   eps=float(cm.layernorm.eps), w3=d["coord"]["w3"])
         d["zeroH"] = torch.zeros(H, dtype=torch.float32, device=Wkv.device)
         att.append(d)
     P["att"] = att
@@ -419,9 +427,18 @@ def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0, bias=None, p_
     qkv = ops.linear(h, p["Wqkv"], p["bqkv"])                                                        # [N, 3H]
     d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay, g.int_by_col)
     zero_cv = torch.zeros((h.shape[0], H), dtype=torch.float32, device=h.device)
-    AB = torch.cat([zero_cv, qkv[:, 2 * H:].float()], 1)                                             # v_e = V[col] + rho w_rv
-    v_e = ops.gcl_pre(AB, H, _InterView(g), rhohat, p["w_rv"])
-    s_ext = _coord_scalar(p["coord"], v_e, pd).sum(1)                                                # [E_int]
+    cf = p.get("coord_fold")
+    if FOLD_EDGE_LN and cf is not None and not ops.needs_grad(qkv, x, p["w_rv"]):
+        V = qkv[:, 2 * H:].float()
+        Vc = V - V.mean(1, keepdim=True)
+        stat = torch.stack([(Vc * Vc).sum(1), Vc @ cf["wc"]], 1).contiguous()                        # [N, 2]
+        Pn = ops.linear(Vc, cf["W1w"], None, out_dtype=torch.bfloat16)                               # [N, H]
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if pd > 0.0 else 0
+        s_ext = K.inter_coord_fold(Pn, H, g.col_int, rhohat, stat, cf["q_w"], cf["eps"], cf["u"], cf["d"], cf["w3"], pd, seed)
+    else:
+        AB = torch.cat([zero_cv, qkv[:, 2 * H:].float()], 1)                                         # v_e = V[col] + rho w_rv
+        v_e = ops.gcl_pre(AB, H, _InterView(g), rhohat, p["w_rv"])
+        s_ext = _coord_scalar(p["coord"], v_e, pd).sum(1)                                            # [E_int]
     h_new, x_new, alpha = ops.inter_attn(qkv, zero_cv, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["zeroH"],
                                          p["zeroH"], clampv, s_ext=s_ext.contiguous())
     if pd > 0.0:

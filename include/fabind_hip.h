@@ -269,6 +269,17 @@ int fabind_edge_ln_concat(const float* h, int ldh, int H, const int* row, const 
 int fabind_edge_lnfold(const void* AB, int ldab, int Kp, int H, const int* row, const int* col, const float* rho,
                        const float* stat, float eps, const float* w_r, const float* c_r, const float* c_c, const float* dvec,
                        int E, void* out, float p_drop, unsigned seed, hipStream_t stream);
+
+/* coord_mlp of FABind+'s inter-edge attention layer (egnn.py:277-300; LN -> Linear -> relu -> dropout -> bias-free Linear)
+ * on the value rows v_e = V[col] + rho * w_rv, LayerNorm folded into a per-node projection, bf16 inference:
+ *   s_out[e] = sum_k w3[k] * drop(relu( rs_e * (P[col[e], k] + rho[e] * u[k]) + d[k] )),
+ *   rs_e = rsqrt( (stat[col][0] + 2 rho stat[col][1] + rho^2 q_w) / H + eps )
+ * P = bf16 [nodes, ldp] = (V - mean 1^T)(W1 diag(ln_w))^T; stat = fp32 [nodes][2] = (|Vc|^2, Vc . wc); wc = w_rv - mean(w_rv),
+ * q_w = |wc|^2, u = W1 diag(ln_w) wc, d = W1 ln_b + b1.  H % 8 == 0, H <= 512.
+ * Dropout mask: hash32(seed + e*H + k) & 0xffff >= round(p*65536). */
+int fabind_inter_coord_fold(const void* P, int ldp, int H, const int* col, const float* rho, const float* stat, float q_w,
+                            float eps, const float* u, const float* d, const float* w3, int E, float* s_out, float p_drop,
+                            unsigned seed, hipStream_t stream);
 /* adjoint of fabind_layernorm_rows: dx (dtype dx_dt, leading dim lddx) and per-block partials of dw, db ([nblk][C] each,
  * nblk = ceil(R/4); the caller adds the rows).  fabind_edge_concat: y[e] = [h[row[e]] | h[col[e]] | rhohat[e] | 0...]
  * (the un-normalised edge input of MC_E_GCL, used under autograd where LayerNorm is a separate differentiable step). */

@@ -416,3 +416,39 @@ def test_edge_lnfold_matches_layernorm_then_linear(H, E, p_drop):
         live = ref > 1e-3
         assert abs(float((~kept)[live].float().mean()) - p_drop) < 0.01
         assert ((out[:, :Cn] * (1 - thr) - ref)[kept].abs() <= 3e-2 * max(1.0, float(ref.abs().max()))).all()
+
+
+@pytest.mark.parametrize("H,E,p_drop", [(512, 3000, 0.0), (64, 500, 0.0), (128, 900, 0.2)])
+def test_inter_coord_fold_matches_layernorm_mlp(H, E, p_drop):
+    """fabind_inter_coord_fold: w3 . relu(W1 LN(V[col] + rho w_rv) + b1) from the per-node projection equals the
+    straightforward LayerNorm -> Linear -> relu -> dot on the per-edge value rows (FABind+ egnn.py:277-300)."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(H * 3 + E)
+    N = 250
+    V = torch.randn(N, H, generator=g) * 1.2 + 2.0
+    w_rv = torch.randn(H, generator=g) * 0.5 + 0.3
+    col = torch.randint(0, N, (E,), generator=g, dtype=torch.int32)
+    rho = torch.rand(E, generator=g) * 3.0
+    lw, lb = torch.rand(H, generator=g) + 0.5, torch.randn(H, generator=g) * 0.2
+    W1, b1, w3 = torch.randn(H, H, generator=g) / H ** 0.5, torch.randn(H, generator=g) * 0.3, torch.randn(H, generator=g)
+    v_e = V[col.long()] + rho[:, None] * w_rv
+    act = torch.relu(torch.nn.functional.layer_norm(v_e, (H,), lw, lb, 1e-5) @ W1.T + b1)
+    W1w = W1 * lw[None, :]
+    Vc, wc = V - V.mean(1, keepdim=True), w_rv - w_rv.mean()
+    stat = torch.stack([(Vc * Vc).sum(1), Vc @ wc], 1).contiguous()
+    d = lambda t: t.to(dev)
+    seed = 4242
+    s = K.inter_coord_fold(d((Vc @ W1w.T).bfloat16()), H, d(col), d(rho), d(stat), float((wc * wc).sum()), 1e-5, d(W1w @ wc),
+                           d(W1 @ lb + b1), d(w3), p_drop, seed).cpu()
+    if p_drop > 0:
+        thr = int(p_drop * 65536.0 + 0.5)
+        e = torch.arange(E, dtype=torch.int64)[:, None]; c = torch.arange(H, dtype=torch.int64)[None, :]
+        x = (seed + e * H + c) & 0xFFFFFFFF
+        x = x ^ (x >> 16); x = (x * 0x7feb352d) & 0xFFFFFFFF
+        x = x ^ (x >> 15); x = (x * 0x846ca68b) & 0xFFFFFFFF
+        x = x ^ (x >> 16)
+        act = act * ((x & 0xFFFF) >= thr).float() / (1.0 - thr / 65536.0)
+    ref = act @ w3
+    assert (s - ref).abs().max() <= 3e-2 * max(1.0, float(ref.abs().max()))
+    assert (s - ref).abs().mean() <= 5e-3 * max(1.0, float(ref.abs().mean()))
