@@ -72,6 +72,7 @@ def prepare_stack_params(model):
 
 def _build_stack_params(model):
     wd = _wd()
+    infer = not torch.is_grad_enabled()          # cached_pack builds the no-autograd pack under no_grad: inference-only extras
     W = lambda t: t.to(wd).contiguous()
     gnn = model.gnn
     H, L = gnn.hidden_nf, gnn.n_layers
@@ -87,7 +88,7 @@ def _build_stack_params(model):
     def gcl(m):
         d = dict(edge=_mlp(m.edge_mlp, W, K8, K8), node=_mlp(m.node_mlp, W), coord=_mlp(m.coord_mlp, W))
         d["coord"]["w3"] = m.coord_mlp.linear2.weight[0].float().contiguous()
-        if wd == torch.bfloat16:
+        if wd == torch.bfloat16 and infer:
             # LayerNorm folded into per-node projections of the first edge Linear (csrc/norm.hip: edge_lnfold_kernel)
             em = m.edge_mlp
             W1w = _padded(em.linear1.weight.float() * em.layernorm.weight.float()[None, :], K8, 2 * H + 1)
@@ -124,7 +125,7 @@ def _build_stack_params(model):
         d["b_ab32"] = _cat([i32.linear_p.bias, z32b, i32.linear_c.bias, z32b]).contiguous()
         d["W_o32"] = W(_cat([i32.linear_out.weight, torch.zeros_like(i32.linear_out.weight)], 1))   # [H, 64]
         d["b_o32"] = i32.linear_out.bias
-        if wd == torch.bfloat16 and H in (64, 128, 256, 512):
+        if wd == torch.bfloat16 and infer and H in (64, 128, 256, 512):
             # fragment-packed operands of the fused pair-update kernel (csrc/pair_fused.hip, inference)
             tz = cam.pair_transition
             d["pair_fused"] = dict(Wop=K.pack_frag(i32.linear_out.weight), bo=i32.linear_out.bias.float().contiguous(),
@@ -143,7 +144,7 @@ def _build_stack_params(model):
         d["b_bias"] = _padvec(m.attn_bias_proj.bias, 8).float().contiguous()
         d["coord"] = _mlp(m.coord_mlp, W)
         d["coord"]["w3"] = m.coord_mlp.linear2.weight[0].float().contiguous()
-        if wd == torch.bfloat16 and H % 8 == 0 and H <= 512:
+        if wd == torch.bfloat16 and infer and H % 8 == 0 and H <= 512:
             # coord_mlp's LayerNorm folded into a per-node projection of V (csrc/norm.hip: inter_coord_fold_kernel)
             cm = m.coord_mlp
             W1w = cm.linear1.weight.float() * cm.layernorm.weight.float()[None, :]

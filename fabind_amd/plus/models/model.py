@@ -1,8 +1,9 @@
 """FABindPlus / get_model on the HIP engine (reference FABind_plus/fabind/models/model.py:13-675).
 
-Same constructor, parameter names and return tuples as the reference (forward -> 13-tuple, inference -> 2-tuple); the
-per-sample python loops (model.py:84-97, 176-197, 225-330) are vectorised index arithmetic.  Round 1: eval / inference
-path (the stack has no autograd yet); the confidence head, DBSCAN centre sampling and dropout sampling are not built."""
+Same constructor, parameter names and return tuples as the reference: forward -> 13-tuple (7-tuple with
+`args.confidence_training`), inference -> 2-tuple (3-tuple with the ranking score); the per-sample python loops
+(model.py:84-97, 176-197, 225-330) are vectorised index arithmetic.  forward is differentiable (autograd through the HIP
+stack); inference covers eval and the dropout-sampling mode with the DBSCAN centre choice."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -256,13 +257,12 @@ class FABindPlus(nn.Module):
     def forward(self, data, stage=2, train=False):
         """model.py:63-401.  train=True (or stage 1): teacher forcing with the native pocket; module.train(): Gumbel noise
         on the centre, dropout, random n_iter.  Differentiable (autograd through the HIP stack)."""
-        if self.confidence_training:
-            raise NotImplementedError("confidence training (7-tuple forward on a frozen backbone) is not built")
-        if self.args.use_clustering:
-            raise NotImplementedError("use_clustering is a sampling-mode option: call inference()")
         cb = data['compound'].batch
         head = self._pocket_head(data)
         center = self._soft_center(head['logits'], head['mask'], head['xyz'], noise=self.pocket_pred_model.training)
+        if self.args.use_clustering:                  # model.py:147-167: the DBSCAN centre replaces the soft one (a constant)
+            with torch.no_grad():
+                center = self._cluster_centers(head, center)
         pocket_cls = torch.zeros_like(head['mask'], dtype=data.pocket_idx.dtype)
         pocket_cls[head['pb'], head['loc']] = data.pocket_idx
         if train or stage == 1:
@@ -272,6 +272,10 @@ class FABindPlus(nn.Module):
             if self.args.train_pred_pocket_noise and train:
                 c2 = center + self.args.train_pred_pocket_noise * (2 * torch.rand_like(center) - 1)
             g = self._stage2(data, head, c2, shift_coords=True)
+        if self.confidence_training:                  # train_confidence.py: the 7-tuple with the ranking score (model.py:393-399)
+            Ho, _, _, _, coords_n = self._complex(g, "none")
+            return (self.unnormalize_coord(coords_n), cb, head['logits'] * head['mask'], head['mask'], g['less5'],
+                    self._confidence(Ho, g['batch'], head['B']), g['bias'])
         Ho, Z, cflag, pflag, coords_n = self._complex(g, "ragged")
         y_pred, y_by = self._dist_heads(data, g, Z, coords_n)
         return (self.unnormalize_coord(coords_n), cb, y_pred, y_by, head['logits'] * head['mask'], pocket_cls, head['mask'],

@@ -222,15 +222,19 @@ def _complex(sd, cfg, g):
     return Xo, Ho, Z, cflag, pflag, Xo[cflag][:, 0]
 
 
-def model_forward(sd, cfg, data, stage=2):
+def model_forward(sd, cfg, data, stage=2, confidence=False, stack_mlp=False, clustering=None):
     """FABindPlus.forward(data, stage, train=False), eval mode -> the reference's 13-tuple plus the shifted data.coords
-    (the reference shifts `data.coords` in place and the caller's loss reads it afterwards, utils/training.py:55-60)."""
+    (the reference shifts `data.coords` in place and the caller's loss reads it afterwards, utils/training.py:55-60).
+    confidence=True: the 7-tuple of confidence training (model.py:393-399); clustering = (eps, min_samples,
+    choose_cluster_prob): the DBSCAN centre choice of model.py:147-167 (python `random`)."""
     scale, thres = cfg["coordinate_scale"], cfg["dis_map_thres"]
     head = _pocket_head(sd, cfg, data)
     B = head["B"]
     c_batch = data["compound"].batch
     center = _soft_center(head["logits"], head["p_mask"], head["xyz_dense"], cfg["gs_tau"], cfg["gs_hard"])
     pocket_cls, _ = _to_dense(data.pocket_idx, data["protein_whole"].batch, B)
+    if clustering is not None:
+        center = cluster_centers(head, center, *clustering)
     if stage == 1:
         cx = data["complex"]
         X = cx.node_coords.clone()
@@ -252,6 +256,12 @@ def model_forward(sd, cfg, data, stage=2):
     else:
         g = _stage2_graph(sd, cfg, data, head, center, shift_coords=True)
     Xo, Ho, Z, cflag, pflag, coords_n = _complex(sd, cfg, g)
+    if confidence:
+        pooled = torch.zeros(B, Ho.shape[1]).index_add_(0, g["batch"], Ho)
+        if stack_mlp:
+            pooled = torch.relu(_mlp4conf(sd, "ranking_mlp_pre.", pooled))
+        score = _mlp4conf(sd, "ranking_score_mlp.", pooled)[:, 0]
+        return (coords_n * scale, c_batch, head["logits"], head["p_mask"], g["less5"], score, g["bias"]), g["coords"]
     _, p_m = _to_dense(Ho[pflag], g["pocket_batch"], B)
     _, c_m = _to_dense(Ho[cflag], c_batch, B)
     xc_d, _ = _to_dense(coords_n, c_batch, B)

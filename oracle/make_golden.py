@@ -332,6 +332,23 @@ def golden_model_plus_sampling(mods, name, sizes, hidden, pocket_hidden, layers,
         out = model.inference(_hetero_to_ref(data))
     save["inf_coords"], save["inf_batch"], save["inf_conf"] = _np(out[0]), _np(out[1]), _np(out[2])
     print("%s: confidence %s" % (name, _np(out[2])))
+    # confidence-mode forward (train_confidence.py / utils/training_confidence.py:39,189): the 7-tuple, for the predicted
+    # pocket (stage 2) and teacher-forced (train=True), and the gradient of a weighted score sum w.r.t. the ranking head
+    names7 = ["coords", "compound_batch", "pocket_cls_pred", "protein_out_mask_whole", "keepNode_less_5", "confidence",
+              "pocket_center_bias"]
+    for k, (tag, kw) in enumerate((("cf2", dict(stage=2, train=False)), ("cf1", dict(stage=1, train=True))), 1):
+        d = _hetero_to_ref(data)
+        model.zero_grad()
+        random.seed(4321 + k)                       # forward draws the DBSCAN cluster choice too (model.py:147-167)
+        out = model(d, **kw)
+        for n, o in zip(names7, out):
+            save["%s_%s" % (tag, n)] = _np(o) if torch.is_tensor(o) else np.array(o)
+        wts = torch.arange(1, out[5].numel() + 1, dtype=out[5].dtype)
+        (out[5].reshape(-1) * wts).sum().backward()
+        for n, p in model.named_parameters():
+            if n.startswith("ranking") and p.grad is not None:
+                save["%s_grad_%s" % (tag, n)] = _np(p.grad)
+        print("%s %s: confidence %s" % (name, tag, _np(out[5]).ravel()))
     for key, st in data._stores.items():
         kname = key if isinstance(key, str) else "|".join(key)
         for k, v in st.items():

@@ -178,6 +178,40 @@ def test_plus_sampling_inference_eval_matches_reference():
     assert np.abs(conf.cpu().numpy() - g["inf_conf"]).max() <= 1e-4 * max(1.0, np.abs(g["inf_conf"]).max())
 
 
+def test_plus_confidence_forward_and_ranking_gradients_match_reference():
+    """Confidence-training step (train_confidence.py, utils/training_confidence.py:39,189): forward returns the reference's
+    7-tuple; the gradient of a weighted score sum w.r.t. the ranking head matches the reference's autograd."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision("fp32")
+    g = load_npz("plus_model_sampling_tiny")
+    m = _sampling_model(g, dev).eval()
+    import random
+    for k, (tag, kw) in enumerate((("cf2", dict(stage=2, train=False)), ("cf1", dict(stage=1, train=True))), 1):
+        m.zero_grad()
+        random.seed(int(g["py_seed"]) + k)
+        out = m(hetero_from_npz(g).to(dev), **kw)
+        assert len(out) == 7
+        assert rmsd(out[0].detach().cpu().numpy(), g[tag + "_coords"]) < 1e-4
+        assert np.array_equal(out[1].cpu().numpy(), g[tag + "_compound_batch"])
+        assert np.abs(out[2].detach().cpu().numpy() - g[tag + "_pocket_cls_pred"]).max() < 1e-4
+        assert np.array_equal(out[3].cpu().numpy(), g[tag + "_protein_out_mask_whole"])
+        assert int(out[4]) == int(g[tag + "_keepNode_less_5"])
+        conf = out[5].reshape(-1)
+        assert np.abs(conf.detach().cpu().numpy() - g[tag + "_confidence"].reshape(-1)).max() <= 1e-4
+        assert np.abs(out[6].cpu().numpy() - g[tag + "_pocket_center_bias"]).max() < 1e-4
+        (conf * torch.arange(1, conf.numel() + 1, dtype=conf.dtype, device=dev)).sum().backward()
+        n_checked = 0
+        for name, p in m.named_parameters():
+            key = "%s_grad_%s" % (tag, name)
+            if key in g:
+                ref = g[key]
+                assert p.grad is not None, name
+                assert np.abs(p.grad.cpu().numpy() - ref).max() <= 1e-3 * max(1e-3, np.abs(ref).max()), name
+                n_checked += 1
+        assert n_checked >= 12
+
+
 def test_plus_dropout_sampling_produces_a_pose_distribution():
     """`--infer-dropout` sampling (inference_sampling_fabind.py:148-152): model.train() with the ranking head in eval; poses
     differ between passes, stay finite and close to the deterministic pose; eval passes are reproducible."""

@@ -224,6 +224,23 @@ def test_plus_sampling_inference_matches_reference():
     assert np.abs(conf.numpy() - g["inf_conf"]).max() <= 2e-5 * max(1.0, np.abs(g["inf_conf"]).max())
 
 
+def test_plus_confidence_forward_matches_reference():
+    """Confidence-training forward (train_confidence.py: `model(data, train=True)` / `model(data, stage=2)`) -> 7-tuple."""
+    g = load_npz("plus_model_sampling_tiny")
+    import random
+    for k, (tag, stage) in enumerate((("cf2", 2), ("cf1", 1)), 1):
+        random.seed(int(g["py_seed"]) + k)
+        with torch.no_grad():
+            out, _ = porc.model_forward(weights(g), _plus_model_cfg(g), hetero_from_npz(g), stage=stage, confidence=True,
+                                        stack_mlp=True, clustering=(9.0, 2, 0.5))
+        assert len(out) == 7
+        assert rmsd(out[0].numpy(), g[tag + "_coords"]) < 2e-5
+        assert np.abs((out[2] * out[3]).numpy() - g[tag + "_pocket_cls_pred"]).max() < 2e-5
+        assert int(out[4]) == int(g[tag + "_keepNode_less_5"])
+        assert np.abs(out[5].numpy() - g[tag + "_confidence"]).max() <= 2e-5
+        assert np.abs(out[6].numpy() - g[tag + "_pocket_center_bias"]).max() < 2e-5
+
+
 def _plus_loss_inputs():
     g, L = load_npz("plus_model_tiny"), load_npz("plus_loss_tiny")
     t = lambda k: torch.from_numpy(g[k])
