@@ -59,6 +59,7 @@ SIGNATURES = {
     "fabind_edge_ln_concat": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _i, _i, _vp],
     "fabind_edge_lnfold": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp, _f, ctypes.c_uint, _vp],
     "fabind_inter_coord_fold": [_vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp, _f, ctypes.c_uint, _vp],
+    "fabind_post_optimize": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "fabind_segment_sum": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
     "fabind_coord_update": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
     "fabind_cross_attn_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i,

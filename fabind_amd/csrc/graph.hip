@@ -12,10 +12,16 @@
 #define EB_THREADS 256
 #define EB_LDS_NODES 4096  // complexes up to this many nodes stage their coordinates in LDS (48 KiB)
 
-// distance predicate with the reference's op order: sub -> square-sum -> sqrt -> <=  (att_model.py:124-126)
+// distance predicate with the reference's op order: sub -> square-sum -> sqrt -> <=  (att_model.py:124-126).
+// Contraction is switched OFF for this function: HIP's __fmul_rn / __fadd_rn are plain `*` / `+` (contractible under
+// the default -ffp-contract=fast), and the count pass, the fill pass and the two directions of one edge each inline this
+// predicate at a different site -- if the compiler fused a different multiply-add at each, a distance exactly at the
+// cut-off would be counted but not filled (an uninitialised CSR slot) or emitted in one direction only.
 __device__ __forceinline__ bool within(float ax, float ay, float az, float bx, float by, float bz, float cut) {
-    float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
-    float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+#pragma clang fp contract(off)
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    const float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const float d2 = (xx + yy) + zz;
     return __fsqrt_rn(d2) <= cut;
 }
 

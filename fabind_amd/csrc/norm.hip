@@ -229,13 +229,15 @@ __global__ __launch_bounds__(256) void edge_lnfold_wave_kernel(const bf16_t* __r
     const int lane = threadIdx.x & 63;
     const int nw = gridDim.x * 4;
     float wr[NPL][8], cr[NPL][8], cc[NPL][8], dv[NPL][8];
+    const int tail0 = H >> 2, n_tail = (Kp >> 3) - tail0;            // 2H / 8 leading chunks, then rho's column + zero padding
+    bool on[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
-        const int b = (k * 64 + lane) * 8;
+        on[k] = k * 64 + lane < tail0;
+        const int b = on[k] ? (k * 64 + lane) * 8 : 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) { wr[k][q] = w_r[b + q]; cr[k][q] = c_r[b + q]; cc[k][q] = c_c[b + q]; dv[k][q] = dvec[b + q]; }
     }
-    const int tail0 = NPL * 64, n_tail = (Kp >> 3) - tail0;          // chunks past the 2H leading columns
     const float Cn = (float)(2 * H + 1), Hf = (float)H;
     for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < E; e += nw) {
         const int r = row[e], c = col[e];
@@ -249,7 +251,10 @@ __global__ __launch_bounds__(256) void edge_lnfold_wave_kernel(const bf16_t* __r
         bf16_t* oe = out + (size_t)e * Kp;
         uint4 ua[NPL], ub[NPL];
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) { ua[k] = *(const uint4*)(ar + (k * 64 + lane) * 8); ub[k] = *(const uint4*)(bc + (k * 64 + lane) * 8); }
+        for (int k = 0; k < NPL; ++k) {
+            const int o8 = on[k] ? (k * 64 + lane) * 8 : 0;
+            ua[k] = *(const uint4*)(ar + o8); ub[k] = *(const uint4*)(bc + o8);
+        }
 #pragma unroll
         for (int k = 0; k < NPL; ++k) {
             const uint32_t wa[4] = {ua[k].x, ua[k].y, ua[k].z, ua[k].w}, wb[4] = {ub[k].x, ub[k].y, ub[k].z, ub[k].w};
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(256) void edge_lnfold_wave_kernel(const bf16_t* __r
             }
             uint4 u;
             u.x = pack2_bf16(o[0], o[1]); u.y = pack2_bf16(o[2], o[3]); u.z = pack2_bf16(o[4], o[5]); u.w = pack2_bf16(o[6], o[7]);
-            *(uint4*)(oe + (k * 64 + lane) * 8) = u;
+            if (on[k]) *(uint4*)(oe + (k * 64 + lane) * 8) = u;
         }
         if (lane < n_tail) {
             const int ch = tail0 + lane;
@@ -294,9 +299,9 @@ extern "C" int fabind_edge_lnfold(const void* AB, int ldab, int Kp, int H, const
     FB_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "fabind_edge_lnfold: p_drop in [0, 1)");
     const uint32_t thr = (uint32_t)(p_drop * 65536.0f + 0.5f);
     const float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
-    if (H % 256 == 0 && H <= 512 && Kp / 8 - H / 4 <= 64) {
+    if (H % 4 == 0 && H <= 512 && Kp / 8 - H / 4 <= 64) {
         const int blocks = (int)std::min<size_t>(((size_t)E + 3) / 4, (size_t)256 * 8);
-        if (H == 512)
+        if (H > 256)
             hipLaunchKernelGGL(edge_lnfold_wave_kernel<2>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)AB, ldab, Kp, H, row,
                                col, rho, (const float2*)stat, eps, w_r, c_r, c_c, dvec, E, (bf16_t*)out, thr, dscale, (uint32_t)seed);
         else

@@ -18,6 +18,8 @@ touches activations runs in libfabind_hip.so.
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -113,7 +115,14 @@ class Graph:
         deg_ctx, deg_int = K.edges_count(x, lay.node_off, lay.c_cnt, lay.B, lay.max_n, bond_row, bond_off, cut_intra,
                                          cut_inter)
         rp_ctx, rp_int = K.exclusive_scan(deg_ctx), K.exclusive_scan(deg_int)
-        E_ctx, E_int = int(rp_ctx[-1].item()), int(rp_int[-1].item())
+        lo = lay.node_off[:-1].long()
+        n_lig_rows = (rp_int[lo + lay.c_cnt.long()] - rp_int[lo]).sum()
+        E_ctx, E_int, n_half = torch.stack([rp_ctx[-1], rp_int[-1], n_lig_rows.to(rp_int.dtype)]).tolist()   # the one host sync
+        if 2 * n_half != E_int:
+            # the pair bookkeeping (inter_meta) needs every ligand->protein edge mirrored; only non-finite coordinates
+            # can break that -- fail loudly on the host instead of faulting on the device
+            raise RuntimeError("fabind_amd: inter-graph is not symmetric (%d ligand-row edges of %d): finite coordinates: %s"
+                               % (n_half, E_int, bool(torch.isfinite(x).all())))
         if E_int == 0:
             # reference fallback (att_model.py:85-86): one fake symmetric pair from the first candidate,
             # i.e. first ligand atom of complex 0 <-> its first protein residue.
@@ -132,6 +141,13 @@ class Graph:
                 x, lay.node_off, lay.c_cnt, lay.B, lay.max_n, bond_row, bond_col, bond_off, cut_intra, cut_inter, rp_ctx,
                 rp_int, E_ctx, E_int)
         self.rp_ctx, self.rp_int, self.E_ctx, self.E_int = rp_ctx, rp_int, E_ctx, E_int
+        if os.environ.get("FABIND_DEBUG_GRAPH", "0") == "1":             # development aid: validate the CSR on the host
+            r, c, Nn = self.row_int.long(), self.col_int.long(), lay.N
+            k1, k2 = torch.sort(r * Nn + c)[0], torch.sort(c * Nn + r)[0]
+            nbad = int((k1 != k2).sum())
+            rr = torch.repeat_interleave(torch.arange(Nn, device=r.device), (rp_int[1:] - rp_int[:-1]).long())
+            print("[fabind] graph check: E_int %d, col range [%d, %d] of %d, row mismatch %d, mirror mismatches %d, finite %s"
+                  % (E_int, int(c.min()), int(c.max()), Nn, int((rr != r).sum()), nbad, bool(torch.isfinite(x).all())), flush=True)
         self.red_off, self.red_idx, self.red_c, self.red_p, self.mirror = K.inter_meta(
             lay.node_off, lay.c_cnt, lay.B, rp_int, self.col_int, self.row_int)
         self._ctx_bycol = None

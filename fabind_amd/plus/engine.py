@@ -423,7 +423,8 @@ def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0, bias=None, p_
         z = ln_mlp(p["tr_z"], z1, True, out_dtype=ad, pdrop=pd)
     # ---- inter-edge attention (att_model / node_model identical to v1; coord_mlp is an LN-MLP on v_e, handed to the
     #      fused kernel as a per-edge scalar)
-    zr = ops.take_rows(z, pairs.index_of(g.red_p, g.red_c, batch_id))                                # [n_red, H]
+    ridx = pairs.index_of(g.red_p, g.red_c, batch_id)
+    zr = ops.take_rows(z, ridx)                                                                      # [n_red, H]
     bias_part = ops.linear(zr, p["W_bias"], p["b_bias"])                                             # [n_red, 8]: col 0
     qkv = ops.linear(h, p["Wqkv"], p["bqkv"])                                                        # [N, 3H]
     d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay, g.int_by_col)

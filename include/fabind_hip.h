@@ -194,6 +194,19 @@ typedef struct FabindPairUpdateArgs {
 } FabindPairUpdateArgs;
 int fabind_pair_update_fused(const FabindPairUpdateArgs* args, int H, hipStream_t stream);
 
+/* Ligand post-optimisation (FABind/fabind/utils/post_optim_utils.py:9-64; called per complex by fabind_inference.py:285-328):
+ * `steps` Adam iterations (lr, betas 0.9 / 0.999, eps 1e-8) on x0 against
+ *   sum_{(i,j) in LAS} | |x_i-x_j| - |ref_i-ref_j| | + 2 sum_{i,j} relu(1.22 - |x_i-x_j|)      (all_pairs = 0), or
+ *   sum_{i,j} | |x_i-x_j| - |ref_i-ref_j| |                                                  (all_pairs = 1: no LAS edges)
+ * for a BATCH of ligands in one launch (one work-group per ligand, all iterations inside the kernel).
+ * x0, ref, x_out: fp32 [sum atoms, 3]; atom_off: int32 [n_ligands+1]; nbr_ptr int32 [sum atoms + 1] / nbr_idx int32 (GLOBAL
+ * atom ids): for every DISTINCT directed LAS edge (i,j) the list of i holds j and the list of j holds i.
+ * loss_out[l] = loss at the last iteration (before its step), rmsd_out[l] = sqrt(mean |ref - x_out|^2), like the reference's
+ * return values.  max_atoms = largest ligand (<= 512). */
+int fabind_post_optimize(const float* x0, const float* ref, const int* atom_off, const int* nbr_ptr, const int* nbr_idx,
+                         int n_ligands, int max_atoms, int all_pairs, int steps, float lr, float* x_out, float* loss_out,
+                         float* rmsd_out, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Cross attention (RowAttentionBlock / Attention._attention, models/cross_att.py:118-134,
  * models/model_utils.py:21-38,96-133).  Ragged: no padding, so the -1e9 mask bias never applies.

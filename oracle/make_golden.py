@@ -456,6 +456,35 @@ def golden_stack_plus_grad(mods, name, sizes, hidden, layers, seed):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def golden_post_optim(name, seed):
+    """Ligand post-optimisation (FABind/fabind/utils/post_optim_utils.py:36-64) run by the reference itself: random-walk
+    ligands (1.5 A bonds, LAS = index distance <= 2 as in fabind_amd.synthetic), prediction = conformer + 0.6 A noise;
+    short horizon (5 epochs), the production horizon (1000 epochs) and the LAS-free variant."""
+    ref_mod = refshim.load_post_optim()
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(seed)
+    sizes = [12, 20, 25, 40]
+    save = {"sizes": np.array(sizes)}
+    for li, n in enumerate(sizes):
+        st = rng.normal(size=(n, 3))
+        st /= np.linalg.norm(st, axis=1, keepdims=True)
+        ref = np.cumsum(1.5 * st, 0).astype(np.float32)
+        idx = np.arange(n)
+        ii, jj = np.nonzero((np.abs(idx[:, None] - idx[None]) <= 2) & (idx[:, None] != idx[None]))
+        las = np.stack([ii, jj]).astype(np.int64)
+        pred = (ref + rng.normal(scale=0.6, size=ref.shape)).astype(np.float32)
+        save["ref_%d" % li], save["pred_%d" % li], save["las_%d" % li] = ref, pred, las
+        for ep in (5, 1000):
+            x, loss, rmsd = ref_mod.post_optimize_compound_coords(torch.from_numpy(ref), torch.from_numpy(pred), total_epoch=ep,
+                                                                  LAS_edge_index=torch.from_numpy(las))
+            save["x_%d_e%d" % (li, ep)], save["loss_%d_e%d" % (li, ep)], save["rmsd_%d_e%d" % (li, ep)] = _np(x), np.array(loss), np.array(rmsd)
+            print("%s ligand %d (%d atoms) epochs %d: loss %.4f rmsd %.4f" % (name, li, n, ep, loss, rmsd))
+        x, loss, rmsd = ref_mod.post_optimize_compound_coords(torch.from_numpy(ref), torch.from_numpy(pred), total_epoch=5,
+                                                              LAS_edge_index=None)
+        save["x_%d_nolas" % li], save["loss_%d_nolas" % li], save["rmsd_%d_nolas" % li] = _np(x), np.array(loss), np.array(rmsd)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def main_plus():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
@@ -471,6 +500,9 @@ def main_plus():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "plus":
         return main_plus()
+    if len(sys.argv) > 1 and sys.argv[1] == "post":
+        os.makedirs(OUT, exist_ok=True)
+        return golden_post_optim("post_optim", seed=21)
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
     mods = refshim.load_reference("FABind")

@@ -122,8 +122,15 @@ def to_dense_batch(x, batch=None, fill_value=0.0, max_num_nodes=None, batch_size
     return out, mask
 
 
-def to_dense_adj(*a, **k):  # name only: imported by egnn.py:14, never called on the production path
-    raise NotImplementedError
+def to_dense_adj(edge_index, batch=None, edge_attr=None, max_num_nodes=None):
+    """torch_geometric.utils.to_dense_adj for ONE graph (batch=None): [1, N, N] edge counts, N = max index + 1.  Imported
+    by egnn.py:14 (never called on the model path) and called by utils/post_optim_utils.py:40."""
+    if batch is not None or edge_attr is not None:
+        raise NotImplementedError
+    n = int(edge_index.max()) + 1 if max_num_nodes is None else max_num_nodes
+    adj = torch.zeros(1, n, n)
+    adj[0].index_put_((edge_index[0], edge_index[1]), torch.ones(edge_index.shape[1]), accumulate=True)
+    return adj
 
 
 # ----------------------------------------------------------------------------------------------
@@ -230,6 +237,18 @@ def load_reference(variant="FABind"):
     finally:
         sys.path.remove(root)
     return mods
+
+
+def load_post_optim(variant="FABind"):
+    """Import the reference's utils/post_optim_utils.py (torch-only arithmetic; rdkit is name-stubbed, file I/O unused)."""
+    root = os.path.join(REFERENCE_ROOT, variant, "fabind")
+    import torch._dynamo  # noqa: F401  (torch.optim pulls it in lazily; import it before the name-only stubs exist)
+    _install_stubs()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_post_optim_utils", os.path.join(root, "utils", "post_optim_utils.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def production_args(**over):

@@ -59,6 +59,41 @@ def test_edges_match_reference_sets():
     assert np.all(np.diff(mine_ctx[0]) >= 0)                         # row-sorted CSR
 
 
+def test_edges_at_the_cutoff_boundary_are_consistent():
+    """Regression: thousands of pair distances sit exactly on (or one ulp around) the inter / intra cut-offs.  The count
+    pass, the fill pass and both directions of an edge must take the same decision -- otherwise a CSR slot stays
+    uninitialised or an edge has no mirror (seen in FABind+ sampling as a device fault before the distance predicate was
+    compiled with floating-point contraction off)."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    B, P, C = 6, 400, 24
+    X, batch, seg = [], [], []
+    for b in range(B):
+        # lattice with spacing 0.4 (normalised units): (5,0,0), (3,4,0), ... x 0.4 = 2.0 = inter cut-off exactly,
+        # (4,0,0) x 0.4 = 1.6 = intra cut-off; plus offsets of a few ulps
+        lig = rng.integers(-3, 4, size=(C, 3)) * 0.4
+        prot = rng.integers(-6, 7, size=(P, 3)) * 0.4
+        x = np.concatenate([np.zeros((1, 3)), lig, np.zeros((1, 3)), prot]).astype(np.float32)
+        x = x * (1.0 + rng.integers(-2, 3, size=x.shape) * 6e-8).astype(np.float32) + np.float32(b * 0.1)
+        X.append(x); batch += [b] * len(x); seg += [0] * (C + 1) + [1] * (P + 1)
+    x = torch.from_numpy(np.concatenate(X)).to(dev)
+    lay = engine.Layout(torch.tensor(batch, device=dev), torch.tensor(seg, dtype=torch.float32, device=dev))
+    br = torch.zeros(0, dtype=torch.int32, device=dev)
+    gr = engine.Graph(lay, x, br, br, lay.ranges(br), 8.0 / 5.0, 10.0 / 5.0)
+    N = lay.N
+    for row, col, rp in ((gr.row_int, gr.col_int, gr.rp_int), (gr.row_ctx, gr.col_ctx, gr.rp_ctx)):
+        r, c = row.long(), col.long()
+        assert int(c.min()) >= 0 and int(c.max()) < N                       # every slot the count pass reserved is filled
+        owner = torch.repeat_interleave(torch.arange(N, device=dev), (rp[1:] - rp[:-1]).long())
+        assert torch.equal(owner, r)
+    r, c = gr.row_int.long(), gr.col_int.long()
+    assert torch.equal(torch.sort(r * N + c)[0], torch.sort(c * N + r)[0])   # every inter edge has its mirror
+    assert gr.E_int > 1000
+    m = gr.mirror.long()
+    assert torch.equal(r[m], c) and torch.equal(c[m], r)
+
+
 @pytest.mark.parametrize("name", STACKS)
 def test_stack_forward_fp32_matches_reference(name):
     """north_star gate: ligand coordinates within 1e-4 A RMSD of the reference CPU path (fp32 mode)."""

@@ -297,3 +297,24 @@ def test_plus_stack_gradients_match_reference():
         else:
             ref = g["grad_" + k]
             assert np.abs(v.grad.numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-7, k
+
+
+def test_post_optim_oracle_matches_reference():
+    """Ligand post-optimisation (post_optim_utils.py:36-64).  Short horizon: step-for-step agreement with the reference's
+    own run (its direct-cdist path, <= 25 atoms; the matmul-based cdist above 25 atoms is itself less exact).  Full horizon
+    (1000 Adam steps on a non-smooth objective, chaotic): the same loss / RMSD level."""
+    from oracle.post_optim_oracle import post_optimize_compound_coords as orc
+    g = load_npz("post_optim")
+    for li, n in enumerate(g["sizes"]):
+        ref, pred, las = g["ref_%d" % li], g["pred_%d" % li], g["las_%d" % li]
+        x, loss, r = orc(ref, pred, 5, las)
+        tol = 1e-5 if n <= 25 else 1e-3
+        assert np.abs(x - g["x_%d_e5" % li]).max() < tol
+        assert abs(loss - float(g["loss_%d_e5" % li])) <= 1e-3 * float(g["loss_%d_e5" % li])
+        assert abs(r - float(g["rmsd_%d_e5" % li])) < 1e-4
+        x, loss, r = orc(ref, pred, 5, None)
+        assert np.abs(x - g["x_%d_nolas" % li]).max() < tol
+    li = 0                                           # one full-horizon case keeps the CPU suite fast
+    x, loss, r = orc(g["ref_0"], g["pred_0"], 1000, g["las_0"])
+    assert abs(loss - float(g["loss_0_e1000"])) <= 0.03 * float(g["loss_0_e1000"])
+    assert abs(r - float(g["rmsd_0_e1000"])) < 0.05
