@@ -485,6 +485,64 @@ def golden_post_optim(name, seed):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def golden_eval_metrics(mods, name, seed):
+    """The reference's own evaluation loop (utils/utils.py:445-604) over three small batches.  The "model" handed to it
+    returns prepared 11-tuples (ligand poses at 0.3-6 A from the truth, random pocket logits incl. complexes with no
+    positive residue = the reference's skip branch), so every branch and threshold of the metric code is exercised; the
+    fixture holds those tuples, the data fields the loop reads and the metrics dict it returns."""
+    from argparse import Namespace
+    g = torch.Generator().manual_seed(seed)
+    args = refshim.production_args()
+    for k, v in dict(disable_tqdm=True, tqdm_interval=1.0, pair_distance_loss_weight=1.0, pair_distance_distill_loss_weight=1.0,
+                     pocket_cls_loss_weight=1.0, pocket_distance_loss_weight=0.05, coord_loss_weight=1.0).items():
+        setattr(args, k, v)
+    nn = torch.nn
+    crit = dict(com=nn.SmoothL1Loss(), pair=nn.MSELoss(), cls=nn.BCEWithLogitsLoss(reduction="mean"), cen=nn.HuberLoss(delta=3.0))
+    ev = mods["utils.utils"].evaluate_mean_pocket_cls_coord_multi_task
+    sizes = [[(60, 8), (75, 6), (50, 10), (40, 5)], [(66, 7), (58, 9), (45, 12)], [(52, 6), (70, 11), (64, 8), (48, 7)]]
+    save = {"n_batches": np.array(len(sizes)), "gs_tau": np.array(args.gs_tau)}
+    names = ["coords", "compound_batch", "y_pred", "y_pred_by_coords", "pocket_cls_pred", "pocket_cls",
+             "protein_out_mask_whole", "protein_coords_batched_whole", "pred_pocket_center", "dis_map"]
+    loader, outs = [], []
+    for bi, sz in enumerate(sizes):
+        b = synthetic.make_hetero_batch(sz, seed=seed + bi)
+        d = _hetero_to_ref(b)
+        B = len(sz)
+        d.pdb = ["c%d_%d" % (bi, i) for i in range(B)]
+        d.to = lambda device, _d=d: _d
+        cb, pb = b["compound"].batch, b["protein_whole"].batch
+        noise = torch.tensor([0.3, 1.5, 3.0, 6.0])[:B]
+        coords = b.coords + torch.randn(b.coords.shape, generator=g) * noise[cb][:, None] + torch.randn(B, 3, generator=g)[cb] * noise[cb][:, None]
+        L = torch.bincount(pb, minlength=B)
+        Lmax = int(L.max())
+        mask = torch.arange(Lmax)[None, :] < L[:, None]
+        logits = torch.randn(B, Lmax, generator=g) * 2.0 - 1.0
+        logits[B - 1] = -3.0 - torch.rand(Lmax, generator=g)                   # no positive residue: the skip branch
+        logits = logits * mask
+        pocket_cls = torch.zeros(B, Lmax, dtype=torch.long)
+        pocket_cls[pb, torch.arange(pb.shape[0]) - torch.cumsum(L, 0)[pb] + L[pb]] = b.pocket_idx.long()
+        xyz = torch.zeros(B, Lmax, 3)
+        xyz[pb, torch.arange(pb.shape[0]) - torch.cumsum(L, 0)[pb] + L[pb]] = b.node_xyz_whole.float()
+        dis_map = b.dis_map.float()
+        y_pred = (dis_map + torch.randn(dis_map.shape, generator=g)).clamp(0, 10)
+        y_by = (dis_map + 2.0 * torch.randn(dis_map.shape, generator=g)).clamp(0, 10)
+        center = b.coords_center + torch.randn(B, 3, generator=g) * 2.0
+        out = (coords, cb, y_pred, y_by, logits, pocket_cls, mask, xyz, center, dis_map, bi)
+        for n, o in zip(names, out[:10]):
+            save["b%d_%s" % (bi, n)] = _np(o)
+        save["b%d_keepNode_less_5" % bi] = np.array(bi)
+        save["b%d_data_coords" % bi], save["b%d_coords_center" % bi] = _np(b.coords), _np(b.coords_center)
+        loader.append(d)
+        outs.append(out)
+    it = iter(outs)
+    met = ev(Namespace(is_main_process=True), args, loader, lambda data, stage: next(it), crit["com"], crit["pair"], crit["cls"],
+             crit["cen"], 0.01, "cpu", pred_dis=True, stage=1)
+    for k, v in met.items():
+        save["metric::%s" % k] = np.array(float(v))
+    print(name, {k: round(float(v), 4) for k, v in met.items()})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def main_plus():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
@@ -500,6 +558,10 @@ def main_plus():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "plus":
         return main_plus()
+    if len(sys.argv) > 1 and sys.argv[1] == "eval":
+        os.makedirs(OUT, exist_ok=True)
+        torch.set_num_threads(1)
+        return golden_eval_metrics(refshim.load_reference("FABind"), "eval_metrics", seed=31)
     if len(sys.argv) > 1 and sys.argv[1] == "post":
         os.makedirs(OUT, exist_ok=True)
         return golden_post_optim("post_optim", seed=21)

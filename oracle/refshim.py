@@ -173,6 +173,16 @@ class FakeHeteroData:
         return self
 
 
+def _pearson_corrcoef(a, b):
+    a, b = a - a.mean(), b - b.mean()
+    return (a * b).sum() / (a.pow(2).sum().sqrt() * b.pow(2).sum().sqrt())
+
+
+def _mean_squared_error(a, b, squared=True):
+    m = (a - b).pow(2).mean()
+    return m if squared else m.sqrt()
+
+
 def _install_stubs():
     ts = types.ModuleType("torch_scatter")
     for n, f in dict(scatter_sum=scatter_sum, scatter_add=scatter_add, scatter_mean=scatter_mean,
@@ -214,6 +224,11 @@ def _install_stubs():
     tm.__getattr__ = lambda name: _Any  # type: ignore
     tm.functional = types.ModuleType("torchmetrics.functional")
     tm.functional.__getattr__ = lambda name: _Any  # type: ignore
+    # the three torchmetrics 0.x functionals the evaluation path calls (utils/metrics.py:62-77), restated from their
+    # published definitions: Pearson r = cov / (std std), RMSE (squared=False) / MSE, MAE
+    tm.functional.pearson_corrcoef = _pearson_corrcoef
+    tm.functional.mean_squared_error = _mean_squared_error
+    tm.functional.mean_absolute_error = lambda a, b: (a - b).abs().mean()
     sys.modules["torchmetrics.functional"] = tm.functional
 
 

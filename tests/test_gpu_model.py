@@ -109,3 +109,10 @@ def test_training_loop_reduces_the_loss():
     first, last = np.mean(losses[:5]), np.mean(losses[-5:])
     print("training sanity: loss %.4f -> %.4f" % (first, last))
     assert last < 0.8 * first, losses
+
+
+def test_eval_metrics_on_device_match_reference_loop():
+    """the evaluation metrics reduced on the GPU (one host sync per evaluation) equal the reference
+    loop's dictionary."""
+    from test_host_cpu import check_eval_metrics
+    check_eval_metrics(torch.device("cuda:0"))

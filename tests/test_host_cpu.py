@@ -122,3 +122,56 @@ def test_plus_refuses_cpu_and_training():
     z = torch.zeros(6, dtype=torch.long)
     with pytest.raises(RuntimeError):
         m(X, H, z, z.bool(), z.bool(), z.bool(), torch.zeros(2, 0, dtype=torch.long), torch.zeros(2, 0, dtype=torch.long), X)
+
+
+def _eval_fixture(device):
+    import numpy as np
+    import torch
+    from helpers import load_npz
+    g = load_npz("eval_metrics")
+    names = ["coords", "compound_batch", "y_pred", "y_pred_by_coords", "pocket_cls_pred", "pocket_cls",
+             "protein_out_mask_whole", "protein_coords_batched_whole", "pred_pocket_center", "dis_map"]
+    batches = []
+    for bi in range(int(g["n_batches"])):
+        out = tuple(torch.from_numpy(np.asarray(g["b%d_%s" % (bi, n)])).to(device) for n in names) + (int(g["b%d_keepNode_less_5" % bi]),)
+        batches.append((out, torch.from_numpy(g["b%d_data_coords" % bi]).to(device),
+                        torch.from_numpy(g["b%d_coords_center" % bi]).to(device)))
+    ref = {k.split("::", 1)[1]: float(v) for k, v in g.items() if k.startswith("metric::")}
+    return batches, ref, float(g["gs_tau"])
+
+
+def check_eval_metrics(device):
+    """fabind_amd.utils.metrics against the metrics dict the reference's own evaluation loop (utils/utils.py:445-604)
+    returned for the same per-batch model outputs (tests/golden/eval_metrics.npz, oracle/make_golden.py `eval`)."""
+    from argparse import Namespace
+    import torch
+    from fabind_amd.utils.metrics import Evaluator, evaluate_mean_pocket_cls_coord_multi_task
+    batches, ref, tau = _eval_fixture(device)
+    args = Namespace(pair_distance_loss_weight=1.0, pair_distance_distill_loss_weight=1.0, pocket_cls_loss_weight=1.0,
+                     pocket_distance_loss_weight=0.05, coord_loss_weight=1.0, gs_tau=tau)
+    nn = torch.nn
+    crit = (nn.SmoothL1Loss(), nn.MSELoss(), nn.BCEWithLogitsLoss(reduction="mean"), nn.HuberLoss(delta=3.0))
+    ev = Evaluator(args, *crit, pred_dis=True)
+    for out, coords, center in batches:
+        ev.update(out, coords, center)
+    got = ev.compute()
+    assert set(got) == set(ref)
+    for k, v in ref.items():
+        assert abs(got[k] - v) <= 2e-5 * max(1.0, abs(v)), (k, got[k], v)
+    assert got["skip_samples"] == 3 and got["samples"] == 11          # the fixture exercises the all-negative branch
+
+    class _D:                                                          # the reference's call signature, loader of batches
+        def __init__(self, c, z):
+            self.coords, self.coords_center = c, z
+
+        def to(self, device):
+            return self
+    it = iter([b[0] for b in batches])
+    got2 = evaluate_mean_pocket_cls_coord_multi_task(None, args, [_D(c, z) for _, c, z in batches], lambda data, stage: next(it),
+                                                     *crit, 0.01, device, pred_dis=True, stage=1)
+    assert got2 == got
+
+
+def test_eval_metrics_match_reference_loop():
+    import torch
+    check_eval_metrics(torch.device("cpu"))
