@@ -8,6 +8,7 @@ the last coord-MLP layers scaled up so that atoms really move -- SURVEY.md secti
 goldens") and seeded synthetic inputs (fabind_amd/synthetic.py) go in, and inputs + weights + outputs
 come out as small .npz fixtures.  Only data is written; no reference source is copied.
 """
+import math
 import os
 import sys
 
@@ -543,6 +544,48 @@ def golden_eval_metrics(mods, name, seed):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def golden_data_builder(mods, name, seed):
+    """The reference's per-sample HeteroData builder (utils/utils.py:202-442, production options) on random raw complexes:
+    the raw inputs and every field it emits, per sample (the test collates them).  Sample 2 has its ligand far from the
+    protein (< 5 residues in the pocket radius -> the first-100-residues fallback)."""
+    from argparse import Namespace
+    g = torch.Generator().manual_seed(seed)
+    args = Namespace(train_pred_pocket_noise=0.0, local_eval=False, train_ligand_torsion_noise=False, data_path=None)
+    build = mods["utils.utils"].construct_data_from_graph_gvp_mean
+    save = {"n": np.array(4)}
+    for i, (L, nc) in enumerate([(130, 9), (96, 14), (150, 6), (88, 11)]):
+        R = (3 * 135.0 * L / (4 * math.pi)) ** (1 / 3)
+        v = torch.randn(L, 3, generator=g)
+        prot = v / v.norm(dim=1, keepdim=True) * R * torch.rand(L, 1, generator=g) ** (1 / 3) + torch.tensor([12.0, -7.0, 3.0])
+        st = torch.randn(nc, 3, generator=g)
+        walk = torch.cumsum(1.5 * st / st.norm(dim=1, keepdim=True), 0)
+        centre = torch.tensor([12.0 + 0.4 * R, -7.0, 3.0]) if i != 2 else torch.tensor([12.0 + R + 45.0, -7.0, 3.0])
+        coords = (walk - walk.mean(0) + centre).numpy().astype(np.float64)
+        rdkit = (walk - walk.mean(0)) @ torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+        idx = torch.arange(nc)
+        bonds = torch.stack([torch.cat([idx[:-1], idx[1:]]), torch.cat([idx[1:], idx[:-1]])], 1)
+        bonds = torch.cat([bonds, torch.zeros(bonds.shape[0], 1, dtype=torch.long)], 1)          # [Eb, 3]: (i, j, bond type)
+        m = ((idx[:, None] - idx[None]).abs() <= 2) & (idx[:, None] != idx[None])
+        las = torch.nonzero(m).t().contiguous()
+        esm, cf = torch.randn(L, 16, generator=g), torch.randn(nc, 8, generator=g)
+        raw = dict(protein_node_xyz=prot, protein_esm2_feat=esm, coords=coords, compound_node_features=cf,
+                   input_atom_edge_list=bonds, LAS_edge_index=las, rdkit_coords=rdkit.numpy())
+        for k, v_ in raw.items():
+            save["raw%d_%s" % (i, k)] = _np(v_) if torch.is_tensor(v_) else np.asarray(v_)
+        data, _, _ = build(args, prot.clone(), "A" * L, coords.copy(), cf, bonds, None, las, rdkit.numpy().copy(), pdb_id="x%d" % i,
+                           group="test", protein_esm2_feat=esm)
+        for key, stt in data._stores.items():
+            kname = key if isinstance(key, str) else "|".join(key)
+            for k, v_ in stt.items():
+                if torch.is_tensor(v_):
+                    save["out%d_%s::%s" % (i, kname, k)] = _np(v_)
+        for k, v_ in data._glob.items():
+            if torch.is_tensor(v_):
+                save["out%d_::%s" % (i, k)] = _np(v_)
+        print(name, i, "pocket residues", int(data["pocket"].keepNode.sum()), "of", L)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def main_plus():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
@@ -562,6 +605,10 @@ def main():
         os.makedirs(OUT, exist_ok=True)
         torch.set_num_threads(1)
         return golden_eval_metrics(refshim.load_reference("FABind"), "eval_metrics", seed=31)
+    if len(sys.argv) > 1 and sys.argv[1] == "data":
+        os.makedirs(OUT, exist_ok=True)
+        torch.set_num_threads(1)
+        return golden_data_builder(refshim.load_reference("FABind"), "data_builder", seed=41)
     if len(sys.argv) > 1 and sys.argv[1] == "post":
         os.makedirs(OUT, exist_ok=True)
         return golden_post_optim("post_optim", seed=21)
