@@ -18,6 +18,42 @@ from .att_model import EfficientMCAttModel
 from .model_utils import MLP, MLP4Confidence
 
 
+def dbscan_labels(pts, valid, eps, min_samples):
+    """Batched DBSCAN with scikit-learn's labelling (sklearn.cluster.DBSCAN, euclidean): pts [B,S,3], valid [B,S] ->
+    labels [B,S] int64 (-1 = noise / padding).  sklearn's rule, restated: a point is core when >= min_samples points
+    (itself included) lie within eps; clusters are the connected components of core points, numbered by their smallest
+    core index; a non-core point within eps of core points joins the lowest-numbered such cluster (clusters are expanded
+    one after the other, the first to reach a border point keeps it).  Distances in float64 like sklearn's tree queries.
+    Components by min-label propagation with pointer jumping on the [S,S] adjacency (S = a few hundred residues)."""
+    B, S, _ = pts.shape
+    dev = pts.device
+    x = pts.double()
+    d2 = (x[:, :, None, :] - x[:, None, :, :]).pow(2).sum(-1)
+    adj = (d2 <= eps * eps) & valid[:, :, None] & valid[:, None, :]
+    core = (adj.sum(-1) >= min_samples) & valid
+    cadj = adj & core[:, :, None] & core[:, None, :]
+    BIG = S
+    idx = torch.arange(S, device=dev)
+    lab = torch.where(core, idx[None, :].expand(B, S), torch.full((B, S), BIG, device=dev))
+    while True:
+        for _ in range(4):
+            nb = torch.where(cadj, lab[:, None, :].expand(B, S, S), torch.full((), BIG, device=dev)).min(-1)[0]
+            new = torch.minimum(lab, nb)
+            new = torch.where(core, torch.gather(torch.cat([new, torch.full((B, 1), BIG, device=dev)], 1), 1, new), new)   # jump
+            changed = (new != lab).any()
+            lab = new
+        if not bool(changed):
+            break
+    # rank the component roots (root = smallest core index of the component) -> cluster numbers 0..k-1
+    is_root = core & (lab == idx[None, :])
+    rank = torch.cumsum(is_root.long(), 1) - 1
+    clus = torch.where(core, torch.gather(rank, 1, lab.clamp(max=S - 1)), torch.full((B, S), -1, device=dev))
+    # border points: the lowest-numbered cluster among the core points within eps
+    cand = torch.where(adj & core[:, None, :], clus[:, None, :].expand(B, S, S), torch.full((), BIG, device=dev)).min(-1)[0]
+    border = torch.where(cand < BIG, cand, torch.full((B, S), -1, device=dev))
+    return torch.where(core, clus, torch.where(valid, border, torch.full((B, S), -1, device=dev)))
+
+
 class FABindPlus(nn.Module):
     def __init__(self, args, embedding_channels=128, pocket_pred_embedding_channels=128):
         super().__init__()
@@ -66,26 +102,32 @@ class FABindPlus(nn.Module):
         return float(self.args.dropout) if self.training else 0.0
 
     def _cluster_centers(self, head, center):
-        """DBSCAN over the residues predicted to be pocket (host-side sklearn, like the reference: model.py:147-167);
-        consumes python's `random` exactly as the reference does (one randint + one random per complex)."""
+        """DBSCAN over the residues predicted to be pocket (reference: host-side scikit-learn per complex, model.py:147-167).
+        The clustering of ALL complexes runs on the device (`dbscan_labels`: same labels as sklearn, see its docstring);
+        python's `random` is consumed exactly as the reference does (one randint + one random per complex), which needs
+        one small read-back (the number of clusters per complex)."""
         import random
         prob = head['logits'].sigmoid()
         sel = prob > 0.5
         for i in (sel.sum(1) < 50).nonzero().flatten().tolist():                # rare: too few predicted pocket residues
             sel[i] = False
             sel[i, torch.argsort(prob[i])[-50:]] = True
-        sel_h, xyz_h = sel.cpu().numpy(), head['xyz'].detach().float().cpu().numpy()   # one download for the whole batch
-        B = center.shape[0]
-        picked = np.zeros((B, 3), dtype=np.float32)
-        use = np.zeros(B, dtype=bool)
+        B, dev = center.shape[0], center.device
+        n_sel = sel.sum(1)
+        S = int(n_sel.max())
+        order = torch.argsort((~sel).to(torch.int8), dim=1, stable=True)[:, :S]       # selected residues first, index order kept
+        valid = torch.arange(S, device=dev)[None, :] < n_sel[:, None]
+        pts = torch.gather(head['xyz'].detach().float(), 1, order[:, :, None].expand(-1, -1, 3))
+        labels = dbscan_labels(pts, valid, float(self.args.dbscan_eps), int(self.args.dbscan_min_samples))
+        n_clusters = (labels.max(1)[0] + 1).tolist()
+        cid, use = [], []
         for i in range(B):
-            pts = xyz_h[i][sel_h[i]]
-            clustering = self.dbscan_module.fit(pts)
-            cid = random.randint(0, clustering.labels_.max())
-            if random.random() < self.args.choose_cluster_prob:
-                picked[i], use[i] = pts[clustering.labels_ == cid].mean(axis=0), True
-        picked_d = torch.from_numpy(picked).to(center.device).to(center.dtype)
-        return torch.where(torch.from_numpy(use).to(center.device)[:, None], picked_d, center)
+            cid.append(random.randint(0, n_clusters[i] - 1))                    # ValueError without any cluster, like the reference
+            use.append(random.random() < self.args.choose_cluster_prob)
+        cid_d = torch.tensor(cid, device=dev)
+        member = (labels == cid_d[:, None]) & valid
+        picked = (member[:, :, None] * pts).sum(1) / member.sum(1, keepdim=True).clamp(min=1)
+        return torch.where(torch.tensor(use, device=dev)[:, None], picked.to(center.dtype), center)
 
     def _confidence(self, Ho, batch, B):
         pooled = torch.zeros(B, Ho.shape[1], dtype=torch.float32, device=Ho.device).index_add_(0, batch, Ho.float())

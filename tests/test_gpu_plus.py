@@ -325,3 +325,26 @@ def test_plus_training_loop_reduces_the_loss():
     first, last = np.mean(losses[:5]), np.mean(losses[-5:])
     print("FABind+ training sanity: loss %.4f -> %.4f" % (first, last))
     assert last < 0.8 * first, losses
+
+
+def test_device_dbscan_labels_equal_sklearn():
+    """`dbscan_labels` (the sampling mode's pocket-centre clustering, model.py:147-167 of FABind+) reproduces
+    scikit-learn's DBSCAN labels bit for bit: core rule, cluster numbering, border-point assignment, noise."""
+    from sklearn.cluster import DBSCAN
+    from fabind_amd.plus.models.model import dbscan_labels
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(1)
+    for trial in range(12):
+        B, S = 8, int(rng.integers(30, 400))
+        eps, ms = float(rng.choice([3.0, 6.0, 9.0])), int(rng.choice([2, 3, 5]))
+        n = rng.integers(5, S + 1, size=B)
+        pts = np.zeros((B, S, 3), np.float32)
+        for b in range(B):
+            k = int(rng.integers(1, 5))
+            cen = rng.normal(size=(k, 3)) * 14
+            pts[b, :n[b]] = (cen[rng.integers(0, k, size=n[b])] + rng.normal(size=(n[b], 3)) * rng.choice([2.0, 4.0])).astype(np.float32)
+        valid = torch.arange(S)[None] < torch.tensor(n)[:, None]
+        lab = dbscan_labels(torch.from_numpy(pts).to(dev), valid.to(dev), eps, ms).cpu().numpy()
+        for b in range(B):
+            ref = DBSCAN(eps=eps, min_samples=ms).fit(pts[b, :n[b]]).labels_
+            assert np.array_equal(ref, lab[b, :n[b]]) and (lab[b, n[b]:] == -1).all(), (trial, b)
