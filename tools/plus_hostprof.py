@@ -10,7 +10,7 @@ engine.set_precision("bf16")
 a = bench.stack_args(512, 5, 8)
 for k_, v_ in dict(use_ln_mlp=True, mlp_hidden_scale=1, dropout=0.1, mha_heads=4, rel_dis_pair_bias="no", inter_additional_mlp=False,
                    only_last_LAS=False, geom_reg_steps=1, use_for_radius_pred="ligand", dis_map_thres=15.0, pocket_radius_buffer=5.0,
-                   min_pocket_radius=20.0, force_fix_radius=False, use_clustering=False, confidence_training=False).items():
+                   min_pocket_radius=20.0, force_fix_radius=False, use_clustering=True, dbscan_eps=9.0, dbscan_min_samples=2, choose_cluster_prob=0.5, confidence_training=False).items():
     setattr(a, k_, v_)
 class L:
     def log_message(self, m): pass
