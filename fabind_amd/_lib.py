@@ -21,7 +21,8 @@ class GemmArgs(ctypes.Structure):
                [(n, _i) for n in ("M", "N", "K", "K1", "lda", "lda2", "ldw", "ldc", "ldr", "ldaux", "dot_ld",
                                   "a_dtype", "w_dtype", "c_dtype", "aux_dtype", "act_pro", "act_epi", "dact_epi",
                                   "accumulate", "store_preact", "n_groups", "max_m", "max_n", "groups_ext", "epi_fast", "k_splits")] + \
-               [("alpha", _f), ("p_drop", _f), ("drop_seed", ctypes.c_uint)]
+               [("alpha", _f), ("p_drop", _f), ("drop_seed", ctypes.c_uint)] + \
+               [(n, _vp) for n in ("row_mu", "row_rs", "col_c")]
 
 
 class EdgeBwdArgs(ctypes.Structure):
@@ -55,6 +56,7 @@ SIGNATURES = {
     "fabind_pair_update_fused": [ctypes.POINTER(PairUpdateArgs), _i, _vp],
     "fabind_gcl_edge_fused_bwd_set_tile": [_i],
     "fabind_gcl_edge_fused_bwd_tile": [],
+    "fabind_row_stats": [_vp, _i, _i, _f, _i, _i, _vp, _vp, _vp],
     "fabind_layernorm_rows": [_vp, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _i, _i, _vp],
     "fabind_edge_ln_concat": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _i, _i, _vp],
     "fabind_edge_lnfold": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp, _f, ctypes.c_uint, _vp],

@@ -221,6 +221,13 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
     }
     const uint32_t drop_thr = (uint32_t)(p.p_drop * 65536.0f + 0.5f);
     const float drop_scale = 1.0f / (1.0f - (float)drop_thr / 65536.0f);
+    const bool fold = p.row_mu != nullptr;
+    float cv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + fr;
+        cv[j] = (fold && col < N) ? p.col_c[col] : 0.f;
+    }
     if (HAS_C2) {                          // derivative tile first (uses the staging buffer), then the value tile
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -240,7 +247,12 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float vp = acc[i][j][r] + bv[j];
+                float vp = acc[i][j][r];
+                if (fold) {            // uniform branch: LayerNorm of the A rows folded into the epilogue
+                    const int rl = min(m0 + wm * 64 + i * 16 + cq * 4 + r, M - 1);
+                    vp = p.row_rs[rl] * (vp - p.row_mu[rl] * cv[j]);
+                }
+                vp += bv[j];
                 if (HAS_RG) {          // + residual row gathered through r_index (adjoint of a segment-sum consumer)
                     const int rowg = m0 + wm * 64 + i * 16 + cq * 4 + r, colg = n0 + wn * 64 + j * 16 + fr;
                     if (rowg < M && colg < N) vp += ((const float*)p.R)[(size_t)p.r_index[rowg] * p.ldr + colg];
@@ -990,6 +1002,8 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     FB_REQUIRE(!(p.w_dtype == FB_DT_BF16 && (p.ldw % 8 != 0)), "fabind_gemm: bf16 W needs ldw % 8 == 0");
     p.epi_fast = 0;
     FB_REQUIRE(p.p_drop >= 0.f && p.p_drop < 1.f, "fabind_gemm: p_drop in [0, 1)");
+    const bool foldq = p.row_mu != nullptr;
+    FB_REQUIRE(!foldq || (p.row_rs != nullptr && p.col_c != nullptr), "fabind_gemm: row_mu needs row_rs and col_c");
     const bool drop = p.p_drop > 0.f;    /* dropout: generic epilogue, or the fast ones without a second / pre-activation tile */
     if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && !p.r_index && p.C != nullptr &&
         p.c_dtype == FB_DT_F32 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
@@ -1012,6 +1026,9 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
         else if (p.act_epi == FB_ACT_SILU && hc && !hc2 && hd && pre) p.epi_fast = 7;
         else if (p.act_epi == FB_ACT_RELU && hc && !hc2 && hd && pre) p.epi_fast = 8;
     }
+    FB_REQUIRE(!foldq || (p.epi_fast >= 1 && p.epi_fast <= 8 && p.epi_fast != 3 && p.C2 == nullptr && p.a_dtype == FB_DT_BF16 &&
+                          p.w_dtype == FB_DT_BF16 && p.K % 64 == 0),
+               "fabind_gemm: the row_mu / row_rs fold needs a staged bf16 epilogue (no residual / second tile / split-K)");
     int maxM = p.groups ? p.max_m : p.M, maxN = p.groups ? p.max_n : p.N;
     if (maxM <= 0 || maxN <= 0) return 0;
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, p.groups ? p.n_groups : (p.k_splits > 1 ? p.k_splits : 1));

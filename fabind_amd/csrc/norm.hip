@@ -130,6 +130,73 @@ extern "C" int fabind_layernorm_rows(const void* x, int x_dt, int ldx, const flo
     return 0;
 }
 
+// Row statistics only (mean, rsqrt(centred variance + eps)): the read half of layernorm_rows, for GEMMs that fold the
+// normalisation into their epilogue (FabindGemmArgs.row_mu / row_rs).  One wave per row.  bf16 rows with C % 8 == 0 and
+// C <= 2048 are read ONCE with 16-B loads and kept in registers for the centred second moment; other shapes take the
+// element-wise two-pass loop.
+template <int NCH>
+__global__ __launch_bounds__(256) void row_stats_bf16_kernel(const bf16_t* __restrict__ x, int ldx, float eps, int R, int C,
+                                                             float* __restrict__ mu, float* __restrict__ rs) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const bf16_t* xr = x + (size_t)r * ldx;
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c0 = (k * 64 + lane) * 8;
+        uint4 u = make_uint4(0u, 0u, 0u, 0u);
+        if (c0 < C) u = *(const uint4*)(xr + c0);
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            v[k][q] = __uint_as_float((q & 1) ? (w[q >> 1] & 0xffff0000u) : (w[q >> 1] << 16));
+            s += v[k][q];
+        }
+    }
+    const float m = wave_sum(s) / (float)C;
+    float qq = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        if ((k * 64 + lane) * 8 < C) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const float t = v[k][q] - m; qq += t * t; }
+        }
+    }
+    qq = wave_sum(qq);
+    if (lane == 0) { mu[r] = m; rs[r] = rsqrtf(qq / (float)C + eps); }
+}
+__global__ __launch_bounds__(256) void row_stats_kernel(const void* __restrict__ x, int x_dt, int ldx, float eps, int R, int C,
+                                                        float* __restrict__ mu, float* __restrict__ rs) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const size_t xo = (size_t)r * ldx;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += ld_any(x, x_dt, xo + c);
+    const float m = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float t = ld_any(x, x_dt, xo + c) - m; q += t * t; }
+    q = wave_sum(q);
+    if (lane == 0) { mu[r] = m; rs[r] = rsqrtf(q / (float)C + eps); }
+}
+extern "C" int fabind_row_stats(const void* x, int x_dt, int ldx, float eps, int R, int C, float* mu, float* rs,
+                                hipStream_t stream) {
+    if (R <= 0) return 0;
+    if (x_dt == FB_DT_BF16 && C % 8 == 0 && ldx % 8 == 0 && C <= 2048 && (((uintptr_t)x) & 15) == 0) {
+        const dim3 grid((R + 3) / 4);
+        if (C <= 512) hipLaunchKernelGGL(row_stats_bf16_kernel<1>, grid, dim3(256), 0, stream, (const bf16_t*)x, ldx, eps, R, C, mu, rs);
+        else if (C <= 1024) hipLaunchKernelGGL(row_stats_bf16_kernel<2>, grid, dim3(256), 0, stream, (const bf16_t*)x, ldx, eps, R, C, mu, rs);
+        else hipLaunchKernelGGL(row_stats_bf16_kernel<4>, grid, dim3(256), 0, stream, (const bf16_t*)x, ldx, eps, R, C, mu, rs);
+        FB_CHECK_LAUNCH();
+        return 0;
+    }
+    hipLaunchKernelGGL(row_stats_kernel, dim3((R + 3) / 4), dim3(256), 0, stream, x, x_dt, ldx, eps, R, C, mu, rs);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
 // LayerNorm of the concatenated edge input of MC_E_GCL, [h[row] | h[col] | rhohat] (2H+1 columns,
 // FABind_plus/fabind/models/egnn.py:52-58 + model_utils.py:44-46), evaluated while gathering: the concatenation is
 // never written un-normalised.  One wave per edge; output columns [2H+1, pad_to) are zero.

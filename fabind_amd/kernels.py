@@ -301,6 +301,16 @@ def inter_coord_fold(P16, H, col, rho, stat, q_w, eps, u, d, w3, p_drop=0.0, see
     return out[:E]
 
 
+def row_stats(x, eps):
+    """(mean, rsqrt(var + eps)) per row of x [R,C] (csrc/norm.hip: row_stats_kernel) -> two fp32 [R]."""
+    R, C = x.shape
+    mu = torch.empty(max(R, 1), dtype=torch.float32, device=x.device)
+    rs = torch.empty(max(R, 1), dtype=torch.float32, device=x.device)
+    check(_lib.load().fabind_row_stats(ptr(x), dt_code(x.dtype), _ld(x), float(eps), R, C, ptr(mu), ptr(rs), stream()),
+          "fabind_row_stats")
+    return mu, rs
+
+
 def pair_update_fused(T, b_off, p_node, c_node, z, Wop, bo, ln_w, ln_b, eps, W1p, b1, W2p, b2, Wbp=None, bb=None, p_drop=0.0,
                       seed=0):
     """FABind+ pair update for a ragged pair list (csrc/pair_fused.hip): z [pairs,H] bf16 -> (z' bf16, bias' [pairs,16] fp32

@@ -194,8 +194,9 @@ def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, 
 # ------------------------------------------------------------------------------------------------
 # linear + row-dot:  s_part[m, t] = sum_{n in tile t} act_epi(act_pro(x) W^T + b)[m,n] * u[n]
 # ------------------------------------------------------------------------------------------------
-def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store, p_drop=0.0, seed=0):
-    """GEMM with row-dot epilogue; store=True keeps the pre-activation matrix (training)."""
+def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store, p_drop=0.0, seed=0, fold=None):
+    """GEMM with row-dot epilogue; store=True keeps the pre-activation matrix (training).  fold = (row_mu, row_rs, col_c):
+    LayerNorm of the rows of x folded into the epilogue (inference)."""
     M, Kd = x.shape
     N = W.shape[0]
     nt = (N + K.GEMM_BN - 1) // K.GEMM_BN
@@ -208,6 +209,9 @@ def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store, p_drop=0.0, seed=0):
     a.a_dtype, a.w_dtype, a.c_dtype = dt_code(x.dtype), dt_code(W.dtype), dt_code(z.dtype) if store else 0
     a.act_pro, a.act_epi, a.store_preact, a.alpha = act_pro, act_epi, 1, 1.0
     a.p_drop, a.drop_seed = float(p_drop), int(seed) & 0xFFFFFFFF
+    if fold is not None:
+        a.store_preact = 0
+        a.row_mu, a.row_rs, a.col_c = ptr(fold[0]), ptr(fold[1]), ptr(fold[2])
     label = "fabind_gemm <%s,%s> M=%d N=%d K=%d" % (str(x.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""), M, N, Kd)
     K._profiled(label, 2.0 * M * N * Kd, lambda: check(load().fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm(rowdot)"))
     return z, part
@@ -240,13 +244,14 @@ class _LinearRowdot(torch.autograd.Function):
         return dx, dW, db, du, None, None
 
 
-def linear_rowdot(x, W, b, u, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, p_drop=0.0):
-    """p_drop > 0 (no-grad paths only): dropout on act(x W^T + b) before the row-dot with u, inside the epilogue."""
+def linear_rowdot(x, W, b, u, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, p_drop=0.0, fold=None):
+    """p_drop > 0 (no-grad paths only): dropout on act(x W^T + b) before the row-dot with u, inside the epilogue.
+    fold = (row_mu, row_rs, col_c) (no-grad, bf16 x): LayerNorm of x's rows folded into the epilogue."""
     if _needs_grad(x, W, b, u):
-        assert p_drop == 0.0, "epilogue dropout has no autograd path yet"
+        assert p_drop == 0.0 and fold is None, "epilogue dropout / LayerNorm fold have no autograd path"
         return _LinearRowdot.apply(x, W, b, u, act_pro, act_epi)
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
-    return _gemm_rowdot(x, W, b, u, act_pro, act_epi, store=False, p_drop=p_drop, seed=seed)[1]
+    return _gemm_rowdot(x, W, b, u, act_pro, act_epi, store=False, p_drop=p_drop, seed=seed, fold=fold)[1]
 
 
 # ------------------------------------------------------------------------------------------------

@@ -88,6 +88,12 @@ def _build_stack_params(model):
     def gcl(m):
         d = dict(edge=_mlp(m.edge_mlp, W, K8, K8), node=_mlp(m.node_mlp, W), coord=_mlp(m.coord_mlp, W))
         d["coord"]["w3"] = m.coord_mlp.linear2.weight[0].float().contiguous()
+        if wd == torch.bfloat16 and infer and H % 64 == 0:
+            # coord_mlp on the messages: LayerNorm folded into the GEMM epilogue (FabindGemmArgs.row_mu / row_rs / col_c)
+            cm = m.coord_mlp
+            Wc = cm.linear1.weight.float() * cm.layernorm.weight.float()[None, :]
+            d["coord"]["foldp"] = dict(W1w=W(Wc), cvec=Wc.to(wd).float().sum(1).contiguous(), eps=float(cm.layernorm.eps),
+                                       dvec=(cm.linear1.weight.float() @ cm.layernorm.bias.float() + cm.linear1.bias.float()).contiguous())
         if wd == torch.bfloat16 and infer:
             # LayerNorm folded into per-node projections of the first edge Linear (csrc/norm.hip: edge_lnfold_kernel)
             em = m.edge_mlp
@@ -336,6 +342,11 @@ def _coord_scalar(c, v, pd):
     """MLPwoBias coord_mlp on per-edge rows v [E,H] -> per-edge scalar partials [E, nt]: LN -> linear1 -> relu ->
     [dropout] -> bias-free linear2 as the row-dot of the GEMM epilogue."""
     ad = ops.act_dtype()
+    fp = c.get("foldp")
+    if FOLD_EDGE_LN and fp is not None and v.dtype == torch.bfloat16 and not ops.needs_grad(v, c["W1"], c["w3"]):
+        # inference: the GEMM runs on the un-normalised messages, the epilogue applies rs * (acc - mu * cvec) + dvec
+        mu, rs = K.row_stats(v, fp["eps"])
+        return ops.linear_rowdot(v, fp["W1w"], fp["dvec"], c["w3"], act_epi=K.ACT_RELU, p_drop=pd, fold=(mu, rs, fp["cvec"]))
     yc = ln_rows(v, c["ln_w"], c["ln_b"], ad, c["k_pad"])
     if pd > 0.0 and ops.needs_grad(yc, c["W1"], c["w3"]):
         tc = _drop(ops.linear(yc, c["W1"], c["b1"], act_epi=K.ACT_RELU), pd)

@@ -67,6 +67,10 @@ typedef struct FabindGemmArgs {
     float p_drop;       /* > 0: epilogue dropout (train / sampling mode): after bias + activation, before the residual, the value is
                            multiplied by keep/(1-p) with keep = [hash32(drop_seed + row*N + col) & 0xffff >= round(p*65536)] */
     unsigned drop_seed;
+    /* optional LayerNorm fold (fast epilogues without residual / second tile only): the accumulator of row r, column c becomes
+       row_rs[r] * (acc - row_mu[r] * col_c[c]) before bias / activation -- i.e. LN(A) W^T evaluated as a GEMM on the
+       UN-normalised A with W pre-scaled by the LN weight, col_c = its row sums, bias = W ln_b + b */
+    const float* row_mu; const float* row_rs; const float* col_c;
 } FabindGemmArgs;
 
 int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream);
@@ -263,6 +267,10 @@ int fabind_select_rows(const float* x, const float* z, const uint8_t* mask, int 
 
 /* LayerNorm over the last dim (models/model.py:15,29): y = (x-mean)*rstd*w + b; backward returns dx and
  * per-block partial sums of dw/db ([ceil(R/4), C] each, reduce with fabind_colsum). */
+/* Per-row LayerNorm statistics without writing the normalised rows: mu[r] = mean, rs[r] = rsqrt(centred variance + eps)
+ * of x[r, 0:C] (two passes over registers, like fabind_layernorm_rows).  Feeds the row_mu / row_rs fold of fabind_gemm. */
+int fabind_row_stats(const void* x, int x_dt, int ldx, float eps, int R, int C, float* mu, float* rs, hipStream_t stream);
+
 /* FABind+ LN-MLPs (FABind_plus/fabind/models/model_utils.py:10-74).  fabind_layernorm_rows: row LayerNorm with free
  * input / output dtypes (FB_DT_*) and strides; output columns [C, pad_to) are zero-filled (GEMM K padding).
  * fabind_edge_ln_concat: LayerNorm over the concatenated edge input [h[row] | h[col] | rhohat] (2H+1 columns,

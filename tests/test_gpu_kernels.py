@@ -452,3 +452,35 @@ def test_inter_coord_fold_matches_layernorm_mlp(H, E, p_drop):
     ref = act @ w3
     assert (s - ref).abs().max() <= 3e-2 * max(1.0, float(ref.abs().max()))
     assert (s - ref).abs().mean() <= 5e-3 * max(1.0, float(ref.abs().mean()))
+
+
+@pytest.mark.parametrize("M,N,Kd,p_drop", [(3000, 512, 512, 0.0), (777, 256, 128, 0.0), (2048, 512, 512, 0.2)])
+def test_gemm_layernorm_fold_epilogue(M, N, Kd, p_drop):
+    """FabindGemmArgs.row_mu / row_rs / col_c: w3 . relu(W1 LN(x) + b1) evaluated as a GEMM on the un-normalised bf16 rows
+    with the LayerNorm folded into the epilogue equals LayerNorm -> Linear -> relu -> dot (FABind+ coord_mlp on the
+    messages, egnn.py:104-118); fabind_row_stats gives the row statistics."""
+    from fabind_amd import kernels as K, ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, Kd, generator=g).abs() * 1.3 + 0.5).bfloat16()            # post-relu-like rows: large positive mean
+    lw, lb = torch.rand(Kd, generator=g) + 0.5, torch.randn(Kd, generator=g) * 0.2
+    W1, b1, w3 = torch.randn(N, Kd, generator=g) / Kd ** 0.5, torch.randn(N, generator=g) * 0.3, torch.randn(N, generator=g)
+    xf = x.float()
+    mu_ref, var = xf.mean(1), xf.var(1, unbiased=False)
+    W1w = (W1 * lw[None, :]).bfloat16()
+    cvec = W1w.float().sum(1)
+    act = torch.relu(((xf - mu_ref[:, None]) * torch.rsqrt(var + 1e-5)[:, None]) @ W1w.float().T + (W1 @ lb + b1))
+    d = lambda t: t.to(dev)
+    mu, rs = K.row_stats(d(x), 1e-5)
+    assert (mu.cpu() - mu_ref).abs().max() < 1e-5 and (rs.cpu() - torch.rsqrt(var + 1e-5)).abs().max() < 1e-4
+    import torch as _t
+    _t.manual_seed(3)
+    part = ops.linear_rowdot(d(x), d(W1w), d(W1 @ lb + b1), d(w3), act_epi=K.ACT_RELU, p_drop=p_drop, fold=(mu, rs, d(cvec)))
+    s = part.sum(1).cpu()
+    if p_drop == 0.0:
+        ref = act @ w3
+        assert (s - ref).abs().max() <= 3e-2 * max(1.0, float(ref.abs().max()))
+        assert (s - ref).abs().mean() <= 3e-3 * max(1.0, float(ref.abs().mean()))
+    else:                                   # mask drawn inside the epilogue: statistics only
+        ref = act @ w3
+        assert abs(float(s.mean()) - float(ref.mean())) < 0.15 * float(ref.std()) and torch.isfinite(s).all()
