@@ -10,6 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfabind_hip.so")
 
+ABI_VERSION = 2          # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -110,6 +111,16 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.fabind_last_error.restype = ctypes.c_char_p
     lib.fabind_abi_version.restype = ctypes.c_int
+    got = lib.fabind_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError("fabind_amd: %s has ABI version %d, this binding needs %d -- rebuild with `python -m fabind_amd.build`"
+                           % (LIB_PATH, got, ABI_VERSION))
+    lib.fabind_sizeof_args.argtypes, lib.fabind_sizeof_args.restype = [ctypes.c_int], ctypes.c_int
+    for which, mirror in enumerate((GemmArgs, EdgeBwdArgs, PairUpdateArgs)):
+        if lib.fabind_sizeof_args(which) != ctypes.sizeof(mirror):
+            raise RuntimeError("fabind_amd: ctypes mirror %s is %d bytes, the library's struct is %d -- _lib.py and "
+                               "include/fabind_hip.h disagree" % (mirror.__name__, ctypes.sizeof(mirror),
+                                                                  lib.fabind_sizeof_args(which)))
     lib.fabind_gemm_set_config.argtypes = [ctypes.c_int]
     lib.fabind_gemm_set_config.restype = None
     lib.fabind_gemm_set_persistent.argtypes = [ctypes.c_int]

@@ -10,4 +10,12 @@ extern "C" void fabind_set_error(const char* msg) {
     g_err[sizeof(g_err) - 1] = 0;
 }
 extern "C" const char* fabind_last_error(void) { return g_err; }
-extern "C" int fabind_abi_version(void) { return 1; }
+extern "C" int fabind_abi_version(void) { return FABIND_ABI_VERSION; }
+extern "C" int fabind_sizeof_args(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(FabindGemmArgs);
+        case 1: return (int)sizeof(FabindEdgeBwdArgs);
+        case 2: return (int)sizeof(FabindPairUpdateArgs);
+        default: return -1;
+    }
+}

@@ -26,7 +26,14 @@ typedef struct ihipStream_t* hipStream_t;
 #endif
 
 const char* fabind_last_error(void);
+/* Bumped whenever an entry point's signature or an argument struct's layout changes.  History: 1 = first round-1 layout;
+ * 2 = FabindGemmArgs grew {p_drop, drop_seed, row_mu, row_rs, col_c}, FabindEdgeBwdArgs / FabindPairUpdateArgs added.
+ * A binding must refuse a library whose version differs from the header it was written against. */
+#define FABIND_ABI_VERSION 2
 int fabind_abi_version(void);
+/* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
+ * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
+int fabind_sizeof_args(int which);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense contractions.  Replaces every nn.Linear / torch.cat+Linear / einsum+Linear on the path:

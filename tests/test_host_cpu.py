@@ -48,7 +48,13 @@ def test_production_model_has_394_keys_and_36M_parameters():
 def test_library_exports_every_declared_symbol():
     from fabind_amd import _lib
     lib = _lib.load()                                        # loads without a GPU (HIP initialises lazily)
-    assert lib.fabind_abi_version() == 1
+    from fabind_amd import _lib as L
+    import ctypes
+    assert lib.fabind_abi_version() == L.ABI_VERSION == 2
+    # the ctypes mirrors have the library's struct sizes (load() refuses a mismatch; checked again here explicitly)
+    for which, mirror in enumerate((L.GemmArgs, L.EdgeBwdArgs, L.PairUpdateArgs)):
+        assert lib.fabind_sizeof_args(which) == ctypes.sizeof(mirror)
+    assert lib.fabind_sizeof_args(99) == -1
     hdr = open(os.path.join(ROOT, "include", "fabind_hip.h")).read()
     names = set(re.findall(r"\b(fabind_[a-z0-9_]+)\s*\(", hdr))
     assert len(names) >= 30
