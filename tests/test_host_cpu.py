@@ -181,3 +181,44 @@ def check_eval_metrics(device):
 def test_eval_metrics_match_reference_loop():
     import torch
     check_eval_metrics(torch.device("cpu"))
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every `int fabind_*(...)` prototype of include/fabind_hip.h against fabind_amd._lib.SIGNATURES: same entry points,
+    same parameter count, and pointer / int / float kinds in the same positions (ctypes itself cannot detect a binding
+    that passes fewer or differently typed arguments than the C side reads)."""
+    import ctypes
+    import os
+    import re
+    from fabind_amd import _lib as L
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fabind_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    protos = dict(re.findall(r"\bint\s+(fabind_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S))
+    special = {"fabind_abi_version", "fabind_sizeof_args", "fabind_gemm_set_config", "fabind_gemm_set_persistent"}
+    assert set(protos) - special == set(L.SIGNATURES), (sorted(set(protos) - special - set(L.SIGNATURES)),
+                                                         sorted(set(L.SIGNATURES) - set(protos)))
+
+    def kind_c(param):
+        p = param.strip()
+        if p == "void" or p == "":
+            return None
+        if "*" in p or "hipStream_t" in p:
+            return "ptr"
+        if re.match(r"(const\s+)?float\b", p):
+            return "float"
+        if re.match(r"(const\s+)?(unsigned|int|long)\b", p):
+            return "int"
+        raise AssertionError("unparsed parameter: %r" % p)
+
+    def kind_py(t):
+        if t in (ctypes.c_void_p,) or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+            return "ptr"
+        if t is ctypes.c_float:
+            return "float"
+        if t in (ctypes.c_int, ctypes.c_long, ctypes.c_uint):
+            return "int"
+        raise AssertionError("unexpected ctypes type %r" % (t,))
+    for name, argt in L.SIGNATURES.items():
+        want = [k for k in (kind_c(p) for p in protos[name].split(",")) if k is not None]
+        got = [kind_py(t) for t in argt]
+        assert got == want, (name, got, want)
