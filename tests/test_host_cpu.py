@@ -120,7 +120,7 @@ def test_plus_production_stack_parameter_count():
     assert sum(p.numel() for p in m.parameters()) == 42507437
 
 
-def test_plus_refuses_cpu_and_training():
+def test_plus_stack_refuses_cpu_tensors():
     from fabind_amd.plus.models.att_model import EfficientMCAttModel
     m = EfficientMCAttModel(_plus_args(32, 32, 1, 1), 32, 32, 1, n_layers=1, n_iter=1, normalize_coord=lambda x: x / 5.0,
                             unnormalize_coord=lambda x: x * 5.0).eval()
@@ -222,3 +222,41 @@ def test_ctypes_signatures_match_the_header_prototypes():
         want = [k for k in (kind_c(p) for p in protos[name].split(",")) if k is not None]
         got = [kind_py(t) for t in argt]
         assert got == want, (name, got, want)
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: no module of the shipped package may import, name or locate anything under
+    oracle/ (a product path routed through the CPU restatement would void every parity claim)."""
+    import ast
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fabind_amd")
+    checked = 0
+    for dirpath, _, files in os.walk(root):
+        for f in files:
+            if not f.endswith(".py"):
+                continue
+            path = os.path.join(dirpath, f)
+            src = open(path).read()
+            assert "oracle" not in src.lower(), path
+            for node in ast.walk(ast.parse(src)):
+                names = []
+                if isinstance(node, ast.Import):
+                    names = [a.name for a in node.names]
+                elif isinstance(node, ast.ImportFrom):
+                    names = [node.module or ""]
+                assert not any(n.split(".")[0] in ("oracle", "refshim", "make_golden") for n in names), (path, names)
+            checked += 1
+    assert checked >= 20
+
+
+def test_missing_library_fails_loudly():
+    """No fallback: without libfabind_hip.so the binding raises and says how to build it."""
+    from fabind_amd import _lib as L
+    saved = (L.LIB_PATH, L._lib)
+    try:
+        L.LIB_PATH, L._lib = os.path.join(os.path.dirname(saved[0]), "no_such_library.so"), None
+        with pytest.raises(RuntimeError, match="fabind_amd.build"):
+            L.load()
+    finally:
+        L.LIB_PATH, L._lib = saved
+    assert L.load() is not None
