@@ -260,3 +260,10 @@ def test_missing_library_fails_loudly():
     finally:
         L.LIB_PATH, L._lib = saved
     assert L.load() is not None
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" entry point: compiles (incrementally here) every HIP source, loads the library and
+    imports the package -- exercised in the CPU suite so that a stale hard-coded check in it cannot go unnoticed again."""
+    import __graft_entry__ as g
+    g.build()
