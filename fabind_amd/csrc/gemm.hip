@@ -190,7 +190,9 @@ template <int ACT> __device__ __forceinline__ float fast_dact(float x) {
     return 1.f;
 }
 
-template <int BM_, int ACT, bool HAS_C, bool HAS_C2, bool HAS_DOT, bool RAW_BARRIER, bool STORE_PRE = false, bool HAS_RG = false>
+template <int BM_, int ACT, bool HAS_C, bool HAS_C2, bool HAS_DOT, bool RAW_BARRIER, bool STORE_PRE = false, bool HAS_RG = false,
+          bool FOLD = false>   // FOLD: LayerNorm of the A rows folded in (row_mu / row_rs / col_c); its own dispatch codes, so
+                               // every other GEMM keeps the un-folded instruction stream
 __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sDot, bf16_t* sOut,
                                                    int M, int N, int ldc, int m0, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -221,12 +223,13 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
     }
     const uint32_t drop_thr = (uint32_t)(p.p_drop * 65536.0f + 0.5f);
     const float drop_scale = 1.0f / (1.0f - (float)drop_thr / 65536.0f);
-    const bool fold = p.row_mu != nullptr;
-    float cv[4];
+    float cv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (FOLD) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn * 64 + j * 16 + fr;
-        cv[j] = (fold && col < N) ? p.col_c[col] : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 64 + j * 16 + fr;
+            cv[j] = col < N ? p.col_c[col] : 0.f;
+        }
     }
     if (HAS_C2) {                          // derivative tile first (uses the staging buffer), then the value tile
 #pragma unroll
@@ -248,7 +251,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float vp = acc[i][j][r];
-                if (fold) {            // uniform branch: LayerNorm of the A rows folded into the epilogue
+                if (FOLD) {            // compile-time: LayerNorm of the A rows folded into the epilogue
                     const int rl = min(m0 + wm * 64 + i * 16 + cq * 4 + r, M - 1);
                     vp = p.row_rs[rl] * (vp - p.row_mu[rl] * cv[j]);
                 }
@@ -366,6 +369,8 @@ __device__ __forceinline__ bool gemm_epilogue_dispatch(const FabindGemmArgs& p, 
         case 7: gemm_epilogue_fast<BM_, FB_ACT_SILU, true, false, true, RAW_BARRIER, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 8: gemm_epilogue_fast<BM_, FB_ACT_RELU, true, false, true, RAW_BARRIER, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 11: gemm_epilogue_fast<BM_, FB_ACT_NONE, true, false, false, RAW_BARRIER, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
+        case 12: gemm_epilogue_fast<BM_, FB_ACT_RELU, true, false, false, RAW_BARRIER, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
+        case 13: gemm_epilogue_fast<BM_, FB_ACT_RELU, false, false, true, RAW_BARRIER, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 9: gemm_epilogue_f32<BM_, false>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0); return true;
         case 10: gemm_epilogue_f32<BM_, true>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0); return true;
         default: return false;
@@ -1026,9 +1031,13 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
         else if (p.act_epi == FB_ACT_SILU && hc && !hc2 && hd && pre) p.epi_fast = 7;
         else if (p.act_epi == FB_ACT_RELU && hc && !hc2 && hd && pre) p.epi_fast = 8;
     }
-    FB_REQUIRE(!foldq || (p.epi_fast >= 1 && p.epi_fast <= 8 && p.epi_fast != 3 && p.C2 == nullptr && p.a_dtype == FB_DT_BF16 &&
-                          p.w_dtype == FB_DT_BF16 && p.K % 64 == 0),
-               "fabind_gemm: the row_mu / row_rs fold needs a staged bf16 epilogue (no residual / second tile / split-K)");
+    if (foldq) {
+        FB_REQUIRE((p.epi_fast == 5 || p.epi_fast == 6) && p.C2 == nullptr && p.a_dtype == FB_DT_BF16 && p.w_dtype == FB_DT_BF16 &&
+                       p.K % 64 == 0,
+                   "fabind_gemm: the row_mu / row_rs fold exists for relu epilogues writing bf16 C or a row-dot only (bf16 operands, "
+                   "K % 64 == 0, no residual / second tile / split-K)");
+        p.epi_fast += 7;        /* 5 -> 12, 6 -> 13: the FOLD instantiations */
+    }
     int maxM = p.groups ? p.max_m : p.M, maxN = p.groups ? p.max_n : p.N;
     if (maxM <= 0 || maxN <= 0) return 0;
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, p.groups ? p.n_groups : (p.k_splits > 1 ? p.k_splits : 1));

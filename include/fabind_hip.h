@@ -74,7 +74,7 @@ typedef struct FabindGemmArgs {
     float p_drop;       /* > 0: epilogue dropout (train / sampling mode): after bias + activation, before the residual, the value is
                            multiplied by keep/(1-p) with keep = [hash32(drop_seed + row*N + col) & 0xffff >= round(p*65536)] */
     unsigned drop_seed;
-    /* optional LayerNorm fold (fast epilogues without residual / second tile only): the accumulator of row r, column c becomes
+    /* optional LayerNorm fold (act_epi = relu writing a bf16 C, or relu + row-dot only; bf16 operands; K % 64 == 0): the accumulator of row r, column c becomes
        row_rs[r] * (acc - row_mu[r] * col_c[c]) before bias / activation -- i.e. LN(A) W^T evaluated as a GEMM on the
        UN-normalised A with W pre-scaled by the LN weight, col_c = its row sums, bias = W ln_b + b */
     const float* row_mu; const float* row_rs; const float* col_c;
