@@ -682,10 +682,13 @@ def las_step(x, x0, las, lay, step, clampv):
 def _pair_bias_fwd(a0b0, H, wcomp, bconst, lay):
     nblk, NO, _ = wcomp.shape
     outs = []
+    # bf16 mode: one cast of the A operand shared by all blocks -- an fp32 A sends every one of these ragged-batched
+    # contractions to the register-staged fallback kernel (which rounds A to bf16 for the MFMA anyway)
+    a0 = a0b0[:, :H].to(torch.bfloat16) if mm_dtype() == torch.bfloat16 else a0b0[:, :H]
     for k in range(nblk):
         bmat = K.pair_bmat(a0b0[:, H:], wcomp[k], lay.c_index, mm_dtype())       # [(sumC*NO), H]
         out = torch.empty((lay.n_pairs, NO), dtype=torch.float32, device=a0b0.device)
-        K.gemm(a0b0[:, :H], bmat, bias=bconst[k].repeat(lay.sumC), out=out, groups=lay.pb_groups, n_groups=lay.B,
+        K.gemm(a0, bmat, bias=bconst[k].repeat(lay.sumC), out=out, groups=lay.pb_groups, n_groups=lay.B,
                max_m=lay.max_P, max_n=lay.pb_max_n, M=lay.N, N=bmat.shape[0], ldc=NO)
         outs.append(out)
     return outs
