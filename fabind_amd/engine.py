@@ -109,6 +109,7 @@ class Layout:
 
 class Graph:
     """ctx + inter CSR of the current coordinates (rebuilt each refinement iteration, no grad)."""
+    _warned_fallback = False
 
     @torch.no_grad()
     def __init__(self, lay, x, bond_row, bond_col, bond_off, cut_intra, cut_inter):
@@ -124,6 +125,13 @@ class Graph:
             raise RuntimeError("fabind_amd: inter-graph is not symmetric (%d ligand-row edges of %d): finite coordinates: %s"
                                % (n_half, E_int, bool(torch.isfinite(x).all())))
         if E_int == 0:
+            if get_precision() == "bf16" and not Graph._warned_fallback:
+                Graph._warned_fallback = True
+                import warnings
+                warnings.warn("fabind_amd: no ligand-protein pair within the inter cut-off in this batch -- the reference's one "
+                              "fake pair is used (att_model.py:85-86).  In bf16 mode ligand coordinates are accurate to only "
+                              "~0.1-0.3 A on such inputs (long edges amplify bf16 operand rounding; DESIGN.md); use "
+                              "engine.set_precision('fp32') if that matters.")
             # reference fallback (att_model.py:85-86): one fake symmetric pair from the first candidate,
             # i.e. first ligand atom of complex 0 <-> its first protein residue.
             u, v = 1, int(lay.C[0]) + 1

@@ -104,13 +104,20 @@ def test_plus_stack_without_inter_edges_uses_reference_fallback():
     # failed at 0.26 A -- on this unphysical geometry the shared bf16 arithmetic (not the inference-only kernels: same gap
     # with them switched off, tools/probes/plus_fallback_bf16.py) loses coordinate accuracy, growing sub-linearly with the
     # ligand-protein distance (0.09 A at 25 A ... 0.26 A at 250 A).  0.6 A is a regression guard chosen after measuring.
+    import warnings
+    from fabind_amd.engine import Graph
     for mode, tol in (("fp32", 1e-4), ("bf16", 5e-2)):
         engine.set_precision(mode)
+        Graph._warned_fallback = False
         try:
             m = _build(g, dev)
-            X, H, Z = _run(m, inp, dev)
+            with warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter("always")
+                X, H, Z = _run(m, inp, dev)
         finally:
             engine.set_precision("fp32")
+        # the product says so once when it falls back in bf16 mode, and stays silent in fp32 mode
+        assert sum("fake pair" in str(w.message) for w in rec) == (1 if mode == "bf16" else 0), mode
         assert m.last_graph.E_int == 2, mode
         assert torch.isfinite(X).all() and torch.isfinite(H).all() and torch.isfinite(Z).all(), mode
         gap = rmsd(X.cpu().numpy()[mask] * 5, Xr.numpy()[mask] * 5)
