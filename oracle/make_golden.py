@@ -115,28 +115,8 @@ def golden_stack(mods, name, sizes, hidden, layers, n_iter, seed):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
-def golden_model(mods, name, sizes, hidden, pocket_hidden, layers, n_iter, seed):
-    torch.manual_seed(seed)
-    args = refshim.production_args(hidden_size=hidden, pocket_pred_hidden_size=pocket_hidden, mean_layers=layers,
-                                   n_iter=n_iter, random_n_iter=False)
-    model = mods["models.model"].get_model(args, _Logger(), None).eval()
-    _boost(model)
-    data = synthetic.make_hetero_batch(sizes, seed=seed)
-    save = {"sizes": np.array(sizes), "cfg": np.array([hidden, pocket_hidden, layers, n_iter, seed])}
-    save.update({"w_" + k: _np(v) for k, v in model.state_dict().items()})
-    names = ["coords", "compound_batch", "y_pred", "y_pred_by_coords", "pocket_cls_pred", "pocket_cls",
-             "protein_out_mask_whole", "protein_coords_batched_whole", "pred_pocket_center", "dis_map"]
-    for stage in (1, 2):
-        with torch.no_grad():
-            out = model(_hetero_to_ref(data), stage=stage, train=False)
-        for n, o in zip(names, out[:10]):
-            save["s%d_%s" % (stage, n)] = _np(o)
-        save["s%d_keepNode_less_5" % stage] = np.array(out[10])
-        moved = (out[0] - data["compound"].node_coords).norm(dim=-1).max()
-        print("%s stage %d: ligand moved up to %.3f A, center %s" % (name, stage, moved, _np(out[8][0])))
-    with torch.no_grad():
-        out = model.inference(_hetero_to_ref(data))
-    save["inf_coords"] = _np(out[0])
+def _loss_and_gradients(model, data, save, name):
+    """Train-step loss (6 terms) + per-parameter gradient norm and 16 samples for both stages, into `save`."""
     # train-step loss + gradients (eval-mode modules: dropout off, no Gumbel noise; stage fixed)
     for stage in (1, 2):
         model.zero_grad()
@@ -161,6 +141,31 @@ def golden_model(mods, name, sizes, hidden, pocket_hidden, layers, n_iter, seed)
                 save["s%d_gradnorm_%s" % (stage, n)] = _np(gflat.norm())
                 save["s%d_gradsmp_%s" % (stage, n)] = _np(gflat[idx])
         print("%s stage %d: loss %.6f" % (name, stage, float(loss)), {k: round(float(v), 5) for k, v in terms.items()})
+
+
+def golden_model(mods, name, sizes, hidden, pocket_hidden, layers, n_iter, seed):
+    torch.manual_seed(seed)
+    args = refshim.production_args(hidden_size=hidden, pocket_pred_hidden_size=pocket_hidden, mean_layers=layers,
+                                   n_iter=n_iter, random_n_iter=False)
+    model = mods["models.model"].get_model(args, _Logger(), None).eval()
+    _boost(model)
+    data = synthetic.make_hetero_batch(sizes, seed=seed)
+    save = {"sizes": np.array(sizes), "cfg": np.array([hidden, pocket_hidden, layers, n_iter, seed])}
+    save.update({"w_" + k: _np(v) for k, v in model.state_dict().items()})
+    names = ["coords", "compound_batch", "y_pred", "y_pred_by_coords", "pocket_cls_pred", "pocket_cls",
+             "protein_out_mask_whole", "protein_coords_batched_whole", "pred_pocket_center", "dis_map"]
+    for stage in (1, 2):
+        with torch.no_grad():
+            out = model(_hetero_to_ref(data), stage=stage, train=False)
+        for n, o in zip(names, out[:10]):
+            save["s%d_%s" % (stage, n)] = _np(o)
+        save["s%d_keepNode_less_5" % stage] = np.array(out[10])
+        moved = (out[0] - data["compound"].node_coords).norm(dim=-1).max()
+        print("%s stage %d: ligand moved up to %.3f A, center %s" % (name, stage, moved, _np(out[8][0])))
+    with torch.no_grad():
+        out = model.inference(_hetero_to_ref(data))
+    save["inf_coords"] = _np(out[0])
+    _loss_and_gradients(model, data, save, name)
     hd = {}
     for key, st in data._stores.items():
         kname = key if isinstance(key, str) else "|".join(key)
@@ -586,6 +591,102 @@ def golden_data_builder(mods, name, seed):
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
 
 
+def _parse_6g3c():
+    """C-alpha coordinates of inference_examples/pdb_files/6g3c.pdb and heavy atoms + heavy-atom bonds of
+    gt_mol_files/6g3c/6g3c_ligand.sdf (V2000), with plain text parsing (no RDKit / Biopython here)."""
+    root = os.path.join(refshim.REFERENCE_ROOT, "FABind", "inference_examples")
+    ca = []
+    for line in open(os.path.join(root, "pdb_files", "6g3c.pdb")):
+        if line.startswith("ATOM") and line[12:16].strip() == "CA" and line[16] in (" ", "A"):
+            ca.append([float(line[30:38]), float(line[38:46]), float(line[46:54])])
+    lines = open(os.path.join(root, "gt_mol_files", "6g3c", "6g3c_ligand.sdf")).read().split("\n")
+    na, nb = int(lines[3][:3]), int(lines[3][3:6])
+    xyz, elem = [], []
+    for l in lines[4:4 + na]:
+        xyz.append([float(l[0:10]), float(l[10:20]), float(l[20:30])])
+        elem.append(l[31:34].strip())
+    heavy = [i for i, e in enumerate(elem) if e != "H"]
+    new = {a: k for k, a in enumerate(heavy)}
+    bonds = []
+    for l in lines[4 + na:4 + na + nb]:
+        a, b = int(l[0:3]) - 1, int(l[3:6]) - 1
+        if a in new and b in new:
+            bonds += [[new[a], new[b]], [new[b], new[a]]]
+    return np.array(ca, np.float32), np.array(xyz, np.float32)[heavy], np.array(bonds, np.int64)
+
+
+def golden_model_6g3c(mods, name, seed):
+    """BASELINE config 0 / SURVEY 8(c): the reference's own example complex 6g3c (real geometry: 272 C-alpha, the ligand's
+    heavy atoms and bonds) through the reference's per-sample builder (utils/utils.py:202-442) and model (1 layer, n_iter 1,
+    fp32; hidden 64 / 32 to keep the fixture small).  Stand-ins for what this image lacks: node features are random
+    (ESM2 / torchdrug absent); the "RDKit conformer" is the crystal pose under a random rotation, re-centred, and the LAS
+    edges are the atom pairs at bond-graph distance <= 2 (RDKit absent) -- geometry, bonds and every model operation are
+    the reference's."""
+    from argparse import Namespace
+    g = torch.Generator().manual_seed(seed)
+    ca, lig, bonds = _parse_6g3c()
+    L, nc = ca.shape[0], lig.shape[0]
+    adj = np.zeros((nc, nc), bool)
+    adj[bonds[:, 0], bonds[:, 1]] = True
+    two = (adj.astype(np.int64) @ adj.astype(np.int64)) > 0
+    las = np.stack(np.nonzero((adj | two) & ~np.eye(nc, dtype=bool)))
+    rot = torch.linalg.qr(torch.randn(3, 3, generator=g))[0].numpy().astype(np.float32)
+    rdk = (lig - lig.mean(0)) @ rot.T
+    esm, cf = 0.1 * torch.randn(L, 1280, generator=g), 0.1 * torch.randn(nc, 56, generator=g)
+    edge3 = torch.from_numpy(np.concatenate([bonds, np.zeros((bonds.shape[0], 1), np.int64)], 1))
+    bargs = Namespace(train_pred_pocket_noise=0.0, local_eval=False, train_ligand_torsion_noise=False, data_path=None)
+    ref_d, _, _ = mods["utils.utils"].construct_data_from_graph_gvp_mean(
+        bargs, torch.from_numpy(ca), "A" * L, lig.astype(np.float64), cf, edge3, None, torch.from_numpy(las), rdk.copy(),
+        pdb_id="6g3c", group="test", protein_esm2_feat=esm)
+    # PyG collation of a batch of one: batch vectors of zeros per node / edge-list store
+    data = synthetic.HeteroBatch()
+    for key, st in ref_d._stores.items():
+        for k, v in st.items():
+            data[key][k] = v
+    for k, v in ref_d._glob.items():
+        if torch.is_tensor(v):
+            setattr(data, k, v)
+    for st, f in (("compound", "node_feats"), ("protein_whole", "node_feats"), ("pocket", "node_feats"),
+                  ("complex", "node_coords"), ("complex_whole_protein", "node_coords"), ("compound_atom_edge_list", "x"),
+                  ("LAS_edge_list", "x")):
+        data[st].batch = torch.zeros(data[st][f].shape[0], dtype=torch.long)
+    data["compound"].node_coords = data["compound"].node_coords.float()
+    data["compound"].rdkit_coords = torch.as_tensor(data["compound"].rdkit_coords).float()
+    data.pocket_residue_center = data.node_xyz.mean(0, keepdim=True)
+    print("%s: %d residues (%d in the 20 A pocket), %d heavy atoms, %d directed bonds, %d LAS edges" % (
+        name, L, int(data["pocket"].keepNode.sum()), nc, bonds.shape[0], las.shape[1]))
+    torch.manual_seed(seed)
+    args = refshim.production_args(hidden_size=64, pocket_pred_hidden_size=32, mean_layers=1, n_iter=1, random_n_iter=False)
+    model = mods["models.model"].get_model(args, _Logger(), None).eval()
+    _boost(model)
+    save = {"sizes": np.array([[L, nc]]), "cfg": np.array([64, 32, 1, 1, seed])}
+    save.update({"w_" + k: _np(v) for k, v in model.state_dict().items()})
+    names = ["coords", "compound_batch", "y_pred", "y_pred_by_coords", "pocket_cls_pred", "pocket_cls",
+             "protein_out_mask_whole", "protein_coords_batched_whole", "pred_pocket_center", "dis_map"]
+    for stage in (1, 2):
+        with torch.no_grad():
+            out = model(_hetero_to_ref(data), stage=stage, train=False)
+        for n, o in zip(names, out[:10]):
+            save["s%d_%s" % (stage, n)] = _np(o)
+        save["s%d_keepNode_less_5" % stage] = np.array(out[10])
+        print("%s stage %d: ligand moved up to %.3f A from its start, RMSD to the crystal pose %.2f A" % (
+            name, stage, (out[0] - data["compound"].node_coords).norm(dim=-1).max(),
+            float(((out[0] - data.coords) ** 2).sum(-1).mean().sqrt())))
+    with torch.no_grad():
+        out = model.inference(_hetero_to_ref(data))
+    save["inf_coords"] = _np(out[0])
+    _loss_and_gradients(model, data, save, name)
+    for key, st in data._stores.items():
+        kname = key if isinstance(key, str) else "|".join(key)
+        for k, v in st.items():
+            if torch.is_tensor(v):
+                save["d_%s::%s" % (kname, k)] = _np(v)
+    for k, v in data._glob.items():
+        if torch.is_tensor(v):
+            save["d_::%s" % k] = _np(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **save)
+
+
 def main_plus():
     torch.set_num_threads(1)
     os.makedirs(OUT, exist_ok=True)
@@ -609,6 +710,10 @@ def main():
         os.makedirs(OUT, exist_ok=True)
         torch.set_num_threads(1)
         return golden_data_builder(refshim.load_reference("FABind"), "data_builder", seed=41)
+    if len(sys.argv) > 1 and sys.argv[1] == "6g3c":
+        os.makedirs(OUT, exist_ok=True)
+        torch.set_num_threads(1)
+        return golden_model_6g3c(refshim.load_reference("FABind"), "model_6g3c", seed=51)
     if len(sys.argv) > 1 and sys.argv[1] == "post":
         os.makedirs(OUT, exist_ok=True)
         return golden_post_optim("post_optim", seed=21)

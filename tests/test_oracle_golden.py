@@ -82,9 +82,13 @@ def _model_cfg(g):
     return cfg
 
 
+MODELS = ["model_tiny", "model_6g3c"]        # synthetic spheres / the reference's example complex 6g3c (real geometry)
+
+
+@pytest.mark.parametrize("name", MODELS)
 @pytest.mark.parametrize("stage", [1, 2])
-def test_model_forward_and_loss(stage):
-    g = load_npz("model_tiny")
+def test_model_forward_and_loss(stage, name):
+    g = load_npz(name)
     sd, data = weights(g), hetero_from_npz(g)
     out = orc.model_forward(sd, _model_cfg(g), data, stage=stage)
     p = "s%d_" % stage
@@ -101,8 +105,9 @@ def test_model_forward_and_loss(stage):
         assert abs(float(v) - float(g[p + "loss_" + k])) <= 1e-5 * max(abs(float(g[p + "loss_" + k])), 1e-3), k
 
 
-def test_model_inference():
-    g = load_npz("model_tiny")
+@pytest.mark.parametrize("name", MODELS)
+def test_model_inference(name):
+    g = load_npz(name)
     coords, batch = orc.model_inference(weights(g), _model_cfg(g), hetero_from_npz(g))
     assert rmsd(coords.numpy(), g["inf_coords"]) < 2e-5
 
