@@ -281,9 +281,14 @@ def test_stack_gradients_bf16_close():
     gmax = max(float(np.abs(g["grad_" + n]).max()) for n, _ in m.named_parameters() if n not in nograd)
     bad = []
     for n, p in m.named_parameters():
-        if n in nograd or p.grad is None:
+        if n in nograd:
             continue
         ref = g["grad_" + n]
+        if p.grad is None:
+            # same rule as the fp32 test above: only the softmax-shift-invariant constants may come without a gradient (the
+            # bf16 mode runs different backward kernels, so this is checked here too instead of being skipped)
+            assert np.abs(ref).max() < 1e-6, n
+            continue
         err = np.abs(p.grad.float().cpu().numpy() - ref).max()
         # tensors whose whole gradient is tiny (second-order paths through the attention bias) sit at bf16 noise level
         if not err <= 8e-2 * np.abs(ref).max() + 1e-4 * gmax:
