@@ -43,3 +43,16 @@ def test_bench_two_ranks_control_flow():
              env={"FABIND_BENCH_DEVICE": "0", "FABIND_BENCH_BACKEND": "gloo"})
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 6
     assert abs(r["value"] - 6 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]      # whole-job aggregate over both ranks
+
+
+def test_rccl_backend_paths_with_one_rank():
+    """The device-tensor collective branch of fabind_amd.parallel.allreduce_gradients and bench.py's "nccl" (= RCCL) process
+    group run on a real GPU with one rank (the two-rank tests above need gloo and stage through the host): a one-rank SUM is the
+    identity, so allreduce_gradients(..., world=2) must leave exactly grad / 2 over several buckets (checked inside the probe),
+    and bench.py under torch.distributed.run must initialise, barrier, time and print its line with the RCCL group."""
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
+    out = subprocess.run(launch + ["--master-port", "29541", os.path.join("tools", "probes", "nccl_single_rank.py")], cwd=ROOT,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL single-rank path ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+    r = _run(launch + ["--master-port", "29542", "bench.py", "--gpus", "1"] + SMALL)
+    assert r["n_gpus"] == 1 and r["value"] > 0
