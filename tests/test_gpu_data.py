@@ -120,3 +120,33 @@ def test_built_batch_feeds_the_model():
     assert out[0].shape == batch.coords.shape and torch.isfinite(out[0]).all() and torch.isfinite(loss)
     coords, _ = model.inference(batch)
     assert torch.isfinite(coords).all()
+
+
+def test_batch_builder_edge_inputs():
+    """Batch of one; a ligand without bonds / LAS edges next to a normal one (empty edge lists, zero-length integer slices);
+    a single-atom ligand."""
+    from fabind_amd.data import build_batch
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+
+    def sample(L, nc, bonds=True):
+        prot = torch.randn(L, 3, generator=g) * 8.0
+        lig = torch.randn(nc, 3, generator=g) + torch.tensor([3.0, 0.0, 0.0])
+        idx = torch.arange(nc)
+        e = torch.stack([torch.cat([idx[:-1], idx[1:]]), torch.cat([idx[1:], idx[:-1]])], 1) if (bonds and nc > 1) else torch.zeros(0, 2, dtype=torch.long)
+        return dict(protein_node_xyz=prot, protein_esm2_feat=torch.randn(L, 16, generator=g), coords=lig,
+                    compound_node_features=torch.randn(nc, 8, generator=g), input_atom_edge_list=e,
+                    LAS_edge_index=e.t().contiguous(), rdkit_coords=lig - lig.mean(0))
+    one = build_batch([sample(40, 7)], dev)
+    assert int(one["compound"].batch.max()) == 0 and one["complex"].node_coords.shape[0] == 7 + int(one["pocket"].keepNode.sum()) + 2
+    mixed = build_batch([sample(30, 5, bonds=False), sample(35, 6), sample(25, 1)], dev)
+    assert mixed["complex", "c2c", "complex"].edge_index.shape == (2, 10)          # only the middle ligand has bonds (5 x 2)
+    assert mixed["compound_atom_edge_list"].batch.tolist() == [1] * 10
+    n = torch.bincount(mixed["complex"].batch).tolist()
+    off1 = n[0]
+    e = mixed["complex", "c2c", "complex"].edge_index
+    assert int(e.min()) == off1 + 1 and int(e.max()) == off1 + 6                   # shifted into the second complex, after its glb_c
+    assert mixed.dis_map.shape[0] == sum(int(k) * c for k, c in zip(torch.bincount(mixed["pocket"].batch, minlength=3).tolist(), (5, 6, 1)))
+    assert torch.isfinite(mixed["complex"].node_coords).all() and torch.isfinite(mixed.dis_map).all()
+    empty = build_batch([sample(20, 4, bonds=False)], dev)                          # no edge of any kind in the whole batch
+    assert empty["complex", "c2c", "complex"].edge_index.shape == (2, 0) and empty["LAS_edge_list"].x.shape == (0, 2)
