@@ -64,17 +64,33 @@ def make_batch(batch, n_prot, n_lig, hidden, seed):
     return out
 
 
-def cpu_baseline(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0):
-    """The oracle (CPU restatement of the reference algorithm, `kind: port`) timed on the host cores."""
+def cpu_baseline(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, backward=False):
+    """The oracle (CPU restatement of the reference algorithm, `kind: port`) timed on the host cores.  backward=True: the
+    same pass as the GPU step of the default mode -- forward, the same scalar loss, backward to every parameter (autograd
+    through the oracle) -- so that `cpu_baseline.value` and `value` measure the same work."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fabind_oracle as orc
+    # torch's default (128 threads on the 256-CPU host of the GPU box) is the WORST setting for this workload: forward
+    # 0.12 complexes/s at 128 threads, 0.26 at 64, 0.39 at 32, 0.38 at 16, 0.31 at 8 (tools/probes/cpu_threads.py)
+    default_threads = torch.get_num_threads()
+    torch.set_num_threads(min(default_threads, 32))
     m = build_model(hidden, layers, n_iter)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    if backward:
+        for v in sd.values():
+            if v.is_floating_point():
+                v.requires_grad_(True)
     inp = make_batch(1, n_prot, n_lig, hidden, seed=0)
-    run = lambda: orc.stack_forward(sd, "", inp["X"], inp["H"], inp["batch_id"], inp["segment_id"], inp["mask"],
-                                    inp["is_global"], inp["compound_edge_index"], inp["LAS_edge_index"],
-                                    inp["coord_LAS"], layers, n_iter)
-    with torch.no_grad():
+
+    def run():
+        X, Hh = orc.stack_forward(sd, "", inp["X"], inp["H"], inp["batch_id"], inp["segment_id"], inp["mask"],
+                                  inp["is_global"], inp["compound_edge_index"], inp["LAS_edge_index"],
+                                  inp["coord_LAS"], layers, n_iter)[:2]
+        if backward:
+            for v in sd.values():
+                v.grad = None
+            ((X * X).mean() + (Hh * Hh).mean() * 1e-6).backward()
+    with torch.set_grad_enabled(backward):
         t0 = time.time()
         run()
         first = time.time() - t0
@@ -83,9 +99,11 @@ def cpu_baseline(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0):
         for _ in range(reps):
             run()
         dt = (time.time() - t0) / reps
-    return dict(value=1.0 / dt, unit="complexes/s", cores=torch.get_num_threads(), kind="port",
-                sample="oracle stack forward, B=1, %d/%d nodes, hidden %d, %d layers, n_iter=%d, fp32, %d timed runs"
-                       % (n_prot, n_lig, hidden, layers, n_iter, reps))
+    cores = torch.get_num_threads()
+    torch.set_num_threads(default_threads)
+    return dict(value=1.0 / dt, unit="complexes/s", cores=cores, kind="port",
+                sample="oracle stack %s, B=1, %d/%d nodes, hidden %d, %d layers, n_iter=%d, fp32, %d timed run(s) after one warm-up"
+                       % ("forward + backward" if backward else "forward", n_prot, n_lig, hidden, layers, n_iter, reps))
 
 
 def main():
@@ -284,7 +302,7 @@ def main():
         except Exception:
             pass
     if not a.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
-        out["cpu_baseline"] = cpu_baseline(a.hidden, a.layers, a.n_iter, a.n_prot, a.n_lig)
+        out["cpu_baseline"] = cpu_baseline(a.hidden, a.layers, a.n_iter, a.n_prot, a.n_lig, backward=(a.mode == "fwdbwd"))
     print(json.dumps(out))
 
 
