@@ -301,7 +301,9 @@ def main():
                     out["roofline"]["traffic"] = val
         except Exception:
             pass
-    if not a.no_cpu_baseline and world == 1:          # reported baseline: rank 0 at N=1 only
+    # reported baseline: rank 0 at N=1 only, and only for the modes whose workload the stack oracle restates (the full-model and
+    # FABind+ sampling modes would otherwise carry a baseline of a different workload)
+    if not a.no_cpu_baseline and world == 1 and a.mode in ("fwd", "fwdbwd"):
         out["cpu_baseline"] = cpu_baseline(a.hidden, a.layers, a.n_iter, a.n_prot, a.n_lig, backward=(a.mode == "fwdbwd"))
     print(json.dumps(out))
 
