@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfabind_hip.so")
 
-ABI_VERSION = 2          # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
+ABI_VERSION = 3          # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -84,7 +84,7 @@ SIGNATURES = {
     "fabind_gather_dact": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "fabind_coord_update_bwd": [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
     "fabind_cross_attn_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                              _vp, _i, _i, _vp],
+                              _vp, _vp, _vp],
     "fabind_pair_hadamard_bwd": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
                                  _vp],
     "fabind_inter_attn_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i,
@@ -116,6 +116,7 @@ def load():
         raise RuntimeError("fabind_amd: %s has ABI version %d, this binding needs %d -- rebuild with `python -m fabind_amd.build`"
                            % (LIB_PATH, got, ABI_VERSION))
     lib.fabind_sizeof_args.argtypes, lib.fabind_sizeof_args.restype = [ctypes.c_int], ctypes.c_int
+    lib.fabind_cross_attn_bwd_scratch.argtypes, lib.fabind_cross_attn_bwd_scratch.restype = [_i, _i, _i], ctypes.c_long
     for which, mirror in enumerate((GemmArgs, EdgeBwdArgs, PairUpdateArgs)):
         if lib.fabind_sizeof_args(which) != ctypes.sizeof(mirror):
             raise RuntimeError("fabind_amd: ctypes mirror %s is %d bytes, the library's struct is %d -- _lib.py and "

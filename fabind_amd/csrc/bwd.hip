@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_q_kernel(const float* __re
                                                                int gate_col, const int* desc, float scale,
                                                                const float* __restrict__ out, const float* lse,
                                                                const float* __restrict__ dout, float* dqg, float* dbias,
-                                                               float* dO, float* Dv, int ksplit) {
+                                                               float* dO, float* Dv, int ksplit, float* part, int part_rows) {
     __shared__ __attribute__((aligned(16))) float sK[CB_KT * 128];
     __shared__ __attribute__((aligned(16))) float sV[CB_KT * 128];
     const int* ds = desc + blockIdx.y * 8;
@@ -464,9 +464,10 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_q_kernel(const float* __re
     }
     if (!valid) return;
     float* dqp = dqg + (size_t)(q_off + qi) * ldq + h * 32;
-    if (ksplit > 1) {      // partial over this key range: dq columns were zeroed by the host
+    if (ksplit > 1) {      // partial over this key range -> part[split][complex][local query][128]; split_reduce_kernel sums them
+        float* pp = part + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * part_rows + qi) * 128 + h * 32;
 #pragma unroll
-        for (int c = 0; c < 32; ++c) atomicAdd(&dqp[c], dq[c] * scale);
+        for (int c = 0; c < 32; ++c) pp[c] = dq[c] * scale;
     } else {
 #pragma unroll
         for (int c = 0; c < 32; ++c) dqp[c] = dq[c] * scale;
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kv_kernel(const float* __r
                                                                 const float* __restrict__ bias, int bias_ld, int lin_col,
                                                                 int gate_col, const int* desc, float scale,
                                                                 const float* lse, const float* __restrict__ dO,
-                                                                const float* Dv, float* dkv, int qsplit) {
+                                                                const float* Dv, float* dkv, int qsplit, float* part, int part_rows) {
     __shared__ __attribute__((aligned(16))) float sQ[CB_KT * 128];
     __shared__ __attribute__((aligned(16))) float sDO[CB_KT * 128];
     __shared__ float sL[CB_KT * 4], sD[CB_KT * 4];
@@ -552,32 +553,67 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kv_kernel(const float* __r
     }
     if (!valid) return;
     float* o = dkv + (size_t)(k_off + kj) * ldkv + h * 32;
-    if (qsplit > 1) {      // partial over this query range: dkv was zeroed by the host
+    if (qsplit > 1) {      // partial over this query range -> part[split][complex][local key][256] (dk | dv)
+        float* pp = part + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * part_rows + kj) * 256 + h * 32;
 #pragma unroll
-        for (int c = 0; c < 32; ++c) { atomicAdd(&o[c], dk[c]); atomicAdd(&o[128 + c], dv[c]); }
+        for (int c = 0; c < 32; ++c) { pp[c] = dk[c]; pp[128 + c] = dv[c]; }
     } else {
 #pragma unroll
         for (int c = 0; c < 32; ++c) { o[c] = dk[c]; o[128 + c] = dv[c]; }
     }
 }
 
+// Sum of the per-split partials of the split direction (<= 256 rows per complex): out[(off_b + r) * ldo + c] = sum_z part[z][b][r][c].
+// Replaces float atomics into dq / dkv (11-way contended, one cache line per lane: ~0.4 ms per launch at the bench shape).
+__global__ __launch_bounds__(256) void split_reduce_kernel(const float* __restrict__ part, int nsplit, int part_rows, int cols,
+                                                           const int* __restrict__ desc, int off_idx, int cnt_idx,
+                                                           float* __restrict__ out, int ldo) {
+    const int* ds = desc + blockIdx.y * 8;
+    const int off = ds[off_idx], n = ds[cnt_idx];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int r = idx / cols, c = idx % cols;
+    if (r >= n) return;
+    float acc = 0.f;
+    for (int z = 0; z < nsplit; ++z) acc += part[(((size_t)z * gridDim.y + blockIdx.y) * part_rows + r) * cols + c];
+    out[(size_t)(off + r) * ldo + c] = acc;
+}
+
+// floats of scratch fabind_cross_attn_bwd needs for (B, max_nq, max_nk); 0 when neither pass is split
+static void ca_splits(int max_nq, int max_nk, int* ksplit, int* qsplit) {
+    // few queries / many keys -> split the keys in pass Q; few keys / many queries -> split the queries in pass KV
+    *ksplit = (max_nq <= 256 && max_nk >= 512) ? max_nk / 128 : 1;
+    *qsplit = (max_nk <= 256 && max_nq >= 512) ? max_nq / 128 : 1;
+    if (*ksplit > 32) *ksplit = 32;
+    if (*qsplit > 32) *qsplit = 32;
+}
+extern "C" long fabind_cross_attn_bwd_scratch(int B, int max_nq, int max_nk) {
+    int ks, qs;
+    ca_splits(max_nq, max_nk, &ks, &qs);
+    if (ks > 1) return (long)ks * B * max_nq * 128;
+    if (qs > 1) return (long)qs * B * max_nk * 256;
+    return 0;
+}
+
 extern "C" int fabind_cross_attn_bwd(const float* qg, int ldq, const float* kv, int ldkv, const float* bias, int bias_ld,
                                      int lin_col, int gate_col, const int* desc, int B, int max_nq, int max_nk,
                                      float scale, const float* out, const float* lse, const float* dout, float* dqg,
-                                     float* dkv, float* dbias, float* dO, float* Dv, int n_q_rows, int n_k_rows,
-                                     hipStream_t stream) {
+                                     float* dkv, float* dbias, float* dO, float* Dv, float* scratch, hipStream_t stream) {
     if (B <= 0) return 0;
-    // few queries / many keys -> split the keys in pass Q; few keys / many queries -> split the queries in pass KV
-    int ksplit = (max_nq <= 256 && max_nk >= 512) ? max_nk / 128 : 1;
-    int qsplit = (max_nk <= 256 && max_nq >= 512) ? max_nq / 128 : 1;
-    if (ksplit > 32) ksplit = 32;
-    if (qsplit > 32) qsplit = 32;
-    if (ksplit > 1) (void)hipMemsetAsync(dqg, 0, (size_t)n_q_rows * ldq * sizeof(float), stream);
-    if (qsplit > 1) (void)hipMemsetAsync(dkv, 0, (size_t)n_k_rows * ldkv * sizeof(float), stream);
+    int ksplit, qsplit;
+    ca_splits(max_nq, max_nk, &ksplit, &qsplit);
+    FB_REQUIRE((ksplit == 1 && qsplit == 1) || scratch != nullptr,
+               "fabind_cross_attn_bwd: this shape splits a pass and needs fabind_cross_attn_bwd_scratch() floats of scratch");
     hipLaunchKernelGGL(cross_attn_bwd_q_kernel, dim3((max_nq + 63) / 64, B, ksplit), dim3(256), 0, stream, qg, ldq, kv,
-                       ldkv, bias, bias_ld, lin_col, gate_col, desc, scale, out, lse, dout, dqg, dbias, dO, Dv, ksplit);
+                       ldkv, bias, bias_ld, lin_col, gate_col, desc, scale, out, lse, dout, dqg, dbias, dO, Dv, ksplit, scratch,
+                       max_nq);
+    if (ksplit > 1)
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((max_nq * 128 + 255) / 256, B), dim3(256), 0, stream, scratch, ksplit, max_nq,
+                           128, desc, 0, 1, dqg, ldq);
     hipLaunchKernelGGL(cross_attn_bwd_kv_kernel, dim3((max_nk + 63) / 64, B, qsplit), dim3(256), 0, stream, qg, ldq, kv,
-                       ldkv, bias, bias_ld, lin_col, gate_col, desc, scale, lse, dO, Dv, dkv, qsplit);
+                       ldkv, bias, bias_ld, lin_col, gate_col, desc, scale, lse, dO, Dv, dkv, qsplit, scratch, max_nk);
+    if (qsplit > 1)
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((max_nk * 256 + 255) / 256, B), dim3(256), 0, stream, scratch, qsplit, max_nk,
+                           256, desc, 2, 3, dkv, ldkv);
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -527,10 +527,12 @@ class _CrossAttn(torch.autograd.Function):
         dqg, dkv, dbias = torch.zeros_like(qg), torch.zeros_like(kv), torch.zeros_like(bias)   # uncovered rows / columns: 0
         dO = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
         Dv = torch.empty((qg.shape[0], 4), dtype=torch.float32, device=qg.device)
+        n_scr = int(load().fabind_cross_attn_bwd_scratch(B, max_nq, max_nk))     # per-split partials of the short side (or 0)
+        scr = torch.empty(n_scr, dtype=torch.float32, device=qg.device) if n_scr else None
         check(load().fabind_cross_attn_bwd(ptr(qg), qg.stride(0), ptr(kv), kv.stride(0), ptr(bias), bias.stride(0), lin_col,
                                            gate_col, ptr(desc), B, max_nq, max_nk, scale, ptr(out), ptr(lse), ptr(dout),
-                                           ptr(dqg), ptr(dkv), ptr(dbias), ptr(dO), ptr(Dv), qg.shape[0], kv.shape[0],
-                                           stream()), "fabind_cross_attn_bwd")
+                                           ptr(dqg), ptr(dkv), ptr(dbias), ptr(dO), ptr(Dv), ptr(scr), stream()),
+              "fabind_cross_attn_bwd")
         return dqg, dkv, dbias, None, None, None, None, None, None, None
 
 

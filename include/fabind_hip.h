@@ -27,9 +27,10 @@ typedef struct ihipStream_t* hipStream_t;
 
 const char* fabind_last_error(void);
 /* Bumped whenever an entry point's signature or an argument struct's layout changes.  History: 1 = first round-1 layout;
- * 2 = FabindGemmArgs grew {p_drop, drop_seed, row_mu, row_rs, col_c}, FabindEdgeBwdArgs / FabindPairUpdateArgs added.
+ * 2 = FabindGemmArgs grew {p_drop, drop_seed, row_mu, row_rs, col_c}, FabindEdgeBwdArgs / FabindPairUpdateArgs added;
+ * 3 = fabind_cross_attn_bwd takes a scratch buffer instead of (n_q_rows, n_k_rows), fabind_cross_attn_bwd_scratch added.
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 2
+#define FABIND_ABI_VERSION 3
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -346,10 +347,15 @@ int fabind_gather_dact(const float* dout, int ldo, const int* row, const void* Z
                        int E, int H, hipStream_t stream);
 int fabind_coord_update_bwd(const float* d, const float* s, const int* rowptr, int n_rows, int mean, float clampv,
                             const float* dxo, float* dd, float* ds, hipStream_t stream);
+/* Adjoint of fabind_cross_attn_fwd.  Writes dqg / dkv / dbias only at the rows / pairs the block descriptors cover (the caller
+ * zero-initialises them if other rows exist).  When one side has <= 256 rows per complex and the other >= 512, the long loop of
+ * the short side is split over work-groups; the per-split partial sums go through `scratch` (fabind_cross_attn_bwd_scratch()
+ * floats, fp32) and are added by a reduce kernel -- no float atomics, the result is deterministic. */
+long fabind_cross_attn_bwd_scratch(int B, int max_nq, int max_nk);
 int fabind_cross_attn_bwd(const float* qg, int ldq, const float* kv, int ldkv, const float* bias, int bias_ld,
                           int lin_col, int gate_col, const int* desc, int B, int max_nq, int max_nk, float scale,
                           const float* out, const float* lse, const float* dout, float* dqg, float* dkv, float* dbias,
-                          float* dO, float* Dv, int n_q_rows, int n_k_rows, hipStream_t stream);
+                          float* dO, float* Dv, float* scratch, hipStream_t stream);
 int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const float* a0, const float* b0, int ld0, int H,
                              const float* a1, const float* b1, int ld1, int H2, const int* red_p, const int* red_c, int n,
                              float* da0, float* db0, int ldd0, float* da1, float* db1, int ldd1, hipStream_t stream);
