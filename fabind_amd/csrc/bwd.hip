@@ -371,6 +371,12 @@ extern "C" int fabind_coord_update_bwd(const float* d, const float* s, const int
 // Probabilities are recomputed from the saved log-sum-exp.
 // ------------------------------------------------------------------------------------------------
 #define CB_KT 32
+// LDS tile rows: the four heads' 32-float segments sit 36 floats apart (row stride 144), so that the four distinct addresses a
+// wave reads per instruction (one per head, each broadcast to 16 lanes) fall in different banks; at 32 apart heads 0/2 and 1/3
+// share banks (64 banks x 4 B) and every inner-loop read is a 2-way conflict
+#define CB_LD 144
+#define CB_H(h) ((h) * 36)
+#define CB_COL(c4) (((c4) >> 5) * 36 + ((c4) & 31))      /* column c4 of a [.,128] row -> padded offset */
 __global__ __launch_bounds__(256) void cross_attn_bwd_q_kernel(const float* __restrict__ qg, int ldq,
                                                                const float* __restrict__ kv, int ldkv,
                                                                const float* __restrict__ bias, int bias_ld, int lin_col,
@@ -378,8 +384,8 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_q_kernel(const float* __re
                                                                const float* __restrict__ out, const float* lse,
                                                                const float* __restrict__ dout, float* dqg, float* dbias,
                                                                float* dO, float* Dv, int ksplit, float* part, int part_rows) {
-    __shared__ __attribute__((aligned(16))) float sK[CB_KT * 128];
-    __shared__ __attribute__((aligned(16))) float sV[CB_KT * 128];
+    __shared__ __attribute__((aligned(16))) float sK[CB_KT * CB_LD];
+    __shared__ __attribute__((aligned(16))) float sV[CB_KT * CB_LD];
     const int* ds = desc + blockIdx.y * 8;
     const int q_off = ds[0], nq = ds[1], k_off = ds[2], nk = ds[3];
     const long pair_off = (long)(unsigned)ds[4] | ((long)ds[5] << 32);
@@ -424,8 +430,8 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_q_kernel(const float* __re
                 kk = *(const float4*)(kv + (size_t)(k_off + j0 + jr) * ldkv + c4);
                 vv = *(const float4*)(kv + (size_t)(k_off + j0 + jr) * ldkv + 128 + c4);
             }
-            *(float4*)(&sK[jr * 128 + c4]) = kk;
-            *(float4*)(&sV[jr * 128 + c4]) = vv;
+            *(float4*)(&sK[jr * CB_LD + CB_COL(c4)]) = kk;
+            *(float4*)(&sV[jr * CB_LD + CB_COL(c4)]) = vv;
         }
         __syncthreads();
         if (!valid) continue;
@@ -444,8 +450,8 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_q_kernel(const float* __re
             for (int u = 0; u < 8; ++u) {
                 const int j = jg + u;
                 if (j < jn) {
-                    const float* kp = &sK[j * 128 + h * 32];
-                    const float* vp = &sV[j * 128 + h * 32];
+                    const float* kp = &sK[j * CB_LD + CB_H(h)];
+                    const float* vp = &sV[j * CB_LD + CB_H(h)];
                     float s = 0.f, dp = 0.f;
 #pragma unroll
                     for (int c = 0; c < 32; ++c) { s += qr[c] * kp[c]; dp += dor[c] * vp[c]; }
@@ -480,8 +486,8 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kv_kernel(const float* __r
                                                                 int gate_col, const int* desc, float scale,
                                                                 const float* lse, const float* __restrict__ dO,
                                                                 const float* Dv, float* dkv, int qsplit, float* part, int part_rows) {
-    __shared__ __attribute__((aligned(16))) float sQ[CB_KT * 128];
-    __shared__ __attribute__((aligned(16))) float sDO[CB_KT * 128];
+    __shared__ __attribute__((aligned(16))) float sQ[CB_KT * CB_LD];
+    __shared__ __attribute__((aligned(16))) float sDO[CB_KT * CB_LD];
     __shared__ float sL[CB_KT * 4], sD[CB_KT * 4];
     const int* ds = desc + blockIdx.y * 8;
     const int q_off = ds[0], nq = ds[1], k_off = ds[2], nk = ds[3];
@@ -513,8 +519,8 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kv_kernel(const float* __r
                 qq = *(const float4*)(qg + (size_t)(q_off + i0 + ir) * ldq + c4);
                 dd_ = *(const float4*)(dO + (size_t)(q_off + i0 + ir) * 128 + c4);
             }
-            *(float4*)(&sQ[ir * 128 + c4]) = qq;
-            *(float4*)(&sDO[ir * 128 + c4]) = dd_;
+            *(float4*)(&sQ[ir * CB_LD + CB_COL(c4)]) = qq;
+            *(float4*)(&sDO[ir * CB_LD + CB_COL(c4)]) = dd_;
         }
         if (tid < CB_KT * 4) {
             int ir = tid >> 2;
@@ -537,8 +543,8 @@ __global__ __launch_bounds__(256) void cross_attn_bwd_kv_kernel(const float* __r
             for (int u = 0; u < 8; ++u) {
                 const int i = ig + u;
                 if (i < in_) {
-                    const float* qp = &sQ[i * 128 + h * 32];
-                    const float* dp_ = &sDO[i * 128 + h * 32];
+                    const float* qp = &sQ[i * CB_LD + CB_H(h)];
+                    const float* dp_ = &sDO[i * CB_LD + CB_H(h)];
                     float s = 0.f, dp = 0.f;
 #pragma unroll
                     for (int c = 0; c < 32; ++c) { s += qp[c] * kr[c]; dp += dp_[c] * vr[c]; }
