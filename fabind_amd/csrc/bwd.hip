@@ -625,6 +625,74 @@ extern "C" int fabind_cross_attn_bwd(const float* qg, int ldq, const float* kv, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Operands of the pair-bias adjoint with all attention blocks concatenated along K (bf16 training path).
+//   Acat [sum_b P_b, nblk*Kp]:  Acat[poff_b + i, k*Kp + j*8 + o] = dout_k[pair(b,i,j), o]      (0 for j >= C_b; Kp = 8*max_C -> %32)
+//   BTcat[B*H,       nblk*Kp]:  BTcat[b*H + h,   k*Kp + j*8 + o] = b0[lig_j, h] * wcomp[k, o, h]
+// so that  d a0[protein rows of b] += Acat_b . BTcat_b^T  is ONE plain-group GEMM (one accumulating epilogue pass over the
+// strided fp32 gradient instead of one per block), and the per-block  T_k = D_k^T a0  contractions read the column slice k of
+// Acat (ldy = nblk*Kp).  A row of dout_k for a (protein i, all ligand j, o) is contiguous, so both kernels move 16-B chunks.
+// ------------------------------------------------------------------------------------------------
+struct PbCatPtrs { const float* d[16]; };
+__global__ __launch_bounds__(256) void pair_bias_dcat_kernel(PbCatPtrs ptrs, int nblk, const int* __restrict__ desc_p, int max_P,
+                                                             int Kp, bf16_t* __restrict__ Acat, int lda) {
+    const int* ds = desc_p + blockIdx.y * 8;
+    const int poff = ds[0], P = ds[1], C = ds[3];
+    const long pair_off = (long)(unsigned)ds[4] | ((long)ds[5] << 32);
+    const int cpr = Kp >> 3;                                        // 8-element chunks per (row, block)
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_row = (long)nblk * cpr;
+    const int i = (int)(idx / per_row);
+    if (i >= P) return;
+    const int rem = (int)(idx % per_row), k = rem / cpr, j = rem % cpr;
+    uint4 u = make_uint4(0u, 0u, 0u, 0u);
+    const float* d = ptrs.d[k];
+    if (j < C && d != nullptr) {
+        const float* src = d + ((size_t)(pair_off + (long)i * C + j)) * 8;
+        const float4 x = *(const float4*)src, y = *(const float4*)(src + 4);
+        u.x = pack2_bf16(x.x, x.y); u.y = pack2_bf16(x.z, x.w); u.z = pack2_bf16(y.x, y.y); u.w = pack2_bf16(y.z, y.w);
+    }
+    *(uint4*)(Acat + (size_t)(poff + i) * lda + k * Kp + j * 8) = u;
+}
+__global__ __launch_bounds__(256) void pair_bias_btcat_kernel(const float* __restrict__ b0, int ld_ab, const int* __restrict__ c_index,
+                                                              const int* __restrict__ desc_p, const float* __restrict__ wcomp,
+                                                              int nblk, int H, int Kp, bf16_t* __restrict__ BTcat, int ldb) {
+    const int* ds = desc_p + blockIdx.y * 8;
+    const int coff = ds[2], C = ds[3];
+    const int cpr = Kp >> 3;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_h = (long)nblk * cpr;
+    const int h = (int)(idx / per_h);
+    if (h >= H) return;
+    const int rem = (int)(idx % per_h), k = rem / cpr, j = rem % cpr;
+    uint4 u = make_uint4(0u, 0u, 0u, 0u);
+    if (j < C) {
+        const float bv = b0[(size_t)c_index[coff + j] * ld_ab + h];
+        const float* w = wcomp + ((size_t)k * 8) * H + h;            // wcomp[k][o][h]
+        float v[8];
+#pragma unroll
+        for (int o = 0; o < 8; ++o) v[o] = bv * w[(size_t)o * H];
+        u.x = pack2_bf16(v[0], v[1]); u.y = pack2_bf16(v[2], v[3]); u.z = pack2_bf16(v[4], v[5]); u.w = pack2_bf16(v[6], v[7]);
+    }
+    *(uint4*)(BTcat + ((size_t)blockIdx.y * H + h) * ldb + k * Kp + j * 8) = u;
+}
+extern "C" int fabind_pair_bias_cat(const void* const* douts, int nblk, const int* desc_p, int B, int max_P, int Kp, void* Acat,
+                                    int lda, const float* b0, int ld_ab, const int* c_index, const float* wcomp, int H,
+                                    void* BTcat, int ldb, hipStream_t stream) {
+    if (B <= 0 || nblk <= 0) return 0;
+    FB_REQUIRE(nblk <= 16 && Kp % 32 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= nblk * Kp && ldb >= nblk * Kp,
+               "fabind_pair_bias_cat: nblk <= 16, Kp % 32 == 0, lda / ldb % 8 == 0 and >= nblk * Kp");
+    PbCatPtrs ptrs;
+    for (int k = 0; k < 16; ++k) ptrs.d[k] = k < nblk ? (const float*)douts[k] : nullptr;
+    const long cpr = Kp / 8;
+    hipLaunchKernelGGL(pair_bias_dcat_kernel, dim3((unsigned)(((long)max_P * nblk * cpr + 255) / 256), B), dim3(256), 0, stream, ptrs,
+                       nblk, desc_p, max_P, Kp, (bf16_t*)Acat, lda);
+    hipLaunchKernelGGL(pair_bias_btcat_kernel, dim3((unsigned)(((long)H * nblk * cpr + 255) / 256), B), dim3(256), 0, stream, b0, ld_ab,
+                       c_index, desc_p, wcomp, nblk, H, Kp, (bf16_t*)BTcat, ldb);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // adjoint of pair_hadamard: hd[e, 0:H] = a0[p]*b0[c], hd[e, H:H+H2] = a1[p]*b1[c]
 // (float atomics: every node collects the few pairs it belongs to)
 // ------------------------------------------------------------------------------------------------

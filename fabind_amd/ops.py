@@ -696,9 +696,10 @@ def _pair_bias_fwd(a0b0, H, wcomp, bconst, lay):
     return outs
 
 
-def _pair_bias_groups(lay, H, ld_ab):
-    """Ragged-batch descriptors of the two adjoint contractions (cached on the layout)."""
-    key = ("pbg", H, ld_ab)
+def _pair_bias_groups(lay, H, ld_ab, nblk, Kp):
+    """Ragged-batch descriptors of the adjoint contractions (cached on the layout): the grouped TN contraction T_k = D_k^T a0
+    reading column slice k of the K-concatenated operand (row stride nblk*Kp), and the plain-group GEMM d a0 += Acat . BTcat^T."""
+    key = ("pbg", H, ld_ab, nblk, Kp)
     if getattr(lay, "_pbg_key", None) != key:
         import numpy as np
         B, NO = lay.B, 8
@@ -706,15 +707,15 @@ def _pair_bias_groups(lay, H, ld_ab):
         hi = lambda v: int(v) >> 32
         s32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v
         dev = lay.node_off.device
-        tn, nn = [], []
+        poff = np.concatenate([[0], np.cumsum(lay.P)])
+        tn, cat = [], []
         for b in range(B):
             C_, P_ = int(lay.C[b]), int(lay.P[b])
-            yoff, coff8 = int(lay.pair_off_np[b]) * NO, int(lay.coff[b]) * NO
-            tn.append([s32(lo(yoff)), hi(yoff), C_ * NO, C_ * NO, int(lay.off[b]) + C_, P_, s32(lo(coff8 * H)), hi(coff8 * H)])
+            yoff, coff8 = int(poff[b]) * nblk * Kp, int(lay.coff[b]) * NO
+            tn.append([s32(lo(yoff)), hi(yoff), nblk * Kp, C_ * NO, int(lay.off[b]) + C_, P_, s32(lo(coff8 * H)), hi(coff8 * H)])
             co = (int(lay.off[b]) + C_) * ld_ab
-            nn.append([P_, H, C_ * NO, C_ * NO, s32(lo(yoff)), hi(yoff), s32(lo(coff8)), hi(coff8), s32(lo(co)), hi(co), ld_ab,
-                       0, 0, 0, 0, 0])
-        lay._pbg = (torch.tensor(tn, dtype=torch.int32, device=dev), torch.tensor(nn, dtype=torch.int32, device=dev))
+            cat.append([int(poff[b]), P_, b * H, H, s32(lo(co)), hi(co), ld_ab, 0])
+        lay._pbg = (torch.tensor(tn, dtype=torch.int32, device=dev), torch.tensor(cat, dtype=torch.int32, device=dev))
         lay._pbg_key = key
     return lay._pbg
 
@@ -735,24 +736,32 @@ class _PairBias(torch.autograd.Function):
         da0b0 = torch.zeros_like(a0b0)
         dwcomp = torch.zeros_like(wcomp)
         dbconst = torch.zeros((nblk, NO), dtype=torch.float32, device=dev)
-        bf16 = _cfg.get_precision() == "bf16" and NO == 8 and H % 8 == 0
+        bf16 = _cfg.get_precision() == "bf16" and NO == 8 and H % 8 == 0 and nblk <= 16
         if bf16:
-            tn_g, nn_g = _pair_bias_groups(lay, H, a0b0.stride(0))
+            # all blocks at once: the gradients of every block, bf16, concatenated along K and padded per complex (Acat) and
+            # the matching b0 * wcomp operand (BTcat) -> d a0 is ONE plain-group GEMM on the pipelined kernel (one accumulating
+            # epilogue pass over the strided fp32 gradient instead of one per block); T_k = D_k^T a0 reads column slice k
+            Kp = (lay.max_C * NO + 31) // 32 * 32
+            tn_g, cat_g = _pair_bias_groups(lay, H, a0b0.stride(0), nblk, Kp)
             a16 = a0b0.to(torch.bfloat16)
             T = torch.empty((lay.sumC * NO, H), dtype=torch.float32, device=dev)
+            ds = [None if d is None else d.contiguous() for d in douts]
+            Acat = torch.empty((lay.sumP, nblk * Kp), dtype=torch.bfloat16, device=dev)
+            BTcat = torch.empty((lay.B * H, nblk * Kp), dtype=torch.bfloat16, device=dev)
+            ptrs = (ctypes.c_void_p * nblk)(*[None if d is None else d.data_ptr() for d in ds])
+            wc = wcomp.contiguous()
+            check(load().fabind_pair_bias_cat(ptrs, nblk, ptr(lay.desc_p), lay.B, lay.max_P, Kp, ptr(Acat), Acat.stride(0),
+                                              ptr(a0b0[:, H:]), a0b0.stride(0), ptr(lay.c_index), ptr(wc), H, ptr(BTcat),
+                                              BTcat.stride(0), stream()), "fabind_pair_bias_cat")
+            K.gemm(Acat, BTcat, out=da0b0, accumulate=True, groups=cat_g, n_groups=lay.B, max_m=lay.max_P, max_n=H,
+                   M=lay.sumP, N=lay.B * H, ldc=a0b0.stride(0))
         for k, dout in enumerate(douts):
             if dout is None:
                 continue
             dout = dout.contiguous()
             dbconst[k] = K.colsum(dout)
             if bf16:
-                # da0[i,:] += D[i,(j,o)] Bmat[(j,o),:]  and  T = D^T a0  as ragged-batched MFMA contractions
-                D16 = dout.to(torch.bfloat16)
-                bmat = K.pair_bmat(a0b0[:, H:], wcomp[k], lay.c_index, torch.bfloat16)          # [(sumC*8), H]
-                bmT = _transposed(bmat, Rp=(bmat.shape[0] + 63) // 64 * 64)                      # [H, sumC*8 (padded)]
-                K.gemm(D16, bmT, out=da0b0, accumulate=True, groups=nn_g, groups_ext=True, n_groups=lay.B,
-                       max_m=lay.max_P, max_n=H, M=lay.max_P, N=H, ldc=a0b0.stride(0))
-                K.gemm_tn_grouped(D16, a16[:, :H], tn_g, lay.B, lay.max_C * NO, H, T, lay.max_P)
+                K.gemm_tn_grouped(Acat[:, k * Kp:], a16[:, :H], tn_g, lay.B, lay.max_C * NO, H, T, lay.max_P)
                 check(load().fabind_pair_bias_finish(ptr(T), ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.c_index),
                                                      lay.sumC, ptr(da0b0), ptr(dwcomp[k]), stream()), "fabind_pair_bias_finish")
             else:

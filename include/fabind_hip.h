@@ -356,6 +356,14 @@ int fabind_cross_attn_bwd(const float* qg, int ldq, const float* kv, int ldkv, c
                           int lin_col, int gate_col, const int* desc, int B, int max_nq, int max_nk, float scale,
                           const float* out, const float* lse, const float* dout, float* dqg, float* dkv, float* dbias,
                           float* dO, float* Dv, float* scratch, hipStream_t stream);
+/* Operands of the pair-bias adjoint (autograd of the pair bias of RowAttentionBlock, cross_att.py:125, all attention blocks at
+ * once) concatenated along K, bf16:  Acat[poff_b + i, k*Kp + j*8 + o] = douts[k][pair(b,i,j), o],
+ * BTcat[b*H + h, k*Kp + j*8 + o] = b0[ligand j of b, h] * wcomp[k][o][h]  (zeros for j >= C_b; Kp = 8 * max_C rounded up to 32).
+ * douts: HOST array of nblk device pointers (fp32 [n_pairs, 8] each, NULL = no gradient); desc_p: the block descriptors of
+ * fabind_cross_attn_fwd with the protein side compact. */
+int fabind_pair_bias_cat(const void* const* douts, int nblk, const int* desc_p, int B, int max_P, int Kp, void* Acat, int lda,
+                         const float* b0, int ld_ab, const int* c_index, const float* wcomp, int H, void* BTcat, int ldb,
+                         hipStream_t stream);
 int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const float* a0, const float* b0, int ld0, int H,
                              const float* a1, const float* b1, int ld1, int H2, const int* red_p, const int* red_c, int n,
                              float* da0, float* db0, int ldd0, float* da1, float* db1, int ldd1, hipStream_t stream);
