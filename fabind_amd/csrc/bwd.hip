@@ -675,6 +675,45 @@ __global__ __launch_bounds__(256) void pair_bias_btcat_kernel(const float* __res
     }
     *(uint4*)(BTcat + ((size_t)blockIdx.y * H + h) * ldb + k * Kp + j * 8) = u;
 }
+// Batched tiled transpose, bf16, with zero padding of the new inner dimension: for z = (b, k) (k < nsub)
+//   out[(k*B + b)*cols + m][i] = in[row0_b + i][k*cols + m]   for i < P_b,   0 for P_b <= i < Pp
+// (row0_b, P_b) = desc[b][0..1].  Feeds the per-block T = D^T a0 contractions of the pair-bias adjoint to the pipelined NT GEMM:
+// K becomes the (padded) protein length, uniform over the complexes, so plain groups apply.  64 x 32 tiles through LDS, 16-byte
+// loads along the input rows and 16-byte stores along the output rows.
+__global__ __launch_bounds__(256) void batched_transpose_pad_kernel(const bf16_t* __restrict__ in, int ld_in, const int* __restrict__ desc,
+                                                                    int B, int nsub, int cols, int Pp, bf16_t* __restrict__ out) {
+    __shared__ bf16_t tile[64][40];                                  // 32 columns + padding (rows stay 16-byte aligned: 80 B)
+    const int b = blockIdx.z / nsub, k = blockIdx.z % nsub;
+    const int* ds = desc + b * 8;
+    const int row0 = ds[0], P = ds[1];
+    const int i0 = blockIdx.x * 64, m0 = blockIdx.y * 32;
+    const int t = threadIdx.x;
+    {
+        const int r = t >> 2, c8 = (t & 3) * 8;
+        uint4 u = make_uint4(0u, 0u, 0u, 0u);
+        if (i0 + r < P) u = *(const uint4*)(in + (size_t)(row0 + i0 + r) * ld_in + k * cols + m0 + c8);
+        *(uint4*)&tile[r][c8] = u;
+    }
+    __syncthreads();
+    {
+        const int m = t >> 3, i8 = (t & 7) * 8;
+        bf16_t v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = tile[i8 + q][m];
+        if (i0 + i8 < Pp)
+            *(uint4*)(out + ((size_t)(k * B + b) * cols + m0 + m) * Pp + i0 + i8) = *(const uint4*)v;
+    }
+}
+extern "C" int fabind_batched_transpose_pad(const void* in, int ld_in, const int* desc, int B, int nsub, int cols, int Pp, void* out,
+                                            hipStream_t stream) {
+    if (B <= 0 || nsub <= 0) return 0;
+    FB_REQUIRE(cols % 32 == 0 && Pp % 8 == 0 && ld_in % 8 == 0, "fabind_batched_transpose_pad: cols % 32, Pp % 8, ld_in % 8");
+    hipLaunchKernelGGL(batched_transpose_pad_kernel, dim3((Pp + 63) / 64, cols / 32, B * nsub), dim3(256), 0, stream, (const bf16_t*)in,
+                       ld_in, desc, B, nsub, cols, Pp, (bf16_t*)out);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int fabind_pair_bias_cat(const void* const* douts, int nblk, const int* desc_p, int B, int max_P, int Kp, void* Acat,
                                     int lda, const float* b0, int ld_ab, const int* c_index, const float* wcomp, int H,
                                     void* BTcat, int ldb, hipStream_t stream) {

@@ -697,8 +697,8 @@ def _pair_bias_fwd(a0b0, H, wcomp, bconst, lay):
 
 
 def _pair_bias_groups(lay, H, ld_ab, nblk, Kp):
-    """Ragged-batch descriptors of the adjoint contractions (cached on the layout): the grouped TN contraction T_k = D_k^T a0
-    reading column slice k of the K-concatenated operand (row stride nblk*Kp), and the plain-group GEMM d a0 += Acat . BTcat^T."""
+    """Plain-group descriptors of the two adjoint contractions (cached on the layout): d a0 += Acat . BTcat^T (all blocks
+    concatenated along K) and T_k = Dt_k . At^T (K = the padded protein length)."""
     key = ("pbg", H, ld_ab, nblk, Kp)
     if getattr(lay, "_pbg_key", None) != key:
         import numpy as np
@@ -708,14 +708,15 @@ def _pair_bias_groups(lay, H, ld_ab, nblk, Kp):
         s32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v
         dev = lay.node_off.device
         poff = np.concatenate([[0], np.cumsum(lay.P)])
-        tn, cat = [], []
+        cat, tg = [], []
         for b in range(B):
             C_, P_ = int(lay.C[b]), int(lay.P[b])
-            yoff, coff8 = int(poff[b]) * nblk * Kp, int(lay.coff[b]) * NO
-            tn.append([s32(lo(yoff)), hi(yoff), nblk * Kp, C_ * NO, int(lay.off[b]) + C_, P_, s32(lo(coff8 * H)), hi(coff8 * H)])
+            coff8 = int(lay.coff[b]) * NO
             co = (int(lay.off[b]) + C_) * ld_ab
             cat.append([int(poff[b]), P_, b * H, H, s32(lo(co)), hi(co), ld_ab, 0])
-        lay._pbg = (torch.tensor(tn, dtype=torch.int32, device=dev), torch.tensor(cat, dtype=torch.int32, device=dev))
+            # T_k[(j,o), :] of complex b = Dt_k[b*Kp + (j,o), :] . At[b*H + h, :]^T  (K = padded protein length)
+            tg.append([b * Kp, C_ * NO, b * H, H, s32(lo(coff8 * H)), hi(coff8 * H), H, 0])
+        lay._pbg = (torch.tensor(cat, dtype=torch.int32, device=dev), torch.tensor(tg, dtype=torch.int32, device=dev))
         lay._pbg_key = key
     return lay._pbg
 
@@ -742,7 +743,7 @@ class _PairBias(torch.autograd.Function):
             # the matching b0 * wcomp operand (BTcat) -> d a0 is ONE plain-group GEMM on the pipelined kernel (one accumulating
             # epilogue pass over the strided fp32 gradient instead of one per block); T_k = D_k^T a0 reads column slice k
             Kp = (lay.max_C * NO + 31) // 32 * 32
-            tn_g, cat_g = _pair_bias_groups(lay, H, a0b0.stride(0), nblk, Kp)
+            cat_g, t_g = _pair_bias_groups(lay, H, a0b0.stride(0), nblk, Kp)
             a16 = a0b0.to(torch.bfloat16)
             T = torch.empty((lay.sumC * NO, H), dtype=torch.float32, device=dev)
             ds = [None if d is None else d.contiguous() for d in douts]
@@ -755,13 +756,21 @@ class _PairBias(torch.autograd.Function):
                                               BTcat.stride(0), stream()), "fabind_pair_bias_cat")
             K.gemm(Acat, BTcat, out=da0b0, accumulate=True, groups=cat_g, n_groups=lay.B, max_m=lay.max_P, max_n=H,
                    M=lay.sumP, N=lay.B * H, ldc=a0b0.stride(0))
+            # the T_k = D_k^T a0 contractions on the pipelined NT kernel: K-major, uniformly padded copies of both operands
+            Pp = (lay.max_P + 31) // 32 * 32
+            Dt = torch.empty((nblk, lay.B * Kp, Pp), dtype=torch.bfloat16, device=dev)
+            At = torch.empty((lay.B * H, Pp), dtype=torch.bfloat16, device=dev)
+            check(load().fabind_batched_transpose_pad(ptr(Acat), Acat.stride(0), ptr(lay.desc_p), lay.B, nblk, Kp, Pp, ptr(Dt),
+                                                      stream()), "fabind_batched_transpose_pad")
+            check(load().fabind_batched_transpose_pad(ptr(a16), a16.stride(0), ptr(lay.desc_pf), lay.B, 1, H, Pp, ptr(At), stream()),
+                  "fabind_batched_transpose_pad")
         for k, dout in enumerate(douts):
             if dout is None:
                 continue
             dout = dout.contiguous()
             dbconst[k] = K.colsum(dout)
             if bf16:
-                K.gemm_tn_grouped(Acat[:, k * Kp:], a16[:, :H], tn_g, lay.B, lay.max_C * NO, H, T, lay.max_P)
+                K.gemm(Dt[k], At, out=T, groups=t_g, n_groups=lay.B, max_m=lay.max_C * NO, max_n=H, M=lay.B * Kp, N=lay.B * H, ldc=H)
                 check(load().fabind_pair_bias_finish(ptr(T), ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.c_index),
                                                      lay.sumC, ptr(da0b0), ptr(dwcomp[k]), stream()), "fabind_pair_bias_finish")
             else:

@@ -364,6 +364,12 @@ int fabind_cross_attn_bwd(const float* qg, int ldq, const float* kv, int ldkv, c
 int fabind_pair_bias_cat(const void* const* douts, int nblk, const int* desc_p, int B, int max_P, int Kp, void* Acat, int lda,
                          const float* b0, int ld_ab, const int* c_index, const float* wcomp, int H, void* BTcat, int ldb,
                          hipStream_t stream);
+/* Batched transpose with zero padding, bf16: for b < B, k < nsub, m < cols:
+ *   out[(k*B + b)*cols + m][i] = in[desc[b][0] + i][k*cols + m]  for i < desc[b][1], 0 for i up to Pp   (out row stride Pp).
+ * Turns the row-major per-complex operands of the pair-bias adjoint into the K-major, uniformly padded layout the pipelined NT GEMM
+ * takes with plain groups. */
+int fabind_batched_transpose_pad(const void* in, int ld_in, const int* desc, int B, int nsub, int cols, int Pp, void* out,
+                                 hipStream_t stream);
 int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const float* a0, const float* b0, int ld0, int H,
                              const float* a1, const float* b1, int ld1, int H2, const int* red_p, const int* red_c, int n,
                              float* da0, float* db0, int ldd0, float* da1, float* db1, int ldd1, hipStream_t stream);
