@@ -406,14 +406,3 @@ def gemm_tn(Y, X, splits=None):
     if splits == 1:
         return part[0]
     return colsum(part.reshape(splits, M * N)).reshape(M, N)
-
-
-def gemm_tn_grouped(Y, X, groups, n_groups, max_M, N, out, max_E):
-    """Ragged batch of TN contractions (one per complex); descriptors as in fabind_gemm_tn."""
-    dev = Y.device
-    zp = _ZERO_PAGE.get(dev)
-    if zp is None:
-        zp = _ZERO_PAGE[dev] = torch.zeros(256, dtype=torch.bfloat16, device=dev)
-    check(_lib.load().fabind_gemm_tn(ptr(Y), 8, ptr(X), _ld(X), ptr(out), max_M, N, max_E, 1, ptr(zp), ptr(groups), n_groups,
-                                     stream()), "fabind_gemm_tn(grouped)")
-    return out

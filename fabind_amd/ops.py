@@ -757,7 +757,7 @@ class _PairBias(torch.autograd.Function):
             K.gemm(Acat, BTcat, out=da0b0, accumulate=True, groups=cat_g, n_groups=lay.B, max_m=lay.max_P, max_n=H,
                    M=lay.sumP, N=lay.B * H, ldc=a0b0.stride(0))
             # the T_k = D_k^T a0 contractions on the pipelined NT kernel: K-major, uniformly padded copies of both operands
-            Pp = (lay.max_P + 31) // 32 * 32
+            Pp = (lay.max_P + 63) // 64 * 64          # K of these contractions: a multiple of 64 selects the LDS-DMA pipelined kernel
             Dt = torch.empty((nblk, lay.B * Kp, Pp), dtype=torch.bfloat16, device=dev)
             At = torch.empty((lay.B * H, Pp), dtype=torch.bfloat16, device=dev)
             check(load().fabind_batched_transpose_pad(ptr(Acat), Acat.stride(0), ptr(lay.desc_p), lay.B, nblk, Kp, Pp, ptr(Dt),
