@@ -605,18 +605,24 @@ def rows_hadamard(t, idx_a, idx_b):
 
 class _InterAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext=None):
+    def forward(ctx, qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext=None, Wc=None, bc=None):
+        v_in = None
+        if Wc is not None:
+            # cv = Linear(V) (egnn.py:225) evaluated inside this node of the autograd graph: its input gradient then accumulates
+            # into the V columns of dqkv in place, instead of autograd padding it to [N,3H] and adding two [N,3H] tensors
+            v_in = _mm_in(qkv[:, 2 * H:])
+            cv, _ = K.gemm(v_in, Wc, bias=bc)
         h_out, x_out, alpha, cvs = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx,
                                                     bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext)
         ctx.g, ctx.H, ctx.clampv, ctx.np = g, H, clampv, bias_part.shape[1]
-        ctx.has_ext = s_ext is not None
-        ctx.save_for_backward(qkv, cv, d, rhohat, w_rk, w_rv, wcr, w3, alpha, cvs)
+        ctx.has_ext, ctx.has_cv = s_ext is not None, Wc is not None
+        ctx.save_for_backward(qkv, cv, d, rhohat, w_rk, w_rv, wcr, w3, alpha, cvs, v_in, Wc)
         ctx.mark_non_differentiable(alpha)
         return h_out, x_out, alpha
 
     @staticmethod
     def backward(ctx, dh_out, dx_out, _dalpha):
-        qkv, cv, d, rhohat, w_rk, w_rv, wcr, w3, alpha, cvs = ctx.saved_tensors
+        qkv, cv, d, rhohat, w_rk, w_rv, wcr, w3, alpha, cvs, v_in, Wc = ctx.saved_tensors
         g, H = ctx.g, ctx.H
         N, E = qkv.shape[0], g.col_int.shape[0]
         dev = qkv.device
@@ -637,15 +643,32 @@ class _InterAttn(torch.autograd.Function):
                                            ptr(dx_out), ptr(dqkv), ptr(dcv), ptr(dd), ptr(drh), ptr(dbias_red), ptr(dlogit),
                                            ptr(dcp), ptr(wpart), nblk, stream()), "fabind_inter_attn_bwd")
         dw = [K.colsum(wpart[i]) for i in range(4)]
+        dWc = dbc = None
+        if ctx.has_cv:                                               # adjoint of cv = V Wc^T + bc, dV added to dqkv[:, 2H:]
+            md = mm_dtype()
+            dpre, dbc = dcv, None
+            if dcv.dtype != md:
+                dpre, dbc = _mul_dact_colsum(dcv, None, K.ACT_NONE, md) if FUSE_DB else (_mul_dact(dcv, None, K.ACT_NONE, md), None)
+            K.gemm(dpre, Wc.t().contiguous(), out=dqkv[:, 2 * H:], accumulate=True)
+            if ctx.needs_input_grad[15]:
+                dWc = _weight_grad(dpre, v_in, K.ACT_NONE).to(Wc.dtype)
+            if ctx.needs_input_grad[16]:
+                dbc = dbc if dbc is not None else K.colsum(dpre)
+            else:
+                dbc = None
+            dcv = None
         return (dqkv, dcv, dh_out, dx_out, dd[:E], drh[:E], dbias_red[:n_red, None].expand(n_red, ctx.np), dw[0], dw[1],
-                dw[2], dw[3], None, None, None, dcp[:E] if ctx.has_ext else None)
+                dw[2], dw[3], None, None, None, dcp[:E] if ctx.has_ext else None, dWc, dbc)
 
 
-def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None):
+def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None, Wc=None, bc=None):
     """s_ext [E] (optional): per-edge scalar added to the coordinate-MLP value inside the kernel (FABind+ evaluates its
-    LN-MLP coord_mlp outside); differentiable."""
-    if _needs_grad(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, s_ext):
-        return _InterAttn.apply(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext)
+    LN-MLP coord_mlp outside); differentiable.  cv=None with (Wc, bc): cv = Linear(qkv[:, 2H:]) is evaluated here."""
+    assert (cv is None) != (Wc is None), "inter_attn: pass either cv or its Linear (Wc, bc)"
+    if _needs_grad(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, s_ext, Wc, bc):
+        return _InterAttn.apply(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext, Wc, bc)
+    if cv is None:
+        cv = linear(qkv[:, 2 * H:], Wc, bc)
     h_out, x_out, alpha, _ = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx, bias_part,
                                               w_rk, w_rv, wcr, w3, clampv, s_ext)
     return h_out, x_out, alpha
