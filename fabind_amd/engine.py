@@ -441,7 +441,8 @@ class StackContext:
         self.x_las = coord_LAS.reshape(-1, 3).float().contiguous()
         self.mask_u8 = mask.to(torch.uint8).contiguous()
         self.Hin = Hin.float().contiguous()
-        self.a0b0 = ops.linear(self.Hin, self.P["W_ab0"], self.P["b_ab0"])
+        # consumed by the pair biases once and by pair_hadamard in every layer: one shared gradient buffer (ops.GradSink)
+        self.a0b0 = ops.shared_grad(ops.linear(self.Hin, self.P["W_ab0"], self.P["b_ab0"]))
         self.pairbias = pair_bias_all(self.P, self.a0b0, lay)
         self.cut_intra = float(model.extract_edges.intra_cutoff)
         self.cut_inter = float(model.extract_edges.inter_cutoff)

@@ -509,6 +509,55 @@ def select_rows(x, z, mask_u8):
 # ------------------------------------------------------------------------------------------------
 # attention ops
 # ------------------------------------------------------------------------------------------------
+class GradSink:
+    """Shared gradient buffer of a tensor with several consumers whose adjoint kernels ACCUMULATE (atomics / accumulating GEMM
+    epilogues): the first consumer whose backward runs allocates the zeroed buffer and hands it to autograd as its gradient;
+    the others add into the same buffer and return None, so autograd neither pads nor sums [N, 2H] tensors.  All of them run
+    on one stream before the producer's backward reads the buffer; `_SinkOwner` drops the reference once autograd has
+    collected it, so a second backward over a retained graph starts from a fresh buffer."""
+
+    def __init__(self):
+        self.buf = None
+
+    def take(self, like):
+        """-> (buffer, True if this call created it and must return it as the gradient)."""
+        if self.buf is None:
+            self.buf = torch.zeros_like(like)
+            return self.buf, True
+        return self.buf, False
+
+
+class _SinkOwner(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, sink):
+        ctx.sink = sink
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.sink.buf = None
+        return g, None
+
+
+def shared_grad(t):
+    """Mark t (about to be consumed several times by sink-aware ops) as having a shared gradient buffer."""
+    if not (torch.is_grad_enabled() and t.requires_grad):
+        return t
+    sink = GradSink()
+    out = _SinkOwner.apply(t, sink)
+    out._fab_gsink = sink
+    return out
+
+
+def _sink_zeros(t, sink):
+    """Gradient buffer of t for an accumulating adjoint: (buffer, what to return to autograd)."""
+    if sink is None:
+        buf = torch.zeros_like(t)
+        return buf, buf
+    buf, first = sink.take(t)
+    return buf, (buf if first else None)
+
+
 class _CrossAttn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qg, kv, bias, lin_col, gate_col, desc, B, max_nq, max_nk, scale):
@@ -551,6 +600,7 @@ class _PairHadamard(torch.autograd.Function):
     @staticmethod
     def forward(ctx, T0, T1, H, H2, red_p, red_c):
         ctx.dims = (H, H2)
+        ctx.sink = getattr(T0, "_fab_gsink", None)        # shared gradient buffer of T0 (shared_grad), or None
         ctx.save_for_backward(T0, T1, red_p, red_c)
         return K.pair_hadamard(T0[:, :H], T0[:, H:], T1[:, :H2], T1[:, H2:], red_p, red_c, act_dtype())
 
@@ -559,12 +609,13 @@ class _PairHadamard(torch.autograd.Function):
         T0, T1, red_p, red_c = ctx.saved_tensors
         H, H2 = ctx.dims
         dhd = dhd.contiguous()
-        d0, d1 = torch.zeros_like(T0), torch.zeros_like(T1)
+        d0, d0_ret = _sink_zeros(T0, ctx.sink)           # the kernel adds into d0 / d1 (atomics)
+        d1 = torch.zeros_like(T1)
         check(load().fabind_pair_hadamard_bwd(
             ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(T0[:, :H]), ptr(T0[:, H:]), T0.stride(0), H, ptr(T1[:, :H2]),
             ptr(T1[:, H2:]), T1.stride(0), H2, ptr(red_p), ptr(red_c), red_p.shape[0], ptr(d0[:, :H]), ptr(d0[:, H:]),
             d0.stride(0), ptr(d1[:, :H2]), ptr(d1[:, H2:]), d1.stride(0), stream()), "fabind_pair_hadamard_bwd")
-        return d0, d1, None, None, None, None
+        return d0_ret, d1, None, None, None, None
 
 
 def pair_hadamard(a0b0, H, ab32, H2, red_p, red_c):
@@ -748,6 +799,7 @@ class _PairBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a0b0, wcomp, bconst, H, lay):
         ctx.H, ctx.lay = H, lay
+        ctx.sink = getattr(a0b0, "_fab_gsink", None)      # shared gradient buffer of a0b0 (shared_grad), or None
         ctx.save_for_backward(a0b0, wcomp)
         return tuple(_pair_bias_fwd(a0b0.detach(), H, wcomp.detach(), bconst.detach(), lay))
 
@@ -757,7 +809,7 @@ class _PairBias(torch.autograd.Function):
         H, lay = ctx.H, ctx.lay
         nblk, NO, _ = wcomp.shape
         dev = a0b0.device
-        da0b0 = torch.zeros_like(a0b0)
+        da0b0, da0b0_ret = _sink_zeros(a0b0, ctx.sink)    # every writer below accumulates (+=, accumulating GEMM, atomics)
         dwcomp = torch.zeros_like(wcomp)
         dbconst = torch.zeros((nblk, NO), dtype=torch.float32, device=dev)
         bf16 = _cfg.get_precision() == "bf16" and NO == 8 and H % 8 == 0 and nblk <= 16
@@ -802,7 +854,7 @@ class _PairBias(torch.autograd.Function):
                                                   lay.B, lay.max_P, lay.max_C, ptr(lay.p_index), ptr(lay.c_index), ptr(da0b0),
                                                   ptr(dwk), stream()), "fabind_pair_bias_bwd")
                 dwcomp[k] = K.colsum(dwk).reshape(NO, H)
-        return da0b0, dwcomp, dbconst, None, None
+        return da0b0_ret, dwcomp, dbconst, None, None
 
 
 def pair_bias(a0b0, H, wcomp, bconst, lay):

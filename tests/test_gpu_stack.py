@@ -193,6 +193,36 @@ def test_stack_gradients_match_reference():
     assert not bad, bad
 
 
+def test_backward_twice_over_a_retained_graph_gives_the_same_gradients():
+    """The shared gradient buffer of the per-node pair projections (ops.GradSink: several accumulating adjoints add into ONE
+    buffer instead of autograd summing padded copies) must be released after every backward pass: a second backward over the
+    retained graph has to reproduce the first one's gradients, not add to a stale buffer.  Also in bf16 mode (its own path)."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    g = load_npz("stack_tiny_grad")
+    for prec in ("fp32", "bf16"):
+        engine.set_precision(prec)
+        try:
+            m = _build_stack(g, dev)
+            inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in stack_inputs(g).items()}
+            Hin = inp["H"].clone().requires_grad_(True)
+            X, H = m(inp["X"].clone(), Hin, inp["batch_id"], inp["segment_id"], inp["mask"], inp["is_global"],
+                     inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"])
+            loss = (X * torch.from_numpy(g["cot_X"]).to(dev)).sum() + (H * torch.from_numpy(g["cot_H"]).to(dev)).sum()
+            params = [p for p in m.parameters() if p.requires_grad]
+            first = torch.autograd.grad(loss, [Hin] + params, retain_graph=True, allow_unused=True)
+            second = torch.autograd.grad(loss, [Hin] + params, retain_graph=False, allow_unused=True)
+            assert any(a is not None for a in first)
+            for a, b in zip(first, second):
+                assert (a is None) == (b is None)
+                if a is not None:
+                    # float atomics in some adjoints reorder sums between runs: equal to round-off, not bitwise
+                    tol = (1e-5 if prec == "fp32" else 1e-3) * max(float(a.abs().max()), 1e-12)
+                    assert float((a - b).abs().max()) <= tol, (prec, float((a - b).abs().max()), float(a.abs().max()))
+        finally:
+            engine.set_precision("fp32")
+
+
 def _random_stack(H, L, it, seed):
     from fabind_amd.models.att_model import EfficientMCAttModel
     torch.manual_seed(seed)
