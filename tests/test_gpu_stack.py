@@ -193,34 +193,57 @@ def test_stack_gradients_match_reference():
     assert not bad, bad
 
 
-def test_backward_twice_over_a_retained_graph_gives_the_same_gradients():
+def _double_backward(prec, dev, g):
+    """Two backward passes over one retained graph -> [(name, first, second)] for the input and every parameter."""
+    from fabind_amd import engine
+    engine.set_precision(prec)
+    try:
+        m = _build_stack(g, dev)
+        inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in stack_inputs(g).items()}
+        Hin = inp["H"].clone().requires_grad_(True)
+        X, H = m(inp["X"].clone(), Hin, inp["batch_id"], inp["segment_id"], inp["mask"], inp["is_global"],
+                 inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"])
+        loss = (X * torch.from_numpy(g["cot_X"]).to(dev)).sum() + (H * torch.from_numpy(g["cot_H"]).to(dev)).sum()
+        named = [("input_H", Hin)] + [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+        ts = [t for _, t in named]
+        first = torch.autograd.grad(loss, ts, retain_graph=True, allow_unused=True)
+        second = torch.autograd.grad(loss, ts, retain_graph=False, allow_unused=True)
+        return [(n, a, b) for (n, _), a, b in zip(named, first, second)]
+    finally:
+        engine.set_precision("fp32")
+
+
+def _passes_differ(triples):
+    """Names of the gradients that differ between the two passes beyond summation-order noise.  Float atomics in some adjoints
+    reorder sums between runs: measured over 20 repetitions (tests/probe_retained_graph_spread.py) the passes differ by at most
+    4.7e-8 (fp32) / 3.6e-11 (bf16) of the model's LARGEST gradient magnitude; relative to a tensor's own maximum the figure is
+    meaningless for the biases whose true gradient is zero (softmax shift invariance: 1.8e-4 of round-off).  Hence two terms:
+    1e-3 of the tensor's own maximum + 1e-6 of the largest one.  A stale shared buffer changes the affected gradients by 100 %."""
+    gmax = max(float(a.abs().max()) for _, a, _ in triples if a is not None)
+    bad = []
+    for n, a, b in triples:
+        if (a is None) != (b is None):
+            bad.append(n)
+        elif a is not None and float((a - b).abs().max()) > 1e-3 * float(a.abs().max()) + 1e-6 * gmax:
+            bad.append(n)
+    return bad
+
+
+def test_backward_twice_over_a_retained_graph_gives_the_same_gradients(monkeypatch):
     """The shared gradient buffer of the per-node pair projections (ops.GradSink: several accumulating adjoints add into ONE
     buffer instead of autograd summing padded copies) must be released after every backward pass: a second backward over the
-    retained graph has to reproduce the first one's gradients, not add to a stale buffer.  Also in bf16 mode (its own path)."""
-    from fabind_amd import engine
+    retained graph has to reproduce the first one's gradients, not add to (or be swallowed by) a stale buffer.  fp32 and bf16
+    (separate adjoint paths).  The test checks itself: with the release disabled the same comparison must fail."""
+    from fabind_amd import ops
     dev = torch.device("cuda:0")
     g = load_npz("stack_tiny_grad")
     for prec in ("fp32", "bf16"):
-        engine.set_precision(prec)
-        try:
-            m = _build_stack(g, dev)
-            inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in stack_inputs(g).items()}
-            Hin = inp["H"].clone().requires_grad_(True)
-            X, H = m(inp["X"].clone(), Hin, inp["batch_id"], inp["segment_id"], inp["mask"], inp["is_global"],
-                     inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"])
-            loss = (X * torch.from_numpy(g["cot_X"]).to(dev)).sum() + (H * torch.from_numpy(g["cot_H"]).to(dev)).sum()
-            params = [p for p in m.parameters() if p.requires_grad]
-            first = torch.autograd.grad(loss, [Hin] + params, retain_graph=True, allow_unused=True)
-            second = torch.autograd.grad(loss, [Hin] + params, retain_graph=False, allow_unused=True)
-            assert any(a is not None for a in first)
-            for a, b in zip(first, second):
-                assert (a is None) == (b is None)
-                if a is not None:
-                    # float atomics in some adjoints reorder sums between runs: equal to round-off, not bitwise
-                    tol = (1e-5 if prec == "fp32" else 1e-3) * max(float(a.abs().max()), 1e-12)
-                    assert float((a - b).abs().max()) <= tol, (prec, float((a - b).abs().max()), float(a.abs().max()))
-        finally:
-            engine.set_precision("fp32")
+        triples = _double_backward(prec, dev, g)
+        assert any(a is not None for _, a, _ in triples)
+        assert _passes_differ(triples) == [], (prec, _passes_differ(triples))
+    # mutation: keep the buffer reference across passes -> the second pass must come out different
+    monkeypatch.setattr(ops._SinkOwner, "backward", staticmethod(lambda ctx, grad: (grad, None)))
+    assert _passes_differ(_double_backward("fp32", dev, g)) != [], "the comparison cannot see a stale shared gradient buffer"
 
 
 def _random_stack(H, L, it, seed):
