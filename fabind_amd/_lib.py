@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfabind_hip.so")
 
-ABI_VERSION = 3          # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
+ABI_VERSION = 4          # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -85,7 +85,7 @@ SIGNATURES = {
     "fabind_coord_update_bwd": [_vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp],
     "fabind_cross_attn_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                               _vp, _vp, _vp],
-    "fabind_pair_bias_cat": [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp],
+    "fabind_pair_bias_cat": [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "fabind_batched_transpose_pad": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp],
     "fabind_pair_hadamard_bwd": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,
                                  _vp],
@@ -119,6 +119,7 @@ def load():
                            % (LIB_PATH, got, ABI_VERSION))
     lib.fabind_sizeof_args.argtypes, lib.fabind_sizeof_args.restype = [ctypes.c_int], ctypes.c_int
     lib.fabind_cross_attn_bwd_scratch.argtypes, lib.fabind_cross_attn_bwd_scratch.restype = [_i, _i, _i], ctypes.c_long
+    lib.fabind_pair_bias_cat_parts.argtypes, lib.fabind_pair_bias_cat_parts.restype = [_i, _i], ctypes.c_long
     for which, mirror in enumerate((GemmArgs, EdgeBwdArgs, PairUpdateArgs)):
         if lib.fabind_sizeof_args(which) != ctypes.sizeof(mirror):
             raise RuntimeError("fabind_amd: ctypes mirror %s is %d bytes, the library's struct is %d -- _lib.py and "
@@ -128,6 +129,8 @@ def load():
     lib.fabind_gemm_set_config.restype = None
     lib.fabind_gemm_set_persistent.argtypes = [ctypes.c_int]
     lib.fabind_gemm_set_persistent.restype = None
+    lib.fabind_gemm_tn_set_waves.argtypes = [ctypes.c_int]
+    lib.fabind_gemm_tn_set_waves.restype = None
     for name, argt in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = argt

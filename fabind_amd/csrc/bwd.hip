@@ -633,25 +633,49 @@ extern "C" int fabind_cross_attn_bwd(const float* qg, int ldq, const float* kv, 
 // Acat (ldy = nblk*Kp).  A row of dout_k for a (protein i, all ligand j, o) is contiguous, so both kernels move 16-B chunks.
 // ------------------------------------------------------------------------------------------------
 struct PbCatPtrs { const float* d[16]; };
-__global__ __launch_bounds__(256) void pair_bias_dcat_kernel(PbCatPtrs ptrs, int nblk, const int* __restrict__ desc_p, int max_P,
-                                                             int Kp, bf16_t* __restrict__ Acat, int lda) {
+// Thread c owns column chunk c = (block k, ligand atom j) for a strip of PB_ROWS protein rows: 32-B loads and 16-B stores are
+// contiguous across the threads of a row, and the eight column sums of the fp32 values it reads (the gradient of the pair-bias
+// constants is the column sum of every dout_k) accumulate in registers -- one plain LDS tree per work-group, no atomics.
+// colpart (optional): [gridDim.y * gridDim.x][nblk * 8] per-work-group partial sums, added up by the caller in a fixed order.
+#define PB_ROWS 32
+__global__ __launch_bounds__(384) void pair_bias_dcat_kernel(PbCatPtrs ptrs, int nblk, const int* __restrict__ desc_p, int max_P,
+                                                             int Kp, bf16_t* __restrict__ Acat, int lda, float* __restrict__ colpart) {
+    extern __shared__ float sS[];                                   // [nblk * cpr][8]
     const int* ds = desc_p + blockIdx.y * 8;
     const int poff = ds[0], P = ds[1], C = ds[3];
     const long pair_off = (long)(unsigned)ds[4] | ((long)ds[5] << 32);
-    const int cpr = Kp >> 3;                                        // 8-element chunks per (row, block)
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    const long per_row = (long)nblk * cpr;
-    const int i = (int)(idx / per_row);
-    if (i >= P) return;
-    const int rem = (int)(idx % per_row), k = rem / cpr, j = rem % cpr;
-    uint4 u = make_uint4(0u, 0u, 0u, 0u);
-    const float* d = ptrs.d[k];
-    if (j < C && d != nullptr) {
-        const float* src = d + ((size_t)(pair_off + (long)i * C + j)) * 8;
-        const float4 x = *(const float4*)src, y = *(const float4*)(src + 4);
-        u.x = pack2_bf16(x.x, x.y); u.y = pack2_bf16(x.z, x.w); u.z = pack2_bf16(y.x, y.y); u.w = pack2_bf16(y.z, y.w);
+    const int cpr = Kp >> 3, ncol = nblk * cpr;
+    const int i0 = blockIdx.x * PB_ROWS, i1 = min(P, i0 + PB_ROWS);
+    for (int c = threadIdx.x; c < ncol; c += blockDim.x) {
+        const int k = c / cpr, j = c % cpr;
+        const float* d = ptrs.d[k];
+        const bool live = j < C && d != nullptr;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = i0; i < i1; ++i) {
+            uint4 u = make_uint4(0u, 0u, 0u, 0u);
+            if (live) {
+                const float* src = d + ((size_t)(pair_off + (long)i * C + j)) * 8;
+                const float4 x = *(const float4*)src, y = *(const float4*)(src + 4);
+                u.x = pack2_bf16(x.x, x.y); u.y = pack2_bf16(x.z, x.w); u.z = pack2_bf16(y.x, y.y); u.w = pack2_bf16(y.z, y.w);
+                acc[0] += x.x; acc[1] += x.y; acc[2] += x.z; acc[3] += x.w;
+                acc[4] += y.x; acc[5] += y.y; acc[6] += y.z; acc[7] += y.w;
+            }
+            *(uint4*)(Acat + (size_t)(poff + i) * lda + (size_t)c * 8) = u;
+        }
+        if (colpart != nullptr) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) sS[c * 8 + o] = acc[o];
+        }
     }
-    *(uint4*)(Acat + (size_t)(poff + i) * lda + k * Kp + j * 8) = u;
+    if (colpart != nullptr) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < nblk * 8; t += blockDim.x) {
+            const int k = t >> 3, o = t & 7;
+            float tot = 0.f;
+            for (int j = 0; j < cpr; ++j) tot += sS[(k * cpr + j) * 8 + o];
+            colpart[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (nblk * 8) + t] = tot;
+        }
+    }
 }
 __global__ __launch_bounds__(256) void pair_bias_btcat_kernel(const float* __restrict__ b0, int ld_ab, const int* __restrict__ c_index,
                                                               const int* __restrict__ desc_p, const float* __restrict__ wcomp,
@@ -714,17 +738,20 @@ extern "C" int fabind_batched_transpose_pad(const void* in, int ld_in, const int
     return 0;
 }
 
+// rows of the colpart array fabind_pair_bias_cat writes (one per work-group of the operand-building kernel)
+extern "C" long fabind_pair_bias_cat_parts(int B, int max_P) { return (long)B * ((max_P + PB_ROWS - 1) / PB_ROWS); }
 extern "C" int fabind_pair_bias_cat(const void* const* douts, int nblk, const int* desc_p, int B, int max_P, int Kp, void* Acat,
                                     int lda, const float* b0, int ld_ab, const int* c_index, const float* wcomp, int H,
-                                    void* BTcat, int ldb, hipStream_t stream) {
+                                    void* BTcat, int ldb, float* colpart, hipStream_t stream) {
     if (B <= 0 || nblk <= 0) return 0;
     FB_REQUIRE(nblk <= 16 && Kp % 32 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= nblk * Kp && ldb >= nblk * Kp,
                "fabind_pair_bias_cat: nblk <= 16, Kp % 32 == 0, lda / ldb % 8 == 0 and >= nblk * Kp");
     PbCatPtrs ptrs;
     for (int k = 0; k < 16; ++k) ptrs.d[k] = k < nblk ? (const float*)douts[k] : nullptr;
     const long cpr = Kp / 8;
-    hipLaunchKernelGGL(pair_bias_dcat_kernel, dim3((unsigned)(((long)max_P * nblk * cpr + 255) / 256), B), dim3(256), 0, stream, ptrs,
-                       nblk, desc_p, max_P, Kp, (bf16_t*)Acat, lda);
+    FB_REQUIRE(nblk * cpr * 8 * sizeof(float) <= 64 * 1024, "fabind_pair_bias_cat: nblk * Kp too large for the column-sum tile");
+    hipLaunchKernelGGL(pair_bias_dcat_kernel, dim3((max_P + PB_ROWS - 1) / PB_ROWS, B), dim3(384), (size_t)nblk * cpr * 8 * sizeof(float),
+                       stream, ptrs, nblk, desc_p, max_P, Kp, (bf16_t*)Acat, lda, colpart);
     hipLaunchKernelGGL(pair_bias_btcat_kernel, dim3((unsigned)(((long)H * nblk * cpr + 255) / 256), B), dim3(256), 0, stream, b0, ld_ab,
                        c_index, desc_p, wcomp, nblk, H, Kp, (bf16_t*)BTcat, ldb);
     FB_CHECK_LAUNCH();

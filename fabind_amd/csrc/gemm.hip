@@ -837,12 +837,15 @@ __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* p_lo, const bf16_t* p_
 }
 __device__ __forceinline__ int tn_swz(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
-template <int NSTAGE>
-__global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ X,
+template <int NSTAGE, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ X,
                                                            int ldx, float* C, int M, int N, int E, int e_per,
                                                            const bf16_t* __restrict__ zero_page, const int* groups,
                                                            int n_tiles, int n_splits) {
-    constexpr int TM = 256, TN_ = 128, BKE = 32, NW = 8;
+    // NW waves per work-group, 2 across N (64 columns each) and NW/2 across M: 4 waves = 128x64 per wave (102 VGPRs + 128 AGPRs,
+    // two work-groups per CU, 25 % fewer LDS fragment reads per flop); 8 waves = 64x64 per wave (132 VGPRs: one work-group per CU)
+    constexpr int TM = 256, TN_ = 128, BKE = 32;
+    constexpr int MI = TM / (NW / 2) / 16;                        // 16-row granules of the Y tile per wave
     constexpr int PY = (BKE * TM * 2) / 1024, PX = (BKE * TN_ * 2) / 1024, PPW = (PY + PX) / NW;   // 16 + 8 pieces -> 3 per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* sT = (bf16_t*)smem;                                  // [NSTAGE][ Y tile 32x256 | X tile 32x128 ]
@@ -898,9 +901,9 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const bf16_t* __restr
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
         }
     };
-    f32x4_t acc[4][4];
+    f32x4_t acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -920,44 +923,62 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_kernel(const bf16_t* __restr
         // round trips per k-step)
         typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
         typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-        u32x2 ya[4], yb[4], xa[4], xb[4];
+        u32x2 ya[MI], yb[MI], xa[4], xb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gm = wm * 4 + i, gn = wn * 4 + i;          // 16-column granules of the Y / X tiles
+        for (int i = 0; i < MI; ++i) {
+            const int gm = wm * MI + i;                          // 16-column granule of the Y tile
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ya[i]) : "v"((unsigned)(uintptr_t)(tY + r1 * TM + ((gm ^ z1) * 16) + co)) : "memory");
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(yb[i]) : "v"((unsigned)(uintptr_t)(tY + r2 * TM + ((gm ^ z2) * 16) + co)) : "memory");
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gn = wn * 4 + i;                           // 16-column granule of the X tile
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xa[i]) : "v"((unsigned)(uintptr_t)(tX + r1 * TN_ + ((gn ^ z1) * 16) + co)) : "memory");
             asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xb[i]) : "v"((unsigned)(uintptr_t)(tX + r2 * TN_ + ((gn ^ z2) * 16) + co)) : "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3]),
-                       "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])
-                     :: "memory");
-        bf16x8_t af[4], bfr[4];
+        if constexpr (MI == 4) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3]),
+                           "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])
+                         :: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(ya[4]), "+v"(ya[5]), "+v"(ya[6]), "+v"(ya[7]),
+                           "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3]), "+v"(yb[4]), "+v"(yb[5]), "+v"(yb[6]), "+v"(yb[7]),
+                           "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])
+                         :: "memory");
+        }
+        bf16x8_t af[MI], bfr[4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const u32x4 ra = {ya[i][0], ya[i][1], yb[i][0], yb[i][1]};
+            af[i] = __builtin_bit_cast(bf16x8_t, ra);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const u32x4 ra = {ya[i][0], ya[i][1], yb[i][0], yb[i][1]}, rb = {xa[i][0], xa[i][1], xb[i][0], xb[i][1]};
-            af[i] = __builtin_bit_cast(bf16x8_t, ra);
+            const u32x4 rb = {xa[i][0], xa[i][1], xb[i][0], xb[i][1]};
             bfr[i] = __builtin_bit_cast(bf16x8_t, rb);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     float* Cs = C + c_goff + (size_t)split * M * N;
     const int fr = lane & 15, cq = lane >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int row = m0 + wm * 64 + i * 16 + cq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
+                const int row = m0 + wm * (MI * 16) + i * 16 + cq * 4 + r, col = n0 + wn * 64 + j * 16 + fr;
                 if (row < M && col < N) Cs[(size_t)row * N + col] = acc[i][j][r];
             }
 }
 
+static int g_tn_waves = 4;   // work-group layout of the TN kernel (see the kernel): 4 (default) or 8 waves
+extern "C" void fabind_gemm_tn_set_waves(int w) { g_tn_waves = (w == 8) ? 8 : 4; }
 extern "C" int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_part, int M, int N, int E, int splits,
                               const void* zero_page, const int* groups, int n_groups, hipStream_t stream) {
     FB_REQUIRE(M % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "fabind_gemm_tn: M, N, ldy, ldx must be multiples of 8");
@@ -966,13 +987,20 @@ extern "C" int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, fl
     if (M <= 0 || N <= 0 || splits <= 0) return 0;
     constexpr int NST = 3;
     const size_t lds = (size_t)NST * 32 * (256 + 128) * 2;
-    static bool set_ = false;
-    if (!set_) { (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; }
     int e_per = ((E + splits - 1) / splits + 31) / 32 * 32;
     const int n_tiles = ((M + 255) / 256) * ((N + 127) / 128);
     dim3 grid(n_tiles * ((splits + 7) / 8 * 8), 1, groups ? n_groups : 1);
-    hipLaunchKernelGGL((gemm_tn_bf16_kernel<NST>), grid, dim3(512), lds, stream, (const bf16_t*)Y, ldy, (const bf16_t*)X, ldx,
-                       C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups, n_tiles, splits);
+    if (g_tn_waves == 4) {
+        static bool set4 = false;
+        if (!set4) { (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<NST, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set4 = true; }
+        hipLaunchKernelGGL((gemm_tn_bf16_kernel<NST, 4>), grid, dim3(256), lds, stream, (const bf16_t*)Y, ldy, (const bf16_t*)X, ldx,
+                           C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups, n_tiles, splits);
+    } else {
+        static bool set8 = false;
+        if (!set8) { (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<NST, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set8 = true; }
+        hipLaunchKernelGGL((gemm_tn_bf16_kernel<NST, 8>), grid, dim3(512), lds, stream, (const bf16_t*)Y, ldy, (const bf16_t*)X, ldx,
+                           C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups, n_tiles, splits);
+    }
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -826,9 +826,12 @@ class _PairBias(torch.autograd.Function):
             BTcat = torch.empty((lay.B * H, nblk * Kp), dtype=torch.bfloat16, device=dev)
             ptrs = (ctypes.c_void_p * nblk)(*[None if d is None else d.data_ptr() for d in ds])
             wc = wcomp.contiguous()
+            n_part = int(load().fabind_pair_bias_cat_parts(lay.B, lay.max_P))
+            colpart = torch.empty((n_part, nblk * NO), dtype=torch.float32, device=dev)   # per-work-group column sums of the douts
             check(load().fabind_pair_bias_cat(ptrs, nblk, ptr(lay.desc_p), lay.B, lay.max_P, Kp, ptr(Acat), Acat.stride(0),
                                               ptr(a0b0[:, H:]), a0b0.stride(0), ptr(lay.c_index), ptr(wc), H, ptr(BTcat),
-                                              BTcat.stride(0), stream()), "fabind_pair_bias_cat")
+                                              BTcat.stride(0), ptr(colpart), stream()), "fabind_pair_bias_cat")
+            dbconst = K.colsum(colpart).reshape(nblk, NO)                                  # = column sums of every dout_k
             K.gemm(Acat, BTcat, out=da0b0, accumulate=True, groups=cat_g, n_groups=lay.B, max_m=lay.max_P, max_n=H,
                    M=lay.sumP, N=lay.B * H, ldc=a0b0.stride(0))
             # the T_k = D_k^T a0 contractions on the pipelined NT kernel: K-major, uniformly padded copies of both operands
@@ -843,7 +846,8 @@ class _PairBias(torch.autograd.Function):
             if dout is None:
                 continue
             dout = dout.contiguous()
-            dbconst[k] = K.colsum(dout)
+            if not bf16:
+                dbconst[k] = K.colsum(dout)
             if bf16:
                 K.gemm(Dt[k], At, out=T, groups=t_g, n_groups=lay.B, max_m=lay.max_C * NO, max_n=H, M=lay.B * Kp, N=lay.B * H, ldc=H)
                 check(load().fabind_pair_bias_finish(ptr(T), ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.c_index),

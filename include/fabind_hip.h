@@ -28,9 +28,11 @@ typedef struct ihipStream_t* hipStream_t;
 const char* fabind_last_error(void);
 /* Bumped whenever an entry point's signature or an argument struct's layout changes.  History: 1 = first round-1 layout;
  * 2 = FabindGemmArgs grew {p_drop, drop_seed, row_mu, row_rs, col_c}, FabindEdgeBwdArgs / FabindPairUpdateArgs added;
- * 3 = fabind_cross_attn_bwd takes a scratch buffer instead of (n_q_rows, n_k_rows), fabind_cross_attn_bwd_scratch added.
+ * 3 = fabind_cross_attn_bwd takes a scratch buffer instead of (n_q_rows, n_k_rows), fabind_cross_attn_bwd_scratch added;
+ * 4 = fabind_pair_bias_cat takes a colpart argument (per-work-group column sums), fabind_pair_bias_cat_parts and the
+ *     fabind_gemm_tn_set_waves knob added.
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 3
+#define FABIND_ABI_VERSION 4
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -360,10 +362,13 @@ int fabind_cross_attn_bwd(const float* qg, int ldq, const float* kv, int ldkv, c
  * once) concatenated along K, bf16:  Acat[poff_b + i, k*Kp + j*8 + o] = douts[k][pair(b,i,j), o],
  * BTcat[b*H + h, k*Kp + j*8 + o] = b0[ligand j of b, h] * wcomp[k][o][h]  (zeros for j >= C_b; Kp = 8 * max_C rounded up to 32).
  * douts: HOST array of nblk device pointers (fp32 [n_pairs, 8] each, NULL = no gradient); desc_p: the block descriptors of
- * fabind_cross_attn_fwd with the protein side compact. */
+ * fabind_cross_attn_fwd with the protein side compact; lda must be nblk*Kp (Acat rows are written contiguously).  colpart
+ * (optional): fp32 [fabind_pair_bias_cat_parts(B, max_P)][nblk*8], one row of partial column sums of the douts per work-group --
+ * their sum over the rows is the gradient of the pair-bias constants (no atomics, fixed order). */
+long fabind_pair_bias_cat_parts(int B, int max_P);
 int fabind_pair_bias_cat(const void* const* douts, int nblk, const int* desc_p, int B, int max_P, int Kp, void* Acat, int lda,
                          const float* b0, int ld_ab, const int* c_index, const float* wcomp, int H, void* BTcat, int ldb,
-                         hipStream_t stream);
+                         float* colpart, hipStream_t stream);
 /* Batched transpose with zero padding, bf16: for b < B, k < nsub, m < cols:
  *   out[(k*B + b)*cols + m][i] = in[desc[b][0] + i][k*cols + m]  for i < desc[b][1], 0 for i up to Pp   (out row stride Pp).
  * Turns the row-major per-complex operands of the pair-bias adjoint into the K-major, uniformly padded layout the pipelined NT GEMM
@@ -389,6 +394,7 @@ int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, cons
                             float* dab, float* dw, hipStream_t stream);
 void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of the bf16 LDS-DMA GEMM */
 void fabind_gemm_set_persistent(int on); /* development knob: persistent tile walk for long-M/short-K GEMMs */
+void fabind_gemm_tn_set_waves(int waves); /* development knob: work-group layout of fabind_gemm_tn, 4 (default) or 8 waves; results are bitwise equal */
 
 #ifdef __cplusplus
 }

@@ -484,3 +484,25 @@ def test_gemm_layernorm_fold_epilogue(M, N, Kd, p_drop):
     else:                                   # mask drawn inside the epilogue: statistics only
         ref = act @ w3
         assert abs(float(s.mean()) - float(ref.mean())) < 0.15 * float(ref.std()) and torch.isfinite(s).all()
+
+
+def test_gemm_tn_work_group_layouts_are_bitwise_equal():
+    """fabind_gemm_tn has two work-group layouts (4 waves x 128x64, the default, and 8 waves x 64x64): same k order per output
+    element, so the results must be identical bit for bit -- on a ragged E, with M, N that do not fill the 256x128 tile."""
+    from fabind_amd import _lib, kernels as K
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    try:
+        for E, M, N in ((4096 + 40, 512, 512), (1000, 328, 136), (70000, 512, 8)):
+            Y = torch.randn(E, M, device=dev).to(torch.bfloat16)
+            X = torch.randn(E, N, device=dev).to(torch.bfloat16)
+            ref = Y.float().t() @ X.float()
+            outs = []
+            for w in (4, 8):
+                lib.fabind_gemm_tn_set_waves(w)
+                outs.append(K.gemm_tn(Y, X))
+            assert torch.equal(outs[0], outs[1]), (E, M, N)
+            assert float((outs[0] - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), (E, M, N)
+    finally:
+        lib.fabind_gemm_tn_set_waves(4)

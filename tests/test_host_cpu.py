@@ -50,7 +50,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()                                        # loads without a GPU (HIP initialises lazily)
     from fabind_amd import _lib as L
     import ctypes
-    assert lib.fabind_abi_version() == L.ABI_VERSION == 3
+    assert lib.fabind_abi_version() == L.ABI_VERSION == 4
     # the ctypes mirrors have the library's struct sizes (load() refuses a mismatch; checked again here explicitly)
     for which, mirror in enumerate((L.GemmArgs, L.EdgeBwdArgs, L.PairUpdateArgs)):
         assert lib.fabind_sizeof_args(which) == ctypes.sizeof(mirror)
@@ -196,7 +196,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
     protos = dict(re.findall(r"\bint\s+(fabind_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S))
     special = {"fabind_abi_version", "fabind_sizeof_args", "fabind_gemm_set_config", "fabind_gemm_set_persistent"}
     protos.update(dict(re.findall(r"\blong\s+(fabind_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)))
-    special.add("fabind_cross_attn_bwd_scratch")
+    special.update({"fabind_cross_attn_bwd_scratch", "fabind_pair_bias_cat_parts"})
     assert set(protos) - special == set(L.SIGNATURES), (sorted(set(protos) - special - set(L.SIGNATURES)),
                                                          sorted(set(L.SIGNATURES) - set(protos)))
 
