@@ -506,3 +506,38 @@ def test_gemm_tn_work_group_layouts_are_bitwise_equal():
             assert float((outs[0] - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), (E, M, N)
     finally:
         lib.fabind_gemm_tn_set_waves(4)
+
+
+@pytest.mark.parametrize("case", ["one_consumer", "two_consumers", "second_output_unused"])
+def test_shared_gradient_buffer_matches_plain_autograd(case):
+    """ops.shared_grad / ops.GradSink: consumers with accumulating adjoints add into ONE gradient buffer (the first to run hands it
+    to autograd, the others return None).  Whatever subset of the consumers takes part in the backward pass, the gradient must
+    equal what plain autograd computes by summing separate per-consumer gradients."""
+    from fabind_amd import engine, ops
+    engine.set_precision("fp32")
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(11)
+    N, H, H2, n = 70, 32, 8, 400
+    T0 = torch.randn(N, 2 * H, generator=gen).to(dev)
+    T1 = torch.randn(N, 2 * H2, generator=gen).to(dev)
+    idx = [torch.randint(0, N, (n,), generator=gen).to(torch.int32).to(dev) for _ in range(4)]
+    w = [torch.randn(n, H + H2, generator=gen).to(dev) for _ in range(2)]
+
+    def run(shared):
+        t0, t1 = T0.clone().requires_grad_(True), T1.clone().requires_grad_(True)
+        base = t0 * 1.0                                     # a non-leaf producer, like the Linear in engine.StackContext
+        s = ops.shared_grad(base) if shared else base
+        a = ops.pair_hadamard(s, H, t1, H2, idx[0], idx[1])
+        loss = (a * w[0]).sum()
+        if case != "one_consumer":
+            b = ops.pair_hadamard(s, H, t1, H2, idx[2], idx[3])
+            if case == "two_consumers":
+                loss = loss + (b * w[1]).sum()
+        loss.backward()
+        return t0.grad, t1.grad
+
+    (g0, g1), (r0, r1) = run(True), run(False)
+    assert g0 is not None and r0 is not None
+    # float atomics inside the adjoint reorder sums: equal to round-off
+    assert float((g0 - r0).abs().max()) <= 1e-5 * float(r0.abs().max())
+    assert float((g1 - r1).abs().max()) <= 1e-5 * float(r1.abs().max())
