@@ -584,8 +584,8 @@ template <int WM, int BK_, int NSTAGE> __host__ __device__ constexpr size_t lds_
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WM, int BK_, int NSTAGE>
-__global__ __launch_bounds__(WM * 128) void gemm_bf16_pipe_kernel(FabindGemmArgs p) {
+template <int WM, int BK_, int NSTAGE, int MINW = 1>
+__global__ __launch_bounds__(WM * 128, MINW) void gemm_bf16_pipe_kernel(FabindGemmArgs p) {
     constexpr int BM_ = WM * 64, NW = WM * 2, NT = NW * 64;
     constexpr int ROWS = BM_ + BN;                    // A rows then W rows share one row space per stage
     constexpr int RPP = 1024 / (BK_ * 2);             // rows per 1-KiB LDS-DMA piece
@@ -1007,21 +1007,25 @@ extern "C" int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, fl
 
 static int g_gemm_persist = 0;   // measured slower than 2 work-groups/CU of the tile-per-block kernel (see tools/gemm_bench.py)
 extern "C" void fabind_gemm_set_persistent(int on) { g_gemm_persist = on; }
-static int g_gemm_cfg = 3;   // 256x128 tile, BK = 32, 3-stage ring (best of the measured set, see tools/gemm_bench.py)
+// 13 = 256x128 tile, BK = 32, 3-stage ring (cfg 3, best tile of the measured set: tools/gemm_bench.py) compiled under a 4-waves-per-SIMD
+// launch bound: 128 VGPRs + 336 B scratch instead of 213 VGPRs, so TWO 8-wave work-groups are resident per CU (LDS 2 x 76 KB) and one tile's
+// pipeline fill / epilogue overlaps the other's main loop: 16-26 % faster on every node-level shape, bitwise-equal results
+// (tools/probes/gemm_node_occ.py)
+static int g_gemm_cfg = 13;
 extern "C" void fabind_gemm_set_config(int cfg) { g_gemm_cfg = cfg; }
 
-template <int WM, int BK_, int NSTAGE>
+template <int WM, int BK_, int NSTAGE, int MINW = 1>
 static int launch_pipe(const FabindGemmArgs& p, int maxM, int maxN, hipStream_t stream) {
     constexpr int BM_ = WM * 64;
     const size_t lds = lds_tile_bytes<WM, BK_, NSTAGE>() + 2 * BM_ * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_pipe_kernel<WM, BK_, NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_bf16_pipe_kernel<WM, BK_, NSTAGE, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM_ - 1) / BM_, p.groups ? p.n_groups : 1);
     if (!p.groups) grid = dim3(grid.x * grid.y, p.k_splits > 1 ? p.k_splits : 1, 1);
-    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<WM, BK_, NSTAGE>), grid, dim3(WM * 128), lds, stream, p);
+    hipLaunchKernelGGL((gemm_bf16_pipe_kernel<WM, BK_, NSTAGE, MINW>), grid, dim3(WM * 128), lds, stream, p);
     return 0;
 }
 
@@ -1099,6 +1103,7 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
             case 7: launch_pipe<4, 32, 2>(p, maxM, maxN, stream); break;
             case 8: launch_pipe<2, 32, 2>(p, maxM, maxN, stream); break;
             case 9: launch_pipe<4, 64, 2>(p, maxM, maxN, stream); break;
+            case 13: launch_pipe<4, 32, 3, 4>(p, maxM, maxN, stream); break;   /* cfg 3 under a 4-waves-per-SIMD bound (default) */
             default: hipLaunchKernelGGL(gemm_bf16_glds_kernel, grid, dim3(256), 0, stream, p);
         }
     } else {

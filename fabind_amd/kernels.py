@@ -12,6 +12,7 @@ __all__ = ["gemm", "transpose_act", "colsum", "edges_count", "edges_fill", "excl
            "inter_attn_fwd", "las_step", "select_rows", "ACT_NONE", "ACT_SILU", "ACT_RELU", "ACT_SIGMOID", "ACT_STORED_DERIV"]
 
 GEMM_BN = 128
+GEMM_DEFAULT_CONFIG = 13   # fabind_gemm_set_config default: 256x128x32 tile, 3 stages, 4-waves-per-SIMD bound (csrc/gemm.hip)
 PROFILE = None  # dict: label -> list of (start_event, end_event, flops) around every MFMA-kernel launch (bench.py)
 
 

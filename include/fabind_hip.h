@@ -392,7 +392,8 @@ int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, int ld, int
                          hipStream_t stream);
 int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, const float* w, const int* c_index, int n_c,
                             float* dab, float* dw, hipStream_t stream);
-void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of the bf16 LDS-DMA GEMM */
+void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of the bf16 LDS-DMA GEMM (default 13 = 256x128x32, 3 stages,
+                                         two work-groups per CU; 0 = register-staged kernel; 1-9 = other tiles; results do not depend on it) */
 void fabind_gemm_set_persistent(int on); /* development knob: persistent tile walk for long-M/short-K GEMMs */
 void fabind_gemm_tn_set_waves(int waves); /* development knob: work-group layout of fabind_gemm_tn, 4 (default) or 8 waves; results are bitwise equal */
 

@@ -181,7 +181,7 @@ def test_layernorm():
     assert (y.cpu() - ref).abs().max() < 1e-4
 
 
-@pytest.mark.parametrize("cfg", [0, 3, 6, 7])
+@pytest.mark.parametrize("cfg", [0, 3, 6, 7, 13])
 @pytest.mark.parametrize("shape", [(1000, 512, 512), (257, 200, 128), (4096, 1024, 576), (130, 64, 64)])
 def test_gemm_bf16_lds_dma_fast_path(shape, cfg):
     """bf16 A and W, K % 64 == 0 -> global_load_lds pipelined kernels (swizzled LDS image), every tile config."""
@@ -204,7 +204,7 @@ def test_gemm_bf16_lds_dma_fast_path(shape, cfg):
     Wa = (torch.arange(128 * 128, dtype=torch.float32).reshape(128, 128) % 251 / 256.0).bfloat16()
     o2, _ = K.gemm(eye.to(dev), Wa.to(dev))
     o3, _ = K.gemm(eye.to(dev), Wa.to(dev), out_dtype=torch.bfloat16)
-    _lib.load().fabind_gemm_set_config(3)
+    _lib.load().fabind_gemm_set_config(K.GEMM_DEFAULT_CONFIG)
     assert torch.equal(o2.cpu(), Wa.float().T.contiguous())
     assert torch.equal(o3.float().cpu(), Wa.float().T.contiguous())
 

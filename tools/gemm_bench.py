@@ -53,7 +53,7 @@ def main():
         for name in ("bf16A plain -> bf16", "bf16A bias+silu -> bf16", "bf16A bias+silu rowdot only"):
             ms = timeit(cases[name])
             print("cfg %d %-40s %8.3f ms  %7.1f TFLOP/s  (err %.3g)" % (cfg, name, ms, fl / ms / 1e9, err))
-    lib.fabind_gemm_set_config(0)
+    lib.fabind_gemm_set_config(0)            # the register-staged kernel for the cases below
     for name in ("bf16A silu-prologue (old kernel) -> bf16", "f32A plain -> f32", "f32A plain -> bf16"):
         ms = timeit(cases[name])
         print("%-45s %8.3f ms  %7.1f TFLOP/s" % (name, ms, fl / ms / 1e9))

@@ -15,11 +15,11 @@ for (N, Kd) in ((512, 512), (1024, 512), (512, 1024), (1536, 512)):
         o32 = torch.empty(M, N, device=dev)
         fl = 2.0 * M * N * Kd
         line = "M=%6d N=%4d K=%4d:" % (M, N, Kd)
-        for cfg in (3, 6, 1, 7):
+        for cfg in (13, 3, 6, 1, 7):
             lib.fabind_gemm_set_config(cfg)
             ms = timeit(lambda: K.gemm(A, W, out=o16), 20)
             line += "  cfg%d bf16 %.0f us (%.0f TF)" % (cfg, ms * 1e3, fl / ms / 1e9)
-        lib.fabind_gemm_set_config(3)
+        lib.fabind_gemm_set_config(K.GEMM_DEFAULT_CONFIG)
         ms = timeit(lambda: K.gemm(A, W, bias=b, out=o32), 20)
-        line += "  | cfg3 bias->f32 %.0f us (%.0f TF)" % (ms * 1e3, fl / ms / 1e9)
+        line += "  | default cfg bias->f32 %.0f us (%.0f TF)" % (ms * 1e3, fl / ms / 1e9)
         print(line)
