@@ -7,6 +7,9 @@ Replaces accelerate -> torch DDP (reference main_fabind.py:194-195, 289-296, 419
   * 33 parameter tensors never receive a gradient (att_i.inter_layer.*, pocket model out_layer.coord_mlp.*;
     the reference needs find_unused_parameters=True).  Here every rank packs the SAME flat buffer over
     all trainable parameters and fills missing gradients with zeros, so no graph inspection is needed.
+  * `GradReducer` overlaps the collective with backward (buckets are issued as they fill); `allreduce_gradients` is the
+    non-overlapped form of the same arithmetic.
+  * the NaN-skip of a step (main_fabind.py:394-396) is agreed on collectively, so no rank waits in a collective alone.
   * xGMI is point-to-point (7 links x ~153 GB/s): the 145 MB fp32 gradient is sent as a few large buckets
     (default 64 MB) so that RCCL can use reduce-scatter + all-gather across all links; the collective is
     issued on RCCL's own stream and overlaps with the packing of the next bucket.
@@ -79,17 +82,143 @@ def clip_grad_norm_(params, max_norm=1.0):
     return total
 
 
-def train_step(model, data, optimizer, compute_loss, world=1, clip=1.0, stage=1):
+class GradReducer:
+    """Gradient all-reduce overlapped with backward (what DDP's reducer does for the reference, main_fabind.py:194-195,
+    419-423), sized for xGMI: the trainable parameters are cut into a few LARGE flat fp32 buckets (default 64 MB -- ring
+    collectives over 7 point-to-point links are per-link bound, so few big messages beat many small ones) in REVERSE
+    registration order, which is roughly the order backward produces them.  A post-accumulate hook on every parameter copies
+    its gradient into the bucket; the bucket's all-reduce is issued asynchronously (RCCL runs it on its own stream) the
+    moment its last gradient has arrived, while backward continues with the earlier layers.  `finish()` issues the buckets
+    that never filled (parameters without a gradient count as zeros on every rank, replacing find_unused_parameters=True),
+    waits, divides by the world size and writes the averaged gradients back.
+
+    Every rank builds the same buckets from the same parameter list, and every bucket is reduced exactly once per step in
+    bucket order or completion order -- both identical across ranks only if completion order is; to be safe against
+    rank-dependent autograd order the collective for bucket k is issued only after buckets 0..k-1 have been issued."""
+
+    def __init__(self, params, world=None, bucket_bytes=64 << 20, group=None):
+        self.group = group
+        self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = [list(b) for b in _buckets(list(reversed(self.params)), bucket_bytes)]
+        self.slot = {}
+        for bi, b in enumerate(self.buckets):
+            off = 0
+            for p in b:
+                self.slot[id(p)] = (bi, off)
+                off += p.numel()
+        self.sizes = [sum(p.numel() for p in b) for b in self.buckets]
+        self.flat = [None] * len(self.buckets)
+        self.pending = [0] * len(self.buckets)
+        self.work = [None] * len(self.buckets)
+        self.next_issue = 0
+        self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params] if self.world > 1 else []
+        self._reset()
+
+    def _reset(self):
+        self.pending = [len(b) for b in self.buckets]
+        self.work = [None] * len(self.buckets)
+        self.seen = set()
+        self.next_issue = 0
+
+    def _buffer(self, bi):
+        if self.flat[bi] is None:
+            dev = self.buckets[bi][0].device
+            self.flat[bi] = torch.zeros(self.sizes[bi], dtype=torch.float32, device=dev)
+        return self.flat[bi]
+
+    def _hook(self, p):
+        if id(p) in self.seen:          # a second accumulation into the same parameter in one step: finish() re-reads .grad
+            return
+        self.seen.add(id(p))
+        bi, off = self.slot[id(p)]
+        self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        self.pending[bi] -= 1
+        self._issue_ready()
+
+    def _issue_ready(self):
+        while self.next_issue < len(self.buckets) and self.pending[self.next_issue] == 0:
+            self._issue(self.next_issue)
+            self.next_issue += 1
+
+    def _issue(self, bi):
+        flat = self._buffer(bi)
+        if flat.is_cuda and dist.get_backend(self.group) == "gloo":      # CPU-only collective backend (tests): host staging
+            flat = flat.cpu()
+        self.work[bi] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat)
+
+    def finish(self):
+        """Call after backward: completes the step's all-reduce and leaves the rank-averaged gradient in every .grad."""
+        if self.world == 1:
+            for p in self.params:
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+            return
+        for bi, b in enumerate(self.buckets):                  # parameters whose hook never fired: zeros
+            if self.work[bi] is None and self.pending[bi] > 0:
+                buf = self._buffer(bi)
+                for p in b:
+                    if id(p) not in self.seen:
+                        _, off = self.slot[id(p)]
+                        buf[off:off + p.numel()].zero_()
+                self.pending[bi] = 0
+        self._issue_ready()
+        for bi, b in enumerate(self.buckets):
+            work, flat = self.work[bi]
+            work.wait()
+            flat = flat.to(self.flat[bi].device)
+            flat.div_(self.world)
+            off = 0
+            for p in b:
+                n = p.numel()
+                g = flat[off:off + n].view_as(p).to(p.dtype)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += n
+        self._reset()
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+
+
+def all_ranks_agree_to_skip(bad, world=None, group=None):
+    """True on EVERY rank when `bad` (a bool / 0-d tensor: this rank saw a NaN) is true on ANY rank.  The reference skips a
+    step on its own NaN only (main_fabind.py:394-396) because accelerate's DDP would otherwise hang the other ranks in the
+    gradient all-reduce; here the decision is made collectively, so all ranks skip the same steps."""
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+    flag = bad if torch.is_tensor(bad) else torch.tensor(bool(bad))
+    if world == 1:
+        return bool(flag)
+    flag = flag.to(torch.int32).reshape(1)
+    if flag.is_cuda and dist.get_backend(group) == "gloo":
+        flag = flag.cpu()
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    return bool(flag.item())
+
+
+def train_step(model, data, optimizer, compute_loss, world=1, clip=1.0, stage=1, reducer=None):
     """One DP step with the reference's order: forward, NaN guard, 6-term loss, backward, all-reduce,
-    clip, optimizer step (main_fabind.py:392-426).  Returns (loss, terms) or None when the batch is skipped."""
+    clip, optimizer step (main_fabind.py:392-426).  Returns (loss, terms) or None when the batch is skipped -- on ALL
+    ranks together (the NaN flag is all-reduced first, so no rank is left waiting in the gradient collective).
+    reducer: a GradReducer over the model's parameters (overlaps the all-reduce with backward); without one the
+    gradients are reduced after backward."""
     out = model(data, stage=stage, train=True)
-    if any(torch.isnan(t).any() for t in (out[0], out[2], out[3], out[4], out[8])):
+    bad = torch.stack([torch.isnan(t).any() for t in (out[0], out[2], out[3], out[4], out[8])]).any()
+    if all_ranks_agree_to_skip(bad, world):
         return None
     loss, terms = compute_loss(out, data)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     params = [p for p in model.parameters() if p.requires_grad]
-    allreduce_gradients(params, world)
+    if reducer is not None:
+        reducer.finish()
+    else:
+        allreduce_gradients(params, world)
     if clip:
         clip_grad_norm_(params, clip)
     optimizer.step()

@@ -22,7 +22,7 @@ def _run(cmd, env=None):
 
 
 SMALL = ["--steps", "2", "--warmup", "1", "--batch", "3", "--n-prot", "70", "--n-lig", "9", "--hidden", "64", "--layers", "2",
-         "--no-cpu-baseline"]
+         "--no-cpu-baseline", "--no-extras"]
 
 
 def test_bench_json_contract_single_rank():
@@ -43,6 +43,29 @@ def test_bench_two_ranks_control_flow():
              env={"FABIND_BENCH_DEVICE": "0", "FABIND_BENCH_BACKEND": "gloo"})
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 6
     assert abs(r["value"] - 6 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]      # whole-job aggregate over both ranks
+
+
+def test_bench_self_launches_without_a_launcher():
+    """`python bench.py --gpus 2` with no torch.distributed.run around it: the parent spawns the ranks before touching the GPU,
+    relays rank 0's line and exit code (it used to die on an assert)."""
+    env = {"FABIND_BENCH_DEVICE": "0", "FABIND_BENCH_BACKEND": "gloo"}
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        assert k not in os.environ
+    r = _run([sys.executable, "bench.py", "--gpus", "2"] + SMALL, env=env)
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 6
+    bad = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + SMALL, cwd=ROOT,       # no such device in the children
+                         env=dict(os.environ, FABIND_BENCH_DEVICE="99", FABIND_BENCH_BACKEND="gloo"), capture_output=True,
+                         text=True, timeout=600)
+    assert bad.returncode != 0                                   # a failing child is reported through the exit code
+
+
+def test_bench_line_carries_the_neighbouring_configurations():
+    """Default mode at N=1: fp32 / train-mode / n_iter=8 / forward-only / full-model sub-objects ride in the same JSON line."""
+    r = _run([sys.executable, "bench.py"] + SMALL[:-1])
+    for k in ("fp32", "train_mode", "n_iter8", "fwd", "model_fwdbwd", "model_fwdbwd_train_n_iter8"):
+        assert k in r and "error" not in r[k], (k, r.get(k))
+        assert r[k]["value"] > 0 and r[k]["unit"] == "complexes/s"
+    assert r["fp32"]["dtype"] == "fp32" and r["train_mode"]["train_mode"] is True and r["n_iter8"]["n_iter"] == 8
 
 
 def test_rccl_backend_paths_with_one_rank():

@@ -71,3 +71,101 @@ def test_shard_complexes_partitions_the_batch():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _reducer_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    lin1, lin2, lin3 = torch.nn.Linear(40, 300), torch.nn.Linear(300, 50), torch.nn.Linear(50, 3)
+    unused = torch.nn.Parameter(torch.randn(11))
+    params = list(lin1.parameters()) + list(lin2.parameters()) + list(lin3.parameters()) + [unused]
+    red = parallel.GradReducer(params, world, bucket_bytes=1 << 13)          # several buckets
+    assert len(red.buckets) > 3
+    out = []
+    for step in range(2):                                                    # second step: buffers are reused
+        x = torch.randn(17, 40, generator=torch.Generator().manual_seed(100 * step + rank))
+        for p in params:
+            p.grad = None
+        loss = lin3(torch.relu(lin2(torch.relu(lin1(x))))).pow(2).sum() * (rank + 1)
+        loss.backward()
+        local = [None if p.grad is None else p.grad.clone() for p in params]
+        red.finish()
+        overl = [p.grad.clone() for p in params]
+        # the non-overlapped form of the same arithmetic on the saved local gradients
+        for p, g in zip(params, local):
+            p.grad = g
+        parallel.allreduce_gradients(params, world, bucket_bytes=1 << 12)
+        out.append(([g.numpy().tolist() for g in overl], [p.grad.numpy().tolist() for p in params]))
+    red.close()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_reducer_equals_plain_allreduce():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, steps in res:
+        for overl, plain in steps:
+            for a, b in zip(overl, plain):
+                assert torch.allclose(torch.tensor(a), torch.tensor(b), rtol=1e-6, atol=1e-7)
+    assert res[0][1] == res[1][1]                                            # identical on both ranks
+    assert all(v == 0.0 for v in res[0][1][0][0][-1])                       # the unused parameter: zeros, not None
+
+
+class _NanModel(torch.nn.Module):
+    """A stand-in with the 11-tuple contract of IaBNet.forward whose outputs go NaN on request (train_step's NaN guard)."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.ones(3))
+
+    def forward(self, data, stage=1, train=True):
+        v = self.w * data["x"]
+        if data["nan"]:
+            v = v * float("nan")
+        z = v.sum().reshape(1)
+        return (v, None, z, z, z, None, None, None, z, None, 0)
+
+
+def _nan_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = _NanModel()
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    loss_fn = lambda out, data: (out[0].sum(), {"coord": out[0].sum()})
+    res = []
+    # step 0: clean on both ranks; step 1: NaN on rank 1 only -> BOTH ranks must skip (and nobody hangs); step 2: clean again
+    for step, nan_on in enumerate([(), (1,), ()]):
+        r = parallel.train_step(m, {"x": torch.full((3,), float(rank + 1)), "nan": rank in nan_on}, opt, loss_fn, world, clip=0)
+        res.append((r is None, m.w.detach().clone().tolist()))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_nan_on_one_rank_skips_the_step_on_every_rank():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nan_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, steps in res:
+        assert [s[0] for s in steps] == [False, True, False]
+        assert steps[0][1] == steps[1][1]                   # the skipped step left the weights alone
+    assert res[0][1] == res[1][1]                           # ranks stay in lock-step: mean gradient (1+2)/2 applied twice
+    assert all(abs(v - (1.0 - 2 * 0.1 * 1.5)) < 1e-6 for v in res[0][1][2][1])
