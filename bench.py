@@ -44,7 +44,8 @@ def build_model(hidden, layers, n_iter, seed=0, dropout=0.0):
     torch.manual_seed(seed)
     m = EfficientMCAttModel(stack_args(hidden, layers, n_iter), hidden, hidden, 1, n_layers=layers, n_iter=n_iter,
                             dropout=dropout, normalize_coord=lambda x: x / 5.0, unnormalize_coord=lambda x: x * 5.0)
-    return m
+    from fabind_amd import synthetic
+    return synthetic.condition_for_large_graphs(m)      # random init kept out of the |h| ~ 1e6 regime (see its docstring)
 
 
 def make_batch(batch, n_prot, n_lig, hidden, seed):
@@ -202,6 +203,7 @@ def main():
             margs = stack_args(a.hidden, a.layers, n_iter)
             torch.manual_seed(0)
             model = get_model(margs, _Log(), dev).to(dev)
+            synthetic.condition_for_large_graphs(model)
             model.train(train_mode)
             hb = synthetic.make_hetero_batch([(a.n_prot, a.n_lig)] * a.batch, seed=rank).to(dev)
             params = list(model.parameters())

@@ -1,0 +1,208 @@
+"""GPU: parity evidence AT THE SHAPE THE HEADLINE IS QUOTED ON (BASELINE configs[1..2]: 1500 protein / 40 ligand nodes,
+hidden 512, 4 FABind layers + out layer) -- the fixtures of test_gpu_stack.py are hidden <= 128, <= 260 nodes.
+
+(i)   one complex, fp32 mode vs the CPU oracle (oracle/fabind_oracle.py, pinned to the reference by test_oracle_golden.py):
+      ligand RMSD < 1e-4 A, H to 1e-4 rel, n_iter = 1 and 2;
+(ii)  the same input in bf16 (the bench dtype): the gap is printed and bounded; input / parameter gradients vs the oracle's
+      autograd in both modes;
+(iii) the full B = 64 bench batch through size-independent properties: finiteness, E(3) equivariance, run-to-run repeatability,
+      and complex 0 of the batch == the same complex run alone.
+
+Reference: FABind/fabind/models/att_model.py:170-246, egnn.py:392-466."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import fabind_oracle as orc
+from helpers import rmsd
+from test_gpu_stack import _args
+
+pytestmark = pytest.mark.gpu
+H, L, NP, NL = 512, 4, 1500, 40
+
+
+def _model(n_iter, seed=0):
+    """Seeded random init, conditioned for 1500-node graphs (synthetic.condition_for_large_graphs: with the plain default init
+    the oracle itself reaches |h| ~ 2e6 and every atom hits the 10 A clamp at this shape; conditioned: |h| <= 0.5, the ligand
+    moves 0.19 A RMS per pass -- measured with the oracle)."""
+    from fabind_amd import synthetic
+    from fabind_amd.models.att_model import EfficientMCAttModel
+    torch.manual_seed(seed)
+    m = EfficientMCAttModel(_args(H, L, n_iter), H, H, 1, n_layers=L, n_iter=n_iter, dropout=0.0,
+                            normalize_coord=lambda x: x / 5.0, unnormalize_coord=lambda x: x * 5.0).eval()
+    return synthetic.condition_for_large_graphs(m)
+
+
+def _oracle(m, inp, n_iter, grad=False):
+    torch.set_num_threads(min(torch.get_num_threads(), 32))          # the measured best on the GPU box's host
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    Hin = inp["H"].clone()
+    if grad:
+        for v in sd.values():
+            if v.is_floating_point():
+                v.requires_grad_(True)
+        Hin.requires_grad_(True)
+    with torch.set_grad_enabled(grad):
+        X, Hh = orc.stack_forward(sd, "", inp["X"].clone(), Hin, inp["batch_id"], inp["segment_id"], inp["mask"],
+                                  inp["is_global"], inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"],
+                                  L, n_iter)[:2]
+    return X, Hh, sd, Hin
+
+
+def _hip(m, inp, dev, grad=False):
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    Hin = t["H"].clone().requires_grad_(grad)
+    with torch.set_grad_enabled(grad):
+        X, Hh = m(t["X"].clone(), Hin, t["batch_id"], t["segment_id"], t["mask"], t["is_global"], t["compound_edge_index"],
+                  t["LAS_edge_index"], t["coord_LAS"])
+    return X, Hh, Hin
+
+
+@pytest.fixture(scope="module")
+def one_complex():
+    from fabind_amd import synthetic
+    return synthetic.make_stack_batch([(NP, NL)], H, seed=7)         # snapped off the cut-offs (parity input)
+
+
+@pytest.mark.parametrize("n_iter", [1, 2])
+def test_headline_shape_fp32_matches_oracle(one_complex, n_iter):
+    """(i) north_star gate at the headline shape: ligand RMSD < 1e-4 A, H to 1e-4 rel (fp32 mode)."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision("fp32")
+    m = _model(n_iter)
+    Xr, Hr, _, _ = _oracle(m, one_complex, n_iter)
+    X, Hh, _ = _hip(m.to(dev), one_complex, dev)
+    lig = one_complex["mask"].numpy()
+    moved = rmsd(Xr.numpy()[lig] * 5, one_complex["X"].numpy()[lig] * 5)
+    gap = rmsd(X.cpu().numpy()[lig] * 5, Xr.numpy()[lig] * 5)
+    herr = float((Hh.cpu() - Hr).abs().max()) / max(1.0, float(Hr.abs().max()))
+    print("headline shape fp32, n_iter=%d: ligand moved %.3f A; RMSD vs oracle %.3e A; H rel err %.3e" % (n_iter, moved, gap, herr))
+    assert moved > 1e-2                                              # the comparison is not vacuous
+    assert gap < 1e-4
+    assert herr <= 1e-4
+
+
+# bf16 ligand-RMSD gap measured at this shape; the asserted bound is 2x the measurement: see DESIGN section 2
+BF16_GAP_BOUND_A = {1: 2e-3, 2: 4e-3}
+
+
+@pytest.mark.parametrize("n_iter", [1, 2])
+def test_headline_shape_bf16_gap_is_measured_and_bounded(one_complex, n_iter):
+    """(ii) the bench dtype at the bench shape (K = 512 contractions): the gap to the fp32 oracle, printed and bounded."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    m = _model(n_iter)
+    Xr, Hr, _, _ = _oracle(m, one_complex, n_iter)
+    engine.set_precision("bf16")
+    try:
+        X, Hh, _ = _hip(m.to(dev), one_complex, dev)
+    finally:
+        engine.set_precision("fp32")
+    lig = one_complex["mask"].numpy()
+    gap = rmsd(X.cpu().numpy()[lig] * 5, Xr.numpy()[lig] * 5)
+    moved = rmsd(Xr.numpy()[lig] * 5, one_complex["X"].numpy()[lig] * 5)
+    herr = float((Hh.cpu() - Hr).abs().max()) / max(1.0, float(Hr.abs().max()))
+    print("headline shape bf16, n_iter=%d: ligand moved %.3f A; RMSD gap vs oracle %.3e A (gate 1e-4: %s); H rel err %.3e"
+          % (n_iter, moved, gap, "met" if gap < 1e-4 else "missed", herr))
+    assert gap < BF16_GAP_BOUND_A[n_iter]
+    assert herr < 5e-2
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 3e-3), ("bf16", 6e-2)])
+def test_headline_shape_gradients_match_oracle_autograd(one_complex, prec, tol):
+    """(ii) d(loss)/d(input H, every parameter) through the HIP backward kernels vs autograd through the oracle."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    m = _model(1)
+    g = torch.Generator().manual_seed(3)
+    N = one_complex["X"].shape[0]
+    cotX, cotH = torch.randn(N, 1, 3, generator=g), torch.randn(N, H, generator=g) * 1e-2
+    Xr, Hr, sd, Hin_r = _oracle(m, one_complex, 1, grad=True)
+    ((Xr * cotX).sum() + (Hr * cotH).sum()).backward()
+    engine.set_precision(prec)
+    try:
+        m = m.to(dev)
+        X, Hh, Hin = _hip(m, one_complex, dev, grad=True)
+        ((X * cotX.to(dev)).sum() + (Hh * cotH.to(dev)).sum()).backward()
+    finally:
+        engine.set_precision("fp32")
+    ref = Hin_r.grad
+    e_in = float((Hin.grad.cpu() - ref).abs().max() / ref.abs().max())
+    worst, n_cmp = ("", 0.0), 0
+    gmax = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    for n, p in m.named_parameters():
+        r = sd[n].grad
+        if r is None or float(r.abs().max()) < 1e-6 * gmax:          # never used / round-off of an exact zero (softmax shifts)
+            assert p.grad is None or float(p.grad.abs().max()) <= 1e-4 * gmax, n
+            continue
+        assert p.grad is not None, n
+        err = float((p.grad.cpu() - r).abs().max() / r.abs().max())
+        n_cmp += 1
+        if err > worst[1]:
+            worst = (n, err)
+    print("headline shape %s gradients: input H rel err %.3e; worst of %d parameter tensors: %s %.3e"
+          % (prec, e_in, n_cmp, worst[0], worst[1]))
+    assert n_cmp > 100
+    assert e_in <= tol and worst[1] <= tol, worst
+
+
+def _rotation(seed):
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(seed)).double())
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    return q.float()
+
+
+@pytest.fixture(scope="module")
+def bench_batch():
+    from fabind_amd import synthetic
+    return synthetic.make_stack_batch([(NP, NL)] * 64, H, seed=0)    # snapped: rotation must not flip an edge at a cut-off
+
+
+@pytest.mark.parametrize("prec,tol_equiv,tol_single", [("fp32", 1e-4, 1e-5), ("bf16", 5e-3, 2e-4)])
+def test_bench_batch_properties(bench_batch, prec, tol_equiv, tol_single):
+    """(iii) the B = 64 batch of bench.py: finite; E(3)-equivariant (inputs rotated and translated -> coordinates rotate and
+    translate, H invariant); two runs repeat; complex 0 inside the batch == the same complex alone."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision(prec)
+    try:
+        m = _model(1).to(dev)
+        inp = bench_batch
+        X1, H1, _ = _hip(m, inp, dev)
+        X2, H2, _ = _hip(m, inp, dev)
+        assert bool(torch.isfinite(X1).all()) and bool(torch.isfinite(H1).all())
+        lig = inp["mask"].to(dev)
+        moved = float((((X1 - inp["X"].to(dev))[lig] * 5) ** 2).sum(-1).mean().sqrt())
+        assert moved > 1e-2
+        # run-to-run repeatability (float atomics at tile-boundary rows of the fused edge kernels make bf16 order-dependent)
+        rep_x, rep_h = float((X1 - X2).abs().max()) * 5, float((H1 - H2).abs().max())
+        print("%s B=64: ligand moved %.3f A; run-to-run max |dX| %.2e A, max |dH| %.2e (%s)"
+              % (prec, moved, rep_x, rep_h, "bit-identical" if rep_x == 0.0 and rep_h == 0.0 else "not bit-identical"))
+        assert rep_x <= 1e-6 and rep_h <= 1e-5 * max(1.0, float(H1.abs().max()))
+        # E(3): x -> R x + t applied to the normalised inputs (and the LAS reference conformer, which enters through distances)
+        R, tvec = _rotation(1).to(dev), torch.tensor([0.37, -1.2, 0.8], device=dev)
+        rot = dict(inp)
+        rot["X"] = (inp["X"].to(dev) @ R.T + tvec).cpu()
+        rot["coord_LAS"] = (inp["coord_LAS"].to(dev) @ R.T).cpu()
+        Xr_, Hr_, _ = _hip(m, rot, dev)
+        ex = float((((Xr_ - (X1 @ R.T + tvec))[lig] * 5) ** 2).sum(-1).mean().sqrt())
+        eh = float((Hr_ - H1).abs().max()) / max(1.0, float(H1.abs().max()))
+        print("%s B=64: E(3) equivariance: ligand RMSD between rotated run and rotated output %.3e A, H invariance %.3e" % (prec, ex, eh))
+        assert ex < tol_equiv and eh < max(tol_equiv, 1e-4) * 10
+        # complex 0 of the batch vs the same complex alone
+        n0 = NP + NL + 2
+        one = {k: (v[:n0] if torch.is_tensor(v) and v.shape[0] == inp["X"].shape[0] else v) for k, v in inp.items()}
+        one["compound_edge_index"] = inp["compound_edge_index"][:, inp["compound_edge_index"][0] < n0]
+        one["LAS_edge_index"] = inp["LAS_edge_index"][:, inp["LAS_edge_index"][0] < n0]
+        Xs, Hs, _ = _hip(m, one, dev)
+        l0 = lig[:n0]
+        es = float((((Xs - X1[:n0])[l0] * 5) ** 2).sum(-1).mean().sqrt())
+        ehs = float((Hs - H1[:n0]).abs().max()) / max(1.0, float(H1.abs().max()))
+        print("%s B=64: complex 0 in the batch vs alone: ligand RMSD %.3e A, H %.3e" % (prec, es, ehs))
+        assert es < tol_single and ehs < 1e-4
+    finally:
+        engine.set_precision("fp32")
