@@ -224,6 +224,45 @@ def prepare_stack_params(model):
     return cached_pack(model, _build_stack_params)
 
 
+def cam_node_params(cam):
+    """Node-path parameters of one CrossAttentionModule (both RowAttentionBlocks' projections, both node transitions, the
+    32-wide Hadamard projections) in the kernels' layout."""
+    wd = _wd()
+    W = lambda t: t.to(wd).contiguous()
+    d = {}
+    for tag, blk in (("p", cam.p_attention_block), ("c", cam.c_attention_block)):
+        a = blk.mha
+        d["Wqg_" + tag] = W(_cat([a.linear_q.weight, a.linear_g.weight]))
+        d["bqg_" + tag] = _cat([torch.zeros_like(a.linear_g.bias), a.linear_g.bias]).contiguous()
+        d["Wkv_" + tag] = W(_cat([a.linear_k.weight, a.linear_v.weight]))
+        d["Wo_" + tag], d["bo_" + tag] = W(a.linear_o.weight), a.linear_o.bias
+    for tag, tr in (("p", cam.p_transition), ("c", cam.c_transition)):
+        d["Wt1_" + tag], d["bt1_" + tag] = W(tr.linear_1.weight), tr.linear_1.bias
+        d["Wt2_" + tag], d["bt2_" + tag] = W(tr.linear_2.weight), tr.linear_2.bias
+    i32 = cam.inter_layer
+    z32w = torch.zeros_like(i32.linear_p.weight)
+    z32b = torch.zeros_like(i32.linear_p.bias)
+    d["W_ab32"] = W(_cat([i32.linear_p.weight, z32w, i32.linear_c.weight, z32w]))
+    d["b_ab32"] = _cat([i32.linear_p.bias, z32b, i32.linear_c.bias, z32b]).contiguous()
+    return d
+
+
+def att_edge_params(m):
+    """Inter-edge attention parameters of one MC_Att_L (egnn.py:197-252): q | k | v projections with the interleaved kv split
+    (k = kv[0::2], v = kv[1::2], egnn.py:205) undone, the radial columns, the coordinate MLP."""
+    wd = _wd()
+    W = lambda t: t.to(wd).contiguous()
+    d = {}
+    Wkv, bkv = m.linear_kv.weight, m.linear_kv.bias
+    d["Wqkv"] = W(_cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]]))
+    d["bqkv"] = _cat([m.linear_q.bias, bkv[0::2], bkv[1::2]]).contiguous()
+    d["w_rk"], d["w_rv"] = Wkv[0::2, 0].contiguous(), Wkv[1::2, 0].contiguous()
+    d["Wc"], d["bc"] = W(m.coord_mlp[0].weight), m.coord_mlp[0].bias
+    d["w3"] = m.coord_mlp[2].weight[0].contiguous()
+    d["wcr"] = (m.coord_mlp[0].weight @ d["w_rv"]).contiguous()
+    return d
+
+
 def _build_stack_params(model):
     wd = _wd()
     gnn = model.gnn
@@ -254,35 +293,16 @@ def _build_stack_params(model):
     for i in range(L):
         m = getattr(gnn, "att_%d" % i)
         cam = m.cross_attn_module
-        d = {}
-        for tag, blk in (("p", cam.p_attention_block), ("c", cam.c_attention_block)):
-            a = blk.mha
-            d["Wqg_" + tag] = W(_cat([a.linear_q.weight, a.linear_g.weight]))
-            d["bqg_" + tag] = _cat([torch.zeros_like(a.linear_g.bias), a.linear_g.bias]).contiguous()
-            d["Wkv_" + tag] = W(_cat([a.linear_k.weight, a.linear_v.weight]))
-            d["Wo_" + tag], d["bo_" + tag] = W(a.linear_o.weight), a.linear_o.bias
-        for tag, tr in (("p", cam.p_transition), ("c", cam.c_transition)):
-            d["Wt1_" + tag], d["bt1_" + tag] = W(tr.linear_1.weight), tr.linear_1.bias
-            d["Wt2_" + tag], d["bt2_" + tag] = W(tr.linear_2.weight), tr.linear_2.bias
+        d = cam_node_params(cam)
         i32 = cam.inter_layer
         # the 32-wide Hadamard block is zero-padded to 64 columns so that K = H + 64 stays a multiple of 64
         # (LDS-DMA GEMM path); the padded rows/columns are exact zeros and do not change the result
-        z32w = torch.zeros_like(i32.linear_p.weight)
-        z32b = torch.zeros_like(i32.linear_p.bias)
-        d["W_ab32"] = W(_cat([i32.linear_p.weight, z32w, i32.linear_c.weight, z32w]))
-        d["b_ab32"] = _cat([i32.linear_p.bias, z32b, i32.linear_c.bias, z32b]).contiguous()
         pt = cam.pair_transition
         Woo = _cat([Wo0, i32.linear_out.weight, torch.zeros_like(i32.linear_out.weight)], 1)   # [H, H+64]
         d["Wcomp1"] = W(pt.linear_1.weight @ Woo)                    # [2H, H+64]
         d["bcomp1"] = (pt.linear_1.weight @ (bo0 + i32.linear_out.bias) + pt.linear_1.bias).contiguous()
         d["u"] = (pt.linear_2.weight.t() @ m.attn_bias_proj.weight[0]).contiguous()   # [2H]
-        Wkv, bkv = m.linear_kv.weight, m.linear_kv.bias
-        d["Wqkv"] = W(_cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]]))
-        d["bqkv"] = _cat([m.linear_q.bias, bkv[0::2], bkv[1::2]]).contiguous()
-        d["w_rk"], d["w_rv"] = Wkv[0::2, 0].contiguous(), Wkv[1::2, 0].contiguous()
-        d["Wc"], d["bc"] = W(m.coord_mlp[0].weight), m.coord_mlp[0].bias
-        d["w3"] = m.coord_mlp[2].weight[0].contiguous()
-        d["wcr"] = (m.coord_mlp[0].weight @ d["w_rv"]).contiguous()
+        d.update(att_edge_params(m))
         att.append(d)
     P["att"] = att
     return P

@@ -1,4 +1,6 @@
-"""CrossAttentionModule / RowAttentionBlock parameter containers (reference cross_att.py:7-134)."""
+"""CrossAttentionModule / RowAttentionBlock (reference cross_att.py:7-134): parameters with the reference's names; the stack runs
+their arithmetic through fabind_amd.engine, the stand-alone forwards with the reference's dense signatures go through the
+adapter fabind_amd/dense.py (same kernels)."""
 import torch.nn as nn
 from torch.nn import LayerNorm, Linear
 
@@ -24,7 +26,9 @@ class RowAttentionBlock(nn.Module):
         self.mha = Attention(node_hidden_dim, node_hidden_dim, node_hidden_dim, attention_hidden_dim, no_heads)
 
     def forward(self, node_embed_i, node_embed_j, pair_embed, pair_mask, node_mask_i):
-        raise NotImplementedError("RowAttentionBlock runs fused (fabind_amd.engine.cross_attention)")
+        """Reference signature (cross_att.py:118-134): [*, I, C], [*, J, C], [*, I, J, C_pair], masks -> [*, I, C]."""
+        from .. import dense
+        return dense.row_attention(self, node_embed_i, node_embed_j, pair_embed, pair_mask, node_mask_i)
 
 
 class CrossAttentionModule(nn.Module):
@@ -43,4 +47,6 @@ class CrossAttentionModule(nn.Module):
 
     def forward(self, p_embed_batched, p_mask, c_embed_batched, c_mask, pair_embed, pair_mask, c_c_dist_embed=None,
                 p_p_dist_embed=None):
-        raise NotImplementedError("CrossAttentionModule runs fused (fabind_amd.engine.att_layer)")
+        """Reference signature (cross_att.py:24-54) -> (p', c', pair') as zero-padded dense tensors."""
+        from .. import dense
+        return dense.cross_attention(self, p_embed_batched, p_mask, c_embed_batched, c_mask, pair_embed, pair_mask)

@@ -65,8 +65,15 @@ class MC_Att_L(nn.Module):
         self.inter_layer = InteractionModule(input_nf, output_nf, hidden_nf, opm=opm, rm_layernorm=args.rm_layernorm)
         self.attn_bias_proj = nn.Linear(hidden_nf, 1)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("MC_Att_L runs inside the fused stack (fabind_amd.engine.att_layer)")
+    def forward(self, h, edge_index, coord, edge_attr=None, segment_id=None, batch_id=None, reduced_tuple=None,
+                pair_embed_batched=None, pair_mask=None, LAS_mask=None, p_p_dist_embed=None, c_c_dist_embed=None):
+        """Reference signature (egnn.py:308-333): h [N,H], inter edges [2,E] (both directions), coord [N,1,3], the dense
+        pair embedding [B,Pmax,Cmax,H] + mask -> (h', coord', attention weights [E]).  `reduced_tuple` is recomputed from the
+        edge list.  The stack itself never takes this route (fabind_amd.engine.att_layer works on the factored pair embedding);
+        this adapter packs the dense tensors into ragged lists and runs the same kernels (fabind_amd/dense.py)."""
+        assert edge_attr is None
+        from .. import dense
+        return dense.att_layer(self, h, edge_index, coord, segment_id, batch_id, pair_embed_batched, pair_mask)
 
 
 class FABindLayer(nn.Module):
@@ -121,11 +128,13 @@ class MCAttEGNN(nn.Module):
     def forward(self, h, x, *reference_args, ctx=None, **reference_kwargs):
         """linear_in -> n_layers x FABindLayer -> out_layer -> linear_out (egnn.py:392-466) -> (h_out, x_out).
 
-        The reference passes edge lists and the dense pair tensor positionally; here that state lives in `ctx`
-        (`EfficientMCAttModel.context(...)`: CSR graphs, factored pair embedding), so `ctx` is required."""
+        Two call forms.  `forward(h, x, ctx=EfficientMCAttModel.context(...))`: the stack's own route (CSR graphs and the
+        factored pair embedding live in `ctx`; the dense [B,P,C,H] tensor is never built).  `forward(h, x, ctx_edges,
+        att_edges, LAS_edge_list, batched_complex_coord_LAS, segment_id=, batch_id=, reduced_tuple=, pair_embed_batched=,
+        pair_mask=, ...)`: the reference's positional signature, served by the dense adapter (fabind_amd/dense.py)."""
         if ctx is None:
-            raise NotImplementedError("MCAttEGNN.forward needs ctx=EfficientMCAttModel.context(...): the dense "
-                                      "[B,P,C,H] pair tensor of the reference signature is never materialised")
+            from .. import dense
+            return dense.egnn_forward(self, h, x, *reference_args, **reference_kwargs)
         shp = x.shape
         h2, x2 = ctx.gnn(h, x.reshape(-1, 3))
         return h2, x2.reshape(shp)

@@ -33,7 +33,9 @@ class Attention(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, q_x, kv_x, biases=None):
-        raise NotImplementedError("Attention runs fused inside the FABind layer kernels (fabind_amd.engine.cross_attention)")
+        """Reference signature (model_utils.py:136-159): [*, Q, C_q], [*, K, C_k], biases broadcastable to [*, H, Q, K]."""
+        from .. import dense
+        return dense.attention(self, q_x, kv_x, biases)
 
 
 class Transition(nn.Module):
@@ -73,5 +75,7 @@ class InteractionModule(nn.Module):
         self.linear_out = nn.Linear(hidden_dim, pair_hidden_dim)
 
     def forward(self, p_embed, c_embed, p_mask=None, c_mask=None):
-        raise NotImplementedError(
-            "the dense [B,P,C,H] pair embedding is never materialised on the HIP path (see fabind_amd/engine.py)")
+        """Reference signature (model_utils.py:200-223) -> (inter_embed [*, P, C, pair_hidden], inter_mask [*, P, C]).  The stack
+        never materialises this tensor (fabind_amd/engine.py); this stand-alone form builds it because the API returns it."""
+        from .. import dense
+        return dense.interaction(self, p_embed, c_embed, p_mask, c_mask)

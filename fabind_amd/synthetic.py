@@ -176,11 +176,11 @@ def condition_for_large_graphs(model, message_scale=0.02, coord_boost=300.0):
 
     The reference has no LayerNorm on the production path (--rm-layernorm) and aggregates messages by SUM; its global nodes
     have ~1500 neighbours, so with nn.Linear's default init the residual stream of a 4-layer, hidden-512 stack reaches |h| ~ 1e6
-    and every atom hits the 10 A per-layer clamp (measured with the reference-pinned oracle) -- a chaotic regime no trained
+    and every atom hits the 10 A per-layer clamp (measured with the CPU restatement of the reference under tests/) -- a chaotic regime no trained
     checkpoint lives in and in which parity numbers mean nothing.  Scaling the OUTPUT Linear of every intra-graph message MLP
     (`edge_mlp.2`, weight and bias) by `message_scale` keeps |h| = O(0.1-1); the coordinate heads (`coord_mlp.2`, xavier gain
     1e-3 in the reference) are scaled by `coord_boost` so that the ligand moves ~0.2 A per stack pass instead of 1e-3 A.
-    Used by the headline-shape parity tests and by bench.py (same weights on the oracle and on the HIP path)."""
+    Used by the headline-shape parity tests and by bench.py (same weights on the CPU checker and on the HIP path)."""
     with torch.no_grad():
         for n, p in model.named_parameters():
             if ".edge_mlp.2." in n:
