@@ -10,6 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))          # tests/test_gpu_stack.py (the args helper) imports the checker
 
 text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
 section = text[text.index("## 1."):]

@@ -176,7 +176,7 @@ def test_mcattegnn_forward_positional_reference_signature():
     assert las_in.dim() == 2                                   # squeezed in place like the reference (egnn.py:435)
     assert len(atts) == 2 and atts[0].shape[0] == inter.shape[1]
     lig = inp["mask"].numpy()
-    rm = float(np.sqrt((((xg[:, 0].cpu().numpy() - xr.numpy())[lig] * 5) ** 2).sum(-1).mean()))
+    rm = float(np.sqrt((((xg[:, 0].detach().cpu().numpy() - xr.numpy())[lig] * 5) ** 2).sum(-1).mean()))
     assert rm < 1e-4, rm
     _close(hg, hr, 1e-4, "h_out")
     # the same module through the stack's own route gives the same answer
