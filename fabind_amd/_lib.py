@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfabind_hip.so")
 
-ABI_VERSION = 4          # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
+ABI_VERSION = 5          # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -67,6 +67,10 @@ SIGNATURES = {
     "fabind_coord_update": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
     "fabind_cross_attn_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i,
                               _vp],
+    "fabind_cross_attn_mfma_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i,
+                                   _vp],
+    "fabind_cross_attn_mfma_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp],
     "fabind_pair_bmat": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp],
     "fabind_pair_hadamard": [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
     "fabind_inter_attn_fwd": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,

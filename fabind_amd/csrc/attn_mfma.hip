@@ -1,0 +1,564 @@
+// Protein<->ligand cross attention (RowAttentionBlock / Attention._attention, reference models/cross_att.py:118-134,
+// models/model_utils.py:21-38,96-133) as MFMA bf16 tiles for gfx950 -- forward and both backward passes.
+//
+// The block is 4 heads x 32 channels, so one v_mfma_f32_16x16x32_bf16 contracts a whole head: a 16-key x 16-query
+// score tile is ONE instruction per head.  All three kernels use the "swapped" orientation so that the softmax axis
+// stays inside a lane and the probabilities feed the second contraction straight from the accumulator registers:
+//
+//   forward / pass Q (wave = 16 queries, loop over 32-key chunks):
+//     S^T[key, query]  = K[key, :] . Q^T          A = K tile (LDS, row-major, swizzled),  B = Q fragment (registers)
+//     lane (n = query, kq = lane>>4) then holds keys {t*16 + kq*4 + r}: bias add, exp, row statistics are lane-local
+//     (+ two xor-shuffles across kq), and {p[t=0][0..3], p[t=1][0..3]} IS the B fragment of
+//     O^T[dim, query] += V^T[dim, key'] . P^T[key', query]   with the LDS image of V^T stored in the permuted key order
+//     key' = kq*8 + t*4 + r  (no cross-lane movement, no P round trip through LDS).
+//   pass KV (wave = 16 keys, loop over 32-query chunks): the same with the roles of queries and keys exchanged.
+//
+// Scores, softmax statistics, the pair bias lin * sigmoid(gate) and every output stay fp32; bf16 only as MFMA operands
+// (Q, K, V, P, dO, dS).  The fp32 VALU kernels (attn.hip / bwd.hip) remain the parity-mode path.  The work is bound by
+// the pair-bias stream (32 B per (query, key) pair against 512 flop), not by the matrix cores: see DESIGN.md section 6.
+#include "common.h"
+#include "fabind_hip.h"
+
+#define CM_KC 32                                   // keys (pass KV: queries) per chunk = K of the second contraction
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+__device__ __forceinline__ bf16x8_t cm_pack8(const float* f) {
+    u32x4_t u;
+    u[0] = pack2_bf16(f[0], f[1]); u[1] = pack2_bf16(f[2], f[3]); u[2] = pack2_bf16(f[4], f[5]); u[3] = pack2_bf16(f[6], f[7]);
+    return *(bf16x8_t*)&u;
+}
+// position of chunk-local row `l` (0..31) in the permuted K order of the second contraction
+__device__ __forceinline__ int cm_perm(int l) { return ((l >> 2) & 3) * 8 + (l >> 4) * 4 + (l & 3); }
+
+// row-major image [32 rows][128 cols] bf16, 16-B chunks XOR-swizzled by the row: A operand of the first contraction
+__device__ __forceinline__ void cm_store_rows(unsigned char* img, int row, int c4, float4 v) {
+    *(uint2*)(img + row * 256 + ((((c4 >> 3) ^ (row & 15))) << 4) + (c4 & 4) * 2) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
+}
+__device__ __forceinline__ bf16x8_t cm_load_rows(const unsigned char* img, int row, int chunk) {
+    return *(const bf16x8_t*)(img + row * 256 + ((chunk ^ (row & 15)) << 4));
+}
+// transposed image [128 cols][32 permuted rows] bf16 (64 B per column, 16-B chunks XOR-swizzled by (col>>2)&3): A operand of the
+// second contraction.  Staged by 256 threads from fp32 rows in global memory: thread = (column, pair of kq groups); the eight
+// rows of one 16-B chunk are read as scalars (coalesced across the lanes' columns) and written with one ds_write_b128 --
+// 16 lanes cover all 64 banks once (per-element 2-B stores at a 64-B column stride were 8-way conflicted).
+__device__ __forceinline__ void cm_stage_cols(unsigned char* img, const float* __restrict__ src, int ld, long row0, int nrows,
+                                              float mul, int tid) {
+    const int col = tid & 127, g = tid >> 7;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int kq = g * 2 + kk;
+        float f[8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = t * 16 + kq * 4 + r;
+                f[t * 4 + r] = (row < nrows) ? src[(size_t)(row0 + row) * ld + col] * mul : 0.f;
+            }
+        *(bf16x8_t*)(img + col * 64 + ((kq ^ ((col >> 2) & 3)) << 4)) = cm_pack8(f);
+    }
+}
+// row-major image of `nrows` (<= 32) fp32 rows [.,128] starting at row0, scaled by mul; rows beyond nrows are zero
+__device__ __forceinline__ void cm_stage_rows(unsigned char* img, const float* __restrict__ src, int ld, long row0, int nrows,
+                                              float mul, int tid) {
+    for (int i = tid; i < CM_KC * 32; i += 256) {
+        const int jr = i >> 5, c4 = (i & 31) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (jr < nrows) {
+            v = *(const float4*)(src + (size_t)(row0 + jr) * ld + c4);
+            v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+        }
+        cm_store_rows(img, jr, c4, v);
+    }
+}
+__device__ __forceinline__ bf16x8_t cm_load_cols(const unsigned char* img, int col, int kq) {
+    return *(const bf16x8_t*)(img + col * 64 + ((kq ^ ((col >> 2) & 3)) << 4));
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cross_attn_mfma_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                                  const float* __restrict__ v, int ldkv,
+                                                                  const float* __restrict__ gpre, int ldg,
+                                                                  const float* __restrict__ bias, int bias_ld, int lin_col,
+                                                                  int gate_col, const int* desc, float scale, float* out, int ldo,
+                                                                  float* lse, int ksplit, float* part) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK[CM_KC * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char sVt[128 * 64];
+    const int* ds = desc + blockIdx.y * 8;
+    const int q_off = ds[0], nq = ds[1], k_off = ds[2], nk = ds[3];
+    const long pair_off = (long)(unsigned)ds[4] | ((long)ds[5] << 32);
+    const int sq = ds[6], sk = ds[7];
+    if ((int)(blockIdx.x * 64) >= nq) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const int qi = blockIdx.x * 64 + wave * 16 + n;
+    const bool qvalid = qi < nq;
+    const size_t qrow = (size_t)(q_off + (qvalid ? qi : 0));
+    bf16x8_t bq[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        float f[8];
+        const float4 a = *(const float4*)(q + qrow * ldq + h * 32 + kq * 8), b = *(const float4*)(q + qrow * ldq + h * 32 + kq * 8 + 4);
+        f[0] = a.x * scale; f[1] = a.y * scale; f[2] = a.z * scale; f[3] = a.w * scale;
+        f[4] = b.x * scale; f[5] = b.y * scale; f[6] = b.z * scale; f[7] = b.w * scale;
+        if (!qvalid) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f[u] = 0.f;
+        }
+        bq[h] = cm_pack8(f);
+    }
+    f32x4_t o[4][2];
+    float m[4], l[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        m[h] = -INFINITY; l[h] = 0.f;
+        o[h][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; o[h][1] = o[h][0];
+    }
+    int kb = 0, ke = nk;
+    if (ksplit > 1) {
+        const int per = ((nk + ksplit - 1) / ksplit + CM_KC - 1) / CM_KC * CM_KC;
+        kb = blockIdx.z * per; ke = min(nk, kb + per);
+    }
+    for (int j0 = kb; j0 < ke; j0 += CM_KC) {
+        __syncthreads();
+        cm_stage_rows(sK, k, ldkv, (long)k_off + j0, ke - j0, 1.f, tid);
+        cm_stage_cols(sVt, v, ldkv, (long)k_off + j0, ke - j0, 1.f, tid);
+        __syncthreads();
+        // pair bias of this lane's 8 (query, key) pairs: all four heads of a pair are one 32-B segment (issued before the MFMAs)
+        float4 lin[2][4], gat[2][4];
+        bool ok[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + t * 16 + kq * 4 + r;
+                ok[t][r] = qvalid && j < ke;
+                const size_t bi = (size_t)(pair_off + (long)(qvalid ? qi : 0) * sq + (long)min(j, ke - 1) * sk) * bias_ld;
+                lin[t][r] = *(const float4*)(bias + bi + lin_col);
+                gat[t][r] = *(const float4*)(bias + bi + gate_col);
+            }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            f32x4_t s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm_load_rows(sK, t * 16 + n, h * 4 + kq), bq[h],
+                                                                f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float lv = ((const float*)&lin[t][r])[h], gv = ((const float*)&gat[t][r])[h];
+                    const float sv = ok[t][r] ? s[t][r] + lv * sigmoid_f(gv) : -INFINITY;
+                    s[t][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m[h], mx);
+            const float ms = (mn == -INFINITY) ? 0.f : mn;
+            const float corr = __expf(m[h] - ms);
+            float p[8], ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { p[t * 4 + r] = __expf(s[t][r] - ms); ps += p[t * 4 + r]; }
+            l[h] = l[h] * corr + ps;
+            m[h] = mn;
+            const bf16x8_t pf = cm_pack8(p);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[h][mi][r] *= corr;
+                o[h][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm_load_cols(sVt, h * 32 + mi * 16 + n, kq), pf, o[h][mi], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        l[h] += __shfl_xor(l[h], 16, 64);
+        l[h] += __shfl_xor(l[h], 32, 64);
+    }
+    if (!qvalid) return;
+    if (ksplit > 1) {      // un-normalised partial: [row][split][head][34] = o[32], m, l  (merged by cross_attn_mfma_combine_kernel)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            float* pp = part + (((size_t)(q_off + qi) * ksplit + blockIdx.z) * 4 + h) * 34;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pp[mi * 16 + kq * 4 + r] = o[h][mi][r];
+            if (kq == 0) { pp[32] = m[h]; pp[33] = l[h]; }
+        }
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const float inv = 1.f / l[h];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int c = h * 32 + mi * 16 + kq * 4;
+            const float4 g = *(const float4*)(gpre + qrow * ldg + c);
+            *(float4*)(out + qrow * ldo + c) = make_float4(o[h][mi][0] * inv * sigmoid_f(g.x), o[h][mi][1] * inv * sigmoid_f(g.y),
+                                                           o[h][mi][2] * inv * sigmoid_f(g.z), o[h][mi][3] * inv * sigmoid_f(g.w));
+        }
+        if (lse && kq == 0) lse[qrow * 4 + h] = m[h] + __logf(l[h]);
+    }
+}
+
+__global__ __launch_bounds__(256) void cross_attn_mfma_combine_kernel(const float* __restrict__ part, int ksplit,
+                                                                      const float* __restrict__ gpre, int ldg, int n_rows, float* out,
+                                                                      int ldo, float* lse) {
+    const int t = blockIdx.x * 256 + threadIdx.x;          // (row, head)
+    if (t >= n_rows * 4) return;
+    const int rowi = t >> 2, h = t & 3;
+    float M = -INFINITY;
+    for (int s_ = 0; s_ < ksplit; ++s_) M = fmaxf(M, part[(((size_t)rowi * ksplit + s_) * 4 + h) * 34 + 32]);
+    float L = 0.f, o[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = 0.f;
+    for (int s_ = 0; s_ < ksplit; ++s_) {
+        const float* pp = part + (((size_t)rowi * ksplit + s_) * 4 + h) * 34;
+        const float w = (pp[33] > 0.f) ? __expf(pp[32] - M) : 0.f;
+        L += pp[33] * w;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) o[d] += pp[d] * w;
+    }
+    const float inv = 1.f / L;
+#pragma unroll
+    for (int d = 0; d < 32; ++d)
+        out[(size_t)rowi * ldo + h * 32 + d] = o[d] * inv * sigmoid_f(gpre[(size_t)rowi * ldg + h * 32 + d]);
+    if (lse) lse[(size_t)rowi * 4 + h] = M + __logf(L);
+}
+
+extern "C" int fabind_cross_attn_mfma_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* gpre,
+                                          int ldg, const float* bias, int bias_ld, int lin_col, int gate_col, const int* desc, int B,
+                                          int max_nq, float scale, float* out, int ldo, float* lse, int ksplit, float* part,
+                                          int n_rows, hipStream_t stream) {
+    FB_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0, "fabind_cross_attn_mfma_fwd: strides % 4");
+    FB_REQUIRE(bias_ld % 4 == 0 && lin_col % 4 == 0 && gate_col % 4 == 0, "fabind_cross_attn_mfma_fwd: bias columns % 4");
+    if (B <= 0 || max_nq <= 0) return 0;
+    if (ksplit < 1) ksplit = 1;
+    FB_REQUIRE(ksplit == 1 || part != nullptr, "fabind_cross_attn_mfma_fwd: ksplit > 1 needs the partials buffer");
+    hipLaunchKernelGGL(cross_attn_mfma_fwd_kernel, dim3((max_nq + 63) / 64, B, ksplit), dim3(256), 0, stream, q, ldq, k, v, ldkv,
+                       gpre, ldg, bias, bias_ld, lin_col, gate_col, desc, scale, out, ldo, lse, ksplit, part);
+    if (ksplit > 1)
+        hipLaunchKernelGGL(cross_attn_mfma_combine_kernel, dim3((n_rows * 4 + 255) / 256), dim3(256), 0, stream, part, ksplit, gpre,
+                           ldg, n_rows, out, ldo, lse);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, pass Q: d q, d gpre, d bias (lin, gate), and the per-query helpers dO = dout * sigmoid(gpre), D = dout . out
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cross_attn_mfma_bwd_q_kernel(const float* __restrict__ qg, int ldq, const float* __restrict__ kv,
+                                                                    int ldkv, const float* __restrict__ bias, int bias_ld,
+                                                                    int lin_col, int gate_col, const int* desc, float scale,
+                                                                    const float* __restrict__ out, const float* lse,
+                                                                    const float* __restrict__ dout, float* dqg, float* dbias,
+                                                                    float* dO, float* Dv, int ksplit, float* part, int part_rows) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK[CM_KC * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[CM_KC * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char sKt[128 * 64];
+    const int* ds = desc + blockIdx.y * 8;
+    const int q_off = ds[0], nq = ds[1], k_off = ds[2], nk = ds[3];
+    const long pair_off = (long)(unsigned)ds[4] | ((long)ds[5] << 32);
+    const int sq = ds[6], sk = ds[7];
+    if ((int)(blockIdx.x * 64) >= nq) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const int qi = blockIdx.x * 64 + wave * 16 + n;
+    const bool qvalid = qi < nq;
+    const size_t qrow = (size_t)(q_off + (qvalid ? qi : 0));
+    bf16x8_t bq[4], bdo[4];
+    float D[4], L[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int c = h * 32 + kq * 8;
+        float fq[8], fo[8], dsum = 0.f;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const float4 a = *(const float4*)(qg + qrow * ldq + c + half * 4);
+            const float4 g = *(const float4*)(qg + qrow * ldq + 128 + c + half * 4);
+            const float4 ov = *(const float4*)(out + qrow * 128 + c + half * 4);
+            const float4 dv = *(const float4*)(dout + qrow * 128 + c + half * 4);
+            const float av[4] = {a.x, a.y, a.z, a.w}, gv[4] = {g.x, g.y, g.z, g.w}, o4[4] = {ov.x, ov.y, ov.z, ov.w},
+                        d4[4] = {dv.x, dv.y, dv.z, dv.w};
+            float dg[4], dov[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float sg = sigmoid_f(gv[u]);
+                fq[half * 4 + u] = qvalid ? av[u] * scale : 0.f;
+                dov[u] = qvalid ? d4[u] * sg : 0.f;
+                fo[half * 4 + u] = dov[u];
+                dsum += d4[u] * o4[u];
+                dg[u] = d4[u] * o4[u] * (1.f - sg);
+            }
+            if (qvalid && blockIdx.z == 0) {
+                *(float4*)(dqg + qrow * ldq + 128 + c + half * 4) = make_float4(dg[0], dg[1], dg[2], dg[3]);     // d gpre
+                *(float4*)(dO + qrow * 128 + c + half * 4) = make_float4(dov[0], dov[1], dov[2], dov[3]);
+            }
+        }
+        dsum += __shfl_xor(dsum, 16, 64);
+        dsum += __shfl_xor(dsum, 32, 64);
+        D[h] = dsum;
+        L[h] = qvalid ? lse[qrow * 4 + h] : 0.f;
+        if (qvalid && kq == 0 && blockIdx.z == 0) Dv[qrow * 4 + h] = dsum;
+        bq[h] = cm_pack8(fq);
+        bdo[h] = cm_pack8(fo);
+    }
+    f32x4_t dq[4][2];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) { dq[h][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dq[h][1] = dq[h][0]; }
+    int kb = 0, ke = nk;
+    if (ksplit > 1) {
+        const int per = ((nk + ksplit - 1) / ksplit + CM_KC - 1) / CM_KC * CM_KC;
+        kb = blockIdx.z * per; ke = min(nk, kb + per);
+    }
+    for (int j0 = kb; j0 < ke; j0 += CM_KC) {
+        __syncthreads();
+        cm_stage_rows(sK, kv, ldkv, (long)k_off + j0, ke - j0, 1.f, tid);
+        cm_stage_rows(sV, kv + 128, ldkv, (long)k_off + j0, ke - j0, 1.f, tid);
+        cm_stage_cols(sKt, kv, ldkv, (long)k_off + j0, ke - j0, 1.f, tid);
+        __syncthreads();
+        float4 lin[2][4], gat[2][4];
+        bool ok[2][4];
+        size_t bidx[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + t * 16 + kq * 4 + r;
+                ok[t][r] = qvalid && j < ke;
+                bidx[t][r] = (size_t)(pair_off + (long)(qvalid ? qi : 0) * sq + (long)min(j, ke - 1) * sk) * bias_ld;
+                lin[t][r] = *(const float4*)(bias + bidx[t][r] + lin_col);
+                gat[t][r] = *(const float4*)(bias + bidx[t][r] + gate_col);
+            }
+        float dl[2][4][4], dgt[2][4][4];                                  // [t][r][head]: the pair's two 16-B gradient segments
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            f32x4_t s[2], dp[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm_load_rows(sK, t * 16 + n, h * 4 + kq), bq[h],
+                                                                f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm_load_rows(sV, t * 16 + n, h * 4 + kq), bdo[h],
+                                                                 f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+            float dsv[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float lv = ((const float*)&lin[t][r])[h], sg = sigmoid_f(((const float*)&gat[t][r])[h]);
+                    const float p = ok[t][r] ? __expf(s[t][r] + lv * sg - L[h]) : 0.f;
+                    const float dsj = p * (dp[t][r] - D[h]);
+                    dsv[t * 4 + r] = dsj;
+                    dl[t][r][h] = dsj * sg;
+                    dgt[t][r][h] = dsj * lv * sg * (1.f - sg);
+                }
+            const bf16x8_t df = cm_pack8(dsv);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                dq[h][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm_load_cols(sKt, h * 32 + mi * 16 + n, kq), df, dq[h][mi], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ok[t][r]) {
+                    *(float4*)(dbias + bidx[t][r] + lin_col) = make_float4(dl[t][r][0], dl[t][r][1], dl[t][r][2], dl[t][r][3]);
+                    *(float4*)(dbias + bidx[t][r] + gate_col) = make_float4(dgt[t][r][0], dgt[t][r][1], dgt[t][r][2], dgt[t][r][3]);
+                }
+    }
+    if (!qvalid) return;
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int c = h * 32 + mi * 16 + kq * 4;
+            const float4 val = make_float4(dq[h][mi][0] * scale, dq[h][mi][1] * scale, dq[h][mi][2] * scale, dq[h][mi][3] * scale);
+            if (ksplit > 1)     // partial over this key range -> part[split][complex][local query][128]
+                *(float4*)(part + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * part_rows + qi) * 128 + c) = val;
+            else
+                *(float4*)(dqg + qrow * ldq + c) = val;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, pass KV: d k, d v (wave = 16 keys, loop over 32-query chunks; probabilities recomputed from the saved log-sum-exp)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cross_attn_mfma_bwd_kv_kernel(const float* __restrict__ qg, int ldq, const float* __restrict__ kv,
+                                                                     int ldkv, const float* __restrict__ bias, int bias_ld,
+                                                                     int lin_col, int gate_col, const int* desc, float scale,
+                                                                     const float* lse, const float* __restrict__ dO, const float* Dv,
+                                                                     float* dkv, int qsplit, float* part, int part_rows) {
+    __shared__ __attribute__((aligned(16))) unsigned char sQ[CM_KC * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char sDO[CM_KC * 256];
+    __shared__ __attribute__((aligned(16))) unsigned char sQt[128 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char sDOt[128 * 64];
+    __shared__ float sL[CM_KC * 4], sD[CM_KC * 4];
+    const int* ds = desc + blockIdx.y * 8;
+    const int q_off = ds[0], nq = ds[1], k_off = ds[2], nk = ds[3];
+    const long pair_off = (long)(unsigned)ds[4] | ((long)ds[5] << 32);
+    const int sq = ds[6], sk = ds[7];
+    if ((int)(blockIdx.x * 64) >= nk) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    const int kj = blockIdx.x * 64 + wave * 16 + n;
+    const bool kvalid = kj < nk;
+    const size_t krow = (size_t)(k_off + (kvalid ? kj : 0));
+    bf16x8_t bk[4], bv[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        float fk[8], fv[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const float4 a = *(const float4*)(kv + krow * ldkv + h * 32 + kq * 8 + half * 4);
+            const float4 b = *(const float4*)(kv + krow * ldkv + 128 + h * 32 + kq * 8 + half * 4);
+            fk[half * 4] = a.x; fk[half * 4 + 1] = a.y; fk[half * 4 + 2] = a.z; fk[half * 4 + 3] = a.w;
+            fv[half * 4] = b.x; fv[half * 4 + 1] = b.y; fv[half * 4 + 2] = b.z; fv[half * 4 + 3] = b.w;
+        }
+        if (!kvalid) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { fk[u] = 0.f; fv[u] = 0.f; }
+        }
+        bk[h] = cm_pack8(fk);
+        bv[h] = cm_pack8(fv);
+    }
+    f32x4_t dk[4][2], dv[4][2];
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) { dk[h][mi] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dv[h][mi] = dk[h][mi]; }
+    int qb = 0, qe = nq;
+    if (qsplit > 1) {
+        const int per = ((nq + qsplit - 1) / qsplit + CM_KC - 1) / CM_KC * CM_KC;
+        qb = blockIdx.z * per; qe = min(nq, qb + per);
+    }
+    for (int i0 = qb; i0 < qe; i0 += CM_KC) {
+        __syncthreads();
+        // q is staged PRE-SCALED (like the forward's fragment), so that the recomputed scores round exactly as the ones whose
+        // log-sum-exp was saved; d k = dS^T (scale q) then needs no further factor
+        cm_stage_rows(sQ, qg, ldq, (long)q_off + i0, qe - i0, scale, tid);
+        cm_stage_rows(sDO, dO, 128, (long)q_off + i0, qe - i0, 1.f, tid);
+        cm_stage_cols(sQt, qg, ldq, (long)q_off + i0, qe - i0, scale, tid);
+        cm_stage_cols(sDOt, dO, 128, (long)q_off + i0, qe - i0, 1.f, tid);
+        if (tid < CM_KC * 4) {
+            const int ir = tid >> 2;
+            sL[tid] = (i0 + ir < qe) ? lse[(size_t)(q_off + i0 + ir) * 4 + (tid & 3)] : 0.f;
+            sD[tid] = (i0 + ir < qe) ? Dv[(size_t)(q_off + i0 + ir) * 4 + (tid & 3)] : 0.f;
+        }
+        __syncthreads();
+        // S[query, key] = Q . K^T: the lane holds queries {t*16 + kq*4 + r} of its key
+        float4 lin[2][4], gat[2][4];
+        bool ok[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = i0 + t * 16 + kq * 4 + r;
+                ok[t][r] = kvalid && i < qe;
+                const size_t bi = (size_t)(pair_off + (long)min(i, qe - 1) * sq + (long)(kvalid ? kj : 0) * sk) * bias_ld;
+                lin[t][r] = *(const float4*)(bias + bi + lin_col);
+                gat[t][r] = *(const float4*)(bias + bi + gate_col);
+            }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            f32x4_t s[2], dp[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm_load_rows(sQ, t * 16 + n, h * 4 + kq), bk[h],
+                                                                f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm_load_rows(sDO, t * 16 + n, h * 4 + kq), bv[h],
+                                                                 f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            }
+            // NOTE the first contraction here has queries as M (rows of the LDS image) and this lane's key as N
+            float pv[8], dsv[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int il = t * 16 + kq * 4 + r;
+                    const float lv = ((const float*)&lin[t][r])[h], sg = sigmoid_f(((const float*)&gat[t][r])[h]);
+                    const float p = ok[t][r] ? __expf(s[t][r] + lv * sg - sL[il * 4 + h]) : 0.f;
+                    pv[t * 4 + r] = p;
+                    dsv[t * 4 + r] = p * (dp[t][r] - sD[il * 4 + h]);
+                }
+            const bf16x8_t pf = cm_pack8(pv), df = cm_pack8(dsv);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                dv[h][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm_load_cols(sDOt, h * 32 + mi * 16 + n, kq), pf, dv[h][mi], 0, 0, 0);
+                dk[h][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm_load_cols(sQt, h * 32 + mi * 16 + n, kq), df, dk[h][mi], 0, 0, 0);
+            }
+        }
+    }
+    if (!kvalid) return;
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int c = h * 32 + mi * 16 + kq * 4;
+            const float4 a = make_float4(dk[h][mi][0], dk[h][mi][1], dk[h][mi][2], dk[h][mi][3]);
+            const float4 b = make_float4(dv[h][mi][0], dv[h][mi][1], dv[h][mi][2], dv[h][mi][3]);
+            if (qsplit > 1) {   // partial over this query range -> part[split][complex][local key][256] (dk | dv)
+                float* pp = part + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * part_rows + kj) * 256;
+                *(float4*)(pp + c) = a;
+                *(float4*)(pp + 128 + c) = b;
+            } else {
+                *(float4*)(dkv + krow * ldkv + c) = a;
+                *(float4*)(dkv + krow * ldkv + 128 + c) = b;
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void cross_attn_mfma_split_reduce_kernel(const float* __restrict__ part, int nsplit, int part_rows,
+                                                                           int cols, const int* __restrict__ desc, int off_idx,
+                                                                           int cnt_idx, float* __restrict__ out, int ldo) {
+    const int* ds = desc + blockIdx.y * 8;
+    const int off = ds[off_idx], n = ds[cnt_idx];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int r = idx / cols, c = idx % cols;
+    if (r >= n) return;
+    float acc = 0.f;
+    for (int z = 0; z < nsplit; ++z) acc += part[(((size_t)z * gridDim.y + blockIdx.y) * part_rows + r) * cols + c];
+    out[(size_t)(off + r) * ldo + c] = acc;
+}
+
+static void cm_splits(int max_nq, int max_nk, int* ksplit, int* qsplit) {
+    *ksplit = (max_nq <= 256 && max_nk >= 512) ? max_nk / 128 : 1;
+    *qsplit = (max_nk <= 256 && max_nq >= 512) ? max_nq / 128 : 1;
+    if (*ksplit > 32) *ksplit = 32;
+    if (*qsplit > 32) *qsplit = 32;
+}
+
+// Same contract, arguments and scratch size (fabind_cross_attn_bwd_scratch) as fabind_cross_attn_bwd.
+extern "C" int fabind_cross_attn_mfma_bwd(const float* qg, int ldq, const float* kv, int ldkv, const float* bias, int bias_ld,
+                                          int lin_col, int gate_col, const int* desc, int B, int max_nq, int max_nk, float scale,
+                                          const float* out, const float* lse, const float* dout, float* dqg, float* dkv, float* dbias,
+                                          float* dO, float* Dv, float* scratch, hipStream_t stream) {
+    if (B <= 0) return 0;
+    FB_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0, "fabind_cross_attn_mfma_bwd: strides % 4");
+    FB_REQUIRE(bias_ld % 4 == 0 && lin_col % 4 == 0 && gate_col % 4 == 0, "fabind_cross_attn_mfma_bwd: bias columns % 4");
+    int ksplit, qsplit;
+    cm_splits(max_nq, max_nk, &ksplit, &qsplit);
+    FB_REQUIRE((ksplit == 1 && qsplit == 1) || scratch != nullptr,
+               "fabind_cross_attn_mfma_bwd: this shape splits a pass and needs fabind_cross_attn_bwd_scratch() floats of scratch");
+    hipLaunchKernelGGL(cross_attn_mfma_bwd_q_kernel, dim3((max_nq + 63) / 64, B, ksplit), dim3(256), 0, stream, qg, ldq, kv, ldkv,
+                       bias, bias_ld, lin_col, gate_col, desc, scale, out, lse, dout, dqg, dbias, dO, Dv, ksplit, scratch, max_nq);
+    if (ksplit > 1)
+        hipLaunchKernelGGL(cross_attn_mfma_split_reduce_kernel, dim3((max_nq * 128 + 255) / 256, B), dim3(256), 0, stream, scratch,
+                           ksplit, max_nq, 128, desc, 0, 1, dqg, ldq);
+    hipLaunchKernelGGL(cross_attn_mfma_bwd_kv_kernel, dim3((max_nk + 63) / 64, B, qsplit), dim3(256), 0, stream, qg, ldq, kv, ldkv,
+                       bias, bias_ld, lin_col, gate_col, desc, scale, lse, dO, Dv, dkv, qsplit, scratch, max_nk);
+    if (qsplit > 1)
+        hipLaunchKernelGGL(cross_attn_mfma_split_reduce_kernel, dim3((max_nk * 256 + 255) / 256, B), dim3(256), 0, stream, scratch,
+                           qsplit, max_nk, 256, desc, 2, 3, dkv, ldkv);
+    FB_CHECK_LAUNCH();
+    return 0;
+}

@@ -203,15 +203,30 @@ def coord_update(x, d, s_part, rowptr, mean, clampv, weight=None, want_s=False):
     return x_out, s_out
 
 
+CROSS_ATTN_MFMA = None   # None: MFMA bf16 tiles in bf16 mode, fp32 VALU kernels in fp32 (parity) mode; True / False force one
+
+
+def cross_attn_use_mfma():
+    from .config import get_precision
+    return (get_precision() == "bf16") if CROSS_ATTN_MFMA is None else bool(CROSS_ATTN_MFMA)
+
+
 def cross_attn_fwd(q, k, v, gpre, bias, lin_col, gate_col, desc, B, max_nq, scale, out, want_lse=False, max_nk=0):
+    """Gated cross attention with pair bias (include/fabind_hip.h: fabind_cross_attn_fwd / fabind_cross_attn_mfma_fwd)."""
     lse = torch.empty((q.shape[0], 4), dtype=torch.float32, device=q.device) if want_lse else None
     assert k.stride(0) == v.stride(0)
     # few queries / many keys (ligand-query block): split the keys so that the launch fills the chip
     ksplit = max(1, min(32, max_nk // 128)) if (max_nq <= 256 and max_nk >= 512) else 1
     part = torch.empty(q.shape[0] * ksplit * 4 * 34, dtype=torch.float32, device=q.device) if ksplit > 1 else None
-    check(_lib.load().fabind_cross_attn_fwd(ptr(q), _ld(q), ptr(k), ptr(v), _ld(k), ptr(gpre), _ld(gpre), ptr(bias),
-                                            _ld(bias), lin_col, gate_col, ptr(desc), B, max_nq, scale, ptr(out), _ld(out),
-                                            ptr(lse), ksplit, ptr(part), q.shape[0], stream()), "fabind_cross_attn_fwd")
+    mfma = cross_attn_use_mfma()
+    fn = _lib.load().fabind_cross_attn_mfma_fwd if mfma else _lib.load().fabind_cross_attn_fwd
+    n_tiles = sum(1 for _ in range(0, max_nq, 16))
+    # executed matrix-core work: per 16-query tile and 32-key chunk, 4 heads x (2 score + 2 value) MFMAs of 16x16x32
+    flops = 2.0 * 16 * 16 * 32 * 16 * n_tiles * ((max_nk + 31) // 32) * B if mfma else 0.0
+    _profiled("cross_attn_%s_fwd B=%d nq<=%d nk<=%d" % ("mfma" if mfma else "fp32", B, max_nq, max_nk), flops,
+              lambda: check(fn(ptr(q), _ld(q), ptr(k), ptr(v), _ld(k), ptr(gpre), _ld(gpre), ptr(bias), _ld(bias), lin_col, gate_col,
+                               ptr(desc), B, max_nq, scale, ptr(out), _ld(out), ptr(lse), ksplit, ptr(part), q.shape[0], stream()),
+                            "fabind_cross_attn_fwd"))
     return out, lse
 
 

@@ -565,6 +565,7 @@ class _CrossAttn(torch.autograd.Function):
         _, lse = K.cross_attn_fwd(qg[:, :128], kv[:, :128], kv[:, 128:], qg[:, 128:], bias, lin_col, gate_col, desc, B,
                                   max_nq, scale, out, want_lse=True, max_nk=max_nk)
         ctx.args = (lin_col, gate_col, desc, B, max_nq, max_nk, scale)
+        ctx.mfma = K.cross_attn_use_mfma()        # the backward recomputes the probabilities the way the forward computed them
         ctx.save_for_backward(qg, kv, bias, out, lse)
         return out
 
@@ -578,9 +579,9 @@ class _CrossAttn(torch.autograd.Function):
         Dv = torch.empty((qg.shape[0], 4), dtype=torch.float32, device=qg.device)
         n_scr = int(load().fabind_cross_attn_bwd_scratch(B, max_nq, max_nk))     # per-split partials of the short side (or 0)
         scr = torch.empty(n_scr, dtype=torch.float32, device=qg.device) if n_scr else None
-        check(load().fabind_cross_attn_bwd(ptr(qg), qg.stride(0), ptr(kv), kv.stride(0), ptr(bias), bias.stride(0), lin_col,
-                                           gate_col, ptr(desc), B, max_nq, max_nk, scale, ptr(out), ptr(lse), ptr(dout),
-                                           ptr(dqg), ptr(dkv), ptr(dbias), ptr(dO), ptr(Dv), ptr(scr), stream()),
+        fn = load().fabind_cross_attn_mfma_bwd if ctx.mfma else load().fabind_cross_attn_bwd
+        check(fn(ptr(qg), qg.stride(0), ptr(kv), kv.stride(0), ptr(bias), bias.stride(0), lin_col, gate_col, ptr(desc), B, max_nq,
+                 max_nk, scale, ptr(out), ptr(lse), ptr(dout), ptr(dqg), ptr(dkv), ptr(dbias), ptr(dO), ptr(Dv), ptr(scr), stream()),
               "fabind_cross_attn_bwd")
         return dqg, dkv, dbias, None, None, None, None, None, None, None
 

@@ -31,8 +31,9 @@ const char* fabind_last_error(void);
  * 3 = fabind_cross_attn_bwd takes a scratch buffer instead of (n_q_rows, n_k_rows), fabind_cross_attn_bwd_scratch added;
  * 4 = fabind_pair_bias_cat takes a colpart argument (per-work-group column sums), fabind_pair_bias_cat_parts and the
  *     fabind_gemm_tn_set_waves knob added.
+ * 5 = fabind_cross_attn_mfma_fwd / fabind_cross_attn_mfma_bwd added (MFMA bf16 form of the cross attention).
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 4
+#define FABIND_ABI_VERSION 5
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -237,6 +238,15 @@ int fabind_cross_attn_fwd(const float* q, int ldq, const float* k, const float* 
                           int max_nq, float scale, float* out, int ldo, float* lse, int ksplit, float* part, int n_rows,
                           hipStream_t stream);
 
+/* The same block with QK^T and softmax.V on the matrix cores (v_mfma_f32_16x16x32_bf16: head dim 32 = one instruction per
+ * 16-key x 16-query tile; csrc/attn_mfma.hip): identical arguments, results and partials layout; q / k / v / probabilities
+ * are rounded to bf16 as MFMA operands, scores, pair bias, softmax statistics and outputs stay fp32.  bias_ld, lin_col and
+ * gate_col must be multiples of 4 (a pair's four heads are read as one 16-byte segment). */
+int fabind_cross_attn_mfma_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* gpre, int ldg,
+                               const float* bias, int bias_ld, int lin_col, int gate_col, const int* desc, int B, int max_nq,
+                               float scale, float* out, int ldo, float* lse, int ksplit, float* part, int n_rows,
+                               hipStream_t stream);
+
 /* pair-bias precompute helpers (RowAttentionBlock.linear/linear_g applied to the initial pair
  * embedding z0 = W_o (a_i * b_j) + b_o; models/cross_att.py:125, models/att_model.py:198-206):
  * bmat[(j*NO + o), k] = b0[c_node(j), k] * wcomp[o, k]  for the ligand-side rows of one batch. */
@@ -358,6 +368,12 @@ int fabind_cross_attn_bwd(const float* qg, int ldq, const float* kv, int ldkv, c
                           int lin_col, int gate_col, const int* desc, int B, int max_nq, int max_nk, float scale,
                           const float* out, const float* lse, const float* dout, float* dqg, float* dkv, float* dbias,
                           float* dO, float* Dv, float* scratch, hipStream_t stream);
+/* MFMA bf16 form of the same adjoint (csrc/attn_mfma.hip): same arguments and scratch size; dO, dS and the recomputed
+ * probabilities enter the contractions as bf16, dbias / dq / dk / dv are accumulated and written in fp32. */
+int fabind_cross_attn_mfma_bwd(const float* qg, int ldq, const float* kv, int ldkv, const float* bias, int bias_ld,
+                               int lin_col, int gate_col, const int* desc, int B, int max_nq, int max_nk, float scale,
+                               const float* out, const float* lse, const float* dout, float* dqg, float* dkv, float* dbias,
+                               float* dO, float* Dv, float* scratch, hipStream_t stream);
 /* Operands of the pair-bias adjoint (autograd of the pair bias of RowAttentionBlock, cross_att.py:125, all attention blocks at
  * once) concatenated along K, bf16:  Acat[poff_b + i, k*Kp + j*8 + o] = douts[k][pair(b,i,j), o],
  * BTcat[b*H + h, k*Kp + j*8 + o] = b0[ligand j of b, h] * wcomp[k][o][h]  (zeros for j >= C_b; Kp = 8 * max_C rounded up to 32).
