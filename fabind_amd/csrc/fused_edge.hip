@@ -31,7 +31,13 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
     int* sRow = (int*)(smem + (size_t)FE_BM * H * 2);
     float* sDot = (float*)(sRow + FE_BM);           // [NW][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int e0 = blockIdx.x * FE_BM;
+    // XCD-aware tile order: work-group b runs on XCD b % 8 (round-robin dispatch), and every XCD has its own 4 MiB L2.  Edges are
+    // complex-contiguous, so giving XCD x the x-th EIGHTH of the tile range makes one XCD own whole complexes: the gathered AB
+    // rows of a complex (3 MB at 1542 nodes x 1024 bf16) are fetched into one L2 once instead of into all eight.
+    const int n_tiles = (E + FE_BM - 1) / FE_BM, tpx = (n_tiles + 7) / 8;
+    const int tile = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= tpx || tile >= n_tiles) return;
+    const int e0 = tile * FE_BM;
     const int ne = min(FE_BM, E - e0);
 
     // ---- phase 0: gather + first Linear + SiLU -> sX
@@ -170,7 +176,7 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
     const float dscale = 1.0f / (1.0f - (float)thr16 / 65536.0f);
     FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_gcl_edge_fused: H must be 64, 128, 256 or 512");
     FB_REQUIRE(ldab % 8 == 0, "fabind_gcl_edge_fused: ldab % 8");
-    const dim3 grid((E + FE_BM - 1) / FE_BM);
+    const dim3 grid((((E + FE_BM - 1) / FE_BM + 7) / 8) * 8);          // 8 x ceil(tiles / 8): see the XCD-aware tile order in the kernel
     const size_t lds = (size_t)FE_BM * H * 2 + FE_BM * sizeof(int) + (size_t)(H / 64) * FE_BM * sizeof(float);
 #define FE_LAUNCH(HH)                                                                                              \
     do {                                                                                                           \
@@ -251,9 +257,21 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
             pfb[q] = *(const uint4*)(AB + (boff + q * 8));
         }
     };
+    // XCD-aware persistent walk (work-group b runs on XCD b % 8): XCD x owns the x-th eighth of the tile range, i.e. whole
+    // complexes, and its work-groups walk that range with stride gridDim.x / 8 -- the gathered AB rows of a complex stay in ONE
+    // XCD's L2 (the grid-stride walk spread every complex over all eight: 1.46x HBM over-fetch, profiles/r01_pmc.json).
+    int t_first, t_end, t_step;
+    if ((gridDim.x & 7) == 0) {
+        const int tpx = (n_tiles + 7) / 8, xcd = blockIdx.x & 7;
+        t_first = xcd * tpx + (int)(blockIdx.x >> 3);
+        t_end = min(n_tiles, (xcd + 1) * tpx);
+        t_step = (int)(gridDim.x >> 3);
+    } else {
+        t_first = blockIdx.x; t_end = n_tiles; t_step = gridDim.x;
+    }
     unsigned ur = 0, uc = 0;                                      // this lane's edge of the current tile
-    if ((int)blockIdx.x < n_tiles) {
-        const int e0 = blockIdx.x * BM;
+    if (t_first < t_end) {
+        const int e0 = t_first * BM;
         if (el < min(BM, p.E - e0)) {
             ur = (unsigned)(p.row + e0)[(unsigned)el];
             uc = (unsigned)(p.col + e0)[(unsigned)el];
@@ -262,7 +280,7 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
     fe_prefetch(ur, uc);                                          // unconditional (row 0 for idle lanes): a guarded
                                                                   // load would keep the old registers live instead
 
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = t_first; tile < t_end; tile += t_step) {
         const int e0 = tile * BM;
         const int ne = min(BM, p.E - e0);
         // Loop-invariant operands (weights, biases, w_r) must be re-read from L2 per tile, not hoisted into ~140
@@ -293,8 +311,8 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
         }
         // indices of this lane's edge in the next tile (their rows are fetched after P5)
         unsigned nr = 0, nc = 0;
-        const int e0n = e0 + (int)gridDim.x * BM;
-        const bool has_next = tile + (int)gridDim.x < n_tiles && el < min(BM, p.E - e0n);
+        const int e0n = e0 + t_step * BM;
+        const bool has_next = tile + t_step < t_end && el < min(BM, p.E - e0n);
         if (has_next) {
             nr = (unsigned)(p.row + e0n)[(unsigned)el];
             nc = (unsigned)(p.col + e0n)[(unsigned)el];
@@ -544,6 +562,323 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
     part[3 * H + tid] = pwr;
 }
 
+#undef FE_COFF
+#undef FE_ROT4
+#undef FE_ROT_ACC
+#undef FE_ROT_D2
+#undef FE_JADDR
+#undef FE_LOFF
+#undef FE_TICK
+
+// =====================================================================================================
+// Single-tile variant of the backward (default since round 2): the SAME phases, but every stage overwrites the one
+// [64][H] LDS tile in place (contraction reads it -> barrier -> epilogue writes it -> barrier), silu'(pre2) waits for
+// phase P3 in an L2-resident per-work-group scratch slab instead of 32 registers, and the gathered AB rows are loaded
+// where they are used.  64 KiB LDS and <= 128 VGPRs put TWO work-groups on a CU (4 waves per SIMD) at the same 64-edge
+// tile, i.e. at the same L2 weight traffic per edge: while one work-group streams weights through the matrix cores the
+// other runs its sigmoid / pack / LDS-store epilogue on the VALU.  (The two-tile kernel above keeps one work-group per
+// CU: its phase counters show contractions 40 % + elementwise 45 % of a tile strictly in sequence; its 32-edge variant
+// got the overlap but doubled the weight traffic -- DESIGN.md section 5.)
+template <int H>
+__global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd1_kernel(const FabindEdgeBwdArgs p) {
+    constexpr int BM = 64;
+    constexpr int TPE = H / BM;                                   // threads per edge in the gather layout
+    constexpr int CPT = BM / 8;                                   // 16-byte chunks per thread there
+    constexpr int MI = 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sX = (bf16_t*)smem;                                   // [64][H] swizzled: S1 -> M -> dT -> dP2 -> dS1 -> dP1
+    int* sRow = (int*)(sX + BM * H);
+    float* sDs = (float*)(sRow + BM);
+    float* sRh = sDs + BM;
+    float* sPart = sRh + BM;                                      // [4][H]: column sums of {d b2, d bc, d w3, d w_r} over this work-group's tiles
+    const bf16_t* __restrict__ AB = (const bf16_t*)p.AB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, cq = lane >> 4;
+    const int el = tid / TPE, cth = tid % TPE;
+    const int n_tiles = (p.E + BM - 1) / BM;
+    const uint32_t thr16 = (uint32_t)(p.p_drop * 65536.0f + 0.5f);
+    const float dscale = 1.0f / (1.0f - (float)thr16 / 65536.0f);
+    // Few values live across the contractions (acc 64 + B fragments 32 + A fragments 16 VGPRs of 128): the fragment address
+    // bases are recomputed per epilogue, the column-sum partials live in LDS, the gathered-row offsets are re-derived in P5.
+#define FE_CBASE()                                                                                                   \
+    int cbase[2][2];                                                                                                 \
+    _Pragma("unroll") for (int f0 = 0; f0 < 2; ++f0) _Pragma("unroll") for (int f2 = 0; f2 < 2; ++f2)                \
+        cbase[f0][f2] = cq * 4 * H + (wave * 8 + (((cq & 1) ^ f2) << 2) + ((fr >> 3) ^ f0)) * 8 + (fr & 7);
+    // adds this lane's column partial v (rows cq*4.. of the tile) into sPart[k_][col]: reduce over the four cq lanes, one writer
+#define FE_PART_ADD(k_, col_, v_)                                                                                    \
+    { float t_ = (v_); t_ += __shfl_xor(t_, 16, 64); t_ += __shfl_xor(t_, 32, 64); if (cq == 0) sPart[(k_) * H + (col_)] += t_; }
+    for (int k = 0; k < 4; ++k) sPart[k * H + tid] = 0.f;
+    const unsigned uld = (unsigned)p.ldab;
+
+    int t_first, t_end, t_step;
+    if ((gridDim.x & 7) == 0) {
+        const int tpx = (n_tiles + 7) / 8, xcd = blockIdx.x & 7;
+        t_first = xcd * tpx + (int)(blockIdx.x >> 3);
+        t_end = min(n_tiles, (xcd + 1) * tpx);
+        t_step = (int)(gridDim.x >> 3);
+    } else {
+        t_first = blockIdx.x; t_end = n_tiles; t_step = gridDim.x;
+    }
+#define FE_ROT4(a_) { auto t_ = a_[0]; a_[0] = a_[1]; a_[1] = a_[2]; a_[2] = a_[3]; a_[3] = t_; }
+#define FE_ROT_ACC() _Pragma("unroll") for (int i = 0; i < MI; ++i) FE_ROT4(acc[i])
+#define FE_JADDR(j_)                                                                          \
+        const int cb[2] = {((j_) >> 1) ? cbase[0][1] : cbase[0][0], ((j_) >> 1) ? cbase[1][1] : cbase[1][0]}; \
+        const int o2[2] = {((j_) & 1) * 16, 16 - ((j_) & 1) * 16};
+#define FE_LOFF(i, r) (cb[(r) & 1] + ((i) * 16 + (r)) * H + o2[(r) >> 1])
+
+    for (int tile = t_first; tile < t_end; tile += t_step) {
+        const int e0 = tile * BM;
+        const int ne = min(BM, p.E - e0);
+        int lz = 0;
+        asm volatile("" : "+s"(lz));                              // loop-invariant operands are re-read per tile, not hoisted
+        const float* w_r = p.w_r + lz;
+        const float* b2 = p.b2 + lz;
+        const float* bc = p.bc + lz;
+        const float* w3 = p.w3 + lz;
+        const bf16_t* W2p = (const bf16_t*)p.W2p + lz;
+        const bf16_t* Wcp = (const bf16_t*)p.Wcp + lz;
+        const bf16_t* W2Tp = (const bf16_t*)p.W2Tp + lz;
+        const bf16_t* WcTp = (const bf16_t*)p.WcTp + lz;
+        const int* grow = p.row + e0;
+        const int* gcol = p.col + e0;
+        const float* grh = p.rhohat + e0;
+        const float* gds = p.ds + e0;
+        if (tid < BM) {
+            const bool ok = tid < ne;
+            sRow[tid] = ok ? grow[(unsigned)tid] : -1;
+            sDs[tid] = ok ? gds[(unsigned)tid] : 0.f;
+            sRh[tid] = ok ? grh[(unsigned)tid] : 0.f;
+        }
+        // ---- P0: gather + first Linear + SiLU -> sX
+        if (el < ne) {
+            const unsigned aoff = (unsigned)grow[(unsigned)el] * uld + cth * (CPT * 8);
+            const unsigned boff = (unsigned)gcol[(unsigned)el] * uld + H + cth * (CPT * 8);
+            const float rh = grh[(unsigned)el];
+            const float* wp = w_r + (unsigned)(cth * (CPT * 8));
+#pragma unroll 2
+            for (int q = 0; q < CPT; ++q) {
+                float fa[8], fb[8], o[8];
+                unpack8(*(const uint4*)(AB + (aoff + q * 8)), fa);
+                unpack8(*(const uint4*)(AB + (boff + q * 8)), fb);
+                const float4 w0 = *(const float4*)(wp + q * 8), w1 = *(const float4*)(wp + q * 8 + 4);
+                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = fe_silu(fa[k] + fb[k] + rh * wv[k]);
+                *(uint4*)&sX[el * H + (((cth * CPT + q) ^ (el & 7)) * 8)] = pack8(o);
+            }
+        } else {
+            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int q = 0; q < CPT; ++q) *(uint4*)&sX[el * H + (((cth * CPT + q) ^ (el & 7)) * 8)] = z;
+        }
+        __syncthreads();
+        fe_tile_store<H>(sX, (bf16_t*)p.S1, e0, ne, tid);
+
+        // ---- P1: pre2 = S1 W2^T + b2;  M -> sX in place;  silu'(pre2) -> scratch
+        f32x4_t acc[MI][4];
+        fe_zero(acc);
+        fe_gemm_rolled<H, MI>(sX, W2p, wave, lane, acc);
+        __syncthreads();                                          // every wave has finished reading S1
+        {
+            FE_CBASE()
+            // silu'(pre2) of this work-group's current tile: [j][half][thread] uint4 (1 KiB per wave store), rewritten every tile
+            uint4* d2s = (uint4*)p.d2scratch + (size_t)blockIdx.x * (8 * H);
+            float bj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bj[j] = b2[wave * 64 + j * 16 + fr];
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                FE_JADDR(j)
+                uint32_t da[MI], db[MI];
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    float dd[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = acc[i][0][r] + bj[0], sg = fe_sigmoid(z);
+                        float kp = 1.0f;
+                        if (thr16)
+                            kp = fe_keep(p.seed, (uint32_t)(e0 + i * 16 + cq * 4 + r), (uint32_t)(wave * 64 + j * 16 + fr), H,
+                                         thr16, dscale);
+                        dd[r] = kp * (sg * (1.0f + z * (1.0f - sg)));
+                        sX[FE_LOFF(i, r)] = f32_to_bf16(kp * (z * sg));
+                    }
+                    da[i] = pack2_bf16(dd[0], dd[1]);
+                    db[i] = pack2_bf16(dd[2], dd[3]);
+                }
+                d2s[(j * 2) * H + tid] = make_uint4(da[0], da[1], da[2], da[3]);
+                d2s[(j * 2 + 1) * H + tid] = make_uint4(db[0], db[1], db[2], db[3]);
+                FE_ROT_ACC() FE_ROT4(bj)
+            }
+        }
+        __syncthreads();
+        fe_tile_store<H>(sX, (bf16_t*)p.Mm, e0, ne, tid);
+
+        // ---- P2: pre3 = M Wc^T + bc;  dT = ds * w3 * silu'(pre3) -> sX in place
+        fe_zero(acc);
+        fe_gemm_rolled<H, MI>(sX, Wcp, wave, lane, acc);
+        __syncthreads();
+        {
+            FE_CBASE()
+            float bj[4], wj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bj[j] = bc[wave * 64 + j * 16 + fr]; wj[j] = w3[wave * 64 + j * 16 + fr]; }
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                FE_JADDR(j)
+                float a3 = 0.f, ac = 0.f;
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float z = acc[i][0][r] + bj[0], sg = fe_sigmoid(z), dsr = sDs[i * 16 + cq * 4 + r];
+                        const float dt = dsr * wj[0] * (sg * (1.0f + z * (1.0f - sg)));
+                        a3 += dsr * (z * sg);
+                        ac += dt;
+                        sX[FE_LOFF(i, r)] = f32_to_bf16(dt);
+                    }
+                FE_PART_ADD(2, wave * 64 + j * 16 + fr, a3)
+                FE_PART_ADD(1, wave * 64 + j * 16 + fr, ac)
+                FE_ROT_ACC() FE_ROT4(bj) FE_ROT4(wj)
+            }
+        }
+        __syncthreads();
+        fe_tile_store<H>(sX, (bf16_t*)p.dT, e0, ne, tid);
+
+        // ---- P3: dM = dT Wc + dagg[row];  dP2 = dM * silu'(pre2) -> sX in place
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int rr = sRow[i * 16 + cq * 4 + r];
+                const unsigned doff = (unsigned)max(rr, 0) * (unsigned)p.lddagg + wave * 64 + fr;
+                const float keep = rr >= 0 ? 1.f : 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j][r] = p.dagg[doff + j * 16] * keep;
+            }
+        fe_gemm_rolled<H, MI>(sX, WcTp, wave, lane, acc);
+        __syncthreads();
+        {
+        FE_CBASE()
+        const uint4* d2s = (const uint4*)p.d2scratch + (size_t)blockIdx.x * (8 * H);
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            FE_JADDR(j)
+            const uint4 qa = d2s[(j * 2) * H + tid], qb = d2s[(j * 2 + 1) * H + tid];
+            const uint32_t da[MI] = {qa.x, qa.y, qa.z, qa.w}, db[MI] = {qb.x, qb.y, qb.z, qb.w};
+            float a2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t pk = (r >> 1) ? db[i] : da[i];
+                    const float dd = __uint_as_float((r & 1) ? (pk & 0xffff0000u) : (pk << 16));
+                    const float dp = acc[i][0][r] * dd;
+                    a2 += dp;
+                    sX[FE_LOFF(i, r)] = f32_to_bf16(dp);
+                }
+            FE_PART_ADD(0, wave * 64 + j * 16 + fr, a2)
+            FE_ROT_ACC()
+        }
+        }
+        __syncthreads();
+        fe_tile_store<H>(sX, (bf16_t*)p.dP2, e0, ne, tid);
+
+        // ---- P4: dS1 = dP2 W2 -> sX in place
+        fe_zero(acc);
+        fe_gemm_rolled<H, MI>(sX, W2Tp, wave, lane, acc);
+        __syncthreads();
+        {
+        FE_CBASE()
+#pragma unroll 1
+        for (int j = 0; j < 4; ++j) {
+            FE_JADDR(j)
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sX[FE_LOFF(i, r)] = f32_to_bf16(acc[i][0][r]);
+            FE_ROT_ACC()
+        }
+        }
+        __syncthreads();
+
+        // ---- P5 (gather layout): dP1 = dS1 * silu'(pre1) in place;  d rhohat = dP1 . w_r
+        if (el < ne) {
+            const unsigned aoff = (unsigned)sRow[el] * uld + cth * (CPT * 8);
+            const unsigned boff = (unsigned)gcol[(unsigned)el] * uld + H + cth * (CPT * 8);
+            const float rh = sRh[el];
+            const float* wp = w_r + (unsigned)(cth * (CPT * 8));
+            float dot = 0.f;
+#pragma unroll 2
+            for (int q = 0; q < CPT; ++q) {
+                float fa[8], fb[8], g[8];
+                unpack8(*(const uint4*)(AB + (aoff + q * 8)), fa);
+                unpack8(*(const uint4*)(AB + (boff + q * 8)), fb);
+                uint4* sp = (uint4*)&sX[el * H + (((cth * CPT + q) ^ (el & 7)) * 8)];
+                unpack8(*sp, g);
+                const float4 w0 = *(const float4*)(wp + q * 8), w1 = *(const float4*)(wp + q * 8 + 4);
+                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float z = fa[k] + fb[k] + rh * wv[k], sg = fe_sigmoid(z);
+                    g[k] *= sg * (1.0f + z * (1.0f - sg));
+                    dot += g[k] * wv[k];
+                }
+                *sp = pack8(g);
+            }
+#pragma unroll
+            for (int o = 1; o < TPE; o <<= 1) dot += __shfl_xor(dot, o, 64);
+            if (cth == 0) (p.drh + e0)[(unsigned)el] = dot;
+        }
+        __syncthreads();
+        fe_tile_store<H>(sX, (bf16_t*)p.dP1, e0, ne, tid);
+
+        // ---- P6 (one column per thread): receiving-side segment sum of dP1 and the d w_r column sum
+        {
+            const int c = tid;
+            float run = 0.f, pwr = 0.f;
+            int cur = sRow[0];
+            bool first = true;
+            for (int rw0 = 0; rw0 < ne; rw0 += 8) {
+                int rr[8];
+                float v[8], rhv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int rw = rw0 + u;
+                    rr[u] = sRow[rw];
+                    rhv[u] = sRh[rw];
+                    v[u] = bf16_to_f32(sX[rw * H + (((c >> 3) ^ (rw & 7)) * 8) + (c & 7)]);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (rw0 + u < ne) {
+                        if (rr[u] != cur) {
+                            const unsigned o = (unsigned)cur * (unsigned)p.lddab + c;
+                            if (first) atomicAdd(&p.dABrow[o], run); else p.dABrow[o] = run;
+                            run = 0.f; cur = rr[u]; first = false;
+                        }
+                        run += v[u];
+                        pwr += rhv[u] * v[u];
+                    }
+                }
+            }
+            if (ne > 0) atomicAdd(&p.dABrow[(unsigned)cur * (unsigned)p.lddab + c], run);
+            sPart[3 * H + c] += pwr;                              // column c belongs to this thread alone
+        }
+        __syncthreads();                                          // the next tile overwrites sX / sRow
+    }
+    // per-work-group partial column sums: part[blockIdx.x][{b2, bc, w3, w_r}][H]   (each sPart slot has ONE writer lane)
+    __syncthreads();
+    float* part = p.part + (size_t)blockIdx.x * 4 * H;
+    for (int k = 0; k < 4; ++k) part[k * H + tid] = sPart[k * H + tid];
+#undef FE_CBASE
+#undef FE_PART_ADD
+#undef FE_ROT4
+#undef FE_ROT_ACC
+#undef FE_JADDR
+#undef FE_LOFF
+}
+
 static int g_fe_bwd_bm = 64;
 extern "C" int fabind_gcl_edge_fused_bwd_set_tile(int bm) {
     FB_REQUIRE(bm == 32 || bm == 64, "fabind_gcl_edge_fused_bwd_set_tile: 32 or 64 edges per tile");
@@ -551,12 +886,33 @@ extern "C" int fabind_gcl_edge_fused_bwd_set_tile(int bm) {
     return 0;
 }
 extern "C" int fabind_gcl_edge_fused_bwd_tile(void) { return g_fe_bwd_bm; }
+static int g_fe_bwd_variant = 1;     // 1 = single in-place LDS tile, two work-groups per CU (default); 0 = two-tile kernel
+extern "C" int fabind_gcl_edge_fused_bwd_set_variant(int v) {
+    FB_REQUIRE(v == 0 || v == 1, "fabind_gcl_edge_fused_bwd_set_variant: 0 (two LDS tiles) or 1 (single in-place tile)");
+    g_fe_bwd_variant = v;
+    return 0;
+}
+extern "C" int fabind_gcl_edge_fused_bwd_variant(void) { return g_fe_bwd_variant; }
 
 extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a, int H, int n_groups, hipStream_t stream) {
     if (a->E <= 0 || n_groups <= 0) return 0;
     FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_gcl_edge_fused_bwd: H must be 64, 128, 256 or 512");
     FB_REQUIRE(a->ldab % 8 == 0, "fabind_gcl_edge_fused_bwd: ldab % 8");
     FB_REQUIRE(a->p_drop >= 0.f && a->p_drop < 1.f, "fabind_gcl_edge_fused_bwd: p_drop in [0, 1)");
+    if (g_fe_bwd_variant == 1) {
+        FB_REQUIRE(a->d2scratch != nullptr, "fabind_gcl_edge_fused_bwd: the single-tile variant needs d2scratch (n_groups x 64 x H x 2 bytes)");
+        const size_t lds1 = (size_t)64 * H * 2 + 64 * (sizeof(int) + 2 * sizeof(float)) + (size_t)4 * H * sizeof(float);
+#define FE_LAUNCH1(HH)                                                                                             \
+    do {                                                                                                           \
+        static bool set_ = false;                                                                                  \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_bwd1_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); set_ = true; } \
+        hipLaunchKernelGGL((gcl_edge_fused_bwd1_kernel<HH>), dim3(n_groups), dim3(HH), lds1, stream, *a);           \
+    } while (0)
+        if (H == 512) FE_LAUNCH1(512); else if (H == 256) FE_LAUNCH1(256); else if (H == 128) FE_LAUNCH1(128); else FE_LAUNCH1(64);
+#undef FE_LAUNCH1
+        FB_CHECK_LAUNCH();
+        return 0;
+    }
     const int BMr = g_fe_bwd_bm;
     const size_t lds = (size_t)2 * BMr * H * 2 + BMr * (sizeof(int) + 2 * sizeof(float));
 #define FE_LAUNCH2(HH, BB)                                                                                         \

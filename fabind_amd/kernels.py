@@ -361,10 +361,19 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     ng = _N_CU.get(dev)
     if ng is None:
         ng = _N_CU[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
-    bm = _lib.load().fabind_gcl_edge_fused_bwd_tile()
-    # persistent work-groups per CU: as many as the two LDS tiles (2 * bm * H * 2 B of 160 KiB) and 2 waves/SIMD allow
-    per_cu = max(1, min(8, (160 * 1024) // (4 * bm * H + 1024), (1024 if bm == 32 else 512) // H))
+    lib = _lib.load()
+    variant = lib.fabind_gcl_edge_fused_bwd_variant()
+    bm = 64 if variant == 1 else lib.fabind_gcl_edge_fused_bwd_tile()
+    if variant == 1:
+        # one in-place [64][H] LDS tile and <= 128 VGPRs: as many work-groups per CU as LDS (160 KiB) and 4 waves/SIMD allow
+        per_cu = max(1, min(8, (160 * 1024) // (2 * bm * H + 1024), 1024 // H))
+    else:
+        # persistent work-groups per CU: as many as the two LDS tiles (2 * bm * H * 2 B of 160 KiB) and 2 waves/SIMD allow
+        per_cu = max(1, min(8, (160 * 1024) // (4 * bm * H + 1024), (1024 if bm == 32 else 512) // H))
     ng = max(1, min(ng * per_cu, (E + bm - 1) // bm))
+    if ng >= 8:
+        ng -= ng % 8                # a multiple of 8 selects the XCD-aware walk (csrc/fused_edge.hip)
+    d2scratch = torch.empty((ng, bm * H), dtype=torch.bfloat16, device=dev) if variant == 1 else None
     buf = torch.empty((5, max(E, 1), H), dtype=torch.bfloat16, device=dev)
     S1, Mm, dT, dP2, dP1 = buf[0], buf[1], buf[2], buf[3], buf[4]
     dAB = torch.zeros((N, 2 * H), dtype=torch.float32, device=dev)
@@ -378,12 +387,12 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     for name, t in (("AB", AB16), ("row", row), ("col", col), ("rhohat", rhohat), ("w_r", w_r), ("W2p", W2p), ("Wcp", Wcp),
                     ("W2Tp", W2Tp), ("WcTp", WcTp), ("b2", b2), ("bc", bc), ("w3", w3), ("ds", ds), ("dagg", dagg),
                     ("S1", S1), ("Mm", Mm), ("dT", dT), ("dP2", dP2), ("dP1", dP1), ("drh", drh), ("dABrow", dAB),
-                    ("part", part)):
+                    ("part", part), ("d2scratch", d2scratch)):
         setattr(a, name, ptr(t))
     a.ldab, a.lddagg, a.lddab, a.E = _ld(AB16), _ld(dagg), _ld(dAB), E
     a.p_drop, a.seed = float(p_drop), int(seed) & 0xFFFFFFFF
     a.dbg = ptr(EDGE_BWD_TIMES) if EDGE_BWD_TIMES is not None else None
-    _profiled("gcl_edge_fused_bwd_kernel<%d> E=%d (recompute + 4 chained H x H contractions per edge)" % (H, E),
+    _profiled("gcl_edge_fused_bwd%s_kernel<%d> E=%d (recompute + 4 chained H x H contractions per edge)" % ("1" if variant == 1 else "", H, E),
               8.0 * E * H * H,
               lambda: check(_lib.load().fabind_gcl_edge_fused_bwd(ctypes.byref(a), H, ng, stream()),
                             "fabind_gcl_edge_fused_bwd"))

@@ -31,7 +31,8 @@ const char* fabind_last_error(void);
  * 3 = fabind_cross_attn_bwd takes a scratch buffer instead of (n_q_rows, n_k_rows), fabind_cross_attn_bwd_scratch added;
  * 4 = fabind_pair_bias_cat takes a colpart argument (per-work-group column sums), fabind_pair_bias_cat_parts and the
  *     fabind_gemm_tn_set_waves knob added.
- * 5 = fabind_cross_attn_mfma_fwd / fabind_cross_attn_mfma_bwd added (MFMA bf16 form of the cross attention).
+ * 5 = fabind_cross_attn_mfma_fwd / fabind_cross_attn_mfma_bwd added (MFMA bf16 form of the cross attention); FabindEdgeBwdArgs grew
+ *     d2scratch, fabind_gcl_edge_fused_bwd_set_variant / _variant added.
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 5
 int fabind_abi_version(void);
@@ -180,7 +181,8 @@ typedef struct FabindEdgeBwdArgs {
     const float* b2; const float* bc; const float* w3; const float* ds; const float* dagg;
     void* S1; void* Mm; void* dT; void* dP2; void* dP1;
     float* drh; float* dABrow; float* part;
-    void* dbg;               /* NULL, or 12 x int64: cycle counts per phase of work-group 0 (profiling aid) */
+    void* dbg;               /* NULL, or 12 x int64: cycle counts per phase of work-group 0 (profiling aid; two-tile variant) */
+    void* d2scratch;         /* single-tile variant: n_groups x 64 x H x 2 bytes of scratch (silu'(pre2) of each work-group's tile) */
     int ldab, lddagg, lddab, E;
     float p_drop;            /* dropout probability of the messages (egnn.py:82); 0 = eval */
     unsigned seed;           /* the seed the forward call used */
@@ -189,6 +191,12 @@ int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* args, int H, int n_groups
 /* Edges per tile of the backward kernel: 64 (one work-group per CU, default) or 32 (two per CU). */
 int fabind_gcl_edge_fused_bwd_set_tile(int bm);
 int fabind_gcl_edge_fused_bwd_tile(void);
+/* Kernel variant: 1 (default) = ONE [64][H] LDS tile rewritten in place by every stage, two work-groups per CU so that one
+ * work-group's elementwise epilogue overlaps the other's contraction (needs FabindEdgeBwdArgs.d2scratch; n_groups up to
+ * 2 x CUs); 0 = the round-1 kernel with two LDS tiles and one work-group per CU.  Results agree to bf16 rounding of nothing:
+ * both variants evaluate the same arithmetic in the same order per element. */
+int fabind_gcl_edge_fused_bwd_set_variant(int v);
+int fabind_gcl_edge_fused_bwd_variant(void);
 
 /* Fused pair-embedding update of FABind+'s CrossAttentionModule (FABind_plus/fabind/models/cross_att.py:42-44 with
  * model_utils.py InteractionModule / MLPwithLastAct), bf16, inference (no adjoint: training runs the separate launches):

@@ -23,6 +23,7 @@ run = lambda: K.gcl_edge_fused_bwd(AB, H, g.row_ctx, g.col_ctx, rh, w_r, W2, b2,
 from fabind_amd import _lib
 import sys as _s
 bm = int(_s.argv[1]) if len(_s.argv) > 1 else 32
+_lib.load().fabind_gcl_edge_fused_bwd_set_variant(0)      # the phase counters live in the two-tile kernel
 _lib.load().fabind_gcl_edge_fused_bwd_set_tile(bm)
 print("tile =", bm)
 K.PROFILE = {}
