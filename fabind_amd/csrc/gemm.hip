@@ -1228,6 +1228,11 @@ extern "C" int fabind_colsum(const void* in, int in_dt, int ldi, float* out, int
     FB_REQUIRE(nchunk >= 1, "fabind_colsum: nchunk >= 1");
     int rows_per = (R + nchunk - 1) / nchunk;
     if (rows_per < 1) rows_per = 1;
+    if (nchunk == 1 && !accumulate) {      // a single chunk (split-K partial sums, R <= 256 rows): its "partial" IS the result
+        hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 255) / 256, 1), dim3(256), 0, stream, in, in_dt, ldi, out, R, C, rows_per);
+        FB_CHECK_LAUNCH();
+        return 0;
+    }
     hipLaunchKernelGGL(colsum_part_kernel, dim3((C + 255) / 256, nchunk), dim3(256), 0, stream, in, in_dt, ldi, scratch, R,
                        C, rows_per);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, scratch, out, C, nchunk,

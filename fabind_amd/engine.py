@@ -336,6 +336,8 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
     H = h.shape[1]
     ad = ops.act_dtype()
     fast = _fast(h, x, p["W2"])
+    if pdrop == 0.0:                # (train mode adds torch-side dropout consumers that do not know the shared buffer)
+        h = ops.shared_grad(h)      # three consumers (first edge Linear, node MLP, residual): one gradient buffer, no autograd adds
     hin = _b16(h) if fast else h
     if get_precision() == "bf16" and FUSED_EDGE and H in (64, 128, 256, 512):
         # the whole edge pipeline in one kernel each way, edge tensors stay in LDS (csrc/fused_edge.hip); under
@@ -372,6 +374,8 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     fast = _fast(h, p["Wo_p"])
     od = ops.act_dtype()
     c16 = (lambda t: _b16(t)) if fast else (lambda t: t)
+    if pdrop == 0.0:
+        h = ops.shared_grad(h)      # consumers: ligand row gather, q / gate projection, residual of the attention update
     hc = ops.take_rows(h, lay.c_index64)
     scale = 1.0 / math.sqrt(32.0)
     bias_p, bias_c = pairbias[2 * layer], pairbias[2 * layer + 1]
@@ -380,6 +384,8 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     og = ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_pf, lay.B, lay.max_P, lay.max_C, scale)
     hp = (h + _drop(ops.linear(c16(og), p["Wo_p"], p["bo_p"]), pdrop)) if pdrop > 0.0 else \
         ops.linear(c16(og), p["Wo_p"], p["bo_p"], residual=h)
+    if pdrop == 0.0:
+        hp = ops.shared_grad(hp)    # consumers: k / v projection of the ligand-query block, transition, its residual
     hp16 = c16(hp)
     qg = ops.linear(c16(hc), p["Wqg_c"], p["bqg_c"])
     kv = ops.linear(hp16, p["Wkv_c"])                                                   # [N, 256], protein rows used
@@ -397,6 +403,8 @@ def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv, pdrop=0.0, pdrop_r
     """MC_Att_L.forward (egnn.py:308-333).  pdrop: dropout on the aggregated attention message (egnn.py:236)."""
     H = h.shape[1]
     h = cross_attention(p, h, lay, pairbias, layer, pdrop_row)
+    if pdrop == 0.0:
+        h = ops.shared_grad(h)      # consumers: 32-wide pair projections, q | k | v projection, the attention layer's residual
     # pair embedding at the inter-edge pairs only -> scalar attention bias (egnn.py:208, 286-304)
     h16 = _b16(h) if _fast(h, x, p["Wqkv"]) else h
     ab32 = ops.linear(h16, p["W_ab32"], p["b_ab32"])                                   # [N,128] (a32|0|b32|0)

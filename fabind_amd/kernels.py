@@ -349,6 +349,7 @@ def pair_update_fused(T, b_off, p_node, c_node, z, Wop, bo, ln_w, ln_b, eps, W1p
 
 
 _N_CU = {}
+EDGE_BWD_GROUPS = 0     # development knob: persistent work-groups of the fused edge backward (0 = derived from CUs and LDS)
 EDGE_BWD_TIMES = None   # set to an int64[12] device tensor to collect per-phase cycle counts (tools/edge_bwd_phases.py)
 
 
@@ -371,6 +372,8 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
         # persistent work-groups per CU: as many as the two LDS tiles (2 * bm * H * 2 B of 160 KiB) and 2 waves/SIMD allow
         per_cu = max(1, min(8, (160 * 1024) // (4 * bm * H + 1024), (1024 if bm == 32 else 512) // H))
     ng = max(1, min(ng * per_cu, (E + bm - 1) // bm))
+    if EDGE_BWD_GROUPS:
+        ng = int(EDGE_BWD_GROUPS)       # development knob (tools/probes/edge_bwd_variants.py)
     if ng >= 8:
         ng -= ng % 8                # a multiple of 8 selects the XCD-aware walk (csrc/fused_edge.hip)
     d2scratch = torch.empty((ng, bm * H), dtype=torch.bfloat16, device=dev) if variant == 1 else None

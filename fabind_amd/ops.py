@@ -106,9 +106,20 @@ def _mul_dact_colsum(dy, aux, act, out_dtype):
 
 
 def _mm_in(x):
-    """Operand as the GEMM wants it: bf16 copy of an fp32 activation in bf16 mode."""
+    """Operand as the GEMM wants it: bf16 copy of an fp32 activation in bf16 mode.  The copy is remembered on the tensor
+    (keyed on its version counter, so an in-place update invalidates it): a residual-stream tensor feeds two or three
+    Linears per layer, and each of them used to cast it again."""
     if x is not None and _cfg.get_precision() == "bf16" and x.dtype == torch.float32:
-        return x.to(torch.bfloat16)
+        c = getattr(x, "_fab_b16", None)
+        if c is not None and c[0] == x._version:
+            return c[1]
+        y = x.to(torch.bfloat16)
+        if x.dim() == 2 and x.is_contiguous():
+            try:
+                x._fab_b16 = (x._version, y)
+            except Exception:
+                pass
+        return y
     return x
 
 
@@ -129,6 +140,8 @@ class _Linear(torch.autograd.Function):
         ctx.act_epi, ctx.x_dtype = (K.ACT_SILU if relu_res else act_epi), x.dtype       # backward: stored derivative
         ctx.x2_dtype = x2.dtype if x2 is not None else None
         ctx.has_b, ctx.has_res, ctx.has_x2 = b is not None, residual is not None, x2 is not None
+        ctx.sink_x, ctx.sink_res = _sink_of(x), _sink_of(residual)
+        ctx.x_shape = x.shape
         ctx.save_for_backward(xin, W, x2in, y if (act_epi == K.ACT_RELU and not relu_res) else None, D)
         return y
 
@@ -151,7 +164,15 @@ class _Linear(torch.autograd.Function):
             dpre = dy
         K1, N = x.shape[1], W.shape[0]
         dx = dx2 = dW = None
-        if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[3]):
+        sink_x = ctx.sink_x if (ctx.x_dtype == torch.float32 and N % 8 == 0 and ctx.needs_input_grad[0]) else None
+        if sink_x is not None:
+            # x has a shared gradient buffer: its input gradient is stored / accumulated there by the GEMM epilogue (x2, if any,
+            # gets its own GEMM over the other K-slice of W)
+            Wt = W.t().contiguous()
+            dx = sink_x.gemm_into(dpre, Wt[:K1], x)
+            if ctx.has_x2 and ctx.needs_input_grad[3]:
+                dx2, _ = K.gemm(dpre, Wt[K1:], out_dtype=torch.float32 if ctx.x2_dtype == torch.float32 else ctx.x2_dtype)
+        elif ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[3]):
             if N % 8 == 0:
                 Wt, dmm = W.t().contiguous(), dpre                      # [K, N] (parameter-only transpose)
             else:                                                       # tiny heads (N = 1): pad the contraction dim to 8
@@ -172,6 +193,8 @@ class _Linear(torch.autograd.Function):
         if want_db and db is None:
             db = K.colsum(dpre)
         dres = dy.float() if (ctx.has_res and ctx.needs_input_grad[4]) else None
+        if dres is not None and ctx.sink_res is not None:
+            dres = ctx.sink_res.deposit(dres)
         return dx, dW, db, dx2, dres, None, None
 
 
@@ -463,8 +486,27 @@ def coord_update(x, d, s_part, rowptr, mean, clampv):
     return K.coord_update(x, d, s_part, rowptr, mean, clampv)[0]
 
 
+class _TakeRows(torch.autograd.Function):
+    """x[idx] whose adjoint adds the rows into x's shared gradient buffer (autograd's own index_select backward builds a
+    zero [N, .] tensor and the engine then adds it to the other gradients of x)."""
+
+    @staticmethod
+    def forward(ctx, x, idx, sink):
+        ctx.sink, ctx.n = sink, x.shape[0]
+        ctx.save_for_backward(idx)
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        idx, = ctx.saved_tensors
+        return ctx.sink.deposit_rows(idx, d_rows), None, None
+
+
 def take_rows(x, index64):
-    """Row gather (torch index_select: pure data movement, autograd-native)."""
+    """Row gather (pure data movement).  With a shared gradient buffer on x the adjoint is a row scatter-add into it."""
+    sink = _sink_of(x)
+    if sink is not None and _needs_grad(x):
+        return _TakeRows.apply(x, index64, sink)
     return x.index_select(0, index64)
 
 
@@ -487,9 +529,14 @@ class _PutRows(torch.autograd.Function):
     def backward(ctx, dout):
         idx, = ctx.saved_tensors
         d_rows = dout.index_select(0, idx)
-        d_base = dout.clone()
+        # the incoming gradient is the engine's / the sink's own accumulation buffer for this node: zero the overwritten rows
+        # in place instead of cloning [N, .] (PUT_ROWS_INPLACE_GRAD = False restores the copy)
+        d_base = dout if (PUT_ROWS_INPLACE_GRAD and dout.is_contiguous()) else dout.clone()
         d_base.index_fill_(0, idx, 0.0)
         return d_base, d_rows, None, None
+
+
+PUT_ROWS_INPLACE_GRAD = True
 
 
 def put_rows(base, rows, index64, inplace=True):
@@ -510,32 +557,96 @@ def select_rows(x, z, mask_u8):
 # attention ops
 # ------------------------------------------------------------------------------------------------
 class GradSink:
-    """Shared gradient buffer of a tensor with several consumers whose adjoint kernels ACCUMULATE (atomics / accumulating GEMM
-    epilogues): the first consumer whose backward runs allocates the zeroed buffer and hands it to autograd as its gradient;
-    the others add into the same buffer and return None, so autograd neither pads nor sums [N, 2H] tensors.  All of them run
-    on one stream before the producer's backward reads the buffer; `_SinkOwner` drops the reference once autograd has
-    collected it, so a second backward over a retained graph starts from a fresh buffer."""
+    """Shared gradient buffer of a tensor with several consumers: autograd neither pads nor sums [N, .] tensors for it.
+
+    Three kinds of contribution (all consumers run on one stream before the producer's backward reads the buffer):
+    * accumulating adjoint kernels (atomics / accumulating GEMM epilogues): `take()` -- the first one allocates the zeroed
+      buffer and hands it to autograd as ITS gradient, the others add in place and return None;
+    * an input-gradient GEMM: `gemm_into()` -- the first writer stores (folding deferred contributions in through the
+      epilogue's residual operand), later ones run with accumulate = 1;
+    * a gradient that already exists as a tensor (the residual branch y = f(x) + x): `deposit()` -- held without any
+      kernel until the next GEMM folds it in.
+    `_SinkOwner` (an identity node between producer and consumers) adds whatever is still deferred when all consumers
+    have run, and drops the references, so a second backward over a retained graph starts fresh."""
 
     def __init__(self):
         self.buf = None
+        self.pending = None          # full-size fp32 tensor deferred by deposit()
+        self.rows = []               # (index64, rows) deferred by deposit_rows()
 
     def take(self, like):
         """-> (buffer, True if this call created it and must return it as the gradient)."""
         if self.buf is None:
             self.buf = torch.zeros_like(like)
+            self._flush_into_buf()
             return self.buf, True
         return self.buf, False
+
+    def _flush_into_buf(self):
+        if self.pending is not None:
+            self.buf.add_(self.pending)
+            self.pending = None
+        for idx, r in self.rows:
+            self.buf.index_add_(0, idx, r.to(self.buf.dtype))
+        self.rows = []
+
+    def deposit(self, g):
+        """Residual-branch gradient g (same shape as the tensor).  Returns None: the contribution reaches autograd through
+        the buffer (or through `_SinkOwner` if no buffer is ever made)."""
+        if self.buf is not None:
+            self.buf.add_(g)
+        elif self.pending is None:
+            self.pending = g
+        else:
+            self.pending = self.pending + g
+        return None
+
+    def deposit_rows(self, idx, rows):
+        """Gradient of a row gather x[idx]: rows added at idx."""
+        if self.buf is not None:
+            self.buf.index_add_(0, idx, rows.to(self.buf.dtype))
+        else:
+            self.rows.append((idx, rows))
+        return None
+
+    def gemm_into(self, A, Wt, like):
+        """d x (+)= A @ Wt^T-form GEMM (K.gemm(A, Wt)) into the shared buffer; returns the buffer if this call created it
+        (the caller hands it to autograd), else None."""
+        if self.buf is None:
+            out = torch.empty(like.shape, dtype=torch.float32, device=like.device)
+            K.gemm(A, Wt, out=out, residual=self.pending)
+            self.pending = None
+            self.buf = out
+            rows, self.rows = self.rows, []
+            for idx, r in rows:
+                out.index_add_(0, idx, r.to(out.dtype))
+            return out
+        K.gemm(A, Wt, out=self.buf, accumulate=True)
+        return None
 
 
 class _SinkOwner(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, sink):
         ctx.sink = sink
+        ctx.meta = (t.shape, t.dtype, t.device)
+        ctx.set_materialize_grads(False)
         return t.view_as(t)
 
     @staticmethod
     def backward(ctx, g):
-        ctx.sink.buf = None
+        sink = ctx.sink
+        pend, rows = sink.pending, sink.rows
+        sink.buf, sink.pending, sink.rows = None, None, []
+        if pend is not None:                       # a deposit that no later GEMM folded in
+            g = pend if g is None else g + pend
+        if rows:
+            if g is None:
+                g = torch.zeros(ctx.meta[0], dtype=ctx.meta[1], device=ctx.meta[2])
+            elif pend is None:
+                g = g.clone()
+            for idx, r in rows:
+                g.index_add_(0, idx, r.to(g.dtype))
         return g, None
 
 
@@ -546,7 +657,14 @@ def shared_grad(t):
     sink = GradSink()
     out = _SinkOwner.apply(t, sink)
     out._fab_gsink = sink
+    c = getattr(t, "_fab_b16", None)
+    if c is not None and c[0] == t._version:       # the bf16 operand copy travels with the view
+        out._fab_b16 = (out._version, c[1])
     return out
+
+
+def _sink_of(t):
+    return getattr(t, "_fab_gsink", None) if t is not None else None
 
 
 def _sink_zeros(t, sink):
@@ -668,6 +786,7 @@ class _InterAttn(torch.autograd.Function):
                                                     bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext)
         ctx.g, ctx.H, ctx.clampv, ctx.np = g, H, clampv, bias_part.shape[1]
         ctx.has_ext, ctx.has_cv = s_ext is not None, Wc is not None
+        ctx.sink_h = _sink_of(h)
         ctx.save_for_backward(qkv, cv, d, rhohat, w_rk, w_rv, wcr, w3, alpha, cvs, v_in, Wc)
         ctx.mark_non_differentiable(alpha)
         return h_out, x_out, alpha
@@ -709,6 +828,8 @@ class _InterAttn(torch.autograd.Function):
             else:
                 dbc = None
             dcv = None
+        if ctx.sink_h is not None and ctx.needs_input_grad[2]:
+            dh_out = ctx.sink_h.deposit(dh_out)           # h_out = h + ...: the residual gradient joins h's shared buffer
         return (dqkv, dcv, dh_out, dx_out, dd[:E], drh[:E], dbias_red[:n_red, None].expand(n_red, ctx.np), dw[0], dw[1],
                 dw[2], dw[3], None, None, None, dcp[:E] if ctx.has_ext else None, dWc, dbc)
 

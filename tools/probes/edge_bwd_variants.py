@@ -42,5 +42,14 @@ for rnd in range(3):
         print("round %d forward    %-60s %.3f ms" % (rnd, k[:60], sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs)), flush=True)
     K.PROFILE = None
 lib.fabind_gcl_edge_fused_bwd_set_variant(1)
+for ng in (128, 256, 384, 512):                       # does a second work-group per CU add throughput?
+    K.EDGE_BWD_GROUPS = ng
+    K.PROFILE = {}
+    timeit(run, 5)
+    for k, evs in K.PROFILE.items():
+        if "bwd" in k:
+            print("variant 1 with %d persistent work-groups: %.3f ms" % (ng, sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs)), flush=True)
+    K.PROFILE = None
+K.EDGE_BWD_GROUPS = 0
 for n, a, b in zip(("dAB", "drh", "dw_r", "dW2", "db2", "dWc", "dbc", "dw3"), outs[0], outs[1]):
     print("variant 1 vs 0  %-5s max rel diff %.2e" % (n, float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))))
