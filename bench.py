@@ -129,12 +129,13 @@ def main():
     ap.add_argument("--n-iter", type=int, default=1)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--poses", type=int, default=20, help="plus_sampling: poses sampled per complex and step")
-    ap.add_argument("--mode", default="fwdbwd", choices=["fwd", "fwdbwd", "model", "plus_sampling"],
+    ap.add_argument("--mode", default="fwdbwd", choices=["fwd", "fwdbwd", "model", "plus_sampling", "plus_train"],
                     help="fwd / fwdbwd: the layer stack on the whole graph (SURVEY 8(d), the headline); model: the full "
                          "IaBNet (pocket model on the whole protein -> pocket crop -> complex model -> heads) with the "
                          "pocket-cls + coord + distmap losses, fwd+bwd (BASELINE configs[2] read literally); plus_sampling: "
                          "FABind+ sampling-mode inference (BASELINE configs[4]: dropout sampling, DBSCAN centre choice, "
-                         "confidence head, --poses per complex)")
+                         "confidence head, --poses per complex); plus_train: one FABind+ training step (train mode, 7-term "
+                         "loss incl. the permutation-invariant coordinate term, fwd+bwd)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="default fwdbwd mode at N=1 also times, inside the same JSON line, the same step in fp32 (the mode that "
@@ -173,7 +174,7 @@ def main():
 
     def make_step(mode, n_iter, train_mode=False):
         """-> (step function, complexes per step on this rank, parameter list).  Inputs are resident in HBM before the timed region."""
-        if mode == "plus_sampling":
+        if mode in ("plus_sampling", "plus_train"):
             from fabind_amd import synthetic
             from fabind_amd.plus.models import get_model as get_model_plus
             margs = stack_args(a.hidden, a.layers if a.layers != 4 else 5, n_iter)
@@ -184,6 +185,30 @@ def main():
                                confidence_training=True, stack_mlp=True, confidence_use_ln_mlp=True, confidence_dropout=0.2,
                                confidence_mlp_hidden_scale=1).items():
                 setattr(margs, k_, v_)
+            if mode == "plus_train":
+                from fabind_amd.plus.models import compute_loss as plus_loss
+                margs.confidence_training, margs.use_clustering = False, False
+                torch.manual_seed(0)
+                model = get_model_plus(margs, _Log()).to(dev)        # LN-MLPs normalise every block: plain init is well conditioned
+                model.train()
+                hb = synthetic.make_hetero_batch([(a.n_prot, a.n_lig)] * a.batch, seed=rank).to(dev)
+                radius = torch.full((a.batch,), 6.0, device=dev)
+                num_atoms = [a.n_lig] * a.batch
+                isos = [[list(range(a.n_lig)), list(reversed(range(a.n_lig)))] for _ in range(a.batch)]
+                params = list(model.parameters())
+
+                def step():
+                    for p in params:
+                        p.grad = None
+                    data = hb.clone()
+                    data.ligand_radius, data.num_atoms, data.isomorphisms = radius, num_atoms, isos
+                    out = model(data, train=True)
+                    loss, _ = plus_loss(out, data)
+                    loss.backward()
+                    if world > 1:
+                        from fabind_amd import parallel
+                        parallel.allreduce_gradients(params, world)
+                return step, a.batch, params
             torch.manual_seed(0)
             model = get_model_plus(margs, _Log()).to(dev)
             model.train()                                              # --infer-dropout: dropout on, ranking head in eval
@@ -294,6 +319,8 @@ def main():
                        if a.mode == "plus_sampling" else
                        "complexes/sec fwd+bwd, full IaBNet (pocket model + pocket crop + complex model + heads) with "
                        "pocket-cls + coord + distmap losses" if a.mode == "model" else
+                       "complexes/sec, one FABind+ training step (train mode, 7-term loss with the permutation-invariant "
+                       "coordinate term, fwd+bwd)" if a.mode == "plus_train" else
                        "complexes/sec %s (1500p/40l nodes), one stack pass per refinement iteration" % (
                            "fwd+bwd" if a.mode == "fwdbwd" else "fwd")),
             "value": value, "unit": "poses/s" if a.mode == "plus_sampling" else "complexes/s", "n_gpus": world, "steps": a.steps,
@@ -303,6 +330,9 @@ def main():
                                     "%d, n_iter=%d), %d poses per complex and step" % (a.batch, a.n_prot, a.n_lig, a.hidden,
                                                                                         a.n_iter, a.poses))
                        if a.mode == "plus_sampling" else
+                       "synthetic batch=%d/GPU, %d protein / %d ligand nodes, FABind+ model (5-layer LN-MLP stack, hidden %d, "
+                       "n_iter=%d), training step" % (a.batch, a.n_prot, a.n_lig, a.hidden, a.n_iter)
+                       if a.mode == "plus_train" else
                        "synthetic batch=%d/GPU (%d distinct seeded geometries), %d protein / %d ligand nodes, %d-layer FABind stack "
                        "+ out layer, hidden %d, n_iter=%d, %s" % (a.batch, a.batch, a.n_prot, a.n_lig, a.layers, a.hidden,
                                                                    a.n_iter, a.mode),

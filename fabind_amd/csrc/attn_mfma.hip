@@ -28,6 +28,15 @@ __device__ __forceinline__ bf16x8_t cm_pack8(const float* f) {
     u[0] = pack2_bf16(f[0], f[1]); u[1] = pack2_bf16(f[2], f[3]); u[2] = pack2_bf16(f[4], f[5]); u[3] = pack2_bf16(f[6], f[7]);
     return *(bf16x8_t*)&u;
 }
+__device__ __forceinline__ float cm_round(float x) { return __uint_as_float(pack2_bf16(x, 0.f) << 16); }   // to bf16 and back
+// sum of the eight bf16 values of a fragment (as fp32)
+__device__ __forceinline__ float cm_sum8(const bf16x8_t f) {
+    const u32x4_t u = *(const u32x4_t*)&f;
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t += __uint_as_float(u[k] << 16) + __uint_as_float(u[k] & 0xffff0000u);
+    return t;
+}
 // position of chunk-local row `l` (0..31) in the permuted K order of the second contraction
 __device__ __forceinline__ int cm_perm(int l) { return ((l >> 2) & 3) * 8 + (l >> 4) * 4 + (l & 3); }
 
@@ -162,14 +171,17 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_fwd_kernel(const float* _
             const float mn = fmaxf(m[h], mx);
             const float ms = (mn == -INFINITY) ? 0.f : mn;
             const float corr = __expf(m[h] - ms);
-            float p[8], ps = 0.f;
+            float p[8];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { p[t * 4 + r] = __expf(s[t][r] - ms); ps += p[t * 4 + r]; }
-            l[h] = l[h] * corr + ps;
-            m[h] = mn;
+                for (int r = 0; r < 4; ++r) p[t * 4 + r] = __expf(s[t][r] - ms);
             const bf16x8_t pf = cm_pack8(p);
+            // the normaliser sums the ROUNDED probabilities, i.e. exactly what P.V consumes: the output is an exact convex
+            // combination of the value rows, and the backward (pass Q) can reproduce every weight bit for bit -- the row sums
+            // of dS, which the pair-bias gradients are made of, then cancel to fp32 round-off instead of to 2^-9
+            l[h] = l[h] * corr + cm_sum8(pf);
+            m[h] = mn;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
@@ -296,7 +308,9 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_bwd_q_kernel(const float*
                 fq[half * 4 + u] = qvalid ? av[u] * scale : 0.f;
                 dov[u] = qvalid ? d4[u] * sg : 0.f;
                 fo[half * 4 + u] = dov[u];
-                dsum += d4[u] * o4[u];
+                // D = dO . o with dO as the contraction sees it (bf16) and o = out / gate the un-gated attention output: then
+                // D = sum_j w_ij dP_ij holds to fp32 round-off for the weights w the forward used, and sum_j dS_ij = 0
+                dsum += cm_round(dov[u]) * (sg > 1e-30f ? o4[u] * __builtin_amdgcn_rcpf(sg) : 0.f);
                 dg[u] = d4[u] * o4[u] * (1.f - sg);
             }
             if (qvalid && blockIdx.z == 0) {
@@ -313,8 +327,9 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_bwd_q_kernel(const float*
         bdo[h] = cm_pack8(fo);
     }
     f32x4_t dq[4][2];
+    float mrun[4];                              // the forward's running row maximum, replayed chunk by chunk (same chunk order)
 #pragma unroll
-    for (int h = 0; h < 4; ++h) { dq[h][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dq[h][1] = dq[h][0]; }
+    for (int h = 0; h < 4; ++h) { dq[h][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dq[h][1] = dq[h][0]; mrun[h] = -INFINITY; }
     int kb = 0, ke = nk;
     if (ksplit > 1) {
         const int per = ((nk + ksplit - 1) / ksplit + CM_KC - 1) / CM_KC * CM_KC;
@@ -350,14 +365,32 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_bwd_q_kernel(const float*
                 dp[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm_load_rows(sV, t * 16 + n, h * 4 + kq), bdo[h],
                                                                  f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
             }
-            float dsv[8];
+            // the weight of (query, key) exactly as the forward applied it: the probability relative to the running maximum
+            // of ITS chunk, rounded to bf16 (the P operand of P.V), times exp(running max - log-sum-exp) in fp32
+            float sgv[8], mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float lv = ((const float*)&lin[t][r])[h], sg = sigmoid_f(((const float*)&gat[t][r])[h]);
-                    const float p = ok[t][r] ? __expf(s[t][r] + lv * sg - L[h]) : 0.f;
-                    const float dsj = p * (dp[t][r] - D[h]);
+                    sgv[t * 4 + r] = sg;
+                    s[t][r] = ok[t][r] ? s[t][r] + lv * sg : -INFINITY;
+                    mx = fmaxf(mx, s[t][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(mrun[h], mx);
+            const float ms = (mn == -INFINITY) ? 0.f : mn;
+            const float wsc = __expf(ms - L[h]);
+            mrun[h] = mn;
+            float dsv[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float lv = ((const float*)&lin[t][r])[h], sg = sgv[t * 4 + r];
+                    const float w = cm_round(__expf(s[t][r] - ms)) * wsc;
+                    const float dsj = w * (dp[t][r] - D[h]);
                     dsv[t * 4 + r] = dsj;
                     dl[t][r][h] = dsj * sg;
                     dgt[t][r][h] = dsj * lv * sg * (1.f - sg);

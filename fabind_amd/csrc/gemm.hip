@@ -1042,6 +1042,11 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     const bool foldq = p.row_mu != nullptr;
     FB_REQUIRE(!foldq || (p.row_rs != nullptr && p.col_c != nullptr), "fabind_gemm: row_mu needs row_rs and col_c");
     const bool drop = p.p_drop > 0.f;    /* dropout: generic epilogue, or the fast ones without a second / pre-activation tile */
+    /* C += A W^T on a plain fp32 C is the residual epilogue with R = C: every element is read and written by the same lane, so
+       the fast fp32 epilogue (row-contiguous 16-B accesses) serves it (the generic one stores element by element) */
+    if (p.accumulate && !p.R && !p.r_index && !p.groups && p.k_splits <= 1 && p.C != nullptr && p.c_dtype == FB_DT_F32) {
+        p.R = p.C; p.ldr = p.ldc; p.accumulate = 0;
+    }
     if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && !p.r_index && p.C != nullptr &&
         p.c_dtype == FB_DT_F32 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
         p.epi_fast = p.R ? 10 : 9;

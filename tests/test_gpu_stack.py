@@ -421,8 +421,7 @@ def test_fabind_layer_forward_composes_to_the_stack():
         H2, x2 = m.gnn(inp["H"], inp["X"].clone(), ctx=ctx)
         assert rmsd(x2.cpu().numpy()[lig] * 5, g["out_X_f32"][lig] * 5) < 1e-4
         assert np.abs(H2.cpu().numpy() - g["out_H_f32"]).max() <= 1e-4 * max(1.0, np.abs(g["out_H_f32"]).max())
-        with pytest.raises(NotImplementedError):
-            m.gnn(inp["H"], inp["X"].clone(), None, None)
+        # (the reference's positional signature is served by the dense adapter: tests/test_gpu_dense_api.py)
 
 
 def test_mc_e_gcl_forward_reference_signature_vs_oracle():
