@@ -29,7 +29,7 @@ class GemmArgs(ctypes.Structure):
 class EdgeBwdArgs(ctypes.Structure):
     """Mirror of FabindEdgeBwdArgs (include/fabind_hip.h)."""
     _fields_ = [(n, _vp) for n in ("AB", "row", "col", "rhohat", "w_r", "W2p", "Wcp", "W2Tp", "WcTp", "b2", "bc", "w3", "ds",
-                                  "dagg", "S1", "Mm", "dT", "dP2", "dP1", "drh", "dABrow", "part", "dbg", "d2scratch")] + \
+                                  "dagg", "S1", "Mm", "dT", "dP2", "dP1", "drh", "dABrow", "part", "dbg", "bnd", "d2scratch")] + \
                [(n, _i) for n in ("ldab", "lddagg", "lddab", "E")] + [("p_drop", _f), ("seed", ctypes.c_uint)]
 
 
@@ -52,7 +52,7 @@ SIGNATURES = {
     "fabind_inter_meta": [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "fabind_edge_geom": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "fabind_gcl_pre": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
-    "fabind_gcl_edge_fused": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp],
+    "fabind_gcl_edge_fused": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp],
     "fabind_gcl_edge_fused_bwd": [ctypes.POINTER(EdgeBwdArgs), _i, _i, _vp],
     "fabind_pair_update_fused": [ctypes.POINTER(PairUpdateArgs), _i, _vp],
     "fabind_gcl_edge_fused_bwd_set_tile": [_i],

@@ -95,3 +95,69 @@ __device__ __forceinline__ void fe_zero(f32x4_t (&acc)[MI][4]) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Deterministic segment sum of a [rows][H] LDS tile over row-sorted edges (one column per thread).
+// A node's edges are contiguous, so inside a 64-edge tile every run of equal row ids is a complete node EXCEPT possibly the
+// tile's first run (it may continue a run of the previous tile: head_cont) and its last run (it may continue into the next
+// tile: tail_cont).  Complete runs are plain stores.  The two boundary runs go to bnd[tile][0 | 1][H] and a fix-up kernel
+// (fe_boundary_fix_kernel) adds the pieces of every node that spans tiles IN TILE ORDER -- no float atomics, so the result
+// does not depend on which work-group finishes first (round 1 used atomicAdd for the boundary runs: a node with 1,500 edges
+// spans 24 tiles, and two identical forward passes differed by an ulp about once in ten runs, amplified to 1e-4 in h by
+// bf16 rounding downstream).  Returns sum_rows rh[row] * value (the d w_r partial of the backward) when WITH_RH.
+template <int H, bool WITH_RH>
+__device__ __forceinline__ float fe_scan_rows(const bf16_t* sX, const int* sRow, const float* sRh, int ne, bool head_cont,
+                                              bool tail_cont, float* out, unsigned ld, float* bnd_tile, int c) {
+    float run = 0.f, pwr = 0.f;
+    int cur = sRow[0];
+    bool first = true;
+    for (int rw0 = 0; rw0 < ne; rw0 += 8) {
+        int rr[8];
+        float v[8], rhv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rw = rw0 + u;                       // < FE_BM: the tile height is a multiple of 8
+            rr[u] = sRow[rw];
+            rhv[u] = WITH_RH ? sRh[rw] : 0.f;
+            v[u] = bf16_to_f32(sX[rw * H + (((c >> 3) ^ (rw & 7)) * 8) + (c & 7)]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (rw0 + u < ne) {
+                if (rr[u] != cur) {
+                    if (first && head_cont) bnd_tile[c] = run; else out[(unsigned)cur * ld + c] = run;
+                    run = 0.f; cur = rr[u]; first = false;
+                }
+                run += v[u];
+                if (WITH_RH) pwr += rhv[u] * v[u];
+            }
+        }
+    }
+    if (ne > 0) {
+        if (first && head_cont) bnd_tile[c] = run;            // the whole tile continues the previous tile's node
+        else if (tail_cont) bnd_tile[H + c] = run;
+        else out[(unsigned)cur * ld + c] = run;
+    }
+    return pwr;
+}
+
+// One work-group (H threads) per tile: the tile where a node's tile-spanning run STARTS adds up its pieces in tile order.
+template <int BM>
+__global__ void fe_boundary_fix_kernel(const int* __restrict__ row, int E, int H, const float* __restrict__ bnd, float* out,
+                                       unsigned ld) {
+    const int t = blockIdx.x, e0 = t * BM, ne = min(BM, E - e0);
+    if (ne <= 0 || e0 + ne >= E) return;
+    const int r = row[e0 + ne - 1];
+    if (row[e0 + ne] != r) return;                                         // the last run ends with the tile
+    if (row[e0] == r && e0 > 0 && row[e0 - 1] == r) return;                // a through tile: the run started earlier
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        float sum = bnd[((size_t)t * 2 + 1) * H + c];
+        for (int u = t + 1;; ++u) {
+            const int f0 = u * BM, fn = min(BM, E - f0);
+            sum += bnd[((size_t)u * 2) * H + c];
+            const bool through = row[f0 + fn - 1] == r && f0 + fn < E && row[f0 + fn] == r;
+            if (!through) break;
+        }
+        out[(unsigned)r * ld + c] = sum;
+    }
+}

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
                                                            const float* __restrict__ b2, const bf16_t* __restrict__ Wcp,
                                                            const float* __restrict__ bc, const float* __restrict__ w3, int E,
                                                            float* agg, float* s_out, uint32_t thr16, float dscale,
-                                                           uint32_t seed) {
+                                                           uint32_t seed, float* bnd) {
     constexpr int NW = H / 64;                      // waves; wave w owns output columns [64w, 64w+64)
     constexpr int CPT = FE_BM * H / H;              // gather: elements per thread = 64 (one 64-column chunk of one edge)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -105,22 +105,11 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
     }
     __syncthreads();
 
-    // ---- phase 2: agg[row] += M  (run-length scan down this thread's column; rows of a node are contiguous)
+    // ---- phase 2: agg[row] = sum of M over the node's edges (deterministic: fused_common.h fe_scan_rows)
     {
-        const int c = tid;                          // H threads <-> H columns
-        float run = 0.f;
-        int cur = sRow[0];
-        bool first = true;                          // a run that starts at the tile's first row may continue a neighbour tile's
-        for (int rw = 0; rw < ne; ++rw) {
-            const int rr = sRow[rw];
-            if (rr != cur) {
-                // interior runs cover ALL edges of their node (rows are node-contiguous): plain store, no read-modify-write
-                if (first) atomicAdd(&agg[(size_t)cur * H + c], run); else agg[(size_t)cur * H + c] = run;
-                run = 0.f; cur = rr; first = false;
-            }
-            run += bf16_to_f32(sX[rw * H + (((c >> 3) ^ (rw & 7)) * 8) + (c & 7)]);
-        }
-        if (ne > 0) atomicAdd(&agg[(size_t)cur * H + c], run);   // last run may continue in the next tile
+        const bool head_cont = e0 > 0 && row[e0 - 1] == sRow[0];
+        const bool tail_cont = e0 + ne < E && row[e0 + ne] == sRow[ne - 1];
+        (void)fe_scan_rows<H, false>(sX, sRow, nullptr, ne, head_cont, tail_cont, agg, (unsigned)H, bnd + (size_t)tile * 2 * H, tid);
     }
 
     // ---- phase 3: s = w3 . silu(M Wc^T + bc)
@@ -169,8 +158,9 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
 extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
                                      const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
                                      const float* w3, int E, float* agg, float* s_out, float p_drop, unsigned seed,
-                                     hipStream_t stream) {
+                                     float* bnd, hipStream_t stream) {
     if (E <= 0) return 0;
+    FB_REQUIRE(bnd != nullptr, "fabind_gcl_edge_fused: bnd (ceil(E/64) x 2 x H floats of scratch) is required");
     FB_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "fabind_gcl_edge_fused: p_drop in [0, 1)");
     const uint32_t thr16 = (uint32_t)(p_drop * 65536.0f + 0.5f);
     const float dscale = 1.0f / (1.0f - (float)thr16 / 65536.0f);
@@ -184,10 +174,12 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
         if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
         hipLaunchKernelGGL((gcl_edge_fused_kernel<HH>), grid, dim3(HH), lds, stream, (const bf16_t*)AB, ldab, row, col, rhohat, \
                            w_r, (const bf16_t*)W2p, b2, (const bf16_t*)Wcp, bc, w3, E, agg, s_out, thr16, dscale, \
-                           (uint32_t)seed);                                                                        \
+                           (uint32_t)seed, bnd);                                                                   \
     } while (0)
     if (H == 512) FE_LAUNCH(512); else if (H == 256) FE_LAUNCH(256); else if (H == 128) FE_LAUNCH(128); else FE_LAUNCH(64);
 #undef FE_LAUNCH
+    hipLaunchKernelGGL((fe_boundary_fix_kernel<FE_BM>), dim3((E + FE_BM - 1) / FE_BM), dim3(H < 256 ? H : 256), 0, stream, row, E, H,
+                       bnd, agg, (unsigned)H);
     FB_CHECK_LAUNCH();
     return 0;
 }
@@ -833,37 +825,12 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd1_kernel(const FabindE
         __syncthreads();
         fe_tile_store<H>(sX, (bf16_t*)p.dP1, e0, ne, tid);
 
-        // ---- P6 (one column per thread): receiving-side segment sum of dP1 and the d w_r column sum
+        // ---- P6 (one column per thread): receiving-side segment sum of dP1 (deterministic, fe_scan_rows) and the d w_r column sum
         {
-            const int c = tid;
-            float run = 0.f, pwr = 0.f;
-            int cur = sRow[0];
-            bool first = true;
-            for (int rw0 = 0; rw0 < ne; rw0 += 8) {
-                int rr[8];
-                float v[8], rhv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int rw = rw0 + u;
-                    rr[u] = sRow[rw];
-                    rhv[u] = sRh[rw];
-                    v[u] = bf16_to_f32(sX[rw * H + (((c >> 3) ^ (rw & 7)) * 8) + (c & 7)]);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (rw0 + u < ne) {
-                        if (rr[u] != cur) {
-                            const unsigned o = (unsigned)cur * (unsigned)p.lddab + c;
-                            if (first) atomicAdd(&p.dABrow[o], run); else p.dABrow[o] = run;
-                            run = 0.f; cur = rr[u]; first = false;
-                        }
-                        run += v[u];
-                        pwr += rhv[u] * v[u];
-                    }
-                }
-            }
-            if (ne > 0) atomicAdd(&p.dABrow[(unsigned)cur * (unsigned)p.lddab + c], run);
-            sPart[3 * H + c] += pwr;                              // column c belongs to this thread alone
+            const bool head_cont = e0 > 0 && p.row[e0 - 1] == sRow[0];
+            const bool tail_cont = e0 + ne < p.E && p.row[e0 + ne] == sRow[ne - 1];
+            sPart[3 * H + tid] += fe_scan_rows<H, true>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dABrow, (unsigned)p.lddab,
+                                                         p.bnd + (size_t)tile * 2 * H, tid);
         }
         __syncthreads();                                          // the next tile overwrites sX / sRow
     }
@@ -908,8 +875,11 @@ extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a, int H, int 
         if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_bwd1_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); set_ = true; } \
         hipLaunchKernelGGL((gcl_edge_fused_bwd1_kernel<HH>), dim3(n_groups), dim3(HH), lds1, stream, *a);           \
     } while (0)
+        FB_REQUIRE(a->bnd != nullptr, "fabind_gcl_edge_fused_bwd: the single-tile variant needs bnd (ceil(E/64) x 2 x H floats)");
         if (H == 512) FE_LAUNCH1(512); else if (H == 256) FE_LAUNCH1(256); else if (H == 128) FE_LAUNCH1(128); else FE_LAUNCH1(64);
 #undef FE_LAUNCH1
+        hipLaunchKernelGGL((fe_boundary_fix_kernel<64>), dim3((a->E + 63) / 64), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
+                           a->bnd, a->dABrow, (unsigned)a->lddab);
         FB_CHECK_LAUNCH();
         return 0;
     }

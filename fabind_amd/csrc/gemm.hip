@@ -191,8 +191,11 @@ template <int ACT> __device__ __forceinline__ float fast_dact(float x) {
 }
 
 template <int BM_, int ACT, bool HAS_C, bool HAS_C2, bool HAS_DOT, bool RAW_BARRIER, bool STORE_PRE = false, bool HAS_RG = false,
-          bool FOLD = false>   // FOLD: LayerNorm of the A rows folded in (row_mu / row_rs / col_c); its own dispatch codes, so
+          bool FOLD = false,   // FOLD: LayerNorm of the A rows folded in (row_mu / row_rs / col_c); its own dispatch codes, so
                                // every other GEMM keeps the un-folded instruction stream
+          bool AUXMUL = false> // AUXMUL: C = acc * act'(aux) with aux a bf16 [M, N] tile read row-contiguously while the staged
+                               // tile is flushed (activation adjoint of an MLP fused into the input-gradient GEMM of its
+                               // second Linear); dact_epi = RELU (aux = the activation's output) or STORED_DERIV (aux = act')
 __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sDot, bf16_t* sOut,
                                                    int M, int N, int ldc, int m0, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -210,6 +213,28 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
             const int row = m0 + rowl, col = n0 + ch * 8;
             if (row >= M || col >= N) continue;
             const bf16_t* sp = &sOut[rowl * OUT_LD + ch * 8];
+            if constexpr (AUXMUL) {
+                const bf16_t* ap = (const bf16_t*)p.aux + (size_t)row * p.ldaux + col;
+                const bool relu = p.dact_epi == FB_ACT_RELU;
+                if (vec_ok && col + 8 <= N && (p.ldaux % 8 == 0) && (((uintptr_t)p.aux & 15) == 0)) {
+                    const uint4 v = *(const uint4*)sp, a = *(const uint4*)ap;
+                    const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, aa[4] = {a.x, a.y, a.z, a.w};
+                    uint32_t oo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a0 = __uint_as_float(aa[e] << 16), a1 = __uint_as_float(aa[e] & 0xffff0000u);
+                        const float f0 = relu ? (a0 > 0.f ? 1.f : 0.f) : a0, f1 = relu ? (a1 > 0.f ? 1.f : 0.f) : a1;
+                        oo[e] = pack2_bf16(__uint_as_float(vv[e] << 16) * f0, __uint_as_float(vv[e] & 0xffff0000u) * f1);
+                    }
+                    *(uint4*)(dst + (size_t)row * ldc + col) = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+                } else {
+                    for (int e = 0; e < 8 && col + e < N; ++e) {
+                        const float a0 = bf16_to_f32(ap[e]);
+                        dst[(size_t)row * ldc + col + e] = f32_to_bf16(bf16_to_f32(sp[e]) * (relu ? (a0 > 0.f ? 1.f : 0.f) : a0));
+                    }
+                }
+                continue;
+            }
             if (vec_ok && col + 8 <= N) *(uint4*)(dst + (size_t)row * ldc + col) = *(const uint4*)sp;
             else for (int e = 0; e < 8 && col + e < N; ++e) dst[(size_t)row * ldc + col + e] = sp[e];
         }
@@ -371,6 +396,7 @@ __device__ __forceinline__ bool gemm_epilogue_dispatch(const FabindGemmArgs& p, 
         case 11: gemm_epilogue_fast<BM_, FB_ACT_NONE, true, false, false, RAW_BARRIER, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 12: gemm_epilogue_fast<BM_, FB_ACT_RELU, true, false, false, RAW_BARRIER, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 13: gemm_epilogue_fast<BM_, FB_ACT_RELU, false, false, true, RAW_BARRIER, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
+        case 14: gemm_epilogue_fast<BM_, FB_ACT_NONE, true, false, false, RAW_BARRIER, false, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 9: gemm_epilogue_f32<BM_, false>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0); return true;
         case 10: gemm_epilogue_f32<BM_, true>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0); return true;
         default: return false;
@@ -1053,6 +1079,10 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     } else if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && p.R && p.r_index && p.C &&
                p.c_dtype == FB_DT_BF16 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
         p.epi_fast = 11;
+    } else if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && p.aux && p.aux_dtype == FB_DT_BF16 &&
+               (p.dact_epi == FB_ACT_RELU || p.dact_epi == FB_ACT_STORED_DERIV) && !p.R && !p.accumulate && !p.r_index && p.C &&
+               p.c_dtype == FB_DT_BF16 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2 && !p.bias && !p.store_preact) {
+        p.epi_fast = 14;     /* C = (A W^T) * act'(aux): the activation adjoint of an MLP inside its input-gradient GEMM */
     } else
     if (!p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.R && !p.accumulate && !p.r_index &&
         (p.C == nullptr || p.c_dtype == FB_DT_BF16) && (p.C2 == nullptr || p.C != nullptr) &&

@@ -287,10 +287,11 @@ def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows,
     E = row.shape[0]
     agg = torch.zeros((n_rows, H), dtype=torch.float32, device=AB16.device)
     s = torch.empty((max(E, 1), 1), dtype=torch.float32, device=AB16.device)
+    bnd = torch.empty(((E + 63) // 64 * 2 + 2, H), dtype=torch.float32, device=AB16.device)      # boundary runs (deterministic sums)
     _profiled("gcl_edge_fused_kernel<%d> E=%d (gather + 2 chained H x H contractions + segment-sum per edge)" % (H, E), 4.0 * E * H * H,
               lambda: check(_lib.load().fabind_gcl_edge_fused(ptr(AB16), _ld(AB16), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
                                                               ptr(W2p), ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s),
-                                                              float(p_drop), int(seed) & 0xFFFFFFFF, stream()),
+                                                              float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd), stream()),
                             "fabind_gcl_edge_fused"))
     return agg, s[:E]
 
@@ -377,6 +378,7 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     if ng >= 8:
         ng -= ng % 8                # a multiple of 8 selects the XCD-aware walk (csrc/fused_edge.hip)
     d2scratch = torch.empty((ng, bm * H), dtype=torch.bfloat16, device=dev) if variant == 1 else None
+    bnd = torch.empty(((E + 63) // 64 * 2 + 2, H), dtype=torch.float32, device=dev) if variant == 1 else None
     buf = torch.empty((5, max(E, 1), H), dtype=torch.bfloat16, device=dev)
     S1, Mm, dT, dP2, dP1 = buf[0], buf[1], buf[2], buf[3], buf[4]
     dAB = torch.zeros((N, 2 * H), dtype=torch.float32, device=dev)
@@ -390,7 +392,7 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     for name, t in (("AB", AB16), ("row", row), ("col", col), ("rhohat", rhohat), ("w_r", w_r), ("W2p", W2p), ("Wcp", Wcp),
                     ("W2Tp", W2Tp), ("WcTp", WcTp), ("b2", b2), ("bc", bc), ("w3", w3), ("ds", ds), ("dagg", dagg),
                     ("S1", S1), ("Mm", Mm), ("dT", dT), ("dP2", dP2), ("dP1", dP1), ("drh", drh), ("dABrow", dAB),
-                    ("part", part), ("d2scratch", d2scratch)):
+                    ("part", part), ("d2scratch", d2scratch), ("bnd", bnd)):
         setattr(a, name, ptr(t))
     a.ldab, a.lddagg, a.lddab, a.E = _ld(AB16), _ld(dagg), _ld(dAB), E
     a.p_drop, a.seed = float(p_drop), int(seed) & 0xFFFFFFFF

@@ -32,7 +32,7 @@ const char* fabind_last_error(void);
  * 4 = fabind_pair_bias_cat takes a colpart argument (per-work-group column sums), fabind_pair_bias_cat_parts and the
  *     fabind_gemm_tn_set_waves knob added.
  * 5 = fabind_cross_attn_mfma_fwd / fabind_cross_attn_mfma_bwd added (MFMA bf16 form of the cross attention); FabindEdgeBwdArgs grew
- *     d2scratch, fabind_gcl_edge_fused_bwd_set_variant / _variant added.
+ *     bnd + d2scratch, fabind_gcl_edge_fused takes bnd (deterministic boundary sums instead of float atomics), fabind_gcl_edge_fused_bwd_set_variant / _variant added.
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 5
 int fabind_abi_version(void);
@@ -158,13 +158,15 @@ int fabind_coord_update(const float* x, const float* d, const float* s_part, int
 /* Fused forward edge pipeline of MC_E_GCL (models/egnn.py:68-128) for 64-edge tiles, bf16:
  *   s_out[e] = w3 . silu( silu( silu(A[row]+Bc[col]+rhohat*w_r) W2^T + b2 ) Wc^T + bc ),  agg[row] += silu(.. W2^T + b2)
  * AB = bf16 [N, 2H] (A | Bc); W2p / Wcp = bf16 weights packed in MFMA fragment order [H/32][H/16][4][16][8];
- * agg must be zero-initialised (float atomics per row run).  H in {64,128,256,512}.
+ * agg must be zero-initialised (nodes without edges are not written); every node with edges gets ONE plain store -- runs that
+ * span 64-edge tiles are added in tile order by a fix-up kernel through `bnd`, so the sum is deterministic.  H in {64,128,256,512}.
  * p_drop > 0 (train mode, egnn.py:82): the messages are multiplied by keep(e,c)/(1-p) before both consumers, with
  *   keep(e,c) = [ half_{e&1}( hash32(seed + (e>>1)*H + c) ) >= round(p*65536) ],
  *   hash32(x): x^=x>>16; x*=0x7feb352d; x^=x>>15; x*=0x846ca68b; x^=x>>16   (evaluated again by the backward). */
 int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
                           const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
                           const float* w3, int E, float* agg, float* s_out, float p_drop, unsigned seed,
+                          float* bnd /* scratch: ceil(E/64) x 2 x H floats (boundary runs of nodes that span tiles) */,
                           hipStream_t stream);
 
 /* Backward of the fused edge pipeline (training, bf16): recomputes the forward per 64-edge tile and chains the four
@@ -182,6 +184,7 @@ typedef struct FabindEdgeBwdArgs {
     void* S1; void* Mm; void* dT; void* dP2; void* dP1;
     float* drh; float* dABrow; float* part;
     void* dbg;               /* NULL, or 12 x int64: cycle counts per phase of work-group 0 (profiling aid; two-tile variant) */
+    float* bnd;              /* single-tile variant: ceil(E/64) x 2 x H floats (boundary runs of dABrow, added in tile order) */
     void* d2scratch;         /* single-tile variant: n_groups x 64 x H x 2 bytes of scratch (silu'(pre2) of each work-group's tile) */
     int ldab, lddagg, lddab, E;
     float p_drop;            /* dropout probability of the messages (egnn.py:82); 0 = eval */
