@@ -347,6 +347,9 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
         d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay, g.ctx_by_col)
         agg, s = ops.fused_edge(AB, rhohat, p["w_r"], p["W2"], p["b2"], p["Wc"], p["bc"], p["w3"], H, g, pdrop)
         x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
+        if pdrop == 0.0 and not fast:
+            # node MLP + residual as one autograd node (activation adjoint and residual gradient inside GEMM epilogues)
+            return ops.mlp2(hin, p["Wn1"], p["bn1"], K.ACT_SILU, p["Wn2"], p["bn2"], residual=h, x2=agg), x_new
         t = ops.linear(hin, p["Wn1"], p["bn1"], x2=agg, act_epi=K.ACT_SILU, out_dtype=ad)
         if pdrop > 0.0:
             return h + _drop(ops.linear(t, p["Wn2"], p["bn2"]), pdrop), x_new
@@ -392,10 +395,14 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     og = ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
     hc = (hc + _drop(ops.linear(c16(og), p["Wo_c"], p["bo_c"]), pdrop)) if pdrop > 0.0 else \
         ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc)
-    t = ops.linear(hp16, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU, out_dtype=od)
-    hp = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp)
-    t = ops.linear(c16(hc), p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU, out_dtype=od)
-    hc = ops.linear(t, p["Wt2_c"], p["bt2_c"], residual=hc)
+    if fast:
+        t = ops.linear(hp16, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU, out_dtype=od)
+        hp = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp)
+        t = ops.linear(c16(hc), p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU, out_dtype=od)
+        hc = ops.linear(t, p["Wt2_c"], p["bt2_c"], residual=hc)
+    else:   # Transition + residual (cross_att.py:48-49) as one autograd node each
+        hp = ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp)
+        hc = ops.mlp2(hc, p["Wt1_c"], p["bt1_c"], K.ACT_RELU, p["Wt2_c"], p["bt2_c"], residual=hc)
     return ops.put_rows(hp, hc, lay.c_index64)
 
 

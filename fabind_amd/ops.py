@@ -214,6 +214,77 @@ def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, 
     return y
 
 
+class _MLP2(torch.autograd.Function):
+    """y = act([x | x2] W1^T + b1) W2^T + b2 (+ residual) as ONE autograd node (the node MLP of MC_E_GCL, egnn.py:99-109, and
+    the Transition blocks, model_utils.py:162-175).  Compared with two chained `linear` nodes the backward
+      * applies the activation adjoint inside the input-gradient GEMM of the second Linear (the epilogue multiplies by act'
+        while it flushes its tile: no separate pass over the [M, hidden] gradient),
+      * folds the residual branch's gradient into the epilogue of the first Linear's input-gradient GEMM (or deposits it in x's
+        shared gradient buffer), so autograd adds nothing."""
+
+    @staticmethod
+    def forward(ctx, x, x2, W1, b1, W2, b2, residual, act):
+        assert act in (K.ACT_RELU, K.ACT_SILU)
+        xin, x2in = _mm_in(x), _mm_in(x2)
+        M, N1 = x.shape[0], W1.shape[0]
+        ad = act_dtype()
+        t = torch.empty((M, N1), dtype=ad, device=x.device)
+        D = torch.empty((M, N1), dtype=ad, device=x.device) if act == K.ACT_SILU else None
+        K.gemm(xin, W1, bias=b1, A2=x2in, act_epi=act, out=t, out2=D)
+        y, _ = K.gemm(t, W2, bias=b2, residual=residual, out_dtype=torch.float32)
+        ctx.act, ctx.has_x2, ctx.has_res = act, x2 is not None, residual is not None
+        ctx.res_is_x = residual is x
+        ctx.sink_x, ctx.sink_res = _sink_of(x), _sink_of(residual)
+        ctx.x2_dtype = x2.dtype if x2 is not None else None
+        ctx.save_for_backward(xin, x2in, W1, W2, t, D)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xin, x2in, W1, W2, t, D = ctx.saved_tensors
+        dy = dy.contiguous()
+        md = mm_dtype()
+        ni = ctx.needs_input_grad
+        if dy.dtype != md:
+            dy16, db2 = _mul_dact_colsum(dy, None, K.ACT_NONE, md)          # one pass: cast + bias gradient
+        else:
+            dy16, db2 = dy, K.colsum(dy)
+        dW2 = _weight_grad(dy16, t, K.ACT_NONE).to(W2.dtype) if ni[4] else None
+        aux, dact = (t, K.ACT_RELU) if ctx.act == K.ACT_RELU else (D, K.ACT_STORED_DERIV)
+        dpre, _ = K.gemm(dy16, W2.t().contiguous(), aux=aux, dact=dact, out_dtype=md)      # (dy W2) * act'(pre)
+        db1 = K.colsum(dpre) if ni[3] else None
+        dW1 = _weight_grad(dpre, xin, K.ACT_NONE, x2in).to(W1.dtype) if ni[2] else None
+        W1t = W1.t().contiguous()
+        K1 = xin.shape[1]
+        dres = dy if (ctx.has_res and ni[6]) else None
+        dx = dx2 = None
+        if ni[0]:
+            if ctx.sink_x is not None:
+                if dres is not None and ctx.sink_res is ctx.sink_x:
+                    ctx.sink_x.deposit(dres)                              # folded into the GEMM below (or into the buffer)
+                    dres = None
+                dx = ctx.sink_x.gemm_into(dpre, W1t[:K1], xin)
+            elif dres is not None and ctx.res_is_x:
+                dx, _ = K.gemm(dpre, W1t[:K1], residual=dres, out_dtype=torch.float32)
+                dres = None
+            else:
+                dx, _ = K.gemm(dpre, W1t[:K1], out_dtype=torch.float32)
+        if dres is not None and ctx.sink_res is not None:
+            dres = ctx.sink_res.deposit(dres)
+        if ctx.has_x2 and ni[1]:
+            dx2, _ = K.gemm(dpre, W1t[K1:], out_dtype=torch.float32 if ctx.x2_dtype == torch.float32 else ctx.x2_dtype)
+        return dx, dx2, dW1, db1, dW2, (db2 if ni[5] else None), dres, None
+
+
+def mlp2(x, W1, b1, act, W2, b2, residual=None, x2=None):
+    """act([x | x2] W1^T + b1) W2^T + b2 (+ residual) -> fp32.  One autograd node under autograd (see _MLP2); without
+    autograd two GEMMs with fused epilogues."""
+    if _needs_grad(x, x2, W1, b1, W2, b2, residual):
+        return _MLP2.apply(x, x2, W1, b1, W2, b2, residual, act)
+    t = linear(x, W1, b1, act_epi=act, x2=x2, out_dtype=act_dtype())
+    return linear(t, W2, b2, residual=residual)
+
+
 # ------------------------------------------------------------------------------------------------
 # linear + row-dot:  s_part[m, t] = sum_{n in tile t} act_epi(act_pro(x) W^T + b)[m,n] * u[n]
 # ------------------------------------------------------------------------------------------------

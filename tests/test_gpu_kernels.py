@@ -545,3 +545,50 @@ def test_shared_gradient_buffer_matches_plain_autograd(case):
     # float atomics inside the adjoint reorder sums: equal to round-off
     assert float((g0 - r0).abs().max()) <= 1e-5 * float(r0.abs().max())
     assert float((g1 - r1).abs().max()) <= 1e-5 * float(r1.abs().max())
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("act", ["relu", "silu"])
+@pytest.mark.parametrize("with_x2,with_sink", [(False, False), (True, False), (False, True), (True, True)])
+def test_mlp2_node_matches_autograd(prec, tol, act, with_x2, with_sink):
+    """ops.mlp2 (Linear -> act -> Linear (+ residual) as one autograd node: activation adjoint inside the GEMM epilogue,
+    residual gradient folded into the input-gradient GEMM or x's shared buffer) against plain torch autograd -- forward,
+    d x, d x2, all four parameter gradients; with and without a second consumer of x sharing the gradient buffer."""
+    from fabind_amd import engine, kernels as K, ops
+    dev = _dev()
+    engine.set_precision(prec)
+    try:
+        g = torch.Generator().manual_seed(7)
+        M, Hh, K2, N1 = 1000, 128, 64, 256
+        x = torch.randn(M, Hh, generator=g)
+        x2 = torch.randn(M, K2, generator=g) if with_x2 else None
+        W1 = torch.randn(N1, Hh + (K2 if with_x2 else 0), generator=g) / 12
+        b1, W2, b2 = torch.randn(N1, generator=g) * 0.1, torch.randn(Hh, N1, generator=g) / 16, torch.randn(Hh, generator=g) * 0.1
+        W3 = torch.randn(64, Hh, generator=g) / 12                       # the second consumer of x
+        cot = torch.randn(M, Hh, generator=g)
+        fa = torch.relu if act == "relu" else torch.nn.functional.silu
+        leaves = [t.clone().requires_grad_(True) for t in (x, W1, b1, W2, b2, W3)] + ([x2.clone().requires_grad_(True)] if with_x2 else [])
+        xr, W1r, b1r, W2r, b2r, W3r = leaves[:6]
+        # bf16 mode: the reference sees the same rounded operands (straight-through), otherwise ReLU masks of entries within
+        # 2^-9 of zero differ and single gradient entries move by O(1) of a term
+        rb = (lambda t_: t_ + (t_.bfloat16().float() - t_).detach()) if prec == "bf16" else (lambda t_: t_)
+        xin = torch.cat([rb(xr), rb(leaves[6])], 1) if with_x2 else rb(xr)
+        yr = rb(fa(xin @ rb(W1r).T + b1r)) @ rb(W2r).T + b2r + xr
+        extra = (xr @ W3r.T).pow(2).sum() if with_sink else 0.0
+        ((yr * cot).sum() + extra).backward()
+        wd = ops.mm_dtype()
+        dl = [t.clone().to(dev).requires_grad_(True) for t in (x, W1, b1, W2, b2, W3)] + ([x2.clone().to(dev).requires_grad_(True)] if with_x2 else [])
+        xd, W1d, b1d, W2d, b2d, W3d = dl[:6]
+        xs = ops.shared_grad(xd) if with_sink else xd
+        code = K.ACT_RELU if act == "relu" else K.ACT_SILU
+        y = ops.mlp2(xs, W1d.to(wd), b1d, code, W2d.to(wd), b2d, residual=xs, x2=dl[6] if with_x2 else None)
+        extra = ops.linear(xs, W3d.to(wd)).pow(2).sum() if with_sink else 0.0
+        ((y * cot.to(dev)).sum() + extra).backward()
+        assert float((y.detach().cpu() - yr.detach()).abs().max()) <= tol * float(yr.abs().max())
+        for name, a, b in zip(("x", "W1", "b1", "W2", "b2", "W3", "x2"), dl, leaves):
+            if name == "W3" and not with_sink:
+                continue
+            err = float((a.grad.float().cpu() - b.grad).abs().max() / b.grad.abs().max())
+            assert err <= tol, (name, err)
+    finally:
+        engine.set_precision("fp32")
