@@ -45,12 +45,27 @@ def build_model(hidden, layers, n_iter, seed=0, dropout=0.0):
     m = EfficientMCAttModel(stack_args(hidden, layers, n_iter), hidden, hidden, 1, n_layers=layers, n_iter=n_iter,
                             dropout=dropout, normalize_coord=lambda x: x / 5.0, unnormalize_coord=lambda x: x * 5.0)
     from fabind_amd import synthetic
+    if LEGACY_BATCH:
+        return m
     return synthetic.condition_for_large_graphs(m)      # random init kept out of the |h| ~ 1e6 regime (see its docstring)
+
+
+LEGACY_BATCH = os.environ.get("FABIND_BENCH_LEGACY_BATCH", "0") == "1"    # round-1 workload (4 geometries tiled 16x, plain init): A/B only
 
 
 def make_batch(batch, n_prot, n_lig, hidden, seed):
     """`batch` DISTINCT seeded synthetic complexes, host generation ~1 s at B=64."""
     from fabind_amd import synthetic
+    if LEGACY_BATCH and batch > 4:          # what round 1's bench.py timed: same-box comparisons against that tree (tools/probes)
+        base = synthetic.make_stack_batch([(n_prot, n_lig)] * 4, hidden, seed=seed, snap=False)
+        reps, n = (batch + 3) // 4, base["X"].shape[0]
+        out = {k: torch.cat([base[k]] * reps)[: n // 4 * batch] for k in ("X", "H", "segment_id", "mask", "is_global", "coord_LAS")}
+        per = n // 4
+        out["batch_id"] = torch.repeat_interleave(torch.arange(batch), per)
+        shift = lambda e: torch.cat([e + i * n for i in range(reps)], 1)
+        ce, le = shift(base["compound_edge_index"]), shift(base["LAS_edge_index"])
+        out["compound_edge_index"], out["LAS_edge_index"] = ce[:, ce[0] < per * batch], le[:, le[0] < per * batch]
+        return out
     return synthetic.make_stack_batch([(n_prot, n_lig)] * batch, hidden, seed=seed, snap=False)
 
 

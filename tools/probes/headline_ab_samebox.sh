@@ -1,6 +1,9 @@
-# Same-box interleaved A/B of the headline (default) bench: current tree vs the side worktree _ab_prev (an older commit).
+# Same-box interleaved A/B of the headline (default) bench: current tree vs the side worktree _ab_prev (an older commit,
+# `git worktree add _ab_prev <commit>` + build there).  Both time the SAME workload: round 1's batch construction
+# (FABIND_BENCH_LEGACY_BATCH=1: 4 geometries tiled 16x, plain init), which is what the older tree's bench.py builds.
 for pass in $(seq 1 ${PASSES:-3}); do
   for tree in . _ab_prev; do
-    (cd $tree && python bench.py --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('HEAD-AB pass $pass tree=$tree', round(d['value'],2), round(d['ms_per_step'],2), 'frac', round(d['roofline']['frac'],4))")
+    extra=""; [ "$tree" = "." ] && extra="--no-extras"
+    (cd $tree && FABIND_BENCH_LEGACY_BATCH=1 python bench.py --no-cpu-baseline $extra 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('HEAD-AB pass $pass tree=$tree', round(d['value'],2), round(d['ms_per_step'],2), 'frac', round(d['roofline']['frac'],4), d['roofline']['kernel'][:40])")
   done
 done
