@@ -30,7 +30,7 @@ class EdgeBwdArgs(ctypes.Structure):
     """Mirror of FabindEdgeBwdArgs (include/fabind_hip.h)."""
     _fields_ = [(n, _vp) for n in ("AB", "row", "col", "rhohat", "w_r", "W2p", "Wcp", "W2Tp", "WcTp", "b2", "bc", "w3", "ds",
                                   "dagg", "S1", "Mm", "dT", "dP2", "dP1", "drh", "dABrow", "part", "dbg", "bnd", "d2scratch")] + \
-               [(n, _i) for n in ("ldab", "lddagg", "lddab", "E")] + [("p_drop", _f), ("seed", ctypes.c_uint)]
+               [(n, _i) for n in ("ldab", "lddagg", "lddab", "E")] + [("p_drop", _f), ("seed", ctypes.c_uint), ("xcd_aware", _i)]
 
 
 class PairUpdateArgs(ctypes.Structure):
@@ -137,6 +137,13 @@ def load():
     lib.fabind_gemm_set_persistent.restype = None
     lib.fabind_gemm_tn_set_waves.argtypes = [ctypes.c_int]
     lib.fabind_gemm_tn_set_waves.restype = None
+    lib.fabind_gcl_edge_fused_set_xcd_aware.argtypes = [ctypes.c_int]
+    lib.fabind_gcl_edge_fused_set_xcd_aware.restype = None
+    if "FABIND_EDGE_BWD_VARIANT" in os.environ:          # development knobs for same-box A/B runs (tools/probes)
+        lib.fabind_gcl_edge_fused_bwd_set_variant.argtypes = [ctypes.c_int]
+        lib.fabind_gcl_edge_fused_bwd_set_variant(int(os.environ["FABIND_EDGE_BWD_VARIANT"]))
+    if "FABIND_EDGE_XCD" in os.environ:
+        lib.fabind_gcl_edge_fused_set_xcd_aware(int(os.environ["FABIND_EDGE_XCD"]))
     for name, argt in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.argtypes = argt

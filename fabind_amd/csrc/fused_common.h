@@ -57,10 +57,12 @@ __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* _
             const int r = i * 16 + fr;
             a[i] = *(const bf16x8_t*)&sX[r * H + (((ks * 4 + fq) ^ (r & 7)) * 8)];
         }
+        __builtin_amdgcn_s_setprio(1);      // co-resident work-groups sit in VALU epilogues: the matrix-core stream goes first
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
         if (ks + 2 < NKS) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) b0[j] = wp[((size_t)(ks + 2) * NG + j) * 64];
@@ -70,10 +72,12 @@ __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* _
             const int r = i * 16 + fr;
             a[i] = *(const bf16x8_t*)&sX[r * H + ((((ks + 1) * 4 + fq) ^ (r & 7)) * 8)];
         }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
     }
 }
 

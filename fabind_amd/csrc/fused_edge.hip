@@ -16,6 +16,9 @@
 #include "fabind_hip.h"
 #include "fused_common.h"
 
+static int g_fe_xcd_aware = 1;       // development knob: XCD-aware tile order (1) vs linear / grid-stride order (0)
+extern "C" void fabind_gcl_edge_fused_set_xcd_aware(int on) { g_fe_xcd_aware = on ? 1 : 0; }
+
 template <int H>
 __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __restrict__ AB, int ldab, const int* __restrict__ row,
                                                            const int* __restrict__ col, const float* __restrict__ rhohat,
@@ -23,7 +26,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
                                                            const float* __restrict__ b2, const bf16_t* __restrict__ Wcp,
                                                            const float* __restrict__ bc, const float* __restrict__ w3, int E,
                                                            float* agg, float* s_out, uint32_t thr16, float dscale,
-                                                           uint32_t seed, float* bnd) {
+                                                           uint32_t seed, float* bnd, int xcd_aware) {
     constexpr int NW = H / 64;                      // waves; wave w owns output columns [64w, 64w+64)
     constexpr int CPT = FE_BM * H / H;              // gather: elements per thread = 64 (one 64-column chunk of one edge)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -35,8 +38,8 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
     // complex-contiguous, so giving XCD x the x-th EIGHTH of the tile range makes one XCD own whole complexes: the gathered AB
     // rows of a complex (3 MB at 1542 nodes x 1024 bf16) are fetched into one L2 once instead of into all eight.
     const int n_tiles = (E + FE_BM - 1) / FE_BM, tpx = (n_tiles + 7) / 8;
-    const int tile = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= tpx || tile >= n_tiles) return;
+    const int tile = xcd_aware ? (int)((blockIdx.x & 7) * tpx + (blockIdx.x >> 3)) : (int)blockIdx.x;
+    if ((xcd_aware && (int)(blockIdx.x >> 3) >= tpx) || tile >= n_tiles) return;
     const int e0 = tile * FE_BM;
     const int ne = min(FE_BM, E - e0);
 
@@ -174,7 +177,7 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
         if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
         hipLaunchKernelGGL((gcl_edge_fused_kernel<HH>), grid, dim3(HH), lds, stream, (const bf16_t*)AB, ldab, row, col, rhohat, \
                            w_r, (const bf16_t*)W2p, b2, (const bf16_t*)Wcp, bc, w3, E, agg, s_out, thr16, dscale, \
-                           (uint32_t)seed, bnd);                                                                   \
+                           (uint32_t)seed, bnd, g_fe_xcd_aware);                                                   \
     } while (0)
     if (H == 512) FE_LAUNCH(512); else if (H == 256) FE_LAUNCH(256); else if (H == 128) FE_LAUNCH(128); else FE_LAUNCH(64);
 #undef FE_LAUNCH
@@ -253,7 +256,7 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
     // complexes, and its work-groups walk that range with stride gridDim.x / 8 -- the gathered AB rows of a complex stay in ONE
     // XCD's L2 (the grid-stride walk spread every complex over all eight: 1.46x HBM over-fetch, profiles/r01_pmc.json).
     int t_first, t_end, t_step;
-    if ((gridDim.x & 7) == 0) {
+    if (p.xcd_aware && (gridDim.x & 7) == 0) {
         const int tpx = (n_tiles + 7) / 8, xcd = blockIdx.x & 7;
         t_first = xcd * tpx + (int)(blockIdx.x >> 3);
         t_end = min(n_tiles, (xcd + 1) * tpx);
@@ -603,7 +606,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd1_kernel(const FabindE
     const unsigned uld = (unsigned)p.ldab;
 
     int t_first, t_end, t_step;
-    if ((gridDim.x & 7) == 0) {
+    if (p.xcd_aware && (gridDim.x & 7) == 0) {
         const int tpx = (n_tiles + 7) / 8, xcd = blockIdx.x & 7;
         t_first = xcd * tpx + (int)(blockIdx.x >> 3);
         t_end = min(n_tiles, (xcd + 1) * tpx);
@@ -861,7 +864,10 @@ extern "C" int fabind_gcl_edge_fused_bwd_set_variant(int v) {
 }
 extern "C" int fabind_gcl_edge_fused_bwd_variant(void) { return g_fe_bwd_variant; }
 
-extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a, int H, int n_groups, hipStream_t stream) {
+extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a_in, int H, int n_groups, hipStream_t stream) {
+    FabindEdgeBwdArgs a_copy = *a_in;
+    a_copy.xcd_aware = g_fe_xcd_aware;           // set by the library (callers leave it 0)
+    const FabindEdgeBwdArgs* a = &a_copy;
     if (a->E <= 0 || n_groups <= 0) return 0;
     FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_gcl_edge_fused_bwd: H must be 64, 128, 256 or 512");
     FB_REQUIRE(a->ldab % 8 == 0, "fabind_gcl_edge_fused_bwd: ldab % 8");

@@ -189,6 +189,7 @@ typedef struct FabindEdgeBwdArgs {
     int ldab, lddagg, lddab, E;
     float p_drop;            /* dropout probability of the messages (egnn.py:82); 0 = eval */
     unsigned seed;           /* the seed the forward call used */
+    int xcd_aware;           /* filled in by the library (fabind_gcl_edge_fused_set_xcd_aware); callers pass 0 */
 } FabindEdgeBwdArgs;
 int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* args, int H, int n_groups, hipStream_t stream);
 /* Edges per tile of the backward kernel: 64 (one work-group per CU, default) or 32 (two per CU). */
@@ -200,6 +201,9 @@ int fabind_gcl_edge_fused_bwd_tile(void);
  * both variants evaluate the same arithmetic in the same order per element. */
 int fabind_gcl_edge_fused_bwd_set_variant(int v);
 int fabind_gcl_edge_fused_bwd_variant(void);
+/* development knob: 1 (default) = XCD-aware tile order in the fused edge kernels (XCD x owns the x-th eighth of the tiles, i.e.
+ * whole complexes); 0 = linear tile order (forward) / grid-stride walk (backward).  Results do not depend on it. */
+void fabind_gcl_edge_fused_set_xcd_aware(int on);
 
 /* Fused pair-embedding update of FABind+'s CrossAttentionModule (FABind_plus/fabind/models/cross_att.py:42-44 with
  * model_utils.py InteractionModule / MLPwithLastAct), bf16, inference (no adjoint: training runs the separate launches):
