@@ -8,7 +8,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfabind_hip.so")
+LIB_PATH = os.environ.get("FABIND_LIB") or os.path.join(_HERE, "libfabind_hip.so")      # FABIND_LIB: an A/B build (tools/probes)
 
 ABI_VERSION = 5          # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1

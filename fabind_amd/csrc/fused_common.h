@@ -4,6 +4,12 @@
 #include "common.h"
 
 #define FE_BM 64
+// wave priority around the MFMA clusters of the tile contractions (build with -DFE_NO_SETPRIO for the A/B library)
+#ifdef FE_NO_SETPRIO
+#define FE_PRIO(x) ((void)0)
+#else
+#define FE_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 
 __device__ __forceinline__ float fe_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
 __device__ __forceinline__ float fe_silu(float x) { return x * fe_sigmoid(x); }
@@ -57,12 +63,12 @@ __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* _
             const int r = i * 16 + fr;
             a[i] = *(const bf16x8_t*)&sX[r * H + (((ks * 4 + fq) ^ (r & 7)) * 8)];
         }
-        __builtin_amdgcn_s_setprio(1);      // co-resident work-groups sit in VALU epilogues: the matrix-core stream goes first
+        FE_PRIO(1);      // co-resident work-groups sit in VALU epilogues: the matrix-core stream goes first
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        FE_PRIO(0);
         if (ks + 2 < NKS) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) b0[j] = wp[((size_t)(ks + 2) * NG + j) * 64];
@@ -72,12 +78,12 @@ __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* _
             const int r = i * 16 + fr;
             a[i] = *(const bf16x8_t*)&sX[r * H + ((((ks + 1) * 4 + fq) ^ (r & 7)) * 8)];
         }
-        __builtin_amdgcn_s_setprio(1);
+        FE_PRIO(1);
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1[j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        FE_PRIO(0);
     }
 }
 
@@ -109,7 +115,7 @@ __device__ __forceinline__ void fe_zero(f32x4_t (&acc)[MI][4]) {
 // does not depend on which work-group finishes first (round 1 used atomicAdd for the boundary runs: a node with 1,500 edges
 // spans 24 tiles, and two identical forward passes differed by an ulp about once in ten runs, amplified to 1e-4 in h by
 // bf16 rounding downstream).  Returns sum_rows rh[row] * value (the d w_r partial of the backward) when WITH_RH.
-template <int H, bool WITH_RH>
+template <int H, bool WITH_RH, int BM_>
 __device__ __forceinline__ float fe_scan_rows(const bf16_t* sX, const int* sRow, const float* sRh, int ne, bool head_cont,
                                               bool tail_cont, float* out, unsigned ld, float* bnd_tile, int c) {
     float run = 0.f, pwr = 0.f;
@@ -120,7 +126,7 @@ __device__ __forceinline__ float fe_scan_rows(const bf16_t* sX, const int* sRow,
         float v[8], rhv[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int rw = rw0 + u;                       // < FE_BM: the tile height is a multiple of 8
+            const int rw = min(rw0 + u, BM_ - 1);         // the tile height BM_ is a multiple of 8
             rr[u] = sRow[rw];
             rhv[u] = WITH_RH ? sRh[rw] : 0.f;
             v[u] = bf16_to_f32(sX[rw * H + (((c >> 3) ^ (rw & 7)) * 8) + (c & 7)]);

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
     {
         const bool head_cont = e0 > 0 && row[e0 - 1] == sRow[0];
         const bool tail_cont = e0 + ne < E && row[e0 + ne] == sRow[ne - 1];
-        (void)fe_scan_rows<H, false>(sX, sRow, nullptr, ne, head_cont, tail_cont, agg, (unsigned)H, bnd + (size_t)tile * 2 * H, tid);
+        (void)fe_scan_rows<H, false, FE_BM>(sX, sRow, nullptr, ne, head_cont, tail_cont, agg, (unsigned)H, bnd + (size_t)tile * 2 * H, tid);
     }
 
     // ---- phase 3: s = w3 . silu(M Wc^T + bc)
@@ -503,37 +503,13 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
         fe_tile_store<H>(sX, (bf16_t*)p.dP1, e0, ne, tid);
         FE_TICK(1)
 
-        // ---- P6 (one column per thread): receiving-side segment sum of dP1 and the d w_r column sum;
-        //      LDS reads batched 8 rows at a time, the run logic consumes them from registers
+        // ---- P6 (one column per thread): receiving-side segment sum of dP1 and the d w_r column sum (deterministic:
+        //      complete runs are plain stores, runs that span tiles go through p.bnd and fe_boundary_fix_kernel)
         {
-            const int c = tid;
-            float run = 0.f;
-            int cur = sRow[0];
-            bool first = true;
-            for (int rw0 = 0; rw0 < ne; rw0 += 8) {
-                int rr[8];
-                float v[8], rhv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int rw = rw0 + u;                       // < BM: BM is a multiple of 8
-                    rr[u] = sRow[rw];
-                    rhv[u] = sRh[rw];
-                    v[u] = bf16_to_f32(sX[rw * H + (((c >> 3) ^ (rw & 7)) * 8) + (c & 7)]);
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (rw0 + u < ne) {
-                        if (rr[u] != cur) {
-                            const unsigned o = (unsigned)cur * (unsigned)p.lddab + c;
-                            if (first) atomicAdd(&p.dABrow[o], run); else p.dABrow[o] = run;
-                            run = 0.f; cur = rr[u]; first = false;
-                        }
-                        run += v[u];
-                        pwr += rhv[u] * v[u];
-                    }
-                }
-            }
-            if (ne > 0) atomicAdd(&p.dABrow[(unsigned)cur * (unsigned)p.lddab + c], run);
+            const bool head_cont = e0 > 0 && p.row[e0 - 1] == sRow[0];
+            const bool tail_cont = e0 + ne < p.E && p.row[e0 + ne] == sRow[ne - 1];
+            pwr += fe_scan_rows<H, true, BM>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dABrow, (unsigned)p.lddab,
+                                             p.bnd + (size_t)tile * 2 * H, tid);
         }
         __syncthreads();                                          // the next tile overwrites sX / sRow
         FE_TICK(9)
@@ -832,7 +808,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd1_kernel(const FabindE
         {
             const bool head_cont = e0 > 0 && p.row[e0 - 1] == sRow[0];
             const bool tail_cont = e0 + ne < p.E && p.row[e0 + ne] == sRow[ne - 1];
-            sPart[3 * H + tid] += fe_scan_rows<H, true>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dABrow, (unsigned)p.lddab,
+            sPart[3 * H + tid] += fe_scan_rows<H, true, 64>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dABrow, (unsigned)p.lddab,
                                                          p.bnd + (size_t)tile * 2 * H, tid);
         }
         __syncthreads();                                          // the next tile overwrites sX / sRow
@@ -889,6 +865,7 @@ extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a_in, int H, i
         FB_CHECK_LAUNCH();
         return 0;
     }
+    FB_REQUIRE(a->bnd != nullptr, "fabind_gcl_edge_fused_bwd: bnd (ceil(E / tile) x 2 x H floats of scratch) is required");
     const int BMr = g_fe_bwd_bm;
     const size_t lds = (size_t)2 * BMr * H * 2 + BMr * (sizeof(int) + 2 * sizeof(float));
 #define FE_LAUNCH2(HH, BB)                                                                                         \
@@ -902,6 +879,12 @@ extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a_in, int H, i
         if (BMr == 32) FE_LAUNCH2(HH, 32); else FE_LAUNCH2(HH, 64);                                                \
     } while (0)
     if (H == 512) FE_LAUNCH(512); else if (H == 256) FE_LAUNCH(256); else if (H == 128) FE_LAUNCH(128); else FE_LAUNCH(64);
+    if (BMr == 32)
+        hipLaunchKernelGGL((fe_boundary_fix_kernel<32>), dim3((a->E + 31) / 32), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
+                           a->bnd, a->dABrow, (unsigned)a->lddab);
+    else
+        hipLaunchKernelGGL((fe_boundary_fix_kernel<64>), dim3((a->E + 63) / 64), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
+                           a->bnd, a->dABrow, (unsigned)a->lddab);
 #undef FE_LAUNCH
 #undef FE_LAUNCH2
 #undef FE_COFF

@@ -378,7 +378,7 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     if ng >= 8:
         ng -= ng % 8                # a multiple of 8 selects the XCD-aware walk (csrc/fused_edge.hip)
     d2scratch = torch.empty((ng, bm * H), dtype=torch.bfloat16, device=dev) if variant == 1 else None
-    bnd = torch.empty(((E + 63) // 64 * 2 + 2, H), dtype=torch.float32, device=dev) if variant == 1 else None
+    bnd = torch.empty(((E + bm - 1) // bm * 2 + 2, H), dtype=torch.float32, device=dev)       # boundary runs (deterministic sums)
     buf = torch.empty((5, max(E, 1), H), dtype=torch.bfloat16, device=dev)
     S1, Mm, dT, dP2, dP1 = buf[0], buf[1], buf[2], buf[3], buf[4]
     dAB = torch.zeros((N, 2 * H), dtype=torch.float32, device=dev)

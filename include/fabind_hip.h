@@ -184,7 +184,7 @@ typedef struct FabindEdgeBwdArgs {
     void* S1; void* Mm; void* dT; void* dP2; void* dP1;
     float* drh; float* dABrow; float* part;
     void* dbg;               /* NULL, or 12 x int64: cycle counts per phase of work-group 0 (profiling aid; two-tile variant) */
-    float* bnd;              /* single-tile variant: ceil(E/64) x 2 x H floats (boundary runs of dABrow, added in tile order) */
+    float* bnd;              /* ceil(E / tile) x 2 x H floats of scratch (boundary runs of dABrow, added in tile order: deterministic) */
     void* d2scratch;         /* single-tile variant: n_groups x 64 x H x 2 bytes of scratch (silu'(pre2) of each work-group's tile) */
     int ldab, lddagg, lddab, E;
     float p_drop;            /* dropout probability of the messages (egnn.py:82); 0 = eval */
