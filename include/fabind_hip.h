@@ -195,10 +195,10 @@ int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* args, int H, int n_groups
 /* Edges per tile of the backward kernel: 64 (one work-group per CU, default) or 32 (two per CU). */
 int fabind_gcl_edge_fused_bwd_set_tile(int bm);
 int fabind_gcl_edge_fused_bwd_tile(void);
-/* Kernel variant: 1 (default) = ONE [64][H] LDS tile rewritten in place by every stage, two work-groups per CU so that one
- * work-group's elementwise epilogue overlaps the other's contraction (needs FabindEdgeBwdArgs.d2scratch; n_groups up to
- * 2 x CUs); 0 = the round-1 kernel with two LDS tiles and one work-group per CU.  Results agree to bf16 rounding of nothing:
- * both variants evaluate the same arithmetic in the same order per element. */
+/* Kernel variant: 0 (default) = two [64][H] LDS tiles, one work-group per CU; 1 = ONE LDS tile rewritten in place by every stage,
+ * two work-groups per CU so that one work-group's elementwise epilogue can overlap the other's contraction (needs
+ * FabindEdgeBwdArgs.d2scratch; n_groups up to 2 x CUs) -- measured no faster, kept as a knob.  Both
+ * evaluate the same arithmetic in the same order per element (outputs equal to 1e-7). */
 int fabind_gcl_edge_fused_bwd_set_variant(int v);
 int fabind_gcl_edge_fused_bwd_variant(void);
 /* development knob: 1 (default) = XCD-aware tile order in the fused edge kernels (XCD x owns the x-th eighth of the tiles, i.e.

@@ -91,7 +91,7 @@ def test_fused_edge_backward_matches_autograd(H, bm, p_drop):
     """csrc/fused_edge.hip backward (recompute + 4 chained contractions) vs torch autograd of the same bf16-rounded
     forward on the CPU: every gradient the kernel produces, including the partial column sums and both halves of dAB.
     bm = 32 / 64: the two-LDS-tile kernel of round 1 (variant 0); bm = 1: the single in-place tile kernel, two work-groups
-    per CU (variant 1, the default)."""
+    per CU (variant 1, a knob)."""
     from fabind_amd import kernels as K, _lib
     dev = _dev()
     _lib.load().fabind_gcl_edge_fused_bwd_set_variant(1 if bm == 1 else 0)
@@ -138,7 +138,7 @@ def test_fused_edge_backward_matches_autograd(H, bm, p_drop):
     assert (agg_k.cpu() - agg.detach()).abs().max() <= 2e-2 * max(1.0, float(agg.abs().max()))
     assert (s_k[:, 0].cpu() - sv.detach()).abs().max() <= 2e-2 * max(1.0, float(sv.abs().max()))
     _lib.load().fabind_gcl_edge_fused_bwd_set_tile(64)
-    _lib.load().fabind_gcl_edge_fused_bwd_set_variant(1)
+    _lib.load().fabind_gcl_edge_fused_bwd_set_variant(0)
     names = ("dAB", "drh", "dw_r", "dW2", "db2", "dWc", "dbc", "dw3")
     refs = (ABf.grad, rhf.grad, wrf.grad, W2f.grad, b2f.grad, Wcf.grad, bcf.grad, w3f.grad)
     for name, got, ref in zip(names, out, refs):

@@ -51,5 +51,6 @@ for ng in (128, 256, 384, 512):                       # does a second work-group
             print("variant 1 with %d persistent work-groups: %.3f ms" % (ng, sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs)), flush=True)
     K.PROFILE = None
 K.EDGE_BWD_GROUPS = 0
+lib.fabind_gcl_edge_fused_bwd_set_variant(0)
 for n, a, b in zip(("dAB", "drh", "dw_r", "dW2", "db2", "dWc", "dbc", "dw3"), outs[0], outs[1]):
     print("variant 1 vs 0  %-5s max rel diff %.2e" % (n, float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))))
