@@ -353,6 +353,14 @@ def main():
                                                                    a.n_iter, a.mode),
                        "global_batch": a.batch * world, "n_iter": a.n_iter, "pass": a.mode},
         }
+        if prof and os.environ.get("FABIND_BENCH_DUMP_PROFILE"):
+            # development aid: live HIP-event time of every profiled launch group (GEMM shapes, fused kernels) in the timed region
+            rows = sorted(((sum(s_.elapsed_time(e_) for s_, e_, _ in evs), len(evs), evs[0][2], label) for label, evs in prof.items()),
+                          reverse=True)
+            with open(os.environ["FABIND_BENCH_DUMP_PROFILE"], "w") as f:
+                for ms, cnt, fl, label in rows:
+                    f.write("%9.3f ms/step  %4d launches/step  %8.1f us avg  %7.1f TFLOP/s  %s\n" % (
+                        ms / a.steps, cnt // a.steps, 1e3 * ms / cnt, fl / (ms / cnt * 1e-3) / 1e12 if ms > 0 else 0.0, label))
         if prof:
             out["roofline"] = roofline_of(prof, dt, a.precision)
             # HBM traffic of the dominant kernel: NOT measured in this run -- the per-launch figure of the committed PMC passes
