@@ -93,6 +93,8 @@ class Layout:
             t = flat[pos:pos + len(v)]
             pos += len(v)
             setattr(self, name, t.view(-1, 8) if name.startswith(("desc", "pb_")) else t)
+        for name in ("desc_p", "desc_c", "desc_pf", "desc_cf"):
+            getattr(self, name)._fab_covers_all = True      # these block descriptors tile the whole pair list (ops._CrossAttn)
         self.c_index64, self.p_index64 = self.c_index.long(), self.p_index.long()
         self.inv_perm = self.inv_perm.long()
         self.pb_max_n = int((C * NO).max())

@@ -755,6 +755,7 @@ class _CrossAttn(torch.autograd.Function):
                                   max_nq, scale, out, want_lse=True, max_nk=max_nk)
         ctx.args = (lin_col, gate_col, desc, B, max_nq, max_nk, scale)
         ctx.mfma = K.cross_attn_use_mfma()        # the backward recomputes the probabilities the way the forward computed them
+        ctx.covers_all = bool(getattr(desc, "_fab_covers_all", False))      # set by engine.Layout: the blocks tile the pair list
         ctx.save_for_backward(qg, kv, bias, out, lse)
         return out
 
@@ -763,7 +764,9 @@ class _CrossAttn(torch.autograd.Function):
         qg, kv, bias, out, lse = ctx.saved_tensors
         lin_col, gate_col, desc, B, max_nq, max_nk, scale = ctx.args
         dout = dout.contiguous()
-        dqg, dkv, dbias = torch.zeros_like(qg), torch.zeros_like(kv), torch.zeros_like(bias)   # uncovered rows / columns: 0
+        dqg, dkv = torch.zeros_like(qg), torch.zeros_like(kv)                                  # uncovered rows: 0
+        # pass Q writes both 16-B segments of every pair the descriptors cover; with an 8-column bias tensor that is all of it
+        dbias = torch.empty_like(bias) if (bias.shape[1] == 8 and lin_col == 0 and gate_col == 4 and ctx.covers_all) else torch.zeros_like(bias)
         dO = torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
         Dv = torch.empty((qg.shape[0], 4), dtype=torch.float32, device=qg.device)
         n_scr = int(load().fabind_cross_attn_bwd_scratch(B, max_nq, max_nk))     # per-split partials of the short side (or 0)
@@ -871,7 +874,7 @@ class _InterAttn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         dh_out = dh_out.contiguous() if dh_out is not None else torch.zeros((N, H), **f32)
         dx_out = dx_out.contiguous() if dx_out is not None else torch.zeros((N, 3), **f32)
-        dqkv = torch.zeros_like(qkv)
+        dqkv = torch.empty_like(qkv)          # every row: d q by pass a, d k | d v by pass b (zeros for nodes without inter edges)
         dcv = torch.empty_like(cv)
         dd, drh = torch.zeros((max(E, 1), 3), **f32), torch.zeros(max(E, 1), **f32)
         n_red = E // 2
