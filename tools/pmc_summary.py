@@ -11,7 +11,7 @@ from collections import defaultdict
 KEYS = {
     "gcl_edge_fused_bwd_kernel": "gcl_edge_fused_bwd_kernel<512>",
     "gcl_edge_fused_kernel": "gcl_edge_fused_kernel<512>",
-    "gemm_tn_bf16_kernel": "fabind_gemm_tn M=512 N=512 E=1556480",
+    "gemm_tn_bf16_kernel": "fabind_gemm_tn M=512 N=512 E=15",
     "segment_sum_kernel": "segment_sum",
     "gcl_pre8_kernel": "gcl_pre",
 }
