@@ -428,7 +428,10 @@ def gemm_tn(Y, X, splits=None):
         zp = _ZERO_PAGE[dev] = torch.zeros(256, dtype=torch.bfloat16, device=dev)
     if splits is None:
         tiles = ((M + 255) // 256) * ((N + 127) // 128)
-        splits = max(1, min(256, (E // 2048), max(1, 1024 // tiles)))
+        # split the E (contraction) range over work-groups: ~2048 rows each on long operands; SHORT operands (ligand rows, small
+        # batches: E of a few thousand) still get up to 16 splits of >= 256 rows -- with E // 2048 a 512 x 512 output ran on 8
+        # work-groups looping over all of E (86 us at 8 TFLOP/s for E = 2,624: profiles/r02_launch_groups.txt)
+        splits = max(1, min(256, max(E // 2048, min(E // 256, 16)), max(1, 1024 // tiles)))
     part = torch.empty((splits, M, N), dtype=torch.float32, device=dev)
     _profiled("fabind_gemm_tn M=%d N=%d E=%d" % (M, N, E), 2.0 * M * N * E,
               lambda: check(_lib.load().fabind_gemm_tn(ptr(Y), _ld(Y), ptr(X), _ld(X), ptr(part), M, N, E, splits, ptr(zp),
