@@ -83,27 +83,25 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
     fe_gemm_rolled<H, 4>(sX, W2p, wave, lane, acc);
     __syncthreads();                                // every wave has finished reading S1
     const int fr = lane & 15, cq = lane >> 4;
-    // rolled over the wave's four 16-column blocks (slot 0 processed, arrays rotate): bounds the live ranges
-#define FE_ROT4(a_) { auto t_ = a_[0]; a_[0] = a_[1]; a_[1] = a_[2]; a_[2] = a_[3]; a_[3] = t_; }
+    // The wave's four 16-column blocks are processed one after the other: the j loop is unrolled (compile-time accumulator
+    // indices, no register rotation) and a scheduling barrier after each block keeps the scheduler from interleaving the exp / rcp
+    // chains of all 64 elements of a lane, which spills by the hundred (round 1 rolled the loop and rotated the accumulator
+    // arrays through slot 0 instead: 4-6 v_mov per element, a fifth of the kernel's VALU instructions).
     {
-        float bj[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bj[j] = b2[wave * 64 + j * 16 + fr];
-#pragma unroll 1
         for (int j = 0; j < 4; ++j) {
             const int colj = wave * 64 + j * 16 + fr;
+            const float bj = b2[colj];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int rw = i * 16 + cq * 4 + r;
-                    float m = fe_silu(acc[i][0][r] + bj[0]);
+                    float m = fe_silu(acc[i][j][r] + bj);
                     if (thr16) m *= fe_keep(seed, (uint32_t)(e0 + rw), (uint32_t)colj, H, thr16, dscale);
                     sX[rw * H + (((colj >> 3) ^ (rw & 7)) * 8) + (colj & 7)] = f32_to_bf16(m);
                 }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) FE_ROT4(acc[i])
-            FE_ROT4(bj)
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
@@ -122,22 +120,19 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     fe_gemm_rolled<H, 4>(sX, Wcp, wave, lane, acc);
     {
-        float dsum[4][4], bj[4], wj[4];
+        float dsum[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) dsum[i][r] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { bj[j] = bc[wave * 64 + j * 16 + fr]; wj[j] = w3[wave * 64 + j * 16 + fr]; }
-#pragma unroll 1
         for (int j = 0; j < 4; ++j) {
+            const float bj = bc[wave * 64 + j * 16 + fr], wj = w3[wave * 64 + j * 16 + fr];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) dsum[i][r] += fe_silu(acc[i][0][r] + bj[0]) * wj[0];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) FE_ROT4(acc[i])
-            FE_ROT4(bj) FE_ROT4(wj)
+                for (int r = 0; r < 4; ++r) dsum[i][r] += fe_silu(acc[i][j][r] + bj) * wj;
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -148,7 +143,6 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
                 if (fr == 0) sDot[wave * FE_BM + i * 16 + cq * 4 + r] = t;
             }
     }
-#undef FE_ROT4
     __syncthreads();
     if (tid < ne) {
         float s = 0.f;
@@ -202,7 +196,9 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
 // trips of the unfused backward -- plus d rhohat, the receiving-side segment sum of dP1 (run-length scan,
 // boundary runs finish with atomics) and per-work-group partial column sums for d b2, d bc, d w3, d w_r.
 // Persistent work-groups (one per CU: 2 x 64 KiB LDS tiles at H = 512) walk the tiles grid-stride.
-template <int H, int BM>
+// DBG: per-phase cycle counters of work-group 0 (tools/edge_bwd_phases.py).  A compile-time switch: as a run-time test of p.dbg the
+// thirteen 64-bit counters stayed live across the whole tile loop of a kernel that sits at its register limit.
+template <int H, int BM, bool DBG>
 __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kernel(const FabindEdgeBwdArgs p) {
     constexpr int TPE = H / BM;                                   // threads per edge in the gather layout
     constexpr int CPT = BM / 8;                                   // 16-byte chunks per thread there
@@ -233,7 +229,7 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
     long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};       // optional per-phase cycle counts (p.dbg != NULL)
     long long tlast = 0;
 #define FE_TICK(k_)                                                   \
-    if (p.dbg) {                                                      \
+    if constexpr (DBG) {                                              \
         const long long now_ = __builtin_readcyclecounter();         \
         tph[k_] += now_ - tlast;                                      \
         tlast = now_;                                                 \
@@ -290,7 +286,7 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
         const bf16_t* Wcp = (const bf16_t*)p.Wcp + lz;
         const bf16_t* W2Tp = (const bf16_t*)p.W2Tp + lz;
         const bf16_t* WcTp = (const bf16_t*)p.WcTp + lz;
-        if (p.dbg) tlast = __builtin_readcyclecounter();
+        if constexpr (DBG) tlast = __builtin_readcyclecounter();
         // ---- P0: gather + first Linear + SiLU -> sX
         // every global access below is (uniform base in SGPRs) + (32-bit lane offset): 64-bit per-lane pointers
         // are loop-invariant per access site, get hoisted out of the tile loop and spill by the hundred
@@ -514,8 +510,10 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
         __syncthreads();                                          // the next tile overwrites sX / sRow
         FE_TICK(9)
     }
-    if (p.dbg && blockIdx.x == 0 && tid == 0)
-        for (int k = 0; k < 12; ++k) ((long long*)p.dbg)[k] = tph[k];
+    if constexpr (DBG) {
+        if (p.dbg && blockIdx.x == 0 && tid == 0)
+            for (int k = 0; k < 12; ++k) ((long long*)p.dbg)[k] = tph[k];
+    }
 
     // per-work-group partial column sums: part[blockIdx.x][{b2, bc, w3, w_r}][H]
     float* part = p.part + (size_t)blockIdx.x * 4 * H;
@@ -872,13 +870,23 @@ extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a_in, int H, i
 #define FE_LAUNCH2(HH, BB)                                                                                         \
     do {                                                                                                           \
         static bool set_ = false;                                                                                  \
-        if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_bwd_kernel<HH, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
-        hipLaunchKernelGGL((gcl_edge_fused_bwd_kernel<HH, BB>), dim3(n_groups), dim3(HH), lds, stream, *a);         \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_bwd_kernel<HH, BB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        hipLaunchKernelGGL((gcl_edge_fused_bwd_kernel<HH, BB, false>), dim3(n_groups), dim3(HH), lds, stream, *a);  \
     } while (0)
 #define FE_LAUNCH(HH)                                                                                              \
     do {                                                                                                           \
         if (BMr == 32) FE_LAUNCH2(HH, 32); else FE_LAUNCH2(HH, 64);                                                \
     } while (0)
+    if (a->dbg != nullptr && H == 512) {          // the instrumented build exists for the bench shape only
+        static bool setd_ = false;
+        if (BMr == 32) {
+            if (!setd_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_bwd_kernel<512, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
+            hipLaunchKernelGGL((gcl_edge_fused_bwd_kernel<512, 32, true>), dim3(n_groups), dim3(512), lds, stream, *a);
+        } else {
+            if (!setd_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_bwd_kernel<512, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
+            hipLaunchKernelGGL((gcl_edge_fused_bwd_kernel<512, 64, true>), dim3(n_groups), dim3(512), lds, stream, *a);
+        }
+    } else
     if (H == 512) FE_LAUNCH(512); else if (H == 256) FE_LAUNCH(256); else if (H == 128) FE_LAUNCH(128); else FE_LAUNCH(64);
     if (BMr == 32)
         hipLaunchKernelGGL((fe_boundary_fix_kernel<32>), dim3((a->E + 31) / 32), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
