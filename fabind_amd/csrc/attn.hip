@@ -236,22 +236,39 @@ __global__ __launch_bounds__(256) void inter_attn_fwd_kernel(
     }
     qw = wave_sum(qw);
     float m = -INFINITY, l = 0.f, sar = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-    for (int e = e0; e < e1; ++e) {
+    // The edge loop is latency-bound (three gathered 2 KB rows per edge, then two wave reductions and two exponentials that depend
+    // on them): the rows of edge e + 1 are requested before edge e is reduced (software prefetch, one edge deep).
+    float4 nk[NS], nv[NS], nc[NS];
+    float nrh = 0.f;
+    auto fetch = [&](int e) {
         const int cn = col[e];
-        const float rh = rhohat[e];
+        nrh = rhohat[e];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = s * 256 + lane * 4;
+            nk[s] = z4; nv[s] = z4; nc[s] = z4;
+            if (c < H) {
+                nk[s] = *(const float4*)(qkv + (size_t)cn * ldqkv + H + c);
+                nv[s] = *(const float4*)(qkv + (size_t)cn * ldqkv + 2 * H + c);
+                nc[s] = *(const float4*)(cv + (size_t)cn * ldcv + c);
+            }
+        }
+    };
+    if (e0 < e1) fetch(e0);
+    for (int e = e0; e < e1; ++e) {
+        const float rh = nrh;
         float lp = 0.f, cp = 0.f;
-        float4 vv[NS];
+        float4 vv[NS], kk[NS], cc[NS];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { kk[s] = nk[s]; vv[s] = nv[s]; cc[s] = nc[s]; }
+        if (e + 1 < e1) fetch(e + 1);
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             int c = s * 256 + lane * 4;
-            vv[s] = z4;
             if (c < H) {
-                float4 kk = *(const float4*)(qkv + (size_t)cn * ldqkv + H + c);
-                vv[s] = *(const float4*)(qkv + (size_t)cn * ldqkv + 2 * H + c);
-                float4 cc = *(const float4*)(cv + (size_t)cn * ldcv + c);
-                lp += qv[s].x * kk.x + qv[s].y * kk.y + qv[s].z * kk.z + qv[s].w * kk.w;
-                cp += w3v[s].x * silu_f(cc.x + rh * wc[s].x) + w3v[s].y * silu_f(cc.y + rh * wc[s].y) +
-                      w3v[s].z * silu_f(cc.z + rh * wc[s].z) + w3v[s].w * silu_f(cc.w + rh * wc[s].w);
+                lp += qv[s].x * kk[s].x + qv[s].y * kk[s].y + qv[s].z * kk[s].z + qv[s].w * kk[s].w;
+                cp += w3v[s].x * silu_f(cc[s].x + rh * wc[s].x) + w3v[s].y * silu_f(cc[s].y + rh * wc[s].y) +
+                      w3v[s].z * silu_f(cc[s].z + rh * wc[s].z) + w3v[s].w * silu_f(cc[s].w + rh * wc[s].w);
             }
         }
         lp = wave_sum(lp);

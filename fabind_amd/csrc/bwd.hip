@@ -822,7 +822,14 @@ __global__ __launch_bounds__(256) void inter_attn_bwd_a_kernel(
     }
     for (int r = blockIdx.x * 4 + wv; r < n_rows; r += gridDim.x * 4) {
         const int e0 = rowptr[r], e1 = rowptr[r + 1];
-        if (e1 == e0) continue;
+        if (e1 == e0) {                                  // no inter edges: d q = 0 (the caller does not pre-zero dqkv)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int c = s * 256 + lane * 4;
+                if (c < H) *(float4*)(dqkv + (size_t)r * ldqkv + c) = z4;
+            }
+            continue;
+        }
         float4 qv[NS], gh[NS], dq[NS];
         float qw = 0.f, gwv = 0.f;
 #pragma unroll
@@ -849,18 +856,28 @@ __global__ __launch_bounds__(256) void inter_attn_bwd_a_kernel(
         const float gz = fabsf(tz) <= clampv ? dx_out[(size_t)r * 3 + 2] : 0.f;
         // pass 1: dalpha_e, stored in dlogit[]; S = sum alpha dalpha
         float S = 0.f;
-        for (int e = e0; e < e1; ++e) {
+        // both edge loops are latency-bound on the gathered rows: the rows of edge e + 1 are requested before edge e is reduced
+        float4 pa[NS], pb[NS];
+        auto fetch_v = [&](int e) {
             const int cn = col[e];
-            const float rh = rhohat[e];
-            float hp = 0.f;
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int c = s * 256 + lane * 4;
-                if (c < H) {
-                    const float4 vv = *(const float4*)(qkv + (size_t)cn * ldqkv + 2 * H + c);
-                    hp += gh[s].x * vv.x + gh[s].y * vv.y + gh[s].z * vv.z + gh[s].w * vv.w;
-                }
+                pa[s] = z4;
+                if (c < H) pa[s] = *(const float4*)(qkv + (size_t)cn * ldqkv + 2 * H + c);
             }
+        };
+        fetch_v(e0);
+        for (int e = e0; e < e1; ++e) {
+            const float rh = rhohat[e];
+            float hp = 0.f;
+            float4 vv[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) vv[s] = pa[s];
+            if (e + 1 < e1) fetch_v(e + 1);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                hp += gh[s].x * vv[s].x + gh[s].y * vv[s].y + gh[s].z * vv[s].z + gh[s].w * vv[s].w;
             hp = wave_sum(hp) + rh * gwv;
             const float gd = gx * d[(size_t)e * 3] + gy * d[(size_t)e * 3 + 1] + gz * d[(size_t)e * 3 + 2];
             const float da = hp + cvs[e] * gd;
@@ -871,9 +888,25 @@ __global__ __launch_bounds__(256) void inter_attn_bwd_a_kernel(
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // pass 2
         float s_lrh = 0.f, s_arh = 0.f;
-        for (int e = e0; e < e1; ++e) {
+        auto fetch_kc = [&](int e) {
             const int cn = col[e];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int c = s * 256 + lane * 4;
+                pa[s] = z4; pb[s] = z4;
+                if (c < H) {
+                    pa[s] = *(const float4*)(qkv + (size_t)cn * ldqkv + H + c);
+                    pb[s] = *(const float4*)(cv + (size_t)cn * ldcv + c);
+                }
+            }
+        };
+        fetch_kc(e0);
+        for (int e = e0; e < e1; ++e) {
             const float rh = rhohat[e], al = alpha[e];
+            float4 kks[NS], ccs[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { kks[s] = pa[s]; ccs[s] = pb[s]; }
+            if (e + 1 < e1) fetch_kc(e + 1);
             const float dl = al * (dlogit[e] - S);
             const float gd = gx * d[(size_t)e * 3] + gy * d[(size_t)e * 3 + 1] + gz * d[(size_t)e * 3 + 2];
             const float dc = al * gd;
@@ -882,8 +915,7 @@ __global__ __launch_bounds__(256) void inter_attn_bwd_a_kernel(
             for (int s = 0; s < NS; ++s) {
                 const int c = s * 256 + lane * 4;
                 if (c < H) {
-                    const float4 kk = *(const float4*)(qkv + (size_t)cn * ldqkv + H + c);
-                    const float4 cc = *(const float4*)(cv + (size_t)cn * ldcv + c);
+                    const float4 kk = kks[s], cc = ccs[s];
                     dq[s].x += dl * (kk.x + rh * wk[s].x); dq[s].y += dl * (kk.y + rh * wk[s].y);
                     dq[s].z += dl * (kk.z + rh * wk[s].z); dq[s].w += dl * (kk.w + rh * wk[s].w);
                     const float ux = cc.x + rh * wc[s].x, uy = cc.y + rh * wc[s].y, uz = cc.z + rh * wc[s].z, uw = cc.w + rh * wc[s].w;
@@ -957,7 +989,8 @@ __global__ __launch_bounds__(256) void inter_attn_bwd_b_kernel(
             wc[s] = *(const float4*)(wcr + c); w3v[s] = *(const float4*)(w3 + c);
         }
     }
-    for (int e = e0; e < e1; ++e) {
+#pragma unroll 2
+    for (int e = e0; e < e1; ++e) {                    // independent gathers: two edges in flight
         const int m = col[e], me = mirror[e];          // edge me = (m <- n)
         const float dl = dlogit[me], al = alpha[me], dcm = dcp[me], rh = rhohat[me];
 #pragma unroll

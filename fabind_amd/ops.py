@@ -874,7 +874,7 @@ class _InterAttn(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         dh_out = dh_out.contiguous() if dh_out is not None else torch.zeros((N, H), **f32)
         dx_out = dx_out.contiguous() if dx_out is not None else torch.zeros((N, 3), **f32)
-        dqkv = torch.zeros_like(qkv)          # pass a writes d q only for nodes that have inter edges
+        dqkv = torch.empty_like(qkv)          # every row is written: d q by pass a (zeros for nodes without inter edges), d k | d v by pass b
         dcv = torch.empty_like(cv)
         dd, drh = torch.zeros((max(E, 1), 3), **f32), torch.zeros(max(E, 1), **f32)
         n_red = E // 2
