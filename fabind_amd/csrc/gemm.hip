@@ -124,6 +124,7 @@ __device__ __forceinline__ void gemm_epilogue(const FabindGemmArgs& p, f32x4_t (
                         size_t ci = (size_t)c_off + (size_t)row * ldc + col;
                         if (p.accumulate) v += ld_any(p.C, p.c_dtype, ci);
                         st_any(p.C, p.c_dtype, ci, p.store_preact ? vpre : v);
+                        if (p.C16) ((bf16_t*)p.C16)[(size_t)row * p.ldc16 + col] = f32_to_bf16(v);
                     }
                 }
                 const float t = v * dv;
@@ -340,6 +341,7 @@ __device__ __forceinline__ void gemm_epilogue_f32(const FabindGemmArgs& p, f32x4
                         float v = acc[i][j][r] + bv;
                         if (HAS_R) v += R[(size_t)row * p.ldr + col];
                         C[(size_t)row * ldc + col] = v;
+                        if (p.C16) ((bf16_t*)p.C16)[(size_t)row * p.ldc16 + col] = f32_to_bf16(v);
                     }
                 }
         }
@@ -374,6 +376,7 @@ __device__ __forceinline__ void gemm_epilogue_f32(const FabindGemmArgs& p, f32x4
                     v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                 }
                 *(float4*)&C[(size_t)row * ldc + col] = v;
+                if (p.C16) *(uint2*)((bf16_t*)p.C16 + (size_t)row * p.ldc16 + col) = make_uint2(pack2_bf16(v.x, v.y), pack2_bf16(v.z, v.w));
             }
         }
     }
@@ -1105,6 +1108,9 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
                    "K % 64 == 0, no residual / second tile / split-K)");
         p.epi_fast += 7;        /* 5 -> 12, 6 -> 13: the FOLD instantiations */
     }
+    FB_REQUIRE(p.C16 == nullptr || (p.C != nullptr && p.c_dtype == FB_DT_F32 && !p.groups && p.k_splits <= 1 && !p.store_preact &&
+                                    p.ldc16 % 4 == 0 && ((uintptr_t)p.C16 & 7) == 0),
+               "fabind_gemm: C16 (bf16 copy of C) needs a plain fp32 C (no groups / split-K / stored pre-activation), ldc16 % 4 == 0");
     int maxM = p.groups ? p.max_m : p.M, maxN = p.groups ? p.max_n : p.N;
     if (maxM <= 0 || maxN <= 0) return 0;
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM - 1) / BM, p.groups ? p.n_groups : (p.k_splits > 1 ? p.k_splits : 1));

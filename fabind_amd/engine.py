@@ -319,7 +319,8 @@ def _fast(*ts):
 
 
 def _b16(t):
-    return t.to(torch.bfloat16)
+    """bf16 operand copy of an activation (remembered on the tensor / emitted by its producer's epilogue: ops._mm_in)."""
+    return ops._mm_in(t) if t.dtype == torch.float32 else t.to(torch.bfloat16)
 
 
 def _drop(t, pr):
@@ -351,11 +352,11 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
         x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
         if pdrop == 0.0 and not fast:
             # node MLP + residual as one autograd node (activation adjoint and residual gradient inside GEMM epilogues)
-            return ops.mlp2(hin, p["Wn1"], p["bn1"], K.ACT_SILU, p["Wn2"], p["bn2"], residual=h, x2=agg), x_new
+            return ops.mlp2(hin, p["Wn1"], p["bn1"], K.ACT_SILU, p["Wn2"], p["bn2"], residual=h, x2=agg, want16=True), x_new
         t = ops.linear(hin, p["Wn1"], p["bn1"], x2=agg, act_epi=K.ACT_SILU, out_dtype=ad)
         if pdrop > 0.0:
             return h + _drop(ops.linear(t, p["Wn2"], p["bn2"]), pdrop), x_new
-        return ops.linear(t, p["Wn2"], p["bn2"], residual=h), x_new
+        return ops.linear(t, p["Wn2"], p["bn2"], residual=h, want16=True), x_new
     AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=ad)                           # [N,2H] node-level
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay, g.ctx_by_col)
     S1 = ops.gcl_pre(AB, H, g, rhohat, p["w_r"], act=K.ACT_SILU)                        # [E,H] silu(first edge Linear)
@@ -388,7 +389,7 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     kv = ops.linear(c16(hc), p["Wkv_p"])                                                # [sum C, 256]
     og = ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_pf, lay.B, lay.max_P, lay.max_C, scale)
     hp = (h + _drop(ops.linear(c16(og), p["Wo_p"], p["bo_p"]), pdrop)) if pdrop > 0.0 else \
-        ops.linear(c16(og), p["Wo_p"], p["bo_p"], residual=h)
+        ops.linear(c16(og), p["Wo_p"], p["bo_p"], residual=h, want16=True)
     if pdrop == 0.0:
         hp = ops.shared_grad(hp)    # consumers: k / v projection of the ligand-query block, transition, its residual
     hp16 = c16(hp)
@@ -399,11 +400,11 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
         ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc)
     if fast:
         t = ops.linear(hp16, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU, out_dtype=od)
-        hp = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp)
+        hp = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True)
         t = ops.linear(c16(hc), p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU, out_dtype=od)
         hc = ops.linear(t, p["Wt2_c"], p["bt2_c"], residual=hc)
     else:   # Transition + residual (cross_att.py:48-49) as one autograd node each
-        hp = ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp)
+        hp = ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True)
         hc = ops.mlp2(hc, p["Wt1_c"], p["bt1_c"], K.ACT_RELU, p["Wt2_c"], p["bt2_c"], residual=hc)
     return ops.put_rows(hp, hc, lay.c_index64)
 
@@ -433,7 +434,7 @@ def egnn_forward(P, h, x, lay, g, las, x_las, a0b0, pairbias, scale, step, drop=
     """MCAttEGNN.forward (egnn.py:392-466).  drop = dict of dropout probabilities (train mode) or None (eval)."""
     clampv = 10.0 / scale
     dp = drop or {}
-    h = _drop(ops.linear(h, P["W_in"], P["b_in"]), dp.get("gnn", 0.0))
+    h = _drop(ops.linear(h, P["W_in"], P["b_in"], want16=True), dp.get("gnn", 0.0))
     cap = DEBUG_CAPTURE
     for i in range(P["L"]):
         h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv, dp.get("gcl", 0.0))

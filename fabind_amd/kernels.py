@@ -35,8 +35,9 @@ def _ld(t):
 def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=None, r_index=None,
          out=None, out_dtype=torch.float32, want_out=True, dotvec=None, aux=None, dact=ACT_NONE, alpha=1.0,
          accumulate=False, groups=None, n_groups=0, max_m=0, max_n=0, M=None, N=None, ldc=None, k_splits=1,
-         out2=None, groups_ext=False, p_drop=0.0, seed=0):
-    """C = epi(pro([A|A2]) @ W^T); see FabindGemmArgs.  Returns (C or None, dot_partials or None).
+         out2=None, groups_ext=False, p_drop=0.0, seed=0, out16=None):
+    """C = epi(pro([A|A2]) @ W^T); see FabindGemmArgs.  Returns (C or None, dot_partials or None).  out16: bf16 tensor that
+    receives a copy of an fp32 C (plain bias / residual epilogues only).
 
     `groups` (int32 [G,8] device tensor) selects the ragged-batched mode; then `out` must be given."""
     lib = _lib.load()
@@ -59,6 +60,8 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     a.bias, a.R, a.r_index = ptr(bias), ptr(residual), ptr(r_index)
     a.dotvec, a.dot_out, a.aux, a.groups = ptr(dotvec), ptr(dot_out), ptr(aux), ptr(groups)
     a.C2 = ptr(out2)
+    if out16 is not None:
+        a.C16, a.ldc16 = ptr(out16), _ld(out16)
     a.M, a.N, a.K, a.K1 = M, N, K, K1
     a.lda, a.lda2, a.ldw = _ld(A), (_ld(A2) if A2 is not None else 0), _ld(W)
     a.ldc = (ldc if ldc is not None else (_ld(out) if want_out else 0))

@@ -123,9 +123,20 @@ def _mm_in(x):
     return x
 
 
+def _attach_b16(y, y16):
+    """Remember y16 as the bf16 operand copy of the fp32 tensor y (what _mm_in would otherwise produce with a cast kernel)."""
+    if y16 is not None:
+        y._fab_b16 = (y._version, y16)
+    return y
+
+
+def _want16(out_dtype, act_epi, want):
+    return bool(want) and _cfg.get_precision() == "bf16" and out_dtype == torch.float32 and act_epi == K.ACT_NONE
+
+
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, x2, residual, act_epi, out_dtype):
+    def forward(ctx, x, W, b, x2, residual, act_epi, out_dtype, holder=None):
         assert act_epi in (K.ACT_NONE, K.ACT_RELU, K.ACT_SILU)
         xin, x2in = _mm_in(x), _mm_in(x2)
         D = None
@@ -136,7 +147,11 @@ class _Linear(torch.autograd.Function):
         relu_res = act_epi == K.ACT_RELU and residual is not None
         if act_epi == K.ACT_SILU or relu_res:
             D = torch.empty((M, N), dtype=out_dtype, device=x.device)
-        K.gemm(xin, W, bias=b, A2=x2in, act_epi=act_epi, residual=residual, out=y, out2=D)
+        y16 = None
+        if holder is not None:                        # the caller wants the epilogue to emit the bf16 operand copy of y as well
+            y16 = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
+            holder.append(y16)
+        K.gemm(xin, W, bias=b, A2=x2in, act_epi=act_epi, residual=residual, out=y, out2=D, out16=y16)
         ctx.act_epi, ctx.x_dtype = (K.ACT_SILU if relu_res else act_epi), x.dtype       # backward: stored derivative
         ctx.x2_dtype = x2.dtype if x2 is not None else None
         ctx.has_b, ctx.has_res, ctx.has_x2 = b is not None, residual is not None, x2 is not None
@@ -195,11 +210,11 @@ class _Linear(torch.autograd.Function):
         dres = dy.float() if (ctx.has_res and ctx.needs_input_grad[4]) else None
         if dres is not None and ctx.sink_res is not None:
             dres = ctx.sink_res.deposit(dres)
-        return dx, dW, db, dx2, dres, None, None
+        return dx, dW, db, dx2, dres, None, None, None
 
 
 def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, x2=None, out_dtype=torch.float32,
-           p_drop=0.0):
+           p_drop=0.0, want16=False):
     """p_drop > 0 (no-grad paths only): dropout on act(x W^T + b) inside the GEMM epilogue, before the residual; the mask is
     a counter-based hash keyed by a seed drawn from torch's CPU generator."""
     if x.stride(-1) != 1:
@@ -207,11 +222,16 @@ def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, 
     if _needs_grad(x, W, b, x2, residual):
         assert act_pro == K.ACT_NONE, "producer-side activations only under autograd"
         assert p_drop == 0.0, "epilogue dropout has no autograd path yet"
-        return _Linear.apply(x, W, b, x2, residual, act_epi, out_dtype)
+        holder = [] if _want16(out_dtype, act_epi, want16) else None
+        y = _Linear.apply(x, W, b, x2, residual, act_epi, out_dtype, holder)
+        return _attach_b16(y, holder[0] if holder else None)
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
+    y16 = None
+    if _want16(out_dtype, act_epi, want16) and act_pro == K.ACT_NONE and p_drop == 0.0:
+        y16 = torch.empty((x.shape[0], W.shape[0]), dtype=torch.bfloat16, device=x.device)
     y, _ = K.gemm(_mm_in(x), W, bias=b, A2=_mm_in(x2), act_pro=act_pro, act_epi=act_epi, residual=residual,
-                  out_dtype=out_dtype, p_drop=p_drop, seed=seed)
-    return y
+                  out_dtype=out_dtype, p_drop=p_drop, seed=seed, out16=y16)
+    return _attach_b16(y, y16)
 
 
 class _MLP2(torch.autograd.Function):
@@ -223,7 +243,7 @@ class _MLP2(torch.autograd.Function):
         shared gradient buffer), so autograd adds nothing."""
 
     @staticmethod
-    def forward(ctx, x, x2, W1, b1, W2, b2, residual, act):
+    def forward(ctx, x, x2, W1, b1, W2, b2, residual, act, holder=None):
         assert act in (K.ACT_RELU, K.ACT_SILU)
         xin, x2in = _mm_in(x), _mm_in(x2)
         M, N1 = x.shape[0], W1.shape[0]
@@ -231,7 +251,11 @@ class _MLP2(torch.autograd.Function):
         t = torch.empty((M, N1), dtype=ad, device=x.device)
         D = torch.empty((M, N1), dtype=ad, device=x.device) if act == K.ACT_SILU else None
         K.gemm(xin, W1, bias=b1, A2=x2in, act_epi=act, out=t, out2=D)
-        y, _ = K.gemm(t, W2, bias=b2, residual=residual, out_dtype=torch.float32)
+        y16 = None
+        if holder is not None:
+            y16 = torch.empty((M, W2.shape[0]), dtype=torch.bfloat16, device=x.device)
+            holder.append(y16)
+        y, _ = K.gemm(t, W2, bias=b2, residual=residual, out_dtype=torch.float32, out16=y16)
         ctx.act, ctx.has_x2, ctx.has_res = act, x2 is not None, residual is not None
         ctx.res_is_x = residual is x
         ctx.sink_x, ctx.sink_res = _sink_of(x), _sink_of(residual)
@@ -273,16 +297,18 @@ class _MLP2(torch.autograd.Function):
             dres = ctx.sink_res.deposit(dres)
         if ctx.has_x2 and ni[1]:
             dx2, _ = K.gemm(dpre, W1t[K1:], out_dtype=torch.float32 if ctx.x2_dtype == torch.float32 else ctx.x2_dtype)
-        return dx, dx2, dW1, db1, dW2, (db2 if ni[5] else None), dres, None
+        return dx, dx2, dW1, db1, dW2, (db2 if ni[5] else None), dres, None, None
 
 
-def mlp2(x, W1, b1, act, W2, b2, residual=None, x2=None):
+def mlp2(x, W1, b1, act, W2, b2, residual=None, x2=None, want16=False):
     """act([x | x2] W1^T + b1) W2^T + b2 (+ residual) -> fp32.  One autograd node under autograd (see _MLP2); without
     autograd two GEMMs with fused epilogues."""
     if _needs_grad(x, x2, W1, b1, W2, b2, residual):
-        return _MLP2.apply(x, x2, W1, b1, W2, b2, residual, act)
+        holder = [] if _want16(torch.float32, K.ACT_NONE, want16) else None
+        y = _MLP2.apply(x, x2, W1, b1, W2, b2, residual, act, holder)
+        return _attach_b16(y, holder[0] if holder else None)
     t = linear(x, W1, b1, act_epi=act, x2=x2, out_dtype=act_dtype())
-    return linear(t, W2, b2, residual=residual)
+    return linear(t, W2, b2, residual=residual, want16=want16)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -592,7 +618,7 @@ class _PutRows(torch.autograd.Function):
             out = base.clone()
             out.index_copy_(0, idx, rows.to(base.dtype))
             return out
-        base.index_copy_(0, idx, rows.to(base.dtype))
+        _put_rows_inplace(base, rows, idx)
         ctx.mark_dirty(base)
         return base
 
@@ -610,11 +636,21 @@ class _PutRows(torch.autograd.Function):
 PUT_ROWS_INPLACE_GRAD = True
 
 
+def _put_rows_inplace(base, rows, idx):
+    """base[idx] = rows in place; a remembered bf16 operand copy of base gets the same rows (and stays valid)."""
+    c = getattr(base, "_fab_b16", None)
+    keep = c is not None and c[0] == base._version
+    base.index_copy_(0, idx, rows.to(base.dtype))
+    if keep:
+        c[1].index_copy_(0, idx, rows.to(torch.bfloat16))
+        base._fab_b16 = (base._version, c[1])
+
+
 def put_rows(base, rows, index64, inplace=True):
     """Row scatter of a small compact array into a node-layout array (index glue: pure data movement)."""
     if _needs_grad(base, rows):
         return _PutRows.apply(base, rows, index64, inplace)
-    base.index_copy_(0, index64, rows.to(base.dtype))
+    _put_rows_inplace(base, rows, index64)
     return base
 
 

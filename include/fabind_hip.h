@@ -31,7 +31,7 @@ const char* fabind_last_error(void);
  * 3 = fabind_cross_attn_bwd takes a scratch buffer instead of (n_q_rows, n_k_rows), fabind_cross_attn_bwd_scratch added;
  * 4 = fabind_pair_bias_cat takes a colpart argument (per-work-group column sums), fabind_pair_bias_cat_parts and the
  *     fabind_gemm_tn_set_waves knob added.
- * 5 = fabind_cross_attn_mfma_fwd / fabind_cross_attn_mfma_bwd added (MFMA bf16 form of the cross attention); FabindEdgeBwdArgs grew
+ * 5 = FabindGemmArgs grew {C16, ldc16}; fabind_cross_attn_mfma_fwd / fabind_cross_attn_mfma_bwd added (MFMA bf16 form of the cross attention); FabindEdgeBwdArgs grew
  *     bnd + d2scratch, fabind_gcl_edge_fused takes bnd (deterministic boundary sums instead of float atomics), fabind_gcl_edge_fused_bwd_set_variant / _variant added.
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 5
@@ -83,6 +83,10 @@ typedef struct FabindGemmArgs {
        row_rs[r] * (acc - row_mu[r] * col_c[c]) before bias / activation -- i.e. LN(A) W^T evaluated as a GEMM on the
        UN-normalised A with W pre-scaled by the LN weight, col_c = its row sums, bias = W ln_b + b */
     const float* row_mu; const float* row_rs; const float* col_c;
+    /* optional bf16 copy of an fp32 C (plain fp32 outputs with bias and/or residual only -- the residual-stream Linears): the
+       epilogue writes C16[m, n] = bf16(C[m, n]) next to C, so the GEMMs that consume the result as an MFMA operand need no
+       separate conversion pass over it */
+    void* C16; int ldc16;
 } FabindGemmArgs;
 
 int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream);

@@ -182,9 +182,10 @@ def bench_batch():
     return synthetic.make_stack_batch([(NP, NL)] * 64, H, seed=0)    # snapped: rotation must not flip an edge at a cut-off
 
 
-# measured: E(3) 3.1e-6 A (fp32) / 4.0e-5 A (bf16); complex 0 in the batch vs alone 0 exactly; two runs bit-identical in both modes
-@pytest.mark.parametrize("prec,tol_equiv,tol_single", [("fp32", 1e-4, 1e-6), ("bf16", 1e-4, 1e-6)])
-def test_bench_batch_properties(bench_batch, prec, tol_equiv, tol_single):
+# measured: E(3) 3.1e-6 A (fp32) / 4.0e-5 A (bf16), H invariance 4.8e-7 (fp32) / 1.4e-3 (bf16: a rotated input rounds differently);
+# complex 0 in the batch vs alone 0 exactly; two runs bit-identical in both modes
+@pytest.mark.parametrize("prec,tol_equiv,tol_h,tol_single", [("fp32", 1e-4, 1e-5, 1e-6), ("bf16", 1e-4, 2.8e-3, 1e-6)])
+def test_bench_batch_properties(bench_batch, prec, tol_equiv, tol_h, tol_single):
     """(iii) the B = 64 batch of bench.py: finite; E(3)-equivariant (inputs rotated and translated -> coordinates rotate and
     translate, H invariant); two runs repeat; complex 0 inside the batch == the same complex alone."""
     from fabind_amd import engine
@@ -215,7 +216,7 @@ def test_bench_batch_properties(bench_batch, prec, tol_equiv, tol_single):
         ex = float((((Xr_ - (X1 @ R.T + tvec))[lig] * 5) ** 2).sum(-1).mean().sqrt())
         eh = float((Hr_ - H1).abs().max()) / max(1.0, float(H1.abs().max()))
         print("%s B=64: E(3) equivariance: ligand RMSD between rotated run and rotated output %.3e A, H invariance %.3e" % (prec, ex, eh))
-        assert ex < tol_equiv and eh < max(tol_equiv, 1e-4) * 10
+        assert ex < tol_equiv and eh < tol_h
         # complex 0 of the batch vs the same complex alone
         n0 = NP + NL + 2
         one = {k: (v[:n0] if torch.is_tensor(v) and v.shape[0] == inp["X"].shape[0] else v) for k, v in inp.items()}
