@@ -59,6 +59,8 @@ SIGNATURES = {
     "fabind_gcl_edge_fused_bwd_tile": [],
     "fabind_gcl_edge_fused_bwd_set_variant": [_i],
     "fabind_gcl_edge_fused_bwd_variant": [],
+    "fabind_gcl_edge_fused_bwd2_set_exp": [_i],
+    "fabind_gcl_edge_fused_bwd3_set_exp": [_i],
     "fabind_row_stats": [_vp, _i, _i, _f, _i, _i, _vp, _vp, _vp],
     "fabind_layernorm_rows": [_vp, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _i, _i, _vp],
     "fabind_edge_ln_concat": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _i, _i, _vp],

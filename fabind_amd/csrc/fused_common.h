@@ -40,7 +40,9 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 // acc[i][j] (+)= X[BM x H] (LDS, swizzled) * Wp (packed [H/32][H/16][64 lanes][8]) for this wave's 64 columns.
 // The k-loop is kept rolled (two k-steps per trip, B fragments ping-pong in registers): a fully unrolled loop lets
 // the scheduler hoist every B-fragment load of the contraction at once and spill.
-template <int H, int MI>
+// SWAP: the operand-swapped form C^T = W x X^T -- the same fragments in the other operand slots; the accumulator quad of a lane
+// is then (row i*16 + (lane & 15), columns j*16 + (lane >> 4)*4 .. +3) instead of (rows i*16 + (lane >> 4)*4 .. +3, column j*16 + (lane & 15)).
+template <int H, int MI, bool SWAP = false>
 __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* __restrict__ Wp, int wave, int lane,
                                                f32x4_t (&acc)[MI][4]) {
     constexpr int NKS = H / 32, NG = H / 16;
@@ -63,7 +65,9 @@ __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* _
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a[i], acc[i][j], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0[j], acc[i][j], 0, 0, 0);
         FE_PRIO(0);
         if (ks + 2 < NKS) {
 #pragma unroll
@@ -78,7 +82,9 @@ __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* _
 #pragma unroll
         for (int i = 0; i < MI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a[i], acc[i][j], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1[j], acc[i][j], 0, 0, 0);
         FE_PRIO(0);
     }
 }
@@ -90,6 +96,27 @@ __device__ __forceinline__ void fe_tile_store(const bf16_t* sB, bf16_t* __restri
     for (unsigned q = tid; q < (unsigned)ne * CH; q += H) {
         const unsigned rw = q / CH, ch = q % CH;
         *(uint4*)&gt[rw * H + ch * 8] = *(const uint4*)&sB[rw * H + ((ch ^ (rw & 7)) * 8)];
+    }
+}
+
+// 16-byte store that does NOT keep its line in the XCD's L2 (sc1: write-through and drop).  The [E,H] operand tiles of the
+// backward are read again only by later launches; stored plainly they allocate 4 MiB per XCD and tile phase -- all of L2 --
+// and push the weight fragments and gathered rows every CU keeps re-reading out of it.
+typedef unsigned int fe_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void fe_store16_stream(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, const uint4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(fe_u32x4_t{v.x, v.y, v.z, v.w}, rsrc, (int)byte_off, 0, /*aux: sc1*/ 16);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fe_rsrc(void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+}
+// fe_tile_store through streaming stores
+template <int H>
+__device__ __forceinline__ void fe_tile_store_stream(const bf16_t* sB, bf16_t* __restrict__ g, int e0, int ne, int tid) {
+    constexpr int CH = H / 8;
+    const __amdgpu_buffer_rsrc_t rs = fe_rsrc(g + (size_t)e0 * H, (unsigned)ne * H * 2);
+    for (unsigned q = tid; q < (unsigned)ne * CH; q += H) {
+        const unsigned rw = q / CH, ch = q % CH;
+        fe_store16_stream(rs, (rw * H + ch * 8) * 2, *(const uint4*)&sB[rw * H + ((ch ^ (rw & 7)) * 8)]);
     }
 }
 
@@ -167,3 +194,9 @@ __global__ void fe_boundary_fix_kernel(const int* __restrict__ row, int E, int H
         out[(unsigned)r * ld + c] = sum;
     }
 }
+
+// fused_edge_bwd2.hip: the row-wise / operand-swapped backward (variants 3 and 4 of fabind_gcl_edge_fused_bwd)
+struct FabindEdgeBwdArgs;
+int fe_bwd2_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipStream_t stream);
+// fused_edge_bwd3.hip: the same with a store wave (variants 5 and 6)
+int fe_bwd3_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipStream_t stream);

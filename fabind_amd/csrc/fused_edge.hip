@@ -549,14 +549,14 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
 // other runs its sigmoid / pack / LDS-store epilogue on the VALU.  (The two-tile kernel above keeps one work-group per
 // CU: its phase counters show contractions 40 % + elementwise 45 % of a tile strictly in sequence; its 32-edge variant
 // got the overlap but doubled the weight traffic -- DESIGN.md section 5.)
-template <int H>
-__global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd1_kernel(const FabindEdgeBwdArgs p) {
-    constexpr int BM = 64;
+template <int H, int BM>
+__global__ __launch_bounds__(H, (BM == 128 ? 2 : 4)) void gcl_edge_fused_bwd1_kernel(const FabindEdgeBwdArgs p) {
     constexpr int TPE = H / BM;                                   // threads per edge in the gather layout
     constexpr int CPT = BM / 8;                                   // 16-byte chunks per thread there
-    constexpr int MI = 4;
+    constexpr int MI = BM / 16;                                   // 16-row MFMA fragments per wave (the wave owns 64 columns of ALL rows)
+    constexpr int MQ = MI / 4;                                    // uint4 per (column block, half) of the silu'(pre2) scratch
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* sX = (bf16_t*)smem;                                   // [64][H] swizzled: S1 -> M -> dT -> dP2 -> dS1 -> dP1
+    bf16_t* sX = (bf16_t*)smem;                                   // [BM][H] swizzled: S1 -> M -> dT -> dP2 -> dS1 -> dP1
     int* sRow = (int*)(sX + BM * H);
     float* sDs = (float*)(sRow + BM);
     float* sRh = sDs + BM;
@@ -651,8 +651,8 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd1_kernel(const FabindE
         __syncthreads();                                          // every wave has finished reading S1
         {
             FE_CBASE()
-            // silu'(pre2) of this work-group's current tile: [j][half][thread] uint4 (1 KiB per wave store), rewritten every tile
-            uint4* d2s = (uint4*)p.d2scratch + (size_t)blockIdx.x * (8 * H);
+            // silu'(pre2) of this work-group's current tile: [j][half][i / 4][thread] uint4 (1 KiB per wave store), rewritten every tile
+            uint4* d2s = (uint4*)p.d2scratch + (size_t)blockIdx.x * (8 * MQ * H);
             float bj[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) bj[j] = b2[wave * 64 + j * 16 + fr];
@@ -676,8 +676,11 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd1_kernel(const FabindE
                     da[i] = pack2_bf16(dd[0], dd[1]);
                     db[i] = pack2_bf16(dd[2], dd[3]);
                 }
-                d2s[(j * 2) * H + tid] = make_uint4(da[0], da[1], da[2], da[3]);
-                d2s[(j * 2 + 1) * H + tid] = make_uint4(db[0], db[1], db[2], db[3]);
+#pragma unroll
+                for (int q = 0; q < MQ; ++q) {
+                    d2s[((j * 2) * MQ + q) * H + tid] = make_uint4(da[q * 4], da[q * 4 + 1], da[q * 4 + 2], da[q * 4 + 3]);
+                    d2s[((j * 2 + 1) * MQ + q) * H + tid] = make_uint4(db[q * 4], db[q * 4 + 1], db[q * 4 + 2], db[q * 4 + 3]);
+                }
                 FE_ROT_ACC() FE_ROT4(bj)
             }
         }
@@ -730,12 +733,17 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd1_kernel(const FabindE
         __syncthreads();
         {
         FE_CBASE()
-        const uint4* d2s = (const uint4*)p.d2scratch + (size_t)blockIdx.x * (8 * H);
+        const uint4* d2s = (const uint4*)p.d2scratch + (size_t)blockIdx.x * (8 * MQ * H);
 #pragma unroll 1
         for (int j = 0; j < 4; ++j) {
             FE_JADDR(j)
-            const uint4 qa = d2s[(j * 2) * H + tid], qb = d2s[(j * 2 + 1) * H + tid];
-            const uint32_t da[MI] = {qa.x, qa.y, qa.z, qa.w}, db[MI] = {qb.x, qb.y, qb.z, qb.w};
+            uint32_t da[MI], db[MI];
+#pragma unroll
+            for (int q = 0; q < MQ; ++q) {
+                const uint4 qa = d2s[((j * 2) * MQ + q) * H + tid], qb = d2s[((j * 2 + 1) * MQ + q) * H + tid];
+                da[q * 4] = qa.x; da[q * 4 + 1] = qa.y; da[q * 4 + 2] = qa.z; da[q * 4 + 3] = qa.w;
+                db[q * 4] = qb.x; db[q * 4 + 1] = qb.y; db[q * 4 + 2] = qb.z; db[q * 4 + 3] = qb.w;
+            }
             float a2 = 0.f;
 #pragma unroll
             for (int i = 0; i < MI; ++i)
@@ -807,7 +815,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd1_kernel(const FabindE
         {
             const bool head_cont = e0 > 0 && p.row[e0 - 1] == sRow[0];
             const bool tail_cont = e0 + ne < p.E && p.row[e0 + ne] == sRow[ne - 1];
-            sPart[3 * H + tid] += fe_scan_rows<H, true, 64>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dABrow, (unsigned)p.lddab,
+            sPart[3 * H + tid] += fe_scan_rows<H, true, BM>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dABrow, (unsigned)p.lddab,
                                                          p.bnd + (size_t)tile * 2 * H, tid);
         }
         __syncthreads();                                          // the next tile overwrites sX / sRow
@@ -831,9 +839,11 @@ extern "C" int fabind_gcl_edge_fused_bwd_set_tile(int bm) {
     return 0;
 }
 extern "C" int fabind_gcl_edge_fused_bwd_tile(void) { return g_fe_bwd_bm; }
-static int g_fe_bwd_variant = 0;     // 0 = two LDS tiles, one work-group per CU (default); 1 = single in-place tile, two per CU
+static int g_fe_bwd_variant = 0;     // 0 = two LDS tiles, one work-group per CU (default); 1 = single in-place tile, two per CU;
+                                     // 2 = single in-place tile of 128 edges, one per CU (H >= 128; half the weight stream per edge)
 extern "C" int fabind_gcl_edge_fused_bwd_set_variant(int v) {
-    FB_REQUIRE(v == 0 || v == 1, "fabind_gcl_edge_fused_bwd_set_variant: 0 (two LDS tiles) or 1 (single in-place tile)");
+    FB_REQUIRE(v >= 0 && v <= 6,
+               "fabind_gcl_edge_fused_bwd_set_variant: 0 (two LDS tiles of 64 edges), 1 / 2 (one in-place tile of 64 / 128), 3 / 4 (row-wise, operand-swapped: 128 / 64), 5 / 6 (the same with a store wave: 96 / 64)");
     g_fe_bwd_variant = v;
     return 0;
 }
@@ -847,20 +857,30 @@ extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a_in, int H, i
     FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_gcl_edge_fused_bwd: H must be 64, 128, 256 or 512");
     FB_REQUIRE(a->ldab % 8 == 0, "fabind_gcl_edge_fused_bwd: ldab % 8");
     FB_REQUIRE(a->p_drop >= 0.f && a->p_drop < 1.f, "fabind_gcl_edge_fused_bwd: p_drop in [0, 1)");
-    if (g_fe_bwd_variant == 1) {
-        FB_REQUIRE(a->d2scratch != nullptr, "fabind_gcl_edge_fused_bwd: the single-tile variant needs d2scratch (n_groups x 64 x H x 2 bytes)");
-        const size_t lds1 = (size_t)64 * H * 2 + 64 * (sizeof(int) + 2 * sizeof(float)) + (size_t)4 * H * sizeof(float);
-#define FE_LAUNCH1(HH)                                                                                             \
+    if (g_fe_bwd_variant == 5 || g_fe_bwd_variant == 6) return fe_bwd3_launch(a, H, g_fe_bwd_variant == 5 ? 96 : 64, n_groups, stream);
+    if (g_fe_bwd_variant == 3 || g_fe_bwd_variant == 4) return fe_bwd2_launch(a, H, g_fe_bwd_variant == 3 ? 128 : 64, n_groups, stream);
+    if (g_fe_bwd_variant == 1 || (g_fe_bwd_variant == 2 && H >= 128)) {
+        const int bm1 = g_fe_bwd_variant == 2 ? 128 : 64;
+        FB_REQUIRE(a->d2scratch != nullptr, "fabind_gcl_edge_fused_bwd: the single-tile variants need d2scratch (n_groups x tile x H x 2 bytes)");
+        const size_t lds1 = (size_t)bm1 * H * 2 + bm1 * (sizeof(int) + 2 * sizeof(float)) + (size_t)4 * H * sizeof(float);
+#define FE_LAUNCH1(HH, BB)                                                                                         \
     do {                                                                                                           \
         static bool set_ = false;                                                                                  \
-        if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_bwd1_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); set_ = true; } \
-        hipLaunchKernelGGL((gcl_edge_fused_bwd1_kernel<HH>), dim3(n_groups), dim3(HH), lds1, stream, *a);           \
+        if (!set_) { const hipError_t e_ = hipFuncSetAttribute((const void*)gcl_edge_fused_bwd1_kernel<HH, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); \
+            if (e_ != hipSuccess) { fabind_set_error(hipGetErrorString(e_)); return (int)e_; } set_ = true; } \
+        hipLaunchKernelGGL((gcl_edge_fused_bwd1_kernel<HH, BB>), dim3(n_groups), dim3(HH), lds1, stream, *a);       \
     } while (0)
-        FB_REQUIRE(a->bnd != nullptr, "fabind_gcl_edge_fused_bwd: the single-tile variant needs bnd (ceil(E/64) x 2 x H floats)");
-        if (H == 512) FE_LAUNCH1(512); else if (H == 256) FE_LAUNCH1(256); else if (H == 128) FE_LAUNCH1(128); else FE_LAUNCH1(64);
+        FB_REQUIRE(a->bnd != nullptr, "fabind_gcl_edge_fused_bwd: the single-tile variants need bnd (ceil(E / tile) x 2 x H floats)");
+        if (bm1 == 128) {
+            if (H == 512) FE_LAUNCH1(512, 128); else if (H == 256) FE_LAUNCH1(256, 128); else FE_LAUNCH1(128, 128);
+            hipLaunchKernelGGL((fe_boundary_fix_kernel<128>), dim3((a->E + 127) / 128), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
+                               a->bnd, a->dABrow, (unsigned)a->lddab);
+        } else {
+            if (H == 512) FE_LAUNCH1(512, 64); else if (H == 256) FE_LAUNCH1(256, 64); else if (H == 128) FE_LAUNCH1(128, 64); else FE_LAUNCH1(64, 64);
+            hipLaunchKernelGGL((fe_boundary_fix_kernel<64>), dim3((a->E + 63) / 64), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
+                               a->bnd, a->dABrow, (unsigned)a->lddab);
+        }
 #undef FE_LAUNCH1
-        hipLaunchKernelGGL((fe_boundary_fix_kernel<64>), dim3((a->E + 63) / 64), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
-                           a->bnd, a->dABrow, (unsigned)a->lddab);
         FB_CHECK_LAUNCH();
         return 0;
     }

@@ -205,6 +205,9 @@ int fabind_gcl_edge_fused_bwd_tile(void);
  * evaluate the same arithmetic in the same order per element (outputs equal to 1e-7). */
 int fabind_gcl_edge_fused_bwd_set_variant(int v);
 int fabind_gcl_edge_fused_bwd_variant(void);
+/* development knob of variants 3 / 4: bit mask of work the kernel SKIPS (results are then wrong -- sensitivity timing only). */
+void fabind_gcl_edge_fused_bwd2_set_exp(int mask);
+void fabind_gcl_edge_fused_bwd3_set_exp(int mask);
 /* development knob: 1 (default) = XCD-aware tile order in the fused edge kernels (XCD x owns the x-th eighth of the tiles, i.e.
  * whole complexes); 0 = linear tile order (forward) / grid-stride walk (backward).  Results do not depend on it. */
 void fabind_gcl_edge_fused_set_xcd_aware(int on);

@@ -23,8 +23,10 @@ run = lambda: K.gcl_edge_fused_bwd(AB, H, g.row_ctx, g.col_ctx, rh, w_r, W2, b2,
 from fabind_amd import _lib
 import sys as _s
 bm = int(_s.argv[1]) if len(_s.argv) > 1 else 32
-_lib.load().fabind_gcl_edge_fused_bwd_set_variant(0)      # the phase counters live in the two-tile kernel
-_lib.load().fabind_gcl_edge_fused_bwd_set_tile(bm)
+variant = int(_s.argv[2]) if len(_s.argv) > 2 else 0      # the phase counters live in the two-tile kernel (0) and the row-wise one (3 / 4)
+_lib.load().fabind_gcl_edge_fused_bwd_set_variant(variant)
+if variant == 0:
+    _lib.load().fabind_gcl_edge_fused_bwd_set_tile(bm)
 print("tile =", bm)
 K.PROFILE = {}
 ms = timeit(run, 5)
@@ -38,7 +40,8 @@ tt = K.EDGE_BWD_TIMES.cpu().tolist()
 names = ["P0 gather+silu", "tile stores (5)", "contractions (4)", "P1 epilogue", "P2 epilogue", "P3 dagg loads", "P3 epilogue",
          "P4 epilogue", "P5 gather+dsilu", "P6 column scan"]
 n_tiles = (E + bm - 1) // bm
-per = (n_tiles + (512 if bm == 32 else 256) - 1) // (512 if bm == 32 else 256)
+ngr = {0: 512 if bm == 32 else 256, 3: 256, 4: 512, 5: 256, 6: 256}[variant]
+per = (n_tiles + ngr - 1) // ngr
 tot = sum(tt)
 for n, c in zip(names, tt):
     print("%-20s %10.0f cycles/tile  %5.1f%%" % (n, c / per, 100.0 * c / max(tot, 1)))
