@@ -59,8 +59,6 @@ SIGNATURES = {
     "fabind_gcl_edge_fused_bwd_tile": [],
     "fabind_gcl_edge_fused_bwd_set_variant": [_i],
     "fabind_gcl_edge_fused_bwd_variant": [],
-    "fabind_gcl_edge_fused_bwd2_set_exp": [_i],
-    "fabind_gcl_edge_fused_bwd3_set_exp": [_i],
     "fabind_row_stats": [_vp, _i, _i, _f, _i, _i, _vp, _vp, _vp],
     "fabind_layernorm_rows": [_vp, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _i, _i, _vp],
     "fabind_edge_ln_concat": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _i, _i, _vp],
@@ -141,6 +139,9 @@ def load():
     lib.fabind_gemm_tn_set_waves.restype = None
     lib.fabind_gcl_edge_fused_set_xcd_aware.argtypes = [ctypes.c_int]
     lib.fabind_gcl_edge_fused_set_xcd_aware.restype = None
+    for nm in ("fabind_gcl_edge_fused_bwd2_set_exp", "fabind_gcl_edge_fused_bwd3_set_exp"):      # development knobs (void)
+        getattr(lib, nm).argtypes = [ctypes.c_int]
+        getattr(lib, nm).restype = None
     if "FABIND_EDGE_BWD_VARIANT" in os.environ:          # development knobs for same-box A/B runs (tools/probes)
         lib.fabind_gcl_edge_fused_bwd_set_variant.argtypes = [ctypes.c_int]
         lib.fabind_gcl_edge_fused_bwd_set_variant(int(os.environ["FABIND_EDGE_BWD_VARIANT"]))
