@@ -42,7 +42,10 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 // the scheduler hoist every B-fragment load of the contraction at once and spill.
 // SWAP: the operand-swapped form C^T = W x X^T -- the same fragments in the other operand slots; the accumulator quad of a lane
 // is then (row i*16 + (lane & 15), columns j*16 + (lane >> 4)*4 .. +3) instead of (rows i*16 + (lane >> 4)*4 .. +3, column j*16 + (lane & 15)).
-template <int H, int MI, bool SWAP = false>
+// SWZ: row bits XOR-ed into the 16-byte chunk index of the LDS tile.  With 7 (round 1) rows r and r + 8 of a 16-row fragment sit in
+// the same 16-byte slot modulo 256 B, and the 16-lane groups of ds_read_b128 see a 2-way bank conflict on every A-fragment read
+// (47 % of the LDS cycles of the round-1 kernels were conflict cycles); 15 spreads a fragment's 16 rows over all 16 slots.
+template <int H, int MI, bool SWAP = false, int SWZ = 7>
 __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* __restrict__ Wp, int wave, int lane,
                                                f32x4_t (&acc)[MI][4]) {
     constexpr int NKS = H / 32, NG = H / 16;
@@ -59,7 +62,7 @@ __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* _
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int r = i * 16 + fr;
-            a[i] = *(const bf16x8_t*)&sX[r * H + (((ks * 4 + fq) ^ (r & 7)) * 8)];
+            a[i] = *(const bf16x8_t*)&sX[r * H + (((ks * 4 + fq) ^ (r & SWZ)) * 8)];
         }
         FE_PRIO(1);      // co-resident work-groups sit in VALU epilogues: the matrix-core stream goes first
 #pragma unroll
@@ -76,7 +79,7 @@ __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* _
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int r = i * 16 + fr;
-            a[i] = *(const bf16x8_t*)&sX[r * H + ((((ks + 1) * 4 + fq) ^ (r & 7)) * 8)];
+            a[i] = *(const bf16x8_t*)&sX[r * H + ((((ks + 1) * 4 + fq) ^ (r & SWZ)) * 8)];
         }
         FE_PRIO(1);
 #pragma unroll
@@ -138,7 +141,7 @@ __device__ __forceinline__ void fe_zero(f32x4_t (&acc)[MI][4]) {
 // does not depend on which work-group finishes first (round 1 used atomicAdd for the boundary runs: a node with 1,500 edges
 // spans 24 tiles, and two identical forward passes differed by an ulp about once in ten runs, amplified to 1e-4 in h by
 // bf16 rounding downstream).  Returns sum_rows rh[row] * value (the d w_r partial of the backward) when WITH_RH.
-template <int H, bool WITH_RH, int BM_>
+template <int H, bool WITH_RH, int BM_, int SWZ = 7>
 __device__ __forceinline__ float fe_scan_rows(const bf16_t* sX, const int* sRow, const float* sRh, int ne, bool head_cont,
                                               bool tail_cont, float* out, unsigned ld, float* bnd_tile, int c) {
     float run = 0.f, pwr = 0.f;
@@ -152,7 +155,7 @@ __device__ __forceinline__ float fe_scan_rows(const bf16_t* sX, const int* sRow,
             const int rw = min(rw0 + u, BM_ - 1);         // the tile height BM_ is a multiple of 8
             rr[u] = sRow[rw];
             rhv[u] = WITH_RH ? sRh[rw] : 0.f;
-            v[u] = bf16_to_f32(sX[rw * H + (((c >> 3) ^ (rw & 7)) * 8) + (c & 7)]);
+            v[u] = bf16_to_f32(sX[rw * H + (((c >> 3) ^ (rw & SWZ)) * 8) + (c & 7)]);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {

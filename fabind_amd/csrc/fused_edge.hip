@@ -842,8 +842,8 @@ extern "C" int fabind_gcl_edge_fused_bwd_tile(void) { return g_fe_bwd_bm; }
 static int g_fe_bwd_variant = 0;     // 0 = two LDS tiles, one work-group per CU (default); 1 = single in-place tile, two per CU;
                                      // 2 = single in-place tile of 128 edges, one per CU (H >= 128; half the weight stream per edge)
 extern "C" int fabind_gcl_edge_fused_bwd_set_variant(int v) {
-    FB_REQUIRE(v >= 0 && v <= 6,
-               "fabind_gcl_edge_fused_bwd_set_variant: 0 (two LDS tiles of 64 edges), 1 / 2 (one in-place tile of 64 / 128), 3 / 4 (row-wise, operand-swapped: 128 / 64), 5 / 6 (the same with a store wave: 96 / 64)");
+    FB_REQUIRE(v >= 0 && v <= 5,
+               "fabind_gcl_edge_fused_bwd_set_variant: 0 (two LDS tiles of 64 edges), 1 / 2 (one in-place tile of 64 / 128), 3 / 4 (row-wise, operand-swapped: 128 / 64), 5 (the same with a store wave, 64 edges)");
     g_fe_bwd_variant = v;
     return 0;
 }
@@ -857,7 +857,7 @@ extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a_in, int H, i
     FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_gcl_edge_fused_bwd: H must be 64, 128, 256 or 512");
     FB_REQUIRE(a->ldab % 8 == 0, "fabind_gcl_edge_fused_bwd: ldab % 8");
     FB_REQUIRE(a->p_drop >= 0.f && a->p_drop < 1.f, "fabind_gcl_edge_fused_bwd: p_drop in [0, 1)");
-    if (g_fe_bwd_variant == 5 || g_fe_bwd_variant == 6) return fe_bwd3_launch(a, H, g_fe_bwd_variant == 5 ? 96 : 64, n_groups, stream);
+    if (g_fe_bwd_variant == 5) return fe_bwd3_launch(a, H, 64, n_groups, stream);
     if (g_fe_bwd_variant == 3 || g_fe_bwd_variant == 4) return fe_bwd2_launch(a, H, g_fe_bwd_variant == 3 ? 128 : 64, n_groups, stream);
     if (g_fe_bwd_variant == 1 || (g_fe_bwd_variant == 2 && H >= 128)) {
         const int bm1 = g_fe_bwd_variant == 2 ? 128 : 64;

@@ -72,7 +72,7 @@ __device__ __forceinline__ void fe3_bstore16(const __amdgpu_buffer_rsrc_t rs, co
 }
 
 // one wave copies the first ne rows of a swizzled [.][H] LDS tile to g[e0 .. e0+ne)[H]
-template <int H>
+template <int H, int SWZ>
 __device__ __forceinline__ void fe3_wave_store(const bf16_t* sB, bf16_t* __restrict__ g, int e0, int ne, int lane) {
     constexpr int CH = H / 8;
     bf16_t* gt = g + (size_t)e0 * H;
@@ -80,14 +80,13 @@ __device__ __forceinline__ void fe3_wave_store(const bf16_t* sB, bf16_t* __restr
 #pragma unroll 8
     for (unsigned q = lane; q < total; q += 64) {
         const unsigned rw = q / CH, ch = q % CH;
-        *(uint4*)&gt[rw * H + ch * 8] = *(const uint4*)&sB[rw * H + ((ch ^ (rw & 7)) * 8)];
+        *(uint4*)&gt[rw * H + ch * 8] = *(const uint4*)&sB[rw * H + ((ch ^ (rw & SWZ)) * 8)];
     }
 }
 
 template <int H, int BM, bool DROP, bool DBG>
 __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const FabindEdgeBwdArgs p, const int xf) {
     constexpr int MI = BM / 16;                                   // 16-edge MFMA blocks per wave (the wave owns 64 features of ALL edges)
-    constexpr int NQ = (2 * MI + 3) / 4;                          // uint4 per (thread, 16-feature block) of the silu'(pre2) scratch
     constexpr int NW = H / 64;                                    // compute waves; wave NW is the store wave
     constexpr int CH = H / 8;                                     // 16-byte chunks per edge row
     constexpr int EPW = 64 / CH;                                  // edges per wave and iteration of the row-wise phases (1 at H = 512)
@@ -95,9 +94,12 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
     constexpr int NIT = BM / EPI;
     constexpr int PB = (NIT % 8 == 0) ? 8 : (NIT % 6 == 0) ? 6 : 4;   // iterations per load batch of the row-wise phases
     static_assert(NIT % PB == 0 && BM % 16 == 0, "tile height");
+    constexpr int SWZ = (H >= 128) ? 15 : 7;                       // LDS tile swizzle: chunk ^ (row & SWZ) (fused_common.h fe_gemm_rolled)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* sX = (bf16_t*)smem;                                   // [BM][H] swizzled: S1 -> M -> dT -> dP2 -> dS1 -> dP1
-    int* sTab = (int*)(sX + BM * H);                              // [2][4][BM]: {row, col, ds, rhohat} of this tile and the next
+    bf16_t* sD = sX + BM * H;                                     // [BM][H] swizzled: silu'(pre1) from P0 until the store wave has copied it to
+                                                                  // this work-group's scratch slab (during contraction 1), then silu'(pre2) (P1 -> P3)
+    int* sTab = (int*)(sD + BM * H);                             // [2][4][BM]: {row, col, ds, rhohat} of this tile and the next
     float* sPart = (float*)(sTab + 8 * BM);                       // [4][H]: column sums of {d b2, d bc, d w3, d w_r} over this work-group's tiles
     const bf16_t* __restrict__ AB = (const bf16_t*)p.AB;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -120,20 +122,21 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
             const int ne = min(BM, p.E - e0);
             const bool st = !(xf & 1);
             __syncthreads();                                      // S1 ready
-            if (st) fe3_wave_store<H>(sX, (bf16_t*)p.S1, e0, ne, lane);
+            if (st) fe3_wave_store<H, SWZ>(sX, (bf16_t*)p.S1, e0, ne, lane);
+            fe3_wave_store<H, SWZ>(sD, (bf16_t*)p.d2scratch + (size_t)blockIdx.x * (BM * H), 0, BM, lane);   // silu'(pre1) -> scratch slab
             __syncthreads();                                      // contraction 1 done
             __syncthreads();                                      // M ready
-            if (st) fe3_wave_store<H>(sX, (bf16_t*)p.Mm, e0, ne, lane);
+            if (st) fe3_wave_store<H, SWZ>(sX, (bf16_t*)p.Mm, e0, ne, lane);
             __syncthreads();                                      // contraction 2 done
             __syncthreads();                                      // dT ready
-            if (st) fe3_wave_store<H>(sX, (bf16_t*)p.dT, e0, ne, lane);
+            if (st) fe3_wave_store<H, SWZ>(sX, (bf16_t*)p.dT, e0, ne, lane);
             __syncthreads();                                      // contraction 3 done
             __syncthreads();                                      // dP2 ready
-            if (st) fe3_wave_store<H>(sX, (bf16_t*)p.dP2, e0, ne, lane);
+            if (st) fe3_wave_store<H, SWZ>(sX, (bf16_t*)p.dP2, e0, ne, lane);
             __syncthreads();                                      // contraction 4 done
             __syncthreads();                                      // dS1 ready
             __syncthreads();                                      // dP1 ready
-            if (st) fe3_wave_store<H>(sX, (bf16_t*)p.dP1, e0, ne, lane);
+            if (st) fe3_wave_store<H, SWZ>(sX, (bf16_t*)p.dP1, e0, ne, lane);
             __syncthreads();                                      // row scan done: the tile may be overwritten
         }
         __syncthreads();                                          // (partial sums)
@@ -148,14 +151,13 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
     for (int k = 0; k < 4; ++k) sPart[k * H + tid] = 0.f;
     const unsigned uld = (unsigned)p.ldab;
     // scratch slabs of this work-group: silu'(pre2) in fragment order, silu'(pre1) in tile order
-    const __amdgpu_buffer_rsrc_t rs_d2 = fe_rsrc((uint4*)p.d2scratch + (size_t)blockIdx.x * (128 * H / 8), 128 * H * 2);
-    const __amdgpu_buffer_rsrc_t rs_d1 = fe_rsrc((uint4*)p.d2scratch + ((size_t)gridDim.x + blockIdx.x) * (128 * H / 8), 128 * H * 2);
+    const __amdgpu_buffer_rsrc_t rs_d1 = fe_rsrc((bf16_t*)p.d2scratch + (size_t)blockIdx.x * (BM * H), BM * H * 2);
+    const unsigned rw_off = (unsigned)((wave * EPW + sub) * CH + ch) * 16;     // byte offset of this lane's chunk in a row-wise iteration
     const __amdgpu_buffer_rsrc_t rs_ab = fe_rsrc(const_cast<void*>(p.AB), 0xffffffffu);
     const __amdgpu_buffer_rsrc_t rs_dagg = fe_rsrc(const_cast<float*>(p.dagg), 0xffffffffu);
-    const unsigned rw_off = (unsigned)((wave * EPW + sub) * CH + ch) * 16;     // byte offset of this lane's chunk in a row-wise iteration
     // LDS element offset of this lane's accumulator quad (i, j): edge i*16 + fr, features wave*64 + j*16 + cq*4 .. +3
-    //   chunk = (wave*8 + j*2 + (cq>>1)) ^ (fr & 7) = cx ^ (j*2)
-    const int cx = (wave * 8 + (cq >> 1)) ^ (fr & 7);
+    //   chunk = (wave*8 + j*2 + (cq>>1)) ^ (fr & SWZ) = cx ^ (j*2)
+    const int cx = (wave * 8 + (cq >> 1)) ^ (fr & SWZ);
     const int lbase = fr * H + (cq & 1) * 4;
 #define FE_QOFF(i, j) (lbase + (i) * 16 * H + ((cx ^ ((j) * 2)) * 8))
     const int fcol = wave * 64 + cq * 4;                          // first feature of the quad of block j: fcol + j*16
@@ -253,8 +255,8 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
                         pd[k] = fe3_pack(d);
                     }
                     const bool ok = e < ne;
-                    *(uint4*)&sX[e * H + ((ch ^ (e & 7)) * 8)] = ok ? make_uint4(po[0], po[1], po[2], po[3]) : make_uint4(0u, 0u, 0u, 0u);
-                    if (!(xf & 2)) fe3_bstore16(rs_d1, rw_off, (unsigned)((b * PB + u) * EPI * CH * 16), make_uint4(pd[0], pd[1], pd[2], pd[3]));
+                    *(uint4*)&sX[e * H + ((ch ^ (e & SWZ)) * 8)] = ok ? make_uint4(po[0], po[1], po[2], po[3]) : make_uint4(0u, 0u, 0u, 0u);
+                    *(uint4*)&sD[e * H + ((ch ^ (e & SWZ)) * 8)] = make_uint4(pd[0], pd[1], pd[2], pd[3]);
                 }
             }
         }
@@ -264,7 +266,7 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
         // ---- P1: pre2 = S1 W2^T + b2;  M -> tile in place;  silu'(pre2) -> scratch
         f32x4_t acc[MI][4];
         fe_zero(acc);
-        fe_gemm_rolled<H, MI, true>(sX, W2p, wave, lane, acc);
+        fe_gemm_rolled<H, MI, true, SWZ>(sX, W2p, wave, lane, acc);
         __syncthreads();                                          // every wave has finished reading S1 (and the store wave has copied it)
         FE_TICK(2)
         {
@@ -274,7 +276,6 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const fe_f2 b01 = fe_f2{bq4[j].x, bq4[j].y}, b23 = fe_f2{bq4[j].z, bq4[j].w};
-                uint32_t dd2[NQ * 4];                             // [0, MI): pairs (r0, r1) of block i;  [MI, 2 MI): pairs (r2, r3)
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     fe_f2 m01, d01, m23, d23;
@@ -286,13 +287,9 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
                         const fe_f2 k23 = fe_f2{fe_keep(p.seed, ee, cc + 2, H, thr16, dscale), fe_keep(p.seed, ee, cc + 3, H, thr16, dscale)};
                         m01 *= k01; d01 *= k01; m23 *= k23; d23 *= k23;
                     }
-                    dd2[i] = fe3_pack(d01);
-                    dd2[MI + i] = fe3_pack(d23);
+                    *(uint2*)&sD[FE_QOFF(i, j)] = make_uint2(fe3_pack(d01), fe3_pack(d23));
                     *(uint2*)&sX[FE_QOFF(i, j)] = make_uint2(fe3_pack(m01), fe3_pack(m23));
                 }
-#pragma unroll
-                for (int q = 0; q < NQ; ++q)
-                    if (!(xf & 2)) fe3_bstore16(rs_d2, (unsigned)tid * 16, (unsigned)((j * NQ + q) * H * 16), make_uint4(dd2[q * 4], dd2[q * 4 + 1], dd2[q * 4 + 2], dd2[q * 4 + 3]));
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -301,7 +298,7 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
 
         // ---- P2: pre3 = M Wc^T + bc;  dT = ds * w3 * silu'(pre3) -> tile in place
         fe_zero(acc);
-        fe_gemm_rolled<H, MI, true>(sX, Wcp, wave, lane, acc);
+        fe_gemm_rolled<H, MI, true, SWZ>(sX, Wcp, wave, lane, acc);
         __syncthreads();
         FE_TICK(2)
         {
@@ -345,11 +342,10 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
         //      block ahead inside the epilogue: loading dagg into the accumulators first put its latency in front of the contraction)
         fe_zero(acc);
         FE_TICK(5)
-        fe_gemm_rolled<H, MI, true>(sX, WcTp, wave, lane, acc);
+        fe_gemm_rolled<H, MI, true, SWZ>(sX, WcTp, wave, lane, acc);
         __syncthreads();
         FE_TICK(2)
         {
-            uint4 dq[2][NQ];                                      // silu'(pre2) of block j, fetched while block j - 1 is processed
             float4 dg[2][MI];                                     // dagg[row of edge i*16 + fr][fcol + j*16 ..]
             unsigned dgo[MI];
             float dgk[MI];
@@ -361,8 +357,6 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
             }
             auto fetch_block = [&](int j, int slot) {
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) dq[slot][q] = fe3_bload16(rs_d2, (unsigned)tid * 16, (unsigned)((j * NQ + q) * H * 16));
-#pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     const uint4 v = fe3_bload16(rs_dagg, dgo[i], (unsigned)(j * 64));
                     dg[slot][i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
@@ -372,18 +366,13 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j < 3) fetch_block(j + 1, (j + 1) & 1);
-                uint32_t dd2[NQ * 4];
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    const uint4 qa = dq[j & 1][q];
-                    dd2[q * 4] = qa.x; dd2[q * 4 + 1] = qa.y; dd2[q * 4 + 2] = qa.z; dd2[q * 4 + 3] = qa.w;
-                }
                 fe_f2 a2a = fe_f2{0.f, 0.f}, a2b = a2a;
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     const float4 g4 = dg[j & 1][i];
-                    const fe_f2 p01 = (fe_f2{acc[i][j][0], acc[i][j][1]} + fe_f2{g4.x, g4.y} * dgk[i]) * fe3_unpack(dd2[i]);
-                    const fe_f2 p23 = (fe_f2{acc[i][j][2], acc[i][j][3]} + fe_f2{g4.z, g4.w} * dgk[i]) * fe3_unpack(dd2[MI + i]);
+                    const uint2 dq = *(const uint2*)&sD[FE_QOFF(i, j)];
+                    const fe_f2 p01 = (fe_f2{acc[i][j][0], acc[i][j][1]} + fe_f2{g4.x, g4.y} * dgk[i]) * fe3_unpack(dq.x);
+                    const fe_f2 p23 = (fe_f2{acc[i][j][2], acc[i][j][3]} + fe_f2{g4.z, g4.w} * dgk[i]) * fe3_unpack(dq.y);
                     a2a += p01; a2b += p23;
                     *(uint2*)&sX[FE_QOFF(i, j)] = make_uint2(fe3_pack(p01), fe3_pack(p23));
                 }
@@ -399,9 +388,12 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
 
         // ---- P4: dS1 = dP2 W2 -> tile in place
         fe_zero(acc);
-        fe_gemm_rolled<H, MI, true>(sX, W2Tp, wave, lane, acc);
+        fe_gemm_rolled<H, MI, true, SWZ>(sX, W2Tp, wave, lane, acc);
         __syncthreads();
         FE_TICK(2)
+        uint4 gd[NIT];                                            // silu'(pre1) of this lane's row-wise chunks, back from the scratch slab for P5
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) gd[it] = fe3_bload16(rs_d1, rw_off, (unsigned)(it * EPI * CH * 16));
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -419,17 +411,15 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
                 const float4 w0 = *(const float4*)(w_r + ch * 8), w1 = *(const float4*)(w_r + ch * 8 + 4);
                 wv2[0] = fe_f2{w0.x, w0.y}; wv2[1] = fe_f2{w0.z, w0.w}; wv2[2] = fe_f2{w1.x, w1.y}; wv2[3] = fe_f2{w1.z, w1.w};
             }
-#pragma unroll 1
-            for (int it0 = 0; it0 < NIT; it0 += PB) {
-                uint4 gd[PB];
 #pragma unroll
-                for (int u = 0; u < PB; ++u) gd[u] = fe3_bload16(rs_d1, rw_off, (unsigned)((it0 + u) * EPI * CH * 16));
+            for (int it0 = 0; it0 < NIT; it0 += PB) {
 #pragma unroll
                 for (int u = 0; u < PB; ++u) {
                     const int e = (it0 + u) * EPI + wave * EPW + sub;
-                    uint4* sp = (uint4*)&sX[e * H + ((ch ^ (e & 7)) * 8)];
+                    uint4* sp = (uint4*)&sX[e * H + ((ch ^ (e & SWZ)) * 8)];
                     const uint4 gs = *sp;
-                    const uint32_t ug[4] = {gs.x, gs.y, gs.z, gs.w}, ud[4] = {gd[u].x, gd[u].y, gd[u].z, gd[u].w};
+                    const uint4 gq = gd[it0 + u];
+                    const uint32_t ug[4] = {gs.x, gs.y, gs.z, gs.w}, ud[4] = {gq.x, gq.y, gq.z, gq.w};
                     uint32_t pg[4];
                     fe_f2 dot2 = fe_f2{0.f, 0.f};
 #pragma unroll
@@ -461,7 +451,7 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
         if (!(xf & 16)) {
             const bool head_cont = e0 > 0 && p.row[e0 - 1] == sRow[0];
             const bool tail_cont = e0 + ne < p.E && p.row[e0 + ne] == sRow[ne - 1];
-            sPart[3 * H + tid] += fe_scan_rows<H, true, BM>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dABrow, (unsigned)p.lddab,
+            sPart[3 * H + tid] += fe_scan_rows<H, true, BM, SWZ>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dABrow, (unsigned)p.lddab,
                                                          p.bnd + (size_t)tile * 2 * H, tid);
         }
         if (has_next) commit_tables(hb ^ 1);
@@ -484,12 +474,12 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
 static int g_fe_bwd3_exp = 0;
 extern "C" void fabind_gcl_edge_fused_bwd3_set_exp(int m) { g_fe_bwd3_exp = m; }
 
-// launched from fabind_gcl_edge_fused_bwd (fused_edge.hip), variant 5 (96 edges per tile) / 6 (64)
+// launched from fabind_gcl_edge_fused_bwd (fused_edge.hip), variant 5
 int fe_bwd3_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipStream_t stream) {
-    FB_REQUIRE(a->d2scratch != nullptr, "fabind_gcl_edge_fused_bwd: the store-wave variants need d2scratch (2 x n_groups x 128 x H x 2 bytes)");
+    FB_REQUIRE(a->d2scratch != nullptr, "fabind_gcl_edge_fused_bwd: the store-wave form needs d2scratch (n_groups x 64 x H x 2 bytes)");
     FB_REQUIRE(a->bnd != nullptr, "fabind_gcl_edge_fused_bwd: bnd (ceil(E / tile) x 2 x H floats of scratch) is required");
     FB_REQUIRE(a->lddagg % 4 == 0 && ((uintptr_t)a->dagg & 15) == 0, "fabind_gcl_edge_fused_bwd: dagg must be 16-byte aligned with lddagg % 4 == 0");
-    const size_t lds = (size_t)bm * H * 2 + (size_t)8 * bm * sizeof(int) + (size_t)4 * H * sizeof(float);
+    const size_t lds = (size_t)2 * bm * H * 2 + (size_t)8 * bm * sizeof(int) + (size_t)4 * H * sizeof(float);
 #define FE_LAUNCH3_(HH, BB, KK, DD)                                                                                   \
     do {                                                                                                           \
         static bool set_ = false;                                                                                  \
@@ -502,20 +492,12 @@ int fe_bwd3_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipS
         hipLaunchKernelGGL((gcl_edge_fused_bwd3_kernel<HH, BB, KK, DD>), dim3(n_groups), dim3(HH + 64), lds, stream, *a, g_fe_bwd3_exp); \
     } while (0)
 #define FE_LAUNCH3(HH, BB, DD) do { if (a->p_drop > 0.f) FE_LAUNCH3_(HH, BB, true, DD); else FE_LAUNCH3_(HH, BB, false, DD); } while (0)
-    if (H < 128) bm = 64;                          // the tables are filled one row per compute thread: tile <= H (callers size bnd for 64 then)
-    if (bm == 96) {
-        if (a->dbg != nullptr && H == 512) FE_LAUNCH3(512, 96, true);
-        else if (H == 512) FE_LAUNCH3(512, 96, false); else if (H == 256) FE_LAUNCH3(256, 96, false);
-        else FE_LAUNCH3(128, 96, false);
-        hipLaunchKernelGGL((fe_boundary_fix_kernel<96>), dim3((a->E + 95) / 96), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
-                           a->bnd, a->dABrow, (unsigned)a->lddab);
-    } else {
-        if (a->dbg != nullptr && H == 512) FE_LAUNCH3(512, 64, true);
-        else if (H == 512) FE_LAUNCH3(512, 64, false); else if (H == 256) FE_LAUNCH3(256, 64, false);
-        else if (H == 128) FE_LAUNCH3(128, 64, false); else FE_LAUNCH3(64, 64, false);
-        hipLaunchKernelGGL((fe_boundary_fix_kernel<64>), dim3((a->E + 63) / 64), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
-                           a->bnd, a->dABrow, (unsigned)a->lddab);
-    }
+    FB_REQUIRE(bm == 64, "fabind_gcl_edge_fused_bwd: the store-wave form has 64-edge tiles");
+    if (a->dbg != nullptr && H == 512) FE_LAUNCH3(512, 64, true);
+    else if (H == 512) FE_LAUNCH3(512, 64, false); else if (H == 256) FE_LAUNCH3(256, 64, false);
+    else if (H == 128) FE_LAUNCH3(128, 64, false); else FE_LAUNCH3(64, 64, false);
+    hipLaunchKernelGGL((fe_boundary_fix_kernel<64>), dim3((a->E + 63) / 64), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
+                       a->bnd, a->dABrow, (unsigned)a->lddab);
 #undef FE_LAUNCH3
 #undef FE_LAUNCH3_
     FB_CHECK_LAUNCH();

@@ -370,12 +370,10 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     variant = lib.fabind_gcl_edge_fused_bwd_variant()
     if variant == 2 and H < 128:
         variant = 0                                          # the 128-edge tile needs >= 128 threads (one per edge in the row tables)
-    bm = {1: 64, 2: 128, 3: 128, 4: 64, 5: 96, 6: 64}.get(variant) or lib.fabind_gcl_edge_fused_bwd_tile()
-    if variant == 5 and H < 128:
-        bm = 64                                              # (csrc/fused_edge_bwd3.hip: tile <= H)
-    if variant in (5, 6):
-        # H/64 compute waves + one store wave per work-group, <= 168 VGPRs (three waves per SIMD): 12 waves per CU
-        per_cu = max(1, min(8, (160 * 1024) // (2 * bm * H + 16 * H + 32 * bm), 12 // (H // 64 + 1)))
+    bm = {1: 64, 2: 128, 3: 128, 4: 64, 5: 64}.get(variant) or lib.fabind_gcl_edge_fused_bwd_tile()
+    if variant == 5:
+        # H/64 compute waves + one store wave per work-group, <= 168 VGPRs (three waves per SIMD): 12 waves per CU; two [64][H] LDS tiles
+        per_cu = max(1, min(8, (160 * 1024) // (4 * bm * H + 16 * H + 32 * bm), 12 // (H // 64 + 1)))
     elif variant in (2, 3):
         # one in-place [128][H] tile (128 KiB at H = 512) and 2 waves per SIMD: one work-group per CU at H = 512, more below
         per_cu = max(1, min(8, (160 * 1024) // (2 * bm * H + 16 * H + 2048), 512 // H))
@@ -390,7 +388,7 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
         ng = int(EDGE_BWD_GROUPS)       # development knob (tools/probes/edge_bwd_variants.py)
     if ng >= 8:
         ng -= ng % 8                # a multiple of 8 selects the XCD-aware walk (csrc/fused_edge.hip)
-    d2scratch = torch.empty((2 if variant >= 3 else 1, ng, (128 if variant >= 5 else bm) * H), dtype=torch.bfloat16, device=dev) if variant else None
+    d2scratch = torch.empty((2 if variant >= 3 else 1, ng, bm * H), dtype=torch.bfloat16, device=dev) if variant else None
     bnd = torch.empty(((E + bm - 1) // bm * 2 + 2, H), dtype=torch.float32, device=dev)       # boundary runs (deterministic sums)
     buf = torch.empty((5, max(E, 1), H), dtype=torch.bfloat16, device=dev)
     S1, Mm, dT, dP2, dP1 = buf[0], buf[1], buf[2], buf[3], buf[4]
@@ -410,7 +408,7 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     a.ldab, a.lddagg, a.lddab, a.E = _ld(AB16), _ld(dagg), _ld(dAB), E
     a.p_drop, a.seed = float(p_drop), int(seed) & 0xFFFFFFFF
     a.dbg = ptr(EDGE_BWD_TIMES) if EDGE_BWD_TIMES is not None else None
-    _profiled("gcl_edge_fused_bwd%s_kernel<%d> E=%d (recompute + 4 chained H x H contractions per edge)" % ({1: "1", 2: "1_128", 3: "2_128", 4: "2_64", 5: "3_96", 6: "3_64"}.get(variant, ""), H, E),
+    _profiled("gcl_edge_fused_bwd%s_kernel<%d> E=%d (recompute + 4 chained H x H contractions per edge)" % ({1: "1", 2: "1_128", 3: "2_128", 4: "2_64", 5: "3"}.get(variant, ""), H, E),
               8.0 * E * H * H,
               lambda: check(_lib.load().fabind_gcl_edge_fused_bwd(ctypes.byref(a), H, ng, stream()),
                             "fabind_gcl_edge_fused_bwd"))

@@ -85,18 +85,18 @@ def test_segment_sum_and_scan():
         assert (out.cpu() - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max())
 
 
-@pytest.mark.parametrize("bm,p_drop", [(32, 0.0), (64, 0.0), (64, 0.25), (1, 0.0), (1, 0.25), (2, 0.0), (2, 0.25), (3, 0.0), (3, 0.25), (4, 0.0), (4, 0.25), (5, 0.0), (5, 0.25), (6, 0.0), (6, 0.25)])
+@pytest.mark.parametrize("bm,p_drop", [(32, 0.0), (64, 0.0), (64, 0.25), (1, 0.0), (1, 0.25), (2, 0.0), (2, 0.25), (3, 0.0), (3, 0.25), (4, 0.0), (4, 0.25), (5, 0.0), (5, 0.25)])
 @pytest.mark.parametrize("H", [64, 128, 512])
 def test_fused_edge_backward_matches_autograd(H, bm, p_drop):
     """csrc/fused_edge.hip backward (recompute + 4 chained contractions) vs torch autograd of the same bf16-rounded
     forward on the CPU: every gradient the kernel produces, including the partial column sums and both halves of dAB.
     bm = 32 / 64: the two-LDS-tile kernel of round 1 (variant 0); bm = 1: the single in-place tile kernel, two work-groups
     per CU (variant 1, a knob); bm = 2: one in-place tile of 128 edges, one work-group per CU (variant 2; falls back to variant 0
-    below 128 columns); bm = 3 / 4: the row-wise, operand-swapped kernel (csrc/fused_edge_bwd2.hip) at 128 / 64 edges per tile; bm = 5 / 6: the same with a store wave (csrc/fused_edge_bwd3.hip) at 96 / 64 edges per tile."""
+    below 128 columns); bm = 3 / 4: the row-wise, operand-swapped kernel (csrc/fused_edge_bwd2.hip) at 128 / 64 edges per tile; bm = 5: the same with a store wave (csrc/fused_edge_bwd3.hip), 64 edges per tile."""
     from fabind_amd import kernels as K, _lib
     dev = _dev()
-    _lib.load().fabind_gcl_edge_fused_bwd_set_variant(bm if bm in (1, 2, 3, 4, 5, 6) else 0)
-    _lib.load().fabind_gcl_edge_fused_bwd_set_tile(64 if bm in (1, 2, 3, 4, 5, 6) else bm)
+    _lib.load().fabind_gcl_edge_fused_bwd_set_variant(bm if bm in (1, 2, 3, 4, 5) else 0)
+    _lib.load().fabind_gcl_edge_fused_bwd_set_tile(64 if bm in (1, 2, 3, 4, 5) else bm)
     g = torch.Generator().manual_seed(100 + H)
     N = 300
     deg = torch.randint(0, 12, (N,), generator=g)

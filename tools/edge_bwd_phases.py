@@ -40,7 +40,7 @@ tt = K.EDGE_BWD_TIMES.cpu().tolist()
 names = ["P0 gather+silu", "tile stores (5)", "contractions (4)", "P1 epilogue", "P2 epilogue", "P3 dagg loads", "P3 epilogue",
          "P4 epilogue", "P5 gather+dsilu", "P6 column scan"]
 n_tiles = (E + bm - 1) // bm
-ngr = {0: 512 if bm == 32 else 256, 3: 256, 4: 512, 5: 256, 6: 256}[variant]
+ngr = {0: 512 if bm == 32 else 256, 3: 256, 4: 512, 5: 256}[variant]
 per = (n_tiles + ngr - 1) // ngr
 tot = sum(tt)
 for n, c in zip(names, tt):
