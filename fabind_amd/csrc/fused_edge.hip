@@ -839,7 +839,8 @@ extern "C" int fabind_gcl_edge_fused_bwd_set_tile(int bm) {
     return 0;
 }
 extern "C" int fabind_gcl_edge_fused_bwd_tile(void) { return g_fe_bwd_bm; }
-static int g_fe_bwd_variant = 0;     // 0 = two LDS tiles, one work-group per CU (default); 1 = single in-place tile, two per CU;
+static int g_fe_bwd_variant = 5;     // 5 = row-wise / operand-swapped in-place tile + store wave (default, fused_edge_bwd3.hip);
+                                     // 0 = two LDS tiles, one work-group per CU (round 1); 1 = single in-place tile, two per CU;
                                      // 2 = single in-place tile of 128 edges, one per CU (H >= 128; half the weight stream per edge)
 extern "C" int fabind_gcl_edge_fused_bwd_set_variant(int v) {
     FB_REQUIRE(v >= 0 && v <= 5,

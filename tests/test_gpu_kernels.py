@@ -139,7 +139,7 @@ def test_fused_edge_backward_matches_autograd(H, bm, p_drop):
     assert (agg_k.cpu() - agg.detach()).abs().max() <= 2e-2 * max(1.0, float(agg.abs().max()))
     assert (s_k[:, 0].cpu() - sv.detach()).abs().max() <= 2e-2 * max(1.0, float(sv.abs().max()))
     _lib.load().fabind_gcl_edge_fused_bwd_set_tile(64)
-    _lib.load().fabind_gcl_edge_fused_bwd_set_variant(0)
+    _lib.load().fabind_gcl_edge_fused_bwd_set_variant(5)
     names = ("dAB", "drh", "dw_r", "dW2", "db2", "dWc", "dbc", "dw3")
     refs = (ABf.grad, rhf.grad, wrf.grad, W2f.grad, b2f.grad, Wcf.grad, bcf.grad, w3f.grad)
     for name, got, ref in zip(names, out, refs):
