@@ -58,6 +58,8 @@ SIGNATURES = {
     "fabind_gcl_edge_fused_bwd_set_tile": [_i],
     "fabind_gcl_edge_fused_bwd_tile": [],
     "fabind_gcl_edge_fused_bwd_set_variant": [_i],
+    "fabind_gcl_edge_fused_set_variant": [_i],
+    "fabind_gcl_edge_fused_variant": [],
     "fabind_gcl_edge_fused_bwd_variant": [],
     "fabind_row_stats": [_vp, _i, _i, _f, _i, _i, _vp, _vp, _vp],
     "fabind_layernorm_rows": [_vp, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _i, _i, _vp],
@@ -145,6 +147,9 @@ def load():
     if "FABIND_EDGE_BWD_VARIANT" in os.environ:          # development knobs for same-box A/B runs (tools/probes)
         lib.fabind_gcl_edge_fused_bwd_set_variant.argtypes = [ctypes.c_int]
         lib.fabind_gcl_edge_fused_bwd_set_variant(int(os.environ["FABIND_EDGE_BWD_VARIANT"]))
+    if os.environ.get("FABIND_EDGE_FWD_VARIANT"):
+        lib.fabind_gcl_edge_fused_set_variant.argtypes = [ctypes.c_int]
+        lib.fabind_gcl_edge_fused_set_variant(int(os.environ["FABIND_EDGE_FWD_VARIANT"]))
     if "FABIND_EDGE_XCD" in os.environ:
         lib.fabind_gcl_edge_fused_set_xcd_aware(int(os.environ["FABIND_EDGE_XCD"]))
     for name, argt in SIGNATURES.items():

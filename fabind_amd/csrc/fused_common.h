@@ -45,19 +45,28 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 // SWZ: row bits XOR-ed into the 16-byte chunk index of the LDS tile.  With 7 (round 1) rows r and r + 8 of a 16-row fragment sit in
 // the same 16-byte slot modulo 256 B, and the 16-lane groups of ds_read_b128 see a 2-way bank conflict on every A-fragment read
 // (47 % of the LDS cycles of the round-1 kernels were conflict cycles); 15 spreads a fragment's 16 rows over all 16 slots.
+// wmode (profiling builds only; 0 everywhere else and folded away): 1 = every k-step re-reads the wave's first fragments (L1 hits),
+// 2 = no weight loads at all -- how much of a contraction is the weight stream?
 template <int H, int MI, bool SWAP = false, int SWZ = 7>
 __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* __restrict__ Wp, int wave, int lane,
-                                               f32x4_t (&acc)[MI][4]) {
-    constexpr int NKS = H / 32, NG = H / 16;
+                                               f32x4_t (&acc)[MI][4], const int wmode = 0) {
+    constexpr int NKS = H / 32;
+    const int NG = wmode == 1 ? 0 : H / 16;
     const int fr = lane & 15, fq = lane >> 4;
     const bf16x8_t* wp = (const bf16x8_t*)Wp + ((size_t)wave * 4) * 64 + lane;
     bf16x8_t b0[4], b1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) b0[j] = wp[(size_t)j * 64];
+    if (wmode == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[j] = b0[j];
+    }
 #pragma unroll 1
     for (int ks = 0; ks < NKS; ks += 2) {
+        if (wmode != 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b1[j] = wp[((size_t)(ks + 1) * NG + j) * 64];
+            for (int j = 0; j < 4; ++j) b1[j] = wp[((size_t)(ks + 1) * NG + j) * 64];
+        }
         bf16x8_t a[MI];
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -72,7 +81,7 @@ __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* _
                 acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a[i], acc[i][j], 0, 0, 0)
                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0[j], acc[i][j], 0, 0, 0);
         FE_PRIO(0);
-        if (ks + 2 < NKS) {
+        if (ks + 2 < NKS && wmode != 2) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) b0[j] = wp[((size_t)(ks + 2) * NG + j) * 64];
         }
@@ -203,3 +212,7 @@ struct FabindEdgeBwdArgs;
 int fe_bwd2_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipStream_t stream);
 // fused_edge_bwd3.hip: the same with a store wave (variants 5 and 6)
 int fe_bwd3_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipStream_t stream);
+// fused_edge_fwd2.hip: the row-wise / operand-swapped forward (variant 1 of fabind_gcl_edge_fused)
+int fe_fwd2_launch(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat, const float* w_r,
+                   const void* W2p, const float* b2, const void* Wcp, const float* bc, const float* w3, int E, float* agg,
+                   float* s_out, uint32_t thr16, float dscale, unsigned seed, float* bnd, int xcd_aware, hipStream_t stream);

@@ -18,6 +18,13 @@
 
 static int g_fe_xcd_aware = 1;       // development knob: XCD-aware tile order (1) vs linear / grid-stride order (0)
 extern "C" void fabind_gcl_edge_fused_set_xcd_aware(int on) { g_fe_xcd_aware = on ? 1 : 0; }
+static int g_fe_fwd_variant = 1;     // 1 = row-wise gather / operand-swapped epilogues (fused_edge_fwd2.hip, default); 0 = round 1's kernel below
+extern "C" int fabind_gcl_edge_fused_set_variant(int v) {
+    FB_REQUIRE(v == 0 || v == 1, "fabind_gcl_edge_fused_set_variant: 0 (round-1 kernel) or 1 (row-wise / operand-swapped)");
+    g_fe_fwd_variant = v;
+    return 0;
+}
+extern "C" int fabind_gcl_edge_fused_variant(void) { return g_fe_fwd_variant; }
 
 template <int H>
 __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __restrict__ AB, int ldab, const int* __restrict__ row,
@@ -165,6 +172,11 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
     FB_REQUIRE(ldab % 8 == 0, "fabind_gcl_edge_fused: ldab % 8");
     const dim3 grid((((E + FE_BM - 1) / FE_BM + 7) / 8) * 8);          // 8 x ceil(tiles / 8): see the XCD-aware tile order in the kernel
     const size_t lds = (size_t)FE_BM * H * 2 + FE_BM * sizeof(int) + (size_t)(H / 64) * FE_BM * sizeof(float);
+    if (g_fe_fwd_variant == 1) {
+        const int rc = fe_fwd2_launch(AB, ldab, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, E, agg, s_out, thr16, dscale, seed, bnd,
+                                      g_fe_xcd_aware, stream);
+        if (rc) return rc;
+    } else
 #define FE_LAUNCH(HH)                                                                                              \
     do {                                                                                                           \
         static bool set_ = false;                                                                                  \

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
     //   chunk = (wave*8 + j*2 + (cq>>1)) ^ (fr & SWZ) = cx ^ (j*2)
     const int cx = (wave * 8 + (cq >> 1)) ^ (fr & SWZ);
     const int lbase = fr * H + (cq & 1) * 4;
+    const int wmode = DBG ? ((xf >> 2) & 3) : 0;                  // profiling build: weight-stream experiment of fe_gemm_rolled
 #define FE_QOFF(i, j) (lbase + (i) * 16 * H + ((cx ^ ((j) * 2)) * 8))
     const int fcol = wave * 64 + cq * 4;                          // first feature of the quad of block j: fcol + j*16
     long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
         // ---- P1: pre2 = S1 W2^T + b2;  M -> tile in place;  silu'(pre2) -> scratch
         f32x4_t acc[MI][4];
         fe_zero(acc);
-        fe_gemm_rolled<H, MI, true, SWZ>(sX, W2p, wave, lane, acc);
+        fe_gemm_rolled<H, MI, true, SWZ>(sX, W2p, wave, lane, acc, wmode);
         __syncthreads();                                          // every wave has finished reading S1 (and the store wave has copied it)
         FE_TICK(2)
         {
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
 
         // ---- P2: pre3 = M Wc^T + bc;  dT = ds * w3 * silu'(pre3) -> tile in place
         fe_zero(acc);
-        fe_gemm_rolled<H, MI, true, SWZ>(sX, Wcp, wave, lane, acc);
+        fe_gemm_rolled<H, MI, true, SWZ>(sX, Wcp, wave, lane, acc, wmode);
         __syncthreads();
         FE_TICK(2)
         {
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
         //      block ahead inside the epilogue: loading dagg into the accumulators first put its latency in front of the contraction)
         fe_zero(acc);
         FE_TICK(5)
-        fe_gemm_rolled<H, MI, true, SWZ>(sX, WcTp, wave, lane, acc);
+        fe_gemm_rolled<H, MI, true, SWZ>(sX, WcTp, wave, lane, acc, wmode);
         __syncthreads();
         FE_TICK(2)
         {
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
 
         // ---- P4: dS1 = dP2 W2 -> tile in place
         fe_zero(acc);
-        fe_gemm_rolled<H, MI, true, SWZ>(sX, W2Tp, wave, lane, acc);
+        fe_gemm_rolled<H, MI, true, SWZ>(sX, W2Tp, wave, lane, acc, wmode);
         __syncthreads();
         FE_TICK(2)
         uint4 gd[NIT];                                            // silu'(pre1) of this lane's row-wise chunks, back from the scratch slab for P5

@@ -211,6 +211,9 @@ void fabind_gcl_edge_fused_bwd3_set_exp(int mask);
 /* development knob: 1 (default) = XCD-aware tile order in the fused edge kernels (XCD x owns the x-th eighth of the tiles, i.e.
  * whole complexes); 0 = linear tile order (forward) / grid-stride walk (backward).  Results do not depend on it. */
 void fabind_gcl_edge_fused_set_xcd_aware(int on);
+/* Forward kernel variant: 1 (default) = row-wise gather + operand-swapped epilogues (csrc/fused_edge_fwd2.hip), 0 = round 1's kernel. */
+int fabind_gcl_edge_fused_set_variant(int v);
+int fabind_gcl_edge_fused_variant(void);
 
 /* Fused pair-embedding update of FABind+'s CrossAttentionModule (FABind_plus/fabind/models/cross_att.py:42-44 with
  * model_utils.py InteractionModule / MLPwithLastAct), bf16, inference (no adjoint: training runs the separate launches):

@@ -34,6 +34,8 @@ for k, evs in K.PROFILE.items():
     print("%-90s %.3f ms" % (k[:90], sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs)))
 K.PROFILE = None
 print("whole backward op (kernel + 2 weight-gradient contractions + sending-side reduction): %.3f ms" % ms)
+if len(_s.argv) > 3:
+    _lib.load().fabind_gcl_edge_fused_bwd3_set_exp(int(_s.argv[3]))          # skip mask (variant 5; bits 2-3 = weight-stream experiment)
 K.EDGE_BWD_TIMES = torch.zeros(12, dtype=torch.int64, device=dev)
 run(); torch.cuda.synchronize()
 tt = K.EDGE_BWD_TIMES.cpu().tolist()

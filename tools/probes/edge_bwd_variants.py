@@ -26,6 +26,7 @@ W2p, Wcp = K.pack_frag(W2), K.pack_frag(Wc)
 fwd = lambda: K.gcl_edge_fused(AB, H, g.row_ctx, g.col_ctx, rh, w_r, W2p, b2, Wcp, bc, w3, N)
 lib = _lib.load()
 outs = {}
+fouts = {}
 for rnd in range(3):
     for v in (0, 3, 5):
         lib.fabind_gcl_edge_fused_bwd_set_variant(v)
@@ -36,11 +37,14 @@ for rnd in range(3):
                 print("round %d variant %d  %-60s %.3f ms" % (rnd, v, k[:60], sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs)), flush=True)
         K.PROFILE = None
         outs[v] = run()
-    K.PROFILE = {}
-    timeit(fwd, 5)
-    for k, evs in K.PROFILE.items():
-        print("round %d forward    %-60s %.3f ms" % (rnd, k[:60], sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs)), flush=True)
-    K.PROFILE = None
+    for fv in (0, 1):
+        lib.fabind_gcl_edge_fused_set_variant(fv)
+        K.PROFILE = {}
+        timeit(fwd, 5)
+        for k, evs in K.PROFILE.items():
+            print("round %d forward %d  %-60s %.3f ms" % (rnd, fv, k[:60], sum(a.elapsed_time(b) for a, b, _ in evs) / len(evs)), flush=True)
+        K.PROFILE = None
+        fouts[fv] = fwd()
 lib.fabind_gcl_edge_fused_bwd_set_variant(1)
 for ng in (128, 256, 384, 512):                       # does a second work-group per CU add throughput?
     K.EDGE_BWD_GROUPS = ng
@@ -55,3 +59,5 @@ lib.fabind_gcl_edge_fused_bwd_set_variant(0)
 for v in (3, 5):
     for n, a, b in zip(("dAB", "drh", "dw_r", "dW2", "db2", "dWc", "dbc", "dw3"), outs[0], outs[v]):
         print("variant %d vs 0  %-5s max rel diff %.2e" % (v, n, float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))))
+for n, a, b in zip(("agg", "s"), fouts[0], fouts[1]):
+    print("forward variant 1 vs 0  %-4s max rel diff %.2e" % (n, float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))))
