@@ -152,7 +152,13 @@ __device__ __forceinline__ void fe_zero(f32x4_t (&acc)[MI][4]) {
 // bf16 rounding downstream).  Returns sum_rows rh[row] * value (the d w_r partial of the backward) when WITH_RH.
 template <int H, bool WITH_RH, int BM_, int SWZ = 7>
 __device__ __forceinline__ float fe_scan_rows(const bf16_t* sX, const int* sRow, const float* sRh, int ne, bool head_cont,
-                                              bool tail_cont, float* out, unsigned ld, float* bnd_tile, int c) {
+                                              bool tail_cont, float* out, unsigned ld, float* bnd_tile, int c,
+                                              bf16_t* out16 = nullptr, unsigned ld16 = 0) {
+    // complete runs go to out (fp32, if given) and / or out16 (bf16, if given)
+    auto put = [&](int node, float v) {
+        if (out) out[(unsigned)node * ld + c] = v;
+        if (out16) out16[(unsigned)node * ld16 + c] = f32_to_bf16(v);
+    };
     float run = 0.f, pwr = 0.f;
     int cur = sRow[0];
     bool first = true;
@@ -170,7 +176,7 @@ __device__ __forceinline__ float fe_scan_rows(const bf16_t* sX, const int* sRow,
         for (int u = 0; u < 8; ++u) {
             if (rw0 + u < ne) {
                 if (rr[u] != cur) {
-                    if (first && head_cont) bnd_tile[c] = run; else out[(unsigned)cur * ld + c] = run;
+                    if (first && head_cont) bnd_tile[c] = run; else put(cur, run);
                     run = 0.f; cur = rr[u]; first = false;
                 }
                 run += v[u];
@@ -181,7 +187,7 @@ __device__ __forceinline__ float fe_scan_rows(const bf16_t* sX, const int* sRow,
     if (ne > 0) {
         if (first && head_cont) bnd_tile[c] = run;            // the whole tile continues the previous tile's node
         else if (tail_cont) bnd_tile[H + c] = run;
-        else out[(unsigned)cur * ld + c] = run;
+        else put(cur, run);
     }
     return pwr;
 }
@@ -189,7 +195,7 @@ __device__ __forceinline__ float fe_scan_rows(const bf16_t* sX, const int* sRow,
 // One work-group (H threads) per tile: the tile where a node's tile-spanning run STARTS adds up its pieces in tile order.
 template <int BM>
 __global__ void fe_boundary_fix_kernel(const int* __restrict__ row, int E, int H, const float* __restrict__ bnd, float* out,
-                                       unsigned ld) {
+                                       unsigned ld, bf16_t* out16 = nullptr, unsigned ld16 = 0) {
     const int t = blockIdx.x, e0 = t * BM, ne = min(BM, E - e0);
     if (ne <= 0 || e0 + ne >= E) return;
     const int r = row[e0 + ne - 1];
@@ -203,7 +209,8 @@ __global__ void fe_boundary_fix_kernel(const int* __restrict__ row, int E, int H
             const bool through = row[f0 + fn - 1] == r && f0 + fn < E && row[f0 + fn] == r;
             if (!through) break;
         }
-        out[(unsigned)r * ld + c] = sum;
+        if (out) out[(unsigned)r * ld + c] = sum;
+        if (out16) out16[(unsigned)r * ld16 + c] = f32_to_bf16(sum);
     }
 }
 
@@ -215,4 +222,4 @@ int fe_bwd3_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipS
 // fused_edge_fwd2.hip: the row-wise / operand-swapped forward (variant 1 of fabind_gcl_edge_fused)
 int fe_fwd2_launch(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat, const float* w_r,
                    const void* W2p, const float* b2, const void* Wcp, const float* bc, const float* w3, int E, float* agg,
-                   float* s_out, uint32_t thr16, float dscale, unsigned seed, float* bnd, int xcd_aware, hipStream_t stream);
+                   float* s_out, uint32_t thr16, float dscale, unsigned seed, float* bnd, void* agg16, int xcd_aware, hipStream_t stream);

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
                                                            const float* __restrict__ b2, const bf16_t* __restrict__ Wcp,
                                                            const float* __restrict__ bc, const float* __restrict__ w3, int E,
                                                            float* agg, float* s_out, uint32_t thr16, float dscale,
-                                                           uint32_t seed, float* bnd, int xcd_aware) {
+                                                           uint32_t seed, float* bnd, bf16_t* agg16, int xcd_aware) {
     constexpr int NW = H / 64;                      // waves; wave w owns output columns [64w, 64w+64)
     constexpr int CPT = FE_BM * H / H;              // gather: elements per thread = 64 (one 64-column chunk of one edge)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
     {
         const bool head_cont = e0 > 0 && row[e0 - 1] == sRow[0];
         const bool tail_cont = e0 + ne < E && row[e0 + ne] == sRow[ne - 1];
-        (void)fe_scan_rows<H, false, FE_BM>(sX, sRow, nullptr, ne, head_cont, tail_cont, agg, (unsigned)H, bnd + (size_t)tile * 2 * H, tid);
+        (void)fe_scan_rows<H, false, FE_BM>(sX, sRow, nullptr, ne, head_cont, tail_cont, agg, (unsigned)H, bnd + (size_t)tile * 2 * H, tid, agg16, (unsigned)H);
     }
 
     // ---- phase 3: s = w3 . silu(M Wc^T + bc)
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
 extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
                                      const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
                                      const float* w3, int E, float* agg, float* s_out, float p_drop, unsigned seed,
-                                     float* bnd, hipStream_t stream) {
+                                     float* bnd, void* agg16, hipStream_t stream) {
     if (E <= 0) return 0;
     FB_REQUIRE(bnd != nullptr, "fabind_gcl_edge_fused: bnd (ceil(E/64) x 2 x H floats of scratch) is required");
     FB_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "fabind_gcl_edge_fused: p_drop in [0, 1)");
@@ -174,7 +174,7 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
     const size_t lds = (size_t)FE_BM * H * 2 + FE_BM * sizeof(int) + (size_t)(H / 64) * FE_BM * sizeof(float);
     if (g_fe_fwd_variant == 1) {
         const int rc = fe_fwd2_launch(AB, ldab, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, E, agg, s_out, thr16, dscale, seed, bnd,
-                                      g_fe_xcd_aware, stream);
+                                      agg16, g_fe_xcd_aware, stream);
         if (rc) return rc;
     } else
 #define FE_LAUNCH(HH)                                                                                              \
@@ -183,12 +183,12 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
         if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
         hipLaunchKernelGGL((gcl_edge_fused_kernel<HH>), grid, dim3(HH), lds, stream, (const bf16_t*)AB, ldab, row, col, rhohat, \
                            w_r, (const bf16_t*)W2p, b2, (const bf16_t*)Wcp, bc, w3, E, agg, s_out, thr16, dscale, \
-                           (uint32_t)seed, bnd, g_fe_xcd_aware);                                                   \
+                           (uint32_t)seed, bnd, (bf16_t*)agg16, g_fe_xcd_aware);                                  \
     } while (0)
     if (H == 512) FE_LAUNCH(512); else if (H == 256) FE_LAUNCH(256); else if (H == 128) FE_LAUNCH(128); else FE_LAUNCH(64);
 #undef FE_LAUNCH
     hipLaunchKernelGGL((fe_boundary_fix_kernel<FE_BM>), dim3((E + FE_BM - 1) / FE_BM), dim3(H < 256 ? H : 256), 0, stream, row, E, H,
-                       bnd, agg, (unsigned)H);
+                       bnd, agg, (unsigned)H, (bf16_t*)agg16, (unsigned)H);
     FB_CHECK_LAUNCH();
     return 0;
 }
@@ -871,6 +871,7 @@ extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a_in, int H, i
     FB_REQUIRE(a->ldab % 8 == 0, "fabind_gcl_edge_fused_bwd: ldab % 8");
     FB_REQUIRE(a->p_drop >= 0.f && a->p_drop < 1.f, "fabind_gcl_edge_fused_bwd: p_drop in [0, 1)");
     if (g_fe_bwd_variant == 5) return fe_bwd3_launch(a, H, 64, n_groups, stream);
+    FB_REQUIRE(a->dAB16 == nullptr, "fabind_gcl_edge_fused_bwd: dAB16 (bf16 receiving-side sums) exists in variant 5 only");
     if (g_fe_bwd_variant == 3 || g_fe_bwd_variant == 4) return fe_bwd2_launch(a, H, g_fe_bwd_variant == 3 ? 128 : 64, n_groups, stream);
     if (g_fe_bwd_variant == 1 || (g_fe_bwd_variant == 2 && H >= 128)) {
         const int bm1 = g_fe_bwd_variant == 2 ? 128 : 64;

@@ -452,8 +452,8 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
         if (!(xf & 16)) {
             const bool head_cont = e0 > 0 && p.row[e0 - 1] == sRow[0];
             const bool tail_cont = e0 + ne < p.E && p.row[e0 + ne] == sRow[ne - 1];
-            sPart[3 * H + tid] += fe_scan_rows<H, true, BM, SWZ>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dABrow, (unsigned)p.lddab,
-                                                         p.bnd + (size_t)tile * 2 * H, tid);
+            sPart[3 * H + tid] += fe_scan_rows<H, true, BM, SWZ>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dAB16 ? nullptr : p.dABrow, (unsigned)p.lddab,
+                                                         p.bnd + (size_t)tile * 2 * H, tid, (bf16_t*)p.dAB16, (unsigned)p.lddab16);
         }
         if (has_next) commit_tables(hb ^ 1);
         __syncthreads();                                          // the next tile overwrites the tile; its tables are in place
@@ -498,7 +498,7 @@ int fe_bwd3_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipS
     else if (H == 512) FE_LAUNCH3(512, 64, false); else if (H == 256) FE_LAUNCH3(256, 64, false);
     else if (H == 128) FE_LAUNCH3(128, 64, false); else FE_LAUNCH3(64, 64, false);
     hipLaunchKernelGGL((fe_boundary_fix_kernel<64>), dim3((a->E + 63) / 64), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
-                       a->bnd, a->dABrow, (unsigned)a->lddab);
+                       a->bnd, a->dAB16 ? nullptr : a->dABrow, (unsigned)a->lddab, (bf16_t*)a->dAB16, (unsigned)a->lddab16);
 #undef FE_LAUNCH3
 #undef FE_LAUNCH3_
     FB_CHECK_LAUNCH();

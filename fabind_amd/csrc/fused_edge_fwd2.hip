@@ -29,7 +29,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused2_kernel(const bf16_t* __r
                                                             const float* __restrict__ b2, const bf16_t* __restrict__ Wcp,
                                                             const float* __restrict__ bc, const float* __restrict__ w3, int E,
                                                             float* agg, float* s_out, uint32_t thr16, float dscale,
-                                                            uint32_t seed, float* bnd, int xcd_aware) {
+                                                            uint32_t seed, float* bnd, bf16_t* agg16, int xcd_aware) {
     constexpr int BM = FE_BM, MI = BM / 16;
     constexpr int NW = H / 64;
     constexpr int CH = H / 8;                                     // 16-byte chunks per edge row
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused2_kernel(const bf16_t* __r
     {
         const bool head_cont = e0 > 0 && row[e0 - 1] == sRow[0];
         const bool tail_cont = e0 + ne < E && row[e0 + ne] == sRow[ne - 1];
-        (void)fe_scan_rows<H, false, BM, SWZ>(sX, sRow, nullptr, ne, head_cont, tail_cont, agg, (unsigned)H, bnd + (size_t)tile * 2 * H, tid);
+        (void)fe_scan_rows<H, false, BM, SWZ>(sX, sRow, nullptr, ne, head_cont, tail_cont, agg, (unsigned)H, bnd + (size_t)tile * 2 * H, tid, agg16, (unsigned)H);
     }
 
     // ---- P3: s = w3 . silu(M Wc^T + bc)
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused2_kernel(const bf16_t* __r
 // launched from fabind_gcl_edge_fused (fused_edge.hip) when the forward variant is 1
 int fe_fwd2_launch(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat, const float* w_r,
                    const void* W2p, const float* b2, const void* Wcp, const float* bc, const float* w3, int E, float* agg,
-                   float* s_out, uint32_t thr16, float dscale, unsigned seed, float* bnd, int xcd_aware, hipStream_t stream) {
+                   float* s_out, uint32_t thr16, float dscale, unsigned seed, float* bnd, void* agg16, int xcd_aware, hipStream_t stream) {
     const dim3 grid((((E + FE_BM - 1) / FE_BM + 7) / 8) * 8);
     const size_t lds = (size_t)FE_BM * H * 2 + 3 * FE_BM * sizeof(int) + (size_t)(H / 64) * FE_BM * sizeof(float);
 #define FW_LAUNCH_(HH, DD)                                                                                         \
@@ -178,7 +178,7 @@ int fe_fwd2_launch(const void* AB, int ldab, int H, const int* row, const int* c
         if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused2_kernel<HH, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
         hipLaunchKernelGGL((gcl_edge_fused2_kernel<HH, DD>), grid, dim3(HH), lds, stream, (const bf16_t*)AB, ldab, row, col, rhohat, \
                            w_r, (const bf16_t*)W2p, b2, (const bf16_t*)Wcp, bc, w3, E, agg, s_out, thr16, dscale, \
-                           (uint32_t)seed, bnd, xcd_aware);                                                        \
+                           (uint32_t)seed, bnd, (bf16_t*)agg16, xcd_aware);                                       \
     } while (0)
 #define FW_LAUNCH(HH) do { if (thr16) FW_LAUNCH_(HH, true); else FW_LAUNCH_(HH, false); } while (0)
     if (H == 512) FW_LAUNCH(512); else if (H == 256) FW_LAUNCH(256); else if (H == 128) FW_LAUNCH(128); else FW_LAUNCH(64);

@@ -200,7 +200,7 @@ __device__ __forceinline__ void ss_accum(const void* __restrict__ Z, int z_dt, i
 template <int NSLAB>
 __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict__ Z, int z_dt, int ldz, int H,
                                                           const int* rowptr, const int* eidx, int act, float* out,
-                                                          int ldo, int n_rows) {
+                                                          int ldo, int n_rows, bf16_t* out16, int ldo16) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
@@ -216,9 +216,12 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict
     for (int s = 0; s < NSLAB; ++s) {
         const int c = s * 512 + lane * 8;
         if (c < H) {
-            float* o = out + (size_t)r * ldo + c;
-            *(float4*)o = make_float4(acc[s].v[0], acc[s].v[1], acc[s].v[2], acc[s].v[3]);
-            *(float4*)(o + 4) = make_float4(acc[s].v[4], acc[s].v[5], acc[s].v[6], acc[s].v[7]);
+            if (out) {
+                float* o = out + (size_t)r * ldo + c;
+                *(float4*)o = make_float4(acc[s].v[0], acc[s].v[1], acc[s].v[2], acc[s].v[3]);
+                *(float4*)(o + 4) = make_float4(acc[s].v[4], acc[s].v[5], acc[s].v[6], acc[s].v[7]);
+            }
+            if (out16) st8_any(out16, FB_DT_BF16, (size_t)r * ldo16 + c, acc[s]);
         }
     }
 }
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict
 template <int NSLAB>
 __global__ __launch_bounds__(1024) void segment_sum_heavy_kernel(const void* __restrict__ Z, int z_dt, int ldz, int H,
                                                                  const int* rowptr, const int* eidx, int act, float* out,
-                                                                 int ldo, int n_rows) {
+                                                                 int ldo, int n_rows, bf16_t* out16, int ldo16) {
     __shared__ F8 part[15][NSLAB * 64];
     __shared__ int heavy[1024];
     __shared__ int n_heavy;
@@ -263,9 +266,12 @@ __global__ __launch_bounds__(1024) void segment_sum_heavy_kernel(const void* __r
                 }
                 const int c = s * 512 + lane * 8;
                 if (c < H) {
-                    float* o = out + (size_t)r * ldo + c;
-                    *(float4*)o = make_float4(acc[s].v[0], acc[s].v[1], acc[s].v[2], acc[s].v[3]);
-                    *(float4*)(o + 4) = make_float4(acc[s].v[4], acc[s].v[5], acc[s].v[6], acc[s].v[7]);
+                    if (out) {
+                        float* o = out + (size_t)r * ldo + c;
+                        *(float4*)o = make_float4(acc[s].v[0], acc[s].v[1], acc[s].v[2], acc[s].v[3]);
+                        *(float4*)(o + 4) = make_float4(acc[s].v[4], acc[s].v[5], acc[s].v[6], acc[s].v[7]);
+                    }
+                    if (out16) st8_any(out16, FB_DT_BF16, (size_t)r * ldo16 + c, acc[s]);
                 }
             }
         }
@@ -274,19 +280,23 @@ __global__ __launch_bounds__(1024) void segment_sum_heavy_kernel(const void* __r
 }
 
 extern "C" int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, const int* eidx,
-                                  int n_rows, int n_edges, int act, float* out, int ldo, hipStream_t stream) {
+                                  int n_rows, int n_edges, int act, float* out, int ldo, void* out16v, int ldo16,
+                                  hipStream_t stream) {
+    bf16_t* out16 = (bf16_t*)out16v;
     FB_REQUIRE(H % 8 == 0 && ldz % 8 == 0 && ldo % 4 == 0, "fabind_segment_sum: H/ldz must be multiples of 8, ldo of 4");
     FB_REQUIRE(H <= 1024, "fabind_segment_sum: H <= 1024");
+    FB_REQUIRE(out != nullptr || out16 != nullptr, "fabind_segment_sum: no output");
     FB_REQUIRE(((uintptr_t)Z % 16 == 0) && ((uintptr_t)out % 16 == 0), "fabind_segment_sum: 16-byte alignment");
+    FB_REQUIRE(out16 == nullptr || (ldo16 % 8 == 0 && (uintptr_t)out16 % 16 == 0), "fabind_segment_sum: out16 needs 16-byte alignment and ldo16 % 8 == 0");
     if (n_rows <= 0) return 0;
     (void)n_edges;
     const dim3 g((n_rows + 3) / 4), gh((n_rows + 1023) / 1024);
     if (H <= 512) {
-        hipLaunchKernelGGL((segment_sum_kernel<1>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows);
-        hipLaunchKernelGGL((segment_sum_heavy_kernel<1>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows);
+        hipLaunchKernelGGL((segment_sum_kernel<1>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16);
+        hipLaunchKernelGGL((segment_sum_heavy_kernel<1>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16);
     } else {
-        hipLaunchKernelGGL((segment_sum_kernel<2>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows);
-        hipLaunchKernelGGL((segment_sum_heavy_kernel<2>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows);
+        hipLaunchKernelGGL((segment_sum_kernel<2>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16);
+        hipLaunchKernelGGL((segment_sum_heavy_kernel<2>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16);
     }
     FB_CHECK_LAUNCH();
     return 0;

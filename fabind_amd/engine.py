@@ -420,7 +420,7 @@ def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv, pdrop=0.0, pdrop_r
     ab32 = ops.linear(h16, p["W_ab32"], p["b_ab32"])                                   # [N,128] (a32|0|b32|0)
     hd = ops.pair_hadamard(a0b0, H, ab32, 64, g.red_p, g.red_c)                        # [n_red, H+64]
     bias_part = ops.linear_rowdot(hd, p["Wcomp1"], p["bcomp1"], p["u"], act_epi=K.ACT_RELU)
-    qkv = ops.linear(h16, p["Wqkv"], p["bqkv"])                                        # [N,3H]
+    qkv = ops.linear(h16, p["Wqkv"], p["bqkv"], want16=True)                           # [N,3H] (+ bf16 copy: V is the next operand)
     d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay, g.int_by_col)
     # cv = Linear(V) [N,H] (egnn.py:225) is evaluated inside inter_attn (its adjoint accumulates into dqkv in place)
     h_new, x_new, alpha = ops.inter_attn(qkv, None, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["wcr"],

@@ -187,14 +187,15 @@ def edge_ln_concat(h, row, col, rhohat, w, b, out_dtype, pad_to, eps=1e-5):
     return y
 
 
-def segment_sum(Z, rowptr, n_rows, act=ACT_NONE, eidx=None, out=None):
+def segment_sum(Z, rowptr, n_rows, act=ACT_NONE, eidx=None, out=None, out16=None):
+    """out16 (bf16 [n_rows, >= H], optional): the result as a bf16 operand; given alone, no fp32 result is written."""
     H = Z.shape[1]
-    if out is None:
+    if out is None and out16 is None:
         out = torch.empty((n_rows, H), dtype=torch.float32, device=Z.device)
     check(_lib.load().fabind_segment_sum(ptr(Z), dt_code(Z.dtype), _ld(Z), H, ptr(rowptr), ptr(eidx), n_rows,
-                                         Z.shape[0] if eidx is None else eidx.numel(), act, ptr(out), _ld(out),
-                                         stream()), "fabind_segment_sum")
-    return out
+                                         Z.shape[0] if eidx is None else eidx.numel(), act, ptr(out), _ld(out) if out is not None else 0,
+                                         ptr(out16), _ld(out16) if out16 is not None else 0, stream()), "fabind_segment_sum")
+    return out if out is not None else out16
 
 
 def coord_update(x, d, s_part, rowptr, mean, clampv, weight=None, want_s=False):
@@ -286,17 +287,19 @@ def pack_frag(W):
     return W.to(torch.bfloat16).view(N // 16, 16, Kd // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
 
 
-def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows, p_drop=0.0, seed=0):
+def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows, p_drop=0.0, seed=0, want16=False):
+    """want16: also return the aggregated messages as bf16 (the node MLP's operand), written by the same kernels."""
     E = row.shape[0]
     agg = torch.zeros((n_rows, H), dtype=torch.float32, device=AB16.device)
+    agg16 = torch.zeros((n_rows, H), dtype=torch.bfloat16, device=AB16.device) if want16 else None
     s = torch.empty((max(E, 1), 1), dtype=torch.float32, device=AB16.device)
     bnd = torch.empty(((E + 63) // 64 * 2 + 2, H), dtype=torch.float32, device=AB16.device)      # boundary runs (deterministic sums)
     _profiled("gcl_edge_fused_kernel<%d> E=%d (gather + 2 chained H x H contractions + segment-sum per edge)" % (H, E), 4.0 * E * H * H,
               lambda: check(_lib.load().fabind_gcl_edge_fused(ptr(AB16), _ld(AB16), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
                                                               ptr(W2p), ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s),
-                                                              float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd), stream()),
+                                                              float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd), ptr(agg16), stream()),
                             "fabind_gcl_edge_fused"))
-    return agg, s[:E]
+    return (agg, s[:E], agg16) if want16 else (agg, s[:E])
 
 
 def edge_lnfold(AB16, Kp, H, row, col, rho, stat, eps, w_r, c_r, c_c, dvec, p_drop=0.0, seed=0):
@@ -358,7 +361,7 @@ EDGE_BWD_TIMES = None   # set to an int64[12] device tensor to collect per-phase
 
 
 def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, dagg, colptr, perm, p_drop=0.0, seed=0,
-                       want_edges=False):
+                       want_edges=False, dab_bf16=False):
     """Adjoint of gcl_edge_fused (csrc/fused_edge.hip): returns dAB [N,2H] fp32, drh [E], dw_r, dW2, db2, dWc, dbc, dw3.
     The five [E,H] bf16 operands it writes (S1, M, dT, dP2 for the weight gradients, dP1 for the sending-side
     reduction) are scratch that is released on return."""
@@ -392,7 +395,8 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     bnd = torch.empty(((E + bm - 1) // bm * 2 + 2, H), dtype=torch.float32, device=dev)       # boundary runs (deterministic sums)
     buf = torch.empty((5, max(E, 1), H), dtype=torch.bfloat16, device=dev)
     S1, Mm, dT, dP2, dP1 = buf[0], buf[1], buf[2], buf[3], buf[4]
-    dAB = torch.zeros((N, 2 * H), dtype=torch.float32, device=dev)
+    dab_bf16 = bool(dab_bf16) and variant == 5          # both halves of dAB written as bf16 by their producers (no cast pass)
+    dAB = torch.zeros((N, 2 * H), dtype=torch.bfloat16 if dab_bf16 else torch.float32, device=dev)
     drh = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
     part = torch.zeros((ng, 4, H), dtype=torch.float32, device=dev)
     dagg = dagg.contiguous()
@@ -402,10 +406,12 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     keep = (W2p, Wcp, W2Tp, WcTp)
     for name, t in (("AB", AB16), ("row", row), ("col", col), ("rhohat", rhohat), ("w_r", w_r), ("W2p", W2p), ("Wcp", Wcp),
                     ("W2Tp", W2Tp), ("WcTp", WcTp), ("b2", b2), ("bc", bc), ("w3", w3), ("ds", ds), ("dagg", dagg),
-                    ("S1", S1), ("Mm", Mm), ("dT", dT), ("dP2", dP2), ("dP1", dP1), ("drh", drh), ("dABrow", dAB),
+                    ("S1", S1), ("Mm", Mm), ("dT", dT), ("dP2", dP2), ("dP1", dP1), ("drh", drh),
+                    ("dABrow", None if dab_bf16 else dAB), ("dAB16", dAB if dab_bf16 else None),
                     ("part", part), ("d2scratch", d2scratch), ("bnd", bnd)):
         setattr(a, name, ptr(t))
     a.ldab, a.lddagg, a.lddab, a.E = _ld(AB16), _ld(dagg), _ld(dAB), E
+    a.lddab16 = _ld(dAB)
     a.p_drop, a.seed = float(p_drop), int(seed) & 0xFFFFFFFF
     a.dbg = ptr(EDGE_BWD_TIMES) if EDGE_BWD_TIMES is not None else None
     _profiled("gcl_edge_fused_bwd%s_kernel<%d> E=%d (recompute + 4 chained H x H contractions per edge)" % ({1: "1", 2: "1_128", 3: "2_128", 4: "2_64", 5: "3"}.get(variant, ""), H, E),
@@ -414,7 +420,10 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
                             "fabind_gcl_edge_fused_bwd"))
     del keep
     if E > 0:
-        segment_sum(dP1[:E], colptr, N, eidx=perm, out=dAB[:, H:])
+        if dab_bf16:
+            segment_sum(dP1[:E], colptr, N, eidx=perm, out16=dAB[:, H:])
+        else:
+            segment_sum(dP1[:E], colptr, N, eidx=perm, out=dAB[:, H:])
         dW2 = gemm_tn(dP2[:E], S1[:E])
         dWc = gemm_tn(dT[:E], Mm[:E])
     else:

@@ -423,12 +423,14 @@ class _FusedEdge(torch.autograd.Function):
     no per-edge tensor, the backward recomputes them tile by tile in LDS."""
 
     @staticmethod
-    def forward(ctx, AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed):
+    def forward(ctx, AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed, holder=None):
         ctx.H, ctx.g, ctx.p_drop, ctx.seed = H, g, p_drop, seed
         ctx.save_for_backward(AB16, rhohat, w_r, W2, b2, Wc, bc, w3)
-        agg, s = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3,
-                                  AB16.shape[0], p_drop, seed)
-        return agg, s
+        out = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3,
+                               AB16.shape[0], p_drop, seed, want16=holder is not None)
+        if holder is not None:
+            holder.append(out[2])                     # the aggregated messages as the node MLP's bf16 operand (same kernels)
+        return out[0], out[1]
 
     @staticmethod
     def backward(ctx, dagg, ds):
@@ -441,18 +443,22 @@ class _FusedEdge(torch.autograd.Function):
             ds = torch.zeros(g.row_ctx.shape[0], dtype=torch.float32, device=AB16.device)
         dAB, drh, dwr, dW2, db2, dWc, dbc, dw3 = K.gcl_edge_fused_bwd(
             AB16, ctx.H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, ds.reshape(-1).float(), dagg.float(),
-            colptr, perm, ctx.p_drop, ctx.seed)
-        return (dAB.to(AB16.dtype), drh, dwr, dW2.to(W2.dtype), db2, dWc.to(Wc.dtype), dbc, dw3, None, None, None, None)
+            colptr, perm, ctx.p_drop, ctx.seed, dab_bf16=AB16.dtype == torch.bfloat16)
+        return (dAB.to(AB16.dtype), drh, dwr, dW2.to(W2.dtype), db2, dWc.to(Wc.dtype), dbc, dw3, None, None, None, None, None)
 
 
 def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop=0.0):
     """(agg [N,H], s [E,1]) of the fused bf16 edge pipeline; differentiable.  p_drop > 0: dropout on the messages
     (egnn.py:82) from a counter-based mask keyed by a seed drawn from torch's CPU generator (no device sync)."""
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
+    w16 = _cfg.get_precision() == "bf16"
     if _needs_grad(AB16, rhohat, w_r, W2, b2, Wc, bc, w3):
-        return _FusedEdge.apply(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed)
-    return K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3,
-                            AB16.shape[0], p_drop, seed)
+        holder = [] if w16 else None
+        agg, s = _FusedEdge.apply(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed, holder)
+        return _attach_b16(agg, holder[0] if holder else None), s
+    out = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3,
+                           AB16.shape[0], p_drop, seed, want16=w16)
+    return (_attach_b16(out[0], out[2]), out[1]) if w16 else out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -649,7 +655,12 @@ def _put_rows_inplace(base, rows, idx):
 def put_rows(base, rows, index64, inplace=True):
     """Row scatter of a small compact array into a node-layout array (index glue: pure data movement)."""
     if _needs_grad(base, rows):
-        return _PutRows.apply(base, rows, index64, inplace)
+        c = getattr(base, "_fab_b16", None)
+        keep = c is not None and c[0] == base._version
+        out = _PutRows.apply(base, rows, index64, inplace)
+        if keep and inplace:                   # (the Function patched the copy's rows; autograd bumped the version once more)
+            out._fab_b16 = (out._version, c[1])
+        return out
     _put_rows_inplace(base, rows, index64)
     return base
 
@@ -890,7 +901,8 @@ class _InterAttn(torch.autograd.Function):
         if Wc is not None:
             # cv = Linear(V) (egnn.py:225) evaluated inside this node of the autograd graph: its input gradient then accumulates
             # into the V columns of dqkv in place, instead of autograd padding it to [N,3H] and adding two [N,3H] tensors
-            v_in = _mm_in(qkv[:, 2 * H:])
+            c16 = getattr(qkv, "_fab_b16", None)
+            v_in = c16[1][:, 2 * H:] if (c16 is not None and c16[0] == qkv._version) else _mm_in(qkv[:, 2 * H:])
             cv, _ = K.gemm(v_in, Wc, bias=bc)
         h_out, x_out, alpha, cvs = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx,
                                                     bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext)

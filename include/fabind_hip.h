@@ -33,8 +33,10 @@ const char* fabind_last_error(void);
  *     fabind_gemm_tn_set_waves knob added.
  * 5 = FabindGemmArgs grew {C16, ldc16}; fabind_cross_attn_mfma_fwd / fabind_cross_attn_mfma_bwd added (MFMA bf16 form of the cross attention); FabindEdgeBwdArgs grew
  *     bnd + d2scratch, fabind_gcl_edge_fused takes bnd (deterministic boundary sums instead of float atomics), fabind_gcl_edge_fused_bwd_set_variant / _variant added.
+ * 6 = bf16 result copies emitted by their producers (no cast kernels): fabind_segment_sum takes (out16, ldo16), fabind_gcl_edge_fused takes agg16,
+ *     FabindEdgeBwdArgs grew {dAB16, lddab16}; fabind_gcl_edge_fused_set_variant / _variant (forward kernel form) added.
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 5
+#define FABIND_ABI_VERSION 6
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -154,7 +156,9 @@ int fabind_edge_geom(const float* x, const int* row, const int* col, const int* 
 int fabind_gcl_pre(const void* AB, int ab_dt, int ldab, int H, const int* row, const int* col, const float* rhohat,
                    const float* w_r, void* pre, int pre_dt, int E, int act, void* dact_out, hipStream_t stream);
 int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowptr, const int* eidx, int n_rows, int n_edges,
-                       int act, float* out, int ldo, hipStream_t stream);
+                       int act, float* out, int ldo,
+                       void* out16 /* NULL, or a bf16 copy of the result [n_rows, ldo16]; `out` may then be NULL */, int ldo16,
+                       hipStream_t stream);
 int fabind_coord_update(const float* x, const float* d, const float* s_part, int n_part, const float* weight,
                         const int* rowptr, int n_rows, int mean, float clampv, float* x_out, float* s_out,
                         hipStream_t stream);
@@ -171,6 +175,7 @@ int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int* row, const
                           const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
                           const float* w3, int E, float* agg, float* s_out, float p_drop, unsigned seed,
                           float* bnd /* scratch: ceil(E/64) x 2 x H floats (boundary runs of nodes that span tiles) */,
+                          void* agg16 /* NULL, or [n_rows, H] bf16: the aggregated messages as the next contraction's operand */,
                           hipStream_t stream);
 
 /* Backward of the fused edge pipeline (training, bf16): recomputes the forward per 64-edge tile and chains the four
@@ -194,6 +199,9 @@ typedef struct FabindEdgeBwdArgs {
     float p_drop;            /* dropout probability of the messages (egnn.py:82); 0 = eval */
     unsigned seed;           /* the seed the forward call used */
     int xcd_aware;           /* filled in by the library (fabind_gcl_edge_fused_set_xcd_aware); callers pass 0 */
+    int lddab16;
+    void* dAB16;             /* NULL, or [N, lddab16] bf16: the receiving-side sums go to its columns [0, H) INSTEAD of dABrow (variant 5
+                              * only; the caller reduces dP1 into columns [H, 2H) with fabind_segment_sum's out16) */
 } FabindEdgeBwdArgs;
 int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* args, int H, int n_groups, hipStream_t stream);
 /* Edges per tile of the backward kernel: 64 (one work-group per CU, default) or 32 (two per CU). */
