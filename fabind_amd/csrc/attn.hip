@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void inter_attn_fwd_kernel(
     int ldh, const float* __restrict__ x, const float* __restrict__ d, const float* __restrict__ rhohat,
     const int* rowptr, const int* col, const int* red_idx, const float* bias_red, int bias_np,
     const float* __restrict__ w_rk, const float* __restrict__ w_rv, const float* __restrict__ wcr,
-    const float* __restrict__ w3, float clampv, int n_rows, float* h_out, float* x_out, float* alpha, float* cvs,
+    const float* __restrict__ w3, float clampv, int n_rows, float* h_out, float* x_out, float* alpha, float* cvs, bf16_t* h16,
     const float* __restrict__ s_ext) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256) void inter_attn_fwd_kernel(
             float4 o = make_float4(hv.x + (acc[s].x + sar * wv.x) * inv, hv.y + (acc[s].y + sar * wv.y) * inv,
                                    hv.z + (acc[s].z + sar * wv.z) * inv, hv.w + (acc[s].w + sar * wv.w) * inv);
             *(float4*)(h_out + (size_t)r * ldh + c) = o;
+            if (h16) *(uint2*)(h16 + (size_t)r * H + c) = make_uint2(pack2_bf16(o.x, o.y), pack2_bf16(o.z, o.w));   // the next contraction's operand
         }
     }
     if (lane == 0) {
@@ -321,7 +322,7 @@ extern "C" int fabind_inter_attn_fwd(const float* qkv, int ldqkv, const float* c
                                      const int* col, const int* red_idx, const float* bias_red, int bias_np,
                                      const float* w_rk, const float* w_rv, const float* wcr, const float* w3,
                                      float clampv, int n_rows, float* h_out, float* x_out, float* alpha, float* cvs,
-                                     const float* s_ext, hipStream_t stream) {
+                                     const float* s_ext, void* h16, hipStream_t stream) {
     FB_REQUIRE(H % 4 == 0 && ldqkv % 4 == 0 && ldcv % 4 == 0 && ldh % 4 == 0, "fabind_inter_attn_fwd: % 4");
     FB_REQUIRE(H <= 1024, "fabind_inter_attn_fwd: H <= 1024");
     if (n_rows <= 0) return 0;
@@ -329,7 +330,7 @@ extern "C" int fabind_inter_attn_fwd(const float* qkv, int ldqkv, const float* c
 #define LAUNCH(NS)                                                                                                   \
     hipLaunchKernelGGL((inter_attn_fwd_kernel<NS>), grid, block, 0, stream, qkv, ldqkv, cv, ldcv, H, h, ldh, x, d,    \
                        rhohat, rowptr, col, red_idx, bias_red, bias_np, w_rk, w_rv, wcr, w3, clampv, n_rows, h_out, \
-                       x_out, alpha, cvs, s_ext)
+                       x_out, alpha, cvs, (bf16_t*)h16, s_ext)
     if (H <= 256) LAUNCH(1); else if (H <= 512) LAUNCH(2); else LAUNCH(4);
 #undef LAUNCH
     FB_CHECK_LAUNCH();

@@ -254,7 +254,8 @@ def pair_hadamard(a0, b0, a1, b1, red_p, red_c, out_dtype):
     return hd
 
 
-def inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, rowptr, col, red_idx, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None):
+def inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, rowptr, col, red_idx, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None, h16=None):
+    """h16 (bf16 [n_rows, H], optional): receives h_out as a bf16 operand."""
     n_rows, E = h.shape[0], col.shape[0]
     h_out, x_out = torch.empty_like(h), torch.empty_like(x)
     alpha = torch.empty(max(E, 1), dtype=torch.float32, device=h.device)
@@ -262,7 +263,7 @@ def inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, rowptr, col, red_idx, bias_part,
     check(_lib.load().fabind_inter_attn_fwd(ptr(qkv), _ld(qkv), ptr(cv), _ld(cv), H, ptr(h), _ld(h), ptr(x), ptr(d),
                                             ptr(rhohat), ptr(rowptr), ptr(col), ptr(red_idx), ptr(bias_part),
                                             bias_part.shape[1], ptr(w_rk), ptr(w_rv), ptr(wcr), ptr(w3), clampv, n_rows,
-                                            ptr(h_out), ptr(x_out), ptr(alpha), ptr(cvs), ptr(s_ext), stream()),
+                                            ptr(h_out), ptr(x_out), ptr(alpha), ptr(cvs), ptr(s_ext), ptr(h16), stream()),
           "fabind_inter_attn_fwd")
     return h_out, x_out, alpha[:E], cvs[:E]
 

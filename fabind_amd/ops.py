@@ -896,7 +896,7 @@ def rows_hadamard(t, idx_a, idx_b):
 
 class _InterAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext=None, Wc=None, bc=None):
+    def forward(ctx, qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext=None, Wc=None, bc=None, holder=None):
         v_in = None
         if Wc is not None:
             # cv = Linear(V) (egnn.py:225) evaluated inside this node of the autograd graph: its input gradient then accumulates
@@ -904,8 +904,12 @@ class _InterAttn(torch.autograd.Function):
             c16 = getattr(qkv, "_fab_b16", None)
             v_in = c16[1][:, 2 * H:] if (c16 is not None and c16[0] == qkv._version) else _mm_in(qkv[:, 2 * H:])
             cv, _ = K.gemm(v_in, Wc, bias=bc)
+        h16 = None
+        if holder is not None:
+            h16 = torch.empty((h.shape[0], H), dtype=torch.bfloat16, device=h.device)
+            holder.append(h16)
         h_out, x_out, alpha, cvs = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx,
-                                                    bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext)
+                                                    bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext, h16)
         ctx.g, ctx.H, ctx.clampv, ctx.np = g, H, clampv, bias_part.shape[1]
         ctx.has_ext, ctx.has_cv = s_ext is not None, Wc is not None
         ctx.sink_h = _sink_of(h)
@@ -953,20 +957,24 @@ class _InterAttn(torch.autograd.Function):
         if ctx.sink_h is not None and ctx.needs_input_grad[2]:
             dh_out = ctx.sink_h.deposit(dh_out)           # h_out = h + ...: the residual gradient joins h's shared buffer
         return (dqkv, dcv, dh_out, dx_out, dd[:E], drh[:E], dbias_red[:n_red, None].expand(n_red, ctx.np), dw[0], dw[1],
-                dw[2], dw[3], None, None, None, dcp[:E] if ctx.has_ext else None, dWc, dbc)
+                dw[2], dw[3], None, None, None, dcp[:E] if ctx.has_ext else None, dWc, dbc, None)
 
 
 def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None, Wc=None, bc=None):
     """s_ext [E] (optional): per-edge scalar added to the coordinate-MLP value inside the kernel (FABind+ evaluates its
     LN-MLP coord_mlp outside); differentiable.  cv=None with (Wc, bc): cv = Linear(qkv[:, 2H:]) is evaluated here."""
     assert (cv is None) != (Wc is None), "inter_attn: pass either cv or its Linear (Wc, bc)"
+    w16 = _cfg.get_precision() == "bf16" and h.is_contiguous()
     if _needs_grad(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, s_ext, Wc, bc):
-        return _InterAttn.apply(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext, Wc, bc)
+        holder = [] if w16 else None
+        h_out, x_out, alpha = _InterAttn.apply(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext, Wc, bc, holder)
+        return _attach_b16(h_out, holder[0] if holder else None), x_out, alpha
     if cv is None:
         cv = linear(qkv[:, 2 * H:], Wc, bc)
+    h16 = torch.empty((h.shape[0], H), dtype=torch.bfloat16, device=h.device) if w16 else None
     h_out, x_out, alpha, _ = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx, bias_part,
-                                              w_rk, w_rv, wcr, w3, clampv, s_ext)
-    return h_out, x_out, alpha
+                                              w_rk, w_rv, wcr, w3, clampv, s_ext, h16)
+    return _attach_b16(h_out, h16), x_out, alpha
 
 
 class _LasStep(torch.autograd.Function):

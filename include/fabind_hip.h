@@ -33,7 +33,7 @@ const char* fabind_last_error(void);
  *     fabind_gemm_tn_set_waves knob added.
  * 5 = FabindGemmArgs grew {C16, ldc16}; fabind_cross_attn_mfma_fwd / fabind_cross_attn_mfma_bwd added (MFMA bf16 form of the cross attention); FabindEdgeBwdArgs grew
  *     bnd + d2scratch, fabind_gcl_edge_fused takes bnd (deterministic boundary sums instead of float atomics), fabind_gcl_edge_fused_bwd_set_variant / _variant added.
- * 6 = bf16 result copies emitted by their producers (no cast kernels): fabind_segment_sum takes (out16, ldo16), fabind_gcl_edge_fused takes agg16,
+ * 6 = bf16 result copies emitted by their producers (no cast kernels): fabind_segment_sum takes (out16, ldo16), fabind_gcl_edge_fused takes agg16, fabind_inter_attn_fwd takes h16,
  *     FabindEdgeBwdArgs grew {dAB16, lddab16}; fabind_gcl_edge_fused_set_variant / _variant (forward kernel form) added.
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 6
@@ -306,6 +306,7 @@ int fabind_inter_attn_fwd(const float* qkv, int ldqkv, const float* cv, int ldcv
                           float* h_out, float* x_out, float* alpha, float* cvs,
                           const float* s_ext /* optional per-edge scalar added to the coord_mlp value (FABind+: its coord_mlp is an
                                                 LN-MLP evaluated outside); its gradient is the backward's dcp[] */,
+                          void* h16 /* NULL, or [n_rows, H] bf16: h_out as the next contraction's operand */,
                           hipStream_t stream);
 
 /* LAS geometry step (models/egnn.py:433-449): x_out = x + clamp(step * sum_{(i,j): j=node} 4(|xi-xj|^2-|x0i-x0j|^2)(xi-xj)).
