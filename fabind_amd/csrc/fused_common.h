@@ -48,15 +48,13 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 // wmode (profiling builds only; 0 everywhere else and folded away): 1 = every k-step re-reads the wave's first fragments (L1 hits),
 // 2 = no weight loads at all -- how much of a contraction is the weight stream?
 template <int H, int MI, bool SWAP = false, int SWZ = 7>
-__device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* __restrict__ Wp, int wave, int lane,
-                                               f32x4_t (&acc)[MI][4], const int wmode = 0) {
+__device__ __forceinline__ void fe_gemm_rolled_pf(const bf16_t* sX, const bf16_t* __restrict__ Wp, int wave, int lane,
+                                                  f32x4_t (&acc)[MI][4], bf16x8_t (&b0)[4], const int wmode = 0) {
     constexpr int NKS = H / 32;
     const int NG = wmode == 1 ? 0 : H / 16;
     const int fr = lane & 15, fq = lane >> 4;
     const bf16x8_t* wp = (const bf16x8_t*)Wp + ((size_t)wave * 4) * 64 + lane;
-    bf16x8_t b0[4], b1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b0[j] = wp[(size_t)j * 64];
+    bf16x8_t b1[4];
     if (wmode == 2) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) b1[j] = b0[j];
@@ -81,9 +79,13 @@ __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* _
                 acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a[i], acc[i][j], 0, 0, 0)
                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0[j], acc[i][j], 0, 0, 0);
         FE_PRIO(0);
-        if (ks + 2 < NKS && wmode != 2) {
+        // Unconditional (the last trip re-reads a fragment it does not use): a load under `if (ks + 2 < NKS)` gives the second half of
+        // the trip two predecessors, and the compiler then waits there for the smaller in-flight count -- vmcnt(3) instead of
+        // vmcnt(7), i.e. for the fragments just requested for the NEXT trip.  That wait was the contraction's main stall.
+        if (wmode != 2) {
+            const int kn = min(ks + 2, NKS - 2);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b0[j] = wp[((size_t)(ks + 2) * NG + j) * 64];
+            for (int j = 0; j < 4; ++j) b0[j] = wp[((size_t)kn * NG + j) * 64];
         }
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -99,6 +101,21 @@ __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* _
                                  : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1[j], acc[i][j], 0, 0, 0);
         FE_PRIO(0);
     }
+}
+
+// the first k-step's weight fragments of a contraction.  (Requesting them ahead of the barrier in front of the contraction, during the
+// preceding epilogue, was tried in the store-wave backward: 5.45 -> 5.82 ms per launch -- sixteen more live registers in the epilogues.)
+__device__ __forceinline__ void fe_gemm_prefetch(const bf16_t* __restrict__ Wp, int wave, int lane, bf16x8_t (&b0)[4]) {
+    const bf16x8_t* wp = (const bf16x8_t*)Wp + ((size_t)wave * 4) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0[j] = wp[(size_t)j * 64];
+}
+template <int H, int MI, bool SWAP = false, int SWZ = 7>
+__device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* __restrict__ Wp, int wave, int lane,
+                                               f32x4_t (&acc)[MI][4], const int wmode = 0) {
+    bf16x8_t b0[4];
+    fe_gemm_prefetch(Wp, wave, lane, b0);
+    fe_gemm_rolled_pf<H, MI, SWAP, SWZ>(sX, Wp, wave, lane, acc, b0, wmode);
 }
 
 template <int H>
