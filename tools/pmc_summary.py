@@ -9,6 +9,8 @@ from collections import defaultdict
 
 # kernel-name substring -> substring of the bench.py roofline label it belongs to
 KEYS = {
+    "gcl_edge_fused_bwd3_kernel": "gcl_edge_fused_bwd3_kernel<512>",
+    "gcl_edge_fused2_kernel": "gcl_edge_fused_kernel<512>",
     "gcl_edge_fused_bwd_kernel": "gcl_edge_fused_bwd_kernel<512>",
     "gcl_edge_fused_kernel": "gcl_edge_fused_kernel<512>",
     "gemm_tn_bf16_kernel": "fabind_gemm_tn M=512 N=512 E=15",
