@@ -32,7 +32,9 @@
 // The gathered rows of P0 and the scratch rows of P5 are loaded a batch of iterations at a time (all loads of a batch in flight
 // before the first is used); the row / col / rhohat / ds tables of the NEXT tile are fetched during P6.  (Issuing the next tile's
 // gathers during P6 as well only moved their latency into the scan, whose own loads return behind them: tried, +5 %; issuing them at the
-// start of P5 with the tables two tiles ahead keeps 64 registers live across the loop's back edge, which the allocator spills: 5.4 -> 7.7 ms.)
+// start of P5 with the tables two tiles ahead keeps 64 registers live across the loop's back edge, which the allocator spills: 5.4 -> 7.7 ms;
+// letting the STORE WAVE fetch the next tile's sender rows by LDS-DMA into the second LDS tile while contraction 4 runs took P0 from
+// 20 k to 13 k cycles per tile and gave the 7 k back in contraction 4 and at the barriers: 5.40 -> 5.56 ms, same process.)
 #include "common.h"
 #include "fabind_hip.h"
 #include "fused_common.h"
