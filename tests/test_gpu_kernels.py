@@ -133,6 +133,11 @@ def test_fused_edge_backward_matches_autograd(H, bm, p_drop):
     out = K.gcl_edge_fused_bwd(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev),
                                Wc.to(dev), bc.to(dev), w3.to(dev), ds.to(dev), dagg.to(dev), colptr.to(dev), i32(perm),
                                p_drop, seed)
+    if bm == 5:     # the default form can write both halves of dAB as bf16 itself (scan / fix-up / segment_sum out16): same values, rounded
+        out16 = K.gcl_edge_fused_bwd(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev),
+                                     Wc.to(dev), bc.to(dev), w3.to(dev), ds.to(dev), dagg.to(dev), colptr.to(dev), i32(perm),
+                                     p_drop, seed, dab_bf16=True)
+        assert out16[0].dtype == torch.bfloat16 and torch.equal(out16[0].cpu(), out[0].cpu().bfloat16())
     # the forward kernel evaluates the same mask
     agg_k, s_k = K.gcl_edge_fused(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), K.pack_frag(W2.to(dev)),
                                   b2.to(dev), K.pack_frag(Wc.to(dev)), bc.to(dev), w3.to(dev), N, p_drop, seed)
@@ -214,11 +219,14 @@ def test_gemm_bf16_lds_dma_fast_path(shape, cfg):
     assert torch.equal(o3.float().cpu(), Wa.float().T.contiguous())
 
 
+@pytest.mark.parametrize("variant", [1, 0])
 @pytest.mark.parametrize("H", [64, 128, 512])
-def test_fused_edge_pipeline_matches_unfused(H):
-    """csrc/fused_edge.hip (gather -> GEMM -> SiLU -> {segment-sum, GEMM -> row-dot}) vs fp32 torch on the CPU."""
-    from fabind_amd import kernels as K
+def test_fused_edge_pipeline_matches_unfused(H, variant):
+    """csrc/fused_edge.hip / fused_edge_fwd2.hip (gather -> GEMM -> SiLU -> {segment-sum, GEMM -> row-dot}) vs fp32 torch on the CPU;
+    variant 0 = round 1's kernel, 1 = the row-wise / operand-swapped form (default), which also emits the bf16 copy of agg."""
+    from fabind_amd import kernels as K, _lib
     dev = _dev()
+    _lib.load().fabind_gcl_edge_fused_set_variant(variant)
     g = torch.Generator().manual_seed(H)
     N, deg = 300, torch.randint(0, 40, (300,), generator=g)
     deg[7] = 333                                                        # a heavy row spanning several 64-edge tiles
@@ -236,10 +244,12 @@ def test_fused_edge_pipeline_matches_unfused(H):
     agg_ref = torch.zeros(N, H).index_add_(0, row, M)
     s_ref = (silu(M @ Wc.float().T + bc) * w3).sum(1)
     i32 = lambda t: t.to(torch.int32).to(dev)
-    agg, s = K.gcl_edge_fused(AB.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), K.pack_frag(W2.to(dev)),
-                              b2.to(dev), K.pack_frag(Wc.to(dev)), bc.to(dev), w3.to(dev), N)
+    agg, s, agg16 = K.gcl_edge_fused(AB.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), K.pack_frag(W2.to(dev)),
+                                     b2.to(dev), K.pack_frag(Wc.to(dev)), bc.to(dev), w3.to(dev), N, want16=True)
+    _lib.load().fabind_gcl_edge_fused_set_variant(1)
     assert (agg.cpu() - agg_ref).abs().max() <= 2e-2 * max(1.0, float(agg_ref.abs().max()))
     assert (s[:, 0].cpu() - s_ref).abs().max() <= 2e-2 * max(1.0, float(s_ref.abs().max()))
+    assert torch.equal(agg16.cpu(), agg.cpu().bfloat16())                # the bf16 copy is the rounded fp32 result, every row
 
 
 @pytest.mark.parametrize("shape", [(5000, 512, 512), (777, 256, 128), (100000, 512, 1024), (33, 64, 64)])
