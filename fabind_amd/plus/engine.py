@@ -500,7 +500,7 @@ def stack_forward(model, X, Hin, batch_id, segment_id, mask, is_global, compound
     scale = float(args.coordinate_scale)
     P = prepare_stack_params(model)
     H = P["H"]
-    lay = Layout(batch_id, segment_id)
+    lay = Layout.of(batch_id, segment_id)
     pairs = PairList(lay, X.device)
     bond_row = compound_edge_index[0].to(torch.int32).contiguous()
     bond_col = compound_edge_index[1].to(torch.int32).contiguous()
