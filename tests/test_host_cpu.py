@@ -269,3 +269,19 @@ def test_graft_entry_build_runs():
     imports the package -- exercised in the CPU suite so that a stale hard-coded check in it cannot go unnoticed again."""
     import __graft_entry__ as g
     g.build()
+
+
+def test_layout_cache_is_keyed_on_tensor_identity_and_version():
+    """engine.Layout.of reuses the layout of the SAME index tensors only: another tensor object (a new batch, even with equal
+    content) and an in-place change of either tensor rebuild it."""
+    import torch
+    from fabind_amd import engine
+    b = torch.tensor([0] * 5 + [1] * 7)
+    s = torch.tensor([0, 0, 1, 1, 1] + [0, 0, 0, 1, 1, 1, 1], dtype=torch.float32)
+    l1 = engine.Layout.of(b, s)
+    assert engine.Layout.of(b, s) is l1
+    assert l1.N == 12 and l1.P.tolist() == [3, 4] and l1.C.tolist() == [2, 3]
+    assert engine.Layout.of(b.clone(), s) is not l1                  # equal content, different object
+    s[2] = 0                                                         # in-place edit bumps the version counter
+    l2 = engine.Layout.of(b, s)
+    assert l2 is not l1 and l2.P.tolist() == [2, 4]
