@@ -540,3 +540,39 @@ extern "C" int fabind_edge_concat(const float* h, int ldh, int H, const int* row
     FB_CHECK_LAUNCH();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Many small strided 2-D copies with dtype conversion in ONE launch: the differentiable parameter pack of a model call (slices /
+// concatenations / zero padding / casts of the nn.Module parameters into the kernels' operand layouts, and its adjoint) was ~450 ATen
+// launches of a few microseconds per training step -- a quarter of all launches at the bench shape, half at the pocket shape.
+// Segment s: dst[r * dst_sr + c * dst_sc] = convert(src[r * src_sr + c * src_sc]) for r < rows, c < cols; src == NULL writes zeros.
+// blockIdx.x = segment, blockIdx.y strides over its elements.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void multi_copy_kernel(const FabindCopySeg* __restrict__ segs) {
+    const FabindCopySeg g = segs[blockIdx.x];
+    const long total = (long)g.rows * g.cols;
+    // four consecutive columns per thread when both sides are column-contiguous and aligned for 4-element accesses
+    if (g.vec4) {
+        const int c4 = g.cols >> 2;
+        const long tot4 = (long)g.rows * c4;
+        for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < tot4; i += (long)gridDim.y * 256) {
+            const long r = i / c4, c = (i % c4) * 4;
+            const float4 v = g.src ? ld4_any(g.src, g.src_dt, (size_t)(r * g.src_sr + c)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            st4_any(g.dst, g.dst_dt, (size_t)(r * g.dst_sr + c), v);
+        }
+        return;
+    }
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+        const long r = i / g.cols, c = i % g.cols;
+        const float v = g.src ? ld_any(g.src, g.src_dt, (size_t)(r * g.src_sr + c * g.src_sc)) : 0.f;
+        st_any(g.dst, g.dst_dt, (size_t)(r * g.dst_sr + c * g.dst_sc), v);
+    }
+}
+
+extern "C" int fabind_multi_copy(const FabindCopySeg* segs_dev, int n_segs, int blocks_per_seg, hipStream_t stream) {
+    if (n_segs <= 0) return 0;
+    FB_REQUIRE(segs_dev != nullptr && blocks_per_seg >= 1 && blocks_per_seg <= 65535, "fabind_multi_copy: segment table / blocks per segment");
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(n_segs, blocks_per_seg), dim3(256), 0, stream, segs_dev);
+    FB_CHECK_LAUNCH();
+    return 0;
+}

@@ -27,6 +27,7 @@ from . import kernels as K
 from . import ops
 
 from .config import get_precision, set_precision  # noqa: F401
+from .param_pack import EagerPack, ParamPack
 
 
 FUSED_EDGE = True     # forward-only bf16: fused gather->GEMM->GEMM->segment-sum edge kernel
@@ -203,18 +204,22 @@ def _cat(ts, d=0):
     return torch.cat(list(ts), d)
 
 
-def gcl_params(m):
-    """Kernel-side parameter pack of one MC_E_GCL module (first edge Linear split per node, see module docstring)."""
+def gcl_params(m, pk=None):
+    """Kernel-side parameter pack of one MC_E_GCL module (first edge Linear split per node, see module docstring).  pk: a
+    param_pack.ParamPack collecting the whole model's copy requests (entries are handles until pk.resolve), default: built here."""
     wd = _wd()
-    W = lambda t: t.to(wd).contiguous()
+    own = pk is None
+    pk = pk or EagerPack(m.edge_mlp[0].weight.device)
     W1 = m.edge_mlp[0].weight
     Hin = (W1.shape[1] - 1) // 2
-    return dict(
-        W_ab=W(_cat([W1[:, :Hin], W1[:, Hin:2 * Hin]])),
-        b_ab=_cat([m.edge_mlp[0].bias, torch.zeros_like(m.edge_mlp[0].bias)]).contiguous(),
-        w_r=W1[:, 2 * Hin].contiguous(), W2=W(m.edge_mlp[2].weight), b2=m.edge_mlp[2].bias,
-        Wc=W(m.coord_mlp[0].weight), bc=m.coord_mlp[0].bias, w3=m.coord_mlp[2].weight[0].contiguous(),
-        Wn1=W(m.node_mlp[0].weight), bn1=m.node_mlp[0].bias, Wn2=W(m.node_mlp[2].weight), bn2=m.node_mlp[2].bias)
+    H = W1.shape[0]
+    d = dict(
+        W_ab=pk.cat([W1[:, :Hin], W1[:, Hin:2 * Hin]], 0, wd),
+        b_ab=pk.cat([m.edge_mlp[0].bias, pk.zeros(H)]),
+        w_r=pk.copy(W1[:, 2 * Hin]), W2=pk.copy(m.edge_mlp[2].weight, wd), b2=m.edge_mlp[2].bias,
+        Wc=pk.copy(m.coord_mlp[0].weight, wd), bc=m.coord_mlp[0].bias, w3=pk.copy(m.coord_mlp[2].weight[0]),
+        Wn1=pk.copy(m.node_mlp[0].weight, wd), bn1=m.node_mlp[0].bias, Wn2=pk.copy(m.node_mlp[2].weight, wd), bn2=m.node_mlp[2].bias)
+    return pk.resolve(d) if own else d
 
 
 _PACK_CACHE = {}
@@ -243,76 +248,99 @@ def prepare_stack_params(model):
     return cached_pack(model, _build_stack_params)
 
 
-def cam_node_params(cam):
+def cam_node_params(cam, pk=None):
     """Node-path parameters of one CrossAttentionModule (both RowAttentionBlocks' projections, both node transitions, the
-    32-wide Hadamard projections) in the kernels' layout."""
+    32-wide Hadamard projections) in the kernels' layout.  pk: see gcl_params."""
     wd = _wd()
-    W = lambda t: t.to(wd).contiguous()
+    own = pk is None
+    pk = pk or EagerPack(cam.inter_layer.linear_p.weight.device)
     d = {}
     for tag, blk in (("p", cam.p_attention_block), ("c", cam.c_attention_block)):
         a = blk.mha
-        d["Wqg_" + tag] = W(_cat([a.linear_q.weight, a.linear_g.weight]))
-        d["bqg_" + tag] = _cat([torch.zeros_like(a.linear_g.bias), a.linear_g.bias]).contiguous()
-        d["Wkv_" + tag] = W(_cat([a.linear_k.weight, a.linear_v.weight]))
-        d["Wo_" + tag], d["bo_" + tag] = W(a.linear_o.weight), a.linear_o.bias
+        d["Wqg_" + tag] = pk.cat([a.linear_q.weight, a.linear_g.weight], 0, wd)
+        d["bqg_" + tag] = pk.cat([pk.zeros(a.linear_g.bias.shape[0]), a.linear_g.bias])
+        d["Wkv_" + tag] = pk.cat([a.linear_k.weight, a.linear_v.weight], 0, wd)
+        d["Wo_" + tag], d["bo_" + tag] = pk.copy(a.linear_o.weight, wd), a.linear_o.bias
     for tag, tr in (("p", cam.p_transition), ("c", cam.c_transition)):
-        d["Wt1_" + tag], d["bt1_" + tag] = W(tr.linear_1.weight), tr.linear_1.bias
-        d["Wt2_" + tag], d["bt2_" + tag] = W(tr.linear_2.weight), tr.linear_2.bias
+        d["Wt1_" + tag], d["bt1_" + tag] = pk.copy(tr.linear_1.weight, wd), tr.linear_1.bias
+        d["Wt2_" + tag], d["bt2_" + tag] = pk.copy(tr.linear_2.weight, wd), tr.linear_2.bias
     i32 = cam.inter_layer
-    z32w = torch.zeros_like(i32.linear_p.weight)
-    z32b = torch.zeros_like(i32.linear_p.bias)
-    d["W_ab32"] = W(_cat([i32.linear_p.weight, z32w, i32.linear_c.weight, z32w]))
-    d["b_ab32"] = _cat([i32.linear_p.bias, z32b, i32.linear_c.bias, z32b]).contiguous()
-    return d
+    zw, zb = pk.zeros(*i32.linear_p.weight.shape), pk.zeros(i32.linear_p.bias.shape[0])
+    d["W_ab32"] = pk.cat([i32.linear_p.weight, zw, i32.linear_c.weight, zw], 0, wd)
+    d["b_ab32"] = pk.cat([i32.linear_p.bias, zb, i32.linear_c.bias, zb])
+    return pk.resolve(d) if own else d
 
 
-def att_edge_params(m):
+def att_edge_params(m, pk=None):
     """Inter-edge attention parameters of one MC_Att_L (egnn.py:197-252): q | k | v projections with the interleaved kv split
-    (k = kv[0::2], v = kv[1::2], egnn.py:205) undone, the radial columns, the coordinate MLP."""
+    (k = kv[0::2], v = kv[1::2], egnn.py:205) undone, the radial columns, the coordinate MLP.  pk: see gcl_params; with a shared pk the
+    composed entry `wcr` is added by `att_edge_composed` after pk.resolve."""
     wd = _wd()
-    W = lambda t: t.to(wd).contiguous()
+    own = pk is None
+    pk = pk or EagerPack(m.linear_q.weight.device)
     d = {}
     Wkv, bkv = m.linear_kv.weight, m.linear_kv.bias
-    d["Wqkv"] = W(_cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]]))
-    d["bqkv"] = _cat([m.linear_q.bias, bkv[0::2], bkv[1::2]]).contiguous()
-    d["w_rk"], d["w_rv"] = Wkv[0::2, 0].contiguous(), Wkv[1::2, 0].contiguous()
-    d["Wc"], d["bc"] = W(m.coord_mlp[0].weight), m.coord_mlp[0].bias
-    d["w3"] = m.coord_mlp[2].weight[0].contiguous()
-    d["wcr"] = (m.coord_mlp[0].weight @ d["w_rv"]).contiguous()
+    d["Wqkv"] = pk.cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]], 0, wd)
+    d["bqkv"] = pk.cat([m.linear_q.bias, bkv[0::2], bkv[1::2]])
+    d["w_rk"], d["w_rv"] = pk.copy(Wkv[0::2, 0]), pk.copy(Wkv[1::2, 0])
+    d["Wc"], d["bc"] = pk.copy(m.coord_mlp[0].weight, wd), m.coord_mlp[0].bias
+    d["w3"] = pk.copy(m.coord_mlp[2].weight[0])
+    if own:
+        d = pk.resolve(d)
+        att_edge_composed(m, d)
     return d
+
+
+def att_edge_composed(m, d):
+    """The product entry of att_edge_params (an ordinary torch op on the resolved pack)."""
+    d["wcr"] = (m.coord_mlp[0].weight @ d["w_rv"]).contiguous()
 
 
 def _build_stack_params(model):
+    """Every copy-type entry (slices / concatenations / zero padding / casts of parameters) goes through ONE param_pack.ParamPack --
+    one launch, one autograd node -- unless FABIND_PARAM_PACK=0 (torch ops, the round-1 behaviour); the products of parameters
+    (composed weights of the pair path) are torch ops on its outputs."""
     wd = _wd()
     gnn = model.gnn
     H = gnn.hidden_nf
     L = gnn.n_layers
     il = model.inter_layer
+    dev = il.linear_p.weight.device
+    pk = EagerPack(dev) if os.environ.get("FABIND_PARAM_PACK", "1") == "0" else ParamPack(dev)
     P = {"H": H, "L": L}
-    W = lambda t: t.to(wd).contiguous()
-    P["W_ab0"] = W(_cat([il.linear_p.weight, il.linear_c.weight]))
-    P["b_ab0"] = _cat([il.linear_p.bias, il.linear_c.bias]).contiguous()
-    Wo0, bo0 = il.linear_out.weight, il.linear_out.bias
+    P["W_ab0"] = pk.cat([il.linear_p.weight, il.linear_c.weight], 0, wd)
+    P["b_ab0"] = pk.cat([il.linear_p.bias, il.linear_c.bias])
     rows, rb = [], []
     for i in range(L):
         cam = getattr(gnn, "att_%d" % i).cross_attn_module
         for blk in (cam.p_attention_block, cam.c_attention_block):
-            rows.append(_cat([blk.linear.weight, blk.linear_g.weight]))       # [8, H]: lin heads 0-3, gate heads 4-7
-            rb.append(_cat([blk.linear.bias, blk.linear_g.bias]))
-    rows, rb = torch.stack(rows), torch.stack(rb)                            # [2L, 8, H], [2L, 8]
-    P["pb_wcomp"] = (rows @ Wo0).contiguous()                                # z0 = Wo0 (a*b) + bo0 folded in
-    P["pb_bconst"] = (rows @ bo0 + rb).contiguous()
-    P["W_in"], P["b_in"] = W(gnn.linear_in.weight), gnn.linear_in.bias
-    P["W_out"], P["b_out"] = W(gnn.linear_out.weight), gnn.linear_out.bias
-
-    gcl = gcl_params
-    P["gcl"] = [gcl(getattr(gnn, "gcl_%d" % i)) for i in range(L)]
-    P["out_layer"] = gcl(gnn.out_layer)
+            rows += [blk.linear.weight, blk.linear_g.weight]                 # [4, H] each: lin heads 0-3, gate heads 4-7
+            rb += [blk.linear.bias, blk.linear_g.bias]
+    P["_rows"], P["_rb"] = pk.cat(rows, 0), pk.cat(rb)                       # [2L * 8, H], [2L * 8]
+    P["W_in"], P["b_in"] = pk.copy(gnn.linear_in.weight, wd), gnn.linear_in.bias
+    P["W_out"], P["b_out"] = pk.copy(gnn.linear_out.weight, wd), gnn.linear_out.bias
+    P["gcl"] = [gcl_params(getattr(gnn, "gcl_%d" % i), pk) for i in range(L)]
+    P["out_layer"] = gcl_params(gnn.out_layer, pk)
     att = []
     for i in range(L):
         m = getattr(gnn, "att_%d" % i)
+        d = cam_node_params(m.cross_attn_module, pk)
+        d.update(att_edge_params(m, pk))
+        att.append(d)
+    P["att"] = att
+    P = pk.resolve(P)
+
+    # ---- products of parameters
+    Wo0, bo0 = il.linear_out.weight, il.linear_out.bias
+    rows, rb = P.pop("_rows").view(2 * L, -1, H), P.pop("_rb").view(2 * L, -1)
+    P["pb_wcomp"] = (rows @ Wo0).contiguous()                                # z0 = Wo0 (a*b) + bo0 folded in
+    P["pb_bconst"] = (rows @ bo0 + rb).contiguous()
+    W = lambda t: t.to(wd).contiguous()
+    for i in range(L):
+        m = getattr(gnn, "att_%d" % i)
         cam = m.cross_attn_module
-        d = cam_node_params(cam)
+        d = P["att"][i]
+        att_edge_composed(m, d)
         i32 = cam.inter_layer
         # the 32-wide Hadamard block is zero-padded to 64 columns so that K = H + 64 stays a multiple of 64
         # (LDS-DMA GEMM path); the padded rows/columns are exact zeros and do not change the result
@@ -321,9 +349,6 @@ def _build_stack_params(model):
         d["Wcomp1"] = W(pt.linear_1.weight @ Woo)                    # [2H, H+64]
         d["bcomp1"] = (pt.linear_1.weight @ (bo0 + i32.linear_out.bias) + pt.linear_1.bias).contiguous()
         d["u"] = (pt.linear_2.weight.t() @ m.attn_bias_proj.weight[0]).contiguous()   # [2H]
-        d.update(att_edge_params(m))
-        att.append(d)
-    P["att"] = att
     return P
 
 

@@ -1,0 +1,240 @@
+"""The kernel-side parameter pack as ONE launch each way.
+
+The kernels want the nn.Module parameters in other layouts than the reference's `__init__` leaves them in (models/egnn.py:40-60,
+186-208, models/cross_att.py:15-40, models/model_utils.py:83-131): the first edge Linear split per node, q | k | v with the interleaved
+kv split undone, zero-padded 32-wide Hadamard projections, bf16 copies.  Built from torch ops that is ~200 launches of a few
+microseconds per model call and ~250 more in its adjoint -- a quarter of all launches of a training step at the bench shape, half
+at the pocket shape.  `ParamPack` collects the copy-type requests (concatenation of parameter views / zero blocks along one axis,
+with a cast) and executes them as one `fabind_multi_copy` launch; under autograd it is one node whose backward is one more launch
+writing every parameter gradient slice.  Products of parameters (composed weights) stay ordinary torch ops on the pack's outputs.
+
+A parameter element may appear in at most ONE request (its gradient slice is written, not accumulated): the builders in engine.py
+keep to that, and `FABIND_PARAM_PACK=check` verifies it on every call."""
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, dt_code, stream
+
+_SEG = np.dtype([("src", np.uint64), ("dst", np.uint64), ("src_sr", np.int64), ("src_sc", np.int64), ("dst_sr", np.int64),
+                 ("dst_sc", np.int64), ("rows", np.int32), ("cols", np.int32), ("src_dt", np.int32), ("dst_dt", np.int32),
+                 ("vec4", np.int32), ("pad", np.int32)])
+_ESZ = {torch.float32: 4, torch.bfloat16: 2}
+_RING, _RING_POS = [], [0]
+
+
+def _upload(table, dev):
+    """Device copy of a segment table through a ring of pinned staging buffers (asynchronous, no stream drain)."""
+    raw = table.view(np.uint8)
+    n = raw.shape[0]
+    if not _RING:
+        _RING.extend(torch.empty(64 * 1024, dtype=torch.uint8, pin_memory=True) for _ in range(16))
+    _RING_POS[0] = (_RING_POS[0] + 1) % len(_RING)
+    stage = _RING[_RING_POS[0]]
+    if n > stage.numel():
+        stage = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+    stage[:n].numpy()[:] = raw
+    return stage[:n].to(dev, non_blocking=True)
+
+
+def _launch(table, dev):
+    if len(table) == 0:
+        return
+    tdev = _upload(table, dev)
+    big = int((table["rows"].astype(np.int64) * table["cols"]).max())
+    blocks = max(1, min(64, (big + 4095) // 4096))
+    check(_lib.load().fabind_multi_copy(tdev.data_ptr(), len(table), blocks, stream()), "fabind_multi_copy")
+    return tdev                                  # the caller keeps it alive until the launch has been queued
+
+
+class _H:
+    """Handle of a ParamPack request (replaced by its tensor in `ParamPack.resolve`)."""
+    __slots__ = ("k",)
+
+    def __init__(self, k):
+        self.k = k
+
+
+class EagerPack:
+    """The same request interface executed immediately with torch ops (the reference behaviour: one launch or more per request;
+    used by the single-module entry points and by FABIND_PARAM_PACK=0)."""
+    def __init__(self, device):
+        self.dev = device
+
+    def cat(self, pieces, dim=0, dtype=None):
+        first = next(p for p in pieces if not isinstance(p, tuple))
+        ts = [torch.zeros(p[1:], dtype=first.dtype, device=self.dev) if isinstance(p, tuple) else p for p in pieces]
+        t = ts[0] if len(ts) == 1 else torch.cat(ts, dim)
+        return (t.to(dtype) if dtype is not None else t).contiguous()
+
+    def copy(self, view, dtype=None):
+        return self.cat([view], 0, dtype)
+
+    zeros = staticmethod(lambda *shape: ("zeros",) + tuple(shape))
+
+    def resolve(self, tree):
+        return tree
+
+
+class ParamPack:
+    def __init__(self, device):
+        self.dev = device
+        self.reqs = []           # (ndim, dtype, dim, [piece]) with piece = tensor view | ("zeros", *shape)
+
+    def resolve(self, tree):
+        """Run the collected requests and replace every handle in a nested dict / list structure by its tensor."""
+        outs = self.run()
+
+        def walk(x):
+            if isinstance(x, _H):
+                return outs[x.k]
+            if isinstance(x, dict):
+                return {k: walk(v) for k, v in x.items()}
+            if isinstance(x, list):
+                return [walk(v) for v in x]
+            return x
+        return walk(tree)
+
+    # ---- requests ------------------------------------------------------------------------------------------------
+    def cat(self, pieces, dim=0, dtype=None):
+        """Handle of cat(pieces, dim) cast to dtype; a piece is a 1-D / 2-D view of a parameter or ParamPack.zeros(...)."""
+        first = next(p for p in pieces if not isinstance(p, tuple))
+        nd = first.dim()
+        assert nd in (1, 2) and (dim == 0 or nd == 2)
+        dtype = dtype or first.dtype
+        self.reqs.append((nd, dtype, dim, list(pieces)))
+        return _H(len(self.reqs) - 1)
+
+    def copy(self, view, dtype=None):
+        return self.cat([view], 0, dtype)
+
+    @staticmethod
+    def zeros(*shape):
+        return ("zeros",) + tuple(shape)
+
+    # ---- execution -----------------------------------------------------------------------------------------------
+    def run(self):
+        """-> list of output tensors (one per request), differentiable w.r.t. the parameters behind the views."""
+        bases, seen = [], {}
+        for _, _, _, pieces in self.reqs:
+            for p in pieces:
+                if isinstance(p, tuple):
+                    continue
+                b = p._base if p._base is not None else p
+                if id(b) not in seen:
+                    seen[id(b)] = len(bases)
+                    bases.append(b)
+        self._bases, self._base_idx = bases, seen
+        if torch.is_grad_enabled() and any(b.requires_grad for b in bases):
+            return list(_PackFn.apply(self, *bases))
+        return self._forward()
+
+    def _layout(self):
+        """Per request: output shape and per piece (r0, c0, rows, cols)."""
+        lay = []
+        for nd, dtype, dim, pieces in self.reqs:
+            shapes = []
+            for p in pieces:
+                sh = tuple(p[1:]) if isinstance(p, tuple) else tuple(p.shape)
+                shapes.append((1, sh[0]) if nd == 1 else sh)
+            if nd == 1 or dim == 1:
+                R = shapes[0][0]
+                assert all(s[0] == R for s in shapes)
+                offs, c = [], 0
+                for s in shapes:
+                    offs.append((0, c))
+                    c += s[1]
+                out = (R, c)
+            else:
+                Cc = shapes[0][1]
+                assert all(s[1] == Cc for s in shapes)
+                offs, r = [], 0
+                for s in shapes:
+                    offs.append((r, 0))
+                    r += s[0]
+                out = (r, Cc)
+            lay.append((out, [(o[0], o[1], s[0], s[1]) for o, s in zip(offs, shapes)]))
+        return lay
+
+    @staticmethod
+    def _strides(v):
+        return (0, v.stride(0)) if v.dim() == 1 else (v.stride(0), v.stride(1))
+
+    def _forward(self):
+        lay = self._layout()
+        outs, rows = [], []
+        for (nd, dtype, dim, pieces), (oshape, offs) in zip(self.reqs, lay):
+            out = torch.empty(oshape if nd == 2 else (oshape[1],), dtype=dtype, device=self.dev)
+            outs.append(out)
+            ld, esz_o = oshape[1], _ESZ[dtype]
+            for p, (r0, c0, nr, nc) in zip(pieces, offs):
+                dst = out.data_ptr() + (r0 * ld + c0) * esz_o
+                if isinstance(p, tuple):
+                    rows.append((0, dst, 0, 0, ld, 1, nr, nc, 0, dt_code(dtype), 0))
+                    continue
+                sr, sc = self._strides(p)
+                v4 = int(sc == 1 and nc % 4 == 0 and (sr % 4 == 0 or nr == 1) and ld % 4 == 0 and p.data_ptr() % (4 * _ESZ[p.dtype]) == 0
+                         and dst % (4 * esz_o) == 0)
+                rows.append((p.data_ptr(), dst, sr, sc, ld, 1, nr, nc, dt_code(p.dtype), dt_code(dtype), v4))
+        self._lay = lay
+        self._keep = _launch(self._table(rows), self.dev)
+        return outs
+
+    @staticmethod
+    def _table(rows):
+        t = np.zeros(len(rows), dtype=_SEG)
+        for k, name in enumerate(("src", "dst", "src_sr", "src_sc", "dst_sr", "dst_sc", "rows", "cols", "src_dt", "dst_dt", "vec4")):
+            t[name] = [r[k] for r in rows]
+        return t
+
+    def _backward(self, gouts):
+        """Gradients of the base parameters: every requested view's slice of its parameter's gradient receives the matching block of
+        the output gradient (fp32); parameter elements outside every request stay zero."""
+        bases = self._bases
+        sizes = [b.numel() for b in bases]
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=self.dev)
+        starts = np.concatenate([[0], np.cumsum(sizes)])
+        rows, keep_g = [], []
+        check_overlap = os.environ.get("FABIND_PARAM_PACK", "") == "check"
+        cover = [np.zeros(n, dtype=np.int8) for n in sizes] if check_overlap else None
+        for (nd, dtype, dim, pieces), (oshape, offs), g in zip(self.reqs, self._lay, gouts):
+            if g is None:
+                continue
+            g = g.contiguous()
+            ld, esz_g = oshape[1], _ESZ[g.dtype]
+            for p, (r0, c0, nr, nc) in zip(pieces, offs):
+                if isinstance(p, tuple):
+                    continue
+                b = p._base if p._base is not None else p
+                k = self._base_idx[id(b)]
+                if not b.requires_grad:
+                    continue
+                assert b.is_contiguous() and b.dtype == torch.float32, "ParamPack: parameters are contiguous fp32 tensors"
+                off = p.storage_offset() - b.storage_offset()
+                sr, sc = self._strides(p)
+                dst = flat.data_ptr() + (int(starts[k]) + off) * 4
+                src = g.data_ptr() + (r0 * ld + c0) * esz_g
+                v4 = int(sc == 1 and nc % 4 == 0 and (sr % 4 == 0 or nr == 1) and ld % 4 == 0 and dst % 16 == 0 and src % (4 * esz_g) == 0)
+                rows.append((src, dst, ld, 1, sr, sc, nr, nc, dt_code(g.dtype), dt_code(torch.float32), v4))
+                if check_overlap:
+                    idx = (off + np.arange(nr)[:, None] * sr + np.arange(nc)[None, :] * sc).reshape(-1)
+                    cover[k][idx] += 1
+            keep_g.append(g)                      # (alive until the launch below has been queued)
+        if check_overlap:
+            for k, c in enumerate(cover):
+                assert c.max(initial=0) <= 1, "ParamPack: a parameter element is requested twice (its gradient would be overwritten)"
+        self._keep_b = _launch(self._table(rows), self.dev) if rows else None
+        return [flat[int(starts[k]):int(starts[k + 1])].view(bases[k].shape) if bases[k].requires_grad else None for k in range(len(bases))]
+
+
+class _PackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pack, *bases):
+        ctx.pack = pack
+        return tuple(pack._forward())
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        return (None,) + tuple(ctx.pack._backward(gouts))

@@ -35,8 +35,9 @@ const char* fabind_last_error(void);
  *     bnd + d2scratch, fabind_gcl_edge_fused takes bnd (deterministic boundary sums instead of float atomics), fabind_gcl_edge_fused_bwd_set_variant / _variant added.
  * 6 = bf16 result copies emitted by their producers (no cast kernels): fabind_segment_sum takes (out16, ldo16), fabind_gcl_edge_fused takes agg16, fabind_inter_attn_fwd takes h16,
  *     FabindEdgeBwdArgs grew {dAB16, lddab16}; fabind_gcl_edge_fused_set_variant / _variant (forward kernel form) added.
+ * 7 = fabind_multi_copy + FabindCopySeg added (the parameter pack and its adjoint as one launch each).
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 6
+#define FABIND_ABI_VERSION 7
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -102,6 +103,19 @@ int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_part
 /* out[C,R] = act(in[R,C])^T -- feeds weight-gradient contractions (autograd of the ops above). */
 int fabind_transpose_act(const void* in, int in_dt, int ldi, void* out, int out_dt, int ldo, int R, int C, int act,
                          hipStream_t stream);
+/* Many strided 2-D copies with dtype conversion in one launch (the differentiable parameter pack of a model call -- slices,
+ * concatenations, zero padding and casts of nn.Module parameters, models/*.py __init__ layouts -> kernel operand layouts -- and its
+ * adjoint).  The table lives in DEVICE memory; strides are in elements; src == NULL writes zeros; vec4 != 0 promises column-contiguous,
+ * 4-element-aligned rows on both sides with cols % 4 == 0. */
+typedef struct FabindCopySeg {
+    const void* src;
+    void* dst;
+    long long src_sr, src_sc, dst_sr, dst_sc;
+    int rows, cols;
+    int src_dt, dst_dt;
+    int vec4, pad_;
+} FabindCopySeg;
+int fabind_multi_copy(const FabindCopySeg* segs_dev, int n_segs, int blocks_per_seg, hipStream_t stream);
 /* out[c] (+)= sum_r in[r,c]; scratch = float[nchunk*C] (bias gradients, deterministic two-pass). */
 int fabind_colsum(const void* in, int in_dt, int ldi, float* out, int R, int C, int accumulate, float* scratch,
                   int nchunk, hipStream_t stream);
