@@ -214,11 +214,12 @@ def gcl_params(m, pk=None):
     Hin = (W1.shape[1] - 1) // 2
     H = W1.shape[0]
     d = dict(
-        W_ab=pk.cat([W1[:, :Hin], W1[:, Hin:2 * Hin]], 0, wd),
+        W_ab=pk.cat([W1[:, :Hin], W1[:, Hin:2 * Hin]], 0, wd, with_T=True),
         b_ab=pk.cat([m.edge_mlp[0].bias, pk.zeros(H)]),
         w_r=pk.copy(W1[:, 2 * Hin]), W2=pk.copy(m.edge_mlp[2].weight, wd), b2=m.edge_mlp[2].bias,
         Wc=pk.copy(m.coord_mlp[0].weight, wd), bc=m.coord_mlp[0].bias, w3=pk.copy(m.coord_mlp[2].weight[0]),
-        Wn1=pk.copy(m.node_mlp[0].weight, wd), bn1=m.node_mlp[0].bias, Wn2=pk.copy(m.node_mlp[2].weight, wd), bn2=m.node_mlp[2].bias)
+        Wn1=pk.copy(m.node_mlp[0].weight, wd, with_T=True), bn1=m.node_mlp[0].bias,
+        Wn2=pk.copy(m.node_mlp[2].weight, wd, with_T=True), bn2=m.node_mlp[2].bias)
     return pk.resolve(d) if own else d
 
 
@@ -257,16 +258,16 @@ def cam_node_params(cam, pk=None):
     d = {}
     for tag, blk in (("p", cam.p_attention_block), ("c", cam.c_attention_block)):
         a = blk.mha
-        d["Wqg_" + tag] = pk.cat([a.linear_q.weight, a.linear_g.weight], 0, wd)
+        d["Wqg_" + tag] = pk.cat([a.linear_q.weight, a.linear_g.weight], 0, wd, with_T=True)
         d["bqg_" + tag] = pk.cat([pk.zeros(a.linear_g.bias.shape[0]), a.linear_g.bias])
-        d["Wkv_" + tag] = pk.cat([a.linear_k.weight, a.linear_v.weight], 0, wd)
-        d["Wo_" + tag], d["bo_" + tag] = pk.copy(a.linear_o.weight, wd), a.linear_o.bias
+        d["Wkv_" + tag] = pk.cat([a.linear_k.weight, a.linear_v.weight], 0, wd, with_T=True)
+        d["Wo_" + tag], d["bo_" + tag] = pk.copy(a.linear_o.weight, wd, with_T=True), a.linear_o.bias
     for tag, tr in (("p", cam.p_transition), ("c", cam.c_transition)):
-        d["Wt1_" + tag], d["bt1_" + tag] = pk.copy(tr.linear_1.weight, wd), tr.linear_1.bias
-        d["Wt2_" + tag], d["bt2_" + tag] = pk.copy(tr.linear_2.weight, wd), tr.linear_2.bias
+        d["Wt1_" + tag], d["bt1_" + tag] = pk.copy(tr.linear_1.weight, wd, with_T=True), tr.linear_1.bias
+        d["Wt2_" + tag], d["bt2_" + tag] = pk.copy(tr.linear_2.weight, wd, with_T=True), tr.linear_2.bias
     i32 = cam.inter_layer
     zw, zb = pk.zeros(*i32.linear_p.weight.shape), pk.zeros(i32.linear_p.bias.shape[0])
-    d["W_ab32"] = pk.cat([i32.linear_p.weight, zw, i32.linear_c.weight, zw], 0, wd)
+    d["W_ab32"] = pk.cat([i32.linear_p.weight, zw, i32.linear_c.weight, zw], 0, wd, with_T=True)
     d["b_ab32"] = pk.cat([i32.linear_p.bias, zb, i32.linear_c.bias, zb])
     return pk.resolve(d) if own else d
 
@@ -280,10 +281,10 @@ def att_edge_params(m, pk=None):
     pk = pk or EagerPack(m.linear_q.weight.device)
     d = {}
     Wkv, bkv = m.linear_kv.weight, m.linear_kv.bias
-    d["Wqkv"] = pk.cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]], 0, wd)
+    d["Wqkv"] = pk.cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]], 0, wd, with_T=True)
     d["bqkv"] = pk.cat([m.linear_q.bias, bkv[0::2], bkv[1::2]])
     d["w_rk"], d["w_rv"] = pk.copy(Wkv[0::2, 0]), pk.copy(Wkv[1::2, 0])
-    d["Wc"], d["bc"] = pk.copy(m.coord_mlp[0].weight, wd), m.coord_mlp[0].bias
+    d["Wc"], d["bc"] = pk.copy(m.coord_mlp[0].weight, wd, with_T=True), m.coord_mlp[0].bias
     d["w3"] = pk.copy(m.coord_mlp[2].weight[0])
     if own:
         d = pk.resolve(d)
@@ -308,7 +309,7 @@ def _build_stack_params(model):
     dev = il.linear_p.weight.device
     pk = EagerPack(dev) if os.environ.get("FABIND_PARAM_PACK", "1") == "0" else ParamPack(dev)
     P = {"H": H, "L": L}
-    P["W_ab0"] = pk.cat([il.linear_p.weight, il.linear_c.weight], 0, wd)
+    P["W_ab0"] = pk.cat([il.linear_p.weight, il.linear_c.weight], 0, wd, with_T=True)
     P["b_ab0"] = pk.cat([il.linear_p.bias, il.linear_c.bias])
     rows, rb = [], []
     for i in range(L):
@@ -317,8 +318,8 @@ def _build_stack_params(model):
             rows += [blk.linear.weight, blk.linear_g.weight]                 # [4, H] each: lin heads 0-3, gate heads 4-7
             rb += [blk.linear.bias, blk.linear_g.bias]
     P["_rows"], P["_rb"] = pk.cat(rows, 0), pk.cat(rb)                       # [2L * 8, H], [2L * 8]
-    P["W_in"], P["b_in"] = pk.copy(gnn.linear_in.weight, wd), gnn.linear_in.bias
-    P["W_out"], P["b_out"] = pk.copy(gnn.linear_out.weight, wd), gnn.linear_out.bias
+    P["W_in"], P["b_in"] = pk.copy(gnn.linear_in.weight, wd, with_T=True), gnn.linear_in.bias
+    P["W_out"], P["b_out"] = pk.copy(gnn.linear_out.weight, wd, with_T=True), gnn.linear_out.bias
     P["gcl"] = [gcl_params(getattr(gnn, "gcl_%d" % i), pk) for i in range(L)]
     P["out_layer"] = gcl_params(gnn.out_layer, pk)
     att = []

@@ -123,6 +123,12 @@ def _mm_in(x):
     return x
 
 
+def _wt(W):
+    """W^T as a contiguous operand: the copy the parameter pack wrote next to W (param_pack.ParamPack.cat(with_T=True)), else a transpose kernel."""
+    t = getattr(W, "_fab_T", None)
+    return t if (t is not None and t.shape == (W.shape[1], W.shape[0])) else W.t().contiguous()
+
+
 def _attach_b16(y, y16):
     """Remember y16 as the bf16 operand copy of the fp32 tensor y (what _mm_in would otherwise produce with a cast kernel)."""
     if y16 is not None:
@@ -158,6 +164,7 @@ class _Linear(torch.autograd.Function):
         ctx.sink_x, ctx.sink_res = _sink_of(x), _sink_of(residual)
         ctx.x_shape = x.shape
         ctx.save_for_backward(xin, W, x2in, y if (act_epi == K.ACT_RELU and not relu_res) else None, D)
+        ctx.Wt = getattr(W, "_fab_T", None)           # W^T written by the parameter pack next to W, if any
         return y
 
     @staticmethod
@@ -183,13 +190,13 @@ class _Linear(torch.autograd.Function):
         if sink_x is not None:
             # x has a shared gradient buffer: its input gradient is stored / accumulated there by the GEMM epilogue (x2, if any,
             # gets its own GEMM over the other K-slice of W)
-            Wt = W.t().contiguous()
+            Wt = ctx.Wt if ctx.Wt is not None else W.t().contiguous()
             dx = sink_x.gemm_into(dpre, Wt[:K1], x)
             if ctx.has_x2 and ctx.needs_input_grad[3]:
                 dx2, _ = K.gemm(dpre, Wt[K1:], out_dtype=torch.float32 if ctx.x2_dtype == torch.float32 else ctx.x2_dtype)
         elif ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[3]):
             if N % 8 == 0:
-                Wt, dmm = W.t().contiguous(), dpre                      # [K, N] (parameter-only transpose)
+                Wt, dmm = (ctx.Wt if ctx.Wt is not None else W.t().contiguous()), dpre      # [K, N] (parameter-only transpose)
             else:                                                       # tiny heads (N = 1): pad the contraction dim to 8
                 Np = (N + 7) // 8 * 8
                 Wt = torch.zeros((W.shape[1], Np), dtype=W.dtype, device=W.device)
@@ -261,6 +268,7 @@ class _MLP2(torch.autograd.Function):
         ctx.sink_x, ctx.sink_res = _sink_of(x), _sink_of(residual)
         ctx.x2_dtype = x2.dtype if x2 is not None else None
         ctx.save_for_backward(xin, x2in, W1, W2, t, D)
+        ctx.W1t, ctx.W2t = getattr(W1, "_fab_T", None), getattr(W2, "_fab_T", None)
         return y
 
     @staticmethod
@@ -275,10 +283,10 @@ class _MLP2(torch.autograd.Function):
             dy16, db2 = dy, K.colsum(dy)
         dW2 = _weight_grad(dy16, t, K.ACT_NONE).to(W2.dtype) if ni[4] else None
         aux, dact = (t, K.ACT_RELU) if ctx.act == K.ACT_RELU else (D, K.ACT_STORED_DERIV)
-        dpre, _ = K.gemm(dy16, W2.t().contiguous(), aux=aux, dact=dact, out_dtype=md)      # (dy W2) * act'(pre)
+        dpre, _ = K.gemm(dy16, ctx.W2t if ctx.W2t is not None else W2.t().contiguous(), aux=aux, dact=dact, out_dtype=md)      # (dy W2) * act'(pre)
         db1 = K.colsum(dpre) if ni[3] else None
         dW1 = _weight_grad(dpre, xin, K.ACT_NONE, x2in).to(W1.dtype) if ni[2] else None
-        W1t = W1.t().contiguous()
+        W1t = ctx.W1t if ctx.W1t is not None else W1.t().contiguous()
         K1 = xin.shape[1]
         dres = dy if (ctx.has_res and ni[6]) else None
         dx = dx2 = None

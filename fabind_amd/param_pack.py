@@ -63,13 +63,13 @@ class EagerPack:
     def __init__(self, device):
         self.dev = device
 
-    def cat(self, pieces, dim=0, dtype=None):
+    def cat(self, pieces, dim=0, dtype=None, with_T=False):
         first = next(p for p in pieces if not isinstance(p, tuple))
         ts = [torch.zeros(p[1:], dtype=first.dtype, device=self.dev) if isinstance(p, tuple) else p for p in pieces]
         t = ts[0] if len(ts) == 1 else torch.cat(ts, dim)
         return (t.to(dtype) if dtype is not None else t).contiguous()
 
-    def copy(self, view, dtype=None):
+    def copy(self, view, dtype=None, with_T=False):
         return self.cat([view], 0, dtype)
 
     zeros = staticmethod(lambda *shape: ("zeros",) + tuple(shape))
@@ -82,10 +82,13 @@ class ParamPack:
     def __init__(self, device):
         self.dev = device
         self.reqs = []           # (ndim, dtype, dim, [piece]) with piece = tensor view | ("zeros", *shape)
+        self.t_of = {}           # request -> request holding its transpose
 
     def resolve(self, tree):
         """Run the collected requests and replace every handle in a nested dict / list structure by its tensor."""
         outs = self.run()
+        for k, kt in self.t_of.items():                        # W._fab_T = W^T, written by the same launch (the adjoints' operand)
+            outs[k]._fab_T = outs[kt]
 
         def walk(x):
             if isinstance(x, _H):
@@ -98,17 +101,24 @@ class ParamPack:
         return walk(tree)
 
     # ---- requests ------------------------------------------------------------------------------------------------
-    def cat(self, pieces, dim=0, dtype=None):
-        """Handle of cat(pieces, dim) cast to dtype; a piece is a 1-D / 2-D view of a parameter or ParamPack.zeros(...)."""
+    def cat(self, pieces, dim=0, dtype=None, with_T=False):
+        """Handle of cat(pieces, dim) cast to dtype; a piece is a 1-D / 2-D view of a parameter or ParamPack.zeros(...).
+        with_T (2-D): the same launch also writes the transpose, attached to the result as `._fab_T` (the input-gradient
+        contraction of a Linear wants W^T; nothing differentiates through it)."""
         first = next(p for p in pieces if not isinstance(p, tuple))
         nd = first.dim()
         assert nd in (1, 2) and (dim == 0 or nd == 2)
         dtype = dtype or first.dtype
         self.reqs.append((nd, dtype, dim, list(pieces)))
-        return _H(len(self.reqs) - 1)
+        k = len(self.reqs) - 1
+        if with_T and nd == 2:
+            tp = [("zeros", p[2], p[1]) if isinstance(p, tuple) else p.t() for p in pieces]
+            self.reqs.append((2, dtype, 1 - dim, tp))
+            self.t_of[k] = k + 1
+        return _H(k)
 
-    def copy(self, view, dtype=None):
-        return self.cat([view], 0, dtype)
+    def copy(self, view, dtype=None, with_T=False):
+        return self.cat([view], 0, dtype, with_T)
 
     @staticmethod
     def zeros(*shape):
@@ -199,8 +209,9 @@ class ParamPack:
         rows, keep_g = [], []
         check_overlap = os.environ.get("FABIND_PARAM_PACK", "") == "check"
         cover = [np.zeros(n, dtype=np.int8) for n in sizes] if check_overlap else None
-        for (nd, dtype, dim, pieces), (oshape, offs), g in zip(self.reqs, self._lay, gouts):
-            if g is None:
+        t_reqs = set(self.t_of.values())
+        for k_req, ((nd, dtype, dim, pieces), (oshape, offs), g) in enumerate(zip(self.reqs, self._lay, gouts)):
+            if g is None or k_req in t_reqs:             # (nothing differentiates through the transposed copies)
                 continue
             g = g.contiguous()
             ld, esz_g = oshape[1], _ESZ[g.dtype]
@@ -233,6 +244,7 @@ class _PackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pack, *bases):
         ctx.pack = pack
+        ctx.set_materialize_grads(False)          # an unused output's gradient stays None (a materialised zero block would be WRITTEN)
         return tuple(pack._forward())
 
     @staticmethod
