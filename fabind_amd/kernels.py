@@ -362,7 +362,7 @@ EDGE_BWD_TIMES = None   # set to an int64[12] device tensor to collect per-phase
 
 
 def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, dagg, colptr, perm, p_drop=0.0, seed=0,
-                       want_edges=False, dab_bf16=False):
+                       want_edges=False, dab_bf16=False, w_dtype=torch.float32):
     """Adjoint of gcl_edge_fused (csrc/fused_edge.hip): returns dAB [N,2H] fp32, drh [E], dw_r, dW2, db2, dWc, dbc, dw3.
     The five [E,H] bf16 operands it writes (S1, M, dT, dP2 for the weight gradients, dP1 for the sending-side
     reduction) are scratch that is released on return."""
@@ -425,11 +425,11 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
             segment_sum(dP1[:E], colptr, N, eidx=perm, out16=dAB[:, H:])
         else:
             segment_sum(dP1[:E], colptr, N, eidx=perm, out=dAB[:, H:])
-        dW2 = gemm_tn(dP2[:E], S1[:E])
-        dWc = gemm_tn(dT[:E], Mm[:E])
+        dW2 = gemm_tn(dP2[:E], S1[:E], out_dtype=w_dtype)       # (the split reduction writes the dtype autograd carries the weights in)
+        dWc = gemm_tn(dT[:E], Mm[:E], out_dtype=w_dtype)
     else:
-        dW2 = torch.zeros((H, H), dtype=torch.float32, device=dev)
-        dWc = torch.zeros((H, H), dtype=torch.float32, device=dev)
+        dW2 = torch.zeros((H, H), dtype=w_dtype, device=dev)
+        dWc = torch.zeros((H, H), dtype=w_dtype, device=dev)
     ps = part.sum(0)
     out = (dAB, drh[:E], ps[3], dW2, ps[0], dWc, ps[1], ps[2])
     return out + (Mm[:E].clone(),) if want_edges else out
@@ -438,7 +438,7 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
 _ZERO_PAGE = {}
 
 
-def gemm_tn(Y, X, splits=None):
+def gemm_tn(Y, X, splits=None, out_dtype=torch.float32):
     """sum_e Y[e,:]^T X[e,:] -> [M, N] fp32 (bf16 operands, LDS transpose reads; no materialised transposes)."""
     E, M = Y.shape
     N = X.shape[1]
@@ -458,5 +458,10 @@ def gemm_tn(Y, X, splits=None):
               lambda: check(_lib.load().fabind_gemm_tn(ptr(Y), _ld(Y), ptr(X), _ld(X), ptr(part), M, N, E, splits, ptr(zp),
                                                        None, 0, stream()), "fabind_gemm_tn"))
     if splits == 1:
-        return part[0]
-    return colsum(part.reshape(splits, M * N)).reshape(M, N)
+        return part[0] if out_dtype == torch.float32 else part[0].to(out_dtype)
+    if (M * N) % 4 == 0:                                   # the split reduction writes the dtype the consumer carries (no cast kernel)
+        out = torch.empty((M, N), dtype=out_dtype, device=dev)
+        check(_lib.load().fabind_split_sum(ptr(part), splits, M * N, ptr(out), dt_code(out_dtype), stream()), "fabind_split_sum")
+        return out
+    out = colsum(part.reshape(splits, M * N)).reshape(M, N)
+    return out if out_dtype == torch.float32 else out.to(out_dtype)

@@ -54,17 +54,23 @@ def _transposed(x, act=K.ACT_NONE, Rp=None):
     return out
 
 
-def _weight_grad(dpre, x, act_pro, x2=None):
-    """dW = dpre^T [act(x) | x2].  bf16: TN contraction with LDS transpose reads (no transposed copies);
-    fp32 parity mode / odd widths: explicit transposes + split-K NT GEMMs over the (padded) row dimension."""
+def _weight_grad(dpre, x, act_pro, x2=None, out_dtype=torch.float32):
+    """dW = dpre^T [act(x) | x2] as out_dtype.  bf16: TN contraction with LDS transpose reads (no transposed copies), its split
+    reduction writing out_dtype directly; fp32 parity mode / odd widths: explicit transposes + split-K NT GEMMs over the (padded)
+    row dimension."""
+    return _weight_grad_f32(dpre, x, act_pro, x2, out_dtype)
+
+
+def _weight_grad_f32(dpre, x, act_pro, x2, out_dtype):
     bf = torch.bfloat16
     if (act_pro == K.ACT_NONE and dpre.dtype == bf and x.dtype == bf and (x2 is None or x2.dtype == bf)
             and dpre.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and (x2 is None or x2.shape[1] % 8 == 0)
             and dpre.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dpre.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
-        dW = K.gemm_tn(dpre, x)
-        if x2 is not None:
-            dW = torch.cat([dW, K.gemm_tn(dpre, x2)], 1)
-        return dW
+        if x2 is None:
+            return K.gemm_tn(dpre, x, out_dtype=out_dtype)
+        return torch.cat([K.gemm_tn(dpre, x, out_dtype=out_dtype), K.gemm_tn(dpre, x2, out_dtype=out_dtype)], 1)
+    if out_dtype != torch.float32:
+        return _weight_grad_f32(dpre, x, act_pro, x2, torch.float32).to(out_dtype)
     S, Rp = _ksplit(dpre.shape[0])
     dpt = _transposed(dpre, Rp=Rp)
     xt = _transposed(x, act_pro, Rp=Rp)
@@ -211,7 +217,7 @@ class _Linear(torch.autograd.Function):
             else:
                 dx = dfull
         if ctx.needs_input_grad[1]:
-            dW = _weight_grad(dpre, x, K.ACT_NONE, x2).to(W.dtype)
+            dW = _weight_grad(dpre, x, K.ACT_NONE, x2, W.dtype)
         if want_db and db is None:
             db = K.colsum(dpre)
         dres = dy.float() if (ctx.has_res and ctx.needs_input_grad[4]) else None
@@ -281,11 +287,11 @@ class _MLP2(torch.autograd.Function):
             dy16, db2 = _mul_dact_colsum(dy, None, K.ACT_NONE, md)          # one pass: cast + bias gradient
         else:
             dy16, db2 = dy, K.colsum(dy)
-        dW2 = _weight_grad(dy16, t, K.ACT_NONE).to(W2.dtype) if ni[4] else None
+        dW2 = _weight_grad(dy16, t, K.ACT_NONE, None, W2.dtype) if ni[4] else None
         aux, dact = (t, K.ACT_RELU) if ctx.act == K.ACT_RELU else (D, K.ACT_STORED_DERIV)
         dpre, _ = K.gemm(dy16, ctx.W2t if ctx.W2t is not None else W2.t().contiguous(), aux=aux, dact=dact, out_dtype=md)      # (dy W2) * act'(pre)
         db1 = K.colsum(dpre) if ni[3] else None
-        dW1 = _weight_grad(dpre, xin, K.ACT_NONE, x2in).to(W1.dtype) if ni[2] else None
+        dW1 = _weight_grad(dpre, xin, K.ACT_NONE, x2in, W1.dtype) if ni[2] else None
         W1t = ctx.W1t if ctx.W1t is not None else W1.t().contiguous()
         K1 = xin.shape[1]
         dres = dy if (ctx.has_res and ni[6]) else None
@@ -367,7 +373,7 @@ class _LinearRowdot(torch.autograd.Function):
         assert ctx.act_pro == K.ACT_NONE
         Wt = W.t().contiguous()
         dx, _ = K.gemm(dz, Wt, out_dtype=x.dtype)
-        dW = _weight_grad(dz, x, K.ACT_NONE).to(W.dtype)
+        dW = _weight_grad(dz, x, K.ACT_NONE, None, W.dtype)
         db = K.colsum(dz)
         return dx, dW, db, du, None, None
 
@@ -414,7 +420,7 @@ class _EdgeTail(torch.autograd.Function):
             dM, _ = K.gemm(dz, Wt, residual=dagg.contiguous(), r_index=row, out_dtype=Mm.dtype)
         else:
             dM, _ = K.gemm(dz, Wt, out_dtype=Mm.dtype)
-        dW = _weight_grad(dz, Mm, K.ACT_NONE).to(Wc.dtype)
+        dW = _weight_grad(dz, Mm, K.ACT_NONE, None, Wc.dtype)
         return dM, dW, K.colsum(dz), du, None, None, None, None
 
 
@@ -451,7 +457,7 @@ class _FusedEdge(torch.autograd.Function):
             ds = torch.zeros(g.row_ctx.shape[0], dtype=torch.float32, device=AB16.device)
         dAB, drh, dwr, dW2, db2, dWc, dbc, dw3 = K.gcl_edge_fused_bwd(
             AB16, ctx.H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, ds.reshape(-1).float(), dagg.float(),
-            colptr, perm, ctx.p_drop, ctx.seed, dab_bf16=AB16.dtype == torch.bfloat16)
+            colptr, perm, ctx.p_drop, ctx.seed, dab_bf16=AB16.dtype == torch.bfloat16, w_dtype=W2.dtype)
         return (dAB.to(AB16.dtype), drh, dwr, dW2.to(W2.dtype), db2, dWc.to(Wc.dtype), dbc, dw3, None, None, None, None, None)
 
 
@@ -956,7 +962,7 @@ class _InterAttn(torch.autograd.Function):
                 dpre, dbc = _mul_dact_colsum(dcv, None, K.ACT_NONE, md) if FUSE_DB else (_mul_dact(dcv, None, K.ACT_NONE, md), None)
             K.gemm(dpre, Wc.t().contiguous(), out=dqkv[:, 2 * H:], accumulate=True)
             if ctx.needs_input_grad[15]:
-                dWc = _weight_grad(dpre, v_in, K.ACT_NONE).to(Wc.dtype)
+                dWc = _weight_grad(dpre, v_in, K.ACT_NONE, None, Wc.dtype)
             if ctx.needs_input_grad[16]:
                 dbc = dbc if dbc is not None else K.colsum(dpre)
             else:

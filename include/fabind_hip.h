@@ -36,8 +36,9 @@ const char* fabind_last_error(void);
  * 6 = bf16 result copies emitted by their producers (no cast kernels): fabind_segment_sum takes (out16, ldo16), fabind_gcl_edge_fused takes agg16, fabind_inter_attn_fwd takes h16,
  *     FabindEdgeBwdArgs grew {dAB16, lddab16}; fabind_gcl_edge_fused_set_variant / _variant (forward kernel form) added.
  * 7 = fabind_multi_copy + FabindCopySeg added (the parameter pack and its adjoint as one launch each).
+ * 8 = fabind_split_sum added (split-contraction partials reduced straight into fp32 or bf16).
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 7
+#define FABIND_ABI_VERSION 8
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -116,6 +117,8 @@ typedef struct FabindCopySeg {
     int vec4, pad_;
 } FabindCopySeg;
 int fabind_multi_copy(const FabindCopySeg* segs_dev, int n_segs, int blocks_per_seg, hipStream_t stream);
+/* out[i] = sum_s part[s * n + i] (fixed order), written as out_dt: the split reduction of fabind_gemm_tn / split-K partials. */
+int fabind_split_sum(const float* part, int splits, long n, void* out, int out_dt, hipStream_t stream);
 /* out[c] (+)= sum_r in[r,c]; scratch = float[nchunk*C] (bias gradients, deterministic two-pass). */
 int fabind_colsum(const void* in, int in_dt, int ldi, float* out, int R, int C, int accumulate, float* scratch,
                   int nchunk, hipStream_t stream);
