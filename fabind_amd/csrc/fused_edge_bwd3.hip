@@ -16,9 +16,9 @@
 //     compute waves                                         store wave
 //     P0  gather, S1 -> tile                                (idle)
 //     --- barrier
-//     contraction 1  (reads S1)                             S1 tile -> global
+//     contraction 1  (reads S1)                             S1 tile -> global, silu'(pre1) tile -> scratch slab
 //     --- barrier
-//     epilogue 1     (M -> tile, silu'(pre2) -> scratch)    (idle)
+//     epilogue 1     (M -> tile, silu'(pre2) -> 2nd tile)   (idle)
 //     --- barrier
 //     contraction 2                                         M tile -> global
 //     ...            (dT with contraction 3, dP2 with contraction 4)
@@ -27,8 +27,11 @@
 //     P6  row scan   (reads dP1)                            dP1 tile -> global
 //     --- barrier
 //
-// Nine waves put three on one SIMD, i.e. <= 168 VGPRs per wave: the tile is 96 edges (accumulators 96 + fragments 56 registers)
-// rather than the 128 of the eight-wave form; one weight-fragment load feeds six matrix-core instructions.
+// Nine waves put three on one SIMD, i.e. <= 168 VGPRs per wave: the tile is 64 edges (accumulators 64 + fragments 48 registers; a
+// 96-edge instantiation spilled in the epilogues, each reload a vector-memory round trip behind the epilogue's own stores).  Two LDS
+// tiles: the edge tile, rewritten in place by every stage, and a second one that holds silu'(pre1) from P0 until the store wave has
+// copied it to the work-group's scratch slab (read back in P5) and then silu'(pre2) from the P1 epilogue to the P3 epilogue -- the
+// compute waves issue no global stores except the per-node sums of the row scan and d rhohat.
 // The gathered rows of P0 and the scratch rows of P5 are loaded a batch of iterations at a time (all loads of a batch in flight
 // before the first is used); the row / col / rhohat / ds tables of the NEXT tile are fetched during P6.  (Issuing the next tile's
 // gathers during P6 as well only moved their latency into the scan, whose own loads return behind them: tried, +5 %; issuing them at the
