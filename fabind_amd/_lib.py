@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FABIND_LIB") or os.path.join(_HERE, "libfabind_hip.so")      # FABIND_LIB: an A/B build (tools/probes)
 
-ABI_VERSION = 8          # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
+ABI_VERSION = 9          # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -68,6 +68,7 @@ SIGNATURES = {
     "fabind_inter_coord_fold": [_vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp, _f, ctypes.c_uint, _vp],
     "fabind_post_optimize": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "fabind_multi_copy": [_vp, _i, _i, _vp],
+    "fabind_zero_empty_rows": [_vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp],
     "fabind_split_sum": [_vp, _i, ctypes.c_long, _vp, _i, _vp],
     "fabind_segment_sum": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp],
     "fabind_coord_update": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],

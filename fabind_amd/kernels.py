@@ -288,11 +288,23 @@ def pack_frag(W):
     return W.to(torch.bfloat16).view(N // 16, 16, Kd // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
 
 
-def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows, p_drop=0.0, seed=0, want16=False):
-    """want16: also return the aggregated messages as bf16 (the node MLP's operand), written by the same kernels."""
+def zero_empty_rows(rowptr, out, C, out2=None):
+    """out[r, :C] (and out2[r, :C]) = 0 for the rows of the CSR `rowptr` that have no entries (csrc/gcl.hip)."""
+    n_rows = rowptr.shape[0] - 1
+    check(_lib.load().fabind_zero_empty_rows(ptr(rowptr), n_rows, ptr(out), dt_code(out.dtype), _ld(out), C, ptr(out2),
+                                             dt_code(out2.dtype) if out2 is not None else 0, _ld(out2) if out2 is not None else 0,
+                                             stream()), "fabind_zero_empty_rows")
+
+
+def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows, p_drop=0.0, seed=0, want16=False, rowptr=None):
+    """want16: also return the aggregated messages as bf16 (the node MLP's operand), written by the same kernels.
+    rowptr (CSR of `row`, optional): only the rows without edges are zeroed instead of the whole output."""
     E = row.shape[0]
-    agg = torch.zeros((n_rows, H), dtype=torch.float32, device=AB16.device)
-    agg16 = torch.zeros((n_rows, H), dtype=torch.bfloat16, device=AB16.device) if want16 else None
+    alloc = torch.zeros if (rowptr is None or E == 0) else torch.empty
+    agg = alloc((n_rows, H), dtype=torch.float32, device=AB16.device)
+    agg16 = alloc((n_rows, H), dtype=torch.bfloat16, device=AB16.device) if want16 else None
+    if alloc is torch.empty:
+        zero_empty_rows(rowptr, agg, H, agg16)
     s = torch.empty((max(E, 1), 1), dtype=torch.float32, device=AB16.device)
     bnd = torch.empty(((E + 63) // 64 * 2 + 2, H), dtype=torch.float32, device=AB16.device)      # boundary runs (deterministic sums)
     _profiled("gcl_edge_fused_kernel<%d> E=%d (gather + 2 chained H x H contractions + segment-sum per edge)" % (H, E), 4.0 * E * H * H,
@@ -362,7 +374,7 @@ EDGE_BWD_TIMES = None   # set to an int64[12] device tensor to collect per-phase
 
 
 def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, dagg, colptr, perm, p_drop=0.0, seed=0,
-                       want_edges=False, dab_bf16=False, w_dtype=torch.float32):
+                       want_edges=False, dab_bf16=False, w_dtype=torch.float32, rowptr=None):
     """Adjoint of gcl_edge_fused (csrc/fused_edge.hip): returns dAB [N,2H] fp32, drh [E], dw_r, dW2, db2, dWc, dbc, dw3.
     The five [E,H] bf16 operands it writes (S1, M, dT, dP2 for the weight gradients, dP1 for the sending-side
     reduction) are scratch that is released on return."""
@@ -397,7 +409,11 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     buf = torch.empty((5, max(E, 1), H), dtype=torch.bfloat16, device=dev)
     S1, Mm, dT, dP2, dP1 = buf[0], buf[1], buf[2], buf[3], buf[4]
     dab_bf16 = bool(dab_bf16) and variant == 5          # both halves of dAB written as bf16 by their producers (no cast pass)
-    dAB = torch.zeros((N, 2 * H), dtype=torch.bfloat16 if dab_bf16 else torch.float32, device=dev)
+    # rowptr (CSR of `row`): columns [0, H) are written for nodes with edges (scan + fix-up), columns [H, 2H) for every node
+    # (segment_sum) -- only the [0, H) halves of nodes without edges need zeroing
+    dAB = (torch.zeros if (rowptr is None or E == 0) else torch.empty)((N, 2 * H), dtype=torch.bfloat16 if dab_bf16 else torch.float32, device=dev)
+    if rowptr is not None and E > 0:
+        zero_empty_rows(rowptr, dAB, H)
     drh = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
     part = torch.zeros((ng, 4, H), dtype=torch.float32, device=dev)
     dagg = dagg.contiguous()

@@ -441,7 +441,7 @@ class _FusedEdge(torch.autograd.Function):
         ctx.H, ctx.g, ctx.p_drop, ctx.seed = H, g, p_drop, seed
         ctx.save_for_backward(AB16, rhohat, w_r, W2, b2, Wc, bc, w3)
         out = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3,
-                               AB16.shape[0], p_drop, seed, want16=holder is not None)
+                               AB16.shape[0], p_drop, seed, want16=holder is not None, rowptr=g.rp_ctx)
         if holder is not None:
             holder.append(out[2])                     # the aggregated messages as the node MLP's bf16 operand (same kernels)
         return out[0], out[1]
@@ -457,7 +457,7 @@ class _FusedEdge(torch.autograd.Function):
             ds = torch.zeros(g.row_ctx.shape[0], dtype=torch.float32, device=AB16.device)
         dAB, drh, dwr, dW2, db2, dWc, dbc, dw3 = K.gcl_edge_fused_bwd(
             AB16, ctx.H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, ds.reshape(-1).float(), dagg.float(),
-            colptr, perm, ctx.p_drop, ctx.seed, dab_bf16=AB16.dtype == torch.bfloat16, w_dtype=W2.dtype)
+            colptr, perm, ctx.p_drop, ctx.seed, dab_bf16=AB16.dtype == torch.bfloat16, w_dtype=W2.dtype, rowptr=g.rp_ctx)
         return (dAB.to(AB16.dtype), drh, dwr, dW2.to(W2.dtype), db2, dWc.to(Wc.dtype), dbc, dw3, None, None, None, None, None)
 
 
@@ -471,7 +471,7 @@ def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop=0.0):
         agg, s = _FusedEdge.apply(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed, holder)
         return _attach_b16(agg, holder[0] if holder else None), s
     out = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3,
-                           AB16.shape[0], p_drop, seed, want16=w16)
+                           AB16.shape[0], p_drop, seed, want16=w16, rowptr=g.rp_ctx)
     return (_attach_b16(out[0], out[2]), out[1]) if w16 else out
 
 

@@ -37,8 +37,9 @@ const char* fabind_last_error(void);
  *     FabindEdgeBwdArgs grew {dAB16, lddab16}; fabind_gcl_edge_fused_set_variant / _variant (forward kernel form) added.
  * 7 = fabind_multi_copy + FabindCopySeg added (the parameter pack and its adjoint as one launch each).
  * 8 = fabind_split_sum added (split-contraction partials reduced straight into fp32 or bf16).
+ * 9 = fabind_zero_empty_rows added (outputs of the fused edge kernels are no longer memset whole).
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 8
+#define FABIND_ABI_VERSION 9
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -176,6 +177,10 @@ int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const int* rowpt
                        int act, float* out, int ldo,
                        void* out16 /* NULL, or a bf16 copy of the result [n_rows, ldo16]; `out` may then be NULL */, int ldo16,
                        hipStream_t stream);
+/* out[r, 0:C) (and out2[r, 0:C), if given) = 0 for every row r of a CSR with no entries (rowptr[r] == rowptr[r+1]): the rows the fused
+ * edge kernels' segment sums (egnn.py:84,790-821 unsorted_segment_sum) do not write. */
+int fabind_zero_empty_rows(const int* rowptr, int n_rows, void* out, int out_dt, int ld, int C, void* out2, int out2_dt, int ld2,
+                           hipStream_t stream);
 int fabind_coord_update(const float* x, const float* d, const float* s_part, int n_part, const float* weight,
                         const int* rowptr, int n_rows, int mean, float clampv, float* x_out, float* s_out,
                         hipStream_t stream);

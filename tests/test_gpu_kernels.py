@@ -103,6 +103,7 @@ def test_fused_edge_backward_matches_autograd(H, bm, p_drop):
     deg[7] = 333
     deg[250:] = 0
     row = torch.repeat_interleave(torch.arange(N), deg)
+    rowptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(deg, 0)]).to(torch.int32)
     E = row.shape[0]
     col = torch.randint(0, N, (E,), generator=g)
     AB16 = torch.randn(N, 2 * H, generator=g).bfloat16()
@@ -136,7 +137,7 @@ def test_fused_edge_backward_matches_autograd(H, bm, p_drop):
     if bm == 5:     # the default form can write both halves of dAB as bf16 itself (scan / fix-up / segment_sum out16): same values, rounded
         out16 = K.gcl_edge_fused_bwd(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev),
                                      Wc.to(dev), bc.to(dev), w3.to(dev), ds.to(dev), dagg.to(dev), colptr.to(dev), i32(perm),
-                                     p_drop, seed, dab_bf16=True)
+                                     p_drop, seed, dab_bf16=True, rowptr=rowptr.to(dev))
         assert out16[0].dtype == torch.bfloat16 and torch.equal(out16[0].cpu(), out[0].cpu().bfloat16())
     # the forward kernel evaluates the same mask
     agg_k, s_k = K.gcl_edge_fused(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), K.pack_frag(W2.to(dev)),
@@ -245,7 +246,8 @@ def test_fused_edge_pipeline_matches_unfused(H, variant):
     s_ref = (silu(M @ Wc.float().T + bc) * w3).sum(1)
     i32 = lambda t: t.to(torch.int32).to(dev)
     agg, s, agg16 = K.gcl_edge_fused(AB.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), K.pack_frag(W2.to(dev)),
-                                     b2.to(dev), K.pack_frag(Wc.to(dev)), bc.to(dev), w3.to(dev), N, want16=True)
+                                     b2.to(dev), K.pack_frag(Wc.to(dev)), bc.to(dev), w3.to(dev), N, want16=True,
+                                     rowptr=torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(deg, 0)]).to(torch.int32).to(dev))
     _lib.load().fabind_gcl_edge_fused_set_variant(1)
     assert (agg.cpu() - agg_ref).abs().max() <= 2e-2 * max(1.0, float(agg_ref.abs().max()))
     assert (s[:, 0].cpu() - s_ref).abs().max() <= 2e-2 * max(1.0, float(s_ref.abs().max()))
