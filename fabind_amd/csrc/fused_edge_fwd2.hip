@@ -127,7 +127,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused2_kernel(const bf16_t* __r
     {
         const bool head_cont = e0 > 0 && row[e0 - 1] == sRow[0];
         const bool tail_cont = e0 + ne < E && row[e0 + ne] == sRow[ne - 1];
-        (void)fe_scan_rows<H, false, BM, SWZ>(sX, sRow, nullptr, ne, head_cont, tail_cont, agg, (unsigned)H, bnd + (size_t)tile * 2 * H, tid, agg16, (unsigned)H);
+        (void)fe_scan_runs64<H, false, SWZ>(sX, sRow, nullptr, ne, head_cont, tail_cont, agg, (unsigned)H, bnd + (size_t)tile * 2 * H, tid, agg16, (unsigned)H);
     }
 
     // ---- P3: s = w3 . silu(M Wc^T + bc)
