@@ -70,9 +70,116 @@ def prepare_stack_params(model):
     return cached_pack(model, _build_stack_params)
 
 
-def _build_stack_params(model):
+def _gcl_pack(m, H):
+    """Kernel-side parameters of one MC_E_GCL (edge / node / coord LN-MLPs; in bf16 inference also the LayerNorm-folded
+    forms)."""
     wd = _wd()
     infer = not torch.is_grad_enabled()          # cached_pack builds the no-autograd pack under no_grad: inference-only extras
+    W = lambda t: t.to(wd).contiguous()
+    K8 = _pad8(2 * H + 1)
+    d = dict(edge=_mlp(m.edge_mlp, W, K8, K8), node=_mlp(m.node_mlp, W), coord=_mlp(m.coord_mlp, W))
+    d["coord"]["w3"] = m.coord_mlp.linear2.weight[0].float().contiguous()
+    if wd == torch.bfloat16 and infer and H % 64 == 0:
+        # coord_mlp on the messages: LayerNorm folded into the GEMM epilogue (FabindGemmArgs.row_mu / row_rs / col_c)
+        cm = m.coord_mlp
+        Wc = cm.linear1.weight.float() * cm.layernorm.weight.float()[None, :]
+        d["coord"]["foldp"] = dict(W1w=W(Wc), cvec=Wc.to(wd).float().sum(1).contiguous(), eps=float(cm.layernorm.eps),
+                                   dvec=(cm.linear1.weight.float() @ cm.layernorm.bias.float() + cm.linear1.bias.float()).contiguous())
+    if wd == torch.bfloat16 and infer:
+        # LayerNorm folded into per-node projections of the first edge Linear (csrc/norm.hip: edge_lnfold_kernel)
+        em = m.edge_mlp
+        W1w = _padded(em.linear1.weight.float() * em.layernorm.weight.float()[None, :], K8, 2 * H + 1)
+        d["fold"] = dict(W_ab=W(_cat([W1w[:, :H], W1w[:, H:2 * H]])), w_r=W1w[:, 2 * H].contiguous(),
+                         c_r=W1w[:, :H].sum(1).contiguous(), c_c=W1w[:, H:2 * H].sum(1).contiguous(),
+                         eps=float(em.layernorm.eps),
+                         dvec=_padvec(em.linear1.weight.float() @ em.layernorm.bias.float() + em.linear1.bias.float(), K8))
+    return d
+
+
+def _cam_pack(cam, H):
+    """Kernel-side parameters of one CrossAttentionModule: both RowAttentionBlocks, the three LN-MLP transitions, the
+    32-wide Hadamard pair update."""
+    wd = _wd()
+    infer = not torch.is_grad_enabled()
+    W = lambda t: t.to(wd).contiguous()
+    d = {}
+    for tag, blk in (("p", cam.p_attention_block), ("c", cam.c_attention_block)):
+        a = blk.mha
+        d["Wqg_" + tag] = W(_cat([a.linear_q.weight, a.linear_g.weight]))
+        d["bqg_" + tag] = _cat([torch.zeros_like(a.linear_g.bias), a.linear_g.bias]).contiguous()
+        d["Wkv_" + tag] = W(_cat([a.linear_k.weight, a.linear_v.weight]))
+        d["Wo_" + tag], d["bo_" + tag] = W(a.linear_o.weight), a.linear_o.bias
+    # pair biases of both blocks from z in one GEMM: columns [p lin 0-3 | p gate 4-7 | c lin 8-11 | c gate 12-15]
+    pb, cb = cam.p_attention_block, cam.c_attention_block
+    d["W_pb"] = W(_cat([pb.linear.weight, pb.linear_g.weight, cb.linear.weight, cb.linear_g.weight]))
+    d["b_pb"] = _cat([pb.linear.bias, pb.linear_g.bias, cb.linear.bias, cb.linear_g.bias]).contiguous()
+    d["tr_p"], d["tr_c"] = _mlp(cam.p_transition, W), _mlp(cam.c_transition, W)
+    d["tr_z"] = _mlp(cam.pair_transition, W)
+    i32 = cam.inter_layer
+    # the 32-wide Hadamard block is zero-padded to 64 (a32 | 0 | b32 | 0) so that the contraction with W_o32 runs on the
+    # LDS-DMA GEMM path (K % 64 == 0); the padded columns are exact zeros
+    z32w, z32b = torch.zeros_like(i32.linear_p.weight), torch.zeros_like(i32.linear_p.bias)
+    d["W_ab32"] = W(_cat([i32.linear_p.weight, z32w, i32.linear_c.weight, z32w]))  # [128, H]
+    d["b_ab32"] = _cat([i32.linear_p.bias, z32b, i32.linear_c.bias, z32b]).contiguous()
+    d["W_o32"] = W(_cat([i32.linear_out.weight, torch.zeros_like(i32.linear_out.weight)], 1))   # [H, 64]
+    d["b_o32"] = i32.linear_out.bias
+    if wd == torch.bfloat16 and infer and H in (64, 128, 256, 512):
+        # fragment-packed operands of the fused pair-update kernel (csrc/pair_fused.hip, inference)
+        tz = cam.pair_transition
+        d["pair_fused"] = dict(Wop=K.pack_frag(i32.linear_out.weight), bo=i32.linear_out.bias.float().contiguous(),
+                               ln_w=tz.layernorm.weight.float().contiguous(), ln_b=tz.layernorm.bias.float().contiguous(),
+                               eps=float(tz.layernorm.eps),
+                               W1p=K.pack_frag(tz.linear1.weight), b1=tz.linear1.bias.float().contiguous(),
+                               W2p=K.pack_frag(tz.linear2.weight), b2=tz.linear2.bias.float().contiguous(),
+                               Wbp=K.pack_frag(d["W_pb"]), bb=d["b_pb"].float().contiguous())
+    return d
+
+
+def _att_pack(m, H):
+    """Kernel-side parameters of one MC_Att_L: its CrossAttentionModule (_cam_pack) and the inter-edge attention."""
+    wd = _wd()
+    infer = not torch.is_grad_enabled()
+    W = lambda t: t.to(wd).contiguous()
+    d = _cam_pack(m.cross_attn_module, H)
+    Wkv, bkv = m.linear_kv.weight, m.linear_kv.bias
+    d["Wqkv"] = W(_cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]]))
+    d["bqkv"] = _cat([m.linear_q.bias, bkv[0::2], bkv[1::2]]).contiguous()
+    d["w_rk"], d["w_rv"] = Wkv[0::2, 0].float().contiguous(), Wkv[1::2, 0].float().contiguous()
+    wb = torch.zeros((8, H), dtype=m.attn_bias_proj.weight.dtype, device=m.attn_bias_proj.weight.device)
+    wb[0] = m.attn_bias_proj.weight[0]
+    d["W_bias"] = W(wb)
+    d["b_bias"] = _padvec(m.attn_bias_proj.bias, 8).float().contiguous()
+    d["coord"] = _mlp(m.coord_mlp, W)
+    d["coord"]["w3"] = m.coord_mlp.linear2.weight[0].float().contiguous()
+    if wd == torch.bfloat16 and infer and H % 8 == 0 and H <= 512:
+        # coord_mlp's LayerNorm folded into a per-node projection of V (csrc/norm.hip: inter_coord_fold_kernel)
+        cm = m.coord_mlp
+        W1w = cm.linear1.weight.float() * cm.layernorm.weight.float()[None, :]
+        wc = d["w_rv"] - d["w_rv"].mean()
+        d["coord_fold"] = dict(W1w=W(W1w), wc=wc.contiguous(), q_w=float((wc * wc).sum()), u=(W1w @ wc).contiguous(),
+                               d=(cm.linear1.weight.float() @ cm.layernorm.bias.float() + cm.linear1.bias.float()).contiguous(),
+                               eps=float(cm.layernorm.eps), w3=d["coord"]["w3"])
+    d["zeroH"] = torch.zeros(H, dtype=torch.float32, device=Wkv.device)
+    return d
+
+
+def gcl_params(m):
+    """Pack of a stand-alone MC_E_GCL (its reference-signature forward, fabind_amd/plus/dense.py)."""
+    return cached_pack(m, lambda mm: _gcl_pack(mm, mm.node_mlp.linear2.weight.shape[0]))
+
+
+def cam_params(cam):
+    """Pack of a stand-alone CrossAttentionModule (reference-signature forward, fabind_amd/plus/dense.py)."""
+    return cached_pack(cam, lambda c: _cam_pack(c, c.pair_hidden_dim))
+
+
+def att_params(m):
+    """Pack of a stand-alone MC_Att_L / its CrossAttentionModule (reference-signature forwards, fabind_amd/plus/dense.py)."""
+    return cached_pack(m, lambda mm: _att_pack(mm, mm.hidden_nf))
+
+
+def _build_stack_params(model):
+    wd = _wd()
     W = lambda t: t.to(wd).contiguous()
     gnn = model.gnn
     H, L = gnn.hidden_nf, gnn.n_layers
@@ -83,84 +190,9 @@ def _build_stack_params(model):
     P["W_o0"], P["b_o0"] = W(il.linear_out.weight), il.linear_out.bias
     P["W_in"], P["b_in"] = W(gnn.linear_in.weight), gnn.linear_in.bias
     P["W_out"], P["b_out"] = W(gnn.linear_out.weight), gnn.linear_out.bias
-    K8 = _pad8(2 * H + 1)
-
-    def gcl(m):
-        d = dict(edge=_mlp(m.edge_mlp, W, K8, K8), node=_mlp(m.node_mlp, W), coord=_mlp(m.coord_mlp, W))
-        d["coord"]["w3"] = m.coord_mlp.linear2.weight[0].float().contiguous()
-        if wd == torch.bfloat16 and infer and H % 64 == 0:
-            # coord_mlp on the messages: LayerNorm folded into the GEMM epilogue (FabindGemmArgs.row_mu / row_rs / col_c)
-            cm = m.coord_mlp
-            Wc = cm.linear1.weight.float() * cm.layernorm.weight.float()[None, :]
-            d["coord"]["foldp"] = dict(W1w=W(Wc), cvec=Wc.to(wd).float().sum(1).contiguous(), eps=float(cm.layernorm.eps),
-                                       dvec=(cm.linear1.weight.float() @ cm.layernorm.bias.float() + cm.linear1.bias.float()).contiguous())
-        if wd == torch.bfloat16 and infer:
-            # LayerNorm folded into per-node projections of the first edge Linear (csrc/norm.hip: edge_lnfold_kernel)
-            em = m.edge_mlp
-            W1w = _padded(em.linear1.weight.float() * em.layernorm.weight.float()[None, :], K8, 2 * H + 1)
-            d["fold"] = dict(W_ab=W(_cat([W1w[:, :H], W1w[:, H:2 * H]])), w_r=W1w[:, 2 * H].contiguous(),
-                             c_r=W1w[:, :H].sum(1).contiguous(), c_c=W1w[:, H:2 * H].sum(1).contiguous(),
-                             eps=float(em.layernorm.eps),
-                             dvec=_padvec(em.linear1.weight.float() @ em.layernorm.bias.float() + em.linear1.bias.float(), K8))
-        return d
-
-    P["gcl"] = [gcl(getattr(gnn, "gcl_%d" % i)) for i in range(L)]
-    P["out_layer"] = gcl(gnn.out_layer)
-    att = []
-    for i in range(L):
-        m = getattr(gnn, "att_%d" % i)
-        cam = m.cross_attn_module
-        d = {}
-        for tag, blk in (("p", cam.p_attention_block), ("c", cam.c_attention_block)):
-            a = blk.mha
-            d["Wqg_" + tag] = W(_cat([a.linear_q.weight, a.linear_g.weight]))
-            d["bqg_" + tag] = _cat([torch.zeros_like(a.linear_g.bias), a.linear_g.bias]).contiguous()
-            d["Wkv_" + tag] = W(_cat([a.linear_k.weight, a.linear_v.weight]))
-            d["Wo_" + tag], d["bo_" + tag] = W(a.linear_o.weight), a.linear_o.bias
-        # pair biases of both blocks from z in one GEMM: columns [p lin 0-3 | p gate 4-7 | c lin 8-11 | c gate 12-15]
-        pb, cb = cam.p_attention_block, cam.c_attention_block
-        d["W_pb"] = W(_cat([pb.linear.weight, pb.linear_g.weight, cb.linear.weight, cb.linear_g.weight]))
-        d["b_pb"] = _cat([pb.linear.bias, pb.linear_g.bias, cb.linear.bias, cb.linear_g.bias]).contiguous()
-        d["tr_p"], d["tr_c"] = _mlp(cam.p_transition, W), _mlp(cam.c_transition, W)
-        d["tr_z"] = _mlp(cam.pair_transition, W)
-        i32 = cam.inter_layer
-        # the 32-wide Hadamard block is zero-padded to 64 (a32 | 0 | b32 | 0) so that the contraction with W_o32 runs on the
-        # LDS-DMA GEMM path (K % 64 == 0); the padded columns are exact zeros
-        z32w, z32b = torch.zeros_like(i32.linear_p.weight), torch.zeros_like(i32.linear_p.bias)
-        d["W_ab32"] = W(_cat([i32.linear_p.weight, z32w, i32.linear_c.weight, z32w]))  # [128, H]
-        d["b_ab32"] = _cat([i32.linear_p.bias, z32b, i32.linear_c.bias, z32b]).contiguous()
-        d["W_o32"] = W(_cat([i32.linear_out.weight, torch.zeros_like(i32.linear_out.weight)], 1))   # [H, 64]
-        d["b_o32"] = i32.linear_out.bias
-        if wd == torch.bfloat16 and infer and H in (64, 128, 256, 512):
-            # fragment-packed operands of the fused pair-update kernel (csrc/pair_fused.hip, inference)
-            tz = cam.pair_transition
-            d["pair_fused"] = dict(Wop=K.pack_frag(i32.linear_out.weight), bo=i32.linear_out.bias.float().contiguous(),
-                                   ln_w=tz.layernorm.weight.float().contiguous(), ln_b=tz.layernorm.bias.float().contiguous(),
-                                   eps=float(tz.layernorm.eps),
-                                   W1p=K.pack_frag(tz.linear1.weight), b1=tz.linear1.bias.float().contiguous(),
-                                   W2p=K.pack_frag(tz.linear2.weight), b2=tz.linear2.bias.float().contiguous(),
-                                   Wbp=K.pack_frag(d["W_pb"]), bb=d["b_pb"].float().contiguous())
-        Wkv, bkv = m.linear_kv.weight, m.linear_kv.bias
-        d["Wqkv"] = W(_cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]]))
-        d["bqkv"] = _cat([m.linear_q.bias, bkv[0::2], bkv[1::2]]).contiguous()
-        d["w_rk"], d["w_rv"] = Wkv[0::2, 0].float().contiguous(), Wkv[1::2, 0].float().contiguous()
-        wb = torch.zeros((8, H), dtype=m.attn_bias_proj.weight.dtype, device=m.attn_bias_proj.weight.device)
-        wb[0] = m.attn_bias_proj.weight[0]
-        d["W_bias"] = W(wb)
-        d["b_bias"] = _padvec(m.attn_bias_proj.bias, 8).float().contiguous()
-        d["coord"] = _mlp(m.coord_mlp, W)
-        d["coord"]["w3"] = m.coord_mlp.linear2.weight[0].float().contiguous()
-        if wd == torch.bfloat16 and infer and H % 8 == 0 and H <= 512:
-            # coord_mlp's LayerNorm folded into a per-node projection of V (csrc/norm.hip: inter_coord_fold_kernel)
-            cm = m.coord_mlp
-            W1w = cm.linear1.weight.float() * cm.layernorm.weight.float()[None, :]
-            wc = d["w_rv"] - d["w_rv"].mean()
-            d["coord_fold"] = dict(W1w=W(W1w), wc=wc.contiguous(), q_w=float((wc * wc).sum()), u=(W1w @ wc).contiguous(),
-                                   d=(cm.linear1.weight.float() @ cm.layernorm.bias.float() + cm.linear1.bias.float()).contiguous(),
-                                   eps=float(cm.layernorm.eps), w3=d["coord"]["w3"])
-        d["zeroH"] = torch.zeros(H, dtype=torch.float32, device=Wkv.device)
-        att.append(d)
-    P["att"] = att
+    P["gcl"] = [_gcl_pack(getattr(gnn, "gcl_%d" % i), H) for i in range(L)]
+    P["out_layer"] = _gcl_pack(gnn.out_layer, H)
+    P["att"] = [_att_pack(getattr(gnn, "att_%d" % i), H) for i in range(L)]
     return P
 
 
@@ -394,15 +426,13 @@ FUSE_PAIR = os.environ.get("FABIND_PLUS_FUSE_PAIR", "1") == "1"
 FOLD_EDGE_LN = os.environ.get("FABIND_PLUS_FOLD_EDGE_LN", "1") == "1"
 
 
-def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0, bias=None, p_next=None):
-    """MC_Att_L.forward of FABind+ (egnn.py:277-300) -> (h, x, alpha, z_updated, bias_next); z is the ragged pair list.
-    pd: dropout of every nn.Dropout on the path (all constructed with args.dropout) in train / sampling mode.
-    bias: this layer's [pairs, 16] row-attention biases when the previous layer's fused pair update already produced
-    them; bias_next: the same for layer p_next (None unless the fused kernel ran)."""
-    H = h.shape[1]
+def cross_part(p, h, z, lay, pairs, pd=0.0, bias=None, p_next=None):
+    """CrossAttentionModule.forward of FABind+ (cross_att.py:20-47) on the node layout and the ragged pair list ->
+    (h, z_updated, bias_next).  bias: this layer's [pairs, 16] row-attention biases when the previous layer's fused pair
+    update already produced them; bias_next: the same for layer p_next (None unless the fused kernel ran)."""
     ad = ops.act_dtype()
     scale = 1.0 / math.sqrt(32.0)
-    # ---- CrossAttentionModule (cross_att.py:20-47), protein side in place in the node layout
+    # ---- both RowAttentionBlocks + node transitions, protein side in place in the node layout
     if bias is None:
         bias = ops.linear(z, p["W_pb"], p["b_pb"])                                                   # [pairs, 16] fp32
     hc = ops.take_rows(h, lay.c_index64)
@@ -432,6 +462,14 @@ def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0, bias=None, p_
         hd32 = pair_had(ab32, 64, pairs.p_node, pairs.c_node, ad)                                    # [pairs, 64]
         z1 = ops.linear(hd32, p["W_o32"], p["b_o32"], residual=z.float() if z.dtype != torch.float32 else z, out_dtype=ad)
         z = ln_mlp(p["tr_z"], z1, True, out_dtype=ad, pdrop=pd)
+    return h, z, bias_next
+
+
+def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0, bias=None, p_next=None):
+    """MC_Att_L.forward of FABind+ (egnn.py:277-300) -> (h, x, alpha, z_updated, bias_next); z is the ragged pair list.
+    pd: dropout of every nn.Dropout on the path (all constructed with args.dropout) in train / sampling mode."""
+    H = h.shape[1]
+    h, z, bias_next = cross_part(p, h, z, lay, pairs, pd, bias, p_next)
     # ---- inter-edge attention (att_model / node_model identical to v1; coord_mlp is an LN-MLP on v_e, handed to the
     #      fused kernel as a per-edge scalar)
     ridx = pairs.index_of(g.red_p, g.red_c, batch_id)

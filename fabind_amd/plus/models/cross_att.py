@@ -1,8 +1,10 @@
-"""CrossAttentionModule / RowAttentionBlock parameter containers (reference FABind_plus/fabind/models/cross_att.py:7-89)."""
+"""CrossAttentionModule / RowAttentionBlock of FABind+ (reference FABind_plus/fabind/models/cross_att.py:7-89): parameters
+under the reference's names; the stack runs them through fabind_amd.plus.engine, the stand-alone forwards with the
+reference's dense signatures through the adapters fabind_amd/plus/dense.py / fabind_amd/dense.py (same kernels)."""
 import torch.nn as nn
 from torch.nn import Linear
 
-from .model_utils import Attention, InteractionModule, MLPwithLastAct, _fused
+from .model_utils import Attention, InteractionModule, MLPwithLastAct
 
 
 class RowAttentionBlock(nn.Module):
@@ -23,8 +25,10 @@ class RowAttentionBlock(nn.Module):
         self.mha = Attention(args, node_hidden_dim, node_hidden_dim, node_hidden_dim, attention_hidden_dim, no_heads,
                              mha_permu=mha_permu)
 
-    def forward(self, *a, **k):
-        _fused("RowAttentionBlock")
+    def forward(self, node_embed_i, node_embed_j, pair_embed, pair_mask, node_mask_i, distance=None):
+        """Reference signature (cross_att.py:72-89): [*, I, C], [*, J, C], [*, I, J, C_pair], masks -> [*, I, C]."""
+        from ... import dense
+        return dense.row_attention(self, node_embed_i, node_embed_j, pair_embed, pair_mask, node_mask_i)
 
 
 class CrossAttentionModule(nn.Module):
@@ -44,5 +48,8 @@ class CrossAttentionModule(nn.Module):
         self.pair_transition = MLPwithLastAct(args, embedding_channels=pair_hidden_dim, n=n, out_channels=pair_hidden_dim)
         self.inter_layer = InteractionModule(node_hidden_dim, pair_hidden_dim, 32, opm=False, rm_layernorm=rm_layernorm)
 
-    def forward(self, *a, **k):
-        _fused("CrossAttentionModule")
+    def forward(self, p_embed_batched, p_mask, c_embed_batched, c_mask, pair_embed, pair_mask, c_c_dist_embed=None,
+                p_p_dist_embed=None, distance=None):
+        """Reference signature (cross_att.py:20-47) -> (p', c', updated pair embedding)."""
+        from .. import dense
+        return dense.cross_attention(self, p_embed_batched, p_mask, c_embed_batched, c_mask, pair_embed, pair_mask)

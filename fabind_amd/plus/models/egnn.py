@@ -1,9 +1,11 @@
-"""MC_E_GCL / MC_Att_L / MCAttEGNN parameter containers of FABind+ (reference FABind_plus/fabind/models/egnn.py:20-433)."""
+"""MC_E_GCL / MC_Att_L / MCAttEGNN of FABind+ (reference FABind_plus/fabind/models/egnn.py:20-433): parameters under the
+reference's names; the stack runs them through fabind_amd.plus.engine.stack_forward, the stand-alone forwards with the
+reference's signatures through fabind_amd/plus/dense.py (same layer functions, same kernels)."""
 import torch
 import torch.nn as nn
 
 from .cross_att import CrossAttentionModule
-from .model_utils import InteractionModule, MLPwithLastAct, MLPwoBias, _fused
+from .model_utils import InteractionModule, MLPwithLastAct, MLPwoBias
 
 
 class MC_E_GCL(nn.Module):
@@ -20,8 +22,11 @@ class MC_E_GCL(nn.Module):
         torch.nn.init.xavier_uniform_(self.coord_mlp.linear2.weight, gain=0.001)
         self.coord_change_maximum = coord_change_maximum
 
-    def forward(self, *a, **k):
-        _fused("MC_E_GCL")
+    def forward(self, h, edge_index, coord, edge_attr=None, node_attr=None, batch_id=None):
+        """Reference signature (egnn.py:100-118) -> (h', coord')."""
+        assert edge_attr is None and node_attr is None and batch_id is not None
+        from .. import dense
+        return dense.gcl_forward(self, h, edge_index, coord, batch_id)
 
 
 class MC_Att_L(nn.Module):
@@ -47,8 +52,13 @@ class MC_Att_L(nn.Module):
         self.inter_layer = InteractionModule(input_nf, output_nf, hidden_nf, opm=opm, rm_layernorm=args.rm_layernorm)
         self.attn_bias_proj = nn.Linear(hidden_nf, 1)
 
-    def forward(self, *a, **k):
-        _fused("MC_Att_L")
+    def forward(self, h, edge_index, coord, edge_attr=None, segment_id=None, batch_id=None, reduced_tuple=None,
+                pair_embed_batched=None, pair_mask=None, LAS_mask=None, p_p_dist_embed=None, c_c_dist_embed=None):
+        """Reference signature (egnn.py:277-300) -> (h', coord', attention weights [E], updated dense pair embedding);
+        `reduced_tuple` is recomputed from the edge list."""
+        assert edge_attr is None
+        from .. import dense
+        return dense.att_layer(self, h, edge_index, coord, segment_id, batch_id, pair_embed_batched, pair_mask)
 
 
 class MCAttEGNN(nn.Module):
@@ -77,5 +87,9 @@ class MCAttEGNN(nn.Module):
         self.out_layer = MC_E_GCL(args, hidden_nf, hidden_nf, hidden_nf, n_channel, edges_in_d=in_edge_nf, act_fn=act_fn,
                                   residual=residual, coord_change_maximum=normalize_coord(10))
 
-    def forward(self, *a, **k):
-        _fused("MCAttEGNN")
+    def forward(self, h, x, *reference_args, **reference_kwargs):
+        """The reference's positional signature (egnn.py:358-433): forward(h, x, ctx_edges, att_edges, LAS_edge_list,
+        batched_complex_coord_LAS, segment_id=, batch_id=, reduced_tuple=, pair_embed_batched=, pair_mask=, ...) ->
+        (h_out, x_out[, attention weights], pair embedding).  The model's own route is engine.stack_forward."""
+        from .. import dense
+        return dense.egnn_forward(self, h, x, *reference_args, **reference_kwargs)

@@ -1,11 +1,9 @@
-"""Parameter containers of the FABind+ LN-MLPs and attention primitives
-(reference FABind_plus/fabind/models/model_utils.py:10-74, 150-320).  The math runs in fabind_amd.plus.engine."""
+"""The FABind+ LN-MLPs and attention primitives (reference FABind_plus/fabind/models/model_utils.py:10-98, 150-320):
+parameters under the reference's names.  The stack runs their arithmetic through fabind_amd.plus.engine; the stand-alone
+forwards with the reference's (dense) signatures go through fabind_amd/plus/dense.py and fabind_amd/dense.py, on the
+same kernels."""
 import torch.nn as nn
 from torch.nn import Linear
-
-
-def _fused(name):
-    raise NotImplementedError(name + " runs fused inside the FABind+ stack (fabind_amd.plus.engine)")
 
 
 class _LnMlp(nn.Module):
@@ -28,7 +26,8 @@ class MLP(_LnMlp):
             self.dropout = nn.Dropout(args.dropout)
 
     def forward(self, z):
-        _fused("MLP")
+        from .. import dense
+        return dense.mlp(self, z, False)
 
 
 class MLPwithLastAct(_LnMlp):
@@ -41,7 +40,8 @@ class MLPwithLastAct(_LnMlp):
             self.dropout2 = nn.Dropout(args.dropout)
 
     def forward(self, z):
-        _fused("MLPwithLastAct")
+        from .. import dense
+        return dense.mlp(self, z, True)
 
 
 class MLPwoBias(_LnMlp):
@@ -53,7 +53,8 @@ class MLPwoBias(_LnMlp):
             self.dropout = nn.Dropout(args.dropout)
 
     def forward(self, z):
-        _fused("MLPwoBias")
+        from .. import dense
+        return dense.mlp(self, z, False)
 
 
 class MLP4Confidence(nn.Module):
@@ -70,7 +71,8 @@ class MLP4Confidence(nn.Module):
         self.linear2 = Linear(n * embedding_channels, out_channels)
 
     def forward(self, z):
-        _fused("MLP4Confidence")
+        from .. import dense
+        return dense.mlp(self, z, False)
 
 
 class Attention(nn.Module):
@@ -88,8 +90,10 @@ class Attention(nn.Module):
         self.linear_g = Linear(c_q, c_hidden * no_heads) if gating else None
         self.sigmoid = nn.Sigmoid()
 
-    def forward(self, *a, **k):
-        _fused("Attention")
+    def forward(self, q_x, kv_x, biases=None, distance=None):
+        """Reference signature (model_utils.py:109-147): [*, Q, Cq], [*, K, Ck], biases broadcastable to [*, heads, Q, K]."""
+        from ... import dense
+        return dense.attention(self, q_x, kv_x, biases)
 
 
 class InteractionModule(nn.Module):
@@ -105,5 +109,7 @@ class InteractionModule(nn.Module):
         self.linear_c = nn.Linear(node_hidden_dim, hidden_dim)
         self.linear_out = nn.Linear(hidden_dim, pair_hidden_dim)
 
-    def forward(self, *a, **k):
-        _fused("InteractionModule")
+    def forward(self, p_embed, c_embed, p_mask=None, c_mask=None):
+        """Reference signature (model_utils.py:296-320) -> (pair embedding [*, P, C, pair_hidden], pair mask)."""
+        from ... import dense
+        return dense.interaction(self, p_embed, c_embed, p_mask, c_mask)
