@@ -142,6 +142,10 @@ def load():
     lib.fabind_gemm_set_persistent.restype = None
     lib.fabind_gemm_tn_set_waves.argtypes = [ctypes.c_int]
     lib.fabind_gemm_tn_set_waves.restype = None
+    lib.fabind_gemm_tn_set_exp.argtypes = [ctypes.c_int]
+    lib.fabind_gemm_tn_set_exp.restype = None
+    lib.fabind_gemm_tn_tile_n.argtypes = []
+    lib.fabind_gemm_tn_tile_n.restype = ctypes.c_int
     lib.fabind_gcl_edge_fused_set_xcd_aware.argtypes = [ctypes.c_int]
     lib.fabind_gcl_edge_fused_set_xcd_aware.restype = None
     for nm in ("fabind_gcl_edge_fused_bwd2_set_exp", "fabind_gcl_edge_fused_bwd3_set_exp"):      # development knobs (void)
@@ -153,6 +157,8 @@ def load():
     if os.environ.get("FABIND_EDGE_FWD_VARIANT"):
         lib.fabind_gcl_edge_fused_set_variant.argtypes = [ctypes.c_int]
         lib.fabind_gcl_edge_fused_set_variant(int(os.environ["FABIND_EDGE_FWD_VARIANT"]))
+    if os.environ.get("FABIND_TN_WAVES"):                        # development knob: work-group layout of the TN contraction
+        lib.fabind_gemm_tn_set_waves(int(os.environ["FABIND_TN_WAVES"]))
     if "FABIND_EDGE_XCD" in os.environ:
         lib.fabind_gcl_edge_fused_set_xcd_aware(int(os.environ["FABIND_EDGE_XCD"]))
     for name, argt in SIGNATURES.items():

@@ -866,21 +866,35 @@ __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* p_lo, const bf16_t* p_
 }
 __device__ __forceinline__ int tn_swz(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
 
-template <int NSTAGE, int NW>
+template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int n) {   // s_waitcnt vmcnt(n * N) for a uniform n in 0..3
+    if (n >= 3) wait_vmcnt<3 * N>(); else if (n == 2) wait_vmcnt<2 * N>(); else if (n == 1) wait_vmcnt<N>(); else wait_vmcnt<0>();
+}
+
+template <int NSTAGE, int NW, int TN_>
 __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ X,
                                                            int ldx, float* C, int M, int N, int E, int e_per,
                                                            const bf16_t* __restrict__ zero_page, const int* groups,
-                                                           int n_tiles, int n_splits) {
-    // NW waves per work-group, 2 across N (64 columns each) and NW/2 across M: 4 waves = 128x64 per wave (102 VGPRs + 128 AGPRs,
-    // two work-groups per CU, 25 % fewer LDS fragment reads per flop); 8 waves = 64x64 per wave (132 VGPRs: one work-group per CU)
-    constexpr int TM = 256, TN_ = 128, BKE = 32;
-    constexpr int MI = TM / (NW / 2) / 16;                        // 16-row granules of the Y tile per wave
-    constexpr int PY = (BKE * TM * 2) / 1024, PX = (BKE * TN_ * 2) / 1024, PPW = (PY + PX) / NW;   // 16 + 8 pieces -> 3 per wave
+                                                           int n_tiles, int n_splits, int xf) {
+    // Output tile 256 x TN_, NW waves per work-group: TN_/64 across N (64 columns each), the rest across M.
+    //   <3, 4, 128>: 128x64 per wave, 124 VGPRs + 128 AGPRs, two work-groups per CU (3 x 24 KiB of LDS each);
+    //   <3, 8, 128>: 64x64 per wave, one work-group per CU (kept as a knob);
+    //   <NSTAGE, 8, 256>: 128x64 per wave, ONE work-group per CU with NSTAGE x 32 KiB of LDS: a third fewer operand bytes per flop from
+    //   L2, and -- what matters on long operands -- NSTAGE - 1 stages of DISTINCT rows in flight per e-range instead of two: the tiles of
+    //   one e-range request the same rows, so the bytes in flight at the HBM are (ranges running) x (stages in flight) x 64 KiB, and the
+    //   contraction over 1.5 M edges is bound by exactly that (probe knobs 1 / 4: loads off 625 us, loads hitting in cache 800 us,
+    //   loads from HBM 1,050 us at 3.0 TB/s with two stages in flight).
+    constexpr int TM = 256, BKE = 32;
+    constexpr int WN = TN_ / 64, WMW = NW / WN;                    // waves across N / across M
+    constexpr int MI = TM / WMW / 16;                             // 16-row granules of the Y tile per wave
+    constexpr int PY = (BKE * TM * 2) / 1024, PX = (BKE * TN_ * 2) / 1024;    // one-KiB pieces per k-step
+    constexpr int YPW = PY / NW, XPW = PX / NW, PPW = YPW + XPW;               // per wave: 4 + 2 (4 waves), 2 + 1 / 2 + 2 (8 waves)
+    constexpr int XRPP = 1024 / (TN_ * 2), XCPR = TN_ * 2 / 16;               // X piece: rows per piece, 16-B chunks per row
+    static_assert(NSTAGE >= 3 && NSTAGE <= 5 && YPW >= 1 && XPW >= 1, "tile configuration");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* sT = (bf16_t*)smem;                                  // [NSTAGE][ Y tile 32x256 | X tile 32x128 ]
-    constexpr int STAGE_ELEMS = BKE * (TM + TN_);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    constexpr unsigned STAGE_BYTES = BKE * (TM + TN_) * 2, X_BYTES0 = BKE * TM * 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: LDS-DMA destinations and piece ids live in SGPRs
+    const int wm = wave / WN, wn = wave % WN;
     long c_goff = 0;
     if (groups) {   // ragged batch: int32[8] = {y_off lo/hi (elements), ldy, M, x_row0, E, c_off lo/hi (elements)}
         const int* g = groups + (size_t)blockIdx.z * 8;
@@ -902,32 +916,45 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __r
     const int ebeg = split * e_per, eend = min(E, ebeg + e_per);
     const int nk = (eend - ebeg + BKE - 1) / BKE;
 
-    // per-lane source descriptors of this wave's PPW pieces: (is_y, row-in-tile, element offset in the row)
-    int p_isy[PPW], p_row[PPW], p_col[PPW];
+    // Staging.  A wave moves YPW pieces of the Y tile (2 rows of 512 B each) and XPW pieces of the X tile (4 rows of 256 B): which is
+    // which is known at compile time, a lane's source pointer is formed ONCE and advanced by 32 rows per k-step, a column outside the
+    // matrix points at the zero page with a zero stride, and a row past the end of the range selects the zero page (two v_cndmask).
+    // (Round 2: the previous form recomputed a 64-bit address per piece per k-step under divergent branches -- ~40 instructions per
+    // piece, VALU busy 31 % of the kernel's time.)
+    const bf16_t* gp[PPW];
+    long ginc[PPW];
+    int grow[PPW];
+    unsigned gdst[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int q = wave * PPW + j;
-        if (q < PY) {                        // Y piece: 2 rows of 512 B
-            const int r = q * 2 + (lane >> 5), p = lane & 31;          // 16-B chunk position in the LDS row
-            const int src = (((p >> 1) ^ tn_swz(r)) << 1) | (p & 1);
-            p_isy[j] = 1; p_row[j] = r; p_col[j] = m0 + src * 8;
-        } else {                             // X piece: 4 rows of 256 B
-            const int r = (q - PY) * 4 + (lane >> 4), p = lane & 15;
-            const int src = (((p >> 1) ^ tn_swz(r)) << 1) | (p & 1);
-            p_isy[j] = 0; p_row[j] = r; p_col[j] = n0 + src * 8;
+        if (j < YPW) {
+            const int q = wave * YPW + j;
+            const int r = q * 2 + (lane >> 5), pp = lane & 31;           // 16-B chunk position in the LDS row
+            const int col = m0 + ((((pp >> 1) ^ tn_swz(r)) << 1) | (pp & 1)) * 8;
+            const bool ok = col < M;
+            gp[j] = ok ? Y + (size_t)(ebeg + r) * ldy + col : zero_page;
+            ginc[j] = ok ? (long)BKE * ldy : 0;
+            grow[j] = ebeg + r;
+            gdst[j] = (unsigned)q * 1024u;
+        } else {
+            const int q = wave * XPW + (j - YPW);
+            const int r = q * XRPP + lane / XCPR, pp = lane % XCPR;
+            const int col = n0 + ((((pp >> 1) ^ tn_swz(r)) << 1) | (pp & 1)) * 8;
+            const bool ok = col < N;
+            gp[j] = ok ? X + (size_t)(ebeg + r) * ldx + col : zero_page;
+            ginc[j] = ok ? (long)BKE * ldx : 0;
+            grow[j] = ebeg + r;
+            gdst[j] = X_BYTES0 + (unsigned)q * 1024u;
         }
     }
-    auto stage = [&](int st, int e0) {
-        bf16_t* base = sT + (size_t)st * STAGE_ELEMS;
+    const uintptr_t zp = (uintptr_t)zero_page;
+    auto stage = [&](unsigned st_bytes) {
 #pragma unroll
         for (int j = 0; j < PPW; ++j) {
-            const int q = wave * PPW + j;
-            const int e = e0 + p_row[j];
-            const bf16_t* src;
-            if (p_isy[j]) src = (e < eend && p_col[j] < M) ? Y + (size_t)e * ldy + p_col[j] : zero_page;
-            else src = (e < eend && p_col[j] < N) ? X + (size_t)e * ldx + p_col[j] : zero_page;
-            bf16_t* dst = p_isy[j] ? base + (size_t)q * 512 : base + BKE * TM + (size_t)(q - PY) * 512;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)dst, 16, 0, 0);
+            const uintptr_t a = grow[j] < eend ? (uintptr_t)gp[j] : zp;
+            __builtin_amdgcn_global_load_lds((gptr_t)a, (lptr_t)(smem + st_bytes + gdst[j]), 16, 0, 0);
+            if (!(xf & 4)) gp[j] += ginc[j];                        // probe bit 4: every k-step re-reads the first rows (cache hits)
+            grow[j] += BKE;
         }
     };
     f32x4_t acc[MI][4];
@@ -936,62 +963,114 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __r
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s_ = 0; s_ < NSTAGE - 1; ++s_)
-        if (s_ < nk) stage(s_, ebeg + s_ * BKE);
+    for (int s_ = 0; s_ < NSTAGE; ++s_)
+        if (s_ < nk) stage((unsigned)s_ * STAGE_BYTES);
+    // transpose-read offsets of this lane inside a stage (bytes): Y granule i at row r1, X granule i at row r1; the second half of
+    // a fragment sits 4 rows further down in the SAME swizzle class (tn_swz(r1 + 4) == tn_swz(r1)) -> an immediate offset
     const int g = lane >> 4, sl = lane & 15;
-    const int r1 = g * 8 + (sl >> 2), r2 = r1 + 4, co = (sl & 3) * 4;
-    const int z1 = tn_swz(r1), z2 = tn_swz(r2);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int ahead = min(NSTAGE - 2, nk - 1 - kt);
-        if (ahead >= 2) wait_vmcnt<2 * PPW>(); else if (ahead == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, ebeg + (kt + NSTAGE - 1) * BKE);
-        const bf16_t* tY = sT + (size_t)(kt % NSTAGE) * STAGE_ELEMS;
-        const bf16_t* tX = tY + BKE * TM;
-        // all 16 transpose reads of the k-step are issued before ONE wait (a wait per fragment serialised 8 LDS
-        // round trips per k-step)
-        typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
-        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-        u32x2 ya[MI], yb[MI], xa[4], xb[4];
+    const int r1 = g * 8 + (sl >> 2), co = (sl & 3) * 4;
+    const int z1 = tn_swz(r1);
+    const unsigned lds0 = (unsigned)(uintptr_t)smem;
+    unsigned offY[MI], offX[4];
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int gm = wm * MI + i;                          // 16-column granule of the Y tile
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ya[i]) : "v"((unsigned)(uintptr_t)(tY + r1 * TM + ((gm ^ z1) * 16) + co)) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(yb[i]) : "v"((unsigned)(uintptr_t)(tY + r2 * TM + ((gm ^ z2) * 16) + co)) : "memory");
-        }
+    for (int i = 0; i < MI; ++i) offY[i] = lds0 + (unsigned)(r1 * TM + (((wm * MI + i) ^ z1) * 16) + co) * 2u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) offX[i] = lds0 + X_BYTES0 + (unsigned)(r1 * TN_ + (((wn * 4 + i) ^ z1) * 16) + co) * 2u;
+    // Schedule of one k-step (round 2 -- the previous loop read all fragments, waited, then ran all MFMAs: its LDS latency,
+    // its barrier and its operand wait added up instead of overlapping, 34 % of the MFMA peak):
+    //   top:  issue the reads of the SECOND half of the Y granules of stage kt; wait for the first half (+ X), issued one phase ago
+    //   A:    MFMAs of the first half
+    //   mid:  second half landed in registers -> this wave is done with stage kt in LDS; wait for this wave's pieces of stage kt+1;
+    //         barrier (every wave done with stage kt, all of stage kt+1 landed); refill the slot of stage kt with stage kt+NSTAGE; issue the
+    //         reads of the first half (+ X) of stage kt+1
+    //   B:    MFMAs of the second half
+    // so every LDS read has half a k-step of MFMAs (16 x 16 cycles) to land under, and operand loads have NSTAGE - 1 k-steps.
+    typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    constexpr int HALF = MI / 2;
+    u32x2 ya[MI], yb[MI], xa[4], xb[4];
+    auto read_first = [&](unsigned sb) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int gn = wn * 4 + i;                           // 16-column granule of the X tile
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xa[i]) : "v"((unsigned)(uintptr_t)(tX + r1 * TN_ + ((gn ^ z1) * 16) + co)) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xb[i]) : "v"((unsigned)(uintptr_t)(tX + r2 * TN_ + ((gn ^ z2) * 16) + co)) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xa[i]) : "v"(offX[i] + sb) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xb[i]) : "v"(offX[i] + sb), "n"(4 * TN_ * 2) : "memory");
         }
-        if constexpr (MI == 4) {
-            asm volatile("s_waitcnt lgkmcnt(0)"
+#pragma unroll
+        for (int i = 0; i < HALF; ++i) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ya[i]) : "v"(offY[i] + sb) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yb[i]) : "v"(offY[i] + sb), "n"(4 * TM * 2) : "memory");
+        }
+    };
+    auto read_second = [&](unsigned sb) {
+#pragma unroll
+        for (int i = HALF; i < MI; ++i) {
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ya[i]) : "v"(offY[i] + sb) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yb[i]) : "v"(offY[i] + sb), "n"(4 * TM * 2) : "memory");
+        }
+    };
+    {   // stage 0 landed for everyone -> first-half reads of stage 0
+        int fl = min(nk, NSTAGE) - 1;                              // stages still in flight behind stage 0
+        if constexpr (NSTAGE == 5) { if (fl >= 4) wait_vmcnt<4 * PPW>(); else wait_vmcnt_upto<PPW>(fl); }
+        else wait_vmcnt_upto<PPW>(fl);
+        __builtin_amdgcn_s_barrier();
+        if (nk > 0) read_first(0u);
+    }
+    unsigned s_cur = 0, s_nxt = STAGE_BYTES;                       // byte offsets of the slots of stage kt and stage kt + 1
+    for (int kt = 0; kt < nk; ++kt) {
+        if (!((xf & 2) && kt)) read_second(s_cur);
+        if constexpr (MI == 8) {
+            asm volatile("s_waitcnt lgkmcnt(8)"
                          : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3]),
                            "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])
                          :: "memory");
         } else {
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(ya[4]), "+v"(ya[5]), "+v"(ya[6]), "+v"(ya[7]),
-                           "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3]), "+v"(yb[4]), "+v"(yb[5]), "+v"(yb[6]), "+v"(yb[7]),
+            asm volatile("s_waitcnt lgkmcnt(4)"
+                         : "+v"(ya[0]), "+v"(ya[1]), "+v"(yb[0]), "+v"(yb[1]),
                            "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])
                          :: "memory");
         }
-        bf16x8_t af[MI], bfr[4];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const u32x4 ra = {ya[i][0], ya[i][1], yb[i][0], yb[i][1]};
-            af[i] = __builtin_bit_cast(bf16x8_t, ra);
-        }
+        bf16x8_t bfr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const u32x4 rb = {xa[i][0], xa[i][1], xb[i][0], xb[i][1]};
             bfr[i] = __builtin_bit_cast(bf16x8_t, rb);
         }
 #pragma unroll
-        for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < HALF; ++i) {
+            const u32x4 ra = {ya[i][0], ya[i][1], yb[i][0], yb[i][1]};
+            const bf16x8_t af = __builtin_bit_cast(bf16x8_t, ra);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8_t af2[MI - HALF];
+        if constexpr (MI == 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(ya[4]), "+v"(ya[5]), "+v"(ya[6]), "+v"(ya[7]), "+v"(yb[4]), "+v"(yb[5]), "+v"(yb[6]), "+v"(yb[7])
+                         :: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ya[2]), "+v"(ya[3]), "+v"(yb[2]), "+v"(yb[3]) :: "memory");
+        }
+#pragma unroll
+        for (int i = HALF; i < MI; ++i) {
+            const u32x4 ra = {ya[i][0], ya[i][1], yb[i][0], yb[i][1]};
+            af2[i - HALF] = __builtin_bit_cast(bf16x8_t, ra);
+        }
+        if (kt + 1 < nk) {
+            wait_vmcnt_upto<PPW>(min(NSTAGE - 2, nk - kt - 2));  // stages kt+2 .. kt+NSTAGE-1 may stay in flight
+            __builtin_amdgcn_s_barrier();
+            if (kt + NSTAGE < nk && !(xf & 1)) stage(s_cur);       // xf: probe knobs (fabind_gemm_tn_set_exp), 0 in production
+            if (!(xf & 2)) read_first(s_nxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // B operand fragments of THIS k-step were consumed into bfr above; the reads just issued overwrite xa / xb only when they land
+#pragma unroll
+        for (int i = HALF; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2[i - HALF], bfr[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        s_cur = s_nxt;
+        s_nxt = (s_nxt + STAGE_BYTES == NSTAGE * STAGE_BYTES) ? 0u : s_nxt + STAGE_BYTES;
     }
     float* Cs = C + c_goff + (size_t)split * M * N;
     const int fr = lane & 15, cq = lane >> 4;
@@ -1006,30 +1085,40 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __r
             }
 }
 
-static int g_tn_waves = 4;   // work-group layout of the TN kernel (see the kernel): 4 (default) or 8 waves
-extern "C" void fabind_gemm_tn_set_waves(int w) { g_tn_waves = (w == 8) ? 8 : 4; }
+static int g_tn_waves = 16;  // work-group layout of the TN kernel (see the kernel): 16 = 256x256 tile, 8 waves, 4-stage ring (default);
+                             // 4 = 256x128, 4 waves, two work-groups per CU (round 1's default); 8 = 256x128, 8 waves
+static int g_tn_exp = 0;     // probe knobs: 1 = no operand loads after the pipeline fill, 2 = no fragment reads after the first k-step,
+                             // 4 = operand loads re-read the first rows of the range (cache hits instead of HBM)
+extern "C" void fabind_gemm_tn_set_exp(int x) { g_tn_exp = x; }
+extern "C" void fabind_gemm_tn_set_waves(int w) { g_tn_waves = (w == 8 || w == 4 || w == 20) ? w : 16; }
+extern "C" int fabind_gemm_tn_tile_n(void) { return g_tn_waves >= 16 ? 256 : 128; }
+
+template <int NSTAGE, int NW, int TN_>
+static void tn_launch(const void* Y, int ldy, const void* X, int ldx, float* C_part, int M, int N, int E, int splits, const void* zero_page,
+                      const int* groups, int n_groups, hipStream_t stream) {
+    const size_t lds = (size_t)NSTAGE * 32 * (256 + TN_) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<NSTAGE, NW, TN_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int e_per = ((E + splits - 1) / splits + 31) / 32 * 32;
+    const int n_tiles = ((M + 255) / 256) * ((N + TN_ - 1) / TN_);
+    dim3 grid(n_tiles * ((splits + 7) / 8 * 8), 1, groups ? n_groups : 1);
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<NSTAGE, NW, TN_>), grid, dim3(NW * 64), lds, stream, (const bf16_t*)Y, ldy, (const bf16_t*)X, ldx,
+                       C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups, n_tiles, splits, g_tn_exp);
+}
+
 extern "C" int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_part, int M, int N, int E, int splits,
                               const void* zero_page, const int* groups, int n_groups, hipStream_t stream) {
     FB_REQUIRE(M % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "fabind_gemm_tn: M, N, ldy, ldx must be multiples of 8");
     FB_REQUIRE(((uintptr_t)Y % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)zero_page % 16 == 0), "fabind_gemm_tn: alignment");
     FB_REQUIRE(!(groups && splits != 1), "fabind_gemm_tn: grouped launches are not split");
     if (M <= 0 || N <= 0 || splits <= 0) return 0;
-    constexpr int NST = 3;
-    const size_t lds = (size_t)NST * 32 * (256 + 128) * 2;
-    int e_per = ((E + splits - 1) / splits + 31) / 32 * 32;
-    const int n_tiles = ((M + 255) / 256) * ((N + 127) / 128);
-    dim3 grid(n_tiles * ((splits + 7) / 8 * 8), 1, groups ? n_groups : 1);
-    if (g_tn_waves == 4) {
-        static bool set4 = false;
-        if (!set4) { (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<NST, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set4 = true; }
-        hipLaunchKernelGGL((gemm_tn_bf16_kernel<NST, 4>), grid, dim3(256), lds, stream, (const bf16_t*)Y, ldy, (const bf16_t*)X, ldx,
-                           C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups, n_tiles, splits);
-    } else {
-        static bool set8 = false;
-        if (!set8) { (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<NST, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set8 = true; }
-        hipLaunchKernelGGL((gemm_tn_bf16_kernel<NST, 8>), grid, dim3(512), lds, stream, (const bf16_t*)Y, ldy, (const bf16_t*)X, ldx,
-                           C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups, n_tiles, splits);
-    }
+    if (g_tn_waves == 4) tn_launch<3, 4, 128>(Y, ldy, X, ldx, C_part, M, N, E, splits, zero_page, groups, n_groups, stream);
+    else if (g_tn_waves == 8) tn_launch<3, 8, 128>(Y, ldy, X, ldx, C_part, M, N, E, splits, zero_page, groups, n_groups, stream);
+    else if (g_tn_waves == 20) tn_launch<5, 8, 256>(Y, ldy, X, ldx, C_part, M, N, E, splits, zero_page, groups, n_groups, stream);
+    else tn_launch<4, 8, 256>(Y, ldy, X, ldx, C_part, M, N, E, splits, zero_page, groups, n_groups, stream);
     FB_CHECK_LAUNCH();
     return 0;
 }

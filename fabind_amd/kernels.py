@@ -1,6 +1,7 @@
 """Thin Python wrappers over the C ABI (include/fabind_hip.h): allocate outputs with torch, pass raw
 device pointers + the current HIP stream.  No math happens here."""
 import ctypes
+import os
 
 import torch
 
@@ -454,6 +455,39 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
 _ZERO_PAGE = {}
 
 
+_TN_SPLITS = {}
+
+
+def _tn_splits(M, N, E, tn):
+    """Split count of a TN contraction.  256x256 layout (one 8-wave work-group per CU): work-group ids go round-robin over the 8 XCDs
+    with all tiles of an e-range on one XCD, so splits come in multiples of 8 and an XCD runs tiles * splits / 8 work-groups on its
+    32 CUs in ceil(. / 32) rounds; the count minimises rounds x (k-steps per work-group) + the partial traffic (a small cost model
+    in microseconds: 0.45 us per 32-row k-step, 3 us per round, 8 bytes per partial element at 3 TB/s; tools/probes/tn_layout_ab.sh).
+    256x128 layout (two 4-wave work-groups per CU): round 1's rule."""
+    key = (M, N, E, tn)
+    s = _TN_SPLITS.get(key)
+    if s is not None:
+        return s
+    if tn != 256:
+        tiles = ((M + 255) // 256) * ((N + 127) // 128)
+        s = max(1, min(256, max(E // 2048, min(E // 256, 16)), max(1, 1024 // tiles)))
+    elif E < 4096:
+        s = max(1, min(16, E // 256))
+    else:
+        tiles = ((M + 255) // 256) * ((N + 255) // 256)
+        best = None
+        for c in range(8, 257, 8):
+            if E // c < 256:
+                break
+            rounds = -(-(tiles * c // 8) // 32)
+            cost = rounds * (-(-E // c) / 32.0 * 0.45 + 3.0) + c * M * N * 8 / 3e6
+            if best is None or cost < best[0]:
+                best = (cost, c)
+        s = best[1] if best else 8
+    _TN_SPLITS[key] = s
+    return s
+
+
 def gemm_tn(Y, X, splits=None, out_dtype=torch.float32):
     """sum_e Y[e,:]^T X[e,:] -> [M, N] fp32 (bf16 operands, LDS transpose reads; no materialised transposes)."""
     E, M = Y.shape
@@ -464,11 +498,7 @@ def gemm_tn(Y, X, splits=None, out_dtype=torch.float32):
     if zp is None:
         zp = _ZERO_PAGE[dev] = torch.zeros(256, dtype=torch.bfloat16, device=dev)
     if splits is None:
-        tiles = ((M + 255) // 256) * ((N + 127) // 128)
-        # split the E (contraction) range over work-groups: ~2048 rows each on long operands; SHORT operands (ligand rows, small
-        # batches: E of a few thousand) still get up to 16 splits of >= 256 rows -- with E // 2048 a 512 x 512 output ran on 8
-        # work-groups looping over all of E (86 us at 8 TFLOP/s for E = 2,624: profiles/r02_launch_groups.txt)
-        splits = max(1, min(256, max(E // 2048, min(E // 256, 16)), max(1, 1024 // tiles)))
+        splits = _tn_splits(M, N, E, _lib.load().fabind_gemm_tn_tile_n())
     part = torch.empty((splits, M, N), dtype=torch.float32, device=dev)
     _profiled("fabind_gemm_tn M=%d N=%d E=%d" % (M, N, E), 2.0 * M * N * E,
               lambda: check(_lib.load().fabind_gemm_tn(ptr(Y), _ld(Y), ptr(X), _ld(X), ptr(part), M, N, E, splits, ptr(zp),

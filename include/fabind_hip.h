@@ -467,7 +467,9 @@ int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, cons
 void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of the bf16 LDS-DMA GEMM (default 13 = 256x128x32, 3 stages,
                                          two work-groups per CU; 0 = register-staged kernel; 1-9 = other tiles; results do not depend on it) */
 void fabind_gemm_set_persistent(int on); /* development knob: persistent tile walk for long-M/short-K GEMMs */
-void fabind_gemm_tn_set_waves(int waves); /* development knob: work-group layout of fabind_gemm_tn, 4 (default) or 8 waves; results are bitwise equal */
+void fabind_gemm_tn_set_waves(int waves); /* development knob: work-group layout of fabind_gemm_tn: 16 (default) = 256x256 tile, 8 waves, 4-stage ring; 20 = the same with 5 stages; 4 = 256x128 tile, 4 waves, two work-groups per CU; 8 = 256x128, 8 waves.  Results are bitwise equal for equal `splits` */
+int fabind_gemm_tn_tile_n(void);          /* 256 or 128: columns of an output tile under the current layout (the host sizes `splits` from the tile count) */
+void fabind_gemm_tn_set_exp(int mask);    /* probe knob (tools/probes/gemm_tn_bench.py): 1 = no operand loads after the pipeline fill, 2 = no fragment reads after the first k-step, 4 = operand loads re-read the first rows (cache hits); 0 in production */
 
 #ifdef __cplusplus
 }
