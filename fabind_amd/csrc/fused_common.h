@@ -103,6 +103,69 @@ __device__ __forceinline__ void fe_gemm_rolled_pf(const bf16_t* sX, const bf16_t
     }
 }
 
+// The same contraction with ROTATING activation fragments (round 2, after the weight-gradient kernel's lesson that a wave's LDS latency
+// and its MFMAs add up unless the reads are issued a phase ahead): a[i] feeds the four MFMAs of row granule i and is then free, so the
+// read of the NEXT half-trip's a[i] is issued right behind them -- every fragment read has twelve MFMAs (192 cycles) to land under and
+// no register is added.  sched_group_barrier pins the order (4 MFMA, 1 DS read) x MI; without it the scheduler hoists the reads to the
+// top of the half-trip, which is the old form.  Same MFMA order as fe_gemm_rolled_pf: results are bit-identical.
+// MEASURED in the store-wave backward (FE3_ROT=1): 1.3-3 % SLOWER per launch than the plain form -- at two to three waves per SIMD the
+// co-resident waves already cover the fragment reads, and the per-granule lgkmcnt waits cost more than they hide.  Kept as a knob.
+template <int H, int MI, bool SWAP = false, int SWZ = 7>
+__device__ __forceinline__ void fe_gemm_rot_pf(const bf16_t* sX, const bf16_t* __restrict__ Wp, int wave, int lane,
+                                               f32x4_t (&acc)[MI][4], bf16x8_t (&b0)[4]) {
+    constexpr int NKS = H / 32;
+    constexpr int NG = H / 16;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16x8_t* wp = (const bf16x8_t*)Wp + ((size_t)wave * 4) * 64 + lane;
+    bf16x8_t b1[4], a[MI];
+    auto frag = [&](int ks, int i) {
+        const int r = i * 16 + fr;
+        return *(const bf16x8_t*)&sX[r * H + (((ks * 4 + fq) ^ (r & SWZ)) * 8)];
+    };
+#pragma unroll
+    for (int i = 0; i < MI; ++i) a[i] = frag(0, i);
+#pragma unroll 1
+    for (int ks = 0; ks < NKS; ks += 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[j] = wp[((size_t)(ks + 1) * NG + j) * 64];
+        FE_PRIO(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a[i], acc[i][j], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b0[j], acc[i][j], 0, 0, 0);
+            a[i] = frag(ks + 1, i);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);        // the four weight loads first
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);    // 4 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);    // 1 DS read
+        }
+        FE_PRIO(0);
+        const int kn = min(ks + 2, NKS - 2);                      // unconditional: see fe_gemm_rolled_pf
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b0[j] = wp[((size_t)kn * NG + j) * 64];
+        FE_PRIO(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a[i], acc[i][j], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b1[j], acc[i][j], 0, 0, 0);
+            a[i] = frag(kn, i);                                   // the last trip re-reads a fragment it does not use
+        }
+        __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        FE_PRIO(0);
+    }
+}
+
 // the first k-step's weight fragments of a contraction.  (Requesting them ahead of the barrier in front of the contraction, during the
 // preceding epilogue, was tried in the store-wave backward: 5.45 -> 5.82 ms per launch -- sixteen more live registers in the epilogues.)
 __device__ __forceinline__ void fe_gemm_prefetch(const bf16_t* __restrict__ Wp, int wave, int lane, bf16x8_t (&b0)[4]) {
@@ -116,6 +179,12 @@ __device__ __forceinline__ void fe_gemm_rolled(const bf16_t* sX, const bf16_t* _
     bf16x8_t b0[4];
     fe_gemm_prefetch(Wp, wave, lane, b0);
     fe_gemm_rolled_pf<H, MI, SWAP, SWZ>(sX, Wp, wave, lane, acc, b0, wmode);
+}
+template <int H, int MI, bool SWAP = false, int SWZ = 7>
+__device__ __forceinline__ void fe_gemm_rot(const bf16_t* sX, const bf16_t* __restrict__ Wp, int wave, int lane, f32x4_t (&acc)[MI][4]) {
+    bf16x8_t b0[4];
+    fe_gemm_prefetch(Wp, wave, lane, b0);
+    fe_gemm_rot_pf<H, MI, SWAP, SWZ>(sX, Wp, wave, lane, acc, b0);
 }
 
 template <int H>

@@ -41,6 +41,10 @@
 #include "common.h"
 #include "fabind_hip.h"
 #include "fused_common.h"
+#ifndef FE3_ROT
+#define FE3_ROT 0     // 1 = contractions with rotating activation fragments (fe_gemm_rot): bit-identical, 5.37 / 5.46 ms per launch against
+                      // 5.30 / 5.29 for the plain form on one box (DESIGN.md iteration-log row 40) -- not the default
+#endif
 
 // sum over the 16 lanes of a DPP row (lanes 16q .. 16q+15); every lane of the row receives the total
 __device__ __forceinline__ float fe3_row16_sum(float v) {
@@ -273,7 +277,8 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
         // ---- P1: pre2 = S1 W2^T + b2;  M -> tile in place;  silu'(pre2) -> scratch
         f32x4_t acc[MI][4];
         fe_zero(acc);
-        fe_gemm_rolled<H, MI, true, SWZ>(sX, W2p, wave, lane, acc, wmode);
+        if (DBG || FE3_ROT == 0) fe_gemm_rolled<H, MI, true, SWZ>(sX, W2p, wave, lane, acc, wmode);
+        else fe_gemm_rot<H, MI, true, SWZ>(sX, W2p, wave, lane, acc);
         __syncthreads();                                          // every wave has finished reading S1 (and the store wave has copied it)
         FE_TICK(2)
         {
@@ -305,7 +310,8 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
 
         // ---- P2: pre3 = M Wc^T + bc;  dT = ds * w3 * silu'(pre3) -> tile in place
         fe_zero(acc);
-        fe_gemm_rolled<H, MI, true, SWZ>(sX, Wcp, wave, lane, acc, wmode);
+        if (DBG || FE3_ROT == 0) fe_gemm_rolled<H, MI, true, SWZ>(sX, Wcp, wave, lane, acc, wmode);
+        else fe_gemm_rot<H, MI, true, SWZ>(sX, Wcp, wave, lane, acc);
         __syncthreads();
         FE_TICK(2)
         {
@@ -349,7 +355,8 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
         //      block ahead inside the epilogue: loading dagg into the accumulators first put its latency in front of the contraction)
         fe_zero(acc);
         FE_TICK(5)
-        fe_gemm_rolled<H, MI, true, SWZ>(sX, WcTp, wave, lane, acc, wmode);
+        if (DBG || FE3_ROT == 0) fe_gemm_rolled<H, MI, true, SWZ>(sX, WcTp, wave, lane, acc, wmode);
+        else fe_gemm_rot<H, MI, true, SWZ>(sX, WcTp, wave, lane, acc);
         __syncthreads();
         FE_TICK(2)
         {
@@ -395,7 +402,8 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
 
         // ---- P4: dS1 = dP2 W2 -> tile in place
         fe_zero(acc);
-        fe_gemm_rolled<H, MI, true, SWZ>(sX, W2Tp, wave, lane, acc, wmode);
+        if (DBG || FE3_ROT == 0) fe_gemm_rolled<H, MI, true, SWZ>(sX, W2Tp, wave, lane, acc, wmode);
+        else fe_gemm_rot<H, MI, true, SWZ>(sX, W2Tp, wave, lane, acc);
         __syncthreads();
         FE_TICK(2)
         uint4 gd[NIT];                                            // silu'(pre1) of this lane's row-wise chunks, back from the scratch slab for P5
