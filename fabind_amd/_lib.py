@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FABIND_LIB") or os.path.join(_HERE, "libfabind_hip.so")      # FABIND_LIB: an A/B build (tools/probes)
 
-ABI_VERSION = 9          # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
+ABI_VERSION = 10         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -140,6 +140,10 @@ def load():
     lib.fabind_gemm_set_config.restype = None
     lib.fabind_gemm_set_persistent.argtypes = [ctypes.c_int]
     lib.fabind_gemm_set_persistent.restype = None
+    lib.fabind_gemm_set_small_m.argtypes = [ctypes.c_int]
+    lib.fabind_gemm_set_small_m.restype = None
+    if os.environ.get("FABIND_GEMM_SMALL_M"):
+        lib.fabind_gemm_set_small_m(int(os.environ["FABIND_GEMM_SMALL_M"]))
     lib.fabind_gemm_tn_set_waves.argtypes = [ctypes.c_int]
     lib.fabind_gemm_tn_set_waves.restype = None
     lib.fabind_gemm_tn_set_exp.argtypes = [ctypes.c_int]

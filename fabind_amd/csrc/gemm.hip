@@ -1130,6 +1130,9 @@ extern "C" void fabind_gemm_set_persistent(int on) { g_gemm_persist = on; }
 // pipeline fill / epilogue overlaps the other's main loop: 16-26 % faster on every node-level shape, bitwise-equal results
 // (tools/probes/gemm_node_occ.py)
 static int g_gemm_cfg = 13;
+static int g_gemm_small_m = 100;   // launches with fewer 256x128 tiles than this use 128x128 tiles (0 = never): 2,624 ligand rows 15.4 -> 12.4 us,
+                                   // but 9,088 rows x 512 columns (144 tiles) 17.7 -> 23.5 us (tools/probes/gemm_small_m.py)
+extern "C" void fabind_gemm_set_small_m(int n) { g_gemm_small_m = n; }
 extern "C" void fabind_gemm_set_config(int cfg) { g_gemm_cfg = cfg; }
 
 template <int WM, int BK_, int NSTAGE, int MINW = 1>
@@ -1223,7 +1226,11 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
             FB_CHECK_LAUNCH();
             return 0;
         }
-        switch ((p.k_splits > 1 && g_gemm_cfg == 0) ? 3 : g_gemm_cfg) {
+        int cfg = (p.k_splits > 1 && g_gemm_cfg == 0) ? 3 : g_gemm_cfg;
+        /* few row tiles (ligand rows, pocket-sized batches): the 256-row tile leaves most CUs idle -- 128-row tiles double the work-group
+           count; same k-order, bitwise-equal results (tools/probes/gemm_small_m.py) */
+        if (cfg == 13 && !p.groups && g_gemm_small_m && n_tiles * (p.k_splits > 1 ? p.k_splits : 1) < g_gemm_small_m) cfg = 6;
+        switch (cfg) {
             case 1: launch_pipe<2, 32, 4>(p, maxM, maxN, stream); break;
             case 2: launch_pipe<2, 64, 3>(p, maxM, maxN, stream); break;
             case 3: launch_pipe<4, 32, 3>(p, maxM, maxN, stream); break;

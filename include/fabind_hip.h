@@ -38,8 +38,10 @@ const char* fabind_last_error(void);
  * 7 = fabind_multi_copy + FabindCopySeg added (the parameter pack and its adjoint as one launch each).
  * 8 = fabind_split_sum added (split-contraction partials reduced straight into fp32 or bf16).
  * 9 = fabind_zero_empty_rows added (outputs of the fused edge kernels are no longer memset whole).
+ * 10 = fabind_gemm_tn_tile_n added (the host sizes the split count of fabind_gemm_tn from the output tile of the current layout: 256 x 256 on
+ *     eight waves by default); knobs fabind_gemm_tn_set_exp, fabind_gemm_set_small_m; fabind_gemm_tn_set_waves accepts 16 / 20.
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 9
+#define FABIND_ABI_VERSION 10
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -467,6 +469,7 @@ int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, cons
 void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of the bf16 LDS-DMA GEMM (default 13 = 256x128x32, 3 stages,
                                          two work-groups per CU; 0 = register-staged kernel; 1-9 = other tiles; results do not depend on it) */
 void fabind_gemm_set_persistent(int on); /* development knob: persistent tile walk for long-M/short-K GEMMs */
+void fabind_gemm_set_small_m(int tiles); /* development knob: fabind_gemm launches with fewer 256x128 tiles than this use 128x128 tiles (default 100; 0 = never); results are bitwise equal */
 void fabind_gemm_tn_set_waves(int waves); /* development knob: work-group layout of fabind_gemm_tn: 16 (default) = 256x256 tile, 8 waves, 4-stage ring; 20 = the same with 5 stages; 4 = 256x128 tile, 4 waves, two work-groups per CU; 8 = 256x128, 8 waves.  Results are bitwise equal for equal `splits` */
 int fabind_gemm_tn_tile_n(void);          /* 256 or 128: columns of an output tile under the current layout (the host sizes `splits` from the tile count) */
 void fabind_gemm_tn_set_exp(int mask);    /* probe knob (tools/probes/gemm_tn_bench.py): 1 = no operand loads after the pipeline fill, 2 = no fragment reads after the first k-step, 4 = operand loads re-read the first rows (cache hits); 0 in production */
