@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FABIND_LIB") or os.path.join(_HERE, "libfabind_hip.so")      # FABIND_LIB: an A/B build (tools/probes)
 
-ABI_VERSION = 10         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
+ABI_VERSION = 11         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -43,7 +43,7 @@ class PairUpdateArgs(ctypes.Structure):
 # name -> argtypes (every function returns int and takes the stream last)
 SIGNATURES = {
     "fabind_gemm": [ctypes.POINTER(GemmArgs), _vp],
-    "fabind_gemm_tn": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
+    "fabind_gemm_tn": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "fabind_transpose_act": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fabind_colsum": [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp],
     "fabind_edges_count": [_vp, _vp, _vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp],

@@ -874,7 +874,7 @@ template <int NSTAGE, int NW, int TN_>
 __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ X,
                                                            int ldx, float* C, int M, int N, int E, int e_per,
                                                            const bf16_t* __restrict__ zero_page, const int* groups,
-                                                           int n_tiles, int n_splits, int xf) {
+                                                           int n_tiles, int n_splits, int xf, int cs) {
     // Output tile 256 x TN_, NW waves per work-group: TN_/64 across N (64 columns each), the rest across M.
     //   <3, 4, 128>: 128x64 per wave, 124 VGPRs + 128 AGPRs, two work-groups per CU (3 x 24 KiB of LDS each);
     //   <3, 8, 128>: 64x64 per wave, one work-group per CU (kept as a knob);
@@ -1016,6 +1016,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __r
         if (nk > 0) read_first(0u);
     }
     unsigned s_cur = 0, s_nxt = STAGE_BYTES;                       // byte offsets of the slots of stage kt and stage kt + 1
+    // cs: the column sums of Y (= the bias gradient dY^T 1 of the Linear whose weight gradient this contraction is) ride along: the WN
+    // waves that share a row block hold the same Y fragments, wave wn sums the granules i = wn (mod WN) of the work-groups in the first
+    // tile column -- 16 VALU instructions per granule and k-step next to 32 MFMAs.  Written behind the M x N partial of the split.
+    constexpr int GPW = MI / WN;
+    float csum[GPW];
+#pragma unroll
+    for (int g_ = 0; g_ < GPW; ++g_) csum[g_] = 0.f;
+    const bool do_cs = cs && n0 == 0;
+    auto sum8 = [](const u32x2 lo, const u32x2 hi) {
+        return (__uint_as_float(lo[0] << 16) + __uint_as_float(lo[0] & 0xffff0000u)) + (__uint_as_float(lo[1] << 16) + __uint_as_float(lo[1] & 0xffff0000u)) +
+               (__uint_as_float(hi[0] << 16) + __uint_as_float(hi[0] & 0xffff0000u)) + (__uint_as_float(hi[1] << 16) + __uint_as_float(hi[1] & 0xffff0000u));
+    };
     for (int kt = 0; kt < nk; ++kt) {
         if (!((xf & 2) && kt)) read_second(s_cur);
         if constexpr (MI == 8) {
@@ -1056,6 +1068,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __r
             const u32x4 ra = {ya[i][0], ya[i][1], yb[i][0], yb[i][1]};
             af2[i - HALF] = __builtin_bit_cast(bf16x8_t, ra);
         }
+        if (do_cs) {                                              // all MI fragments of stage kt are in registers here
+#pragma unroll
+            for (int w_ = 0; w_ < WN; ++w_)
+                if (wn == w_) {
+#pragma unroll
+                    for (int g_ = 0; g_ < GPW; ++g_) csum[g_] += sum8(ya[w_ + g_ * WN], yb[w_ + g_ * WN]);
+                }
+        }
         if (kt + 1 < nk) {
             wait_vmcnt_upto<PPW>(min(NSTAGE - 2, nk - kt - 2));  // stages kt+2 .. kt+NSTAGE-1 may stay in flight
             __builtin_amdgcn_s_barrier();
@@ -1072,8 +1092,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __r
         s_cur = s_nxt;
         s_nxt = (s_nxt + STAGE_BYTES == NSTAGE * STAGE_BYTES) ? 0u : s_nxt + STAGE_BYTES;
     }
-    float* Cs = C + c_goff + (size_t)split * M * N;
+    float* Cs = C + c_goff + (size_t)split * ((size_t)M * N + (cs ? M : 0));
     const int fr = lane & 15, cq = lane >> 4;
+    if (do_cs) {
+#pragma unroll
+        for (int g_ = 0; g_ < GPW; ++g_) {
+            float v = csum[g_];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            const int row = m0 + wm * (MI * 16) + (wn + g_ * WN) * 16 + fr;
+            if (cq == 0 && row < M) Cs[(size_t)M * N + row] = v;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -1095,7 +1125,7 @@ extern "C" int fabind_gemm_tn_tile_n(void) { return g_tn_waves >= 16 ? 256 : 128
 
 template <int NSTAGE, int NW, int TN_>
 static void tn_launch(const void* Y, int ldy, const void* X, int ldx, float* C_part, int M, int N, int E, int splits, const void* zero_page,
-                      const int* groups, int n_groups, hipStream_t stream) {
+                      const int* groups, int n_groups, int with_colsum, hipStream_t stream) {
     const size_t lds = (size_t)NSTAGE * 32 * (256 + TN_) * 2;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1106,19 +1136,20 @@ static void tn_launch(const void* Y, int ldy, const void* X, int ldx, float* C_p
     const int n_tiles = ((M + 255) / 256) * ((N + TN_ - 1) / TN_);
     dim3 grid(n_tiles * ((splits + 7) / 8 * 8), 1, groups ? n_groups : 1);
     hipLaunchKernelGGL((gemm_tn_bf16_kernel<NSTAGE, NW, TN_>), grid, dim3(NW * 64), lds, stream, (const bf16_t*)Y, ldy, (const bf16_t*)X, ldx,
-                       C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups, n_tiles, splits, g_tn_exp);
+                       C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups, n_tiles, splits, g_tn_exp, with_colsum);
 }
 
 extern "C" int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_part, int M, int N, int E, int splits,
-                              const void* zero_page, const int* groups, int n_groups, hipStream_t stream) {
+                              const void* zero_page, const int* groups, int n_groups, int with_colsum, hipStream_t stream) {
+    FB_REQUIRE(!(groups && with_colsum), "fabind_gemm_tn: grouped launches carry no column sums");
     FB_REQUIRE(M % 8 == 0 && N % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0, "fabind_gemm_tn: M, N, ldy, ldx must be multiples of 8");
     FB_REQUIRE(((uintptr_t)Y % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)zero_page % 16 == 0), "fabind_gemm_tn: alignment");
     FB_REQUIRE(!(groups && splits != 1), "fabind_gemm_tn: grouped launches are not split");
     if (M <= 0 || N <= 0 || splits <= 0) return 0;
-    if (g_tn_waves == 4) tn_launch<3, 4, 128>(Y, ldy, X, ldx, C_part, M, N, E, splits, zero_page, groups, n_groups, stream);
-    else if (g_tn_waves == 8) tn_launch<3, 8, 128>(Y, ldy, X, ldx, C_part, M, N, E, splits, zero_page, groups, n_groups, stream);
-    else if (g_tn_waves == 20) tn_launch<5, 8, 256>(Y, ldy, X, ldx, C_part, M, N, E, splits, zero_page, groups, n_groups, stream);
-    else tn_launch<4, 8, 256>(Y, ldy, X, ldx, C_part, M, N, E, splits, zero_page, groups, n_groups, stream);
+    if (g_tn_waves == 4) tn_launch<3, 4, 128>(Y, ldy, X, ldx, C_part, M, N, E, splits, zero_page, groups, n_groups, with_colsum, stream);
+    else if (g_tn_waves == 8) tn_launch<3, 8, 128>(Y, ldy, X, ldx, C_part, M, N, E, splits, zero_page, groups, n_groups, with_colsum, stream);
+    else if (g_tn_waves == 20) tn_launch<5, 8, 256>(Y, ldy, X, ldx, C_part, M, N, E, splits, zero_page, groups, n_groups, with_colsum, stream);
+    else tn_launch<4, 8, 256>(Y, ldy, X, ldx, C_part, M, N, E, splits, zero_page, groups, n_groups, with_colsum, stream);
     FB_CHECK_LAUNCH();
     return 0;
 }

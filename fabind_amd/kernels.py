@@ -488,8 +488,9 @@ def _tn_splits(M, N, E, tn):
     return s
 
 
-def gemm_tn(Y, X, splits=None, out_dtype=torch.float32):
-    """sum_e Y[e,:]^T X[e,:] -> [M, N] fp32 (bf16 operands, LDS transpose reads; no materialised transposes)."""
+def gemm_tn(Y, X, splits=None, out_dtype=torch.float32, with_colsum=False):
+    """sum_e Y[e,:]^T X[e,:] -> [M, N] as out_dtype (bf16 operands, LDS transpose reads; no materialised transposes).
+    with_colsum: also the column sums of Y, [M] as out_dtype, from the same launches -> (dW, colsum)."""
     E, M = Y.shape
     N = X.shape[1]
     assert X.shape[0] == E and Y.dtype == torch.bfloat16 and X.dtype == torch.bfloat16
@@ -499,15 +500,19 @@ def gemm_tn(Y, X, splits=None, out_dtype=torch.float32):
         zp = _ZERO_PAGE[dev] = torch.zeros(256, dtype=torch.bfloat16, device=dev)
     if splits is None:
         splits = _tn_splits(M, N, E, _lib.load().fabind_gemm_tn_tile_n())
-    part = torch.empty((splits, M, N), dtype=torch.float32, device=dev)
+    n = M * N + (M if with_colsum else 0)
+    part = torch.empty((splits, n), dtype=torch.float32, device=dev)
     _profiled("fabind_gemm_tn M=%d N=%d E=%d" % (M, N, E), 2.0 * M * N * E,
               lambda: check(_lib.load().fabind_gemm_tn(ptr(Y), _ld(Y), ptr(X), _ld(X), ptr(part), M, N, E, splits, ptr(zp),
-                                                       None, 0, stream()), "fabind_gemm_tn"))
+                                                       None, 0, 1 if with_colsum else 0, stream()), "fabind_gemm_tn"))
     if splits == 1:
-        return part[0] if out_dtype == torch.float32 else part[0].to(out_dtype)
-    if (M * N) % 4 == 0:                                   # the split reduction writes the dtype the consumer carries (no cast kernel)
-        out = torch.empty((M, N), dtype=out_dtype, device=dev)
-        check(_lib.load().fabind_split_sum(ptr(part), splits, M * N, ptr(out), dt_code(out_dtype), stream()), "fabind_split_sum")
-        return out
-    out = colsum(part.reshape(splits, M * N)).reshape(M, N)
-    return out if out_dtype == torch.float32 else out.to(out_dtype)
+        out = part[0] if out_dtype == torch.float32 else part[0].to(out_dtype)
+    elif n % 4 == 0:                                       # the split reduction writes the dtype the consumer carries (no cast kernel)
+        out = torch.empty(n, dtype=out_dtype, device=dev)
+        check(_lib.load().fabind_split_sum(ptr(part), splits, n, ptr(out), dt_code(out_dtype), stream()), "fabind_split_sum")
+    else:
+        out = colsum(part)
+        out = out if out_dtype == torch.float32 else out.to(out_dtype)
+    if with_colsum:
+        return out[:M * N].view(M, N), out[M * N:]
+    return out.view(M, N)

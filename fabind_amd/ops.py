@@ -54,18 +54,33 @@ def _transposed(x, act=K.ACT_NONE, Rp=None):
     return out
 
 
-def _weight_grad(dpre, x, act_pro, x2=None, out_dtype=torch.float32):
+FUSE_DB_TN = os.environ.get("FABIND_FUSE_DB_TN", "1") == "1"   # bias gradients ride along with the TN weight-gradient contraction
+
+
+def _tn_ok(dpre, x, x2):
+    bf = torch.bfloat16
+    return (dpre.dtype == bf and x.dtype == bf and (x2 is None or x2.dtype == bf)
+            and dpre.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and (x2 is None or x2.shape[1] % 8 == 0)
+            and dpre.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dpre.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
+
+
+def _weight_grad(dpre, x, act_pro, x2=None, out_dtype=torch.float32, want_db=False):
     """dW = dpre^T [act(x) | x2] as out_dtype.  bf16: TN contraction with LDS transpose reads (no transposed copies), its split
     reduction writing out_dtype directly; fp32 parity mode / odd widths: explicit transposes + split-K NT GEMMs over the (padded)
-    row dimension."""
-    return _weight_grad_f32(dpre, x, act_pro, x2, out_dtype)
+    row dimension.  want_db: -> (dW, db) with db = dpre^T 1 (fp32) -- from the SAME contraction launches when the TN path runs and
+    the weight gradient is carried in fp32 (`fabind_gemm_tn(..., with_colsum)`), a separate column sum otherwise."""
+    if not want_db:
+        return _weight_grad_f32(dpre, x, act_pro, x2, out_dtype)
+    if FUSE_DB_TN and act_pro == K.ACT_NONE and out_dtype == torch.float32 and _tn_ok(dpre, x, x2):
+        dW, db = K.gemm_tn(dpre, x, out_dtype=out_dtype, with_colsum=True)
+        if x2 is not None:
+            dW = torch.cat([dW, K.gemm_tn(dpre, x2, out_dtype=out_dtype)], 1)
+        return dW, db
+    return _weight_grad_f32(dpre, x, act_pro, x2, out_dtype), K.colsum(dpre)
 
 
 def _weight_grad_f32(dpre, x, act_pro, x2, out_dtype):
-    bf = torch.bfloat16
-    if (act_pro == K.ACT_NONE and dpre.dtype == bf and x.dtype == bf and (x2 is None or x2.dtype == bf)
-            and dpre.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and (x2 is None or x2.shape[1] % 8 == 0)
-            and dpre.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dpre.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0):
+    if act_pro == K.ACT_NONE and _tn_ok(dpre, x, x2):
         if x2 is None:
             return K.gemm_tn(dpre, x, out_dtype=out_dtype)
         return torch.cat([K.gemm_tn(dpre, x, out_dtype=out_dtype), K.gemm_tn(dpre, x2, out_dtype=out_dtype)], 1)
@@ -216,7 +231,9 @@ class _Linear(torch.autograd.Function):
                     dx2 = dx2.to(ctx.x2_dtype)
             else:
                 dx = dfull
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and want_db and db is None:
+            dW, db = _weight_grad(dpre, x, K.ACT_NONE, x2, W.dtype, want_db=True)
+        elif ctx.needs_input_grad[1]:
             dW = _weight_grad(dpre, x, K.ACT_NONE, x2, W.dtype)
         if want_db and db is None:
             db = K.colsum(dpre)
@@ -286,12 +303,19 @@ class _MLP2(torch.autograd.Function):
         if dy.dtype != md:
             dy16, db2 = _mul_dact_colsum(dy, None, K.ACT_NONE, md)          # one pass: cast + bias gradient
         else:
-            dy16, db2 = dy, K.colsum(dy)
-        dW2 = _weight_grad(dy16, t, K.ACT_NONE, None, W2.dtype) if ni[4] else None
+            dy16, db2 = dy, None
+        if ni[4] and db2 is None:
+            dW2, db2 = _weight_grad(dy16, t, K.ACT_NONE, None, W2.dtype, want_db=True)
+        else:
+            dW2 = _weight_grad(dy16, t, K.ACT_NONE, None, W2.dtype) if ni[4] else None
+            db2 = db2 if db2 is not None else K.colsum(dy16)
         aux, dact = (t, K.ACT_RELU) if ctx.act == K.ACT_RELU else (D, K.ACT_STORED_DERIV)
         dpre, _ = K.gemm(dy16, ctx.W2t if ctx.W2t is not None else W2.t().contiguous(), aux=aux, dact=dact, out_dtype=md)      # (dy W2) * act'(pre)
-        db1 = K.colsum(dpre) if ni[3] else None
-        dW1 = _weight_grad(dpre, xin, K.ACT_NONE, x2in, W1.dtype) if ni[2] else None
+        if ni[2] and ni[3]:
+            dW1, db1 = _weight_grad(dpre, xin, K.ACT_NONE, x2in, W1.dtype, want_db=True)
+        else:
+            db1 = K.colsum(dpre) if ni[3] else None
+            dW1 = _weight_grad(dpre, xin, K.ACT_NONE, x2in, W1.dtype) if ni[2] else None
         W1t = ctx.W1t if ctx.W1t is not None else W1.t().contiguous()
         K1 = xin.shape[1]
         dres = dy if (ctx.has_res and ni[6]) else None
@@ -373,8 +397,7 @@ class _LinearRowdot(torch.autograd.Function):
         assert ctx.act_pro == K.ACT_NONE
         Wt = W.t().contiguous()
         dx, _ = K.gemm(dz, Wt, out_dtype=x.dtype)
-        dW = _weight_grad(dz, x, K.ACT_NONE, None, W.dtype)
-        db = K.colsum(dz)
+        dW, db = _weight_grad(dz, x, K.ACT_NONE, None, W.dtype, want_db=True)
         return dx, dW, db, du, None, None
 
 
@@ -420,8 +443,8 @@ class _EdgeTail(torch.autograd.Function):
             dM, _ = K.gemm(dz, Wt, residual=dagg.contiguous(), r_index=row, out_dtype=Mm.dtype)
         else:
             dM, _ = K.gemm(dz, Wt, out_dtype=Mm.dtype)
-        dW = _weight_grad(dz, Mm, K.ACT_NONE, None, Wc.dtype)
-        return dM, dW, K.colsum(dz), du, None, None, None, None
+        dW, dbc = _weight_grad(dz, Mm, K.ACT_NONE, None, Wc.dtype, want_db=True)
+        return dM, dW, dbc, du, None, None, None, None
 
 
 def edge_tail(Mm, Wc, bc, w3, rowptr, row, n_rows, act_epi=K.ACT_SILU):
@@ -961,7 +984,9 @@ class _InterAttn(torch.autograd.Function):
             if dcv.dtype != md:
                 dpre, dbc = _mul_dact_colsum(dcv, None, K.ACT_NONE, md) if FUSE_DB else (_mul_dact(dcv, None, K.ACT_NONE, md), None)
             K.gemm(dpre, Wc.t().contiguous(), out=dqkv[:, 2 * H:], accumulate=True)
-            if ctx.needs_input_grad[15]:
+            if ctx.needs_input_grad[15] and ctx.needs_input_grad[16] and dbc is None:
+                dWc, dbc = _weight_grad(dpre, v_in, K.ACT_NONE, None, Wc.dtype, want_db=True)
+            elif ctx.needs_input_grad[15]:
                 dWc = _weight_grad(dpre, v_in, K.ACT_NONE, None, Wc.dtype)
             if ctx.needs_input_grad[16]:
                 dbc = dbc if dbc is not None else K.colsum(dpre)

@@ -40,8 +40,9 @@ const char* fabind_last_error(void);
  * 9 = fabind_zero_empty_rows added (outputs of the fused edge kernels are no longer memset whole).
  * 10 = fabind_gemm_tn_tile_n added (the host sizes the split count of fabind_gemm_tn from the output tile of the current layout: 256 x 256 on
  *     eight waves by default); knobs fabind_gemm_tn_set_exp, fabind_gemm_set_small_m; fabind_gemm_tn_set_waves accepts 16 / 20.
+ * 11 = fabind_gemm_tn takes with_colsum (the bias gradient rides along with the weight gradient: no separate column-sum launches).
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 10
+#define FABIND_ABI_VERSION 11
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -99,9 +100,12 @@ typedef struct FabindGemmArgs {
 int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream);
 
 /* Weight-gradient contraction without transposes: C_part[s][m][n] = sum_{e in split s} Y[e,m] * X[e,n]
- * (bf16 row-major operands, fp32 partials [splits, M, N]; zero_page = >= 16 zero bytes in device memory). */
+ * (bf16 row-major operands, fp32 partials [splits, M, N]; zero_page = >= 16 zero bytes in device memory).
+ * with_colsum != 0 (no groups): every split's partial is [M * N + M] floats, the last M being sum_{e in split s} Y[e,m] -- the bias
+ * gradient dY^T 1 of the Linear whose weight gradient dY^T X this is (reference: autograd of nn.Linear, e.g. model_utils.py:162-175),
+ * so that ONE fabind_split_sum over M * N + M elements finishes both. */
 int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_part, int M, int N, int E, int splits,
-                   const void* zero_page, const int* groups, int n_groups, hipStream_t stream);
+                   const void* zero_page, const int* groups, int n_groups, int with_colsum, hipStream_t stream);
 /* groups (optional, splits == 1): int32[8] per group {y_off lo/hi (elements), ldy, M, x_row0, E, c_off lo/hi}. */
 
 /* out[C,R] = act(in[R,C])^T -- feeds weight-gradient contractions (autograd of the ops above). */

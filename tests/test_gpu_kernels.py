@@ -504,25 +504,51 @@ def test_gemm_layernorm_fold_epilogue(M, N, Kd, p_drop):
 
 
 def test_gemm_tn_work_group_layouts_are_bitwise_equal():
-    """fabind_gemm_tn has two work-group layouts (4 waves x 128x64, the default, and 8 waves x 64x64): same k order per output
-    element, so the results must be identical bit for bit -- on a ragged E, with M, N that do not fill the 256x128 tile."""
+    """fabind_gemm_tn has four work-group layouts (16 = 256x256 tile on 8 waves with a 4-slot ring, the default; 20 = 5 slots;
+    4 = 256x128 on 4 waves; 8 = 256x128 on 8 waves): same k order per output element, so for the SAME split count the results must be
+    identical bit for bit -- on a ragged E, with M, N that do not fill a tile -- and so must the column sums that ride along."""
     from fabind_amd import _lib, kernels as K
     lib = _lib.load()
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
     try:
-        for E, M, N in ((4096 + 40, 512, 512), (1000, 328, 136), (70000, 512, 8)):
+        for E, M, N, sp in ((4096 + 40, 512, 512, 8), (1000, 328, 136, 3), (70000, 512, 8, 16), (33000, 1024, 576, 8)):
             Y = torch.randn(E, M, device=dev).to(torch.bfloat16)
             X = torch.randn(E, N, device=dev).to(torch.bfloat16)
             ref = Y.float().t() @ X.float()
             outs = []
-            for w in (4, 8):
+            for w in (16, 20, 4, 8):
                 lib.fabind_gemm_tn_set_waves(w)
-                outs.append(K.gemm_tn(Y, X))
-            assert torch.equal(outs[0], outs[1]), (E, M, N)
-            assert float((outs[0] - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), (E, M, N)
+                outs.append(K.gemm_tn(Y, X, splits=sp, with_colsum=True))
+            for o in outs[1:]:
+                assert torch.equal(outs[0][0], o[0]), (E, M, N)
+                assert torch.equal(outs[0][1], o[1]), (E, M, N)
+            assert float((outs[0][0] - ref).abs().max()) <= 2e-3 * float(ref.abs().max()), (E, M, N)
     finally:
-        lib.fabind_gemm_tn_set_waves(4)
+        lib.fabind_gemm_tn_set_waves(16)
+
+
+@pytest.mark.parametrize("shape", [(98688 // 8, 512, 512), (1000, 328, 136), (5000, 1536, 512), (777, 8, 512), (40000, 1024, 576)])
+def test_gemm_tn_column_sums_ride_along(shape):
+    """fabind_gemm_tn(with_colsum): the bias gradient dY^T 1 from the same launches as the weight gradient dY^T X (fp32 sums of the
+    bf16 operand; one split reduction over M*N + M elements) -- against float64 sums, and the weight part against the plain call."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    E, M, N = shape
+    g = torch.Generator().manual_seed(E + M)
+    Y = (torch.randn(E, M, generator=g) * 0.3 + 0.05).bfloat16().to(dev)
+    X = torch.randn(E, N, generator=g).bfloat16().to(dev)
+    dW, db = K.gemm_tn(Y, X, with_colsum=True)
+    assert dW.shape == (M, N) and db.shape == (M,)
+    assert torch.equal(dW, K.gemm_tn(Y, X))
+    ref = Y.double().sum(0)
+    assert float((db.double() - ref).abs().max()) <= 1e-5 * float(Y.double().abs().sum(0).max()) + 1e-6
+    # one split, bf16 result dtype, a column slice as Y
+    Yw = (torch.randn(E, M + 64, generator=g) * 0.3).bfloat16().to(dev)
+    dW1, db1 = K.gemm_tn(Yw[:, 64:], X, splits=1, with_colsum=True)
+    assert float((db1.double() - Yw[:, 64:].double().sum(0)).abs().max()) <= 1e-5 * float(Yw.double().abs().sum(0).max()) + 1e-6
+    dWb, dbb = K.gemm_tn(Y, X, out_dtype=torch.bfloat16, with_colsum=True)
+    assert dWb.dtype == torch.bfloat16 and float((dbb.double() - ref).abs().max()) <= 1e-2 * float(ref.abs().max()) + 1e-3
 
 
 @pytest.mark.parametrize("case", ["one_consumer", "two_consumers", "second_output_unused"])
