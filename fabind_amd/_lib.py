@@ -69,7 +69,7 @@ SIGNATURES = {
     "fabind_post_optimize": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "fabind_multi_copy": [_vp, _i, _i, _vp],
     "fabind_zero_empty_rows": [_vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _vp],
-    "fabind_split_sum": [_vp, _i, ctypes.c_long, _vp, _i, _vp],
+    "fabind_split_sum": [_vp, _i, ctypes.c_long, _vp, _i, ctypes.c_long, _vp, _vp],
     "fabind_segment_sum": [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp],
     "fabind_coord_update": [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, _f, _vp, _vp, _vp],
     "fabind_cross_attn_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i,

@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256) void inter_attn_bwd_a_kernel(
             }
         }
     }
-    // block partials of the four vector gradients: [4][gridDim.x][H]
+    // block partials of the four vector gradients: [gridDim.x][4][H]
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
         shp[(0 * 4 + wv) * NS * 64 + s * 64 + lane] = a_wrk[s];
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void inter_attn_bwd_a_kernel(
             const float4 o = shp[(qn * 4 + w2) * NS * 64 + rem];
             t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
         }
-        *(float4*)(wpart + ((size_t)qn * gridDim.x + blockIdx.x) * H + c) = t;
+        *(float4*)(wpart + ((size_t)blockIdx.x * 4 + qn) * H + c) = t;      // [block][4][H]: ONE column sum over [nblk, 4H] finishes all four
     }
 }
 

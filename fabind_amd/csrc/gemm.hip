@@ -1392,21 +1392,27 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* scratch,
 
 // out[i] = sum_s part[s][i] in fixed split order, written as fp32 or bf16: the reduction of a split contraction's partial results
 // straight into the dtype its consumer wants (a weight gradient that autograd carries as bf16 needed a cast kernel after the sum).
-__global__ __launch_bounds__(256) void split_sum_kernel(const float* __restrict__ part, int splits, long n, void* out, int out_dt) {
+__global__ __launch_bounds__(256) void split_sum_kernel(const float* __restrict__ part, int splits, long n, void* out, int out_dt,
+                                                        long n_head, float* out_tail) {
     const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (i >= n) return;                                           // n % 4 == 0
+    if (i >= n) return;                                           // n % 4 == 0, n_head % 4 == 0
     float4 s = *(const float4*)(part + i);
     for (int k = 1; k < splits; ++k) {
         const float4 v = *(const float4*)(part + (size_t)k * n + i);
         s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    st4_any(out, out_dt, (size_t)i, s);
+    if (i < n_head) st4_any(out, out_dt, (size_t)i, s);
+    else *(float4*)(out_tail + (i - n_head)) = s;                 // the tail (a bias gradient behind a weight gradient) stays fp32
 }
 
-extern "C" int fabind_split_sum(const float* part, int splits, long n, void* out, int out_dt, hipStream_t stream) {
+extern "C" int fabind_split_sum(const float* part, int splits, long n, void* out, int out_dt, long n_tail, float* out_tail,
+                                hipStream_t stream) {
     if (n <= 0 || splits <= 0) return 0;
     FB_REQUIRE(n % 4 == 0 && ((uintptr_t)part & 15) == 0 && ((uintptr_t)out & 7) == 0, "fabind_split_sum: n % 4 == 0, aligned buffers");
-    hipLaunchKernelGGL(split_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, part, splits, n, out, out_dt);
+    FB_REQUIRE(n_tail >= 0 && n_tail <= n && n_tail % 4 == 0 && (n_tail == 0 || (out_tail && ((uintptr_t)out_tail & 15) == 0)),
+               "fabind_split_sum: n_tail % 4 == 0 with a 16-byte aligned fp32 out_tail");
+    hipLaunchKernelGGL(split_sum_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, stream, part, splits, n, out, out_dt,
+                       n - n_tail, out_tail);
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -490,7 +490,7 @@ def _tn_splits(M, N, E, tn):
 
 def gemm_tn(Y, X, splits=None, out_dtype=torch.float32, with_colsum=False):
     """sum_e Y[e,:]^T X[e,:] -> [M, N] as out_dtype (bf16 operands, LDS transpose reads; no materialised transposes).
-    with_colsum: also the column sums of Y, [M] as out_dtype, from the same launches -> (dW, colsum)."""
+    with_colsum: also the column sums of Y, [M] fp32, from the same launches -> (dW, colsum)."""
     E, M = Y.shape
     N = X.shape[1]
     assert X.shape[0] == E and Y.dtype == torch.bfloat16 and X.dtype == torch.bfloat16
@@ -505,14 +505,20 @@ def gemm_tn(Y, X, splits=None, out_dtype=torch.float32, with_colsum=False):
     _profiled("fabind_gemm_tn M=%d N=%d E=%d" % (M, N, E), 2.0 * M * N * E,
               lambda: check(_lib.load().fabind_gemm_tn(ptr(Y), _ld(Y), ptr(X), _ld(X), ptr(part), M, N, E, splits, ptr(zp),
                                                        None, 0, 1 if with_colsum else 0, stream()), "fabind_gemm_tn"))
+    if with_colsum and n % 4 == 0 and M % 4 == 0 and (splits > 1 or out_dtype != torch.float32):
+        # one reduction launch: the weight part as out_dtype, the column sums behind it as fp32
+        dW = torch.empty((M, N), dtype=out_dtype, device=dev)
+        db = torch.empty(M, dtype=torch.float32, device=dev)
+        check(_lib.load().fabind_split_sum(ptr(part), splits, n, ptr(dW), dt_code(out_dtype), M, ptr(db), stream()), "fabind_split_sum")
+        return dW, db
     if splits == 1:
         out = part[0] if out_dtype == torch.float32 else part[0].to(out_dtype)
     elif n % 4 == 0:                                       # the split reduction writes the dtype the consumer carries (no cast kernel)
         out = torch.empty(n, dtype=out_dtype, device=dev)
-        check(_lib.load().fabind_split_sum(ptr(part), splits, n, ptr(out), dt_code(out_dtype), stream()), "fabind_split_sum")
+        check(_lib.load().fabind_split_sum(ptr(part), splits, n, ptr(out), dt_code(out_dtype), 0, None, stream()), "fabind_split_sum")
     else:
         out = colsum(part)
         out = out if out_dtype == torch.float32 else out.to(out_dtype)
     if with_colsum:
-        return out[:M * N].view(M, N), out[M * N:]
+        return out[:M * N].view(M, N), out[M * N:].float()
     return out.view(M, N)

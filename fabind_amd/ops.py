@@ -67,11 +67,11 @@ def _tn_ok(dpre, x, x2):
 def _weight_grad(dpre, x, act_pro, x2=None, out_dtype=torch.float32, want_db=False):
     """dW = dpre^T [act(x) | x2] as out_dtype.  bf16: TN contraction with LDS transpose reads (no transposed copies), its split
     reduction writing out_dtype directly; fp32 parity mode / odd widths: explicit transposes + split-K NT GEMMs over the (padded)
-    row dimension.  want_db: -> (dW, db) with db = dpre^T 1 (fp32) -- from the SAME contraction launches when the TN path runs and
-    the weight gradient is carried in fp32 (`fabind_gemm_tn(..., with_colsum)`), a separate column sum otherwise."""
+    row dimension.  want_db: -> (dW, db) with db = dpre^T 1 (fp32) -- from the SAME contraction launches when the TN path runs
+    (`fabind_gemm_tn(..., with_colsum)`; the split reduction writes dW as out_dtype and db as fp32), a separate column sum otherwise."""
     if not want_db:
         return _weight_grad_f32(dpre, x, act_pro, x2, out_dtype)
-    if FUSE_DB_TN and act_pro == K.ACT_NONE and out_dtype == torch.float32 and _tn_ok(dpre, x, x2):
+    if FUSE_DB_TN and act_pro == K.ACT_NONE and _tn_ok(dpre, x, x2):
         dW, db = K.gemm_tn(dpre, x, out_dtype=out_dtype, with_colsum=True)
         if x2 is not None:
             dW = torch.cat([dW, K.gemm_tn(dpre, x2, out_dtype=out_dtype)], 1)
@@ -970,13 +970,14 @@ class _InterAttn(torch.autograd.Function):
         dbias_red = torch.zeros(max(n_red, 1), **f32)
         dlogit, dcp = torch.zeros(max(E, 1), **f32), torch.zeros(max(E, 1), **f32)
         nblk = min((N + 3) // 4, 1024)
-        wpart = torch.empty((4, nblk, H), **f32)
+        wpart = torch.empty((nblk, 4 * H), **f32)                     # [block][4][H] partials of the four vector gradients
         check(load().fabind_inter_attn_bwd(ptr(qkv), qkv.stride(0), ptr(cv), cv.stride(0), H, ptr(d), ptr(rhohat),
                                            ptr(g.rp_int), ptr(g.col_int), ptr(g.mirror), ptr(g.red_idx), ptr(w_rk),
                                            ptr(w_rv), ptr(wcr), ptr(w3), ptr(alpha), ptr(cvs), ctx.clampv, N, ptr(dh_out),
                                            ptr(dx_out), ptr(dqkv), ptr(dcv), ptr(dd), ptr(drh), ptr(dbias_red), ptr(dlogit),
                                            ptr(dcp), ptr(wpart), nblk, stream()), "fabind_inter_attn_bwd")
-        dw = [K.colsum(wpart[i]) for i in range(4)]
+        dw_all = K.colsum(wpart)                                      # one launch pair for all four
+        dw = [dw_all[i * H:(i + 1) * H] for i in range(4)]
         dWc = dbc = None
         if ctx.has_cv:                                               # adjoint of cv = V Wc^T + bc, dV added to dqkv[:, 2H:]
             md = mm_dtype()

@@ -40,7 +40,8 @@ const char* fabind_last_error(void);
  * 9 = fabind_zero_empty_rows added (outputs of the fused edge kernels are no longer memset whole).
  * 10 = fabind_gemm_tn_tile_n added (the host sizes the split count of fabind_gemm_tn from the output tile of the current layout: 256 x 256 on
  *     eight waves by default); knobs fabind_gemm_tn_set_exp, fabind_gemm_set_small_m; fabind_gemm_tn_set_waves accepts 16 / 20.
- * 11 = fabind_gemm_tn takes with_colsum (the bias gradient rides along with the weight gradient: no separate column-sum launches).
+ * 11 = fabind_gemm_tn takes with_colsum (the bias gradient rides along with the weight gradient: no separate column-sum launches);
+ *     fabind_split_sum takes (n_tail, out_tail); fabind_inter_attn_bwd writes wpart as [nblk][4][H] (was [4][nblk][H]).
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 11
 int fabind_abi_version(void);
@@ -125,7 +126,8 @@ typedef struct FabindCopySeg {
 } FabindCopySeg;
 int fabind_multi_copy(const FabindCopySeg* segs_dev, int n_segs, int blocks_per_seg, hipStream_t stream);
 /* out[i] = sum_s part[s * n + i] (fixed order), written as out_dt: the split reduction of fabind_gemm_tn / split-K partials. */
-int fabind_split_sum(const float* part, int splits, long n, void* out, int out_dt, hipStream_t stream);
+int fabind_split_sum(const float* part, int splits, long n, void* out, int out_dt, long n_tail, float* out_tail, hipStream_t stream);
+/* n_tail > 0: the LAST n_tail of the n elements are written to out_tail as fp32 instead (a bias gradient behind a bf16 weight gradient). */
 /* out[c] (+)= sum_r in[r,c]; scratch = float[nchunk*C] (bias gradients, deterministic two-pass). */
 int fabind_colsum(const void* in, int in_dt, int ldi, float* out, int R, int C, int accumulate, float* scratch,
                   int nchunk, hipStream_t stream);
