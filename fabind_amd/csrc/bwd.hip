@@ -782,6 +782,68 @@ __global__ __launch_bounds__(256) void pair_hadamard_bwd_kernel(const void* dhd,
         atomicAdd(&db1[(size_t)cn * ldd1 + c], g * a1[(size_t)pn * ld1 + c]);
     }
 }
+// The same adjoint over the inter graph's reduced pairs WITHOUT float atomics: the inter graph is symmetric, so the pairs of a node are
+// the inter edges of its own row (pair index = red_idx[e], partner = col[e]).  One wave per node walks that row; every output element
+// has one writer and a fixed summation order (the atomic form adds in whatever order the work-groups arrive).  T = (a | b) per block:
+// a ligand node receives d b = sum g * a[partner], a protein node d a = sum g * b[partner]; the sums are ADDED to d0 / d1 (d0 may be a
+// shared gradient buffer that already holds other consumers' contributions).
+__global__ __launch_bounds__(256) void pair_hadamard_bwd_rows_kernel(const void* dhd, int dt, int ldh, const float* __restrict__ t0,
+                                                                    int ld0, int H, const float* __restrict__ t1, int ld1, int H2,
+                                                                    const int* __restrict__ rowptr, const int* __restrict__ col,
+                                                                    const int* __restrict__ red_idx, const int* __restrict__ red_c,
+                                                                    int n_rows, float* d0, int ldd0, float* d1, int ldd1) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_rows) return;
+    const int e0 = rowptr[n], e1 = rowptr[n + 1];
+    if (e0 == e1) return;
+    const bool lig = red_c[red_idx[e0]] == n;                 // which side of its pairs this node is
+    {
+        const int src = lig ? 0 : H, dst = lig ? H : 0;       // partner's factor / this node's gradient slot inside (a | b)
+        for (int c = lane * 4; c < H; c += 256) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = e0; e < e1; ++e) {
+                const float4 g = ld4_any(dhd, dt, (size_t)red_idx[e] * ldh + c);
+                const float4 v = *(const float4*)(t0 + (size_t)col[e] * ld0 + src + c);
+                acc.x += g.x * v.x; acc.y += g.y * v.y; acc.z += g.z * v.z; acc.w += g.w * v.w;
+            }
+            float4* o = (float4*)(d0 + (size_t)n * ldd0 + dst + c);
+            float4 q = *o;
+            q.x += acc.x; q.y += acc.y; q.z += acc.z; q.w += acc.w;
+            *o = q;
+        }
+    }
+    if (H2 > 0) {
+        const int src = lig ? 0 : H2, dst = lig ? H2 : 0;
+        for (int c = lane * 4; c < H2; c += 256) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = e0; e < e1; ++e) {
+                const float4 g = ld4_any(dhd, dt, (size_t)red_idx[e] * ldh + H + c);
+                const float4 v = *(const float4*)(t1 + (size_t)col[e] * ld1 + src + c);
+                acc.x += g.x * v.x; acc.y += g.y * v.y; acc.z += g.z * v.z; acc.w += g.w * v.w;
+            }
+            float4* o = (float4*)(d1 + (size_t)n * ldd1 + dst + c);
+            float4 q = *o;
+            q.x += acc.x; q.y += acc.y; q.z += acc.z; q.w += acc.w;
+            *o = q;
+        }
+    }
+}
+extern "C" int fabind_pair_hadamard_bwd_rows(const void* dhd, int dt, int ldh, const float* t0, int ld0, int H, const float* t1,
+                                             int ld1, int H2, const int* rowptr, const int* col, const int* red_idx,
+                                             const int* red_c, int n_rows, float* d0, int ldd0, float* d1, int ldd1,
+                                             hipStream_t stream) {
+    if (n_rows <= 0) return 0;
+    FB_REQUIRE(H % 4 == 0 && H2 % 4 == 0 && ldh % 4 == 0 && ld0 % 4 == 0 && ldd0 % 4 == 0 && (H2 == 0 || (ld1 % 4 == 0 && ldd1 % 4 == 0)),
+               "fabind_pair_hadamard_bwd_rows: widths and leading dimensions must be multiples of 4");
+    FB_REQUIRE((((uintptr_t)t0 | (uintptr_t)d0 | (uintptr_t)dhd) & 15) == 0 && (H2 == 0 || (((uintptr_t)t1 | (uintptr_t)d1) & 15) == 0),
+               "fabind_pair_hadamard_bwd_rows: 16-byte aligned buffers");
+    hipLaunchKernelGGL(pair_hadamard_bwd_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, dhd, dt, ldh, t0, ld0, H, t1, ld1, H2,
+                       rowptr, col, red_idx, red_c, n_rows, d0, ldd0, d1, ldd1);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const float* a0, const float* b0, int ld0,
                                         int H, const float* a1, const float* b1, int ld1, int H2, const int* red_p,
                                         const int* red_c, int n, float* da0, float* db0, int ldd0, float* da1,

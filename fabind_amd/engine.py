@@ -461,7 +461,7 @@ def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv, pdrop=0.0, pdrop_r
     # pair embedding at the inter-edge pairs only -> scalar attention bias (egnn.py:208, 286-304)
     h16 = _b16(h) if _fast(h, x, p["Wqkv"]) else h
     ab32 = ops.linear(h16, p["W_ab32"], p["b_ab32"])                                   # [N,128] (a32|0|b32|0)
-    hd = ops.pair_hadamard(a0b0, H, ab32, 64, g.red_p, g.red_c)                        # [n_red, H+64]
+    hd = ops.pair_hadamard(a0b0, H, ab32, 64, g.red_p, g.red_c, graph=g)               # [n_red, H+64]
     bias_part = ops.linear_rowdot(hd, p["Wcomp1"], p["bcomp1"], p["u"], act_epi=K.ACT_RELU)
     qkv = ops.linear(h16, p["Wqkv"], p["bqkv"], want16=True)                           # [N,3H] (+ bf16 copy: V is the next operand)
     d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay, g.int_by_col)

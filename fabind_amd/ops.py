@@ -875,9 +875,10 @@ class _PairHadamard(torch.autograd.Function):
     """hd[e, :H] = T0[p, :H] * T0[c, H:2H];  hd[e, H:H+H2] = T1[p, :H2] * T1[c, H2:2*H2]"""
 
     @staticmethod
-    def forward(ctx, T0, T1, H, H2, red_p, red_c):
+    def forward(ctx, T0, T1, H, H2, red_p, red_c, graph):
         ctx.dims = (H, H2)
         ctx.sink = getattr(T0, "_fab_gsink", None)        # shared gradient buffer of T0 (shared_grad), or None
+        ctx.graph = graph
         ctx.save_for_backward(T0, T1, red_p, red_c)
         return K.pair_hadamard(T0[:, :H], T0[:, H:], T1[:, :H2], T1[:, H2:], red_p, red_c, act_dtype())
 
@@ -886,18 +887,31 @@ class _PairHadamard(torch.autograd.Function):
         T0, T1, red_p, red_c = ctx.saved_tensors
         H, H2 = ctx.dims
         dhd = dhd.contiguous()
-        d0, d0_ret = _sink_zeros(T0, ctx.sink)           # the kernel adds into d0 / d1 (atomics)
+        d0, d0_ret = _sink_zeros(T0, ctx.sink)           # the kernel adds into d0 / d1
         d1 = torch.zeros_like(T1)
+        g = ctx.graph
+        if (PAIRHAD_ROWS and g is not None and T0.dtype == torch.float32 and T1.dtype == torch.float32 and H % 4 == 0 and H2 % 4 == 0
+                and dhd.stride(0) % 4 == 0):
+            # the pairs are the inter graph's own rows: one wave per node, one writer per element, fixed order (no float atomics)
+            check(load().fabind_pair_hadamard_bwd_rows(
+                ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(T0), T0.stride(0), H, ptr(T1), T1.stride(0), H2, ptr(g.rp_int),
+                ptr(g.col_int), ptr(g.red_idx), ptr(red_c), T0.shape[0], ptr(d0), d0.stride(0), ptr(d1), d1.stride(0), stream()),
+                "fabind_pair_hadamard_bwd_rows")
+            return d0_ret, d1, None, None, None, None, None
         check(load().fabind_pair_hadamard_bwd(
             ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(T0[:, :H]), ptr(T0[:, H:]), T0.stride(0), H, ptr(T1[:, :H2]),
             ptr(T1[:, H2:]), T1.stride(0), H2, ptr(red_p), ptr(red_c), red_p.shape[0], ptr(d0[:, :H]), ptr(d0[:, H:]),
             d0.stride(0), ptr(d1[:, :H2]), ptr(d1[:, H2:]), d1.stride(0), stream()), "fabind_pair_hadamard_bwd")
-        return d0_ret, d1, None, None, None, None
+        return d0_ret, d1, None, None, None, None, None
 
 
-def pair_hadamard(a0b0, H, ab32, H2, red_p, red_c):
+PAIRHAD_ROWS = os.environ.get("FABIND_PAIRHAD_ROWS", "1") == "1"   # adjoint of the pair Hadamard as a row walk of the inter graph (no atomics)
+
+
+def pair_hadamard(a0b0, H, ab32, H2, red_p, red_c, graph=None):
+    """graph: the inter graph whose reduced pairs (red_p, red_c) are (rp_int / col_int / red_idx) -- enables the atomic-free adjoint."""
     if _needs_grad(a0b0, ab32):
-        return _PairHadamard.apply(a0b0, ab32, H, H2, red_p, red_c)
+        return _PairHadamard.apply(a0b0, ab32, H, H2, red_p, red_c, graph)
     return K.pair_hadamard(a0b0[:, :H], a0b0[:, H:], ab32[:, :H2], ab32[:, H2:], red_p, red_c, act_dtype())
 
 

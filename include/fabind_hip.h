@@ -41,7 +41,8 @@ const char* fabind_last_error(void);
  * 10 = fabind_gemm_tn_tile_n added (the host sizes the split count of fabind_gemm_tn from the output tile of the current layout: 256 x 256 on
  *     eight waves by default); knobs fabind_gemm_tn_set_exp, fabind_gemm_set_small_m; fabind_gemm_tn_set_waves accepts 16 / 20.
  * 11 = fabind_gemm_tn takes with_colsum (the bias gradient rides along with the weight gradient: no separate column-sum launches);
- *     fabind_split_sum takes (n_tail, out_tail); fabind_inter_attn_bwd writes wpart as [nblk][4][H] (was [4][nblk][H]).
+ *     fabind_split_sum takes (n_tail, out_tail); fabind_inter_attn_bwd writes wpart as [nblk][4][H] (was [4][nblk][H]);
+ *     fabind_pair_hadamard_bwd_rows added (the pair-Hadamard adjoint over the inter graph without float atomics).
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 11
 int fabind_abi_version(void);
@@ -458,6 +459,12 @@ int fabind_batched_transpose_pad(const void* in, int ld_in, const int* desc, int
 int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const float* a0, const float* b0, int ld0, int H,
                              const float* a1, const float* b1, int ld1, int H2, const int* red_p, const int* red_c, int n,
                              float* da0, float* db0, int ldd0, float* da1, float* db1, int ldd1, hipStream_t stream);
+/* fabind_pair_hadamard_bwd over the inter graph's reduced pairs without float atomics: one wave per node walks the inter edges of its own
+ * row (pair = red_idx[e], partner = col[e]); t0 = (a | b) [N, 2H], t1 = (a | b) [N, 2 H2] (H2 may be 0), the sums are ADDED to d0 / d1
+ * in the same layout.  Deterministic summation order. */
+int fabind_pair_hadamard_bwd_rows(const void* dhd, int dt, int ldh, const float* t0, int ld0, int H, const float* t1, int ld1, int H2,
+                                  const int* rowptr, const int* col, const int* red_idx, const int* red_c, int n_rows, float* d0,
+                                  int ldd0, float* d1, int ldd1, hipStream_t stream);
 int fabind_inter_attn_bwd(const float* qkv, int ldqkv, const float* cv, int ldcv, int H, const float* d,
                           const float* rhohat, const int* rowptr, const int* col, const int* mirror, const int* red_idx,
                           const float* w_rk, const float* w_rv, const float* wcr, const float* w3, const float* alpha,

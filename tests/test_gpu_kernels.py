@@ -551,6 +551,63 @@ def test_gemm_tn_column_sums_ride_along(shape):
     assert dWb.dtype == torch.bfloat16 and float((dbb.double() - ref).abs().max()) <= 1e-2 * float(ref.abs().max()) + 1e-3
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_pair_hadamard_adjoint_row_walk_matches_atomics(dt):
+    """Adjoint of the pair Hadamard over the inter graph's reduced pairs: the row walk (one wave per node over its own inter edges,
+    one writer per element, fabind_pair_hadamard_bwd_rows) against the float-atomics kernel and against torch autograd; the row walk
+    must give the same bits twice, and it must ADD to a gradient buffer that already holds something (shared gradient sink)."""
+    from fabind_amd import engine, ops, synthetic
+    import fabind_amd.ops as ops_mod
+    dev = _dev()
+    engine.set_precision("fp32")
+    H, H2 = 64, 8
+    inp = synthetic.make_stack_batch([(70, 9), (33, 17), (120, 5)], H, seed=5)
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    lay = engine.Layout(t["batch_id"], t["segment_id"])
+    br, bc_ = t["compound_edge_index"][0].to(torch.int32), t["compound_edge_index"][1].to(torch.int32)
+    g = engine.Graph(lay, t["X"][:, 0].contiguous(), br, bc_, lay.ranges(br), 1.6, 2.0)
+    n_red, N = int(g.red_p.shape[0]), lay.N
+    assert n_red > 50
+    gen = torch.Generator().manual_seed(3)
+    T0 = torch.randn(N, 2 * H, generator=gen).to(dev)
+    T1 = torch.randn(N, 2 * H2, generator=gen).to(dev)
+    w = torch.randn(n_red, H + H2, generator=gen).to(dev)
+
+    def run(graph, shared=False):
+        t0, t1 = T0.clone().requires_grad_(True), T1.clone().requires_grad_(True)
+        base = t0 * 1.0
+        s = ops.shared_grad(base) if shared else base
+        hd = ops.pair_hadamard(s, H, t1, H2, g.red_p, g.red_c, graph=graph)
+        loss = (hd.float() * w).sum()
+        if shared:
+            loss = loss + (ops.pair_hadamard(s, H, t1, H2, g.red_p, g.red_c, graph=graph).float() * w).sum() * 0.5
+        loss.backward()
+        return t0.grad, t1.grad
+
+    old = ops_mod.act_dtype
+    try:
+        ops_mod.act_dtype = lambda: dt                       # the gradient arrives in the activation dtype of the forward output
+        a0, a1 = run(g)
+        b0, b1 = run(g)
+        assert torch.equal(a0, b0) and torch.equal(a1, b1)
+        r0, r1 = run(None)                                    # float atomics
+        assert float((a0 - r0).abs().max()) <= 1e-5 * float(r0.abs().max())
+        assert float((a1 - r1).abs().max()) <= 1e-5 * float(r1.abs().max())
+        s0, s1 = run(g, shared=True)
+        assert float((s0 - 1.5 * a0).abs().max()) <= 1e-5 * float(a0.abs().max())
+        assert float((s1 - 1.5 * a1).abs().max()) <= 1e-5 * float(a1.abs().max())
+    finally:
+        ops_mod.act_dtype = old
+    # torch autograd on the same expression
+    t0, t1 = T0.clone().requires_grad_(True), T1.clone().requires_grad_(True)
+    p, c = g.red_p.long(), g.red_c.long()
+    ref = torch.cat([t0[p, :H] * t0[c, H:], t1[p, :H2] * t1[c, H2:]], 1)
+    if dt == torch.float32:
+        (ref * w).sum().backward()
+        assert float((a0 - t0.grad).abs().max()) <= 1e-5 * float(t0.grad.abs().max())
+        assert float((a1 - t1.grad).abs().max()) <= 1e-5 * float(t1.grad.abs().max())
+
+
 @pytest.mark.parametrize("case", ["one_consumer", "two_consumers", "second_output_unused"])
 def test_shared_gradient_buffer_matches_plain_autograd(case):
     """ops.shared_grad / ops.GradSink: consumers with accumulating adjoints add into ONE gradient buffer (the first to run hands it
