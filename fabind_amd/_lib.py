@@ -82,7 +82,7 @@ SIGNATURES = {
     "fabind_pair_hadamard": [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
     "fabind_inter_attn_fwd": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
                               _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "fabind_layernorm_rows_bwd": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _i, _vp, _i, _i, _vp, _vp, _vp],
+    "fabind_layernorm_rows_bwd": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp],
     "fabind_edge_concat": [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "fabind_las_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp],
     "fabind_select_rows": [_vp, _vp, _vp, _i, _i, _vp, _vp],

@@ -446,12 +446,16 @@ __global__ __launch_bounds__(256) void layernorm_rows_bwd_kernel(const void* __r
                                                                  const float* __restrict__ w, const void* __restrict__ dy,
                                                                  int dy_dt, int lddy, float eps, int R, int C, void* dx,
                                                                  int dx_dt, int lddx, float* dwp, float* dbp) {
+    // One wave per row, rows strided over the grid; the weight / bias gradient of a wave's rows accumulates in REGISTERS (one column set
+    // per lane) and the four waves of a work-group are added in wave order through LDS at the end: one [C] partial per work-group and a
+    // fixed summation order.  (Round 1 zeroed an LDS accumulator per work-group of FOUR rows, added into it with LDS atomics and wrote a
+    // [C] partial per four rows -- as many partial bytes as input bytes, 25 % of the kernel time of a FABind+ training step.)
     extern __shared__ float sh[];                   // [2][C]
-    const int lane = threadIdx.x & 63;
-    for (int c = threadIdx.x; c < 2 * C; c += 256) sh[c] = 0.f;
-    __syncthreads();
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r < R) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float aw[NPL], ab[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) { aw[k] = 0.f; ab[k] = 0.f; }
+    for (int r = blockIdx.x * 4 + wave; r < R; r += gridDim.x * 4) {
         const size_t xo = (size_t)r * ldx, go = (size_t)r * lddy, o = (size_t)r * lddx;
         float v[NPL], g[NPL];
         float s = 0.f;
@@ -487,12 +491,24 @@ __global__ __launch_bounds__(256) void layernorm_rows_bwd_kernel(const void* __r
             if (c < C) {
                 const float xh = (v[k] - mu) * rs, gw = g[k] * w[c];
                 st_any(dx, dx_dt, o + c, rs * (gw - s1 - xh * s2));
-                atomicAdd(&sh[c], g[k] * xh);
-                atomicAdd(&sh[C + c], g[k]);
+                aw[k] += g[k] * xh;
+                ab[k] += g[k];
             }
         }
     }
-    __syncthreads();
+    for (int wv = 0; wv < 4; ++wv) {                // waves add in order: no atomics, fixed order
+        if (wave == wv) {
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const int c = k * 64 + lane;
+                if (c < C) {
+                    sh[c] = (wv ? sh[c] : 0.f) + aw[k];
+                    sh[C + c] = (wv ? sh[C + c] : 0.f) + ab[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < C; c += 256) {
         dwp[(size_t)blockIdx.x * C + c] = sh[c];
         dbp[(size_t)blockIdx.x * C + c] = sh[C + c];
@@ -500,15 +516,17 @@ __global__ __launch_bounds__(256) void layernorm_rows_bwd_kernel(const void* __r
 }
 extern "C" int fabind_layernorm_rows_bwd(const void* x, int x_dt, int ldx, const float* w, const void* dy, int dy_dt, int lddy,
                                          float eps, int R, int C, void* dx, int dx_dt, int lddx, float* dw_part, float* db_part,
-                                         hipStream_t stream) {
+                                         int nblk, hipStream_t stream) {
     if (R <= 0) return 0;
     FB_REQUIRE(C <= 2048, "fabind_layernorm_rows_bwd: C <= 2048");
+    FB_REQUIRE(nblk >= 1, "fabind_layernorm_rows_bwd: nblk >= 1 (rows of the dw / db partial buffers)");
     const size_t lds = (size_t)2 * C * sizeof(float);
-#define LNB_LAUNCH(NPL_) hipLaunchKernelGGL((layernorm_rows_bwd_kernel<NPL_>), dim3((R + 3) / 4), dim3(256), lds, stream, x, x_dt, \
+#define LNB_LAUNCH(NPL_) hipLaunchKernelGGL((layernorm_rows_bwd_kernel<NPL_>), dim3(nblk), dim3(256), lds, stream, x, x_dt, \
                                             ldx, w, dy, dy_dt, lddy, eps, R, C, dx, dx_dt, lddx, dw_part, db_part)
     if (C <= 128) LNB_LAUNCH(2);
     else if (C <= 512) LNB_LAUNCH(8);
     else if (C <= 1024) LNB_LAUNCH(16);
+    else if (C <= 1280) LNB_LAUNCH(20);   /* the FABind+ edge input (2H + 1 = 1025 padded to 1088 at H = 512): 32 column sets per lane left one wave per SIMD */
     else LNB_LAUNCH(32);
 #undef LNB_LAUNCH
     FB_CHECK_LAUNCH();

@@ -257,12 +257,12 @@ class _LnRows(torch.autograd.Function):
         R, C = x.shape
         dy = dy if dy.stride(-1) == 1 else dy.contiguous()
         dx = torch.empty((R, C), dtype=x.dtype, device=x.device)
-        nblk = (R + 3) // 4
+        nblk = max(1, min((R + 3) // 4, 2048))              # work-groups of four waves, rows strided over them: 8 per CU
         dwp = torch.empty((nblk, C), dtype=torch.float32, device=x.device)
         dbp = torch.empty((nblk, C), dtype=torch.float32, device=x.device)
         check(load().fabind_layernorm_rows_bwd(ptr(x), dt_code(x.dtype), x.stride(0), ptr(w), ptr(dy), dt_code(dy.dtype),
                                                dy.stride(0), 1e-5, R, C, ptr(dx), dt_code(dx.dtype), C, ptr(dwp), ptr(dbp),
-                                               stream()), "fabind_layernorm_rows_bwd")
+                                               nblk, stream()), "fabind_layernorm_rows_bwd")
         return dx, K.colsum(dwp), K.colsum(dbp), None, None
 
 

@@ -42,7 +42,8 @@ const char* fabind_last_error(void);
  *     eight waves by default); knobs fabind_gemm_tn_set_exp, fabind_gemm_set_small_m; fabind_gemm_tn_set_waves accepts 16 / 20.
  * 11 = fabind_gemm_tn takes with_colsum (the bias gradient rides along with the weight gradient: no separate column-sum launches);
  *     fabind_split_sum takes (n_tail, out_tail); fabind_inter_attn_bwd writes wpart as [nblk][4][H] (was [4][nblk][H]);
- *     fabind_pair_hadamard_bwd_rows added (the pair-Hadamard adjoint over the inter graph without float atomics).
+ *     fabind_pair_hadamard_bwd_rows added (the pair-Hadamard adjoint over the inter graph without float atomics);
+ *     fabind_layernorm_rows_bwd takes nblk (the caller sizes the partial buffers; the kernel strides rows over that grid).
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 11
 int fabind_abi_version(void);
@@ -386,11 +387,11 @@ int fabind_edge_lnfold(const void* AB, int ldab, int Kp, int H, const int* row, 
 int fabind_inter_coord_fold(const void* P, int ldp, int H, const int* col, const float* rho, const float* stat, float q_w,
                             float eps, const float* u, const float* d, const float* w3, int E, float* s_out, float p_drop,
                             unsigned seed, hipStream_t stream);
-/* adjoint of fabind_layernorm_rows: dx (dtype dx_dt, leading dim lddx) and per-block partials of dw, db ([nblk][C] each,
- * nblk = ceil(R/4); the caller adds the rows).  fabind_edge_concat: y[e] = [h[row[e]] | h[col[e]] | rhohat[e] | 0...]
+/* adjoint of fabind_layernorm_rows: dx (dtype dx_dt, leading dim lddx) and per-work-group partials of dw, db ([nblk][C] each;
+ * nblk = the grid the caller chooses, one wave per row strided over it -- every partial row is written; the caller adds the rows).  fabind_edge_concat: y[e] = [h[row[e]] | h[col[e]] | rhohat[e] | 0...]
  * (the un-normalised edge input of MC_E_GCL, used under autograd where LayerNorm is a separate differentiable step). */
 int fabind_layernorm_rows_bwd(const void* x, int x_dt, int ldx, const float* w, const void* dy, int dy_dt, int lddy, float eps,
-                              int R, int C, void* dx, int dx_dt, int lddx, float* dw_part, float* db_part, hipStream_t stream);
+                              int R, int C, void* dx, int dx_dt, int lddx, float* dw_part, float* db_part, int nblk, hipStream_t stream);
 int fabind_edge_concat(const float* h, int ldh, int H, const int* row, const int* col, const float* rhohat, int E, void* y,
                        int y_dt, int ldy, int pad_to, hipStream_t stream);
 int fabind_layernorm_fwd(const float* x, const float* w, const float* b, float eps, int R, int C, float* y, float* mean,
