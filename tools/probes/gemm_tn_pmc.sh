@@ -15,9 +15,9 @@ from collections import defaultdict
 v = defaultdict(list)
 for p in sys.argv[1:]:
     for r in csv.DictReader(open(p)):
-        if "gemm_tn_bf16" in r["Kernel_Name"] and int(r["Grid_Size"]) >= 200000:
+        if "gemm_tn_bf16" in r["Kernel_Name"] and int(r["Grid_Size"]) >= 131072:
             v[r["Counter_Name"]].append(float(r["Counter_Value"]))
-print("TN contraction, E = 1,539,196, M = N = 512 (grid >= 200000 threads), per launch:")
+print("TN contraction, E = 1,539,196, M = N = 512 (grid >= 131072 threads: the edge-level shape and the 8-tile node-level shapes), per launch:")
 for k in sorted(v):
     print("  %-32s %.4g  (%d launches)" % (k, sum(v[k]) / len(v[k]), len(v[k])))
 PY
