@@ -285,3 +285,19 @@ def test_layout_cache_is_keyed_on_tensor_identity_and_version():
     s[2] = 0                                                         # in-place edit bumps the version counter
     l2 = engine.Layout.of(b, s)
     assert l2 is not l1 and l2.P.tolist() == [2, 4]
+
+
+def test_tn_split_count_keeps_the_xcds_evenly_loaded():
+    """kernels._tn_splits (256x256 layout): work-group ids go round-robin over the 8 XCDs with all tiles of an e-range on one XCD, so
+    the split count of a long operand is a multiple of 8, every split keeps at least 256 rows, and the edge-level contraction of the
+    bench (4 tiles) runs in one round of 256 work-groups; the 256x128 layout keeps round 1's rule."""
+    from fabind_amd import kernels as K
+    for M, N, E in ((512, 512, 1539196), (512, 512, 98688), (1024, 512, 98688), (1536, 512, 98688), (1024, 576, 78837),
+                    (256, 512, 98688), (512, 128, 98688), (512, 512, 9088)):
+        s = K._tn_splits(M, N, E, 256)
+        assert s % 8 == 0 and E // s >= 256, (M, N, E, s)
+        assert K._tn_splits(M, N, E, 256) == s                      # memoised
+    assert K._tn_splits(512, 512, 1539196, 256) == 64               # 4 tiles x 64 splits = 256 work-groups: one per CU
+    assert K._tn_splits(1536, 512, 98688, 256) == 16                # 12 tiles: 24 work-groups per XCD, one round
+    assert 1 <= K._tn_splits(512, 512, 2624, 256) <= 16             # short operands: a few splits of >= 256 rows
+    assert K._tn_splits(512, 512, 1539196, 128) == 128              # round-1 layout: 8 tiles x 128 splits
