@@ -311,6 +311,10 @@ def egnn_forward(gnn, h, x, ctx_edges, att_edges, LAS_edge_list, batched_complex
     """MCAttEGNN.forward with the reference's positional arguments (egnn.py:392-466)."""
     _require_cuda(h, "MCAttEGNN")
     assert ctx_edge_attr is None and att_edge_attr is None
+    a = gnn.args
+    if getattr(a, "fix_pocket", False) or getattr(a, "rm_LAS_constrained_optim", False) or getattr(gnn, "dense", False):
+        # (the constructor refuses these too; this catches flags flipped on a built module -- egnn.py:404-405,433,458-460)
+        raise NotImplementedError("MCAttEGNN.forward: fix_pocket / rm_LAS_constrained_optim / dense are not built (production flags only)")
     lay = engine.Layout(batch_id, segment_id)
     from .plus.engine import PairList
     pairs = PairList(lay, h.device)
@@ -338,7 +342,8 @@ def egnn_forward(gnn, h, x, ctx_edges, att_edges, LAS_edge_list, batched_complex
         h, xx, alpha = att_layer(att, h, att_edges, xx, segment_id, batch_id, None, None, lay=lay, g=g_int, z_list=z_list,
                                  pairs=pairs)
         atts.append(alpha)
-        xx = ops.las_step(xx, x_las, las, lay, float(gnn.geometry_reg_step_size), 15.0 / scale)
+        for _ in range(int(gnn.geom_reg_steps)):                # egnn.py:436 (the reference fixes it to 1, egnn.py:357)
+            xx = ops.las_step(xx, x_las, las, lay, float(gnn.geometry_reg_step_size), 15.0 / scale)
     ol = gnn.out_layer
     h, xx = engine.gcl_layer(engine.gcl_params(ol), h, xx, lay, g_ctx, float(ol.coord_change_maximum),
                              ol.dropout.p if training else 0.0)

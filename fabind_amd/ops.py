@@ -669,14 +669,26 @@ class _PutRows(torch.autograd.Function):
     def backward(ctx, dout):
         idx, = ctx.saved_tensors
         d_rows = dout.index_select(0, idx)
-        # the incoming gradient is the engine's / the sink's own accumulation buffer for this node: zero the overwritten rows
-        # in place instead of cloning [N, .] (PUT_ROWS_INPLACE_GRAD = False restores the copy)
-        d_base = dout if (PUT_ROWS_INPLACE_GRAD and dout.is_contiguous()) else dout.clone()
-        d_base.index_fill_(0, idx, 0.0)
+        # d base = dout with the overwritten rows zeroed.  In place ONLY when this node provably owns the tensor: it carries the
+        # `_fab_owned` mark of `_SinkOwner.backward` (the shared gradient buffer this library allocated and handed to autograd
+        # itself, or a tensor created there) and nobody but the engine's frame and this Python wrapper references it -- a
+        # producer that hands one gradient tensor to several edges (AddBackward on the pdrop > 0 paths) shows a higher use
+        # count, and anything autograd summed or copied on the way has lost the mark.  Everything else gets a fresh tensor.
+        if PUT_ROWS_INPLACE_GRAD and dout.is_contiguous() and _owned_grad(dout):
+            d_base = dout
+            d_base.index_fill_(0, idx, 0.0)
+        else:
+            d_base = dout.index_fill(0, idx, 0.0)
         return d_base, d_rows, None, None
 
 
 PUT_ROWS_INPLACE_GRAD = True
+
+
+def _owned_grad(g):
+    """True if the incoming gradient `g` is a buffer this library created for exactly this edge of the graph (marked by
+    `_SinkOwner.backward`) and no other holder exists (TensorImpl use count: the engine's input list + this Python wrapper)."""
+    return bool(getattr(g, "_fab_owned", False)) and g._use_count() <= 2
 
 
 def _put_rows_inplace(base, rows, idx):
@@ -792,16 +804,23 @@ class _SinkOwner(torch.autograd.Function):
     def backward(ctx, g):
         sink = ctx.sink
         pend, rows = sink.pending, sink.rows
+        owned = g is not None and g is sink.buf    # the buffer this sink allocated and returned to autograd as the one gradient
         sink.buf, sink.pending, sink.rows = None, None, []
         if pend is not None:                       # a deposit that no later GEMM folded in
-            g = pend if g is None else g + pend
+            if g is None:
+                g, owned = pend, False             # `pend` may alias another node's incoming gradient (deposit() does not copy)
+            else:
+                g, owned = g + pend, True
         if rows:
             if g is None:
                 g = torch.zeros(ctx.meta[0], dtype=ctx.meta[1], device=ctx.meta[2])
-            elif pend is None:
-                g = g.clone()
+            elif not owned:
+                g = g.clone()                      # never index_add_ into a tensor this node does not own
+            owned = True
             for idx, r in rows:
                 g.index_add_(0, idx, r.to(g.dtype))
+        if owned:
+            g._fab_owned = True                    # consumers upstream (_PutRows.backward) may reuse it in place
         return g, None
 
 

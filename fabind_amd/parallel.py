@@ -119,7 +119,17 @@ class GradReducer:
         self.pending = [len(b) for b in self.buckets]
         self.work = [None] * len(self.buckets)
         self.seen = set()
+        self.stale = set()         # buckets holding a parameter whose .grad changed after its copy (gradient accumulation)
         self.next_issue = 0
+
+    def abort(self):
+        """Abandon the current step (backward raised, or the step is skipped after some hooks fired): wait for the collectives
+        already issued -- every rank issues the same ones, so this cannot hang as long as all ranks abort the same step -- and
+        forget the partial state.  The .grad fields are left as backward left them."""
+        for w in self.work:
+            if w is not None:
+                w[0].wait()
+        self._reset()
 
     def _buffer(self, bi):
         if self.flat[bi] is None:
@@ -128,10 +138,19 @@ class GradReducer:
         return self.flat[bi]
 
     def _hook(self, p):
-        if id(p) in self.seen:          # a second accumulation into the same parameter in one step: finish() re-reads .grad
+        bi, off = self.slot[id(p)]
+        if id(p) in self.seen:
+            # A second accumulation into the same parameter before finish() (two backward() calls per step = gradient
+            # accumulation, or a parameter reached twice by one backward): .grad now holds the SUM, the bucket the first
+            # micro-batch only.  If the bucket is still here it is refreshed in place; if its collective has already left,
+            # it is marked stale and finish() reduces it again from .grad (the first result is discarded).  Every rank
+            # runs the same number of backward() calls, so every rank marks the same buckets.
+            if self.work[bi] is None:
+                self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            else:
+                self.stale.add(bi)
             return
         self.seen.add(id(p))
-        bi, off = self.slot[id(p)]
         self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
         self.pending[bi] -= 1
         self._issue_ready()
@@ -148,7 +167,10 @@ class GradReducer:
         self.work[bi] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat)
 
     def finish(self):
-        """Call after backward: completes the step's all-reduce and leaves the rank-averaged gradient in every .grad."""
+        """Call after the step's LAST backward: completes the all-reduce and leaves the rank-averaged gradient in every .grad.
+        With gradient accumulation (several backward() calls before finish()) the result is the average of the accumulated
+        gradients: buckets whose collective left before a later micro-batch added to one of their parameters are reduced
+        again from .grad."""
         if self.world == 1:
             for p in self.params:
                 if p.grad is None:
@@ -163,6 +185,16 @@ class GradReducer:
                         buf[off:off + p.numel()].zero_()
                 self.pending[bi] = 0
         self._issue_ready()
+        for bi in sorted(self.stale):                          # same order on every rank
+            self.work[bi][0].wait()                            # (its result is superseded)
+            buf = self._buffer(bi)
+            for p in self.buckets[bi]:
+                _, off = self.slot[id(p)]
+                if p.grad is None:
+                    buf[off:off + p.numel()].zero_()
+                else:
+                    buf[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            self._issue(bi)
         for bi, b in enumerate(self.buckets):
             work, flat = self.work[bi]
             work.wait()

@@ -22,21 +22,34 @@ _SEG = np.dtype([("src", np.uint64), ("dst", np.uint64), ("src_sr", np.int64), (
                  ("dst_sc", np.int64), ("rows", np.int32), ("cols", np.int32), ("src_dt", np.int32), ("dst_dt", np.int32),
                  ("vec4", np.int32), ("pad", np.int32)])
 _ESZ = {torch.float32: 4, torch.bfloat16: 2}
-_RING, _RING_POS = [], [0]
+_RING, _RING_POS, _RING_EVT = [], [0], []
+_RING_SLOTS = 16
 
 
 def _upload(table, dev):
-    """Device copy of a segment table through a ring of pinned staging buffers (asynchronous, no stream drain)."""
+    """Device copy of a segment table through a ring of pinned staging buffers (asynchronous, no stream drain).  Every slot
+    carries the event recorded behind its last host-to-device copy; a slot is rewritten only after that copy has run, so a
+    host that gets more than a ring's worth of pack launches ahead of the device (a training loop without a per-step sync)
+    waits here instead of overwriting a table the device has not read yet."""
     raw = table.view(np.uint8)
     n = raw.shape[0]
     if not _RING:
-        _RING.extend(torch.empty(64 * 1024, dtype=torch.uint8, pin_memory=True) for _ in range(16))
-    _RING_POS[0] = (_RING_POS[0] + 1) % len(_RING)
-    stage = _RING[_RING_POS[0]]
-    if n > stage.numel():
-        stage = torch.empty(n, dtype=torch.uint8, pin_memory=True)
+        _RING.extend(torch.empty(64 * 1024, dtype=torch.uint8, pin_memory=True) for _ in range(_RING_SLOTS))
+        _RING_EVT.extend([None] * _RING_SLOTS)
+    k = _RING_POS[0] = (_RING_POS[0] + 1) % len(_RING)
+    if n > _RING[k].numel():
+        if _RING_EVT[k] is not None:
+            _RING_EVT[k].synchronize()          # the old (smaller) buffer may still be the source of a queued copy
+        _RING[k] = torch.empty(max(n, 2 * _RING[k].numel()), dtype=torch.uint8, pin_memory=True)
+    elif _RING_EVT[k] is not None:
+        _RING_EVT[k].synchronize()
+    stage = _RING[k]
     stage[:n].numpy()[:] = raw
-    return stage[:n].to(dev, non_blocking=True)
+    out = stage[:n].to(dev, non_blocking=True)
+    if out.is_cuda:
+        _RING_EVT[k] = torch.cuda.Event()
+        _RING_EVT[k].record(torch.cuda.current_stream(out.device))
+    return out
 
 
 def _launch(table, dev):
