@@ -1181,6 +1181,197 @@ static int launch_pipe(const FabindGemmArgs& p, int maxM, int maxN, hipStream_t 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 ("bf16x3") NT GEMM: fp32 A (optionally [A | A2]) and fp32 W at (nearly) fp32 accuracy on the bf16 matrix cores.
+// Every operand element x is split WHILE IT IS STAGED into hi = bf16_rn(x) and lo = bf16_rn(x - hi) -- 16 significand bits
+// together -- and a product term is three v_mfma_f32_16x16x32_bf16: lo*hi + hi*lo + hi*hi, fp32 accumulate (the lo*lo term,
+// 2^-18 of the product, is dropped).  Against the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32, 1/16 of the bf16 rate) that is
+// 3/16 of the matrix-core time; the reference computes these contractions in fp32 (FABind/fabind/models/egnn.py:68-144,
+// model_utils.py:83-131), and this is the mode that meets the 1e-4 A gate at speed.
+//   * tile (64 WM) x 128 x 32, WM x 2 waves of 64 x 64; operands go global -> registers (fp32, 16-B loads) -> split -> two bf16
+//     LDS planes (hi | lo) per operand; two LDS stages and a register prefetch of the tile after next: ONE barrier per k-step,
+//     and the splitting VALU work of tile k+1 sits next to the MFMAs of tile k in every wave;
+//   * rows are 32 bf16 + 8 pad (80 B): the 16 lanes of a fragment read hit 16 different 16-byte bank groups;
+//   * epilogues, ragged groups, split-K and the XCD-aware tile order are those of the bf16 kernels.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void x3_split8(const Vec8& x, uint4& hi, uint4& lo) {
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        h[q] = pack2_bf16(x.v[2 * q], x.v[2 * q + 1]);
+        l[q] = pack2_bf16(x.v[2 * q] - __uint_as_float(h[q] << 16), x.v[2 * q + 1] - __uint_as_float(h[q] & 0xffff0000u));
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+template <int WM> __host__ __device__ constexpr size_t x3_lds_bytes() {
+    return (size_t)2 * 2 * (WM * 64 + BN) * (BK + 8) * 2;          // [stage][hi | lo][rows][40] bf16
+}
+
+template <int WM, int MINW>
+__global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs p) {
+    constexpr int BM_ = WM * 64, NT = WM * 128, LS = BK + 8;
+    constexpr int ROWS = BM_ + BN, PLANE = ROWS * LS;             // A rows then W rows; one plane = hi or lo of one stage
+    constexpr int NA = BM_ * 4 / NT, NB = BN * 4 / NT;            // 8-float chunks per thread and k-step (a row = 4 chunks)
+    static_assert(NA >= 1 && NB >= 1 && (BM_ * 4) % NT == 0 && (BN * 4) % NT == 0, "staging divides evenly");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sT = (bf16_t*)smem;                                   // [2][2][ROWS][LS]
+    // epilogue scratch lives in the (finished) stages: the bf16 / fp32 staging tile first, the row-dot partials behind it
+    float* sDot = (float*)(smem + x3_lds_bytes<WM>() - 2 * BM_ * sizeof(float));
+
+    int M = p.M, N = p.N, ldc = p.ldc;
+    long a_row0 = 0, w_row0 = 0, c_off = 0;
+    int Kg = p.K, lda_g = p.lda, K1g = p.K1;
+    long a_eoff = 0, w_eoff = 0;
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.groups && p.groups_ext) {
+        const int* g = p.groups + (size_t)blockIdx.z * 16;
+        M = g[0]; N = g[1]; Kg = g[2]; lda_g = g[3];
+        a_eoff = (long)(unsigned)g[4] | ((long)g[5] << 32);
+        w_eoff = (long)(unsigned)g[6] | ((long)g[7] << 32);
+        c_off = (long)(unsigned)g[8] | ((long)g[9] << 32);
+        ldc = g[10];
+        K1g = Kg;
+    } else if (p.groups) {
+        const int* g = p.groups + (size_t)blockIdx.z * 8;
+        a_row0 = g[0]; M = g[1]; w_row0 = g[2]; N = g[3];
+        c_off = (long)(unsigned)g[4] | ((long)g[5] << 32);
+        if (g[6] > 0) ldc = g[6];
+    } else {
+        // 1-D launch, XCD-aware tile order (see gemm_bf16_pipe_kernel): the N-tiles of one M-panel share an XCD's L2 copy of the A panel
+        const int nbx = (N + BN - 1) / BN, total = gridDim.x;
+        const int L = blockIdx.x, q = total / 8, r = total % 8, xcd = L % 8;
+        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + L / 8;
+        bx = t % nbx; by = t / nbx;
+    }
+    const int m0 = by * BM_, n0 = bx * BN;
+    if (m0 >= M || n0 >= N) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const float* A = (const float*)p.A + a_row0 * lda_g + a_eoff;
+    const float* A2 = p.A2 ? (const float*)p.A2 + a_row0 * p.lda2 : nullptr;
+    const float* W = (const float*)p.W + w_row0 * p.ldw + w_eoff;
+    int K = Kg;
+    const int K1 = K1g;
+    int kbeg = 0;
+    if (!p.groups && p.k_splits > 1) {      // split-K over blockIdx.y (non-grouped launches are 1-D in x)
+        const int per = ((p.K / p.k_splits + BK - 1) / BK) * BK;
+        kbeg = blockIdx.y * per;
+        K = min(p.K, kbeg + per);
+        c_off = (long)blockIdx.y * M * ldc;
+    }
+    if (p.groups_ext) { a_row0 = 0; w_row0 = 0; }
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int lr = tid >> 2, lc = (tid & 3) * 8;                 // this thread's row (+ NT/4 per chunk) and k offset in a k-tile
+    Vec8 ra[NA], rb[NB];
+    auto fetch = [&](int k0) {
+        const int gk = k0 + lc;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int gm = m0 + lr + (NT / 4) * i;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ra[i].v[q] = 0.f;
+            if (gm < M && gk < K) {
+                const float* src = (gk < K1) ? A + (size_t)gm * lda_g + gk : A2 + (size_t)gm * p.lda2 + (gk - K1);
+                ra[i] = load8<float>(src);
+                if (p.act_pro != FB_ACT_NONE) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) ra[i].v[q] = apply_act(ra[i].v[q], p.act_pro);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int gn = n0 + lr + (NT / 4) * i;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rb[i].v[q] = 0.f;
+            if (gn < N && gk < K) rb[i] = load8<float>(W + (size_t)gn * p.ldw + gk);
+        }
+    };
+    auto split_store = [&](int st) {
+        bf16_t* hi = sT + (size_t)st * 2 * PLANE;
+        bf16_t* lo = hi + PLANE;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            uint4 h, l;
+            x3_split8(ra[i], h, l);
+            const int o = (lr + (NT / 4) * i) * LS + lc;
+            *(uint4*)&hi[o] = h;
+            *(uint4*)&lo[o] = l;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            uint4 h, l;
+            x3_split8(rb[i], h, l);
+            const int o = (BM_ + lr + (NT / 4) * i) * LS + lc;
+            *(uint4*)&hi[o] = h;
+            *(uint4*)&lo[o] = l;
+        }
+    };
+
+    const int nk = (K - kbeg + BK - 1) / BK;
+    const int fr = lane & 15, fk = (lane >> 4) * 8;
+    if (nk > 0) {
+        fetch(kbeg);
+        split_store(0);
+        if (nk > 1) fetch(kbeg + BK);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) split_store((kt + 1) & 1);             // (stage (kt+1)&1 was last read in step kt-1, before its barrier)
+        if (kt + 2 < nk) fetch(kbeg + (kt + 2) * BK);
+        const bf16_t* hi = sT + (size_t)(kt & 1) * 2 * PLANE;
+        const bf16_t* lo = hi + PLANE;
+        bf16x8_t bh[4], bl[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int o = (BM_ + wn * 64 + j * 16 + fr) * LS + fk;
+            bh[j] = *(const bf16x8_t*)&hi[o];
+            bl[j] = *(const bf16x8_t*)&lo[o];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = (wm * 64 + i * 16 + fr) * LS + fk;
+            const bf16x8_t ah = *(const bf16x8_t*)&hi[o], al = *(const bf16x8_t*)&lo[o];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (p.epi_fast && gemm_epilogue_dispatch<BM_, false>(p, acc, sDot, sT, M, N, ldc, m0, n0, (int)(x3_lds_bytes<WM>() - 2 * BM_ * sizeof(float)))) return;
+    gemm_epilogue<BM_>(p, acc, sDot, sT, M, N, ldc, a_row0, w_row0, c_off, m0, n0);
+}
+
+static int g_x3_wm = 2;      // tile height of the split-bf16 kernel in units of 64 rows (2: two 4-wave work-groups per CU, 4: one 8-wave)
+extern "C" void fabind_gemm_set_x3_tile(int wm) { g_x3_wm = (wm == 4) ? 4 : 2; }
+
+template <int WM, int MINW>
+static int launch_x3(const FabindGemmArgs& p, int maxM, int maxN, hipStream_t stream) {
+    constexpr int BM_ = WM * 64;
+    const size_t lds = x3_lds_bytes<WM>();
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<WM, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((maxN + BN - 1) / BN, (maxM + BM_ - 1) / BM_, p.groups ? p.n_groups : 1);
+    if (!p.groups) grid = dim3(grid.x * grid.y, p.k_splits > 1 ? p.k_splits : 1, 1);
+    hipLaunchKernelGGL((gemm_x3_kernel<WM, MINW>), grid, dim3(WM * 128), lds, stream, p);
+    return 0;
+}
+
 extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     FabindGemmArgs p = *args;
     FB_REQUIRE(p.groups_ext || p.K % 8 == 0, "fabind_gemm: K must be a multiple of 8");
@@ -1243,7 +1434,12 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
                    "fabind_gemm: split-K needs a plain fp32 epilogue");
         FB_REQUIRE(p.K % 64 == 0, "fabind_gemm: split-K needs K % 64 == 0");
     }
-    if (p.w_dtype == FB_DT_F32) {
+    if (p.w_dtype == FB_DT_F32 && p.split3) {
+        FB_REQUIRE(p.a_dtype == FB_DT_F32, "fabind_gemm: the split-bf16 contraction takes fp32 A and fp32 W");
+        FB_REQUIRE(((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) && (p.A2 == nullptr || ((uintptr_t)p.A2 % 16 == 0 && p.lda2 % 4 == 0)),
+                   "fabind_gemm: split-bf16 operands must be 16-byte aligned");
+        if (g_x3_wm == 4) launch_x3<4, 2>(p, maxM, maxN, stream); else launch_x3<2, 2>(p, maxM, maxN, stream);
+    } else if (p.w_dtype == FB_DT_F32) {
         FB_REQUIRE(p.a_dtype == FB_DT_F32, "fabind_gemm: fp32 MMA needs fp32 A");
         hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, stream, p);
     } else if (p.a_dtype == FB_DT_F32) {

@@ -26,7 +26,7 @@ import torch
 from . import kernels as K
 from . import ops
 
-from .config import get_precision, set_precision  # noqa: F401
+from .config import fp32_storage, get_precision, set_precision  # noqa: F401
 from .param_pack import EagerPack, ParamPack
 
 
@@ -35,7 +35,7 @@ DEBUG_CAPTURE = None  # set to a dict to record per-layer outputs of the LAST eg
 
 
 def _wd():
-    return torch.float32 if get_precision() == "fp32" else torch.bfloat16
+    return torch.float32 if fp32_storage() else torch.bfloat16
 
 
 # ------------------------------------------------------------------------------------------------

@@ -28,6 +28,11 @@ def _profiled(label, flops, fn):
     return r
 
 
+def _split3():
+    from .config import get_precision
+    return get_precision() == "bf16x3"
+
+
 def _ld(t):
     assert t.stride(-1) == 1 or t.shape[-1] == 1, "innermost dimension must be contiguous"
     return t.stride(0) if t.dim() == 2 else t.shape[-1]
@@ -80,7 +85,11 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     a.groups_ext = 1 if groups_ext else 0
     a.alpha = alpha
     a.p_drop, a.drop_seed = float(p_drop), int(seed) & 0xFFFFFFFF
-    label = "fabind_gemm <%s,%s> M=%d N=%d K=%d" % (str(A.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""), M, N, K)
+    # 'bf16x3' mode: fp32 x fp32 contractions run as split bf16 (three bf16 MFMAs per product term) instead of the exact fp32 MFMA
+    x3 = A.dtype == torch.float32 and W.dtype == torch.float32 and _split3()
+    a.split3 = 1 if x3 else 0
+    label = "fabind_gemm <%s,%s%s> M=%d N=%d K=%d" % (str(A.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""),
+                                                      ",x3" if x3 else "", M, N, K)
     _profiled(label, 2.0 * M * N * K, lambda: check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm"))
     return (out if want_out else None), dot_out
 

@@ -16,11 +16,11 @@ from ._lib import GemmArgs, check, dt_code, load, ptr, stream
 
 def act_dtype():
     """Storage type of the large edge-/pair-level intermediates."""
-    return torch.float32 if _cfg.get_precision() == "fp32" else torch.bfloat16
+    return torch.float32 if _cfg.fp32_storage() else torch.bfloat16
 
 
 def mm_dtype():
-    return torch.float32 if _cfg.get_precision() == "fp32" else torch.bfloat16
+    return torch.float32 if _cfg.fp32_storage() else torch.bfloat16
 
 
 def _needs_grad(*ts):

@@ -28,7 +28,7 @@ from ..engine import Graph, Layout, _cat, cached_pack
 
 
 def _wd():
-    return torch.float32 if get_precision() == "fp32" else torch.bfloat16
+    return torch.float32 if fp32_storage() else torch.bfloat16
 
 
 def _pad8(n):

@@ -45,7 +45,7 @@ const char* fabind_last_error(void);
  *     fabind_pair_hadamard_bwd_rows added (the pair-Hadamard adjoint over the inter graph without float atomics);
  *     fabind_layernorm_rows_bwd takes nblk (the caller sizes the partial buffers; the kernel strides rows over that grid).
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 11
+#define FABIND_ABI_VERSION 12
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -98,6 +98,10 @@ typedef struct FabindGemmArgs {
        epilogue writes C16[m, n] = bf16(C[m, n]) next to C, so the GEMMs that consume the result as an MFMA operand need no
        separate conversion pass over it */
     void* C16; int ldc16;
+    /* != 0 with fp32 A and fp32 W: the contraction runs as split bf16 ("bf16x3": every operand element x = hi + lo with
+       hi = bf16(x), lo = bf16(x - hi); three bf16 MFMAs per product term, fp32 accumulate; ~2^-17 relative operand error) instead
+       of the exact fp32 MFMA.  The reference contracts in fp32 (egnn.py:68-144, model_utils.py:83-131). */
+    int split3;
 } FabindGemmArgs;
 
 int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream);

@@ -35,7 +35,14 @@ def _model(n_iter, seed=0):
     return synthetic.condition_for_large_graphs(m)
 
 
+_ORACLE_FWD = {}
+
+
 def _oracle(m, inp, n_iter, grad=False):
+    """Forward-only results are kept per n_iter (same seeded model and input in every test of this file): the n_iter = 8 pass takes
+    the host about a minute and three tests compare against it."""
+    if not grad and n_iter in _ORACLE_FWD:
+        return _ORACLE_FWD[n_iter]
     torch.set_num_threads(min(torch.get_num_threads(), 32))          # the measured best on the GPU box's host (DESIGN section 5)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     Hin = inp["H"].clone()
@@ -48,6 +55,8 @@ def _oracle(m, inp, n_iter, grad=False):
         X, Hh = orc.stack_forward(sd, "", inp["X"].clone(), Hin, inp["batch_id"], inp["segment_id"], inp["mask"],
                                   inp["is_global"], inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"],
                                   L, n_iter)[:2]
+    if not grad:
+        _ORACLE_FWD[n_iter] = (X, Hh, sd, Hin)
     return X, Hh, sd, Hin
 
 
@@ -66,9 +75,10 @@ def one_complex():
     return synthetic.make_stack_batch([(NP, NL)], H, seed=7)         # snapped off the cut-offs (parity input)
 
 
-@pytest.mark.parametrize("n_iter", [1, 2])
+@pytest.mark.parametrize("n_iter", [1, 2, 8])
 def test_headline_shape_fp32_matches_oracle(one_complex, n_iter):
-    """(i) north_star gate at the headline shape: ligand RMSD < 1e-4 A, H to 1e-4 rel (fp32 mode)."""
+    """(i) north_star gate at the headline shape: ligand RMSD < 1e-4 A, H to 1e-4 rel (fp32 mode); n_iter = 8 is the production
+    refinement loop (test_fabind.py:182) -- VERDICT r2 item 1(iii)."""
     from fabind_amd import engine
     dev = torch.device("cuda:0")
     engine.set_precision("fp32")
@@ -87,10 +97,11 @@ def test_headline_shape_fp32_matches_oracle(one_complex, n_iter):
 
 # bf16 ligand-RMSD gap at this shape; the asserted bound is 2x the measurement: measured
 # 7.9e-5 .. 8.4e-5 A (n_iter = 1: inside the 1e-4 A gate) and 1.48e-4 .. 1.70e-4 A (n_iter = 2: outside) over the round's runs
-BF16_GAP_BOUND_A = {1: 1.7e-4, 2: 3.4e-4}
+# n_iter = 8 (the production loop; first measured in round 3): see DESIGN section 2
+BF16_GAP_BOUND_A = {1: 1.7e-4, 2: 3.4e-4, 8: 4e-3}
 
 
-@pytest.mark.parametrize("n_iter", [1, 2])
+@pytest.mark.parametrize("n_iter", [1, 2, 8])
 def test_headline_shape_bf16_gap_is_measured_and_bounded(one_complex, n_iter):
     """(ii) the bench dtype at the bench shape (K = 512 contractions): the gap to the fp32 oracle, printed and bounded."""
     from fabind_amd import engine
