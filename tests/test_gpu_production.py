@@ -37,9 +37,9 @@ def _threads():
 
 def _grad_rows(named_params, ref_grads):
     """[(error / tolerance scale, name, own max / largest max, l2-rel)] over EVERY parameter the oracle's autograd reaches.  The error
-    of a tensor is its largest entry error over (its own largest entry + 1e-4 x the model's largest gradient entry): the second term is
-    the fp32 round-off a tensor thousands of times smaller than the largest one inherits from shared upstream sums (the model's
-    gradients span 1e-7 .. 45 here).  A parameter the oracle gives no gradient (the 33 never-used tensors) must not get one."""
+    of a tensor is its largest entry error over (its own largest entry + 1e-6 x the model's largest gradient entry): the second term is
+    the fp32 round-off (8 eps) a tensor a million times smaller than the largest one inherits from shared upstream sums (the
+    model's gradient entries span 1e-7 .. 45 here).  A parameter the oracle gives no gradient (the 33 never-used tensors) must not get one."""
     gmax = max(float(v.abs().max()) for v in ref_grads.values() if v is not None)
     rows = []
     for n, p in named_params:
@@ -52,7 +52,7 @@ def _grad_rows(named_params, ref_grads):
             assert rmax <= 1e-6 * gmax, (n, rmax, gmax)
             continue
         d = p.grad.detach().cpu() - r
-        rows.append((float(d.abs().max()) / (rmax + 1e-4 * gmax), n, rmax / gmax, float(d.norm() / max(float(r.norm()), 1e-30))))
+        rows.append((float(d.abs().max()) / (rmax + 1e-6 * gmax), n, rmax / gmax, float(d.norm() / max(float(r.norm()), 1e-30))))
     rows.sort(reverse=True)
     return rows
 
