@@ -53,6 +53,7 @@ SIGNATURES = {
     "fabind_edge_geom": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "fabind_gcl_pre": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "fabind_gcl_edge_fused": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp, _vp],
+    "fabind_gcl_edge_fused_x3": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp],
     "fabind_gcl_edge_fused_bwd": [ctypes.POINTER(EdgeBwdArgs), _i, _i, _vp],
     "fabind_pair_update_fused": [ctypes.POINTER(PairUpdateArgs), _i, _vp],
     "fabind_gemm_set_x3_tile": [_i],

@@ -187,6 +187,77 @@ __device__ __forceinline__ void fe_gemm_rot(const bf16_t* sX, const bf16_t* __re
     fe_gemm_rot_pf<H, MI, SWAP, SWZ>(sX, Wp, wave, lane, acc, b0);
 }
 
+// Split-bf16 ("bf16x3") form of the operand-swapped tile contraction: the activation tile exists as two swizzled bf16 LDS planes
+// (hi = bf16(x), lo = bf16(x - hi)), the packed weight as two fragment arrays (hi | lo); a product term is three MFMAs
+// lo*hi + hi*lo + hi*hi with fp32 accumulation -- fp32-grade results at 3/16 of the exact-fp32 matrix time (the
+// reference contracts in fp32, egnn.py:68-144).  Same rolled two-k-steps-per-trip structure and unconditional next-trip loads as
+// fe_gemm_rolled_pf; 96 MFMAs per trip and wave at MI = 4.
+template <int H, int MI, int SWZ>
+__device__ __forceinline__ void fe_gemm_x3(const bf16_t* sXh, const bf16_t* sXl, const bf16_t* __restrict__ Wph,
+                                           const bf16_t* __restrict__ Wpl, int wave, int lane, f32x4_t (&acc)[MI][4]) {
+    constexpr int NKS = H / 32;
+    constexpr int NG = H / 16;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16x8_t* wh = (const bf16x8_t*)Wph + ((size_t)wave * 4) * 64 + lane;
+    const bf16x8_t* wl = (const bf16x8_t*)Wpl + ((size_t)wave * 4) * 64 + lane;
+    bf16x8_t h0[4], l0[4], h1[4], l1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h0[j] = wh[(size_t)j * 64]; l0[j] = wl[(size_t)j * 64]; }
+#pragma unroll 1
+    for (int ks = 0; ks < NKS; ks += 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { h1[j] = wh[((size_t)(ks + 1) * NG + j) * 64]; l1[j] = wl[((size_t)(ks + 1) * NG + j) * 64]; }
+        bf16x8_t ah[MI], al[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = i * 16 + fr;
+            const int o = r * H + (((ks * 4 + fq) ^ (r & SWZ)) * 8);
+            ah[i] = *(const bf16x8_t*)&sXh[o];
+            al[i] = *(const bf16x8_t*)&sXl[o];
+        }
+        FE_PRIO(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l0[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h0[j], ah[i], acc[i][j], 0, 0, 0);
+        }
+        FE_PRIO(0);
+        {
+            const int kn = min(ks + 2, NKS - 2);                  // unconditional: see fe_gemm_rolled_pf
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h0[j] = wh[((size_t)kn * NG + j) * 64]; l0[j] = wl[((size_t)kn * NG + j) * 64]; }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int r = i * 16 + fr;
+            const int o = r * H + ((((ks + 1) * 4 + fq) ^ (r & SWZ)) * 8);
+            ah[i] = *(const bf16x8_t*)&sXh[o];
+            al[i] = *(const bf16x8_t*)&sXl[o];
+        }
+        FE_PRIO(1);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l1[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h1[j], ah[i], acc[i][j], 0, 0, 0);
+        }
+        FE_PRIO(0);
+    }
+}
+
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi), for a pair of values: -> (packed hi pair, packed lo pair)
+__device__ __forceinline__ void fe_split2(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    hi = pack2_bf16(x0, x1);
+    lo = pack2_bf16(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+}
+
 template <int H>
 __device__ __forceinline__ void fe_tile_store(const bf16_t* sB, bf16_t* __restrict__ g, int e0, int ne, int tid) {
     constexpr int CH = H / 8;
@@ -286,7 +357,7 @@ __device__ __forceinline__ float fe_scan_rows(const bf16_t* sX, const int* sRow,
 template <int H, bool WITH_RH, int SWZ>
 __device__ __forceinline__ float fe_scan_runs64(const bf16_t* sX, const int* sRow, const float* sRh, int ne, bool head_cont,
                                                 bool tail_cont, float* out, unsigned ld, float* bnd_tile, int c,
-                                                bf16_t* out16 = nullptr, unsigned ld16 = 0) {
+                                                bf16_t* out16 = nullptr, unsigned ld16 = 0, const bf16_t* sXlo = nullptr) {
     const int lane = threadIdx.x & 63;
     const int mine = sRow[lane], prev = sRow[max(lane - 1, 0)];
     const float rhl = WITH_RH ? sRh[lane] : 0.f;
@@ -295,6 +366,10 @@ __device__ __forceinline__ float fe_scan_runs64(const bf16_t* sX, const int* sRo
     float v[64];
 #pragma unroll
     for (int rw = 0; rw < 64; ++rw) v[rw] = bf16_to_f32(sX[rw * H + ((c8 ^ (rw & SWZ)) * 8) + c7]);
+    if (sXlo) {                                                     // split-bf16 tile: the value is hi + lo
+#pragma unroll
+        for (int rw = 0; rw < 64; ++rw) v[rw] += bf16_to_f32(sXlo[rw * H + ((c8 ^ (rw & SWZ)) * 8) + c7]);
+    }
     float run = 0.f, pwr = 0.f;
     int rs = 0;                                                     // first row of the current run (wave-uniform)
     auto flush = [&](bool last) {
@@ -349,6 +424,11 @@ struct FabindEdgeBwdArgs;
 int fe_bwd2_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipStream_t stream);
 // fused_edge_bwd3.hip: the same with a store wave (variants 5 and 6)
 int fe_bwd3_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipStream_t stream);
+// fused_edge_fwd3.hip: the split-bf16 forward (fabind_gcl_edge_fused_x3: fp32 AB rows, hi | lo packed weights)
+int fe_fwd3_launch(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat, const float* w_r,
+                   const void* W2ph, const void* W2pl, const float* b2, const void* Wcph, const void* Wcpl, const float* bc,
+                   const float* w3, int E, float* agg, float* s_out, uint32_t thr16, float dscale, unsigned seed, float* bnd,
+                   int xcd_aware, hipStream_t stream);
 // fused_edge_fwd2.hip: the row-wise / operand-swapped forward (variant 1 of fabind_gcl_edge_fused)
 int fe_fwd2_launch(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat, const float* w_r,
                    const void* W2p, const float* b2, const void* Wcp, const float* bc, const float* w3, int E, float* agg,

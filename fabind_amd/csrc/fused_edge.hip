@@ -193,6 +193,26 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
     return 0;
 }
 
+extern "C" int fabind_gcl_edge_fused_x3(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
+                                        const float* w_r, const void* W2ph, const void* W2pl, const float* b2, const void* Wcph,
+                                        const void* Wcpl, const float* bc, const float* w3, int E, float* agg, float* s_out,
+                                        float p_drop, unsigned seed, float* bnd, hipStream_t stream) {
+    if (E <= 0) return 0;
+    FB_REQUIRE(bnd != nullptr, "fabind_gcl_edge_fused_x3: bnd (ceil(E/64) x 2 x H floats of scratch) is required");
+    FB_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "fabind_gcl_edge_fused_x3: p_drop in [0, 1)");
+    FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_gcl_edge_fused_x3: H must be 64, 128, 256 or 512");
+    FB_REQUIRE(ldab % 4 == 0 && ((uintptr_t)AB & 15) == 0, "fabind_gcl_edge_fused_x3: AB must be 16-byte aligned with ldab % 4 == 0");
+    const uint32_t thr16 = (uint32_t)(p_drop * 65536.0f + 0.5f);
+    const float dscale = 1.0f / (1.0f - (float)thr16 / 65536.0f);
+    const int rc = fe_fwd3_launch(AB, ldab, H, row, col, rhohat, w_r, W2ph, W2pl, b2, Wcph, Wcpl, bc, w3, E, agg, s_out, thr16, dscale,
+                                  seed, bnd, g_fe_xcd_aware, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL((fe_boundary_fix_kernel<FE_BM>), dim3((E + FE_BM - 1) / FE_BM), dim3(H < 256 ? H : 256), 0, stream, row, E, H,
+                       bnd, agg, (unsigned)H, (bf16_t*)nullptr, 0u);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
 // =====================================================================================================
 // Backward of the same pipeline (training, bf16): nothing per-edge was saved by the forward kernel.
 // Per 64-edge tile the work-group recomputes S1, pre2, M, pre3 and chains the four H x H contractions

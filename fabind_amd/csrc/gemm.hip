@@ -382,6 +382,66 @@ __device__ __forceinline__ void gemm_epilogue_f32(const FabindGemmArgs& p, f32x4
     }
 }
 
+// fp32 outputs WITH an activation (value + optionally the stored derivative as a second fp32 tile) or with the activation adjoint
+// of an MLP (C = acc * act'(aux), aux an fp32 [M, N] tile): the epilogues the fp32-storage modes ('fp32', 'bf16x3') run on every
+// hidden layer -- same wave-private slab transpose and 256-byte row segments as gemm_epilogue_f32 (the generic epilogue stores
+// 4-byte elements, 64-byte pieces of four rows per instruction).  AUXD: 0 none, 1 relu'(aux) = [aux > 0], 2 aux holds act' itself.
+// Returns false when the shape / alignment does not allow 16-byte accesses (the caller falls back to the generic epilogue).
+template <int BM_, int ACT, bool HAS_C2, int AUXD>
+__device__ __forceinline__ bool gemm_epilogue_f32x(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sStage, int stage_bytes,
+                                                   int M, int N, int ldc, int m0, int n0) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, cq = lane >> 4;
+    float* C = (float*)p.C;
+    float* C2 = (float*)p.C2;
+    const float* AX = (const float*)p.aux;
+    const bool vec = (ldc % 4 == 0) && (N % 4 == 0) && (((uintptr_t)C & 15) == 0) && (!HAS_C2 || (((uintptr_t)C2 & 15) == 0)) &&
+                     (AUXD == 0 || ((p.ldaux % 4 == 0) && (((uintptr_t)AX & 15) == 0))) &&
+                     stage_bytes >= (int)(blockDim.x / 64) * 32 * F32_SLAB_LD * 4;
+    if (!vec) return false;
+    float* my = sStage + (size_t)wave * (32 * F32_SLAB_LD);
+    float bv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + fr;
+        bv[j] = (p.bias && col < N) ? p.bias[col] : 0.f;
+    }
+    const int rr = lane >> 4, c4 = (lane & 15) * 4;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    my[(ii * 16 + cq * 4 + r) * F32_SLAB_LD + j * 16 + fr] = acc[half * 2 + ii][j][r] + bv[j];
+        const int col = n0 + wn * 64 + c4;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int rl = k * 4 + rr;
+            const int row = m0 + wm * 64 + half * 32 + rl;
+            const float4 v = *(const float4*)&my[rl * F32_SLAB_LD + c4];
+            if (row < M && col < N) {
+                float o[4] = {v.x, v.y, v.z, v.w};
+                if (AUXD != 0) {
+                    const float4 a = *(const float4*)&AX[(size_t)row * p.ldaux + col];
+                    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] *= (AUXD == 1) ? (av[e] > 0.f ? 1.f : 0.f) : av[e];
+                }
+                if (HAS_C2) {
+                    *(float4*)&C2[(size_t)row * ldc + col] = make_float4(fast_dact<ACT>(o[0]), fast_dact<ACT>(o[1]), fast_dact<ACT>(o[2]),
+                                                                         fast_dact<ACT>(o[3]));
+                }
+                *(float4*)&C[(size_t)row * ldc + col] = make_float4(fast_act<ACT>(o[0]), fast_act<ACT>(o[1]), fast_act<ACT>(o[2]),
+                                                                    fast_act<ACT>(o[3]));
+            }
+        }
+    }
+    return true;
+}
+
 // returns true when the fast epilogue applies (decided per launch on the host -> p.epi_fast)
 template <int BM_, bool RAW_BARRIER>
 __device__ __forceinline__ bool gemm_epilogue_dispatch(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sDot, bf16_t* sOut,
@@ -400,6 +460,12 @@ __device__ __forceinline__ bool gemm_epilogue_dispatch(const FabindGemmArgs& p, 
         case 12: gemm_epilogue_fast<BM_, FB_ACT_RELU, true, false, false, RAW_BARRIER, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 13: gemm_epilogue_fast<BM_, FB_ACT_RELU, false, false, true, RAW_BARRIER, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 14: gemm_epilogue_fast<BM_, FB_ACT_NONE, true, false, false, RAW_BARRIER, false, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
+        case 20: return gemm_epilogue_f32x<BM_, FB_ACT_NONE, false, 1>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0);
+        case 21: return gemm_epilogue_f32x<BM_, FB_ACT_NONE, false, 2>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0);
+        case 22: return gemm_epilogue_f32x<BM_, FB_ACT_SILU, true, 0>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0);
+        case 23: return gemm_epilogue_f32x<BM_, FB_ACT_SILU, false, 0>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0);
+        case 24: return gemm_epilogue_f32x<BM_, FB_ACT_RELU, false, 0>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0);
+        case 25: return gemm_epilogue_f32x<BM_, FB_ACT_RELU, true, 0>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0);
         case 9: gemm_epilogue_f32<BM_, false>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0); return true;
         case 10: gemm_epilogue_f32<BM_, true>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0); return true;
         default: return false;
@@ -1270,23 +1336,19 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // Staging: a thread owns NA + NB chunks of 8 consecutive k (two 16-byte loads each) per k-tile.  TWO register sets alternate, so
+    // a tile's loads are requested two k-steps before its split -- one k-step (~0.3 us of MFMA work) is less than an HBM round trip,
+    // and with one or two 4- / 8-wave work-groups per CU nothing else covers it.
     const int lr = tid >> 2, lc = (tid & 3) * 8;                 // this thread's row (+ NT/4 per chunk) and k offset in a k-tile
-    Vec8 ra[NA], rb[NB];
-    auto fetch = [&](int k0) {
+    const bool pro = p.act_pro != FB_ACT_NONE;
+    auto fetch = [&](Vec8 (&ra)[NA], Vec8 (&rb)[NB], int k0) {
         const int gk = k0 + lc;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int gm = m0 + lr + (NT / 4) * i;
 #pragma unroll
             for (int q = 0; q < 8; ++q) ra[i].v[q] = 0.f;
-            if (gm < M && gk < K) {
-                const float* src = (gk < K1) ? A + (size_t)gm * lda_g + gk : A2 + (size_t)gm * p.lda2 + (gk - K1);
-                ra[i] = load8<float>(src);
-                if (p.act_pro != FB_ACT_NONE) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) ra[i].v[q] = apply_act(ra[i].v[q], p.act_pro);
-                }
-            }
+            if (gm < M && gk < K) ra[i] = load8<float>((gk < K1) ? A + (size_t)gm * lda_g + gk : A2 + (size_t)gm * p.lda2 + (gk - K1));
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -1296,11 +1358,15 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
             if (gn < N && gk < K) rb[i] = load8<float>(W + (size_t)gn * p.ldw + gk);
         }
     };
-    auto split_store = [&](int st) {
+    auto split_store = [&](Vec8 (&ra)[NA], Vec8 (&rb)[NB], int st) {
         bf16_t* hi = sT + (size_t)st * 2 * PLANE;
         bf16_t* lo = hi + PLANE;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
+            if (pro) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ra[i].v[q] = apply_act(ra[i].v[q], p.act_pro);
+            }
             uint4 h, l;
             x3_split8(ra[i], h, l);
             const int o = (lr + (NT / 4) * i) * LS + lc;
@@ -1316,19 +1382,9 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
             *(uint4*)&lo[o] = l;
         }
     };
-
-    const int nk = (K - kbeg + BK - 1) / BK;
     const int fr = lane & 15, fk = (lane >> 4) * 8;
-    if (nk > 0) {
-        fetch(kbeg);
-        split_store(0);
-        if (nk > 1) fetch(kbeg + BK);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) split_store((kt + 1) & 1);             // (stage (kt+1)&1 was last read in step kt-1, before its barrier)
-        if (kt + 2 < nk) fetch(kbeg + (kt + 2) * BK);
-        const bf16_t* hi = sT + (size_t)(kt & 1) * 2 * PLANE;
+    auto compute = [&](int st) {
+        const bf16_t* hi = sT + (size_t)st * 2 * PLANE;
         const bf16_t* lo = hi + PLANE;
         bf16x8_t bh[4], bl[4];
 #pragma unroll
@@ -1348,7 +1404,29 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j], acc[i][j], 0, 0, 0);
         }
+    };
+
+    const int nk = (K - kbeg + BK - 1) / BK;
+    Vec8 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+    // invariant at the top of step kt (even): stage kt & 1 holds tile kt; set 1 holds tile kt+1 (in flight), set 0 tile kt+2 (just requested)
+    if (nk > 0) {
+        fetch(ra0, rb0, kbeg);
+        if (nk > 1) fetch(ra1, rb1, kbeg + BK);
+        split_store(ra0, rb0, 0);
+        if (nk > 2) fetch(ra0, rb0, kbeg + 2 * BK);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {
+        if (kt + 1 < nk) split_store(ra1, rb1, 1);               // (stage 1 was last read in step kt-1, before its barrier)
+        if (kt + 3 < nk) fetch(ra1, rb1, kbeg + (kt + 3) * BK);
+        compute(0);
         __syncthreads();
+        if (kt + 1 < nk) {
+            if (kt + 2 < nk) split_store(ra0, rb0, 0);
+            if (kt + 4 < nk) fetch(ra0, rb0, kbeg + (kt + 4) * BK);
+            compute(1);
+            __syncthreads();
+        }
     }
     if (p.epi_fast && gemm_epilogue_dispatch<BM_, false>(p, acc, sDot, sT, M, N, ldc, m0, n0, (int)(x3_lds_bytes<WM>() - 2 * BM_ * sizeof(float)))) return;
     gemm_epilogue<BM_>(p, acc, sDot, sT, M, N, ldc, a_row0, w_row0, c_off, m0, n0);
@@ -1414,6 +1492,14 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
         else if (p.act_epi == FB_ACT_RELU && !hc && !hc2 && hd) p.epi_fast = 6;
         else if (p.act_epi == FB_ACT_SILU && hc && !hc2 && hd && pre) p.epi_fast = 7;
         else if (p.act_epi == FB_ACT_RELU && hc && !hc2 && hd && pre) p.epi_fast = 8;
+    }
+    if (p.epi_fast == 0 && !drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.accumulate && !p.r_index && !p.R && p.C != nullptr &&
+        p.c_dtype == FB_DT_F32 && !p.dotvec && !p.store_preact && !p.C16 && !foldq) {
+        /* fp32 C with an activation (+ stored derivative) or with the activation adjoint through an fp32 aux tile */
+        if (p.aux && p.aux_dtype == FB_DT_F32 && p.act_epi == FB_ACT_NONE && !p.C2 && (p.dact_epi == FB_ACT_RELU || p.dact_epi == FB_ACT_STORED_DERIV))
+            p.epi_fast = p.dact_epi == FB_ACT_RELU ? 20 : 21;
+        else if (!p.aux && p.act_epi == FB_ACT_SILU) p.epi_fast = p.C2 ? 22 : 23;
+        else if (!p.aux && p.act_epi == FB_ACT_RELU) p.epi_fast = p.C2 ? 25 : 24;
     }
     if (foldq) {
         FB_REQUIRE((p.epi_fast == 5 || p.epi_fast == 6) && p.C2 == nullptr && p.a_dtype == FB_DT_BF16 && p.w_dtype == FB_DT_BF16 &&

@@ -385,11 +385,11 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
     if pdrop == 0.0:                # (train mode adds torch-side dropout consumers that do not know the shared buffer)
         h = ops.shared_grad(h)      # three consumers (first edge Linear, node MLP, residual): one gradient buffer, no autograd adds
     hin = _b16(h) if fast else h
-    if get_precision() == "bf16" and FUSED_EDGE and H in (64, 128, 256, 512):
+    if get_precision() in ("bf16", "bf16x3") and FUSED_EDGE and H in (64, 128, 256, 512):
         # the whole edge pipeline in one kernel each way, edge tensors stay in LDS (csrc/fused_edge.hip); under
         # autograd nothing per-edge is saved, the backward kernel recomputes tile by tile.  Train-mode dropout on the
         # messages is a counter-based mask evaluated inside both kernels.
-        AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=torch.bfloat16)
+        AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=ad)          # bf16 rows, or fp32 rows for the split-bf16 kernel
         d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay, g.ctx_by_col)
         agg, s = ops.fused_edge(AB, rhohat, p["w_r"], p["W2"], p["b2"], p["Wc"], p["bc"], p["w3"], H, g, pdrop)
         x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)

@@ -41,11 +41,13 @@ def _ld(t):
 def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=None, r_index=None,
          out=None, out_dtype=torch.float32, want_out=True, dotvec=None, aux=None, dact=ACT_NONE, alpha=1.0,
          accumulate=False, groups=None, n_groups=0, max_m=0, max_n=0, M=None, N=None, ldc=None, k_splits=1,
-         out2=None, groups_ext=False, p_drop=0.0, seed=0, out16=None):
+         out2=None, groups_ext=False, p_drop=0.0, seed=0, out16=None, flops=None):
     """C = epi(pro([A|A2]) @ W^T); see FabindGemmArgs.  Returns (C or None, dot_partials or None).  out16: bf16 tensor that
     receives a copy of an fp32 C (plain bias / residual epilogues only).
 
-    `groups` (int32 [G,8] device tensor) selects the ragged-batched mode; then `out` must be given."""
+    `groups` (int32 [G,8] device tensor) selects the ragged-batched mode; then `out` must be given.
+    flops: executed multiply-add flops of a ragged launch (bench.py's live roofline accounting; default 2 M N K, which for a
+    grouped launch is the padded bounding box, not the work)."""
     lib = _lib.load()
     a = GemmArgs()
     K1 = A.shape[1]
@@ -90,7 +92,10 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     a.split3 = 1 if x3 else 0
     label = "fabind_gemm <%s,%s%s> M=%d N=%d K=%d" % (str(A.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""),
                                                       ",x3" if x3 else "", M, N, K)
-    _profiled(label, 2.0 * M * N * K, lambda: check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm"))
+    if groups is not None:
+        label += " (ragged, %d groups)" % n_groups
+    _profiled(label, 2.0 * M * N * K if flops is None else float(flops),
+              lambda: check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm"))
     return (out if want_out else None), dot_out
 
 
@@ -296,6 +301,35 @@ def pack_frag(W):
     """[N,K] weight -> bf16 MFMA-fragment order [K/32][N/16][4][16][8] (one contiguous 1 KiB block per wave load)."""
     N, Kd = W.shape
     return W.to(torch.bfloat16).view(N // 16, 16, Kd // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
+
+
+def pack_frag_split(W):
+    """fp32 [N,K] weight -> (hi, lo) bf16 fragment packs of the split-bf16 kernels: hi = bf16(W), lo = bf16(W - hi)."""
+    hi = W.to(torch.bfloat16)
+    lo = (W.float() - hi.float()).to(torch.bfloat16)
+    return pack_frag(hi), pack_frag(lo)
+
+
+def gcl_edge_fused_x3(AB, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, n_rows, p_drop=0.0, seed=0, rowptr=None):
+    """The fused forward edge pipeline in split-bf16 arithmetic (csrc/fused_edge_fwd3.hip): AB fp32 [N, 2H], fp32 weights (split into
+    hi | lo fragment packs here) -> (agg [N,H] fp32, s [E,1] fp32).  rowptr: see gcl_edge_fused."""
+    E = row.shape[0]
+    assert AB.dtype == torch.float32 and AB.stride(1) == 1
+    alloc = torch.zeros if (rowptr is None or E == 0) else torch.empty
+    agg = alloc((n_rows, H), dtype=torch.float32, device=AB.device)
+    if alloc is torch.empty:
+        zero_empty_rows(rowptr, agg, H)
+    s = torch.empty((max(E, 1), 1), dtype=torch.float32, device=AB.device)
+    bnd = torch.empty(((E + 63) // 64 * 2 + 2, H), dtype=torch.float32, device=AB.device)
+    W2h, W2l = pack_frag_split(W2)
+    Wch, Wcl = pack_frag_split(Wc)
+    _profiled("gcl_edge_fused_x3_kernel<%d> E=%d (gather + 2 chained H x H split-bf16 contractions + segment-sum per edge)" % (H, E),
+              4.0 * E * H * H,
+              lambda: check(_lib.load().fabind_gcl_edge_fused_x3(ptr(AB), _ld(AB), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
+                                                                 ptr(W2h), ptr(W2l), ptr(b2), ptr(Wch), ptr(Wcl), ptr(bc), ptr(w3), E,
+                                                                 ptr(agg), ptr(s), float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd),
+                                                                 stream()), "fabind_gcl_edge_fused_x3"))
+    return agg, s[:E]
 
 
 def zero_empty_rows(rowptr, out, C, out2=None):

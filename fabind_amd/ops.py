@@ -79,7 +79,30 @@ def _weight_grad(dpre, x, act_pro, x2=None, out_dtype=torch.float32, want_db=Fal
     return _weight_grad_f32(dpre, x, act_pro, x2, out_dtype), K.colsum(dpre)
 
 
+X3_WGRAD_BF16 = os.environ.get("FABIND_X3_WGRAD", "bf16") == "bf16"
+X3_PAIRBIAS_BWD_BF16 = os.environ.get("FABIND_X3_PAIRBIAS_BWD", "bf16") == "bf16"
+
+
+def _x3_tn_ok(dpre, x, x2):
+    """'bf16x3' mode: the weight-gradient contraction dW = dpre^T x runs on bf16 ROUNDINGS of its two fp32 operands through the
+    TN kernel (fp32 accumulation over the rows; no transposed copies).  Every weight-gradient entry is a sum over 1e5 .. 1e6 rows
+    with heavy cancellation, so single-bf16 operands cost ~2e-3 of the entry -- the level at which this mode's gradients differ
+    from exact fp32 anyway (a ReLU unit whose pre-activation sits within the 2^-17 forward error of zero flips its derivative;
+    tests/test_gpu_headline.py prints both) -- against explicit transposes + three-MFMA contractions at 4x the time.  The forward
+    pass and the activation-gradient chain stay split-bf16.  FABIND_X3_WGRAD=x3 restores the split contraction."""
+    f32 = torch.float32
+    return (X3_WGRAD_BF16 and _cfg.get_precision() == "bf16x3" and dpre.dtype == f32 and x.dtype == f32 and (x2 is None or x2.dtype == f32)
+            and dpre.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and (x2 is None or x2.shape[1] % 8 == 0) and dpre.shape[0] >= 256)
+
+
 def _weight_grad_f32(dpre, x, act_pro, x2, out_dtype):
+    if act_pro == K.ACT_NONE and _x3_tn_ok(dpre, x, x2):
+        bf = torch.bfloat16
+        d16 = dpre.to(bf)
+        parts = [K.gemm_tn(d16, x.to(bf), out_dtype=out_dtype)]
+        if x2 is not None:
+            parts.append(K.gemm_tn(d16, x2.to(bf), out_dtype=out_dtype))
+        return parts[0] if x2 is None else torch.cat(parts, 1)
     if act_pro == K.ACT_NONE and _tn_ok(dpre, x, x2):
         if x2 is None:
             return K.gemm_tn(dpre, x, out_dtype=out_dtype)
@@ -370,7 +393,10 @@ def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store, p_drop=0.0, seed=0, fold=N
     if fold is not None:
         a.store_preact = 0
         a.row_mu, a.row_rs, a.col_c = ptr(fold[0]), ptr(fold[1]), ptr(fold[2])
-    label = "fabind_gemm <%s,%s> M=%d N=%d K=%d" % (str(x.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""), M, N, Kd)
+    x3 = x.dtype == torch.float32 and W.dtype == torch.float32 and _cfg.get_precision() == "bf16x3"
+    a.split3 = 1 if x3 else 0
+    label = "fabind_gemm <%s,%s%s> M=%d N=%d K=%d" % (str(x.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""),
+                                                      ",x3" if x3 else "", M, N, Kd)
     K._profiled(label, 2.0 * M * N * Kd, lambda: check(load().fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm(rowdot)"))
     return z, part
 
@@ -484,10 +510,42 @@ class _FusedEdge(torch.autograd.Function):
         return (dAB.to(AB16.dtype), drh, dwr, dW2.to(W2.dtype), db2, dWc.to(Wc.dtype), dbc, dw3, None, None, None, None, None)
 
 
+class _FusedEdgeX3(torch.autograd.Function):
+    """The same pipeline in the split-bf16 mode: forward = csrc/fused_edge_fwd3.hip (fp32 AB rows, three bf16 MFMAs per product
+    term: the quantities the 1e-4 A gate is stated on); backward = the bf16 recompute kernel on bf16 copies of AB and the weights --
+    the gradients of this block carry bf16 operand rounding (like 'bf16' mode), everything upstream / downstream of it stays fp32."""
+
+    @staticmethod
+    def forward(ctx, AB, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed):
+        ctx.H, ctx.g, ctx.p_drop, ctx.seed = H, g, p_drop, seed
+        ctx.save_for_backward(AB, rhohat, w_r, W2, b2, Wc, bc, w3)
+        return K.gcl_edge_fused_x3(AB, H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, AB.shape[0], p_drop, seed,
+                                   rowptr=g.rp_ctx)
+
+    @staticmethod
+    def backward(ctx, dagg, ds):
+        AB, rhohat, w_r, W2, b2, Wc, bc, w3 = ctx.saved_tensors
+        g = ctx.g
+        colptr, perm = g.ctx_by_col()
+        if dagg is None:
+            dagg = torch.zeros((AB.shape[0], ctx.H), dtype=torch.float32, device=AB.device)
+        if ds is None:
+            ds = torch.zeros(g.row_ctx.shape[0], dtype=torch.float32, device=AB.device)
+        dAB, drh, dwr, dW2, db2, dWc, dbc, dw3 = K.gcl_edge_fused_bwd(
+            AB.to(torch.bfloat16), ctx.H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, ds.reshape(-1).float(), dagg.float(),
+            colptr, perm, ctx.p_drop, ctx.seed, dab_bf16=False, w_dtype=torch.float32, rowptr=g.rp_ctx)
+        return (dAB, drh, dwr, dW2, db2, dWc, dbc, dw3, None, None, None, None)
+
+
 def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop=0.0):
-    """(agg [N,H], s [E,1]) of the fused bf16 edge pipeline; differentiable.  p_drop > 0: dropout on the messages
-    (egnn.py:82) from a counter-based mask keyed by a seed drawn from torch's CPU generator (no device sync)."""
+    """(agg [N,H], s [E,1]) of the fused edge pipeline (bf16, or split bf16 on fp32 AB in 'bf16x3' mode); differentiable.  p_drop > 0:
+    dropout on the messages (egnn.py:82) from a counter-based mask keyed by a seed drawn from torch's CPU generator (no device sync)."""
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
+    if _cfg.get_precision() == "bf16x3":
+        if _needs_grad(AB16, rhohat, w_r, W2, b2, Wc, bc, w3):
+            return _FusedEdgeX3.apply(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed)
+        return K.gcl_edge_fused_x3(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, AB16.shape[0], p_drop, seed,
+                                   rowptr=g.rp_ctx)
     w16 = _cfg.get_precision() == "bf16"
     if _needs_grad(AB16, rhohat, w_r, W2, b2, Wc, bc, w3):
         holder = [] if w16 else None
@@ -1090,7 +1148,7 @@ def _pair_bias_fwd(a0b0, H, wcomp, bconst, lay):
         bmat = K.pair_bmat(a0b0[:, H:], wcomp[k], lay.c_index, mm_dtype())       # [(sumC*NO), H]
         out = torch.empty((lay.n_pairs, NO), dtype=torch.float32, device=a0b0.device)
         K.gemm(a0, bmat, bias=bconst[k].repeat(lay.sumC), out=out, groups=lay.pb_groups, n_groups=lay.B,
-               max_m=lay.max_P, max_n=lay.pb_max_n, M=lay.N, N=bmat.shape[0], ldc=NO)
+               max_m=lay.max_P, max_n=lay.pb_max_n, M=lay.N, N=bmat.shape[0], ldc=NO, flops=2.0 * lay.n_pairs * NO * H)
         outs.append(out)
     return outs
 
@@ -1137,7 +1195,10 @@ class _PairBias(torch.autograd.Function):
         da0b0, da0b0_ret = _sink_zeros(a0b0, ctx.sink)    # every writer below accumulates (+=, accumulating GEMM, atomics)
         dwcomp = torch.zeros_like(wcomp)
         dbconst = torch.zeros((nblk, NO), dtype=torch.float32, device=dev)
-        bf16 = _cfg.get_precision() == "bf16" and NO == 8 and H % 8 == 0 and nblk <= 16
+        # ('bf16x3': the adjoint of the pair-bias contraction takes the bf16 route too -- see _x3_tn_ok; FABIND_X3_PAIRBIAS_BWD=fp32
+        #  restores the fp32 atomics kernels, 30 ms per step at the headline shape)
+        mode = _cfg.get_precision()
+        bf16 = (mode == "bf16" or (mode == "bf16x3" and X3_PAIRBIAS_BWD_BF16)) and NO == 8 and H % 8 == 0 and nblk <= 16
         if bf16:
             # all blocks at once: the gradients of every block, bf16, concatenated along K and padded per complex (Acat) and
             # the matching b0 * wcomp operand (BTcat) -> d a0 is ONE plain-group GEMM on the pipelined kernel (one accumulating
@@ -1158,7 +1219,7 @@ class _PairBias(torch.autograd.Function):
                                               BTcat.stride(0), ptr(colpart), stream()), "fabind_pair_bias_cat")
             dbconst = K.colsum(colpart).reshape(nblk, NO)                                  # = column sums of every dout_k
             K.gemm(Acat, BTcat, out=da0b0, accumulate=True, groups=cat_g, n_groups=lay.B, max_m=lay.max_P, max_n=H,
-                   M=lay.sumP, N=lay.B * H, ldc=a0b0.stride(0))
+                   M=lay.sumP, N=lay.B * H, ldc=a0b0.stride(0), flops=2.0 * lay.n_pairs * NO * nblk * H)
             # the T_k = D_k^T a0 contractions on the pipelined NT kernel: K-major, uniformly padded copies of both operands
             Pp = (lay.max_P + 63) // 64 * 64          # K of these contractions: a multiple of 64 selects the LDS-DMA pipelined kernel
             Dt = torch.empty((nblk, lay.B * Kp, Pp), dtype=torch.bfloat16, device=dev)
@@ -1174,7 +1235,8 @@ class _PairBias(torch.autograd.Function):
             if not bf16:
                 dbconst[k] = K.colsum(dout)
             if bf16:
-                K.gemm(Dt[k], At, out=T, groups=t_g, n_groups=lay.B, max_m=lay.max_C * NO, max_n=H, M=lay.B * Kp, N=lay.B * H, ldc=H)
+                K.gemm(Dt[k], At, out=T, groups=t_g, n_groups=lay.B, max_m=lay.max_C * NO, max_n=H, M=lay.B * Kp, N=lay.B * H, ldc=H,
+                       flops=2.0 * lay.n_pairs * NO * H)
                 check(load().fabind_pair_bias_finish(ptr(T), ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.c_index),
                                                      lay.sumC, ptr(da0b0), ptr(dwcomp[k]), stream()), "fabind_pair_bias_finish")
             else:

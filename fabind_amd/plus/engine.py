@@ -23,7 +23,7 @@ import torch
 
 from .. import kernels as K
 from .. import ops
-from ..config import get_precision
+from ..config import fp32_storage, get_precision
 from ..engine import Graph, Layout, _cat, cached_pack
 
 

@@ -199,6 +199,14 @@ int fabind_coord_update(const float* x, const float* d, const float* s_part, int
                         const int* rowptr, int n_rows, int mean, float clampv, float* x_out, float* s_out,
                         hipStream_t stream);
 
+/* The same fused forward edge pipeline (models/egnn.py:68-128) in SPLIT-bf16 arithmetic (precision mode 'bf16x3': fp32-grade results
+ * on the bf16 matrix cores, three MFMAs per product term): AB = fp32 [N, 2H]; every packed weight is given as TWO fragment arrays in
+ * the layout of fabind_gcl_edge_fused, W..ph = bf16(W) and W..pl = bf16(W - float(W..ph)); agg / s_out / bnd / dropout as there. */
+int fabind_gcl_edge_fused_x3(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
+                             const float* w_r, const void* W2ph, const void* W2pl, const float* b2, const void* Wcph,
+                             const void* Wcpl, const float* bc, const float* w3, int E, float* agg, float* s_out, float p_drop,
+                             unsigned seed, float* bnd, hipStream_t stream);
+
 /* Fused forward edge pipeline of MC_E_GCL (models/egnn.py:68-128) for 64-edge tiles, bf16:
  *   s_out[e] = w3 . silu( silu( silu(A[row]+Bc[col]+rhohat*w_r) W2^T + b2 ) Wc^T + bc ),  agg[row] += silu(.. W2^T + b2)
  * AB = bf16 [N, 2H] (A | Bc); W2p / Wcp = bf16 weights packed in MFMA fragment order [H/32][H/16][4][16][8];

@@ -123,7 +123,28 @@ def test_headline_shape_bf16_gap_is_measured_and_bounded(one_complex, n_iter):
     assert herr < 5e-2
 
 
-@pytest.mark.parametrize("prec,tol", [("fp32", 3e-3), ("bf16", 6e-2)])
+@pytest.mark.parametrize("n_iter", [1, 2, 8])
+def test_headline_shape_bf16x3_meets_the_gate(one_complex, n_iter):
+    """the split-bf16 mode (fp32 storage, three bf16 MFMAs per product term) must meet the 1e-4 A gate at the
+    headline shape for one, two and the production eight refinement passes -- the mode bench.py's `gate_mode` sub-object times."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    m = _model(n_iter)
+    Xr, Hr, _, _ = _oracle(m, one_complex, n_iter)
+    engine.set_precision("bf16x3")
+    try:
+        X, Hh, _ = _hip(m.to(dev), one_complex, dev)
+    finally:
+        engine.set_precision("fp32")
+    lig = one_complex["mask"].numpy()
+    gap = rmsd(X.cpu().numpy()[lig] * 5, Xr.numpy()[lig] * 5)
+    herr = float((Hh.cpu() - Hr).abs().max()) / max(1.0, float(Hr.abs().max()))
+    print("headline shape bf16x3, n_iter=%d: RMSD vs oracle %.3e A (gate 1e-4); H rel err %.3e" % (n_iter, gap, herr))
+    assert gap < 1e-4
+    assert herr <= 1e-4
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 3e-3), ("bf16x3", 3e-2), ("bf16", 6e-2)])
 def test_headline_shape_gradients_match_oracle_autograd(one_complex, prec, tol):
     """(ii) d(loss)/d(input H, every parameter) through the HIP backward kernels vs autograd through the oracle."""
     from fabind_amd import engine
@@ -164,6 +185,11 @@ def test_headline_shape_gradients_match_oracle_autograd(one_complex, prec, tol):
     if prec == "fp32":
         assert rows[0][0] <= tol, rows[0]
     else:
+        # bf16x3: the FORWARD is fp32-grade (the gate tests above); its gradients are not held to 3e-3 per entry and cannot be: a ReLU
+        # unit whose pre-activation lies within the 2^-17 forward error of zero flips its derivative, and one flipped unit in a column
+        # moves that column's weight gradient (a sum of ~1e5 signed terms) by ~1 % of its largest entry -- measured with exact-fp32
+        # weight-gradient contractions: input 7.8e-3, worst tensor 1.9e-2 (the relu Transition weights), per-tensor l2 2.4e-3.  The
+        # shipped mode additionally contracts weight gradients and the fused edge backward on bf16 roundings (ops._x3_tn_ok).
         # bf16 operands: every gradient entry is a sum over 1e5-1e6 rounded products.  What is bounded: the error of the whole
         # gradient vector in the l2 sense (dominated by the tensors that carry the gradient), and of every single tensor
         # loosely -- 37 of 223 tensors, all with |g| <= 1e-2 of the largest (the scalar attention-bias path, the 41-row ligand
@@ -195,7 +221,7 @@ def bench_batch():
 
 # measured: E(3) 3.1e-6 A (fp32) / 4.0e-5 A (bf16), H invariance 4.8e-7 (fp32) / 1.4e-3 (bf16: a rotated input rounds differently);
 # complex 0 in the batch vs alone 0 exactly; two runs bit-identical in both modes
-@pytest.mark.parametrize("prec,tol_equiv,tol_h,tol_single", [("fp32", 1e-4, 1e-5, 1e-6), ("bf16", 1e-4, 2.8e-3, 1e-6)])
+@pytest.mark.parametrize("prec,tol_equiv,tol_h,tol_single", [("fp32", 1e-4, 1e-5, 1e-6), ("bf16x3", 1e-4, 1e-4, 1e-6), ("bf16", 1e-4, 2.8e-3, 1e-6)])
 def test_bench_batch_properties(bench_batch, prec, tol_equiv, tol_h, tol_single):
     """(iii) the B = 64 batch of bench.py: finite; E(3)-equivariant (inputs rotated and translated -> coordinates rotate and
     translate, H invariant); two runs repeat; complex 0 inside the batch == the same complex alone."""

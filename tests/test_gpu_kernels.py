@@ -11,6 +11,83 @@ def _dev():
     return torch.device("cuda:0")
 
 
+@pytest.fixture
+def x3_mode():
+    """split-bf16 contractions for fp32 operands (config 'bf16x3'), restored afterwards"""
+    from fabind_amd import config
+    old = config.get_precision()
+    config.set_precision("bf16x3")
+    yield
+    config.set_precision(old)
+
+
+@pytest.mark.parametrize("wm", [2, 4])
+def test_gemm_split_bf16_accuracy_and_forms(x3_mode, wm):
+    """fabind_gemm with split3: fp32 operands contracted as hi/lo bf16 pairs (three MFMAs per term).  Against float64: the error
+    must sit at the 2^-16 operand-split level (two orders below bf16, within ~30x of the exact-fp32 MFMA), in every form the fp32
+    path uses: plain, K-concatenated A | A2, bias / SiLU epilogue with the stored derivative, residual, accumulate, row-dot,
+    split-K partials and ragged groups.  Both tile heights (fabind_gemm_set_x3_tile)."""
+    from fabind_amd import _lib, config
+    from fabind_amd import kernels as K
+    dev = _dev()
+    _lib.load().fabind_gemm_set_x3_tile(wm)
+    try:
+        g = torch.Generator().manual_seed(11 + wm)
+        for (M, N, Kd) in [(1000, 512, 512), (257, 136, 96), (3000, 1024, 1536), (64, 8, 32)]:
+            A = torch.randn(M, Kd, generator=g, dtype=torch.float64)
+            W = torch.randn(N, Kd, generator=g, dtype=torch.float64) / Kd ** 0.5
+            ref = A @ W.T
+            Ad, Wd = A.float().to(dev), W.float().to(dev)
+            ref32 = Ad.double().cpu() @ Wd.double().cpu().T                     # what exact arithmetic gives on the fp32-rounded operands
+            out, _ = K.gemm(Ad, Wd)
+            e_x3 = float((out.double().cpu() - ref32).abs().max() / ref32.abs().max())
+            config.set_precision("fp32")
+            out32, _ = K.gemm(Ad, Wd)
+            config.set_precision("bf16x3")
+            e_32 = float((out32.double().cpu() - ref32).abs().max() / ref32.abs().max())
+            e_16 = float(((Ad.bfloat16().double().cpu() @ Wd.bfloat16().double().cpu().T) - ref32).abs().max() / ref32.abs().max())
+            print("split-bf16 GEMM %dx%dx%d (tile %d rows): max err / max |C|: x3 %.2e, exact-fp32 MFMA %.2e, plain bf16 operands %.2e"
+                  % (M, N, Kd, 64 * wm, e_x3, e_32, e_16))
+            assert e_x3 < 2e-5 and e_x3 < e_16 / 100
+        # forms
+        M, N, Kd = 777, 200, 256
+        A = torch.randn(M, Kd, generator=g)
+        W = torch.randn(N, Kd, generator=g) / Kd ** 0.5
+        b, R, u = torch.randn(N, generator=g), torch.randn(M, N, generator=g), torch.randn(N, generator=g)
+        Ad, Wd = A.to(dev), W.to(dev)
+        pre = (A.double() @ W.double().T + b.double())
+        tol = lambda r: 3e-5 * max(1.0, float(r.abs().max()))
+        out, _ = K.gemm(Ad[:, :128].contiguous(), Wd, A2=Ad[:, 128:].contiguous(), bias=b.to(dev), residual=R.to(dev))
+        assert (out.double().cpu() - (pre + R.double())).abs().max() <= tol(pre)
+        D = torch.empty(M, N, device=dev)
+        out, _ = K.gemm(Ad, Wd, bias=b.to(dev), act_epi=K.ACT_SILU, out2=D)
+        sg = torch.sigmoid(pre)
+        assert (out.double().cpu() - pre * sg).abs().max() <= tol(pre)
+        assert (D.double().cpu() - sg * (1 + pre * (1 - sg))).abs().max() <= 3e-5 * 2
+        C = R.to(dev).clone()
+        K.gemm(Ad, Wd, out=C, accumulate=True)
+        assert (C.double().cpu() - (A.double() @ W.double().T + R.double())).abs().max() <= tol(pre)
+        _, part = K.gemm(Ad, Wd, bias=b.to(dev), act_epi=K.ACT_RELU, dotvec=u.to(dev), want_out=False)
+        refd = (torch.relu(pre) * u.double()).sum(1)
+        assert (part.sum(1).double().cpu() - refd).abs().max() <= 1e-4 * max(1.0, float(refd.abs().max()))
+        parts, _ = K.gemm(Ad, Wd, k_splits=2)
+        assert (parts.sum(0).double().cpu() - A.double() @ W.double().T).abs().max() <= tol(pre)
+        # ragged groups {a_row0, M, w_row0, N, c_off lo, c_off hi, ldc, -}: three blocks of different sizes into one output list
+        ms, ns = [100, 33, 260], [40, 8, 136]
+        a0 = np.concatenate([[0], np.cumsum(ms)]); w0 = np.concatenate([[0], np.cumsum(ns)])
+        c0 = np.concatenate([[0], np.cumsum([m * n for m, n in zip(ms, ns)])])
+        Ag = torch.randn(int(a0[-1]), Kd, generator=g); Wg = torch.randn(int(w0[-1]), Kd, generator=g) / Kd ** 0.5
+        grp = torch.tensor([[a0[i], ms[i], w0[i], ns[i], c0[i], 0, ns[i], 0] for i in range(3)], dtype=torch.int32, device=dev)
+        outg = torch.zeros(int(c0[-1]), device=dev)
+        K.gemm(Ag.to(dev), Wg.to(dev), out=outg, groups=grp, n_groups=3, max_m=max(ms), max_n=max(ns), M=int(a0[-1]), N=int(w0[-1]), ldc=1)
+        for i in range(3):
+            r = Ag[a0[i]:a0[i + 1]].double() @ Wg[w0[i]:w0[i + 1]].double().T
+            got = outg[c0[i]:c0[i + 1]].view(ms[i], ns[i]).double().cpu()
+            assert (got - r).abs().max() <= tol(r), i
+    finally:
+        _lib.load().fabind_gemm_set_x3_tile(2)
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 @pytest.mark.parametrize("shape", [(300, 96, 64), (129, 130, 56), (1000, 512, 544), (17, 1, 2048), (5, 256, 128)])
 def test_gemm_epilogues(mode, shape):
@@ -688,3 +765,47 @@ def test_mlp2_node_matches_autograd(prec, tol, act, with_x2, with_sink):
             assert err <= tol, (name, err)
     finally:
         engine.set_precision("fp32")
+
+
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+@pytest.mark.parametrize("H", [64, 128, 256, 512])
+def test_fused_edge_split_bf16_matches_float64(H, p_drop):
+    """csrc/fused_edge_fwd3.hip: the fused forward edge pipeline in split-bf16 arithmetic (fp32 AB rows, hi | lo LDS planes and weight
+    packs, three MFMAs per product term) against the same pipeline in float64 -- fp32-grade agreement (1e-5 of the largest entry;
+    the bf16 kernel's bound on this test is 2e-2), ragged last tile, a heavy row spanning tiles, rows without edges, dropout mask."""
+    from fabind_amd import kernels as K
+    from helpers import fused_edge_keep_mask
+    dev = _dev()
+    g = torch.Generator().manual_seed(H + 1)
+    N, deg = 300, torch.randint(0, 40, (300,), generator=g)
+    deg[7] = 333
+    deg[11] = 0
+    row = torch.repeat_interleave(torch.arange(N), deg)
+    E = row.shape[0]
+    col = torch.randint(0, N, (E,), generator=g)
+    AB = torch.randn(N, 2 * H, generator=g)
+    rh = torch.rand(E, generator=g)
+    w_r, b2, bc, w3 = [torch.randn(H, generator=g) * 0.5 for _ in range(4)]
+    W2 = torch.randn(H, H, generator=g) / H ** 0.5
+    Wc = torch.randn(H, H, generator=g) / H ** 0.5
+    silu = torch.nn.functional.silu
+    d = lambda t: t.double()
+    S1 = silu(d(AB)[row, :H] + d(AB)[col, H:] + d(rh)[:, None] * d(w_r))
+    M = silu(S1 @ d(W2).T + d(b2))
+    seed = 1234
+    if p_drop > 0.0:
+        M = M * fused_edge_keep_mask(seed, E, H, p_drop).double()
+    agg_ref = torch.zeros(N, H, dtype=torch.float64).index_add_(0, row, M)
+    s_ref = (silu(M @ d(Wc).T + d(bc)) * d(w3)).sum(1)
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    rp = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(deg, 0)]).to(torch.int32).to(dev)
+    agg, s = K.gcl_edge_fused_x3(AB.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev), Wc.to(dev),
+                                 bc.to(dev), w3.to(dev), N, p_drop=p_drop, seed=seed, rowptr=rp)
+    e_agg = float((agg.double().cpu() - agg_ref).abs().max() / agg_ref.abs().max())
+    e_s = float((s[:, 0].double().cpu() - s_ref).abs().max() / s_ref.abs().max())
+    print("fused edge forward, split bf16, H=%d p=%.2f: agg err %.2e, s err %.2e (of the largest entry)" % (H, p_drop, e_agg, e_s))
+    assert e_agg <= 1e-5 and e_s <= 1e-5
+    assert float(agg[11].abs().max()) == 0.0                            # a node without edges
+    agg2, s2 = K.gcl_edge_fused_x3(AB.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev), Wc.to(dev),
+                                   bc.to(dev), w3.to(dev), N, p_drop=p_drop, seed=seed, rowptr=rp)
+    assert torch.equal(agg, agg2) and torch.equal(s, s2)                # deterministic

@@ -28,13 +28,21 @@ def _model(g, dev):
 MODELS = ["model_tiny", "model_6g3c"]        # synthetic spheres / the reference's example complex 6g3c (BASELINE config 0)
 
 
+@pytest.fixture(params=["fp32", "bf16x3"])
+def gate_mode(request):
+    """the two modes that must meet the parity gates: exact fp32 and split bf16"""
+    from fabind_amd import engine
+    engine.set_precision(request.param)
+    yield request.param
+    engine.set_precision("fp32")
+
+
 @pytest.mark.parametrize("name", MODELS)
 @pytest.mark.parametrize("stage", [1, 2])
-def test_model_forward_loss_and_gradients(stage, name):
+def test_model_forward_loss_and_gradients(stage, name, gate_mode):
     from fabind_amd import engine
     from fabind_amd.models.model import compute_loss
     dev = torch.device("cuda:0")
-    engine.set_precision("fp32")
     g = load_npz(name)
     m = _model(g, dev)
     data = hetero_from_npz(g).to(dev)

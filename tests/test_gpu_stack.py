@@ -94,12 +94,14 @@ def test_edges_at_the_cutoff_boundary_are_consistent():
     assert torch.equal(r[m], c) and torch.equal(c[m], r)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("name", STACKS)
-def test_stack_forward_fp32_matches_reference(name):
-    """north_star gate: ligand coordinates within 1e-4 A RMSD of the reference CPU path (fp32 mode)."""
+def test_stack_forward_fp32_matches_reference(name, mode):
+    """north_star gate: ligand coordinates within 1e-4 A RMSD of the reference CPU path -- in fp32 mode (exact-fp32 MFMA) and in
+    bf16x3 mode (fp32 storage, split-bf16 contractions: the fast gate-meeting mode)."""
     from fabind_amd import engine
     dev = torch.device("cuda:0")
-    engine.set_precision("fp32")
+    engine.set_precision(mode)
     g = load_npz(name)
     m = _build_stack(g, dev)
     cap = {}
@@ -108,6 +110,7 @@ def test_stack_forward_fp32_matches_reference(name):
         X, H = _run(m, stack_inputs(g), dev)
     finally:
         engine.DEBUG_CAPTURE = None
+        engine.set_precision("fp32")
     if name == "stack_tiny_it1":
         for k in ("gcl_0.h", "gcl_0.x", "att_0.h", "att_0.x", "att_0.alpha", "gcl_1.h", "att_1.x"):
             ref = g["cap_" + k]
@@ -161,20 +164,25 @@ def test_stack_forward_vs_oracle_larger():
     assert (Hh.cpu() - Hr).abs().max() <= 1e-4 * max(1.0, float(Hr.abs().max()))
 
 
-def test_stack_gradients_match_reference():
-    """Backward through the HIP kernels: d(loss)/d(parameters, input H) vs the reference's autograd (fp32 mode)."""
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_stack_gradients_match_reference(mode):
+    """Backward through the HIP kernels: d(loss)/d(parameters, input H) vs the reference's autograd (fp32 mode and the
+    split-bf16 mode, same gates)."""
     from fabind_amd import engine
     dev = torch.device("cuda:0")
-    engine.set_precision("fp32")
-    g = load_npz("stack_tiny_grad")
-    m = _build_stack(g, dev)
-    inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in stack_inputs(g).items()}
-    Hin = inp["H"].clone().requires_grad_(True)
-    X, H = m(inp["X"].clone(), Hin, inp["batch_id"], inp["segment_id"], inp["mask"], inp["is_global"],
-             inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"])
-    loss = (X * torch.from_numpy(g["cot_X"]).to(dev)).sum() + (H * torch.from_numpy(g["cot_H"]).to(dev)).sum()
-    assert abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
-    loss.backward()
+    engine.set_precision(mode)
+    try:
+        g = load_npz("stack_tiny_grad")
+        m = _build_stack(g, dev)
+        inp = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in stack_inputs(g).items()}
+        Hin = inp["H"].clone().requires_grad_(True)
+        X, H = m(inp["X"].clone(), Hin, inp["batch_id"], inp["segment_id"], inp["mask"], inp["is_global"],
+                 inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"])
+        loss = (X * torch.from_numpy(g["cot_X"]).to(dev)).sum() + (H * torch.from_numpy(g["cot_H"]).to(dev)).sum()
+        assert abs(float(loss) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+        loss.backward()
+    finally:
+        engine.set_precision("fp32")
     ref = g["grad_in_H"]
     assert np.abs(Hin.grad.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
     nograd = set(str(s) for s in g["nograd"])
