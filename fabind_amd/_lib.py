@@ -56,7 +56,6 @@ SIGNATURES = {
     "fabind_gcl_edge_fused_x3": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp],
     "fabind_gcl_edge_fused_bwd": [ctypes.POINTER(EdgeBwdArgs), _i, _i, _vp],
     "fabind_pair_update_fused": [ctypes.POINTER(PairUpdateArgs), _i, _vp],
-    "fabind_gemm_set_x3_tile": [_i],
     "fabind_gcl_edge_fused_bwd_set_tile": [_i],
     "fabind_gcl_edge_fused_bwd_tile": [],
     "fabind_gcl_edge_fused_bwd_set_variant": [_i],
@@ -145,6 +144,8 @@ def load():
     lib.fabind_gemm_set_persistent.restype = None
     lib.fabind_gemm_set_small_m.argtypes = [ctypes.c_int]
     lib.fabind_gemm_set_small_m.restype = None
+    lib.fabind_gemm_set_x3_tile.argtypes = [ctypes.c_int]
+    lib.fabind_gemm_set_x3_tile.restype = None
     if os.environ.get("FABIND_GEMM_SMALL_M"):
         lib.fabind_gemm_set_small_m(int(os.environ["FABIND_GEMM_SMALL_M"]))
     lib.fabind_gemm_tn_set_waves.argtypes = [ctypes.c_int]

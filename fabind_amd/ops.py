@@ -71,6 +71,8 @@ def _weight_grad(dpre, x, act_pro, x2=None, out_dtype=torch.float32, want_db=Fal
     (`fabind_gemm_tn(..., with_colsum)`; the split reduction writes dW as out_dtype and db as fp32), a separate column sum otherwise."""
     if not want_db:
         return _weight_grad_f32(dpre, x, act_pro, x2, out_dtype)
+    if FUSE_DB_TN and act_pro == K.ACT_NONE and _x3_tn_ok(dpre, x, x2) and dpre.shape[1] % 4 == 0:
+        return _x3_weight_grad(dpre, x, x2, out_dtype, True)
     if FUSE_DB_TN and act_pro == K.ACT_NONE and _tn_ok(dpre, x, x2):
         dW, db = K.gemm_tn(dpre, x, out_dtype=out_dtype, with_colsum=True)
         if x2 is not None:
@@ -95,14 +97,37 @@ def _x3_tn_ok(dpre, x, x2):
             and dpre.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and (x2 is None or x2.shape[1] % 8 == 0) and dpre.shape[0] >= 256)
 
 
+def _b16_copy(x):
+    """bf16 copy of an fp32 activation, remembered on the tensor (an epilogue may already have attached one: _attach_b16)."""
+    if x.dtype == torch.bfloat16:
+        return x
+    c = getattr(x, "_fab_b16", None)
+    if c is not None and c[0] == x._version and c[1].shape == x.shape:
+        return c[1]
+    y = x.to(torch.bfloat16)
+    if x.dim() == 2 and x.is_contiguous():
+        try:
+            x._fab_b16 = (x._version, y)
+        except Exception:
+            pass
+    return y
+
+
+def _x3_weight_grad(dpre, x, x2, out_dtype, want_db):
+    """-> (dW, db or None): the 'bf16x3' weight gradient on bf16 roundings (see _x3_tn_ok); db rides along as the TN kernel's column sums."""
+    d16 = dpre.to(torch.bfloat16)
+    if want_db:
+        dW, db = K.gemm_tn(d16, _b16_copy(x), out_dtype=out_dtype, with_colsum=True)
+    else:
+        dW, db = K.gemm_tn(d16, _b16_copy(x), out_dtype=out_dtype), None
+    if x2 is not None:
+        dW = torch.cat([dW, K.gemm_tn(d16, _b16_copy(x2), out_dtype=out_dtype)], 1)
+    return dW, db
+
+
 def _weight_grad_f32(dpre, x, act_pro, x2, out_dtype):
     if act_pro == K.ACT_NONE and _x3_tn_ok(dpre, x, x2):
-        bf = torch.bfloat16
-        d16 = dpre.to(bf)
-        parts = [K.gemm_tn(d16, x.to(bf), out_dtype=out_dtype)]
-        if x2 is not None:
-            parts.append(K.gemm_tn(d16, x2.to(bf), out_dtype=out_dtype))
-        return parts[0] if x2 is None else torch.cat(parts, 1)
+        return _x3_weight_grad(dpre, x, x2, out_dtype, False)[0]
     if act_pro == K.ACT_NONE and _tn_ok(dpre, x, x2):
         if x2 is None:
             return K.gemm_tn(dpre, x, out_dtype=out_dtype)
@@ -181,7 +206,9 @@ def _attach_b16(y, y16):
 
 
 def _want16(out_dtype, act_epi, want):
-    return bool(want) and _cfg.get_precision() == "bf16" and out_dtype == torch.float32 and act_epi == K.ACT_NONE
+    """Should the epilogue also emit the bf16 copy of an fp32 output?  'bf16': it is the next GEMM's operand; 'bf16x3': it is the
+    operand of the weight-gradient TN contractions (ops._x3_tn_ok), saving their cast passes."""
+    return bool(want) and _cfg.get_precision() in ("bf16", "bf16x3") and out_dtype == torch.float32 and act_epi == K.ACT_NONE
 
 
 class _Linear(torch.autograd.Function):

@@ -40,6 +40,8 @@ const char* fabind_last_error(void);
  * 9 = fabind_zero_empty_rows added (outputs of the fused edge kernels are no longer memset whole).
  * 10 = fabind_gemm_tn_tile_n added (the host sizes the split count of fabind_gemm_tn from the output tile of the current layout: 256 x 256 on
  *     eight waves by default); knobs fabind_gemm_tn_set_exp, fabind_gemm_set_small_m; fabind_gemm_tn_set_waves accepts 16 / 20.
+ * 12: FabindGemmArgs.split3 (fp32 x fp32 contracted as split bf16, three MFMAs per product term: precision mode 'bf16x3');
+ *     fabind_gcl_edge_fused_x3 (the fused forward edge pipeline in that arithmetic); knob fabind_gemm_set_x3_tile.
  * 11 = fabind_gemm_tn takes with_colsum (the bias gradient rides along with the weight gradient: no separate column-sum launches);
  *     fabind_split_sum takes (n_tail, out_tail); fabind_inter_attn_bwd writes wpart as [nblk][4][H] (was [4][nblk][H]);
  *     fabind_pair_hadamard_bwd_rows added (the pair-Hadamard adjoint over the inter graph without float atomics);
@@ -495,6 +497,7 @@ int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, cons
 void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of the bf16 LDS-DMA GEMM (default 13 = 256x128x32, 3 stages,
                                          two work-groups per CU; 0 = register-staged kernel; 1-9 = other tiles; results do not depend on it) */
 void fabind_gemm_set_persistent(int on); /* development knob: persistent tile walk for long-M/short-K GEMMs */
+void fabind_gemm_set_x3_tile(int wm); /* development knob: tile height of the split-bf16 fabind_gemm kernel in units of 64 rows (2 = default: 128x128, two 4-wave work-groups per CU; 4: 256x128, one 8-wave work-group) */
 void fabind_gemm_set_small_m(int tiles); /* development knob: fabind_gemm launches with fewer 256x128 tiles than this use 128x128 tiles (default 100; 0 = never); results are bitwise equal */
 void fabind_gemm_tn_set_waves(int waves); /* development knob: work-group layout of fabind_gemm_tn: 16 (default) = 256x256 tile, 8 waves, 4-stage ring; 20 = the same with 5 stages; 4 = 256x128 tile, 4 waves, two work-groups per CU; 8 = 256x128, 8 waves.  Results are bitwise equal for equal `splits` */
 int fabind_gemm_tn_tile_n(void);          /* 256 or 128: columns of an output tile under the current layout (the host sizes `splits` from the tile count) */

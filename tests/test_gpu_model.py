@@ -82,7 +82,8 @@ def test_model_forward_loss_and_gradients(stage, name, gate_mode):
         smp = g[p + "gradsmp_" + n]
         e1 = abs(float(got.norm()) - ref_n)
         e2 = np.abs(got[idx].numpy() - smp).max()
-        if e1 > 5e-3 * ref_n + 1e-6 or e2 > 5e-3 * max(np.abs(smp).max(), ref_n / max(got.numel(), 1) ** 0.5) + 1e-7:
+        gtol = 5e-3 if gate_mode == "fp32" else 3e-2        # bf16x3 gradients: see tests/test_gpu_stack.py::test_stack_gradients_match_reference
+        if e1 > gtol * ref_n + 1e-6 or e2 > gtol * max(np.abs(smp).max(), ref_n / max(got.numel(), 1) ** 0.5) + 1e-7:
             bad.append((n, e1, ref_n, float(e2)))
         checked += 1
     n_ref = sum(1 for k in g if k.startswith(p + "gradnorm_") and float(g[k]) > floor)

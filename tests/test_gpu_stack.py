@@ -183,8 +183,11 @@ def test_stack_gradients_match_reference(mode):
         loss.backward()
     finally:
         engine.set_precision("fp32")
+    # bf16x3: the forward quantities above are held to the same gates in both modes; its GRADIENTS carry single-bf16 weight-gradient
+    # contractions and ReLU-derivative flips (tests/test_gpu_headline.py measures both): 2e-2 per tensor instead of 3e-3
+    gtol = 3e-3 if mode == "fp32" else 2e-2
     ref = g["grad_in_H"]
-    assert np.abs(Hin.grad.cpu().numpy() - ref).max() <= 2e-3 * np.abs(ref).max()
+    assert np.abs(Hin.grad.cpu().numpy() - ref).max() <= (2e-3 if mode == "fp32" else 2e-2) * np.abs(ref).max()
     nograd = set(str(s) for s in g["nograd"])
     bad = []
     for n, p in m.named_parameters():
@@ -198,7 +201,7 @@ def test_stack_gradients_match_reference(mode):
             assert np.abs(ref).max() < 1e-6, n
             continue
         err = np.abs(p.grad.cpu().numpy() - ref).max()
-        if not err <= 3e-3 * np.abs(ref).max() + 1e-7:
+        if not err <= gtol * np.abs(ref).max() + 1e-7:
             bad.append((n, float(err), float(np.abs(ref).max())))
     assert not bad, bad
 
