@@ -77,6 +77,8 @@ SIGNATURES = {
                               _vp],
     "fabind_cross_attn_mfma_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i,
                                    _vp],
+    "fabind_cross_attn_fused_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp],
+    "fabind_pair_bo_pack": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "fabind_cross_attn_mfma_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp],
     "fabind_pair_bmat": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp],

@@ -595,3 +595,341 @@ extern "C" int fabind_cross_attn_mfma_bwd(const float* qg, int ldq, const float*
     FB_CHECK_LAUNCH();
     return 0;
 }
+
+// =====================================================================================================================
+// Cross attention with the pair bias RECOMPUTED IN THE KERNEL (round 3): the block's matrix-core form.
+//
+// In the v1 stack every layer's RowAttention pair bias is  bias[h,i,j] = lin_h(z0_ij) * sigmoid(gate_h(z0_ij))  of the SAME factored pair
+// embedding z0_ij = W_o (a_i . b_j) + b_o (att_model.py:198-206, cross_att.py:118-134), i.e. with the composed weights Wc = W_{lin|gate} W_o
+//     lin_h / gate_h (i, j) = sum_k a_i[k] * (b_j[k] Wc[o,k]) + c_o          -- a K = H contraction per head-column o (8 of them).
+// Rounds 1-2 evaluated it as one ragged GEMM per layer and block into eight [pairs, 8] fp32 tensors (126 MB each at the headline
+// shape), which the three attention kernels then stream at 32 B per pair against 512 flop: HBM / latency-bound at 1 % matrix-core
+// utilisation.  Here a work-group owns 64 PROTEIN rows of one complex:
+//   A. stage their a0 rows (bf16) into a swizzled [64][H] LDS tile and contract them with the complex's packed ligand-side operand
+//      Bo[(atom, slot), k] = b_atom[k] Wc[slot, k] (fragments streamed from L2, built once per layer and block by pair_bo_pack_kernel;
+//      slots per atom: lin0, gate0, lin1, gate1, lin2, gate2, lin3, gate3) in the operand-swapped form: a lane's accumulator quad is
+//      (lin_h, gate_h, lin_h+1, gate_h+1) of ONE (protein row, atom) pair -- the bias lin * sigmoid(gate) is formed in registers and
+//      written as a [.][.][4 heads] fp32 LDS tile over the dead a0 tile: 8.2 kFLOP per pair on the matrix cores instead of 32 B of HBM;
+//   B. runs the attention of cross_attn_mfma_fwd_kernel with the bias read from that tile:
+//      MODE 0 (protein-query block): the 64 rows are the queries of 4 waves, keys = the complex's ligand atoms;
+//      MODE 1 (ligand-query block):  the 64 rows are the KEYS (two 32-key chunks), queries = the ligand atoms (16 per wave); the
+//              un-normalised partial (o, m, l) of every (atom, head) goes to `part` and cross_attn_mfma_combine_kernel merges the
+//              ceil(P / 64) row tiles of a complex.
+// Ligands of up to 62 atoms (the bias tile of 64 rows x 62 atoms x 4 heads is what fits beside the K / V images at two work-groups
+// per CU); larger ones take the tensor path.  Forward only so far: under autograd the tensor path runs (its backward reads the bias
+// tensors).  Reference: cross_att.py:118-134, model_utils.py:21-38.
+// =====================================================================================================================
+#define CF_ROWS 64
+#define CF_KEYS 62                                  // atoms per bias tile; MODE 1 row stride = 62 * 4 + 4 floats (bank-conflict-free)
+
+// Bo fragments of one layer / block: out[(toff[b] * NKS + ks * T_b + tl) * 512 + lane * 8 + e], T_b = ceil(C_b / 2) column tiles
+__global__ __launch_bounds__(64) void pair_bo_pack_kernel(const float* __restrict__ b0, int ldb, const float* __restrict__ wcomp, int H,
+                                                         const int* __restrict__ c_index, const int* __restrict__ desc,
+                                                         const int* __restrict__ toff, const int* __restrict__ tile_b, bf16_t* out) {
+    const int t = blockIdx.x, ks = blockIdx.y, lane = threadIdx.x;
+    const int b = tile_b[t];
+    const int tl = t - toff[b], T = toff[b + 1] - toff[b];
+    const int fr = lane & 15, fq = lane >> 4;
+    const int c = tl * 16 + fr, key = c >> 3, slot = c & 7;
+    const int C = desc[b * 8 + 3], lig0 = desc[b * 8 + 2];
+    const int wrow = (slot & 1) * 4 + (slot >> 1);                // slot order lin0, gate0, lin1, gate1, ...: wcomp rows are lin0..3, gate0..3
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = 0.f;
+    if (key < C) {
+        const size_t node = (size_t)c_index[lig0 + key];
+        const int k0 = ks * 32 + fq * 8;
+        const float4 x0 = *(const float4*)(b0 + node * ldb + k0), x1 = *(const float4*)(b0 + node * ldb + k0 + 4);
+        const float4 w0 = *(const float4*)(wcomp + (size_t)wrow * H + k0), w1 = *(const float4*)(wcomp + (size_t)wrow * H + k0 + 4);
+        f[0] = x0.x * w0.x; f[1] = x0.y * w0.y; f[2] = x0.z * w0.z; f[3] = x0.w * w0.w;
+        f[4] = x1.x * w1.x; f[5] = x1.y * w1.y; f[6] = x1.z * w1.z; f[7] = x1.w * w1.w;
+    }
+    const int NKS = H / 32;
+    *(bf16x8_t*)(out + ((size_t)toff[b] * NKS + (size_t)ks * T + tl) * 512 + lane * 8) = cm_pack8(f);
+}
+
+extern "C" int fabind_pair_bo_pack(const float* b0, int ldb, const float* wcomp, int H, const int* c_index, const int* desc,
+                                   const int* toff, const int* tile_b, int n_tiles, void* out, hipStream_t stream) {
+    if (n_tiles <= 0) return 0;
+    FB_REQUIRE(H % 32 == 0 && ldb % 4 == 0 && ((uintptr_t)b0 & 15) == 0 && ((uintptr_t)wcomp & 15) == 0 && ((uintptr_t)out & 15) == 0,
+               "fabind_pair_bo_pack: H % 32 == 0, 16-byte aligned rows");
+    hipLaunchKernelGGL(pair_bo_pack_kernel, dim3(n_tiles, H / 32), dim3(64), 0, stream, b0, ldb, wcomp, H, c_index, desc, toff, tile_b,
+                       (bf16_t*)out);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// one pass of the bias contraction: acc[i][j] += sA tile (64 rows) x the wave's column tiles t0 .. t0+3 (tiles past `nt` repeat the last
+// one; their results are not used).  Operand-swapped form, rolled two k-steps per trip with ping-pong fragments (fused_common.h).
+template <int H, int SWZ>
+__device__ __forceinline__ void cf_gemm_pass(const bf16_t* sA, const bf16_t* __restrict__ bo_c, int T, int t0, int nt, int lane,
+                                             f32x4_t (&acc)[4][4]) {
+    constexpr int NKS = H / 32;
+    const int fr = lane & 15, fq = lane >> 4;
+    const bf16_t* wp[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wp[j] = bo_c + (size_t)(t0 + min(j, nt - 1)) * 512 + lane * 8;
+    const size_t kstride = (size_t)T * 512;
+    bf16x8_t b0[4], b1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b0[j] = *(const bf16x8_t*)wp[j];
+#pragma unroll 1
+    for (int ks = 0; ks < NKS; ks += 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b1[j] = *(const bf16x8_t*)(wp[j] + (size_t)(ks + 1) * kstride);
+        bf16x8_t a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 16 + fr;
+            a[i] = *(const bf16x8_t*)&sA[r * H + (((ks * 4 + fq) ^ (r & SWZ)) * 8)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a[i], acc[i][j], 0, 0, 0);
+        {
+            const int kn = min(ks + 2, NKS - 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b0[j] = *(const bf16x8_t*)(wp[j] + (size_t)kn * kstride);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 16 + fr;
+            a[i] = *(const bf16x8_t*)&sA[r * H + ((((ks + 1) * 4 + fq) ^ (r & SWZ)) * 8)];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a[i], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <int H, int MODE>
+__global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+                                                                      const float* __restrict__ v, int ldkv,
+                                                                      const float* __restrict__ gpre, int ldg,
+                                                                      const bf16_t* __restrict__ a0, int lda0,
+                                                                      const bf16_t* __restrict__ bo, const int* __restrict__ toff,
+                                                                      const float* __restrict__ bconst, const int* __restrict__ desc,
+                                                                      float scale, float* out, int ldo, float* part, int nsplit) {
+    constexpr int SWZ = (H >= 128) ? 15 : 7;
+    constexpr int TILE_BYTES = (CF_ROWS * H * 2 > 65536) ? CF_ROWS * H * 2 : 65536;
+    // bias tile: MODE 0 [atom][row][4] (lanes of a wave = rows: consecutive 16-byte reads), MODE 1 [row][CF_KEYS + 1][4] (lanes = atoms)
+    constexpr int LDB1 = (CF_KEYS + 1) * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sA = (bf16_t*)smem;
+    float* sB = (float*)smem;                                       // over the a0 tile once the contraction is done
+    unsigned char* sK = smem + TILE_BYTES;
+    unsigned char* sVt = sK + CM_KC * 256;
+    const int* ds = desc + blockIdx.y * 8;
+    const int prow0 = ds[0], P = ds[1], lig0 = ds[2], C = ds[3];
+    const int m0 = blockIdx.x * CF_ROWS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    if (m0 >= P) {
+        if (MODE == 1) {                                            // neutral partials of a row tile past the end of this complex
+            for (int t = tid; t < C * 4; t += 256) {
+                float* pp = part + (((size_t)(lig0 + (t >> 2)) * nsplit + blockIdx.x) * 4 + (t & 3)) * 34;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) pp[d] = 0.f;
+                pp[32] = -INFINITY; pp[33] = 0.f;
+            }
+        }
+        return;
+    }
+    const int nrow = min(CF_ROWS, P - m0);
+
+    // ---- A1: a0 rows of the tile -> swizzled LDS image (rows past the end repeat the last row; their results are not used)
+    {
+        constexpr int CH = H / 8;
+        for (int c = tid; c < CF_ROWS * CH; c += 256) {
+            const int r = c / CH, ch = c % CH;
+            const uint4 val = *(const uint4*)(a0 + (size_t)(prow0 + m0 + min(r, nrow - 1)) * lda0 + ch * 8);
+            *(uint4*)&sA[r * H + ((ch ^ (r & SWZ)) * 8)] = val;
+        }
+    }
+    __syncthreads();
+
+    // ---- A2: bias contraction.  T column tiles (2 atoms each) are dealt to the 4 waves in contiguous ranges of <= 8 (two passes of 4)
+    const int T = toff[blockIdx.y + 1] - toff[blockIdx.y];
+    const bf16_t* bo_c = bo + (size_t)toff[blockIdx.y] * (H / 32) * 512;
+    const int per = (T + 3) / 4;
+    const int t0 = wave * per, t1 = min(T, t0 + per);
+    f32x4_t acc0[4][4], acc1[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { acc0[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc1[i][j] = acc0[i][j]; }
+    const int n0 = min(4, t1 - t0), n1 = min(4, t1 - t0 - 4);
+    if (n0 > 0) cf_gemm_pass<H, SWZ>(sA, bo_c, T, t0, n0, lane, acc0);
+    if (n1 > 0) cf_gemm_pass<H, SWZ>(sA, bo_c, T, t0 + 4, n1, lane, acc1);
+    __syncthreads();                                                // every wave has finished reading the a0 tile
+
+    // ---- A3: bias = (lin + c_lin) * sigmoid(gate + c_gate) for the lane's two heads -> LDS tile
+    {
+        const int hb = (kq & 1) * 2;                                // this lane's quad: (lin_hb, gate_hb, lin_hb+1, gate_hb+1)
+        const float cl0 = bconst[hb], cg0 = bconst[4 + hb], cl1 = bconst[hb + 1], cg1 = bconst[4 + hb + 1];
+        auto put = [&](const f32x4_t (&acc)[4][4], int tb, int nt) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < nt) {
+                    const int atom = (tb + j) * 2 + (kq >> 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int row = i * 16 + n;
+                        const float2 bv = make_float2((acc[i][j][0] + cl0) * sigmoid_f(acc[i][j][1] + cg0),
+                                                      (acc[i][j][2] + cl1) * sigmoid_f(acc[i][j][3] + cg1));
+                        if (atom < CF_KEYS) {
+                            if (MODE == 0) *(float2*)&sB[(atom * CF_ROWS + row) * 4 + hb] = bv;
+                            else *(float2*)&sB[row * LDB1 + atom * 4 + hb] = bv;
+                        }
+                    }
+                }
+            }
+        };
+        put(acc0, t0, n0);
+        put(acc1, t0 + 4, n1);
+    }
+    // (the barrier in front of the first K / V staging below orders these writes before the reads)
+
+    // ---- B: attention (cross_attn_mfma_fwd_kernel with the bias from the tile)
+    const int nq_total = MODE == 0 ? nrow : C;                      // queries this work-group serves
+    const int qi = wave * 16 + n;                                   // MODE 0: row of the tile; MODE 1: atom
+    const bool qvalid = qi < nq_total;
+    const size_t qrow = MODE == 0 ? (size_t)(prow0 + m0 + (qvalid ? qi : 0)) : (size_t)(lig0 + (qvalid ? qi : 0));
+    bf16x8_t bq[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        float f[8];
+        const float4 a = *(const float4*)(q + qrow * ldq + h * 32 + kq * 8), b = *(const float4*)(q + qrow * ldq + h * 32 + kq * 8 + 4);
+        f[0] = a.x * scale; f[1] = a.y * scale; f[2] = a.z * scale; f[3] = a.w * scale;
+        f[4] = b.x * scale; f[5] = b.y * scale; f[6] = b.z * scale; f[7] = b.w * scale;
+        if (!qvalid) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) f[u] = 0.f;
+        }
+        bq[h] = cm_pack8(f);
+    }
+    f32x4_t o[4][2];
+    float m[4], l[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        m[h] = -INFINITY; l[h] = 0.f;
+        o[h][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; o[h][1] = o[h][0];
+    }
+    const int ke = MODE == 0 ? C : nrow;                            // keys: the ligand atoms / the rows of the tile
+    const long krow0 = MODE == 0 ? (long)lig0 : (long)prow0 + m0;
+    for (int j0 = 0; j0 < ke; j0 += CM_KC) {
+        __syncthreads();
+        cm_stage_rows(sK, k, ldkv, krow0 + j0, ke - j0, 1.f, tid);
+        cm_stage_cols(sVt, v, ldkv, krow0 + j0, ke - j0, 1.f, tid);
+        __syncthreads();
+        float4 bia[2][4];
+        bool ok[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = j0 + t * 16 + kq * 4 + r;
+                ok[t][r] = qvalid && j < ke;
+                const int jc = min(j, ke - 1), qc = qvalid ? qi : 0;
+                bia[t][r] = MODE == 0 ? *(const float4*)&sB[(jc * CF_ROWS + qc) * 4] : *(const float4*)&sB[jc * LDB1 + qc * 4];
+            }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            f32x4_t s[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm_load_rows(sK, t * 16 + n, h * 4 + kq), bq[h],
+                                                                f32x4_t{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float sv = ok[t][r] ? s[t][r] + ((const float*)&bia[t][r])[h] : -INFINITY;
+                    s[t][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m[h], mx);
+            const float ms = (mn == -INFINITY) ? 0.f : mn;
+            const float corr = __expf(m[h] - ms);
+            float p[8];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[t * 4 + r] = __expf(s[t][r] - ms);
+            const bf16x8_t pf = cm_pack8(p);
+            l[h] = l[h] * corr + cm_sum8(pf);                     // (the normaliser sums the ROUNDED probabilities: see the tensor-path kernel)
+            m[h] = mn;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[h][mi][r] *= corr;
+                o[h][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cm_load_cols(sVt, h * 32 + mi * 16 + n, kq), pf, o[h][mi], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        l[h] += __shfl_xor(l[h], 16, 64);
+        l[h] += __shfl_xor(l[h], 32, 64);
+    }
+    if (!qvalid) return;
+    if (MODE == 1) {       // un-normalised partial of this row tile: [atom][tile][head][34] = o[32], m, l
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            float* pp = part + (((size_t)(lig0 + qi) * nsplit + blockIdx.x) * 4 + h) * 34;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pp[mi * 16 + kq * 4 + r] = o[h][mi][r];
+            if (kq == 0) { pp[32] = m[h]; pp[33] = l[h]; }
+        }
+        return;
+    }
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const float inv = 1.f / l[h];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int c = h * 32 + mi * 16 + kq * 4;
+            const float4 g = *(const float4*)(gpre + qrow * ldg + c);
+            *(float4*)(out + qrow * ldo + c) = make_float4(o[h][mi][0] * inv * sigmoid_f(g.x), o[h][mi][1] * inv * sigmoid_f(g.y),
+                                                           o[h][mi][2] * inv * sigmoid_f(g.z), o[h][mi][3] * inv * sigmoid_f(g.w));
+        }
+    }
+}
+
+extern "C" int fabind_cross_attn_fused_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* gpre, int ldg,
+                                           const void* a0, int lda0, const void* bo, const int* toff, const float* bconst,
+                                           const int* desc, int B, int max_P, int max_C, int H, int mode, float scale, float* out,
+                                           int ldo, float* part, int n_lig_rows, hipStream_t stream) {
+    FB_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && lda0 % 8 == 0, "fabind_cross_attn_fused_fwd: strides");
+    FB_REQUIRE(max_C <= CF_KEYS, "fabind_cross_attn_fused_fwd: at most 62 ligand atoms per complex (larger ligands take the tensor path)");
+    FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_cross_attn_fused_fwd: H must be 64, 128, 256 or 512");
+    FB_REQUIRE(mode == 0 || part != nullptr, "fabind_cross_attn_fused_fwd: the ligand-query block needs the partials buffer");
+    if (B <= 0 || max_P <= 0) return 0;
+    const int nsplit = (max_P + CF_ROWS - 1) / CF_ROWS;
+    const size_t lds = (size_t)((CF_ROWS * H * 2 > 65536) ? CF_ROWS * H * 2 : 65536) + CM_KC * 256 + 128 * 64;
+#define CF_LAUNCH(HH, MM)                                                                                                          \
+    do {                                                                                                                           \
+        static bool set_ = false;                                                                                                  \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)cross_attn_fused_fwd_kernel<HH, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        hipLaunchKernelGGL((cross_attn_fused_fwd_kernel<HH, MM>), dim3(nsplit, B), dim3(256), lds, stream, q, ldq, k, v, ldkv, gpre, ldg, \
+                           (const bf16_t*)a0, lda0, (const bf16_t*)bo, toff, bconst, desc, scale, out, ldo, part, nsplit);        \
+    } while (0)
+#define CF_LAUNCH_H(MM) do { if (H == 512) CF_LAUNCH(512, MM); else if (H == 256) CF_LAUNCH(256, MM); else if (H == 128) CF_LAUNCH(128, MM); else CF_LAUNCH(64, MM); } while (0)
+    if (mode == 0) CF_LAUNCH_H(0);
+    else {
+        CF_LAUNCH_H(1);
+        hipLaunchKernelGGL(cross_attn_mfma_combine_kernel, dim3((n_lig_rows * 4 + 255) / 256), dim3(256), 0, stream, part, nsplit, gpre,
+                           ldg, n_lig_rows, out, ldo, (float*)nullptr);
+    }
+#undef CF_LAUNCH_H
+#undef CF_LAUNCH
+    FB_CHECK_LAUNCH();
+    return 0;
+}

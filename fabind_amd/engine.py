@@ -427,10 +427,16 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
         h = ops.shared_grad(h)      # consumers: ligand row gather, q / gate projection, residual of the attention update
     hc = ops.take_rows(h, lay.c_index64)
     scale = 1.0 / math.sqrt(32.0)
-    bias_p, bias_c = pairbias[2 * layer], pairbias[2 * layer + 1]
+    # forward-only bf16 passes recompute the pair bias inside the attention kernels (ops.PairBias.fused); everything else reads the
+    # [pairs, 8] bias tensors
+    fused = fast and isinstance(pairbias, ops.PairBias) and pairbias.can_fuse()
+    if not fused:
+        pbt = pairbias.tensors() if isinstance(pairbias, ops.PairBias) else pairbias
+        bias_p, bias_c = pbt[2 * layer], pbt[2 * layer + 1]
     qg = ops.linear(c16(h), p["Wqg_p"], p["bqg_p"])                                     # [N, 256]
     kv = ops.linear(c16(hc), p["Wkv_p"])                                                # [sum C, 256]
-    og = ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_pf, lay.B, lay.max_P, lay.max_C, scale)
+    og = ops.cross_attn_fused(qg, kv, pairbias, 2 * layer, 0, lay, scale) if fused else \
+        ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_pf, lay.B, lay.max_P, lay.max_C, scale)
     hp = (h + _drop(ops.linear(c16(og), p["Wo_p"], p["bo_p"]), pdrop)) if pdrop > 0.0 else \
         ops.linear(c16(og), p["Wo_p"], p["bo_p"], residual=h, want16=True)
     if pdrop == 0.0:
@@ -438,7 +444,8 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     hp16 = c16(hp)
     qg = ops.linear(c16(hc), p["Wqg_c"], p["bqg_c"])
     kv = ops.linear(hp16, p["Wkv_c"])                                                   # [N, 256], protein rows used
-    og = ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
+    og = ops.cross_attn_fused(qg, kv, pairbias, 2 * layer + 1, 1, lay, scale) if fused else \
+        ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
     hc = (hc + _drop(ops.linear(c16(og), p["Wo_c"], p["bo_c"]), pdrop)) if pdrop > 0.0 else \
         ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc)
     if fast:
@@ -492,9 +499,10 @@ def egnn_forward(P, h, x, lay, g, las, x_las, a0b0, pairbias, scale, step, drop=
 
 
 def pair_bias_all(P, a0b0, lay):
-    """RowAttention pair biases of every layer from z0 in one ragged-batched K=H contraction."""
+    """RowAttention pair biases of every layer from z0: a lazy holder -- [pairs, 8] tensors from one ragged-batched K = H contraction
+    per block when a consumer asks for them, or the operands of the kernels that recompute the bias on the matrix cores."""
     H = P["H"]
-    return ops.pair_bias(a0b0, H, P["pb_wcomp"], P["pb_bconst"], lay)
+    return ops.PairBias(a0b0, H, P["pb_wcomp"], P["pb_bconst"], lay)
 
 
 class StackContext:

@@ -249,6 +249,52 @@ def cross_attn_fwd(q, k, v, gpre, bias, lin_col, gate_col, desc, B, max_nq, scal
     return out, lse
 
 
+CROSS_ATTN_FUSED = os.environ.get("FABIND_ATTN_FUSED", "1") == "1"   # forward-only bf16 passes: pair bias recomputed inside the attention kernels
+CROSS_ATTN_FUSED_MAX_C = 62
+
+
+def bo_tiles(lay):
+    """(toff [B+1], tile_b [n_tiles], n_tiles) of the packed ligand-side operand of the fused cross attention: complex b owns
+    ceil(C_b / 2) 16-column tiles (cached on the layout)."""
+    c = getattr(lay, "_bo_tiles", None)
+    if c is None:
+        import numpy as np
+        T = (np.asarray(lay.C) + 1) // 2
+        toff = np.concatenate([[0], np.cumsum(T)]).astype(np.int32)
+        tile_b = np.repeat(np.arange(lay.B, dtype=np.int32), T)
+        dev = lay.node_off.device
+        c = lay._bo_tiles = (torch.from_numpy(toff).to(dev), torch.from_numpy(tile_b).to(dev), int(toff[-1]))
+    return c
+
+
+def pair_bo_pack(b0, wcomp8, H, lay):
+    """Packed bf16 operand Bo of one layer / block (include/fabind_hip.h: fabind_pair_bo_pack).  b0 = fp32 [N, ld] view (a0b0[:, H:]),
+    wcomp8 = fp32 [8, H]."""
+    toff, tile_b, n_tiles = bo_tiles(lay)
+    out = torch.empty(max(n_tiles, 1) * (H // 32) * 512, dtype=torch.bfloat16, device=b0.device)
+    wc = wcomp8.contiguous()
+    check(_lib.load().fabind_pair_bo_pack(ptr(b0), _ld(b0), ptr(wc), H, ptr(lay.c_index), ptr(lay.desc_pf), ptr(toff), ptr(tile_b),
+                                          n_tiles, ptr(out), stream()), "fabind_pair_bo_pack")
+    return out
+
+
+def cross_attn_fused_fwd(q, k, v, gpre, a0_16, bo, bconst8, lay, H, mode, scale, out):
+    """Gated cross attention with the pair bias recomputed in the kernel (include/fabind_hip.h: fabind_cross_attn_fused_fwd)."""
+    toff, _, _ = bo_tiles(lay)
+    nsplit = (lay.max_P + 63) // 64
+    part = torch.empty(lay.sumC * nsplit * 4 * 34, dtype=torch.float32, device=q.device) if mode == 1 else None
+    assert k.stride(0) == v.stride(0) and a0_16.dtype == torch.bfloat16
+    n_wg = nsplit * lay.B
+    # executed matrix-core work: bias contraction 64 rows x (8 tiles of the busiest wave x 4 waves) x H per work-group + the attention's own
+    flops = 2.0 * n_wg * 64 * (((lay.max_C + 1) // 2 + 3) // 4 * 4 * 16) * H + 2.0 * 16 * 16 * 32 * 16 * n_wg * 4 * ((lay.max_C if mode == 0 else 64) + 31) // 32
+    _profiled("cross_attn_fused_fwd mode=%d B=%d P<=%d C<=%d (bias contraction K=%d + attention)" % (mode, lay.B, lay.max_P, lay.max_C, H), flops,
+              lambda: check(_lib.load().fabind_cross_attn_fused_fwd(ptr(q), _ld(q), ptr(k), ptr(v), _ld(k), ptr(gpre), _ld(gpre), ptr(a0_16),
+                                                                    _ld(a0_16), ptr(bo), ptr(toff), ptr(bconst8), ptr(lay.desc_pf), lay.B,
+                                                                    lay.max_P, lay.max_C, H, mode, scale, ptr(out), _ld(out), ptr(part),
+                                                                    lay.sumC, stream()), "fabind_cross_attn_fused_fwd"))
+    return out
+
+
 def pair_bmat(b0, wcomp, c_node, out_dtype):
     NO, H = wcomp.shape
     n_c = c_node.shape[0]

@@ -1056,7 +1056,7 @@ class _InterAttn(torch.autograd.Function):
         if Wc is not None:
             # cv = Linear(V) (egnn.py:225) evaluated inside this node of the autograd graph: its input gradient then accumulates
             # into the V columns of dqkv in place, instead of autograd padding it to [N,3H] and adding two [N,3H] tensors
-            c16 = getattr(qkv, "_fab_b16", None)
+            c16 = getattr(qkv, "_fab_b16", None) if _cfg.get_precision() == "bf16" else None    # (bf16x3 attaches copies for TN operands only)
             v_in = c16[1][:, 2 * H:] if (c16 is not None and c16[0] == qkv._version) else _mm_in(qkv[:, 2 * H:])
             cv, _ = K.gemm(v_in, Wc, bias=bc)
         h16 = None
@@ -1279,6 +1279,48 @@ def pair_bias(a0b0, H, wcomp, bconst, lay):
     if _needs_grad(a0b0, wcomp, bconst):
         return list(_PairBias.apply(a0b0, wcomp, bconst, H, lay))
     return _pair_bias_fwd(a0b0, H, wcomp, bconst, lay)
+
+
+class PairBias:
+    """The RowAttention pair biases of every layer and block of one stack call, in the two forms the attention kernels take:
+    * `tensors()` -- eight [pairs, 8] fp32 tensors (differentiable; what the autograd path and the fp32-storage modes use);
+    * `fused(k)` -- the operands of the kernels that recompute block k's bias on the matrix cores (bf16 forward-only passes:
+      inference, and the no-grad refinement iterations of training): the bf16 a0 rows, block k's packed ligand-side operand and
+      its eight constants.  Both are built on first use and kept for the refinement iterations that follow."""
+
+    def __init__(self, a0b0, H, wcomp, bconst, lay):
+        self.a0b0, self.H, self.wcomp, self.bconst, self.lay = a0b0, H, wcomp, bconst, lay
+        self._tensors, self._a16, self._bo = None, None, {}
+        # a differentiable pass will come (training: the last refinement iteration), or nothing can be fused: build the tensors NOW,
+        # under the caller's grad mode -- a first use inside a no-grad refinement iteration would cache tensors without a graph
+        if _needs_grad(a0b0, wcomp, bconst) or not self.can_fuse():
+            self.tensors()
+
+    def can_fuse(self):
+        return (K.CROSS_ATTN_FUSED and _cfg.get_precision() == "bf16" and self.lay.max_C <= K.CROSS_ATTN_FUSED_MAX_C
+                and self.H in (64, 128, 256, 512) and self.wcomp.shape[1] == 8)
+
+    def tensors(self):
+        if self._tensors is None:
+            self._tensors = pair_bias(self.a0b0, self.H, self.wcomp, self.bconst, self.lay)
+        return self._tensors
+
+    def fused(self, k):
+        with torch.no_grad():
+            if self._a16 is None:
+                self._a16 = self.a0b0[:, :self.H].to(torch.bfloat16)
+            bo = self._bo.get(k)
+            if bo is None:
+                bo = self._bo[k] = K.pair_bo_pack(self.a0b0[:, self.H:], self.wcomp[k].float(), self.H, self.lay)
+        return self._a16, bo, self.bconst[k].float().contiguous()
+
+
+def cross_attn_fused(qg, kv, pb, k_blk, mode, lay, scale):
+    """Forward-only gated cross attention of block k_blk with the pair bias recomputed in the kernel (csrc/attn_mfma.hip)."""
+    a16, bo, bc = pb.fused(k_blk)
+    out = torch.zeros((qg.shape[0], 128), dtype=torch.float32, device=qg.device) if mode == 0 else \
+        torch.empty((qg.shape[0], 128), dtype=torch.float32, device=qg.device)
+    return K.cross_attn_fused_fwd(qg[:, :128], kv[:, :128], kv[:, 128:], qg[:, 128:], a16, bo, bc, lay, pb.H, mode, scale, out)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -317,6 +317,23 @@ int fabind_cross_attn_fwd(const float* q, int ldq, const float* k, const float* 
                           int max_nq, float scale, float* out, int ldo, float* lse, int ksplit, float* part, int n_rows,
                           hipStream_t stream);
 
+/* Cross attention with the pair bias recomputed in the kernel (v1 stack; csrc/attn_mfma.hip, "fused" section): a work-group owns 64
+ * protein rows of a complex, contracts their a0 rows (bf16 [rows, lda0], node-indexed) with the complex's packed ligand-side operand
+ * `bo` (fabind_pair_bo_pack) on the matrix cores, forms bias = (lin + c) * sigmoid(gate + c') in registers and runs the attention of
+ * fabind_cross_attn_mfma_fwd with it.  desc = int32[8] per complex {first protein row (node index), P, first ligand row (compact),
+ * C, ...}; mode 0: queries = protein rows (q / gpre / out node-indexed, k / v compact ligand rows); mode 1: queries = ligand atoms
+ * (q / gpre / out compact, k / v node-indexed), `part` = float[n_lig_rows * ceil(max_P / 64) * 4 * 34] scratch.  bconst = the eight
+ * constants (lin0..3, gate0..3).  max_C <= 62.  Replaces RowAttentionBlock.forward incl. its pair-bias Linears (cross_att.py:118-134). */
+int fabind_cross_attn_fused_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* gpre, int ldg,
+                                const void* a0, int lda0, const void* bo, const int* toff, const float* bconst, const int* desc, int B,
+                                int max_P, int max_C, int H, int mode, float scale, float* out, int ldo, float* part, int n_lig_rows,
+                                hipStream_t stream);
+/* bo[(toff[b] * H/32 + ks * T_b + tile) * 512 + lane * 8 + e] = b0[c_index[lig0_b + atom], k] * wcomp[slot_row, k] in MFMA fragment
+ * order (tile = 16 columns = 2 atoms x {lin0, gate0, lin1, gate1, lin2, gate2, lin3, gate3}; T_b = ceil(C_b / 2); toff = prefix sum of
+ * T_b; tile_b[t] = complex of global tile t); wcomp = fp32 [8, H] rows lin0..3, gate0..3 (the composed weights W_{lin|gate} W_o). */
+int fabind_pair_bo_pack(const float* b0, int ldb, const float* wcomp, int H, const int* c_index, const int* desc, const int* toff,
+                        const int* tile_b, int n_tiles, void* out, hipStream_t stream);
+
 /* The same block with QK^T and softmax.V on the matrix cores (v_mfma_f32_16x16x32_bf16: head dim 32 = one instruction per
  * 16-key x 16-query tile; csrc/attn_mfma.hip): identical arguments, results and partials layout; q / k / v / probabilities
  * are rounded to bf16 as MFMA operands, scores, pair bias, softmax statistics and outputs stay fp32.  bias_ld, lin_col and

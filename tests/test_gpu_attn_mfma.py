@@ -99,3 +99,45 @@ def test_mfma_attention_vs_oracle_mha_at_headline_block_shapes(Q, Kn):
     err = float((got.cpu() - ref).abs().max() / ref.abs().max())
     print("Attention (MFMA core) vs oracle.mha at Q=%d K=%d: max rel err %.3e" % (Q, Kn, err))
     assert err < 1e-2 and float((got.cpu() - ref).norm() / ref.norm()) < 4e-3
+
+
+@pytest.mark.parametrize("H", [512, 128])
+@pytest.mark.parametrize("sizes", [[(1500, 40)], [(70, 9), (130, 33), (64, 62), (200, 1)], [(1500, 40), (1100, 27), (333, 41)]])
+def test_fused_attention_recomputes_the_pair_bias_in_the_kernel(sizes, H):
+    """csrc/attn_mfma.hip, fused section: the RowAttention block with its pair bias lin * sigmoid(gate) of z0 = W_o (a_i . b_j) + b_o
+    contracted on the matrix cores inside the attention kernel (64 protein rows per work-group), against the tensor path -- the
+    ragged [pairs, 8] bias GEMM + cross_attn_mfma_fwd -- on the same operands: both blocks (protein queries / ligand queries with the
+    row-tile partials + combine), ragged complexes incl. a one-atom ligand, the 62-atom limit, a 64-row tile boundary."""
+    from fabind_amd import config, engine, ops, synthetic
+    config.set_precision("bf16")
+    try:
+        inp = synthetic.make_stack_batch(sizes, 8, seed=3)
+        lay = engine.Layout(inp["batch_id"].to(DEV), inp["segment_id"].to(DEV))
+        g = torch.Generator().manual_seed(len(sizes) * 100 + H)
+        N = lay.N
+        a0b0 = (torch.randn(N, 2 * H, generator=g) * 0.5).to(DEV)
+        wcomp = (torch.randn(2, 8, H, generator=g) / H ** 0.5).to(DEV)
+        bconst = torch.randn(2, 8, generator=g).to(DEV)
+        scale = 1.0 / math.sqrt(32.0)
+        with torch.no_grad():
+            pb = ops.PairBias(a0b0, H, wcomp, bconst, lay)
+            assert pb.can_fuse()
+            bias = ops.pair_bias(a0b0, H, wcomp, bconst, lay)
+            # protein-query block: q / gate rows node-indexed, k / v compact ligand rows
+            qg_p = torch.randn(N, 256, generator=g).to(DEV)
+            kv_p = torch.randn(lay.sumC, 256, generator=g).to(DEV)
+            ref_p = ops.cross_attn(qg_p, kv_p, bias[0], 0, 4, lay.desc_pf, lay.B, lay.max_P, lay.max_C, scale)
+            got_p = ops.cross_attn_fused(qg_p, kv_p, pb, 0, 0, lay, scale)
+            # ligand-query block: q / gate compact, k / v node-indexed
+            qg_c = torch.randn(lay.sumC, 256, generator=g).to(DEV)
+            kv_c = torch.randn(N, 256, generator=g).to(DEV)
+            ref_c = ops.cross_attn(qg_c, kv_c, bias[1], 0, 4, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
+            got_c = ops.cross_attn_fused(qg_c, kv_c, pb, 1, 1, lay, scale)
+        prot = lay.p_index64
+        e_p, e_c = _rel(got_p[prot], ref_p[prot]), _rel(got_c, ref_c)
+        print("fused attention vs tensor path, sizes %s H=%d: protein-query block %.2e, ligand-query block %.2e" % (sizes, H, e_p, e_c))
+        assert torch.isfinite(got_p).all() and torch.isfinite(got_c).all()
+        assert e_p < 3e-3 and e_c < 3e-3
+        assert float(got_p[lay.c_index64].abs().max()) == 0.0          # rows outside the block stay zero
+    finally:
+        config.set_precision("fp32")
