@@ -161,6 +161,8 @@ def load():
     for nm in ("fabind_gcl_edge_fused_bwd2_set_exp", "fabind_gcl_edge_fused_bwd3_set_exp"):      # development knobs (void)
         getattr(lib, nm).argtypes = [ctypes.c_int]
         getattr(lib, nm).restype = None
+    if os.environ.get("FABIND_EDGE_BWD3_EXP"):           # development knob: experiment mask of the store-wave backward (32 = nt operand stores)
+        lib.fabind_gcl_edge_fused_bwd3_set_exp(int(os.environ["FABIND_EDGE_BWD3_EXP"]))
     if "FABIND_EDGE_BWD_VARIANT" in os.environ:          # development knobs for same-box A/B runs (tools/probes)
         lib.fabind_gcl_edge_fused_bwd_set_variant.argtypes = [ctypes.c_int]
         lib.fabind_gcl_edge_fused_bwd_set_variant(int(os.environ["FABIND_EDGE_BWD_VARIANT"]))

@@ -94,6 +94,23 @@ __device__ __forceinline__ void fe3_wave_store(const bf16_t* sB, bf16_t* __restr
     }
 }
 
+// the same copy with NON-TEMPORAL stores (nt: streamed past the L2's allocation): for the five [E,H] operand tiles, which nothing in this
+// launch reads again -- round 3 experiment: do the operand streams evict the work-group's silu'(pre1) scratch slab (64 KiB, rewritten
+// and re-read every tile) from L2 and turn its round trip into 3.2 GB of HBM traffic per launch?  (knob bit 32 of
+// fabind_gcl_edge_fused_bwd3_set_exp; profiles/r03_edge_bwd_nt.txt has the counters)
+template <int H, int SWZ>
+__device__ __forceinline__ void fe3_wave_store_nt(const bf16_t* sB, bf16_t* __restrict__ g, int e0, int ne, int lane) {
+    constexpr int CH = H / 8;
+    const __amdgpu_buffer_rsrc_t rs = fe_rsrc(g + (size_t)e0 * H, (unsigned)ne * H * 2);
+    const unsigned total = (unsigned)ne * CH;
+#pragma unroll 8
+    for (unsigned q = lane; q < total; q += 64) {
+        const unsigned rw = q / CH, ch = q % CH;
+        const uint4 v = *(const uint4*)&sB[rw * H + ((ch ^ (rw & SWZ)) * 8)];
+        __builtin_amdgcn_raw_buffer_store_b128(fe_u32x4_t{v.x, v.y, v.z, v.w}, rs, (int)((rw * H + ch * 8) * 2), 0, /*aux: nt*/ 2);
+    }
+}
+
 template <int H, int BM, bool DROP, bool DBG>
 __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const FabindEdgeBwdArgs p, const int xf) {
     constexpr int MI = BM / 16;                                   // 16-edge MFMA blocks per wave (the wave owns 64 features of ALL edges)
@@ -130,23 +147,26 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
         for (int tile = t_first; tile < t_end; tile += t_step) {
             const int e0 = tile * BM;
             const int ne = min(BM, p.E - e0);
-            const bool st = !(xf & 1);
+            const bool st = !(xf & 1), nt = (xf & 32) != 0;
+            auto put = [&](bf16_t* dst) {
+                if (nt) fe3_wave_store_nt<H, SWZ>(sX, dst, e0, ne, lane); else fe3_wave_store<H, SWZ>(sX, dst, e0, ne, lane);
+            };
             __syncthreads();                                      // S1 ready
-            if (st) fe3_wave_store<H, SWZ>(sX, (bf16_t*)p.S1, e0, ne, lane);
+            if (st) put((bf16_t*)p.S1);
             fe3_wave_store<H, SWZ>(sD, (bf16_t*)p.d2scratch + (size_t)blockIdx.x * (BM * H), 0, BM, lane);   // silu'(pre1) -> scratch slab
             __syncthreads();                                      // contraction 1 done
             __syncthreads();                                      // M ready
-            if (st) fe3_wave_store<H, SWZ>(sX, (bf16_t*)p.Mm, e0, ne, lane);
+            if (st) put((bf16_t*)p.Mm);
             __syncthreads();                                      // contraction 2 done
             __syncthreads();                                      // dT ready
-            if (st) fe3_wave_store<H, SWZ>(sX, (bf16_t*)p.dT, e0, ne, lane);
+            if (st) put((bf16_t*)p.dT);
             __syncthreads();                                      // contraction 3 done
             __syncthreads();                                      // dP2 ready
-            if (st) fe3_wave_store<H, SWZ>(sX, (bf16_t*)p.dP2, e0, ne, lane);
+            if (st) put((bf16_t*)p.dP2);
             __syncthreads();                                      // contraction 4 done
             __syncthreads();                                      // dS1 ready
             __syncthreads();                                      // dP1 ready
-            if (st) fe3_wave_store<H, SWZ>(sX, (bf16_t*)p.dP1, e0, ne, lane);
+            if (st) put((bf16_t*)p.dP1);
             __syncthreads();                                      // row scan done: the tile may be overwritten
         }
         __syncthreads();                                          // (partial sums)
@@ -487,7 +507,7 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
 
 // development knob: bit mask of work the kernel SKIPS (wrong results; sensitivity timing only): 1 operand stores, 16 no row scan
 static int g_fe_bwd3_exp = 0;
-extern "C" void fabind_gcl_edge_fused_bwd3_set_exp(int m) { g_fe_bwd3_exp = m; }
+extern "C" void fabind_gcl_edge_fused_bwd3_set_exp(int m) { g_fe_bwd3_exp = m; }      // (bit 32 gives correct results: non-temporal operand stores)
 
 // launched from fabind_gcl_edge_fused_bwd (fused_edge.hip), variant 5
 int fe_bwd3_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipStream_t stream) {

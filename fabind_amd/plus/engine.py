@@ -256,12 +256,13 @@ class _LnRows(torch.autograd.Function):
         x, w = ctx.saved_tensors
         R, C = x.shape
         dy = dy if dy.stride(-1) == 1 else dy.contiguous()
-        dx = torch.empty((R, C), dtype=x.dtype, device=x.device)
+        C8 = (C + 7) // 8 * 8                               # rows padded to 8 elements: the adjoint kernel's 16-byte accesses (csrc/norm.hip)
+        dx = torch.empty((R, C8), dtype=x.dtype, device=x.device)[:, :C]
         nblk = max(1, min((R + 3) // 4, 2048))              # work-groups of four waves, rows strided over them: 8 per CU
         dwp = torch.empty((nblk, C), dtype=torch.float32, device=x.device)
         dbp = torch.empty((nblk, C), dtype=torch.float32, device=x.device)
         check(load().fabind_layernorm_rows_bwd(ptr(x), dt_code(x.dtype), x.stride(0), ptr(w), ptr(dy), dt_code(dy.dtype),
-                                               dy.stride(0), 1e-5, R, C, ptr(dx), dt_code(dx.dtype), C, ptr(dwp), ptr(dbp),
+                                               dy.stride(0), 1e-5, R, C, ptr(dx), dt_code(dx.dtype), C8, ptr(dwp), ptr(dbp),
                                                nblk, stream()), "fabind_layernorm_rows_bwd")
         return dx, K.colsum(dwp), K.colsum(dbp), None, None
 

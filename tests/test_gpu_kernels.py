@@ -809,3 +809,32 @@ def test_fused_edge_split_bf16_matches_float64(H, p_drop):
     agg2, s2 = K.gcl_edge_fused_x3(AB.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev), Wc.to(dev),
                                    bc.to(dev), w3.to(dev), N, p_drop=p_drop, seed=seed, rowptr=rp)
     assert torch.equal(agg, agg2) and torch.equal(s, s2)                # deterministic
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("R,C,ld", [(1000, 512, 512), (333, 1025, 1088), (77, 128, 128), (50, 36, 36), (129, 1088, 1088), (64, 96, 200)])
+def test_layernorm_rows_and_adjoint(R, C, ld, dt):
+    """Row LayerNorm of the FABind+ LN-MLPs (model_utils.py:10-74) and its adjoint: the eight-columns-per-lane kernels (16-byte
+    accesses; rows and leading dimensions that are multiples of 8) and the scalar fallback (C = 36), incl. the 1025-wide edge input
+    inside a 1088-wide buffer, against torch's layer_norm and its autograd."""
+    from fabind_amd.plus import engine as pe
+    dev = _dev()
+    g = torch.Generator().manual_seed(R + C)
+    xb = torch.randn(R, ld, generator=g).to(dt)
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    cot = torch.randn(R, C, generator=g)
+    xr = xb[:, :C].float().clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (C,), wr, br, 1e-5)
+    (ref * cot).sum().backward()
+    xd = xb.to(dev)[:, :C].requires_grad_(True)
+    wd, bd = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    pad = (C + 7) // 8 * 8
+    y = pe.ln_rows(xd, wd, bd, torch.float32, pad)
+    assert y.shape[1] == pad and (pad == C or float(y[:, C:].abs().max()) == 0.0)
+    tol = 2e-2 if dt == torch.bfloat16 else 1e-4
+    assert (y[:, :C].detach().cpu() - ref.detach()).abs().max() <= 1e-4 * max(1.0, float(ref.abs().max()))
+    (y[:, :C] * cot.to(dev)).sum().backward()
+    assert (xd.grad.float().cpu() - xr.grad).abs().max() <= tol * max(1.0, float(xr.grad.abs().max()))
+    assert (wd.grad.cpu() - wr.grad).abs().max() <= 1e-3 * max(1.0, float(wr.grad.abs().max()))
+    assert (bd.grad.cpu() - br.grad).abs().max() <= 1e-3 * max(1.0, float(br.grad.abs().max()))

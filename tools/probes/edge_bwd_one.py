@@ -1,4 +1,4 @@
-"""One variant of the fused edge backward at the bench shape, 6 launches (for rocprofv3 --pmc): argv[1] = variant (0 / 1)."""
+"""One variant of the fused edge backward at the bench shape, 6 launches (for rocprofv3 --pmc): argv[1] = variant (0 .. 5), argv[2] = experiment mask."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -19,6 +19,8 @@ W2 = (torch.randn(H, H, device=dev) / H ** 0.5).bfloat16(); Wc = (torch.randn(H,
 ds = torch.randn(E, device=dev); dagg = torch.randn(N, H, device=dev)
 colptr, perm = g.ctx_by_col()
 _lib.load().fabind_gcl_edge_fused_bwd_set_variant(int(sys.argv[1]))
+if len(sys.argv) > 2:                                      # experiment mask of the store-wave kernel (32 = non-temporal operand stores)
+    _lib.load().fabind_gcl_edge_fused_bwd3_set_exp(int(sys.argv[2]))
 W2p, Wcp = K.pack_frag(W2), K.pack_frag(Wc)
 for _ in range(6):
     K.gcl_edge_fused_bwd(AB, H, g.row_ctx, g.col_ctx, rh, w_r, W2, b2, Wc, bc, w3, ds, dagg, colptr, perm)
