@@ -711,9 +711,15 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
                                                                       const bf16_t* __restrict__ a0, int lda0,
                                                                       const bf16_t* __restrict__ bo, const int* __restrict__ toff,
                                                                       const float* __restrict__ bconst, const int* __restrict__ desc,
-                                                                      float scale, float* out, int ldo, float* part, int nsplit) {
+                                                                      float scale, float* out, int ldo, float* part, int nsplit, int B) {
     constexpr int SWZ = (H >= 128) ? 15 : 7;
     constexpr int TILE_BYTES = (CF_ROWS * H * 2 > 65536) ? CF_ROWS * H * 2 : 65536;
+    // XCD-aware work-group order (1-D grid; consecutive ids go round-robin to the 8 XCDs): ALL row tiles of a complex run on the XCD
+    // (complex % 8), so the complex's packed operand Bo (336 KiB at 41 ligand-side nodes) is fetched into that XCD's L2 once and hit by
+    // the other tiles -- with tile-major ids every XCD streamed every complex's Bo from HBM and the k-loop ran at HBM latency
+    const int cplx = (int)(blockIdx.x >> 3) / nsplit * 8 + (int)(blockIdx.x & 7);
+    const int rtile = (int)(blockIdx.x >> 3) % nsplit;
+    if (cplx >= B) return;
     // bias tile: MODE 0 [atom][row][4] (lanes of a wave = rows: consecutive 16-byte reads), MODE 1 [row][CF_KEYS + 1][4] (lanes = atoms)
     constexpr int LDB1 = (CF_KEYS + 1) * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -721,15 +727,15 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
     float* sB = (float*)smem;                                       // over the a0 tile once the contraction is done
     unsigned char* sK = smem + TILE_BYTES;
     unsigned char* sVt = sK + CM_KC * 256;
-    const int* ds = desc + blockIdx.y * 8;
+    const int* ds = desc + cplx * 8;
     const int prow0 = ds[0], P = ds[1], lig0 = ds[2], C = ds[3];
-    const int m0 = blockIdx.x * CF_ROWS;
+    const int m0 = rtile * CF_ROWS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, kq = lane >> 4;
     if (m0 >= P) {
         if (MODE == 1) {                                            // neutral partials of a row tile past the end of this complex
             for (int t = tid; t < C * 4; t += 256) {
-                float* pp = part + (((size_t)(lig0 + (t >> 2)) * nsplit + blockIdx.x) * 4 + (t & 3)) * 34;
+                float* pp = part + (((size_t)(lig0 + (t >> 2)) * nsplit + rtile) * 4 + (t & 3)) * 34;
 #pragma unroll
                 for (int d = 0; d < 32; ++d) pp[d] = 0.f;
                 pp[32] = -INFINITY; pp[33] = 0.f;
@@ -751,8 +757,8 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
     __syncthreads();
 
     // ---- A2: bias contraction.  T column tiles (2 atoms each) are dealt to the 4 waves in contiguous ranges of <= 8 (two passes of 4)
-    const int T = toff[blockIdx.y + 1] - toff[blockIdx.y];
-    const bf16_t* bo_c = bo + (size_t)toff[blockIdx.y] * (H / 32) * 512;
+    const int T = toff[cplx + 1] - toff[cplx];
+    const bf16_t* bo_c = bo + (size_t)toff[cplx] * (H / 32) * 512;
     const int per = (T + 3) / 4;
     const int t0 = wave * per, t1 = min(T, t0 + per);
     f32x4_t acc0[4][4], acc1[4][4];
@@ -881,7 +887,7 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
     if (MODE == 1) {       // un-normalised partial of this row tile: [atom][tile][head][34] = o[32], m, l
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
-            float* pp = part + (((size_t)(lig0 + qi) * nsplit + blockIdx.x) * 4 + h) * 34;
+            float* pp = part + (((size_t)(lig0 + qi) * nsplit + rtile) * 4 + h) * 34;
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -918,8 +924,8 @@ extern "C" int fabind_cross_attn_fused_fwd(const float* q, int ldq, const float*
     do {                                                                                                                           \
         static bool set_ = false;                                                                                                  \
         if (!set_) { (void)hipFuncSetAttribute((const void*)cross_attn_fused_fwd_kernel<HH, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
-        hipLaunchKernelGGL((cross_attn_fused_fwd_kernel<HH, MM>), dim3(nsplit, B), dim3(256), lds, stream, q, ldq, k, v, ldkv, gpre, ldg, \
-                           (const bf16_t*)a0, lda0, (const bf16_t*)bo, toff, bconst, desc, scale, out, ldo, part, nsplit);        \
+        hipLaunchKernelGGL((cross_attn_fused_fwd_kernel<HH, MM>), dim3(8 * nsplit * ((B + 7) / 8)), dim3(256), lds, stream, q, ldq, k, v, \
+                           ldkv, gpre, ldg, (const bf16_t*)a0, lda0, (const bf16_t*)bo, toff, bconst, desc, scale, out, ldo, part, nsplit, B); \
     } while (0)
 #define CF_LAUNCH_H(MM) do { if (H == 512) CF_LAUNCH(512, MM); else if (H == 256) CF_LAUNCH(256, MM); else if (H == 128) CF_LAUNCH(128, MM); else CF_LAUNCH(64, MM); } while (0)
     if (mode == 0) CF_LAUNCH_H(0);

@@ -429,7 +429,9 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     scale = 1.0 / math.sqrt(32.0)
     # forward-only bf16 passes recompute the pair bias inside the attention kernels (ops.PairBias.fused); everything else reads the
     # [pairs, 8] bias tensors
-    fused = fast and isinstance(pairbias, ops.PairBias) and pairbias.can_fuse()
+    # (when the bias tensors exist anyway -- a training call builds them for its differentiable pass -- the no-grad refinement
+    #  iterations read them too: recomputing the contraction per iteration measured 8 % slower at n_iter = 8)
+    fused = fast and isinstance(pairbias, ops.PairBias) and pairbias.can_fuse() and not pairbias.has_tensors()
     if not fused:
         pbt = pairbias.tensors() if isinstance(pairbias, ops.PairBias) else pairbias
         bias_p, bias_c = pbt[2 * layer], pbt[2 * layer + 1]

@@ -1300,6 +1300,9 @@ class PairBias:
         return (K.CROSS_ATTN_FUSED and _cfg.get_precision() == "bf16" and self.lay.max_C <= K.CROSS_ATTN_FUSED_MAX_C
                 and self.H in (64, 128, 256, 512) and self.wcomp.shape[1] == 8)
 
+    def has_tensors(self):
+        return self._tensors is not None
+
     def tensors(self):
         if self._tensors is None:
             self._tensors = pair_bias(self.a0b0, self.H, self.wcomp, self.bconst, self.lay)

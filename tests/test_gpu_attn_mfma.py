@@ -102,12 +102,13 @@ def test_mfma_attention_vs_oracle_mha_at_headline_block_shapes(Q, Kn):
 
 
 @pytest.mark.parametrize("H", [512, 128])
-@pytest.mark.parametrize("sizes", [[(1500, 40)], [(70, 9), (130, 33), (64, 62), (200, 1)], [(1500, 40), (1100, 27), (333, 41)]])
+@pytest.mark.parametrize("sizes", [[(1500, 40)], [(70, 9), (130, 33), (63, 61), (200, 1)], [(1500, 40), (1100, 27), (333, 41)]])
 def test_fused_attention_recomputes_the_pair_bias_in_the_kernel(sizes, H):
     """csrc/attn_mfma.hip, fused section: the RowAttention block with its pair bias lin * sigmoid(gate) of z0 = W_o (a_i . b_j) + b_o
     contracted on the matrix cores inside the attention kernel (64 protein rows per work-group), against the tensor path -- the
     ragged [pairs, 8] bias GEMM + cross_attn_mfma_fwd -- on the same operands: both blocks (protein queries / ligand queries with the
-    row-tile partials + combine), ragged complexes incl. a one-atom ligand, the 62-atom limit, a 64-row tile boundary."""
+    row-tile partials + combine), ragged complexes incl. a one-atom ligand, the limit of 62 ligand-side nodes (61 atoms + the global
+    node), a protein side of exactly one 64-row tile (63 residues + the global node)."""
     from fabind_amd import config, engine, ops, synthetic
     config.set_precision("bf16")
     try:

@@ -68,6 +68,7 @@ def test_model_forward_loss_and_gradients(stage, name, gate_mode):
     # round-off argument, not from the gap.)  Before this check such parameters were skipped silently.
     floor = float(np.finfo(np.float32).eps) * max(float(g[k]) for k in g if k.startswith(p + "gradnorm_"))
     checked, bad, missing = 0, [], []
+    gmax_norm = max(float(g[k]) for k in g if k.startswith(p + "gradnorm_"))
     for n, prm in m.named_parameters():
         key = p + "gradnorm_" + n
         if key not in g:
@@ -82,8 +83,11 @@ def test_model_forward_loss_and_gradients(stage, name, gate_mode):
         smp = g[p + "gradsmp_" + n]
         e1 = abs(float(got.norm()) - ref_n)
         e2 = np.abs(got[idx].numpy() - smp).max()
-        gtol = 5e-3 if gate_mode == "fp32" else 3e-2        # bf16x3 gradients: see tests/test_gpu_stack.py::test_stack_gradients_match_reference
-        if e1 > gtol * ref_n + 1e-6 or e2 > gtol * max(np.abs(smp).max(), ref_n / max(got.numel(), 1) ** 0.5) + 1e-7:
+        # bf16x3 gradients (tests/test_gpu_stack.py::test_stack_gradients_match_reference): 3e-2 of the tensor + 1e-4 of the largest
+        # gradient norm of the model -- its weight gradients are contracted on bf16 roundings, which a tensor 1e4 times smaller than the
+        # largest one (the 1e-5-sized pair-path biases here) sees as an absolute, not a relative, error
+        gtol, gabs = (5e-3, 0.0) if gate_mode == "fp32" else (3e-2, 1e-4 * gmax_norm)
+        if e1 > gtol * ref_n + 1e-6 + gabs or e2 > gtol * max(np.abs(smp).max(), ref_n / max(got.numel(), 1) ** 0.5) + 1e-7 + gabs:
             bad.append((n, e1, ref_n, float(e2)))
         checked += 1
     n_ref = sum(1 for k in g if k.startswith(p + "gradnorm_") and float(g[k]) > floor)

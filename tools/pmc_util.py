@@ -6,7 +6,7 @@ import csv
 import sys
 from collections import defaultdict
 
-KEEP = ("cross_attn_mfma", "gcl_edge_fused", "gemm_bf16_pipe", "gemm_tn_bf16", "inter_attn", "cross_attn_fwd", "cross_attn_bwd")
+KEEP = ("cross_attn_mfma", "cross_attn_fused", "gemm_x3", "pair_update_fused", "gcl_edge_fused", "gemm_bf16_pipe", "gemm_tn_bf16", "inter_attn", "cross_attn_fwd", "cross_attn_bwd")
 
 
 def main():
