@@ -855,6 +855,70 @@ extern "C" int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const 
     return 0;
 }
 
+// The same adjoint for the ALL-PAIRS list of a batch (FABind+ threads the pair embedding over every protein x ligand pair: pair
+// (b, i, j) sits at pair_off[b] + i * C_b + j, fabind_amd/plus/engine.py: PairList) without float atomics: one wave per node; a protein
+// node i sums its C_b CONTIGUOUS rows against the ligand factors b[j], a ligand node j its P_b rows (stride C_b) against the protein
+// factors a[i].  Every output element has one writer and a fixed summation order; the atomics form took 1.4 ms per launch on average
+// (4.3 ms at W = 512) in the FABind+ training step because a ligand node's ~250 pairs all hit the same W addresses.
+// T = (a | b) rows of width ld; d T gets d a in [0, W) of protein rows and d b in [W, 2W) of ligand rows (the other halves untouched).
+__global__ __launch_bounds__(256) void pair_hadamard_bwd_grid_kernel(const void* __restrict__ dhd, int dt, int ldh,
+                                                                    const float* __restrict__ T, int ldt, int W,
+                                                                    const int* __restrict__ node_off, const int* __restrict__ c_cnt,
+                                                                    const int* __restrict__ node_b, const int* __restrict__ desc_p,
+                                                                    int n_nodes, float* dT, int lddt) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_nodes) return;
+    const int b = node_b[n];
+    const int off = node_off[b], C = c_cnt[b], P = node_off[b + 1] - off - C;
+    const long po = (long)(unsigned)desc_p[b * 8 + 4] | ((long)desc_p[b * 8 + 5] << 32);
+    const int loc = n - off;
+    const bool lig = loc < C;
+    // rows of this node: ligand j = loc: pairs po + i * C + j (i < P), partner protein node off + C + i, its factor a = T[.][0, W)
+    //                    protein i = loc - C: pairs po + i * C + j (j < C), partner ligand node off + j, its factor b = T[.][W, 2W)
+    const int cnt = lig ? P : C;
+    const long first = lig ? po + loc : po + (long)(loc - C) * C;
+    const int pstep = lig ? C : 1;
+    const int partner0 = lig ? off + C : off;
+    const int src = lig ? 0 : W, dst = lig ? W : 0;
+    const int LPR = W / 4;                                    // lanes per row (float4 each)
+    if (LPR >= 64) {
+        for (int c = lane * 4; c < W; c += 256) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < cnt; ++k) {
+                const float4 g = ld4_any(dhd, dt, (size_t)(first + (long)k * pstep) * ldh + c);
+                const float4 v = *(const float4*)(T + (size_t)(partner0 + k) * ldt + src + c);
+                acc.x += g.x * v.x; acc.y += g.y * v.y; acc.z += g.z * v.z; acc.w += g.w * v.w;
+            }
+            *(float4*)(dT + (size_t)n * lddt + dst + c) = acc;
+        }
+    } else {                                                  // narrow rows: 64 / LPR rows of the node per wave iteration, combined at the end
+        const int G = 64 / LPR, grp = lane / LPR, c = (lane % LPR) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = grp; k < cnt; k += G) {
+            const float4 g = ld4_any(dhd, dt, (size_t)(first + (long)k * pstep) * ldh + c);
+            const float4 v = *(const float4*)(T + (size_t)(partner0 + k) * ldt + src + c);
+            acc.x += g.x * v.x; acc.y += g.y * v.y; acc.z += g.z * v.z; acc.w += g.w * v.w;
+        }
+        for (int o = LPR; o < 64; o <<= 1) {                  // fixed combination order of the G partial sums
+            acc.x += __shfl_xor(acc.x, o, 64); acc.y += __shfl_xor(acc.y, o, 64);
+            acc.z += __shfl_xor(acc.z, o, 64); acc.w += __shfl_xor(acc.w, o, 64);
+        }
+        if (grp == 0) *(float4*)(dT + (size_t)n * lddt + dst + c) = acc;
+    }
+}
+extern "C" int fabind_pair_hadamard_bwd_grid(const void* dhd, int dt, int ldh, const float* T, int ldt, int W, const int* node_off,
+                                             const int* c_cnt, const int* node_b, const int* desc_p, int n_nodes, float* dT, int lddt,
+                                             hipStream_t stream) {
+    if (n_nodes <= 0) return 0;
+    FB_REQUIRE(W % 4 == 0 && W >= 4 && (W >= 256 || 256 % W == 0) && ldt % 4 == 0 && lddt % 4 == 0 && ldh % 4 == 0,
+               "fabind_pair_hadamard_bwd_grid: W a multiple of 4 that divides 256 (or >= 256), strides % 4");
+    hipLaunchKernelGGL(pair_hadamard_bwd_grid_kernel, dim3((n_nodes + 3) / 4), dim3(256), 0, stream, dhd, dt, ldh, T, ldt, W, node_off,
+                       c_cnt, node_b, desc_p, n_nodes, dT, lddt);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // inter-graph attention backward.
 // Pass A (waves stride over rows): softmax adjoint per row -> dlogit[e], dcp[e], dd[e], drh[e], dq[r],

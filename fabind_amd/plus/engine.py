@@ -304,8 +304,8 @@ class _PairHad1(torch.autograd.Function):
     """hd[e] = T[p_node[e], :Hh] * T[c_node[e], Hh:2Hh] with the atomic adjoint kernel of the v1 path."""
 
     @staticmethod
-    def forward(ctx, T, Hh, p_node, c_node, out_dtype):
-        ctx.Hh = Hh
+    def forward(ctx, T, Hh, p_node, c_node, out_dtype, lay=None):
+        ctx.Hh, ctx.lay = Hh, lay
         ctx.save_for_backward(T, p_node, c_node)
         return _pair_hadamard_call(T, Hh, p_node, c_node, out_dtype)
 
@@ -313,21 +313,36 @@ class _PairHad1(torch.autograd.Function):
     def backward(ctx, dhd):
         from .._lib import check, dt_code, load, ptr, stream
         T, p_node, c_node = ctx.saved_tensors
-        Hh = ctx.Hh
+        Hh, lay = ctx.Hh, ctx.lay
         dhd = dhd.contiguous()
         dT = torch.zeros_like(T)
+        if (lay is not None and PAIRHAD_GRID and T.dtype == torch.float32 and p_node.shape[0] == lay.n_pairs and Hh % 4 == 0
+                and (Hh >= 256 or 256 % Hh == 0) and T.stride(0) % 4 == 0 and dhd.stride(0) % 4 == 0):
+            # the list is the batch's full protein x ligand grid: deterministic row walk instead of float atomics (csrc/bwd.hip)
+            nb = getattr(lay, "_node_b", None)
+            if nb is None:
+                nb = lay._node_b = torch.repeat_interleave(torch.arange(lay.B, dtype=torch.int32, device=T.device),
+                                                           (lay.node_off[1:] - lay.node_off[:-1]).long())
+            check(load().fabind_pair_hadamard_bwd_grid(ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(T), T.stride(0), Hh,
+                                                       ptr(lay.node_off), ptr(lay.c_cnt), ptr(nb), ptr(lay.desc_p), lay.N, ptr(dT),
+                                                       dT.stride(0), stream()), "fabind_pair_hadamard_bwd_grid")
+            return dT, None, None, None, None, None
         a0, b0 = T[:, :Hh], T[:, Hh:2 * Hh]
         da, db = dT[:, :Hh], dT[:, Hh:2 * Hh]
         check(load().fabind_pair_hadamard_bwd(ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(a0), ptr(b0), T.stride(0), Hh,
                                               ptr(a0), ptr(b0), T.stride(0), 0, ptr(p_node), ptr(c_node), p_node.shape[0], ptr(da),
                                               ptr(db), dT.stride(0), ptr(da), ptr(db), dT.stride(0), stream()),
               "fabind_pair_hadamard_bwd")
-        return dT, None, None, None, None
+        return dT, None, None, None, None, None
 
 
-def pair_had(T, Hh, p_node, c_node, out_dtype):
+PAIRHAD_GRID = os.environ.get("FABIND_PAIRHAD_GRID", "1") == "1"     # adjoint of the all-pairs Hadamard as a row walk (no float atomics)
+
+
+def pair_had(T, Hh, p_node, c_node, out_dtype, lay=None):
+    """lay: the batch layout when (p_node, c_node) is its complete pair list (PairList order) -- selects the atomics-free adjoint."""
     if ops.needs_grad(T):
-        return _PairHad1.apply(T, Hh, p_node, c_node, out_dtype)
+        return _PairHad1.apply(T, Hh, p_node, c_node, out_dtype, lay)
     return _pair_hadamard_call(T, Hh, p_node, c_node, out_dtype)
 
 
@@ -460,7 +475,7 @@ def cross_part(p, h, z, lay, pairs, pd=0.0, bias=None, p_next=None):
                                            pf["ln_b"], pf["eps"], pf["W1p"], pf["b1"], pf["W2p"], pf["b2"],
                                            nf["Wbp"] if nf else None, nf["bb"] if nf else None, pd, seed)
     else:
-        hd32 = pair_had(ab32, 64, pairs.p_node, pairs.c_node, ad)                                    # [pairs, 64]
+        hd32 = pair_had(ab32, 64, pairs.p_node, pairs.c_node, ad, lay)                               # [pairs, 64]
         z1 = ops.linear(hd32, p["W_o32"], p["b_o32"], residual=z.float() if z.dtype != torch.float32 else z, out_dtype=ad)
         z = ln_mlp(p["tr_z"], z1, True, out_dtype=ad, pdrop=pd)
     return h, z, bias_next
@@ -552,7 +567,7 @@ def stack_forward(model, X, Hin, batch_id, segment_id, mask, is_global, compound
     Hin = Hin.float().contiguous()
     ad = ops.act_dtype()
     a0b0 = ops.linear(Hin, P["W_ab0"], P["b_ab0"])                                                   # [N, 2H]
-    hd0 = pair_had(a0b0, H, pairs.p_node, pairs.c_node, ad)
+    hd0 = pair_had(a0b0, H, pairs.p_node, pairs.c_node, ad, lay)
     z0 = ops.linear(hd0, P["W_o0"], P["b_o0"], out_dtype=ad)                                         # [pairs, H]
     cut_intra, cut_inter = float(model.extract_edges.intra_cutoff), float(model.extract_edges.inter_cutoff)
     Hout = z = None

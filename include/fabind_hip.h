@@ -491,6 +491,13 @@ int fabind_batched_transpose_pad(const void* in, int ld_in, const int* desc, int
 int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const float* a0, const float* b0, int ld0, int H,
                              const float* a1, const float* b1, int ld1, int H2, const int* red_p, const int* red_c, int n,
                              float* da0, float* db0, int ldd0, float* da1, float* db1, int ldd1, hipStream_t stream);
+/* Adjoint of the pair Hadamard over the ALL-PAIRS list of a batch (pair (b, i, j) at pair_off[b] + i * C_b + j: FABind+ threads the
+ * pair embedding over every protein x ligand pair, FABind_plus/fabind/models/model_utils.py:96-146) without float atomics: one wave per
+ * node, one writer per element.  T = (a | b) fp32 rows; dT receives d a in columns [0, W) of protein rows and d b in [W, 2W) of ligand
+ * rows.  node_b[n] = complex of node n; desc_p = the layout's int32[8] block descriptors (pair offset in words 4, 5). */
+int fabind_pair_hadamard_bwd_grid(const void* dhd, int dt, int ldh, const float* T, int ldt, int W, const int* node_off,
+                                  const int* c_cnt, const int* node_b, const int* desc_p, int n_nodes, float* dT, int lddt,
+                                  hipStream_t stream);
 /* fabind_pair_hadamard_bwd over the inter graph's reduced pairs without float atomics: one wave per node walks the inter edges of its own
  * row (pair = red_idx[e], partner = col[e]); t0 = (a | b) [N, 2H], t1 = (a | b) [N, 2 H2] (H2 may be 0), the sums are ADDED to d0 / d1
  * in the same layout.  Deterministic summation order. */

@@ -58,12 +58,11 @@ def _grad_rows(named_params, ref_grads):
 
 
 def _print_rows(title, rows):
-    num = sum((r[3] * 1.0) ** 2 for r in rows)
     print("%s: %d parameter tensors compared; worst (max-rel, name, |ref|max / largest, l2-rel):" % (title, len(rows)))
     for r_ in rows[:5]:
         print("    %.3e  %s  %.2e  %.3e" % r_)
-    l2 = sorted(r[3] for r in rows)
-    print("    per-tensor l2-rel: median %.3e, worst %.3e (rms over tensors %.3e)" % (l2[len(l2) // 2], l2[-1], (num / len(rows)) ** 0.5))
+    l2 = sorted(r[3] for r in rows if r[2] >= 1e-6)        # (tensors at the round-off floor have no meaningful relative error)
+    print("    per-tensor l2-rel over the %d tensors above 1e-6 of the largest gradient: median %.3e, worst %.3e" % (len(l2), l2[len(l2) // 2], l2[-1]))
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
@@ -108,7 +107,7 @@ def _iabnet_oracle(stage):
 
 TUPLE = ((2, "y_pred"), (3, "y_pred_by_coords"), (4, "pocket_cls_pred"), (8, "pred_pocket_center"), (9, "dis_map"))
 # bf16 gaps measured at the first run of this file (ligand RMSD in A / relative loss gap); asserted at 2x
-IAB_BF16_BOUND = {1: (4e-2, 2e-3), 2: (4e-2, 2e-3)}
+IAB_BF16_BOUND = {1: (1.2e-3, 1e-5), 2: (1.3e-3, 1e-5)}     # measured 5.9e-4 / 6.4e-4 A, loss 2.4e-6 / 6.9e-8
 
 
 @pytest.mark.parametrize("stage", [1, 2])
@@ -194,7 +193,7 @@ def _plus_stack(n_iter):
 
 
 # measured at the first run of this file: bf16 ligand RMSD gap (A), asserted at 2x
-PLUS_STACK_BF16_BOUND = {1: 1e-1, 2: 2e-1}
+PLUS_STACK_BF16_BOUND = {1: 1.8e-2, 2: 3.2e-2}                      # measured 8.7e-3 / 1.6e-2 A
 
 
 @pytest.mark.parametrize("n_iter", [1, 2])
@@ -280,7 +279,7 @@ def _plus_oracle(stage):
 PLUS_NAMES = ["coords", "compound_batch", "y_pred", "y_pred_by_coords", "pocket_cls_pred", "pocket_cls", "protein_out_mask_whole",
               "protein_coords_batched_whole", "pred_pocket_center", "dis_map", "keepNode_less_5", "pocket_radius_pred",
               "pocket_center_bias"]
-PLUS_BF16_BOUND = {1: (2e-1, 2e-2), 2: (2e-1, 2e-2)}
+PLUS_BF16_BOUND = {1: (3.7e-2, 1e-3), 2: (4e-2, 1e-3)}      # measured 1.8e-2 / 2.0e-2 A, loss 4.6e-4 / 1.4e-4
 
 
 @pytest.mark.parametrize("stage", [1, 2])
