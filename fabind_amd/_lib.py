@@ -90,8 +90,8 @@ SIGNATURES = {
     "fabind_las_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp],
     "fabind_select_rows": [_vp, _vp, _vp, _i, _i, _vp, _vp],
     "fabind_add": [_vp, _vp, _vp, _l, _vp],
-    "fabind_mul_dact": [_vp, _i, _vp, _i, _i, _vp, _i, _l, _vp],
-    "fabind_mul_dact_colsum": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp],
+    "fabind_mul_dact": [_vp, _i, _vp, _i, _i, _vp, _i, _l, _f, _vp],
+    "fabind_mul_dact_colsum": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _f, _vp],
     "fabind_rowdot_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "fabind_edge_geom_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "fabind_gcl_pre_bwd": [_vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp],

@@ -8,23 +8,23 @@
 // ------------------------------------------------------------------------------------------------
 // out = dy * act'(y)   (elementwise; for ReLU the derivative can be taken at the output)
 // ------------------------------------------------------------------------------------------------
-__global__ void mul_dact_kernel(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, long n) {
+__global__ void mul_dact_kernel(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, long n, float scale) {
     long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {   // 4 elements per thread (8/16-byte accesses)
         float4 g = ld4_any(dy, dy_dt, i), v = ld4_any(y, y_dt, i);
-        st4_any(out, out_dt, i, make_float4(g.x * apply_dact(v.x, act), g.y * apply_dact(v.y, act),
-                                            g.z * apply_dact(v.z, act), g.w * apply_dact(v.w, act)));
+        st4_any(out, out_dt, i, make_float4(scale * g.x * apply_dact(v.x, act), scale * g.y * apply_dact(v.y, act),
+                                            scale * g.z * apply_dact(v.z, act), scale * g.w * apply_dact(v.w, act)));
     } else {
-        for (; i < n; ++i) st_any(out, out_dt, i, ld_any(dy, dy_dt, i) * apply_dact(ld_any(y, y_dt, i), act));
+        for (; i < n; ++i) st_any(out, out_dt, i, scale * ld_any(dy, dy_dt, i) * apply_dact(ld_any(y, y_dt, i), act));
     }
 }
-extern "C" int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, long n,
+extern "C" int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, long n, float scale,
                                hipStream_t stream) {
     if (n <= 0) return 0;
     FB_REQUIRE(((uintptr_t)dy % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)out % 16 == 0), "fabind_mul_dact: 16-byte alignment");
     long nt = (n + 3) / 4;
     hipLaunchKernelGGL(mul_dact_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, stream, dy, dy_dt, y, y_dt, act,
-                       out, out_dt, n);
+                       out, out_dt, n, scale);
     FB_CHECK_LAUNCH();
     return 0;
 }
@@ -33,7 +33,7 @@ extern "C" int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_d
 // chunk of rows, 4 row-lanes with 4 independent row loads in flight, fixed-order combine (deterministic).
 __global__ __launch_bounds__(256) void mul_dact_colsum_kernel(const void* __restrict__ dy, int dy_dt, const void* __restrict__ y,
                                                               int y_dt, int act, void* __restrict__ out, int out_dt, int R, int C,
-                                                              float* scratch, int rows_per) {
+                                                              float* scratch, int rows_per, float scale) {
     __shared__ float4 part[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + lane * 4;
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(256) void mul_dact_colsum_kernel(const void* __rest
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float4 o = make_float4(g[u].x * apply_dact(v[u].x, act), g[u].y * apply_dact(v[u].y, act),
-                                             g[u].z * apply_dact(v[u].z, act), g[u].w * apply_dact(v[u].w, act));
+                const float4 o = make_float4(scale * g[u].x * apply_dact(v[u].x, act), scale * g[u].y * apply_dact(v[u].y, act),
+                                             scale * g[u].z * apply_dact(v[u].z, act), scale * g[u].w * apply_dact(v[u].w, act));
                 st4_any(out, out_dt, (size_t)(r + 4 * u) * C + c, o);
                 s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
             }
@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256) void mul_dact_colsum_kernel(const void* __rest
         for (; r < r1; r += 4) {
             const float4 g = ld4_any(dy, dy_dt, (size_t)r * C + c);
             const float4 v = y ? ld4_any(y, y_dt, (size_t)r * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 o = make_float4(g.x * apply_dact(v.x, act), g.y * apply_dact(v.y, act), g.z * apply_dact(v.z, act),
-                                         g.w * apply_dact(v.w, act));
+            const float4 o = make_float4(scale * g.x * apply_dact(v.x, act), scale * g.y * apply_dact(v.y, act),
+                                         scale * g.z * apply_dact(v.z, act), scale * g.w * apply_dact(v.w, act));
             st4_any(out, out_dt, (size_t)r * C + c, o);
             s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
         }
@@ -78,14 +78,14 @@ __global__ __launch_bounds__(256) void mul_dact_colsum_kernel(const void* __rest
 #define SUMC_GRID(C_) dim3(((C_) + 63) / 64)
 __global__ void sum_chunks_kernel(const float* __restrict__ scratch, float* out, int C, int nchunk);
 extern "C" int fabind_mul_dact_colsum(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt,
-                                      int R, int C, float* colsum, float* scratch, int nchunk, hipStream_t stream) {
+                                      int R, int C, float* colsum, float* scratch, int nchunk, float scale, hipStream_t stream) {
     if (R <= 0 || C <= 0) return 0;
     FB_REQUIRE(C % 4 == 0 && nchunk >= 1, "fabind_mul_dact_colsum: C % 4 == 0, nchunk >= 1");
     FB_REQUIRE(((uintptr_t)dy % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)out % 16 == 0),
                "fabind_mul_dact_colsum: 16-byte alignment");
     const int rows_per = (R + nchunk - 1) / nchunk;
     hipLaunchKernelGGL(mul_dact_colsum_kernel, dim3((C + 255) / 256, nchunk), dim3(256), 0, stream, dy, dy_dt, y, y_dt, act, out,
-                       out_dt, R, C, scratch, rows_per);
+                       out_dt, R, C, scratch, rows_per, scale);
     hipLaunchKernelGGL(sum_chunks_kernel, SUMC_GRID(C), dim3(SUMC_BLOCK), 0, stream, scratch, colsum, C, nchunk);
     FB_CHECK_LAUNCH();
     return 0;

@@ -150,26 +150,26 @@ def _weight_grad_f32(dpre, x, act_pro, x2, out_dtype):
 # Under autograd the kernel also emits act_epi'(pre-activation) (SiLU) so that backward is a plain multiply,
 # and fp32 activations are fed to the MFMA kernels as bf16 copies in bf16 mode (also what is saved).
 # ------------------------------------------------------------------------------------------------
-def _mul_dact(dy, aux, act, out_dtype):
+def _mul_dact(dy, aux, act, out_dtype, scale=1.0):
     out = torch.empty(dy.shape, dtype=out_dtype, device=dy.device)
     a = aux if aux is not None else dy
     check(load().fabind_mul_dact(ptr(dy), dt_code(dy.dtype), ptr(a), dt_code(a.dtype), act, ptr(out), dt_code(out_dtype),
-                                 dy.numel(), stream()), "fabind_mul_dact")
+                                 dy.numel(), float(scale), stream()), "fabind_mul_dact")
     return out
 
 
 FUSE_DB = os.environ.get("FABIND_FUSE_DB", "1") == "1"
 
 
-def _mul_dact_colsum(dy, aux, act, out_dtype):
-    """(dy * act'(aux), its column sums) in one pass (bias gradient fused into the activation adjoint / cast)."""
+def _mul_dact_colsum(dy, aux, act, out_dtype, scale=1.0):
+    """(scale * dy * act'(aux), its column sums) in one pass (bias gradient fused into the activation adjoint / cast)."""
     R, C = dy.shape
     out = torch.empty((R, C), dtype=out_dtype, device=dy.device)
     nchunk = max(1, min(4096, (R + 63) // 64))           # >= 2 blocks per SIMD at C = 512: the pass is latency-bound
     scratch = torch.empty((nchunk, C), dtype=torch.float32, device=dy.device)
     db = torch.empty(C, dtype=torch.float32, device=dy.device)
     check(load().fabind_mul_dact_colsum(ptr(dy), dt_code(dy.dtype), ptr(aux), dt_code(aux.dtype) if aux is not None else 0,
-                                        act, ptr(out), dt_code(out_dtype), R, C, ptr(db), ptr(scratch), nchunk, stream()),
+                                        act, ptr(out), dt_code(out_dtype), R, C, ptr(db), ptr(scratch), nchunk, float(scale), stream()),
           "fabind_mul_dact_colsum")
     return out, db
 
@@ -213,8 +213,13 @@ def _want16(out_dtype, act_epi, want):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, x2, residual, act_epi, out_dtype, holder=None):
+    def forward(ctx, x, W, b, x2, residual, act_epi, out_dtype, holder=None, p_drop=0.0, seed=0):
         assert act_epi in (K.ACT_NONE, K.ACT_RELU, K.ACT_SILU)
+        # epilogue dropout under autograd: ReLU outputs only -- y = relu(pre) keep / (1 - p) is what is saved, its zeros ARE the dropped
+        # positions (and the inactive units), so the adjoint is [y > 0] / (1 - p): no mask is stored or recomputed
+        assert p_drop == 0.0 or (act_epi == K.ACT_RELU and residual is None), "epilogue dropout under autograd: ReLU, no residual"
+        thr = int(p_drop * 65536.0 + 0.5)
+        ctx.drop_scale = 1.0 / (1.0 - thr / 65536.0)
         xin, x2in = _mm_in(x), _mm_in(x2)
         D = None
         M, N = x.shape[0], W.shape[0]
@@ -228,7 +233,7 @@ class _Linear(torch.autograd.Function):
         if holder is not None:                        # the caller wants the epilogue to emit the bf16 operand copy of y as well
             y16 = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
             holder.append(y16)
-        K.gemm(xin, W, bias=b, A2=x2in, act_epi=act_epi, residual=residual, out=y, out2=D, out16=y16)
+        K.gemm(xin, W, bias=b, A2=x2in, act_epi=act_epi, residual=residual, out=y, out2=D, out16=y16, p_drop=p_drop, seed=seed)
         ctx.act_epi, ctx.x_dtype = (K.ACT_SILU if relu_res else act_epi), x.dtype       # backward: stored derivative
         ctx.x2_dtype = x2.dtype if x2 is not None else None
         ctx.has_b, ctx.has_res, ctx.has_x2 = b is not None, residual is not None, x2 is not None
@@ -246,9 +251,9 @@ class _Linear(torch.autograd.Function):
         db = None
         want_db = ctx.has_b and ctx.needs_input_grad[2]
         fuse_db = FUSE_DB and want_db and dy.dim() == 2 and dy.shape[1] % 4 == 0   # bias gradient in the same pass over dy
-        md_op = _mul_dact_colsum if fuse_db else (lambda *a: (_mul_dact(*a), None))
+        md_op = _mul_dact_colsum if fuse_db else (lambda *a: (_mul_dact(*a), None))      # (dy, aux, act, out dtype[, scale])
         if ctx.act_epi == K.ACT_RELU:
-            dpre, db = md_op(dy, y, K.ACT_RELU, md)
+            dpre, db = md_op(dy, y, K.ACT_RELU, md, ctx.drop_scale)
         elif ctx.act_epi == K.ACT_SILU:
             dpre, db = md_op(dy, D, K.ACT_STORED_DERIV, md)
         elif dy.dtype != md:
@@ -290,7 +295,7 @@ class _Linear(torch.autograd.Function):
         dres = dy.float() if (ctx.has_res and ctx.needs_input_grad[4]) else None
         if dres is not None and ctx.sink_res is not None:
             dres = ctx.sink_res.deposit(dres)
-        return dx, dW, db, dx2, dres, None, None, None
+        return dx, dW, db, dx2, dres, None, None, None, None, None
 
 
 def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, x2=None, out_dtype=torch.float32,
@@ -299,13 +304,12 @@ def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, 
     a counter-based hash keyed by a seed drawn from torch's CPU generator."""
     if x.stride(-1) != 1:
         x = x.contiguous()
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
     if _needs_grad(x, W, b, x2, residual):
         assert act_pro == K.ACT_NONE, "producer-side activations only under autograd"
-        assert p_drop == 0.0, "epilogue dropout has no autograd path yet"
         holder = [] if _want16(out_dtype, act_epi, want16) else None
-        y = _Linear.apply(x, W, b, x2, residual, act_epi, out_dtype, holder)
+        y = _Linear.apply(x, W, b, x2, residual, act_epi, out_dtype, holder, p_drop, seed)
         return _attach_b16(y, holder[0] if holder else None)
-    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
     y16 = None
     if _want16(out_dtype, act_epi, want16) and act_pro == K.ACT_NONE and p_drop == 0.0:
         y16 = torch.empty((x.shape[0], W.shape[0]), dtype=torch.bfloat16, device=x.device)

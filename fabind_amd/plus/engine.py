@@ -356,6 +356,9 @@ class _InterView:
 # ------------------------------------------------------------------------------------------------
 # layers
 # ------------------------------------------------------------------------------------------------
+EPI_DROP_GRAD = os.environ.get("FABIND_EPI_DROP_GRAD", "1") == "1"   # training: ReLU + dropout inside the GEMM epilogue (no torch mask kernels)
+
+
 def _drop(t, pr):
     """nn.Dropout of the reference modules (train mode = FABind+ sampling inference): element-wise mask + scale between
     kernels, torch's generator."""
@@ -369,8 +372,13 @@ def ln_mlp(m, x, last_act, residual=None, out_dtype=torch.float32, pdrop=0.0):
     y = ln_rows(x, m["ln_w"], m["ln_b"], ad, m["k_pad"]) if m["ln_w"] is not None else x
     act2 = K.ACT_RELU if last_act else K.ACT_NONE
     if pdrop > 0.0 and ops.needs_grad(y, m["W1"], m["W2"], residual):
-        t = _drop(ops.linear(y, m["W1"], m["b1"], act_epi=K.ACT_RELU, out_dtype=ad), pdrop)
+        # under autograd the ReLU + dropout pairs run inside the GEMM epilogue too (ops._Linear: the zeros of the saved output are the
+        # dropped positions); only a dropout that is followed by a residual keeps the torch mask
+        t = ops.linear(y, m["W1"], m["b1"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pdrop if EPI_DROP_GRAD else 0.0)
+        t = t if EPI_DROP_GRAD else _drop(t, pdrop)
         if last_act:
+            if residual is None and EPI_DROP_GRAD:
+                return ops.linear(t, m["W2"], m["b2"], act_epi=act2, out_dtype=out_dtype, p_drop=pdrop)
             y2 = _drop(ops.linear(t, m["W2"], m["b2"], act_epi=act2), pdrop)
             return (y2 if residual is None else residual + y2).to(out_dtype)
         return ops.linear(t, m["W2"], m["b2"], act_epi=act2, residual=residual, out_dtype=out_dtype)
@@ -397,7 +405,8 @@ def _coord_scalar(c, v, pd):
         return ops.linear_rowdot(v, fp["W1w"], fp["dvec"], c["w3"], act_epi=K.ACT_RELU, p_drop=pd, fold=(mu, rs, fp["cvec"]))
     yc = ln_rows(v, c["ln_w"], c["ln_b"], ad, c["k_pad"])
     if pd > 0.0 and ops.needs_grad(yc, c["W1"], c["w3"]):
-        tc = _drop(ops.linear(yc, c["W1"], c["b1"], act_epi=K.ACT_RELU), pd)
+        tc = ops.linear(yc, c["W1"], c["b1"], act_epi=K.ACT_RELU, p_drop=pd) if EPI_DROP_GRAD else \
+            _drop(ops.linear(yc, c["W1"], c["b1"], act_epi=K.ACT_RELU), pd)
         return (tc * c["w3"]).sum(1, keepdim=True)
     return ops.linear_rowdot(yc, c["W1"], c["b1"], c["w3"], act_epi=K.ACT_RELU, p_drop=pd)
 
@@ -412,8 +421,12 @@ def gcl_layer(p, h, x, lay, g, clampv, pd=0.0):
     if grad:       # the concatenation is materialised so that LayerNorm is a separate differentiable step
         cat = _EdgeConcat.apply(h, rhohat, g.row_ctx, g.col_ctx, g.rp_ctx, g.ctx_by_col, ad, e["k_pad"])
         y = ln_rows(cat[:, :2 * H + 1], e["ln_w"], e["ln_b"], ad, e["k_pad"])
-        t = _drop(ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad), pd)
-        m = _drop(ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad), pd)
+        if EPI_DROP_GRAD:
+            t = ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)
+            m = ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)
+        else:
+            t = _drop(ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad), pd)
+            m = _drop(ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad), pd)
     elif FOLD_EDGE_LN and "fold" in p:
         # inference, bf16: W1 LN([h_r | h_c | rho]) from per-node projections and per-node statistics -- the
         # [E, 2H+1] x [2H+1, 2H+1] contraction becomes one [N, H] x [H, 2(2H+1)] contraction and a gather

@@ -40,7 +40,9 @@ const char* fabind_last_error(void);
  * 9 = fabind_zero_empty_rows added (outputs of the fused edge kernels are no longer memset whole).
  * 10 = fabind_gemm_tn_tile_n added (the host sizes the split count of fabind_gemm_tn from the output tile of the current layout: 256 x 256 on
  *     eight waves by default); knobs fabind_gemm_tn_set_exp, fabind_gemm_set_small_m; fabind_gemm_tn_set_waves accepts 16 / 20.
- * 12: FabindGemmArgs.split3 (fp32 x fp32 contracted as split bf16, three MFMAs per product term: precision mode 'bf16x3');
+ * 12: fabind_mul_dact / fabind_mul_dact_colsum take `scale` (ReLU + epilogue dropout under autograd);
+ *     fabind_cross_attn_fused_fwd / fabind_pair_bo_pack (pair bias recomputed inside the attention kernel), fabind_pair_hadamard_bwd_grid;
+ *     FabindGemmArgs.split3 (fp32 x fp32 contracted as split bf16, three MFMAs per product term: precision mode 'bf16x3');
  *     fabind_gcl_edge_fused_x3 (the fused forward edge pipeline in that arithmetic); knob fabind_gemm_set_x3_tile.
  * 11 = fabind_gemm_tn takes with_colsum (the bias gradient rides along with the weight gradient: no separate column-sum launches);
  *     fabind_split_sum takes (n_tail, out_tail); fabind_inter_attn_bwd writes wpart as [nblk][4][H] (was [4][nblk][H]);
@@ -438,12 +440,14 @@ int fabind_add(const float* a, const float* b, float* out, long n, hipStream_t s
  * reference's ATen/torch_scatter graph for the same ops).  Contractions in backward passes go through
  * fabind_gemm / fabind_transpose_act / fabind_colsum.
  * -------------------------------------------------------------------------------------------*/
-int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, long n,
+int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, long n, float scale,
                     hipStream_t stream);
-/* out = dy * act'(y) (y = NULL with FB_ACT_NONE: dtype conversion) and colsum[c] = sum_r out[r,c] in one pass
- * (bias gradient of the Linear whose activation is being undone); [R,C] contiguous, scratch [nchunk, C]. */
+/* out = scale * dy * act'(y) (y = NULL with FB_ACT_NONE: dtype conversion) and colsum[c] = sum_r out[r,c] in one pass
+ * (bias gradient of the Linear whose activation is being undone); [R,C] contiguous, scratch [nchunk, C].
+ * scale: 1, or keep^-1 = 1 / (1 - p) when y is the output of a ReLU epilogue WITH dropout (fabind_gemm p_drop): y = relu(pre) keep / (1 - p),
+ * so d y / d pre = [y > 0] / (1 - p) -- the dropped positions are exactly the zeros of y, no mask is stored or recomputed. */
 int fabind_mul_dact_colsum(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, int R, int C,
-                           float* colsum, float* scratch, int nchunk, hipStream_t stream);
+                           float* colsum, float* scratch, int nchunk, float scale, hipStream_t stream);
 int fabind_rowdot_bwd(const void* z, int z_dt, const float* dpart, int np, const float* u, int act, int M, int N,
                       void* dz, float* du, float* scratch, int nchunk, hipStream_t stream);
 int fabind_edge_geom_bwd(const float* d, const float* rho, const float* norm, const float* dd, const float* drhohat,

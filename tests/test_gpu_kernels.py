@@ -838,3 +838,44 @@ def test_layernorm_rows_and_adjoint(R, C, ld, dt):
     assert (xd.grad.float().cpu() - xr.grad).abs().max() <= tol * max(1.0, float(xr.grad.abs().max()))
     assert (wd.grad.cpu() - wr.grad).abs().max() <= 1e-3 * max(1.0, float(wr.grad.abs().max()))
     assert (bd.grad.cpu() - br.grad).abs().max() <= 1e-3 * max(1.0, float(br.grad.abs().max()))
+
+
+@pytest.mark.parametrize("mode", ["bf16", "fp32"])
+def test_linear_relu_with_epilogue_dropout_under_autograd(mode):
+    """ops.linear(act_epi=RELU, p_drop > 0) under autograd (FABind+ training: every LN-MLP is Linear -> ReLU -> Dropout,
+    model_utils.py:10-74): the mask is applied in the GEMM epilogue and never stored; the backward takes it from the zeros of the saved
+    output.  Checked against torch autograd of relu(x W^T + b) * mask / (1 - p) with the mask read off the kernel's own output."""
+    from fabind_amd import config, ops
+    from fabind_amd import kernels as K
+    dev = _dev()
+    config.set_precision(mode)
+    try:
+        g = torch.Generator().manual_seed(5)
+        M, N, Kd, p = 700, 256, 192, 0.25
+        wd = torch.float32 if mode == "fp32" else torch.bfloat16
+        x = torch.randn(M, Kd, generator=g)
+        W = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).to(wd).float()
+        b = torch.randn(N, generator=g)
+        cot = torch.randn(M, N, generator=g)
+        xd = x.to(dev).requires_grad_(True)
+        Wd = W.to(dev).to(wd).requires_grad_(True)
+        bd = b.to(dev).requires_grad_(True)
+        torch.manual_seed(11)
+        y = ops.linear(xd, Wd, bd, act_epi=K.ACT_RELU, p_drop=p, out_dtype=torch.float32 if mode == "fp32" else torch.bfloat16)
+        xr = (x.bfloat16().float() if mode == "bf16" else x).clone().requires_grad_(True)
+        Wr, br = W.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        pre = xr @ Wr.T + br
+        plain = torch.relu(pre)
+        keep = ((y.detach().float().cpu() != 0) | (plain.detach() <= 1e-3)).float()          # dropped = zero output where the unit is clearly active
+        frac = 1.0 - float(((y.detach().float().cpu() != 0) & (plain.detach() > 1e-3)).sum() / (plain.detach() > 1e-3).sum())
+        assert abs(frac - p) < 0.02, frac                                                       # the epilogue's mask has the requested rate
+        ref = plain * keep / (1.0 - round(p * 65536) / 65536.0)
+        tol = 2e-5 if mode == "fp32" else 2e-2
+        assert (y.detach().float().cpu() - ref.detach()).abs().max() <= tol * max(1.0, float(ref.abs().max()))
+        (y.float() * cot.to(dev)).sum().backward()
+        (ref * cot).sum().backward()
+        for got, want, name in ((xd.grad, xr.grad, "dx"), (Wd.grad, Wr.grad, "dW"), (bd.grad, br.grad, "db")):
+            e = float((got.float().cpu() - want).abs().max() / want.abs().max())
+            assert e <= (1e-4 if mode == "fp32" else 3e-2), (name, e)
+    finally:
+        config.set_precision("fp32")
