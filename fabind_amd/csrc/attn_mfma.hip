@@ -659,24 +659,27 @@ extern "C" int fabind_pair_bo_pack(const float* b0, int ldb, const float* wcomp,
     return 0;
 }
 
-// one pass of the bias contraction: acc[i][j] += sA tile (64 rows) x the wave's column tiles t0 .. t0+3 (tiles past `nt` repeat the last
-// one; their results are not used).  Operand-swapped form, rolled two k-steps per trip with ping-pong fragments (fused_common.h).
-template <int H, int SWZ>
+// The bias contraction of one wave: acc[i][j] += sA tile (64 rows) x the wave's column tiles t0 .. t0 + NJ - 1 (tiles past `nt` repeat the
+// last one; their results are not used).  Operand-swapped form, rolled two k-steps per trip with ping-pong fragments (fused_common.h).
+// NJ = 8: both halves of a wave's tile range in ONE k-loop -- 8 fragment loads in flight against 32 MFMAs per half-trip; with the two
+// halves run one after the other (NJ = 4 twice) a half-trip's 16 MFMAs (256 cycles) covered less than an L2 round trip at two waves
+// per SIMD, and the kernel sat at 14 % matrix-core utilisation waiting for weight fragments (profiles/r03_pmc_util.txt).
+template <int H, int SWZ, int NJ>
 __device__ __forceinline__ void cf_gemm_pass(const bf16_t* sA, const bf16_t* __restrict__ bo_c, int T, int t0, int nt, int lane,
-                                             f32x4_t (&acc)[4][4]) {
+                                             f32x4_t (&acc)[4][NJ]) {
     constexpr int NKS = H / 32;
     const int fr = lane & 15, fq = lane >> 4;
-    const bf16_t* wp[4];
+    const bf16_t* wp[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wp[j] = bo_c + (size_t)(t0 + min(j, nt - 1)) * 512 + lane * 8;
+    for (int j = 0; j < NJ; ++j) wp[j] = bo_c + (size_t)(t0 + min(j, nt - 1)) * 512 + lane * 8;
     const size_t kstride = (size_t)T * 512;
-    bf16x8_t b0[4], b1[4];
+    bf16x8_t b0[NJ], b1[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b0[j] = *(const bf16x8_t*)wp[j];
+    for (int j = 0; j < NJ; ++j) b0[j] = *(const bf16x8_t*)wp[j];
 #pragma unroll 1
     for (int ks = 0; ks < NKS; ks += 2) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b1[j] = *(const bf16x8_t*)(wp[j] + (size_t)(ks + 1) * kstride);
+        for (int j = 0; j < NJ; ++j) b1[j] = *(const bf16x8_t*)(wp[j] + (size_t)(ks + 1) * kstride);
         bf16x8_t a[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -686,11 +689,11 @@ __device__ __forceinline__ void cf_gemm_pass(const bf16_t* sA, const bf16_t* __r
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a[i], acc[i][j], 0, 0, 0);
         {
             const int kn = min(ks + 2, NKS - 2);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b0[j] = *(const bf16x8_t*)(wp[j] + (size_t)kn * kstride);
+            for (int j = 0; j < NJ; ++j) b0[j] = *(const bf16x8_t*)(wp[j] + (size_t)kn * kstride);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -700,7 +703,7 @@ __device__ __forceinline__ void cf_gemm_pass(const bf16_t* sA, const bf16_t* __r
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a[i], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a[i], acc[i][j], 0, 0, 0);
     }
 }
 
@@ -761,40 +764,47 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
     const bf16_t* bo_c = bo + (size_t)toff[cplx] * (H / 32) * 512;
     const int per = (T + 3) / 4;
     const int t0 = wave * per, t1 = min(T, t0 + per);
-    f32x4_t acc0[4][4], acc1[4][4];
+    const int nw = t1 - t0;                                         // this wave's tiles (<= 8)
+    f32x4_t acc[4][8];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { acc0[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc1[i][j] = acc0[i][j]; }
-    const int n0 = min(4, t1 - t0), n1 = min(4, t1 - t0 - 4);
-    if (n0 > 0) cf_gemm_pass<H, SWZ>(sA, bo_c, T, t0, n0, lane, acc0);
-    if (n1 > 0) cf_gemm_pass<H, SWZ>(sA, bo_c, T, t0 + 4, n1, lane, acc1);
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (nw > 4) cf_gemm_pass<H, SWZ, 8>(sA, bo_c, T, t0, nw, lane, acc);
+    else if (nw > 0) {                                              // small ligands (<= 32 ligand-side nodes): four tiles per wave at most
+        f32x4_t acc4[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc4[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        cf_gemm_pass<H, SWZ, 4>(sA, bo_c, T, t0, nw, lane, acc4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = acc4[i][j];
+    }
     __syncthreads();                                                // every wave has finished reading the a0 tile
 
     // ---- A3: bias = (lin + c_lin) * sigmoid(gate + c_gate) for the lane's two heads -> LDS tile
     {
         const int hb = (kq & 1) * 2;                                // this lane's quad: (lin_hb, gate_hb, lin_hb+1, gate_hb+1)
         const float cl0 = bconst[hb], cg0 = bconst[4 + hb], cl1 = bconst[hb + 1], cg1 = bconst[4 + hb + 1];
-        auto put = [&](const f32x4_t (&acc)[4][4], int tb, int nt) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (j < nt) {
-                    const int atom = (tb + j) * 2 + (kq >> 1);
+        for (int j = 0; j < 8; ++j) {
+            if (j < nw) {
+                const int atom = (t0 + j) * 2 + (kq >> 1);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int row = i * 16 + n;
-                        const float2 bv = make_float2((acc[i][j][0] + cl0) * sigmoid_f(acc[i][j][1] + cg0),
-                                                      (acc[i][j][2] + cl1) * sigmoid_f(acc[i][j][3] + cg1));
-                        if (atom < CF_KEYS) {
-                            if (MODE == 0) *(float2*)&sB[(atom * CF_ROWS + row) * 4 + hb] = bv;
-                            else *(float2*)&sB[row * LDB1 + atom * 4 + hb] = bv;
-                        }
+                for (int i = 0; i < 4; ++i) {
+                    const int row = i * 16 + n;
+                    const float2 bv = make_float2((acc[i][j][0] + cl0) * sigmoid_f(acc[i][j][1] + cg0),
+                                                  (acc[i][j][2] + cl1) * sigmoid_f(acc[i][j][3] + cg1));
+                    if (atom < CF_KEYS) {
+                        if (MODE == 0) *(float2*)&sB[(atom * CF_ROWS + row) * 4 + hb] = bv;
+                        else *(float2*)&sB[row * LDB1 + atom * 4 + hb] = bv;
                     }
                 }
             }
-        };
-        put(acc0, t0, n0);
-        put(acc1, t0 + 4, n1);
+        }
     }
     // (the barrier in front of the first K / V staging below orders these writes before the reads)
 

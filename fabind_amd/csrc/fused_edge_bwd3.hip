@@ -94,10 +94,12 @@ __device__ __forceinline__ void fe3_wave_store(const bf16_t* sB, bf16_t* __restr
     }
 }
 
-// the same copy with NON-TEMPORAL stores (nt: streamed past the L2's allocation): for the five [E,H] operand tiles, which nothing in this
-// launch reads again -- round 3 experiment: do the operand streams evict the work-group's silu'(pre1) scratch slab (64 KiB, rewritten
-// and re-read every tile) from L2 and turn its round trip into 3.2 GB of HBM traffic per launch?  (knob bit 32 of
-// fabind_gcl_edge_fused_bwd3_set_exp; profiles/r03_edge_bwd_nt.txt has the counters)
+// the same copy with NON-TEMPORAL stores (nt) for the five [E,H] operand tiles, which nothing in this launch reads again.  Round-3
+// experiment (profiles/r03_edge_bwd_nt.txt): the question was whether the operand streams evict the work-group's silu'(pre1) scratch slab
+// (64 KiB, rewritten and re-read every tile) from L2 and so cause its 3.2 GB of HBM round trip per launch.  They do not -- FETCH_SIZE /
+// WRITE_SIZE are unchanged (5.7 GB / 9.7 GB per launch) -- but the launch is 1.2-2.5 % shorter in the step (5,327 / 5,356 / 5,306 us ->
+// 5,196 / 5,229 / 5,241 us in three interleaved pairs), results bit-identical: the default since then (knob bit 32 of
+// fabind_gcl_edge_fused_bwd3_set_exp restores the plain stores).
 template <int H, int SWZ>
 __device__ __forceinline__ void fe3_wave_store_nt(const bf16_t* sB, bf16_t* __restrict__ g, int e0, int ne, int lane) {
     constexpr int CH = H / 8;
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
         for (int tile = t_first; tile < t_end; tile += t_step) {
             const int e0 = tile * BM;
             const int ne = min(BM, p.E - e0);
-            const bool st = !(xf & 1), nt = (xf & 32) != 0;
+            const bool st = !(xf & 1), nt = (xf & 32) == 0;     // non-temporal operand stores unless knob bit 32 is set
             auto put = [&](bf16_t* dst) {
                 if (nt) fe3_wave_store_nt<H, SWZ>(sX, dst, e0, ne, lane); else fe3_wave_store<H, SWZ>(sX, dst, e0, ne, lane);
             };
@@ -507,7 +509,7 @@ __global__ __launch_bounds__(H + 64) void gcl_edge_fused_bwd3_kernel(const Fabin
 
 // development knob: bit mask of work the kernel SKIPS (wrong results; sensitivity timing only): 1 operand stores, 16 no row scan
 static int g_fe_bwd3_exp = 0;
-extern "C" void fabind_gcl_edge_fused_bwd3_set_exp(int m) { g_fe_bwd3_exp = m; }      // (bit 32 gives correct results: non-temporal operand stores)
+extern "C" void fabind_gcl_edge_fused_bwd3_set_exp(int m) { g_fe_bwd3_exp = m; }      // (bit 32 gives correct results: plain instead of non-temporal operand stores)
 
 // launched from fabind_gcl_edge_fused_bwd (fused_edge.hip), variant 5
 int fe_bwd3_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipStream_t stream) {
