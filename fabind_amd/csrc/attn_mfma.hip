@@ -919,6 +919,13 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
     }
 }
 
+// development probe: resident work-groups per CU of the fused forward kernel (80 KiB of LDS each at H = 512)
+extern "C" int fabind_cross_attn_fused_occupancy(int lds_bytes) {
+    int n = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)cross_attn_fused_fwd_kernel<512, 0>, 256, (size_t)lds_bytes);
+    return n;
+}
+
 extern "C" int fabind_cross_attn_fused_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* gpre, int ldg,
                                            const void* a0, int lda0, const void* bo, const int* toff, const float* bconst,
                                            const int* desc, int B, int max_P, int max_C, int H, int mode, float scale, float* out,

@@ -1432,6 +1432,15 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
     gemm_epilogue<BM_>(p, acc, sDot, sT, M, N, ldc, a_row0, w_row0, c_off, m0, n0);
 }
 
+// development probe: resident work-groups per CU of the split-bf16 kernel as the runtime computes it (its two LDS stages are exactly
+// 80 KiB at the 128-row tile: do two fit beside each other in 160 KiB?)
+extern "C" int fabind_gemm_x3_occupancy(int wm) {
+    int n = -1;
+    if (wm == 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_x3_kernel<4, 2>, 512, x3_lds_bytes<4>());
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_x3_kernel<2, 2>, 256, x3_lds_bytes<2>());
+    return n;
+}
+
 static int g_x3_wm = 2;      // tile height of the split-bf16 kernel in units of 64 rows (2: two 4-wave work-groups per CU, 4: one 8-wave)
 extern "C" void fabind_gemm_set_x3_tile(int wm) { g_x3_wm = (wm == 4) ? 4 : 2; }
 

@@ -525,6 +525,8 @@ int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, cons
 void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of the bf16 LDS-DMA GEMM (default 13 = 256x128x32, 3 stages,
                                          two work-groups per CU; 0 = register-staged kernel; 1-9 = other tiles; results do not depend on it) */
 void fabind_gemm_set_persistent(int on); /* development knob: persistent tile walk for long-M/short-K GEMMs */
+int fabind_gemm_x3_occupancy(int wm); /* development probe: resident work-groups per CU of the split-bf16 GEMM kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor) */
+int fabind_cross_attn_fused_occupancy(int lds_bytes); /* the same for the fused cross-attention forward at the given dynamic LDS size */
 void fabind_gemm_set_x3_tile(int wm); /* development knob: tile height of the split-bf16 fabind_gemm kernel in units of 64 rows (2 = default: 128x128, two 4-wave work-groups per CU; 4: 256x128, one 8-wave work-group) */
 void fabind_gemm_set_small_m(int tiles); /* development knob: fabind_gemm launches with fewer 256x128 tiles than this use 128x128 tiles (default 100; 0 = never); results are bitwise equal */
 void fabind_gemm_tn_set_waves(int waves); /* development knob: work-group layout of fabind_gemm_tn: 16 (default) = 256x256 tile, 8 waves, 4-stage ring; 20 = the same with 5 stages; 4 = 256x128 tile, 4 waves, two work-groups per CU; 8 = 256x128, 8 waves.  Results are bitwise equal for equal `splits` */
