@@ -611,7 +611,7 @@ extern "C" int fabind_cross_attn_mfma_bwd(const float* qg, int ldq, const float*
 //      (lin_h, gate_h, lin_h+1, gate_h+1) of ONE (protein row, atom) pair -- the bias lin * sigmoid(gate) is formed in registers and
 //      written as a [.][.][4 heads] fp32 LDS tile over the dead a0 tile: 8.2 kFLOP per pair on the matrix cores instead of 32 B of HBM;
 //   B. runs the attention of cross_attn_mfma_fwd_kernel with the bias read from that tile:
-//      MODE 0 (protein-query block): the 64 rows are the queries of waves 0..3 (of eight), keys = the complex's ligand-side nodes;
+//      MODE 0 (protein-query block): the 64 rows are the queries of 4 waves, keys = the complex's ligand atoms;
 //      MODE 1 (ligand-query block):  the 64 rows are the KEYS (two 32-key chunks), queries = the ligand atoms (16 per wave); the
 //              un-normalised partial (o, m, l) of every (atom, head) goes to `part` and cross_attn_mfma_combine_kernel merges the
 //              ceil(P / 64) row tiles of a complex.
@@ -708,7 +708,7 @@ __device__ __forceinline__ void cf_gemm_pass(const bf16_t* sA, const bf16_t* __r
 }
 
 template <int H, int MODE>
-__global__ __launch_bounds__(512, 4) void cross_attn_fused_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
+__global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const float* __restrict__ q, int ldq, const float* __restrict__ k,
                                                                       const float* __restrict__ v, int ldkv,
                                                                       const float* __restrict__ gpre, int ldg,
                                                                       const bf16_t* __restrict__ a0, int lda0,
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(512, 4) void cross_attn_fused_fwd_kernel(const floa
     const int n = lane & 15, kq = lane >> 4;
     if (m0 >= P) {
         if (MODE == 1) {                                            // neutral partials of a row tile past the end of this complex
-            for (int t = tid; t < C * 4; t += 512) {
+            for (int t = tid; t < C * 4; t += 256) {
                 float* pp = part + (((size_t)(lig0 + (t >> 2)) * nsplit + rtile) * 4 + (t & 3)) * 34;
 #pragma unroll
                 for (int d = 0; d < 32; ++d) pp[d] = 0.f;
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(512, 4) void cross_attn_fused_fwd_kernel(const floa
     // ---- A1: a0 rows of the tile -> swizzled LDS image (rows past the end repeat the last row; their results are not used)
     {
         constexpr int CH = H / 8;
-        for (int c = tid; c < CF_ROWS * CH; c += 512) {
+        for (int c = tid; c < CF_ROWS * CH; c += 256) {
             const int r = c / CH, ch = c % CH;
             const uint4 val = *(const uint4*)(a0 + (size_t)(prow0 + m0 + min(r, nrow - 1)) * lda0 + ch * 8);
             *(uint4*)&sA[r * H + ((ch ^ (r & SWZ)) * 8)] = val;
@@ -759,21 +759,30 @@ __global__ __launch_bounds__(512, 4) void cross_attn_fused_fwd_kernel(const floa
     }
     __syncthreads();
 
-    // ---- A2: bias contraction.  T <= 31 column tiles (2 ligand-side nodes each) are dealt to the EIGHT waves in contiguous ranges of <= 4.
-    // (Round 3, second form: four waves with 8 tiles each ran the k-loop at two waves per SIMD -- a half-trip's MFMAs covered less than
-    // an L2 round trip of the weight-fragment stream and the kernel sat at 15 % matrix-core utilisation; eight waves of <= 128 VGPRs put
-    // four on a SIMD.  Waves 4..7 only contract: the attention phase below belongs to waves 0..3, 16 queries each.)
+    // ---- A2: bias contraction.  T column tiles (2 atoms each) are dealt to the 4 waves in contiguous ranges of <= 8 (two passes of 4)
     const int T = toff[cplx + 1] - toff[cplx];
     const bf16_t* bo_c = bo + (size_t)toff[cplx] * (H / 32) * 512;
-    const int per = (T + 7) / 8;
+    const int per = (T + 3) / 4;
     const int t0 = wave * per, t1 = min(T, t0 + per);
-    const int nw = t1 - t0;                                         // this wave's tiles (<= 4)
-    f32x4_t acc[4][4];
+    const int nw = t1 - t0;                                         // this wave's tiles (<= 8)
+    f32x4_t acc[4][8];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (nw > 0) cf_gemm_pass<H, SWZ, 4>(sA, bo_c, T, t0, nw, lane, acc);
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (nw > 4) cf_gemm_pass<H, SWZ, 8>(sA, bo_c, T, t0, nw, lane, acc);
+    else if (nw > 0) {                                              // small ligands (<= 32 ligand-side nodes): four tiles per wave at most
+        f32x4_t acc4[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc4[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        cf_gemm_pass<H, SWZ, 4>(sA, bo_c, T, t0, nw, lane, acc4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = acc4[i][j];
+    }
     __syncthreads();                                                // every wave has finished reading the a0 tile
 
     // ---- A3: bias = (lin + c_lin) * sigmoid(gate + c_gate) for the lane's two heads -> LDS tile
@@ -781,7 +790,7 @@ __global__ __launch_bounds__(512, 4) void cross_attn_fused_fwd_kernel(const floa
         const int hb = (kq & 1) * 2;                                // this lane's quad: (lin_hb, gate_hb, lin_hb+1, gate_hb+1)
         const float cl0 = bconst[hb], cg0 = bconst[4 + hb], cl1 = bconst[hb + 1], cg1 = bconst[4 + hb + 1];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) {
             if (j < nw) {
                 const int atom = (t0 + j) * 2 + (kq >> 1);
 #pragma unroll
@@ -801,9 +810,8 @@ __global__ __launch_bounds__(512, 4) void cross_attn_fused_fwd_kernel(const floa
 
     // ---- B: attention (cross_attn_mfma_fwd_kernel with the bias from the tile)
     const int nq_total = MODE == 0 ? nrow : C;                      // queries this work-group serves
-    const bool att = wave < 4;                                      // waves 4..7: barriers only from here on
-    const int qi = (wave & 3) * 16 + n;                             // MODE 0: row of the tile; MODE 1: ligand-side node
-    const bool qvalid = att && qi < nq_total;
+    const int qi = wave * 16 + n;                                   // MODE 0: row of the tile; MODE 1: atom
+    const bool qvalid = qi < nq_total;
     const size_t qrow = MODE == 0 ? (size_t)(prow0 + m0 + (qvalid ? qi : 0)) : (size_t)(lig0 + (qvalid ? qi : 0));
     bf16x8_t bq[4];
 #pragma unroll
@@ -829,15 +837,10 @@ __global__ __launch_bounds__(512, 4) void cross_attn_fused_fwd_kernel(const floa
     const long krow0 = MODE == 0 ? (long)lig0 : (long)prow0 + m0;
     for (int j0 = 0; j0 < ke; j0 += CM_KC) {
         __syncthreads();
-        if (att) {
-            cm_stage_rows(sK, k, ldkv, krow0 + j0, ke - j0, 1.f, tid);
-            cm_stage_cols(sVt, v, ldkv, krow0 + j0, ke - j0, 1.f, tid);
-        }
+        cm_stage_rows(sK, k, ldkv, krow0 + j0, ke - j0, 1.f, tid);
+        cm_stage_cols(sVt, v, ldkv, krow0 + j0, ke - j0, 1.f, tid);
         __syncthreads();
-        if (!att) continue;
-        // LDS offsets of this lane's 8 (query, key) pairs in the bias tile; the head's value is read inside the head loop (four
-        // heads of eight pairs held at once were 32 registers too many at the 128-register budget of four waves per SIMD)
-        int bo_[2][4];
+        float4 bia[2][4];
         bool ok[2][4];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -846,7 +849,7 @@ __global__ __launch_bounds__(512, 4) void cross_attn_fused_fwd_kernel(const floa
                 const int j = j0 + t * 16 + kq * 4 + r;
                 ok[t][r] = qvalid && j < ke;
                 const int jc = min(j, ke - 1), qc = qvalid ? qi : 0;
-                bo_[t][r] = MODE == 0 ? (jc * CF_ROWS + qc) * 4 : jc * LDB1 + qc * 4;
+                bia[t][r] = MODE == 0 ? *(const float4*)&sB[(jc * CF_ROWS + qc) * 4] : *(const float4*)&sB[jc * LDB1 + qc * 4];
             }
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
@@ -860,7 +863,7 @@ __global__ __launch_bounds__(512, 4) void cross_attn_fused_fwd_kernel(const floa
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float sv = ok[t][r] ? s[t][r] + sB[bo_[t][r] + h] : -INFINITY;
+                    const float sv = ok[t][r] ? s[t][r] + ((const float*)&bia[t][r])[h] : -INFINITY;
                     s[t][r] = sv;
                     mx = fmaxf(mx, sv);
                 }
@@ -919,7 +922,7 @@ __global__ __launch_bounds__(512, 4) void cross_attn_fused_fwd_kernel(const floa
 // development probe: resident work-groups per CU of the fused forward kernel (80 KiB of LDS each at H = 512)
 extern "C" int fabind_cross_attn_fused_occupancy(int lds_bytes) {
     int n = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)cross_attn_fused_fwd_kernel<512, 0>, 512, (size_t)lds_bytes);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)cross_attn_fused_fwd_kernel<512, 0>, 256, (size_t)lds_bytes);
     return n;
 }
 
@@ -938,7 +941,7 @@ extern "C" int fabind_cross_attn_fused_fwd(const float* q, int ldq, const float*
     do {                                                                                                                           \
         static bool set_ = false;                                                                                                  \
         if (!set_) { (void)hipFuncSetAttribute((const void*)cross_attn_fused_fwd_kernel<HH, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
-        hipLaunchKernelGGL((cross_attn_fused_fwd_kernel<HH, MM>), dim3(8 * nsplit * ((B + 7) / 8)), dim3(512), lds, stream, q, ldq, k, v, \
+        hipLaunchKernelGGL((cross_attn_fused_fwd_kernel<HH, MM>), dim3(8 * nsplit * ((B + 7) / 8)), dim3(256), lds, stream, q, ldq, k, v, \
                            ldkv, gpre, ldg, (const bf16_t*)a0, lda0, (const bf16_t*)bo, toff, bconst, desc, scale, out, ldo, part, nsplit, B); \
     } while (0)
 #define CF_LAUNCH_H(MM) do { if (H == 512) CF_LAUNCH(512, MM); else if (H == 256) CF_LAUNCH(256, MM); else if (H == 128) CF_LAUNCH(128, MM); else CF_LAUNCH(64, MM); } while (0)
