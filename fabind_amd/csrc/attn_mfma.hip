@@ -714,7 +714,8 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
                                                                       const bf16_t* __restrict__ a0, int lda0,
                                                                       const bf16_t* __restrict__ bo, const int* __restrict__ toff,
                                                                       const float* __restrict__ bconst, const int* __restrict__ desc,
-                                                                      float scale, float* out, int ldo, float* part, int nsplit, int B) {
+                                                                      float scale, float* out, int ldo, float* part, int nsplit, int B,
+                                                                      long long* dbg) {
     constexpr int SWZ = (H >= 128) ? 15 : 7;
     constexpr int TILE_BYTES = (CF_ROWS * H * 2 > 65536) ? CF_ROWS * H * 2 : 65536;
     // XCD-aware work-group order (1-D grid; consecutive ids go round-robin to the 8 XCDs): ALL row tiles of a complex run on the XCD
@@ -747,6 +748,11 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
         return;
     }
     const int nrow = min(CF_ROWS, P - m0);
+    // phase cycle counters of one work-group's wave 0 (tools/probes/attn_fused_phases.py): t[0] start, [1] a0 tile staged, [2] contraction
+    // done, [3] bias tile written, [4] attention done
+    long long tph[5] = {0, 0, 0, 0, 0};
+    const bool timed = dbg != nullptr && blockIdx.x == 8 * 3 && wave == 0;      // a work-group in the middle of a complex
+    if (timed) tph[0] = __builtin_readcyclecounter();
 
     // ---- A1: a0 rows of the tile -> swizzled LDS image (rows past the end repeat the last row; their results are not used)
     {
@@ -758,6 +764,7 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
         }
     }
     __syncthreads();
+    if (timed) tph[1] = __builtin_readcyclecounter();
 
     // ---- A2: bias contraction.  T column tiles (2 atoms each) are dealt to the 4 waves in contiguous ranges of <= 8 (two passes of 4)
     const int T = toff[cplx + 1] - toff[cplx];
@@ -784,6 +791,7 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
             for (int j = 0; j < 4; ++j) acc[i][j] = acc4[i][j];
     }
     __syncthreads();                                                // every wave has finished reading the a0 tile
+    if (timed) tph[2] = __builtin_readcyclecounter();
 
     // ---- A3: bias = (lin + c_lin) * sigmoid(gate + c_gate) for the lane's two heads -> LDS tile
     {
@@ -807,6 +815,7 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
         }
     }
     // (the barrier in front of the first K / V staging below orders these writes before the reads)
+    if (timed) tph[3] = __builtin_readcyclecounter();
 
     // ---- B: attention (cross_attn_mfma_fwd_kernel with the bias from the tile)
     const int nq_total = MODE == 0 ? nrow : C;                      // queries this work-group serves
@@ -893,6 +902,11 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
         l[h] += __shfl_xor(l[h], 16, 64);
         l[h] += __shfl_xor(l[h], 32, 64);
     }
+    if (timed && lane == 0) {
+        tph[4] = __builtin_readcyclecounter();
+#pragma unroll
+        for (int u = 0; u < 5; ++u) dbg[u] = tph[u];
+    }
     if (!qvalid) return;
     if (MODE == 1) {       // un-normalised partial of this row tile: [atom][tile][head][34] = o[32], m, l
 #pragma unroll
@@ -919,6 +933,9 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
     }
 }
 
+static long long* g_cf_dbg = nullptr;      // development probe: device buffer of 5 int64 receiving one work-group's phase cycle counters
+extern "C" void fabind_cross_attn_fused_set_dbg(void* p) { g_cf_dbg = (long long*)p; }
+
 // development probe: resident work-groups per CU of the fused forward kernel (80 KiB of LDS each at H = 512)
 extern "C" int fabind_cross_attn_fused_occupancy(int lds_bytes) {
     int n = -1;
@@ -942,7 +959,8 @@ extern "C" int fabind_cross_attn_fused_fwd(const float* q, int ldq, const float*
         static bool set_ = false;                                                                                                  \
         if (!set_) { (void)hipFuncSetAttribute((const void*)cross_attn_fused_fwd_kernel<HH, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
         hipLaunchKernelGGL((cross_attn_fused_fwd_kernel<HH, MM>), dim3(8 * nsplit * ((B + 7) / 8)), dim3(256), lds, stream, q, ldq, k, v, \
-                           ldkv, gpre, ldg, (const bf16_t*)a0, lda0, (const bf16_t*)bo, toff, bconst, desc, scale, out, ldo, part, nsplit, B); \
+                           ldkv, gpre, ldg, (const bf16_t*)a0, lda0, (const bf16_t*)bo, toff, bconst, desc, scale, out, ldo, part, nsplit, B, \
+                           g_cf_dbg);                                                                                              \
     } while (0)
 #define CF_LAUNCH_H(MM) do { if (H == 512) CF_LAUNCH(512, MM); else if (H == 256) CF_LAUNCH(256, MM); else if (H == 128) CF_LAUNCH(128, MM); else CF_LAUNCH(64, MM); } while (0)
     if (mode == 0) CF_LAUNCH_H(0);

@@ -526,6 +526,7 @@ void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of
                                          two work-groups per CU; 0 = register-staged kernel; 1-9 = other tiles; results do not depend on it) */
 void fabind_gemm_set_persistent(int on); /* development knob: persistent tile walk for long-M/short-K GEMMs */
 int fabind_gemm_x3_occupancy(int wm); /* development probe: resident work-groups per CU of the split-bf16 GEMM kernel (hipOccupancyMaxActiveBlocksPerMultiprocessor) */
+void fabind_cross_attn_fused_set_dbg(void* five_int64_on_device); /* development probe: phase cycle counters of one work-group of the fused cross-attention forward (NULL = off) */
 int fabind_cross_attn_fused_occupancy(int lds_bytes); /* the same for the fused cross-attention forward at the given dynamic LDS size */
 void fabind_gemm_set_x3_tile(int wm); /* development knob: tile height of the split-bf16 fabind_gemm kernel in units of 64 rows (2 = default: 128x128, two 4-wave work-groups per CU; 4: 256x128, one 8-wave work-group) */
 void fabind_gemm_set_small_m(int tiles); /* development knob: fabind_gemm launches with fewer 256x128 tiles than this use 128x128 tiles (default 100; 0 = never); results are bitwise equal */
