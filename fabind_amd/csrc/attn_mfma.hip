@@ -619,6 +619,42 @@ extern "C" int fabind_cross_attn_mfma_bwd(const float* qg, int ldq, const float*
 // per CU); larger ones take the tensor path.  Forward only so far: under autograd the tensor path runs (its backward reads the bias
 // tensors).  Reference: cross_att.py:118-134, model_utils.py:21-38.
 // =====================================================================================================================
+// K / V staging of the fused kernel with ALL global loads of a chunk in flight before the first LDS store (cm_stage_rows / cm_stage_cols
+// above interleave load and store per iteration; the phase counters of tools/probes/attn_fused_phases.py showed the fused kernel spending
+// 11 k cycles per 32-key chunk there -- a dozen serialised L2 round trips -- against ~8 k of matrix-core work in its whole contraction)
+__device__ __forceinline__ void cf_stage_kv(unsigned char* sK, unsigned char* sVt, const float* __restrict__ k, const float* __restrict__ v,
+                                            int ld, long row0, int nrows, int tid) {
+    float4 kr[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = tid + u * 256, jr = i >> 5, c4 = (i & 31) * 4;
+        kr[u] = (jr < nrows) ? *(const float4*)(k + (size_t)(row0 + jr) * ld + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int col = tid & 127, g = tid >> 7;
+    float f[2][8];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int kq = g * 2 + kk;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = t * 16 + kq * 4 + r;
+                f[kk][t * 4 + r] = (row < nrows) ? v[(size_t)(row0 + row) * ld + col] : 0.f;
+            }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = tid + u * 256;
+        cm_store_rows(sK, i >> 5, (i & 31) * 4, kr[u]);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const int kq = g * 2 + kk;
+        *(bf16x8_t*)(sVt + col * 64 + ((kq ^ ((col >> 2) & 3)) << 4)) = cm_pack8(f[kk]);
+    }
+}
+
 #define CF_ROWS 64
 #define CF_KEYS 62                                  // atoms per bias tile; MODE 1 row stride = 62 * 4 + 4 floats (bank-conflict-free)
 
@@ -754,13 +790,24 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
     const bool timed = dbg != nullptr && blockIdx.x == 8 * 3 && wave == 0;      // a work-group in the middle of a complex
     if (timed) tph[0] = __builtin_readcyclecounter();
 
-    // ---- A1: a0 rows of the tile -> swizzled LDS image (rows past the end repeat the last row; their results are not used)
+    // ---- A1: a0 rows of the tile -> swizzled LDS image (rows past the end repeat the last row; their results are not used); every load
+    // is requested before the first store (a rolled load / store loop cost 12 k cycles of serialised round trips per work-group), and the
+    // first K / V chunk of the attention phase is staged here as well, under the same latency
+    const int ke = MODE == 0 ? C : nrow;                            // keys: the ligand-side nodes / the rows of the tile
+    const long krow0 = MODE == 0 ? (long)lig0 : (long)prow0 + m0;
     {
-        constexpr int CH = H / 8;
-        for (int c = tid; c < CF_ROWS * CH; c += 256) {
-            const int r = c / CH, ch = c % CH;
-            const uint4 val = *(const uint4*)(a0 + (size_t)(prow0 + m0 + min(r, nrow - 1)) * lda0 + ch * 8);
-            *(uint4*)&sA[r * H + ((ch ^ (r & SWZ)) * 8)] = val;
+        constexpr int CH = H / 8, NLD = CF_ROWS * CH / 256;
+        uint4 val[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int c = tid + u * 256, r = c / CH, ch = c % CH;
+            val[u] = *(const uint4*)(a0 + (size_t)(prow0 + m0 + min(r, nrow - 1)) * lda0 + ch * 8);
+        }
+        cf_stage_kv(sK, sVt, k, v, ldkv, krow0, ke, tid);
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int c = tid + u * 256, r = c / CH, ch = c % CH;
+            *(uint4*)&sA[r * H + ((ch ^ (r & SWZ)) * 8)] = val[u];
         }
     }
     __syncthreads();
@@ -842,13 +889,12 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
         m[h] = -INFINITY; l[h] = 0.f;
         o[h][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; o[h][1] = o[h][0];
     }
-    const int ke = MODE == 0 ? C : nrow;                            // keys: the ligand atoms / the rows of the tile
-    const long krow0 = MODE == 0 ? (long)lig0 : (long)prow0 + m0;
     for (int j0 = 0; j0 < ke; j0 += CM_KC) {
-        __syncthreads();
-        cm_stage_rows(sK, k, ldkv, krow0 + j0, ke - j0, 1.f, tid);
-        cm_stage_cols(sVt, v, ldkv, krow0 + j0, ke - j0, 1.f, tid);
-        __syncthreads();
+        __syncthreads();                                            // (chunk 0: orders the bias-tile writes before their reads)
+        if (j0 > 0) {                                               // chunk 0 was staged with the a0 tile
+            cf_stage_kv(sK, sVt, k, v, ldkv, krow0 + j0, ke - j0, tid);
+            __syncthreads();
+        }
         float4 bia[2][4];
         bool ok[2][4];
 #pragma unroll
