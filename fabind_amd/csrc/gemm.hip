@@ -1275,7 +1275,7 @@ template <int WM> __host__ __device__ constexpr size_t x3_lds_bytes() {
     return (size_t)2 * 2 * (WM * 64 + BN) * (BK + 8) * 2;          // [stage][hi | lo][rows][40] bf16
 }
 
-template <int WM, int MINW>
+template <int WM, int MINW, bool PRO>
 __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs p) {
     constexpr int BM_ = WM * 64, NT = WM * 128, LS = BK + 8;
     constexpr int ROWS = BM_ + BN, PLANE = ROWS * LS;             // A rows then W rows; one plane = hi or lo of one stage
@@ -1338,34 +1338,51 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
 
     // Staging: a thread owns NA + NB chunks of 8 consecutive k (two 16-byte loads each) per k-tile.  TWO register sets alternate, so
     // a tile's loads are requested two k-steps before its split -- one k-step (~0.3 us of MFMA work) is less than an HBM round trip,
-    // and with one or two 4- / 8-wave work-groups per CU nothing else covers it.
+    // and with one or two 4- / 8-wave work-groups per CU nothing else covers it.  Every load is UNCONDITIONAL (row and k indices are
+    // clamped, out-of-range values are zeroed by a select when they are split): the first form put the loads under per-lane bounds
+    // branches and the prologue activation under a run-time switch, and the compiler answered with `s_waitcnt vmcnt(0)` at every join
+    // -- 1,764 of them in the kernel, the prefetch distance collapsed to nothing (ISA of round 3's first build; 245 us at
+    // M = 98,688, N = K = 512).  PRO: prologue activation as a compile-time variant.
     const int lr = tid >> 2, lc = (tid & 3) * 8;                 // this thread's row (+ NT/4 per chunk) and k offset in a k-tile
-    const bool pro = p.act_pro != FB_ACT_NONE;
+    const float* arow[NA];
+    const float* a2row[NA];
+    const float* wrow[NB];
+    bool aok[NA], wok[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int gm = m0 + lr + (NT / 4) * i;
+        aok[i] = gm < M;
+        const size_t gmc = (size_t)min(gm, M - 1);
+        arow[i] = A + gmc * lda_g;
+        a2row[i] = A2 ? A2 + gmc * p.lda2 - K1 : arow[i];         // indexed with the global k as well
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int gn = n0 + lr + (NT / 4) * i;
+        wok[i] = gn < N;
+        wrow[i] = W + (size_t)min(gn, N - 1) * p.ldw;
+    }
     auto fetch = [&](Vec8 (&ra)[NA], Vec8 (&rb)[NB], int k0) {
+        const bool second = k0 >= K1;                             // uniform: K1 is a multiple of the k-tile when A2 is given
         const int gk = k0 + lc;
+        const int gkc = gk < K ? gk : (second ? K1 : 0);          // (K % 8 == 0: a chunk is inside or outside as a whole)
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int gm = m0 + lr + (NT / 4) * i;
+        for (int i = 0; i < NA; ++i) ra[i] = load8<float>((second ? a2row[i] : arow[i]) + gkc);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) ra[i].v[q] = 0.f;
-            if (gm < M && gk < K) ra[i] = load8<float>((gk < K1) ? A + (size_t)gm * lda_g + gk : A2 + (size_t)gm * p.lda2 + (gk - K1));
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const int gn = n0 + lr + (NT / 4) * i;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) rb[i].v[q] = 0.f;
-            if (gn < N && gk < K) rb[i] = load8<float>(W + (size_t)gn * p.ldw + gk);
-        }
+        for (int i = 0; i < NB; ++i) rb[i] = load8<float>(wrow[i] + gkc);
     };
-    auto split_store = [&](Vec8 (&ra)[NA], Vec8 (&rb)[NB], int st) {
+    auto split_store = [&](Vec8 (&ra)[NA], Vec8 (&rb)[NB], int st, int k0) {
         bf16_t* hi = sT + (size_t)st * 2 * PLANE;
         bf16_t* lo = hi + PLANE;
+        const bool kok = k0 + lc < K;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            if (pro) {
+            const bool ok = kok && aok[i];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) ra[i].v[q] = apply_act(ra[i].v[q], p.act_pro);
+            for (int q = 0; q < 8; ++q) {
+                float x = ra[i].v[q];
+                if constexpr (PRO) x = apply_act(x, p.act_pro);
+                ra[i].v[q] = ok ? x : 0.f;
             }
             uint4 h, l;
             x3_split8(ra[i], h, l);
@@ -1375,6 +1392,9 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
+            const bool ok = kok && wok[i];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rb[i].v[q] = ok ? rb[i].v[q] : 0.f;
             uint4 h, l;
             x3_split8(rb[i], h, l);
             const int o = (BM_ + lr + (NT / 4) * i) * LS + lc;
@@ -1409,21 +1429,23 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
     const int nk = (K - kbeg + BK - 1) / BK;
     Vec8 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
     // invariant at the top of step kt (even): stage kt & 1 holds tile kt; set 1 holds tile kt+1 (in flight), set 0 tile kt+2 (just requested)
+    // (loads past the last k-tile are issued anyway -- clamped addresses, values never used -- so that the loop body has no branch
+    //  around a load and the waits count instructions)
     if (nk > 0) {
         fetch(ra0, rb0, kbeg);
-        if (nk > 1) fetch(ra1, rb1, kbeg + BK);
-        split_store(ra0, rb0, 0);
-        if (nk > 2) fetch(ra0, rb0, kbeg + 2 * BK);
+        fetch(ra1, rb1, kbeg + BK);
+        split_store(ra0, rb0, 0, kbeg);
+        fetch(ra0, rb0, kbeg + 2 * BK);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 2) {
-        if (kt + 1 < nk) split_store(ra1, rb1, 1);               // (stage 1 was last read in step kt-1, before its barrier)
-        if (kt + 3 < nk) fetch(ra1, rb1, kbeg + (kt + 3) * BK);
+        if (kt + 1 < nk) split_store(ra1, rb1, 1, kbeg + (kt + 1) * BK);   // (stage 1 was last read in step kt-1, before its barrier)
+        fetch(ra1, rb1, kbeg + (kt + 3) * BK);
         compute(0);
         __syncthreads();
         if (kt + 1 < nk) {
-            if (kt + 2 < nk) split_store(ra0, rb0, 0);
-            if (kt + 4 < nk) fetch(ra0, rb0, kbeg + (kt + 4) * BK);
+            if (kt + 2 < nk) split_store(ra0, rb0, 0, kbeg + (kt + 2) * BK);
+            fetch(ra0, rb0, kbeg + (kt + 4) * BK);
             compute(1);
             __syncthreads();
         }
@@ -1436,26 +1458,26 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
 // 80 KiB at the 128-row tile: do two fit beside each other in 160 KiB?)
 extern "C" int fabind_gemm_x3_occupancy(int wm) {
     int n = -1;
-    if (wm == 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_x3_kernel<4, 2>, 512, x3_lds_bytes<4>());
-    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_x3_kernel<2, 2>, 256, x3_lds_bytes<2>());
+    if (wm == 4) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_x3_kernel<4, 2, false>, 512, x3_lds_bytes<4>());
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void*)gemm_x3_kernel<2, 2, false>, 256, x3_lds_bytes<2>());
     return n;
 }
 
 static int g_x3_wm = 2;      // tile height of the split-bf16 kernel in units of 64 rows (2: two 4-wave work-groups per CU, 4: one 8-wave)
 extern "C" void fabind_gemm_set_x3_tile(int wm) { g_x3_wm = (wm == 4) ? 4 : 2; }
 
-template <int WM, int MINW>
+template <int WM, int MINW, bool PRO>
 static int launch_x3(const FabindGemmArgs& p, int maxM, int maxN, hipStream_t stream) {
     constexpr int BM_ = WM * 64;
     const size_t lds = x3_lds_bytes<WM>();
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<WM, MINW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)gemm_x3_kernel<WM, MINW, PRO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((maxN + BN - 1) / BN, (maxM + BM_ - 1) / BM_, p.groups ? p.n_groups : 1);
     if (!p.groups) grid = dim3(grid.x * grid.y, p.k_splits > 1 ? p.k_splits : 1, 1);
-    hipLaunchKernelGGL((gemm_x3_kernel<WM, MINW>), grid, dim3(WM * 128), lds, stream, p);
+    hipLaunchKernelGGL((gemm_x3_kernel<WM, MINW, PRO>), grid, dim3(WM * 128), lds, stream, p);
     return 0;
 }
 
@@ -1533,7 +1555,9 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
         FB_REQUIRE(p.a_dtype == FB_DT_F32, "fabind_gemm: the split-bf16 contraction takes fp32 A and fp32 W");
         FB_REQUIRE(((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) && (p.A2 == nullptr || ((uintptr_t)p.A2 % 16 == 0 && p.lda2 % 4 == 0)),
                    "fabind_gemm: split-bf16 operands must be 16-byte aligned");
-        if (g_x3_wm == 4) launch_x3<4, 2>(p, maxM, maxN, stream); else launch_x3<2, 2>(p, maxM, maxN, stream);
+        if (p.act_pro != FB_ACT_NONE) launch_x3<2, 2, true>(p, maxM, maxN, stream);
+        else if (g_x3_wm == 4) launch_x3<4, 2, false>(p, maxM, maxN, stream);
+        else launch_x3<2, 2, false>(p, maxM, maxN, stream);
     } else if (p.w_dtype == FB_DT_F32) {
         FB_REQUIRE(p.a_dtype == FB_DT_F32, "fabind_gemm: fp32 MMA needs fp32 A");
         hipLaunchKernelGGL((gemm_nt_kernel<float, float>), grid, dim3(256), 0, stream, p);
