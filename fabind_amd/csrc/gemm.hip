@@ -1363,13 +1363,14 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
         wrow[i] = W + (size_t)min(gn, N - 1) * p.ldw;
     }
     auto fetch = [&](Vec8 (&ra)[NA], Vec8 (&rb)[NB], int k0) {
-        const bool second = k0 >= K1;                             // uniform: K1 is a multiple of the k-tile when A2 is given
         const int gk = k0 + lc;
-        const int gkc = gk < K ? gk : (second ? K1 : 0);          // (K % 8 == 0: a chunk is inside or outside as a whole)
+        const bool inside = gk < K;                               // (K % 8 == 0: a chunk is inside or outside as a whole)
+        const bool second = inside && k0 >= K1;                   // k0 >= K1 is uniform: K1 is a multiple of the k-tile when A2 is given
+        const int gkc = inside ? gk : min(lc, K1 - 8);            // a chunk past the end re-reads a valid one of the first operand
 #pragma unroll
         for (int i = 0; i < NA; ++i) ra[i] = load8<float>((second ? a2row[i] : arow[i]) + gkc);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = load8<float>(wrow[i] + gkc);
+        for (int i = 0; i < NB; ++i) rb[i] = load8<float>(wrow[i] + (inside ? gk : min(lc, K - 8)));
     };
     auto split_store = [&](Vec8 (&ra)[NA], Vec8 (&rb)[NB], int st, int k0) {
         bf16_t* hi = sT + (size_t)st * 2 * PLANE;
