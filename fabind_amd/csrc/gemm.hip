@@ -1343,7 +1343,10 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
     // branches and the prologue activation under a run-time switch, and the compiler answered with `s_waitcnt vmcnt(0)` at every join
     // -- 1,764 of them in the kernel, the prefetch distance collapsed to nothing (ISA of round 3's first build; 245 us at
     // M = 98,688, N = K = 512).  PRO: prologue activation as a compile-time variant.
-    const int lr = tid >> 2, lc = (tid & 3) * 8;                 // this thread's row (+ NT/4 per chunk) and k offset in a k-tile
+    // thread -> (row, 8-wide k chunk) of a k-tile: 16 CONSECUTIVE lanes own 16 consecutive rows of one chunk, so that a ds_write_b128
+    // of the split planes hits 16 different 4-bank groups (row stride 20 dwords) like the fragment reads do; with four lanes per row
+    // (the first form) rows r and r + 3 shared banks and 48 % of the kernel's LDS cycles were conflict cycles (profiles/r03_gemm_x3_pmc.txt)
+    const int lr = (tid & 15) | ((tid >> 6) << 4), lc = ((tid >> 4) & 3) * 8;
     const float* arow[NA];
     const float* a2row[NA];
     const float* wrow[NB];
@@ -1372,18 +1375,21 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
 #pragma unroll
         for (int i = 0; i < NB; ++i) rb[i] = load8<float>(wrow[i] + (inside ? gk : min(lc, K - 8)));
     };
+    const bool tile_inside = (m0 + BM_ <= M) && (n0 + BN <= N) && (K % BK == 0);      // uniform: no element of any k-tile needs zeroing
     auto split_store = [&](Vec8 (&ra)[NA], Vec8 (&rb)[NB], int st, int k0) {
         bf16_t* hi = sT + (size_t)st * 2 * PLANE;
         bf16_t* lo = hi + PLANE;
-        const bool kok = k0 + lc < K;
+        const bool kok = tile_inside || k0 + lc < K;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const bool ok = kok && aok[i];
+            if (PRO || !tile_inside) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                float x = ra[i].v[q];
-                if constexpr (PRO) x = apply_act(x, p.act_pro);
-                ra[i].v[q] = ok ? x : 0.f;
+                for (int q = 0; q < 8; ++q) {
+                    float x = ra[i].v[q];
+                    if constexpr (PRO) x = apply_act(x, p.act_pro);
+                    ra[i].v[q] = ok ? x : 0.f;
+                }
             }
             uint4 h, l;
             x3_split8(ra[i], h, l);
@@ -1394,8 +1400,10 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const bool ok = kok && wok[i];
+            if (!tile_inside) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) rb[i].v[q] = ok ? rb[i].v[q] : 0.f;
+                for (int q = 0; q < 8; ++q) rb[i].v[q] = ok ? rb[i].v[q] : 0.f;
+            }
             uint4 h, l;
             x3_split8(rb[i], h, l);
             const int o = (BM_ + lr + (NT / 4) * i) * LS + lc;
