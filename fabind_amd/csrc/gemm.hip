@@ -1279,8 +1279,7 @@ template <int WM, int MINW, bool PRO>
 __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs p) {
     constexpr int BM_ = WM * 64, NT = WM * 128, LS = BK + 8;
     constexpr int ROWS = BM_ + BN, PLANE = ROWS * LS;             // A rows then W rows; one plane = hi or lo of one stage
-    constexpr int NA = BM_ * 4 / NT, NB = BN * 4 / NT;            // 8-float chunks per thread and k-step (a row = 4 chunks)
-    static_assert(NA >= 1 && NB >= 1 && (BM_ * 4) % NT == 0 && (BN * 4) % NT == 0, "staging divides evenly");
+    static_assert((BM_ * 8) % NT == 0 && (BN * 8) % NT == 0, "staging divides evenly");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16_t* sT = (bf16_t*)smem;                                   // [2][2][ROWS][LS]
     // epilogue scratch lives in the (finished) stages: the bf16 / fp32 staging tile first, the row-dot partials behind it
@@ -1343,73 +1342,67 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
     // branches and the prologue activation under a run-time switch, and the compiler answered with `s_waitcnt vmcnt(0)` at every join
     // -- 1,764 of them in the kernel, the prefetch distance collapsed to nothing (ISA of round 3's first build; 245 us at
     // M = 98,688, N = K = 512).  PRO: prologue activation as a compile-time variant.
-    // thread -> (row, 8-wide k chunk) of a k-tile: 16 CONSECUTIVE lanes own 16 consecutive rows of one chunk, so that a ds_write_b128
-    // of the split planes hits 16 different 4-bank groups (row stride 20 dwords) like the fragment reads do; with four lanes per row
-    // (the first form) rows r and r + 3 shared banks and 48 % of the kernel's LDS cycles were conflict cycles (profiles/r03_gemm_x3_pmc.txt)
-    const int lr = (tid & 15) | ((tid >> 6) << 4), lc = ((tid >> 4) & 3) * 8;
-    const float* arow[NA];
-    const float* a2row[NA];
-    const float* wrow[NB];
-    bool aok[NA], wok[NB];
+    // thread -> (row, 4-float piece) of a k-tile: EIGHT consecutive lanes read the 128 contiguous bytes a row contributes to a k-tile, so a
+    // wave's load instruction covers 8 whole 128-byte lines.  Three staging maps were measured at M = 98,688, N = K = 512, bias -> fp32
+    // (profiles/r03_gemm_x3_pmc.txt): four lanes per row with two 16-byte loads per lane 245-262 us; sixteen consecutive lanes on sixteen
+    // rows (conflict-free plane writes: LDS conflict cycles 2.6e7 -> 1.3e7, VALU instructions 4.1e7 -> 3.5e7) 301 us -- 64 quarter-used
+    // lines per load instruction; this one 257 us (128-row tile) / 243 us (256-row tile).  None moves the launch: per SIMD it issues
+    // ~148 k cycles of MFMA and ~146 k cycles of VALU (the split: five instructions per pair of elements) in ~455 k, LDS active 46 %.
+    constexpr int NA4 = BM_ * 8 / NT, NB4 = BN * 8 / NT;          // float4 pieces per thread and k-tile
+    const int lr = tid >> 3, lc = (tid & 7) * 4;                 // this thread's row (+ NT/8 per piece) and k offset in a k-tile
+    const float* arow[NA4];
+    const float* a2row[NA4];
+    const float* wrow[NB4];
+    bool aok[NA4], wok[NB4];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int gm = m0 + lr + (NT / 4) * i;
+    for (int i = 0; i < NA4; ++i) {
+        const int gm = m0 + lr + (NT / 8) * i;
         aok[i] = gm < M;
         const size_t gmc = (size_t)min(gm, M - 1);
         arow[i] = A + gmc * lda_g;
         a2row[i] = A2 ? A2 + gmc * p.lda2 - K1 : arow[i];         // indexed with the global k as well
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int gn = n0 + lr + (NT / 4) * i;
+    for (int i = 0; i < NB4; ++i) {
+        const int gn = n0 + lr + (NT / 8) * i;
         wok[i] = gn < N;
         wrow[i] = W + (size_t)min(gn, N - 1) * p.ldw;
     }
-    auto fetch = [&](Vec8 (&ra)[NA], Vec8 (&rb)[NB], int k0) {
+    auto fetch = [&](float4 (&ra)[NA4], float4 (&rb)[NB4], int k0) {
         const int gk = k0 + lc;
-        const bool inside = gk < K;                               // (K % 8 == 0: a chunk is inside or outside as a whole)
+        const bool inside = gk < K;                               // (K % 8 == 0: a 4-float piece is inside or outside as a whole)
         const bool second = inside && k0 >= K1;                   // k0 >= K1 is uniform: K1 is a multiple of the k-tile when A2 is given
-        const int gkc = inside ? gk : min(lc, K1 - 8);            // a chunk past the end re-reads a valid one of the first operand
+        const int gkc = inside ? gk : min(lc, K1 - 4);            // a piece past the end re-reads a valid one of the first operand
 #pragma unroll
-        for (int i = 0; i < NA; ++i) ra[i] = load8<float>((second ? a2row[i] : arow[i]) + gkc);
+        for (int i = 0; i < NA4; ++i) ra[i] = *(const float4*)((second ? a2row[i] : arow[i]) + gkc);
 #pragma unroll
-        for (int i = 0; i < NB; ++i) rb[i] = load8<float>(wrow[i] + (inside ? gk : min(lc, K - 8)));
+        for (int i = 0; i < NB4; ++i) rb[i] = *(const float4*)(wrow[i] + (inside ? gk : min(lc, K - 4)));
     };
     const bool tile_inside = (m0 + BM_ <= M) && (n0 + BN <= N) && (K % BK == 0);      // uniform: no element of any k-tile needs zeroing
-    auto split_store = [&](Vec8 (&ra)[NA], Vec8 (&rb)[NB], int st, int k0) {
+    auto put4 = [&](bf16_t* hi, bf16_t* lo, int o, float4 x, bool ok) {
+        if (PRO || !tile_inside) {
+            float v[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if constexpr (PRO) v[q] = apply_act(v[q], p.act_pro);
+                v[q] = ok ? v[q] : 0.f;
+            }
+            x = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        const uint32_t h0 = pack2_bf16(x.x, x.y), h1 = pack2_bf16(x.z, x.w);
+        const uint32_t l0 = pack2_bf16(x.x - __uint_as_float(h0 << 16), x.y - __uint_as_float(h0 & 0xffff0000u));
+        const uint32_t l1 = pack2_bf16(x.z - __uint_as_float(h1 << 16), x.w - __uint_as_float(h1 & 0xffff0000u));
+        *(uint2*)&hi[o] = make_uint2(h0, h1);
+        *(uint2*)&lo[o] = make_uint2(l0, l1);
+    };
+    auto split_store = [&](float4 (&ra)[NA4], float4 (&rb)[NB4], int st, int k0) {
         bf16_t* hi = sT + (size_t)st * 2 * PLANE;
         bf16_t* lo = hi + PLANE;
         const bool kok = tile_inside || k0 + lc < K;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const bool ok = kok && aok[i];
-            if (PRO || !tile_inside) {
+        for (int i = 0; i < NA4; ++i) put4(hi, lo, (lr + (NT / 8) * i) * LS + lc, ra[i], kok && aok[i]);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    float x = ra[i].v[q];
-                    if constexpr (PRO) x = apply_act(x, p.act_pro);
-                    ra[i].v[q] = ok ? x : 0.f;
-                }
-            }
-            uint4 h, l;
-            x3_split8(ra[i], h, l);
-            const int o = (lr + (NT / 4) * i) * LS + lc;
-            *(uint4*)&hi[o] = h;
-            *(uint4*)&lo[o] = l;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            const bool ok = kok && wok[i];
-            if (!tile_inside) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) rb[i].v[q] = ok ? rb[i].v[q] : 0.f;
-            }
-            uint4 h, l;
-            x3_split8(rb[i], h, l);
-            const int o = (BM_ + lr + (NT / 4) * i) * LS + lc;
-            *(uint4*)&hi[o] = h;
-            *(uint4*)&lo[o] = l;
-        }
+        for (int i = 0; i < NB4; ++i) put4(hi, lo, (BM_ + lr + (NT / 8) * i) * LS + lc, rb[i], kok && wok[i]);
     };
     const int fr = lane & 15, fk = (lane >> 4) * 8;
     auto compute = [&](int st) {
@@ -1436,7 +1429,7 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_x3_kernel(FabindGemmArgs 
     };
 
     const int nk = (K - kbeg + BK - 1) / BK;
-    Vec8 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+    float4 ra0[NA4], rb0[NB4], ra1[NA4], rb1[NB4];
     // invariant at the top of step kt (even): stage kt & 1 holds tile kt; set 1 holds tile kt+1 (in flight), set 0 tile kt+2 (just requested)
     // (loads past the last k-tile are issued anyway -- clamped addresses, values never used -- so that the loop body has no branch
     //  around a load and the waits count instructions)
