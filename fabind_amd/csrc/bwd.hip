@@ -1336,28 +1336,39 @@ extern "C" int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, 
 
 // finishing pass of the GEMM formulation of the pair-bias adjoint:  T[(jc,o), h] = sum_i D[i,(j,o)] a0[i,h]
 //   db0[node(jc), h] += sum_o w[o,h] T[(jc,o),h];   dw[o,h] += sum_jc b0[node(jc),h] T[(jc,o),h]   (float atomics, sumC adds)
+// One work-group = 16 ligand-side nodes x 256 features: the weight gradient is summed over the work-group's nodes in registers and leaves
+// as ONE atomic per (o, h) and work-group.  (First form: one work-group per node, 8 atomics per node and feature -- 10.7 M float atomics
+// per launch onto 4,096 addresses at the bench shape, 152 us for a 43 MB read; 8 launches per step.)
+constexpr int PBF_NODES = 16;
 __global__ __launch_bounds__(256) void pair_bias_finish_kernel(const float* __restrict__ T, const float* __restrict__ ab, int ld,
                                                                int H, const float* __restrict__ w, const int* c_index, int n_c,
                                                                float* dab, float* dw) {
-    const int jc = blockIdx.x;
-    if (jc >= n_c) return;
-    const int cn = c_index[jc];
-    for (int h = threadIdx.x; h < H; h += 256) {
+    const int h = blockIdx.y * 256 + threadIdx.x;
+    if (h >= H) return;
+    const int j0 = blockIdx.x * PBF_NODES, j1 = min(n_c, j0 + PBF_NODES);
+    float wv[8], dwv[8];
+#pragma unroll
+    for (int o = 0; o < 8; ++o) { wv[o] = w[o * H + h]; dwv[o] = 0.f; }
+    for (int jc = j0; jc < j1; ++jc) {
+        const int cn = c_index[jc];
         const float bj = ab[(size_t)cn * ld + H + h];
         float db = 0.f;
 #pragma unroll
         for (int o = 0; o < 8; ++o) {
             const float t = T[((size_t)jc * 8 + o) * H + h];
-            db += w[o * H + h] * t;
-            atomicAdd(&dw[o * H + h], bj * t);
+            db += wv[o] * t;
+            dwv[o] += bj * t;
         }
         dab[(size_t)cn * ld + H + h] += db;
     }
+#pragma unroll
+    for (int o = 0; o < 8; ++o) atomicAdd(&dw[o * H + h], dwv[o]);
 }
 extern "C" int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, const float* w, const int* c_index,
                                        int n_c, float* dab, float* dw, hipStream_t stream) {
     if (n_c <= 0) return 0;
-    hipLaunchKernelGGL(pair_bias_finish_kernel, dim3(n_c), dim3(256), 0, stream, T, ab, ld, H, w, c_index, n_c, dab, dw);
+    hipLaunchKernelGGL(pair_bias_finish_kernel, dim3((n_c + PBF_NODES - 1) / PBF_NODES, (H + 255) / 256), dim3(256), 0, stream, T, ab, ld, H, w,
+                       c_index, n_c, dab, dw);
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -217,6 +217,7 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
             if constexpr (AUXMUL) {
                 const bf16_t* ap = (const bf16_t*)p.aux + (size_t)row * p.ldaux + col;
                 const bool relu = p.dact_epi == FB_ACT_RELU;
+                const float al = p.alpha;      // (the 1 / (1 - p) of an epilogue dropout whose kept positions are aux's non-zeros)
                 if (vec_ok && col + 8 <= N && (p.ldaux % 8 == 0) && (((uintptr_t)p.aux & 15) == 0)) {
                     const uint4 v = *(const uint4*)sp, a = *(const uint4*)ap;
                     const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, aa[4] = {a.x, a.y, a.z, a.w};
@@ -224,14 +225,14 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float a0 = __uint_as_float(aa[e] << 16), a1 = __uint_as_float(aa[e] & 0xffff0000u);
-                        const float f0 = relu ? (a0 > 0.f ? 1.f : 0.f) : a0, f1 = relu ? (a1 > 0.f ? 1.f : 0.f) : a1;
+                        const float f0 = relu ? (a0 > 0.f ? al : 0.f) : a0 * al, f1 = relu ? (a1 > 0.f ? al : 0.f) : a1 * al;
                         oo[e] = pack2_bf16(__uint_as_float(vv[e] << 16) * f0, __uint_as_float(vv[e] & 0xffff0000u) * f1);
                     }
                     *(uint4*)(dst + (size_t)row * ldc + col) = make_uint4(oo[0], oo[1], oo[2], oo[3]);
                 } else {
                     for (int e = 0; e < 8 && col + e < N; ++e) {
                         const float a0 = bf16_to_f32(ap[e]);
-                        dst[(size_t)row * ldc + col + e] = f32_to_bf16(bf16_to_f32(sp[e]) * (relu ? (a0 > 0.f ? 1.f : 0.f) : a0));
+                        dst[(size_t)row * ldc + col + e] = f32_to_bf16(bf16_to_f32(sp[e]) * (relu ? (a0 > 0.f ? al : 0.f) : a0 * al));
                     }
                 }
                 continue;
@@ -460,6 +461,7 @@ __device__ __forceinline__ bool gemm_epilogue_dispatch(const FabindGemmArgs& p, 
         case 12: gemm_epilogue_fast<BM_, FB_ACT_RELU, true, false, false, RAW_BARRIER, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 13: gemm_epilogue_fast<BM_, FB_ACT_RELU, false, false, true, RAW_BARRIER, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 14: gemm_epilogue_fast<BM_, FB_ACT_NONE, true, false, false, RAW_BARRIER, false, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
+        case 15: gemm_epilogue_fast<BM_, FB_ACT_RELU, true, false, true, RAW_BARRIER, false>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;   // C = relu output (+ dropout), row-dot of it
         case 20: return gemm_epilogue_f32x<BM_, FB_ACT_NONE, false, 1>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0);
         case 21: return gemm_epilogue_f32x<BM_, FB_ACT_NONE, false, 2>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0);
         case 22: return gemm_epilogue_f32x<BM_, FB_ACT_SILU, true, 0>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0);
@@ -1507,7 +1509,7 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     } else if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && p.R && p.r_index && p.C &&
                p.c_dtype == FB_DT_BF16 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
         p.epi_fast = 11;
-    } else if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && p.aux && p.aux_dtype == FB_DT_BF16 &&
+    } else if (!drop && !p.groups && p.k_splits <= 1 && p.aux && p.aux_dtype == FB_DT_BF16 &&      /* (any alpha: applied with act') */
                (p.dact_epi == FB_ACT_RELU || p.dact_epi == FB_ACT_STORED_DERIV) && !p.R && !p.accumulate && !p.r_index && p.C &&
                p.c_dtype == FB_DT_BF16 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2 && !p.bias && !p.store_preact) {
         p.epi_fast = 14;     /* C = (A W^T) * act'(aux): the activation adjoint of an MLP inside its input-gradient GEMM */
@@ -1525,6 +1527,7 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
         else if (p.act_epi == FB_ACT_RELU && !hc && !hc2 && hd) p.epi_fast = 6;
         else if (p.act_epi == FB_ACT_SILU && hc && !hc2 && hd && pre) p.epi_fast = 7;
         else if (p.act_epi == FB_ACT_RELU && hc && !hc2 && hd && pre) p.epi_fast = 8;
+        else if (p.act_epi == FB_ACT_RELU && hc && !hc2 && hd && !pre) p.epi_fast = 15;
     }
     if (p.epi_fast == 0 && !drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.accumulate && !p.r_index && !p.R && p.C != nullptr &&
         p.c_dtype == FB_DT_F32 && !p.dotvec && !p.store_preact && !p.C16 && !foldq) {

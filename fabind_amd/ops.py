@@ -403,12 +403,83 @@ def mlp2(x, W1, b1, act, W2, b2, residual=None, x2=None, want16=False):
     return linear(t, W2, b2, residual=residual, want16=want16)
 
 
+class _MLP2Relu(torch.autograd.Function):
+    """y = act2(drop(relu(x W1^T + b1)) W2^T + b2) [dropout on y when act2 = relu] (+ residual when act2 = none) as ONE autograd node:
+    the two Linears of the FABind+ LN-MLPs (model_utils.py:10-74) with the ReLU + dropout pairs inside the GEMM epilogues.  What is
+    saved are the two epilogue outputs themselves -- their zeros are the dropped and the inactive positions -- and the backward applies
+    the hidden layer's adjoint ([t > 0] / (1 - p)) inside the input-gradient GEMM of the second Linear while it flushes its tile, so the
+    [M, hidden] gradient is written once instead of written, re-read and re-written by a separate pass; both bias gradients ride along
+    with the weight-gradient contractions (or with the one pass over dy that the output activation needs anyway)."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, residual, last_act, out_dtype, p_drop, seed1, seed2):
+        assert not (last_act and residual is not None), "relu + dropout on the output: the residual is added by the caller"
+        thr = int(p_drop * 65536.0 + 0.5)
+        ctx.drop_scale = 1.0 / (1.0 - thr / 65536.0)
+        ad = act_dtype()
+        M = x.shape[0]
+        t = torch.empty((M, W1.shape[0]), dtype=ad, device=x.device)
+        K.gemm(x, W1, bias=b1, act_epi=K.ACT_RELU, out=t, p_drop=p_drop, seed=seed1)
+        y = torch.empty((M, W2.shape[0]), dtype=out_dtype, device=x.device)
+        if last_act:
+            K.gemm(t, W2, bias=b2, act_epi=K.ACT_RELU, out=y, p_drop=p_drop, seed=seed2)
+        else:
+            K.gemm(t, W2, bias=b2, residual=residual, out=y)
+        ctx.last_act, ctx.has_res = last_act, residual is not None
+        ctx.sink_res = _sink_of(residual)
+        ctx.save_for_backward(x, W1, W2, t, y if last_act else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W1, W2, t, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        md = mm_dtype()
+        ni = ctx.needs_input_grad
+        s = ctx.drop_scale
+        db2 = None
+        if ctx.last_act:
+            dpre2, db2 = _mul_dact_colsum(dy, y, K.ACT_RELU, md, s)
+        elif dy.dtype != md:
+            dpre2, db2 = _mul_dact_colsum(dy, None, K.ACT_NONE, md)
+        else:
+            dpre2 = dy
+        dW2 = None
+        if ni[3] and db2 is None and ni[4]:
+            dW2, db2 = _weight_grad(dpre2, t, K.ACT_NONE, None, W2.dtype, want_db=True)
+        elif ni[3]:
+            dW2 = _weight_grad(dpre2, t, K.ACT_NONE, None, W2.dtype)
+        if ni[4] and db2 is None:
+            db2 = K.colsum(dpre2)
+        dpre1, _ = K.gemm(dpre2, _wt(W2), aux=t, dact=K.ACT_RELU, alpha=s, out_dtype=md)          # (dpre2 W2) * [t > 0] / (1 - p)
+        dW1 = db1 = None
+        if ni[1] and ni[2]:
+            dW1, db1 = _weight_grad(dpre1, x, K.ACT_NONE, None, W1.dtype, want_db=True)
+        else:
+            dW1 = _weight_grad(dpre1, x, K.ACT_NONE, None, W1.dtype) if ni[1] else None
+            db1 = K.colsum(dpre1) if ni[2] else None
+        dx = K.gemm(dpre1, _wt(W1), out_dtype=x.dtype)[0] if ni[0] else None
+        dres = None
+        if ctx.has_res and ni[5]:
+            dres = dy if dy.dtype == torch.float32 else dy.float()
+            if ctx.sink_res is not None:
+                dres = ctx.sink_res.deposit(dres)
+        return dx, dW1, db1, dW2, (db2 if ni[4] else None), dres, None, None, None, None, None
+
+
+def mlp2_relu(x, W1, b1, W2, b2, last_act, residual=None, out_dtype=torch.float32, p_drop=0.0):
+    """One-node form of relu-Linear -> [dropout] -> Linear (-> relu -> [dropout] | + residual) under autograd; bf16 operands only
+    (the caller falls back to chained `linear` nodes otherwise)."""
+    seeds = torch.randint(0, 2 ** 31 - 1, (2,)).tolist() if p_drop > 0.0 else (0, 0)
+    return _MLP2Relu.apply(x, W1, b1, W2, b2, residual, last_act, out_dtype, p_drop, int(seeds[0]), int(seeds[1]))
+
+
 # ------------------------------------------------------------------------------------------------
 # linear + row-dot:  s_part[m, t] = sum_{n in tile t} act_epi(act_pro(x) W^T + b)[m,n] * u[n]
 # ------------------------------------------------------------------------------------------------
-def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store, p_drop=0.0, seed=0, fold=None):
-    """GEMM with row-dot epilogue; store=True keeps the pre-activation matrix (training).  fold = (row_mu, row_rs, col_c):
-    LayerNorm of the rows of x folded into the epilogue (inference)."""
+def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store, p_drop=0.0, seed=0, fold=None, post=False):
+    """GEMM with row-dot epilogue; store=True keeps the pre-activation matrix (training) -- or, with post=True, the activation's
+    output after the epilogue dropout.  fold = (row_mu, row_rs, col_c): LayerNorm of the rows of x folded into the epilogue (inference)."""
     M, Kd = x.shape
     N = W.shape[0]
     nt = (N + K.GEMM_BN - 1) // K.GEMM_BN
@@ -419,7 +490,7 @@ def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store, p_drop=0.0, seed=0, fold=N
     a.M, a.N, a.K, a.K1 = M, N, Kd, Kd
     a.lda, a.ldw, a.ldc, a.dot_ld = x.stride(0), W.stride(0), N, nt
     a.a_dtype, a.w_dtype, a.c_dtype = dt_code(x.dtype), dt_code(W.dtype), dt_code(z.dtype) if store else 0
-    a.act_pro, a.act_epi, a.store_preact, a.alpha = act_pro, act_epi, 1, 1.0
+    a.act_pro, a.act_epi, a.store_preact, a.alpha = act_pro, act_epi, (0 if post else 1), 1.0
     a.p_drop, a.drop_seed = float(p_drop), int(seed) & 0xFFFFFFFF
     if fold is not None:
         a.store_preact = 0
@@ -458,11 +529,43 @@ class _LinearRowdot(torch.autograd.Function):
         return dx, dW, db, du, None, None
 
 
+class _LinearRowdotDrop(torch.autograd.Function):
+    """Row-dot of drop(relu(x W^T + b)) with u under autograd: the epilogue stores the dropped ReLU output z (its zeros are the
+    dropped and the inactive positions), so the adjoint is one pass -- dz = dpart u [z > 0] / (1 - p), du = sum_r dpart z."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, u, p_drop, seed):
+        z, part = _gemm_rowdot(x, W, b, u, K.ACT_NONE, K.ACT_RELU, store=True, p_drop=p_drop, seed=seed, post=True)
+        thr = int(p_drop * 65536.0 + 0.5)
+        ctx.scale = 1.0 / (1.0 - thr / 65536.0)
+        ctx.save_for_backward(x, W, u, z)
+        return part
+
+    @staticmethod
+    def backward(ctx, dpart):
+        x, W, u, z = ctx.saved_tensors
+        M, N = z.shape
+        dps = (dpart * ctx.scale).contiguous()                 # [M, tiles]: the 1 / (1 - p) of the kept positions
+        dz = torch.empty_like(z)
+        nchunk = _nchunk(M)
+        scratch = torch.empty((nchunk, N), dtype=torch.float32, device=z.device)
+        du = torch.empty(N, dtype=torch.float32, device=z.device)
+        check(load().fabind_rowdot_bwd(ptr(z), dt_code(z.dtype), ptr(dps), dps.shape[1], ptr(u), K.ACT_RELU, M, N,
+                                       ptr(dz), ptr(du), ptr(scratch), nchunk, stream()), "fabind_rowdot_bwd")
+        dx, _ = K.gemm(dz, _wt(W), out_dtype=x.dtype)
+        dW, db = _weight_grad(dz, x, K.ACT_NONE, None, W.dtype, want_db=True)
+        return dx, dW, db, du / ctx.scale, None, None
+
+
 def linear_rowdot(x, W, b, u, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, p_drop=0.0, fold=None):
     """p_drop > 0 (no-grad paths only): dropout on act(x W^T + b) before the row-dot with u, inside the epilogue.
     fold = (row_mu, row_rs, col_c) (no-grad, bf16 x): LayerNorm of x's rows folded into the epilogue."""
     if _needs_grad(x, W, b, u):
-        assert p_drop == 0.0 and fold is None, "epilogue dropout / LayerNorm fold have no autograd path"
+        assert fold is None, "the LayerNorm fold has no autograd path"
+        if p_drop > 0.0:
+            assert act_pro == K.ACT_NONE and act_epi == K.ACT_RELU, "epilogue dropout under autograd: ReLU outputs only"
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+            return _LinearRowdotDrop.apply(x, W, b, u, p_drop, seed)
         return _LinearRowdot.apply(x, W, b, u, act_pro, act_epi)
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
     return _gemm_rowdot(x, W, b, u, act_pro, act_epi, store=False, p_drop=p_drop, seed=seed, fold=fold)[1]

@@ -356,6 +356,8 @@ class _InterView:
 # ------------------------------------------------------------------------------------------------
 # layers
 # ------------------------------------------------------------------------------------------------
+MLP2_NODE = os.environ.get("FABIND_PLUS_MLP2_NODE", "1") == "1"      # training: the two Linears of an LN-MLP as one autograd node (ops._MLP2Relu)
+ROWDOT_DROP_GRAD = os.environ.get("FABIND_PLUS_ROWDOT_DROP", "1") == "1"   # training: coord-MLP row-dot with its dropout inside the GEMM epilogue
 EPI_DROP_GRAD = os.environ.get("FABIND_EPI_DROP_GRAD", "1") == "1"   # training: ReLU + dropout inside the GEMM epilogue (no torch mask kernels)
 
 
@@ -371,6 +373,15 @@ def ln_mlp(m, x, last_act, residual=None, out_dtype=torch.float32, pdrop=0.0):
     ad = ops.act_dtype()
     y = ln_rows(x, m["ln_w"], m["ln_b"], ad, m["k_pad"]) if m["ln_w"] is not None else x
     act2 = K.ACT_RELU if last_act else K.ACT_NONE
+    if (MLP2_NODE and (pdrop == 0.0 or EPI_DROP_GRAD) and ops.needs_grad(y, m["W1"], m["W2"], residual)
+            and y.dtype == torch.bfloat16 and m["W1"].dtype == torch.bfloat16 and m["b1"] is not None and m["b2"] is not None
+            and m["W1"].shape[0] % 8 == 0 and m["W2"].shape[0] % 8 == 0):
+        # both Linears as one autograd node (ops._MLP2Relu); relu + dropout ahead of a residual: the node returns the dropped
+        # activation, the residual is added here
+        if last_act and residual is not None:
+            y2 = ops.mlp2_relu(y, m["W1"], m["b1"], m["W2"], m["b2"], True, None, torch.float32, pdrop)
+            return (residual + y2).to(out_dtype)
+        return ops.mlp2_relu(y, m["W1"], m["b1"], m["W2"], m["b2"], last_act, residual, out_dtype, pdrop)
     if pdrop > 0.0 and ops.needs_grad(y, m["W1"], m["W2"], residual):
         # under autograd the ReLU + dropout pairs run inside the GEMM epilogue too (ops._Linear: the zeros of the saved output are the
         # dropped positions); only a dropout that is followed by a residual keeps the torch mask
@@ -404,7 +415,7 @@ def _coord_scalar(c, v, pd):
         mu, rs = K.row_stats(v, fp["eps"])
         return ops.linear_rowdot(v, fp["W1w"], fp["dvec"], c["w3"], act_epi=K.ACT_RELU, p_drop=pd, fold=(mu, rs, fp["cvec"]))
     yc = ln_rows(v, c["ln_w"], c["ln_b"], ad, c["k_pad"])
-    if pd > 0.0 and ops.needs_grad(yc, c["W1"], c["w3"]):
+    if pd > 0.0 and ops.needs_grad(yc, c["W1"], c["w3"]) and not (EPI_DROP_GRAD and ROWDOT_DROP_GRAD):
         tc = ops.linear(yc, c["W1"], c["b1"], act_epi=K.ACT_RELU, p_drop=pd) if EPI_DROP_GRAD else \
             _drop(ops.linear(yc, c["W1"], c["b1"], act_epi=K.ACT_RELU), pd)
         return (tc * c["w3"]).sum(1, keepdim=True)
@@ -421,7 +432,9 @@ def gcl_layer(p, h, x, lay, g, clampv, pd=0.0):
     if grad:       # the concatenation is materialised so that LayerNorm is a separate differentiable step
         cat = _EdgeConcat.apply(h, rhohat, g.row_ctx, g.col_ctx, g.rp_ctx, g.ctx_by_col, ad, e["k_pad"])
         y = ln_rows(cat[:, :2 * H + 1], e["ln_w"], e["ln_b"], ad, e["k_pad"])
-        if EPI_DROP_GRAD:
+        if MLP2_NODE and EPI_DROP_GRAD and y.dtype == torch.bfloat16 and e["W1"].dtype == torch.bfloat16:
+            m = ops.mlp2_relu(y, e["W1"], e["b1"], e["W2"], e["b2"], True, None, ad, pd)
+        elif EPI_DROP_GRAD:
             t = ops.linear(y, e["W1"], e["b1"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)
             m = ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)
         else:

@@ -891,3 +891,102 @@ def test_linear_relu_with_epilogue_dropout_under_autograd(mode):
             assert e <= (1e-4 if mode == "fp32" else 3e-2), (name, e)
     finally:
         config.set_precision("fp32")
+
+
+def _hash_keep(seed, M, N, p):
+    """The GEMM epilogue's dropout mask (counter-based hash of seed + row * N + column; include/fabind_hip.h FabindGemmArgs.p_drop)."""
+    r_ = torch.arange(M, dtype=torch.int64)[:, None]
+    c_ = torch.arange(N, dtype=torch.int64)[None, :]
+    MSK = 0xFFFFFFFF
+    hsh = (seed + r_ * N + c_) & MSK
+    hsh = hsh ^ (hsh >> 16); hsh = (hsh * 0x7feb352d) & MSK
+    hsh = hsh ^ (hsh >> 15); hsh = (hsh * 0x846ca68b) & MSK
+    hsh = hsh ^ (hsh >> 16)
+    return ((hsh & 0xFFFF) >= round(p * 65536)).float()
+
+
+@pytest.mark.parametrize("dims", [(900, 136, 264, 128), (1100, 128, 256, 128)])      # register-staged fallback GEMM / LDS-DMA pipelined GEMM
+@pytest.mark.parametrize("last_act,with_res,p", [(True, False, 0.25), (False, True, 0.25), (False, False, 0.0), (True, False, 0.0)])
+def test_relu_mlp_as_one_autograd_node(last_act, with_res, p, dims):
+    """ops.mlp2_relu (the two Linears of a FABind+ LN-MLP, model_utils.py:10-74, as one autograd node: ReLU + dropout in both GEMM
+    epilogues, the hidden layer's adjoint inside the input-gradient GEMM of the second Linear) against torch autograd with the
+    epilogue masks restated on the host."""
+    from fabind_amd import config, ops
+    dev = _dev()
+    config.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(17)
+        M, Kd, N1, N2 = dims
+        x = torch.randn(M, Kd, generator=g).bfloat16()
+        W1 = (torch.randn(N1, Kd, generator=g) / Kd ** 0.5).bfloat16()
+        W2 = (torch.randn(N2, N1, generator=g) / N1 ** 0.5).bfloat16()
+        b1, b2 = torch.randn(N1, generator=g), torch.randn(N2, generator=g)
+        res = torch.randn(M, N2, generator=g) if with_res else None
+        cot = torch.randn(M, N2, generator=g)
+        xd = x.to(dev).requires_grad_(True)
+        W1d, W2d = W1.to(dev).requires_grad_(True), W2.to(dev).requires_grad_(True)
+        b1d, b2d = b1.to(dev).requires_grad_(True), b2.to(dev).requires_grad_(True)
+        rd = res.to(dev).requires_grad_(True) if with_res else None
+        torch.manual_seed(23)
+        seeds = torch.randint(0, 2 ** 31 - 1, (2,)).tolist() if p > 0.0 else (0, 0)
+        torch.manual_seed(23)
+        y = ops.mlp2_relu(xd, W1d, b1d, W2d, b2d, last_act, rd, torch.float32, p)
+        sc = 1.0 / (1.0 - round(p * 65536) / 65536.0)
+        k1 = _hash_keep(seeds[0], M, N1, p) if p > 0.0 else torch.ones(M, N1)
+        k2 = _hash_keep(seeds[1], M, N2, p) if p > 0.0 else torch.ones(M, N2)
+        xr = x.float().clone().requires_grad_(True)
+        W1r, W2r = W1.float().clone().requires_grad_(True), W2.float().clone().requires_grad_(True)
+        b1r, b2r = b1.clone().requires_grad_(True), b2.clone().requires_grad_(True)
+        rr = res.clone().requires_grad_(True) if with_res else None
+        t = torch.relu(xr @ W1r.T + b1r) * k1 * sc
+        t = t + (t.bfloat16().float() - t).detach()                      # the hidden activation is stored / contracted as bf16
+        ref = t @ W2r.T + b2r
+        ref = torch.relu(ref) * k2 * sc if last_act else ref
+        ref = ref + rr if with_res else ref
+        assert (y.detach().float().cpu() - ref.detach()).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max()))
+        (y.float() * cot.to(dev)).sum().backward()
+        (ref * cot).sum().backward()
+        pairs = [(xd.grad, xr.grad, "dx"), (W1d.grad, W1r.grad, "dW1"), (b1d.grad, b1r.grad, "db1"), (W2d.grad, W2r.grad, "dW2"),
+                 (b2d.grad, b2r.grad, "db2")] + ([(rd.grad, rr.grad, "dres")] if with_res else [])
+        for got, want, name in pairs:
+            e = float((got.float().cpu() - want).abs().max() / want.abs().max())
+            assert e <= 3e-2, (name, e)
+    finally:
+        config.set_precision("fp32")
+
+
+@pytest.mark.parametrize("Kd", [136, 128])
+def test_linear_rowdot_with_epilogue_dropout_under_autograd(Kd):
+    """ops.linear_rowdot(act_epi=RELU, p_drop > 0) under autograd (coord_mlp of the FABind+ layers in train mode: Linear -> ReLU ->
+    Dropout -> bias-free Linear to one scalar, model_utils.py:45-58): the dropped ReLU output is what the epilogue stores and dots."""
+    from fabind_amd import config, ops
+    from fabind_amd import kernels as K
+    dev = _dev()
+    config.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(29)
+        M, N, p = 777, 256, 0.25
+        x = torch.randn(M, Kd, generator=g).bfloat16()
+        W = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).bfloat16()
+        b, u = torch.randn(N, generator=g), torch.randn(N, generator=g)
+        cot = torch.randn(M, generator=g)
+        xd, Wd = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True)
+        bd, ud = b.to(dev).requires_grad_(True), u.to(dev).requires_grad_(True)
+        torch.manual_seed(31)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        torch.manual_seed(31)
+        part = ops.linear_rowdot(xd, Wd, bd, ud, act_epi=K.ACT_RELU, p_drop=p)
+        s = part.sum(1)
+        keep = _hash_keep(seed, M, N, p)
+        sc = 1.0 / (1.0 - round(p * 65536) / 65536.0)
+        xr, Wr = x.float().clone().requires_grad_(True), W.float().clone().requires_grad_(True)
+        br, ur = b.clone().requires_grad_(True), u.clone().requires_grad_(True)
+        ref = ((torch.relu(xr @ Wr.T + br) * keep * sc) * ur).sum(1)
+        assert (s.detach().cpu() - ref.detach()).abs().max() <= 2e-2 * max(1.0, float(ref.abs().max()))
+        (s * cot.to(dev)).sum().backward()
+        (ref * cot).sum().backward()
+        for got, want, name in ((xd.grad, xr.grad, "dx"), (Wd.grad, Wr.grad, "dW"), (bd.grad, br.grad, "db"), (ud.grad, ur.grad, "du")):
+            e = float((got.float().cpu() - want).abs().max() / want.abs().max())
+            assert e <= 3e-2, (name, e)
+    finally:
+        config.set_precision("fp32")
