@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FABIND_LIB") or os.path.join(_HERE, "libfabind_hip.so")      # FABIND_LIB: an A/B build (tools/probes)
 
-ABI_VERSION = 12         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
+ABI_VERSION = 13         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -23,7 +23,7 @@ class GemmArgs(ctypes.Structure):
                                   "a_dtype", "w_dtype", "c_dtype", "aux_dtype", "act_pro", "act_epi", "dact_epi",
                                   "accumulate", "store_preact", "n_groups", "max_m", "max_n", "groups_ext", "epi_fast", "k_splits")] + \
                [("alpha", _f), ("p_drop", _f), ("drop_seed", ctypes.c_uint)] + \
-               [(n, _vp) for n in ("row_mu", "row_rs", "col_c", "C16")] + [("ldc16", _i), ("split3", _i)]
+               [(n, _vp) for n in ("row_mu", "row_rs", "col_c", "C16")] + [("ldc16", _i), ("split3", _i), ("r_dtype", _i)]
 
 
 class EdgeBwdArgs(ctypes.Structure):

@@ -115,7 +115,7 @@ __device__ __forceinline__ void gemm_epilogue(const FabindGemmArgs& p, f32x4_t (
                     if (drop_thr) v *= ((fb_hash32(p.drop_seed + (uint32_t)row * (uint32_t)N + (uint32_t)col) & 0xffffu) >= drop_thr) ? drop_scale : 0.f;
                     if (p.R) {
                         long rr = p.r_index ? (long)p.r_index[a_row0 + row] : (a_row0 + row);
-                        v += ((const float*)p.R)[(size_t)rr * p.ldr + col];
+                        v += ld_any(p.R, p.r_dtype, (size_t)rr * p.ldr + col);
                     }
                     if (p.C2) st_any(p.C2, p.c_dtype, (size_t)c_off + (size_t)row * ldc + col, apply_dact(vpre, p.act_epi));
                     if (staged) {
@@ -194,9 +194,10 @@ template <int ACT> __device__ __forceinline__ float fast_dact(float x) {
 template <int BM_, int ACT, bool HAS_C, bool HAS_C2, bool HAS_DOT, bool RAW_BARRIER, bool STORE_PRE = false, bool HAS_RG = false,
           bool FOLD = false,   // FOLD: LayerNorm of the A rows folded in (row_mu / row_rs / col_c); its own dispatch codes, so
                                // every other GEMM keeps the un-folded instruction stream
-          bool AUXMUL = false> // AUXMUL: C = acc * act'(aux) with aux a bf16 [M, N] tile read row-contiguously while the staged
+          bool AUXMUL = false, // AUXMUL: C = acc * act'(aux) with aux a bf16 [M, N] tile read row-contiguously while the staged
                                // tile is flushed (activation adjoint of an MLP fused into the input-gradient GEMM of its
                                // second Linear); dact_epi = RELU (aux = the activation's output) or STORED_DERIV (aux = act')
+          bool RESADD = false> // RESADD: C = (acc + bias) + R with R a bf16 [M, N] residual read row-contiguously during the flush
 __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x4_t (&acc)[4][4], float* sDot, bf16_t* sOut,
                                                    int M, int N, int ldc, int m0, int n0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -234,6 +235,23 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
                         const float a0 = bf16_to_f32(ap[e]);
                         dst[(size_t)row * ldc + col + e] = f32_to_bf16(bf16_to_f32(sp[e]) * (relu ? (a0 > 0.f ? al : 0.f) : a0 * al));
                     }
+                }
+                continue;
+            }
+            if constexpr (RESADD) {
+                const bf16_t* rp = (const bf16_t*)p.R + (size_t)row * p.ldr + col;
+                if (vec_ok && col + 8 <= N && (p.ldr % 8 == 0) && (((uintptr_t)p.R & 15) == 0)) {
+                    const uint4 v = *(const uint4*)sp, a = *(const uint4*)rp;
+                    const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, aa[4] = {a.x, a.y, a.z, a.w};
+                    uint32_t oo[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        oo[e] = pack2_bf16(__uint_as_float(vv[e] << 16) + __uint_as_float(aa[e] << 16),
+                                           __uint_as_float(vv[e] & 0xffff0000u) + __uint_as_float(aa[e] & 0xffff0000u));
+                    *(uint4*)(dst + (size_t)row * ldc + col) = make_uint4(oo[0], oo[1], oo[2], oo[3]);
+                } else {
+                    for (int e = 0; e < 8 && col + e < N; ++e)
+                        dst[(size_t)row * ldc + col + e] = f32_to_bf16(bf16_to_f32(sp[e]) + bf16_to_f32(rp[e]));
                 }
                 continue;
             }
@@ -461,6 +479,7 @@ __device__ __forceinline__ bool gemm_epilogue_dispatch(const FabindGemmArgs& p, 
         case 12: gemm_epilogue_fast<BM_, FB_ACT_RELU, true, false, false, RAW_BARRIER, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 13: gemm_epilogue_fast<BM_, FB_ACT_RELU, false, false, true, RAW_BARRIER, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
         case 14: gemm_epilogue_fast<BM_, FB_ACT_NONE, true, false, false, RAW_BARRIER, false, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;
+        case 16: gemm_epilogue_fast<BM_, FB_ACT_NONE, true, false, false, RAW_BARRIER, false, false, false, false, true>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;   // bf16 C = acc + bias + bf16 R
         case 15: gemm_epilogue_fast<BM_, FB_ACT_RELU, true, false, true, RAW_BARRIER, false>(p, acc, sDot, sOut, M, N, ldc, m0, n0); return true;   // C = relu output (+ dropout), row-dot of it
         case 20: return gemm_epilogue_f32x<BM_, FB_ACT_NONE, false, 1>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0);
         case 21: return gemm_epilogue_f32x<BM_, FB_ACT_NONE, false, 2>(p, acc, (float*)sOut, stage_bytes, M, N, ldc, m0, n0);
@@ -1501,14 +1520,20 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     /* C += A W^T on a plain fp32 C is the residual epilogue with R = C: every element is read and written by the same lane, so
        the fast fp32 epilogue (row-contiguous 16-B accesses) serves it (the generic one stores element by element) */
     if (p.accumulate && !p.R && !p.r_index && !p.groups && p.k_splits <= 1 && p.C != nullptr && p.c_dtype == FB_DT_F32) {
-        p.R = p.C; p.ldr = p.ldc; p.accumulate = 0;
+        p.R = p.C; p.ldr = p.ldc; p.accumulate = 0; p.r_dtype = FB_DT_F32;
     }
-    if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && !p.r_index && p.C != nullptr &&
+    if (!p.R) p.r_dtype = FB_DT_F32;
+    FB_REQUIRE(p.r_dtype == FB_DT_F32 || p.r_dtype == FB_DT_BF16, "fabind_gemm: r_dtype");
+    const bool r32 = p.r_dtype == FB_DT_F32;
+    if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && !p.r_index && p.C != nullptr && r32 &&
         p.c_dtype == FB_DT_F32 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
         p.epi_fast = p.R ? 10 : 9;
-    } else if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && p.R && p.r_index && p.C &&
+    } else if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && p.R && p.r_index && p.C && r32 &&
                p.c_dtype == FB_DT_BF16 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
         p.epi_fast = 11;
+    } else if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && p.R && !p.r_index && p.C && !r32 &&
+               p.c_dtype == FB_DT_BF16 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2 && !p.store_preact) {
+        p.epi_fast = 16;     /* bf16 C = A W^T + bias + bf16 R: the residual stream of the FABind+ pair embedding */
     } else if (!drop && !p.groups && p.k_splits <= 1 && p.aux && p.aux_dtype == FB_DT_BF16 &&      /* (any alpha: applied with act') */
                (p.dact_epi == FB_ACT_RELU || p.dact_epi == FB_ACT_STORED_DERIV) && !p.R && !p.accumulate && !p.r_index && p.C &&
                p.c_dtype == FB_DT_BF16 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2 && !p.bias && !p.store_preact) {

@@ -74,6 +74,7 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     a.lda, a.lda2, a.ldw = _ld(A), (_ld(A2) if A2 is not None else 0), _ld(W)
     a.ldc = (ldc if ldc is not None else (_ld(out) if want_out else 0))
     a.ldr = _ld(residual) if residual is not None else 0
+    a.r_dtype = dt_code(residual.dtype) if residual is not None else 0
     a.ldaux = _ld(aux) if aux is not None else 0
     a.a_dtype, a.w_dtype = dt_code(A.dtype), dt_code(W.dtype)
     a.c_dtype = dt_code(out.dtype) if want_out else 0

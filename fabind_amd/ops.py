@@ -237,6 +237,7 @@ class _Linear(torch.autograd.Function):
         ctx.act_epi, ctx.x_dtype = (K.ACT_SILU if relu_res else act_epi), x.dtype       # backward: stored derivative
         ctx.x2_dtype = x2.dtype if x2 is not None else None
         ctx.has_b, ctx.has_res, ctx.has_x2 = b is not None, residual is not None, x2 is not None
+        ctx.res_dtype = residual.dtype if residual is not None else None
         ctx.sink_x, ctx.sink_res = _sink_of(x), _sink_of(residual)
         ctx.x_shape = x.shape
         ctx.save_for_backward(xin, W, x2in, y if (act_epi == K.ACT_RELU and not relu_res) else None, D)
@@ -271,10 +272,14 @@ class _Linear(torch.autograd.Function):
             if ctx.has_x2 and ctx.needs_input_grad[3]:
                 dx2, _ = K.gemm(dpre, Wt[K1:], out_dtype=torch.float32 if ctx.x2_dtype == torch.float32 else ctx.x2_dtype)
         elif ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[3]):
-            if N % 8 == 0:
+            # few output columns over many rows (FABind+: the 16 pair-bias columns of 6e5 .. 4e6 pairs): a contraction dim that is not
+            # a multiple of 32 sends the input-gradient GEMM to the register-staged fallback kernel, which wrote the [M, K] gradient
+            # at < 1 TB/s (756 us for 648 MB); zero-padded to 32 it runs on the LDS-DMA kernel with the row-contiguous epilogue
+            pad32 = N % 32 != 0 and N <= 64 and dpre.shape[0] >= 65536 and dpre.dtype == torch.bfloat16
+            if N % 8 == 0 and not pad32:
                 Wt, dmm = (ctx.Wt if ctx.Wt is not None else W.t().contiguous()), dpre      # [K, N] (parameter-only transpose)
             else:                                                       # tiny heads (N = 1): pad the contraction dim to 8
-                Np = (N + 7) // 8 * 8
+                Np = (N + 31) // 32 * 32 if pad32 else (N + 7) // 8 * 8
                 Wt = torch.zeros((W.shape[1], Np), dtype=W.dtype, device=W.device)
                 Wt[:, :N] = W.t()
                 dmm = torch.zeros((dpre.shape[0], Np), dtype=dpre.dtype, device=dpre.device)
@@ -292,7 +297,9 @@ class _Linear(torch.autograd.Function):
             dW = _weight_grad(dpre, x, K.ACT_NONE, x2, W.dtype)
         if want_db and db is None:
             db = K.colsum(dpre)
-        dres = dy.float() if (ctx.has_res and ctx.needs_input_grad[4]) else None
+        dres = None
+        if ctx.has_res and ctx.needs_input_grad[4]:
+            dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)      # (a bf16 residual stream takes dy as it is)
         if dres is not None and ctx.sink_res is not None:
             dres = ctx.sink_res.deposit(dres)
         return dx, dW, db, dx2, dres, None, None, None, None, None
@@ -426,6 +433,7 @@ class _MLP2Relu(torch.autograd.Function):
         else:
             K.gemm(t, W2, bias=b2, residual=residual, out=y)
         ctx.last_act, ctx.has_res = last_act, residual is not None
+        ctx.res_dtype = residual.dtype if residual is not None else None
         ctx.sink_res = _sink_of(residual)
         ctx.save_for_backward(x, W1, W2, t, y if last_act else None)
         return y
@@ -461,7 +469,7 @@ class _MLP2Relu(torch.autograd.Function):
         dx = K.gemm(dpre1, _wt(W1), out_dtype=x.dtype)[0] if ni[0] else None
         dres = None
         if ctx.has_res and ni[5]:
-            dres = dy if dy.dtype == torch.float32 else dy.float()
+            dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)
             if ctx.sink_res is not None:
                 dres = ctx.sink_res.deposit(dres)
         return dx, dW1, db1, dW2, (db2 if ni[4] else None), dres, None, None, None, None, None

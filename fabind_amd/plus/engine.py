@@ -502,7 +502,7 @@ def cross_part(p, h, z, lay, pairs, pd=0.0, bias=None, p_next=None):
                                            nf["Wbp"] if nf else None, nf["bb"] if nf else None, pd, seed)
     else:
         hd32 = pair_had(ab32, 64, pairs.p_node, pairs.c_node, ad, lay)                               # [pairs, 64]
-        z1 = ops.linear(hd32, p["W_o32"], p["b_o32"], residual=z.float() if z.dtype != torch.float32 else z, out_dtype=ad)
+        z1 = ops.linear(hd32, p["W_o32"], p["b_o32"], residual=z, out_dtype=ad)      # (a bf16 z is added as it is: FabindGemmArgs.r_dtype)
         z = ln_mlp(p["tr_z"], z1, True, out_dtype=ad, pdrop=pd)
     return h, z, bias_next
 

@@ -49,7 +49,7 @@ const char* fabind_last_error(void);
  *     fabind_pair_hadamard_bwd_rows added (the pair-Hadamard adjoint over the inter graph without float atomics);
  *     fabind_layernorm_rows_bwd takes nblk (the caller sizes the partial buffers; the kernel strides rows over that grid).
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 12
+#define FABIND_ABI_VERSION 13
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -106,6 +106,9 @@ typedef struct FabindGemmArgs {
        hi = bf16(x), lo = bf16(x - hi); three bf16 MFMAs per product term, fp32 accumulate; ~2^-17 relative operand error) instead
        of the exact fp32 MFMA.  The reference contracts in fp32 (egnn.py:68-144, model_utils.py:83-131). */
     int split3;
+    /* dtype of R (FB_DT_F32 = 0: the default; FB_DT_BF16: a bf16 residual stream -- the FABind+ pair embedding, cross_att.py:41-46 --
+       is added without a converted copy; row-contiguous 16-byte reads when C is bf16 with no activation, no r_index) */
+    int r_dtype;
 } FabindGemmArgs;
 
 int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream);

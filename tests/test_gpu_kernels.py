@@ -812,7 +812,8 @@ def test_fused_edge_split_bf16_matches_float64(H, p_drop):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
-@pytest.mark.parametrize("R,C,ld", [(1000, 512, 512), (333, 1025, 1088), (77, 128, 128), (50, 36, 36), (129, 1088, 1088), (64, 96, 200)])
+@pytest.mark.parametrize("R,C,ld", [(1000, 512, 512), (333, 1025, 1088), (77, 128, 128), (50, 36, 36), (129, 1088, 1088), (64, 96, 200),
+                                    (1003, 256, 256), (333, 200, 256), (4099, 64, 64), (9001, 128, 136)])
 def test_layernorm_rows_and_adjoint(R, C, ld, dt):
     """Row LayerNorm of the FABind+ LN-MLPs (model_utils.py:10-74) and its adjoint: the eight-columns-per-lane kernels (16-byte
     accesses; rows and leading dimensions that are multiples of 8) and the scalar fallback (C = 36), incl. the 1025-wide edge input
@@ -986,6 +987,62 @@ def test_linear_rowdot_with_epilogue_dropout_under_autograd(Kd):
         (s * cot.to(dev)).sum().backward()
         (ref * cot).sum().backward()
         for got, want, name in ((xd.grad, xr.grad, "dx"), (Wd.grad, Wr.grad, "dW"), (bd.grad, br.grad, "db"), (ud.grad, ur.grad, "du")):
+            e = float((got.float().cpu() - want).abs().max() / want.abs().max())
+            assert e <= 3e-2, (name, e)
+    finally:
+        config.set_precision("fp32")
+
+
+@pytest.mark.parametrize("M,N,Kd", [(1000, 512, 64), (777, 136, 72), (300, 128, 512)])
+def test_gemm_with_bf16_residual(M, N, Kd):
+    """FabindGemmArgs.r_dtype = bf16 (the FABind+ pair embedding z <- z + linear_out(a * b), cross_att.py:41-46, kept in bf16):
+    the row-contiguous epilogue (bf16 C, no activation) and the generic one (fp32 C) against fp32 torch, and autograd through
+    ops.linear hands the residual its gradient in its own dtype."""
+    from fabind_amd import config, ops
+    from fabind_amd import kernels as K
+    dev = _dev()
+    config.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(M + N)
+        x = torch.randn(M, Kd, generator=g).bfloat16()
+        W = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).bfloat16()
+        b = torch.randn(N, generator=g)
+        R = torch.randn(M, N, generator=g).bfloat16()
+        ref = x.float() @ W.float().T + b + R.float()
+        for od in (torch.bfloat16, torch.float32):
+            y, _ = K.gemm(x.to(dev), W.to(dev), bias=b.to(dev), residual=R.to(dev), out_dtype=od)
+            assert (y.float().cpu() - ref).abs().max() <= (3e-2 if od == torch.bfloat16 else 2e-2) * max(1.0, float(ref.abs().max()))
+        xd, Wd, Rd = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True), R.to(dev).requires_grad_(True)
+        y = ops.linear(xd, Wd, b.to(dev), residual=Rd, out_dtype=torch.bfloat16)
+        cot = torch.randn(M, N, generator=g)
+        (y.float() * cot.to(dev)).sum().backward()
+        assert Rd.grad.dtype == torch.bfloat16
+        assert (Rd.grad.float().cpu() - cot).abs().max() <= 2e-2 * float(cot.abs().max())
+        dx_ref = cot.bfloat16().float() @ W.float()
+        assert (xd.grad.float().cpu() - dx_ref).abs().max() <= 3e-2 * float(dx_ref.abs().max())
+    finally:
+        config.set_precision("fp32")
+
+
+def test_linear_backward_pads_a_narrow_contraction_to_32():
+    """ops.linear with 16 output columns over >= 65536 rows (the FABind+ pair-bias Linear, cross_att.py:118-134): the input-gradient
+    GEMM's contraction dim is zero-padded to 32 (LDS-DMA kernel instead of the register-staged fallback); same gradients."""
+    from fabind_amd import config, ops
+    dev = _dev()
+    config.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(3)
+        M, N, Kd = 70000, 16, 128
+        x = torch.randn(M, Kd, generator=g).bfloat16()
+        W = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).bfloat16()
+        b = torch.randn(N, generator=g)
+        cot = torch.randn(M, N, generator=g)
+        xd, Wd, bd = x.to(dev).requires_grad_(True), W.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+        y = ops.linear(xd, Wd, bd)
+        (y * cot.to(dev)).sum().backward()
+        xr, Wr, br = x.float().requires_grad_(True), W.float().requires_grad_(True), b.clone().requires_grad_(True)
+        ((xr @ Wr.T + br) * cot).sum().backward()
+        for got, want, name in ((xd.grad, xr.grad, "dx"), (Wd.grad, Wr.grad, "dW"), (bd.grad, br.grad, "db")):
             e = float((got.float().cpu() - want).abs().max() / want.abs().max())
             assert e <= 3e-2, (name, e)
     finally:
