@@ -263,34 +263,35 @@ class _Linear(torch.autograd.Function):
             dpre = dy
         K1, N = x.shape[1], W.shape[0]
         dx = dx2 = dW = None
-        sink_x = ctx.sink_x if (ctx.x_dtype == torch.float32 and N % 8 == 0 and ctx.needs_input_grad[0]) else None
-        if sink_x is not None:
-            # x has a shared gradient buffer: its input gradient is stored / accumulated there by the GEMM epilogue (x2, if any,
-            # gets its own GEMM over the other K-slice of W)
-            Wt = ctx.Wt if ctx.Wt is not None else W.t().contiguous()
-            dx = sink_x.gemm_into(dpre, Wt[:K1], x)
-            if ctx.has_x2 and ctx.needs_input_grad[3]:
-                dx2, _ = K.gemm(dpre, Wt[K1:], out_dtype=torch.float32 if ctx.x2_dtype == torch.float32 else ctx.x2_dtype)
-        elif ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[3]):
+        # x with a shared gradient buffer (ops.shared_grad): its input gradient is stored / accumulated there by the GEMM epilogue.
+        # fp32 tensors (the v1 residual stream) and bf16 ones (the FABind+ pair embedding: next layer's residual deposit + this
+        # Linear's gradient + the inter-edge row gather meet in ONE epilogue pass instead of two [pairs, H] adds)
+        sink_x = ctx.sink_x if (ctx.x_dtype in (torch.float32, torch.bfloat16) and ctx.needs_input_grad[0]) else None
+        if ctx.needs_input_grad[0] or (ctx.has_x2 and ctx.needs_input_grad[3]):
             # few output columns over many rows (FABind+: the 16 pair-bias columns of 6e5 .. 4e6 pairs): a contraction dim that is not
-            # a multiple of 32 sends the input-gradient GEMM to the register-staged fallback kernel, which wrote the [M, K] gradient
-            # at < 1 TB/s (756 us for 648 MB); zero-padded to 32 it runs on the LDS-DMA kernel with the row-contiguous epilogue
-            pad32 = N % 32 != 0 and N <= 64 and dpre.shape[0] >= 65536 and dpre.dtype == torch.bfloat16
-            if N % 8 == 0 and not pad32:
+            # a multiple of 64 sends the input-gradient GEMM to the register-staged fallback kernel, which wrote the [M, K] gradient
+            # at < 1 TB/s (756 us for 648 MB); zero-padded to 64 it runs on the LDS-DMA kernel with the row-contiguous epilogue
+            pad64 = N % 64 != 0 and N <= 64 and dpre.shape[0] >= 65536 and dpre.dtype == torch.bfloat16
+            if N % 8 == 0 and not pad64:
                 Wt, dmm = (ctx.Wt if ctx.Wt is not None else W.t().contiguous()), dpre      # [K, N] (parameter-only transpose)
             else:                                                       # tiny heads (N = 1): pad the contraction dim to 8
-                Np = (N + 31) // 32 * 32 if pad32 else (N + 7) // 8 * 8
+                Np = 64 if pad64 else (N + 7) // 8 * 8
                 Wt = torch.zeros((W.shape[1], Np), dtype=W.dtype, device=W.device)
                 Wt[:, :N] = W.t()
                 dmm = torch.zeros((dpre.shape[0], Np), dtype=dpre.dtype, device=dpre.device)
                 dmm[:, :N] = dpre
-            dfull, _ = K.gemm(dmm, Wt, out_dtype=torch.float32 if ctx.x_dtype == torch.float32 else ctx.x_dtype)
-            if ctx.has_x2:
-                dx, dx2 = dfull[:, :K1], dfull[:, K1:]
-                if ctx.x2_dtype != dx2.dtype:
-                    dx2 = dx2.to(ctx.x2_dtype)
+            if sink_x is not None:
+                dx = sink_x.gemm_into(dmm, Wt[:K1], x, ctx.x_dtype)     # (x2, if any, gets its own GEMM over the other K-slice of W)
+                if ctx.has_x2 and ctx.needs_input_grad[3]:
+                    dx2, _ = K.gemm(dmm, Wt[K1:], out_dtype=torch.float32 if ctx.x2_dtype == torch.float32 else ctx.x2_dtype)
             else:
-                dx = dfull
+                dfull, _ = K.gemm(dmm, Wt, out_dtype=torch.float32 if ctx.x_dtype == torch.float32 else ctx.x_dtype)
+                if ctx.has_x2:
+                    dx, dx2 = dfull[:, :K1], dfull[:, K1:]
+                    if ctx.x2_dtype != dx2.dtype:
+                        dx2 = dx2.to(ctx.x2_dtype)
+                else:
+                    dx = dfull
         if ctx.needs_input_grad[1] and want_db and db is None:
             dW, db = _weight_grad(dpre, x, K.ACT_NONE, x2, W.dtype, want_db=True)
         elif ctx.needs_input_grad[1]:
@@ -976,12 +977,15 @@ class GradSink:
             self.rows.append((idx, rows))
         return None
 
-    def gemm_into(self, A, Wt, like):
+    def gemm_into(self, A, Wt, like, dtype=torch.float32):
         """d x (+)= A @ Wt^T-form GEMM (K.gemm(A, Wt)) into the shared buffer; returns the buffer if this call created it
         (the caller hands it to autograd), else None."""
         if self.buf is None:
-            out = torch.empty(like.shape, dtype=torch.float32, device=like.device)
-            K.gemm(A, Wt, out=out, residual=self.pending)
+            out = torch.empty(like.shape, dtype=dtype, device=like.device)      # (`like` may be the bf16 operand copy of an fp32 tensor)
+            pend = self.pending
+            if pend is not None and pend.dtype != out.dtype and not (pend.dtype == torch.bfloat16 and out.dtype == torch.float32):
+                pend = pend.to(out.dtype)
+            K.gemm(A, Wt, out=out, residual=pend)
             self.pending = None
             self.buf = out
             rows, self.rows = self.rows, []

@@ -357,6 +357,7 @@ class _InterView:
 # layers
 # ------------------------------------------------------------------------------------------------
 MLP2_NODE = os.environ.get("FABIND_PLUS_MLP2_NODE", "1") == "1"      # training: the two Linears of an LN-MLP as one autograd node (ops._MLP2Relu)
+Z_SINK = os.environ.get("FABIND_PLUS_Z_SINK", "1") == "1"             # training: shared gradient buffer for the pair embedding of every layer
 ROWDOT_DROP_GRAD = os.environ.get("FABIND_PLUS_ROWDOT_DROP", "1") == "1"   # training: coord-MLP row-dot with its dropout inside the GEMM epilogue
 EPI_DROP_GRAD = os.environ.get("FABIND_EPI_DROP_GRAD", "1") == "1"   # training: ReLU + dropout inside the GEMM epilogue (no torch mask kernels)
 
@@ -504,6 +505,8 @@ def cross_part(p, h, z, lay, pairs, pd=0.0, bias=None, p_next=None):
         hd32 = pair_had(ab32, 64, pairs.p_node, pairs.c_node, ad, lay)                               # [pairs, 64]
         z1 = ops.linear(hd32, p["W_o32"], p["b_o32"], residual=z, out_dtype=ad)      # (a bf16 z is added as it is: FabindGemmArgs.r_dtype)
         z = ln_mlp(p["tr_z"], z1, True, out_dtype=ad, pdrop=pd)
+        if Z_SINK:      # consumers: the inter-edge row gather, the next layer's pair-bias Linear and its residual: one gradient buffer
+            z = ops.shared_grad(z)
     return h, z, bias_next
 
 
@@ -543,7 +546,7 @@ def egnn_forward(P, h, x, z0, lay, g, las, x_las, pairs, batch_id, scale, step, 
     clampv = 10.0 / scale
     h = _drop(ops.linear(h, P["W_in"], P["b_in"]), pd) if (pd > 0.0 and ops.needs_grad(h, P["W_in"])) else \
         ops.linear(h, P["W_in"], P["b_in"], p_drop=pd)
-    z, bias = z0, None
+    z, bias = (ops.shared_grad(z0) if Z_SINK else z0), None
     for i in range(P["L"]):
         h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv, pd)
         if capture is not None:

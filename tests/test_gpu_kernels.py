@@ -1024,9 +1024,9 @@ def test_gemm_with_bf16_residual(M, N, Kd):
         config.set_precision("fp32")
 
 
-def test_linear_backward_pads_a_narrow_contraction_to_32():
+def test_linear_backward_pads_a_narrow_contraction_to_64():
     """ops.linear with 16 output columns over >= 65536 rows (the FABind+ pair-bias Linear, cross_att.py:118-134): the input-gradient
-    GEMM's contraction dim is zero-padded to 32 (LDS-DMA kernel instead of the register-staged fallback); same gradients."""
+    GEMM's contraction dim is zero-padded to 64 (LDS-DMA kernel instead of the register-staged fallback); same gradients."""
     from fabind_amd import config, ops
     dev = _dev()
     config.set_precision("bf16")
