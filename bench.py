@@ -51,6 +51,8 @@ def build_model(hidden, layers, n_iter, seed=0, dropout=0.0):
     return synthetic.condition_for_large_graphs(m)      # random init kept out of the |h| ~ 1e6 regime (see its docstring)
 
 
+PREFETCH = {"1": True, "0": False}.get(os.environ.get("FABIND_BENCH_PREFETCH", ""))   # next batch's layout + input graph on a feeder stream
+prefetching = [False]                                                     # (engine.prefetch); None = the per-mode default below
 LEGACY_BATCH = os.environ.get("FABIND_BENCH_LEGACY_BATCH", "0") == "1"    # round-1 workload (4 geometries tiled 16x, plain init): A/B only
 
 
@@ -279,25 +281,62 @@ def main():
             from fabind_amd import parallel
             reducer = parallel.GradReducer(params, world)           # all-reduce buckets overlap the rest of backward
 
-        def step():
+        # The batch of step k + 1 "arrives" while step k runs, the way a data feeder delivers it (fabind_amd.data.DeviceFeeder works the
+        # same way): fresh tensor objects made on a feeder stream, and engine.prefetch builds its layout and input-coordinate graph
+        # there, so their host round trips do not drain the compute stream at the start of the step.  Every step still does all of
+        # that work, inside the timed region.
+        from fabind_amd import engine as _engine
+        # Measured on one box (gpurun_out/r3p): forward-only 2,587 -> 2,770 complexes/s; fwd+bwd unchanged within the run-to-run spread
+        # (604.8 / 615.0 / 627.7 against 625.3 / 613.1 / 621.7 -- its step boundary is bound by host work of the backward's tail, not
+        # by the drain); pocket-sized shape 2,071 -> 1,939 (host-bound: the stream switches cost more than the drain).  So the
+        # default prefetches in forward-only mode at protein sizes >= 500 and nowhere else; FABIND_BENCH_PREFETCH=1 / 0 forces it.
+        want = (mode == "fwd" and a.n_prot >= 500) if PREFETCH is None else PREFETCH
+        feeder = torch.cuda.Stream(dev) if (want and not LEGACY_BATCH) else None
+        prefetching[0] = feeder is not None
+        pending = []
+
+        def arrive():
             t = dict(batches[counter[0] % n_res])
             counter[0] += 1
-            if not LEGACY_BATCH:
+            if feeder is None:
+                if not LEGACY_BATCH:
+                    t["batch_id"], t["segment_id"] = t["batch_id"].clone(), t["segment_id"].clone()
+                return t, t["X"].clone(), None
+            with torch.cuda.stream(feeder):
                 t["batch_id"], t["segment_id"] = t["batch_id"].clone(), t["segment_id"].clone()
-            X0 = t["X"].clone()
+                X0 = t["X"].clone()
+                with torch.no_grad():
+                    _engine.prefetch(model, X0, t["batch_id"], t["segment_id"], t["compound_edge_index"])
+                ev = torch.cuda.Event()
+                ev.record(feeder)
+            return t, X0, ev
+
+        def step():
+            if feeder is None:
+                t, X0, _ = arrive()
+            else:
+                if not pending:
+                    pending.append(arrive())
+                t, X0, ev = pending.pop()
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(ev)
+                for v in (X0, t["batch_id"], t["segment_id"]):
+                    v.record_stream(cur)
             if mode == "fwd":
                 with torch.no_grad():
                     model(X0, t["H"], t["batch_id"], t["segment_id"], t["mask"], t["is_global"], t["compound_edge_index"],
                           t["LAS_edge_index"], t["coord_LAS"])
-                return
-            for p in params:
-                p.grad = None
-            X, Hh = model(X0, t["H"], t["batch_id"], t["segment_id"], t["mask"], t["is_global"],
-                          t["compound_edge_index"], t["LAS_edge_index"], t["coord_LAS"])
-            loss = (X * X).mean() + (Hh * Hh).mean() * 1e-6
-            loss.backward()
-            if reducer is not None:
-                reducer.finish()
+            else:
+                for p in params:
+                    p.grad = None
+                X, Hh = model(X0, t["H"], t["batch_id"], t["segment_id"], t["mask"], t["is_global"],
+                              t["compound_edge_index"], t["LAS_edge_index"], t["coord_LAS"])
+                loss = (X * X).mean() + (Hh * Hh).mean() * 1e-6
+                loss.backward()
+                if reducer is not None:
+                    reducer.finish()
+            if feeder is not None:
+                pending.append(arrive())                     # the next batch arrives while this step's kernels are still queued
         return step, a.batch, params
 
     def sync():
@@ -377,7 +416,10 @@ def main():
                        "synthetic batch=%d/GPU (%d distinct seeded geometries), %d protein / %d ligand nodes, %d-layer FABind stack "
                        "+ out layer, hidden %d, n_iter=%d, %s" % (a.batch, a.batch, a.n_prot, a.n_lig, a.layers, a.hidden,
                                                                    a.n_iter, a.mode),
-                       "global_batch": a.batch * world, "n_iter": a.n_iter, "pass": a.mode},
+                       "global_batch": a.batch * world, "n_iter": a.n_iter, "pass": a.mode,
+                       "batch_arrival": ("fresh index tensors per step; layout + input-coordinate graph of step k+1 built on a "
+                                         "feeder stream during step k (engine.prefetch)") if prefetching[0]
+                       else "fresh index tensors per step, layout built at the start of the step"},
         }
         if prof and os.environ.get("FABIND_BENCH_DUMP_PROFILE"):
             # development aid: live HIP-event time of every profiled launch group (GEMM shapes, fused kernels) in the timed region

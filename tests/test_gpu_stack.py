@@ -483,3 +483,56 @@ def test_mc_e_gcl_forward_reference_signature_vs_oracle():
         assert x2.shape == x.shape
         assert (h2.cpu() - h_ref).abs().max() <= tol * max(1.0, float(h_ref.abs().max())), prec
         assert (x2[:, 0].cpu() - x_ref).abs().max() <= tol * max(1.0, float(x_ref.abs().max())), prec
+
+
+def test_prefetched_layout_and_graph_are_picked_up_and_change_nothing():
+    """engine.prefetch on a feeder stream (the batch layout and the graph of the input coordinates, att_model.py:209-214, built ahead
+    of the stack call): the call on the same tensor objects takes both -- no second construction -- and returns bit-identical
+    coordinates and features; a call on other tensor objects, or after X changed, builds its own."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    g = load_npz("stack_mid_it2")
+    m = _build_stack(g, dev)
+    inp = stack_inputs(g)
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    args = lambda X, b: (X, t["H"], b, t["segment_id"], t["mask"], t["is_global"], t["compound_edge_index"], t["LAS_edge_index"],
+                         t["coord_LAS"])
+    with torch.no_grad():
+        X_ref, H_ref = m(*args(t["X"].clone(), t["batch_id"].clone()))
+    side = torch.cuda.Stream(dev)
+    built = []
+    orig = engine.Graph.__init__
+
+    def counting(self, *a, **k):
+        built.append(1)
+        return orig(self, *a, **k)
+    engine.Graph.__init__ = counting
+    try:
+        with torch.cuda.stream(side):
+            X0, b0 = t["X"].clone(), t["batch_id"].clone()
+            engine.prefetch(m, X0, b0, t["segment_id"], t["compound_edge_index"])
+            ev = torch.cuda.Event()
+            ev.record(side)
+        torch.cuda.current_stream(dev).wait_event(ev)
+        n_pre = len(built)
+        assert n_pre == 1 and len(engine._PREFETCHED) >= 1
+        with torch.no_grad():
+            X1, H1 = m(*args(X0, b0))
+        n_iter = int(g["cfg"][2])
+        assert len(built) - n_pre == n_iter - 1                          # the first pass took the prefetched graph
+        assert not any(e[0]() is X0 for e in engine._PREFETCHED)         # consumed
+        assert torch.equal(X1, X_ref) and torch.equal(H1, H_ref)
+        # a prefetch for other tensor objects is not taken; a changed X invalidates its entry
+        with torch.cuda.stream(side):
+            X2, b2 = t["X"].clone(), t["batch_id"].clone()
+            engine.prefetch(m, X2, b2, t["segment_id"], t["compound_edge_index"])
+        side.synchronize()
+        X2.add_(0.0)                                                      # version bump
+        n0 = len(built)
+        with torch.no_grad():
+            X3, H3 = m(*args(X2, b2))
+        assert len(built) - n0 == n_iter
+        assert torch.equal(X3, X_ref) and torch.equal(H3, H_ref)
+    finally:
+        engine.Graph.__init__ = orig
+        del engine._PREFETCHED[:]
