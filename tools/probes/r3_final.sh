@@ -23,5 +23,10 @@ FABIND_BENCH_DUMP_PROFILE=$O/x3_launch_groups.txt python bench.py --precision bf
 python tools/pmc_summary.py $(find $O/pmc_f -name "*counter_collection.csv" | head -1) $(find $O/pmc_w -name "*counter_collection.csv" | head -1) $O/pmc.json > $O/pmc_summary.log 2>&1
 { echo "# headline step (bf16, fwd+bwd)"; python tools/pmc_util.py $(find $O/pmc_u -name "*counter_collection.csv" | head -1); echo; echo "# forward-only step (fused cross attention)"; python tools/pmc_util.py $(find $O/pmc_uf -name "*counter_collection.csv" | head -1); echo; echo "# split-bf16 step (bf16x3, fwd+bwd)"; python tools/pmc_util.py $(find $O/pmc_ux -name "*counter_collection.csv" | head -1); } > $O/pmc_util.txt 2>&1
 python tools/probes/gemm_x3_bench.py > $O/gemm_x3_bench.txt 2>&1
+python tools/probes/attn_fused_phases.py > $O/attn_fused.txt 2>&1
+FABIND_BENCH_DUMP_PROFILE=$O/plus_train_launch_groups.txt python bench.py --mode plus_train --no-cpu-baseline --no-extras --steps 3 --warmup 1 > $O/bench_plus_train.json 2>/dev/null
+python bench.py --n-prot 100 --no-cpu-baseline --no-extras --steps 20 --warmup 5 > $O/bench_pocket.json 2>/dev/null
+python bench.py --mode fwd --no-cpu-baseline --no-extras --steps 10 --warmup 3 > $O/bench_fwd.json 2>/dev/null
+FABIND_BENCH_PREFETCH=0 python bench.py --mode fwd --no-cpu-baseline --no-extras --steps 10 --warmup 3 > $O/bench_fwd_serial.json 2>/dev/null
 rm -rf $O/prof $O/profx3 $O/proffwd $O/profpt $O/pmc_f $O/pmc_w $O/pmc_u $O/pmc_uf $O/pmc_ux
 ls $O; cat $O/pmc_util.txt
