@@ -224,6 +224,7 @@ def gcl_params(m, pk=None):
 
 
 _PACK_CACHE = {}
+_LAST_PARAMS = [None, None]
 
 
 def cached_pack(model, builder):
@@ -231,6 +232,7 @@ def cached_pack(model, builder):
     calls) the pack is built once and reused until a parameter is modified or replaced or the precision mode changes;
     under autograd it is rebuilt every call, because it must be a differentiable function of the parameters."""
     params = list(model.parameters())
+    _LAST_PARAMS[:] = [id(model), params]                  # (the builders key their kept request plans on the same list: one module walk)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         return builder(model)
     key = (get_precision(), tuple((p.data_ptr(), p._version) for p in params))
@@ -297,10 +299,12 @@ def att_edge_composed(m, d):
     d["wcr"] = (m.coord_mlp[0].weight @ d["w_rv"]).contiguous()
 
 
-def _build_stack_params(model):
-    """Every copy-type entry (slices / concatenations / zero padding / casts of parameters) goes through ONE param_pack.ParamPack --
-    one launch, one autograd node -- unless FABIND_PARAM_PACK=0 (torch ops, the round-1 behaviour); the products of parameters
-    (composed weights of the pair path) are torch ops on its outputs."""
+PACK_PLAN = os.environ.get("FABIND_PACK_PLAN", "1") == "1"      # keep a model's pack requests across calls (0: rebuild them per call, A/B)
+_PLAN_CACHE = {}           # id(model) -> (key, ParamPack with its requests, request tree, weakref(model))
+
+
+def _stack_requests(model):
+    """The copy-type requests of a stack model's parameter pack (the ParamPack holding them, and the tree of handles / raw parameters)."""
     wd = _wd()
     gnn = model.gnn
     H = gnn.hidden_nf
@@ -329,7 +333,32 @@ def _build_stack_params(model):
         d.update(att_edge_params(m, pk))
         att.append(d)
     P["att"] = att
-    P = pk.resolve(P)
+    return pk, P
+
+
+def _build_stack_params(model):
+    """Every copy-type entry (slices / concatenations / zero padding / casts of parameters) goes through ONE param_pack.ParamPack --
+    one launch, one autograd node -- unless FABIND_PARAM_PACK=0 (torch ops, the round-1 behaviour); the products of parameters
+    (composed weights of the pair path) are torch ops on its outputs.
+    The REQUESTS (which views of which parameters go where: ~130 requests over ~1,000 parameter views, 5-8 ms of Python per call) are
+    a property of the model's parameter objects, not of their values: they are built once per model and precision mode and kept;
+    a training step re-runs the kept pack (fresh outputs, one launch each way).  Replaced or moved parameters rebuild them."""
+    wd = _wd()
+    gnn = model.gnn
+    H = gnn.hidden_nf
+    L = gnn.n_layers
+    il = model.inter_layer
+    params = _LAST_PARAMS[1] if _LAST_PARAMS[0] == id(model) else list(model.parameters())
+    key = (get_precision(), os.environ.get("FABIND_PARAM_PACK", "1"), tuple((id(p_), p_.data_ptr()) for p_ in params))
+    ent = _PLAN_CACHE.get(id(model))
+    if ent is not None and ent[0] == key and ent[3]() is model and isinstance(ent[1], ParamPack) and PACK_PLAN:
+        pk, tree = ent[1], ent[2]
+    else:
+        import weakref
+        pk, tree = _stack_requests(model)
+        if isinstance(pk, ParamPack):
+            _PLAN_CACHE[id(model)] = (key, pk, tree, weakref.ref(model, lambda _r, k=id(model): _PLAN_CACHE.pop(k, None)))
+    P = pk.resolve(tree)
 
     # ---- products of parameters
     Wo0, bo0 = il.linear_out.weight, il.linear_out.bias

@@ -140,16 +140,19 @@ class ParamPack:
     # ---- execution -----------------------------------------------------------------------------------------------
     def run(self):
         """-> list of output tensors (one per request), differentiable w.r.t. the parameters behind the views."""
-        bases, seen = [], {}
-        for _, _, _, pieces in self.reqs:
-            for p in pieces:
-                if isinstance(p, tuple):
-                    continue
-                b = p._base if p._base is not None else p
-                if id(b) not in seen:
-                    seen[id(b)] = len(bases)
-                    bases.append(b)
-        self._bases, self._base_idx = bases, seen
+        if getattr(self, "_n_planned", -1) != len(self.reqs):       # (a pack that is run again keeps its base list)
+            bases, seen = [], {}
+            for _, _, _, pieces in self.reqs:
+                for p in pieces:
+                    if isinstance(p, tuple):
+                        continue
+                    b = p._base if p._base is not None else p
+                    if id(b) not in seen:
+                        seen[id(b)] = len(bases)
+                        bases.append(b)
+            self._bases, self._base_idx, self._n_planned = bases, seen, len(self.reqs)
+            self._fwd = self._bwd = None
+        bases = self._bases
         if torch.is_grad_enabled() and any(b.requires_grad for b in bases):
             return list(_PackFn.apply(self, *bases))
         return self._forward()
@@ -185,24 +188,43 @@ class ParamPack:
     def _strides(v):
         return (0, v.stride(0)) if v.dim() == 1 else (v.stride(0), v.stride(1))
 
-    def _forward(self):
+    # The table of a launch is (static part) + (addresses of this call's outputs / incoming gradients): the static part -- which rows
+    # exist, their shapes, strides, dtypes, parameter addresses, offsets inside an output -- is computed ONCE per pack and kept
+    # (`_plan_fwd` / `_plan_bwd`), so a pack that is run again (engine.py keeps the pack of a model across training steps) costs one
+    # torch.empty per output, one vectorised address computation and one launch instead of ~1,000 Python-level tensor queries.
+    def _plan_forward(self):
         lay = self._layout()
-        outs, rows = [], []
-        for (nd, dtype, dim, pieces), (oshape, offs) in zip(self.reqs, lay):
-            out = torch.empty(oshape if nd == 2 else (oshape[1],), dtype=dtype, device=self.dev)
-            outs.append(out)
+        specs, rows, req, rel = [], [], [], []
+        for k, ((nd, dtype, dim, pieces), (oshape, offs)) in enumerate(zip(self.reqs, lay)):
+            specs.append((oshape if nd == 2 else (oshape[1],), dtype))
             ld, esz_o = oshape[1], _ESZ[dtype]
             for p, (r0, c0, nr, nc) in zip(pieces, offs):
-                dst = out.data_ptr() + (r0 * ld + c0) * esz_o
+                d_rel = (r0 * ld + c0) * esz_o
+                req.append(k)
+                rel.append(d_rel)
                 if isinstance(p, tuple):
-                    rows.append((0, dst, 0, 0, ld, 1, nr, nc, 0, dt_code(dtype), 0))
+                    rows.append((0, 0, 0, 0, ld, 1, nr, nc, 0, dt_code(dtype), 0))
                     continue
                 sr, sc = self._strides(p)
+                # (outputs are fresh allocations: 256-byte aligned, so the alignment of a destination is that of its offset)
                 v4 = int(sc == 1 and nc % 4 == 0 and (sr % 4 == 0 or nr == 1) and ld % 4 == 0 and p.data_ptr() % (4 * _ESZ[p.dtype]) == 0
-                         and dst % (4 * esz_o) == 0)
-                rows.append((p.data_ptr(), dst, sr, sc, ld, 1, nr, nc, dt_code(p.dtype), dt_code(dtype), v4))
+                         and d_rel % (4 * esz_o) == 0)
+                rows.append((p.data_ptr(), 0, sr, sc, ld, 1, nr, nc, dt_code(p.dtype), dt_code(dtype), v4))
         self._lay = lay
-        self._keep = _launch(self._table(rows), self.dev)
+        self._fwd = (specs, self._table(rows), np.asarray(req, dtype=np.int64), np.asarray(rel, dtype=np.uint64))
+        self._fwd_key = tuple(b.data_ptr() for b in self._bases)
+
+    def _forward(self):
+        if getattr(self, "_fwd", None) is None or self._fwd_key != tuple(b.data_ptr() for b in self._bases):
+            self._plan_forward()
+            self._bwd = None
+        specs, table, req, rel = self._fwd
+        outs = [torch.empty(sh, dtype=dt, device=self.dev) for sh, dt in specs]
+        if len(table):
+            optr = np.fromiter((o.data_ptr() for o in outs), dtype=np.uint64, count=len(outs))
+            t = table.copy()
+            t["dst"] = optr[req] + rel
+            self._keep = _launch(t, self.dev)
         return outs
 
     @staticmethod
@@ -212,22 +234,18 @@ class ParamPack:
             t[name] = [r[k] for r in rows]
         return t
 
-    def _backward(self, gouts):
-        """Gradients of the base parameters: every requested view's slice of its parameter's gradient receives the matching block of
-        the output gradient (fp32); parameter elements outside every request stay zero."""
+    def _plan_backward(self):
         bases = self._bases
         sizes = [b.numel() for b in bases]
-        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=self.dev)
-        starts = np.concatenate([[0], np.cumsum(sizes)])
-        rows, keep_g = [], []
+        starts = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        rows, req, rel, esz = [], [], [], []
+        t_reqs = set(self.t_of.values())
         check_overlap = os.environ.get("FABIND_PARAM_PACK", "") == "check"
         cover = [np.zeros(n, dtype=np.int8) for n in sizes] if check_overlap else None
-        t_reqs = set(self.t_of.values())
-        for k_req, ((nd, dtype, dim, pieces), (oshape, offs), g) in enumerate(zip(self.reqs, self._lay, gouts)):
-            if g is None or k_req in t_reqs:             # (nothing differentiates through the transposed copies)
+        for k_req, ((nd, dtype, dim, pieces), (oshape, offs)) in enumerate(zip(self.reqs, self._lay)):
+            if k_req in t_reqs:                          # (nothing differentiates through the transposed copies)
                 continue
-            g = g.contiguous()
-            ld, esz_g = oshape[1], _ESZ[g.dtype]
+            ld = oshape[1]
             for p, (r0, c0, nr, nc) in zip(pieces, offs):
                 if isinstance(p, tuple):
                     continue
@@ -238,18 +256,49 @@ class ParamPack:
                 assert b.is_contiguous() and b.dtype == torch.float32, "ParamPack: parameters are contiguous fp32 tensors"
                 off = p.storage_offset() - b.storage_offset()
                 sr, sc = self._strides(p)
-                dst = flat.data_ptr() + (int(starts[k]) + off) * 4
-                src = g.data_ptr() + (r0 * ld + c0) * esz_g
-                v4 = int(sc == 1 and nc % 4 == 0 and (sr % 4 == 0 or nr == 1) and ld % 4 == 0 and dst % 16 == 0 and src % (4 * esz_g) == 0)
-                rows.append((src, dst, ld, 1, sr, sc, nr, nc, dt_code(g.dtype), dt_code(torch.float32), v4))
+                d_rel = (int(starts[k]) + off) * 4
+                vstat = int(sc == 1 and nc % 4 == 0 and (sr % 4 == 0 or nr == 1) and ld % 4 == 0 and d_rel % 16 == 0)
+                rows.append((0, d_rel, ld, 1, sr, sc, nr, nc, 0, dt_code(torch.float32), vstat))
+                req.append(k_req)
+                rel.append(r0 * ld + c0)                  # in ELEMENTS of the incoming gradient (its dtype is known per call)
                 if check_overlap:
                     idx = (off + np.arange(nr)[:, None] * sr + np.arange(nc)[None, :] * sc).reshape(-1)
                     cover[k][idx] += 1
-            keep_g.append(g)                      # (alive until the launch below has been queued)
         if check_overlap:
             for k, c in enumerate(cover):
                 assert c.max(initial=0) <= 1, "ParamPack: a parameter element is requested twice (its gradient would be overwritten)"
-        self._keep_b = _launch(self._table(rows), self.dev) if rows else None
+        self._bwd = (sizes, starts, self._table(rows), np.asarray(req, dtype=np.int64), np.asarray(rel, dtype=np.int64))
+
+    def _backward(self, gouts):
+        """Gradients of the base parameters: every requested view's slice of its parameter's gradient receives the matching block of
+        the output gradient (fp32); parameter elements outside every request stay zero."""
+        if getattr(self, "_bwd", None) is None:
+            self._plan_backward()
+        sizes, starts, table, req, rel = self._bwd
+        bases = self._bases
+        flat = torch.zeros(int(starts[-1]), dtype=torch.float32, device=self.dev)
+        n_req = len(self.reqs)
+        gptr = np.zeros(n_req, dtype=np.uint64)
+        gesz = np.ones(n_req, dtype=np.int64)
+        gdt = np.zeros(n_req, dtype=np.int32)
+        have = np.zeros(n_req, dtype=bool)
+        keep_g = []
+        for k_req, g in enumerate(gouts):
+            if g is None:
+                continue
+            g = g.contiguous()
+            keep_g.append(g)                      # (alive until the launch below has been queued)
+            gptr[k_req], gesz[k_req], gdt[k_req], have[k_req] = g.data_ptr(), _ESZ[g.dtype], dt_code(g.dtype), True
+        if len(table):
+            sel = have[req]
+            t = table[sel].copy()
+            r = req[sel]
+            src = gptr[r] + (rel[sel] * gesz[r]).astype(np.uint64)
+            t["src"] = src
+            t["dst"] = t["dst"] + np.uint64(flat.data_ptr())
+            t["src_dt"] = gdt[r]
+            t["vec4"] = t["vec4"] & ((src % (4 * gesz[r]).astype(np.uint64)) == 0)
+            self._keep_b = _launch(t, self.dev) if len(t) else None
         return [flat[int(starts[k]):int(starts[k + 1])].view(bases[k].shape) if bases[k].requires_grad else None for k in range(len(bases))]
 
 
