@@ -895,6 +895,30 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const FabindCopySeg* __
         }
         return;
     }
+    if (g.src && g.src_sr == 1 && g.src_sc > 1 && g.dst_sc == 1 && g.rows >= 32 && g.cols >= 32) {
+        // a transposed view of a row-major parameter (the W^T copies the input-gradient GEMMs read): the element-wise loop below reads
+        // one 4-byte element per 64-byte line (393 us for the 340 segments of the bench model's pack, a third of it here); 64 x 64
+        // tiles through LDS read and write whole lines
+        __shared__ float tile[64][65];
+        const int tr = (g.rows + 63) >> 6, tc = (g.cols + 63) >> 6;
+        const int a = threadIdx.x & 63, b0 = threadIdx.x >> 6;
+        for (int t = blockIdx.y; t < tr * tc; t += gridDim.y) {
+            const int r0 = (t / tc) << 6, c0 = (t % tc) << 6;
+#pragma unroll 4
+            for (int b = b0; b < 64; b += 4) {           // source: contiguous along the destination ROW index
+                const int r = r0 + a, c = c0 + b;
+                tile[b][a] = (r < g.rows && c < g.cols) ? ld_any(g.src, g.src_dt, (size_t)((long)c * g.src_sc + r)) : 0.f;
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int b = b0; b < 64; b += 4) {           // destination: contiguous along its column index
+                const int r = r0 + b, c = c0 + a;
+                if (r < g.rows && c < g.cols) st_any(g.dst, g.dst_dt, (size_t)((long)r * g.dst_sr + c), tile[a][b]);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
         const long r = i / g.cols, c = i % g.cols;
         const float v = g.src ? ld_any(g.src, g.src_dt, (size_t)(r * g.src_sr + c * g.src_sc)) : 0.f;

@@ -57,3 +57,55 @@ def test_param_pack_matches_torch_ops(precision):
     finally:
         os.environ.pop("FABIND_PARAM_PACK", None)
         engine.set_precision("bf16")
+
+
+def test_kept_requests_follow_the_parameters_and_transposes_match():
+    """The requests of a model's pack are planned once and re-run every call (engine._build_stack_params): a second call after an
+    in-place parameter update returns the updated values, a parameter whose storage was replaced rebuilds the plan, gradients of the
+    re-run pack equal those of a freshly planned one, and every W^T written next to a W (`_fab_T`: the LDS-tiled transpose path
+    of fabind_multi_copy) is the transpose of that W."""
+    from fabind_amd import engine
+    from fabind_amd.models.att_model import EfficientMCAttModel
+    dev = torch.device("cuda:0")
+    engine.set_precision("bf16")
+    torch.manual_seed(5)
+    m = EfficientMCAttModel(_args(64, 2, 1), 64, 64, 1, n_layers=2, n_iter=1, normalize_coord=lambda x: x / 5.0,
+                            unnormalize_coord=lambda x: x * 5.0).to(dev)
+    params = [p for p in m.parameters() if p.requires_grad]
+
+    def build():
+        for p in params:
+            p.grad = None
+        flat = _flat(engine._build_stack_params(m))
+        g = torch.Generator(device="cpu").manual_seed(11)
+        loss = sum((v.float() * torch.randn(v.shape, generator=g).to(dev)).sum() for k, v in sorted(flat.items()) if v.requires_grad)
+        loss.backward()
+        return flat, [None if p.grad is None else p.grad.detach().clone() for p in params]
+    engine._PLAN_CACHE.clear()
+    f1, g1 = build()                                                  # plans
+    n_T = 0
+    for k, v in f1.items():
+        t = getattr(v, "_fab_T", None)
+        if t is not None:
+            n_T += 1
+            assert torch.equal(t, v.detach().t().contiguous()), k
+    assert n_T >= 10
+    ent = engine._PLAN_CACHE[id(m)]
+    f2, g2 = build()                                                  # re-runs the kept plan
+    assert engine._PLAN_CACHE[id(m)][1] is ent[1]
+    for k in f1:
+        assert torch.equal(f1[k], f2[k]), k
+    for a, b in zip(g1, g2):
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+    w = m.gnn.gcl_0.edge_mlp[2].weight
+    with torch.no_grad():
+        w.add_(1.0)                                                   # in place: same plan, new values
+    f3, _ = build()
+    assert engine._PLAN_CACHE[id(m)][1] is ent[1]
+    assert torch.equal(f3["gcl.0.W2"].float(), w.detach().to(torch.bfloat16).float())
+    w.data = w.data.clone()                                           # replaced storage: the kept views are stale -> new plan
+    with torch.no_grad():
+        w.mul_(0.5)
+    f4, _ = build()
+    assert engine._PLAN_CACHE[id(m)][1] is not ent[1]
+    assert torch.equal(f4["gcl.0.W2"].float(), w.detach().to(torch.bfloat16).float())
