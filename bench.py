@@ -345,17 +345,38 @@ def main():
         torch.cuda.synchronize()
 
     def timed(step, warmup, steps, profile):
-        for _ in range(warmup):
-            step()
+        """Timing protocol of the contract (warm-up, barrier + synchronize, exactly `steps` steps, barrier + synchronize).  Live HIP
+        events for the roofline: the LAST warm-up step times every labelled launch and names the dominant kernel family; the timed
+        region then times that family's launches only (all of them, every step) -- events around every launch of the step cost the
+        host 2 % of the headline step and 6-11 % of the pocket-sized one (same-box pairs in profiles/r03_ab_same_box.txt).
+        FABIND_BENCH_DUMP_PROFILE keeps the events of every launch (the launch-group listing needs them)."""
+        probe = profile and not os.environ.get("FABIND_BENCH_DUMP_PROFILE")      # (the same on every rank: sync() holds a barrier)
+        profile = profile and rank == 0
+        only = None
+        for w in range(warmup):
+            if probe and w == warmup - 1:
+                sync()
+                K.PROFILE, K.PROFILE_ONLY = ({} if profile else None), None
+                step()
+                sync()
+                fams = {}
+                for label, evs in (K.PROFILE or {}).items():
+                    fams[family(label)] = fams.get(family(label), 0.0) + sum(s_.elapsed_time(e_) for s_, e_, _ in evs)
+                K.PROFILE = None
+                if fams:
+                    only = max(fams.items(), key=lambda kv: kv[1])[0].split(" ")[0]
+            else:
+                step()
         sync()
-        K.PROFILE = {} if (profile and rank == 0) else None
+        K.PROFILE = {} if profile else None
+        K.PROFILE_ONLY = only
         t0 = time.time()
         for _ in range(steps):
             step()
         sync()
         dt = time.time() - t0
         prof = K.PROFILE
-        K.PROFILE = None
+        K.PROFILE, K.PROFILE_ONLY = None, None
         if world > 1:
             tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -389,7 +410,7 @@ def main():
                 "flop_per_launch": flops / cnt, "launches": cnt, "avg_us": 1e3 * ms / cnt, "share_of_step": ms / (1e3 * dt)}
 
     step, per_rank, _ = make_step(a.mode, a.n_iter)
-    dt, prof = timed(step, a.warmup, a.steps, True)
+    dt, prof = timed(step, a.warmup, a.steps, os.environ.get("FABIND_BENCH_NO_PROFILE", "0") != "1")   # (=1: no per-launch events, A/B of their cost)
     poses = a.poses if a.mode == "plus_sampling" else 1
     value = per_rank * world * a.steps / dt * poses
     out = None

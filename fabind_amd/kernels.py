@@ -15,10 +15,13 @@ __all__ = ["gemm", "transpose_act", "colsum", "edges_count", "edges_fill", "excl
 GEMM_BN = 128
 GEMM_DEFAULT_CONFIG = 13   # fabind_gemm_set_config default: 256x128x32 tile, 3 stages, 4-waves-per-SIMD bound (csrc/gemm.hip)
 PROFILE = None  # dict: label -> list of (start_event, end_event, flops) around every MFMA-kernel launch (bench.py)
+PROFILE_ONLY = None
 
 
 def _profiled(label, flops, fn):
-    if PROFILE is None:
+    # PROFILE_ONLY: name prefix of the one kernel family to time (bench.py: the dominant family, found in a fully timed warm-up step --
+    # two events around each of the ~300 labelled launches of a step cost the host 1.7-2.6 ms of a 100 ms step, 2-3 ms of a 26 ms one)
+    if PROFILE is None or (PROFILE_ONLY is not None and not label.startswith(PROFILE_ONLY)):
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(cmd, env=None):
     e = dict(os.environ)
     e.update(env or {})
-    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=420)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -55,7 +55,7 @@ def test_bench_self_launches_without_a_launcher():
     assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 6
     bad = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + SMALL, cwd=ROOT,       # no such device in the children
                          env=dict(os.environ, FABIND_BENCH_DEVICE="99", FABIND_BENCH_BACKEND="gloo"), capture_output=True,
-                         text=True, timeout=600)
+                         text=True, timeout=300)
     assert bad.returncode != 0                                   # a failing child is reported through the exit code
 
 
@@ -75,7 +75,7 @@ def test_rccl_backend_paths_with_one_rank():
     and bench.py under torch.distributed.run must initialise, barrier, time and print its line with the RCCL group."""
     launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
     out = subprocess.run(launch + ["--master-port", "29541", os.path.join("tools", "probes", "nccl_single_rank.py")], cwd=ROOT,
-                         capture_output=True, text=True, timeout=600)
+                         capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "RCCL single-rank path ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
     r = _run(launch + ["--master-port", "29542", "bench.py", "--gpus", "1"] + SMALL)
     assert r["n_gpus"] == 1 and r["value"] > 0
