@@ -25,23 +25,15 @@ __device__ __forceinline__ bool within(float ax, float ay, float az, float bx, f
     return __fsqrt_rn(d2) <= cut;
 }
 
+// The walk of one node over the other nodes of its complex, on coordinates in LDS or (complexes of more than EB_LDS_NODES nodes) in
+// global memory.  Two instantiations called from two branches: with ONE pointer selected between the two address spaces the walk
+// compiled to flat_load_dwordx3 (30 of them in the count kernel) -- flat accesses to LDS take the vector-memory path, and the count /
+// fill passes ran at 536 / 721 us for 1.5e8 candidate pairs; with the address space known they are ds_read_b96 broadcasts.
 template <bool FILL>
-__global__ __launch_bounds__(EB_THREADS) void edges_kernel(const float* __restrict__ x, const int* node_off,
-                                                           const int* c_cnt, const int* bond_row, const int* bond_col,
-                                                           const int* bond_off, float cut_intra, float cut_inter,
-                                                           int* deg_ctx, int* deg_int, const int* rowptr_ctx,
-                                                           const int* rowptr_int, int* col_ctx, int* row_ctx,
-                                                           int* col_int, int* row_int) {
-    __shared__ float sx[EB_LDS_NODES * 3];
-    const int b = blockIdx.y;
-    const int off = node_off[b], n = node_off[b + 1] - off, C = c_cnt[b];
-    if ((int)(blockIdx.x * EB_THREADS) >= n) return;
-    const bool use_lds = n <= EB_LDS_NODES;
-    if (use_lds) {
-        for (int i = threadIdx.x; i < n * 3; i += EB_THREADS) sx[i] = x[(size_t)off * 3 + i];
-        __syncthreads();
-    }
-    const float* px = use_lds ? sx : x + (size_t)off * 3;
+__device__ __forceinline__ void edges_walk(const float* px, const int b, const int off, const int n, const int C,
+                                           const int* bond_row, const int* bond_col, const int* bond_off, const float cut_intra,
+                                           const float cut_inter, int* deg_ctx, int* deg_int, const int* rowptr_ctx,
+                                           const int* rowptr_int, int* col_ctx, int* row_ctx, int* col_int, int* row_int) {
     const int u = blockIdx.x * EB_THREADS + threadIdx.x;  // local node index
     if (u >= n) return;
     const int gu = off + u;
@@ -61,6 +53,7 @@ __global__ __launch_bounds__(EB_THREADS) void edges_kernel(const float* __restri
         for (int e = bond_off[b]; e < bond_off[b + 1]; ++e)
             if (bond_row[e] == gu) EMIT_CTX(FILL ? bond_col[e] : 0);
         EMIT_CTX(off);
+#pragma unroll 8
         for (int v = C + 1; v < n; ++v)
             if (within(ux, uy, uz, px[v * 3], px[v * 3 + 1], px[v * 3 + 2], cut_inter)) EMIT_INT(off + v);
     } else if (u == C) {                // glb_p: glb_c sorts first (smaller index), then every residue
@@ -70,6 +63,9 @@ __global__ __launch_bounds__(EB_THREADS) void edges_kernel(const float* __restri
     } else {                            // protein residue: radial neighbours ascending, then star to glb_p
         for (int v = 1; v < C; ++v)
             if (within(ux, uy, uz, px[v * 3], px[v * 3 + 1], px[v * 3 + 2], cut_inter)) EMIT_INT(off + v);
+        // (one thread per node walks every other node of its complex: the walk is a chain of broadcast LDS reads -- unrolled so that
+        //  eight candidates' coordinates are in flight per lane; with < 2 waves per SIMD nothing else hides their latency)
+#pragma unroll 8
         for (int v = C + 1; v < n; ++v)
             if (v != u && within(ux, uy, uz, px[v * 3], px[v * 3 + 1], px[v * 3 + 2], cut_intra)) EMIT_CTX(off + v);
         EMIT_CTX(off + C);
@@ -77,6 +73,28 @@ __global__ __launch_bounds__(EB_THREADS) void edges_kernel(const float* __restri
 #undef EMIT_CTX
 #undef EMIT_INT
     if (!FILL) { deg_ctx[gu] = nc; deg_int[gu] = ni; }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(EB_THREADS) void edges_kernel(const float* __restrict__ x, const int* node_off,
+                                                           const int* c_cnt, const int* bond_row, const int* bond_col,
+                                                           const int* bond_off, float cut_intra, float cut_inter,
+                                                           int* deg_ctx, int* deg_int, const int* rowptr_ctx,
+                                                           const int* rowptr_int, int* col_ctx, int* row_ctx,
+                                                           int* col_int, int* row_int) {
+    __shared__ float sx[EB_LDS_NODES * 3];
+    const int b = blockIdx.y;
+    const int off = node_off[b], n = node_off[b + 1] - off, C = c_cnt[b];
+    if ((int)(blockIdx.x * EB_THREADS) >= n) return;
+    const bool use_lds = n <= EB_LDS_NODES;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < n * 3; i += EB_THREADS) sx[i] = x[(size_t)off * 3 + i];
+        __syncthreads();
+    }
+    if (use_lds) edges_walk<FILL>(sx, b, off, n, C, bond_row, bond_col, bond_off, cut_intra, cut_inter, deg_ctx, deg_int, rowptr_ctx,
+                                  rowptr_int, col_ctx, row_ctx, col_int, row_int);
+    else edges_walk<FILL>(x + (size_t)off * 3, b, off, n, C, bond_row, bond_col, bond_off, cut_intra, cut_inter, deg_ctx, deg_int,
+                          rowptr_ctx, rowptr_int, col_ctx, row_ctx, col_int, row_int);
 }
 
 extern "C" int fabind_edges_count(const float* x, const int* node_off, const int* c_cnt, int B, int max_n,
