@@ -349,7 +349,7 @@ def _build_stack_params(model):
     L = gnn.n_layers
     il = model.inter_layer
     params = _LAST_PARAMS[1] if _LAST_PARAMS[0] == id(model) else list(model.parameters())
-    key = (get_precision(), os.environ.get("FABIND_PARAM_PACK", "1"), tuple((id(p_), p_.data_ptr()) for p_ in params))
+    key = (get_precision(), os.environ.get("FABIND_PARAM_PACK", "1"), tuple((id(p_), p_.data_ptr(), p_.requires_grad) for p_ in params))
     ent = _PLAN_CACHE.get(id(model))
     if ent is not None and ent[0] == key and ent[3]() is model and isinstance(ent[1], ParamPack) and PACK_PLAN:
         pk, tree = ent[1], ent[2]
