@@ -178,16 +178,18 @@ __global__ __launch_bounds__(256) void pair_hadamard_kernel(const float* __restr
                                                             int ld0, int H, const float* __restrict__ a1,
                                                             const float* __restrict__ b1, int ld1, int H2,
                                                             const int* red_p, const int* red_c, int n_red, void* hd,
-                                                            int hd_dt, int ldh) {
-    const int lane = threadIdx.x & 63;
-    int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+                                                            int hd_dt, int ldh, int lp) {
+    // lp lanes per pair (16 / 32 / 64): narrow products (the 64-wide all-pairs product of FABind+, 3.9 M pairs in the pocket
+    // model) put 4 / 2 pairs on a wave -- one pair per wave kept 16 lanes busy and wrote 504 MB in 828 us
+    const int lane = threadIdx.x & 63, sl = lane % lp;
+    const int e = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (64 / lp) + lane / lp;
     if (e >= n_red) return;
     const int pn = red_p[e], cn = red_c[e];
-    for (int c = lane * 4; c < H; c += 256) {
+    for (int c = sl * 4; c < H; c += lp * 4) {
         float4 a = *(const float4*)(a0 + (size_t)pn * ld0 + c), b = *(const float4*)(b0 + (size_t)cn * ld0 + c);
         st4_any(hd, hd_dt, (size_t)e * ldh + c, make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w));
     }
-    for (int c = lane * 4; c < H2; c += 256) {
+    for (int c = sl * 4; c < H2; c += lp * 4) {
         float4 a = *(const float4*)(a1 + (size_t)pn * ld1 + c), b = *(const float4*)(b1 + (size_t)cn * ld1 + c);
         st4_any(hd, hd_dt, (size_t)e * ldh + H + c, make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w));
     }
@@ -198,8 +200,11 @@ extern "C" int fabind_pair_hadamard(const float* a0, const float* b0, int ld0, i
                                     int ldh, hipStream_t stream) {
     FB_REQUIRE(H % 4 == 0 && H2 % 4 == 0 && ld0 % 4 == 0 && ld1 % 4 == 0 && ldh % 4 == 0, "fabind_pair_hadamard: % 4");
     if (n_red <= 0) return 0;
-    hipLaunchKernelGGL(pair_hadamard_kernel, dim3((n_red + 3) / 4), dim3(256), 0, stream, a0, b0, ld0, H, a1, b1, ld1,
-                       H2, red_p, red_c, n_red, hd, hd_dt, ldh);
+    const int widest = H > H2 ? H : H2;
+    const int lp = widest <= 64 ? 16 : widest <= 128 ? 32 : 64;
+    const int per_block = 4 * (64 / lp);
+    hipLaunchKernelGGL(pair_hadamard_kernel, dim3((n_red + per_block - 1) / per_block), dim3(256), 0, stream, a0, b0, ld0, H, a1, b1, ld1,
+                       H2, red_p, red_c, n_red, hd, hd_dt, ldh, lp);
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -1047,3 +1047,25 @@ def test_linear_backward_pads_a_narrow_contraction_to_64():
             assert e <= 3e-2, (name, e)
     finally:
         config.set_precision("fp32")
+
+
+@pytest.mark.parametrize("H,dt", [(512, torch.bfloat16), (64, torch.bfloat16), (20, torch.bfloat16), (64, torch.float32)])
+def test_edge_concat_rows(H, dt):
+    """[h[row] | h[col] | rhohat | 0 ...] per edge (the FABind+ edge-MLP input, egnn.py:104-118): the eight-columns-per-lane bf16
+    path and the scalar path against torch indexing."""
+    from fabind_amd.plus import engine as pe
+    dev = _dev()
+    g = torch.Generator().manual_seed(H)
+    N, E = 300, 5000
+    h = torch.randn(N, H, generator=g)
+    row = torch.sort(torch.randint(0, N, (E,), generator=g))[0].to(torch.int32)
+    col = torch.randint(0, N, (E,), generator=g).to(torch.int32)
+    rh = torch.rand(E, generator=g)
+    pad = (2 * H + 1 + 7) // 8 * 8 + 8
+    rp = torch.zeros(N + 1, dtype=torch.int32)
+    rp[1:] = torch.cumsum(torch.bincount(row.long(), minlength=N), 0).to(torch.int32)
+    y = pe._EdgeConcat.apply(h.to(dev), rh.to(dev), row.to(dev), col.to(dev), rp.to(dev), None, dt, pad)
+    ref = torch.zeros(E, pad)
+    ref[:, :H], ref[:, H:2 * H], ref[:, 2 * H] = h[row.long()], h[col.long()], rh
+    assert y.dtype == dt and y.shape == (E, pad)
+    assert torch.equal(y.float().cpu(), ref.to(dt).float())
