@@ -224,7 +224,13 @@ def gcl_params(m, pk=None):
 
 
 _PACK_CACHE = {}
-_LAST_PARAMS = [None, None]
+_LAST_PARAMS = [None, None]                                # [weakref(model), list(model.parameters())] of the last cached_pack call
+
+
+def last_params_of(model):
+    """list(model.parameters()), reusing the walk cached_pack has just made for this very model object."""
+    ref = _LAST_PARAMS[0]
+    return _LAST_PARAMS[1] if (ref is not None and ref() is model) else list(model.parameters())
 
 
 def cached_pack(model, builder):
@@ -232,7 +238,8 @@ def cached_pack(model, builder):
     calls) the pack is built once and reused until a parameter is modified or replaced or the precision mode changes;
     under autograd it is rebuilt every call, because it must be a differentiable function of the parameters."""
     params = list(model.parameters())
-    _LAST_PARAMS[:] = [id(model), params]                  # (the builders key their kept request plans on the same list: one module walk)
+    import weakref
+    _LAST_PARAMS[:] = [weakref.ref(model), params]         # (the builders key their kept request plans on the same list: one module walk)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         return builder(model)
     key = (get_precision(), tuple((p.data_ptr(), p._version) for p in params))
@@ -348,7 +355,7 @@ def _build_stack_params(model):
     H = gnn.hidden_nf
     L = gnn.n_layers
     il = model.inter_layer
-    params = _LAST_PARAMS[1] if _LAST_PARAMS[0] == id(model) else list(model.parameters())
+    params = last_params_of(model)
     key = (get_precision(), os.environ.get("FABIND_PARAM_PACK", "1"), tuple((id(p_), p_.data_ptr(), p_.requires_grad) for p_ in params))
     ent = _PLAN_CACHE.get(id(model))
     if ent is not None and ent[0] == key and ent[3]() is model and isinstance(ent[1], ParamPack) and PACK_PLAN:

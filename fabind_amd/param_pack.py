@@ -85,6 +85,11 @@ class EagerPack:
     def copy(self, view, dtype=None, with_T=False):
         return self.cat([view], 0, dtype)
 
+    def pad2d(self, view, rows, cols, dtype=None, with_T=False):
+        out = torch.zeros((rows, cols), dtype=view.dtype, device=self.dev)
+        out[:view.shape[0], :view.shape[1]] = view
+        return out.to(dtype) if dtype is not None else out
+
     zeros = staticmethod(lambda *shape: ("zeros",) + tuple(shape))
 
     def resolve(self, tree):
@@ -133,6 +138,19 @@ class ParamPack:
     def copy(self, view, dtype=None, with_T=False):
         return self.cat([view], 0, dtype, with_T)
 
+    def pad2d(self, view, rows, cols, dtype=None, with_T=False):
+        """Handle of a [rows, cols] tensor holding the 2-D view in its top-left corner, zeros elsewhere (the zero-padded weights of
+        the FABind+ LN-MLPs: contraction dims padded to the GEMM's K granularity).  with_T as in `cat`."""
+        r, c = view.shape
+        assert view.dim() == 2 and r <= rows and c <= cols
+        dtype = dtype or view.dtype
+        self.reqs.append((2, dtype, "pad", [view, ("zeros", r, cols - c), ("zeros", rows - r, cols)]))
+        k = len(self.reqs) - 1
+        if with_T:
+            self.reqs.append((2, dtype, "pad", [view.t(), ("zeros", c, rows - r), ("zeros", cols - c, rows)]))
+            self.t_of[k] = k + 1
+        return _H(k)
+
     @staticmethod
     def zeros(*shape):
         return ("zeros",) + tuple(shape)
@@ -165,6 +183,10 @@ class ParamPack:
             for p in pieces:
                 sh = tuple(p[1:]) if isinstance(p, tuple) else tuple(p.shape)
                 shapes.append((1, sh[0]) if nd == 1 else sh)
+            if dim == "pad":                 # [view | zeros right] over [zeros bottom]
+                (r, c), (_, cr), (rb, cb) = shapes
+                lay.append(((r + rb, c + cr), [(0, 0, r, c), (0, c, r, cr), (r, 0, rb, cb)]))
+                continue
             if nd == 1 or dim == 1:
                 R = shapes[0][0]
                 assert all(s[0] == R for s in shapes)
@@ -199,6 +221,8 @@ class ParamPack:
             specs.append((oshape if nd == 2 else (oshape[1],), dtype))
             ld, esz_o = oshape[1], _ESZ[dtype]
             for p, (r0, c0, nr, nc) in zip(pieces, offs):
+                if nr == 0 or nc == 0:                 # (an empty zero strip of a pad2d request)
+                    continue
                 d_rel = (r0 * ld + c0) * esz_o
                 req.append(k)
                 rel.append(d_rel)

@@ -25,6 +25,7 @@ from .. import kernels as K
 from .. import ops
 from ..config import fp32_storage, get_precision
 from ..engine import Graph, Layout, _cat, cached_pack
+from ..param_pack import EagerPack, ParamPack
 
 
 def _wd():
@@ -52,33 +53,37 @@ def _padvec(v, n):
 # ------------------------------------------------------------------------------------------------
 # parameters
 # ------------------------------------------------------------------------------------------------
-def _mlp(m, W, k_pad=None, n_pad=None):
-    """LN-MLP pack: LayerNorm (w, b), linear1 padded to [n_pad, k_pad], linear2 padded to [., n_pad]."""
-    w1, w2 = m.linear1.weight, m.linear2.weight
+def _mlp(m, pk, k_pad=None, n_pad=None, w2=True):
+    """LN-MLP pack: LayerNorm (w, b), linear1 padded to [n_pad, k_pad], linear2 padded to [., n_pad].  pk: the pack collecting the
+    copy requests (param_pack.ParamPack: one launch for the whole model; EagerPack: torch ops)."""
+    wd = _wd()
+    w1 = m.linear1.weight
     k_pad = k_pad or w1.shape[1]
     n_pad = n_pad or w1.shape[0]
     has_ln = hasattr(m, "layernorm")
-    return dict(ln_w=m.layernorm.weight.float().contiguous() if has_ln else None,
-                ln_b=m.layernorm.bias.float().contiguous() if has_ln else None,
+    return dict(ln_w=m.layernorm.weight if has_ln else None, ln_b=m.layernorm.bias if has_ln else None,
                 C=w1.shape[1], k_pad=k_pad,
-                W1=W(_padded(w1, n_pad, k_pad)), b1=_padvec(m.linear1.bias, n_pad).float().contiguous(),
-                W2=W(_padded(w2, w2.shape[0], n_pad)),
-                b2=None if m.linear2.bias is None else m.linear2.bias.float().contiguous())
+                W1=pk.pad2d(w1, n_pad, k_pad, wd, with_T=True), b1=pk.cat([m.linear1.bias, pk.zeros(n_pad - w1.shape[0])]),
+                # (w2 = False: the caller requests linear2's one row itself -- a parameter element may sit in ONE request of a pack)
+                W2=pk.pad2d(m.linear2.weight, m.linear2.weight.shape[0], n_pad, wd, with_T=True) if w2 else None,
+                b2=None if m.linear2.bias is None else m.linear2.bias)
 
 
 def prepare_stack_params(model):
     return cached_pack(model, _build_stack_params)
 
 
-def _gcl_pack(m, H):
+def _gcl_pack(m, H, pk=None):
     """Kernel-side parameters of one MC_E_GCL (edge / node / coord LN-MLPs; in bf16 inference also the LayerNorm-folded
-    forms)."""
+    forms).  pk: see _mlp (default: torch ops, resolved here)."""
     wd = _wd()
     infer = not torch.is_grad_enabled()          # cached_pack builds the no-autograd pack under no_grad: inference-only extras
+    own = pk is None
+    pk = pk or EagerPack(m.node_mlp.linear2.weight.device)
     W = lambda t: t.to(wd).contiguous()
     K8 = _pad8(2 * H + 1)
-    d = dict(edge=_mlp(m.edge_mlp, W, K8, K8), node=_mlp(m.node_mlp, W), coord=_mlp(m.coord_mlp, W))
-    d["coord"]["w3"] = m.coord_mlp.linear2.weight[0].float().contiguous()
+    d = dict(edge=_mlp(m.edge_mlp, pk, K8, K8), node=_mlp(m.node_mlp, pk), coord=_mlp(m.coord_mlp, pk, w2=False))
+    d["coord"]["w3"] = pk.copy(m.coord_mlp.linear2.weight[0])
     if wd == torch.bfloat16 and infer and H % 64 == 0:
         # coord_mlp on the messages: LayerNorm folded into the GEMM epilogue (FabindGemmArgs.row_mu / row_rs / col_c)
         cm = m.coord_mlp
@@ -93,37 +98,41 @@ def _gcl_pack(m, H):
                          c_r=W1w[:, :H].sum(1).contiguous(), c_c=W1w[:, H:2 * H].sum(1).contiguous(),
                          eps=float(em.layernorm.eps),
                          dvec=_padvec(em.linear1.weight.float() @ em.layernorm.bias.float() + em.linear1.bias.float(), K8))
-    return d
+    return pk.resolve(d) if own else d
 
 
-def _cam_pack(cam, H):
+def _cam_pack(cam, H, pk=None):
     """Kernel-side parameters of one CrossAttentionModule: both RowAttentionBlocks, the three LN-MLP transitions, the
-    32-wide Hadamard pair update."""
+    32-wide Hadamard pair update.  pk: see _mlp."""
     wd = _wd()
     infer = not torch.is_grad_enabled()
-    W = lambda t: t.to(wd).contiguous()
+    own = pk is None
+    pk = pk or EagerPack(cam.inter_layer.linear_p.weight.device)
     d = {}
     for tag, blk in (("p", cam.p_attention_block), ("c", cam.c_attention_block)):
         a = blk.mha
-        d["Wqg_" + tag] = W(_cat([a.linear_q.weight, a.linear_g.weight]))
-        d["bqg_" + tag] = _cat([torch.zeros_like(a.linear_g.bias), a.linear_g.bias]).contiguous()
-        d["Wkv_" + tag] = W(_cat([a.linear_k.weight, a.linear_v.weight]))
-        d["Wo_" + tag], d["bo_" + tag] = W(a.linear_o.weight), a.linear_o.bias
+        d["Wqg_" + tag] = pk.cat([a.linear_q.weight, a.linear_g.weight], 0, wd, with_T=True)
+        d["bqg_" + tag] = pk.cat([pk.zeros(a.linear_g.bias.shape[0]), a.linear_g.bias])
+        d["Wkv_" + tag] = pk.cat([a.linear_k.weight, a.linear_v.weight], 0, wd, with_T=True)
+        d["Wo_" + tag], d["bo_" + tag] = pk.copy(a.linear_o.weight, wd, with_T=True), a.linear_o.bias
     # pair biases of both blocks from z in one GEMM: columns [p lin 0-3 | p gate 4-7 | c lin 8-11 | c gate 12-15]
     pb, cb = cam.p_attention_block, cam.c_attention_block
-    d["W_pb"] = W(_cat([pb.linear.weight, pb.linear_g.weight, cb.linear.weight, cb.linear_g.weight]))
-    d["b_pb"] = _cat([pb.linear.bias, pb.linear_g.bias, cb.linear.bias, cb.linear_g.bias]).contiguous()
-    d["tr_p"], d["tr_c"] = _mlp(cam.p_transition, W), _mlp(cam.c_transition, W)
-    d["tr_z"] = _mlp(cam.pair_transition, W)
+    d["W_pb"] = pk.cat([pb.linear.weight, pb.linear_g.weight, cb.linear.weight, cb.linear_g.weight], 0, wd, with_T=True)
+    d["b_pb"] = pk.cat([pb.linear.bias, pb.linear_g.bias, cb.linear.bias, cb.linear_g.bias])
+    d["tr_p"], d["tr_c"] = _mlp(cam.p_transition, pk), _mlp(cam.c_transition, pk)
+    d["tr_z"] = _mlp(cam.pair_transition, pk)
     i32 = cam.inter_layer
     # the 32-wide Hadamard block is zero-padded to 64 (a32 | 0 | b32 | 0) so that the contraction with W_o32 runs on the
     # LDS-DMA GEMM path (K % 64 == 0); the padded columns are exact zeros
-    z32w, z32b = torch.zeros_like(i32.linear_p.weight), torch.zeros_like(i32.linear_p.bias)
-    d["W_ab32"] = W(_cat([i32.linear_p.weight, z32w, i32.linear_c.weight, z32w]))  # [128, H]
-    d["b_ab32"] = _cat([i32.linear_p.bias, z32b, i32.linear_c.bias, z32b]).contiguous()
-    d["W_o32"] = W(_cat([i32.linear_out.weight, torch.zeros_like(i32.linear_out.weight)], 1))   # [H, 64]
+    n32, Hn = i32.linear_p.weight.shape
+    d["W_ab32"] = pk.cat([i32.linear_p.weight, pk.zeros(n32, Hn), i32.linear_c.weight, pk.zeros(n32, Hn)], 0, wd, with_T=True)  # [128, H]
+    d["b_ab32"] = pk.cat([i32.linear_p.bias, pk.zeros(n32), i32.linear_c.bias, pk.zeros(n32)])
+    wo = i32.linear_out.weight
+    d["W_o32"] = pk.cat([wo, pk.zeros(wo.shape[0], wo.shape[1])], 1, wd, with_T=True)                                        # [H, 64]
     d["b_o32"] = i32.linear_out.bias
-    if wd == torch.bfloat16 and infer and H in (64, 128, 256, 512):
+    if own:
+        d = pk.resolve(d)
+    if wd == torch.bfloat16 and infer and H in (64, 128, 256, 512) and own:
         # fragment-packed operands of the fused pair-update kernel (csrc/pair_fused.hip, inference)
         tz = cam.pair_transition
         d["pair_fused"] = dict(Wop=K.pack_frag(i32.linear_out.weight), bo=i32.linear_out.bias.float().contiguous(),
@@ -135,23 +144,28 @@ def _cam_pack(cam, H):
     return d
 
 
-def _att_pack(m, H):
-    """Kernel-side parameters of one MC_Att_L: its CrossAttentionModule (_cam_pack) and the inter-edge attention."""
+def _att_pack(m, H, pk=None):
+    """Kernel-side parameters of one MC_Att_L: its CrossAttentionModule (_cam_pack) and the inter-edge attention.  pk: see _mlp (with
+    a shared pack the inference-only extras are left out: shared packs serve the differentiable path)."""
     wd = _wd()
     infer = not torch.is_grad_enabled()
+    own = pk is None
+    pk = pk or EagerPack(m.linear_kv.weight.device)
     W = lambda t: t.to(wd).contiguous()
-    d = _cam_pack(m.cross_attn_module, H)
+    d = _cam_pack(m.cross_attn_module, H, pk if not own else None)
     Wkv, bkv = m.linear_kv.weight, m.linear_kv.bias
-    d["Wqkv"] = W(_cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]]))
-    d["bqkv"] = _cat([m.linear_q.bias, bkv[0::2], bkv[1::2]]).contiguous()
-    d["w_rk"], d["w_rv"] = Wkv[0::2, 0].float().contiguous(), Wkv[1::2, 0].float().contiguous()
-    wb = torch.zeros((8, H), dtype=m.attn_bias_proj.weight.dtype, device=m.attn_bias_proj.weight.device)
-    wb[0] = m.attn_bias_proj.weight[0]
-    d["W_bias"] = W(wb)
-    d["b_bias"] = _padvec(m.attn_bias_proj.bias, 8).float().contiguous()
-    d["coord"] = _mlp(m.coord_mlp, W)
-    d["coord"]["w3"] = m.coord_mlp.linear2.weight[0].float().contiguous()
-    if wd == torch.bfloat16 and infer and H % 8 == 0 and H <= 512:
+    d2 = {}
+    d2["Wqkv"] = pk.cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]], 0, wd, with_T=True)
+    d2["bqkv"] = pk.cat([m.linear_q.bias, bkv[0::2], bkv[1::2]])
+    d2["w_rk"], d2["w_rv"] = pk.copy(Wkv[0::2, 0]), pk.copy(Wkv[1::2, 0])
+    d2["W_bias"] = pk.cat([m.attn_bias_proj.weight[0:1], pk.zeros(7, H)], 0, wd, with_T=True)
+    d2["b_bias"] = pk.cat([m.attn_bias_proj.bias, pk.zeros(8 - m.attn_bias_proj.bias.shape[0])])
+    d2["coord"] = _mlp(m.coord_mlp, pk, w2=False)
+    d2["coord"]["w3"] = pk.copy(m.coord_mlp.linear2.weight[0])
+    if own:
+        d2 = pk.resolve(d2)
+    d.update(d2)
+    if wd == torch.bfloat16 and infer and H % 8 == 0 and H <= 512 and own:
         # coord_mlp's LayerNorm folded into a per-node projection of V (csrc/norm.hip: inter_coord_fold_kernel)
         cm = m.coord_mlp
         W1w = cm.linear1.weight.float() * cm.layernorm.weight.float()[None, :]
@@ -159,8 +173,19 @@ def _att_pack(m, H):
         d["coord_fold"] = dict(W1w=W(W1w), wc=wc.contiguous(), q_w=float((wc * wc).sum()), u=(W1w @ wc).contiguous(),
                                d=(cm.linear1.weight.float() @ cm.layernorm.bias.float() + cm.linear1.bias.float()).contiguous(),
                                eps=float(cm.layernorm.eps), w3=d["coord"]["w3"])
-    d["zeroH"] = torch.zeros(H, dtype=torch.float32, device=Wkv.device)
+    d["zeroH"] = _zeros_const(H, Wkv.device)
     return d
+
+
+_ZEROS = {}
+
+
+def _zeros_const(n, dev):
+    """A shared read-only zero vector (the unused per-node bias operands of the inter-edge attention kernels)."""
+    z = _ZEROS.get((n, dev))
+    if z is None:
+        z = _ZEROS[(n, dev)] = torch.zeros(n, dtype=torch.float32, device=dev)
+    return z
 
 
 def gcl_params(m):
@@ -178,22 +203,60 @@ def att_params(m):
     return cached_pack(m, lambda mm: _att_pack(mm, mm.hidden_nf))
 
 
-def _build_stack_params(model):
-    wd = _wd()
-    W = lambda t: t.to(wd).contiguous()
+_PLAN_CACHE = {}           # id(model) -> (key, ParamPack with its requests, request tree, weakref(model))
+PLUS_PARAM_PACK = os.environ.get("FABIND_PLUS_PARAM_PACK", "1") == "1"     # training: one-launch differentiable pack (0: torch ops per entry)
+
+
+def _stack_requests(model, pk):
     gnn = model.gnn
     H, L = gnn.hidden_nf, gnn.n_layers
     il = model.inter_layer
+    wd = _wd()
     P = {"H": H, "L": L}
-    P["W_ab0"] = W(_cat([il.linear_p.weight, il.linear_c.weight]))
-    P["b_ab0"] = _cat([il.linear_p.bias, il.linear_c.bias]).contiguous()
-    P["W_o0"], P["b_o0"] = W(il.linear_out.weight), il.linear_out.bias
-    P["W_in"], P["b_in"] = W(gnn.linear_in.weight), gnn.linear_in.bias
-    P["W_out"], P["b_out"] = W(gnn.linear_out.weight), gnn.linear_out.bias
-    P["gcl"] = [_gcl_pack(getattr(gnn, "gcl_%d" % i), H) for i in range(L)]
-    P["out_layer"] = _gcl_pack(gnn.out_layer, H)
-    P["att"] = [_att_pack(getattr(gnn, "att_%d" % i), H) for i in range(L)]
+    P["W_ab0"] = pk.cat([il.linear_p.weight, il.linear_c.weight], 0, wd, with_T=True)
+    P["b_ab0"] = pk.cat([il.linear_p.bias, il.linear_c.bias])
+    P["W_o0"], P["b_o0"] = pk.copy(il.linear_out.weight, wd, with_T=True), il.linear_out.bias
+    P["W_in"], P["b_in"] = pk.copy(gnn.linear_in.weight, wd, with_T=True), gnn.linear_in.bias
+    P["W_out"], P["b_out"] = pk.copy(gnn.linear_out.weight, wd, with_T=True), gnn.linear_out.bias
+    P["gcl"] = [_gcl_pack(getattr(gnn, "gcl_%d" % i), H, pk) for i in range(L)]
+    P["out_layer"] = _gcl_pack(gnn.out_layer, H, pk)
+    P["att"] = [_att_pack(getattr(gnn, "att_%d" % i), H, pk) for i in range(L)]
     return P
+
+
+def _build_stack_params(model):
+    """Without autograd (inference / sampling: built once per weight version by cached_pack): torch ops per entry + the inference-only
+    folded / fragment-packed forms.  Under autograd: every entry is a copy-type request (slices, concatenations, zero padding, casts,
+    transposes) of ONE param_pack.ParamPack -- one launch each way instead of ~700 torch launches per model and step -- whose requests
+    are planned once per model and re-run every step (v1: engine._build_stack_params)."""
+    gnn = model.gnn
+    H, L = gnn.hidden_nf, gnn.n_layers
+    if not (torch.is_grad_enabled() and PLUS_PARAM_PACK and os.environ.get("FABIND_PARAM_PACK", "1") != "0"):
+        P = {"H": H, "L": L}
+        wd = _wd()
+        W = lambda t: t.to(wd).contiguous()
+        il = model.inter_layer
+        P["W_ab0"] = W(_cat([il.linear_p.weight, il.linear_c.weight]))
+        P["b_ab0"] = _cat([il.linear_p.bias, il.linear_c.bias]).contiguous()
+        P["W_o0"], P["b_o0"] = W(il.linear_out.weight), il.linear_out.bias
+        P["W_in"], P["b_in"] = W(gnn.linear_in.weight), gnn.linear_in.bias
+        P["W_out"], P["b_out"] = W(gnn.linear_out.weight), gnn.linear_out.bias
+        P["gcl"] = [_gcl_pack(getattr(gnn, "gcl_%d" % i), H) for i in range(L)]
+        P["out_layer"] = _gcl_pack(gnn.out_layer, H)
+        P["att"] = [_att_pack(getattr(gnn, "att_%d" % i), H) for i in range(L)]
+        return P
+    from .. import engine as _e
+    params = _e.last_params_of(model)
+    key = (_wd(), tuple((id(p_), p_.data_ptr(), p_.requires_grad) for p_ in params))
+    ent = _PLAN_CACHE.get(id(model))
+    if ent is not None and ent[0] == key and ent[3]() is model and _e.PACK_PLAN:
+        pk, tree = ent[1], ent[2]
+    else:
+        import weakref
+        pk = ParamPack(model.inter_layer.linear_p.weight.device)
+        tree = _stack_requests(model, pk)
+        _PLAN_CACHE[id(model)] = (key, pk, tree, weakref.ref(model, lambda _r, k=id(model): _PLAN_CACHE.pop(k, None)))
+    return pk.resolve(tree)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -567,8 +630,10 @@ DEBUG_CAPTURE = None
 def mlp_module(m, x, last_act=False, out_dtype=torch.float32, pdrop=0.0):
     """Apply one of the reference's MLP modules (MLP / MLPwithLastAct / MLPwoBias / MLP4Confidence parameter containers)
     to rows x."""
-    wd = _wd()
-    pack = cached_pack(m, lambda mm: _mlp(mm, lambda t: t.to(wd).contiguous()))
+    def build(mm):
+        pk = EagerPack(mm.linear1.weight.device)
+        return pk.resolve(_mlp(mm, pk))
+    pack = cached_pack(m, build)
     return ln_mlp(pack, x.contiguous(), last_act, out_dtype=out_dtype, pdrop=pdrop)
 
 
