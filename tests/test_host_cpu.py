@@ -302,3 +302,84 @@ def test_tn_split_count_keeps_the_xcds_evenly_loaded():
     assert K._tn_splits(1536, 512, 98688, 256) == 16                # 12 tiles: 24 work-groups per XCD, one round
     assert 1 <= K._tn_splits(512, 512, 2624, 256) <= 16             # short operands: a few splits of >= 256 rows
     assert K._tn_splits(512, 512, 1539196, 128) == 128              # round-1 layout: 8 tiles x 128 splits
+
+
+def _emulate_multi_copy(table):
+    """fabind_multi_copy restated on the host for CPU tensors: dst[r * dst_sr + c * dst_sc] = convert(src[r * src_sr + c * src_sc])
+    for every segment of a launch table (include/fabind_hip.h FabindCopySeg); src == NULL writes zeros; dtype codes 0 = fp32, 1 = bf16."""
+    import ctypes
+
+    def arr(ptr, dt, n):
+        ct = ctypes.c_float if dt == 0 else ctypes.c_uint16
+        return np.ctypeslib.as_array((ct * n).from_address(int(ptr)))
+    for s in table:
+        R, C = int(s["rows"]), int(s["cols"])
+        if R == 0 or C == 0:
+            continue
+        r, c = np.meshgrid(np.arange(R), np.arange(C), indexing="ij")
+        di = (r * int(s["dst_sr"]) + c * int(s["dst_sc"])).reshape(-1)
+        if int(s["src"]) == 0:
+            vals = np.zeros(R * C, dtype=np.float32)
+        else:
+            si = (r * int(s["src_sr"]) + c * int(s["src_sc"])).reshape(-1)
+            src = arr(s["src"], int(s["src_dt"]), int(si.max()) + 1)[si]
+            vals = src.astype(np.float32) if int(s["src_dt"]) == 0 else (src.astype(np.uint32) << 16).view(np.float32)
+        dst = arr(s["dst"], int(s["dst_dt"]), int(di.max()) + 1)
+        if int(s["dst_dt"]) == 0:
+            dst[di] = vals
+        else:
+            dst[di] = torch.from_numpy(vals.copy()).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+
+
+def test_param_pack_plans_on_the_host(monkeypatch):
+    """param_pack.ParamPack without a GPU: the launch tables of its planned forward and backward are interpreted on the host
+    (`_emulate_multi_copy`) for CPU tensors -- concatenations with zero blocks, strided views, casts, the W^T copies, zero-padded
+    weights (`pad2d`), 1-D pieces -- and must reproduce the same requests executed with torch ops (EagerPack) and torch autograd's
+    parameter gradients; a second run of the kept plan after an in-place update follows the new values."""
+    from fabind_amd import param_pack as pp
+    monkeypatch.setattr(pp, "_launch", lambda table, dev: _emulate_multi_copy(table))
+    torch.manual_seed(0)
+    A = torch.nn.Parameter(torch.randn(6, 10))
+    B = torch.nn.Parameter(torch.randn(4, 10))
+    v = torch.nn.Parameter(torch.randn(6))
+    K2 = torch.nn.Parameter(torch.randn(8, 7))
+    D = torch.nn.Parameter(torch.randn(4, 10))
+    E = torch.nn.Parameter(torch.randn(6, 10))
+    leaves = (A, B, v, K2, D, E)
+    bf = torch.bfloat16
+
+    def build(pk):          # (every parameter element sits in ONE request: the pack writes gradient slices, it does not accumulate)
+        return dict(cat0=pk.cat([A, pk.zeros(2, 10), B], 0, bf, with_T=True),
+                    cat1=pk.cat([K2[0::2, 1:], K2[1::2, 1:]], 0),
+                    col=pk.copy(K2[0::2, 0]),
+                    vec=pk.cat([v, pk.zeros(2)]),
+                    pad=pk.pad2d(D, 8, 16, bf, with_T=True),
+                    pad_exact=pk.pad2d(E, 6, 10))
+    pk = pp.ParamPack(torch.device("cpu"))
+    tree = build(pk)
+    got = pk.resolve(tree)
+    want = build(pp.EagerPack(torch.device("cpu")))
+    for k in want:
+        assert got[k].dtype == want[k].dtype and got[k].shape == want[k].shape, k
+        assert torch.equal(got[k].detach(), want[k].detach()), k
+    assert torch.equal(got["cat0"]._fab_T, got["cat0"].detach().t().contiguous())
+    assert torch.equal(got["pad"]._fab_T, got["pad"].detach().t().contiguous())
+    g = torch.Generator().manual_seed(1)
+    cots = {k: torch.randn(want[k].shape, generator=g) for k in want}
+    for p_ in leaves:
+        p_.grad = None
+    sum((got[k].float() * cots[k]).sum() for k in got).backward()
+    mine = [p_.grad.clone() for p_ in leaves]
+    for p_ in leaves:
+        p_.grad = None
+    sum((want[k].float() * cots[k]).sum() for k in want).backward()
+    for a_, p_ in zip(mine, leaves):
+        assert torch.allclose(a_, p_.grad, rtol=0, atol=1e-6)
+    # the kept plan, re-run after an in-place update
+    with torch.no_grad():
+        B.mul_(2.0)
+        D.add_(1.0)
+    again = pk.resolve(tree)
+    assert torch.equal(again["pad"].detach()[:4, :10], D.detach().to(bf)) and float(again["pad"].detach()[4:].abs().max()) == 0.0
+    assert float(again["pad"].detach()[:, 10:].abs().max()) == 0.0
+    assert torch.equal(again["cat0"].detach()[8:], B.detach().to(bf))
