@@ -53,6 +53,8 @@ def build_model(hidden, layers, n_iter, seed=0, dropout=0.0):
 
 PREFETCH = {"1": True, "0": False}.get(os.environ.get("FABIND_BENCH_PREFETCH", ""))   # next batch's layout + input graph on a feeder stream
 prefetching = [False]                                                     # (engine.prefetch); None = the per-mode default below
+REUSE_BATCH = os.environ.get("FABIND_BENCH_REUSE_BATCH", "0") == "1"    # round 2's protocol (one resident batch, same index tensor objects every
+                                                                       # step: its layout is built once): same-box comparisons with that tree only
 LEGACY_BATCH = os.environ.get("FABIND_BENCH_LEGACY_BATCH", "0") == "1"    # round-1 workload (4 geometries tiled 16x, plain init): A/B only
 
 
@@ -291,15 +293,15 @@ def main():
         # by the drain); pocket-sized shape 2,071 -> 1,939 (host-bound: the stream switches cost more than the drain).  So the
         # default prefetches in forward-only mode at protein sizes >= 500 and nowhere else; FABIND_BENCH_PREFETCH=1 / 0 forces it.
         want = (mode == "fwd" and a.n_prot >= 500) if PREFETCH is None else PREFETCH
-        feeder = torch.cuda.Stream(dev) if (want and not LEGACY_BATCH) else None
+        feeder = torch.cuda.Stream(dev) if (want and not LEGACY_BATCH and not REUSE_BATCH) else None
         prefetching[0] = feeder is not None
         pending = []
 
         def arrive():
-            t = dict(batches[counter[0] % n_res])
+            t = dict(batches[0 if REUSE_BATCH else counter[0] % n_res])
             counter[0] += 1
             if feeder is None:
-                if not LEGACY_BATCH:
+                if not LEGACY_BATCH and not REUSE_BATCH:
                     t["batch_id"], t["segment_id"] = t["batch_id"].clone(), t["segment_id"].clone()
                 return t, t["X"].clone(), None
             with torch.cuda.stream(feeder):
@@ -440,7 +442,8 @@ def main():
                        "global_batch": a.batch * world, "n_iter": a.n_iter, "pass": a.mode,
                        "batch_arrival": ("fresh index tensors per step; layout + input-coordinate graph of step k+1 built on a "
                                          "feeder stream during step k (engine.prefetch)") if prefetching[0]
-                       else "fresh index tensors per step, layout built at the start of the step"},
+                       else ("ONE resident batch re-served (round 2's protocol, FABIND_BENCH_REUSE_BATCH=1)" if REUSE_BATCH else
+                             "fresh index tensors per step, layout built at the start of the step")},
         }
         if prof and os.environ.get("FABIND_BENCH_DUMP_PROFILE"):
             # development aid: live HIP-event time of every profiled launch group (GEMM shapes, fused kernels) in the timed region
