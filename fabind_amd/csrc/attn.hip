@@ -224,6 +224,19 @@ __global__ __launch_bounds__(256) void inter_attn_fwd_kernel(
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
+    if (e0 == e1) {                        // no inter edges (92 % of the rows of the bench batch): h and x pass through
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int c = s * 256 + lane * 4;
+            if (c < H) {
+                const float4 o = *(const float4*)(h + (size_t)r * ldh + c);
+                *(float4*)(h_out + (size_t)r * ldh + c) = o;
+                if (h16) *(uint2*)(h16 + (size_t)r * H + c) = make_uint2(pack2_bf16(o.x, o.y), pack2_bf16(o.z, o.w));
+            }
+        }
+        if (lane < 3) x_out[(size_t)r * 3 + lane] = x[(size_t)r * 3 + lane];
+        return;
+    }
     float4 qv[NS], acc[NS], wk[NS], wc[NS], w3v[NS];
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     float qw = 0.f;
@@ -241,13 +254,16 @@ __global__ __launch_bounds__(256) void inter_attn_fwd_kernel(
     }
     qw = wave_sum(qw);
     float m = -INFINITY, l = 0.f, sar = 0.f, ax = 0.f, ay = 0.f, az = 0.f;
-    // The edge loop is latency-bound (three gathered 2 KB rows per edge, then two wave reductions and two exponentials that depend
-    // on them): the rows of edge e + 1 are requested before edge e is reduced (software prefetch, one edge deep).
+    // The edge loop is latency-bound: three gathered 2 KB rows per edge, then two wave reductions and two exponentials that depend
+    // on them.  (a) The rows of edge j + 1 are requested before edge j is reduced (software prefetch, one edge deep).  (b) Everything
+    // else an edge needs -- its sending node, rhohat, the summed attention bias (a load through red_idx[]: two dependent global
+    // loads), the three components of d, the FABind+ scalar -- is loaded for up to 64 edges AT ONCE, one edge per lane, ahead of the
+    // loop and handed out with v_readlane; the per-edge results (logit, coordinate scalar) collect in the lane of their edge and leave
+    // as one coalesced store per batch.  Inside the loop those were ~2 us of exposed latency per edge in a serial chain of ~27 edges
+    // (7,380 of the 98,688 rows of the bench batch hold all inter edges, 5,496 of them 96 %: few waves, long chains -- the launch
+    // took 366 us at 98,688 nodes and 156 us at 9,088 with the same 1.3e5-1.6e5 edges).
     float4 nk[NS], nv[NS], nc[NS];
-    float nrh = 0.f;
-    auto fetch = [&](int e) {
-        const int cn = col[e];
-        nrh = rhohat[e];
+    auto fetch = [&](int cn) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int c = s * 256 + lane * 4;
@@ -259,42 +275,54 @@ __global__ __launch_bounds__(256) void inter_attn_fwd_kernel(
             }
         }
     };
-    if (e0 < e1) fetch(e0);
-    for (int e = e0; e < e1; ++e) {
-        const float rh = nrh;
-        float lp = 0.f, cp = 0.f;
-        float4 vv[NS], kk[NS], cc[NS];
+    for (int eb = e0; eb < e1; eb += 64) {
+        const int ne = min(64, e1 - eb);
+        int my_col = 0;
+        float my_rh = 0.f, my_b = 0.f, my_dx = 0.f, my_dy = 0.f, my_dz = 0.f, my_logit = 0.f, my_cp = 0.f;
+        if (lane < ne) {
+            const int e = eb + lane;
+            my_col = col[e];
+            my_rh = rhohat[e];
+            const int ri = red_idx[e];
+            for (int kb = 0; kb < bias_np; ++kb) my_b += bias_red[(size_t)ri * bias_np + kb];
+            my_dx = d[(size_t)e * 3]; my_dy = d[(size_t)e * 3 + 1]; my_dz = d[(size_t)e * 3 + 2];
+            if (s_ext) my_cp = s_ext[e];           // FABind+: the coord_mlp is an LN-MLP evaluated outside (per-edge scalar)
+        }
+        fetch(__shfl(my_col, 0, 64));
+        for (int j = 0; j < ne; ++j) {
+            const float rh = __shfl(my_rh, j, 64);
+            float lp = 0.f, cp = 0.f;
+            float4 vv[NS], kk[NS], cc[NS];
 #pragma unroll
-        for (int s = 0; s < NS; ++s) { kk[s] = nk[s]; vv[s] = nv[s]; cc[s] = nc[s]; }
-        if (e + 1 < e1) fetch(e + 1);
+            for (int s = 0; s < NS; ++s) { kk[s] = nk[s]; vv[s] = nv[s]; cc[s] = nc[s]; }
+            if (j + 1 < ne) fetch(__shfl(my_col, j + 1, 64));
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            int c = s * 256 + lane * 4;
-            if (c < H) {
-                lp += qv[s].x * kk[s].x + qv[s].y * kk[s].y + qv[s].z * kk[s].z + qv[s].w * kk[s].w;
-                cp += w3v[s].x * silu_f(cc[s].x + rh * wc[s].x) + w3v[s].y * silu_f(cc[s].y + rh * wc[s].y) +
-                      w3v[s].z * silu_f(cc[s].z + rh * wc[s].z) + w3v[s].w * silu_f(cc[s].w + rh * wc[s].w);
+            for (int s = 0; s < NS; ++s) {
+                int c = s * 256 + lane * 4;
+                if (c < H) {
+                    lp += qv[s].x * kk[s].x + qv[s].y * kk[s].y + qv[s].z * kk[s].z + qv[s].w * kk[s].w;
+                    cp += w3v[s].x * silu_f(cc[s].x + rh * wc[s].x) + w3v[s].y * silu_f(cc[s].y + rh * wc[s].y) +
+                          w3v[s].z * silu_f(cc[s].z + rh * wc[s].z) + w3v[s].w * silu_f(cc[s].w + rh * wc[s].w);
+                }
             }
-        }
-        lp = wave_sum(lp);
-        cp = wave_sum(cp);
-        if (s_ext) cp += s_ext[e];                 // FABind+: the coord_mlp is an LN-MLP evaluated outside (per-edge scalar)
-        float bsum = 0.f;
-        for (int kb = 0; kb < bias_np; ++kb) bsum += bias_red[(size_t)red_idx[e] * bias_np + kb];
-        const float logit = lp + rh * qw + bsum;
-        const float mn = fmaxf(m, logit);
-        const float corr = __expf(m - mn), pj = __expf(logit - mn);
-        l = l * corr + pj;
-        sar = sar * corr + pj * rh;
-        const float t = pj * cp;
-        ax = ax * corr + t * d[(size_t)e * 3]; ay = ay * corr + t * d[(size_t)e * 3 + 1]; az = az * corr + t * d[(size_t)e * 3 + 2];
+            lp = wave_sum(lp);
+            cp = wave_sum(cp) + __shfl(my_cp, j, 64);
+            const float logit = lp + rh * qw + __shfl(my_b, j, 64);
+            const float mn = fmaxf(m, logit);
+            const float corr = __expf(m - mn), pj = __expf(logit - mn);
+            l = l * corr + pj;
+            sar = sar * corr + pj * rh;
+            const float t = pj * cp;
+            ax = ax * corr + t * __shfl(my_dx, j, 64); ay = ay * corr + t * __shfl(my_dy, j, 64); az = az * corr + t * __shfl(my_dz, j, 64);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            acc[s].x = acc[s].x * corr + pj * vv[s].x; acc[s].y = acc[s].y * corr + pj * vv[s].y;
-            acc[s].z = acc[s].z * corr + pj * vv[s].z; acc[s].w = acc[s].w * corr + pj * vv[s].w;
+            for (int s = 0; s < NS; ++s) {
+                acc[s].x = acc[s].x * corr + pj * vv[s].x; acc[s].y = acc[s].y * corr + pj * vv[s].y;
+                acc[s].z = acc[s].z * corr + pj * vv[s].z; acc[s].w = acc[s].w * corr + pj * vv[s].w;
+            }
+            m = mn;
+            if (lane == j) { my_logit = logit; my_cp = cp; }
         }
-        m = mn;
-        if (lane == 0) { alpha[e] = logit; cvs[e] = cp; }
+        if (lane < ne) { alpha[eb + lane] = my_logit; cvs[eb + lane] = my_cp; }
     }
     const float inv = (e1 > e0) ? 1.f / l : 0.f;
 #pragma unroll
