@@ -981,11 +981,13 @@ __global__ __launch_bounds__(256) void inter_attn_bwd_a_kernel(
         const float gy = fabsf(ty) <= clampv ? dx_out[(size_t)r * 3 + 1] : 0.f;
         const float gz = fabsf(tz) <= clampv ? dx_out[(size_t)r * 3 + 2] : 0.f;
         // pass 1: dalpha_e, stored in dlogit[]; S = sum alpha dalpha
+        // Both edge loops are latency-bound on the gathered rows: the rows of edge j + 1 are requested before edge j is reduced; every
+        // per-edge scalar (sending node, rhohat, alpha, the coordinate scalar, d) is loaded for up to 64 edges at once, one edge per
+        // lane, and handed out with v_readlane; per-edge results collect in the lane of their edge and leave as coalesced stores
+        // (see inter_attn_fwd_kernel: inside the loop those loads were ~2 us of exposed latency per edge of a ~27-edge chain).
         float S = 0.f;
-        // both edge loops are latency-bound on the gathered rows: the rows of edge e + 1 are requested before edge e is reduced
         float4 pa[NS], pb[NS];
-        auto fetch_v = [&](int e) {
-            const int cn = col[e];
+        auto fetch_v = [&](int cn) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int c = s * 256 + lane * 4;
@@ -993,29 +995,38 @@ __global__ __launch_bounds__(256) void inter_attn_bwd_a_kernel(
                 if (c < H) pa[s] = *(const float4*)(qkv + (size_t)cn * ldqkv + 2 * H + c);
             }
         };
-        fetch_v(e0);
-        for (int e = e0; e < e1; ++e) {
-            const float rh = rhohat[e];
-            float hp = 0.f;
-            float4 vv[NS];
+        for (int eb = e0; eb < e1; eb += 64) {
+            const int ne = min(64, e1 - eb);
+            int my_col = 0;
+            float my_rh = 0.f, my_al = 0.f, my_cvs = 0.f, my_gd = 0.f, my_da = 0.f;
+            if (lane < ne) {
+                const int e = eb + lane;
+                my_col = col[e]; my_rh = rhohat[e]; my_al = alpha[e]; my_cvs = cvs[e];
+                my_gd = gx * d[(size_t)e * 3] + gy * d[(size_t)e * 3 + 1] + gz * d[(size_t)e * 3 + 2];
+            }
+            fetch_v(__shfl(my_col, 0, 64));
+            for (int j = 0; j < ne; ++j) {
+                const float rh = __shfl(my_rh, j, 64);
+                float hp = 0.f;
+                float4 vv[NS];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) vv[s] = pa[s];
-            if (e + 1 < e1) fetch_v(e + 1);
+                for (int s = 0; s < NS; ++s) vv[s] = pa[s];
+                if (j + 1 < ne) fetch_v(__shfl(my_col, j + 1, 64));
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-                hp += gh[s].x * vv[s].x + gh[s].y * vv[s].y + gh[s].z * vv[s].z + gh[s].w * vv[s].w;
-            hp = wave_sum(hp) + rh * gwv;
-            const float gd = gx * d[(size_t)e * 3] + gy * d[(size_t)e * 3 + 1] + gz * d[(size_t)e * 3 + 2];
-            const float da = hp + cvs[e] * gd;
-            S += alpha[e] * da;
-            if (lane == 0) dlogit[e] = da;
+                for (int s = 0; s < NS; ++s)
+                    hp += gh[s].x * vv[s].x + gh[s].y * vv[s].y + gh[s].z * vv[s].z + gh[s].w * vv[s].w;
+                hp = wave_sum(hp) + rh * gwv;
+                const float da = hp + __shfl(my_cvs, j, 64) * __shfl(my_gd, j, 64);
+                S += __shfl(my_al, j, 64) * da;
+                if (lane == j) my_da = da;
+            }
+            if (lane < ne) dlogit[eb + lane] = my_da;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // pass 2
         float s_lrh = 0.f, s_arh = 0.f;
-        auto fetch_kc = [&](int e) {
-            const int cn = col[e];
+        auto fetch_kc = [&](int cn) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int c = s * 256 + lane * 4;
@@ -1026,38 +1037,49 @@ __global__ __launch_bounds__(256) void inter_attn_bwd_a_kernel(
                 }
             }
         };
-        fetch_kc(e0);
-        for (int e = e0; e < e1; ++e) {
-            const float rh = rhohat[e], al = alpha[e];
-            float4 kks[NS], ccs[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) { kks[s] = pa[s]; ccs[s] = pb[s]; }
-            if (e + 1 < e1) fetch_kc(e + 1);
-            const float dl = al * (dlogit[e] - S);
-            const float gd = gx * d[(size_t)e * 3] + gy * d[(size_t)e * 3 + 1] + gz * d[(size_t)e * 3 + 2];
-            const float dc = al * gd;
-            float dsum = 0.f;
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int c = s * 256 + lane * 4;
-                if (c < H) {
-                    const float4 kk = kks[s], cc = ccs[s];
-                    dq[s].x += dl * (kk.x + rh * wk[s].x); dq[s].y += dl * (kk.y + rh * wk[s].y);
-                    dq[s].z += dl * (kk.z + rh * wk[s].z); dq[s].w += dl * (kk.w + rh * wk[s].w);
-                    const float ux = cc.x + rh * wc[s].x, uy = cc.y + rh * wc[s].y, uz = cc.z + rh * wc[s].z, uw = cc.w + rh * wc[s].w;
-                    const float px = w3v[s].x * dsilu_f(ux), py = w3v[s].y * dsilu_f(uy), pz = w3v[s].z * dsilu_f(uz), pw = w3v[s].w * dsilu_f(uw);
-                    dsum += px * wc[s].x + py * wc[s].y + pz * wc[s].z + pw * wc[s].w;
-                    a_wcr[s].x += dc * rh * px; a_wcr[s].y += dc * rh * py; a_wcr[s].z += dc * rh * pz; a_wcr[s].w += dc * rh * pw;
-                    a_w3[s].x += dc * silu_f(ux); a_w3[s].y += dc * silu_f(uy); a_w3[s].z += dc * silu_f(uz); a_w3[s].w += dc * silu_f(uw);
-                }
+        for (int eb = e0; eb < e1; eb += 64) {
+            const int ne = min(64, e1 - eb);
+            int my_col = 0;
+            float my_rh = 0.f, my_al = 0.f, my_cvs = 0.f, my_gd = 0.f, my_da = 0.f, o_dl = 0.f, o_dc = 0.f, o_drh = 0.f;
+            if (lane < ne) {
+                const int e = eb + lane;
+                my_col = col[e]; my_rh = rhohat[e]; my_al = alpha[e]; my_cvs = cvs[e]; my_da = dlogit[e];
+                my_gd = gx * d[(size_t)e * 3] + gy * d[(size_t)e * 3 + 1] + gz * d[(size_t)e * 3 + 2];
             }
-            dsum = wave_sum(dsum);
-            s_lrh += dl * rh; s_arh += al * rh;
-            if (lane == 0) {
-                dlogit[e] = dl;
-                dcp[e] = dc;
-                drh[e] = dl * qw + al * gwv + dc * dsum;
-                const float w = al * cvs[e];
+            fetch_kc(__shfl(my_col, 0, 64));
+            for (int j = 0; j < ne; ++j) {
+                const float rh = __shfl(my_rh, j, 64), al = __shfl(my_al, j, 64);
+                float4 kks[NS], ccs[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s) { kks[s] = pa[s]; ccs[s] = pb[s]; }
+                if (j + 1 < ne) fetch_kc(__shfl(my_col, j + 1, 64));
+                const float dl = al * (__shfl(my_da, j, 64) - S);
+                const float dc = al * __shfl(my_gd, j, 64);
+                float dsum = 0.f;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const int c = s * 256 + lane * 4;
+                    if (c < H) {
+                        const float4 kk = kks[s], cc = ccs[s];
+                        dq[s].x += dl * (kk.x + rh * wk[s].x); dq[s].y += dl * (kk.y + rh * wk[s].y);
+                        dq[s].z += dl * (kk.z + rh * wk[s].z); dq[s].w += dl * (kk.w + rh * wk[s].w);
+                        const float ux = cc.x + rh * wc[s].x, uy = cc.y + rh * wc[s].y, uz = cc.z + rh * wc[s].z, uw = cc.w + rh * wc[s].w;
+                        const float px = w3v[s].x * dsilu_f(ux), py = w3v[s].y * dsilu_f(uy), pz = w3v[s].z * dsilu_f(uz), pw = w3v[s].w * dsilu_f(uw);
+                        dsum += px * wc[s].x + py * wc[s].y + pz * wc[s].z + pw * wc[s].w;
+                        a_wcr[s].x += dc * rh * px; a_wcr[s].y += dc * rh * py; a_wcr[s].z += dc * rh * pz; a_wcr[s].w += dc * rh * pw;
+                        a_w3[s].x += dc * silu_f(ux); a_w3[s].y += dc * silu_f(uy); a_w3[s].z += dc * silu_f(uz); a_w3[s].w += dc * silu_f(uw);
+                    }
+                }
+                dsum = wave_sum(dsum);
+                s_lrh += dl * rh; s_arh += al * rh;
+                if (lane == j) { o_dl = dl; o_dc = dc; o_drh = dl * qw + al * gwv + dc * dsum; }
+            }
+            if (lane < ne) {
+                const int e = eb + lane;
+                dlogit[e] = o_dl;
+                dcp[e] = o_dc;
+                drh[e] = o_drh;
+                const float w = my_al * my_cvs;
                 dd[(size_t)e * 3] = w * gx; dd[(size_t)e * 3 + 1] = w * gy; dd[(size_t)e * 3 + 2] = w * gz;
             }
         }
@@ -1115,25 +1137,35 @@ __global__ __launch_bounds__(256) void inter_attn_bwd_b_kernel(
             wc[s] = *(const float4*)(wcr + c); w3v[s] = *(const float4*)(w3 + c);
         }
     }
+    for (int eb = e0; eb < e1; eb += 64) {             // per-edge scalars (through mirror[]: dependent loads) one edge per lane, ahead of the loop
+        const int ne = min(64, e1 - eb);
+        int m_l = 0;
+        float dl_l = 0.f, al_l = 0.f, dcm_l = 0.f, rh_l = 0.f;
+        if (lane < ne) {
+            const int e = eb + lane, me = mirror[e];   // edge me = (m <- n)
+            m_l = col[e];
+            dl_l = dlogit[me]; al_l = alpha[me]; dcm_l = dcp[me]; rh_l = rhohat[me];
+            if (n < m_l) dbias_red[red_idx[e]] = dlogit[e] + dl_l;   // ligand rows precede their proteins
+        }
 #pragma unroll 2
-    for (int e = e0; e < e1; ++e) {                    // independent gathers: two edges in flight
-        const int m = col[e], me = mirror[e];          // edge me = (m <- n)
-        const float dl = dlogit[me], al = alpha[me], dcm = dcp[me], rh = rhohat[me];
+        for (int j = 0; j < ne; ++j) {                 // independent gathers: two edges in flight
+            const int m = __shfl(m_l, j, 64);
+            const float dl = __shfl(dl_l, j, 64), al = __shfl(al_l, j, 64), dcm = __shfl(dcm_l, j, 64), rh = __shfl(rh_l, j, 64);
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int c = s * 256 + lane * 4;
-            if (c < H) {
-                const float4 qm = *(const float4*)(qkv + (size_t)m * ldqkv + c);
-                const float4 gm = *(const float4*)(dh_out + (size_t)m * H + c);
-                dk[s].x += dl * qm.x; dk[s].y += dl * qm.y; dk[s].z += dl * qm.z; dk[s].w += dl * qm.w;
-                dv[s].x += al * gm.x; dv[s].y += al * gm.y; dv[s].z += al * gm.z; dv[s].w += al * gm.w;
-                dc[s].x += dcm * w3v[s].x * dsilu_f(cvn[s].x + rh * wc[s].x);
-                dc[s].y += dcm * w3v[s].y * dsilu_f(cvn[s].y + rh * wc[s].y);
-                dc[s].z += dcm * w3v[s].z * dsilu_f(cvn[s].z + rh * wc[s].z);
-                dc[s].w += dcm * w3v[s].w * dsilu_f(cvn[s].w + rh * wc[s].w);
+            for (int s = 0; s < NS; ++s) {
+                const int c = s * 256 + lane * 4;
+                if (c < H) {
+                    const float4 qm = *(const float4*)(qkv + (size_t)m * ldqkv + c);
+                    const float4 gm = *(const float4*)(dh_out + (size_t)m * H + c);
+                    dk[s].x += dl * qm.x; dk[s].y += dl * qm.y; dk[s].z += dl * qm.z; dk[s].w += dl * qm.w;
+                    dv[s].x += al * gm.x; dv[s].y += al * gm.y; dv[s].z += al * gm.z; dv[s].w += al * gm.w;
+                    dc[s].x += dcm * w3v[s].x * dsilu_f(cvn[s].x + rh * wc[s].x);
+                    dc[s].y += dcm * w3v[s].y * dsilu_f(cvn[s].y + rh * wc[s].y);
+                    dc[s].z += dcm * w3v[s].z * dsilu_f(cvn[s].z + rh * wc[s].z);
+                    dc[s].w += dcm * w3v[s].w * dsilu_f(cvn[s].w + rh * wc[s].w);
+                }
             }
         }
-        if (lane == 0 && n < m) dbias_red[red_idx[e]] = dlogit[e] + dl;   // ligand rows precede their proteins
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
