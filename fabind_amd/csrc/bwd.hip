@@ -798,35 +798,52 @@ __global__ __launch_bounds__(256) void pair_hadamard_bwd_rows_kernel(const void*
     const int e0 = rowptr[n], e1 = rowptr[n + 1];
     if (e0 == e1) return;
     const bool lig = red_c[red_idx[e0]] == n;                 // which side of its pairs this node is
-    {
-        const int src = lig ? 0 : H, dst = lig ? H : 0;       // partner's factor / this node's gradient slot inside (a | b)
-        for (int c = lane * 4; c < H; c += 256) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int e = e0; e < e1; ++e) {
-                const float4 g = ld4_any(dhd, dt, (size_t)red_idx[e] * ldh + c);
-                const float4 v = *(const float4*)(t0 + (size_t)col[e] * ld0 + src + c);
-                acc.x += g.x * v.x; acc.y += g.y * v.y; acc.z += g.z * v.z; acc.w += g.w * v.w;
+    // Edge loop outside, column chunks inside; the two index loads of an edge (its pair's row of dhd, its partner node) are made for
+    // up to 64 edges at once, one edge per lane, and handed out with v_readlane -- inside the loop each was the head of a dependent
+    // load chain per edge and column chunk (see inter_attn_fwd_kernel).  H <= 1024, H2 <= 256 (checked by the entry point).
+    const int src0 = lig ? 0 : H, dst0 = lig ? H : 0;         // partner's factor / this node's gradient slot inside (a | b)
+    const int src1 = lig ? 0 : H2, dst1 = lig ? H2 : 0;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc0[4] = {z4, z4, z4, z4}, acc1 = z4;
+    for (int eb = e0; eb < e1; eb += 64) {
+        const int ne = min(64, e1 - eb);
+        int ri_l = 0, cn_l = 0;
+        if (lane < ne) { ri_l = red_idx[eb + lane]; cn_l = col[eb + lane]; }
+#pragma unroll 2
+        for (int j = 0; j < ne; ++j) {
+            const size_t ri = (size_t)__shfl(ri_l, j, 64), cn = (size_t)__shfl(cn_l, j, 64);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = lane * 4 + 256 * k;
+                if (c < H) {
+                    const float4 g = ld4_any(dhd, dt, ri * ldh + c);
+                    const float4 v = *(const float4*)(t0 + cn * ld0 + src0 + c);
+                    acc0[k].x += g.x * v.x; acc0[k].y += g.y * v.y; acc0[k].z += g.z * v.z; acc0[k].w += g.w * v.w;
+                }
             }
-            float4* o = (float4*)(d0 + (size_t)n * ldd0 + dst + c);
+            if (lane * 4 < H2) {
+                const int c = lane * 4;
+                const float4 g = ld4_any(dhd, dt, ri * ldh + H + c);
+                const float4 v = *(const float4*)(t1 + cn * ld1 + src1 + c);
+                acc1.x += g.x * v.x; acc1.y += g.y * v.y; acc1.z += g.z * v.z; acc1.w += g.w * v.w;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane * 4 + 256 * k;
+        if (c < H) {
+            float4* o = (float4*)(d0 + (size_t)n * ldd0 + dst0 + c);
             float4 q = *o;
-            q.x += acc.x; q.y += acc.y; q.z += acc.z; q.w += acc.w;
+            q.x += acc0[k].x; q.y += acc0[k].y; q.z += acc0[k].z; q.w += acc0[k].w;
             *o = q;
         }
     }
-    if (H2 > 0) {
-        const int src = lig ? 0 : H2, dst = lig ? H2 : 0;
-        for (int c = lane * 4; c < H2; c += 256) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int e = e0; e < e1; ++e) {
-                const float4 g = ld4_any(dhd, dt, (size_t)red_idx[e] * ldh + H + c);
-                const float4 v = *(const float4*)(t1 + (size_t)col[e] * ld1 + src + c);
-                acc.x += g.x * v.x; acc.y += g.y * v.y; acc.z += g.z * v.z; acc.w += g.w * v.w;
-            }
-            float4* o = (float4*)(d1 + (size_t)n * ldd1 + dst + c);
-            float4 q = *o;
-            q.x += acc.x; q.y += acc.y; q.z += acc.z; q.w += acc.w;
-            *o = q;
-        }
+    if (lane * 4 < H2) {
+        float4* o = (float4*)(d1 + (size_t)n * ldd1 + dst1 + lane * 4);
+        float4 q = *o;
+        q.x += acc1.x; q.y += acc1.y; q.z += acc1.z; q.w += acc1.w;
+        *o = q;
     }
 }
 extern "C" int fabind_pair_hadamard_bwd_rows(const void* dhd, int dt, int ldh, const float* t0, int ld0, int H, const float* t1,
@@ -838,6 +855,7 @@ extern "C" int fabind_pair_hadamard_bwd_rows(const void* dhd, int dt, int ldh, c
                "fabind_pair_hadamard_bwd_rows: widths and leading dimensions must be multiples of 4");
     FB_REQUIRE((((uintptr_t)t0 | (uintptr_t)d0 | (uintptr_t)dhd) & 15) == 0 && (H2 == 0 || (((uintptr_t)t1 | (uintptr_t)d1) & 15) == 0),
                "fabind_pair_hadamard_bwd_rows: 16-byte aligned buffers");
+    FB_REQUIRE(H <= 1024 && H2 <= 256, "fabind_pair_hadamard_bwd_rows: H <= 1024, H2 <= 256");
     hipLaunchKernelGGL(pair_hadamard_bwd_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, dhd, dt, ldh, t0, ld0, H, t1, ld1, H2,
                        rowptr, col, red_idx, red_c, n_rows, d0, ldd0, d1, ldd1);
     FB_CHECK_LAUNCH();

@@ -1114,6 +1114,7 @@ class _PairHadamard(torch.autograd.Function):
         d1 = torch.zeros_like(T1)
         g = ctx.graph
         if (PAIRHAD_ROWS and g is not None and T0.dtype == torch.float32 and T1.dtype == torch.float32 and H % 4 == 0 and H2 % 4 == 0
+                and H <= 1024 and H2 <= 256
                 and dhd.stride(0) % 4 == 0):
             # the pairs are the inter graph's own rows: one wave per node, one writer per element, fixed order (no float atomics)
             check(load().fabind_pair_hadamard_bwd_rows(
