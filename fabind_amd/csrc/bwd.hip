@@ -903,6 +903,7 @@ __global__ __launch_bounds__(256) void pair_hadamard_bwd_grid_kernel(const void*
     if (LPR >= 64) {
         for (int c = lane * 4; c < W; c += 256) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
             for (int k = 0; k < cnt; ++k) {
                 const float4 g = ld4_any(dhd, dt, (size_t)(first + (long)k * pstep) * ldh + c);
                 const float4 v = *(const float4*)(T + (size_t)(partner0 + k) * ldt + src + c);
@@ -913,7 +914,8 @@ __global__ __launch_bounds__(256) void pair_hadamard_bwd_grid_kernel(const void*
     } else {                                                  // narrow rows: 64 / LPR rows of the node per wave iteration, combined at the end
         const int G = 64 / LPR, grp = lane / LPR, c = (lane % LPR) * 4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = grp; k < cnt; k += G) {
+#pragma unroll 8
+        for (int k = grp; k < cnt; k += G) {             // (a ligand node of the pocket model walks 1,500 pairs: eight row pairs in flight)
             const float4 g = ld4_any(dhd, dt, (size_t)(first + (long)k * pstep) * ldh + c);
             const float4 v = *(const float4*)(T + (size_t)(partner0 + k) * ldt + src + c);
             acc.x += g.x * v.x; acc.y += g.y * v.y; acc.z += g.z * v.z; acc.w += g.w * v.w;

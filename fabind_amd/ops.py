@@ -1203,11 +1203,16 @@ class _InterAttn(torch.autograd.Function):
         dx_out = dx_out.contiguous() if dx_out is not None else torch.zeros((N, 3), **f32)
         dqkv = torch.empty_like(qkv)          # every row is written: d q by pass a (zeros for nodes without inter edges), d k | d v by pass b
         dcv = torch.empty_like(cv)
-        dd, drh = torch.zeros((max(E, 1), 3), **f32), torch.zeros(max(E, 1), **f32)
+        # (pass a writes d d, d rhohat, d logit and d cp of EVERY edge -- each edge lies in one row's range: no pre-zeroing)
+        dd, drh = torch.empty((max(E, 1), 3), **f32), torch.empty(max(E, 1), **f32)
         n_red = E // 2
         dbias_red = torch.zeros(max(n_red, 1), **f32)
-        dlogit, dcp = torch.zeros(max(E, 1), **f32), torch.zeros(max(E, 1), **f32)
-        nblk = min((N + 3) // 4, 1024)
+        dlogit, dcp = torch.empty(max(E, 1), **f32), torch.empty(max(E, 1), **f32)
+        if E == 0:
+            dd.zero_(); drh.zero_()
+        # (pass a strides its waves over the rows; 7 % of the rows hold all the edges, but the draw is not what bounds it: 1,024 / 2,048 /
+        #  4,096 work-groups measured 1,034 / 1,035 / 1,088 us forward + backward at the bench shape, tools/probes/inter_attn_time.py)
+        nblk = min((N + 3) // 4, INTER_BWD_BLOCKS)
         wpart = torch.empty((nblk, 4 * H), **f32)                     # [block][4][H] partials of the four vector gradients
         check(load().fabind_inter_attn_bwd(ptr(qkv), qkv.stride(0), ptr(cv), cv.stride(0), H, ptr(d), ptr(rhohat),
                                            ptr(g.rp_int), ptr(g.col_int), ptr(g.mirror), ptr(g.red_idx), ptr(w_rk),
@@ -1236,6 +1241,9 @@ class _InterAttn(torch.autograd.Function):
             dh_out = ctx.sink_h.deposit(dh_out)           # h_out = h + ...: the residual gradient joins h's shared buffer
         return (dqkv, dcv, dh_out, dx_out, dd[:E], drh[:E], dbias_red[:n_red, None].expand(n_red, ctx.np), dw[0], dw[1],
                 dw[2], dw[3], None, None, None, dcp[:E] if ctx.has_ext else None, dWc, dbc, None)
+
+
+INTER_BWD_BLOCKS = int(os.environ.get("FABIND_INTER_BWD_BLOCKS", "1024"))
 
 
 def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None, Wc=None, bc=None):
