@@ -1069,3 +1069,22 @@ def test_edge_concat_rows(H, dt):
     ref[:, :H], ref[:, H:2 * H], ref[:, 2 * H] = h[row.long()], h[col.long()], rh
     assert y.dtype == dt and y.shape == (E, pad)
     assert torch.equal(y.float().cpu(), ref.to(dt).float())
+
+
+@pytest.mark.parametrize("H,H2", [(64, 0), (128, 0), (128, 64), (512, 64), (20, 0)])
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_pair_hadamard_products_all_lane_groupings(H, H2, dt):
+    """fabind_pair_hadamard (InteractionModule's a_i * b_j, model_utils.py:200-223 / FABind+ model_utils.py:96-146): 16, 32 and 64 lanes
+    per pair (4, 2, 1 pairs per wave), with and without the second product block, odd pair counts -- against torch indexing."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(H + H2)
+    N, P = 333, 4099
+    T0 = torch.randn(N, 2 * H, generator=g)
+    T1 = torch.randn(N, 2 * max(H2, 4), generator=g)
+    rp = torch.randint(0, N, (P,), generator=g).to(torch.int32)
+    rc = torch.randint(0, N, (P,), generator=g).to(torch.int32)
+    t0, t1 = T0.to(dev), T1.to(dev)
+    hd = K.pair_hadamard(t0[:, :H], t0[:, H:], t1[:, :H2], t1[:, max(H2, 4):max(H2, 4) + H2], rp.to(dev), rc.to(dev), dt)
+    ref = torch.cat([T0[rp.long(), :H] * T0[rc.long(), H:], T1[rp.long(), :H2] * T1[rc.long(), max(H2, 4):max(H2, 4) + H2]], 1)
+    assert hd.shape == ref.shape and torch.equal(hd.float().cpu(), ref.to(dt).float())

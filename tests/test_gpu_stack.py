@@ -536,3 +536,43 @@ def test_prefetched_layout_and_graph_are_picked_up_and_change_nothing():
     finally:
         engine.Graph.__init__ = orig
         del engine._PREFETCHED[:]
+
+
+def test_edge_case_rows_with_more_than_64_inter_edges():
+    """A compact protein around the ligand: every ligand atom has > 64 inter edges (the row walks of the inter-edge attention load
+    their per-edge scalars in batches of 64 edges, one per lane: this exercises a second and third batch) -- forward vs the oracle,
+    and input gradients vs oracle autograd."""
+    from fabind_amd import engine, synthetic
+    engine.set_precision("fp32")
+    inp = synthetic.make_stack_batch([(170, 9), (140, 12)], 32, seed=12, snap=False)
+    pr = (inp["segment_id"] > 0.5) & ~inp["is_global"]
+    lig = (inp["segment_id"] < 0.5) & ~inp["is_global"]
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for b in range(2):
+            sel_l = lig & (inp["batch_id"] == b)
+            sel_p = pr & (inp["batch_id"] == b)
+            centre = inp["X"][sel_l].mean(0, keepdim=True)
+            # residues in a 6.5 A ball around the ligand centre (coordinates are in units of 5 A): all within the 10 A inter cut-off
+            # of every ligand atom after the ligand itself is shrunk to a 1.5 A ball
+            inp["X"][sel_l] = centre + 0.3 * (torch.rand(int(sel_l.sum()), 1, 3, generator=g) - 0.5)
+            inp["X"][sel_p] = centre + 1.3 * (torch.rand(int(sel_p.sum()), 1, 3, generator=g) - 0.5) * 2 * 0.75
+    m = _vs_oracle(_random_stack(32, 2, 2, 24), inp, 2, 2, tol=2e-4)
+    gr = m.last_graph
+    deg = (gr.rp_int[1:] - gr.rp_int[:-1])
+    assert int(deg.max()) > 128, int(deg.max())
+    # gradients with respect to the node features through both layers
+    dev = torch.device("cuda:0")
+    sd = {k: v.detach().clone().cpu() for k, v in m.state_dict().items()}
+    Hr = inp["H"].clone().requires_grad_(True)
+    Xr, Ho = orc.stack_forward(sd, "", inp["X"].clone(), Hr, inp["batch_id"], inp["segment_id"], inp["mask"], inp["is_global"],
+                               inp["compound_edge_index"], inp["LAS_edge_index"], inp["coord_LAS"], 2, 1)
+    ((Xr * Xr).sum() + (Ho * Ho).sum() * 1e-3).backward()
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    Hd = t["H"].clone().requires_grad_(True)
+    m.n_iter = 1
+    X, Hh = m(t["X"].clone(), Hd, t["batch_id"], t["segment_id"], t["mask"], t["is_global"], t["compound_edge_index"],
+              t["LAS_edge_index"], t["coord_LAS"])
+    ((X * X).sum() + (Hh * Hh).sum() * 1e-3).backward()
+    err = float((Hd.grad.cpu() - Hr.grad).abs().max() / Hr.grad.abs().max())
+    assert err <= 3e-3, err
