@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FABIND_LIB") or os.path.join(_HERE, "libfabind_hip.so")      # FABIND_LIB: an A/B build (tools/probes)
 
-ABI_VERSION = 13         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
+ABI_VERSION = 14         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -101,6 +101,7 @@ SIGNATURES = {
                               _vp, _vp, _vp],
     "fabind_pair_bias_cat": [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "fabind_batched_transpose_pad": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp],
+    "fabind_rows_hadamard_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "fabind_pair_hadamard_bwd_grid": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "fabind_pair_hadamard_bwd_rows": [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],
     "fabind_pair_hadamard_bwd": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _i,

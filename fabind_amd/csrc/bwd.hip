@@ -862,6 +862,54 @@ extern "C" int fabind_pair_hadamard_bwd_rows(const void* dhd, int dt, int ldh, c
     return 0;
 }
 
+// Adjoint of out[e, :] = t[ia[e], :] * t[ib[e], :] as a row walk (see the header): the float-atomics kernel below took 2.2 ms per call
+// in the full model's distance-map head (every ligand atom's ~150 pairs add 512-float rows into the same row of d t).
+__global__ __launch_bounds__(256) void rows_hadamard_bwd_kernel(const void* __restrict__ dout, int dt, int ldo, const float* __restrict__ t,
+                                                               int ldt, int W, const int* __restrict__ rowptr,
+                                                               const int* __restrict__ pair_idx, const int* __restrict__ partner,
+                                                               int n_rows, float* dT, int lddt) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= n_rows) return;
+    const int e0 = rowptr[n], e1 = rowptr[n + 1];
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc[4] = {z4, z4, z4, z4};
+    for (int eb = e0; eb < e1; eb += 64) {               // the two indices of up to 64 pairs, one pair per lane, ahead of the walk
+        const int ne = min(64, e1 - eb);
+        int pi_l = 0, pn_l = 0;
+        if (lane < ne) { pi_l = pair_idx[eb + lane]; pn_l = partner[eb + lane]; }
+#pragma unroll 2
+        for (int j = 0; j < ne; ++j) {
+            const size_t pi = (size_t)__shfl(pi_l, j, 64), pn = (size_t)__shfl(pn_l, j, 64);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = lane * 4 + 256 * k;
+                if (c < W) {
+                    const float4 g = ld4_any(dout, dt, pi * ldo + c);
+                    const float4 v = *(const float4*)(t + pn * ldt + c);
+                    acc[k].x += g.x * v.x; acc[k].y += g.y * v.y; acc[k].z += g.z * v.z; acc[k].w += g.w * v.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = lane * 4 + 256 * k;
+        if (c < W) *(float4*)(dT + (size_t)n * lddt + c) = acc[k];
+    }
+}
+extern "C" int fabind_rows_hadamard_bwd(const void* dout, int dt, int ldo, const float* t, int ldt, int W, const int* rowptr,
+                                        const int* pair_idx, const int* partner, int n_rows, float* dT, int lddt, hipStream_t stream) {
+    if (n_rows <= 0) return 0;
+    FB_REQUIRE(W % 4 == 0 && W >= 4 && W <= 1024 && ldo % 4 == 0 && ldt % 4 == 0 && lddt % 4 == 0,
+               "fabind_rows_hadamard_bwd: W a multiple of 4, <= 1024; strides % 4");
+    FB_REQUIRE((((uintptr_t)t | (uintptr_t)dT | (uintptr_t)dout) & 15) == 0, "fabind_rows_hadamard_bwd: 16-byte aligned buffers");
+    hipLaunchKernelGGL(rows_hadamard_bwd_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, dout, dt, ldo, t, ldt, W, rowptr, pair_idx,
+                       partner, n_rows, dT, lddt);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const float* a0, const float* b0, int ld0,
                                         int H, const float* a1, const float* b1, int ld1, int H2, const int* red_p,
                                         const int* red_c, int n, float* da0, float* db0, int ldd0, float* da1,

@@ -235,7 +235,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         ln = ops.layernorm(torch.cat([Ho[pflag], Ho[cflag]], 0).contiguous(), self.layernorm.weight, self.layernorm.bias,
                            self.layernorm.eps)
         npk = int(pflag.sum().item())
-        hd = ops.rows_hadamard(ln, pi, npk + ci)                                       # LN(p_i) * LN(c_j)
+        hd = ops.rows_hadamard(ln, pi, npk + ci, a_sorted=True)                                       # LN(p_i) * LN(c_j)
         wd = ops.mm_dtype()
         part = ops.linear_rowdot(hd, self.distmap_mlp[0].weight.to(wd), self.distmap_mlp[0].bias,
                                  self.distmap_mlp[2].weight[0].contiguous(), act_epi=K.ACT_RELU)

@@ -1143,8 +1143,9 @@ class _RowsHadamard(torch.autograd.Function):
     """out[e,:] = t[ia[e],:] * t[ib[e],:]"""
 
     @staticmethod
-    def forward(ctx, t, ia, ib):
+    def forward(ctx, t, ia, ib, a_sorted=False):
         ctx.save_for_backward(t, ia, ib)
+        ctx.a_sorted = a_sorted
         dummy = t[:, :0]
         return K.pair_hadamard(t, t, dummy, dummy, ia, ib, act_dtype())
 
@@ -1152,19 +1153,59 @@ class _RowsHadamard(torch.autograd.Function):
     def backward(ctx, dout):
         t, ia, ib = ctx.saved_tensors
         dout = dout.contiguous()
-        dt_ = torch.zeros_like(t)
         W = t.shape[1]
+        if ROWS_HADAMARD_WALK and t.dtype == torch.float32 and W % 4 == 0 and W <= 1024 and t.stride(0) % 4 == 0 and dout.stride(0) % 4 == 0:
+            # every row of t gets its pairs as a CSR: as first factor (the pairs sorted by ia) and as second factor (sorted by ib);
+            # one wave per row sums them -- no float atomics, fixed order (index glue: two stable sorts and two histograms per call)
+            n = t.shape[0]
+            rowptr, pair_idx, partner = _rows_hadamard_csr(ia, ib, n, ctx.a_sorted)
+            dt_ = torch.empty_like(t)
+            check(load().fabind_rows_hadamard_bwd(ptr(dout), dt_code(dout.dtype), dout.stride(0), ptr(t), t.stride(0), W,
+                                                  ptr(rowptr), ptr(pair_idx), ptr(partner), n, ptr(dt_), dt_.stride(0),
+                                                  stream()), "fabind_rows_hadamard_bwd")
+            return dt_, None, None, None
+        dt_ = torch.zeros_like(t)
         check(load().fabind_pair_hadamard_bwd(ptr(dout), dt_code(dout.dtype), dout.stride(0), ptr(t), ptr(t), t.stride(0), W,
                                               None, None, 0, 0, ptr(ia), ptr(ib), ia.shape[0], ptr(dt_), ptr(dt_),
                                               dt_.stride(0), None, None, 0, stream()), "fabind_pair_hadamard_bwd")
-        return dt_, None, None
+        return dt_, None, None, None
 
 
-def rows_hadamard(t, idx_a, idx_b):
-    """einsum('bik,bjk->bijk') restricted to the valid pairs (reference model.py:355)."""
+def _rows_hadamard_csr(ia, ib, n, a_sorted=False):
+    """CSR of the pairs of every row of t for the adjoint of out[e] = t[ia[e]] * t[ib[e]]: row r lists first its pairs as first factor
+    (partner = ib of the pair), then its pairs as second factor (partner = ia), each block in pair order.
+    -> (rowptr int32 [n + 1], pair_idx int32 [2 P], partner int32 [2 P])."""
+    P = ia.shape[0]
+    dev = ia.device
+    ia64, ib64 = ia.long(), ib.long()
+    pa = torch.arange(P, device=dev) if a_sorted else torch.argsort(ia64, stable=True)     # (a_sorted: ia is non-decreasing)
+    pb = torch.argsort(ib64, stable=True)
+    ca = torch.bincount(ia64, minlength=n)
+    cb_ = torch.bincount(ib64, minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(ca + cb_, 0)
+    starts = rowptr[:-1]
+    sa, sb = ia64[pa], ib64[pb]
+    ar = torch.arange(P, device=dev)
+    ra = ar - (torch.cumsum(ca, 0) - ca)[sa]                          # rank inside the row's first-factor block
+    rb = ar - (torch.cumsum(cb_, 0) - cb_)[sb]
+    pair_idx = torch.empty(2 * P, dtype=torch.int32, device=dev)
+    partner = torch.empty(2 * P, dtype=torch.int32, device=dev)
+    posa, posb = starts[sa] + ra, starts[sb] + ca[sb] + rb
+    pair_idx[posa], partner[posa] = pa.to(torch.int32), ib64[pa].to(torch.int32)
+    pair_idx[posb], partner[posb] = pb.to(torch.int32), ia64[pb].to(torch.int32)
+    return rowptr.to(torch.int32), pair_idx, partner
+
+
+ROWS_HADAMARD_WALK = os.environ.get("FABIND_ROWS_HADAMARD_WALK", "1") == "1"      # adjoint of rows_hadamard as a row walk (0: float atomics)
+
+
+def rows_hadamard(t, idx_a, idx_b, a_sorted=False):
+    """einsum('bik,bjk->bijk') restricted to the valid pairs (reference model.py:355).  a_sorted: idx_a is non-decreasing (a
+    protein-major pair list) -- the adjoint's index glue skips one sort."""
     ia, ib = idx_a.to(torch.int32).contiguous(), idx_b.to(torch.int32).contiguous()
     if _needs_grad(t):
-        return _RowsHadamard.apply(t, ia, ib)
+        return _RowsHadamard.apply(t, ia, ib, a_sorted)
     dummy = t[:, :0]
     return K.pair_hadamard(t, t, dummy, dummy, ia, ib, act_dtype())
 

@@ -48,8 +48,9 @@ const char* fabind_last_error(void);
  *     fabind_split_sum takes (n_tail, out_tail); fabind_inter_attn_bwd writes wpart as [nblk][4][H] (was [4][nblk][H]);
  *     fabind_pair_hadamard_bwd_rows added (the pair-Hadamard adjoint over the inter graph without float atomics);
  *     fabind_layernorm_rows_bwd takes nblk (the caller sizes the partial buffers; the kernel strides rows over that grid).
+ * 13 = FabindGemmArgs.r_dtype (bf16 residual operand).  14 = fabind_rows_hadamard_bwd added.
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 13
+#define FABIND_ABI_VERSION 14
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -505,6 +506,12 @@ int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const float* a0, 
 int fabind_pair_hadamard_bwd_grid(const void* dhd, int dt, int ldh, const float* T, int ldt, int W, const int* node_off,
                                   const int* c_cnt, const int* node_b, const int* desc_p, int n_nodes, float* dT, int lddt,
                                   hipStream_t stream);
+/* Adjoint of out[e, :] = t[ia[e], :] * t[ib[e], :] (the distance-map head's LN(p_i) * LN(c_j) over every pocket residue x ligand atom
+ * pair, FABind/fabind/models/model.py:355) without float atomics: the pairs of every row of t are given as a CSR (rowptr [n_rows + 1];
+ * per entry the pair's row of dout and the partner's row of t); one wave per row, dT[n, :] = sum_e dout[pair_idx[e], :] * t[partner[e], :]
+ * (written, not accumulated; rows without pairs receive zeros).  W <= 1024, W % 4 == 0.  Deterministic summation order. */
+int fabind_rows_hadamard_bwd(const void* dout, int dt, int ldo, const float* t, int ldt, int W, const int* rowptr, const int* pair_idx,
+                             const int* partner, int n_rows, float* dT, int lddt, hipStream_t stream);
 /* fabind_pair_hadamard_bwd over the inter graph's reduced pairs without float atomics: one wave per node walks the inter edges of its own
  * row (pair = red_idx[e], partner = col[e]); t0 = (a | b) [N, 2H], t1 = (a | b) [N, 2 H2] (H2 may be 0), the sums are ADDED to d0 / d1
  * in the same layout.  Deterministic summation order. */

@@ -1088,3 +1088,42 @@ def test_pair_hadamard_products_all_lane_groupings(H, H2, dt):
     hd = K.pair_hadamard(t0[:, :H], t0[:, H:], t1[:, :H2], t1[:, max(H2, 4):max(H2, 4) + H2], rp.to(dev), rc.to(dev), dt)
     ref = torch.cat([T0[rp.long(), :H] * T0[rc.long(), H:], T1[rp.long(), :H2] * T1[rc.long(), max(H2, 4):max(H2, 4) + H2]], 1)
     assert hd.shape == ref.shape and torch.equal(hd.float().cpu(), ref.to(dt).float())
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_rows_hadamard_adjoint_row_walk(mode):
+    """ops.rows_hadamard (the distance-map head's LN(p_i) * LN(c_j) over every pocket residue x ligand atom pair, model.py:355) under
+    autograd: forward and the atomics-free adjoint (one wave per row of t walks its pairs) against torch indexing + autograd and
+    against the float-atomics kernel; a full protein x ligand grid per complex as in the model."""
+    from fabind_amd import config, ops
+    dev = _dev()
+    config.set_precision(mode)
+    try:
+        g = torch.Generator().manual_seed(3)
+        n_p, n_c, W = [150, 97], [40, 23], 512
+        npk, ncs = sum(n_p), sum(n_c)
+        t = torch.randn(npk + ncs, W, generator=g)
+        ia, ib, po, co = [], [], 0, 0
+        for P_, C_ in zip(n_p, n_c):
+            ia.append(po + torch.arange(P_).repeat_interleave(C_))
+            ib.append(npk + co + torch.arange(C_).repeat(P_))
+            po, co = po + P_, co + C_
+        ia, ib = torch.cat(ia), torch.cat(ib)
+        cot = torch.randn(ia.shape[0], W, generator=g)
+        tr = t.clone().requires_grad_(True)
+        ref = tr[ia] * tr[ib]
+        (ref * cot).sum().backward()
+        outs = {}
+        for walk in (True, False):
+            ops.ROWS_HADAMARD_WALK = walk
+            td = t.to(dev).requires_grad_(True)
+            y = ops.rows_hadamard(td, ia.to(dev), ib.to(dev))
+            (y.float() * cot.to(dev)).sum().backward()
+            outs[walk] = (y.detach().float().cpu(), td.grad.cpu())
+        tol = 1e-5 if mode == "fp32" else 2e-2
+        assert (outs[True][0] - ref.detach()).abs().max() <= tol * float(ref.abs().max())
+        assert (outs[True][1] - tr.grad).abs().max() <= tol * float(tr.grad.abs().max())
+        assert (outs[True][1] - outs[False][1]).abs().max() <= 1e-4 * float(tr.grad.abs().max())
+    finally:
+        ops.ROWS_HADAMARD_WALK = True
+        config.set_precision("fp32")

@@ -50,7 +50,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()                                        # loads without a GPU (HIP initialises lazily)
     from fabind_amd import _lib as L
     import ctypes
-    assert lib.fabind_abi_version() == L.ABI_VERSION == 13
+    assert lib.fabind_abi_version() == L.ABI_VERSION == 14
     # the ctypes mirrors have the library's struct sizes (load() refuses a mismatch; checked again here explicitly)
     for which, mirror in enumerate((L.GemmArgs, L.EdgeBwdArgs, L.PairUpdateArgs)):
         assert lib.fabind_sizeof_args(which) == ctypes.sizeof(mirror)
@@ -383,3 +383,24 @@ def test_param_pack_plans_on_the_host(monkeypatch):
     assert torch.equal(again["pad"].detach()[:4, :10], D.detach().to(bf)) and float(again["pad"].detach()[4:].abs().max()) == 0.0
     assert float(again["pad"].detach()[:, 10:].abs().max()) == 0.0
     assert torch.equal(again["cat0"].detach()[8:], B.detach().to(bf))
+
+
+def test_rows_hadamard_csr_lists_every_pair_under_both_rows():
+    """ops._rows_hadamard_csr (index glue of the atomics-free adjoint of out[e] = t[ia[e]] * t[ib[e]], model.py:355): interpreting the
+    CSR row by row on the host reproduces torch's index_add form bit for bit -- incl. a row that occurs on both sides and empty rows."""
+    from fabind_amd import ops
+    g = torch.Generator().manual_seed(0)
+    n, P, W = 37, 400, 8
+    ia = torch.randint(0, 20, (P,), generator=g).to(torch.int32)
+    ib = (20 + torch.randint(0, 15, (P,), generator=g)).to(torch.int32)
+    ib[5] = 3
+    t, dout = torch.randn(n, W, generator=g), torch.randn(P, W, generator=g)
+    rp, pi, pn = ops._rows_hadamard_csr(ia, ib, n)
+    assert rp.dtype == torch.int32 and int(rp[-1]) == 2 * P and rp.shape[0] == n + 1
+    got = torch.zeros(n, W)
+    for r in range(n):
+        for e in range(int(rp[r]), int(rp[r + 1])):
+            got[r] += dout[int(pi[e])] * t[int(pn[e])]
+    ref = torch.zeros(n, W).index_add_(0, ia.long(), dout * t[ib.long()]).index_add_(0, ib.long(), dout * t[ia.long()])
+    assert torch.allclose(got, ref, rtol=0, atol=1e-5)
+    assert int(rp[36]) == int(rp[37])                      # rows 35, 36 have no pair
