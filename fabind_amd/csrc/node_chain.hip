@@ -1,0 +1,193 @@
+// Forward-only node-level chains: Linear -> activation -> Linear (+ residual) over 64-row tiles with the hidden activation kept in LDS.
+//
+//   kind 0 (the node MLP of MC_E_GCL, egnn.py:99-109):          out = act([X1 | X2] W1^T + b1) W2^T + b2 + R      (hidden = H)
+//   kind 1 (the Transition blocks, model_utils.py:162-175):     out = act(X1 W1^T + b1) W2^T + b2 + R             (hidden = 2 H)
+//
+// As two GEMM launches the hidden activation is written to HBM and read back (100 MB each way at 98,688 rows x 512, 200 MB each way for
+// the 1,024-wide Transition): a fifth to two fifths of the pair's traffic, on launches that are HBM-bound.  Here a work-group of H / 64
+// waves owns 64 rows: X tiles are staged into ONE swizzled [64][H] bf16 LDS tile (two work-groups per CU), every H x H weight block is a
+// fragment-packed operand streamed from L2 (fused_common.h: fe_gemm_rolled, the operand-swapped contraction of the fused edge kernels),
+// the hidden activation overwrites the tile in place, and only the fp32 output (+ its bf16 operand copy) leaves the CU.
+// Inference only: under autograd the hidden activation and its gradient are the operands of the weight-gradient contractions and have
+// to exist in HBM anyway.
+#include "common.h"
+#include "fabind_hip.h"
+#include "fused_common.h"
+
+typedef float nc_f2 __attribute__((ext_vector_type(2)));
+template <int ACT> __device__ __forceinline__ nc_f2 nc_act_pair(const nc_f2 z) {
+    if constexpr (ACT == FB_ACT_SILU) {
+        const nc_f2 t = z * -1.44269504f;
+        const nc_f2 o = nc_f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+        return z * nc_f2{__builtin_amdgcn_rcpf(o.x), __builtin_amdgcn_rcpf(o.y)};
+    } else {
+        return nc_f2{fmaxf(z.x, 0.f), fmaxf(z.y, 0.f)};
+    }
+}
+
+struct NodeChainArgs {
+    const bf16_t* X1; int ld1;
+    const bf16_t* X2; int ld2;        // kind 0 only
+    const bf16_t* W1a; const bf16_t* W1b; const float* b1;        // kind 0: the two K-halves of W1; kind 1: its two hidden halves
+    const bf16_t* W2a; const bf16_t* W2b; const float* b2;        // kind 0: W2 (W2b unused); kind 1: the two K-halves of W2
+    const float* R; int ldr;
+    float* out; int ldo;
+    bf16_t* out16; int ldo16;
+    int M;
+};
+
+template <int H, int KIND, int ACT>
+__global__ __launch_bounds__(H, ((KIND == 0 && H == 512) ? 4 : 2)) void node_chain_fwd_kernel(const NodeChainArgs p) {
+    constexpr int BM = 64, MI = BM / 16, CH = H / 8;
+    constexpr int SWZ = (H >= 128) ? 15 : 7;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sX = (bf16_t*)smem;                                   // [64][H] swizzled: X1 -> (X2) -> hidden activation
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, cq = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    const int nr = min(BM, p.M - m0);
+    // LDS element offset of this lane's accumulator quad (i, j): row i*16 + fr, columns wave*64 + j*16 + cq*4 .. +3 (fused_edge_fwd2.hip)
+    const int cx = (wave * 8 + (cq >> 1)) ^ (fr & SWZ);
+    const int lbase = fr * H + (cq & 1) * 4;
+#define NC_QOFF(i, j) (lbase + (i) * 16 * H + ((cx ^ ((j) * 2)) * 8))
+    const int fcol = wave * 64 + cq * 4;
+
+    constexpr int NLD = BM * CH / H;                              // 16-byte chunks per thread and tile (= 8)
+    auto stage = [&](const bf16_t* X, int ld) {                   // every load of the tile in flight before the first LDS store;
+        uint4 v[NLD];                                             // rows past the end are zero rows
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int q = tid + u * H, rw = q / CH, ch = q % CH;
+            v[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (rw < nr) v[u] = *(const uint4*)(X + (size_t)(m0 + rw) * ld + ch * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int q = tid + u * H, rw = q / CH, ch = q % CH;
+            *(uint4*)&sX[rw * H + ((ch ^ (rw & SWZ)) * 8)] = v[u];
+        }
+    };
+    auto hidden_to_tile = [&](f32x4_t (&acc)[MI][4], const float* bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 bq = *(const float4*)(bias + fcol + j * 16);
+            const nc_f2 b01 = nc_f2{bq.x, bq.y}, b23 = nc_f2{bq.z, bq.w};
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const nc_f2 t01 = nc_act_pair<ACT>(nc_f2{acc[i][j][0], acc[i][j][1]} + b01);
+                const nc_f2 t23 = nc_act_pair<ACT>(nc_f2{acc[i][j][2], acc[i][j][3]} + b23);
+                *(uint2*)&sX[NC_QOFF(i, j)] = make_uint2(pack2_bf16(t01.x, t01.y), pack2_bf16(t23.x, t23.y));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    f32x4_t acc[MI][4], out[MI][4];
+    fe_zero(out);
+    stage(p.X1, p.ld1);
+    __syncthreads();
+    if constexpr (KIND == 0) {
+        fe_zero(acc);
+        fe_gemm_rolled<H, MI, true, SWZ>(sX, p.W1a, wave, lane, acc);
+        __syncthreads();
+        stage(p.X2, p.ld2);
+        __syncthreads();
+        fe_gemm_rolled<H, MI, true, SWZ>(sX, p.W1b, wave, lane, acc);
+        __syncthreads();                                          // every wave has finished reading X2
+        hidden_to_tile(acc, p.b1);
+        __syncthreads();
+        fe_gemm_rolled<H, MI, true, SWZ>(sX, p.W2a, wave, lane, out);
+    } else {
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            if (c) {                                              // the tile held the first hidden half: X1 comes back from L2
+                __syncthreads();
+                stage(p.X1, p.ld1);
+                __syncthreads();
+            }
+            fe_zero(acc);
+            fe_gemm_rolled<H, MI, true, SWZ>(sX, c ? p.W1b : p.W1a, wave, lane, acc);
+            __syncthreads();
+            hidden_to_tile(acc, p.b1 + c * H);
+            __syncthreads();
+            fe_gemm_rolled<H, MI, true, SWZ>(sX, c ? p.W2b : p.W2a, wave, lane, out);
+        }
+    }
+    // out = acc + b2 (+ R), fp32 (+ bf16 copy).  A lane's accumulator quad is four consecutive columns of one row: stored from the
+    // registers that is 64-byte pieces of sixteen rows per instruction (the two-GEMM form's epilogue moves 256-byte row segments and was
+    // as fast as this whole kernel).  The tile is dead after the last contraction: the fp32 result goes through it in two column halves
+    // ([64][H / 2] fp32 = the tile's 64 x H x 2 bytes), and leaves as whole rows -- a wave per row, 16 bytes per lane.
+    {
+        float* sO = (float*)smem;                                 // [64][H / 2] fp32, row-major
+        constexpr int HW = H / 2;                                 // columns per half
+        constexpr int WPH = (H / 64) / 2;                         // waves whose columns lie in one half
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();                                      // the contraction (or the previous half's readers) are done with the tile
+            if (wave / WPH == half) {
+                const int lc = (wave % WPH) * 64 + cq * 4;        // this lane's first column inside the half
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 bq = *(const float4*)(p.b2 + fcol + j * 16);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        *(float4*)&sO[(i * 16 + fr) * HW + lc + j * 16] =
+                            make_float4(out[i][j][0] + bq.x, out[i][j][1] + bq.y, out[i][j][2] + bq.z, out[i][j][3] + bq.w);
+                }
+            }
+            __syncthreads();
+            constexpr int C4 = HW / 4;                            // float4 chunks per row of the half
+            for (int q = tid; q < BM * C4; q += H) {
+                const int rw = q / C4, c4 = q % C4;
+                if (rw >= nr) continue;
+                const size_t row = (size_t)(m0 + rw);
+                const int col = half * HW + c4 * 4;
+                float4 o = *(const float4*)&sO[rw * HW + c4 * 4];
+                if (p.R) {
+                    const float4 r = *(const float4*)(p.R + row * p.ldr + col);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                *(float4*)(p.out + row * p.ldo + col) = o;
+                if (p.out16) *(uint2*)(p.out16 + row * p.ldo16 + col) = make_uint2(pack2_bf16(o.x, o.y), pack2_bf16(o.z, o.w));
+            }
+        }
+    }
+#undef NC_QOFF
+}
+
+extern "C" int fabind_node_chain_fwd(const void* X1, int ld1, const void* X2, int ld2, const void* W1a, const void* W1b, const float* b1,
+                                     const void* W2a, const void* W2b, const float* b2, int act, int kind, const float* R, int ldr,
+                                     float* out, int ldo, void* out16, int ldo16, int M, int H, hipStream_t stream) {
+    if (M <= 0) return 0;
+    FB_REQUIRE(H == 512 || H == 256 || H == 128, "fabind_node_chain_fwd: H in {128, 256, 512}");
+    FB_REQUIRE(kind == 0 || kind == 1, "fabind_node_chain_fwd: kind 0 (K = 2H, hidden H) or 1 (K = H, hidden 2H)");
+    FB_REQUIRE(act == FB_ACT_SILU || act == FB_ACT_RELU, "fabind_node_chain_fwd: silu or relu");
+    FB_REQUIRE(X1 && W1a && W1b && W2a && b1 && b2 && out && (kind == 0 ? X2 != nullptr : W2b != nullptr), "fabind_node_chain_fwd: operands");
+    FB_REQUIRE(ld1 % 8 == 0 && (kind == 1 || ld2 % 8 == 0) && ldo % 4 == 0 && (!R || ldr % 4 == 0) && (!out16 || ldo16 % 4 == 0),
+               "fabind_node_chain_fwd: leading dimensions (bf16 rows % 8, fp32 rows % 4)");
+    FB_REQUIRE((((uintptr_t)X1 | (uintptr_t)X2 | (uintptr_t)out | (uintptr_t)R | (uintptr_t)out16 | (uintptr_t)b1 | (uintptr_t)b2) & 15) == 0,
+               "fabind_node_chain_fwd: 16-byte aligned buffers");
+    NodeChainArgs a;
+    a.X1 = (const bf16_t*)X1; a.ld1 = ld1; a.X2 = (const bf16_t*)X2; a.ld2 = ld2;
+    a.W1a = (const bf16_t*)W1a; a.W1b = (const bf16_t*)W1b; a.b1 = b1;
+    a.W2a = (const bf16_t*)W2a; a.W2b = (const bf16_t*)W2b; a.b2 = b2;
+    a.R = R; a.ldr = ldr; a.out = out; a.ldo = ldo; a.out16 = (bf16_t*)out16; a.ldo16 = ldo16; a.M = M;
+    const dim3 grid((M + 63) / 64);
+#define NC_LAUNCH_(HH, KK, AA)                                                                                                  \
+    do {                                                                                                                        \
+        const size_t lds = (size_t)64 * HH * 2;                                                                                 \
+        static bool set_ = false;                                                                                               \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)node_chain_fwd_kernel<HH, KK, AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        hipLaunchKernelGGL((node_chain_fwd_kernel<HH, KK, AA>), grid, dim3(HH), lds, stream, a);                                 \
+    } while (0)
+#define NC_LAUNCH(HH)                                                                                                           \
+    do {                                                                                                                        \
+        if (kind == 0) { if (act == FB_ACT_SILU) NC_LAUNCH_(HH, 0, FB_ACT_SILU); else NC_LAUNCH_(HH, 0, FB_ACT_RELU); }          \
+        else { if (act == FB_ACT_SILU) NC_LAUNCH_(HH, 1, FB_ACT_SILU); else NC_LAUNCH_(HH, 1, FB_ACT_RELU); }                    \
+    } while (0)
+    if (H == 512) NC_LAUNCH(512); else if (H == 256) NC_LAUNCH(256); else NC_LAUNCH(128);
+#undef NC_LAUNCH
+#undef NC_LAUNCH_
+    FB_CHECK_LAUNCH();
+    return 0;
+}

@@ -408,6 +408,28 @@ def _drop(t, pr):
     return torch.nn.functional.dropout(t, pr, True) if pr > 0.0 else t
 
 
+NODE_CHAIN = os.environ.get("FABIND_NODE_CHAIN", "1") == "1"     # forward-only bf16 passes: node MLP / Transition as one kernel (csrc/node_chain.hip)
+
+
+def _node_chain(p, key, W1, b1, W2, b2, act, kind, x1, x2, residual, want16):
+    """Linear -> act -> Linear + residual as one forward kernel with the hidden activation in LDS; None when the shapes do not fit
+    (H in {128, 256, 512}; kind 0: W1 [H, 2H]; kind 1: W1 [2H, H]).  The fragment packs are kept in the (cached, no-grad) parameter
+    pack p under `key`."""
+    H = W2.shape[0]
+    if not (NODE_CHAIN and H in (128, 256, 512) and W1.dtype == torch.bfloat16 and b1 is not None and b2 is not None
+            and x1.dtype == torch.bfloat16 and x1.shape[1] == H and x1.stride(1) == 1 and x1.stride(0) % 8 == 0
+            and residual.dtype == torch.float32 and residual.stride(1) == 1 and residual.stride(0) % 4 == 0
+            and W1.shape == ((H, 2 * H) if kind == 0 else (2 * H, H)) and W2.shape == ((H, H) if kind == 0 else (H, 2 * H))):
+        return None
+    if kind == 0 and not (x2 is not None and x2.dtype == torch.bfloat16 and x2.shape == x1.shape and x2.stride(1) == 1 and x2.stride(0) % 8 == 0):
+        return None
+    packs = p.get(key)
+    if packs is None:
+        packs = p[key] = K.node_chain_pack(W1, W2, kind)
+    out, out16 = K.node_chain_fwd(x1, x2 if kind == 0 else None, packs, b1.float(), b2.float(), act, kind, residual=residual, want16=want16)
+    return ops._attach_b16(out, out16)
+
+
 def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
     """MC_E_GCL.forward (egnn.py:130-144): edge -> coord -> node, all from the layer's input h, x.
 
@@ -432,6 +454,10 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
         if pdrop == 0.0 and not fast:
             # node MLP + residual as one autograd node (activation adjoint and residual gradient inside GEMM epilogues)
             return ops.mlp2(hin, p["Wn1"], p["bn1"], K.ACT_SILU, p["Wn2"], p["bn2"], residual=h, x2=agg, want16=True), x_new
+        if fast and pdrop == 0.0:
+            hn = _node_chain(p, "_nc_node", p["Wn1"], p["bn1"], p["Wn2"], p["bn2"], K.ACT_SILU, 0, hin, ops._mm_in(agg), h, True)
+            if hn is not None:
+                return hn, x_new
         t = ops.linear(hin, p["Wn1"], p["bn1"], x2=agg, act_epi=K.ACT_SILU, out_dtype=ad)
         if pdrop > 0.0:
             return h + _drop(ops.linear(t, p["Wn2"], p["bn2"]), pdrop), x_new
@@ -487,10 +513,19 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     hc = (hc + _drop(ops.linear(c16(og), p["Wo_c"], p["bo_c"]), pdrop)) if pdrop > 0.0 else \
         ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc)
     if fast:
-        t = ops.linear(hp16, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU, out_dtype=od)
-        hp = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True)
-        t = ops.linear(c16(hc), p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU, out_dtype=od)
-        hc = ops.linear(t, p["Wt2_c"], p["bt2_c"], residual=hc)
+        hp2 = _node_chain(p, "_nc_tp", p["Wt1_p"], p["bt1_p"], p["Wt2_p"], p["bt2_p"], K.ACT_RELU, 1, hp16, None, hp, True) \
+            if pdrop == 0.0 else None
+        if hp2 is None:
+            t = ops.linear(hp16, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU, out_dtype=od)
+            hp2 = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True)
+        hp = hp2
+        hc16 = c16(hc)
+        hc2 = _node_chain(p, "_nc_tc", p["Wt1_c"], p["bt1_c"], p["Wt2_c"], p["bt2_c"], K.ACT_RELU, 1, hc16, None, hc, False) \
+            if pdrop == 0.0 else None
+        if hc2 is None:
+            t = ops.linear(hc16, p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU, out_dtype=od)
+            hc2 = ops.linear(t, p["Wt2_c"], p["bt2_c"], residual=hc)
+        hc = hc2
     else:   # Transition + residual (cross_att.py:48-49) as one autograd node each
         hp = ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True)
         hc = ops.mlp2(hc, p["Wt1_c"], p["bt1_c"], K.ACT_RELU, p["Wt2_c"], p["bt2_c"], residual=hc)

@@ -353,6 +353,34 @@ def pack_frag(W):
     return W.to(torch.bfloat16).view(N // 16, 16, Kd // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
 
 
+def node_chain_pack(W1, W2, kind):
+    """Fragment packs of the H x H blocks of a chain's two weights (see node_chain_fwd): kind 0: W1 [H, 2H], W2 [H, H];
+    kind 1: W1 [2H, H], W2 [H, 2H]."""
+    H = W2.shape[0]
+    if kind == 0:
+        assert W1.shape == (H, 2 * H) and W2.shape == (H, H)
+        return pack_frag(W1[:, :H].contiguous()), pack_frag(W1[:, H:].contiguous()), pack_frag(W2), None
+    assert W1.shape == (2 * H, H) and W2.shape == (H, 2 * H)
+    return pack_frag(W1[:H].contiguous()), pack_frag(W1[H:].contiguous()), pack_frag(W2[:, :H].contiguous()), pack_frag(W2[:, H:].contiguous())
+
+
+def node_chain_fwd(X1, X2, packs, b1, b2, act, kind, residual=None, want16=False):
+    """out = act([X1 | X2] W1^T + b1) W2^T + b2 (+ residual) with the hidden activation kept in LDS (csrc/node_chain.hip, forward only).
+    -> (out fp32 [M, H], bf16 copy or None)."""
+    M, H = X1.shape
+    assert X1.dtype == torch.bfloat16 and (X2 is None or X2.dtype == torch.bfloat16)
+    out = torch.empty((M, H), dtype=torch.float32, device=X1.device)
+    out16 = torch.empty((M, H), dtype=torch.bfloat16, device=X1.device) if want16 else None
+    W1a, W1b, W2a, W2b = packs
+    hidden = H if kind == 0 else 2 * H
+    _profiled("fabind_node_chain_fwd kind=%d M=%d H=%d" % (kind, M, H), 2.0 * M * (2 * H * hidden),
+              lambda: check(_lib.load().fabind_node_chain_fwd(
+                  ptr(X1), _ld(X1), ptr(X2), _ld(X2) if X2 is not None else 0, ptr(W1a), ptr(W1b), ptr(b1), ptr(W2a), ptr(W2b), ptr(b2), act,
+                  kind, ptr(residual), _ld(residual) if residual is not None else 0, ptr(out), _ld(out), ptr(out16),
+                  H if want16 else 0, M, H, stream()), "fabind_node_chain_fwd"))
+    return out, out16
+
+
 def pack_frag_split(W):
     """fp32 [N,K] weight -> (hi, lo) bf16 fragment packs of the split-bf16 kernels: hi = bf16(W), lo = bf16(W - hi)."""
     hi = W.to(torch.bfloat16)

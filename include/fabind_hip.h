@@ -48,7 +48,7 @@ const char* fabind_last_error(void);
  *     fabind_split_sum takes (n_tail, out_tail); fabind_inter_attn_bwd writes wpart as [nblk][4][H] (was [4][nblk][H]);
  *     fabind_pair_hadamard_bwd_rows added (the pair-Hadamard adjoint over the inter graph without float atomics);
  *     fabind_layernorm_rows_bwd takes nblk (the caller sizes the partial buffers; the kernel strides rows over that grid).
- * 13 = FabindGemmArgs.r_dtype (bf16 residual operand).  14 = fabind_rows_hadamard_bwd added.
+ * 13 = FabindGemmArgs.r_dtype (bf16 residual operand).  14 = fabind_rows_hadamard_bwd, fabind_node_chain_fwd added.
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 14
 int fabind_abi_version(void);
@@ -506,6 +506,16 @@ int fabind_pair_hadamard_bwd(const void* dhd, int dt, int ldh, const float* a0, 
 int fabind_pair_hadamard_bwd_grid(const void* dhd, int dt, int ldh, const float* T, int ldt, int W, const int* node_off,
                                   const int* c_cnt, const int* node_b, const int* desc_p, int n_nodes, float* dT, int lddt,
                                   hipStream_t stream);
+/* Forward-only node-level chain over 64-row tiles with the hidden activation kept in LDS (csrc/node_chain.hip):
+ *   kind 0: out = act([X1 | X2] W1^T + b1) W2^T + b2 (+ R)   hidden = H    -- MC_E_GCL.node_model, FABind/fabind/models/egnn.py:99-109
+ *   kind 1: out = act(X1 W1^T + b1) W2^T + b2 (+ R)          hidden = 2 H  -- Transition, FABind/fabind/models/model_utils.py:162-175
+ * X1, X2: bf16 [M, H]; every weight operand is one H x H block in the fragment order of the fused edge kernels ([K/32][N/16][64][8]):
+ * kind 0: W1a / W1b = W1[:, :H] / W1[:, H:], W2a = W2 (W2b unused); kind 1: W1a / W1b = W1[:H] / W1[H:], W2a / W2b = W2[:, :H] / W2[:, H:].
+ * b1 has the hidden width; R (optional) and out are fp32 [M, H]; out16 (optional) receives bf16(out).  act = FB_ACT_SILU | FB_ACT_RELU.
+ * H in {128, 256, 512}. */
+int fabind_node_chain_fwd(const void* X1, int ld1, const void* X2, int ld2, const void* W1a, const void* W1b, const float* b1,
+                          const void* W2a, const void* W2b, const float* b2, int act, int kind, const float* R, int ldr, float* out,
+                          int ldo, void* out16, int ldo16, int M, int H, hipStream_t stream);
 /* Adjoint of out[e, :] = t[ia[e], :] * t[ib[e], :] (the distance-map head's LN(p_i) * LN(c_j) over every pocket residue x ligand atom
  * pair, FABind/fabind/models/model.py:355) without float atomics: the pairs of every row of t are given as a CSR (rowptr [n_rows + 1];
  * per entry the pair's row of dout and the partner's row of t); one wave per row, dT[n, :] = sum_e dout[pair_idx[e], :] * t[partner[e], :]

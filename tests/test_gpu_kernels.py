@@ -1127,3 +1127,35 @@ def test_rows_hadamard_adjoint_row_walk(mode):
     finally:
         ops.ROWS_HADAMARD_WALK = True
         config.set_precision("fp32")
+
+
+@pytest.mark.parametrize("H", [512, 128])
+@pytest.mark.parametrize("kind,act", [(0, "silu"), (1, "relu"), (0, "relu"), (1, "silu")])
+def test_node_chain_forward_matches_two_linears(H, kind, act):
+    """csrc/node_chain.hip (node MLP of MC_E_GCL, egnn.py:99-109, and the Transition blocks, model_utils.py:162-175, as one forward
+    kernel with the hidden activation in LDS) against fp32 torch on the same bf16 operands, with the hidden activation rounded to bf16
+    as the kernel holds it; ragged last tile; with / without residual and bf16 copy."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(H + kind)
+    M = 1000 + 37
+    hid = H if kind == 0 else 2 * H
+    kin = 2 * H if kind == 0 else H
+    X = torch.randn(M, kin, generator=g).bfloat16()
+    W1 = (torch.randn(hid, kin, generator=g) / kin ** 0.5).bfloat16()
+    W2 = (torch.randn(H, hid, generator=g) / hid ** 0.5).bfloat16()
+    b1, b2 = torch.randn(hid, generator=g) * 0.3, torch.randn(H, generator=g) * 0.3
+    R = torch.randn(M, H, generator=g)
+    fa = torch.nn.functional.silu if act == "silu" else torch.relu
+    t = fa(X.float() @ W1.float().T + b1).bfloat16().float()
+    ref = t @ W2.float().T + b2 + R
+    code = K.ACT_SILU if act == "silu" else K.ACT_RELU
+    packs = K.node_chain_pack(W1.to(dev), W2.to(dev), kind)
+    Xd = X.to(dev)
+    X1, X2 = (Xd[:, :H].contiguous(), Xd[:, H:].contiguous()) if kind == 0 else (Xd, None)
+    out, out16 = K.node_chain_fwd(X1, X2, packs, b1.to(dev), b2.to(dev), code, kind, residual=R.to(dev), want16=True)
+    err = float((out.cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= 5e-3, err
+    assert torch.equal(out16.float().cpu(), out.cpu().bfloat16().float())
+    out_nr, none16 = K.node_chain_fwd(X1, X2, packs, b1.to(dev), b2.to(dev), code, kind)
+    assert none16 is None and float((out_nr.cpu() - (ref - R)).abs().max() / ref.abs().max()) <= 5e-3
