@@ -94,6 +94,9 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     # 'bf16x3' mode: fp32 x fp32 contractions run as split bf16 (three bf16 MFMAs per product term) instead of the exact fp32 MFMA
     x3 = A.dtype == torch.float32 and W.dtype == torch.float32 and _split3()
     a.split3 = 1 if x3 else 0
+    if PROFILE is None:                                    # (the label costs more host time than the launch: formatted only when events are taken)
+        check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm")
+        return (out if want_out else None), dot_out
     label = "fabind_gemm <%s,%s%s> M=%d N=%d K=%d" % (str(A.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""),
                                                       ",x3" if x3 else "", M, N, K)
     if groups is not None:
@@ -623,9 +626,12 @@ def gemm_tn(Y, X, splits=None, out_dtype=torch.float32, with_colsum=False):
         splits = _tn_splits(M, N, E, _lib.load().fabind_gemm_tn_tile_n())
     n = M * N + (M if with_colsum else 0)
     part = torch.empty((splits, n), dtype=torch.float32, device=dev)
-    _profiled("fabind_gemm_tn M=%d N=%d E=%d" % (M, N, E), 2.0 * M * N * E,
-              lambda: check(_lib.load().fabind_gemm_tn(ptr(Y), _ld(Y), ptr(X), _ld(X), ptr(part), M, N, E, splits, ptr(zp),
-                                                       None, 0, 1 if with_colsum else 0, stream()), "fabind_gemm_tn"))
+    launch = lambda: check(_lib.load().fabind_gemm_tn(ptr(Y), _ld(Y), ptr(X), _ld(X), ptr(part), M, N, E, splits, ptr(zp),
+                                                      None, 0, 1 if with_colsum else 0, stream()), "fabind_gemm_tn")
+    if PROFILE is None:
+        launch()
+    else:
+        _profiled("fabind_gemm_tn M=%d N=%d E=%d" % (M, N, E), 2.0 * M * N * E, launch)
     if with_colsum and n % 4 == 0 and M % 4 == 0 and (splits > 1 or out_dtype != torch.float32):
         # one reduction launch: the weight part as out_dtype, the column sums behind it as fp32
         dW = torch.empty((M, N), dtype=out_dtype, device=dev)
