@@ -47,6 +47,8 @@ for _ in range(steps):
 t_host = time.time() - t0
 torch.cuda.synchronize()
 print("host-only (no final sync in the window) %.2f ms per step" % (t_host / steps * 1e3))
+if len(sys.argv) > 3 and sys.argv[3] == "1":                # backward in the calling thread: cProfile sees the Function.backward bodies
+    torch.autograd.set_multithreading_enabled(False)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(steps):
@@ -54,5 +56,5 @@ for _ in range(steps):
 pr.disable()
 torch.cuda.synchronize()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45)
-print(s.getvalue()[:9000])
+pstats.Stats(pr, stream=s).sort_stats(sys.argv[4] if len(sys.argv) > 4 else "tottime").print_stats(60)
+print(s.getvalue()[:14000])
