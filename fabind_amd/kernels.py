@@ -270,7 +270,8 @@ def bo_tiles(lay):
         toff = np.concatenate([[0], np.cumsum(T)]).astype(np.int32)
         tile_b = np.repeat(np.arange(lay.B, dtype=np.int32), T)
         dev = lay.node_off.device
-        c = lay._bo_tiles = (torch.from_numpy(toff).to(dev), torch.from_numpy(tile_b).to(dev), int(toff[-1]))
+        from .param_pack import upload
+        c = lay._bo_tiles = (upload(toff, dev, torch.int32), upload(tile_b, dev, torch.int32), int(toff[-1]))
     return c
 
 

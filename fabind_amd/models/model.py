@@ -219,22 +219,26 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         cb = data['compound'].batch
         Xn = self.normalize_coord(g['X'].unsqueeze(-2)).float()
         Xl = self.normalize_coord(g['XL'].unsqueeze(-2)).float()
+        # the row indices of the ligand atoms / pocket residues are read back BEFORE the complex model is queued: boolean-mask indexing
+        # of its outputs would read their counts back behind its whole forward pass (three queue drains per step)
+        seg1 = g['segment'].bool() if not g['segment'].is_floating_point() else g['segment'] > 0.5
+        cidx = torch.nonzero(~seg1 & ~g['is_global']).squeeze(1)
+        pidx = torch.nonzero(seg1 & ~g['is_global']).squeeze(1)
         Xo, Ho = self.complex_model(Xn, g['H'], batch_id=g['batch'], segment_id=g['segment'], mask=g['mask'],
                                     is_global=g['is_global'], compound_edge_index=g['c2c'], LAS_edge_index=g['LAS'],
                                     batched_complex_coord_LAS=Xl, LAS_mask=None)
-        seg1 = g['segment'].bool() if not g['segment'].is_floating_point() else g['segment'] > 0.5
-        cflag, pflag = ~seg1 & ~g['is_global'], seg1 & ~g['is_global']
-        coords_n = Xo[cflag].squeeze(-2)
-        return Ho, cflag, pflag, coords_n
+        coords_n = Xo.index_select(0, cidx).squeeze(-2)
+        return Ho, cidx, pidx, coords_n
 
-    def _dist_heads(self, data, g, Ho, cflag, pflag, coords_n):
+    def _dist_heads(self, data, g, Ho, cidx, pidx, coords_n):
         cb = data['compound'].batch
-        B = int(cb[-1].item()) + 1
-        pi, ci = g.get('pairs') or self._pair_lists(g['pocket_batch'], cb, torch.bincount(g['pocket_batch'], minlength=B),
-                                                   torch.bincount(cb, minlength=B))
-        ln = ops.layernorm(torch.cat([Ho[pflag], Ho[cflag]], 0).contiguous(), self.layernorm.weight, self.layernorm.bias,
-                           self.layernorm.eps)
-        npk = int(pflag.sum().item())
+        pairs = g.get('pairs')
+        if pairs is None:
+            B = int(cb[-1].item()) + 1
+            pairs = self._pair_lists(g['pocket_batch'], cb, torch.bincount(g['pocket_batch'], minlength=B), torch.bincount(cb, minlength=B))
+        pi, ci = pairs
+        ln = ops.layernorm(Ho.index_select(0, torch.cat([pidx, cidx])), self.layernorm.weight, self.layernorm.bias, self.layernorm.eps)
+        npk = pidx.shape[0]
         hd = ops.rows_hadamard(ln, pi, npk + ci, a_sorted=True)                                       # LN(p_i) * LN(c_j)
         wd = ops.mm_dtype()
         part = ops.linear_rowdot(hd, self.distmap_mlp[0].weight.to(wd), self.distmap_mlp[0].bias,
@@ -270,8 +274,8 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
                      is_global=cx.is_global, batch=cx.batch, c2c=data['complex', 'c2c', 'complex'].edge_index,
                      LAS=data['complex', 'LAS', 'complex'].edge_index, pocket_xyz=data.node_xyz,
                      pocket_batch=data['pocket'].batch, dis_map=data.dis_map, less5=0)
-        Ho, cflag, pflag, coords_n = self._complex_and_heads(data, g)
-        y_pred, y_by = self._dist_heads(data, g, Ho, cflag, pflag, coords_n)
+        Ho, cidx, pidx, coords_n = self._complex_and_heads(data, g)
+        y_pred, y_by = self._dist_heads(data, g, Ho, cidx, pidx, coords_n)
         return (self.unnormalize_coord(coords_n), cb, y_pred, y_by, head['logits'] * head['mask'], pocket_cls,
                 head['mask'], head['xyz'], center, g['dis_map'], g['less5'])
 

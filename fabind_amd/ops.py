@@ -1355,7 +1355,7 @@ def _pair_bias_groups(lay, H, ld_ab, nblk, Kp):
     key = ("pbg", H, ld_ab, nblk, Kp)
     if getattr(lay, "_pbg_key", None) != key:
         import numpy as np
-        from .param_pack import _upload
+        from .param_pack import upload
         B, NO = lay.B, 8
         dev = lay.node_off.device
         P, C = np.asarray(lay.P, dtype=np.int64), np.asarray(lay.C, dtype=np.int64)
@@ -1370,11 +1370,11 @@ def _pair_bias_groups(lay, H, ld_ab, nblk, Kp):
         # T_k[(j,o), :] of complex b = Dt_k[b*Kp + (j,o), :] . At[b*H + h, :]^T  (K = padded protein length)
         ch = coff * NO * H
         tg = np.stack([bb * Kp, C * NO, bb * H, np.full(B, H), lo(ch), hi(ch), np.full(B, H), zero], 1)
-        # one asynchronous upload from the pinned staging ring (param_pack._upload): `torch.tensor(list, device=...)` is a pageable
+        # one asynchronous upload from the pinned staging ring (param_pack.upload): `torch.tensor(list, device=...)` is a pageable
         # host-to-device copy, i.e. it waits for everything the stream still has queued -- in the middle of the backward pass that was
         # 2.4 ms per tensor, 4.8 ms per step at B = 64 (tools/probes/stack_hostprof.py, backward in the calling thread)
         both = (np.concatenate([cat, tg], 0) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
-        devt = _upload(np.ascontiguousarray(both).reshape(-1), dev).view(torch.int32).view(2 * B, 8)     # (_upload takes a flat array)
+        devt = upload(both, dev, torch.int32)
         lay._pbg = (devt[:B], devt[B:])
         lay._pbg_key = key
     return lay._pbg

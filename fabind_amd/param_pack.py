@@ -52,6 +52,14 @@ def _upload(table, dev):
     return out
 
 
+def upload(arr, dev, dtype):
+    """Device copy of a small contiguous numpy array as a tensor of `dtype`, ASYNCHRONOUS (pinned staging ring): a plain
+    `torch.from_numpy(a).to(device)` / `torch.tensor(list, device=...)` is a pageable copy, which waits for everything the stream still
+    has queued -- index tables built in the middle of a step (group descriptors, tile maps, pair offsets) used to drain the device."""
+    flat = np.ascontiguousarray(arr).reshape(-1)
+    return _upload(flat, dev).view(dtype).view(arr.shape)
+
+
 def _launch(table, dev):
     if len(table) == 0:
         return

@@ -267,7 +267,8 @@ class PairList:
     """Built with device index arithmetic (no per-complex host loop, no large upload)."""
 
     def __init__(self, lay, device):
-        i64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int64)).to(device)
+        from ..param_pack import upload
+        i64 = lambda a: upload(np.ascontiguousarray(a, dtype=np.int64), device, torch.int64)         # (asynchronous: no queue drain)
         packed = i64(np.stack([lay.off[:-1], lay.C, lay.pair_off_np[:-1], lay.P * lay.C]))       # one small upload
         self.off, self.C, self.pair_off, npair = packed[0], packed[1], packed[2], packed[3]
         self.n = int(lay.n_pairs)

@@ -258,17 +258,20 @@ class FABindPlus(nn.Module):
         return dict(X=X, XL=cx.node_coords_LAS, segment=cx.segment, mask=cx.mask, is_global=cx.is_global, batch=cx.batch,
                     c2c=data['complex', 'c2c', 'complex'].edge_index, LAS=data['complex', 'LAS', 'complex'].edge_index,
                     pocket_xyz=data.node_xyz, pocket_batch=data['pocket'].batch, dis_map=data.dis_map, less5=0,
-                    bias=torch.zeros(B, 3, device=dev))
+                    bias=torch.zeros(B, 3, device=dev), B=B)
 
     def _complex(self, g, pair):
         Xn = self.normalize_coord(g['X'].unsqueeze(-2)).float()
         Xl = self.normalize_coord(g['XL'].unsqueeze(-2)).float()
+        # (the ligand rows are read back BEFORE the complex model is queued: boolean-mask indexing of its output would read the count
+        #  back behind the whole forward pass)
+        seg1 = g['segment'].bool() if not g['segment'].is_floating_point() else g['segment'] > 0.5
+        cflag, pflag = ~seg1 & ~g['is_global'], seg1 & ~g['is_global']
+        cidx = torch.nonzero(cflag).squeeze(1)
         Xo, Ho, Z = self.complex_model(Xn, g['H'], batch_id=g['batch'], segment_id=g['segment'], mask=g['mask'],
                                        is_global=g['is_global'], compound_edge_index=g['c2c'], LAS_edge_index=g['LAS'],
                                        batched_complex_coord_LAS=Xl, LAS_mask=None, pair=pair)
-        seg1 = g['segment'].bool() if not g['segment'].is_floating_point() else g['segment'] > 0.5
-        cflag, pflag = ~seg1 & ~g['is_global'], seg1 & ~g['is_global']
-        return Ho, Z, cflag, pflag, Xo[cflag].squeeze(-2)
+        return Ho, Z, cflag, pflag, Xo.index_select(0, cidx).squeeze(-2)
 
     def _dist_heads(self, data, g, Z, coords_n):
         """distmap_mlp on the threaded pair embedding without its global rows (model.py:379-388) + coordinate distances."""
@@ -279,18 +282,20 @@ class FABindPlus(nn.Module):
         wd = ops.mm_dtype()
         y = pengine.ln_rows(zz, m.layernorm.weight.float(), m.layernorm.bias.float(), ops.act_dtype())
         pd = self._pd()
-        if pd > 0.0 and ops.needs_grad(y):
+        if pd > 0.0 and ops.needs_grad(y) and not (pengine.EPI_DROP_GRAD and pengine.ROWDOT_DROP_GRAD):
             t = pengine._drop(ops.linear(y, m.linear1.weight.to(wd).contiguous(), m.linear1.bias, act_epi=K.ACT_RELU), pd)
             part = (t * m.linear2.weight[0].float()).sum(1, keepdim=True)
-        else:
+        else:       # (under autograd with dropout: the row-dot node with the dropout inside the GEMM epilogue, ops._LinearRowdotDrop)
             part = ops.linear_rowdot(y, m.linear1.weight.to(wd).contiguous(), m.linear1.bias,
                                      m.linear2.weight[0].float().contiguous(), act_epi=K.ACT_RELU, p_drop=pd)
         thres = self.args.dis_map_thres
         y_pred = (part.sum(1) + m.linear2.bias).sigmoid() * thres
         cb = data['compound'].batch
-        B = int(cb[-1].item()) + 1
-        pi, ci = g.get('pairs') or self._pair_lists(g['pocket_batch'], cb, torch.bincount(g['pocket_batch'], minlength=B),
-                                                   torch.bincount(cb, minlength=B))
+        pairs_ = g.get('pairs')
+        if pairs_ is None:
+            B = g['B'] if 'B' in g else int(cb[-1].item()) + 1
+            pairs_ = self._pair_lists(g['pocket_batch'], cb, torch.bincount(g['pocket_batch'], minlength=B), torch.bincount(cb, minlength=B))
+        pi, ci = pairs_
         xp = self.normalize_coord(g['pocket_xyz']).float()
         y_by = self.unnormalize_coord((xp[pi] - coords_n[ci]).norm(dim=-1)).clamp(0, thres)
         return y_pred, y_by
