@@ -41,6 +41,13 @@ def _wd():
 # ------------------------------------------------------------------------------------------------
 # layout of a batch of complexes
 # ------------------------------------------------------------------------------------------------
+def _count(idx, n):
+    """Histogram of idx over [0, n) WITHOUT a host round trip: torch.bincount reads the largest index back to size its output, i.e. it
+    waits for everything queued -- `ctx_by_col` is first asked for in the middle of the backward pass, `Layout.ranges` in the middle of a
+    full-model step (tools/probes/sync_sites.py lists every synchronising call of a step)."""
+    return torch.zeros(n, dtype=torch.int64, device=idx.device).index_add_(0, idx.long(), torch.ones_like(idx, dtype=torch.int64))
+
+
 class Layout:
     """Per-batch index arrays.  One host sync (reading per-complex node counts) per construction; `Layout.of` reuses the layout of
     the SAME index tensors (object identity + version counter), so a batch that is run again -- the bench loop, several stages or
@@ -121,7 +128,7 @@ class Layout:
     def ranges(self, idx_first):
         """Per-complex [start,end) offsets of a complex-contiguous edge list given its first-node ids."""
         which = torch.bucketize(idx_first, self.node_off[1:].to(idx_first.dtype), right=True)
-        cnt = torch.bincount(which, minlength=self.B)
+        cnt = _count(which, self.B)
         out = torch.zeros(self.B + 1, dtype=torch.int32, device=idx_first.device)
         out[1:] = torch.cumsum(cnt, 0).to(torch.int32)
         return out
@@ -190,7 +197,7 @@ class Graph:
         """(colptr, perm): ctx edges grouped by their SENDING node (for column-wise reductions in backward)."""
         if self._ctx_bycol is None:
             colsorted, perm = torch.sort(self.col_ctx.long(), stable=True)
-            cnt = torch.bincount(colsorted, minlength=self.N)
+            cnt = _count(colsorted, self.N)
             colptr = torch.zeros(self.N + 1, dtype=torch.int32, device=perm.device)
             colptr[1:] = torch.cumsum(cnt, 0).to(torch.int32)
             self._ctx_bycol = (colptr, perm.to(torch.int32).contiguous())

@@ -274,6 +274,9 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
                      is_global=cx.is_global, batch=cx.batch, c2c=data['complex', 'c2c', 'complex'].edge_index,
                      LAS=data['complex', 'LAS', 'complex'].edge_index, pocket_xyz=data.node_xyz,
                      pocket_batch=data['pocket'].batch, dis_map=data.dis_map, less5=0)
+        if g.get('pairs') is None:        # (the pair lists read a size back: built before the complex model is queued)
+            B = head['B']
+            g['pairs'] = self._pair_lists(g['pocket_batch'], cb, torch.bincount(g['pocket_batch'], minlength=B), torch.bincount(cb, minlength=B))
         Ho, cidx, pidx, coords_n = self._complex_and_heads(data, g)
         y_pred, y_by = self._dist_heads(data, g, Ho, cidx, pidx, coords_n)
         return (self.unnormalize_coord(coords_n), cb, y_pred, y_by, head['logits'] * head['mask'], pocket_cls,

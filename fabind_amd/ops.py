@@ -1180,8 +1180,9 @@ def _rows_hadamard_csr(ia, ib, n, a_sorted=False):
     ia64, ib64 = ia.long(), ib.long()
     pa = torch.arange(P, device=dev) if a_sorted else torch.argsort(ia64, stable=True)     # (a_sorted: ia is non-decreasing)
     pb = torch.argsort(ib64, stable=True)
-    ca = torch.bincount(ia64, minlength=n)
-    cb_ = torch.bincount(ib64, minlength=n)
+    one = torch.ones_like(ia64)
+    ca = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, ia64, one)      # (no torch.bincount: it reads its maximum back)
+    cb_ = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, ib64, one)
     rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     rowptr[1:] = torch.cumsum(ca + cb_, 0)
     starts = rowptr[:-1]

@@ -56,6 +56,8 @@ def upload(arr, dev, dtype):
     """Device copy of a small contiguous numpy array as a tensor of `dtype`, ASYNCHRONOUS (pinned staging ring): a plain
     `torch.from_numpy(a).to(device)` / `torch.tensor(list, device=...)` is a pageable copy, which waits for everything the stream still
     has queued -- index tables built in the middle of a step (group descriptors, tile maps, pair offsets) used to drain the device."""
+    if torch.device(dev).type != "cuda":                    # host tensors (CPU-side tests of index logic): nothing to stage
+        return torch.from_numpy(np.ascontiguousarray(arr).copy()).view(dtype).view(arr.shape)
     flat = np.ascontiguousarray(arr).reshape(-1)
     return _upload(flat, dev).view(dtype).view(arr.shape)
 

@@ -272,6 +272,7 @@ class PairList:
         packed = i64(np.stack([lay.off[:-1], lay.C, lay.pair_off_np[:-1], lay.P * lay.C]))       # one small upload
         self.off, self.C, self.pair_off, npair = packed[0], packed[1], packed[2], packed[3]
         self.n = int(lay.n_pairs)
+        self.n_inner = int(((lay.P - 1) * (lay.C - 1)).sum())        # pairs of non-global nodes (i >= 1, j >= 1): a size the host knows
         self.b = torch.repeat_interleave(torch.arange(lay.B, device=device), npair, output_size=self.n)
         loc = torch.arange(self.n, device=device) - self.pair_off[self.b]
         Cb, ob = self.C[self.b], self.off[self.b]
@@ -386,7 +387,7 @@ class _PairHad1(torch.autograd.Function):
             nb = getattr(lay, "_node_b", None)
             if nb is None:
                 nb = lay._node_b = torch.repeat_interleave(torch.arange(lay.B, dtype=torch.int32, device=T.device),
-                                                           (lay.node_off[1:] - lay.node_off[:-1]).long())
+                                                           (lay.node_off[1:] - lay.node_off[:-1]).long(), output_size=lay.N)
             check(load().fabind_pair_hadamard_bwd_grid(ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(T), T.stride(0), Hh,
                                                        ptr(lay.node_off), ptr(lay.c_cnt), ptr(nb), ptr(lay.desc_p), lay.N, ptr(dT),
                                                        dT.stride(0), stream()), "fabind_pair_hadamard_bwd_grid")

@@ -277,7 +277,12 @@ class FABindPlus(nn.Module):
         """distmap_mlp on the threaded pair embedding without its global rows (model.py:379-388) + coordinate distances."""
         z, pairs, _ = Z
         sel = (pairs.i >= 1) & (pairs.j >= 1)                                   # z[:, 1:, 1:] in (b, i, j) order
-        zz = z[sel].contiguous()
+        # z[sel] without the read-back of boolean indexing (it would wait for the whole forward pass): the number of selected pairs is
+        # known on the host; their positions come from a running count, the unselected ones are parked in one spare slot
+        n_sel = pairs.n_inner
+        slot = torch.where(sel, torch.cumsum(sel, 0) - 1, torch.full_like(pairs.i, n_sel))
+        idx = torch.empty(n_sel + 1, dtype=torch.int64, device=z.device).scatter_(0, slot, torch.arange(sel.shape[0], device=z.device))[:n_sel]
+        zz = z.index_select(0, idx)
         m = self.distmap_mlp
         wd = ops.mm_dtype()
         y = pengine.ln_rows(zz, m.layernorm.weight.float(), m.layernorm.bias.float(), ops.act_dtype())
@@ -323,6 +328,10 @@ class FABindPlus(nn.Module):
             Ho, _, _, _, coords_n = self._complex(g, "none")
             return (self.unnormalize_coord(coords_n), cb, head['logits'] * head['mask'], head['mask'], g['less5'],
                     self._confidence(Ho, g['batch'], head['B']), g['bias'])
+        if g.get('pairs') is None:        # (the pair lists read a size back: built before the complex model is queued)
+            B_ = g['B'] if 'B' in g else int(data['compound'].batch[-1].item()) + 1
+            cb_ = data['compound'].batch
+            g['pairs'] = self._pair_lists(g['pocket_batch'], cb_, torch.bincount(g['pocket_batch'], minlength=B_), torch.bincount(cb_, minlength=B_))
         Ho, Z, cflag, pflag, coords_n = self._complex(g, "ragged")
         y_pred, y_by = self._dist_heads(data, g, Z, coords_n)
         return (self.unnormalize_coord(coords_n), cb, y_pred, y_by, head['logits'] * head['mask'], pocket_cls, head['mask'],
@@ -348,21 +357,43 @@ class FABindPlus(nn.Module):
 
 def best_isomorphism_index(pos_x, pos_y, num_atoms, isomorphisms):
     """Per ligand, the precomputed automorphism (index list) with the smallest mean SmoothL1 to the target
-    (reference utils/permutation_loss.py:4-33).  Small per-ligand index work on the device, no gradient."""
+    (reference utils/permutation_loss.py:4-33).  No gradient.
+    All ligands at once: the automorphism lists are flattened on the host (numpy) and uploaded in ONE asynchronous copy; the per-
+    automorphism losses, the per-ligand minimum (first automorphism reaching it, like argmin) and the chosen index lists are segment
+    operations on the device -- no host round trip.  (The per-ligand loop made two synchronising calls per ligand -- a pageable upload
+    of its lists and int(argmin) -- each behind the whole forward pass: 128 queue drains per training step at B = 64.)"""
+    import numpy as np
     import torch.nn.functional as F
-    idx, pre = [], 0
+    from ...param_pack import upload
+    dev = pos_x.device
+    ns = [int(n) for n in (num_atoms.tolist() if torch.is_tensor(num_atoms) else num_atoms)]
+    src, tgt, iso_id, iso_lig, iso_n, iso_off, atom_lig, atom_p = [], [], [], [], [], [], [], []
+    pre = n_iso = n_flat = 0
+    for b, (n, isos) in enumerate(zip(ns, isomorphisms)):
+        a = np.asarray(isos, dtype=np.int64).reshape(-1, n)
+        K_ = a.shape[0]
+        src.append(a.reshape(-1) + pre)
+        tgt.append(np.tile(np.arange(n, dtype=np.int64) + pre, K_))
+        iso_id.append(np.repeat(np.arange(K_, dtype=np.int64) + n_iso, n))
+        iso_lig.append(np.full(K_, b, dtype=np.int64))
+        iso_n.append(np.full(K_, n, dtype=np.int64))
+        iso_off.append(n_flat + np.arange(K_, dtype=np.int64) * n)
+        atom_lig.append(np.full(n, b, dtype=np.int64))
+        atom_p.append(np.arange(n, dtype=np.int64))
+        pre, n_iso, n_flat = pre + n, n_iso + K_, n_flat + K_ * n
+    parts = [np.concatenate(v) for v in (src, tgt, iso_id, iso_lig, iso_n, iso_off, atom_lig, atom_p)]
+    sizes = [len(v) for v in parts]
+    flat = upload(np.concatenate(parts), dev, torch.int64)
+    src_d, tgt_d, iso_id_d, iso_lig_d, iso_n_d, iso_off_d, atom_lig_d, atom_p_d = torch.split(flat, sizes)
+    B = len(ns)
     with torch.no_grad():
-        for n, isos in zip(num_atoms, isomorphisms):
-            n = int(n)
-            isos = torch.as_tensor(isos, dtype=torch.long, device=pos_x.device).reshape(-1, n)
-            if isos.shape[0] == 1:
-                idx.append(isos[0] + pre)
-            else:
-                x, y = pos_x[pre:pre + n], pos_y[pre:pre + n]
-                losses = F.smooth_l1_loss(x[isos], y[None].expand(isos.shape[0], -1, -1), reduction="none").mean(dim=(1, 2))
-                idx.append(isos[int(torch.argmin(losses))] + pre)
-            pre += n
-    return torch.cat(idx)
+        le = F.smooth_l1_loss(pos_x.detach()[src_d], pos_y.detach()[tgt_d], reduction="none").mean(1)            # [sum K n]
+        iso_loss = torch.zeros(n_iso, dtype=le.dtype, device=dev).index_add_(0, iso_id_d, le) / iso_n_d.to(le.dtype)
+        lig_min = torch.full((B,), float("inf"), dtype=le.dtype, device=dev).scatter_reduce_(0, iso_lig_d, iso_loss, "amin")
+        ar = torch.arange(n_iso, device=dev)
+        cand = torch.where(iso_loss <= lig_min[iso_lig_d], ar, torch.full_like(ar, n_iso))
+        kstar = torch.full((B,), n_iso, dtype=torch.int64, device=dev).scatter_reduce_(0, iso_lig_d, cand, "amin")   # first minimiser
+        return src_d[iso_off_d[kstar[atom_lig_d]] + atom_p_d]
 
 
 def compute_loss(out, data, args=None):
