@@ -89,7 +89,11 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         idx = torch.empty(N, dtype=torch.long, device=seg1.device)
         idx[is_global & ~seg1] = 0
         idx[is_global & seg1] = 1
-        cf, pf = ~seg1 & ~is_global, seg1 & ~is_global
+        # the rows of the ligand atoms / residues as INDEX tensors (two read-backs here, before the model that consumes the result is
+        # queued): the callers gather the model's output rows with index_select -- boolean-mask indexing would read the counts back
+        # again behind the model's forward pass, and once more in its backward
+        cf = torch.nonzero(~seg1 & ~is_global).squeeze(1)
+        pf = torch.nonzero(seg1 & ~is_global).squeeze(1)
         idx[cf] = 2 + torch.arange(c_emb.shape[0], device=idx.device)
         idx[pf] = 2 + c_emb.shape[0] + torch.arange(p_emb.shape[0], device=idx.device)
         return torch.cat([self.glb_c, self.glb_p, c_emb, p_emb], 0).index_select(0, idx), cf, pf
@@ -109,7 +113,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
             LAS_edge_index=data['complex_whole_protein', 'LAS', 'complex_whole_protein'].edge_index,
             batched_complex_coord_LAS=Xl, LAS_mask=None)
         hw = self._lin(self.embedding_enlarge, hw)
-        c_out, p_out = hw[cf], hw[pf]
+        c_out, p_out = hw.index_select(0, cf), hw.index_select(0, pf)
         logits_flat = self.protein_to_pocket(p_out).squeeze(-1)                      # [sum L]
         pb = data['protein_whole'].batch
         B = int(pb[-1].item()) + 1
@@ -174,7 +178,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         cb = data['compound'].batch
         B = head['B']
         pocket_xyz = data.node_xyz_whole[ix['keep']]
-        pemb = head['p_out'][ix['keep']]
+        pemb = head['p_out'].index_select(0, torch.nonzero(ix['keep']).squeeze(1))
         H, _, _ = self._assemble(ix['segment'], ix['is_global'], head['c_out'], pemb)
         with torch.no_grad():
             li = data['compound'].node_coords.float()
@@ -268,7 +272,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
             g = self._stage2(data, head, c2)
         else:
             cx = data['complex']
-            pemb = head['p_out'][data['pocket'].keepNode]
+            pemb = head['p_out'].index_select(0, torch.nonzero(data['pocket'].keepNode).squeeze(1))
             H, _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], pemb)
             g = dict(H=H, X=cx.node_coords, XL=cx.node_coords_LAS, segment=cx.segment, mask=cx.mask,
                      is_global=cx.is_global, batch=cx.batch, c2c=data['complex', 'c2c', 'complex'].edge_index,

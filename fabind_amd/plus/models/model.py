@@ -156,7 +156,7 @@ class FABindPlus(nn.Module):
             LAS_edge_index=data['complex_whole_protein', 'LAS', 'complex_whole_protein'].edge_index,
             batched_complex_coord_LAS=Xl, LAS_mask=None, pair="none")
         hw = self._lin(self.embedding_enlarge, hw)
-        c_out, p_out = hw[cf], hw[pf]
+        c_out, p_out = hw.index_select(0, cf), hw.index_select(0, pf)
         cb, pb = data['compound'].batch, data['protein_whole'].batch
         B = int(pb[-1].item()) + 1
         csum = torch.zeros(B, c_out.shape[1], dtype=torch.float32, device=hw.device).index_add_(0, cb, c_out.float())
@@ -175,7 +175,7 @@ class FABindPlus(nn.Module):
     # ---- radius crop around the predicted centre, pocket-centred frame (model.py:212-330) --------------------------
     def _stage2(self, data, head, center, shift_coords):
         g = self._stage2_nograd(data, head, center, shift_coords)
-        g['H'], _, _ = self._assemble(g['segment'], g['is_global'], head['c_out'], head['p_out'][g.pop('keep')])
+        g['H'], _, _ = self._assemble(g['segment'], g['is_global'], head['c_out'], head['p_out'].index_select(0, torch.nonzero(g.pop('keep')).squeeze(1)))
         return g
 
     @torch.no_grad()
@@ -239,7 +239,7 @@ class FABindPlus(nn.Module):
         with torch.no_grad():
             g = self._stage1_nograd(data, head)
         cx = data['complex']
-        g['H'], _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], head['p_out'][data['pocket'].keepNode])
+        g['H'], _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], head['p_out'].index_select(0, torch.nonzero(data['pocket'].keepNode).squeeze(1)))
         return g
 
     def _stage1_nograd(self, data, head):
