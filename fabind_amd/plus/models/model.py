@@ -109,9 +109,12 @@ class FABindPlus(nn.Module):
         import random
         prob = head['logits'].sigmoid()
         sel = prob > 0.5
-        for i in (sel.sum(1) < 50).nonzero().flatten().tolist():                # rare: too few predicted pocket residues
-            sel[i] = False
-            sel[i, torch.argsort(prob[i])[-50:]] = True
+        # too few predicted pocket residues (rare with trained weights, every complex with random ones): the 50 most probable instead
+        # (model.py:152-154) -- for all such complexes at once; a per-complex loop made a synchronising indexed assignment per complex
+        # and pose batch (1,280 queue drains per sampling step of the bench)
+        few = sel.sum(1) < 50
+        top = torch.argsort(prob, dim=1)[:, -50:]
+        sel = torch.where(few[:, None], torch.zeros_like(sel).scatter_(1, top, True), sel)
         B, dev = center.shape[0], center.device
         n_sel = sel.sum(1)
         S = int(n_sel.max())
