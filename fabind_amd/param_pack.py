@@ -23,7 +23,7 @@ _SEG = np.dtype([("src", np.uint64), ("dst", np.uint64), ("src_sr", np.int64), (
                  ("vec4", np.int32), ("pad", np.int32)])
 _ESZ = {torch.float32: 4, torch.bfloat16: 2}
 _RING, _RING_POS, _RING_EVT = [], [0], []
-_RING_SLOTS = 16
+_RING_SLOTS = 64          # (several small index tables per step share the ring with the two pack tables; a slot is rewritten only after its copy ran)
 
 
 def _upload(table, dev):
