@@ -72,8 +72,11 @@ class Layout:
         dev = batch_id.device
         B = int(batch_id[-1].item()) + 1
         seg = (segment_id > 0.5) if segment_id.is_floating_point() else segment_id.bool()
-        cnt = torch.stack([torch.bincount(batch_id, minlength=B),
-                           torch.bincount(batch_id, weights=seg.to(torch.float64), minlength=B).long()]).cpu().numpy()
+        bid = batch_id.long()                               # (two read-backs in all: B above, the counts here -- no torch.bincount)
+        cnt = torch.zeros((2, B), dtype=torch.int64, device=dev)
+        cnt[0].index_add_(0, bid, torch.ones_like(bid))
+        cnt[1].index_add_(0, bid, seg.to(torch.int64))
+        cnt = cnt.cpu().numpy()
         n, P = cnt[0].astype(np.int64), cnt[1].astype(np.int64)
         C = n - P
         off = np.concatenate([[0], np.cumsum(n)])
