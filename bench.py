@@ -288,11 +288,13 @@ def main():
         # there, so their host round trips do not drain the compute stream at the start of the step.  Every step still does all of
         # that work, inside the timed region.
         from fabind_amd import engine as _engine
-        # Measured on one box (gpurun_out/r3p): forward-only 2,587 -> 2,770 complexes/s; fwd+bwd unchanged within the run-to-run spread
-        # (604.8 / 615.0 / 627.7 against 625.3 / 613.1 / 621.7 -- its step boundary is bound by host work of the backward's tail, not
-        # by the drain); pocket-sized shape 2,071 -> 1,939 (host-bound: the stream switches cost more than the drain).  So the
-        # default prefetches in forward-only mode at protein sizes >= 500 and nowhere else; FABIND_BENCH_PREFETCH=1 / 0 forces it.
-        want = (mode == "fwd" and a.n_prot >= 500) if PREFETCH is None else PREFETCH
+        # Measured same-box (profiles/r03_ab_same_box.txt).  While the step still had read-backs in its middle (pair-bias descriptors,
+        # bincounts, boolean-mask indexing) the prefetch only paid forward-only (2,587 -> 2,770 complexes/s); with those gone the host
+        # runs ahead of the device and the step-start read-backs are what is left: fwd+bwd 688.1 / 703.5 / 692.2 -> 715.5 / 711.2 /
+        # 718.1; at the pocket-sized shape the step is host-bound and the boxes' hosts are shared (load average 25 on one): 2,720 /
+        # 2,698 -> 3,019 / 3,137 on one box, 2,726 / 2,878 / 2,740 / 2,964 against 2,222 / 3,083 / 2,914 / 2,741 on another -- no call.
+        # Default: on for the stack modes at protein sizes >= 500; FABIND_BENCH_PREFETCH=1 / 0 forces it.
+        want = (mode in ("fwd", "fwdbwd") and a.n_prot >= 500) if PREFETCH is None else PREFETCH
         feeder = torch.cuda.Stream(dev) if (want and not LEGACY_BATCH and not REUSE_BATCH) else None
         prefetching[0] = feeder is not None
         pending = []
