@@ -505,17 +505,17 @@ def main():
                  "the 1e-4 A parity gate at n_iter 1, 2 and 8 (tests/test_gpu_headline.py)")
         sub("fp32", "fwdbwd", a.n_iter, precision="fp32",
             note="the headline step in fp32 mode (exact-fp32 MFMA, unfused edge pipeline): the exact reference arithmetic")
-        sub("train_mode", "fwdbwd", a.n_iter, train_mode=True,
+        sub("train_mode", "fwdbwd", a.n_iter, train_mode=True, steps=5, warmup=2,
             note="the headline step with model.train(): dropout p=0.1 at the reference's six sites")
         sub("n_iter8", "fwdbwd", 8, note="production refinement loop: 8 stack passes, gradient on the last one")
-        sub("fwd", "fwd", a.n_iter, note="forward only, one stack pass")
-        sub("model_fwdbwd", "model", a.n_iter,
+        sub("fwd", "fwd", a.n_iter, steps=10, warmup=3, note="forward only, one stack pass")
+        sub("model_fwdbwd", "model", a.n_iter, steps=6, warmup=2,
             note="full IaBNet (pocket model on 1500 residues -> pocket crop -> 4-layer complex model -> heads) with the reference's "
                  "six-term loss (pocket-cls + pocket-centre + contact x2 + distill + coord), eval mode")
         sub("model_fwdbwd_train_n_iter8", "model", 8, train_mode=True,
             note="the same with model.train() (dropout, Gumbel noise) and n_iter=8: the reference's training configuration")
         n_it8 = 8
-        sub("plus_train", "plus_train", a.n_iter,
+        sub("plus_train", "plus_train", a.n_iter, steps=4, warmup=2,
             note="one FABind+ training step (5-layer LN-MLP stack, train mode, 7-term loss with the permutation-invariant term)")
         sub("plus_sampling", "plus_sampling", n_it8, steps=2,
             note="FABind+ sampling-mode inference (BASELINE configs[4]): n_iter 8, dropout sampling, DBSCAN centre, ranking head, "

@@ -7,7 +7,7 @@ import torch
 import bench
 mode = sys.argv[1] if len(sys.argv) > 1 else "stack"
 sys.argv = ["bench.py", "--mode", {"stack": "fwdbwd", "fwd": "fwd"}.get(mode, mode), "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
-            "--no-extras"] + (["--n-prot", sys.argv[2]] if len(sys.argv) > 2 else [])
+            "--no-extras"] + (["--n-prot", sys.argv[2]] if len(sys.argv) > 2 else []) + (["--precision", sys.argv[3]] if len(sys.argv) > 3 else [])
 sites = collections.Counter()
 orig = warnings.showwarning
 
