@@ -107,6 +107,17 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         h0 = self._lin(self.embedding_shrink, h0)
         Xw = self.normalize_coord(w.node_coords.unsqueeze(-2)).float()
         Xl = self.normalize_coord(w.node_coords_LAS.unsqueeze(-2)).float()
+        # the padded [B, Lmax] bookkeeping of the classifier reads two sizes back: done BEFORE the pocket model is queued, so that
+        # nothing waits behind its forward pass
+        pb = data['protein_whole'].batch
+        B = int(pb[-1].item()) + 1
+        cnt = torch.bincount(pb, minlength=B)
+        loc = torch.arange(pb.shape[0], device=pb.device) - _offsets(cnt)[pb]
+        Lmax = int(cnt.max().item())
+        mask = torch.zeros(B, Lmax, dtype=torch.bool, device=pb.device)
+        mask[pb, loc] = True
+        xyz = torch.zeros(B, Lmax, 3, dtype=data.node_xyz_whole.dtype, device=pb.device)
+        xyz[pb, loc] = data.node_xyz_whole
         _, hw = self.pocket_pred_model(
             Xw, h0, batch_id=w.batch, segment_id=w.segment, mask=w.mask, is_global=w.is_global,
             compound_edge_index=data['complex_whole_protein', 'c2c', 'complex_whole_protein'].edge_index,
@@ -115,16 +126,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         hw = self._lin(self.embedding_enlarge, hw)
         c_out, p_out = hw.index_select(0, cf), hw.index_select(0, pf)
         logits_flat = self.protein_to_pocket(p_out).squeeze(-1)                      # [sum L]
-        pb = data['protein_whole'].batch
-        B = int(pb[-1].item()) + 1
-        cnt = torch.bincount(pb, minlength=B)
-        loc = torch.arange(pb.shape[0], device=pb.device) - _offsets(cnt)[pb]
-        Lmax = int(cnt.max().item())
-        mask = torch.zeros(B, Lmax, dtype=torch.bool, device=pb.device)
-        mask[pb, loc] = True
         logits = torch.zeros(B, Lmax, dtype=logits_flat.dtype, device=pb.device).index_put((pb, loc), logits_flat)
-        xyz = torch.zeros(B, Lmax, 3, dtype=data.node_xyz_whole.dtype, device=pb.device)
-        xyz[pb, loc] = data.node_xyz_whole
         return dict(B=B, c_out=c_out, p_out=p_out, logits=logits, mask=mask, xyz=xyz, pb=pb, loc=loc, cnt=cnt,
                     logits_flat=logits_flat)
 
@@ -255,6 +257,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
     # ---- reference API ------------------------------------------------------------------------
     def forward(self, data, stage=1, train=False):
         cb = data['compound'].batch
+        keep_idx = torch.nonzero(data['pocket'].keepNode).squeeze(1) if (stage == 1 or self.pocket_pred_model.training) else None
         head = self._pocket_head(data)
         training = self.pocket_pred_model.training
         center = self._soft_center(head['logits'], head['mask'], head['xyz'], noise=training)
@@ -272,7 +275,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
             g = self._stage2(data, head, c2)
         else:
             cx = data['complex']
-            pemb = head['p_out'].index_select(0, torch.nonzero(data['pocket'].keepNode).squeeze(1))
+            pemb = head['p_out'].index_select(0, keep_idx if keep_idx is not None else torch.nonzero(data['pocket'].keepNode).squeeze(1))
             H, _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], pemb)
             g = dict(H=H, X=cx.node_coords, XL=cx.node_coords_LAS, segment=cx.segment, mask=cx.mask,
                      is_global=cx.is_global, batch=cx.batch, c2c=data['complex', 'c2c', 'complex'].edge_index,

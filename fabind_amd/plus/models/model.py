@@ -153,6 +153,16 @@ class FABindPlus(nn.Module):
         h0 = self._lin(self.embedding_shrink, h0)
         Xw = self.normalize_coord(w.node_coords.unsqueeze(-2)).float()
         Xl = self.normalize_coord(w.node_coords_LAS.unsqueeze(-2)).float()
+        # (the padded [B, Lmax] bookkeeping reads two sizes back: before the pocket model is queued)
+        cb, pb = data['compound'].batch, data['protein_whole'].batch
+        B = int(pb[-1].item()) + 1
+        cnt = torch.bincount(pb, minlength=B)
+        loc = torch.arange(pb.shape[0], device=pb.device) - _offsets(cnt)[pb]
+        Lmax = int(cnt.max().item())
+        mask = torch.zeros(B, Lmax, dtype=torch.bool, device=pb.device)
+        mask[pb, loc] = True
+        xyz = torch.zeros(B, Lmax, 3, dtype=data.node_xyz_whole.dtype, device=pb.device)
+        xyz[pb, loc] = data.node_xyz_whole
         _, hw, _ = self.pocket_pred_model(
             Xw, h0, batch_id=w.batch, segment_id=w.segment, mask=w.mask, is_global=w.is_global,
             compound_edge_index=data['complex_whole_protein', 'c2c', 'complex_whole_protein'].edge_index,
@@ -160,19 +170,10 @@ class FABindPlus(nn.Module):
             batched_complex_coord_LAS=Xl, LAS_mask=None, pair="none")
         hw = self._lin(self.embedding_enlarge, hw)
         c_out, p_out = hw.index_select(0, cf), hw.index_select(0, pf)
-        cb, pb = data['compound'].batch, data['protein_whole'].batch
-        B = int(pb[-1].item()) + 1
         csum = torch.zeros(B, c_out.shape[1], dtype=torch.float32, device=hw.device).index_add_(0, cb, c_out.float())
         radius = pengine.mlp_module(self.pocket_radius_head, csum, pdrop=self._pd()).relu()                      # [B,1]
         logits_flat = pengine.mlp_module(self.protein_to_pocket, p_out, pdrop=self._pd()).squeeze(-1)            # [sum L]
-        cnt = torch.bincount(pb, minlength=B)
-        loc = torch.arange(pb.shape[0], device=pb.device) - _offsets(cnt)[pb]
-        Lmax = int(cnt.max().item())
-        mask = torch.zeros(B, Lmax, dtype=torch.bool, device=pb.device)
-        mask[pb, loc] = True
         logits = torch.zeros(B, Lmax, dtype=logits_flat.dtype, device=pb.device).index_put((pb, loc), logits_flat)
-        xyz = torch.zeros(B, Lmax, 3, dtype=data.node_xyz_whole.dtype, device=pb.device)
-        xyz[pb, loc] = data.node_xyz_whole
         return dict(B=B, c_out=c_out, p_out=p_out, logits=logits, mask=mask, xyz=xyz, pb=pb, loc=loc, cnt=cnt, radius=radius)
 
     # ---- radius crop around the predicted centre, pocket-centred frame (model.py:212-330) --------------------------
