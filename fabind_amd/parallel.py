@@ -7,23 +7,50 @@ Replaces accelerate -> torch DDP (reference main_fabind.py:194-195, 289-296, 419
   * 33 parameter tensors never receive a gradient (att_i.inter_layer.*, pocket model out_layer.coord_mlp.*;
     the reference needs find_unused_parameters=True).  Here every rank packs the SAME flat buffer over
     all trainable parameters and fills missing gradients with zeros, so no graph inspection is needed.
-  * `GradReducer` overlaps the collective with backward (buckets are issued as they fill); `allreduce_gradients` is the
+  * `GradReducer` overlaps the collective with backward (buckets are issued as they fill).  The first step is the discovery step, as
+    in DDP: it records the order in which gradients arrive and which parameters never get one, then rebuilds the buckets in arrival
+    order with the never-used tensors in a trailing bucket that no bucket waits for -- from the second step on every bucket but the
+    last leaves while backward is still running (the first step reduces after backward).  `allreduce_gradients` is the
     non-overlapped form of the same arithmetic.
   * the NaN-skip of a step (main_fabind.py:394-396) is agreed on collectively, so no rank waits in a collective alone.
   * xGMI is point-to-point (7 links x ~153 GB/s): the 145 MB fp32 gradient is sent as a few large buckets
     (default 64 MB) so that RCCL can use reduce-scatter + all-gather across all links; the collective is
-    issued on RCCL's own stream and overlaps with the packing of the next bucket.
+    issued on RCCL's own stream and overlaps with the packing of the next bucket.  `bucket_dtype=torch.bfloat16` halves the
+    bytes on the links (73 MB; the sum over ranks is then rounded to bf16 -- SURVEY 8(e) allows it, fp32 is the default).
+  * `shard_complexes(..., weights=P*C)` deals the complexes of a global batch to the ranks length-bucketed: equal counts (+-1, what the
+    reference's DistributedSampler gives, main_fabind.py:289-296) and balanced pair work, so that no rank waits for the one that drew
+    the large proteins.
   * gradient clipping (max_norm 1.0) happens after the all-reduce on the full gradient (main_fabind.py:420-423).
 """
 import torch
 import torch.distributed as dist
 
 
-def shard_complexes(n_complexes, rank, world):
-    """Contiguous, balanced shard [lo, hi) of a global batch of complexes for `rank`."""
+def shard_complexes(n_complexes, rank, world, weights=None):
+    """Shard of a global batch of complexes for `rank`.
+    weights=None: the contiguous, balanced range [lo, hi).
+    weights = per-complex work (P*C: the pair path is 62 % of the flops): -> sorted int64 index array of this rank's
+    complexes -- every rank gets n // world complexes (+1 for the first n % world ranks, like the contiguous form) and the sums of
+    weights are balanced greedily: complexes in decreasing weight, each to the rank with the least work among those that still have
+    room (longest-processing-time rule with a count cap).  Deterministic (stable sort, ties to the lower rank), so every rank
+    computes the same deal without communicating."""
     base, rem = divmod(n_complexes, world)
-    lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    if weights is None:
+        lo = rank * base + min(rank, rem)
+        return lo, lo + base + (1 if rank < rem else 0)
+    import numpy as np
+    w = np.asarray(weights, dtype=np.float64).reshape(-1)
+    assert w.shape[0] == n_complexes, "shard_complexes: one weight per complex"
+    room = [base + (1 if r < rem else 0) for r in range(world)]
+    load = [0.0] * world
+    mine = []
+    for i in np.argsort(-w, kind="stable"):
+        r = min((r_ for r_ in range(world) if room[r_] > 0), key=lambda r_: (load[r_], r_))
+        room[r] -= 1
+        load[r] += float(w[i])
+        if r == rank:
+            mine.append(int(i))
+    return np.sort(np.asarray(mine, dtype=np.int64))
 
 
 def _buckets(params, bucket_bytes):
@@ -39,8 +66,8 @@ def _buckets(params, bucket_bytes):
         yield cur
 
 
-def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, group=None):
-    """Average .grad of `params` over all ranks (flat fp32 buckets; missing grads count as zeros)."""
+def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, group=None, bucket_dtype=torch.float32):
+    """Average .grad of `params` over all ranks (flat buckets of bucket_dtype, fp32 by default; missing grads count as zeros)."""
     if world is None:
         world = dist.get_world_size(group) if dist.is_initialized() else 1
     params = [p for p in params if p.requires_grad]
@@ -51,7 +78,7 @@ def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, group=None):
         return
     pending = []
     for bucket in _buckets(params, bucket_bytes):
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(bucket_dtype) for p in bucket])
         dev = flat.device
         if flat.is_cuda and dist.get_backend(group) == "gloo":      # CPU-only collective backend (tests): stage through the host
             flat = flat.cpu()
@@ -59,7 +86,7 @@ def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, group=None):
         pending.append((bucket, flat, work, dev))
     for bucket, flat, work, dev in pending:
         work.wait()
-        flat = flat.to(dev)
+        flat = flat.to(dev).float()
         flat.div_(world)
         off = 0
         for p in bucket:
@@ -84,23 +111,44 @@ def clip_grad_norm_(params, max_norm=1.0):
 
 class GradReducer:
     """Gradient all-reduce overlapped with backward (what DDP's reducer does for the reference, main_fabind.py:194-195,
-    419-423), sized for xGMI: the trainable parameters are cut into a few LARGE flat fp32 buckets (default 64 MB -- ring
-    collectives over 7 point-to-point links are per-link bound, so few big messages beat many small ones) in REVERSE
-    registration order, which is roughly the order backward produces them.  A post-accumulate hook on every parameter copies
-    its gradient into the bucket; the bucket's all-reduce is issued asynchronously (RCCL runs it on its own stream) the
-    moment its last gradient has arrived, while backward continues with the earlier layers.  `finish()` issues the buckets
-    that never filled (parameters without a gradient count as zeros on every rank, replacing find_unused_parameters=True),
-    waits, divides by the world size and writes the averaged gradients back.
+    419-423), sized for xGMI: the trainable parameters are cut into a few LARGE flat buckets (default 64 MB of fp32 -- ring
+    collectives over 7 point-to-point links are per-link bound, so few big messages beat many small ones).  A post-accumulate
+    hook on every parameter copies its gradient into its bucket; a bucket's all-reduce is issued asynchronously (RCCL runs it
+    on its own stream) the moment its last EXPECTED gradient has arrived, while backward continues with the earlier layers.
+    `finish()` issues what is left, waits, divides by the world size and writes the averaged gradients back.
 
-    Every rank builds the same buckets from the same parameter list, and every bucket is reduced exactly once per step in
-    bucket order or completion order -- both identical across ranks only if completion order is; to be safe against
-    rank-dependent autograd order the collective for bucket k is issued only after buckets 0..k-1 have been issued."""
+    Which gradients to expect is learned, as in DDP (`find_unused_parameters=True` + the bucket rebuild after the first
+    iteration): the FIRST step runs on provisional buckets in reverse registration order and cannot overlap on the real model --
+    33 of its tensors never receive a gradient (`att_i.inter_layer.*`, the pocket model's `out_layer.coord_mlp.*`)
+    and they sit in the leading buckets, whose count therefore never reaches zero before `finish()`.  At the end of that step
+    rank 0's arrival order is broadcast and every rank rebuilds the same buckets: parameters in the order their gradients
+    arrived, then the never-used ones in trailing bucket(s) that are zero-filled once and that no bucket waits for.  From the
+    second step on a bucket leaves as soon as its used parameters have reported.  A parameter from the never-used set that does
+    get a gradient later (another stage, another loss) is copied like any other; if its bucket has already left it is reduced
+    again in `finish()`, and the parameter is expected from then on.
 
-    def __init__(self, params, world=None, bucket_bytes=64 << 20, group=None):
+    Every rank issues the same collectives in the same order: bucket k is issued only after buckets 0..k-1, and the set of
+    buckets reduced a second time (gradient accumulation over several backward() calls, late parameters) is agreed on by one
+    tiny MAX all-reduce in `finish()`.
+    bucket_dtype: torch.float32 (default) or torch.bfloat16 (half the bytes on the links; the sum is rounded to bf16)."""
+
+    def __init__(self, params, world=None, bucket_bytes=64 << 20, group=None, bucket_dtype=torch.float32, rebuild=True):
         self.group = group
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.params = [p for p in params if p.requires_grad]
-        self.buckets = [list(b) for b in _buckets(list(reversed(self.params)), bucket_bytes)]
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+        self.bucket_bytes, self.bucket_dtype = bucket_bytes, bucket_dtype
+        self.rebuild = bool(rebuild)
+        self.steps_done = 0
+        self.unused = set()            # ids of parameters no bucket waits for (never fired in the discovery step)
+        self.issued_early = 0          # buckets of the LAST finished step whose collective left before finish() (diagnostic, tests)
+        self._layout(list(reversed(self.params)))
+        self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params] if self.world > 1 else []
+        self._reset()
+
+    def _layout(self, ordered):
+        """Cut `ordered` (every trainable parameter once) into buckets; parameters in self.unused are not waited for."""
+        self.buckets = [list(b) for b in _buckets(ordered, self.bucket_bytes)]
         self.slot = {}
         for bi, b in enumerate(self.buckets):
             off = 0
@@ -109,18 +157,15 @@ class GradReducer:
                 off += p.numel()
         self.sizes = [sum(p.numel() for p in b) for b in self.buckets]
         self.flat = [None] * len(self.buckets)
-        self.pending = [0] * len(self.buckets)
-        self.work = [None] * len(self.buckets)
-        self.next_issue = 0
-        self.handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params] if self.world > 1 else []
-        self._reset()
 
     def _reset(self):
-        self.pending = [len(b) for b in self.buckets]
+        self.pending = [sum(1 for p in b if id(p) not in self.unused) for b in self.buckets]
         self.work = [None] * len(self.buckets)
         self.seen = set()
-        self.stale = set()         # buckets holding a parameter whose .grad changed after its copy (gradient accumulation)
+        self.order = []            # parameter indices in arrival order (this step)
+        self.stale = set()         # buckets holding a parameter whose .grad changed after the bucket's collective left
         self.next_issue = 0
+        self._early = 0
 
     def abort(self):
         """Abandon the current step (backward raised, or the step is skipped after some hooks fired): wait for the collectives
@@ -129,12 +174,15 @@ class GradReducer:
         for w in self.work:
             if w is not None:
                 w[0].wait()
+        for bi, b in enumerate(self.buckets):                  # slots of never-used parameters must read zero next step
+            if self.flat[bi] is not None and any(id(p) in self.unused for p in b):
+                self.flat[bi].zero_()
         self._reset()
 
     def _buffer(self, bi):
         if self.flat[bi] is None:
             dev = self.buckets[bi][0].device
-            self.flat[bi] = torch.zeros(self.sizes[bi], dtype=torch.float32, device=dev)
+            self.flat[bi] = torch.zeros(self.sizes[bi], dtype=self.bucket_dtype, device=dev)
         return self.flat[bi]
 
     def _hook(self, p):
@@ -143,28 +191,47 @@ class GradReducer:
             # A second accumulation into the same parameter before finish() (two backward() calls per step = gradient
             # accumulation, or a parameter reached twice by one backward): .grad now holds the SUM, the bucket the first
             # micro-batch only.  If the bucket is still here it is refreshed in place; if its collective has already left,
-            # it is marked stale and finish() reduces it again from .grad (the first result is discarded).  Every rank
-            # runs the same number of backward() calls, so every rank marks the same buckets.
+            # it is marked stale and finish() reduces it again from .grad (the first result is discarded).
             if self.work[bi] is None:
                 self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
             else:
                 self.stale.add(bi)
             return
         self.seen.add(id(p))
+        self.order.append(self.index[id(p)])
+        if id(p) in self.unused:
+            # a tensor the discovery step never saw a gradient for: no bucket counted on it.  Expected from the next step on.
+            self.unused.discard(id(p))
+            if self.work[bi] is None:
+                self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            else:
+                self.stale.add(bi)
+            return
         self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
         self.pending[bi] -= 1
-        self._issue_ready()
+        self._issue_ready(True)
 
-    def _issue_ready(self):
+    def _issue_ready(self, early=False):
         while self.next_issue < len(self.buckets) and self.pending[self.next_issue] == 0:
             self._issue(self.next_issue)
             self.next_issue += 1
+            self._early += 1 if early else 0
 
     def _issue(self, bi):
         flat = self._buffer(bi)
         if flat.is_cuda and dist.get_backend(self.group) == "gloo":      # CPU-only collective backend (tests): host staging
             flat = flat.cpu()
+        if flat.dtype == torch.bfloat16 and dist.get_backend(self.group) == "gloo":
+            flat = flat.float()                                          # (gloo has no bf16 sum; the operands are bf16-rounded all the same)
         self.work[bi] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat)
+
+    def _agree(self, flags):
+        """Element-wise OR over ranks of a small list of 0/1 flags (one tiny collective; every rank calls it once per finish())."""
+        t = torch.tensor(flags, dtype=torch.int32)
+        if dist.get_backend(self.group) != "gloo":
+            t = t.to(self.params[0].device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return [bool(v) for v in t.tolist()]
 
     def finish(self):
         """Call after the step's LAST backward: completes the all-reduce and leaves the rank-averaged gradient in every .grad.
@@ -176,21 +243,24 @@ class GradReducer:
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
             return
-        for bi, b in enumerate(self.buckets):                  # parameters whose hook never fired: zeros
+        for bi, b in enumerate(self.buckets):                  # expected parameters whose hook never fired this step: zeros
             if self.work[bi] is None and self.pending[bi] > 0:
                 buf = self._buffer(bi)
                 for p in b:
-                    if id(p) not in self.seen:
+                    if id(p) not in self.seen and id(p) not in self.unused:
                         _, off = self.slot[id(p)]
                         buf[off:off + p.numel()].zero_()
                 self.pending[bi] = 0
+        self.issued_early = self._early
         self._issue_ready()
-        for bi in sorted(self.stale):                          # same order on every rank
+        # the buckets to reduce again must be the same on every rank (a late parameter may have fired on one rank only)
+        stale = self._agree([1 if bi in self.stale else 0 for bi in range(len(self.buckets))])
+        for bi in [i for i, v in enumerate(stale) if v]:       # same order on every rank
             self.work[bi][0].wait()                            # (its result is superseded)
             buf = self._buffer(bi)
             for p in self.buckets[bi]:
                 _, off = self.slot[id(p)]
-                if p.grad is None:
+                if p.grad is None or (id(p) not in self.seen):
                     buf[off:off + p.numel()].zero_()
                 else:
                     buf[off:off + p.numel()].copy_(p.grad.reshape(-1))
@@ -198,18 +268,39 @@ class GradReducer:
         for bi, b in enumerate(self.buckets):
             work, flat = self.work[bi]
             work.wait()
-            flat = flat.to(self.flat[bi].device)
-            flat.div_(self.world)
+            own = self.flat[bi]
+            if flat is not own:                                # staged through the host and / or widened (gloo)
+                own.copy_(flat.to(own.device))
+            res = own if own.dtype == torch.float32 else own.float()
+            res.div_(self.world)                               # (slots of never-used parameters hold 0 / world = 0: nothing to restore)
             off = 0
             for p in b:
                 n = p.numel()
-                g = flat[off:off + n].view_as(p).to(p.dtype)
+                g = res[off:off + n].view_as(p).to(p.dtype)
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
                     p.grad.copy_(g)
                 off += n
+        order = self.order
+        self.steps_done += 1
+        if self.rebuild and self.steps_done == 1:
+            self._rebuild(order)
         self._reset()
+
+    def _rebuild(self, order):
+        """End of the discovery step: rank 0's arrival order becomes the bucket order on every rank (never-used tensors last)."""
+        n = len(self.params)
+        t = torch.full((n,), -1, dtype=torch.int64)
+        t[:len(order)] = torch.tensor(order, dtype=torch.int64) if order else t[:0]
+        if dist.get_backend(self.group) != "gloo":
+            t = t.to(self.params[0].device)
+        dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        fired = [int(v) for v in t.tolist() if v >= 0]
+        fired_set = set(fired)
+        rest = [i for i in range(n - 1, -1, -1) if i not in fired_set]          # reverse registration order, like the provisional layout
+        self.unused = {id(self.params[i]) for i in rest}
+        self._layout([self.params[i] for i in fired] + [self.params[i] for i in rest])
 
     def close(self):
         for h in self.handles:

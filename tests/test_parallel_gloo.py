@@ -230,3 +230,117 @@ def test_reducer_with_gradient_accumulation_and_abort():
             assert any(v != 0.0 for v in overl[-2])          # the late parameter did receive its (averaged) gradient
             assert all(v == 0.0 for v in overl[-1])
     assert res[0][1] == res[1][1]
+
+
+NEVER_USED = ("inter_layer.", "pocket_pred_model.gnn.out_layer.coord_mlp.")   # 33 tensors without a gradient
+
+
+def _production_params():
+    """The production IaBNet's trainable tensors (394 state keys, 36,270,615 parameters) with their names, and which of them the
+    reference's training step never reaches (30 x `...att_i.inter_layer.*` + 3 x the pocket model's `out_layer.coord_mlp.*`)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_host_cpu import _Logger, _args
+    from fabind_amd.models import get_model
+    a = _args(512, 4, 8)
+    a.pocket_pred_hidden_size = 128
+    m = get_model(a, _Logger(), None)
+    named = [(n, p) for n, p in m.named_parameters() if p.requires_grad]
+    dead = [n for n, _ in named if ".gnn.att_" in n and ".inter_layer." in n and "cross_attn_module" not in n
+            or n.startswith("pocket_pred_model.gnn.out_layer.coord_mlp.")]
+    return m, named, set(dead)
+
+
+def _production_worker(rank, world, port, q, bucket_dtype):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    torch.set_num_threads(2)
+    m, named, dead = _production_params()
+    params = [p for _, p in named]
+    used = [p for n, p in named if n not in dead]
+    dt = {"fp32": torch.float32, "bf16": torch.bfloat16}[bucket_dtype]
+    red = parallel.GradReducer(params, world, bucket_dtype=dt)                 # default 64 MB buckets: 3 of them at 145 MB
+    info = dict(n_params=len(params), n_dead=len(dead), n_buckets=len(red.buckets), early=[], unused_after=[], max_err=[])
+    for step in range(3):
+        for p in params:
+            p.grad = None
+        # backward produces the gradients roughly in reverse registration order: one backward() per tensor makes that order exact
+        # (every hook fires once per step; the dead tensors get none, like in the real step)
+        for i, p in enumerate(reversed(used)):
+            (p * float((rank + 1) * (1 + i % 3))).sum().backward()
+        local = [None if p.grad is None else p.grad.clone() for p in params]
+        red.finish()
+        info["early"].append(red.issued_early)
+        info["unused_after"].append(len(red.unused))
+        got = [p.grad.clone() for p in params]
+        for p, g in zip(params, local):
+            p.grad = g
+        parallel.allreduce_gradients(params, world, bucket_dtype=dt)
+        info["max_err"].append(max(float((a_ - p.grad).abs().max()) for a_, p in zip(got, params)))
+        if step == 2:
+            info["dead_zero"] = all(float(p.grad.abs().max()) == 0.0 for n, p in named if n in dead)
+            info["sample"] = [float(got[0].reshape(-1)[0]), float(got[-1].reshape(-1)[0])]
+    info["n_buckets_rebuilt"] = len(red.buckets)
+    info["last_bucket_is_dead_tail"] = all(id(p) in red.unused for p in red.buckets[-1][-len(dead):])
+    red.close()
+    q.put((rank, info))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_production(bucket_dtype):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_production_worker, args=(r, world, port, q, bucket_dtype)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return res
+
+
+def test_reducer_overlaps_on_the_production_parameter_list():
+    """on the real model's 394 tensors the 33 never-used ones sat in the leading buckets, so no bucket left
+    before finish().  After the discovery step the buckets follow the arrival order with the never-used tensors last: at least 2 of
+    the 3 buckets must be on the wire before finish(), and the result must equal the plain all-reduce on both ranks."""
+    res = _run_production("fp32")
+    for rank, info in res:
+        assert info["n_params"] == 394 and info["n_dead"] == 33 and info["n_buckets"] == 3 and info["n_buckets_rebuilt"] == 3
+        assert info["early"][0] == 0                      # the discovery step cannot overlap (what round 3 shipped for every step)
+        assert info["early"][1] >= 2 and info["early"][2] >= 2
+        assert info["unused_after"] == [33, 33, 33]
+        assert info["last_bucket_is_dead_tail"] and info["dead_zero"]
+        assert max(info["max_err"]) == 0.0                # same arithmetic as the non-overlapped form: bit-identical
+    assert res[0][1]["sample"] == res[1][1]["sample"]
+
+
+def test_reducer_bf16_buckets_on_the_production_parameter_list():
+    res = _run_production("bf16")
+    for rank, info in res:
+        assert info["early"][1] >= 2
+        assert max(info["max_err"]) == 0.0                # both forms round the per-rank gradients to bf16 before the sum
+    assert res[0][1]["sample"] == res[1][1]["sample"]
+
+
+def test_weighted_sharding_balances_pair_work_with_equal_counts():
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for n, world in ((16, 2), (64, 8), (129, 8), (7, 4)):
+        P, C = rng.integers(60, 600, n), rng.integers(10, 80, n)            # PDBbind-like spread: P*C varies > 10x
+        w = P * C
+        parts = [parallel.shard_complexes(n, r, world, weights=w) for r in range(world)]
+        allidx = np.concatenate(parts)
+        assert sorted(allidx.tolist()) == list(range(n))                      # a partition
+        sizes = [len(p_) for p_ in parts]
+        assert sizes == [hi - lo for lo, hi in (parallel.shard_complexes(n, r, world) for r in range(world))]
+        loads = np.array([w[p_].sum() for p_ in parts], dtype=np.float64)
+        contiguous = np.array([w[lo:hi].sum() for lo, hi in (parallel.shard_complexes(n, r, world) for r in range(world))], dtype=np.float64)
+        if n >= 2 * world:
+            assert loads.max() / loads.mean() <= 1.10                         # the slowest rank within 10 % of the mean
+            assert loads.max() <= contiguous.max()
+        # deterministic: every rank computes the same deal
+        assert all((parallel.shard_complexes(n, r, world, weights=w) == parts[r]).all() for r in range(world))
