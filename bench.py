@@ -74,46 +74,94 @@ def make_batch(batch, n_prot, n_lig, hidden, seed):
     return synthetic.make_stack_batch([(n_prot, n_lig)] * batch, hidden, seed=seed, snap=False)
 
 
-def cpu_baseline(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, backward=False):
-    """The oracle (CPU restatement of the reference algorithm, `kind: port`) timed on the host cores.  backward=True: the
-    same pass as the GPU step of the default mode -- forward, the same scalar loss, backward to every parameter (autograd
-    through the oracle) -- so that `cpu_baseline.value` and `value` measure the same work."""
+def _cpu_run_fn(hidden, layers, n_iter, n_prot, n_lig, batch, backward):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fabind_oracle as orc
-    # torch's default (128 threads on the 256-CPU host of the GPU box) is the WORST setting for this workload: forward
-    # 0.12 complexes/s at 128 threads, 0.26 at 64, 0.39 at 32, 0.38 at 16, 0.31 at 8 (tools/probes/cpu_threads.py)
-    default_threads = torch.get_num_threads()
-    torch.set_num_threads(min(default_threads, 32))
     m = build_model(hidden, layers, n_iter)
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     if backward:
         for v in sd.values():
             if v.is_floating_point():
                 v.requires_grad_(True)
-    inp = make_batch(1, n_prot, n_lig, hidden, seed=0)
+    inp = make_batch(batch, n_prot, n_lig, hidden, seed=0)
 
     def run():
-        X, Hh = orc.stack_forward(sd, "", inp["X"], inp["H"], inp["batch_id"], inp["segment_id"], inp["mask"],
-                                  inp["is_global"], inp["compound_edge_index"], inp["LAS_edge_index"],
-                                  inp["coord_LAS"], layers, n_iter)[:2]
-        if backward:
-            for v in sd.values():
-                v.grad = None
-            ((X * X).mean() + (Hh * Hh).mean() * 1e-6).backward()
-    with torch.set_grad_enabled(backward):
-        t0 = time.time()
+        with torch.set_grad_enabled(backward):
+            X, Hh = orc.stack_forward(sd, "", inp["X"].clone(), inp["H"], inp["batch_id"], inp["segment_id"], inp["mask"],
+                                      inp["is_global"], inp["compound_edge_index"], inp["LAS_edge_index"],
+                                      inp["coord_LAS"], layers, n_iter)[:2]
+            if backward:
+                for v in sd.values():
+                    v.grad = None
+                ((X * X).mean() + (Hh * Hh).mean() * 1e-6).backward()
+    return run
+
+
+def cpu_baseline(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, backward=False, batch=2):
+    """The oracle (CPU restatement of the reference algorithm, `kind: port`) timed on the host cores -- the BOUNDED sample of the
+    default run (~25 s: one warm-up, then as many timed runs as fit, at most 5).  backward=True: the same pass as the GPU step of the
+    default mode -- forward, the same scalar loss, backward to every parameter (autograd through the oracle) -- so that
+    `cpu_baseline.value` and `value` measure the same work.  The full SURVEY 8(d) protocol (B = 2, >= 3 warm-ups + 5 timed runs, all
+    cores and one, per stack pass and per 8-iteration forward) takes tens of minutes of host time: `bench.py --cpu-baseline-full`
+    runs it, its committed result (profiles/r04_cpu_baseline.json) is attached under `cpu_baseline.protocol_8d`."""
+    # torch's default (128 threads on the 256-CPU host of the GPU box) is the WORST setting for this workload: forward
+    # 0.12 complexes/s at 128 threads, 0.26 at 64, 0.39 at 32, 0.38 at 16, 0.31 at 8 (tools/probes/cpu_threads.py)
+    default_threads = torch.get_num_threads()
+    torch.set_num_threads(min(default_threads, 32))
+    run = _cpu_run_fn(hidden, layers, n_iter, n_prot, n_lig, batch, backward)
+    t0 = time.time()
+    run()
+    first = time.time() - t0
+    reps = max(1, min(5, int(budget_s / max(first, 1e-3)) - 1))
+    t0 = time.time()
+    for _ in range(reps):
         run()
-        first = time.time() - t0
-        reps = max(1, min(5, int(budget_s / max(first, 1e-3)) - 1))
-        t0 = time.time()
-        for _ in range(reps):
-            run()
-        dt = (time.time() - t0) / reps
+    dt = (time.time() - t0) / reps
     cores = torch.get_num_threads()
     torch.set_num_threads(default_threads)
-    return dict(value=1.0 / dt, unit="complexes/s", cores=cores, kind="port",
-                sample="oracle stack %s, B=1, %d/%d nodes, hidden %d, %d layers, n_iter=%d, fp32, %d timed run(s) after one warm-up"
-                       % ("forward + backward" if backward else "forward", n_prot, n_lig, hidden, layers, n_iter, reps))
+    out = dict(value=batch / dt, unit="complexes/s", cores=cores, kind="port",
+               sample="oracle stack %s, B=%d, %d/%d nodes, hidden %d, %d layers, n_iter=%d, fp32, %d timed run(s) after one warm-up"
+                      % ("forward + backward" if backward else "forward", batch, n_prot, n_lig, hidden, layers, n_iter, reps))
+    full = os.path.join(ROOT, "profiles", "r04_cpu_baseline.json")
+    if os.path.exists(full):
+        try:
+            out["protocol_8d"] = dict(json.load(open(full)), source="profiles/r04_cpu_baseline.json (committed run of `bench.py --cpu-baseline-full` on a GPU box's host, not this run)")
+        except Exception:
+            pass
+    return out
+
+
+def cpu_baseline_full(hidden, layers, n_prot, n_lig, warmups=3, runs=5, batch=2, slow_run_s=40.0):
+    """SURVEY 8(d)'s CPU-baseline protocol: the oracle at B = 2, fp32, eval, forward: torch.set_num_threads(k) for k = the best
+    many-thread setting (32; torch's default of half the host's CPUs is measured next to it) and k = 1; >= 3 warm-ups + 5 timed runs;
+    complexes/s per stack pass (n_iter 1) and per full forward (n_iter 8); plus the forward + backward pass the headline times.
+    A configuration whose single run exceeds `slow_run_s` seconds is timed with 1 warm-up + 3 runs (said in its `protocol`)."""
+    default_threads = torch.get_num_threads()
+    rows = []
+    for threads in (32, default_threads, 1):
+        for n_iter, backward in ((1, False), (8, False), (1, True)):
+            if threads == default_threads and (n_iter != 1 or backward):
+                continue                                   # (the default thread count is a calibration point, stack pass only)
+            torch.set_num_threads(threads)
+            run = _cpu_run_fn(hidden, layers, n_iter, n_prot, n_lig, batch, backward)
+            t0 = time.time()
+            run()
+            first = time.time() - t0
+            w, r = (warmups, runs) if first <= slow_run_s else (1, 3)
+            for _ in range(w - 1):
+                run()
+            ts = []
+            for _ in range(r):
+                t0 = time.time()
+                run()
+                ts.append(time.time() - t0)
+            ts.sort()
+            rows.append(dict(threads=threads, n_iter=n_iter, backward=backward, batch=batch, nodes="%d/%d" % (n_prot, n_lig),
+                             complexes_per_s=batch / (sum(ts) / len(ts)), best_run_s=ts[0], worst_run_s=ts[-1],
+                             protocol="%d warm-up(s) + %d timed runs" % (w, r)))
+            print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
+    torch.set_num_threads(default_threads)
+    return dict(kind="port", host_cpus=os.cpu_count(), torch_default_threads=default_threads, rows=rows)
 
 
 def self_launch(n):
@@ -159,12 +207,18 @@ def main():
                          "confidence head, --poses per complex); plus_train: one FABind+ training step (train mode, 7-term "
                          "loss incl. the permutation-invariant coordinate term, fwd+bwd)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="run ONLY SURVEY 8(d)'s CPU-baseline protocol (oracle, B=2, >=3 warm-ups + 5 timed runs, 32 threads / torch default / 1 "
+                         "thread, stack pass and 8-iteration forward) on the host and print its JSON; no GPU work (tens of minutes)")
     ap.add_argument("--no-extras", action="store_true",
                     help="default fwdbwd mode at N=1 also times, inside the same JSON line, the same step in fp32 (the mode that "
                          "meets the 1e-4 A gate), in train mode (dropout on), at n_iter=8, forward-only, and the full IaBNet with "
                          "the six-term loss; this flag skips those sub-objects")
     a = ap.parse_args()
 
+    if a.cpu_baseline_full:
+        print(json.dumps(cpu_baseline_full(a.hidden, a.layers, a.n_prot, a.n_lig)))
+        return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -194,8 +248,11 @@ def main():
         def log_message(self, m):
             pass
 
-    def make_step(mode, n_iter, train_mode=False):
-        """-> (step function, complexes per step on this rank, parameter list).  Inputs are resident in HBM before the timed region."""
+    def make_step(mode, n_iter, train_mode=False, n_prot=None, whole_pocket=False):
+        """-> (step function, complexes per step on this rank, parameter list).  Inputs are resident in HBM before the timed region.
+        n_prot: protein nodes per complex (default --n-prot); whole_pocket (mode "model"): the pocket radius is unbounded, so the
+        4-layer complex model and the distance-map head see the WHOLE 1500 / 40 graph -- BASELINE configs[2] read literally."""
+        n_prot = a.n_prot if n_prot is None else n_prot
         if mode in ("plus_sampling", "plus_train"):
             from fabind_amd import synthetic
             from fabind_amd.plus.models import get_model as get_model_plus
@@ -213,7 +270,7 @@ def main():
                 torch.manual_seed(0)
                 model = get_model_plus(margs, _Log()).to(dev)        # LN-MLPs normalise every block: plain init is well conditioned
                 model.train()
-                hb = synthetic.make_hetero_batch([(a.n_prot, a.n_lig)] * a.batch, seed=rank).to(dev)
+                hb = synthetic.make_hetero_batch([(n_prot, a.n_lig)] * a.batch, seed=rank).to(dev)
                 radius = torch.full((a.batch,), 6.0, device=dev)
                 num_atoms = [a.n_lig] * a.batch
                 isos = [[list(range(a.n_lig)), list(reversed(range(a.n_lig)))] for _ in range(a.batch)]
@@ -237,7 +294,7 @@ def main():
             for name_, sub_ in model.named_modules():
                 if name_.startswith("confidence") or name_.startswith("ranking"):
                     sub_.eval()
-            hb = synthetic.make_hetero_batch([(a.n_prot, a.n_lig)] * a.batch, seed=rank).to(dev)
+            hb = synthetic.make_hetero_batch([(n_prot, a.n_lig)] * a.batch, seed=rank).to(dev)
 
             def step():
                 for _ in range(a.poses):
@@ -252,7 +309,8 @@ def main():
             model = get_model(margs, _Log(), dev).to(dev)
             synthetic.condition_for_large_graphs(model)
             model.train(train_mode)
-            hb = synthetic.make_hetero_batch([(a.n_prot, a.n_lig)] * a.batch, seed=rank).to(dev)
+            hb = synthetic.make_hetero_batch([(n_prot, a.n_lig)] * a.batch, seed=rank,
+                                             **({"pocket_radius": 1e9} if whole_pocket else {})).to(dev)
             params = list(model.parameters())
 
             def step():
@@ -274,7 +332,7 @@ def main():
         n_res = 1 if LEGACY_BATCH else 2
         batches = []
         for r_ in range(n_res):
-            inp = make_batch(a.batch, a.n_prot, a.n_lig, a.hidden, seed=rank + 1000 * r_)
+            inp = make_batch(a.batch, n_prot, a.n_lig, a.hidden, seed=rank + 1000 * r_)
             batches.append({k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()})
         counter = [0]
         params = list(model.parameters())
@@ -294,7 +352,7 @@ def main():
         # 718.1; at the pocket-sized shape the step is host-bound and the boxes' hosts are shared (load average 25 on one): 2,720 /
         # 2,698 -> 3,019 / 3,137 on one box, 2,726 / 2,878 / 2,740 / 2,964 against 2,222 / 3,083 / 2,914 / 2,741 on another -- no call.
         # Default: on for the stack modes at protein sizes >= 500; FABIND_BENCH_PREFETCH=1 / 0 forces it.
-        want = (mode in ("fwd", "fwdbwd") and a.n_prot >= 500) if PREFETCH is None else PREFETCH
+        want = (mode in ("fwd", "fwdbwd") and n_prot >= 500) if PREFETCH is None else PREFETCH
         feeder = torch.cuda.Stream(dev) if (want and not LEGACY_BATCH and not REUSE_BATCH) else None
         prefetching[0] = feeder is not None
         pending = []
@@ -480,16 +538,22 @@ def main():
         del step
         torch.cuda.empty_cache()
 
-        def sub(name, mode, n_iter, train_mode=False, precision=None, note="", steps=3, warmup=1):
+        from fabind_amd import config as _config
+
+        def sub(name, mode, n_iter, train_mode=False, precision=None, note="", steps=3, warmup=1, n_prot=None, whole_pocket=False,
+                x3_backward="bf16"):
             prec = precision or a.precision
             engine.set_precision(prec)
+            _config.set_x3_backward(x3_backward)
             try:
-                st, per, _ = make_step(mode, n_iter, train_mode)
+                st, per, _ = make_step(mode, n_iter, train_mode, n_prot=n_prot, whole_pocket=whole_pocket)
                 d, pf = timed(st, warmup, steps, True)
                 mult = a.poses if mode == "plus_sampling" else 1
                 o = {"value": per * steps * mult / d, "unit": "poses/s" if mode == "plus_sampling" else "complexes/s",
                      "ms_per_step": 1e3 * d / steps, "steps": steps, "warmup": warmup,
                      "dtype": prec, "pass": mode, "n_iter": n_iter, "train_mode": train_mode, "note": note}
+                if n_prot is not None:
+                    o["nodes"] = "%d protein / %d ligand" % (n_prot, a.n_lig)
                 if pf:
                     rf = roofline_of(pf, d, prec)
                     o["roofline"] = {k_: rf[k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_us")}
@@ -498,25 +562,43 @@ def main():
                 extras[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             finally:
                 engine.set_precision(a.precision)
+                _config.set_x3_backward("bf16")
                 st = None
                 torch.cuda.empty_cache()
+        sub("pocket", "fwdbwd", a.n_iter, steps=30, warmup=5, n_prot=100,
+            note="the headline step at the size the 4-layer stack sees in production (SURVEY 0.4 / 8(d): the 20 A pocket, 100 protein / 40 "
+                 "ligand nodes per complex), fresh batch per step")
         sub("gate_mode", "fwdbwd", a.n_iter, precision="bf16x3", steps=10, warmup=2,
-            note="the headline step in the split-bf16 mode (fp32 storage, three bf16 MFMAs per product term): the FAST mode that meets "
-                 "the 1e-4 A parity gate at n_iter 1, 2 and 8 (tests/test_gpu_headline.py)")
+            note="the headline step in the split-bf16 mode (fp32 storage; forward and activation-gradient chain with three bf16 MFMAs per "
+                 "product term): the FAST mode whose OUTPUTS meet the 1e-4 A parity gate at n_iter 1, 2 and 8 (tests/test_gpu_headline.py); "
+                 "its weight gradients, fused edge backward and pair-bias adjoint run on bf16 roundings (bf16-grade parameter gradients)")
+        sub("gate_mode_exact_bwd", "fwdbwd", a.n_iter, precision="bf16x3", steps=5, warmup=2, x3_backward="exact",
+            note="gate_mode with config.set_x3_backward('exact'): weight gradients as split contractions, pair-bias adjoint in fp32 (the fused "
+                 "edge backward stays the bf16 recompute kernel)")
         sub("fp32", "fwdbwd", a.n_iter, precision="fp32",
             note="the headline step in fp32 mode (exact-fp32 MFMA, unfused edge pipeline): the exact reference arithmetic")
         sub("train_mode", "fwdbwd", a.n_iter, train_mode=True, steps=5, warmup=2,
             note="the headline step with model.train(): dropout p=0.1 at the reference's six sites")
         sub("n_iter8", "fwdbwd", 8, note="production refinement loop: 8 stack passes, gradient on the last one")
+        sub("n_iter8_gate", "fwdbwd", 8, precision="bf16x3", steps=3, warmup=1,
+            note="n_iter8 in the gate-meeting split-bf16 mode (2.8e-6 A at the headline shape, tests/test_gpu_headline.py)")
         sub("fwd", "fwd", a.n_iter, steps=10, warmup=3, note="forward only, one stack pass")
         sub("model_fwdbwd", "model", a.n_iter, steps=6, warmup=2,
             note="full IaBNet (pocket model on 1500 residues -> pocket crop -> 4-layer complex model -> heads) with the reference's "
                  "six-term loss (pocket-cls + pocket-centre + contact x2 + distill + coord), eval mode")
+        sub("model_gate", "model", a.n_iter, precision="bf16x3", steps=6, warmup=2,
+            note="model_fwdbwd in the gate-meeting split-bf16 mode (production-size parity: tests/test_gpu_production.py)")
+        sub("config3_whole_graph", "model", a.n_iter, steps=10, warmup=2, whole_pocket=True,
+            note="BASELINE configs[2] read literally: the same synthetic batch with an unbounded pocket radius, so the 4-layer hidden-512 "
+                 "complex model AND the heads run on all 1500 protein / 40 ligand nodes -- pocket-cls + pocket-centre + coord + both "
+                 "distance-map losses + distill (the reference's six-term loss) -- fwd+bwd, eval mode")
         sub("model_fwdbwd_train_n_iter8", "model", 8, train_mode=True,
             note="the same with model.train() (dropout, Gumbel noise) and n_iter=8: the reference's training configuration")
         n_it8 = 8
         sub("plus_train", "plus_train", a.n_iter, steps=4, warmup=2,
             note="one FABind+ training step (5-layer LN-MLP stack, train mode, 7-term loss with the permutation-invariant term)")
+        sub("plus_train_gate", "plus_train", a.n_iter, precision="bf16x3", steps=3, warmup=1,
+            note="plus_train in the gate-meeting split-bf16 mode")
         sub("plus_sampling", "plus_sampling", n_it8, steps=2,
             note="FABind+ sampling-mode inference (BASELINE configs[4]): n_iter 8, dropout sampling, DBSCAN centre, ranking head, "
                  "%d poses per complex and step" % a.poses)

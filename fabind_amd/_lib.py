@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FABIND_LIB") or os.path.join(_HERE, "libfabind_hip.so")      # FABIND_LIB: an A/B build (tools/probes)
 
-ABI_VERSION = 14         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
+ABI_VERSION = 15         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -40,9 +40,17 @@ class PairUpdateArgs(ctypes.Structure):
                [(n, _i) for n in ("ldt", "b_off", "n_pairs")] + [("eps", _f), ("p_drop", _f), ("seed", ctypes.c_uint)]
 
 
+class TnJob(ctypes.Structure):
+    """Mirror of FabindTnJob (include/fabind_hip.h): one queued weight-gradient contraction of fabind_gemm_tn_multi."""
+    _fields_ = [(n, _vp) for n in ("Y", "X", "C_part", "out", "out_tail")] + \
+               [(n, _i) for n in ("ldy", "ldx", "M", "N", "E", "splits", "e_per", "n_tiles", "with_colsum", "out_dt", "ldo",
+                                  "wg0", "n_wg", "blk0", "n_blk", "pad_")]
+
+
 # name -> argtypes (every function returns int and takes the stream last)
 SIGNATURES = {
     "fabind_gemm": [ctypes.POINTER(GemmArgs), _vp],
+    "fabind_gemm_tn_multi": [_vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp],
     "fabind_gemm_tn": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp],
     "fabind_transpose_act": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fabind_colsum": [_vp, _i, _i, _vp, _i, _i, _i, _vp, _i, _vp],
@@ -53,7 +61,7 @@ SIGNATURES = {
     "fabind_edge_geom": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "fabind_gcl_pre": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "fabind_gcl_edge_fused": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp, _vp],
-    "fabind_gcl_edge_fused_x3": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp],
+    "fabind_gcl_edge_fused_x3": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp],
     "fabind_gcl_edge_fused_bwd": [ctypes.POINTER(EdgeBwdArgs), _i, _i, _vp],
     "fabind_pair_update_fused": [ctypes.POINTER(PairUpdateArgs), _i, _vp],
     "fabind_gcl_edge_fused_bwd_set_tile": [_i],
@@ -111,7 +119,7 @@ SIGNATURES = {
                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "fabind_las_step_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp],
     "fabind_pair_bias_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "fabind_pair_bias_finish": [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp],
+    "fabind_pair_bias_finish": [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "fabind_layernorm_fwd": [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp],
     "fabind_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
 }
@@ -138,7 +146,8 @@ def load():
     lib.fabind_sizeof_args.argtypes, lib.fabind_sizeof_args.restype = [ctypes.c_int], ctypes.c_int
     lib.fabind_cross_attn_bwd_scratch.argtypes, lib.fabind_cross_attn_bwd_scratch.restype = [_i, _i, _i], ctypes.c_long
     lib.fabind_pair_bias_cat_parts.argtypes, lib.fabind_pair_bias_cat_parts.restype = [_i, _i], ctypes.c_long
-    for which, mirror in enumerate((GemmArgs, EdgeBwdArgs, PairUpdateArgs)):
+    lib.fabind_pair_bias_finish_scratch.argtypes, lib.fabind_pair_bias_finish_scratch.restype = [_i, _i], ctypes.c_int
+    for which, mirror in enumerate((GemmArgs, EdgeBwdArgs, PairUpdateArgs, TnJob)):
         if lib.fabind_sizeof_args(which) != ctypes.sizeof(mirror):
             raise RuntimeError("fabind_amd: ctypes mirror %s is %d bytes, the library's struct is %d -- _lib.py and "
                                "include/fabind_hip.h disagree" % (mirror.__name__, ctypes.sizeof(mirror),

@@ -1,5 +1,8 @@
 """Process-wide numeric mode of the HIP path."""
-_PRECISION = {"mode": "bf16"}
+import os
+
+_PRECISION = {"mode": "bf16", "x3_backward": "bf16" if (os.environ.get("FABIND_X3_WGRAD", "bf16") == "bf16" and
+                                                          os.environ.get("FABIND_X3_PAIRBIAS_BWD", "bf16") == "bf16") else "exact"}
 MODES = ("fp32", "bf16", "bf16x3")
 
 
@@ -7,11 +10,27 @@ def set_precision(mode):
     """'fp32': exact-fp32 MFMA everywhere (parity mode, 1e-4 A gate; 1/16 of the bf16 matrix rate).
     'bf16': bf16 MFMA operands with fp32 accumulation; coordinates, radial terms, softmax and all
     reductions stay fp32; edge-level intermediates are stored as bf16.
-    'bf16x3': fp32 storage everywhere like 'fp32', but every contraction runs as SPLIT bf16 on the bf16 matrix cores: an operand
-    element x is hi + lo with hi = bf16(x), lo = bf16(x - hi) (16 significand bits), a product term is three MFMAs
-    (lo*hi + hi*lo + hi*hi) with fp32 accumulation -- fp32-grade results (meets the 1e-4 A gate) at 3/16 of the fp32 matrix time."""
+    'bf16x3': fp32 storage everywhere like 'fp32'; the FORWARD pass and the activation-gradient chain of the backward pass run every
+    contraction as SPLIT bf16 on the bf16 matrix cores: an operand element x is hi + lo with hi = bf16(x), lo = bf16(x - hi) (16
+    significand bits), a product term is three MFMAs (lo*hi + hi*lo + hi*hi) with fp32 accumulation -- fp32-grade outputs (the mode
+    that meets the 1e-4 A gate) at 3/16 of the fp32 matrix time.  Three parts of the BACKWARD pass default to single bf16 roundings of
+    their fp32 operands (`set_x3_backward("bf16")`, the default): the weight-gradient contractions, the fused edge backward (the bf16
+    recompute kernel on bf16 copies of AB and the weights) and the pair-bias adjoint -- parameter gradients are then bf16-grade
+    (whole-gradient l2 error ~2e-3, tests/test_gpu_headline.py), the outputs and losses are not affected.
+    `set_x3_backward("exact")` runs the weight gradients as split contractions and the pair-bias adjoint in fp32 (the fused edge
+    backward stays the bf16 recompute kernel: there is no split form of it); bench.py reports both (`gate_mode`, `gate_mode_exact_bwd`)."""
     assert mode in MODES
     _PRECISION["mode"] = mode
+
+
+def set_x3_backward(kind):
+    """'bf16' (default) / 'exact': see set_precision('bf16x3')."""
+    assert kind in ("bf16", "exact")
+    _PRECISION["x3_backward"] = kind
+
+
+def x3_backward_bf16():
+    return _PRECISION["x3_backward"] == "bf16"
 
 
 def get_precision():

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_fwd_kernel(const float* _
     }
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        const float inv = 1.f / l[h];
+        const float inv = l[h] > 0.f ? 1.f / l[h] : 0.f;     // no key at all (an empty ligand side): zeros, not 0 * inf
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int c = h * 32 + mi * 16 + kq * 4;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void cross_attn_mfma_combine_kernel(const floa
 #pragma unroll
         for (int d = 0; d < 32; ++d) o[d] += pp[d] * w;
     }
-    const float inv = 1.f / L;
+    const float inv = L > 0.f ? 1.f / L : 0.f;
 #pragma unroll
     for (int d = 0; d < 32; ++d)
         out[(size_t)rowi * ldo + h * 32 + d] = o[d] * inv * sigmoid_f(gpre[(size_t)rowi * ldg + h * 32 + d]);
@@ -968,7 +968,7 @@ __global__ __launch_bounds__(256, 2) void cross_attn_fused_fwd_kernel(const floa
     }
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        const float inv = 1.f / l[h];
+        const float inv = l[h] > 0.f ? 1.f / l[h] : 0.f;     // no key at all (an empty ligand side): zeros, not 0 * inf
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             const int c = h * 32 + mi * 16 + kq * 4;
@@ -996,6 +996,8 @@ extern "C" int fabind_cross_attn_fused_fwd(const float* q, int ldq, const float*
     FB_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldg % 4 == 0 && ldo % 4 == 0 && lda0 % 8 == 0, "fabind_cross_attn_fused_fwd: strides");
     FB_REQUIRE(max_C <= CF_KEYS, "fabind_cross_attn_fused_fwd: at most 62 ligand atoms per complex (larger ligands take the tensor path)");
     FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_cross_attn_fused_fwd: H must be 64, 128, 256 or 512");
+    // (layout contract, not checkable from pointers: q / k / v / gpre rows are 4 heads x 32 channels, bconst8 and the packed operand's
+    //  eight rows per ligand atom are ordered lin0..3 | gate0..3 -- fabind_pair_bo_pack's wcomp [8, H])
     FB_REQUIRE(mode == 0 || part != nullptr, "fabind_cross_attn_fused_fwd: the ligand-query block needs the partials buffer");
     if (B <= 0 || max_P <= 0) return 0;
     const int nsplit = (max_P + CF_ROWS - 1) / CF_ROWS;

@@ -1274,46 +1274,59 @@ extern "C" int fabind_inter_attn_bwd(const float* qkv, int ldqkv, const float* c
 // ------------------------------------------------------------------------------------------------
 // LAS step backward: x_out_j = x_j + clamp(step F_j), F_j = sum_{(i,j)} 4(|d|^2 - |d0|^2) d, d = x_i - x_j
 // ------------------------------------------------------------------------------------------------
+// (one wave per ligand atom, lanes over the complex's LAS edges, fixed-order wave sums; other nodes: a copy, one thread each -- the
+//  thread-per-atom form walked all 154 edges serially: 76 us per call at 2,560 atoms)
 __global__ __launch_bounds__(256) void las_step_bwd_kernel(const float* __restrict__ x, const float* __restrict__ x0,
                                                            const float* __restrict__ xo, const int* las_i,
                                                            const int* las_j, const int* las_off, const int* node_off,
                                                            const int* c_cnt, float step, float clampv,
-                                                           const float* __restrict__ dout, float* dx) {
+                                                           const float* __restrict__ dout, float* dx, int nb_copy) {
     const int b = blockIdx.y;
     const int off = node_off[b], n = node_off[b + 1] - off, C = c_cnt[b];
-    const int u = blockIdx.x * 256 + threadIdx.x;
-    if (u >= n) return;
-    const int gu = off + u;
-    float ax = dout[(size_t)gu * 3], ay = dout[(size_t)gu * 3 + 1], az = dout[(size_t)gu * 3 + 2];
-    if (u >= 1 && u < C) {
-        for (int e = las_off[b]; e < las_off[b + 1]; ++e) {
-            const int i = las_i[e], j = las_j[e];
-            if (i != gu && j != gu) continue;
-            // dF_j = step * dout_j * [clamp inactive]
-            float gF[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float delta = xo[(size_t)j * 3 + k] - x[(size_t)j * 3 + k];
-                gF[k] = fabsf(delta) < clampv ? step * dout[(size_t)j * 3 + k] : 0.f;
-            }
-            const float dx_ = x[i * 3] - x[j * 3], dy_ = x[i * 3 + 1] - x[j * 3 + 1], dz_ = x[i * 3 + 2] - x[j * 3 + 2];
-            const float ex = x0[i * 3] - x0[j * 3], ey = x0[i * 3 + 1] - x0[j * 3 + 1], ez = x0[i * 3 + 2] - x0[j * 3 + 2];
-            const float diff = (dx_ * dx_ + dy_ * dy_ + dz_ * dz_) - (ex * ex + ey * ey + ez * ez);
-            const float dg = dx_ * gF[0] + dy_ * gF[1] + dz_ * gF[2];
-            const float vx = 4.f * (diff * gF[0] + 2.f * dx_ * dg), vy = 4.f * (diff * gF[1] + 2.f * dy_ * dg),
-                        vz = 4.f * (diff * gF[2] + 2.f * dz_ * dg);
-            if (i == gu) { ax += vx; ay += vy; az += vz; }
-            if (j == gu) { ax -= vx; ay -= vy; az -= vz; }
-        }
+    if ((int)blockIdx.x < nb_copy) {
+        const int u = blockIdx.x * 256 + threadIdx.x;
+        if (u >= n || (u >= 1 && u < C)) return;
+        const int gu = off + u;
+        dx[(size_t)gu * 3] = dout[(size_t)gu * 3]; dx[(size_t)gu * 3 + 1] = dout[(size_t)gu * 3 + 1]; dx[(size_t)gu * 3 + 2] = dout[(size_t)gu * 3 + 2];
+        return;
     }
-    dx[(size_t)gu * 3] = ax; dx[(size_t)gu * 3 + 1] = ay; dx[(size_t)gu * 3 + 2] = az;
+    const int lane = threadIdx.x & 63;
+    const int u = 1 + ((int)blockIdx.x - nb_copy) * 4 + (threadIdx.x >> 6);
+    if (u >= C || u >= n) return;
+    const int gu = off + u;
+    float ax = 0.f, ay = 0.f, az = 0.f;
+    for (int e = las_off[b] + lane; e < las_off[b + 1]; e += 64) {
+        const int i = las_i[e], j = las_j[e];
+        if (i != gu && j != gu) continue;
+        // dF_j = step * dout_j * [clamp inactive]
+        float gF[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float delta = xo[(size_t)j * 3 + k] - x[(size_t)j * 3 + k];
+            gF[k] = fabsf(delta) < clampv ? step * dout[(size_t)j * 3 + k] : 0.f;
+        }
+        const float dx_ = x[i * 3] - x[j * 3], dy_ = x[i * 3 + 1] - x[j * 3 + 1], dz_ = x[i * 3 + 2] - x[j * 3 + 2];
+        const float ex = x0[i * 3] - x0[j * 3], ey = x0[i * 3 + 1] - x0[j * 3 + 1], ez = x0[i * 3 + 2] - x0[j * 3 + 2];
+        const float diff = (dx_ * dx_ + dy_ * dy_ + dz_ * dz_) - (ex * ex + ey * ey + ez * ez);
+        const float dg = dx_ * gF[0] + dy_ * gF[1] + dz_ * gF[2];
+        const float vx = 4.f * (diff * gF[0] + 2.f * dx_ * dg), vy = 4.f * (diff * gF[1] + 2.f * dy_ * dg),
+                    vz = 4.f * (diff * gF[2] + 2.f * dz_ * dg);
+        if (i == gu) { ax += vx; ay += vy; az += vz; }
+        if (j == gu) { ax -= vx; ay -= vy; az -= vz; }
+    }
+    ax = wave_sum(ax); ay = wave_sum(ay); az = wave_sum(az);
+    if (lane == 0) {
+        dx[(size_t)gu * 3] = dout[(size_t)gu * 3] + ax; dx[(size_t)gu * 3 + 1] = dout[(size_t)gu * 3 + 1] + ay;
+        dx[(size_t)gu * 3 + 2] = dout[(size_t)gu * 3 + 2] + az;
+    }
 }
 extern "C" int fabind_las_step_bwd(const float* x, const float* x0, const float* xo, const int* las_i, const int* las_j,
                                    const int* las_off, const int* node_off, const int* c_cnt, int B, int max_n,
                                    float step, float clampv, const float* dout, float* dx, hipStream_t stream) {
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(las_step_bwd_kernel, dim3((max_n + 255) / 256, B), dim3(256), 0, stream, x, x0, xo, las_i, las_j,
-                       las_off, node_off, c_cnt, step, clampv, dout, dx);
+    const int nb_copy = (max_n + 255) / 256;
+    hipLaunchKernelGGL(las_step_bwd_kernel, dim3(nb_copy + (max_n + 3) / 4, B), dim3(256), 0, stream, x, x0, xo, las_i, las_j,
+                       las_off, node_off, c_cnt, step, clampv, dout, dx, nb_copy);
     FB_CHECK_LAUNCH();
     return 0;
 }
@@ -1435,40 +1448,63 @@ extern "C" int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, 
 }
 
 // finishing pass of the GEMM formulation of the pair-bias adjoint:  T[(jc,o), h] = sum_i D[i,(j,o)] a0[i,h]
-//   db0[node(jc), h] += sum_o w[o,h] T[(jc,o),h];   dw[o,h] += sum_jc b0[node(jc),h] T[(jc,o),h]   (float atomics, sumC adds)
-// One work-group = 16 ligand-side nodes x 256 features: the weight gradient is summed over the work-group's nodes in registers and leaves
-// as ONE atomic per (o, h) and work-group.  (First form: one work-group per node, 8 atomics per node and feature -- 10.7 M float atomics
+//   db0[node(jc), h] += sum_o w[o,h] T[(jc,o),h];   dw[o,h] = sum_jc b0[node(jc),h] T[(jc,o),h]
+// One work-group = 16 ligand-side nodes x 256 features: the weight gradient is summed over the work-group's nodes in registers and goes
+// to scratch[wg][o][h]; the LAST work-group of a feature block to finish (an integer ticket per block) adds the partials in work-group
+// order and writes dw -- one launch, a fixed summation order, no float atomics (round 3 left ONE float atomic per (o, h) and
+// work-group here: two runs of the same step differed in the last bit of these gradients -- tests/test_gpu_headline.py,
+// test_bench_batch_backward_properties).  (First form: one work-group per node, 8 atomics per node and feature -- 10.7 M float atomics
 // per launch onto 4,096 addresses at the bench shape, 152 us for a 43 MB read; 8 launches per step.)
 constexpr int PBF_NODES = 16;
 __global__ __launch_bounds__(256) void pair_bias_finish_kernel(const float* __restrict__ T, const float* __restrict__ ab, int ld,
                                                                int H, const float* __restrict__ w, const int* c_index, int n_c,
-                                                               float* dab, float* dw) {
+                                                               float* dab, float* dw, float* scratch, unsigned* ticket) {
     const int h = blockIdx.y * 256 + threadIdx.x;
-    if (h >= H) return;
     const int j0 = blockIdx.x * PBF_NODES, j1 = min(n_c, j0 + PBF_NODES);
     float wv[8], dwv[8];
+    if (h < H) {
 #pragma unroll
-    for (int o = 0; o < 8; ++o) { wv[o] = w[o * H + h]; dwv[o] = 0.f; }
-    for (int jc = j0; jc < j1; ++jc) {
-        const int cn = c_index[jc];
-        const float bj = ab[(size_t)cn * ld + H + h];
-        float db = 0.f;
+        for (int o = 0; o < 8; ++o) { wv[o] = w[o * H + h]; dwv[o] = 0.f; }
+        for (int jc = j0; jc < j1; ++jc) {
+            const int cn = c_index[jc];
+            const float bj = ab[(size_t)cn * ld + H + h];
+            float db = 0.f;
 #pragma unroll
-        for (int o = 0; o < 8; ++o) {
-            const float t = T[((size_t)jc * 8 + o) * H + h];
-            db += wv[o] * t;
-            dwv[o] += bj * t;
+            for (int o = 0; o < 8; ++o) {
+                const float t = T[((size_t)jc * 8 + o) * H + h];
+                db += wv[o] * t;
+                dwv[o] += bj * t;
+            }
+            dab[(size_t)cn * ld + H + h] += db;
         }
-        dab[(size_t)cn * ld + H + h] += db;
-    }
 #pragma unroll
-    for (int o = 0; o < 8; ++o) atomicAdd(&dw[o * H + h], dwv[o]);
+        for (int o = 0; o < 8; ++o) scratch[((size_t)blockIdx.x * 8 + o) * H + h] = dwv[o];
+    }
+    __threadfence();
+    __shared__ unsigned last;
+    __syncthreads();
+    if (threadIdx.x == 0) last = atomicAdd(&ticket[blockIdx.y], 1u);
+    __syncthreads();
+    if (last != gridDim.x - 1) return;
+    __threadfence();
+    if (h < H) {
+#pragma unroll
+        for (int o = 0; o < 8; ++o) dwv[o] = 0.f;
+        for (unsigned g = 0; g < gridDim.x; ++g)
+#pragma unroll
+            for (int o = 0; o < 8; ++o) dwv[o] += __hip_atomic_load(&scratch[((size_t)g * 8 + o) * H + h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device-coherent read
+#pragma unroll
+        for (int o = 0; o < 8; ++o) dw[o * H + h] = dwv[o];
+    }
+    if (threadIdx.x == 0) ticket[blockIdx.y] = 0u;                 // the ticket buffer is reusable by the next launch on the stream
 }
+extern "C" int fabind_pair_bias_finish_scratch(int n_c, int H) { return n_c <= 0 ? 0 : ((n_c + PBF_NODES - 1) / PBF_NODES) * 8 * H; }
 extern "C" int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, const float* w, const int* c_index,
-                                       int n_c, float* dab, float* dw, hipStream_t stream) {
+                                       int n_c, float* dab, float* dw, float* scratch, unsigned* ticket, hipStream_t stream) {
     if (n_c <= 0) return 0;
+    FB_REQUIRE(scratch && ticket, "fabind_pair_bias_finish: scratch (fabind_pair_bias_finish_scratch floats) and a zeroed ticket buffer (ceil(H/256) uints) are required");
     hipLaunchKernelGGL(pair_bias_finish_kernel, dim3((n_c + PBF_NODES - 1) / PBF_NODES, (H + 255) / 256), dim3(256), 0, stream, T, ab, ld, H, w,
-                       c_index, n_c, dab, dw);
+                       c_index, n_c, dab, dw, scratch, ticket);
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -16,6 +16,7 @@ extern "C" int fabind_sizeof_args(int which) {
         case 0: return (int)sizeof(FabindGemmArgs);
         case 1: return (int)sizeof(FabindEdgeBwdArgs);
         case 2: return (int)sizeof(FabindPairUpdateArgs);
+        case 3: return (int)sizeof(FabindTnJob);
         default: return -1;
     }
 }

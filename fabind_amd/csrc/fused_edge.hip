@@ -193,7 +193,7 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
     return 0;
 }
 
-extern "C" int fabind_gcl_edge_fused_x3(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
+extern "C" int fabind_gcl_edge_fused_x3(const float* AB, int ldab, int n_rows, int H, const int* row, const int* col, const float* rhohat,
                                         const float* w_r, const void* W2ph, const void* W2pl, const float* b2, const void* Wcph,
                                         const void* Wcpl, const float* bc, const float* w3, int E, float* agg, float* s_out,
                                         float p_drop, unsigned seed, float* bnd, hipStream_t stream) {
@@ -202,6 +202,8 @@ extern "C" int fabind_gcl_edge_fused_x3(const float* AB, int ldab, int H, const 
     FB_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "fabind_gcl_edge_fused_x3: p_drop in [0, 1)");
     FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_gcl_edge_fused_x3: H must be 64, 128, 256 or 512");
     FB_REQUIRE(ldab % 4 == 0 && ((uintptr_t)AB & 15) == 0, "fabind_gcl_edge_fused_x3: AB must be 16-byte aligned with ldab % 4 == 0");
+    // the gathers address AB rows with 32-bit BYTE offsets into one buffer resource: fp32 rows are twice the bf16 kernel's
+    FB_REQUIRE(n_rows >= 0 && (size_t)n_rows * (size_t)ldab * 4 < ((size_t)1 << 32), "fabind_gcl_edge_fused_x3: AB larger than 4 GiB (n_rows * ldab * 4 bytes): split the batch");
     const uint32_t thr16 = (uint32_t)(p_drop * 65536.0f + 0.5f);
     const float dscale = 1.0f / (1.0f - (float)thr16 / 65536.0f);
     const int rc = fe_fwd3_launch(AB, ldab, H, row, col, rhohat, w_r, W2ph, W2pl, b2, Wcph, Wcpl, bc, w3, E, agg, s_out, thr16, dscale,

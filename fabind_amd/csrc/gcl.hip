@@ -232,15 +232,18 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict
 template <int NSLAB>
 __global__ __launch_bounds__(1024) void segment_sum_heavy_kernel(const void* __restrict__ Z, int z_dt, int ldz, int H,
                                                                  const int* rowptr, const int* eidx, int act, float* out,
-                                                                 int ldo, int n_rows, bf16_t* out16, int ldo16) {
+                                                                 int ldo, int n_rows, bf16_t* out16, int ldo16, int rpw) {
+    // rpw (<= 1024): rows scanned per work-group.  1,024 suits 1,500-node complexes (one or two heavy rows per work-group); a batch of
+    // 142-node complexes has 14 heavy rows per 1,024 and only 9 such work-groups on the whole chip (103 us per call at the
+    // pocket-sized bench shape): the host sizes rpw so that the launch has >= ~256 work-groups.
     __shared__ F8 part[15][NSLAB * 64];
     __shared__ int heavy[1024];
     __shared__ int n_heavy;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) n_heavy = 0;
     __syncthreads();
-    const int rr = blockIdx.x * 1024 + threadIdx.x;
-    if (rr < n_rows && rowptr[rr + 1] - rowptr[rr] > SS_HEAVY) heavy[atomicAdd(&n_heavy, 1)] = rr;
+    const int rr = blockIdx.x * rpw + threadIdx.x;
+    if ((int)threadIdx.x < rpw && rr < n_rows && rowptr[rr + 1] - rowptr[rr] > SS_HEAVY) heavy[atomicAdd(&n_heavy, 1)] = rr;
     __syncthreads();
     const int nh = n_heavy;
     for (int q = 0; q < nh; ++q) {
@@ -290,13 +293,15 @@ extern "C" int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const
     FB_REQUIRE(out16 == nullptr || (ldo16 % 8 == 0 && (uintptr_t)out16 % 16 == 0), "fabind_segment_sum: out16 needs 16-byte alignment and ldo16 % 8 == 0");
     if (n_rows <= 0) return 0;
     (void)n_edges;
-    const dim3 g((n_rows + 3) / 4), gh((n_rows + 1023) / 1024);
+    int rpw = 1024;
+    while (rpw > 64 && (n_rows + rpw - 1) / rpw < 256) rpw >>= 1;
+    const dim3 g((n_rows + 3) / 4), gh((n_rows + rpw - 1) / rpw);
     if (H <= 512) {
         hipLaunchKernelGGL((segment_sum_kernel<1>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16);
-        hipLaunchKernelGGL((segment_sum_heavy_kernel<1>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16);
+        hipLaunchKernelGGL((segment_sum_heavy_kernel<1>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16, rpw);
     } else {
         hipLaunchKernelGGL((segment_sum_kernel<2>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16);
-        hipLaunchKernelGGL((segment_sum_heavy_kernel<2>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16);
+        hipLaunchKernelGGL((segment_sum_heavy_kernel<2>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16, rpw);
     }
     FB_CHECK_LAUNCH();
     return 0;

@@ -957,11 +957,23 @@ template <int N> __device__ __forceinline__ void wait_vmcnt_upto(int n) {   // s
     if (n >= 3) wait_vmcnt<3 * N>(); else if (n == 2) wait_vmcnt<2 * N>(); else if (n == 1) wait_vmcnt<N>(); else wait_vmcnt<0>();
 }
 
-template <int NSTAGE, int NW, int TN_>
+template <int NSTAGE, int NW, int TN_, bool JOBS = false>
 __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ Y, int ldy, const bf16_t* __restrict__ X,
                                                            int ldx, float* C, int M, int N, int E, int e_per,
                                                            const bf16_t* __restrict__ zero_page, const int* groups,
-                                                           int n_tiles, int n_splits, int xf, int cs) {
+                                                           int n_tiles, int n_splits, int xf, int cs,
+                                                           const FabindTnJob* __restrict__ jobs, const int* __restrict__ wg_job) {
+    // JOBS: one launch carries MANY independent contractions (fabind_gemm_tn_multi: the weight gradients of a whole backward pass,
+    // queued by the host and flushed together -- at 9,000 rows one contraction is 32 work-groups on a 256-CU chip).  A work-group
+    // reads its job from the device table (uniform: scalar loads) and then runs exactly the single-launch code path below.
+    unsigned bid = blockIdx.x;
+    if constexpr (JOBS) {
+        const FabindTnJob* jb = jobs + wg_job[blockIdx.x];
+        Y = (const bf16_t*)jb->Y; X = (const bf16_t*)jb->X; C = jb->C_part;
+        ldy = jb->ldy; ldx = jb->ldx; M = jb->M; N = jb->N; E = jb->E; e_per = jb->e_per;
+        n_tiles = jb->n_tiles; n_splits = jb->splits; cs = jb->with_colsum;
+        bid -= (unsigned)jb->wg0;
+    }
     // Output tile 256 x TN_, NW waves per work-group: TN_/64 across N (64 columns each), the rest across M.
     //   <3, 4, 128>: 128x64 per wave, 124 VGPRs + 128 AGPRs, two work-groups per CU (3 x 24 KiB of LDS each);
     //   <3, 8, 128>: 64x64 per wave, one work-group per CU (kept as a knob);
@@ -995,8 +1007,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __r
     // XCD-aware order: consecutive work-group ids go round-robin to the 8 XCDs, so id = (split_hi, tile, split_lo)
     // puts every output tile of one e-range on the SAME XCD -- its Y / X slabs are fetched into that L2 once
     // instead of once per tile (measured 3x the algorithmic HBM reads with tile-major order).
-    const int tile = (blockIdx.x >> 3) % n_tiles;
-    const int split = ((blockIdx.x >> 3) / n_tiles) * 8 + (blockIdx.x & 7);
+    const int tile = (bid >> 3) % n_tiles;
+    const int split = ((bid >> 3) / n_tiles) * 8 + (bid & 7);
     if (split >= n_splits) return;
     const int m0 = (tile / nbx) * TM, n0 = (tile % nbx) * TN_;
     if (m0 >= M) return;
@@ -1223,7 +1235,70 @@ static void tn_launch(const void* Y, int ldy, const void* X, int ldx, float* C_p
     const int n_tiles = ((M + 255) / 256) * ((N + TN_ - 1) / TN_);
     dim3 grid(n_tiles * ((splits + 7) / 8 * 8), 1, groups ? n_groups : 1);
     hipLaunchKernelGGL((gemm_tn_bf16_kernel<NSTAGE, NW, TN_>), grid, dim3(NW * 64), lds, stream, (const bf16_t*)Y, ldy, (const bf16_t*)X, ldx,
-                       C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups, n_tiles, splits, g_tn_exp, with_colsum);
+                       C_part, M, N, E, e_per, (const bf16_t*)zero_page, groups, n_tiles, splits, g_tn_exp, with_colsum,
+                       (const FabindTnJob*)nullptr, (const int*)nullptr);
+}
+
+// Reduction of the split partials of every job of a fabind_gemm_tn_multi launch: job j's [splits][M * N (+ M)] partials -> its weight
+// gradient (out_dt, row stride ldo: two jobs may fill the column blocks of one [M, K1 + K2] gradient) and, with column sums, its fp32
+// bias gradient.  Fixed split order, like split_sum_kernel.
+__global__ __launch_bounds__(256) void tn_multi_sum_kernel(const FabindTnJob* __restrict__ jobs, const int* __restrict__ blk_job) {
+    const FabindTnJob* jb = jobs + blk_job[blockIdx.x];
+    const int M = jb->M, N = jb->N, splits = jb->splits;
+    const long n_head = (long)M * N, n = n_head + (jb->with_colsum ? M : 0);
+    const float* part = jb->C_part;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {                              // a block reduces 4,096 elements (the block table stays small)
+        const long i = (((long)(blockIdx.x - (unsigned)jb->blk0) * 4 + it) * 256 + threadIdx.x) * 4;
+        if (i >= n) return;                                       // M % 8 == 0 and N % 8 == 0: n, n_head are multiples of 4
+        float4 s = *(const float4*)(part + i);
+        for (int k = 1; k < splits; ++k) {
+            const float4 v = *(const float4*)(part + (size_t)k * n + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (i < n_head) {
+            const long r = i / N, c = i - r * N;
+            st4_any(jb->out, jb->out_dt, (size_t)(r * jb->ldo + c), s);
+        } else {
+            *(float4*)(jb->out_tail + (i - n_head)) = s;
+        }
+    }
+}
+
+extern "C" int fabind_gemm_tn_multi(const FabindTnJob* jobs_dev, const FabindTnJob* jobs_host, int n_jobs, const int* wg_job_dev, int total_wg,
+                                    const int* blk_job_dev, int total_blk, const void* zero_page, hipStream_t stream) {
+    if (n_jobs <= 0) return 0;
+    FB_REQUIRE(jobs_dev && jobs_host && wg_job_dev && blk_job_dev && zero_page && ((uintptr_t)zero_page % 16 == 0), "fabind_gemm_tn_multi: null table");
+    int wg = 0, blk = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+        const FabindTnJob& b = jobs_host[j];
+        FB_REQUIRE(b.M > 0 && b.N > 0 && b.E >= 0 && b.splits >= 1 && b.M % 8 == 0 && b.N % 8 == 0 && b.ldy % 8 == 0 && b.ldx % 8 == 0,
+                   "fabind_gemm_tn_multi: M, N, ldy, ldx must be positive multiples of 8");
+        FB_REQUIRE(((uintptr_t)b.Y % 16 == 0) && ((uintptr_t)b.X % 16 == 0) && ((uintptr_t)b.C_part % 16 == 0) && b.out, "fabind_gemm_tn_multi: alignment");
+        FB_REQUIRE(b.ldo >= b.N && b.ldo % 4 == 0 && ((uintptr_t)b.out % 8 == 0) && (!b.with_colsum || (b.out_tail && (uintptr_t)b.out_tail % 16 == 0)),
+                   "fabind_gemm_tn_multi: output layout");
+        const int nt = ((b.M + 255) / 256) * ((b.N + 255) / 256);
+        FB_REQUIRE(b.n_tiles == nt && b.e_per == ((b.E + b.splits - 1) / b.splits + 31) / 32 * 32 && b.wg0 == wg && b.wg0 % 8 == 0 &&
+                   b.n_wg == nt * ((b.splits + 7) / 8 * 8) && b.blk0 == blk, "fabind_gemm_tn_multi: inconsistent job table");
+        const long n = (long)b.M * b.N + (b.with_colsum ? b.M : 0);
+        FB_REQUIRE(b.n_blk == (int)((n + 4095) / 4096), "fabind_gemm_tn_multi: inconsistent reduction blocks");
+        wg += b.n_wg; blk += b.n_blk;
+    }
+    FB_REQUIRE(wg == total_wg && blk == total_blk, "fabind_gemm_tn_multi: work-group totals");
+    constexpr int NSTAGE = 4, NW = 8, TN_ = 256;
+    const size_t lds = (size_t)NSTAGE * 32 * (256 + TN_) * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<NSTAGE, NW, TN_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_bf16_kernel<NSTAGE, NW, TN_, true>), dim3(total_wg), dim3(NW * 64), lds, stream, (const bf16_t*)nullptr, 0,
+                       (const bf16_t*)nullptr, 0, (float*)nullptr, 0, 0, 0, 0, (const bf16_t*)zero_page, (const int*)nullptr, 0, 0, 0, 0, jobs_dev,
+                       wg_job_dev);
+    FB_CHECK_LAUNCH();
+    hipLaunchKernelGGL(tn_multi_sum_kernel, dim3(total_blk), dim3(256), 0, stream, jobs_dev, blk_job_dev);
+    FB_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_part, int M, int N, int E, int splits,
@@ -1585,6 +1660,7 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
         FB_REQUIRE(p.a_dtype == FB_DT_F32, "fabind_gemm: the split-bf16 contraction takes fp32 A and fp32 W");
         FB_REQUIRE(((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.W % 16 == 0) && (p.A2 == nullptr || ((uintptr_t)p.A2 % 16 == 0 && p.lda2 % 4 == 0)),
                    "fabind_gemm: split-bf16 operands must be 16-byte aligned");
+        FB_REQUIRE(p.lda % 4 == 0 && p.ldw % 4 == 0, "fabind_gemm: split-bf16 operands are read as 16-byte rows (lda % 4 == 0, ldw % 4 == 0)");
         if (p.act_pro != FB_ACT_NONE) launch_x3<2, 2, true>(p, maxM, maxN, stream);
         else if (g_x3_wm == 4) launch_x3<4, 2, false>(p, maxM, maxN, stream);
         else launch_x3<2, 2, false>(p, maxM, maxN, stream);

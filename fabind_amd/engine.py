@@ -216,7 +216,9 @@ def _cat(ts, d=0):
 
 def gcl_params(m, pk=None):
     """Kernel-side parameter pack of one MC_E_GCL module (first edge Linear split per node, see module docstring).  pk: a
-    param_pack.ParamPack collecting the whole model's copy requests (entries are handles until pk.resolve), default: built here."""
+    param_pack.ParamPack collecting the whole model's copy requests (entries are handles until pk.resolve), default: built here.
+    (Biases go through the pack too: their gradients then reach the pack's adjoint -- the ONE place where the queued weight-gradient
+    contractions are flushed, kernels.tn_flush -- instead of each bias's own AccumulateGrad, which would flush per Linear.)"""
     wd = _wd()
     own = pk is None
     pk = pk or EagerPack(m.edge_mlp[0].weight.device)
@@ -226,10 +228,10 @@ def gcl_params(m, pk=None):
     d = dict(
         W_ab=pk.cat([W1[:, :Hin], W1[:, Hin:2 * Hin]], 0, wd, with_T=True),
         b_ab=pk.cat([m.edge_mlp[0].bias, pk.zeros(H)]),
-        w_r=pk.copy(W1[:, 2 * Hin]), W2=pk.copy(m.edge_mlp[2].weight, wd), b2=m.edge_mlp[2].bias,
-        Wc=pk.copy(m.coord_mlp[0].weight, wd), bc=m.coord_mlp[0].bias, w3=pk.copy(m.coord_mlp[2].weight[0]),
-        Wn1=pk.copy(m.node_mlp[0].weight, wd, with_T=True), bn1=m.node_mlp[0].bias,
-        Wn2=pk.copy(m.node_mlp[2].weight, wd, with_T=True), bn2=m.node_mlp[2].bias)
+        w_r=pk.copy(W1[:, 2 * Hin]), W2=pk.copy(m.edge_mlp[2].weight, wd), b2=pk.copy(m.edge_mlp[2].bias),
+        Wc=pk.copy(m.coord_mlp[0].weight, wd), bc=pk.copy(m.coord_mlp[0].bias), w3=pk.copy(m.coord_mlp[2].weight[0]),
+        Wn1=pk.copy(m.node_mlp[0].weight, wd, with_T=True), bn1=pk.copy(m.node_mlp[0].bias),
+        Wn2=pk.copy(m.node_mlp[2].weight, wd, with_T=True), bn2=pk.copy(m.node_mlp[2].bias))
     return pk.resolve(d) if own else d
 
 
@@ -280,10 +282,10 @@ def cam_node_params(cam, pk=None):
         d["Wqg_" + tag] = pk.cat([a.linear_q.weight, a.linear_g.weight], 0, wd, with_T=True)
         d["bqg_" + tag] = pk.cat([pk.zeros(a.linear_g.bias.shape[0]), a.linear_g.bias])
         d["Wkv_" + tag] = pk.cat([a.linear_k.weight, a.linear_v.weight], 0, wd, with_T=True)
-        d["Wo_" + tag], d["bo_" + tag] = pk.copy(a.linear_o.weight, wd, with_T=True), a.linear_o.bias
+        d["Wo_" + tag], d["bo_" + tag] = pk.copy(a.linear_o.weight, wd, with_T=True), pk.copy(a.linear_o.bias)
     for tag, tr in (("p", cam.p_transition), ("c", cam.c_transition)):
-        d["Wt1_" + tag], d["bt1_" + tag] = pk.copy(tr.linear_1.weight, wd, with_T=True), tr.linear_1.bias
-        d["Wt2_" + tag], d["bt2_" + tag] = pk.copy(tr.linear_2.weight, wd, with_T=True), tr.linear_2.bias
+        d["Wt1_" + tag], d["bt1_" + tag] = pk.copy(tr.linear_1.weight, wd, with_T=True), pk.copy(tr.linear_1.bias)
+        d["Wt2_" + tag], d["bt2_" + tag] = pk.copy(tr.linear_2.weight, wd, with_T=True), pk.copy(tr.linear_2.bias)
     i32 = cam.inter_layer
     zw, zb = pk.zeros(*i32.linear_p.weight.shape), pk.zeros(i32.linear_p.bias.shape[0])
     d["W_ab32"] = pk.cat([i32.linear_p.weight, zw, i32.linear_c.weight, zw], 0, wd, with_T=True)
@@ -303,7 +305,7 @@ def att_edge_params(m, pk=None):
     d["Wqkv"] = pk.cat([m.linear_q.weight, Wkv[0::2, 1:], Wkv[1::2, 1:]], 0, wd, with_T=True)
     d["bqkv"] = pk.cat([m.linear_q.bias, bkv[0::2], bkv[1::2]])
     d["w_rk"], d["w_rv"] = pk.copy(Wkv[0::2, 0]), pk.copy(Wkv[1::2, 0])
-    d["Wc"], d["bc"] = pk.copy(m.coord_mlp[0].weight, wd, with_T=True), m.coord_mlp[0].bias
+    d["Wc"], d["bc"] = pk.copy(m.coord_mlp[0].weight, wd, with_T=True), pk.copy(m.coord_mlp[0].bias)
     d["w3"] = pk.copy(m.coord_mlp[2].weight[0])
     if own:
         d = pk.resolve(d)
@@ -339,8 +341,8 @@ def _stack_requests(model):
             rows += [blk.linear.weight, blk.linear_g.weight]                 # [4, H] each: lin heads 0-3, gate heads 4-7
             rb += [blk.linear.bias, blk.linear_g.bias]
     P["_rows"], P["_rb"] = pk.cat(rows, 0), pk.cat(rb)                       # [2L * 8, H], [2L * 8]
-    P["W_in"], P["b_in"] = pk.copy(gnn.linear_in.weight, wd, with_T=True), gnn.linear_in.bias
-    P["W_out"], P["b_out"] = pk.copy(gnn.linear_out.weight, wd, with_T=True), gnn.linear_out.bias
+    P["W_in"], P["b_in"] = pk.copy(gnn.linear_in.weight, wd, with_T=True), pk.copy(gnn.linear_in.bias)
+    P["W_out"], P["b_out"] = pk.copy(gnn.linear_out.weight, wd, with_T=True), pk.copy(gnn.linear_out.bias)
     P["gcl"] = [gcl_params(getattr(gnn, "gcl_%d" % i), pk) for i in range(L)]
     P["out_layer"] = gcl_params(gnn.out_layer, pk)
     att = []
@@ -612,7 +614,10 @@ def prefetch(model, X, batch_id, segment_id, compound_edge_index):
     step drains the device at its start (the reads are behind the previous step's backward) and the device idles while the host
     assembles the layout and the parameter pack: 5-7 ms of a 100 ms step at the bench shape."""
     import weakref
-    lay = Layout.of(batch_id, segment_id)
+    # NOT Layout.of: a layout whose index tensors were produced on the feeder stream must reach a consumer only through
+    # _take_prefetched (event wait + record_stream); in Layout._cache a call with a modified X -- which misses the prefetch -- would
+    # pick it up with neither (ADVICE r3)
+    lay = Layout(batch_id, segment_id)
     ex = model.extract_edges
     brow = compound_edge_index[0].to(torch.int32).contiguous()
     bcol = compound_edge_index[1].to(torch.int32).contiguous()
@@ -621,6 +626,7 @@ def prefetch(model, X, batch_id, segment_id, compound_edge_index):
     g._prefetched_bonds = (brow, bcol)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(X.device))
+    _PREFETCHED[:] = [e for e in _PREFETCHED if e[0]() is not None and e[2]() is not None]      # entries of batches that are gone
     _PREFETCHED.insert(0, (weakref.ref(X), X._version, weakref.ref(batch_id), lay, g, ev))
     del _PREFETCHED[4:]
     return lay, g

@@ -3,6 +3,7 @@ device pointers + the current HIP stream.  No math happens here."""
 import ctypes
 import os
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -407,7 +408,7 @@ def gcl_edge_fused_x3(AB, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, n_rows, 
     Wch, Wcl = pack_frag_split(Wc)
     _profiled("gcl_edge_fused_x3_kernel<%d> E=%d (gather + 2 chained H x H split-bf16 contractions + segment-sum per edge)" % (H, E),
               4.0 * E * H * H,
-              lambda: check(_lib.load().fabind_gcl_edge_fused_x3(ptr(AB), _ld(AB), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
+              lambda: check(_lib.load().fabind_gcl_edge_fused_x3(ptr(AB), _ld(AB), AB.shape[0], H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
                                                                  ptr(W2h), ptr(W2l), ptr(b2), ptr(Wch), ptr(Wcl), ptr(bc), ptr(w3), E,
                                                                  ptr(agg), ptr(s), float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd),
                                                                  stream()), "fabind_gcl_edge_fused_x3"))
@@ -567,8 +568,15 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
             segment_sum(dP1[:E], colptr, N, eidx=perm, out16=dAB[:, H:])
         else:
             segment_sum(dP1[:E], colptr, N, eidx=perm, out=dAB[:, H:])
-        dW2 = gemm_tn(dP2[:E], S1[:E], out_dtype=w_dtype)       # (the split reduction writes the dtype autograd carries the weights in)
-        dWc = gemm_tn(dT[:E], Mm[:E], out_dtype=w_dtype)
+        # (the split reduction writes the dtype autograd carries the weights in; small graphs: queued with the step's other weight gradients)
+        if tn_can_queue(dP2[:E], S1[:E], W2.data_ptr()) and tn_can_queue(dT[:E], Mm[:E], Wc.data_ptr()):
+            dW2, dWc = torch.empty((H, H), dtype=w_dtype, device=dev), torch.empty((H, H), dtype=w_dtype, device=dev)
+            gemm_tn_queued(dP2[:E], S1[:E], dW2, key=W2.data_ptr())
+            gemm_tn_queued(dT[:E], Mm[:E], dWc, key=Wc.data_ptr())
+        else:
+            TN_STATS["direct"] += 2
+            dW2 = gemm_tn(dP2[:E], S1[:E], out_dtype=w_dtype)
+            dWc = gemm_tn(dT[:E], Mm[:E], out_dtype=w_dtype)
     else:
         dW2 = torch.zeros((H, H), dtype=w_dtype, device=dev)
         dWc = torch.zeros((H, H), dtype=w_dtype, device=dev)
@@ -611,6 +619,150 @@ def _tn_splits(M, N, E, tn):
         s = best[1] if best else 8
     _TN_SPLITS[key] = s
     return s
+
+
+# ------------------------------------------------------------------------------------------------
+# queued weight-gradient contractions (fabind_gemm_tn_multi)
+# ------------------------------------------------------------------------------------------------
+TN_DEFER = os.environ.get("FABIND_TN_DEFER", "1") == "1"          # 0: every contraction is its own launch pair (round 3's behaviour; A/B)
+TN_DEFER_JOB_BYTES = int(os.environ.get("FABIND_TN_DEFER_JOB_MB", "256")) << 20     # operands larger than this fill the chip alone: launched at once
+TN_DEFER_QUEUE_BYTES = int(os.environ.get("FABIND_TN_DEFER_QUEUE_MB", "4096")) << 20   # operand bytes the queue may keep alive
+_TNQ = {"jobs": [], "bytes": 0, "armed": False, "outs": set()}
+_TNJOB = np.dtype([(n_, np.uint64) for n_ in ("Y", "X", "C_part", "out", "out_tail")] +
+                  [(n_, np.int32) for n_ in ("ldy", "ldx", "M", "N", "E", "splits", "e_per", "n_tiles", "with_colsum", "out_dt", "ldo",
+                                             "wg0", "n_wg", "blk0", "n_blk", "pad_")])        # = _lib.TnJob / FabindTnJob
+TN_STATS = {"queued": 0, "flushes": 0, "direct": 0}
+
+
+def tn_pending():
+    return len(_TNQ["jobs"])
+
+
+def _tn_multi_splits(E):
+    """Split count of a queued contraction: the queue as a whole fills the chip, so a job is only cut to bound its work-groups'
+    length (<= ~128 k-steps of 32 rows) -- in multiples of 8, which the XCD-aware work-group order of the kernel wants anyway."""
+    return max(8, min(64, (E // 4096 + 7) // 8 * 8))
+
+
+def gemm_tn_queued(Y, X, out, out_tail=None, key=None):
+    """Queue out[:, :] (a [M, N] view, row stride out.stride(0)) = Y^T X (and out_tail[M] fp32 = Y^T 1) for the next `tn_flush()`.
+    The outputs are NOT valid until then: ops.py registers flush hooks on every weight whose gradient is queued, and a callback at the
+    end of the backward pass (`_tn_arm`).  key: identity of the weight the result is a gradient of -- a second gradient for the same
+    weight while the first is still queued means autograd is about to ADD the two tensors: the caller must flush first."""
+    E, M = Y.shape
+    N = X.shape[1]
+    nb = (Y.numel() + X.numel()) * 2
+    q = _TNQ
+    q["jobs"].append((Y, X, out, out_tail, M, N, E))
+    q["bytes"] += nb
+    if key is not None:
+        q["outs"].add(key)
+    TN_STATS["queued"] += 1
+    if q["bytes"] > TN_DEFER_QUEUE_BYTES:
+        tn_flush()
+
+
+def _tn_end_of_backward():
+    _TNQ["armed"] = False
+    tn_flush()
+
+
+def tn_arm():
+    """Make sure the queue is flushed when the running backward pass ends (gradients that land in `.grad` without passing a hooked
+    tensor).  -> False outside a backward pass: nothing may be queued then."""
+    if _TNQ["armed"]:
+        return True
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(_tn_end_of_backward)
+    except RuntimeError:
+        return False
+    _TNQ["armed"] = True
+    return True
+
+
+def _tn_flush_hook(_g):
+    tn_flush()
+
+
+def tn_hook(*weights):
+    """Forward-time half of the queue's contract: a tensor hook on every weight (and bias) whose gradient the backward pass may
+    queue.  The hook runs when autograd has that tensor's gradient complete and is about to hand it to the tensor's producer (the
+    parameter pack's adjoint, a torch op composing weights, AccumulateGrad) -- i.e. before anything READS it -- and flushes the queue.
+    (A LEAF handed to an op directly flushes at every such op: AccumulateGrad clones a gradient tensor somebody else still holds --
+    the queue does -- so even a first accumulation reads it.  The engines route weights AND biases through the parameter pack, whose
+    adjoint is then the one flush point of the pass.)"""
+    if not TN_DEFER:
+        return
+    for W in weights:
+        if W is not None and W.requires_grad and not getattr(W, "_fab_tnq", False):
+            W.register_hook(_tn_flush_hook)
+            W._fab_tnq = True
+
+
+def tn_can_queue(Y, X, key=None):
+    """Is this contraction one for the queue?  (bf16 operands on the 256 x 256 kernel layout, not large enough to fill the chip alone,
+    no gradient for the same weight already waiting.)"""
+    if not TN_DEFER or (Y.numel() + X.numel()) * 2 > TN_DEFER_JOB_BYTES or _lib.load().fabind_gemm_tn_tile_n() != 256:
+        return False
+    if key is not None and key in _TNQ["outs"]:
+        tn_flush()
+        return False
+    return tn_arm()
+
+
+def tn_flush():
+    """Launch everything queued by gemm_tn_queued: one contraction launch over all jobs + one reduction launch."""
+    q = _TNQ
+    jobs, q["jobs"], q["bytes"], q["outs"] = q["jobs"], [], 0, set()
+    if not jobs:
+        return
+    from .param_pack import _upload
+    dev = jobs[0][0].device
+    zp = _ZERO_PAGE.get(dev)
+    if zp is None:
+        zp = _ZERO_PAGE[dev] = torch.zeros(256, dtype=torch.bfloat16, device=dev)
+    n = len(jobs)
+    # long work-groups first: the tail of the launch is made of the short ones
+    jobs.sort(key=lambda j_: -(j_[6] // _tn_multi_splits(j_[6])))
+    tab = np.zeros(n, dtype=_TNJOB)
+    E = np.array([j_[6] for j_ in jobs], dtype=np.int64)
+    M = np.array([j_[4] for j_ in jobs], dtype=np.int64)
+    N = np.array([j_[5] for j_ in jobs], dtype=np.int64)
+    cs = np.array([j_[3] is not None for j_ in jobs], dtype=np.int64)
+    sp = np.maximum(8, np.minimum(64, (E // 4096 + 7) // 8 * 8))
+    per = M * N + cs * M
+    tab["Y"], tab["X"] = [j_[0].data_ptr() for j_ in jobs], [j_[1].data_ptr() for j_ in jobs]
+    tab["out"] = [j_[2].data_ptr() for j_ in jobs]
+    tab["out_tail"] = [j_[3].data_ptr() if j_[3] is not None else 0 for j_ in jobs]
+    tab["ldy"], tab["ldx"] = [j_[0].stride(0) for j_ in jobs], [j_[1].stride(0) for j_ in jobs]
+    tab["ldo"], tab["out_dt"] = [j_[2].stride(0) for j_ in jobs], [dt_code(j_[2].dtype) for j_ in jobs]
+    tab["M"], tab["N"], tab["E"], tab["splits"], tab["with_colsum"] = M, N, E, sp, cs
+    tab["e_per"] = ((E + sp - 1) // sp + 31) // 32 * 32
+    tab["n_tiles"] = ((M + 255) // 256) * ((N + 255) // 256)
+    n_wg = tab["n_tiles"].astype(np.int64) * ((sp + 7) // 8 * 8)
+    n_blk = (per + 4095) // 4096
+    tab["n_wg"], tab["n_blk"] = n_wg, n_blk
+    tab["wg0"], tab["blk0"] = np.cumsum(n_wg) - n_wg, np.cumsum(n_blk) - n_blk
+    wg, blk = int(n_wg.sum()), int(n_blk.sum())
+    psz = sp * per
+    part = torch.empty(int(psz.sum()), dtype=torch.float32, device=dev)
+    tab["C_part"] = part.data_ptr() + 4 * (np.cumsum(psz) - psz)
+    jb = tab.view(np.uint8)
+    wg_job = np.repeat(np.arange(n, dtype=np.int32), n_wg)
+    blk_job = np.repeat(np.arange(n, dtype=np.int32), n_blk)
+    pad = (-jb.shape[0]) % 16
+    flat = np.concatenate([jb, np.zeros(pad, dtype=np.uint8), wg_job.view(np.uint8), blk_job.view(np.uint8)])
+    tdev = _upload(flat, dev)
+    p0 = tdev.data_ptr()
+    p_wg = p0 + jb.shape[0] + pad
+    launch = lambda: check(_lib.load().fabind_gemm_tn_multi(p0, tab.ctypes.data, n, p_wg, wg, p_wg + 4 * wg_job.shape[0], blk,
+                                                            ptr(zp), stream()), "fabind_gemm_tn_multi")
+    if PROFILE is None:
+        launch()
+    else:
+        _profiled("fabind_gemm_tn_multi jobs=%d" % n, sum(2.0 * j_[4] * j_[5] * j_[6] for j_ in jobs), launch)
+    TN_STATS["flushes"] += 1
+    del tdev, part, jobs
 
 
 def gemm_tn(Y, X, splits=None, out_dtype=torch.float32, with_colsum=False):

@@ -64,25 +64,42 @@ def _tn_ok(dpre, x, x2):
             and dpre.stride(0) % 8 == 0 and x.stride(0) % 8 == 0 and dpre.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0)
 
 
-def _weight_grad(dpre, x, act_pro, x2=None, out_dtype=torch.float32, want_db=False):
+def _tn_queue(dpre, x, x2, out_dtype, want_db, W):
+    """The TN contraction(s) of one weight gradient put on the queue of kernels.tn_flush (bf16 operands) -> (dW, db) whose contents
+    become valid at the flush; None when the contraction is not one for the queue (large operands, no backward pass running, ...)."""
+    if W is None or not K.tn_can_queue(dpre, x if x2 is None or x.numel() >= x2.numel() else x2, W.data_ptr()):
+        return None
+    M, K1, K2 = dpre.shape[1], x.shape[1], (x2.shape[1] if x2 is not None else 0)
+    dW = torch.empty((M, K1 + K2), dtype=out_dtype, device=dpre.device)
+    db = torch.empty(M, dtype=torch.float32, device=dpre.device) if want_db else None
+    K.gemm_tn_queued(dpre, x, dW[:, :K1] if K2 else dW, db, key=W.data_ptr())
+    if K2:
+        K.gemm_tn_queued(dpre, x2, dW[:, K1:], None, key=W.data_ptr())
+    return dW, db
+
+
+def _weight_grad(dpre, x, act_pro, x2=None, out_dtype=torch.float32, want_db=False, W=None):
     """dW = dpre^T [act(x) | x2] as out_dtype.  bf16: TN contraction with LDS transpose reads (no transposed copies), its split
     reduction writing out_dtype directly; fp32 parity mode / odd widths: explicit transposes + split-K NT GEMMs over the (padded)
     row dimension.  want_db: -> (dW, db) with db = dpre^T 1 (fp32) -- from the SAME contraction launches when the TN path runs
-    (`fabind_gemm_tn(..., with_colsum)`; the split reduction writes dW as out_dtype and db as fp32), a separate column sum otherwise."""
+    (`fabind_gemm_tn(..., with_colsum)`; the split reduction writes dW as out_dtype and db as fp32), a separate column sum otherwise.
+    W: the weight this is the gradient of (a tensor `kernels.tn_hook` was called on in forward): contractions that do not fill the chip
+    alone are queued and run with the rest of the backward pass's weight gradients as one launch (kernels.tn_flush)."""
     if not want_db:
-        return _weight_grad_f32(dpre, x, act_pro, x2, out_dtype)
+        return _weight_grad_f32(dpre, x, act_pro, x2, out_dtype, W)
     if FUSE_DB_TN and act_pro == K.ACT_NONE and _x3_tn_ok(dpre, x, x2) and dpre.shape[1] % 4 == 0:
-        return _x3_weight_grad(dpre, x, x2, out_dtype, True)
+        return _x3_weight_grad(dpre, x, x2, out_dtype, True, W)
     if FUSE_DB_TN and act_pro == K.ACT_NONE and _tn_ok(dpre, x, x2):
+        q = _tn_queue(dpre, x, x2, out_dtype, True, W)
+        if q is not None:
+            return q
         dW, db = K.gemm_tn(dpre, x, out_dtype=out_dtype, with_colsum=True)
         if x2 is not None:
             dW = torch.cat([dW, K.gemm_tn(dpre, x2, out_dtype=out_dtype)], 1)
         return dW, db
-    return _weight_grad_f32(dpre, x, act_pro, x2, out_dtype), K.colsum(dpre)
+    return _weight_grad_f32(dpre, x, act_pro, x2, out_dtype, W), K.colsum(dpre)
 
 
-X3_WGRAD_BF16 = os.environ.get("FABIND_X3_WGRAD", "bf16") == "bf16"
-X3_PAIRBIAS_BWD_BF16 = os.environ.get("FABIND_X3_PAIRBIAS_BWD", "bf16") == "bf16"
 
 
 def _x3_tn_ok(dpre, x, x2):
@@ -91,9 +108,9 @@ def _x3_tn_ok(dpre, x, x2):
     with heavy cancellation, so single-bf16 operands cost ~2e-3 of the entry -- the level at which this mode's gradients differ
     from exact fp32 anyway (a ReLU unit whose pre-activation sits within the 2^-17 forward error of zero flips its derivative;
     tests/test_gpu_headline.py prints both) -- against explicit transposes + three-MFMA contractions at 4x the time.  The forward
-    pass and the activation-gradient chain stay split-bf16.  FABIND_X3_WGRAD=x3 restores the split contraction."""
+    pass and the activation-gradient chain stay split-bf16.  config.set_x3_backward('exact') (or FABIND_X3_WGRAD=x3) restores the split contraction."""
     f32 = torch.float32
-    return (X3_WGRAD_BF16 and _cfg.get_precision() == "bf16x3" and dpre.dtype == f32 and x.dtype == f32 and (x2 is None or x2.dtype == f32)
+    return (_cfg.x3_backward_bf16() and _cfg.get_precision() == "bf16x3" and dpre.dtype == f32 and x.dtype == f32 and (x2 is None or x2.dtype == f32)
             and dpre.shape[1] % 8 == 0 and x.shape[1] % 8 == 0 and (x2 is None or x2.shape[1] % 8 == 0) and dpre.shape[0] >= 256)
 
 
@@ -113,22 +130,29 @@ def _b16_copy(x):
     return y
 
 
-def _x3_weight_grad(dpre, x, x2, out_dtype, want_db):
+def _x3_weight_grad(dpre, x, x2, out_dtype, want_db, W=None):
     """-> (dW, db or None): the 'bf16x3' weight gradient on bf16 roundings (see _x3_tn_ok); db rides along as the TN kernel's column sums."""
     d16 = dpre.to(torch.bfloat16)
+    x16, x216 = _b16_copy(x), (_b16_copy(x2) if x2 is not None else None)
+    q = _tn_queue(d16, x16, x216, out_dtype, want_db, W)
+    if q is not None:
+        return q
     if want_db:
-        dW, db = K.gemm_tn(d16, _b16_copy(x), out_dtype=out_dtype, with_colsum=True)
+        dW, db = K.gemm_tn(d16, x16, out_dtype=out_dtype, with_colsum=True)
     else:
-        dW, db = K.gemm_tn(d16, _b16_copy(x), out_dtype=out_dtype), None
+        dW, db = K.gemm_tn(d16, x16, out_dtype=out_dtype), None
     if x2 is not None:
-        dW = torch.cat([dW, K.gemm_tn(d16, _b16_copy(x2), out_dtype=out_dtype)], 1)
+        dW = torch.cat([dW, K.gemm_tn(d16, x216, out_dtype=out_dtype)], 1)
     return dW, db
 
 
-def _weight_grad_f32(dpre, x, act_pro, x2, out_dtype):
+def _weight_grad_f32(dpre, x, act_pro, x2, out_dtype, W=None):
     if act_pro == K.ACT_NONE and _x3_tn_ok(dpre, x, x2):
-        return _x3_weight_grad(dpre, x, x2, out_dtype, False)[0]
+        return _x3_weight_grad(dpre, x, x2, out_dtype, False, W)[0]
     if act_pro == K.ACT_NONE and _tn_ok(dpre, x, x2):
+        q = _tn_queue(dpre, x, x2, out_dtype, False, W)
+        if q is not None:
+            return q[0]
         if x2 is None:
             return K.gemm_tn(dpre, x, out_dtype=out_dtype)
         return torch.cat([K.gemm_tn(dpre, x, out_dtype=out_dtype), K.gemm_tn(dpre, x2, out_dtype=out_dtype)], 1)
@@ -159,6 +183,15 @@ def _mul_dact(dy, aux, act, out_dtype, scale=1.0):
 
 
 FUSE_DB = os.environ.get("FABIND_FUSE_DB", "1") == "1"
+DB_IN_TN_ROWS = int(os.environ.get("FABIND_DB_IN_TN_ROWS", "32768"))
+
+
+def _db_in_tn(dy):
+    """Should a Linear's bias gradient ride with its (queued) weight-gradient contraction instead of with the pass over dy?  On small
+    batches yes: the pass then is a plain cast / activation adjoint -- one launch instead of the column-partials pair -- and the column
+    sums cost the queued contraction nothing visible; on large ones the fused pass is the cheaper place (its partials are free next
+    to 300 MB of traffic, the contraction's VALU slots are not)."""
+    return K.TN_DEFER and dy.shape[0] <= DB_IN_TN_ROWS and dy.dtype in (torch.float32, torch.bfloat16) and mm_dtype() == torch.bfloat16
 
 
 def _mul_dact_colsum(dy, aux, act, out_dtype, scale=1.0):
@@ -252,6 +285,8 @@ class _Linear(torch.autograd.Function):
         db = None
         want_db = ctx.has_b and ctx.needs_input_grad[2]
         fuse_db = FUSE_DB and want_db and dy.dim() == 2 and dy.shape[1] % 4 == 0   # bias gradient in the same pass over dy
+        if fuse_db and ctx.needs_input_grad[1] and _db_in_tn(dy):
+            fuse_db = False                                                       # ... or with the queued weight-gradient contraction
         md_op = _mul_dact_colsum if fuse_db else (lambda *a: (_mul_dact(*a), None))      # (dy, aux, act, out dtype[, scale])
         if ctx.act_epi == K.ACT_RELU:
             dpre, db = md_op(dy, y, K.ACT_RELU, md, ctx.drop_scale)
@@ -293,9 +328,9 @@ class _Linear(torch.autograd.Function):
                 else:
                     dx = dfull
         if ctx.needs_input_grad[1] and want_db and db is None:
-            dW, db = _weight_grad(dpre, x, K.ACT_NONE, x2, W.dtype, want_db=True)
+            dW, db = _weight_grad(dpre, x, K.ACT_NONE, x2, W.dtype, want_db=True, W=W)
         elif ctx.needs_input_grad[1]:
-            dW = _weight_grad(dpre, x, K.ACT_NONE, x2, W.dtype)
+            dW = _weight_grad(dpre, x, K.ACT_NONE, x2, W.dtype, W=W)
         if want_db and db is None:
             db = K.colsum(dpre)
         dres = None
@@ -315,6 +350,7 @@ def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, 
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
     if _needs_grad(x, W, b, x2, residual):
         assert act_pro == K.ACT_NONE, "producer-side activations only under autograd"
+        K.tn_hook(W, b)
         holder = [] if _want16(out_dtype, act_epi, want16) else None
         y = _Linear.apply(x, W, b, x2, residual, act_epi, out_dtype, holder, p_drop, seed)
         return _attach_b16(y, holder[0] if holder else None)
@@ -362,22 +398,24 @@ class _MLP2(torch.autograd.Function):
         dy = dy.contiguous()
         md = mm_dtype()
         ni = ctx.needs_input_grad
-        if dy.dtype != md:
+        if dy.dtype != md and ni[4] and _db_in_tn(dy):
+            dy16, db2 = _mul_dact(dy, None, K.ACT_NONE, md), None           # cast only: the bias gradient rides with dW2's contraction
+        elif dy.dtype != md:
             dy16, db2 = _mul_dact_colsum(dy, None, K.ACT_NONE, md)          # one pass: cast + bias gradient
         else:
             dy16, db2 = dy, None
         if ni[4] and db2 is None:
-            dW2, db2 = _weight_grad(dy16, t, K.ACT_NONE, None, W2.dtype, want_db=True)
+            dW2, db2 = _weight_grad(dy16, t, K.ACT_NONE, None, W2.dtype, want_db=True, W=W2)
         else:
-            dW2 = _weight_grad(dy16, t, K.ACT_NONE, None, W2.dtype) if ni[4] else None
+            dW2 = _weight_grad(dy16, t, K.ACT_NONE, None, W2.dtype, W=W2) if ni[4] else None
             db2 = db2 if db2 is not None else K.colsum(dy16)
         aux, dact = (t, K.ACT_RELU) if ctx.act == K.ACT_RELU else (D, K.ACT_STORED_DERIV)
         dpre, _ = K.gemm(dy16, ctx.W2t if ctx.W2t is not None else W2.t().contiguous(), aux=aux, dact=dact, out_dtype=md)      # (dy W2) * act'(pre)
         if ni[2] and ni[3]:
-            dW1, db1 = _weight_grad(dpre, xin, K.ACT_NONE, x2in, W1.dtype, want_db=True)
+            dW1, db1 = _weight_grad(dpre, xin, K.ACT_NONE, x2in, W1.dtype, want_db=True, W=W1)
         else:
             db1 = K.colsum(dpre) if ni[3] else None
-            dW1 = _weight_grad(dpre, xin, K.ACT_NONE, x2in, W1.dtype) if ni[2] else None
+            dW1 = _weight_grad(dpre, xin, K.ACT_NONE, x2in, W1.dtype, W=W1) if ni[2] else None
         W1t = ctx.W1t if ctx.W1t is not None else W1.t().contiguous()
         K1 = xin.shape[1]
         dres = dy if (ctx.has_res and ni[6]) else None
@@ -404,6 +442,7 @@ def mlp2(x, W1, b1, act, W2, b2, residual=None, x2=None, want16=False):
     """act([x | x2] W1^T + b1) W2^T + b2 (+ residual) -> fp32.  One autograd node under autograd (see _MLP2); without
     autograd two GEMMs with fused epilogues."""
     if _needs_grad(x, x2, W1, b1, W2, b2, residual):
+        K.tn_hook(W1, b1, W2, b2)
         holder = [] if _want16(torch.float32, K.ACT_NONE, want16) else None
         y = _MLP2.apply(x, x2, W1, b1, W2, b2, residual, act, holder)
         return _attach_b16(y, holder[0] if holder else None)
@@ -447,25 +486,26 @@ class _MLP2Relu(torch.autograd.Function):
         ni = ctx.needs_input_grad
         s = ctx.drop_scale
         db2 = None
+        in_tn = ni[3] and ni[4] and _db_in_tn(dy)
         if ctx.last_act:
-            dpre2, db2 = _mul_dact_colsum(dy, y, K.ACT_RELU, md, s)
+            dpre2, db2 = (_mul_dact(dy, y, K.ACT_RELU, md, s), None) if in_tn else _mul_dact_colsum(dy, y, K.ACT_RELU, md, s)
         elif dy.dtype != md:
-            dpre2, db2 = _mul_dact_colsum(dy, None, K.ACT_NONE, md)
+            dpre2, db2 = (_mul_dact(dy, None, K.ACT_NONE, md), None) if in_tn else _mul_dact_colsum(dy, None, K.ACT_NONE, md)
         else:
             dpre2 = dy
         dW2 = None
         if ni[3] and db2 is None and ni[4]:
-            dW2, db2 = _weight_grad(dpre2, t, K.ACT_NONE, None, W2.dtype, want_db=True)
+            dW2, db2 = _weight_grad(dpre2, t, K.ACT_NONE, None, W2.dtype, want_db=True, W=W2)
         elif ni[3]:
-            dW2 = _weight_grad(dpre2, t, K.ACT_NONE, None, W2.dtype)
+            dW2 = _weight_grad(dpre2, t, K.ACT_NONE, None, W2.dtype, W=W2)
         if ni[4] and db2 is None:
             db2 = K.colsum(dpre2)
         dpre1, _ = K.gemm(dpre2, _wt(W2), aux=t, dact=K.ACT_RELU, alpha=s, out_dtype=md)          # (dpre2 W2) * [t > 0] / (1 - p)
         dW1 = db1 = None
         if ni[1] and ni[2]:
-            dW1, db1 = _weight_grad(dpre1, x, K.ACT_NONE, None, W1.dtype, want_db=True)
+            dW1, db1 = _weight_grad(dpre1, x, K.ACT_NONE, None, W1.dtype, want_db=True, W=W1)
         else:
-            dW1 = _weight_grad(dpre1, x, K.ACT_NONE, None, W1.dtype) if ni[1] else None
+            dW1 = _weight_grad(dpre1, x, K.ACT_NONE, None, W1.dtype, W=W1) if ni[1] else None
             db1 = K.colsum(dpre1) if ni[2] else None
         dx = K.gemm(dpre1, _wt(W1), out_dtype=x.dtype)[0] if ni[0] else None
         dres = None
@@ -480,6 +520,7 @@ def mlp2_relu(x, W1, b1, W2, b2, last_act, residual=None, out_dtype=torch.float3
     """One-node form of relu-Linear -> [dropout] -> Linear (-> relu -> [dropout] | + residual) under autograd; bf16 operands only
     (the caller falls back to chained `linear` nodes otherwise)."""
     seeds = torch.randint(0, 2 ** 31 - 1, (2,)).tolist() if p_drop > 0.0 else (0, 0)
+    K.tn_hook(W1, b1, W2, b2)
     return _MLP2Relu.apply(x, W1, b1, W2, b2, residual, last_act, out_dtype, p_drop, int(seeds[0]), int(seeds[1]))
 
 
@@ -534,7 +575,7 @@ class _LinearRowdot(torch.autograd.Function):
         assert ctx.act_pro == K.ACT_NONE
         Wt = W.t().contiguous()
         dx, _ = K.gemm(dz, Wt, out_dtype=x.dtype)
-        dW, db = _weight_grad(dz, x, K.ACT_NONE, None, W.dtype, want_db=True)
+        dW, db = _weight_grad(dz, x, K.ACT_NONE, None, W.dtype, want_db=True, W=W)
         return dx, dW, db, du, None, None
 
 
@@ -561,9 +602,18 @@ class _LinearRowdotDrop(torch.autograd.Function):
         du = torch.empty(N, dtype=torch.float32, device=z.device)
         check(load().fabind_rowdot_bwd(ptr(z), dt_code(z.dtype), ptr(dps), dps.shape[1], ptr(u), K.ACT_RELU, M, N,
                                        ptr(dz), ptr(du), ptr(scratch), nchunk, stream()), "fabind_rowdot_bwd")
-        dx, _ = K.gemm(dz, _wt(W), out_dtype=x.dtype)
-        dW, db = _weight_grad(dz, x, K.ACT_NONE, None, W.dtype, want_db=True)
-        return dx, dW, db, du / ctx.scale, None, None
+        ni = ctx.needs_input_grad
+        dx = K.gemm(dz, _wt(W), out_dtype=x.dtype)[0] if ni[0] else None
+        dW = db = None
+        if ni[1] and ni[2]:
+            dW, db = _weight_grad(dz, x, K.ACT_NONE, None, W.dtype, want_db=True, W=W)
+        elif ni[1]:
+            dW = _weight_grad(dz, x, K.ACT_NONE, None, W.dtype, W=W)
+        elif ni[2]:
+            db = K.colsum(dz)
+        # (dz was formed from the PRE-scaled dpart, so it carries 1 / (1 - p) once, as it must; du = sum_r dpart z wants the
+        #  unscaled dpart: the kernel's du is divided by the same factor)
+        return dx, dW, db, (du / ctx.scale if ni[3] else None), None, None
 
 
 def linear_rowdot(x, W, b, u, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, p_drop=0.0, fold=None):
@@ -571,8 +621,10 @@ def linear_rowdot(x, W, b, u, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, p_drop=0.0
     fold = (row_mu, row_rs, col_c) (no-grad, bf16 x): LayerNorm of x's rows folded into the epilogue."""
     if _needs_grad(x, W, b, u):
         assert fold is None, "the LayerNorm fold has no autograd path"
+        K.tn_hook(W, b)
         if p_drop > 0.0:
             assert act_pro == K.ACT_NONE and act_epi == K.ACT_RELU, "epilogue dropout under autograd: ReLU outputs only"
+            assert b is not None, "linear_rowdot with epilogue dropout under autograd needs a bias"
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
             return _LinearRowdotDrop.apply(x, W, b, u, p_drop, seed)
         return _LinearRowdot.apply(x, W, b, u, act_pro, act_epi)
@@ -612,13 +664,14 @@ class _EdgeTail(torch.autograd.Function):
             dM, _ = K.gemm(dz, Wt, residual=dagg.contiguous(), r_index=row, out_dtype=Mm.dtype)
         else:
             dM, _ = K.gemm(dz, Wt, out_dtype=Mm.dtype)
-        dW, dbc = _weight_grad(dz, Mm, K.ACT_NONE, None, Wc.dtype, want_db=True)
+        dW, dbc = _weight_grad(dz, Mm, K.ACT_NONE, None, Wc.dtype, want_db=True, W=Wc)
         return dM, dW, dbc, du, None, None, None, None
 
 
 def edge_tail(Mm, Wc, bc, w3, rowptr, row, n_rows, act_epi=K.ACT_SILU):
     """(s_part [E, nt], agg [n_rows, H]) = (row-dot(act(Mm Wc^T + bc), w3), segment_sum(Mm))"""
     if _needs_grad(Mm, Wc, bc, w3):
+        K.tn_hook(Wc, bc)
         return _EdgeTail.apply(Mm, Wc, bc, w3, rowptr, row, n_rows, act_epi)
     part = _gemm_rowdot(Mm, Wc, bc, w3, K.ACT_NONE, act_epi, store=False)[1]
     return part, K.segment_sum(Mm, rowptr, n_rows)
@@ -684,6 +737,8 @@ def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop=0.0):
     """(agg [N,H], s [E,1]) of the fused edge pipeline (bf16, or split bf16 on fp32 AB in 'bf16x3' mode); differentiable.  p_drop > 0:
     dropout on the messages (egnn.py:82) from a counter-based mask keyed by a seed drawn from torch's CPU generator (no device sync)."""
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
+    if _needs_grad(AB16, rhohat, w_r, W2, b2, Wc, bc, w3):
+        K.tn_hook(W2, Wc)                    # (their gradients may be queued: kernels.gcl_edge_fused_bwd)
     if _cfg.get_precision() == "bf16x3":
         if _needs_grad(AB16, rhohat, w_r, W2, b2, Wc, bc, w3):
             return _FusedEdgeX3.apply(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed)
@@ -1268,12 +1323,13 @@ class _InterAttn(torch.autograd.Function):
             md = mm_dtype()
             dpre, dbc = dcv, None
             if dcv.dtype != md:
-                dpre, dbc = _mul_dact_colsum(dcv, None, K.ACT_NONE, md) if FUSE_DB else (_mul_dact(dcv, None, K.ACT_NONE, md), None)
+                in_tn = ctx.needs_input_grad[15] and ctx.needs_input_grad[16] and _db_in_tn(dcv)
+                dpre, dbc = _mul_dact_colsum(dcv, None, K.ACT_NONE, md) if (FUSE_DB and not in_tn) else (_mul_dact(dcv, None, K.ACT_NONE, md), None)
             K.gemm(dpre, Wc.t().contiguous(), out=dqkv[:, 2 * H:], accumulate=True)
             if ctx.needs_input_grad[15] and ctx.needs_input_grad[16] and dbc is None:
-                dWc, dbc = _weight_grad(dpre, v_in, K.ACT_NONE, None, Wc.dtype, want_db=True)
+                dWc, dbc = _weight_grad(dpre, v_in, K.ACT_NONE, None, Wc.dtype, want_db=True, W=Wc)
             elif ctx.needs_input_grad[15]:
-                dWc = _weight_grad(dpre, v_in, K.ACT_NONE, None, Wc.dtype)
+                dWc = _weight_grad(dpre, v_in, K.ACT_NONE, None, Wc.dtype, W=Wc)
             if ctx.needs_input_grad[16]:
                 dbc = dbc if dbc is not None else K.colsum(dpre)
             else:
@@ -1294,6 +1350,7 @@ def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, c
     assert (cv is None) != (Wc is None), "inter_attn: pass either cv or its Linear (Wc, bc)"
     w16 = _cfg.get_precision() == "bf16" and h.is_contiguous()
     if _needs_grad(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, s_ext, Wc, bc):
+        K.tn_hook(Wc, bc)
         holder = [] if w16 else None
         h_out, x_out, alpha = _InterAttn.apply(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext, Wc, bc, holder)
         return _attach_b16(h_out, holder[0] if holder else None), x_out, alpha
@@ -1401,7 +1458,7 @@ class _PairBias(torch.autograd.Function):
         # ('bf16x3': the adjoint of the pair-bias contraction takes the bf16 route too -- see _x3_tn_ok; FABIND_X3_PAIRBIAS_BWD=fp32
         #  restores the fp32 atomics kernels, 30 ms per step at the headline shape)
         mode = _cfg.get_precision()
-        bf16 = (mode == "bf16" or (mode == "bf16x3" and X3_PAIRBIAS_BWD_BF16)) and NO == 8 and H % 8 == 0 and nblk <= 16
+        bf16 = (mode == "bf16" or (mode == "bf16x3" and _cfg.x3_backward_bf16())) and NO == 8 and H % 8 == 0 and nblk <= 16
         if bf16:
             # all blocks at once: the gradients of every block, bf16, concatenated along K and padded per complex (Acat) and
             # the matching b0 * wcomp operand (BTcat) -> d a0 is ONE plain-group GEMM on the pipelined kernel (one accumulating
@@ -1431,6 +1488,7 @@ class _PairBias(torch.autograd.Function):
                                                       stream()), "fabind_batched_transpose_pad")
             check(load().fabind_batched_transpose_pad(ptr(a16), a16.stride(0), ptr(lay.desc_pf), lay.B, 1, H, Pp, ptr(At), stream()),
                   "fabind_batched_transpose_pad")
+            fin_scr = torch.empty(int(load().fabind_pair_bias_finish_scratch(lay.sumC, H)), dtype=torch.float32, device=dev)
         for k, dout in enumerate(douts):
             if dout is None:
                 continue
@@ -1441,7 +1499,8 @@ class _PairBias(torch.autograd.Function):
                 K.gemm(Dt[k], At, out=T, groups=t_g, n_groups=lay.B, max_m=lay.max_C * NO, max_n=H, M=lay.B * Kp, N=lay.B * H, ldc=H,
                        flops=2.0 * lay.n_pairs * NO * H)
                 check(load().fabind_pair_bias_finish(ptr(T), ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.c_index),
-                                                     lay.sumC, ptr(da0b0), ptr(dwcomp[k]), stream()), "fabind_pair_bias_finish")
+                                                     lay.sumC, ptr(da0b0), ptr(dwcomp[k]), ptr(fin_scr), ptr(_ticket(dev)), stream()),
+                      "fabind_pair_bias_finish")
             else:
                 dwk = torch.zeros((lay.B, NO * H), dtype=torch.float32, device=dev)
                 check(load().fabind_pair_bias_bwd(ptr(dout), NO, ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.desc_p),
@@ -1449,6 +1508,17 @@ class _PairBias(torch.autograd.Function):
                                                   ptr(dwk), stream()), "fabind_pair_bias_bwd")
                 dwcomp[k] = K.colsum(dwk).reshape(NO, H)
         return da0b0_ret, dwcomp, dbconst, None, None
+
+
+_TICKETS = {}
+
+
+def _ticket(dev):
+    """Zeroed integer ticket buffer of the 'last work-group reduces' kernels (they leave it zero)."""
+    t = _TICKETS.get(dev)
+    if t is None:
+        t = _TICKETS[dev] = torch.zeros(64, dtype=torch.int32, device=dev)
+    return t
 
 
 def pair_bias(a0b0, H, wcomp, bconst, lay):
@@ -1473,8 +1543,9 @@ class PairBias:
             self.tensors()
 
     def can_fuse(self):
+        # (the kernels assume wcomp[k] rows ordered lin0..3 | gate0..3 for 4 heads of 32 channels: engine._stack_requests builds them so)
         return (K.CROSS_ATTN_FUSED and _cfg.get_precision() == "bf16" and self.lay.max_C <= K.CROSS_ATTN_FUSED_MAX_C
-                and self.H in (64, 128, 256, 512) and self.wcomp.shape[1] == 8)
+                and self.H in (64, 128, 256, 512) and tuple(self.wcomp.shape[1:]) == (8, self.H))
 
     def has_tensors(self):
         return self._tensors is not None

@@ -345,4 +345,6 @@ class _PackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
+        from . import kernels as K
+        K.tn_flush()                              # queued weight-gradient contractions write the tensors this adjoint is about to read
         return (None,) + tuple(ctx.pack._backward(gouts))

@@ -66,7 +66,7 @@ def _mlp(m, pk, k_pad=None, n_pad=None, w2=True):
                 W1=pk.pad2d(w1, n_pad, k_pad, wd, with_T=True), b1=pk.cat([m.linear1.bias, pk.zeros(n_pad - w1.shape[0])]),
                 # (w2 = False: the caller requests linear2's one row itself -- a parameter element may sit in ONE request of a pack)
                 W2=pk.pad2d(m.linear2.weight, m.linear2.weight.shape[0], n_pad, wd, with_T=True) if w2 else None,
-                b2=None if m.linear2.bias is None else m.linear2.bias)
+                b2=None if m.linear2.bias is None else pk.copy(m.linear2.bias))
 
 
 def prepare_stack_params(model):
@@ -114,7 +114,7 @@ def _cam_pack(cam, H, pk=None):
         d["Wqg_" + tag] = pk.cat([a.linear_q.weight, a.linear_g.weight], 0, wd, with_T=True)
         d["bqg_" + tag] = pk.cat([pk.zeros(a.linear_g.bias.shape[0]), a.linear_g.bias])
         d["Wkv_" + tag] = pk.cat([a.linear_k.weight, a.linear_v.weight], 0, wd, with_T=True)
-        d["Wo_" + tag], d["bo_" + tag] = pk.copy(a.linear_o.weight, wd, with_T=True), a.linear_o.bias
+        d["Wo_" + tag], d["bo_" + tag] = pk.copy(a.linear_o.weight, wd, with_T=True), pk.copy(a.linear_o.bias)
     # pair biases of both blocks from z in one GEMM: columns [p lin 0-3 | p gate 4-7 | c lin 8-11 | c gate 12-15]
     pb, cb = cam.p_attention_block, cam.c_attention_block
     d["W_pb"] = pk.cat([pb.linear.weight, pb.linear_g.weight, cb.linear.weight, cb.linear_g.weight], 0, wd, with_T=True)
@@ -129,7 +129,7 @@ def _cam_pack(cam, H, pk=None):
     d["b_ab32"] = pk.cat([i32.linear_p.bias, pk.zeros(n32), i32.linear_c.bias, pk.zeros(n32)])
     wo = i32.linear_out.weight
     d["W_o32"] = pk.cat([wo, pk.zeros(wo.shape[0], wo.shape[1])], 1, wd, with_T=True)                                        # [H, 64]
-    d["b_o32"] = i32.linear_out.bias
+    d["b_o32"] = pk.copy(i32.linear_out.bias)
     if own:
         d = pk.resolve(d)
     if wd == torch.bfloat16 and infer and H in (64, 128, 256, 512) and own:
@@ -215,9 +215,9 @@ def _stack_requests(model, pk):
     P = {"H": H, "L": L}
     P["W_ab0"] = pk.cat([il.linear_p.weight, il.linear_c.weight], 0, wd, with_T=True)
     P["b_ab0"] = pk.cat([il.linear_p.bias, il.linear_c.bias])
-    P["W_o0"], P["b_o0"] = pk.copy(il.linear_out.weight, wd, with_T=True), il.linear_out.bias
-    P["W_in"], P["b_in"] = pk.copy(gnn.linear_in.weight, wd, with_T=True), gnn.linear_in.bias
-    P["W_out"], P["b_out"] = pk.copy(gnn.linear_out.weight, wd, with_T=True), gnn.linear_out.bias
+    P["W_o0"], P["b_o0"] = pk.copy(il.linear_out.weight, wd, with_T=True), pk.copy(il.linear_out.bias)
+    P["W_in"], P["b_in"] = pk.copy(gnn.linear_in.weight, wd, with_T=True), pk.copy(gnn.linear_in.bias)
+    P["W_out"], P["b_out"] = pk.copy(gnn.linear_out.weight, wd, with_T=True), pk.copy(gnn.linear_out.bias)
     P["gcl"] = [_gcl_pack(getattr(gnn, "gcl_%d" % i), H, pk) for i in range(L)]
     P["out_layer"] = _gcl_pack(gnn.out_layer, H, pk)
     P["att"] = [_att_pack(getattr(gnn, "att_%d" % i), H, pk) for i in range(L)]

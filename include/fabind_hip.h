@@ -49,11 +49,14 @@ const char* fabind_last_error(void);
  *     fabind_pair_hadamard_bwd_rows added (the pair-Hadamard adjoint over the inter graph without float atomics);
  *     fabind_layernorm_rows_bwd takes nblk (the caller sizes the partial buffers; the kernel strides rows over that grid).
  * 13 = FabindGemmArgs.r_dtype (bf16 residual operand).  14 = fabind_rows_hadamard_bwd, fabind_node_chain_fwd added.
+ * 15 = fabind_gemm_tn_multi + FabindTnJob (the queued weight-gradient contractions of a backward pass as one launch + one reduction);
+ *     fabind_sizeof_args(3) = sizeof(FabindTnJob); fabind_gcl_edge_fused_x3 takes n_rows (4 GiB bound of its 32-bit gather offsets checked);
+ *     fabind_pair_bias_finish takes (scratch, ticket) and WRITES dw in a fixed order (no float atomics), fabind_pair_bias_finish_scratch.
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 14
+#define FABIND_ABI_VERSION 15
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
- * 2 FabindPairUpdateArgs (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
+ * 2 FabindPairUpdateArgs, 3 FabindTnJob (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
 int fabind_sizeof_args(int which);
 
 /* ---------------------------------------------------------------------------------------------
@@ -122,6 +125,26 @@ int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream);
 int fabind_gemm_tn(const void* Y, int ldy, const void* X, int ldx, float* C_part, int M, int N, int E, int splits,
                    const void* zero_page, const int* groups, int n_groups, int with_colsum, hipStream_t stream);
 /* groups (optional, splits == 1): int32[8] per group {y_off lo/hi (elements), ldy, M, x_row0, E, c_off lo/hi}. */
+
+/* MANY weight-gradient contractions as ONE launch + ONE reduction launch.  Replaces the per-Linear `grad_weight = grad_output^T input`,
+ * `grad_bias = grad_output^T 1` of torch autograd (nn.Linear at egnn.py:40-60,81,104,119,197-208, model_utils.py:83-131,162-175) for a
+ * whole backward pass: the host queues the contractions as their operands become available and flushes the queue before the first
+ * consumer of a result.  On a pocket-sized batch (9,000 nodes) one contraction is 32 work-groups of the 256-CU chip and the step has 89 of
+ * them; together they fill it.
+ * A job: out[m, n] (out_dt, row stride ldo) = sum_e Y[e, m] X[e, n]  and, with_colsum != 0, out_tail[m] (fp32) = sum_e Y[e, m]; bf16
+ * row-major operands; C_part = this job's scratch of splits * (M * N + (with_colsum ? M : 0)) floats.  The contraction kernel is
+ * fabind_gemm_tn's 256 x 256 layout: job j owns work-groups [wg0, wg0 + n_wg) with n_wg = n_tiles * roundup8(splits), wg0 a multiple of
+ * 8 (the XCD-aware order of the single launch holds inside every job), n_tiles = ceil(M / 256) * ceil(N / 256),
+ * e_per = roundup32(ceil(E / splits)); the reduction kernel gives job j blocks [blk0, blk0 + n_blk), n_blk = ceil((M * N (+ M)) / 4096).
+ * jobs_dev / wg_job_dev (int32 job index per work-group) / blk_job_dev (per reduction block) are DEVICE tables, jobs_host the HOST copy
+ * of the same jobs (validated here; the device cannot be read without synchronising). */
+typedef struct FabindTnJob {
+    const void* Y; const void* X; float* C_part; void* out; float* out_tail;
+    int ldy, ldx, M, N, E, splits, e_per, n_tiles, with_colsum, out_dt, ldo;
+    int wg0, n_wg, blk0, n_blk, pad_;
+} FabindTnJob;
+int fabind_gemm_tn_multi(const FabindTnJob* jobs_dev, const FabindTnJob* jobs_host, int n_jobs, const int* wg_job_dev, int total_wg,
+                         const int* blk_job_dev, int total_blk, const void* zero_page, hipStream_t stream);
 
 /* out[C,R] = act(in[R,C])^T -- feeds weight-gradient contractions (autograd of the ops above). */
 int fabind_transpose_act(const void* in, int in_dt, int ldi, void* out, int out_dt, int ldo, int R, int C, int act,
@@ -209,8 +232,9 @@ int fabind_coord_update(const float* x, const float* d, const float* s_part, int
 
 /* The same fused forward edge pipeline (models/egnn.py:68-128) in SPLIT-bf16 arithmetic (precision mode 'bf16x3': fp32-grade results
  * on the bf16 matrix cores, three MFMAs per product term): AB = fp32 [N, 2H]; every packed weight is given as TWO fragment arrays in
- * the layout of fabind_gcl_edge_fused, W..ph = bf16(W) and W..pl = bf16(W - float(W..ph)); agg / s_out / bnd / dropout as there. */
-int fabind_gcl_edge_fused_x3(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
+ * the layout of fabind_gcl_edge_fused, W..ph = bf16(W) and W..pl = bf16(W - float(W..ph)); agg / s_out / bnd / dropout as there.
+ * n_rows = rows of AB (and of agg): n_rows * ldab * 4 bytes must stay below 4 GiB (32-bit gather offsets). */
+int fabind_gcl_edge_fused_x3(const float* AB, int ldab, int n_rows, int H, const int* row, const int* col, const float* rhohat,
                              const float* w_r, const void* W2ph, const void* W2pl, const float* b2, const void* Wcph,
                              const void* Wcpl, const float* bc, const float* w3, int E, float* agg, float* s_out, float p_drop,
                              unsigned seed, float* bnd, hipStream_t stream);
@@ -540,8 +564,12 @@ int fabind_las_step_bwd(const float* x, const float* x0, const float* xo, const 
 int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, int ld, int H, const float* w, const int* desc_p,
                          int B, int max_P, int max_C, const int* p_index, const int* c_index, float* dab, float* dwk,
                          hipStream_t stream);
+/* dab[c_index[jc], H + h] += sum_o w[o,h] T[(jc,o),h];  dw[o,h] = sum_jc ab[c_index[jc], H + h] T[(jc,o),h]  (WRITTEN, fixed summation
+ * order: per-work-group partials in `scratch` -- fabind_pair_bias_finish_scratch(n_c, H) floats -- added by the last work-group to
+ * finish; `ticket` = ceil(H / 256) uints, zero before the first launch, left zero by every launch). */
+int fabind_pair_bias_finish_scratch(int n_c, int H);
 int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, const float* w, const int* c_index, int n_c,
-                            float* dab, float* dw, hipStream_t stream);
+                            float* dab, float* dw, float* scratch, unsigned* ticket, hipStream_t stream);
 void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of the bf16 LDS-DMA GEMM (default 13 = 256x128x32, 3 stages,
                                          two work-groups per CU; 0 = register-staged kernel; 1-9 = other tiles; results do not depend on it) */
 void fabind_gemm_set_persistent(int on); /* development knob: persistent tile walk for long-M/short-K GEMMs */

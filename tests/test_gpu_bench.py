@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(cmd, env=None):
     e = dict(os.environ)
     e.update(env or {})
-    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=420)
+    out = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -59,13 +59,25 @@ def test_bench_self_launches_without_a_launcher():
     assert bad.returncode != 0                                   # a failing child is reported through the exit code
 
 
+SUB_OBJECTS = ("pocket", "gate_mode", "gate_mode_exact_bwd", "fp32", "train_mode", "n_iter8", "n_iter8_gate", "fwd", "model_fwdbwd",
+               "model_gate", "config3_whole_graph", "model_fwdbwd_train_n_iter8", "plus_train", "plus_train_gate", "plus_sampling")
+
+
 def test_bench_line_carries_the_neighbouring_configurations():
-    """Default mode at N=1: fp32 / train-mode / n_iter=8 / forward-only / full-model sub-objects ride in the same JSON line."""
-    r = _run([sys.executable, "bench.py"] + SMALL[:-1])
-    for k in ("fp32", "train_mode", "n_iter8", "fwd", "model_fwdbwd", "model_fwdbwd_train_n_iter8"):
+    """Default mode at N=1: EVERY sub-object of the driver line rides in the same JSON line and none of them is an `{"error": ...}`
+    (bench.py swallows a failing sub-object so that the headline survives; this test is what fails instead -- VERDICT r3 weak 19)."""
+    r = _run([sys.executable, "bench.py", "--poses", "2"] + SMALL[:-1])
+    for k in SUB_OBJECTS:
         assert k in r and "error" not in r[k], (k, r.get(k))
-        assert r[k]["value"] > 0 and r[k]["unit"] == "complexes/s"
+        assert r[k]["value"] > 0 and r[k]["unit"] == ("poses/s" if k == "plus_sampling" else "complexes/s")
+        assert r[k]["steps"] >= 1 and r[k]["ms_per_step"] > 0
     assert r["fp32"]["dtype"] == "fp32" and r["train_mode"]["train_mode"] is True and r["n_iter8"]["n_iter"] == 8
+    for k in ("gate_mode", "gate_mode_exact_bwd", "n_iter8_gate", "model_gate", "plus_train_gate"):
+        assert r[k]["dtype"] == "bf16x3", k
+    assert r["pocket"]["nodes"].startswith("100 protein") and r["pocket"]["pass"] == "fwdbwd"
+    assert r["config3_whole_graph"]["pass"] == "model"
+    # nothing else in the line is an unreported failure either
+    assert not [k for k, v in r.items() if isinstance(v, dict) and "error" in v]
 
 
 def test_rccl_backend_paths_with_one_rank():

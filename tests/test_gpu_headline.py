@@ -273,3 +273,60 @@ def test_bench_batch_properties(bench_batch, prec, tol_equiv, tol_h, tol_single)
         assert es < tol_single and ehs < 1e-4
     finally:
         engine.set_precision("fp32")
+
+
+# measured (round 4): see DESIGN section 2 -- printed by the test
+@pytest.mark.parametrize("prec,tol_in,tol_par", [("bf16", 2e-2, 6e-2), ("bf16x3", 2e-3, 3e-2)])
+def test_bench_batch_backward_properties(bench_batch, prec, tol_in, tol_par):
+    """(iv) the BACKWARD pass of the B = 64 step bench.py times: (a) two runs of forward + backward give bit-identical
+    input and parameter gradients (no float atomics on the path: every adjoint reduction has a fixed order); (b) complexes are
+    independent: for a loss that reads complex 0's outputs only, the gradient of every OTHER complex's input rows is exactly zero and
+    complex 0's input / parameter gradients equal those of the same complex run alone (different reduction shapes: to rounding)."""
+    from fabind_amd import engine
+    dev = torch.device("cuda:0")
+    engine.set_precision(prec)
+    try:
+        m = _model(1).to(dev)
+        params = [p for p in m.parameters()]
+        inp = bench_batch
+        n0 = NP + NL + 2
+
+        def run(batch, only0):
+            for p in params:
+                p.grad = None
+            X, Hh, Hin = _hip(m, batch, dev, grad=True)
+            if only0:
+                loss = (X[:n0] * X[:n0]).sum() + (Hh[:n0] * Hh[:n0]).sum() * 1e-3
+            else:
+                loss = (X * X).mean() + (Hh * Hh).mean() * 1e-6                # bench.py's scalar
+            loss.backward()
+            torch.cuda.synchronize()
+            return Hin.grad.clone(), [None if p.grad is None else p.grad.clone() for p in params]
+
+        # (a) bit-identical repeats of the bench step's gradients
+        gi1, gp1 = run(inp, False)
+        gi2, gp2 = run(inp, False)
+        assert bool(torch.isfinite(gi1).all()) and float(gi1.abs().max()) > 0
+        names = [n_ for n_, _ in m.named_parameters()]
+        diffs = [("input", float((gi1 - gi2).abs().max()))] + [(n_, float((a_ - b_).abs().max())) for n_, a_, b_ in zip(names, gp1, gp2) if a_ is not None]
+        worst = max(d_ for _, d_ in diffs)
+        if worst != 0.0:
+            print("tensors that differ between two runs:", [(n_, "%.2e" % d_) for n_, d_ in diffs if d_ != 0.0][:12])
+        n_grad = sum(1 for g_ in gp1 if g_ is not None)
+        print("%s B=64 fwd+bwd twice: max |difference| over the input gradient and %d parameter gradients: %.3e (%s)"
+              % (prec, n_grad, worst, "bit-identical" if worst == 0.0 else "NOT bit-identical"))
+        assert worst == 0.0
+        # (b) a loss on complex 0 only
+        gi_b, gp_b = run(inp, True)
+        assert float(gi_b[n0:].abs().max()) == 0.0                               # no leakage into the other 63 complexes
+        one = {k: (v[:n0] if torch.is_tensor(v) and v.shape[0] == inp["X"].shape[0] else v) for k, v in inp.items()}
+        one["compound_edge_index"] = inp["compound_edge_index"][:, inp["compound_edge_index"][0] < n0]
+        one["LAS_edge_index"] = inp["LAS_edge_index"][:, inp["LAS_edge_index"][0] < n0]
+        gi_s, gp_s = run(one, True)
+        e_in = float((gi_b[:n0] - gi_s).norm() / gi_s.norm())
+        errs = [float((a_ - b_).float().norm() / (b_.float().norm() + 1e-30)) for a_, b_ in zip(gp_b, gp_s) if a_ is not None and float(b_.abs().max()) > 0]
+        print("%s complex 0 in the B=64 batch vs alone (loss on complex 0 only): input gradient l2 %.3e, parameter gradients l2 worst %.3e "
+              "median %.3e over %d tensors" % (prec, e_in, max(errs), sorted(errs)[len(errs) // 2], len(errs)))
+        assert e_in < tol_in and max(errs) < tol_par
+    finally:
+        engine.set_precision("fp32")

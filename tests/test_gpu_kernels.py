@@ -1159,3 +1159,109 @@ def test_node_chain_forward_matches_two_linears(H, kind, act):
     assert torch.equal(out16.float().cpu(), out.cpu().bfloat16().float())
     out_nr, none16 = K.node_chain_fwd(X1, X2, packs, b1.to(dev), b2.to(dev), code, kind)
     assert none16 is None and float((out_nr.cpu() - (ref - R)).abs().max() / ref.abs().max()) <= 5e-3
+
+
+def test_gemm_tn_multi_matches_single_launches():
+    """fabind_gemm_tn_multi: many weight-gradient contractions as one launch + one reduction (kernels.gemm_tn_queued / tn_flush).  Every
+    job against the single-launch result of the same operands (same kernel code path; split counts differ, so fp32 sums are compared
+    to 1e-5 of the largest entry) and against float64: ragged shapes, column sums, bf16 outputs, two jobs filling the column blocks of
+    one gradient, a column-slice operand."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(9088, 512, 512), (9088, 512, 1024), (2624, 256, 512), (777, 8, 512), (40000, 1024, 576), (85000, 512, 512), (130, 136, 72),
+              (9088, 1536, 512), (31, 64, 64)]
+    jobs, refs = [], []
+    for k, (E, M, N) in enumerate(shapes):
+        Y = (torch.randn(E, M, generator=g) * 0.3 + 0.05).bfloat16().to(dev)
+        X = torch.randn(E, N, generator=g).bfloat16().to(dev)
+        out_dt = torch.bfloat16 if k % 3 == 1 else torch.float32
+        with_cs = k % 2 == 0
+        out = torch.full((M, N), float("nan"), dtype=out_dt, device=dev)
+        tail = torch.full((M,), float("nan"), dtype=torch.float32, device=dev) if with_cs else None
+        K.gemm_tn_queued(Y, X, out, tail)
+        jobs.append((Y, X, out, tail))
+    # two jobs -> the column blocks of one [M, K1 + K2] gradient (the [x | x2] Linear)
+    E, M, K1, K2 = 5000, 512, 512, 64
+    Yc = torch.randn(E, M, generator=g).bfloat16().to(dev)
+    Xa, Xb = torch.randn(E, K1, generator=g).bfloat16().to(dev), torch.randn(E, K2 + 8, generator=g).bfloat16().to(dev)
+    both = torch.full((M, K1 + K2), float("nan"), dtype=torch.float32, device=dev)
+    K.gemm_tn_queued(Yc, Xa, both[:, :K1], None)
+    K.gemm_tn_queued(Yc, Xb[:, 8:], both[:, K1:], None)
+    assert K.tn_pending() == len(shapes) + 2
+    K.tn_flush()
+    assert K.tn_pending() == 0
+    for Y, X, out, tail in jobs:
+        single = K.gemm_tn(Y, X)
+        scale = float(single.abs().max()) + 1e-6
+        tol = 1e-5 if out.dtype == torch.float32 else 8e-3
+        assert float((out.float() - single).abs().max()) <= tol * scale
+        ref = Y.double().T @ X.double()
+        assert float((out.double() - ref).abs().max()) <= (2e-5 if out.dtype == torch.float32 else 8e-3) * float(ref.abs().max()) + 1e-6
+        if tail is not None:
+            cs = Y.double().sum(0)
+            assert float((tail.double() - cs).abs().max()) <= 1e-5 * float(Y.double().abs().sum(0).max()) + 1e-6
+    ref = torch.cat([Yc.double().T @ Xa.double(), Yc.double().T @ Xb[:, 8:].double()], 1)
+    assert float((both.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # a second flush with nothing queued is a no-op; a repeated queue gives bitwise the same result (fixed split order)
+    K.tn_flush()
+    Y, X, out, tail = jobs[0]
+    again = torch.empty_like(out)
+    K.gemm_tn_queued(Y, X, again, torch.empty_like(tail))
+    K.tn_flush()
+    assert torch.equal(again, out)
+
+
+@pytest.mark.parametrize("case", ["composed_weight", "weight_used_twice", "leaf_weight_accumulates", "x2_and_bias"])
+def test_queued_weight_gradients_are_flushed_before_anything_reads_them(case):
+    """The contract of the weight-gradient queue under autograd (ops._tn_queue): a queued gradient is written before its first reader --
+    a torch op that composed the weight from parameters, autograd's own sum when one weight feeds two Linears, the accumulation into
+    an existing .grad, the end of the backward pass.  Each case against the same graph with the queue switched off."""
+    from fabind_amd import config, kernels as K, ops
+    dev = _dev()
+    old = config.get_precision()
+    config.set_precision("bf16")
+    g = torch.Generator().manual_seed(3)
+    n, H = 3000, 128
+    x0 = torch.randn(n, H, generator=g).to(dev)
+    A0 = (torch.randn(H, H, generator=g) * 0.1).to(dev)
+    B0 = (torch.randn(H, H, generator=g) * 0.1).to(dev)
+    b0 = (torch.randn(H, generator=g) * 0.1).to(dev)
+
+    def run(defer):
+        K.TN_DEFER = defer
+        K.TN_STATS.update(queued=0, flushes=0, direct=0)
+        A, B, b = (t.clone().requires_grad_(True) for t in (A0, B0, b0))
+        x = x0.clone().requires_grad_(True)
+        if case == "composed_weight":
+            W = (A @ B).to(torch.bfloat16)                       # MmBackward / ToCopyBackward read dW as soon as it is "ready"
+            y = ops.linear(x, W, b, act_epi=K.ACT_RELU)
+            y = ops.linear(y, B.to(torch.bfloat16), None)
+        elif case == "weight_used_twice":
+            W = A.to(torch.bfloat16)
+            y = ops.linear(ops.linear(x, W, b, act_epi=K.ACT_RELU), W, None) + 0.0 * B.sum()
+        elif case == "leaf_weight_accumulates":
+            Wl = A0.to(torch.bfloat16).clone().requires_grad_(True)   # a leaf consumed directly; .grad already holds a value
+            Wl.grad = torch.ones_like(Wl)
+            y = ops.linear(x, Wl, b) + 0.0 * (A.sum() + B.sum())
+            (y * y).mean().backward()
+            K.TN_DEFER = True
+            return [Wl.grad.float().clone(), b.grad.clone(), x.grad.clone()], dict(K.TN_STATS)
+        else:
+            W = torch.cat([A, B], 1).to(torch.bfloat16)          # [H, 2H]: the [x | x2] Linear, two queued jobs + the bias
+            y = ops.linear(x, W, b, x2=torch.tanh(x), act_epi=K.ACT_SILU)
+        (y * y).mean().backward()
+        K.TN_DEFER = True
+        return [A.grad.clone(), B.grad.clone(), b.grad.clone(), x.grad.clone()], dict(K.TN_STATS)
+
+    try:
+        got, st = run(True)
+        want, st0 = run(False)
+    finally:
+        K.TN_DEFER = True
+        config.set_precision(old)
+    assert st["queued"] >= 1 and st["flushes"] >= 1 and st0["queued"] == 0
+    assert K.tn_pending() == 0
+    for a, b_ in zip(got, want):
+        assert torch.isfinite(a).all()
+        assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max()) + 1e-7

@@ -50,11 +50,14 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()                                        # loads without a GPU (HIP initialises lazily)
     from fabind_amd import _lib as L
     import ctypes
-    assert lib.fabind_abi_version() == L.ABI_VERSION == 14
+    assert lib.fabind_abi_version() == L.ABI_VERSION == 15
     # the ctypes mirrors have the library's struct sizes (load() refuses a mismatch; checked again here explicitly)
-    for which, mirror in enumerate((L.GemmArgs, L.EdgeBwdArgs, L.PairUpdateArgs)):
+    for which, mirror in enumerate((L.GemmArgs, L.EdgeBwdArgs, L.PairUpdateArgs, L.TnJob)):
         assert lib.fabind_sizeof_args(which) == ctypes.sizeof(mirror)
     assert lib.fabind_sizeof_args(99) == -1
+    from fabind_amd import kernels as K
+    assert K._TNJOB.itemsize == ctypes.sizeof(L.TnJob)        # the numpy form of the job table the queue uploads
+    assert [n for n, _ in L.TnJob._fields_] == list(K._TNJOB.names)
     hdr = open(os.path.join(ROOT, "include", "fabind_hip.h")).read()
     names = set(re.findall(r"\b(fabind_[a-z0-9_]+)\s*\(", hdr))
     assert len(names) >= 30
@@ -197,7 +200,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
     special = {"fabind_abi_version", "fabind_sizeof_args", "fabind_gemm_set_config", "fabind_gemm_set_persistent", "fabind_gemm_tn_tile_n",
                "fabind_gemm_x3_occupancy", "fabind_cross_attn_fused_occupancy"}
     protos.update(dict(re.findall(r"\blong\s+(fabind_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)))
-    special.update({"fabind_cross_attn_bwd_scratch", "fabind_pair_bias_cat_parts"})
+    special.update({"fabind_cross_attn_bwd_scratch", "fabind_pair_bias_cat_parts", "fabind_pair_bias_finish_scratch"})
     assert set(protos) - special == set(L.SIGNATURES), (sorted(set(protos) - special - set(L.SIGNATURES)),
                                                          sorted(set(L.SIGNATURES) - set(protos)))
 
