@@ -243,6 +243,8 @@ def main():
     from fabind_amd import engine
     from fabind_amd import kernels as K
     engine.set_precision(a.precision)
+    if os.environ.get("FABIND_BENCH_ST_BACKWARD", "0") == "1":        # A/B knob: backward's Python in the calling thread (no hand-off to autograd's device thread)
+        torch.autograd.set_multithreading_enabled(False)
 
     class _Log:
         def log_message(self, m):

@@ -119,7 +119,8 @@ SIGNATURES = {
                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "fabind_las_step_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp],
     "fabind_pair_bias_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
-    "fabind_pair_bias_finish": [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
+    "fabind_pair_bias_finish": [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _l, _vp],
+    "fabind_pack_frag_multi": [_vp, _vp, _i, _vp],
     "fabind_layernorm_fwd": [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp],
     "fabind_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
 }
@@ -146,7 +147,7 @@ def load():
     lib.fabind_sizeof_args.argtypes, lib.fabind_sizeof_args.restype = [ctypes.c_int], ctypes.c_int
     lib.fabind_cross_attn_bwd_scratch.argtypes, lib.fabind_cross_attn_bwd_scratch.restype = [_i, _i, _i], ctypes.c_long
     lib.fabind_pair_bias_cat_parts.argtypes, lib.fabind_pair_bias_cat_parts.restype = [_i, _i], ctypes.c_long
-    lib.fabind_pair_bias_finish_scratch.argtypes, lib.fabind_pair_bias_finish_scratch.restype = [_i, _i], ctypes.c_int
+    lib.fabind_pair_bias_finish_parts.argtypes, lib.fabind_pair_bias_finish_parts.restype = [_i], ctypes.c_int
     for which, mirror in enumerate((GemmArgs, EdgeBwdArgs, PairUpdateArgs, TnJob)):
         if lib.fabind_sizeof_args(which) != ctypes.sizeof(mirror):
             raise RuntimeError("fabind_amd: ctypes mirror %s is %d bytes, the library's struct is %d -- _lib.py and "

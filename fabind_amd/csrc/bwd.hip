@@ -1448,63 +1448,46 @@ extern "C" int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, 
 }
 
 // finishing pass of the GEMM formulation of the pair-bias adjoint:  T[(jc,o), h] = sum_i D[i,(j,o)] a0[i,h]
-//   db0[node(jc), h] += sum_o w[o,h] T[(jc,o),h];   dw[o,h] = sum_jc b0[node(jc),h] T[(jc,o),h]
-// One work-group = 16 ligand-side nodes x 256 features: the weight gradient is summed over the work-group's nodes in registers and goes
-// to scratch[wg][o][h]; the LAST work-group of a feature block to finish (an integer ticket per block) adds the partials in work-group
-// order and writes dw -- one launch, a fixed summation order, no float atomics (round 3 left ONE float atomic per (o, h) and
-// work-group here: two runs of the same step differed in the last bit of these gradients -- tests/test_gpu_headline.py,
-// test_bench_batch_backward_properties).  (First form: one work-group per node, 8 atomics per node and feature -- 10.7 M float atomics
-// per launch onto 4,096 addresses at the bench shape, 152 us for a 43 MB read; 8 launches per step.)
+//   db0[node(jc), h] += sum_o w[o,h] T[(jc,o),h];   dw_part[wg][o,h] = sum_{jc in wg} b0[node(jc),h] T[(jc,o),h]
+// One work-group = 16 ligand-side nodes x 256 features: the weight gradient is summed over the work-group's nodes in registers and WRITTEN
+// as this work-group's partial row (row stride ld_part: the caller lays the partials of all blocks side by side and sums the rows with
+// ONE fabind_colsum) -- a fixed summation order.  (Round 3 added the partial with one float atomic per (o, h) and work-group: two runs
+// of the same step differed in the last bit of these gradients, tests/test_gpu_headline.py test_bench_batch_backward_properties.  A
+// "last work-group reduces" form with a device-scope fence cost 98 us instead of 14: the fence writes the XCD's L2 back.)
+// (First form: one work-group per node, 8 atomics per node and feature -- 10.7 M float atomics per launch onto 4,096 addresses at the
+// bench shape, 152 us for a 43 MB read; 8 launches per step.)
 constexpr int PBF_NODES = 16;
 __global__ __launch_bounds__(256) void pair_bias_finish_kernel(const float* __restrict__ T, const float* __restrict__ ab, int ld,
                                                                int H, const float* __restrict__ w, const int* c_index, int n_c,
-                                                               float* dab, float* dw, float* scratch, unsigned* ticket) {
+                                                               float* dab, float* dw_part, long ld_part) {
     const int h = blockIdx.y * 256 + threadIdx.x;
+    if (h >= H) return;
     const int j0 = blockIdx.x * PBF_NODES, j1 = min(n_c, j0 + PBF_NODES);
     float wv[8], dwv[8];
-    if (h < H) {
 #pragma unroll
-        for (int o = 0; o < 8; ++o) { wv[o] = w[o * H + h]; dwv[o] = 0.f; }
-        for (int jc = j0; jc < j1; ++jc) {
-            const int cn = c_index[jc];
-            const float bj = ab[(size_t)cn * ld + H + h];
-            float db = 0.f;
+    for (int o = 0; o < 8; ++o) { wv[o] = w[o * H + h]; dwv[o] = 0.f; }
+    for (int jc = j0; jc < j1; ++jc) {
+        const int cn = c_index[jc];
+        const float bj = ab[(size_t)cn * ld + H + h];
+        float db = 0.f;
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                const float t = T[((size_t)jc * 8 + o) * H + h];
-                db += wv[o] * t;
-                dwv[o] += bj * t;
-            }
-            dab[(size_t)cn * ld + H + h] += db;
+        for (int o = 0; o < 8; ++o) {
+            const float t = T[((size_t)jc * 8 + o) * H + h];
+            db += wv[o] * t;
+            dwv[o] += bj * t;
         }
-#pragma unroll
-        for (int o = 0; o < 8; ++o) scratch[((size_t)blockIdx.x * 8 + o) * H + h] = dwv[o];
+        dab[(size_t)cn * ld + H + h] += db;
     }
-    __threadfence();
-    __shared__ unsigned last;
-    __syncthreads();
-    if (threadIdx.x == 0) last = atomicAdd(&ticket[blockIdx.y], 1u);
-    __syncthreads();
-    if (last != gridDim.x - 1) return;
-    __threadfence();
-    if (h < H) {
 #pragma unroll
-        for (int o = 0; o < 8; ++o) dwv[o] = 0.f;
-        for (unsigned g = 0; g < gridDim.x; ++g)
-#pragma unroll
-            for (int o = 0; o < 8; ++o) dwv[o] += __hip_atomic_load(&scratch[((size_t)g * 8 + o) * H + h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // device-coherent read
-#pragma unroll
-        for (int o = 0; o < 8; ++o) dw[o * H + h] = dwv[o];
-    }
-    if (threadIdx.x == 0) ticket[blockIdx.y] = 0u;                 // the ticket buffer is reusable by the next launch on the stream
+    for (int o = 0; o < 8; ++o) dw_part[(size_t)blockIdx.x * ld_part + o * H + h] = dwv[o];
 }
-extern "C" int fabind_pair_bias_finish_scratch(int n_c, int H) { return n_c <= 0 ? 0 : ((n_c + PBF_NODES - 1) / PBF_NODES) * 8 * H; }
+extern "C" int fabind_pair_bias_finish_parts(int n_c) { return n_c <= 0 ? 0 : (n_c + PBF_NODES - 1) / PBF_NODES; }
 extern "C" int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, const float* w, const int* c_index,
-                                       int n_c, float* dab, float* dw, float* scratch, unsigned* ticket, hipStream_t stream) {
+                                       int n_c, float* dab, float* dw_part, long ld_part, hipStream_t stream) {
     if (n_c <= 0) return 0;
-    FB_REQUIRE(scratch && ticket, "fabind_pair_bias_finish: scratch (fabind_pair_bias_finish_scratch floats) and a zeroed ticket buffer (ceil(H/256) uints) are required");
+    FB_REQUIRE(dw_part && ld_part >= 8L * H, "fabind_pair_bias_finish: dw_part [fabind_pair_bias_finish_parts(n_c)] rows of >= 8 * H floats");
     hipLaunchKernelGGL(pair_bias_finish_kernel, dim3((n_c + PBF_NODES - 1) / PBF_NODES, (H + 255) / 256), dim3(256), 0, stream, T, ab, ld, H, w,
-                       c_index, n_c, dab, dw, scratch, ticket);
+                       c_index, n_c, dab, dw_part, ld_part);
     FB_CHECK_LAUNCH();
     return 0;
 }

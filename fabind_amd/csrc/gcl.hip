@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict
     for (int s = 0; s < NSLAB; ++s)
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc[s].v[k] = 0.f;
-    ss_accum<NSLAB, 4>(Z, z_dt, ldz, H, eidx, act, lane, e0, e1, 1, acc);
+    // (8 row loads in flight per lane at H <= 512: a 40-atom ligand's rows hold 40-128 edges, and the walk is bound by the latency of
+    //  its dependent index -> row loads, not by bytes: 103 us per call at the pocket-sized bench shape with 4 in flight)
+    ss_accum<NSLAB, 8 / NSLAB>(Z, z_dt, ldz, H, eidx, act, lane, e0, e1, 1, acc);
 #pragma unroll
     for (int s = 0; s < NSLAB; ++s) {
         const int c = s * 512 + lane * 8;
@@ -371,6 +373,57 @@ extern "C" int fabind_zero_empty_rows(const int* rowptr, int n_rows, void* out, 
     FB_REQUIRE(rowptr != nullptr && out != nullptr, "fabind_zero_empty_rows: rowptr / out");
     hipLaunchKernelGGL(zero_empty_rows_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, rowptr, n_rows, out, out_dt, ld, C, out2,
                        out2_dt, ld2);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Many weights -> bf16 MFMA-fragment order [K/32][N/16][4][16][8] in ONE launch (the operand packs of the fused edge kernels: W2, Wc and
+// their transposes of every GCL layer -- 30 torch permute-copies per training step before).  A segment reads W'[n, k] =
+// src[n * src_sr + k * src_sc] (a transposed source is a stride swap), fp32 or bf16.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_frag_multi_kernel(const FabindPackSeg* __restrict__ segs) {
+    const FabindPackSeg sg = segs[blockIdx.y];
+    const int N = sg.N, Kd = sg.K;
+    const long n_vec = (long)N * Kd / 8;
+    bf16_t* dst = (bf16_t*)sg.dst;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < n_vec; t += (long)gridDim.x * 256) {
+        // t = ((kb * (N / 16) + nb) * 4 + q) * 16 + r
+        const int r = (int)(t & 15), q = (int)((t >> 4) & 3);
+        const long tb = t >> 6;
+        const int nb = (int)(tb % (N / 16)), kb = (int)(tb / (N / 16));
+        const long n = (long)nb * 16 + r, k0 = (long)kb * 32 + q * 8;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float a, b;
+            const long i0 = n * sg.src_sr + (k0 + 2 * j) * sg.src_sc, i1 = i0 + sg.src_sc;
+            if (sg.src_dt == FB_DT_BF16) {
+                a = bf16_to_f32(((const bf16_t*)sg.src)[i0]);
+                b = bf16_to_f32(((const bf16_t*)sg.src)[i1]);
+            } else {
+                a = ((const float*)sg.src)[i0];
+                b = ((const float*)sg.src)[i1];
+            }
+            w[j] = pack2_bf16(a, b);
+        }
+        *(uint4*)(dst + t * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+extern "C" int fabind_pack_frag_multi(const FabindPackSeg* segs_dev, const FabindPackSeg* segs_host, int n_segs, hipStream_t stream) {
+    if (n_segs <= 0) return 0;
+    FB_REQUIRE(segs_dev && segs_host, "fabind_pack_frag_multi: null table");
+    long big = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const FabindPackSeg& g = segs_host[i];
+        FB_REQUIRE(g.src && g.dst && g.N > 0 && g.K > 0 && g.N % 16 == 0 && g.K % 32 == 0 && ((uintptr_t)g.dst % 16 == 0) &&
+                   (g.src_dt == FB_DT_F32 || g.src_dt == FB_DT_BF16), "fabind_pack_frag_multi: N % 16 == 0, K % 32 == 0, 16-byte aligned dst");
+        const long nv = (long)g.N * g.K / 8;
+        big = nv > big ? nv : big;
+    }
+    const int bx = (int)((big + 255) / 256 < 256 ? (big + 255) / 256 : 256);
+    hipLaunchKernelGGL(pack_frag_multi_kernel, dim3(bx, n_segs), dim3(256), 0, stream, segs_dev);
     FB_CHECK_LAUNCH();
     return 0;
 }

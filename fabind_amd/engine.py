@@ -398,7 +398,27 @@ def _build_stack_params(model):
         d["Wcomp1"] = W(pt.linear_1.weight @ Woo)                    # [2H, H+64]
         d["bcomp1"] = (pt.linear_1.weight @ (bo0 + i32.linear_out.bias) + pt.linear_1.bias).contiguous()
         d["u"] = (pt.linear_2.weight.t() @ m.attn_bias_proj.weight[0]).contiguous()   # [2H]
+    _edge_frags(P)
     return P
+
+
+def _edge_frags(P):
+    """Fragment packs of every GCL layer's W2 / Wc (and, when a backward pass will come, their transposes) for the fused edge kernels,
+    ONE launch for the whole model (kernels.pack_frag_multi; 30 torch permute-copies per training step before).  Operand layouts of
+    the pack's bf16 outputs, not differentiable: the gradients of W2 / Wc come out of the fused backward kernel's own contractions."""
+    if get_precision() != "bf16" or P["H"] not in (64, 128, 256, 512):
+        return
+    layers = list(P["gcl"]) + [P["out_layer"]]
+    train = torch.is_grad_enabled() and any(d_["W2"].requires_grad for d_ in layers)
+    with torch.no_grad():
+        ws = []
+        for d_ in layers:
+            W2, Wc = d_["W2"].detach(), d_["Wc"].detach()
+            ws += [W2, Wc] + ([W2.t(), Wc.t()] if train else [])
+        packs = K.pack_frag_multi(ws)
+    n = 4 if train else 2
+    for i, d_ in enumerate(layers):
+        d_["_frags"] = tuple(packs[i * n:(i + 1) * n])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -461,7 +481,8 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
         # messages is a counter-based mask evaluated inside both kernels.
         AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=ad)          # bf16 rows, or fp32 rows for the split-bf16 kernel
         d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay, g.ctx_by_col)
-        agg, s = ops.fused_edge(AB, rhohat, p["w_r"], p["W2"], p["b2"], p["Wc"], p["bc"], p["w3"], H, g, pdrop)
+        agg, s = ops.fused_edge(AB, rhohat, p["w_r"], p["W2"], p["b2"], p["Wc"], p["bc"], p["w3"], H, g, pdrop,
+                                frags=p.get("_frags") if get_precision() == "bf16" else None)
         x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
         if pdrop == 0.0 and not fast:
             # node MLP + residual as one autograd node (activation adjoint and residual gradient inside GEMM epilogues)

@@ -358,6 +358,36 @@ def pack_frag(W):
     return W.to(torch.bfloat16).view(N // 16, 16, Kd // 32, 4, 8).permute(2, 0, 3, 1, 4).contiguous()
 
 
+_PACKSEG = np.dtype([("src", np.uint64), ("dst", np.uint64), ("src_sr", np.int64), ("src_sc", np.int64), ("N", np.int32), ("K", np.int32),
+                     ("src_dt", np.int32), ("pad_", np.int32)])          # = FabindPackSeg
+
+
+def pack_frag_multi(weights):
+    """pack_frag of MANY [N, K] weights (any 2-D views: a transposed view is a stride swap) in one launch (csrc/gcl.hip) -> list of
+    bf16 tensors in fragment order [K/32][N/16][4][16][8]."""
+    from .param_pack import _upload
+    n = len(weights)
+    if n == 0:
+        return []
+    dev = weights[0].device
+    sizes = [W.shape[0] * W.shape[1] for W in weights]
+    buf = torch.empty(sum(sizes), dtype=torch.bfloat16, device=dev)
+    tab = np.zeros(n, dtype=_PACKSEG)
+    off = np.cumsum([0] + sizes[:-1])
+    tab["src"] = [W.data_ptr() for W in weights]
+    tab["dst"] = buf.data_ptr() + 2 * off
+    tab["src_sr"], tab["src_sc"] = [W.stride(0) for W in weights], [W.stride(1) for W in weights]
+    tab["N"], tab["K"] = [W.shape[0] for W in weights], [W.shape[1] for W in weights]
+    tab["src_dt"] = [dt_code(W.dtype) for W in weights]
+    tdev = _upload(tab, dev)
+    check(_lib.load().fabind_pack_frag_multi(tdev.data_ptr(), tab.ctypes.data, n, stream()), "fabind_pack_frag_multi")
+    outs = []
+    for W, o, sz in zip(weights, off, sizes):
+        N, Kd = W.shape
+        outs.append(buf[int(o):int(o) + sz].view(Kd // 32, N // 16, 4, 16, 8))
+    return outs
+
+
 def node_chain_pack(W1, W2, kind):
     """Fragment packs of the H x H blocks of a chain's two weights (see node_chain_fwd): kind 0: W1 [H, 2H], W2 [H, H];
     kind 1: W1 [2H, H], W2 [H, 2H]."""
@@ -501,7 +531,7 @@ EDGE_BWD_TIMES = None   # set to an int64[12] device tensor to collect per-phase
 
 
 def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, dagg, colptr, perm, p_drop=0.0, seed=0,
-                       want_edges=False, dab_bf16=False, w_dtype=torch.float32, rowptr=None):
+                       want_edges=False, dab_bf16=False, w_dtype=torch.float32, rowptr=None, frags=None):
     """Adjoint of gcl_edge_fused (csrc/fused_edge.hip): returns dAB [N,2H] fp32, drh [E], dw_r, dW2, db2, dWc, dbc, dw3.
     The five [E,H] bf16 operands it writes (S1, M, dT, dP2 for the weight gradients, dP1 for the sending-side
     reduction) are scratch that is released on return."""
@@ -546,7 +576,8 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     dagg = dagg.contiguous()
     ds = ds.contiguous()
     a = _lib.EdgeBwdArgs()
-    W2p, Wcp, W2Tp, WcTp = pack_frag(W2), pack_frag(Wc), pack_frag(W2.t()), pack_frag(Wc.t())
+    # frags: (W2p, Wcp, W2Tp, WcTp) packed with the rest of the model's operand packs in one launch (engine._build_stack_params)
+    W2p, Wcp, W2Tp, WcTp = frags if (frags is not None and len(frags) == 4) else (pack_frag(W2), pack_frag(Wc), pack_frag(W2.t()), pack_frag(Wc.t()))
     keep = (W2p, Wcp, W2Tp, WcTp)
     for name, t in (("AB", AB16), ("row", row), ("col", col), ("rhohat", rhohat), ("w_r", w_r), ("W2p", W2p), ("Wcp", Wcp),
                     ("W2Tp", W2Tp), ("WcTp", WcTp), ("b2", b2), ("bc", bc), ("w3", w3), ("ds", ds), ("dagg", dagg),
@@ -640,7 +671,9 @@ def tn_pending():
 
 def _tn_multi_splits(E):
     """Split count of a queued contraction: the queue as a whole fills the chip, so a job is only cut to bound its work-groups'
-    length (<= ~128 k-steps of 32 rows) -- in multiples of 8, which the XCD-aware work-group order of the kernel wants anyway."""
+    length (<= ~128 k-steps of 32 rows) -- in multiples of 8, which the XCD-aware work-group order of the kernel wants anyway.
+    (Measured at the pocket-sized bench shape, 89 jobs: 4 splits for the 9,088-row jobs halve the reduction's partial traffic, 237 -> 159 us,
+    but the contraction launch loses more on its tail, 1,364 -> 1,636 us.)"""
     return max(8, min(64, (E // 4096 + 7) // 8 * 8))
 
 

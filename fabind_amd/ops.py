@@ -682,10 +682,11 @@ class _FusedEdge(torch.autograd.Function):
     no per-edge tensor, the backward recomputes them tile by tile in LDS."""
 
     @staticmethod
-    def forward(ctx, AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed, holder=None):
-        ctx.H, ctx.g, ctx.p_drop, ctx.seed = H, g, p_drop, seed
+    def forward(ctx, AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed, holder=None, frags=None):
+        ctx.H, ctx.g, ctx.p_drop, ctx.seed, ctx.frags = H, g, p_drop, seed, frags
         ctx.save_for_backward(AB16, rhohat, w_r, W2, b2, Wc, bc, w3)
-        out = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3,
+        W2p, Wcp = (frags[0], frags[1]) if frags is not None else (K.pack_frag(W2), K.pack_frag(Wc))
+        out = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, W2p, b2, Wcp, bc, w3,
                                AB16.shape[0], p_drop, seed, want16=holder is not None, rowptr=g.rp_ctx)
         if holder is not None:
             holder.append(out[2])                     # the aggregated messages as the node MLP's bf16 operand (same kernels)
@@ -702,8 +703,8 @@ class _FusedEdge(torch.autograd.Function):
             ds = torch.zeros(g.row_ctx.shape[0], dtype=torch.float32, device=AB16.device)
         dAB, drh, dwr, dW2, db2, dWc, dbc, dw3 = K.gcl_edge_fused_bwd(
             AB16, ctx.H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, ds.reshape(-1).float(), dagg.float(),
-            colptr, perm, ctx.p_drop, ctx.seed, dab_bf16=AB16.dtype == torch.bfloat16, w_dtype=W2.dtype, rowptr=g.rp_ctx)
-        return (dAB.to(AB16.dtype), drh, dwr, dW2.to(W2.dtype), db2, dWc.to(Wc.dtype), dbc, dw3, None, None, None, None, None)
+            colptr, perm, ctx.p_drop, ctx.seed, dab_bf16=AB16.dtype == torch.bfloat16, w_dtype=W2.dtype, rowptr=g.rp_ctx, frags=ctx.frags)
+        return (dAB.to(AB16.dtype), drh, dwr, dW2.to(W2.dtype), db2, dWc.to(Wc.dtype), dbc, dw3, None, None, None, None, None, None)
 
 
 class _FusedEdgeX3(torch.autograd.Function):
@@ -733,8 +734,9 @@ class _FusedEdgeX3(torch.autograd.Function):
         return (dAB, drh, dwr, dW2, db2, dWc, dbc, dw3, None, None, None, None)
 
 
-def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop=0.0):
-    """(agg [N,H], s [E,1]) of the fused edge pipeline (bf16, or split bf16 on fp32 AB in 'bf16x3' mode); differentiable.  p_drop > 0:
+def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop=0.0, frags=None):
+    """(agg [N,H], s [E,1]) of the fused edge pipeline (bf16, or split bf16 on fp32 AB in 'bf16x3' mode); differentiable.  frags
+    (bf16 mode): (W2p, Wcp[, W2Tp, WcTp]) fragment packs made ahead by kernels.pack_frag_multi (all four when a backward will come).  p_drop > 0:
     dropout on the messages (egnn.py:82) from a counter-based mask keyed by a seed drawn from torch's CPU generator (no device sync)."""
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
     if _needs_grad(AB16, rhohat, w_r, W2, b2, Wc, bc, w3):
@@ -747,9 +749,10 @@ def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop=0.0):
     w16 = _cfg.get_precision() == "bf16"
     if _needs_grad(AB16, rhohat, w_r, W2, b2, Wc, bc, w3):
         holder = [] if w16 else None
-        agg, s = _FusedEdge.apply(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed, holder)
+        agg, s = _FusedEdge.apply(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed, holder, frags)
         return _attach_b16(agg, holder[0] if holder else None), s
-    out = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3,
+    W2p, Wcp = (frags[0], frags[1]) if frags is not None else (K.pack_frag(W2), K.pack_frag(Wc))
+    out = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, W2p, b2, Wcp, bc, w3,
                            AB16.shape[0], p_drop, seed, want16=w16, rowptr=g.rp_ctx)
     return (_attach_b16(out[0], out[2]), out[1]) if w16 else out
 
@@ -1453,7 +1456,7 @@ class _PairBias(torch.autograd.Function):
         nblk, NO, _ = wcomp.shape
         dev = a0b0.device
         da0b0, da0b0_ret = _sink_zeros(a0b0, ctx.sink)    # every writer below accumulates (+=, accumulating GEMM, atomics)
-        dwcomp = torch.zeros_like(wcomp)
+        dwcomp = None
         dbconst = torch.zeros((nblk, NO), dtype=torch.float32, device=dev)
         # ('bf16x3': the adjoint of the pair-bias contraction takes the bf16 route too -- see _x3_tn_ok; FABIND_X3_PAIRBIAS_BWD=fp32
         #  restores the fp32 atomics kernels, 30 ms per step at the headline shape)
@@ -1488,7 +1491,9 @@ class _PairBias(torch.autograd.Function):
                                                       stream()), "fabind_batched_transpose_pad")
             check(load().fabind_batched_transpose_pad(ptr(a16), a16.stride(0), ptr(lay.desc_pf), lay.B, 1, H, Pp, ptr(At), stream()),
                   "fabind_batched_transpose_pad")
-            fin_scr = torch.empty(int(load().fabind_pair_bias_finish_scratch(lay.sumC, H)), dtype=torch.float32, device=dev)
+            # per-group partials of every block's d wcomp side by side: [groups of 16 ligand-side nodes, nblk * 8 * H] -> one column sum
+            n_fin = int(load().fabind_pair_bias_finish_parts(lay.sumC))
+            fin = (torch.empty if all(d is not None for d in douts) else torch.zeros)((n_fin, nblk * NO * H), dtype=torch.float32, device=dev)
         for k, dout in enumerate(douts):
             if dout is None:
                 continue
@@ -1499,26 +1504,19 @@ class _PairBias(torch.autograd.Function):
                 K.gemm(Dt[k], At, out=T, groups=t_g, n_groups=lay.B, max_m=lay.max_C * NO, max_n=H, M=lay.B * Kp, N=lay.B * H, ldc=H,
                        flops=2.0 * lay.n_pairs * NO * H)
                 check(load().fabind_pair_bias_finish(ptr(T), ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.c_index),
-                                                     lay.sumC, ptr(da0b0), ptr(dwcomp[k]), ptr(fin_scr), ptr(_ticket(dev)), stream()),
+                                                     lay.sumC, ptr(da0b0), ptr(fin[:, k * NO * H:]), fin.stride(0), stream()),
                       "fabind_pair_bias_finish")
             else:
+                if dwcomp is None:
+                    dwcomp = torch.zeros_like(wcomp)
                 dwk = torch.zeros((lay.B, NO * H), dtype=torch.float32, device=dev)
                 check(load().fabind_pair_bias_bwd(ptr(dout), NO, ptr(a0b0), a0b0.stride(0), H, ptr(wcomp[k]), ptr(lay.desc_p),
                                                   lay.B, lay.max_P, lay.max_C, ptr(lay.p_index), ptr(lay.c_index), ptr(da0b0),
                                                   ptr(dwk), stream()), "fabind_pair_bias_bwd")
                 dwcomp[k] = K.colsum(dwk).reshape(NO, H)
+        if bf16:
+            dwcomp = K.colsum(fin).view(nblk, NO, H)           # fixed order: no float atomics anywhere on this path
         return da0b0_ret, dwcomp, dbconst, None, None
-
-
-_TICKETS = {}
-
-
-def _ticket(dev):
-    """Zeroed integer ticket buffer of the 'last work-group reduces' kernels (they leave it zero)."""
-    t = _TICKETS.get(dev)
-    if t is None:
-        t = _TICKETS[dev] = torch.zeros(64, dtype=torch.int32, device=dev)
-    return t
 
 
 def pair_bias(a0b0, H, wcomp, bconst, lay):

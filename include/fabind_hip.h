@@ -51,7 +51,8 @@ const char* fabind_last_error(void);
  * 13 = FabindGemmArgs.r_dtype (bf16 residual operand).  14 = fabind_rows_hadamard_bwd, fabind_node_chain_fwd added.
  * 15 = fabind_gemm_tn_multi + FabindTnJob (the queued weight-gradient contractions of a backward pass as one launch + one reduction);
  *     fabind_sizeof_args(3) = sizeof(FabindTnJob); fabind_gcl_edge_fused_x3 takes n_rows (4 GiB bound of its 32-bit gather offsets checked);
- *     fabind_pair_bias_finish takes (scratch, ticket) and WRITES dw in a fixed order (no float atomics), fabind_pair_bias_finish_scratch.
+ *     fabind_pair_bias_finish writes per-work-group partials of dw (no float atomics; the caller sums them with fabind_colsum);
+ *     fabind_pack_frag_multi + FabindPackSeg (all fragment packs of a model call in one launch).
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 15
 int fabind_abi_version(void);
@@ -162,6 +163,16 @@ typedef struct FabindCopySeg {
     int vec4, pad_;
 } FabindCopySeg;
 int fabind_multi_copy(const FabindCopySeg* segs_dev, int n_segs, int blocks_per_seg, hipStream_t stream);
+/* Many [N, K] weights (fp32 or bf16; element (n, k) at src[n * src_sr + k * src_sc], so a transposed source is a stride swap) into the
+ * bf16 MFMA-fragment order [K/32][N/16][4][16][8] the fused edge / pair kernels take (fabind_gcl_edge_fused: W2p, Wcp; FabindEdgeBwdArgs:
+ * W2p, Wcp, W2Tp, WcTp), one launch for all.  segs_dev: the table in DEVICE memory, segs_host: the same table on the host (validated). */
+typedef struct FabindPackSeg {
+    const void* src;
+    void* dst;
+    long long src_sr, src_sc;
+    int N, K, src_dt, pad_;
+} FabindPackSeg;
+int fabind_pack_frag_multi(const FabindPackSeg* segs_dev, const FabindPackSeg* segs_host, int n_segs, hipStream_t stream);
 /* out[i] = sum_s part[s * n + i] (fixed order), written as out_dt: the split reduction of fabind_gemm_tn / split-K partials. */
 int fabind_split_sum(const float* part, int splits, long n, void* out, int out_dt, long n_tail, float* out_tail, hipStream_t stream);
 /* n_tail > 0: the LAST n_tail of the n elements are written to out_tail as fp32 instead (a bias gradient behind a bf16 weight gradient). */
@@ -564,12 +575,12 @@ int fabind_las_step_bwd(const float* x, const float* x0, const float* xo, const 
 int fabind_pair_bias_bwd(const float* dout, int NO, const float* ab, int ld, int H, const float* w, const int* desc_p,
                          int B, int max_P, int max_C, const int* p_index, const int* c_index, float* dab, float* dwk,
                          hipStream_t stream);
-/* dab[c_index[jc], H + h] += sum_o w[o,h] T[(jc,o),h];  dw[o,h] = sum_jc ab[c_index[jc], H + h] T[(jc,o),h]  (WRITTEN, fixed summation
- * order: per-work-group partials in `scratch` -- fabind_pair_bias_finish_scratch(n_c, H) floats -- added by the last work-group to
- * finish; `ticket` = ceil(H / 256) uints, zero before the first launch, left zero by every launch). */
-int fabind_pair_bias_finish_scratch(int n_c, int H);
+/* dab[c_index[jc], H + h] += sum_o w[o,h] T[(jc,o),h];  dw_part[g * ld_part + o * H + h] = sum_{jc in group g of 16} ab[c_index[jc], H + h]
+ * T[(jc,o),h] for g < fabind_pair_bias_finish_parts(n_c): per-group partials of the weight gradient, WRITTEN (no float atomics); the
+ * caller sums the rows (fabind_colsum over [parts, ld_part]) -- several blocks' partials side by side take one sum. */
+int fabind_pair_bias_finish_parts(int n_c);
 int fabind_pair_bias_finish(const float* T, const float* ab, int ld, int H, const float* w, const int* c_index, int n_c,
-                            float* dab, float* dw, float* scratch, unsigned* ticket, hipStream_t stream);
+                            float* dab, float* dw_part, long ld_part, hipStream_t stream);
 void fabind_gemm_set_config(int cfg); /* development knob: tile configuration of the bf16 LDS-DMA GEMM (default 13 = 256x128x32, 3 stages,
                                          two work-groups per CU; 0 = register-staged kernel; 1-9 = other tiles; results do not depend on it) */
 void fabind_gemm_set_persistent(int on); /* development knob: persistent tile walk for long-M/short-K GEMMs */

@@ -1264,4 +1264,24 @@ def test_queued_weight_gradients_are_flushed_before_anything_reads_them(case):
     assert K.tn_pending() == 0
     for a, b_ in zip(got, want):
         assert torch.isfinite(a).all()
-        assert float((a - b_).abs().max()) <= 2e-5 * float(b_.abs().max()) + 1e-7
+        # (the queued contraction cuts its rows differently from the single launch, and weight gradients are delivered as bf16 here:
+        #  agreement to a bf16 rounding; an unflushed buffer would be garbage, not 2^-9 off)
+        assert float((a - b_).abs().max()) <= 1e-2 * float(b_.abs().max()) + 1e-7
+
+
+def test_pack_frag_multi_equals_the_torch_permute():
+    """kernels.pack_frag_multi: the fragment packs of many weights (fp32 / bf16, plain and transposed views, several sizes) from one
+    launch are bit-equal to kernels.pack_frag's torch permute-copy of each."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(9)
+    ws = []
+    for (N, Kd, dt) in [(512, 512, torch.bfloat16), (512, 512, torch.float32), (128, 64, torch.bfloat16), (64, 128, torch.float32), (256, 512, torch.bfloat16)]:
+        W = torch.randn(N, Kd, generator=g).to(dt).to(dev)
+        ws += [W, W.t()] if N == Kd or True else [W]
+    ws.append(torch.randn(96, 512 + 64, generator=g).to(dev)[:, 64:])            # a column slice (row stride != width)
+    packs = K.pack_frag_multi(ws)
+    for W, p in zip(ws, packs):
+        ref = K.pack_frag(W.contiguous())
+        assert p.shape == ref.shape and p.dtype == torch.bfloat16
+        assert torch.equal(p, ref)

@@ -167,6 +167,20 @@ def test_iabnet_production_size_matches_oracle(stage):
     print("    bf16: ligand RMSD gap %.3e A (gate 1e-4: %s), loss rel gap %.3e" % (g16, "met" if g16 < 1e-4 else "missed", le16))
     assert g16 < IAB_BF16_BOUND[stage][0] and le16 < IAB_BF16_BOUND[stage][1]
 
+    # ... and in the gate-meeting fast mode (split bf16): the north_star gates themselves, 1e-4 A and 1e-5 relative loss
+    engine.set_precision("bf16x3")
+    try:
+        data = ref["data"].clone().to(dev)
+        with torch.no_grad():
+            o3 = m(data, stage=stage, train=False)
+            l3, _ = compute_loss(o3, data)
+    finally:
+        engine.set_precision("fp32")
+    g3 = rmsd(o3[0].cpu().numpy(), ref["out"][0].numpy())
+    le3 = abs(float(l3) - ref["loss"]) / abs(ref["loss"])
+    print("    bf16x3: ligand RMSD gap %.3e A, loss rel gap %.3e (gates 1e-4 A / 1e-5)" % (g3, le3))
+    assert g3 < 1e-4 and le3 <= 1e-5
+
 
 def test_iabnet_production_size_inference():
     from fabind_amd import engine
@@ -222,7 +236,7 @@ def test_plus_stack_production_size_matches_oracle(n_iter):
     lig = inp["mask"].numpy()
     moved = rmsd(Xr.numpy()[lig] * 5, inp["X"].numpy()[lig] * 5)
     res = {}
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "bf16", "bf16x3"):
         engine.set_precision(prec)
         try:
             with torch.no_grad():
@@ -235,8 +249,9 @@ def test_plus_stack_production_size_matches_oracle(n_iter):
                      float((Z.cpu() - Zr).abs().max()) / max(1.0, float(Zr.abs().max())))
         assert Z.shape == Zr.shape
     print("FABind+ stack 1500/40, hidden 512, 5 layers, n_iter=%d: ligand moved %.3f A; fp32 RMSD vs oracle %.3e A, H %.3e, Z %.3e; "
-          "bf16 gap %.3e A, H %.3e, Z %.3e" % ((n_iter, moved) + res["fp32"] + res["bf16"]))
+          "bf16 gap %.3e A, H %.3e, Z %.3e; bf16x3 gap %.3e A, H %.3e, Z %.3e" % ((n_iter, moved) + res["fp32"] + res["bf16"] + res["bf16x3"]))
     assert moved > 1e-2
+    assert res["bf16x3"][0] < 1e-4 and res["bf16x3"][1] <= 1e-4 and res["bf16x3"][2] <= 1e-4     # the gate-meeting fast mode: the gate itself
     assert res["fp32"][0] < 1e-4 and res["fp32"][1] <= 1e-4 and res["fp32"][2] <= 1e-4
     assert res["bf16"][0] < PLUS_STACK_BF16_BOUND[n_iter] and res["bf16"][1] < 5e-2 and res["bf16"][2] < 5e-2
 
@@ -347,3 +362,16 @@ def test_plus_model_production_size_matches_oracle(stage):
     le16 = abs(float(l16) - ref["loss"]) / abs(ref["loss"])
     print("    bf16: ligand RMSD gap %.3e A, loss rel gap %.3e" % (g16, le16))
     assert g16 < PLUS_BF16_BOUND[stage][0] and le16 < PLUS_BF16_BOUND[stage][1]
+
+    engine.set_precision("bf16x3")                  # the gate-meeting fast mode: 1e-4 A / 1e-5 relative loss
+    try:
+        data = batch()
+        with torch.no_grad():
+            o3 = m(data, stage=stage, train=False)
+            l3, _ = compute_loss(o3, data)
+    finally:
+        engine.set_precision("fp32")
+    g3 = rmsd(o3[0].cpu().numpy(), ref["out"][0].numpy())
+    le3 = abs(float(l3) - ref["loss"]) / abs(ref["loss"])
+    print("    bf16x3: ligand RMSD gap %.3e A, loss rel gap %.3e (gates 1e-4 A / 1e-5)" % (g3, le3))
+    assert g3 < 1e-4 and le3 <= 1e-5
