@@ -131,35 +131,43 @@ def cpu_baseline(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, backward=
     return out
 
 
-def cpu_baseline_full(hidden, layers, n_prot, n_lig, warmups=3, runs=5, batch=2, slow_run_s=40.0):
-    """SURVEY 8(d)'s CPU-baseline protocol: the oracle at B = 2, fp32, eval, forward: torch.set_num_threads(k) for k = the best
-    many-thread setting (32; torch's default of half the host's CPUs is measured next to it) and k = 1; >= 3 warm-ups + 5 timed runs;
-    complexes/s per stack pass (n_iter 1) and per full forward (n_iter 8); plus the forward + backward pass the headline times.
-    A configuration whose single run exceeds `slow_run_s` seconds is timed with 1 warm-up + 3 runs (said in its `protocol`)."""
+def cpu_baseline_full(hidden, layers, n_lig, warmups=3, runs=5, batch=2, slow_run_s=40.0, skip_run_s=150.0):
+    """SURVEY 8(d)'s CPU-baseline protocol: the oracle at B = 2, fp32, eval: torch.set_num_threads(k) for k = the best many-thread
+    setting (32; torch's default of half the host's CPUs is measured next to it on the stack pass) and k = 1; >= 3 warm-ups + 5 timed
+    runs; complexes/s per stack pass (n_iter 1) and per full forward (n_iter 8), at the headline shape (1500 / 40) and at the
+    pocket-sized one (100 / 40); plus the forward + backward pass the headline times.  A configuration whose first run exceeds
+    `slow_run_s` seconds is timed with 1 warm-up + 3 runs, one whose first run exceeds `skip_run_s` is recorded from that single run
+    (both said in its `protocol`): the whole protocol has to fit a GPU box's time limit."""
     default_threads = torch.get_num_threads()
     rows = []
-    for threads in (32, default_threads, 1):
-        for n_iter, backward in ((1, False), (8, False), (1, True)):
-            if threads == default_threads and (n_iter != 1 or backward):
-                continue                                   # (the default thread count is a calibration point, stack pass only)
-            torch.set_num_threads(threads)
-            run = _cpu_run_fn(hidden, layers, n_iter, n_prot, n_lig, batch, backward)
-            t0 = time.time()
-            run()
-            first = time.time() - t0
-            w, r = (warmups, runs) if first <= slow_run_s else (1, 3)
-            for _ in range(w - 1):
-                run()
-            ts = []
-            for _ in range(r):
+    for n_prot in (1500, 100):
+        for threads in (32, default_threads, 1):
+            for n_iter, backward in ((1, False), (8, False), (1, True)):
+                if threads == default_threads and (n_iter != 1 or backward or n_prot != 1500):
+                    continue                               # (the default thread count is a calibration point: stack pass, headline shape)
+                if threads == 1 and backward:
+                    continue
+                torch.set_num_threads(threads)
+                run = _cpu_run_fn(hidden, layers, n_iter, n_prot, n_lig, batch, backward)
                 t0 = time.time()
                 run()
-                ts.append(time.time() - t0)
-            ts.sort()
-            rows.append(dict(threads=threads, n_iter=n_iter, backward=backward, batch=batch, nodes="%d/%d" % (n_prot, n_lig),
-                             complexes_per_s=batch / (sum(ts) / len(ts)), best_run_s=ts[0], worst_run_s=ts[-1],
-                             protocol="%d warm-up(s) + %d timed runs" % (w, r)))
-            print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
+                first = time.time() - t0
+                if first > skip_run_s:
+                    ts, proto = [first], "ONE run (%.0f s; no warm-up)" % first
+                else:
+                    w, r = (warmups, runs) if first <= slow_run_s else (1, 3)
+                    for _ in range(w - 1):
+                        run()
+                    ts = []
+                    for _ in range(r):
+                        t0 = time.time()
+                        run()
+                        ts.append(time.time() - t0)
+                    ts.sort()
+                    proto = "%d warm-up(s) + %d timed runs" % (w, r)
+                rows.append(dict(threads=threads, n_iter=n_iter, backward=backward, batch=batch, nodes="%d/%d" % (n_prot, n_lig),
+                                 complexes_per_s=batch / (sum(ts) / len(ts)), best_run_s=ts[0], worst_run_s=ts[-1], protocol=proto))
+                print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
     torch.set_num_threads(default_threads)
     return dict(kind="port", host_cpus=os.cpu_count(), torch_default_threads=default_threads, rows=rows)
 
@@ -217,7 +225,7 @@ def main():
     a = ap.parse_args()
 
     if a.cpu_baseline_full:
-        print(json.dumps(cpu_baseline_full(a.hidden, a.layers, a.n_prot, a.n_lig)))
+        print(json.dumps(cpu_baseline_full(a.hidden, a.layers, a.n_lig)))
         return
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a.gpus))
@@ -243,7 +251,11 @@ def main():
     from fabind_amd import engine
     from fabind_amd import kernels as K
     engine.set_precision(a.precision)
-    if os.environ.get("FABIND_BENCH_ST_BACKWARD", "0") == "1":        # A/B knob: backward's Python in the calling thread (no hand-off to autograd's device thread)
+    # backward's Python (the adjoint kernels' launch code) runs in the CALLING thread: autograd's default hands every backward pass to a
+    # per-device worker thread, and the two Python threads then trade the interpreter lock launch by launch.  Same-box pairs (round 4,
+    # profiles/r04_ab_same_box.txt): pocket-sized step +8 ... +19 %, full model +1 %, headline +0.7 %.  A process-level torch setting any
+    # training script can make; FABIND_BENCH_ST_BACKWARD=0 restores torch's default for A/B runs.
+    if os.environ.get("FABIND_BENCH_ST_BACKWARD", "1") == "1":
         torch.autograd.set_multithreading_enabled(False)
 
     class _Log:
@@ -348,13 +360,12 @@ def main():
         # there, so their host round trips do not drain the compute stream at the start of the step.  Every step still does all of
         # that work, inside the timed region.
         from fabind_amd import engine as _engine
-        # Measured same-box (profiles/r03_ab_same_box.txt).  While the step still had read-backs in its middle (pair-bias descriptors,
-        # bincounts, boolean-mask indexing) the prefetch only paid forward-only (2,587 -> 2,770 complexes/s); with those gone the host
-        # runs ahead of the device and the step-start read-backs are what is left: fwd+bwd 688.1 / 703.5 / 692.2 -> 715.5 / 711.2 /
-        # 718.1; at the pocket-sized shape the step is host-bound and the boxes' hosts are shared (load average 25 on one): 2,720 /
-        # 2,698 -> 3,019 / 3,137 on one box, 2,726 / 2,878 / 2,740 / 2,964 against 2,222 / 3,083 / 2,914 / 2,741 on another -- no call.
-        # Default: on for the stack modes at protein sizes >= 500; FABIND_BENCH_PREFETCH=1 / 0 forces it.
-        want = (mode in ("fwd", "fwdbwd") and n_prot >= 500) if PREFETCH is None else PREFETCH
+        # Measured same-box.  Round 3 (profiles/r03_ab_same_box.txt): with the read-backs gone from the middle of the step the prefetch paid
+        # at the headline shape (fwd+bwd 688.1 / 703.5 / 692.2 -> 715.5 / 711.2 / 718.1) and was a coin flip at the pocket-sized one, whose
+        # step was host-bound.  Round 4 (profiles/r04_ab_same_box.txt): the pocket-sized step is device-bound once a batch's layout and
+        # graph exist (15.97 ms = 4,007 complexes/s with ONE resident batch), and the step-start read-backs are what a fresh batch costs:
+        # 3,042 / 3,129 -> 3,474 / 3,235 complexes/s with the prefetch.  Default: on for the stack modes; FABIND_BENCH_PREFETCH=1 / 0 forces it.
+        want = (mode in ("fwd", "fwdbwd")) if PREFETCH is None else PREFETCH
         feeder = torch.cuda.Stream(dev) if (want and not LEGACY_BATCH and not REUSE_BATCH) else None
         prefetching[0] = feeder is not None
         pending = []

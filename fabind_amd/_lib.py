@@ -70,6 +70,7 @@ SIGNATURES = {
     "fabind_gcl_edge_fused_set_variant": [_i],
     "fabind_gcl_edge_fused_variant": [],
     "fabind_gcl_edge_fused_bwd_variant": [],
+    "fabind_gcl_edge_fused_bwd_variant_for": [_i],
     "fabind_row_stats": [_vp, _i, _i, _f, _i, _i, _vp, _vp, _vp],
     "fabind_layernorm_rows": [_vp, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _i, _i, _vp],
     "fabind_edge_ln_concat": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _i, _i, _vp],
@@ -121,6 +122,7 @@ SIGNATURES = {
     "fabind_pair_bias_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fabind_pair_bias_finish": [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _l, _vp],
     "fabind_pack_frag_multi": [_vp, _vp, _i, _vp],
+    "fabind_lower_bound": [_vp, _i, _vp, _i, _vp, _vp],
     "fabind_layernorm_fwd": [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp],
     "fabind_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
 }

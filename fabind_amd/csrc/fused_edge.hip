@@ -873,6 +873,7 @@ extern "C" int fabind_gcl_edge_fused_bwd_set_tile(int bm) {
     return 0;
 }
 extern "C" int fabind_gcl_edge_fused_bwd_tile(void) { return g_fe_bwd_bm; }
+static bool g_fe_bwd_variant_set = false;
 static int g_fe_bwd_variant = 5;     // 5 = row-wise / operand-swapped in-place tile + store wave (default, fused_edge_bwd3.hip);
                                      // 0 = two LDS tiles, one work-group per CU (round 1); 1 = single in-place tile, two per CU;
                                      // 2 = single in-place tile of 128 edges, one per CU (H >= 128; half the weight stream per edge)
@@ -880,9 +881,17 @@ extern "C" int fabind_gcl_edge_fused_bwd_set_variant(int v) {
     FB_REQUIRE(v >= 0 && v <= 5,
                "fabind_gcl_edge_fused_bwd_set_variant: 0 (two LDS tiles of 64 edges), 1 / 2 (one in-place tile of 64 / 128), 3 / 4 (row-wise, operand-swapped: 128 / 64), 5 (the same with a store wave, 64 edges)");
     g_fe_bwd_variant = v;
+    g_fe_bwd_variant_set = true;
     return 0;
 }
 extern "C" int fabind_gcl_edge_fused_bwd_variant(void) { return g_fe_bwd_variant; }
+// The variant a launch at hidden size H takes.  Unless a variant was set explicitly, H <= 128 runs the two-tile kernel (variant 0):
+// at H = 128 a 64-edge tile of the store-wave form is two compute waves and thirteen barriers around four 64 x 128 x 128 contractions --
+// the pocket model of the full IaBNet (1 layer + out layer, H = 128, 1.5 M edges of the whole proteins): 2,799 us per call with the
+// store-wave form, 2,138 with the two-tile form (tools/probes/edge_bwd_h128.py); at H = 512 the order is 7,441 / 8,407 us.
+extern "C" int fabind_gcl_edge_fused_bwd_variant_for(int H) {
+    return (!g_fe_bwd_variant_set && g_fe_bwd_variant == 5 && H <= 128) ? 0 : g_fe_bwd_variant;
+}
 
 extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a_in, int H, int n_groups, hipStream_t stream) {
     FabindEdgeBwdArgs a_copy = *a_in;
@@ -892,6 +901,7 @@ extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a_in, int H, i
     FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_gcl_edge_fused_bwd: H must be 64, 128, 256 or 512");
     FB_REQUIRE(a->ldab % 8 == 0, "fabind_gcl_edge_fused_bwd: ldab % 8");
     FB_REQUIRE(a->p_drop >= 0.f && a->p_drop < 1.f, "fabind_gcl_edge_fused_bwd: p_drop in [0, 1)");
+    const int g_fe_bwd_variant = fabind_gcl_edge_fused_bwd_variant_for(H);      // (shadows the file-level setting inside this launch)
     if (g_fe_bwd_variant == 5) return fe_bwd3_launch(a, H, 64, n_groups, stream);
     FB_REQUIRE(a->dAB16 == nullptr, "fabind_gcl_edge_fused_bwd: dAB16 (bf16 receiving-side sums) exists in variant 5 only");
     if (g_fe_bwd_variant == 3 || g_fe_bwd_variant == 4) return fe_bwd2_launch(a, H, g_fe_bwd_variant == 3 ? 128 : 64, n_groups, stream);

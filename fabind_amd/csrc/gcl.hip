@@ -145,7 +145,6 @@ extern "C" int fabind_gcl_pre(const void* AB, int ab_dt, int ldab, int H, const 
 
 // One wave per CSR row (4 rows per work-group): no LDS, no barrier, few registers (8 waves/SIMD).  Each lane owns 8
 // consecutive columns per 512-column slab (16-byte bf16 loads), 4 independent row loads in flight per lane.
-#define SS_HEAVY 128
 template <int NSLAB, int U>
 __device__ __forceinline__ void ss_accum(const void* __restrict__ Z, int z_dt, int ldz, int H, const int* eidx, int act,
                                          int lane, int e0, int e1, int estep, F8 (&acc)[NSLAB]) {
@@ -200,12 +199,12 @@ __device__ __forceinline__ void ss_accum(const void* __restrict__ Z, int z_dt, i
 template <int NSLAB>
 __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict__ Z, int z_dt, int ldz, int H,
                                                           const int* rowptr, const int* eidx, int act, float* out,
-                                                          int ldo, int n_rows, bf16_t* out16, int ldo16) {
+                                                          int ldo, int n_rows, bf16_t* out16, int ldo16, int heavy_min) {
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
     const int e0 = rowptr[r], e1 = rowptr[r + 1];
-    if (e1 - e0 > SS_HEAVY) return;                // left to segment_sum_heavy_kernel
+    if (e1 - e0 > heavy_min) return;               // left to segment_sum_heavy_kernel
     F8 acc[NSLAB];
 #pragma unroll
     for (int s = 0; s < NSLAB; ++s)
@@ -228,13 +227,13 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const void* __restrict
     }
 }
 
-// Rows longer than SS_HEAVY edges (the global nodes of a complex: ~1500 star edges): each 1024-thread work-group scans
+// Rows longer than heavy_min edges (the global nodes of a complex: ~1500 star edges): each 1024-thread work-group scans
 // 1024 row lengths, then its 16 waves reduce every heavy row among them cooperatively (8 row loads in flight per
 // wave), partials combined through LDS in fixed wave order.
 template <int NSLAB>
 __global__ __launch_bounds__(1024) void segment_sum_heavy_kernel(const void* __restrict__ Z, int z_dt, int ldz, int H,
                                                                  const int* rowptr, const int* eidx, int act, float* out,
-                                                                 int ldo, int n_rows, bf16_t* out16, int ldo16, int rpw) {
+                                                                 int ldo, int n_rows, bf16_t* out16, int ldo16, int rpw, int heavy_min) {
     // rpw (<= 1024): rows scanned per work-group.  1,024 suits 1,500-node complexes (one or two heavy rows per work-group); a batch of
     // 142-node complexes has 14 heavy rows per 1,024 and only 9 such work-groups on the whole chip (103 us per call at the
     // pocket-sized bench shape): the host sizes rpw so that the launch has >= ~256 work-groups.
@@ -245,7 +244,7 @@ __global__ __launch_bounds__(1024) void segment_sum_heavy_kernel(const void* __r
     if (threadIdx.x == 0) n_heavy = 0;
     __syncthreads();
     const int rr = blockIdx.x * rpw + threadIdx.x;
-    if ((int)threadIdx.x < rpw && rr < n_rows && rowptr[rr + 1] - rowptr[rr] > SS_HEAVY) heavy[atomicAdd(&n_heavy, 1)] = rr;
+    if ((int)threadIdx.x < rpw && rr < n_rows && rowptr[rr + 1] - rowptr[rr] > heavy_min) heavy[atomicAdd(&n_heavy, 1)] = rr;
     __syncthreads();
     const int nh = n_heavy;
     for (int q = 0; q < nh; ++q) {
@@ -297,13 +296,17 @@ extern "C" int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const
     (void)n_edges;
     int rpw = 1024;
     while (rpw > 64 && (n_rows + rpw - 1) / rpw < 256) rpw >>= 1;
+    // rows one wave sums alone vs rows a 16-wave work-group sums together: 128 edges on large batches (the one-wave rows stream at the HBM
+    // rate, 1,500-edge star rows are the exception); on small ones the launch is as long as its longest one-wave row -- the 128 global
+    // nodes of a pocket-sized batch (101 edges each) made it 90 us for 87 MB, plain or permuted rows alike: 32 there
+    const int heavy_min = n_rows < 32768 ? 32 : 128;
     const dim3 g((n_rows + 3) / 4), gh((n_rows + rpw - 1) / rpw);
     if (H <= 512) {
-        hipLaunchKernelGGL((segment_sum_kernel<1>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16);
-        hipLaunchKernelGGL((segment_sum_heavy_kernel<1>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16, rpw);
+        hipLaunchKernelGGL((segment_sum_kernel<1>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16, heavy_min);
+        hipLaunchKernelGGL((segment_sum_heavy_kernel<1>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16, rpw, heavy_min);
     } else {
-        hipLaunchKernelGGL((segment_sum_kernel<2>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16);
-        hipLaunchKernelGGL((segment_sum_heavy_kernel<2>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16, rpw);
+        hipLaunchKernelGGL((segment_sum_kernel<2>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16, heavy_min);
+        hipLaunchKernelGGL((segment_sum_heavy_kernel<2>), gh, dim3(1024), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16, rpw, heavy_min);
     }
     FB_CHECK_LAUNCH();
     return 0;

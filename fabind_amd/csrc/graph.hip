@@ -156,6 +156,28 @@ extern "C" int fabind_exclusive_scan(const int* in, int* out, int n, hipStream_t
     return 0;
 }
 
+// out[k] = index of the first element of the non-decreasing int32 array `vals` that is >= keys[k] (lower bound; n if none): the
+// per-complex [start, end) offsets of a complex-contiguous edge list from node_off (engine.Layout.ranges: replaces ATen's bucketize ->
+// index_add histogram -> cumsum -> cast chain, five launches of index glue per list).
+__global__ void lower_bound_kernel(const int* __restrict__ vals, int n, const int* __restrict__ keys, int n_keys, int* out) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_keys) return;
+    const int key = keys[k];
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (vals[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    out[k] = lo;
+}
+extern "C" int fabind_lower_bound(const int* vals, int n, const int* keys, int n_keys, int* out, hipStream_t stream) {
+    if (n_keys <= 0) return 0;
+    FB_REQUIRE(keys && out && (n == 0 || vals), "fabind_lower_bound: null pointer");
+    hipLaunchKernelGGL(lower_bound_kernel, dim3((n_keys + 255) / 256), dim3(256), 0, stream, vals, n, keys, n_keys, out);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
 // ---- inter-edge pair bookkeeping ----
 __global__ void red_off_kernel(const int* node_off, const int* c_cnt, int B, const int* rowptr_int, int* red_off) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {

@@ -130,6 +130,11 @@ class Layout:
 
     def ranges(self, idx_first):
         """Per-complex [start,end) offsets of a complex-contiguous edge list given its first-node ids."""
+        if idx_first.is_cuda and idx_first.dtype == torch.int32 and idx_first.is_contiguous():
+            out = torch.empty(self.B + 1, dtype=torch.int32, device=idx_first.device)       # one kernel: a binary search per complex
+            K.check(K._lib.load().fabind_lower_bound(K.ptr(idx_first), idx_first.shape[0], K.ptr(self.node_off), self.B + 1, K.ptr(out),
+                                                     K.stream()), "fabind_lower_bound")
+            return out
         which = torch.bucketize(idx_first, self.node_off[1:].to(idx_first.dtype), right=True)
         cnt = _count(which, self.B)
         out = torch.zeros(self.B + 1, dtype=torch.int32, device=idx_first.device)
@@ -341,6 +346,16 @@ def _stack_requests(model):
             rows += [blk.linear.weight, blk.linear_g.weight]                 # [4, H] each: lin heads 0-3, gate heads 4-7
             rb += [blk.linear.bias, blk.linear_g.bias]
     P["_rows"], P["_rb"] = pk.cat(rows, 0), pk.cat(rb)                       # [2L * 8, H], [2L * 8]
+    # the parameters the pair path only ever uses COMPOSED (pair_transition, the 32-wide Hadamard block's linear_out, attn_bias_proj:
+    # egnn.py:208,286-304, cross_att.py:51-53), stacked over the layers by the same launch: the compositions below are then a handful of
+    # batched products for all layers instead of ~10 small launches per layer each way (~100 of a pocket-sized step's ~800)
+    cams = [getattr(gnn, "att_%d" % i).cross_attn_module for i in range(L)]
+    P["_W1s"] = pk.cat([c.pair_transition.linear_1.weight for c in cams], 0)             # [L * 2H, H]
+    P["_b1s"] = pk.cat([c.pair_transition.linear_1.bias for c in cams])                  # [L * 2H]
+    P["_W2s"] = pk.cat([c.pair_transition.linear_2.weight for c in cams], 0)             # [L * H, 2H]
+    P["_aps"] = pk.cat([getattr(gnn, "att_%d" % i).attn_bias_proj.weight for i in range(L)], 0)   # [L, H]
+    P["_Wis"] = pk.cat([c.inter_layer.linear_out.weight for c in cams], 0)               # [L * H, 32]
+    P["_bis"] = pk.cat([c.inter_layer.linear_out.bias for c in cams])                    # [L * H]
     P["W_in"], P["b_in"] = pk.copy(gnn.linear_in.weight, wd, with_T=True), pk.copy(gnn.linear_in.bias)
     P["W_out"], P["b_out"] = pk.copy(gnn.linear_out.weight, wd, with_T=True), pk.copy(gnn.linear_out.bias)
     P["gcl"] = [gcl_params(getattr(gnn, "gcl_%d" % i), pk) for i in range(L)]
@@ -384,20 +399,24 @@ def _build_stack_params(model):
     rows, rb = P.pop("_rows").view(2 * L, -1, H), P.pop("_rb").view(2 * L, -1)
     P["pb_wcomp"] = (rows @ Wo0).contiguous()                                # z0 = Wo0 (a*b) + bo0 folded in
     P["pb_bconst"] = (rows @ bo0 + rb).contiguous()
-    W = lambda t: t.to(wd).contiguous()
+    # the 32-wide Hadamard block is zero-padded to 64 columns so that K = H + 64 stays a multiple of 64 (LDS-DMA GEMM path); the padded
+    # rows/columns are exact zeros and do not change the result.  Per layer l (all layers at once, batched):
+    #   Wcomp1_l = W1_l [Wo0 | Wi_l | 0]   [2H, H+64];   bcomp1_l = W1_l (bo0 + bi_l) + b1_l   [2H];   u_l = W2_l^T a_l   [2H]
+    W1s, b1s = P.pop("_W1s").view(L, 2 * H, H), P.pop("_b1s").view(L, 2 * H)
+    W2s, aps = P.pop("_W2s").view(L, H, 2 * H), P.pop("_aps").view(L, H)
+    Wis, bis = P.pop("_Wis").view(L, H, -1), P.pop("_bis").view(L, H)
+    n32 = Wis.shape[2]
+    A = (W1s.reshape(L * 2 * H, H) @ Wo0).view(L, 2 * H, H)
+    Bm = torch.bmm(W1s, Wis)
+    Wcomp1 = torch.cat([A, Bm, torch.zeros((L, 2 * H, 64 - n32), dtype=A.dtype, device=A.device)], 2).to(wd)
+    bcomp1 = torch.baddbmm(b1s.unsqueeze(2), W1s, (bo0.unsqueeze(0) + bis).unsqueeze(2)).squeeze(2)
+    u = torch.bmm(W2s.transpose(1, 2), aps.unsqueeze(2)).squeeze(2)
+    Wc_l, bc_l, u_l = Wcomp1.unbind(0), bcomp1.unbind(0), u.unbind(0)        # (unbind: the adjoint is ONE stack of the layers' gradients)
     for i in range(L):
         m = getattr(gnn, "att_%d" % i)
-        cam = m.cross_attn_module
         d = P["att"][i]
         att_edge_composed(m, d)
-        i32 = cam.inter_layer
-        # the 32-wide Hadamard block is zero-padded to 64 columns so that K = H + 64 stays a multiple of 64
-        # (LDS-DMA GEMM path); the padded rows/columns are exact zeros and do not change the result
-        pt = cam.pair_transition
-        Woo = _cat([Wo0, i32.linear_out.weight, torch.zeros_like(i32.linear_out.weight)], 1)   # [H, H+64]
-        d["Wcomp1"] = W(pt.linear_1.weight @ Woo)                    # [2H, H+64]
-        d["bcomp1"] = (pt.linear_1.weight @ (bo0 + i32.linear_out.bias) + pt.linear_1.bias).contiguous()
-        d["u"] = (pt.linear_2.weight.t() @ m.attn_bias_proj.weight[0]).contiguous()   # [2H]
+        d["Wcomp1"], d["bcomp1"], d["u"] = Wc_l[i], bc_l[i], u_l[i]
     _edge_frags(P)
     return P
 

@@ -540,7 +540,7 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     if ng is None:
         ng = _N_CU[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
     lib = _lib.load()
-    variant = lib.fabind_gcl_edge_fused_bwd_variant()
+    variant = lib.fabind_gcl_edge_fused_bwd_variant_for(H)
     if variant == 2 and H < 128:
         variant = 0                                          # the 128-edge tile needs >= 128 threads (one per edge in the row tables)
     bm = {1: 64, 2: 128, 3: 128, 4: 64, 5: 64}.get(variant) or lib.fabind_gcl_edge_fused_bwd_tile()
@@ -656,8 +656,8 @@ def _tn_splits(M, N, E, tn):
 # queued weight-gradient contractions (fabind_gemm_tn_multi)
 # ------------------------------------------------------------------------------------------------
 TN_DEFER = os.environ.get("FABIND_TN_DEFER", "1") == "1"          # 0: every contraction is its own launch pair (round 3's behaviour; A/B)
-TN_DEFER_JOB_BYTES = int(os.environ.get("FABIND_TN_DEFER_JOB_MB", "256")) << 20     # operands larger than this fill the chip alone: launched at once
-TN_DEFER_QUEUE_BYTES = int(os.environ.get("FABIND_TN_DEFER_QUEUE_MB", "4096")) << 20   # operand bytes the queue may keep alive
+TN_DEFER_JOB_BYTES = int(os.environ.get("FABIND_TN_DEFER_JOB_MB", "1024")) << 20     # operands larger than this fill the chip alone: launched at once
+TN_DEFER_QUEUE_BYTES = int(os.environ.get("FABIND_TN_DEFER_QUEUE_MB", "6144")) << 20   # operand bytes the queue may keep alive
 _TNQ = {"jobs": [], "bytes": 0, "armed": False, "outs": set()}
 _TNJOB = np.dtype([(n_, np.uint64) for n_ in ("Y", "X", "C_part", "out", "out_tail")] +
                   [(n_, np.int32) for n_ in ("ldy", "ldx", "M", "N", "E", "splits", "e_per", "n_tiles", "with_colsum", "out_dt", "ldo",

@@ -52,7 +52,7 @@ const char* fabind_last_error(void);
  * 15 = fabind_gemm_tn_multi + FabindTnJob (the queued weight-gradient contractions of a backward pass as one launch + one reduction);
  *     fabind_sizeof_args(3) = sizeof(FabindTnJob); fabind_gcl_edge_fused_x3 takes n_rows (4 GiB bound of its 32-bit gather offsets checked);
  *     fabind_pair_bias_finish writes per-work-group partials of dw (no float atomics; the caller sums them with fabind_colsum);
- *     fabind_pack_frag_multi + FabindPackSeg (all fragment packs of a model call in one launch).
+ *     fabind_pack_frag_multi + FabindPackSeg (all fragment packs of a model call in one launch); fabind_lower_bound.
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 15
 int fabind_abi_version(void);
@@ -199,6 +199,10 @@ int fabind_edges_fill(const float* x, const int* node_off, const int* c_cnt, int
                       int* row_int, hipStream_t stream);
 /* out[0]=0, out[i+1]=out[i]+in[i], i<n (single work-group scan; n up to a few million). */
 int fabind_exclusive_scan(const int* in, int* out, int n, hipStream_t stream);
+/* out[k] = first index i with vals[i] >= keys[k] (n if none), vals non-decreasing int32 [n]: per-complex [start, end) offsets of a
+ * complex-contiguous edge / bond / LAS list from node_off (keys = node_off [B + 1] gives out [B + 1]).  Replaces the bucketize +
+ * histogram + cumsum index glue around att_model.py:37-116 / egnn.py:433-449's per-sample loops. */
+int fabind_lower_bound(const int* vals, int n, const int* keys, int n_keys, int* out, hipStream_t stream);
 /* Inter-edge pair bookkeeping (replaces trio_encoder's index arithmetic, models/egnn.py:286-304):
  * red_off[B+1] = prefix of ligand-row inter edges per complex; for every inter edge e, red_idx[e] =
  * index of its unordered (ligand, protein) pair in the reduced list; red_c/red_p = the pair's nodes;
@@ -300,6 +304,7 @@ int fabind_gcl_edge_fused_bwd_tile(void);
  * evaluate the same arithmetic in the same order per element (outputs equal to 1e-7). */
 int fabind_gcl_edge_fused_bwd_set_variant(int v);
 int fabind_gcl_edge_fused_bwd_variant(void);
+int fabind_gcl_edge_fused_bwd_variant_for(int H);   /* the variant a launch at hidden size H takes: the set one, or -- when none was set explicitly -- 0 for H <= 128 (measured faster there), 5 otherwise.  The caller sizes d2scratch / n_groups from THIS value */
 /* development knob of variants 3 / 4: bit mask of work the kernel SKIPS (results are then wrong -- sensitivity timing only). */
 void fabind_gcl_edge_fused_bwd2_set_exp(int mask);
 void fabind_gcl_edge_fused_bwd3_set_exp(int mask);

@@ -1285,3 +1285,24 @@ def test_pack_frag_multi_equals_the_torch_permute():
         ref = K.pack_frag(W.contiguous())
         assert p.shape == ref.shape and p.dtype == torch.bfloat16
         assert torch.equal(p, ref)
+
+
+def test_layout_ranges_is_a_lower_bound_per_complex():
+    """engine.Layout.ranges on int32 lists (one fabind_lower_bound launch) equals the torch bucketize / histogram / cumsum form it
+    replaced -- ragged complexes, complexes without any entry, an empty list."""
+    from fabind_amd import engine
+    dev = _dev()
+    sizes = [(30, 7), (5, 3), (64, 1), (12, 9)]
+    bid = torch.cat([torch.full((p + c + 2,), b) for b, (p, c) in enumerate(sizes)]).to(dev)
+    seg = torch.cat([torch.cat([torch.zeros(c + 1), torch.ones(p + 1)]) for p, c in sizes]).to(dev)
+    lay = engine.Layout(bid, seg)
+    g = torch.Generator().manual_seed(1)
+    for keep in ([0, 1, 2, 3], [0, 3], [2], []):
+        rows = []
+        for b in keep:
+            lo = int(lay.off[b])
+            rows.append(lo + torch.sort(torch.randint(0, int(lay.n[b]), (11 + 3 * b,), generator=g))[0])
+        idx = (torch.cat(rows) if rows else torch.zeros(0)).to(torch.int32).to(dev)
+        got = lay.ranges(idx)
+        want = lay.ranges(idx.long())                     # int64: the torch path
+        assert got.dtype == torch.int32 and torch.equal(got, want), (keep, got, want)
