@@ -555,6 +555,9 @@ def main():
 
         def sub(name, mode, n_iter, train_mode=False, precision=None, note="", steps=3, warmup=1, n_prot=None, whole_pocket=False,
                 x3_backward="bf16"):
+            only = os.environ.get("FABIND_BENCH_ONLY")             # development knob: comma-separated sub-object names to run
+            if only and name not in only.split(","):
+                return
             prec = precision or a.precision
             engine.set_precision(prec)
             _config.set_x3_backward(x3_backward)
@@ -576,7 +579,10 @@ def main():
             finally:
                 engine.set_precision(a.precision)
                 _config.set_x3_backward("bf16")
-                st = None
+                st = per = _ = pf = None          # (model, batches, events: nothing of this sub-object may live into the next one)
+                import gc
+                gc.collect()
+                torch.cuda.synchronize()
                 torch.cuda.empty_cache()
         sub("pocket", "fwdbwd", a.n_iter, steps=30, warmup=5, n_prot=100,
             note="the headline step at the size the 4-layer stack sees in production (SURVEY 0.4 / 8(d): the 20 A pocket, 100 protein / 40 "
