@@ -298,8 +298,10 @@ extern "C" int fabind_segment_sum(const void* Z, int z_dt, int ldz, int H, const
     while (rpw > 64 && (n_rows + rpw - 1) / rpw < 256) rpw >>= 1;
     // rows one wave sums alone vs rows a 16-wave work-group sums together: 128 edges on large batches (the one-wave rows stream at the HBM
     // rate, 1,500-edge star rows are the exception); on small ones the launch is as long as its longest one-wave row -- the 128 global
-    // nodes of a pocket-sized batch (101 edges each) made it 90 us for 87 MB, plain or permuted rows alike: 32 there
-    const int heavy_min = n_rows < 32768 ? 32 : 128;
+    // nodes of a pocket-sized batch (101 edges each) made it 90 us for 87 MB, plain or permuted rows alike: 32 there (53 us).  (Not for
+    // the 18,000-row batches of the full model's pocket crop / FABind+ training: there thousands of ligand rows hold 33-128 edges, and
+    // sending them all through the cooperative kernel cost FABind+ training +2.4 ms per step.)
+    const int heavy_min = n_rows < 16384 ? 32 : 128;
     const dim3 g((n_rows + 3) / 4), gh((n_rows + rpw - 1) / rpw);
     if (H <= 512) {
         hipLaunchKernelGGL((segment_sum_kernel<1>), g, dim3(256), 0, stream, Z, z_dt, ldz, H, rowptr, eidx, act, out, ldo, n_rows, out16, ldo16, heavy_min);

@@ -276,6 +276,9 @@ __device__ __forceinline__ void gemm_epilogue_fast(const FabindGemmArgs& p, f32x
             cv[j] = col < N ? p.col_c[col] : 0.f;
         }
     }
+    // (Round 4 tried value AND derivative of the SiLU from ONE sigmoid per element, the two half-tiles staged side by side and flushed
+    //  together: 429 us per [98,688 x 1024] -> 512 launch against 268 us for this form -- the fully unrolled two-output body does not fit
+    //  the 128-VGPR budget of the two-work-groups-per-CU build and spills; reverted, tools/probes/gemm_node_epi.py.)
     if (HAS_C2) {                          // derivative tile first (uses the staging buffer), then the value tile
 #pragma unroll
         for (int i = 0; i < 4; ++i)
