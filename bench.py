@@ -326,17 +326,43 @@ def main():
             hb = synthetic.make_hetero_batch([(n_prot, a.n_lig)] * a.batch, seed=rank,
                                              **({"pocket_radius": 1e9} if whole_pocket else {})).to(dev)
             params = list(model.parameters())
+            # The batch of step k + 1 "arrives" on a feeder stream while step k runs (what fabind_amd.data.DeviceFeeder does for a real
+            # loader) and model.plan_stage1 builds, there, everything the forward would otherwise read back from the device in the middle
+            # of the step: gather indices, pair lists, both stack models' layouts and input-coordinate graphs (~18 queue drains per
+            # step).  All of that work still happens every step, inside the timed region.  FABIND_BENCH_PLAN=0: no plan (A/B).
+            use_plan = os.environ.get("FABIND_BENCH_PLAN", "1") == "1"
+            feeder = torch.cuda.Stream(dev) if use_plan else None
+            pending = []
+
+            def arrive():
+                if feeder is None:
+                    return hb.clone(), None
+                with torch.cuda.stream(feeder):
+                    data = hb.clone()
+                    plan = model.plan_stage1(data)
+                return data, plan
 
             def step():
                 for p in params:
                     p.grad = None
-                data = hb.clone()
-                out = model(data, stage=1, train=train_mode)
+                if not pending:
+                    pending.append(arrive())
+                data, plan = pending.pop()
+                if plan is not None:
+                    cur = torch.cuda.current_stream(dev)
+                    cur.wait_event(plan["event"])
+                    for st_ in list(data._stores.values()) + [data._glob]:       # tensors made on the feeder stream, used on this one
+                        for v_ in st_.values():
+                            if torch.is_tensor(v_) and v_.is_cuda:
+                                v_.record_stream(cur)
+                out = model(data, stage=1, train=train_mode, plan=plan)
                 loss, _ = compute_loss(out, data)
                 loss.backward()
                 if world > 1:
                     from fabind_amd import parallel
                     parallel.allreduce_gradients(params, world)
+                if feeder is not None:
+                    pending.append(arrive())                 # the next batch arrives while this step's kernels are still queued
             return step, a.batch, params
         model = build_model(a.hidden, a.layers, n_iter, dropout=0.1 if train_mode else 0.0).to(dev)
         model.train(train_mode)

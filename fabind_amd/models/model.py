@@ -82,8 +82,10 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
     def _lin(self, lin, x, **kw):
         return ops.linear(x.float().contiguous(), lin.weight.to(ops.mm_dtype()), lin.bias, **kw)
 
-    def _assemble(self, segment, is_global, c_emb, p_emb):
-        """[glb_c | ligand | glb_p | protein] per complex as one gather (replaces model.py:104-115)."""
+    @staticmethod
+    def _assemble_index(segment, is_global, n_c, n_p):
+        """(gather index into [glb_c | glb_p | c_emb | p_emb], ligand-atom rows, residue rows) of a complex layout: index glue that
+        depends on the batch only (two read-backs: `plan_stage1` builds it ahead of the step)."""
         seg1 = segment.bool() if not segment.is_floating_point() else segment > 0.5
         N = seg1.shape[0]
         idx = torch.empty(N, dtype=torch.long, device=seg1.device)
@@ -94,21 +96,18 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         # again behind the model's forward pass, and once more in its backward
         cf = torch.nonzero(~seg1 & ~is_global).squeeze(1)
         pf = torch.nonzero(seg1 & ~is_global).squeeze(1)
-        idx[cf] = 2 + torch.arange(c_emb.shape[0], device=idx.device)
-        idx[pf] = 2 + c_emb.shape[0] + torch.arange(p_emb.shape[0], device=idx.device)
+        idx[cf] = 2 + torch.arange(n_c, device=idx.device)
+        idx[pf] = 2 + n_c + torch.arange(n_p, device=idx.device)
+        return idx, cf, pf
+
+    def _assemble(self, segment, is_global, c_emb, p_emb, index=None):
+        """[glb_c | ligand | glb_p | protein] per complex as one gather (replaces model.py:104-115)."""
+        idx, cf, pf = index if index is not None else self._assemble_index(segment, is_global, c_emb.shape[0], p_emb.shape[0])
         return torch.cat([self.glb_c, self.glb_p, c_emb, p_emb], 0).index_select(0, idx), cf, pf
 
-    def _pocket_head(self, data):
-        """Whole-protein pocket model + classifier (model.py:98-141)."""
-        w = data['complex_whole_protein']
-        c_emb = self._lin(self.compound_linear_whole_protein, data['compound'].node_feats)
-        p_emb = self._lin(self.protein_linear_whole_protein, data['protein_whole'].node_feats)
-        h0, cf, pf = self._assemble(w.segment, w.is_global, c_emb, p_emb)
-        h0 = self._lin(self.embedding_shrink, h0)
-        Xw = self.normalize_coord(w.node_coords.unsqueeze(-2)).float()
-        Xl = self.normalize_coord(w.node_coords_LAS.unsqueeze(-2)).float()
-        # the padded [B, Lmax] bookkeeping of the classifier reads two sizes back: done BEFORE the pocket model is queued, so that
-        # nothing waits behind its forward pass
+    @staticmethod
+    def _classifier_index(data):
+        """Padded [B, Lmax] bookkeeping of the pocket classifier (model.py:138-144): batch-only, two read-backs."""
         pb = data['protein_whole'].batch
         B = int(pb[-1].item()) + 1
         cnt = torch.bincount(pb, minlength=B)
@@ -118,6 +117,78 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         mask[pb, loc] = True
         xyz = torch.zeros(B, Lmax, 3, dtype=data.node_xyz_whole.dtype, device=pb.device)
         xyz[pb, loc] = data.node_xyz_whole
+        return dict(pb=pb, B=B, cnt=cnt, loc=loc, Lmax=Lmax, mask=mask, xyz=xyz)
+
+    @torch.no_grad()
+    def plan_stage1(self, data):
+        """Everything a STAGE-1 forward needs that depends on the batch alone and costs a host round trip: the gather indices of both
+        complex layouts, the classifier's padded bookkeeping, the (pocket, ligand) pair lists, the output-row indices, and -- through
+        `engine.prefetch` -- the batch layouts and the ctx / inter graphs of the input coordinates of BOTH stack models.  A forward
+        without a plan reads ~18 sizes back at 18 points of the step, each one a drain of the launch queue (the host cannot run ahead of
+        the device, and the device idles while the host catches up: 51 ms per step for 45.5 ms of kernels at the bench shape).
+        Call it on the data feeder's stream while the previous step is still running, hand the result to `forward(data, stage=1,
+        plan=...)`: the forward then waits for the plan's event on the device and makes no host round trip of its own (stage 1 only:
+        stage 2 crops the pocket around a PREDICTED centre).  The tensors of `data` must not be replaced between the two calls."""
+        from .. import engine
+        p = {}
+        w, cx, cb = data['complex_whole_protein'], data['complex'], data['compound'].batch
+        n_c, n_pw = data['compound'].node_feats.shape[0], data['protein_whole'].node_feats.shape[0]
+        p['keep_idx'] = torch.nonzero(data['pocket'].keepNode).squeeze(1)
+        p['asm_w'] = self._assemble_index(w.segment, w.is_global, n_c, n_pw)
+        p['cls'] = self._classifier_index(data)
+        p['Xw'] = self.normalize_coord(w.node_coords.unsqueeze(-2)).float()
+        p['Xl_w'] = self.normalize_coord(w.node_coords_LAS.unsqueeze(-2)).float()
+        engine.prefetch(self.pocket_pred_model, p['Xw'], w.batch, w.segment,
+                        data['complex_whole_protein', 'c2c', 'complex_whole_protein'].edge_index)
+        p['asm_c'] = self._assemble_index(cx.segment, cx.is_global, n_c, p['keep_idx'].shape[0])
+        B = p['cls']['B']
+        pkb = data['pocket'].batch
+        p['pairs'] = self._pair_lists(pkb, cb, torch.bincount(pkb, minlength=B), torch.bincount(cb, minlength=B))
+        seg1 = cx.segment.bool() if not cx.segment.is_floating_point() else cx.segment > 0.5
+        p['cidx'] = torch.nonzero(~seg1 & ~cx.is_global).squeeze(1)
+        p['pidx'] = torch.nonzero(seg1 & ~cx.is_global).squeeze(1)
+        p['Xn'] = self.normalize_coord(cx.node_coords.unsqueeze(-2)).float()
+        p['Xl'] = self.normalize_coord(cx.node_coords_LAS.unsqueeze(-2)).float()
+        engine.prefetch(self.complex_model, p['Xn'], cx.batch, cx.segment, data['complex', 'c2c', 'complex'].edge_index)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(cb.device))
+        p['event'] = ev
+        return p
+
+    @staticmethod
+    def _adopt_plan(plan, device):
+        """The current stream waits for the plan; the allocator learns that the plan's tensors (made on another stream) are used here."""
+        if plan.get('_adopted'):
+            return
+        cur = torch.cuda.current_stream(device)
+        cur.wait_event(plan['event'])
+
+        def rec(v):
+            if torch.is_tensor(v):
+                if v.is_cuda:
+                    v.record_stream(cur)
+            elif isinstance(v, dict):
+                for u in v.values():
+                    rec(u)
+            elif isinstance(v, (tuple, list)):
+                for u in v:
+                    rec(u)
+        rec({k: v for k, v in plan.items() if k != 'event'})
+        plan['_adopted'] = True
+
+    def _pocket_head(self, data, plan=None):
+        """Whole-protein pocket model + classifier (model.py:98-141)."""
+        w = data['complex_whole_protein']
+        c_emb = self._lin(self.compound_linear_whole_protein, data['compound'].node_feats)
+        p_emb = self._lin(self.protein_linear_whole_protein, data['protein_whole'].node_feats)
+        h0, cf, pf = self._assemble(w.segment, w.is_global, c_emb, p_emb, index=plan['asm_w'] if plan else None)
+        h0 = self._lin(self.embedding_shrink, h0)
+        Xw = plan['Xw'] if plan else self.normalize_coord(w.node_coords.unsqueeze(-2)).float()
+        Xl = plan['Xl_w'] if plan else self.normalize_coord(w.node_coords_LAS.unsqueeze(-2)).float()
+        # the padded [B, Lmax] bookkeeping of the classifier reads two sizes back: done BEFORE the pocket model is queued, so that
+        # nothing waits behind its forward pass (or ahead of the step altogether: plan_stage1)
+        ci = plan['cls'] if plan else self._classifier_index(data)
+        pb, B, cnt, loc, Lmax, mask, xyz = ci['pb'], ci['B'], ci['cnt'], ci['loc'], ci['Lmax'], ci['mask'], ci['xyz']
         _, hw = self.pocket_pred_model(
             Xw, h0, batch_id=w.batch, segment_id=w.segment, mask=w.mask, is_global=w.is_global,
             compound_edge_index=data['complex_whole_protein', 'c2c', 'complex_whole_protein'].edge_index,
@@ -220,16 +291,19 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         ci = _offsets(ncnt)[pocket_batch][pi] + j
         return pi, ci
 
-    def _complex_and_heads(self, data, g):
+    def _complex_and_heads(self, data, g, plan=None):
         scale = self.coordinate_scale
         cb = data['compound'].batch
-        Xn = self.normalize_coord(g['X'].unsqueeze(-2)).float()
-        Xl = self.normalize_coord(g['XL'].unsqueeze(-2)).float()
-        # the row indices of the ligand atoms / pocket residues are read back BEFORE the complex model is queued: boolean-mask indexing
-        # of its outputs would read their counts back behind its whole forward pass (three queue drains per step)
-        seg1 = g['segment'].bool() if not g['segment'].is_floating_point() else g['segment'] > 0.5
-        cidx = torch.nonzero(~seg1 & ~g['is_global']).squeeze(1)
-        pidx = torch.nonzero(seg1 & ~g['is_global']).squeeze(1)
+        if plan:
+            Xn, Xl, cidx, pidx = plan['Xn'], plan['Xl'], plan['cidx'], plan['pidx']
+        else:
+            Xn = self.normalize_coord(g['X'].unsqueeze(-2)).float()
+            Xl = self.normalize_coord(g['XL'].unsqueeze(-2)).float()
+            # the row indices of the ligand atoms / pocket residues are read back BEFORE the complex model is queued: boolean-mask indexing
+            # of its outputs would read their counts back behind its whole forward pass (three queue drains per step)
+            seg1 = g['segment'].bool() if not g['segment'].is_floating_point() else g['segment'] > 0.5
+            cidx = torch.nonzero(~seg1 & ~g['is_global']).squeeze(1)
+            pidx = torch.nonzero(seg1 & ~g['is_global']).squeeze(1)
         Xo, Ho = self.complex_model(Xn, g['H'], batch_id=g['batch'], segment_id=g['segment'], mask=g['mask'],
                                     is_global=g['is_global'], compound_edge_index=g['c2c'], LAS_edge_index=g['LAS'],
                                     batched_complex_coord_LAS=Xl, LAS_mask=None)
@@ -255,10 +329,17 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         return y_pred, y_by
 
     # ---- reference API ------------------------------------------------------------------------
-    def forward(self, data, stage=1, train=False):
+    def forward(self, data, stage=1, train=False, plan=None):
+        """plan (optional, not in the reference's signature): the result of `plan_stage1(data)` built ahead of the step; used when the
+        forward takes the stage-1 path, ignored otherwise."""
         cb = data['compound'].batch
-        keep_idx = torch.nonzero(data['pocket'].keepNode).squeeze(1) if (stage == 1 or self.pocket_pred_model.training) else None
-        head = self._pocket_head(data)
+        if plan is not None:
+            self._adopt_plan(plan, cb.device)
+        if plan is not None:
+            keep_idx = plan['keep_idx']
+        else:
+            keep_idx = torch.nonzero(data['pocket'].keepNode).squeeze(1) if (stage == 1 or self.pocket_pred_model.training) else None
+        head = self._pocket_head(data, plan)
         training = self.pocket_pred_model.training
         center = self._soft_center(head['logits'], head['mask'], head['xyz'], noise=training)
         pocket_cls = torch.zeros_like(head['mask'], dtype=data.pocket_idx.dtype)
@@ -276,15 +357,19 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         else:
             cx = data['complex']
             pemb = head['p_out'].index_select(0, keep_idx if keep_idx is not None else torch.nonzero(data['pocket'].keepNode).squeeze(1))
-            H, _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], pemb)
+            H, _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], pemb, index=plan['asm_c'] if plan else None)
+
             g = dict(H=H, X=cx.node_coords, XL=cx.node_coords_LAS, segment=cx.segment, mask=cx.mask,
                      is_global=cx.is_global, batch=cx.batch, c2c=data['complex', 'c2c', 'complex'].edge_index,
                      LAS=data['complex', 'LAS', 'complex'].edge_index, pocket_xyz=data.node_xyz,
                      pocket_batch=data['pocket'].batch, dis_map=data.dis_map, less5=0)
+        stage1_plan = plan if (plan is not None and final_stage != 2) else None
+        if stage1_plan is not None:
+            g['pairs'] = plan['pairs']
         if g.get('pairs') is None:        # (the pair lists read a size back: built before the complex model is queued)
             B = head['B']
             g['pairs'] = self._pair_lists(g['pocket_batch'], cb, torch.bincount(g['pocket_batch'], minlength=B), torch.bincount(cb, minlength=B))
-        Ho, cidx, pidx, coords_n = self._complex_and_heads(data, g)
+        Ho, cidx, pidx, coords_n = self._complex_and_heads(data, g, stage1_plan)
         y_pred, y_by = self._dist_heads(data, g, Ho, cidx, pidx, coords_n)
         return (self.unnormalize_coord(coords_n), cb, y_pred, y_by, head['logits'] * head['mask'], pocket_cls,
                 head['mask'], head['xyz'], center, g['dis_map'], g['less5'])

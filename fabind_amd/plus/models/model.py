@@ -141,6 +141,7 @@ class FABindPlus(nn.Module):
 
     _lin = _V1._lin
     _assemble = _V1._assemble
+    _assemble_index = staticmethod(_V1._assemble_index)
     _soft_center = _V1._soft_center
     _pair_lists = staticmethod(_V1._pair_lists)
 
