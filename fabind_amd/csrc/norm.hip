@@ -35,11 +35,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             const float* __restrict__ dy, const float* mean,
                                                             const float* rstd, int R, int C, float* dx, float* dwp,
                                                             float* dbp) {
-    extern __shared__ float sh[];  // [2][C] block partials
+    extern __shared__ float sh[];  // [4 waves][2][C]: every wave's row contribution, combined in wave order (fixed summation order:
+                                   // the LDS float atomics of the first form made the heads' LayerNorm gradients differ by 1 ulp between runs)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int c = threadIdx.x; c < 2 * C; c += 256) sh[c] = 0.f;
-    __syncthreads();
     const int r = blockIdx.x * 4 + wv;
+    float* mine = sh + (size_t)wv * 2 * C;
     if (r < R) {
         const float mu = mean[r], rs = rstd[r];
         const float* xp = x + (size_t)r * C;
@@ -53,14 +53,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int c = lane; c < C; c += 64) {
             float xh = (xp[c] - mu) * rs, g = gp[c] * w[c];
             dx[(size_t)r * C + c] = rs * (g - s1 - xh * s2);
-            atomicAdd(&sh[c], gp[c] * xh);          // LDS atomics, 4 waves per block: order-insensitive to 1 ulp
-            atomicAdd(&sh[C + c], gp[c]);
+            mine[c] = gp[c] * xh;
+            mine[C + c] = gp[c];
         }
+    } else {
+        for (int c = lane; c < 2 * C; c += 64) mine[c] = 0.f;
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        dwp[(size_t)blockIdx.x * C + c] = sh[c];
-        dbp[(size_t)blockIdx.x * C + c] = sh[C + c];
+        dwp[(size_t)blockIdx.x * C + c] = ((sh[c] + sh[2 * C + c]) + sh[4 * C + c]) + sh[6 * C + c];
+        dbp[(size_t)blockIdx.x * C + c] = ((sh[C + c] + sh[3 * C + c]) + sh[5 * C + c]) + sh[7 * C + c];
     }
 }
 
@@ -68,7 +70,7 @@ extern "C" int fabind_layernorm_bwd(const float* x, const float* w, const float*
                                     const float* rstd, int R, int C, float* dx, float* dw_part, float* db_part,
                                     hipStream_t stream) {
     if (R <= 0) return 0;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((R + 3) / 4), dim3(256), 2 * C * sizeof(float), stream, x, w, dy, mean,
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((R + 3) / 4), dim3(256), 8 * C * sizeof(float), stream, x, w, dy, mean,
                        rstd, R, C, dx, dw_part, db_part);
     FB_CHECK_LAUNCH();
     return 0;

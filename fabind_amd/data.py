@@ -183,8 +183,11 @@ class DeviceFeeder:
     """Double-buffered feeder: while the model works on batch k, batch k+1 is packed on a host thread, copied on a side
     stream and assembled there; `__iter__` yields device-resident batches in order."""
 
-    def __init__(self, sample_batches, device, **build_kw):
-        self.src, self.device, self.kw = sample_batches, torch.device(device), build_kw
+    def __init__(self, sample_batches, device, plan_with=None, **build_kw):
+        """plan_with: an IaBNet model -- every batch is yielded as (batch, plan) with plan = model.plan_stage1(batch) built on the side
+        stream too (the forward's index tables, pair lists, layouts and input graphs: `model(batch, stage=1, train=..., plan=plan)`
+        then makes no host round trip of its own)."""
+        self.src, self.device, self.kw, self.plan_with = sample_batches, torch.device(device), build_kw, plan_with
 
     def __iter__(self):
         import queue
@@ -201,6 +204,7 @@ class DeviceFeeder:
         while nxt is not None:
             with torch.cuda.stream(side):
                 batch = build_batch(None, self.device, packed=nxt, **self.kw)
+                plan = self.plan_with.plan_stage1(batch) if self.plan_with is not None else None
                 ready = torch.cuda.Event()
                 ready.record(side)
             nxt = q.get()                                       # overlap: the next pack is already in flight
@@ -209,4 +213,4 @@ class DeviceFeeder:
                 for v in st.values():
                     if torch.is_tensor(v):
                         v.record_stream(torch.cuda.current_stream(self.device))
-            yield batch
+            yield batch if plan is None else (batch, plan)

@@ -14,7 +14,7 @@ def main():
          "max(k.end-k.start)/1e3 from %s k join %s s on k.kernel_id = s.id group by s.kernel_name order by 3 desc" % (kt, sym))
     rows = list(cur.execute(q))
     tot = sum(r[2] for r in rows)
-    lines = ["rocprofv3 kernel-trace summary: %d kernels, %.2f ms total GPU kernel time" % (len(rows), tot),
+    lines = ["rocprofv3 kernel-trace summary: %d kernels, %d launches, %.2f ms total GPU kernel time" % (len(rows), sum(r[1] for r in rows), tot),
              "%-96s %7s %11s %11s %10s %10s %6s" % ("kernel", "calls", "total_ms", "avg_us", "min_us", "max_us", "pct")]
     for r in rows[:40]:
         lines.append("%-96s %7d %11.3f %11.1f %10.1f %10.1f %5.1f%%" % (r[0][:96], r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot))
