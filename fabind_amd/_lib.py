@@ -47,6 +47,14 @@ class TnJob(ctypes.Structure):
                                   "wg0", "n_wg", "blk0", "n_blk", "pad_")]
 
 
+class AttnFusedBwdArgs(ctypes.Structure):
+    """Mirror of FabindAttnFusedBwdArgs (include/fabind_hip.h)."""
+    _fields_ = [(n, _vp) for n in ("qg", "kv", "a0", "bo", "boT", "toff", "koff", "bconst", "desc", "desc_p", "out", "lse", "dout",
+                                  "dqg", "dkv", "dO", "Dv", "da0", "acat", "colpart", "part")] + \
+               [(n, _i) for n in ("ldq", "ldkv", "lda0", "ldda0", "ldacat", "kcol0", "ldcolpart", "kp")] + [("scale", _f)] + \
+               [(n, _i) for n in ("nsplit", "B", "part_rows")]
+
+
 # name -> argtypes (every function returns int and takes the stream last)
 SIGNATURES = {
     "fabind_gemm": [ctypes.POINTER(GemmArgs), _vp],
@@ -86,8 +94,10 @@ SIGNATURES = {
                               _vp],
     "fabind_cross_attn_mfma_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _f, _vp, _i, _vp, _i, _vp, _i,
                                    _vp],
-    "fabind_cross_attn_fused_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp],
-    "fabind_pair_bo_pack": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "fabind_cross_attn_fused_fwd": [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _i, _vp, _i, _vp, _vp],
+    "fabind_cross_attn_fused_bwd": [ctypes.POINTER(AttnFusedBwdArgs), _i, _i, _i, _i, _i, _i, _vp],
+    "fabind_pair_bot_pack": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _l, _vp],
+    "fabind_pair_bo_pack": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _l, _vp],
     "fabind_cross_attn_mfma_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                    _vp, _vp, _vp],
     "fabind_pair_bmat": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp],
@@ -120,6 +130,7 @@ SIGNATURES = {
                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "fabind_las_step_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp],
     "fabind_pair_bias_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "fabind_pair_bias_btcat": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp],
     "fabind_pair_bias_finish": [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _l, _vp],
     "fabind_pack_frag_multi": [_vp, _vp, _i, _vp],
     "fabind_lower_bound": [_vp, _i, _vp, _i, _vp, _vp],
@@ -149,8 +160,10 @@ def load():
     lib.fabind_sizeof_args.argtypes, lib.fabind_sizeof_args.restype = [ctypes.c_int], ctypes.c_int
     lib.fabind_cross_attn_bwd_scratch.argtypes, lib.fabind_cross_attn_bwd_scratch.restype = [_i, _i, _i], ctypes.c_long
     lib.fabind_pair_bias_cat_parts.argtypes, lib.fabind_pair_bias_cat_parts.restype = [_i, _i], ctypes.c_long
+    lib.fabind_cross_attn_fused_bwd_scratch.argtypes, lib.fabind_cross_attn_fused_bwd_scratch.restype = [_i, _i, _i, _i, _i], ctypes.c_long
+    lib.fabind_cross_attn_fused_bwd_parts.argtypes, lib.fabind_cross_attn_fused_bwd_parts.restype = [_i, _i], ctypes.c_int
     lib.fabind_pair_bias_finish_parts.argtypes, lib.fabind_pair_bias_finish_parts.restype = [_i], ctypes.c_int
-    for which, mirror in enumerate((GemmArgs, EdgeBwdArgs, PairUpdateArgs, TnJob)):
+    for which, mirror in enumerate((GemmArgs, EdgeBwdArgs, PairUpdateArgs, TnJob, AttnFusedBwdArgs)):
         if lib.fabind_sizeof_args(which) != ctypes.sizeof(mirror):
             raise RuntimeError("fabind_amd: ctypes mirror %s is %d bytes, the library's struct is %d -- _lib.py and "
                                "include/fabind_hip.h disagree" % (mirror.__name__, ctypes.sizeof(mirror),

@@ -758,6 +758,18 @@ extern "C" int fabind_pair_bias_cat(const void* const* douts, int nblk, const in
     return 0;
 }
 
+// The ligand-side operand alone (the fused attention backward writes the gradient rows `Acat` itself): BTcat of fabind_pair_bias_cat
+extern "C" int fabind_pair_bias_btcat(const float* b0, int ld_ab, const int* c_index, const int* desc_p, const float* wcomp, int nblk, int H,
+                                      int Kp, void* BTcat, int ldb, int B, hipStream_t stream) {
+    if (B <= 0 || nblk <= 0) return 0;
+    FB_REQUIRE(nblk <= 16 && Kp % 32 == 0 && ldb % 8 == 0 && ldb >= nblk * Kp, "fabind_pair_bias_btcat: nblk <= 16, Kp % 32 == 0, ldb % 8 == 0 and >= nblk * Kp");
+    const long cpr = Kp / 8;
+    hipLaunchKernelGGL(pair_bias_btcat_kernel, dim3((unsigned)(((long)H * nblk * cpr + 255) / 256), B), dim3(256), 0, stream, b0, ld_ab,
+                       c_index, desc_p, wcomp, nblk, H, Kp, (bf16_t*)BTcat, ldb);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // adjoint of pair_hadamard: hd[e, 0:H] = a0[p]*b0[c], hd[e, H:H+H2] = a1[p]*b1[c]
 // (float atomics: every node collects the few pairs it belongs to)

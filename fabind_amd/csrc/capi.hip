@@ -17,6 +17,7 @@ extern "C" int fabind_sizeof_args(int which) {
         case 1: return (int)sizeof(FabindEdgeBwdArgs);
         case 2: return (int)sizeof(FabindPairUpdateArgs);
         case 3: return (int)sizeof(FabindTnJob);
+        case 4: return (int)sizeof(FabindAttnFusedBwdArgs);
         default: return -1;
     }
 }

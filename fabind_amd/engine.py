@@ -546,12 +546,16 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     # (when the bias tensors exist anyway -- a training call builds them for its differentiable pass -- the no-grad refinement
     #  iterations read them too: recomputing the contraction per iteration measured 8 % slower at n_iter = 8)
     fused = fast and isinstance(pairbias, ops.PairBias) and pairbias.can_fuse() and not pairbias.has_tensors()
-    if not fused:
+    # the differentiable pass in bf16 mode: the same recomputation in the forward AND the backward kernels (ops._CrossAttnFused)
+    ftrain = (not fast) and pdrop >= 0.0 and isinstance(pairbias, ops.PairBias) and not pairbias.has_tensors() and pairbias.can_fuse_train() \
+        and ops.needs_grad(h, p["Wo_p"], pairbias.a0b0)
+    if not fused and not ftrain:
         pbt = pairbias.tensors() if isinstance(pairbias, ops.PairBias) else pairbias
         bias_p, bias_c = pbt[2 * layer], pbt[2 * layer + 1]
     qg = ops.linear(c16(h), p["Wqg_p"], p["bqg_p"])                                     # [N, 256]
     kv = ops.linear(c16(hc), p["Wkv_p"])                                                # [sum C, 256]
     og = ops.cross_attn_fused(qg, kv, pairbias, 2 * layer, 0, lay, scale) if fused else \
+        ops.cross_attn_fused_train(qg, kv, pairbias, 2 * layer, 0, scale) if ftrain else \
         ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_pf, lay.B, lay.max_P, lay.max_C, scale)
     hp = (h + _drop(ops.linear(c16(og), p["Wo_p"], p["bo_p"]), pdrop)) if pdrop > 0.0 else \
         ops.linear(c16(og), p["Wo_p"], p["bo_p"], residual=h, want16=True)
@@ -561,6 +565,7 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     qg = ops.linear(c16(hc), p["Wqg_c"], p["bqg_c"])
     kv = ops.linear(hp16, p["Wkv_c"])                                                   # [N, 256], protein rows used
     og = ops.cross_attn_fused(qg, kv, pairbias, 2 * layer + 1, 1, lay, scale) if fused else \
+        ops.cross_attn_fused_train(qg, kv, pairbias, 2 * layer + 1, 1, scale) if ftrain else \
         ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
     hc = (hc + _drop(ops.linear(c16(og), p["Wo_c"], p["bo_c"]), pdrop)) if pdrop > 0.0 else \
         ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc)

@@ -276,19 +276,22 @@ def bo_tiles(lay):
     return c
 
 
-def pair_bo_pack(b0, wcomp8, H, lay):
-    """Packed bf16 operand Bo of one layer / block (include/fabind_hip.h: fabind_pair_bo_pack).  b0 = fp32 [N, ld] view (a0b0[:, H:]),
-    wcomp8 = fp32 [8, H]."""
+def pair_bo_pack(b0, wcomp, H, lay):
+    """Packed bf16 operands Bo of ALL layers / blocks in one launch (include/fabind_hip.h: fabind_pair_bo_pack).  b0 = fp32 [N, ld] view
+    (a0b0[:, H:]), wcomp = fp32 [nblk, 8, H] (or [8, H]) -> list of nblk flat bf16 tensors."""
     toff, tile_b, n_tiles = bo_tiles(lay)
-    out = torch.empty(max(n_tiles, 1) * (H // 32) * 512, dtype=torch.bfloat16, device=b0.device)
-    wc = wcomp8.contiguous()
+    wc = wcomp.reshape(-1, 8, wcomp.shape[-1]).float().contiguous()
+    nblk = wc.shape[0]
+    per = max(n_tiles, 1) * (H // 32) * 512
+    out = torch.empty((nblk, per), dtype=torch.bfloat16, device=b0.device)
     check(_lib.load().fabind_pair_bo_pack(ptr(b0), _ld(b0), ptr(wc), H, ptr(lay.c_index), ptr(lay.desc_pf), ptr(toff), ptr(tile_b),
-                                          n_tiles, ptr(out), stream()), "fabind_pair_bo_pack")
-    return out
+                                          n_tiles, ptr(out), nblk, per, stream()), "fabind_pair_bo_pack")
+    return [out[k] for k in range(nblk)]
 
 
-def cross_attn_fused_fwd(q, k, v, gpre, a0_16, bo, bconst8, lay, H, mode, scale, out):
-    """Gated cross attention with the pair bias recomputed in the kernel (include/fabind_hip.h: fabind_cross_attn_fused_fwd)."""
+def cross_attn_fused_fwd(q, k, v, gpre, a0_16, bo, bconst8, lay, H, mode, scale, out, lse=None):
+    """Gated cross attention with the pair bias recomputed in the kernel (include/fabind_hip.h: fabind_cross_attn_fused_fwd).
+    lse (fp32 [query rows, 4], optional): receives the log-sum-exp per (query, head) for the fused backward."""
     toff, _, _ = bo_tiles(lay)
     nsplit = (lay.max_P + 63) // 64
     part = torch.empty(lay.sumC * nsplit * 4 * 34, dtype=torch.float32, device=q.device) if mode == 1 else None
@@ -300,8 +303,66 @@ def cross_attn_fused_fwd(q, k, v, gpre, a0_16, bo, bconst8, lay, H, mode, scale,
               lambda: check(_lib.load().fabind_cross_attn_fused_fwd(ptr(q), _ld(q), ptr(k), ptr(v), _ld(k), ptr(gpre), _ld(gpre), ptr(a0_16),
                                                                     _ld(a0_16), ptr(bo), ptr(toff), ptr(bconst8), ptr(lay.desc_pf), lay.B,
                                                                     lay.max_P, lay.max_C, H, mode, scale, ptr(out), _ld(out), ptr(part),
-                                                                    lay.sumC, stream()), "fabind_cross_attn_fused_fwd"))
+                                                                    lay.sumC, ptr(lse), stream()), "fabind_cross_attn_fused_fwd"))
     return out
+
+
+def bot_ksteps(lay):
+    """(koff [B+1], kstep_b [n_ksteps], n_ksteps) of the packed operand of the fused attention backward's d a0 contraction: complex b
+    owns ceil(C_b / 4) k-steps of 4 ligand-side nodes (cached on the layout)."""
+    c = getattr(lay, "_bot_ksteps", None)
+    if c is None:
+        KS = (np.asarray(lay.C) + 3) // 4
+        koff = np.concatenate([[0], np.cumsum(KS)]).astype(np.int32)
+        kstep_b = np.repeat(np.arange(lay.B, dtype=np.int32), KS)
+        dev = lay.node_off.device
+        from .param_pack import upload
+        c = lay._bot_ksteps = (upload(koff, dev, torch.int32), upload(kstep_b, dev, torch.int32), int(koff[-1]))
+    return c
+
+
+def pair_bot_pack(b0, wcomp, H, lay):
+    """Packed bf16 operands Bo^T of ALL layers / blocks for the fused backward, one launch (include/fabind_hip.h: fabind_pair_bot_pack)."""
+    koff, kstep_b, n_ks = bot_ksteps(lay)
+    wc = wcomp.reshape(-1, 8, wcomp.shape[-1]).float().contiguous()
+    nblk = wc.shape[0]
+    per = max(n_ks, 1) * (H // 16) * 512
+    out = torch.empty((nblk, per), dtype=torch.bfloat16, device=b0.device)
+    check(_lib.load().fabind_pair_bot_pack(ptr(b0), _ld(b0), ptr(wc), H, ptr(lay.c_index), ptr(lay.desc_pf), ptr(koff), ptr(kstep_b), n_ks,
+                                           ptr(out), nblk, per, stream()), "fabind_pair_bot_pack")
+    return [out[k] for k in range(nblk)]
+
+
+def cross_attn_fused_bwd(qg, kv, a0_16, bo, boT, bconst8, lay, H, mode, scale, out, lse, dout, dqg, dkv, da0b0, acat, kcol0, colpart, kp):
+    """Fused backward of the cross attention (include/fabind_hip.h: fabind_cross_attn_fused_bwd).  dqg / dkv are written (covered rows),
+    da0b0[:, :H] is accumulated, acat[:, kcol0 : kcol0 + C * 8] receives the bf16 gradient rows, colpart (a [tiles, >= 8] view: the
+    first 8 columns of every row) the per-tile column sums of the per-pair gradients in slot order lin0, gate0, lin1, gate1, ..."""
+    lib = _lib.load()
+    toff, _, _ = bo_tiles(lay)
+    koff, _, _ = bot_ksteps(lay)
+    dev = qg.device
+    nq = qg.shape[0]
+    dO = torch.empty((nq, 128), dtype=torch.float32, device=dev)
+    Dv = torch.empty((nq, 4), dtype=torch.float32, device=dev)
+    part = torch.empty(max(1, int(lib.fabind_cross_attn_fused_bwd_scratch(lay.B, lay.max_P, lay.max_C, lay.sumC, mode))), dtype=torch.float32, device=dev)
+    a = _lib.AttnFusedBwdArgs()
+    for name, t in (("qg", qg), ("kv", kv), ("a0", a0_16), ("bo", bo), ("boT", boT), ("toff", toff), ("koff", koff), ("bconst", bconst8),
+                    ("desc", lay.desc_pf), ("desc_p", lay.desc_p), ("out", out), ("lse", lse), ("dout", dout), ("dqg", dqg), ("dkv", dkv),
+                    ("dO", dO), ("Dv", Dv), ("da0", da0b0), ("acat", acat), ("colpart", colpart), ("part", part)):
+        setattr(a, name, ptr(t))
+    a.ldq, a.ldkv, a.lda0, a.ldacat, a.kcol0, a.ldcolpart = _ld(qg), _ld(kv), _ld(a0_16), _ld(acat), int(kcol0), colpart.stride(0)
+    a.ldda0 = _ld(da0b0) if da0b0 is not None else 0
+    a.kp = int(kp)
+    a.scale = float(scale)
+    nsplit = (lay.max_P + 63) // 64
+    n_wg = nsplit * lay.B
+    # executed matrix-core work per work-group: bias contraction twice (both passes) + the d a0 contraction + the attention's own tiles
+    kt = ((lay.max_C + 1) // 2 + 3) // 4 * 4 * 16
+    flops = 2.0 * n_wg * 64 * kt * H * 2 + 2.0 * n_wg * 64 * ((lay.max_C + 3) // 4 * 32) * H
+    _profiled("cross_attn_fused_bwd mode=%d B=%d P<=%d C<=%d (2 x bias contraction K=%d + d a0 contraction + attention adjoint)" % (mode, lay.B, lay.max_P, lay.max_C, H),
+              flops, lambda: check(lib.fabind_cross_attn_fused_bwd(ctypes.byref(a), lay.B, lay.max_P, lay.max_C, H, mode, lay.sumC, stream()),
+                                   "fabind_cross_attn_fused_bwd"))
+    return colpart
 
 
 def pair_bmat(b0, wcomp, c_node, out_dtype):

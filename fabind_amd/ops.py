@@ -1535,9 +1535,12 @@ class PairBias:
     def __init__(self, a0b0, H, wcomp, bconst, lay):
         self.a0b0, self.H, self.wcomp, self.bconst, self.lay = a0b0, H, wcomp, bconst, lay
         self._tensors, self._a16, self._bo = None, None, {}
-        # a differentiable pass will come (training: the last refinement iteration), or nothing can be fused: build the tensors NOW,
-        # under the caller's grad mode -- a first use inside a no-grad refinement iteration would cache tensors without a graph
-        if _needs_grad(a0b0, wcomp, bconst) or not self.can_fuse():
+        self._bot, self._bw = {}, None            # fused backward: Bo^T packs per block; state shared by the blocks of one backward pass
+        self._n_fused = 0
+        # a differentiable pass will come (training: the last refinement iteration) and its backward cannot recompute the bias in the
+        # kernels, or nothing can be fused: build the tensors NOW, under the caller's grad mode -- a first use inside a no-grad refinement
+        # iteration would cache tensors without a graph
+        if (_needs_grad(a0b0, wcomp, bconst) and not self.can_fuse_train()) or not self.can_fuse():
             self.tensors()
 
     def can_fuse(self):
@@ -1545,8 +1548,22 @@ class PairBias:
         return (K.CROSS_ATTN_FUSED and _cfg.get_precision() == "bf16" and self.lay.max_C <= K.CROSS_ATTN_FUSED_MAX_C
                 and self.H in (64, 128, 256, 512) and tuple(self.wcomp.shape[1:]) == (8, self.H))
 
+    def can_fuse_train(self):
+        """The differentiable pass takes the fused kernels each way (forward with the log-sum-exp saved, backward recomputing the bias)."""
+        # (large batches only: one work-group per CU and 64 protein rows per work-group -- a pocket-sized batch is 128 work-groups per
+        #  launch, and its tensor-path kernels are 25-45 us each: same-box pocket step 3,086 fused vs 3,532 complexes/s, headline 731 vs 722)
+        tiles = self.lay.B * ((self.lay.max_P + 63) // 64)
+        return FUSED_ATTN_TRAIN and tiles >= FUSED_ATTN_TRAIN_MIN_TILES and self.can_fuse() and self.a0b0.dtype == torch.float32 \
+            and self.a0b0.stride(0) == 2 * self.H
+
     def has_tensors(self):
         return self._tensors is not None
+
+    def bot(self, k):
+        with torch.no_grad():
+            if not self._bot:
+                self._bot = dict(enumerate(K.pair_bot_pack(self.a0b0[:, self.H:], self.wcomp, self.H, self.lay)))
+        return self._bot[k]
 
     def tensors(self):
         if self._tensors is None:
@@ -1557,10 +1574,110 @@ class PairBias:
         with torch.no_grad():
             if self._a16 is None:
                 self._a16 = self.a0b0[:, :self.H].to(torch.bfloat16)
-            bo = self._bo.get(k)
-            if bo is None:
-                bo = self._bo[k] = K.pair_bo_pack(self.a0b0[:, self.H:], self.wcomp[k].float(), self.H, self.lay)
-        return self._a16, bo, self.bconst[k].float().contiguous()
+            if not self._bo:                 # the packed operands of ALL blocks from one launch
+                self._bo = dict(enumerate(K.pair_bo_pack(self.a0b0[:, self.H:], self.wcomp, self.H, self.lay)))
+                self._bc = self.bconst.float().contiguous()
+            bo = self._bo[k]
+        return self._a16, bo, self._bc[k]
+
+
+ATTN_DA0_IN_KERNEL = os.environ.get("FABIND_ATTN_DA0_IN_KERNEL", "0") == "1"    # 1: d a0 contracted inside every block's backward kernel (A/B)
+FUSED_ATTN_TRAIN_MIN_TILES = int(os.environ.get("FABIND_ATTN_FUSED_TRAIN_MIN_TILES", "512"))
+FUSED_ATTN_TRAIN = os.environ.get("FABIND_ATTN_FUSED_TRAIN", "1") == "1"     # 0: the differentiable pass reads / writes [pairs, 8] bias tensors (round 3)
+_SLOT_TO_ROW = [0, 4, 1, 5, 2, 6, 3, 7]          # slot order of the packed operands (lin0, gate0, lin1, gate1, ...) -> row of wcomp / bconst (lin0..3, gate0..3)
+
+
+class _CrossAttnFused(torch.autograd.Function):
+    """Gated cross attention of one block with the pair bias recomputed in the kernels, BOTH ways (csrc/attn_mfma.hip): no [pairs, 8]
+    tensor exists in either direction.  Inputs with a gradient: qg (q | gate pre-activations), kv, a0b0 (the factored pair embedding:
+    a0 through the kernel's own contraction, b0 through the T = D^T a0 GEMM + finishing pass), wcomp, bconst (all blocks' composed
+    weights / constants: every block's backward fills its slice of ONE gradient tensor, the last block to run hands it to autograd)."""
+
+    @staticmethod
+    def forward(ctx, qg, kv, a0b0, wcomp, bconst, pb, k_blk, mode, scale):
+        lay = pb.lay
+        a16, bo, bc = pb.fused(k_blk)
+        nq = qg.shape[0]
+        out = (torch.zeros if mode == 0 else torch.empty)((nq, 128), dtype=torch.float32, device=qg.device)      # rows outside every block: 0
+        lse = torch.empty((nq, 4), dtype=torch.float32, device=qg.device)
+        K.cross_attn_fused_fwd(qg[:, :128], kv[:, :128], kv[:, 128:], qg[:, 128:], a16, bo, bc, lay, pb.H, mode, scale, out, lse)
+        ctx.pb, ctx.k, ctx.mode, ctx.scale = pb, k_blk, mode, scale
+        ctx.sink = getattr(a0b0, "_fab_gsink", None)
+        ctx.save_for_backward(qg, kv, out, lse, a0b0, wcomp)
+        pb._n_fused += 1
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qg, kv, out, lse, a0b0, wcomp = ctx.saved_tensors
+        pb, k, mode = ctx.pb, ctx.k, ctx.mode
+        lay, H = pb.lay, pb.H
+        dev = qg.device
+        nblk, NO = wcomp.shape[0], 8
+        dout = dout.contiguous()
+        bw = pb._bw
+        if bw is None:                       # first block of this backward pass: the state the blocks share
+            Kp = (lay.max_C * NO + 31) // 32 * 32
+            n_tiles = int(load().fabind_cross_attn_fused_bwd_parts(lay.B, lay.max_P))
+            bw = pb._bw = dict(Kp=Kp, left=pb._n_fused, done=[],
+                               acat=torch.empty((lay.sumP, nblk * Kp), dtype=torch.bfloat16, device=dev),
+                               colpart=torch.zeros((n_tiles, nblk * NO), dtype=torch.float32, device=dev))
+        Kp = bw["Kp"]
+        da0b0, da0b0_ret = _sink_zeros(a0b0, ctx.sink)
+        a16, bo, bc = pb.fused(k)
+        # uncovered rows (the ligand rows of a node-layout array) must read zero: they flow into the projections' adjoints
+        dqg = (torch.zeros_like if mode == 0 else torch.empty_like)(qg)
+        dkv = (torch.empty_like if mode == 0 else torch.zeros_like)(kv)
+        in_k = ATTN_DA0_IN_KERNEL
+        K.cross_attn_fused_bwd(qg, kv, a16, bo, pb.bot(k) if in_k else None, bc, lay, H, mode, ctx.scale, out, lse, dout, dqg, dkv,
+                               da0b0 if in_k else None, bw["acat"], k * Kp, bw["colpart"][:, k * NO:], Kp)
+        bw["done"].append(k)
+        bw["left"] -= 1
+        dw_ret = db_ret = None
+        if bw["left"] <= 0:
+            # The last block of the pass finishes ALL of them: the ligand-side and weight gradients need T_k[(j, slot), h] = sum_i
+            # D_k[i, (j, slot)] a0[i, h] over ALL rows of a complex -- one batched transpose of the bf16 gradient rows, one ragged GEMM and
+            # one finishing pass per block, one column sum for all weight gradients and one for all constants -- and hands the shared
+            # gradients to autograd.
+            Pp = (lay.max_P + 63) // 64 * 64
+            cat_g, t_g = _pair_bias_groups(lay, H, a0b0.stride(0), nblk, Kp)
+            acat = bw["acat"]
+            wslot = wcomp.float()[:, _SLOT_TO_ROW].contiguous()              # [nblk, 8, H], rows in the packed operands' slot order
+            ran = sorted(bw["done"])
+            if not in_k:
+                # d a0 of ALL blocks as ONE ragged GEMM over the stored gradient rows (K = nblk x C x 8): the gradient is written once
+                if len(ran) != nblk:
+                    for kk in set(range(nblk)) - set(ran):
+                        acat[:, kk * Kp:(kk + 1) * Kp].zero_()
+                BTcat = torch.empty((lay.B * H, nblk * Kp), dtype=torch.bfloat16, device=dev)
+                check(load().fabind_pair_bias_btcat(ptr(a0b0[:, H:]), a0b0.stride(0), ptr(lay.c_index), ptr(lay.desc_p), ptr(wslot), nblk, H, Kp,
+                                                    ptr(BTcat), BTcat.stride(0), lay.B, stream()), "fabind_pair_bias_btcat")
+                K.gemm(acat, BTcat, out=da0b0, accumulate=True, groups=cat_g, n_groups=lay.B, max_m=lay.max_P, max_n=H,
+                       M=lay.sumP, N=lay.B * H, ldc=a0b0.stride(0), flops=2.0 * lay.n_pairs * NO * nblk * H)
+            Dt = torch.empty((nblk, lay.B * Kp, Pp), dtype=torch.bfloat16, device=dev)
+            At = torch.empty((lay.B * H, Pp), dtype=torch.bfloat16, device=dev)
+            check(load().fabind_batched_transpose_pad(ptr(acat), acat.stride(0), ptr(lay.desc_p), lay.B, nblk, Kp, Pp, ptr(Dt), stream()),
+                  "fabind_batched_transpose_pad")
+            check(load().fabind_batched_transpose_pad(ptr(a16), a16.stride(0), ptr(lay.desc_pf), lay.B, 1, H, Pp, ptr(At), stream()),
+                  "fabind_batched_transpose_pad")
+            n_fin = int(load().fabind_pair_bias_finish_parts(lay.sumC))
+            fin = (torch.empty if len(ran) == nblk else torch.zeros)((n_fin, nblk * NO * H), dtype=torch.float32, device=dev)
+            T = torch.empty((lay.sumC * NO, H), dtype=torch.float32, device=dev)
+            for kk in ran:
+                K.gemm(Dt[kk], At, out=T, groups=t_g, n_groups=lay.B, max_m=lay.max_C * NO, max_n=H, M=lay.B * Kp, N=lay.B * H, ldc=H,
+                       flops=2.0 * lay.n_pairs * NO * H)
+                check(load().fabind_pair_bias_finish(ptr(T), ptr(a0b0), a0b0.stride(0), H, ptr(wslot[kk]), ptr(lay.c_index), lay.sumC,
+                                                     ptr(da0b0), ptr(fin[:, kk * NO * H:]), fin.stride(0), stream()), "fabind_pair_bias_finish")
+            inv = [_SLOT_TO_ROW.index(r_) for r_ in range(NO)]              # wcomp / bconst row -> slot
+            dw_ret = K.colsum(fin).view(nblk, NO, H)[:, inv].contiguous().to(wcomp.dtype)
+            db_ret = K.colsum(bw["colpart"]).view(nblk, NO)[:, inv].contiguous()
+            pb._bw = None
+        return dqg, dkv, da0b0_ret, dw_ret, db_ret, None, None, None, None
+
+
+def cross_attn_fused_train(qg, kv, pb, k_blk, mode, scale):
+    """Differentiable gated cross attention of block k_blk with the pair bias recomputed in the kernels both ways."""
+    return _CrossAttnFused.apply(qg, kv, pb.a0b0, pb.wcomp, pb.bconst, pb, k_blk, mode, scale)
 
 
 def cross_attn_fused(qg, kv, pb, k_blk, mode, lay, scale):

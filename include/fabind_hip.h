@@ -52,7 +52,9 @@ const char* fabind_last_error(void);
  * 15 = fabind_gemm_tn_multi + FabindTnJob (the queued weight-gradient contractions of a backward pass as one launch + one reduction);
  *     fabind_sizeof_args(3) = sizeof(FabindTnJob); fabind_gcl_edge_fused_x3 takes n_rows (4 GiB bound of its 32-bit gather offsets checked);
  *     fabind_pair_bias_finish writes per-work-group partials of dw (no float atomics; the caller sums them with fabind_colsum);
- *     fabind_pack_frag_multi + FabindPackSeg (all fragment packs of a model call in one launch); fabind_lower_bound.
+ *     fabind_pack_frag_multi + FabindPackSeg (all fragment packs of a model call in one launch); fabind_lower_bound;
+ *     fabind_cross_attn_fused_fwd takes lse; fabind_cross_attn_fused_bwd + FabindAttnFusedBwdArgs, fabind_pair_bot_pack (fused backward of the
+ *     cross attention: fabind_sizeof_args(4)).
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 15
 int fabind_abi_version(void);
@@ -370,15 +372,48 @@ int fabind_cross_attn_fwd(const float* q, int ldq, const float* k, const float* 
  * C, ...}; mode 0: queries = protein rows (q / gpre / out node-indexed, k / v compact ligand rows); mode 1: queries = ligand atoms
  * (q / gpre / out compact, k / v node-indexed), `part` = float[n_lig_rows * ceil(max_P / 64) * 4 * 34] scratch.  bconst = the eight
  * constants (lin0..3, gate0..3).  max_C <= 62.  Replaces RowAttentionBlock.forward incl. its pair-bias Linears (cross_att.py:118-134). */
+/* lse (optional): receives the log-sum-exp of every (query row, head) -- what fabind_cross_attn_fused_bwd replays the weights from. */
 int fabind_cross_attn_fused_fwd(const float* q, int ldq, const float* k, const float* v, int ldkv, const float* gpre, int ldg,
                                 const void* a0, int lda0, const void* bo, const int* toff, const float* bconst, const int* desc, int B,
                                 int max_P, int max_C, int H, int mode, float scale, float* out, int ldo, float* part, int n_lig_rows,
-                                hipStream_t stream);
+                                float* lse, hipStream_t stream);
 /* bo[(toff[b] * H/32 + ks * T_b + tile) * 512 + lane * 8 + e] = b0[c_index[lig0_b + atom], k] * wcomp[slot_row, k] in MFMA fragment
  * order (tile = 16 columns = 2 atoms x {lin0, gate0, lin1, gate1, lin2, gate2, lin3, gate3}; T_b = ceil(C_b / 2); toff = prefix sum of
  * T_b; tile_b[t] = complex of global tile t); wcomp = fp32 [8, H] rows lin0..3, gate0..3 (the composed weights W_{lin|gate} W_o). */
 int fabind_pair_bo_pack(const float* b0, int ldb, const float* wcomp, int H, const int* c_index, const int* desc, const int* toff,
-                        const int* tile_b, int n_tiles, void* out, hipStream_t stream);
+                        const int* tile_b, int n_tiles, void* out, int n_blocks, long blk_stride, hipStream_t stream);
+/* (n_blocks packs in one launch: block k reads wcomp + k * 8 * H and writes out + k * blk_stride elements) */
+
+/* Fused BACKWARD of the same block (round 4): the bias is recomputed on the matrix cores in both passes, the per-pair gradients
+ * D = (d lin_h, d gate_h)_h never leave the chip as fp32 -- they overwrite the LDS bias tile as bf16, are contracted with the packed
+ * operand `boT` (fabind_pair_bot_pack) for  d a0 += D Bo  in the kernel, and go out as bf16 rows of `acat` (row = compact protein
+ * index, columns kcol0 + atom * 8 + slot, slot order lin0, gate0, lin1, gate1, ...) for the T = D^T a0 contraction that the ligand-side
+ * and weight gradients need over ALL row tiles of a complex (fabind_batched_transpose_pad + fabind_gemm + fabind_pair_bias_finish,
+ * as on the tensor path).  Replaces autograd of cross_att.py:118-134 / model_utils.py:21-38,96-159 for the v1 stack.
+ * qg = q | gate pre-activations of the QUERY side [rows, ldq >= 256] (mode 0: protein rows in the node layout; mode 1: compact ligand
+ * rows), kv = k | v of the KEY side, out / dout = the forward's output and its gradient [query rows, 128], lse = the forward's
+ * log-sum-exp [query rows, 4]; outputs: dqg [query rows, ldq] (d q | d gate-pre), dkv [key rows, ldkv], scratch dO [query rows, 128],
+ * Dv [query rows, 4]; da0 (optional: +=, fp32 [N, ldda0], columns [0, H); NULL: the caller contracts `acat` with fabind_pair_bias_btcat's operand), colpart = fabind_cross_attn_fused_bwd_parts(B, max_P) rows of ldcolpart >= 8
+ * floats (per-tile column sums of D in the first 8 of a row: their sum is d bconst in slot order), part = float[fabind_cross_attn_fused_bwd_scratch(...)].
+ * desc = the forward's descriptors, desc_p = int32[8] per complex whose first entry is the complex's first row in the compact protein
+ * list; toff / koff = int32[B + 1] prefix sums of ceil(C / 2) / ceil(C / 4).  nsplit, B, part_rows are filled in by the library. */
+typedef struct FabindAttnFusedBwdArgs {
+    const float* qg; const float* kv; const void* a0; const void* bo; const void* boT; const int* toff; const int* koff;
+    const float* bconst; const int* desc; const int* desc_p; const float* out; const float* lse; const float* dout;
+    float* dqg; float* dkv; float* dO; float* Dv; float* da0; void* acat; float* colpart; float* part;
+    int ldq, ldkv, lda0, ldda0, ldacat, kcol0, ldcolpart, kp;   /* kp: width of this block's column range of acat (>= max_C * 8; the tail is zero-filled) */
+    float scale;
+    int nsplit, B, part_rows;
+} FabindAttnFusedBwdArgs;
+int fabind_cross_attn_fused_bwd(const FabindAttnFusedBwdArgs* args, int B, int max_P, int max_C, int H, int mode, int n_lig_rows,
+                                hipStream_t stream);
+long fabind_cross_attn_fused_bwd_scratch(int B, int max_P, int max_C, int n_lig_rows, int mode);
+int fabind_cross_attn_fused_bwd_parts(int B, int max_P);
+/* boT[((koff[b] + ks) * (H / 16) + nt) * 512 + lane * 8 + e] = b0[atom][h] * wcomp[(e & 1) * 4 + (e >> 1)][h], atom = ks * 4 + (lane >> 4),
+ * h = nt * 16 + (lane & 15) (zero rows past C): the A operand of the kernel's d a0 contraction.  kstep_b = int32[n_ksteps]: complex of
+ * every k-step. */
+int fabind_pair_bot_pack(const float* b0, int ldb, const float* wcomp, int H, const int* c_index, const int* desc, const int* koff,
+                         const int* kstep_b, int n_ksteps, void* out, int n_blocks, long blk_stride, hipStream_t stream);
 
 /* The same block with QK^T and softmax.V on the matrix cores (v_mfma_f32_16x16x32_bf16: head dim 32 = one instruction per
  * 16-key x 16-query tile; csrc/attn_mfma.hip): identical arguments, results and partials layout; q / k / v / probabilities
@@ -530,6 +565,10 @@ long fabind_pair_bias_cat_parts(int B, int max_P);
 int fabind_pair_bias_cat(const void* const* douts, int nblk, const int* desc_p, int B, int max_P, int Kp, void* Acat, int lda,
                          const float* b0, int ld_ab, const int* c_index, const float* wcomp, int H, void* BTcat, int ldb,
                          float* colpart, hipStream_t stream);
+/* BTcat alone -- BTcat[b * H + h, k * Kp + j * 8 + o] = b0[c_index[lig0_b + j], h] * wcomp[k][o][h] (bf16, zero padded) -- for callers that
+ * write the gradient rows Acat themselves (fabind_cross_attn_fused_bwd; pass wcomp rows in ITS slot order). */
+int fabind_pair_bias_btcat(const float* b0, int ld_ab, const int* c_index, const int* desc_p, const float* wcomp, int nblk, int H, int Kp,
+                           void* BTcat, int ldb, int B, hipStream_t stream);
 /* Batched transpose with zero padding, bf16: for b < B, k < nsub, m < cols:
  *   out[(k*B + b)*cols + m][i] = in[desc[b][0] + i][k*cols + m]  for i < desc[b][1], 0 for i up to Pp   (out row stride Pp).
  * Turns the row-major per-complex operands of the pair-bias adjoint into the K-major, uniformly padded layout the pipelined NT GEMM

@@ -52,7 +52,7 @@ def test_library_exports_every_declared_symbol():
     import ctypes
     assert lib.fabind_abi_version() == L.ABI_VERSION == 15
     # the ctypes mirrors have the library's struct sizes (load() refuses a mismatch; checked again here explicitly)
-    for which, mirror in enumerate((L.GemmArgs, L.EdgeBwdArgs, L.PairUpdateArgs, L.TnJob)):
+    for which, mirror in enumerate((L.GemmArgs, L.EdgeBwdArgs, L.PairUpdateArgs, L.TnJob, L.AttnFusedBwdArgs)):
         assert lib.fabind_sizeof_args(which) == ctypes.sizeof(mirror)
     assert lib.fabind_sizeof_args(99) == -1
     from fabind_amd import kernels as K
@@ -200,7 +200,8 @@ def test_ctypes_signatures_match_the_header_prototypes():
     special = {"fabind_abi_version", "fabind_sizeof_args", "fabind_gemm_set_config", "fabind_gemm_set_persistent", "fabind_gemm_tn_tile_n",
                "fabind_gemm_x3_occupancy", "fabind_cross_attn_fused_occupancy"}
     protos.update(dict(re.findall(r"\blong\s+(fabind_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)))
-    special.update({"fabind_cross_attn_bwd_scratch", "fabind_pair_bias_cat_parts", "fabind_pair_bias_finish_parts"})
+    special.update({"fabind_cross_attn_bwd_scratch", "fabind_pair_bias_cat_parts", "fabind_pair_bias_finish_parts", "fabind_cross_attn_fused_bwd_scratch",
+                    "fabind_cross_attn_fused_bwd_parts"})
     assert set(protos) - special == set(L.SIGNATURES), (sorted(set(protos) - special - set(L.SIGNATURES)),
                                                          sorted(set(L.SIGNATURES) - set(protos)))
 
