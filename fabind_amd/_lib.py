@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FABIND_LIB") or os.path.join(_HERE, "libfabind_hip.so")      # FABIND_LIB: an A/B build (tools/probes)
 
-ABI_VERSION = 15         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
+ABI_VERSION = 16         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -30,7 +30,8 @@ class EdgeBwdArgs(ctypes.Structure):
     """Mirror of FabindEdgeBwdArgs (include/fabind_hip.h)."""
     _fields_ = [(n, _vp) for n in ("AB", "row", "col", "rhohat", "w_r", "W2p", "Wcp", "W2Tp", "WcTp", "b2", "bc", "w3", "ds",
                                   "dagg", "S1", "Mm", "dT", "dP2", "dP1", "drh", "dABrow", "part", "dbg", "bnd", "d2scratch")] + \
-               [(n, _i) for n in ("ldab", "lddagg", "lddab", "E")] + [("p_drop", _f), ("seed", ctypes.c_uint), ("xcd_aware", _i), ("lddab16", _i), ("dAB16", _vp)]
+               [(n, _i) for n in ("ldab", "lddagg", "lddab", "E")] + [("p_drop", _f), ("seed", ctypes.c_uint), ("xcd_aware", _i), ("lddab16", _i), ("dAB16", _vp),
+                                                                  ("d2f", _vp), ("z3f", _vp)]
 
 
 class PairUpdateArgs(ctypes.Structure):
@@ -69,6 +70,7 @@ SIGNATURES = {
     "fabind_edge_geom": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp],
     "fabind_gcl_pre": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "fabind_gcl_edge_fused": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp, _vp],
+    "fabind_gcl_edge_fused_train": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp, _vp, _vp, _vp, _vp],
     "fabind_gcl_edge_fused_x3": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp],
     "fabind_gcl_edge_fused_bwd": [ctypes.POINTER(EdgeBwdArgs), _i, _i, _vp],
     "fabind_pair_update_fused": [ctypes.POINTER(PairUpdateArgs), _i, _vp],

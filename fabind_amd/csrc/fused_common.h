@@ -419,6 +419,43 @@ __global__ void fe_boundary_fix_kernel(const int* __restrict__ row, int E, int H
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Element-wise helpers of the row-wise / operand-swapped kernels (fused_edge_bwd3.hip, fused_edge_bwd4.hip, the saving forward)
+// sum over the 16 lanes of a DPP row (lanes 16q .. 16q+15); every lane of the row receives the total
+__device__ __forceinline__ float fe3_row16_sum(float v) {
+#define FE_DPP_ADD(ctrl_) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), (ctrl_), 0xF, 0xF, true))
+    FE_DPP_ADD(0xB1);        // quad_perm [1,0,3,2]
+    FE_DPP_ADD(0x4E);        // quad_perm [2,3,0,1]
+    FE_DPP_ADD(0x141);       // row_half_mirror
+    FE_DPP_ADD(0x140);       // row_mirror
+#undef FE_DPP_ADD
+    return v;
+}
+
+// Pairs of fp32 values in adjacent registers: the arithmetic below compiles to the packed v_pk_{add,mul,fma}_f32 forms, two
+// elements per VALU instruction; the two transcendentals per element (v_exp_f32, v_rcp_f32: quarter rate) stay scalar.
+typedef float fe_f2 __attribute__((ext_vector_type(2)));
+// m = silu(z) = z s(z), d = silu'(z) = s + m (1 - s)
+__device__ __forceinline__ void fe3_silu_pair(const fe_f2 z, fe_f2& m, fe_f2& d) {
+    const fe_f2 t = z * -1.44269504f;
+    const fe_f2 o = fe_f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+    const fe_f2 s = fe_f2{__builtin_amdgcn_rcpf(o.x), __builtin_amdgcn_rcpf(o.y)};
+    m = z * s;
+    d = s + (m - m * s);
+}
+__device__ __forceinline__ uint32_t fe3_pack(const fe_f2 v) { return pack2_bf16(v.x, v.y); }
+__device__ __forceinline__ fe_f2 fe3_unpack(const uint32_t u) { return fe_f2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+
+// 16-byte buffer accesses: (uniform base in a descriptor) + (32-bit lane offset) + (uniform offset in an SGPR / literal): no 64-bit
+// per-lane pointers, which the compiler hoists out of the tile loop by the dozen and spills
+__device__ __forceinline__ uint4 fe3_bload16(const __amdgpu_buffer_rsrc_t rs, const unsigned voff, const unsigned soff) {
+    const fe_u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void fe3_bstore16(const __amdgpu_buffer_rsrc_t rs, const unsigned voff, const unsigned soff, const uint4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(fe_u32x4_t{v.x, v.y, v.z, v.w}, rs, (int)voff, (int)soff, 0);
+}
+
 // fused_edge_bwd2.hip: the row-wise / operand-swapped backward (variants 3 and 4 of fabind_gcl_edge_fused_bwd)
 struct FabindEdgeBwdArgs;
 int fe_bwd2_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipStream_t stream);
@@ -432,4 +469,7 @@ int fe_fwd3_launch(const float* AB, int ldab, int H, const int* row, const int* 
 // fused_edge_fwd2.hip: the row-wise / operand-swapped forward (variant 1 of fabind_gcl_edge_fused)
 int fe_fwd2_launch(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat, const float* w_r,
                    const void* W2p, const float* b2, const void* Wcp, const float* bc, const float* w3, int E, float* agg,
-                   float* s_out, uint32_t thr16, float dscale, unsigned seed, float* bnd, void* agg16, int xcd_aware, hipStream_t stream);
+                   float* s_out, uint32_t thr16, float dscale, unsigned seed, float* bnd, void* agg16, int xcd_aware, hipStream_t stream,
+                   void* Msave = nullptr, void* d2f = nullptr, void* z3f = nullptr);
+// fused_edge_bwd4.hip: the backward over what the saving forward left (FabindEdgeBwdArgs.d2f / z3f / Mm): two contractions per edge
+int fe_bwd4_launch(const FabindEdgeBwdArgs* a, int H, int n_groups, hipStream_t stream);

@@ -159,11 +159,14 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __re
     }
 }
 
-extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
-                                     const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
-                                     const float* w3, int E, float* agg, float* s_out, float p_drop, unsigned seed,
-                                     float* bnd, void* agg16, hipStream_t stream) {
+static int fe_fwd_entry(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
+                        const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
+                        const float* w3, int E, float* agg, float* s_out, float p_drop, unsigned seed,
+                        float* bnd, void* agg16, void* Msave, void* d2f, void* z3f, hipStream_t stream) {
     if (E <= 0) return 0;
+    FB_REQUIRE((Msave != nullptr) == (d2f != nullptr) && (Msave != nullptr) == (z3f != nullptr),
+               "fabind_gcl_edge_fused_train: M, d2f and z3f come together");
+    FB_REQUIRE(Msave == nullptr || g_fe_fwd_variant == 1, "fabind_gcl_edge_fused_train: the saving forward is the row-wise / operand-swapped kernel (variant 1)");
     FB_REQUIRE(bnd != nullptr, "fabind_gcl_edge_fused: bnd (ceil(E/64) x 2 x H floats of scratch) is required");
     FB_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "fabind_gcl_edge_fused: p_drop in [0, 1)");
     const uint32_t thr16 = (uint32_t)(p_drop * 65536.0f + 0.5f);
@@ -174,7 +177,7 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
     const size_t lds = (size_t)FE_BM * H * 2 + FE_BM * sizeof(int) + (size_t)(H / 64) * FE_BM * sizeof(float);
     if (g_fe_fwd_variant == 1) {
         const int rc = fe_fwd2_launch(AB, ldab, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, E, agg, s_out, thr16, dscale, seed, bnd,
-                                      agg16, g_fe_xcd_aware, stream);
+                                      agg16, g_fe_xcd_aware, stream, Msave, d2f, z3f);
         if (rc) return rc;
     } else
 #define FE_LAUNCH(HH)                                                                                              \
@@ -191,6 +194,21 @@ extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int*
                        bnd, agg, (unsigned)H, (bf16_t*)agg16, (unsigned)H);
     FB_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
+                                     const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
+                                     const float* w3, int E, float* agg, float* s_out, float p_drop, unsigned seed,
+                                     float* bnd, void* agg16, hipStream_t stream) {
+    return fe_fwd_entry(AB, ldab, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, E, agg, s_out, p_drop, seed, bnd, agg16, nullptr, nullptr,
+                        nullptr, stream);
+}
+extern "C" int fabind_gcl_edge_fused_train(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
+                                           const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
+                                           const float* w3, int E, float* agg, float* s_out, float p_drop, unsigned seed,
+                                           float* bnd, void* agg16, void* M, void* d2f, void* z3f, hipStream_t stream) {
+    FB_REQUIRE(M != nullptr && d2f != nullptr && z3f != nullptr, "fabind_gcl_edge_fused_train: M, d2f, z3f are required");
+    return fe_fwd_entry(AB, ldab, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, E, agg, s_out, p_drop, seed, bnd, agg16, M, d2f, z3f, stream);
 }
 
 extern "C" int fabind_gcl_edge_fused_x3(const float* AB, int ldab, int n_rows, int H, const int* row, const int* col, const float* rhohat,
@@ -902,6 +920,10 @@ extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a_in, int H, i
     FB_REQUIRE(a->ldab % 8 == 0, "fabind_gcl_edge_fused_bwd: ldab % 8");
     FB_REQUIRE(a->p_drop >= 0.f && a->p_drop < 1.f, "fabind_gcl_edge_fused_bwd: p_drop in [0, 1)");
     const int g_fe_bwd_variant = fabind_gcl_edge_fused_bwd_variant_for(H);      // (shadows the file-level setting inside this launch)
+    if (a->d2f != nullptr || a->z3f != nullptr) {
+        FB_REQUIRE(a->d2f != nullptr && a->z3f != nullptr, "fabind_gcl_edge_fused_bwd: d2f and z3f (saved by fabind_gcl_edge_fused_train) come together");
+        return fe_bwd4_launch(a, H, n_groups, stream);
+    }
     if (g_fe_bwd_variant == 5) return fe_bwd3_launch(a, H, 64, n_groups, stream);
     FB_REQUIRE(a->dAB16 == nullptr, "fabind_gcl_edge_fused_bwd: dAB16 (bf16 receiving-side sums) exists in variant 5 only");
     if (g_fe_bwd_variant == 3 || g_fe_bwd_variant == 4) return fe_bwd2_launch(a, H, g_fe_bwd_variant == 3 ? 128 : 64, n_groups, stream);

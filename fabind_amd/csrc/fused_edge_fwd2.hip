@@ -9,6 +9,12 @@
 //   * the element-wise arithmetic is written on fp32 PAIRS (v_pk_add / mul / fma_f32);
 //   * the LDS tile swizzle uses four row bits (conflict-free ds_read_b128 of the A fragments, fused_common.h);
 //   * dropout is a compile-time variant.
+// SAVE (round 4, the training forward of the bf16 step): the kernel also leaves what the adjoint of fused_edge_bwd4.hip would otherwise
+// recompute with two more H x H contractions per edge -- the messages M as a row-major [E, H] bf16 operand (copied out of the LDS tile;
+// the weight gradient d Wc = dT^T M reads it as it is), silu'(pre2) (times the dropout keep factor) and pre3 = M Wc^T + bc as bf16 in
+// the ACCUMULATOR-FRAGMENT order of this kernel: tile t, wave w, quad (i, j), lane l -> 4 consecutive features at
+// ((t * NW + w) * 16 + i * 4 + j) * 64 + l) * 4 -- every store instruction is 512 contiguous bytes, and the backward's waves have the
+// same lane <-> (edge, feature) map, so they load their quads back the same way.  +3 x E x H x 2 bytes of stores per launch.
 #include "common.h"
 #include "fabind_hip.h"
 #include "fused_common.h"
@@ -22,14 +28,24 @@ __device__ __forceinline__ fw_f2 fw_silu_pair(const fw_f2 z) {
 __device__ __forceinline__ uint32_t fw_pack(const fw_f2 v) { return pack2_bf16(v.x, v.y); }
 __device__ __forceinline__ fw_f2 fw_unpack(const uint32_t u) { return fw_f2{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
 
-template <int H, bool DROP>
+// (m, d) = (silu(z), silu'(z)) on a pair
+__device__ __forceinline__ void fw_silu_pair_d(const fw_f2 z, fw_f2& m, fw_f2& d) {
+    const fw_f2 t = z * -1.44269504f;
+    const fw_f2 o = fw_f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+    const fw_f2 s = fw_f2{__builtin_amdgcn_rcpf(o.x), __builtin_amdgcn_rcpf(o.y)};
+    m = z * s;
+    d = s + (m - m * s);
+}
+
+template <int H, bool DROP, bool SAVE>
 __global__ __launch_bounds__(H, 4) void gcl_edge_fused2_kernel(const bf16_t* __restrict__ AB, int ldab, const int* __restrict__ row,
                                                             const int* __restrict__ col, const float* __restrict__ rhohat,
                                                             const float* __restrict__ w_r, const bf16_t* __restrict__ W2p,
                                                             const float* __restrict__ b2, const bf16_t* __restrict__ Wcp,
                                                             const float* __restrict__ bc, const float* __restrict__ w3, int E,
                                                             float* agg, float* s_out, uint32_t thr16, float dscale,
-                                                            uint32_t seed, float* bnd, bf16_t* agg16, int xcd_aware) {
+                                                            uint32_t seed, float* bnd, bf16_t* agg16, int xcd_aware,
+                                                            bf16_t* __restrict__ Msave, bf16_t* __restrict__ d2f, bf16_t* __restrict__ z3f) {
     constexpr int BM = FE_BM, MI = BM / 16;
     constexpr int NW = H / 64;
     constexpr int CH = H / 8;                                     // 16-byte chunks per edge row
@@ -95,6 +111,9 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused2_kernel(const bf16_t* __r
     const int cx = (wave * 8 + (cq >> 1)) ^ (fr & SWZ);
     const int lbase = fr * H + (cq & 1) * 4;
 #define FW_QOFF(i, j) (lbase + (i) * 16 * H + ((cx ^ ((j) * 2)) * 8))
+    // element offset of the same quad in the fragment-ordered save arrays (SAVE)
+    const size_t fbase = (((size_t)tile * NW + wave) * (MI * 4) * 64 + lane) * 4;
+#define FW_FOFF(i, j) (fbase + (size_t)((i) * 4 + (j)) * 256)
     const int fcol = wave * 64 + cq * 4;
 
     // ---- P1: M = silu(S1 W2^T + b2) -> tile in place
@@ -110,18 +129,36 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused2_kernel(const bf16_t* __r
         const fw_f2 b01 = fw_f2{bq4[j].x, bq4[j].y}, b23 = fw_f2{bq4[j].z, bq4[j].w};
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            fw_f2 m01 = fw_silu_pair(fw_f2{acc[i][j][0], acc[i][j][1]} + b01);
-            fw_f2 m23 = fw_silu_pair(fw_f2{acc[i][j][2], acc[i][j][3]} + b23);
+            fw_f2 m01, m23, d01, d23;
+            if constexpr (SAVE) {
+                fw_silu_pair_d(fw_f2{acc[i][j][0], acc[i][j][1]} + b01, m01, d01);
+                fw_silu_pair_d(fw_f2{acc[i][j][2], acc[i][j][3]} + b23, m23, d23);
+            } else {
+                m01 = fw_silu_pair(fw_f2{acc[i][j][0], acc[i][j][1]} + b01);
+                m23 = fw_silu_pair(fw_f2{acc[i][j][2], acc[i][j][3]} + b23);
+            }
             if constexpr (DROP) {
                 const uint32_t ee = (uint32_t)(e0 + i * 16 + fr), cc = (uint32_t)(fcol + j * 16);
-                m01 *= fw_f2{fe_keep(seed, ee, cc, H, thr16, dscale), fe_keep(seed, ee, cc + 1, H, thr16, dscale)};
-                m23 *= fw_f2{fe_keep(seed, ee, cc + 2, H, thr16, dscale), fe_keep(seed, ee, cc + 3, H, thr16, dscale)};
+                const fw_f2 k01 = fw_f2{fe_keep(seed, ee, cc, H, thr16, dscale), fe_keep(seed, ee, cc + 1, H, thr16, dscale)};
+                const fw_f2 k23 = fw_f2{fe_keep(seed, ee, cc + 2, H, thr16, dscale), fe_keep(seed, ee, cc + 3, H, thr16, dscale)};
+                m01 *= k01; m23 *= k23;
+                if constexpr (SAVE) { d01 *= k01; d23 *= k23; }
             }
             *(uint2*)&sX[FW_QOFF(i, j)] = make_uint2(fw_pack(m01), fw_pack(m23));
+            if constexpr (SAVE) *(uint2*)&d2f[FW_FOFF(i, j)] = make_uint2(fw_pack(d01), fw_pack(d23));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
+    if constexpr (SAVE) {                                         // the message tile as the weight gradient's row-major operand
+        const __amdgpu_buffer_rsrc_t rs_m = fe_rsrc(Msave + (size_t)e0 * H, (unsigned)ne * H * 2);
+#pragma unroll
+        for (int q = tid; q < BM * CH; q += H) {
+            const int rw = q / CH, c8 = q % CH;
+            const uint4 v = *(const uint4*)&sX[rw * H + ((c8 ^ (rw & SWZ)) * 8)];
+            __builtin_amdgcn_raw_buffer_store_b128(fe_u32x4_t{v.x, v.y, v.z, v.w}, rs_m, (int)((rw * H + c8 * 8) * 2), 0, /*aux: nt*/ 2);
+        }
+    }
 
     // ---- P2: agg[row] = sum of M over the node's edges (deterministic: fused_common.h fe_scan_rows)
     {
@@ -143,8 +180,10 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused2_kernel(const bf16_t* __r
             const fw_f2 b01 = fw_f2{bq.x, bq.y}, b23 = fw_f2{bq.z, bq.w}, w01 = fw_f2{wq.x, wq.y}, w23 = fw_f2{wq.z, wq.w};
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                da[i] += fw_silu_pair(fw_f2{acc[i][j][0], acc[i][j][1]} + b01) * w01;
-                db[i] += fw_silu_pair(fw_f2{acc[i][j][2], acc[i][j][3]} + b23) * w23;
+                const fw_f2 z01 = fw_f2{acc[i][j][0], acc[i][j][1]} + b01, z23 = fw_f2{acc[i][j][2], acc[i][j][3]} + b23;
+                da[i] += fw_silu_pair(z01) * w01;
+                db[i] += fw_silu_pair(z23) * w23;
+                if constexpr (SAVE) *(uint2*)&z3f[FW_FOFF(i, j)] = make_uint2(fw_pack(z01), fw_pack(z23));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -164,23 +203,29 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused2_kernel(const bf16_t* __r
         s_out[e0 + tid] = s;
     }
 #undef FW_QOFF
+#undef FW_FOFF
 }
 
 // launched from fabind_gcl_edge_fused (fused_edge.hip) when the forward variant is 1
 int fe_fwd2_launch(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat, const float* w_r,
                    const void* W2p, const float* b2, const void* Wcp, const float* bc, const float* w3, int E, float* agg,
-                   float* s_out, uint32_t thr16, float dscale, unsigned seed, float* bnd, void* agg16, int xcd_aware, hipStream_t stream) {
+                   float* s_out, uint32_t thr16, float dscale, unsigned seed, float* bnd, void* agg16, int xcd_aware, hipStream_t stream,
+                   void* Msave, void* d2f, void* z3f) {
     const dim3 grid((((E + FE_BM - 1) / FE_BM + 7) / 8) * 8);
     const size_t lds = (size_t)FE_BM * H * 2 + 3 * FE_BM * sizeof(int) + (size_t)(H / 64) * FE_BM * sizeof(float);
-#define FW_LAUNCH_(HH, DD)                                                                                         \
+#define FW_LAUNCH_(HH, DD, SS)                                                                                       \
     do {                                                                                                           \
         static bool set_ = false;                                                                                  \
-        if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused2_kernel<HH, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
-        hipLaunchKernelGGL((gcl_edge_fused2_kernel<HH, DD>), grid, dim3(HH), lds, stream, (const bf16_t*)AB, ldab, row, col, rhohat, \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused2_kernel<HH, DD, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        hipLaunchKernelGGL((gcl_edge_fused2_kernel<HH, DD, SS>), grid, dim3(HH), lds, stream, (const bf16_t*)AB, ldab, row, col, rhohat, \
                            w_r, (const bf16_t*)W2p, b2, (const bf16_t*)Wcp, bc, w3, E, agg, s_out, thr16, dscale, \
-                           (uint32_t)seed, bnd, (bf16_t*)agg16, xcd_aware);                                       \
+                           (uint32_t)seed, bnd, (bf16_t*)agg16, xcd_aware, (bf16_t*)Msave, (bf16_t*)d2f, (bf16_t*)z3f); \
     } while (0)
-#define FW_LAUNCH(HH) do { if (thr16) FW_LAUNCH_(HH, true); else FW_LAUNCH_(HH, false); } while (0)
+#define FW_LAUNCH(HH)                                                                  \
+    do {                                                                               \
+        if (Msave) { if (thr16) FW_LAUNCH_(HH, true, true); else FW_LAUNCH_(HH, false, true); } \
+        else { if (thr16) FW_LAUNCH_(HH, true, false); else FW_LAUNCH_(HH, false, false); }    \
+    } while (0)
     if (H == 512) FW_LAUNCH(512); else if (H == 256) FW_LAUNCH(256); else if (H == 128) FW_LAUNCH(128); else FW_LAUNCH(64);
 #undef FW_LAUNCH
 #undef FW_LAUNCH_

@@ -514,10 +514,20 @@ def zero_empty_rows(rowptr, out, C, out2=None):
                                              stream()), "fabind_zero_empty_rows")
 
 
-def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows, p_drop=0.0, seed=0, want16=False, rowptr=None):
+def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows, p_drop=0.0, seed=0, want16=False, rowptr=None, save=False):
     """want16: also return the aggregated messages as bf16 (the node MLP's operand), written by the same kernels.
-    rowptr (CSR of `row`, optional): only the rows without edges are zeroed instead of the whole output."""
+    rowptr (CSR of `row`, optional): only the rows without edges are zeroed instead of the whole output.
+    save (training forward): the kernel also leaves (M [E,H] bf16, d2f, z3f) -- the messages and, in its accumulator-fragment order,
+    silu'(pre2) and pre3 -- appended to the result as one tuple: what gcl_edge_fused_bwd(saved=...) needs to run without the forward
+    recompute (csrc/fused_edge_bwd4.hip)."""
     E = row.shape[0]
+    if save and E > 0:
+        nt = (E + 63) // 64
+        Msave = torch.empty((E, H), dtype=torch.bfloat16, device=AB16.device)
+        d2f = torch.empty((nt * 64, H), dtype=torch.bfloat16, device=AB16.device)
+        z3f = torch.empty((nt * 64, H), dtype=torch.bfloat16, device=AB16.device)
+    else:
+        save, Msave, d2f, z3f = False, None, None, None
     alloc = torch.zeros if (rowptr is None or E == 0) else torch.empty
     agg = alloc((n_rows, H), dtype=torch.float32, device=AB16.device)
     agg16 = alloc((n_rows, H), dtype=torch.bfloat16, device=AB16.device) if want16 else None
@@ -525,12 +535,22 @@ def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows,
         zero_empty_rows(rowptr, agg, H, agg16)
     s = torch.empty((max(E, 1), 1), dtype=torch.float32, device=AB16.device)
     bnd = torch.empty(((E + 63) // 64 * 2 + 2, H), dtype=torch.float32, device=AB16.device)      # boundary runs (deterministic sums)
-    _profiled("gcl_edge_fused_kernel<%d> E=%d (gather + 2 chained H x H contractions + segment-sum per edge)" % (H, E), 4.0 * E * H * H,
-              lambda: check(_lib.load().fabind_gcl_edge_fused(ptr(AB16), _ld(AB16), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
-                                                              ptr(W2p), ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s),
-                                                              float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd), ptr(agg16), stream()),
-                            "fabind_gcl_edge_fused"))
-    return (agg, s[:E], agg16) if want16 else (agg, s[:E])
+    if save:
+        _profiled("gcl_edge_fused_kernel<%d> E=%d saving (gather + 2 chained H x H contractions + segment-sum per edge; M, silu'(pre2), pre3 kept)" % (H, E),
+                  4.0 * E * H * H,
+                  lambda: check(_lib.load().fabind_gcl_edge_fused_train(ptr(AB16), _ld(AB16), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
+                                                                        ptr(W2p), ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s),
+                                                                        float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd), ptr(agg16),
+                                                                        ptr(Msave), ptr(d2f), ptr(z3f), stream()),
+                                "fabind_gcl_edge_fused_train"))
+    else:
+        _profiled("gcl_edge_fused_kernel<%d> E=%d (gather + 2 chained H x H contractions + segment-sum per edge)" % (H, E), 4.0 * E * H * H,
+                  lambda: check(_lib.load().fabind_gcl_edge_fused(ptr(AB16), _ld(AB16), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
+                                                                  ptr(W2p), ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s),
+                                                                  float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd), ptr(agg16), stream()),
+                                "fabind_gcl_edge_fused"))
+    out = (agg, s[:E], agg16) if want16 else (agg, s[:E])
+    return out + ((Msave, d2f, z3f),) if save else out
 
 
 def edge_lnfold(AB16, Kp, H, row, col, rho, stat, eps, w_r, c_r, c_c, dvec, p_drop=0.0, seed=0):
@@ -592,20 +612,27 @@ EDGE_BWD_TIMES = None   # set to an int64[12] device tensor to collect per-phase
 
 
 def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, dagg, colptr, perm, p_drop=0.0, seed=0,
-                       want_edges=False, dab_bf16=False, w_dtype=torch.float32, rowptr=None, frags=None):
+                       want_edges=False, dab_bf16=False, w_dtype=torch.float32, rowptr=None, frags=None, saved=None):
     """Adjoint of gcl_edge_fused (csrc/fused_edge.hip): returns dAB [N,2H] fp32, drh [E], dw_r, dW2, db2, dWc, dbc, dw3.
     The five [E,H] bf16 operands it writes (S1, M, dT, dP2 for the weight gradients, dP1 for the sending-side
-    reduction) are scratch that is released on return."""
+    reduction) are scratch that is released on return.
+    saved = (M, d2f, z3f) of gcl_edge_fused(save=True): the two-contraction kernel (csrc/fused_edge_bwd4.hip) -- no forward recompute,
+    M is the forward's, two work-groups per CU."""
     E, N, dev = row.shape[0], AB16.shape[0], AB16.device
     ng = _N_CU.get(dev)
     if ng is None:
         ng = _N_CU[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
     lib = _lib.load()
     variant = lib.fabind_gcl_edge_fused_bwd_variant_for(H)
+    if saved is not None and E > 0:
+        variant = 6                                          # (chosen by the arguments: FabindEdgeBwdArgs.d2f / z3f)
     if variant == 2 and H < 128:
         variant = 0                                          # the 128-edge tile needs >= 128 threads (one per edge in the row tables)
-    bm = {1: 64, 2: 128, 3: 128, 4: 64, 5: 64}.get(variant) or lib.fabind_gcl_edge_fused_bwd_tile()
-    if variant == 5:
+    bm = {1: 64, 2: 128, 3: 128, 4: 64, 5: 64, 6: 64}.get(variant) or lib.fabind_gcl_edge_fused_bwd_tile()
+    if variant == 6:
+        # one in-place [64][H] LDS tile + tables + partial sums, <= 128 VGPRs (four waves per SIMD): two work-groups per CU at H = 512
+        per_cu = max(1, min(8, (160 * 1024) // (2 * bm * H + 16 * H + 32 * bm), 16 // max(1, H // 64)))
+    elif variant == 5:
         # H/64 compute waves + one store wave per work-group, <= 168 VGPRs (three waves per SIMD): 12 waves per CU; two [64][H] LDS tiles
         per_cu = max(1, min(8, (160 * 1024) // (4 * bm * H + 16 * H + 32 * bm), 12 // (H // 64 + 1)))
     elif variant in (2, 3):
@@ -622,11 +649,15 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
         ng = int(EDGE_BWD_GROUPS)       # development knob (tools/probes/edge_bwd_variants.py)
     if ng >= 8:
         ng -= ng % 8                # a multiple of 8 selects the XCD-aware walk (csrc/fused_edge.hip)
-    d2scratch = torch.empty((2 if variant >= 3 else 1, ng, bm * H), dtype=torch.bfloat16, device=dev) if variant else None
+    d2scratch = torch.empty((2 if variant >= 3 else 1, ng, bm * H), dtype=torch.bfloat16, device=dev) if variant in (1, 2, 3, 4, 5) else None
     bnd = torch.empty(((E + bm - 1) // bm * 2 + 2, H), dtype=torch.float32, device=dev)       # boundary runs (deterministic sums)
-    buf = torch.empty((5, max(E, 1), H), dtype=torch.bfloat16, device=dev)
-    S1, Mm, dT, dP2, dP1 = buf[0], buf[1], buf[2], buf[3], buf[4]
-    dab_bf16 = bool(dab_bf16) and variant == 5          # both halves of dAB written as bf16 by their producers (no cast pass)
+    if variant == 6:
+        buf = torch.empty((4, max(E, 1), H), dtype=torch.bfloat16, device=dev)
+        S1, Mm, dT, dP2, dP1 = buf[0], saved[0], buf[1], buf[2], buf[3]
+    else:
+        buf = torch.empty((5, max(E, 1), H), dtype=torch.bfloat16, device=dev)
+        S1, Mm, dT, dP2, dP1 = buf[0], buf[1], buf[2], buf[3], buf[4]
+    dab_bf16 = bool(dab_bf16) and variant in (5, 6)     # both halves of dAB written as bf16 by their producers (no cast pass)
     # rowptr (CSR of `row`): columns [0, H) are written for nodes with edges (scan + fix-up), columns [H, 2H) for every node
     # (segment_sum) -- only the [0, H) halves of nodes without edges need zeroing
     dAB = (torch.zeros if (rowptr is None or E == 0) else torch.empty)((N, 2 * H), dtype=torch.bfloat16 if dab_bf16 else torch.float32, device=dev)
@@ -649,9 +680,12 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     a.ldab, a.lddagg, a.lddab, a.E = _ld(AB16), _ld(dagg), _ld(dAB), E
     a.lddab16 = _ld(dAB)
     a.p_drop, a.seed = float(p_drop), int(seed) & 0xFFFFFFFF
-    a.dbg = ptr(EDGE_BWD_TIMES) if EDGE_BWD_TIMES is not None else None
-    _profiled("gcl_edge_fused_bwd%s_kernel<%d> E=%d (recompute + 4 chained H x H contractions per edge)" % ({1: "1", 2: "1_128", 3: "2_128", 4: "2_64", 5: "3"}.get(variant, ""), H, E),
-              8.0 * E * H * H,
+    a.dbg = ptr(EDGE_BWD_TIMES) if (EDGE_BWD_TIMES is not None and variant != 6) else None
+    if variant == 6:
+        a.d2f, a.z3f = ptr(saved[1]), ptr(saved[2])
+    _profiled(("gcl_edge_fused_bwd4_kernel<%d> E=%d (2 chained H x H contractions per edge over the forward's saved tiles)" % (H, E)) if variant == 6 else
+              "gcl_edge_fused_bwd%s_kernel<%d> E=%d (recompute + 4 chained H x H contractions per edge)" % ({1: "1", 2: "1_128", 3: "2_128", 4: "2_64", 5: "3"}.get(variant, ""), H, E),
+              (4.0 if variant == 6 else 8.0) * E * H * H,
               lambda: check(_lib.load().fabind_gcl_edge_fused_bwd(ctypes.byref(a), H, ng, stream()),
                             "fabind_gcl_edge_fused_bwd"))
     del keep

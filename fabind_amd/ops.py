@@ -677,24 +677,34 @@ def edge_tail(Mm, Wc, bc, w3, rowptr, row, n_rows, act_epi=K.ACT_SILU):
     return part, K.segment_sum(Mm, rowptr, n_rows)
 
 
+EDGE_SAVE_FWD = os.environ.get("FABIND_EDGE_SAVE_FWD", "1") != "0"          # 0: the recompute backward (four contractions, nothing kept)
+EDGE_SAVE_MIN_EDGES = int(os.environ.get("FABIND_EDGE_SAVE_MIN_EDGES", "0"))
+
+
 class _FusedEdge(torch.autograd.Function):
-    """Whole intra-graph edge pipeline of MC_E_GCL as one kernel each way (csrc/fused_edge.hip): the forward keeps
-    no per-edge tensor, the backward recomputes them tile by tile in LDS."""
+    """Whole intra-graph edge pipeline of MC_E_GCL as one kernel each way (csrc/fused_edge.hip).  H >= 256 (the store-wave domain of the
+    recompute backward): the training forward leaves the messages and two bf16 per-edge tiles (silu'(pre2), pre3: 6 H bytes per edge
+    until the backward has run) and the backward chains two contractions per edge (csrc/fused_edge_bwd4.hip); otherwise -- and with
+    FABIND_EDGE_SAVE_FWD=0 -- the forward keeps no per-edge tensor and the backward recomputes them tile by tile in LDS."""
 
     @staticmethod
     def forward(ctx, AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed, holder=None, frags=None):
         ctx.H, ctx.g, ctx.p_drop, ctx.seed, ctx.frags = H, g, p_drop, seed, frags
-        ctx.save_for_backward(AB16, rhohat, w_r, W2, b2, Wc, bc, w3)
         W2p, Wcp = (frags[0], frags[1]) if frags is not None else (K.pack_frag(W2), K.pack_frag(Wc))
+        E = g.row_ctx.shape[0]
+        save = EDGE_SAVE_FWD and H >= 256 and E >= max(1, EDGE_SAVE_MIN_EDGES) and AB16.dtype == torch.bfloat16
         out = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, W2p, b2, Wcp, bc, w3,
-                               AB16.shape[0], p_drop, seed, want16=holder is not None, rowptr=g.rp_ctx)
+                               AB16.shape[0], p_drop, seed, want16=holder is not None, rowptr=g.rp_ctx, save=save)
+        ctx.n_saved = 3 if save else 0
+        ctx.save_for_backward(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, *(out[-1] if save else ()))
         if holder is not None:
             holder.append(out[2])                     # the aggregated messages as the node MLP's bf16 operand (same kernels)
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, dagg, ds):
-        AB16, rhohat, w_r, W2, b2, Wc, bc, w3 = ctx.saved_tensors
+        AB16, rhohat, w_r, W2, b2, Wc, bc, w3 = ctx.saved_tensors[:8]
+        saved = tuple(ctx.saved_tensors[8:]) if ctx.n_saved else None
         g = ctx.g
         colptr, perm = g.ctx_by_col()
         if dagg is None:
@@ -703,7 +713,8 @@ class _FusedEdge(torch.autograd.Function):
             ds = torch.zeros(g.row_ctx.shape[0], dtype=torch.float32, device=AB16.device)
         dAB, drh, dwr, dW2, db2, dWc, dbc, dw3 = K.gcl_edge_fused_bwd(
             AB16, ctx.H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, ds.reshape(-1).float(), dagg.float(),
-            colptr, perm, ctx.p_drop, ctx.seed, dab_bf16=AB16.dtype == torch.bfloat16, w_dtype=W2.dtype, rowptr=g.rp_ctx, frags=ctx.frags)
+            colptr, perm, ctx.p_drop, ctx.seed, dab_bf16=AB16.dtype == torch.bfloat16, w_dtype=W2.dtype, rowptr=g.rp_ctx, frags=ctx.frags,
+            saved=saved)
         return (dAB.to(AB16.dtype), drh, dwr, dW2.to(W2.dtype), db2, dWc.to(Wc.dtype), dbc, dw3, None, None, None, None, None, None)
 
 

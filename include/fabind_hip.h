@@ -55,8 +55,9 @@ const char* fabind_last_error(void);
  *     fabind_pack_frag_multi + FabindPackSeg (all fragment packs of a model call in one launch); fabind_lower_bound;
  *     fabind_cross_attn_fused_fwd takes lse; fabind_cross_attn_fused_bwd + FabindAttnFusedBwdArgs, fabind_pair_bot_pack (fused backward of the
  *     cross attention: fabind_sizeof_args(4)).
+ * 16 = fabind_gcl_edge_fused_train (the forward that saves M / silu'(pre2) / pre3) and FabindEdgeBwdArgs.{d2f, z3f} (the two-contraction backward).
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 15
+#define FABIND_ABI_VERSION 16
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs, 3 FabindTnJob (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -271,6 +272,15 @@ int fabind_gcl_edge_fused(const void* AB, int ldab, int H, const int* row, const
                           void* agg16 /* NULL, or [n_rows, H] bf16: the aggregated messages as the next contraction's operand */,
                           hipStream_t stream);
 
+/* The same forward for a training step: additionally leaves M [E, H] bf16 row-major (the messages after dropout: operand of
+ * d Wc = dT^T M), and d2f / z3f = silu'(pre2) x keep and pre3 = M Wc^T + bc as bf16 in the kernel's accumulator-fragment order
+ * (ceil(E/64) x 64 x H elements each; opaque to the caller, consumed by fabind_gcl_edge_fused_bwd through FabindEdgeBwdArgs.d2f / z3f),
+ * so that the backward chains two H x H contractions per edge instead of four (no forward recompute). */
+int fabind_gcl_edge_fused_train(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
+                                const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
+                                const float* w3, int E, float* agg, float* s_out, float p_drop, unsigned seed, float* bnd,
+                                void* agg16, void* M, void* d2f, void* z3f, hipStream_t stream);
+
 /* Backward of the fused edge pipeline (training, bf16): recomputes the forward per 64-edge tile and chains the four
  * H x H contractions of the adjoint (autograd of models/egnn.py:68-128).  Inputs: the forward's operands, ds [E]
  * (gradient of s), dagg [n_rows, lddagg] fp32 (gradient of agg); W2p/Wcp = fragment-packed W2 / Wc, W2Tp/WcTp =
@@ -295,6 +305,10 @@ typedef struct FabindEdgeBwdArgs {
     int lddab16;
     void* dAB16;             /* NULL, or [N, lddab16] bf16: the receiving-side sums go to its columns [0, H) INSTEAD of dABrow (variant 5
                               * only; the caller reduces dP1 into columns [H, 2H) with fabind_segment_sum's out16) */
+    const void* d2f;         /* NULL, or silu'(pre2) as saved by fabind_gcl_edge_fused_train (bf16, ceil(E/64) x 64 x H, fragment order) and */
+    const void* z3f;         /* pre3 likewise: the launch then takes the TWO-contraction kernel (csrc/fused_edge_bwd4.hip), which reads these
+                              * instead of recomputing them, does NOT write Mm (the forward's M is the weight gradient's operand) and needs
+                              * neither d2scratch nor dbg; n_groups up to 2 x CUs at H = 512 (64 KiB LDS tile, <= 128 VGPRs) */
 } FabindEdgeBwdArgs;
 int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* args, int H, int n_groups, hipStream_t stream);
 /* Edges per tile of the backward kernel: 64 (one work-group per CU, default) or 32 (two per CU). */

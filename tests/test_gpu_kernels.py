@@ -162,18 +162,20 @@ def test_segment_sum_and_scan():
         assert (out.cpu() - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max())
 
 
-@pytest.mark.parametrize("bm,p_drop", [(32, 0.0), (64, 0.0), (64, 0.25), (1, 0.0), (1, 0.25), (2, 0.0), (2, 0.25), (3, 0.0), (3, 0.25), (4, 0.0), (4, 0.25), (5, 0.0), (5, 0.25)])
-@pytest.mark.parametrize("H", [64, 128, 512])
+@pytest.mark.parametrize("bm,p_drop", [(32, 0.0), (64, 0.0), (64, 0.25), (1, 0.0), (1, 0.25), (2, 0.0), (2, 0.25), (3, 0.0), (3, 0.25), (4, 0.0), (4, 0.25), (5, 0.0), (5, 0.25), (6, 0.0), (6, 0.25)])
+@pytest.mark.parametrize("H", [64, 128, 256, 512])
 def test_fused_edge_backward_matches_autograd(H, bm, p_drop):
     """csrc/fused_edge.hip backward (recompute + 4 chained contractions) vs torch autograd of the same bf16-rounded
     forward on the CPU: every gradient the kernel produces, including the partial column sums and both halves of dAB.
     bm = 32 / 64: the two-LDS-tile kernel of round 1 (variant 0); bm = 1: the single in-place tile kernel, two work-groups
     per CU (variant 1, a knob); bm = 2: one in-place tile of 128 edges, one work-group per CU (variant 2; falls back to variant 0
-    below 128 columns); bm = 3 / 4: the row-wise, operand-swapped kernel (csrc/fused_edge_bwd2.hip) at 128 / 64 edges per tile; bm = 5: the same with a store wave (csrc/fused_edge_bwd3.hip), 64 edges per tile."""
+    below 128 columns); bm = 3 / 4: the row-wise, operand-swapped kernel (csrc/fused_edge_bwd2.hip) at 128 / 64 edges per tile; bm = 5: the same with a store wave (csrc/fused_edge_bwd3.hip), 64 edges per tile;
+    bm = 6: the two-contraction kernel over what the SAVING forward left (csrc/fused_edge_bwd4.hip: M, silu'(pre2) x keep, pre3 from
+    fabind_gcl_edge_fused_train -- no recompute; the dropout mask reaches the backward through the saved tiles only)."""
     from fabind_amd import kernels as K, _lib
     dev = _dev()
-    _lib.load().fabind_gcl_edge_fused_bwd_set_variant(bm if bm in (1, 2, 3, 4, 5) else 0)
-    _lib.load().fabind_gcl_edge_fused_bwd_set_tile(64 if bm in (1, 2, 3, 4, 5) else bm)
+    _lib.load().fabind_gcl_edge_fused_bwd_set_variant(bm if bm in (1, 2, 3, 4, 5) else 5 if bm == 6 else 0)
+    _lib.load().fabind_gcl_edge_fused_bwd_set_tile(64 if bm in (1, 2, 3, 4, 5, 6) else bm)
     g = torch.Generator().manual_seed(100 + H)
     N = 300
     deg = torch.randint(0, 12, (N,), generator=g)
@@ -208,9 +210,28 @@ def test_fused_edge_backward_matches_autograd(H, bm, p_drop):
     colsorted, perm = torch.sort(col, stable=True)
     colptr = torch.zeros(N + 1, dtype=torch.int32)
     colptr[1:] = torch.cumsum(torch.bincount(colsorted, minlength=N), 0)
+    saved = None
+    if bm == 6:
+        fw = K.gcl_edge_fused(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), K.pack_frag(W2.to(dev)),
+                              b2.to(dev), K.pack_frag(Wc.to(dev)), bc.to(dev), w3.to(dev), N, p_drop, seed, save=True)
+        saved = fw[-1]
+        assert len(saved) == 3 and saved[0].shape == (E, H) and saved[1].shape == ((E + 63) // 64 * 64, H)
+        assert (saved[0].float().cpu() - M.detach()).abs().max() <= 2e-2 * max(1.0, float(M.abs().max()))      # the messages, row-major
+        fw0 = K.gcl_edge_fused(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), K.pack_frag(W2.to(dev)),
+                               b2.to(dev), K.pack_frag(Wc.to(dev)), bc.to(dev), w3.to(dev), N, p_drop, seed)
+        assert torch.equal(fw[0], fw0[0]) and torch.equal(fw[1], fw0[1])                                       # same outputs as the plain forward
     out = K.gcl_edge_fused_bwd(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev),
                                Wc.to(dev), bc.to(dev), w3.to(dev), ds.to(dev), dagg.to(dev), colptr.to(dev), i32(perm),
-                               p_drop, seed)
+                               p_drop, seed, saved=saved)
+    if bm == 6:     # twice: bit-identical (no float atomics); and the bf16 dAB form
+        out2 = K.gcl_edge_fused_bwd(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev),
+                                    Wc.to(dev), bc.to(dev), w3.to(dev), ds.to(dev), dagg.to(dev), colptr.to(dev), i32(perm),
+                                    p_drop, seed, saved=saved)
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(out, out2))
+        out16 = K.gcl_edge_fused_bwd(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev),
+                                     Wc.to(dev), bc.to(dev), w3.to(dev), ds.to(dev), dagg.to(dev), colptr.to(dev), i32(perm),
+                                     p_drop, seed, dab_bf16=True, rowptr=rowptr.to(dev), saved=saved)
+        assert out16[0].dtype == torch.bfloat16 and torch.equal(out16[0].cpu(), out[0].cpu().bfloat16())
     if bm == 5:     # the default form can write both halves of dAB as bf16 itself (scan / fix-up / segment_sum out16): same values, rounded
         out16 = K.gcl_edge_fused_bwd(AB16.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev),
                                      Wc.to(dev), bc.to(dev), w3.to(dev), ds.to(dev), dagg.to(dev), colptr.to(dev), i32(perm),
