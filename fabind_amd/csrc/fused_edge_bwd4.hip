@@ -32,6 +32,9 @@
 #ifndef FE4_E3_DB
 #define FE4_E3_DB 0        // 1 = dagg / silu'(pre2) of the next 16-feature block requested under the current block's arithmetic (48 more live registers)
 #endif
+#ifndef FE4_SCAN64
+#define FE4_SCAN64 0       // 1 = the all-rows-in-registers scan of the forward kernel (fe_scan_runs64) instead of fe_scan_rows
+#endif
 #ifndef FE4_P5_BATCH
 #define FE4_P5_BATCH 4     // gathered rows in flight per lane and batch of the row-wise phase (8 = the whole tile: 64 registers)
 #endif
@@ -318,8 +321,13 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd4_kernel(const FabindE
         {
             const bool head_cont = e0 > 0 && p.row[e0 - 1] == sRow[0];
             const bool tail_cont = e0 + ne < p.E && p.row[e0 + ne] == sRow[ne - 1];
+#if FE4_SCAN64
+            sPart[3 * H + tid] += fe_scan_runs64<H, true, SWZ>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dAB16 ? nullptr : p.dABrow, (unsigned)p.lddab,
+                                                              p.bnd + (size_t)tile * 2 * H, tid, (bf16_t*)p.dAB16, (unsigned)p.lddab16);
+#else
             sPart[3 * H + tid] += fe_scan_rows<H, true, BM, SWZ>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dAB16 ? nullptr : p.dABrow, (unsigned)p.lddab,
                                                                 p.bnd + (size_t)tile * 2 * H, tid, (bf16_t*)p.dAB16, (unsigned)p.lddab16);
+#endif
         }
         if (has_next) commit_tables(hb ^ 1);
         __syncthreads();                                          // the next tile overwrites the tile; its tables are in place
