@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 # dense matrix-core peaks (MI355X_MICROARCH.md); "bf16x3": three bf16 MFMAs per product term, so a third of the bf16 peak in USEFUL flops
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3.0}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
 def stack_args(hidden, layers, n_iter):
@@ -470,6 +471,7 @@ def main():
                 step()
         sync()
         K.PROFILE = {} if profile else None
+        K.PROFILE_BYTES.clear()
         K.PROFILE_ONLY = only
         t0 = time.time()
         for _ in range(steps):
@@ -498,17 +500,26 @@ def main():
         flops of its actual group sizes."""
         fams = {}
         for label, evs in prof.items():
-            f = fams.setdefault(family(label), [0.0, 0, 0.0, label])
+            f = fams.setdefault(family(label), [0.0, 0, 0.0, label, 0.0])
             for s_, e_, fl in evs:
                 f[0] += s_.elapsed_time(e_)
                 f[1] += 1
                 f[2] += fl
-        name, (ms, cnt, flops, label) = max(fams.items(), key=lambda kv: kv[1][0])
+            f[4] += K.PROFILE_BYTES.get(label, 0.0)
+        name, (ms, cnt, flops, label, nbytes) = max(fams.items(), key=lambda kv: kv[1][0])
         peak = MFMA_PEAK_TFLOPS[precision]
         ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        return {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+        hbm = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0                 # algorithmic GB/s of the same launches
+        out_ = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                 "kernel": label if len([1 for l_ in prof if family(l_) == name]) == 1 else name + " (all shapes of the step)",
-                "flop_per_launch": flops / cnt, "launches": cnt, "avg_us": 1e3 * ms / cnt, "share_of_step": ms / (1e3 * dt)}
+                "flop_per_launch": flops / cnt, "launches": cnt, "avg_us": 1e3 * ms / cnt, "share_of_step": ms / (1e3 * dt),
+                "algorithmic_bytes_per_launch": nbytes / cnt}
+        other = {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS}
+        if other["frac"] > out_["frac"]:                                   # the roofline that binds is the one the launches sit closer to
+            for k_ in ("bound", "achieved", "peak", "unit", "frac"):
+                out_[k_], other[k_] = other[k_], out_[k_]
+        out_["other_roofline"] = other
+        return out_
 
     step, per_rank, _ = make_step(a.mode, a.n_iter)
     dt, prof = timed(step, a.warmup, a.steps, os.environ.get("FABIND_BENCH_NO_PROFILE", "0") != "1")   # (=1: no per-launch events, A/B of their cost)
@@ -556,7 +567,7 @@ def main():
             out["roofline"] = roofline_of(prof, dt, a.precision)
             # HBM traffic of the dominant kernel: NOT measured in this run -- the per-launch figure of the committed PMC passes
             # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per MI355X_MICROARCH.md "HBM"); the source is named
-            for name in ("r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+            for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
                 pmc = os.path.join(ROOT, "profiles", name)
                 if not os.path.exists(pmc):
                     continue

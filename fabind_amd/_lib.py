@@ -176,6 +176,10 @@ def load():
     lib.fabind_gemm_set_persistent.restype = None
     lib.fabind_gemm_set_small_m.argtypes = [ctypes.c_int]
     lib.fabind_gemm_set_small_m.restype = None
+    lib.fabind_gemm_set_big.argtypes = [ctypes.c_int]
+    lib.fabind_gemm_set_big.restype = None
+    if os.environ.get("FABIND_GEMM_BIG"):                # A/B knob: 0 = the 256 x 128 tile kernel only
+        lib.fabind_gemm_set_big(int(os.environ["FABIND_GEMM_BIG"]))
     lib.fabind_gemm_set_x3_tile.argtypes = [ctypes.c_int]
     lib.fabind_gemm_set_x3_tile.restype = None
     if os.environ.get("FABIND_GEMM_SMALL_M"):
@@ -188,11 +192,13 @@ def load():
     lib.fabind_gemm_tn_tile_n.restype = ctypes.c_int
     lib.fabind_gcl_edge_fused_set_xcd_aware.argtypes = [ctypes.c_int]
     lib.fabind_gcl_edge_fused_set_xcd_aware.restype = None
-    for nm in ("fabind_gcl_edge_fused_bwd2_set_exp", "fabind_gcl_edge_fused_bwd3_set_exp"):      # development knobs (void)
+    for nm in ("fabind_gcl_edge_fused_bwd2_set_exp", "fabind_gcl_edge_fused_bwd3_set_exp", "fabind_gcl_edge_fused_bwd4_set_exp"):      # development knobs (void)
         getattr(lib, nm).argtypes = [ctypes.c_int]
         getattr(lib, nm).restype = None
     if os.environ.get("FABIND_EDGE_BWD3_EXP"):           # development knob: experiment mask of the store-wave backward (32 = nt operand stores)
         lib.fabind_gcl_edge_fused_bwd3_set_exp(int(os.environ["FABIND_EDGE_BWD3_EXP"]))
+    if os.environ.get("FABIND_EDGE_BWD4_EXP"):           # sensitivity mask of the saved-forward backward (results wrong: timing only)
+        lib.fabind_gcl_edge_fused_bwd4_set_exp(int(os.environ["FABIND_EDGE_BWD4_EXP"]))
     if "FABIND_EDGE_BWD_VARIANT" in os.environ:          # development knobs for same-box A/B runs (tools/probes)
         lib.fabind_gcl_edge_fused_bwd_set_variant.argtypes = [ctypes.c_int]
         lib.fabind_gcl_edge_fused_bwd_set_variant(int(os.environ["FABIND_EDGE_BWD_VARIANT"]))

@@ -40,7 +40,7 @@
 #endif
 
 template <int H>
-__global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd4_kernel(const FabindEdgeBwdArgs p) {
+__global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd4_kernel(const FabindEdgeBwdArgs p, const int xf) {
     constexpr int BM = FE_BM, MI = BM / 16;
     constexpr int NW = H / 64;
     constexpr int CH = H / 8;                                     // 16-byte chunks per edge row
@@ -182,10 +182,10 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd4_kernel(const FabindE
         __syncthreads();                                          // dT ready
 
         // ---- C3: dM = dT Wc   (the dT tile leaves as the operand of d Wc = dT^T M)
-        copy_out(p.dT);
+        if (!(xf & 1)) copy_out(p.dT);
         f32x4_t acc[MI][4];
         fe_zero(acc);
-        fe_gemm_rolled<H, MI, true, SWZ>(sX, WcTp, wave, lane, acc);
+        if (!(xf & 8)) fe_gemm_rolled<H, MI, true, SWZ>(sX, WcTp, wave, lane, acc);
         __syncthreads();                                          // every wave has finished reading dT
 
         // ---- E3: dP2 = (dM + dagg[row]) * silu'(pre2) -> tile in place   (dagg and silu'(pre2) fetched one 16-feature block ahead)
@@ -234,9 +234,9 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd4_kernel(const FabindE
         __syncthreads();                                          // dP2 ready
 
         // ---- C4: dS1 = dP2 W2   (the dP2 tile leaves as the operand of d W2 = dP2^T S1)
-        copy_out(p.dP2);
+        if (!(xf & 1)) copy_out(p.dP2);
         fe_zero(acc);
-        fe_gemm_rolled<H, MI, true, SWZ>(sX, W2Tp, wave, lane, acc);
+        if (!(xf & 8)) fe_gemm_rolled<H, MI, true, SWZ>(sX, W2Tp, wave, lane, acc);
         __syncthreads();
         {
             int cx_ = cx, lb_ = lbase;
@@ -297,8 +297,10 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd4_kernel(const FabindE
                 }
                 *sp = make_uint4(pg[0], pg[1], pg[2], pg[3]);
                 const unsigned goff = (unsigned)(e * H + ch * 8) * 2;        // (rows >= ne: outside the descriptors, dropped)
-                __builtin_amdgcn_raw_buffer_store_b128(fe_u32x4_t{po[0], po[1], po[2], po[3]}, rs_s1, (int)goff, 0, /*aux: nt*/ 2);
-                __builtin_amdgcn_raw_buffer_store_b128(fe_u32x4_t{pg[0], pg[1], pg[2], pg[3]}, rs_p1, (int)goff, 0, /*aux: nt*/ 2);
+                if (!(xf & 2)) {
+                    __builtin_amdgcn_raw_buffer_store_b128(fe_u32x4_t{po[0], po[1], po[2], po[3]}, rs_s1, (int)goff, 0, /*aux: nt*/ 2);
+                    __builtin_amdgcn_raw_buffer_store_b128(fe_u32x4_t{pg[0], pg[1], pg[2], pg[3]}, rs_p1, (int)goff, 0, /*aux: nt*/ 2);
+                }
                 float dot = dot2.x + dot2.y;
                 if constexpr (CH >= 16) {
                     dot = fe3_row16_sum(dot);
@@ -318,7 +320,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd4_kernel(const FabindE
         // ---- P6 (one column per thread): receiving-side segment sum of dP1 (deterministic) and the d w_r column sum; the tables of the
         //      next tile are fetched underneath it
         if (has_next) fetch_tables(tile + t_step);
-        {
+        if (!(xf & 4)) {
             const bool head_cont = e0 > 0 && p.row[e0 - 1] == sRow[0];
             const bool tail_cont = e0 + ne < p.E && p.row[e0 + ne] == sRow[ne - 1];
 #if FE4_SCAN64
@@ -341,6 +343,11 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd4_kernel(const FabindE
 #undef FE_OPAQUE
 }
 
+// development knob: bit mask of work the kernel SKIPS (wrong results; sensitivity timing only): 1 dT / dP2 copy-outs, 2 S1 / dP1 stores,
+// 4 row scan, 8 both contractions
+static int g_fe_bwd4_exp = 0;
+extern "C" void fabind_gcl_edge_fused_bwd4_set_exp(int m) { g_fe_bwd4_exp = m; }
+
 // launched from fabind_gcl_edge_fused_bwd (fused_edge.hip) when the arguments carry the forward's d2f / z3f
 int fe_bwd4_launch(const FabindEdgeBwdArgs* a, int H, int n_groups, hipStream_t stream) {
     FB_REQUIRE(a->bnd != nullptr, "fabind_gcl_edge_fused_bwd: bnd (ceil(E / 64) x 2 x H floats of scratch) is required");
@@ -355,7 +362,7 @@ int fe_bwd4_launch(const FabindEdgeBwdArgs* a, int H, int n_groups, hipStream_t 
             if (e_ != hipSuccess) { fabind_set_error(hipGetErrorString(e_)); return (int)e_; }                     \
             set_ = true;                                                                                           \
         }                                                                                                          \
-        hipLaunchKernelGGL((gcl_edge_fused_bwd4_kernel<HH>), dim3(n_groups), dim3(HH), lds, stream, *a);            \
+        hipLaunchKernelGGL((gcl_edge_fused_bwd4_kernel<HH>), dim3(n_groups), dim3(HH), lds, stream, *a, g_fe_bwd4_exp); \
     } while (0)
     if (H == 512) FE_LAUNCH4(512); else if (H == 256) FE_LAUNCH4(256); else if (H == 128) FE_LAUNCH4(128); else FE_LAUNCH4(64);
 #undef FE_LAUNCH4

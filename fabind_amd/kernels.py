@@ -19,7 +19,10 @@ PROFILE = None  # dict: label -> list of (start_event, end_event, flops) around 
 PROFILE_ONLY = None
 
 
-def _profiled(label, flops, fn):
+PROFILE_BYTES = {}        # label -> ALGORITHMIC HBM bytes of the launches timed under that label (operands read once + results written once)
+
+
+def _profiled(label, flops, fn, nbytes=0.0):
     # PROFILE_ONLY: name prefix of the one kernel family to time (bench.py: the dominant family, found in a fully timed warm-up step --
     # two events around each of the ~300 labelled launches of a step cost the host 1.7-2.6 ms of a 100 ms step, 2-3 ms of a 26 ms one)
     if PROFILE is None or (PROFILE_ONLY is not None and not label.startswith(PROFILE_ONLY)):
@@ -29,6 +32,7 @@ def _profiled(label, flops, fn):
     r = fn()
     e1.record()
     PROFILE.setdefault(label, []).append((e0, e1, flops))
+    PROFILE_BYTES[label] = PROFILE_BYTES.get(label, 0.0) + float(nbytes)
     return r
 
 
@@ -102,8 +106,19 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
                                                       ",x3" if x3 else "", M, N, K)
     if groups is not None:
         label += " (ragged, %d groups)" % n_groups
+    # algorithmic HBM bytes: every operand read once, every result written once (ragged launches: not counted)
+    nb = 0.0
+    if groups is None:
+        mn = float(M) * N
+        nb = float(M) * K * A.element_size() + float(N) * K * W.element_size()
+        nb += mn * out.element_size() * (2 if accumulate else 1) if want_out else 0.0
+        for t_ in (out2, residual, aux):
+            if t_ is not None:
+                nb += mn * t_.element_size()
+        if out16 is not None:
+            nb += mn * 2
     _profiled(label, 2.0 * M * N * K if flops is None else float(flops),
-              lambda: check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm"))
+              lambda: check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm"), nb)
     return (out if want_out else None), dot_out
 
 
@@ -542,13 +557,16 @@ def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows,
                                                                         ptr(W2p), ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s),
                                                                         float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd), ptr(agg16),
                                                                         ptr(Msave), ptr(d2f), ptr(z3f), stream()),
-                                "fabind_gcl_edge_fused_train"))
+                                "fabind_gcl_edge_fused_train"),
+                  # per edge: 3 saved bf16 rows + row / col / rhohat / s; per node: the AB row once + agg fp32 (+ bf16)
+                  E * (6.0 * H + 16) + n_rows * (4.0 * H + 4.0 * H + (2.0 * H if want16 else 0.0)))
     else:
         _profiled("gcl_edge_fused_kernel<%d> E=%d (gather + 2 chained H x H contractions + segment-sum per edge)" % (H, E), 4.0 * E * H * H,
                   lambda: check(_lib.load().fabind_gcl_edge_fused(ptr(AB16), _ld(AB16), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
                                                                   ptr(W2p), ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s),
                                                                   float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd), ptr(agg16), stream()),
-                                "fabind_gcl_edge_fused"))
+                                "fabind_gcl_edge_fused"),
+                  E * 16.0 + n_rows * (4.0 * H + 4.0 * H + (2.0 * H if want16 else 0.0)))
     out = (agg, s[:E], agg16) if want16 else (agg, s[:E])
     return out + ((Msave, d2f, z3f),) if save else out
 
@@ -687,7 +705,10 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
               "gcl_edge_fused_bwd%s_kernel<%d> E=%d (recompute + 4 chained H x H contractions per edge)" % ({1: "1", 2: "1_128", 3: "2_128", 4: "2_64", 5: "3"}.get(variant, ""), H, E),
               (4.0 if variant == 6 else 8.0) * E * H * H,
               lambda: check(_lib.load().fabind_gcl_edge_fused_bwd(ctypes.byref(a), H, ng, stream()),
-                            "fabind_gcl_edge_fused_bwd"))
+                            "fabind_gcl_edge_fused_bwd"),
+              # per edge: the [E,H] bf16 tiles read (saved form: silu'(pre2), pre3) and written (S1, dT, dP2, dP1; recompute form: + M) +
+              # row / col / rhohat / ds / drh; per node: the AB row and dagg once, dAB's receiving half
+              E * ((12.0 if variant == 6 else 10.0) * H + 20) + N * (4.0 * H + 4.0 * H + (2.0 if dab_bf16 else 4.0) * H))
     del keep
     if E > 0:
         if dab_bf16:
@@ -888,7 +909,8 @@ def tn_flush():
     if PROFILE is None:
         launch()
     else:
-        _profiled("fabind_gemm_tn_multi jobs=%d" % n, sum(2.0 * j_[4] * j_[5] * j_[6] for j_ in jobs), launch)
+        _profiled("fabind_gemm_tn_multi jobs=%d" % n, sum(2.0 * j_[4] * j_[5] * j_[6] for j_ in jobs), launch,
+                  sum(2.0 * (j_[4] + j_[5]) * j_[6] for j_ in jobs))
     TN_STATS["flushes"] += 1
     del tdev, part, jobs
 
@@ -912,7 +934,7 @@ def gemm_tn(Y, X, splits=None, out_dtype=torch.float32, with_colsum=False):
     if PROFILE is None:
         launch()
     else:
-        _profiled("fabind_gemm_tn M=%d N=%d E=%d" % (M, N, E), 2.0 * M * N * E, launch)
+        _profiled("fabind_gemm_tn M=%d N=%d E=%d" % (M, N, E), 2.0 * M * N * E, launch, 2.0 * (M + N) * E + 4.0 * splits * M * N)
     if with_colsum and n % 4 == 0 and M % 4 == 0 and (splits > 1 or out_dtype != torch.float32):
         # one reduction launch: the weight part as out_dtype, the column sums behind it as fp32
         dW = torch.empty((M, N), dtype=out_dtype, device=dev)

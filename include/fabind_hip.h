@@ -324,6 +324,7 @@ int fabind_gcl_edge_fused_bwd_variant_for(int H);   /* the variant a launch at h
 /* development knob of variants 3 / 4: bit mask of work the kernel SKIPS (results are then wrong -- sensitivity timing only). */
 void fabind_gcl_edge_fused_bwd2_set_exp(int mask);
 void fabind_gcl_edge_fused_bwd3_set_exp(int mask);
+void fabind_gcl_edge_fused_bwd4_set_exp(int mask);   /* the saved-forward kernel: 1 dT / dP2 copy-outs, 2 S1 / dP1 stores, 4 row scan, 8 both contractions */
 /* development knob: 1 (default) = XCD-aware tile order in the fused edge kernels (XCD x owns the x-th eighth of the tiles, i.e.
  * whole complexes); 0 = linear tile order (forward) / grid-stride walk (backward).  Results do not depend on it. */
 void fabind_gcl_edge_fused_set_xcd_aware(int on);
@@ -646,6 +647,7 @@ int fabind_gemm_x3_occupancy(int wm); /* development probe: resident work-groups
 void fabind_cross_attn_fused_set_dbg(void* five_int64_on_device); /* development probe: phase cycle counters of one work-group of the fused cross-attention forward (NULL = off) */
 int fabind_cross_attn_fused_occupancy(int lds_bytes); /* the same for the fused cross-attention forward at the given dynamic LDS size */
 void fabind_gemm_set_x3_tile(int wm); /* development knob: tile height of the split-bf16 fabind_gemm kernel in units of 64 rows (2 = default: 128x128, two 4-wave work-groups per CU; 4: 256x128, one 8-wave work-group) */
+void fabind_gemm_set_big(int on);        /* development knob (default 0: measured slower, csrc/gemm.hip): 1 = long-M launches with N % 256 == 0 and K >= 1024 or N >= 1024 run whole 256-work-group rounds of 256 x 256 tiles (gemm_bf16_big_kernel) and the 256 x 128 kernel on the remaining row tiles; 0 = the 256 x 128 kernel only; same k-order per output element: bitwise-equal results */
 void fabind_gemm_set_small_m(int tiles); /* development knob: fabind_gemm launches with fewer 256x128 tiles than this use 128x128 tiles (default 100; 0 = never); results are bitwise equal */
 void fabind_gemm_tn_set_waves(int waves); /* development knob: work-group layout of fabind_gemm_tn: 16 (default) = 256x256 tile, 8 waves, 4-stage ring; 20 = the same with 5 stages; 4 = 256x128 tile, 4 waves, two work-groups per CU; 8 = 256x128, 8 waves.  Results are bitwise equal for equal `splits` */
 int fabind_gemm_tn_tile_n(void);          /* 256 or 128: columns of an output tile under the current layout (the host sizes `splits` from the tile count) */

@@ -262,6 +262,13 @@ def test_bench_batch_properties(bench_batch, prec, tol_equiv, tol_h, tol_single)
         rep_x, rep_h = float((X1 - X2).abs().max()) * 5, float((H1 - H2).abs().max())
         print("%s B=64: ligand moved %.3f A; run-to-run max |dX| %.2e A, max |dH| %.2e (%s)"
               % (prec, moved, rep_x, rep_h, "bit-identical" if rep_x == 0.0 and rep_h == 0.0 else "not bit-identical"))
+        if not (rep_x == 0.0 and rep_h == 0.0):          # diagnostics of a rare miss (seen once in a full-suite run, never in isolation)
+            dh = (H1 - H2).abs().max(1).values
+            bad = torch.nonzero(dh > 0).reshape(-1)
+            n0 = NP + NL + 2
+            print("    rows that differ: %d of %d; complexes %s; first rows (index within complex, |dH|): %s; a third run vs the first: %.2e"
+                  % (bad.numel(), dh.numel(), sorted(set((bad // n0).tolist()))[:12],
+                     [(int(b_) % n0, "%.1e" % float(dh[b_])) for b_ in bad[:8]], float((_hip(m, inp, dev)[1] - H1).abs().max())))
         assert rep_x == 0.0 and rep_h == 0.0
         # E(3): x -> R x + t applied to the normalised inputs (and the LAS reference conformer, which enters through distances)
         R, tvec = _rotation(1).to(dev), torch.tensor([0.37, -1.2, 0.8], device=dev)

@@ -1327,3 +1327,51 @@ def test_layout_ranges_is_a_lower_bound_per_complex():
         got = lay.ranges(idx)
         want = lay.ranges(idx.long())                     # int64: the torch path
         assert got.dtype == torch.int32 and torch.equal(got, want), (keep, got, want)
+
+
+@pytest.mark.parametrize("N,Kd,two_seg", [(512, 1024, True), (1024, 512, False), (1536, 512, False), (512, 1536, False)])
+def test_gemm_big_tile_rounds_are_bitwise_equal(N, Kd, two_seg):
+    """csrc/gemm.hip, round 4 (a knob, off by default): long-M launches whose main loop bounds them (K >= 1024 or N >= 1024, N % 256 == 0) run whole 256-work-group
+    rounds of 256 x 256 tiles (gemm_bf16_big_kernel: each 128-column half goes through the SAME epilogue code as the 256 x 128 kernel) and
+    the 256 x 128 kernel on the remaining row tiles.  Same k-order per output element: every epilogue form the node level uses must be
+    bitwise equal to the 256 x 128 kernel alone (fabind_gemm_set_big(0)), including the rows of the tail launch and a ragged last tile."""
+    from fabind_amd import kernels as K, _lib
+    dev = _dev()
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(N + Kd)
+    M = 256 * (256 // (N // 256)) + 256 + 77            # one whole round of big tiles + a full and a ragged tile for the 256 x 128 kernel
+    A = (torch.randn(M, Kd, generator=g) * 0.5).bfloat16().to(dev)
+    W = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).bfloat16().to(dev)
+    b = torch.randn(N, generator=g).to(dev)
+    R = torch.randn(M, N, generator=g).to(dev)
+    aux = torch.rand(M, N, generator=g).bfloat16().to(dev)
+    A1, A2 = (A[:, :Kd // 2].contiguous(), A[:, Kd // 2:].contiguous()) if two_seg else (A, None)
+
+    def forms():
+        out = {}
+        out["bf16"] = K.gemm(A1, W, bias=b, A2=A2, out_dtype=torch.bfloat16)[0]
+        t = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        d = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        K.gemm(A1, W, bias=b, A2=A2, act_epi=K.ACT_SILU, out=t, out2=d)
+        out["silu"], out["silu_d"] = t, d
+        out["relu"] = K.gemm(A1, W, bias=b, A2=A2, act_epi=K.ACT_RELU, out_dtype=torch.bfloat16)[0]
+        y16 = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
+        out["res_f32"] = K.gemm(A1, W, bias=b, A2=A2, residual=R, out_dtype=torch.float32, out16=y16)[0]
+        out["res_f32_16"] = y16
+        out["f32"] = K.gemm(A1, W, A2=A2, out_dtype=torch.float32)[0]
+        out["dact"] = K.gemm(A1, W, A2=A2, aux=aux, dact=K.ACT_STORED_DERIV, out_dtype=torch.bfloat16)[0]
+        out["dact_relu"] = K.gemm(A1, W, A2=A2, aux=aux, dact=K.ACT_RELU, out_dtype=torch.bfloat16)[0]
+        torch.cuda.synchronize()
+        return out
+
+    try:
+        lib.fabind_gemm_set_big(0)
+        ref = forms()
+        lib.fabind_gemm_set_big(1)
+        got = forms()
+    finally:
+        lib.fabind_gemm_set_big(0)                      # (the default: measured slower than two 256 x 128 work-groups per CU, csrc/gemm.hip)
+    x = A.float().cpu() @ W.float().cpu().T
+    assert (ref["f32"].cpu() - x).abs().max() <= 2e-3 * max(1.0, float(x.abs().max()))
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), (k, float((ref[k].float() - got[k].float()).abs().max()))
