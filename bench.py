@@ -446,31 +446,36 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    def timed(step, warmup, steps, profile):
+    def timed(step, warmup, steps, profile, events_in_timed=True):
         """Timing protocol of the contract (warm-up, barrier + synchronize, exactly `steps` steps, barrier + synchronize).  Live HIP
         events for the roofline: the LAST warm-up step times every labelled launch and names the dominant kernel family; the timed
         region then times that family's launches only (all of them, every step) -- events around every launch of the step cost the
         host 2 % of the headline step and 6-11 % of the pocket-sized one (same-box pairs in profiles/r03_ab_same_box.txt).
-        FABIND_BENCH_DUMP_PROFILE keeps the events of every launch (the launch-group listing needs them)."""
+        FABIND_BENCH_DUMP_PROFILE keeps the events of every launch (the launch-group listing needs them).
+        events_in_timed=False (the sub-objects, several of which are host-bound): the timed region carries NO events at all; the returned
+        profile is the fully timed warm-up step (every labelled launch of ONE step)."""
         probe = profile and not os.environ.get("FABIND_BENCH_DUMP_PROFILE")      # (the same on every rank: sync() holds a barrier)
+        probe_prof, probe_bytes = None, {}
         profile = profile and rank == 0
         only = None
         for w in range(warmup):
             if probe and w == warmup - 1:
                 sync()
                 K.PROFILE, K.PROFILE_ONLY = ({} if profile else None), None
+                K.PROFILE_BYTES.clear()
                 step()
                 sync()
                 fams = {}
                 for label, evs in (K.PROFILE or {}).items():
                     fams[family(label)] = fams.get(family(label), 0.0) + sum(s_.elapsed_time(e_) for s_, e_, _ in evs)
+                probe_prof, probe_bytes = K.PROFILE, dict(K.PROFILE_BYTES)
                 K.PROFILE = None
                 if fams:
                     only = max(fams.items(), key=lambda kv: kv[1])[0].split(" ")[0]
             else:
                 step()
         sync()
-        K.PROFILE = {} if profile else None
+        K.PROFILE = {} if (profile and events_in_timed) else None
         K.PROFILE_BYTES.clear()
         K.PROFILE_ONLY = only
         t0 = time.time()
@@ -480,6 +485,10 @@ def main():
         dt = time.time() - t0
         prof = K.PROFILE
         K.PROFILE, K.PROFILE_ONLY = None, None
+        if profile and not events_in_timed and probe_prof:
+            prof = probe_prof
+            K.PROFILE_BYTES.clear()
+            K.PROFILE_BYTES.update(probe_bytes)
         if world > 1:
             tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -600,7 +609,7 @@ def main():
             _config.set_x3_backward(x3_backward)
             try:
                 st, per, _ = make_step(mode, n_iter, train_mode, n_prot=n_prot, whole_pocket=whole_pocket)
-                d, pf = timed(st, warmup, steps, True)
+                d, pf = timed(st, warmup, steps, True, events_in_timed=False)
                 mult = a.poses if mode == "plus_sampling" else 1
                 o = {"value": per * steps * mult / d, "unit": "poses/s" if mode == "plus_sampling" else "complexes/s",
                      "ms_per_step": 1e3 * d / steps, "steps": steps, "warmup": warmup,
@@ -610,6 +619,7 @@ def main():
                 if pf:
                     rf = roofline_of(pf, d, prec)
                     o["roofline"] = {k_: rf[k_] for k_ in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_us")}
+                    o["roofline"]["from"] = "the fully timed last warm-up step (no events inside this object's timed region)"
                 extras[name] = o
             except Exception as e:                      # a sub-object must never cost the headline line
                 extras[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}

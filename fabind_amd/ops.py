@@ -679,6 +679,7 @@ def edge_tail(Mm, Wc, bc, w3, rowptr, row, n_rows, act_epi=K.ACT_SILU):
 
 EDGE_SAVE_FWD = os.environ.get("FABIND_EDGE_SAVE_FWD", "1") != "0"          # 0: the recompute backward (four contractions, nothing kept)
 EDGE_SAVE_MIN_EDGES = int(os.environ.get("FABIND_EDGE_SAVE_MIN_EDGES", "0"))
+EDGE_SAVE_MIN_H = int(os.environ.get("FABIND_EDGE_SAVE_MIN_H", "256"))
 
 
 class _FusedEdge(torch.autograd.Function):
@@ -692,7 +693,7 @@ class _FusedEdge(torch.autograd.Function):
         ctx.H, ctx.g, ctx.p_drop, ctx.seed, ctx.frags = H, g, p_drop, seed, frags
         W2p, Wcp = (frags[0], frags[1]) if frags is not None else (K.pack_frag(W2), K.pack_frag(Wc))
         E = g.row_ctx.shape[0]
-        save = EDGE_SAVE_FWD and H >= 256 and E >= max(1, EDGE_SAVE_MIN_EDGES) and AB16.dtype == torch.bfloat16
+        save = EDGE_SAVE_FWD and H >= EDGE_SAVE_MIN_H and E >= max(1, EDGE_SAVE_MIN_EDGES) and AB16.dtype == torch.bfloat16
         out = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, W2p, b2, Wcp, bc, w3,
                                AB16.shape[0], p_drop, seed, want16=holder is not None, rowptr=g.rp_ctx, save=save)
         ctx.n_saved = 3 if save else 0
