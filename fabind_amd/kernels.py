@@ -630,7 +630,7 @@ EDGE_BWD_TIMES = None   # set to an int64[12] device tensor to collect per-phase
 
 
 def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, dagg, colptr, perm, p_drop=0.0, seed=0,
-                       want_edges=False, dab_bf16=False, w_dtype=torch.float32, rowptr=None, frags=None, saved=None):
+                       dab_bf16=False, w_dtype=torch.float32, rowptr=None, frags=None, saved=None):
     """Adjoint of gcl_edge_fused (csrc/fused_edge.hip): returns dAB [N,2H] fp32, drh [E], dw_r, dW2, db2, dWc, dbc, dw3.
     The five [E,H] bf16 operands it writes (S1, M, dT, dP2 for the weight gradients, dP1 for the sending-side
     reduction) are scratch that is released on return.
@@ -729,7 +729,7 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
         dWc = torch.zeros((H, H), dtype=w_dtype, device=dev)
     ps = part.sum(0)
     out = (dAB, drh[:E], ps[3], dW2, ps[0], dWc, ps[1], ps[2])
-    return out + (Mm[:E].clone(),) if want_edges else out
+    return out
 
 
 _ZERO_PAGE = {}
