@@ -27,6 +27,16 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3.0}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
+def price_against_rooflines(flops, nbytes, ms, precision):
+    """(binding, other) roofline objects of a set of launches: `flops` executed and `nbytes` algorithmic HBM bytes in `ms` milliseconds.
+    The binding one is the roofline the launches sit closer to (the larger fraction of its peak)."""
+    tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    gb = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    mfma = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS[precision]}
+    hbm = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS}
+    return (hbm, mfma) if hbm["frac"] > mfma["frac"] else (mfma, hbm)
+
+
 def stack_args(hidden, layers, n_iter):
     from argparse import Namespace
     return Namespace(
@@ -516,18 +526,12 @@ def main():
                 f[2] += fl
             f[4] += K.PROFILE_BYTES.get(label, 0.0)
         name, (ms, cnt, flops, label, nbytes) = max(fams.items(), key=lambda kv: kv[1][0])
-        peak = MFMA_PEAK_TFLOPS[precision]
-        ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-        hbm = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0                 # algorithmic GB/s of the same launches
-        out_ = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
-                "kernel": label if len([1 for l_ in prof if family(l_) == name]) == 1 else name + " (all shapes of the step)",
-                "flop_per_launch": flops / cnt, "launches": cnt, "avg_us": 1e3 * ms / cnt, "share_of_step": ms / (1e3 * dt),
-                "algorithmic_bytes_per_launch": nbytes / cnt}
-        other = {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS}
-        if other["frac"] > out_["frac"]:                                   # the roofline that binds is the one the launches sit closer to
-            for k_ in ("bound", "achieved", "peak", "unit", "frac"):
-                out_[k_], other[k_] = other[k_], out_[k_]
-        out_["other_roofline"] = other
+        binding, other = price_against_rooflines(flops, nbytes, ms, precision)
+        out_ = dict(binding)
+        out_.update({"traffic": None,
+                     "kernel": label if len([1 for l_ in prof if family(l_) == name]) == 1 else name + " (all shapes of the step)",
+                     "flop_per_launch": flops / cnt, "launches": cnt, "avg_us": 1e3 * ms / cnt, "share_of_step": ms / (1e3 * dt),
+                     "algorithmic_bytes_per_launch": nbytes / cnt, "other_roofline": other})
         return out_
 
     step, per_rank, _ = make_step(a.mode, a.n_iter)

@@ -408,3 +408,18 @@ def test_rows_hadamard_csr_lists_every_pair_under_both_rows():
     ref = torch.zeros(n, W).index_add_(0, ia.long(), dout * t[ib.long()]).index_add_(0, ib.long(), dout * t[ia.long()])
     assert torch.allclose(got, ref, rtol=0, atol=1e-5)
     assert int(rp[36]) == int(rp[37])                      # rows 35, 36 have no pair
+
+
+def test_bench_prices_a_family_against_both_rooflines():
+    """bench.py: the dominant family's launches are priced against the MFMA and the HBM roofline; the one they sit closer to binds."""
+    import bench
+    # the node-level GEMM family of the round-4 headline: 50.3 GFLOP and 312 MB per launch in 119 us -> HBM-shaped
+    b, o = bench.price_against_rooflines(50.3e9 * 755, 312e6 * 755, 0.119 * 755, "bf16")
+    assert b["bound"] == "hbm" and o["bound"] == "mfma" and abs(b["achieved"] - 2621.8) < 5 and abs(o["achieved"] - 422.7) < 2
+    assert abs(b["frac"] - b["achieved"] / 8000.0) < 1e-12 and abs(o["frac"] - o["achieved"] / 2500.0) < 1e-12
+    # the fused edge forward: 1.61 TFLOP and 0.4 GB in 1.83 ms -> MFMA-shaped
+    b, o = bench.price_against_rooflines(1.61e12, 0.4e9, 1.83, "bf16")
+    assert b["bound"] == "mfma" and 0.34 < b["frac"] < 0.36 and o["frac"] < 0.05
+    # no time measured: zeros, not a division error; the split-bf16 mode is priced at a third of the bf16 peak
+    b, o = bench.price_against_rooflines(1e12, 1e9, 0.0, "bf16x3")
+    assert b["achieved"] == 0.0 and o["achieved"] == 0.0 and {b["peak"], o["peak"]} == {8000.0, 2500.0 / 3.0}
