@@ -679,12 +679,14 @@ def edge_tail(Mm, Wc, bc, w3, rowptr, row, n_rows, act_epi=K.ACT_SILU):
 
 EDGE_SAVE_FWD = os.environ.get("FABIND_EDGE_SAVE_FWD", "1") != "0"          # 0: the recompute backward (four contractions, nothing kept)
 EDGE_SAVE_MIN_EDGES = int(os.environ.get("FABIND_EDGE_SAVE_MIN_EDGES", "0"))
+# (hidden 128 -- the pocket model of the full IaBNet on whole proteins, 1.5 M edges: forward 280 -> 434 us, backward 1,086 -> 657 us per launch with
+#  FABIND_EDGE_SAVE_MIN_H=128, but the full-model step is host-bound there: 1,234 / 1,301 / 1,351 against 1,308 / 1,313 / 1,304 complexes/s in
+#  three interleaved pairs (tools/probes/r4_call36.sh) -- the default stays 256, which keeps 1.2 GB per pocket-model layer free)
 EDGE_SAVE_MIN_H = int(os.environ.get("FABIND_EDGE_SAVE_MIN_H", "256"))
 
 
 class _FusedEdge(torch.autograd.Function):
-    """Whole intra-graph edge pipeline of MC_E_GCL as one kernel each way (csrc/fused_edge.hip).  H >= 256 (the store-wave domain of the
-    recompute backward): the training forward leaves the messages and two bf16 per-edge tiles (silu'(pre2), pre3: 6 H bytes per edge
+    """Whole intra-graph edge pipeline of MC_E_GCL as one kernel each way (csrc/fused_edge.hip).  H >= 256 (EDGE_SAVE_MIN_H): the training forward leaves the messages and two bf16 per-edge tiles (silu'(pre2), pre3: 6 H bytes per edge
     until the backward has run) and the backward chains two contractions per edge (csrc/fused_edge_bwd4.hip); otherwise -- and with
     FABIND_EDGE_SAVE_FWD=0 -- the forward keeps no per-edge tensor and the backward recomputes them tile by tile in LDS."""
 
