@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FABIND_LIB") or os.path.join(_HERE, "libfabind_hip.so")      # FABIND_LIB: an A/B build (tools/probes)
 
-ABI_VERSION = 16         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
+ABI_VERSION = 17         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -176,10 +176,6 @@ def load():
     lib.fabind_gemm_set_persistent.restype = None
     lib.fabind_gemm_set_small_m.argtypes = [ctypes.c_int]
     lib.fabind_gemm_set_small_m.restype = None
-    lib.fabind_gemm_set_big.argtypes = [ctypes.c_int]
-    lib.fabind_gemm_set_big.restype = None
-    if os.environ.get("FABIND_GEMM_BIG"):                # A/B knob: 0 = the 256 x 128 tile kernel only
-        lib.fabind_gemm_set_big(int(os.environ["FABIND_GEMM_BIG"]))
     lib.fabind_gemm_set_x3_tile.argtypes = [ctypes.c_int]
     lib.fabind_gemm_set_x3_tile.restype = None
     if os.environ.get("FABIND_GEMM_SMALL_M"):
@@ -192,7 +188,7 @@ def load():
     lib.fabind_gemm_tn_tile_n.restype = ctypes.c_int
     lib.fabind_gcl_edge_fused_set_xcd_aware.argtypes = [ctypes.c_int]
     lib.fabind_gcl_edge_fused_set_xcd_aware.restype = None
-    for nm in ("fabind_gcl_edge_fused_bwd2_set_exp", "fabind_gcl_edge_fused_bwd3_set_exp", "fabind_gcl_edge_fused_bwd4_set_exp"):      # development knobs (void)
+    for nm in ("fabind_gcl_edge_fused_bwd3_set_exp", "fabind_gcl_edge_fused_bwd4_set_exp"):      # development knobs (void)
         getattr(lib, nm).argtypes = [ctypes.c_int]
         getattr(lib, nm).restype = None
     if os.environ.get("FABIND_EDGE_BWD3_EXP"):           # development knob: experiment mask of the store-wave backward (32 = nt operand stores)

@@ -458,7 +458,6 @@ __device__ __forceinline__ void fe3_bstore16(const __amdgpu_buffer_rsrc_t rs, co
 
 // fused_edge_bwd2.hip: the row-wise / operand-swapped backward (variants 3 and 4 of fabind_gcl_edge_fused_bwd)
 struct FabindEdgeBwdArgs;
-int fe_bwd2_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipStream_t stream);
 // fused_edge_bwd3.hip: the same with a store wave (variants 5 and 6)
 int fe_bwd3_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipStream_t stream);
 // fused_edge_fwd3.hip: the split-bf16 forward (fabind_gcl_edge_fused_x3: fp32 AB rows, hi | lo packed weights)

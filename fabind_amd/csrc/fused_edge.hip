@@ -18,146 +18,14 @@
 
 static int g_fe_xcd_aware = 1;       // development knob: XCD-aware tile order (1) vs linear / grid-stride order (0)
 extern "C" void fabind_gcl_edge_fused_set_xcd_aware(int on) { g_fe_xcd_aware = on ? 1 : 0; }
-static int g_fe_fwd_variant = 1;     // 1 = row-wise gather / operand-swapped epilogues (fused_edge_fwd2.hip, default); 0 = round 1's kernel below
+static int g_fe_fwd_variant = 1;     // 1 = row-wise gather / operand-swapped epilogues (fused_edge_fwd2.hip): the only form built since round 5
+                                     // (round 1's kernel, variant 0, was a knob nobody reached: retired, git history up to 8fbe227)
 extern "C" int fabind_gcl_edge_fused_set_variant(int v) {
-    FB_REQUIRE(v == 0 || v == 1, "fabind_gcl_edge_fused_set_variant: 0 (round-1 kernel) or 1 (row-wise / operand-swapped)");
+    FB_REQUIRE(v == 1, "fabind_gcl_edge_fused_set_variant: 1 (row-wise / operand-swapped) is the only forward form built (variant 0 was retired in round 5)");
     g_fe_fwd_variant = v;
     return 0;
 }
 extern "C" int fabind_gcl_edge_fused_variant(void) { return g_fe_fwd_variant; }
-
-template <int H>
-__global__ __launch_bounds__(H, 4) void gcl_edge_fused_kernel(const bf16_t* __restrict__ AB, int ldab, const int* __restrict__ row,
-                                                           const int* __restrict__ col, const float* __restrict__ rhohat,
-                                                           const float* __restrict__ w_r, const bf16_t* __restrict__ W2p,
-                                                           const float* __restrict__ b2, const bf16_t* __restrict__ Wcp,
-                                                           const float* __restrict__ bc, const float* __restrict__ w3, int E,
-                                                           float* agg, float* s_out, uint32_t thr16, float dscale,
-                                                           uint32_t seed, float* bnd, bf16_t* agg16, int xcd_aware) {
-    constexpr int NW = H / 64;                      // waves; wave w owns output columns [64w, 64w+64)
-    constexpr int CPT = FE_BM * H / H;              // gather: elements per thread = 64 (one 64-column chunk of one edge)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* sX = (bf16_t*)smem;                     // [64][H] bf16, 16-B chunk index XOR (row & 7)
-    int* sRow = (int*)(smem + (size_t)FE_BM * H * 2);
-    float* sDot = (float*)(sRow + FE_BM);           // [NW][64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // XCD-aware tile order: work-group b runs on XCD b % 8 (round-robin dispatch), and every XCD has its own 4 MiB L2.  Edges are
-    // complex-contiguous, so giving XCD x the x-th EIGHTH of the tile range makes one XCD own whole complexes: the gathered AB
-    // rows of a complex (3 MB at 1542 nodes x 1024 bf16) are fetched into one L2 once instead of into all eight.
-    const int n_tiles = (E + FE_BM - 1) / FE_BM, tpx = (n_tiles + 7) / 8;
-    const int tile = xcd_aware ? (int)((blockIdx.x & 7) * tpx + (blockIdx.x >> 3)) : (int)blockIdx.x;
-    if ((xcd_aware && (int)(blockIdx.x >> 3) >= tpx) || tile >= n_tiles) return;
-    const int e0 = tile * FE_BM;
-    const int ne = min(FE_BM, E - e0);
-
-    // ---- phase 0: gather + first Linear + SiLU -> sX
-    {
-        constexpr int TPE = H / 64;                 // threads per edge
-        const int el = tid / TPE, c64 = tid % TPE;
-        if (tid < FE_BM) sRow[tid] = (tid < ne) ? row[e0 + tid] : -1;
-        if (el < ne) {
-            const int r = row[e0 + el], c = col[e0 + el];
-            const float rh = rhohat[e0 + el];
-            const bf16_t* ap = AB + (size_t)r * ldab + c64 * 64;
-            const bf16_t* bp = AB + (size_t)c * ldab + H + c64 * 64;
-            const float* wp = w_r + c64 * 64;
-#pragma unroll 4
-            for (int q = 0; q < 8; ++q) {
-                float fa[8], fb[8], o[8];
-                unpack8(*(const uint4*)(ap + q * 8), fa);
-                unpack8(*(const uint4*)(bp + q * 8), fb);
-                const float4 w0 = *(const float4*)(wp + q * 8), w1 = *(const float4*)(wp + q * 8 + 4);
-                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = fe_silu(fa[k] + fb[k] + rh * wv[k]);
-                const int ch = c64 * 8 + q;
-                *(uint4*)&sX[el * H + ((ch ^ (el & 7)) * 8)] = pack8(o);
-            }
-        } else if (el < FE_BM) {
-            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) *(uint4*)&sX[el * H + (((c64 * 8 + q) ^ (el & 7)) * 8)] = z;
-        }
-    }
-    __syncthreads();
-
-    // ---- phase 1: M = silu(S1 W2^T + b2)
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    fe_gemm_rolled<H, 4>(sX, W2p, wave, lane, acc);
-    __syncthreads();                                // every wave has finished reading S1
-    const int fr = lane & 15, cq = lane >> 4;
-    // The wave's four 16-column blocks are processed one after the other: the j loop is unrolled (compile-time accumulator
-    // indices, no register rotation) and a scheduling barrier after each block keeps the scheduler from interleaving the exp / rcp
-    // chains of all 64 elements of a lane, which spills by the hundred (round 1 rolled the loop and rotated the accumulator
-    // arrays through slot 0 instead: 4-6 v_mov per element, a fifth of the kernel's VALU instructions).
-    {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int colj = wave * 64 + j * 16 + fr;
-            const float bj = b2[colj];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int rw = i * 16 + cq * 4 + r;
-                    float m = fe_silu(acc[i][j][r] + bj);
-                    if (thr16) m *= fe_keep(seed, (uint32_t)(e0 + rw), (uint32_t)colj, H, thr16, dscale);
-                    sX[rw * H + (((colj >> 3) ^ (rw & 7)) * 8) + (colj & 7)] = f32_to_bf16(m);
-                }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    __syncthreads();
-
-    // ---- phase 2: agg[row] = sum of M over the node's edges (deterministic: fused_common.h fe_scan_rows)
-    {
-        const bool head_cont = e0 > 0 && row[e0 - 1] == sRow[0];
-        const bool tail_cont = e0 + ne < E && row[e0 + ne] == sRow[ne - 1];
-        (void)fe_scan_rows<H, false, FE_BM>(sX, sRow, nullptr, ne, head_cont, tail_cont, agg, (unsigned)H, bnd + (size_t)tile * 2 * H, tid, agg16, (unsigned)H);
-    }
-
-    // ---- phase 3: s = w3 . silu(M Wc^T + bc)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    fe_gemm_rolled<H, 4>(sX, Wcp, wave, lane, acc);
-    {
-        float dsum[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dsum[i][r] = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float bj = bc[wave * 64 + j * 16 + fr], wj = w3[wave * 64 + j * 16 + fr];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dsum[i][r] += fe_silu(acc[i][j][r] + bj) * wj;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = dsum[i][r];
-                t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
-                if (fr == 0) sDot[wave * FE_BM + i * 16 + cq * 4 + r] = t;
-            }
-    }
-    __syncthreads();
-    if (tid < ne) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) s += sDot[w * FE_BM + tid];
-        s_out[e0 + tid] = s;
-    }
-}
 
 static int fe_fwd_entry(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat,
                         const float* w_r, const void* W2p, const float* b2, const void* Wcp, const float* bc,
@@ -173,23 +41,11 @@ static int fe_fwd_entry(const void* AB, int ldab, int H, const int* row, const i
     const float dscale = 1.0f / (1.0f - (float)thr16 / 65536.0f);
     FB_REQUIRE(H == 512 || H == 256 || H == 128 || H == 64, "fabind_gcl_edge_fused: H must be 64, 128, 256 or 512");
     FB_REQUIRE(ldab % 8 == 0, "fabind_gcl_edge_fused: ldab % 8");
-    const dim3 grid((((E + FE_BM - 1) / FE_BM + 7) / 8) * 8);          // 8 x ceil(tiles / 8): see the XCD-aware tile order in the kernel
-    const size_t lds = (size_t)FE_BM * H * 2 + FE_BM * sizeof(int) + (size_t)(H / 64) * FE_BM * sizeof(float);
-    if (g_fe_fwd_variant == 1) {
+    {
         const int rc = fe_fwd2_launch(AB, ldab, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, E, agg, s_out, thr16, dscale, seed, bnd,
                                       agg16, g_fe_xcd_aware, stream, Msave, d2f, z3f);
         if (rc) return rc;
-    } else
-#define FE_LAUNCH(HH)                                                                                              \
-    do {                                                                                                           \
-        static bool set_ = false;                                                                                  \
-        if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
-        hipLaunchKernelGGL((gcl_edge_fused_kernel<HH>), grid, dim3(HH), lds, stream, (const bf16_t*)AB, ldab, row, col, rhohat, \
-                           w_r, (const bf16_t*)W2p, b2, (const bf16_t*)Wcp, bc, w3, E, agg, s_out, thr16, dscale, \
-                           (uint32_t)seed, bnd, (bf16_t*)agg16, g_fe_xcd_aware);                                  \
-    } while (0)
-    if (H == 512) FE_LAUNCH(512); else if (H == 256) FE_LAUNCH(256); else if (H == 128) FE_LAUNCH(128); else FE_LAUNCH(64);
-#undef FE_LAUNCH
+    }
     hipLaunchKernelGGL((fe_boundary_fix_kernel<FE_BM>), dim3((E + FE_BM - 1) / FE_BM), dim3(H < 256 ? H : 256), 0, stream, row, E, H,
                        bnd, agg, (unsigned)H, (bf16_t*)agg16, (unsigned)H);
     FB_CHECK_LAUNCH();
@@ -591,313 +447,20 @@ __global__ __launch_bounds__(H, (BM == 32 ? 4 : 2)) void gcl_edge_fused_bwd_kern
 #undef FE_LOFF
 #undef FE_TICK
 
-// =====================================================================================================
-// Single-tile variant of the backward (round 2, NOT the default: measured equal standalone and 2-7 % slower per launch inside
-// the training step than the two-tile kernel): the SAME phases, but every stage overwrites the one
-// [64][H] LDS tile in place (contraction reads it -> barrier -> epilogue writes it -> barrier), silu'(pre2) waits for
-// phase P3 in an L2-resident per-work-group scratch slab instead of 32 registers, and the gathered AB rows are loaded
-// where they are used.  64 KiB LDS and <= 128 VGPRs put TWO work-groups on a CU (4 waves per SIMD) at the same 64-edge
-// tile, i.e. at the same L2 weight traffic per edge: while one work-group streams weights through the matrix cores the
-// other runs its sigmoid / pack / LDS-store epilogue on the VALU.  (The two-tile kernel above keeps one work-group per
-// CU: its phase counters show contractions 40 % + elementwise 45 % of a tile strictly in sequence; its 32-edge variant
-// got the overlap but doubled the weight traffic -- DESIGN.md section 5.)
-template <int H, int BM>
-__global__ __launch_bounds__(H, (BM == 128 ? 2 : 4)) void gcl_edge_fused_bwd1_kernel(const FabindEdgeBwdArgs p) {
-    constexpr int TPE = H / BM;                                   // threads per edge in the gather layout
-    constexpr int CPT = BM / 8;                                   // 16-byte chunks per thread there
-    constexpr int MI = BM / 16;                                   // 16-row MFMA fragments per wave (the wave owns 64 columns of ALL rows)
-    constexpr int MQ = MI / 4;                                    // uint4 per (column block, half) of the silu'(pre2) scratch
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* sX = (bf16_t*)smem;                                   // [BM][H] swizzled: S1 -> M -> dT -> dP2 -> dS1 -> dP1
-    int* sRow = (int*)(sX + BM * H);
-    float* sDs = (float*)(sRow + BM);
-    float* sRh = sDs + BM;
-    float* sPart = sRh + BM;                                      // [4][H]: column sums of {d b2, d bc, d w3, d w_r} over this work-group's tiles
-    const bf16_t* __restrict__ AB = (const bf16_t*)p.AB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int fr = lane & 15, cq = lane >> 4;
-    const int el = tid / TPE, cth = tid % TPE;
-    const int n_tiles = (p.E + BM - 1) / BM;
-    const uint32_t thr16 = (uint32_t)(p.p_drop * 65536.0f + 0.5f);
-    const float dscale = 1.0f / (1.0f - (float)thr16 / 65536.0f);
-    // Few values live across the contractions (acc 64 + B fragments 32 + A fragments 16 VGPRs of 128): the fragment address
-    // bases are recomputed per epilogue, the column-sum partials live in LDS, the gathered-row offsets are re-derived in P5.
-#define FE_CBASE()                                                                                                   \
-    int cbase[2][2];                                                                                                 \
-    _Pragma("unroll") for (int f0 = 0; f0 < 2; ++f0) _Pragma("unroll") for (int f2 = 0; f2 < 2; ++f2)                \
-        cbase[f0][f2] = cq * 4 * H + (wave * 8 + (((cq & 1) ^ f2) << 2) + ((fr >> 3) ^ f0)) * 8 + (fr & 7);
-    // adds this lane's column partial v (rows cq*4.. of the tile) into sPart[k_][col]: reduce over the four cq lanes, one writer
-#define FE_PART_ADD(k_, col_, v_)                                                                                    \
-    { float t_ = (v_); t_ += __shfl_xor(t_, 16, 64); t_ += __shfl_xor(t_, 32, 64); if (cq == 0) sPart[(k_) * H + (col_)] += t_; }
-    for (int k = 0; k < 4; ++k) sPart[k * H + tid] = 0.f;
-    const unsigned uld = (unsigned)p.ldab;
-
-    int t_first, t_end, t_step;
-    if (p.xcd_aware && (gridDim.x & 7) == 0) {
-        const int tpx = (n_tiles + 7) / 8, xcd = blockIdx.x & 7;
-        t_first = xcd * tpx + (int)(blockIdx.x >> 3);
-        t_end = min(n_tiles, (xcd + 1) * tpx);
-        t_step = (int)(gridDim.x >> 3);
-    } else {
-        t_first = blockIdx.x; t_end = n_tiles; t_step = gridDim.x;
-    }
-#define FE_ROT4(a_) { auto t_ = a_[0]; a_[0] = a_[1]; a_[1] = a_[2]; a_[2] = a_[3]; a_[3] = t_; }
-#define FE_ROT_ACC() _Pragma("unroll") for (int i = 0; i < MI; ++i) FE_ROT4(acc[i])
-#define FE_JADDR(j_)                                                                          \
-        const int cb[2] = {((j_) >> 1) ? cbase[0][1] : cbase[0][0], ((j_) >> 1) ? cbase[1][1] : cbase[1][0]}; \
-        const int o2[2] = {((j_) & 1) * 16, 16 - ((j_) & 1) * 16};
-#define FE_LOFF(i, r) (cb[(r) & 1] + ((i) * 16 + (r)) * H + o2[(r) >> 1])
-
-    for (int tile = t_first; tile < t_end; tile += t_step) {
-        const int e0 = tile * BM;
-        const int ne = min(BM, p.E - e0);
-        int lz = 0;
-        asm volatile("" : "+s"(lz));                              // loop-invariant operands are re-read per tile, not hoisted
-        const float* w_r = p.w_r + lz;
-        const float* b2 = p.b2 + lz;
-        const float* bc = p.bc + lz;
-        const float* w3 = p.w3 + lz;
-        const bf16_t* W2p = (const bf16_t*)p.W2p + lz;
-        const bf16_t* Wcp = (const bf16_t*)p.Wcp + lz;
-        const bf16_t* W2Tp = (const bf16_t*)p.W2Tp + lz;
-        const bf16_t* WcTp = (const bf16_t*)p.WcTp + lz;
-        const int* grow = p.row + e0;
-        const int* gcol = p.col + e0;
-        const float* grh = p.rhohat + e0;
-        const float* gds = p.ds + e0;
-        if (tid < BM) {
-            const bool ok = tid < ne;
-            sRow[tid] = ok ? grow[(unsigned)tid] : -1;
-            sDs[tid] = ok ? gds[(unsigned)tid] : 0.f;
-            sRh[tid] = ok ? grh[(unsigned)tid] : 0.f;
-        }
-        // ---- P0: gather + first Linear + SiLU -> sX
-        if (el < ne) {
-            const unsigned aoff = (unsigned)grow[(unsigned)el] * uld + cth * (CPT * 8);
-            const unsigned boff = (unsigned)gcol[(unsigned)el] * uld + H + cth * (CPT * 8);
-            const float rh = grh[(unsigned)el];
-            const float* wp = w_r + (unsigned)(cth * (CPT * 8));
-#pragma unroll 2
-            for (int q = 0; q < CPT; ++q) {
-                float fa[8], fb[8], o[8];
-                unpack8(*(const uint4*)(AB + (aoff + q * 8)), fa);
-                unpack8(*(const uint4*)(AB + (boff + q * 8)), fb);
-                const float4 w0 = *(const float4*)(wp + q * 8), w1 = *(const float4*)(wp + q * 8 + 4);
-                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-                for (int k = 0; k < 8; ++k) o[k] = fe_silu(fa[k] + fb[k] + rh * wv[k]);
-                *(uint4*)&sX[el * H + (((cth * CPT + q) ^ (el & 7)) * 8)] = pack8(o);
-            }
-        } else {
-            const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-            for (int q = 0; q < CPT; ++q) *(uint4*)&sX[el * H + (((cth * CPT + q) ^ (el & 7)) * 8)] = z;
-        }
-        __syncthreads();
-        fe_tile_store<H>(sX, (bf16_t*)p.S1, e0, ne, tid);
-
-        // ---- P1: pre2 = S1 W2^T + b2;  M -> sX in place;  silu'(pre2) -> scratch
-        f32x4_t acc[MI][4];
-        fe_zero(acc);
-        fe_gemm_rolled<H, MI>(sX, W2p, wave, lane, acc);
-        __syncthreads();                                          // every wave has finished reading S1
-        {
-            FE_CBASE()
-            // silu'(pre2) of this work-group's current tile: [j][half][i / 4][thread] uint4 (1 KiB per wave store), rewritten every tile
-            uint4* d2s = (uint4*)p.d2scratch + (size_t)blockIdx.x * (8 * MQ * H);
-            float bj[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bj[j] = b2[wave * 64 + j * 16 + fr];
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) {
-                FE_JADDR(j)
-                uint32_t da[MI], db[MI];
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    float dd[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float z = acc[i][0][r] + bj[0], sg = fe_sigmoid(z);
-                        float kp = 1.0f;
-                        if (thr16)
-                            kp = fe_keep(p.seed, (uint32_t)(e0 + i * 16 + cq * 4 + r), (uint32_t)(wave * 64 + j * 16 + fr), H,
-                                         thr16, dscale);
-                        dd[r] = kp * (sg * (1.0f + z * (1.0f - sg)));
-                        sX[FE_LOFF(i, r)] = f32_to_bf16(kp * (z * sg));
-                    }
-                    da[i] = pack2_bf16(dd[0], dd[1]);
-                    db[i] = pack2_bf16(dd[2], dd[3]);
-                }
-#pragma unroll
-                for (int q = 0; q < MQ; ++q) {
-                    d2s[((j * 2) * MQ + q) * H + tid] = make_uint4(da[q * 4], da[q * 4 + 1], da[q * 4 + 2], da[q * 4 + 3]);
-                    d2s[((j * 2 + 1) * MQ + q) * H + tid] = make_uint4(db[q * 4], db[q * 4 + 1], db[q * 4 + 2], db[q * 4 + 3]);
-                }
-                FE_ROT_ACC() FE_ROT4(bj)
-            }
-        }
-        __syncthreads();
-        fe_tile_store<H>(sX, (bf16_t*)p.Mm, e0, ne, tid);
-
-        // ---- P2: pre3 = M Wc^T + bc;  dT = ds * w3 * silu'(pre3) -> sX in place
-        fe_zero(acc);
-        fe_gemm_rolled<H, MI>(sX, Wcp, wave, lane, acc);
-        __syncthreads();
-        {
-            FE_CBASE()
-            float bj[4], wj[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { bj[j] = bc[wave * 64 + j * 16 + fr]; wj[j] = w3[wave * 64 + j * 16 + fr]; }
-#pragma unroll 1
-            for (int j = 0; j < 4; ++j) {
-                FE_JADDR(j)
-                float a3 = 0.f, ac = 0.f;
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float z = acc[i][0][r] + bj[0], sg = fe_sigmoid(z), dsr = sDs[i * 16 + cq * 4 + r];
-                        const float dt = dsr * wj[0] * (sg * (1.0f + z * (1.0f - sg)));
-                        a3 += dsr * (z * sg);
-                        ac += dt;
-                        sX[FE_LOFF(i, r)] = f32_to_bf16(dt);
-                    }
-                FE_PART_ADD(2, wave * 64 + j * 16 + fr, a3)
-                FE_PART_ADD(1, wave * 64 + j * 16 + fr, ac)
-                FE_ROT_ACC() FE_ROT4(bj) FE_ROT4(wj)
-            }
-        }
-        __syncthreads();
-        fe_tile_store<H>(sX, (bf16_t*)p.dT, e0, ne, tid);
-
-        // ---- P3: dM = dT Wc + dagg[row];  dP2 = dM * silu'(pre2) -> sX in place
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int rr = sRow[i * 16 + cq * 4 + r];
-                const unsigned doff = (unsigned)max(rr, 0) * (unsigned)p.lddagg + wave * 64 + fr;
-                const float keep = rr >= 0 ? 1.f : 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j][r] = p.dagg[doff + j * 16] * keep;
-            }
-        fe_gemm_rolled<H, MI>(sX, WcTp, wave, lane, acc);
-        __syncthreads();
-        {
-        FE_CBASE()
-        const uint4* d2s = (const uint4*)p.d2scratch + (size_t)blockIdx.x * (8 * MQ * H);
-#pragma unroll 1
-        for (int j = 0; j < 4; ++j) {
-            FE_JADDR(j)
-            uint32_t da[MI], db[MI];
-#pragma unroll
-            for (int q = 0; q < MQ; ++q) {
-                const uint4 qa = d2s[((j * 2) * MQ + q) * H + tid], qb = d2s[((j * 2 + 1) * MQ + q) * H + tid];
-                da[q * 4] = qa.x; da[q * 4 + 1] = qa.y; da[q * 4 + 2] = qa.z; da[q * 4 + 3] = qa.w;
-                db[q * 4] = qb.x; db[q * 4 + 1] = qb.y; db[q * 4 + 2] = qb.z; db[q * 4 + 3] = qb.w;
-            }
-            float a2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const uint32_t pk = (r >> 1) ? db[i] : da[i];
-                    const float dd = __uint_as_float((r & 1) ? (pk & 0xffff0000u) : (pk << 16));
-                    const float dp = acc[i][0][r] * dd;
-                    a2 += dp;
-                    sX[FE_LOFF(i, r)] = f32_to_bf16(dp);
-                }
-            FE_PART_ADD(0, wave * 64 + j * 16 + fr, a2)
-            FE_ROT_ACC()
-        }
-        }
-        __syncthreads();
-        fe_tile_store<H>(sX, (bf16_t*)p.dP2, e0, ne, tid);
-
-        // ---- P4: dS1 = dP2 W2 -> sX in place
-        fe_zero(acc);
-        fe_gemm_rolled<H, MI>(sX, W2Tp, wave, lane, acc);
-        __syncthreads();
-        {
-        FE_CBASE()
-#pragma unroll 1
-        for (int j = 0; j < 4; ++j) {
-            FE_JADDR(j)
-#pragma unroll
-            for (int i = 0; i < MI; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) sX[FE_LOFF(i, r)] = f32_to_bf16(acc[i][0][r]);
-            FE_ROT_ACC()
-        }
-        }
-        __syncthreads();
-
-        // ---- P5 (gather layout): dP1 = dS1 * silu'(pre1) in place;  d rhohat = dP1 . w_r
-        if (el < ne) {
-            const unsigned aoff = (unsigned)sRow[el] * uld + cth * (CPT * 8);
-            const unsigned boff = (unsigned)gcol[(unsigned)el] * uld + H + cth * (CPT * 8);
-            const float rh = sRh[el];
-            const float* wp = w_r + (unsigned)(cth * (CPT * 8));
-            float dot = 0.f;
-#pragma unroll 2
-            for (int q = 0; q < CPT; ++q) {
-                float fa[8], fb[8], g[8];
-                unpack8(*(const uint4*)(AB + (aoff + q * 8)), fa);
-                unpack8(*(const uint4*)(AB + (boff + q * 8)), fb);
-                uint4* sp = (uint4*)&sX[el * H + (((cth * CPT + q) ^ (el & 7)) * 8)];
-                unpack8(*sp, g);
-                const float4 w0 = *(const float4*)(wp + q * 8), w1 = *(const float4*)(wp + q * 8 + 4);
-                const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const float z = fa[k] + fb[k] + rh * wv[k], sg = fe_sigmoid(z);
-                    g[k] *= sg * (1.0f + z * (1.0f - sg));
-                    dot += g[k] * wv[k];
-                }
-                *sp = pack8(g);
-            }
-#pragma unroll
-            for (int o = 1; o < TPE; o <<= 1) dot += __shfl_xor(dot, o, 64);
-            if (cth == 0) (p.drh + e0)[(unsigned)el] = dot;
-        }
-        __syncthreads();
-        fe_tile_store<H>(sX, (bf16_t*)p.dP1, e0, ne, tid);
-
-        // ---- P6 (one column per thread): receiving-side segment sum of dP1 (deterministic, fe_scan_rows) and the d w_r column sum
-        {
-            const bool head_cont = e0 > 0 && p.row[e0 - 1] == sRow[0];
-            const bool tail_cont = e0 + ne < p.E && p.row[e0 + ne] == sRow[ne - 1];
-            sPart[3 * H + tid] += fe_scan_rows<H, true, BM>(sX, sRow, sRh, ne, head_cont, tail_cont, p.dABrow, (unsigned)p.lddab,
-                                                         p.bnd + (size_t)tile * 2 * H, tid);
-        }
-        __syncthreads();                                          // the next tile overwrites sX / sRow
-    }
-    // per-work-group partial column sums: part[blockIdx.x][{b2, bc, w3, w_r}][H]   (each sPart slot has ONE writer lane)
-    __syncthreads();
-    float* part = p.part + (size_t)blockIdx.x * 4 * H;
-    for (int k = 0; k < 4; ++k) part[k * H + tid] = sPart[k * H + tid];
-#undef FE_CBASE
-#undef FE_PART_ADD
-#undef FE_ROT4
-#undef FE_ROT_ACC
-#undef FE_JADDR
-#undef FE_LOFF
-}
-
 static int g_fe_bwd_bm = 64;
 extern "C" int fabind_gcl_edge_fused_bwd_set_tile(int bm) {
-    FB_REQUIRE(bm == 32 || bm == 64, "fabind_gcl_edge_fused_bwd_set_tile: 32 or 64 edges per tile");
+    FB_REQUIRE(bm == 64, "fabind_gcl_edge_fused_bwd_set_tile: 64 edges per tile (the 32-edge build of the two-tile kernel was retired in round 5)");
     g_fe_bwd_bm = bm;
     return 0;
 }
 extern "C" int fabind_gcl_edge_fused_bwd_tile(void) { return g_fe_bwd_bm; }
 static bool g_fe_bwd_variant_set = false;
 static int g_fe_bwd_variant = 5;     // 5 = row-wise / operand-swapped in-place tile + store wave (default, fused_edge_bwd3.hip);
-                                     // 0 = two LDS tiles, one work-group per CU (round 1); 1 = single in-place tile, two per CU;
-                                     // 2 = single in-place tile of 128 edges, one per CU (H >= 128; half the weight stream per edge)
+                                     // 0 = two LDS tiles, one work-group per CU (round 1; the default for H <= 128).  Variants 1-4 (in-place
+                                     // single-tile forms, fused_edge_bwd2.hip) were knob-only and were retired in round 5 (history: 8fbe227)
 extern "C" int fabind_gcl_edge_fused_bwd_set_variant(int v) {
-    FB_REQUIRE(v >= 0 && v <= 5,
-               "fabind_gcl_edge_fused_bwd_set_variant: 0 (two LDS tiles of 64 edges), 1 / 2 (one in-place tile of 64 / 128), 3 / 4 (row-wise, operand-swapped: 128 / 64), 5 (the same with a store wave, 64 edges)");
+    FB_REQUIRE(v == 0 || v == 5,
+               "fabind_gcl_edge_fused_bwd_set_variant: 0 (two LDS tiles of 64 edges: the default for H <= 128) or 5 (row-wise, operand-swapped in-place tile + store wave: the recompute default above); variants 1-4 were knobs nobody reached and were retired in round 5");
     g_fe_bwd_variant = v;
     g_fe_bwd_variant_set = true;
     return 0;
@@ -926,32 +489,6 @@ extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a_in, int H, i
     }
     if (g_fe_bwd_variant == 5) return fe_bwd3_launch(a, H, 64, n_groups, stream);
     FB_REQUIRE(a->dAB16 == nullptr, "fabind_gcl_edge_fused_bwd: dAB16 (bf16 receiving-side sums) exists in variant 5 only");
-    if (g_fe_bwd_variant == 3 || g_fe_bwd_variant == 4) return fe_bwd2_launch(a, H, g_fe_bwd_variant == 3 ? 128 : 64, n_groups, stream);
-    if (g_fe_bwd_variant == 1 || (g_fe_bwd_variant == 2 && H >= 128)) {
-        const int bm1 = g_fe_bwd_variant == 2 ? 128 : 64;
-        FB_REQUIRE(a->d2scratch != nullptr, "fabind_gcl_edge_fused_bwd: the single-tile variants need d2scratch (n_groups x tile x H x 2 bytes)");
-        const size_t lds1 = (size_t)bm1 * H * 2 + bm1 * (sizeof(int) + 2 * sizeof(float)) + (size_t)4 * H * sizeof(float);
-#define FE_LAUNCH1(HH, BB)                                                                                         \
-    do {                                                                                                           \
-        static bool set_ = false;                                                                                  \
-        if (!set_) { const hipError_t e_ = hipFuncSetAttribute((const void*)gcl_edge_fused_bwd1_kernel<HH, BB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1); \
-            if (e_ != hipSuccess) { fabind_set_error(hipGetErrorString(e_)); return (int)e_; } set_ = true; } \
-        hipLaunchKernelGGL((gcl_edge_fused_bwd1_kernel<HH, BB>), dim3(n_groups), dim3(HH), lds1, stream, *a);       \
-    } while (0)
-        FB_REQUIRE(a->bnd != nullptr, "fabind_gcl_edge_fused_bwd: the single-tile variants need bnd (ceil(E / tile) x 2 x H floats)");
-        if (bm1 == 128) {
-            if (H == 512) FE_LAUNCH1(512, 128); else if (H == 256) FE_LAUNCH1(256, 128); else FE_LAUNCH1(128, 128);
-            hipLaunchKernelGGL((fe_boundary_fix_kernel<128>), dim3((a->E + 127) / 128), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
-                               a->bnd, a->dABrow, (unsigned)a->lddab);
-        } else {
-            if (H == 512) FE_LAUNCH1(512, 64); else if (H == 256) FE_LAUNCH1(256, 64); else if (H == 128) FE_LAUNCH1(128, 64); else FE_LAUNCH1(64, 64);
-            hipLaunchKernelGGL((fe_boundary_fix_kernel<64>), dim3((a->E + 63) / 64), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
-                               a->bnd, a->dABrow, (unsigned)a->lddab);
-        }
-#undef FE_LAUNCH1
-        FB_CHECK_LAUNCH();
-        return 0;
-    }
     FB_REQUIRE(a->bnd != nullptr, "fabind_gcl_edge_fused_bwd: bnd (ceil(E / tile) x 2 x H floats of scratch) is required");
     const int BMr = g_fe_bwd_bm;
     const size_t lds = (size_t)2 * BMr * H * 2 + BMr * (sizeof(int) + 2 * sizeof(float));
@@ -961,26 +498,14 @@ extern "C" int fabind_gcl_edge_fused_bwd(const FabindEdgeBwdArgs* a_in, int H, i
         if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_bwd_kernel<HH, BB, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
         hipLaunchKernelGGL((gcl_edge_fused_bwd_kernel<HH, BB, false>), dim3(n_groups), dim3(HH), lds, stream, *a);  \
     } while (0)
-#define FE_LAUNCH(HH)                                                                                              \
-    do {                                                                                                           \
-        if (BMr == 32) FE_LAUNCH2(HH, 32); else FE_LAUNCH2(HH, 64);                                                \
-    } while (0)
+#define FE_LAUNCH(HH) FE_LAUNCH2(HH, 64)
     if (a->dbg != nullptr && H == 512) {          // the instrumented build exists for the bench shape only
         static bool setd_ = false;
-        if (BMr == 32) {
-            if (!setd_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_bwd_kernel<512, 32, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
-            hipLaunchKernelGGL((gcl_edge_fused_bwd_kernel<512, 32, true>), dim3(n_groups), dim3(512), lds, stream, *a);
-        } else {
-            if (!setd_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_bwd_kernel<512, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
-            hipLaunchKernelGGL((gcl_edge_fused_bwd_kernel<512, 64, true>), dim3(n_groups), dim3(512), lds, stream, *a);
-        }
+        if (!setd_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_bwd_kernel<512, 64, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }
+        hipLaunchKernelGGL((gcl_edge_fused_bwd_kernel<512, 64, true>), dim3(n_groups), dim3(512), lds, stream, *a);
     } else
     if (H == 512) FE_LAUNCH(512); else if (H == 256) FE_LAUNCH(256); else if (H == 128) FE_LAUNCH(128); else FE_LAUNCH(64);
-    if (BMr == 32)
-        hipLaunchKernelGGL((fe_boundary_fix_kernel<32>), dim3((a->E + 31) / 32), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
-                           a->bnd, a->dABrow, (unsigned)a->lddab);
-    else
-        hipLaunchKernelGGL((fe_boundary_fix_kernel<64>), dim3((a->E + 63) / 64), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
+    hipLaunchKernelGGL((fe_boundary_fix_kernel<64>), dim3((a->E + 63) / 64), dim3(H < 256 ? H : 256), 0, stream, a->row, a->E, H,
                            a->bnd, a->dABrow, (unsigned)a->lddab);
 #undef FE_LAUNCH
 #undef FE_LAUNCH2

@@ -729,7 +729,7 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_bf16_pipe_kernel(FabindGe
         const int nbx = (N + BN - 1) / BN, total = gridDim.x;
         const int L = blockIdx.x, q = total / 8, r = total % 8, xcd = L % 8;
         const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + L / 8;
-        bx = t % nbx; by = t / nbx + row_tile0;      // (row_tile0 > 0: the row tiles below it belong to the big-tile launch, gemm_bf16_big_kernel)
+        bx = t % nbx; by = t / nbx + row_tile0;      // (row_tile0: first row tile of this launch)
     }
     const int m0 = by * BM_, n0 = bx * BN;
     if (m0 >= M || n0 >= N) return;
@@ -812,111 +812,8 @@ __global__ __launch_bounds__(WM * 128, MINW) void gemm_bf16_pipe_kernel(FabindGe
     gemm_epilogue<BM_>(p, acc, sDot, sT, M, N, ldc, a_row0, w_row0, c_off, m0, n0);
 }
 
-// ------------------------------------------------------------------------------------------------
-// Big-tile variant (round 4) for the long-M node-level GEMMs whose main loop, not their epilogue traffic, bounds them
-// ([98,688 x 1024] -> 512, [98,688 x 512] -> 1024 / 1536: 460-560 TFLOP/s on the 256 x 128 tile): a work-group owns a 256 x 256 output
-// tile -- eight waves of 64 rows x (64 + 64) columns: wave (wm, wn) holds columns [wn*64, wn*64+64) of BOTH 128-column halves, so each
-// half is exactly the 256 x 128 tile / wave map every epilogue of this file is written for, and the epilogues run unchanged, once per half --
-// operand bytes per flop from L2 halve (one A k-tile feeds 256 columns), LDS fragment reads per MFMA drop from 0.5 to 0.375, ONE
-// work-group per CU on a 4-stage LDS-DMA ring of 32 KiB stages.  One work-group per CU makes the tile count matter: the host sends
-// a whole number of 256-work-group rounds here and the remaining row tiles to the 256 x 128 kernel (row_tile0).
-// ------------------------------------------------------------------------------------------------
-template <int NSTAGE>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_big_kernel(FabindGemmArgs p, const int nby) {
-    constexpr int BM_ = 256, BN2 = 256, BK_ = 32, NW = 8;
-    constexpr int ROWS = BM_ + BN2;                   // A rows then W rows share one row space per stage
-    constexpr int RPP = 1024 / (BK_ * 2);             // rows per 1-KiB LDS-DMA piece (16)
-    constexpr int PT = ROWS / RPP, PPW = PT / NW;     // pieces per stage (32) / per wave (4)
-    constexpr int LPR = 64 / RPP;                     // lanes (16-B chunks) per row (4)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bf16_t* sT = (bf16_t*)smem;                       // [NSTAGE][ROWS][BK_]
-    float* sDot = (float*)(smem + (size_t)NSTAGE * ROWS * BK_ * 2);
-    const int M = p.M, N = p.N, ldc = p.ldc;
-    // XCD-aware tile order: every XCD gets a contiguous run of tiles (the column tiles of one row panel share its L2 copy of the A panel)
-    const int nbx = N / BN2, total = gridDim.x;
-    const int L = blockIdx.x, q = total / 8, r = total % 8, xcd = L % 8;
-    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + L / 8;
-    const int bx = t % nbx, by = t / nbx;
-    if (by >= nby) return;
-    const int m0 = by * BM_, n0 = bx * BN2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const bf16_t* A = (const bf16_t*)p.A;
-    const bf16_t* W = (const bf16_t*)p.W;
-    const int K = p.K, K1 = p.K1;
-
-    const bf16_t* src[PPW];
-    const bf16_t* src2[PPW];   // second K-segment of A (K-concatenated operand); W rows keep one segment
-#pragma unroll
-    for (int j = 0; j < PPW; ++j) {
-        const int row = (wave * PPW + j) * RPP + lane / LPR;      // row in the combined (A|W) space
-        const int cl = lane % LPR;                                 // LDS chunk slot
-        const int chunk = cl ^ ((row >> 2) & 3);
-        if (row < BM_) {
-            const size_t gm = (size_t)min(m0 + row, M - 1);
-            src[j] = A + gm * p.lda + chunk * 8;
-            src2[j] = p.A2 ? (const bf16_t*)p.A2 + gm * p.lda2 + chunk * 8 - K1 : src[j];
-        } else {
-            src[j] = W + (size_t)min(n0 + row - BM_, N - 1) * p.ldw + chunk * 8;
-            src2[j] = src[j];
-        }
-    }
-    auto stage = [&](int st, int k0) {
-        bf16_t* base = sT + (size_t)st * ROWS * BK_;
-#pragma unroll
-        for (int j = 0; j < PPW; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t)((k0 < K1 ? src[j] : src2[j]) + k0),
-                                             (lptr_t)(base + (size_t)(wave * PPW + j) * RPP * BK_), 16, 0, 0);
-    };
-
-    f32x4_t acc0[4][4], acc1[4][4];                  // columns n0 + wn*64 + [0, 64) and n0 + 128 + wn*64 + [0, 64)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { acc0[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc1[i][j] = acc0[i][j]; }
-
-    const int nk = K / BK_;
-    const int fr = lane & 15, fq = lane >> 4;
-#pragma unroll
-    for (int s = 0; s < NSTAGE - 1; ++s)
-        if (s < nk) stage(s, s * BK_);
-    for (int kt = 0; kt < nk; ++kt) {
-        const int ahead = min(NSTAGE - 2, nk - 1 - kt);           // tiles kt+1 .. kt+NSTAGE-2 may stay in flight
-        if (ahead >= 2) wait_vmcnt<2 * PPW>(); else if (ahead == 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + NSTAGE - 1 < nk) stage((kt + NSTAGE - 1) % NSTAGE, (kt + NSTAGE - 1) * BK_);
-        const bf16_t* tA = sT + (size_t)(kt % NSTAGE) * ROWS * BK_;
-        const bf16_t* tB = tA + BM_ * BK_;
-        bf16x8_t af[4], b0[4], b1[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ra = wm * 64 + i * 16 + fr, rb = wn * 64 + i * 16 + fr, rc = 128 + rb;
-            af[i] = *(const bf16x8_t*)&tA[ra * BK_ + (fq ^ ((ra >> 2) & 3)) * 8];
-            b0[i] = *(const bf16x8_t*)&tB[rb * BK_ + (fq ^ ((rb >> 2) & 3)) * 8];
-            b1[i] = *(const bf16x8_t*)&tB[rc * BK_ + (fq ^ ((rc >> 2) & 3)) * 8];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], b0[j], acc0[i][j], 0, 0, 0);
-                acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], b1[j], acc1[i][j], 0, 0, 0);
-            }
-    }
-    __syncthreads();
-    const int stage_bytes = NSTAGE * ROWS * BK_ * 2;
-    if (!(p.epi_fast && gemm_epilogue_dispatch<BM_, false>(p, acc0, sDot, sT, M, N, ldc, m0, n0, stage_bytes)))
-        gemm_epilogue<BM_>(p, acc0, sDot, sT, M, N, ldc, 0, 0, 0, m0, n0);
-    __syncthreads();                                  // the staging tile / slabs / sDot are reused by the second half
-    if (!(p.epi_fast && gemm_epilogue_dispatch<BM_, false>(p, acc1, sDot, sT, M, N, ldc, m0, n0 + BN, stage_bytes)))
-        gemm_epilogue<BM_>(p, acc1, sDot, sT, M, N, ldc, 0, 0, 0, m0, n0 + BN);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Persistent variant for long-M / short-K problems (edge MLPs: K = 512 = 16 k-steps): every work-group
-// walks a contiguous range of output tiles (the N-tiles of its M-panels, so the A panel stays in its own
-// L1/L2) and keeps ONE continuous LDS-DMA ring across tile boundaries -- no pipeline fill/drain per
-// tile, and the epilogue of tile t runs while the operands of tile t+1 are already landing.
+// (Round 4's 256 x 256 big-tile variant -- bitwise equal and slower, profiles/r04_gemm_big_tile.txt -- was a knob nobody reached:
+// retired in round 5, source in tools/probes/retired/gemm_big_tile.hip.txt.)
 // ------------------------------------------------------------------------------------------------
 template <int WM, int BK_, int NSTAGE>
 __global__ __launch_bounds__(WM * 128) void gemm_bf16_persist_kernel(FabindGemmArgs p, int tiles_total, int nbx) {
@@ -1447,35 +1344,6 @@ static int launch_pipe(const FabindGemmArgs& p, int maxM, int maxN, hipStream_t 
     return 0;
 }
 
-// Big-tile launch: a whole number of 256-work-group rounds of 256 x 256 tiles; returns the number of 256-row tiles it covered (the
-// caller sends the rest to the 256 x 128 kernel with row_tile0 = that number).  0 = shape not taken.
-// Measured (same box, profiles/r04_gemm_big_tile.txt): bitwise-equal results and SLOWER -- [98,688 x 1024] -> 512: 258 vs 224 us,
-// [98,688 x 512] -> 1024: 228 vs 185 us, headline 761 vs 771 complexes/s: one work-group per CU (128 KiB ring, 256 VGPRs) has nothing to run
-// under a tile's pipeline fill and its two epilogue passes, which is exactly what the two-work-groups-per-CU build of the 256 x 128 kernel buys
-// (iteration-log row 23).  Kept as a knob, OFF by default.
-static int g_gemm_big = 0;           // development knob fabind_gemm_set_big / FABIND_GEMM_BIG
-extern "C" void fabind_gemm_set_big(int on) { g_gemm_big = on; }
-static int launch_big(const FabindGemmArgs& p, hipStream_t stream) {
-    constexpr int NSTAGE = 4;
-    if (!g_gemm_big || p.groups || p.k_splits > 1 || p.N % 256 != 0 || p.K % 32 != 0 || (p.A2 && p.K1 % 32 != 0)) return 0;
-    // main-loop-bound shapes only: K >= 1024, or N >= 1024 (the K = 512 -> 512 launches are bound by their epilogue traffic)
-    if (!(p.K >= 1024 || p.N >= 1024)) return 0;
-    const int nbx = p.N / 256, nby_full = p.M / 256;
-    int n_cu = 256;
-    const int rounds = (int)(((long)nby_full * nbx) / n_cu);
-    if (rounds < 1) return 0;
-    const int nby = (int)(((long)rounds * n_cu) / nbx);          // row tiles covered by whole rounds
-    if (nby < 1) return 0;
-    const size_t lds = (size_t)NSTAGE * 512 * 32 * 2 + 2 * 256 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_bf16_big_kernel<NSTAGE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((gemm_bf16_big_kernel<NSTAGE>), dim3(nby * nbx), dim3(512), lds, stream, p, nby);
-    return nby;
-}
-
 // ------------------------------------------------------------------------------------------------
 // Split-bf16 ("bf16x3") NT GEMM: fp32 A (optionally [A | A2]) and fp32 W at (nearly) fp32 accuracy on the bf16 matrix cores.
 // Every operand element x is split WHILE IT IS STAGED into hi = bf16_rn(x) and lo = bf16_rn(x - hi) -- 16 significand bits
@@ -1813,7 +1681,6 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
         }
         int cfg = (p.k_splits > 1 && g_gemm_cfg == 0) ? 3 : g_gemm_cfg;
         int row_tile0 = 0;
-        if (cfg == 13 && maxM == p.M && maxN == p.N) row_tile0 = launch_big(p, stream);      // whole rounds of 256 x 256 tiles first
         /* few row tiles (ligand rows, pocket-sized batches): the 256-row tile leaves most CUs idle -- 128-row tiles double the work-group
            count; same k-order, bitwise-equal results (tools/probes/gemm_small_m.py) */
         if (cfg == 13 && !p.groups && g_gemm_small_m && n_tiles * (p.k_splits > 1 ? p.k_splits : 1) < g_gemm_small_m) cfg = 6;

@@ -644,30 +644,22 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     variant = lib.fabind_gcl_edge_fused_bwd_variant_for(H)
     if saved is not None and E > 0:
         variant = 6                                          # (chosen by the arguments: FabindEdgeBwdArgs.d2f / z3f)
-    if variant == 2 and H < 128:
-        variant = 0                                          # the 128-edge tile needs >= 128 threads (one per edge in the row tables)
-    bm = {1: 64, 2: 128, 3: 128, 4: 64, 5: 64, 6: 64}.get(variant) or lib.fabind_gcl_edge_fused_bwd_tile()
+    bm = 64                                                  # edges per tile of every form that is built (variants 0, 5, 6)
     if variant == 6:
         # one in-place [64][H] LDS tile + tables + partial sums, <= 128 VGPRs (four waves per SIMD): two work-groups per CU at H = 512
         per_cu = max(1, min(8, (160 * 1024) // (2 * bm * H + 16 * H + 32 * bm), 16 // max(1, H // 64)))
     elif variant == 5:
         # H/64 compute waves + one store wave per work-group, <= 168 VGPRs (three waves per SIMD): 12 waves per CU; two [64][H] LDS tiles
         per_cu = max(1, min(8, (160 * 1024) // (4 * bm * H + 16 * H + 32 * bm), 12 // (H // 64 + 1)))
-    elif variant in (2, 3):
-        # one in-place [128][H] tile (128 KiB at H = 512) and 2 waves per SIMD: one work-group per CU at H = 512, more below
-        per_cu = max(1, min(8, (160 * 1024) // (2 * bm * H + 16 * H + 2048), 512 // H))
-    elif variant in (1, 4):
-        # one in-place [64][H] LDS tile and <= 128 VGPRs: as many work-groups per CU as LDS (160 KiB) and 4 waves/SIMD allow
-        per_cu = max(1, min(8, (160 * 1024) // (2 * bm * H + 1024), 1024 // H))
     else:
-        # persistent work-groups per CU: as many as the two LDS tiles (2 * bm * H * 2 B of 160 KiB) and 2 waves/SIMD allow
-        per_cu = max(1, min(8, (160 * 1024) // (4 * bm * H + 1024), (1024 if bm == 32 else 512) // H))
+        # variant 0: persistent work-groups per CU: as many as the two LDS tiles (2 * bm * H * 2 B of 160 KiB) and 2 waves/SIMD allow
+        per_cu = max(1, min(8, (160 * 1024) // (4 * bm * H + 1024), 512 // H))
     ng = max(1, min(ng * per_cu, (E + bm - 1) // bm))
     if EDGE_BWD_GROUPS:
         ng = int(EDGE_BWD_GROUPS)       # development knob (tools/probes/edge_bwd_variants.py)
     if ng >= 8:
         ng -= ng % 8                # a multiple of 8 selects the XCD-aware walk (csrc/fused_edge.hip)
-    d2scratch = torch.empty((2 if variant >= 3 else 1, ng, bm * H), dtype=torch.bfloat16, device=dev) if variant in (1, 2, 3, 4, 5) else None
+    d2scratch = torch.empty((2, ng, bm * H), dtype=torch.bfloat16, device=dev) if variant == 5 else None
     bnd = torch.empty(((E + bm - 1) // bm * 2 + 2, H), dtype=torch.float32, device=dev)       # boundary runs (deterministic sums)
     if variant == 6:
         buf = torch.empty((4, max(E, 1), H), dtype=torch.bfloat16, device=dev)
@@ -702,7 +694,7 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
     if variant == 6:
         a.d2f, a.z3f = ptr(saved[1]), ptr(saved[2])
     _profiled(("gcl_edge_fused_bwd4_kernel<%d> E=%d (2 chained H x H contractions per edge over the forward's saved tiles)" % (H, E)) if variant == 6 else
-              "gcl_edge_fused_bwd%s_kernel<%d> E=%d (recompute + 4 chained H x H contractions per edge)" % ({1: "1", 2: "1_128", 3: "2_128", 4: "2_64", 5: "3"}.get(variant, ""), H, E),
+              "gcl_edge_fused_bwd%s_kernel<%d> E=%d (recompute + 4 chained H x H contractions per edge)" % ("3" if variant == 5 else "", H, E),
               (4.0 if variant == 6 else 8.0) * E * H * H,
               lambda: check(_lib.load().fabind_gcl_edge_fused_bwd(ctypes.byref(a), H, ng, stream()),
                             "fabind_gcl_edge_fused_bwd"),

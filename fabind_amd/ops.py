@@ -681,7 +681,7 @@ EDGE_SAVE_FWD = os.environ.get("FABIND_EDGE_SAVE_FWD", "1") != "0"          # 0:
 EDGE_SAVE_MIN_EDGES = int(os.environ.get("FABIND_EDGE_SAVE_MIN_EDGES", "0"))
 # (hidden 128 -- the pocket model of the full IaBNet on whole proteins, 1.5 M edges: forward 280 -> 434 us, backward 1,086 -> 657 us per launch with
 #  FABIND_EDGE_SAVE_MIN_H=128, but the full-model step is host-bound there: 1,234 / 1,301 / 1,351 against 1,308 / 1,313 / 1,304 complexes/s in
-#  three interleaved pairs (tools/probes/r4_call36.sh) -- the default stays 256, which keeps 1.2 GB per pocket-model layer free)
+#  three interleaved pairs (profiles/r04_ab_same_box.txt) -- the default stays 256, which keeps 1.2 GB per pocket-model layer free)
 EDGE_SAVE_MIN_H = int(os.environ.get("FABIND_EDGE_SAVE_MIN_H", "256"))
 
 

@@ -66,6 +66,18 @@ def _buckets(params, bucket_bytes):
         yield cur
 
 
+def _staged(flat, group):
+    """The tensor the collective backend can reduce for `flat`: itself under RCCL; under gloo (the CPU-only backend of the tests) a host
+    copy, widened to fp32 when the bucket is bf16 (gloo has no bf16 sum; the operands are bf16-rounded all the same).  One helper for
+    the overlapped and the plain path, so that both reduce the same numbers on every backend."""
+    if dist.get_backend(group) == "gloo":
+        if flat.is_cuda:
+            flat = flat.cpu()
+        if flat.dtype == torch.bfloat16:
+            flat = flat.float()
+    return flat
+
+
 def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, group=None, bucket_dtype=torch.float32):
     """Average .grad of `params` over all ranks (flat buckets of bucket_dtype, fp32 by default; missing grads count as zeros)."""
     if world is None:
@@ -80,8 +92,7 @@ def allreduce_gradients(params, world=None, bucket_bytes=64 << 20, group=None, b
     for bucket in _buckets(params, bucket_bytes):
         flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(bucket_dtype) for p in bucket])
         dev = flat.device
-        if flat.is_cuda and dist.get_backend(group) == "gloo":      # CPU-only collective backend (tests): stage through the host
-            flat = flat.cpu()
+        flat = _staged(flat, group)
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
         pending.append((bucket, flat, work, dev))
     for bucket, flat, work, dev in pending:
@@ -124,21 +135,27 @@ class GradReducer:
     rank 0's arrival order is broadcast and every rank rebuilds the same buckets: parameters in the order their gradients
     arrived, then the never-used ones in trailing bucket(s) that are zero-filled once and that no bucket waits for.  From the
     second step on a bucket leaves as soon as its used parameters have reported.  A parameter from the never-used set that does
-    get a gradient later (another stage, another loss) is copied like any other; if its bucket has already left it is reduced
-    again in `finish()`, and the parameter is expected from then on.
+    get a gradient later (another stage, another loss) -- on ANY rank -- is copied like any other; if its bucket has already left
+    it is reduced again in `finish()`, and the parameter is expected from then on ON EVERY RANK: membership in the never-used set
+    is collective (the per-parameter "fired late" flags travel in the same tiny MAX all-reduce as the stale-bucket mask), so a
+    rank on which it never fires zero-fills its slot in every later step instead of re-sending the previous step's average
+    (the buffers are reduced and divided in place).
 
     Every rank issues the same collectives in the same order: bucket k is issued only after buckets 0..k-1, and the set of
     buckets reduced a second time (gradient accumulation over several backward() calls, late parameters) is agreed on by one
     tiny MAX all-reduce in `finish()`.
-    bucket_dtype: torch.float32 (default) or torch.bfloat16 (half the bytes on the links; the sum is rounded to bf16)."""
+    bucket_dtype: torch.float32 (default) or torch.bfloat16 (half the bytes on the links; the sum is rounded to bf16).
+    check_late=False: the caller promises ONE backward per step and no late parameters after the discovery step -- `finish()` then
+    skips the agreement collective (and its host read-back); a second accumulation or a late parameter raises instead."""
 
-    def __init__(self, params, world=None, bucket_bytes=64 << 20, group=None, bucket_dtype=torch.float32, rebuild=True):
+    def __init__(self, params, world=None, bucket_bytes=64 << 20, group=None, bucket_dtype=torch.float32, rebuild=True, check_late=True):
         self.group = group
         self.world = world if world is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.params = [p for p in params if p.requires_grad]
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.bucket_bytes, self.bucket_dtype = bucket_bytes, bucket_dtype
         self.rebuild = bool(rebuild)
+        self.check_late = bool(check_late)
         self.steps_done = 0
         self.unused = set()            # ids of parameters no bucket waits for (never fired in the discovery step)
         self.issued_early = 0          # buckets of the LAST finished step whose collective left before finish() (diagnostic, tests)
@@ -164,6 +181,7 @@ class GradReducer:
         self.seen = set()
         self.order = []            # parameter indices in arrival order (this step)
         self.stale = set()         # buckets holding a parameter whose .grad changed after the bucket's collective left
+        self.late = set()          # indices of never-used parameters whose hook fired this step (on this rank)
         self.next_issue = 0
         self._early = 0
 
@@ -192,6 +210,8 @@ class GradReducer:
             # accumulation, or a parameter reached twice by one backward): .grad now holds the SUM, the bucket the first
             # micro-batch only.  If the bucket is still here it is refreshed in place; if its collective has already left,
             # it is marked stale and finish() reduces it again from .grad (the first result is discarded).
+            if not self.check_late and self.steps_done > 0:
+                raise RuntimeError("GradReducer(check_late=False): a second accumulation into a parameter before finish()")
             if self.work[bi] is None:
                 self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
             else:
@@ -200,8 +220,11 @@ class GradReducer:
         self.seen.add(id(p))
         self.order.append(self.index[id(p)])
         if id(p) in self.unused:
-            # a tensor the discovery step never saw a gradient for: no bucket counted on it.  Expected from the next step on.
-            self.unused.discard(id(p))
+            # a tensor the discovery step never saw a gradient for: no bucket counted on it.  It leaves the never-used set in
+            # finish(), on every rank together (self.late is OR-ed over the ranks there), and is expected from the next step on.
+            if not self.check_late:
+                raise RuntimeError("GradReducer(check_late=False): a never-used parameter received a gradient after the discovery step")
+            self.late.add(self.index[id(p)])
             if self.work[bi] is None:
                 self._buffer(bi)[off:off + p.numel()].copy_(p.grad.reshape(-1))
             else:
@@ -218,11 +241,7 @@ class GradReducer:
             self._early += 1 if early else 0
 
     def _issue(self, bi):
-        flat = self._buffer(bi)
-        if flat.is_cuda and dist.get_backend(self.group) == "gloo":      # CPU-only collective backend (tests): host staging
-            flat = flat.cpu()
-        if flat.dtype == torch.bfloat16 and dist.get_backend(self.group) == "gloo":
-            flat = flat.float()                                          # (gloo has no bf16 sum; the operands are bf16-rounded all the same)
+        flat = _staged(self._buffer(bi), self.group)
         self.work[bi] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat)
 
     def _agree(self, flags):
@@ -253,8 +272,22 @@ class GradReducer:
                 self.pending[bi] = 0
         self.issued_early = self._early
         self._issue_ready()
-        # the buckets to reduce again must be the same on every rank (a late parameter may have fired on one rank only)
-        stale = self._agree([1 if bi in self.stale else 0 for bi in range(len(self.buckets))])
+        # the buckets to reduce again must be the same on every rank (a late parameter may have fired on one rank only), and so must
+        # the never-used set: one collective carries the stale-bucket mask and a "fired late" flag per never-used parameter
+        nb = len(self.buckets)
+        unused_idx = sorted(self.index[i] for i in self.unused)            # same list on every rank (the set only changes below)
+        if self.check_late or self.steps_done == 0:
+            flags = self._agree([1 if bi in self.stale else 0 for bi in range(nb)] + [1 if i in self.late else 0 for i in unused_idx])
+        else:
+            flags = [False] * (nb + len(unused_idx))
+        stale = flags[:nb]
+        for i, fired in zip(unused_idx, flags[nb:]):
+            if fired:
+                p = self.params[i]
+                self.unused.discard(id(p))                     # expected from the next step on, on every rank
+                # (this step's sum is already right on every rank: while a parameter is in the never-used set EVERYWHERE its slot only
+                #  ever receives zeros -- 0 / world = 0 -- so a rank where it did not fire contributes 0; from the next step on the slot
+                #  is an expected one: overwritten by the hook or zero-filled at the top of finish())
         for bi in [i for i, v in enumerate(stale) if v]:       # same order on every rank
             self.work[bi][0].wait()                            # (its result is superseded)
             buf = self._buffer(bi)

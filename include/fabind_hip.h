@@ -56,8 +56,10 @@ const char* fabind_last_error(void);
  *     fabind_cross_attn_fused_fwd takes lse; fabind_cross_attn_fused_bwd + FabindAttnFusedBwdArgs, fabind_pair_bot_pack (fused backward of the
  *     cross attention: fabind_sizeof_args(4)).
  * 16 = fabind_gcl_edge_fused_train (the forward that saves M / silu'(pre2) / pre3) and FabindEdgeBwdArgs.{d2f, z3f} (the two-contraction backward).
+ * 17 = round-5 retirement of knob-only kernels: fabind_gemm_set_big removed (256 x 256 GEMM tiles); fabind_gcl_edge_fused_set_variant accepts 1 only,
+ *     fabind_gcl_edge_fused_bwd_set_variant 0 / 5 only, fabind_gcl_edge_fused_bwd_set_tile 64 only (their other kernels are no longer built).
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 16
+#define FABIND_ABI_VERSION 17
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs, 3 FabindTnJob (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -322,7 +324,6 @@ int fabind_gcl_edge_fused_bwd_set_variant(int v);
 int fabind_gcl_edge_fused_bwd_variant(void);
 int fabind_gcl_edge_fused_bwd_variant_for(int H);   /* the variant a launch at hidden size H takes: the set one, or -- when none was set explicitly -- 0 for H <= 128 (measured faster there), 5 otherwise.  The caller sizes d2scratch / n_groups from THIS value */
 /* development knob of variants 3 / 4: bit mask of work the kernel SKIPS (results are then wrong -- sensitivity timing only). */
-void fabind_gcl_edge_fused_bwd2_set_exp(int mask);
 void fabind_gcl_edge_fused_bwd3_set_exp(int mask);
 void fabind_gcl_edge_fused_bwd4_set_exp(int mask);   /* the saved-forward kernel: 1 dT / dP2 copy-outs, 2 S1 / dP1 stores, 4 row scan, 8 both contractions */
 /* development knob: 1 (default) = XCD-aware tile order in the fused edge kernels (XCD x owns the x-th eighth of the tiles, i.e.
@@ -647,7 +648,6 @@ int fabind_gemm_x3_occupancy(int wm); /* development probe: resident work-groups
 void fabind_cross_attn_fused_set_dbg(void* five_int64_on_device); /* development probe: phase cycle counters of one work-group of the fused cross-attention forward (NULL = off) */
 int fabind_cross_attn_fused_occupancy(int lds_bytes); /* the same for the fused cross-attention forward at the given dynamic LDS size */
 void fabind_gemm_set_x3_tile(int wm); /* development knob: tile height of the split-bf16 fabind_gemm kernel in units of 64 rows (2 = default: 128x128, two 4-wave work-groups per CU; 4: 256x128, one 8-wave work-group) */
-void fabind_gemm_set_big(int on);        /* development knob (default 0: measured slower, csrc/gemm.hip): 1 = long-M launches with N % 256 == 0 and K >= 1024 or N >= 1024 run whole 256-work-group rounds of 256 x 256 tiles (gemm_bf16_big_kernel) and the 256 x 128 kernel on the remaining row tiles; 0 = the 256 x 128 kernel only; same k-order per output element: bitwise-equal results */
 void fabind_gemm_set_small_m(int tiles); /* development knob: fabind_gemm launches with fewer 256x128 tiles than this use 128x128 tiles (default 100; 0 = never); results are bitwise equal */
 void fabind_gemm_tn_set_waves(int waves); /* development knob: work-group layout of fabind_gemm_tn: 16 (default) = 256x256 tile, 8 waves, 4-stage ring; 20 = the same with 5 stages; 4 = 256x128 tile, 4 waves, two work-groups per CU; 8 = 256x128, 8 waves.  Results are bitwise equal for equal `splits` */
 int fabind_gemm_tn_tile_n(void);          /* 256 or 128: columns of an output tile under the current layout (the host sizes `splits` from the tile count) */

@@ -162,20 +162,20 @@ def test_segment_sum_and_scan():
         assert (out.cpu() - ref).abs().max() <= 1e-4 * max(1.0, ref.abs().max())
 
 
-@pytest.mark.parametrize("bm,p_drop", [(32, 0.0), (64, 0.0), (64, 0.25), (1, 0.0), (1, 0.25), (2, 0.0), (2, 0.25), (3, 0.0), (3, 0.25), (4, 0.0), (4, 0.25), (5, 0.0), (5, 0.25), (6, 0.0), (6, 0.25)])
+@pytest.mark.parametrize("bm,p_drop", [(64, 0.0), (64, 0.25), (5, 0.0), (5, 0.25), (6, 0.0), (6, 0.25)])
 @pytest.mark.parametrize("H", [64, 128, 256, 512])
 def test_fused_edge_backward_matches_autograd(H, bm, p_drop):
     """csrc/fused_edge.hip backward (recompute + 4 chained contractions) vs torch autograd of the same bf16-rounded
     forward on the CPU: every gradient the kernel produces, including the partial column sums and both halves of dAB.
-    bm = 32 / 64: the two-LDS-tile kernel of round 1 (variant 0); bm = 1: the single in-place tile kernel, two work-groups
-    per CU (variant 1, a knob); bm = 2: one in-place tile of 128 edges, one work-group per CU (variant 2; falls back to variant 0
-    below 128 columns); bm = 3 / 4: the row-wise, operand-swapped kernel (csrc/fused_edge_bwd2.hip) at 128 / 64 edges per tile; bm = 5: the same with a store wave (csrc/fused_edge_bwd3.hip), 64 edges per tile;
+    bm = 64: the two-LDS-tile kernel of round 1 (variant 0: the default for H <= 128); bm = 5: the row-wise, operand-swapped kernel with a
+    store wave (csrc/fused_edge_bwd3.hip; the recompute default above 128), 64 edges per tile (variants 1-4 and the 32-edge tile were
+    knob-only and were retired in round 5);
     bm = 6: the two-contraction kernel over what the SAVING forward left (csrc/fused_edge_bwd4.hip: M, silu'(pre2) x keep, pre3 from
     fabind_gcl_edge_fused_train -- no recompute; the dropout mask reaches the backward through the saved tiles only)."""
     from fabind_amd import kernels as K, _lib
     dev = _dev()
-    _lib.load().fabind_gcl_edge_fused_bwd_set_variant(bm if bm in (1, 2, 3, 4, 5) else 5 if bm == 6 else 0)
-    _lib.load().fabind_gcl_edge_fused_bwd_set_tile(64 if bm in (1, 2, 3, 4, 5, 6) else bm)
+    _lib.load().fabind_gcl_edge_fused_bwd_set_variant(5 if bm in (5, 6) else 0)
+    _lib.load().fabind_gcl_edge_fused_bwd_set_tile(64)
     g = torch.Generator().manual_seed(100 + H)
     N = 300
     deg = torch.randint(0, 12, (N,), generator=g)
@@ -318,11 +318,11 @@ def test_gemm_bf16_lds_dma_fast_path(shape, cfg):
     assert torch.equal(o3.float().cpu(), Wa.float().T.contiguous())
 
 
-@pytest.mark.parametrize("variant", [1, 0])
+@pytest.mark.parametrize("variant", [1])
 @pytest.mark.parametrize("H", [64, 128, 512])
 def test_fused_edge_pipeline_matches_unfused(H, variant):
-    """csrc/fused_edge.hip / fused_edge_fwd2.hip (gather -> GEMM -> SiLU -> {segment-sum, GEMM -> row-dot}) vs fp32 torch on the CPU;
-    variant 0 = round 1's kernel, 1 = the row-wise / operand-swapped form (default), which also emits the bf16 copy of agg."""
+    """csrc/fused_edge_fwd2.hip (gather -> GEMM -> SiLU -> {segment-sum, GEMM -> row-dot}) vs fp32 torch on the CPU;
+    variant 1 = the row-wise / operand-swapped form (the only one built since round 5), which also emits the bf16 copy of agg."""
     from fabind_amd import kernels as K, _lib
     dev = _dev()
     _lib.load().fabind_gcl_edge_fused_set_variant(variant)
@@ -1327,51 +1327,3 @@ def test_layout_ranges_is_a_lower_bound_per_complex():
         got = lay.ranges(idx)
         want = lay.ranges(idx.long())                     # int64: the torch path
         assert got.dtype == torch.int32 and torch.equal(got, want), (keep, got, want)
-
-
-@pytest.mark.parametrize("N,Kd,two_seg", [(512, 1024, True), (1024, 512, False), (1536, 512, False), (512, 1536, False)])
-def test_gemm_big_tile_rounds_are_bitwise_equal(N, Kd, two_seg):
-    """csrc/gemm.hip, round 4 (a knob, off by default): long-M launches whose main loop bounds them (K >= 1024 or N >= 1024, N % 256 == 0) run whole 256-work-group
-    rounds of 256 x 256 tiles (gemm_bf16_big_kernel: each 128-column half goes through the SAME epilogue code as the 256 x 128 kernel) and
-    the 256 x 128 kernel on the remaining row tiles.  Same k-order per output element: every epilogue form the node level uses must be
-    bitwise equal to the 256 x 128 kernel alone (fabind_gemm_set_big(0)), including the rows of the tail launch and a ragged last tile."""
-    from fabind_amd import kernels as K, _lib
-    dev = _dev()
-    lib = _lib.load()
-    g = torch.Generator().manual_seed(N + Kd)
-    M = 256 * (256 // (N // 256)) + 256 + 77            # one whole round of big tiles + a full and a ragged tile for the 256 x 128 kernel
-    A = (torch.randn(M, Kd, generator=g) * 0.5).bfloat16().to(dev)
-    W = (torch.randn(N, Kd, generator=g) / Kd ** 0.5).bfloat16().to(dev)
-    b = torch.randn(N, generator=g).to(dev)
-    R = torch.randn(M, N, generator=g).to(dev)
-    aux = torch.rand(M, N, generator=g).bfloat16().to(dev)
-    A1, A2 = (A[:, :Kd // 2].contiguous(), A[:, Kd // 2:].contiguous()) if two_seg else (A, None)
-
-    def forms():
-        out = {}
-        out["bf16"] = K.gemm(A1, W, bias=b, A2=A2, out_dtype=torch.bfloat16)[0]
-        t = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        d = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        K.gemm(A1, W, bias=b, A2=A2, act_epi=K.ACT_SILU, out=t, out2=d)
-        out["silu"], out["silu_d"] = t, d
-        out["relu"] = K.gemm(A1, W, bias=b, A2=A2, act_epi=K.ACT_RELU, out_dtype=torch.bfloat16)[0]
-        y16 = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-        out["res_f32"] = K.gemm(A1, W, bias=b, A2=A2, residual=R, out_dtype=torch.float32, out16=y16)[0]
-        out["res_f32_16"] = y16
-        out["f32"] = K.gemm(A1, W, A2=A2, out_dtype=torch.float32)[0]
-        out["dact"] = K.gemm(A1, W, A2=A2, aux=aux, dact=K.ACT_STORED_DERIV, out_dtype=torch.bfloat16)[0]
-        out["dact_relu"] = K.gemm(A1, W, A2=A2, aux=aux, dact=K.ACT_RELU, out_dtype=torch.bfloat16)[0]
-        torch.cuda.synchronize()
-        return out
-
-    try:
-        lib.fabind_gemm_set_big(0)
-        ref = forms()
-        lib.fabind_gemm_set_big(1)
-        got = forms()
-    finally:
-        lib.fabind_gemm_set_big(0)                      # (the default: measured slower than two 256 x 128 work-groups per CU, csrc/gemm.hip)
-    x = A.float().cpu() @ W.float().cpu().T
-    assert (ref["f32"].cpu() - x).abs().max() <= 2e-3 * max(1.0, float(x.abs().max()))
-    for k in ref:
-        assert torch.equal(ref[k], got[k]), (k, float((ref[k].float() - got[k].float()).abs().max()))

@@ -50,7 +50,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()                                        # loads without a GPU (HIP initialises lazily)
     from fabind_amd import _lib as L
     import ctypes
-    assert lib.fabind_abi_version() == L.ABI_VERSION == 16
+    assert lib.fabind_abi_version() == L.ABI_VERSION == 17
     # the ctypes mirrors have the library's struct sizes (load() refuses a mismatch; checked again here explicitly)
     for which, mirror in enumerate((L.GemmArgs, L.EdgeBwdArgs, L.PairUpdateArgs, L.TnJob, L.AttnFusedBwdArgs)):
         assert lib.fabind_sizeof_args(which) == ctypes.sizeof(mirror)

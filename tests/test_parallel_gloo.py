@@ -232,6 +232,53 @@ def test_reducer_with_gradient_accumulation_and_abort():
     assert res[0][1] == res[1][1]
 
 
+def _asym_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    a = torch.nn.Parameter(torch.randn(600, 30))           # always used; big enough to fill buckets of its own
+    b = torch.nn.Parameter(torch.randn(300, 20))
+    c = torch.nn.Parameter(torch.randn(9))                 # never used in the discovery step; fires on rank 1 ONLY in step 2, never again
+    params = [a, b, c]
+    red = parallel.GradReducer(params, world, bucket_bytes=1 << 13)
+    out = []
+    for step in range(5):
+        for p in params:
+            p.grad = None
+        loss = (a ** 2).sum() * (rank + 1) + b.sum() * (step + 1)
+        if step == 2 and rank == 1:
+            loss = loss + 8.0 * c.sum()
+        loss.backward()
+        red.finish()
+        out.append([p.grad.numpy().tolist() for p in params])
+        assert (id(c) in red.unused) == (step < 2)         # membership in the never-used set changes on BOTH ranks together
+    red.close()
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducer_late_parameter_on_one_rank_only():
+    """a never-used parameter that fires late on ONE rank must leave the never-used set on EVERY rank -- the flat
+    buckets are reduced and divided in place, so on a rank that kept it 'never used' the slot would hold the previous step's average
+    and be summed again in every later step (4.0, 2.0, 1.0, ... instead of 4.0, 0, 0)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_asym_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1]                          # identical averaged gradients on both ranks, every step
+    for step, grads in enumerate(res[0][1]):
+        expect_c = 4.0 if step == 2 else 0.0               # (0 + 8) / 2 in the step it fired, zeros before and after
+        assert all(abs(v - expect_c) < 1e-6 for v in grads[2]), (step, grads[2])
+        assert all(abs(v - (step + 1.0)) < 1e-6 for row in grads[1] for v in row)
+
+
 NEVER_USED = ("inter_layer.", "pocket_pred_model.gnn.out_layer.coord_mlp.")   # SURVEY 2.2 / B.2: 33 tensors without a gradient
 
 
