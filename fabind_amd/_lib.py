@@ -72,6 +72,7 @@ SIGNATURES = {
     "fabind_gcl_edge_fused": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp, _vp],
     "fabind_gcl_edge_fused_train": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp, _vp, _vp, _vp, _vp],
     "fabind_gcl_edge_fused_x3": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp],
+    "fabind_gcl_edge_fused_x3_train": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _f, ctypes.c_uint, _vp, _vp, _vp, _vp, _vp],
     "fabind_gcl_edge_fused_bwd": [ctypes.POINTER(EdgeBwdArgs), _i, _i, _vp],
     "fabind_pair_update_fused": [ctypes.POINTER(PairUpdateArgs), _i, _vp],
     "fabind_gcl_edge_fused_bwd_set_tile": [_i],

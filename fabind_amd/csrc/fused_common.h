@@ -464,7 +464,7 @@ int fe_bwd3_launch(const FabindEdgeBwdArgs* a, int H, int bm, int n_groups, hipS
 int fe_fwd3_launch(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat, const float* w_r,
                    const void* W2ph, const void* W2pl, const float* b2, const void* Wcph, const void* Wcpl, const float* bc,
                    const float* w3, int E, float* agg, float* s_out, uint32_t thr16, float dscale, unsigned seed, float* bnd,
-                   int xcd_aware, hipStream_t stream);
+                   int xcd_aware, hipStream_t stream, void* Msave = nullptr, void* d2f = nullptr, void* z3f = nullptr);
 // fused_edge_fwd2.hip: the row-wise / operand-swapped forward (variant 1 of fabind_gcl_edge_fused)
 int fe_fwd2_launch(const void* AB, int ldab, int H, const int* row, const int* col, const float* rhohat, const float* w_r,
                    const void* W2p, const float* b2, const void* Wcp, const float* bc, const float* w3, int E, float* agg,

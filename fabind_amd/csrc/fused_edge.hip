@@ -67,10 +67,10 @@ extern "C" int fabind_gcl_edge_fused_train(const void* AB, int ldab, int H, cons
     return fe_fwd_entry(AB, ldab, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, E, agg, s_out, p_drop, seed, bnd, agg16, M, d2f, z3f, stream);
 }
 
-extern "C" int fabind_gcl_edge_fused_x3(const float* AB, int ldab, int n_rows, int H, const int* row, const int* col, const float* rhohat,
-                                        const float* w_r, const void* W2ph, const void* W2pl, const float* b2, const void* Wcph,
-                                        const void* Wcpl, const float* bc, const float* w3, int E, float* agg, float* s_out,
-                                        float p_drop, unsigned seed, float* bnd, hipStream_t stream) {
+static int fe_x3_entry(const float* AB, int ldab, int n_rows, int H, const int* row, const int* col, const float* rhohat,
+                       const float* w_r, const void* W2ph, const void* W2pl, const float* b2, const void* Wcph,
+                       const void* Wcpl, const float* bc, const float* w3, int E, float* agg, float* s_out,
+                       float p_drop, unsigned seed, float* bnd, void* Msave, void* d2f, void* z3f, hipStream_t stream) {
     if (E <= 0) return 0;
     FB_REQUIRE(bnd != nullptr, "fabind_gcl_edge_fused_x3: bnd (ceil(E/64) x 2 x H floats of scratch) is required");
     FB_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "fabind_gcl_edge_fused_x3: p_drop in [0, 1)");
@@ -81,12 +81,27 @@ extern "C" int fabind_gcl_edge_fused_x3(const float* AB, int ldab, int n_rows, i
     const uint32_t thr16 = (uint32_t)(p_drop * 65536.0f + 0.5f);
     const float dscale = 1.0f / (1.0f - (float)thr16 / 65536.0f);
     const int rc = fe_fwd3_launch(AB, ldab, H, row, col, rhohat, w_r, W2ph, W2pl, b2, Wcph, Wcpl, bc, w3, E, agg, s_out, thr16, dscale,
-                                  seed, bnd, g_fe_xcd_aware, stream);
+                                  seed, bnd, g_fe_xcd_aware, stream, Msave, d2f, z3f);
     if (rc) return rc;
     hipLaunchKernelGGL((fe_boundary_fix_kernel<FE_BM>), dim3((E + FE_BM - 1) / FE_BM), dim3(H < 256 ? H : 256), 0, stream, row, E, H,
                        bnd, agg, (unsigned)H, (bf16_t*)nullptr, 0u);
     FB_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int fabind_gcl_edge_fused_x3(const float* AB, int ldab, int n_rows, int H, const int* row, const int* col, const float* rhohat,
+                                        const float* w_r, const void* W2ph, const void* W2pl, const float* b2, const void* Wcph,
+                                        const void* Wcpl, const float* bc, const float* w3, int E, float* agg, float* s_out,
+                                        float p_drop, unsigned seed, float* bnd, hipStream_t stream) {
+    return fe_x3_entry(AB, ldab, n_rows, H, row, col, rhohat, w_r, W2ph, W2pl, b2, Wcph, Wcpl, bc, w3, E, agg, s_out, p_drop, seed, bnd,
+                       nullptr, nullptr, nullptr, stream);
+}
+extern "C" int fabind_gcl_edge_fused_x3_train(const float* AB, int ldab, int n_rows, int H, const int* row, const int* col, const float* rhohat,
+                                              const float* w_r, const void* W2ph, const void* W2pl, const float* b2, const void* Wcph,
+                                              const void* Wcpl, const float* bc, const float* w3, int E, float* agg, float* s_out,
+                                              float p_drop, unsigned seed, float* bnd, void* M, void* d2f, void* z3f, hipStream_t stream) {
+    FB_REQUIRE(M != nullptr && d2f != nullptr && z3f != nullptr, "fabind_gcl_edge_fused_x3_train: M, d2f, z3f are required");
+    return fe_x3_entry(AB, ldab, n_rows, H, row, col, rhohat, w_r, W2ph, W2pl, b2, Wcph, Wcpl, bc, w3, E, agg, s_out, p_drop, seed, bnd,
+                       M, d2f, z3f, stream);
 }
 
 // =====================================================================================================

@@ -39,6 +39,17 @@
 #define FE4_P5_BATCH 4     // gathered rows in flight per lane and batch of the row-wise phase (8 = the whole tile: 64 registers)
 #endif
 
+#ifndef FE4_NT_LOADS
+#define FE4_NT_LOADS 1     // 1 = the forward's fragment-ordered tiles (read once, 2 x 64 KiB per tile) are loaded non-temporally: they stream past the L2
+                           //     lines that hold the AB rows P5 gathers a second time (profiles/r04_pmc.json: 1.31 x the algorithmic bytes)
+#endif
+#if FE4_NT_LOADS
+typedef unsigned fe_u32x2_nt_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint2 fe4_ldq(const bf16_t* p_) { const fe_u32x2_nt_t v = __builtin_nontemporal_load((const fe_u32x2_nt_t*)p_); return make_uint2(v.x, v.y); }
+#else
+__device__ __forceinline__ uint2 fe4_ldq(const bf16_t* p_) { return *(const uint2*)p_; }
+#endif
+
 template <int H>
 __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd4_kernel(const FabindEdgeBwdArgs p, const int xf) {
     constexpr int BM = FE_BM, MI = BM / 16;
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd4_kernel(const FabindE
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < MI; ++i) zq[j][i] = *(const uint2*)&z3f[FE_FOFF(i, j)];
+                for (int i = 0; i < MI; ++i) zq[j][i] = fe4_ldq(&z3f[FE_FOFF(i, j)]);
             float dsr[MI];
 #pragma unroll
             for (int i = 0; i < MI; ++i) dsr[i] = sDs[i * 16 + fr];
@@ -207,7 +218,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused_bwd4_kernel(const FabindE
                 for (int i = 0; i < MI; ++i) {
                     const uint4 v = fe3_bload16(rs_dagg, dgo[i], (unsigned)(j * 64));
                     dg[slot][i] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-                    dq[slot][i] = *(const uint2*)&d2f[FE_FOFF(i, j)];
+                    dq[slot][i] = fe4_ldq(&d2f[FE_FOFF(i, j)]);
                 }
             };
             if (FE4_E3_DB) fetch_block(0, 0);

@@ -37,6 +37,18 @@ __device__ __forceinline__ void fw_silu_pair_d(const fw_f2 z, fw_f2& m, fw_f2& d
     d = s + (m - m * s);
 }
 
+#ifndef FW2_NT_SAVE
+#define FW2_NT_SAVE 1      // 1 = the fragment-ordered saved tiles (silu'(pre2), pre3) are stored non-temporally (they are read back once, a backward pass later)
+#endif
+typedef unsigned fw_u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void fw_stq(bf16_t* p_, uint32_t a, uint32_t b) {
+#if FW2_NT_SAVE
+    __builtin_nontemporal_store(fw_u32x2_t{a, b}, (fw_u32x2_t*)p_);
+#else
+    *(uint2*)p_ = make_uint2(a, b);
+#endif
+}
+
 template <int H, bool DROP, bool SAVE>
 __global__ __launch_bounds__(H, 4) void gcl_edge_fused2_kernel(const bf16_t* __restrict__ AB, int ldab, const int* __restrict__ row,
                                                             const int* __restrict__ col, const float* __restrict__ rhohat,
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused2_kernel(const bf16_t* __r
                 if constexpr (SAVE) { d01 *= k01; d23 *= k23; }
             }
             *(uint2*)&sX[FW_QOFF(i, j)] = make_uint2(fw_pack(m01), fw_pack(m23));
-            if constexpr (SAVE) *(uint2*)&d2f[FW_FOFF(i, j)] = make_uint2(fw_pack(d01), fw_pack(d23));
+            if constexpr (SAVE) fw_stq(&d2f[FW_FOFF(i, j)], fw_pack(d01), fw_pack(d23));
         }
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(H, 4) void gcl_edge_fused2_kernel(const bf16_t* __r
                 const fw_f2 z01 = fw_f2{acc[i][j][0], acc[i][j][1]} + b01, z23 = fw_f2{acc[i][j][2], acc[i][j][3]} + b23;
                 da[i] += fw_silu_pair(z01) * w01;
                 db[i] += fw_silu_pair(z23) * w23;
-                if constexpr (SAVE) *(uint2*)&z3f[FW_FOFF(i, j)] = make_uint2(fw_pack(z01), fw_pack(z23));
+                if constexpr (SAVE) fw_stq(&z3f[FW_FOFF(i, j)], fw_pack(z01), fw_pack(z23));
             }
             __builtin_amdgcn_sched_barrier(0);
         }

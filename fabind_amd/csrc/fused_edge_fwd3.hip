@@ -21,7 +21,25 @@ __device__ __forceinline__ f3_f2 f3_silu_pair(const f3_f2 z) {
     return z * f3_f2{__builtin_amdgcn_rcpf(o.x), __builtin_amdgcn_rcpf(o.y)};
 }
 
-template <int H, bool DROP>
+// value and derivative of silu from one sigmoid (the SAVE form's P1 epilogue)
+__device__ __forceinline__ void f3_silu_pair_d(const f3_f2 z, f3_f2& m, f3_f2& d) {
+    const f3_f2 t = z * -1.44269504f;
+    const f3_f2 o = f3_f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+    const f3_f2 s = f3_f2{__builtin_amdgcn_rcpf(o.x), __builtin_amdgcn_rcpf(o.y)};
+    m = z * s;
+    d = s + (m - m * s);
+}
+__device__ __forceinline__ uint32_t f3_pack(const f3_f2 v) { return pack2_bf16(v.x, v.y); }
+typedef unsigned f3_u32x2_t __attribute__((ext_vector_type(2)));
+// (non-temporal like fused_edge_fwd2.hip's: the saved tiles are read back once, a backward pass later)
+__device__ __forceinline__ void f3_stq(bf16_t* p_, uint32_t a, uint32_t b) { __builtin_nontemporal_store(f3_u32x2_t{a, b}, (f3_u32x2_t*)p_); }
+
+// SAVE (round 5, the training forward of the 'bf16x3' step): like the SAVE form of fused_edge_fwd2.hip, the kernel leaves what the
+// two-contraction backward (fused_edge_bwd4.hip) reads -- the messages M as bf16 row-major (= the hi plane: bf16(M), the operand the
+// bf16-grade weight gradient of this mode takes anyway), silu'(pre2) x keep and pre3 as bf16 quads in accumulator-fragment order (same
+// lane <-> (edge, feature) map as fused_edge_fwd2.hip: one wave per 64 features, quad (i, j) of lane l at ((tile * NW + wave) * 16 + i * 4 + j) * 64 + l) --
+// evaluated on the split-bf16 accumulators, i.e. closer to the fp32 values than the bf16 kernel's.
+template <int H, bool DROP, bool SAVE>
 __global__ __launch_bounds__(H, 2) void gcl_edge_fused_x3_kernel(const float* __restrict__ AB, int ldab, const int* __restrict__ row,
                                                               const int* __restrict__ col, const float* __restrict__ rhohat,
                                                               const float* __restrict__ w_r, const bf16_t* __restrict__ W2ph,
@@ -29,7 +47,8 @@ __global__ __launch_bounds__(H, 2) void gcl_edge_fused_x3_kernel(const float* __
                                                               const bf16_t* __restrict__ Wcph, const bf16_t* __restrict__ Wcpl,
                                                               const float* __restrict__ bc, const float* __restrict__ w3, int E,
                                                               float* agg, float* s_out, uint32_t thr16, float dscale, uint32_t seed,
-                                                              float* bnd, int xcd_aware) {
+                                                              float* bnd, int xcd_aware, bf16_t* __restrict__ Msave,
+                                                              bf16_t* __restrict__ d2f, bf16_t* __restrict__ z3f) {
     constexpr int BM = FE_BM, MI = BM / 16;
     constexpr int NW = H / 64;
     constexpr int CH = H / 8;                                     // 8-feature chunks per edge row
@@ -113,6 +132,8 @@ __global__ __launch_bounds__(H, 2) void gcl_edge_fused_x3_kernel(const float* __
     const int lbase = fr * H + (cq & 1) * 4;
 #define F3_QOFF(i, j) (lbase + (i) * 16 * H + ((cx ^ ((j) * 2)) * 8))
     const int fcol = wave * 64 + cq * 4;
+    const size_t fbase = (((size_t)tile * NW + wave) * (MI * 4) * 64 + lane) * 4;
+#define F3_FOFF(i, j) (fbase + (size_t)((i) * 4 + (j)) * 256)
 
     // ---- P1: M = silu(S1 W2^T + b2) -> planes in place
     f32x4_t acc[MI][4];
@@ -127,13 +148,22 @@ __global__ __launch_bounds__(H, 2) void gcl_edge_fused_x3_kernel(const float* __
         const f3_f2 b01 = f3_f2{bq4[j].x, bq4[j].y}, b23 = f3_f2{bq4[j].z, bq4[j].w};
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            f3_f2 m01 = f3_silu_pair(f3_f2{acc[i][j][0], acc[i][j][1]} + b01);
-            f3_f2 m23 = f3_silu_pair(f3_f2{acc[i][j][2], acc[i][j][3]} + b23);
+            f3_f2 m01, m23, d01, d23;
+            if constexpr (SAVE) {
+                f3_silu_pair_d(f3_f2{acc[i][j][0], acc[i][j][1]} + b01, m01, d01);
+                f3_silu_pair_d(f3_f2{acc[i][j][2], acc[i][j][3]} + b23, m23, d23);
+            } else {
+                m01 = f3_silu_pair(f3_f2{acc[i][j][0], acc[i][j][1]} + b01);
+                m23 = f3_silu_pair(f3_f2{acc[i][j][2], acc[i][j][3]} + b23);
+            }
             if constexpr (DROP) {
                 const uint32_t ee = (uint32_t)(e0 + i * 16 + fr), cc = (uint32_t)(fcol + j * 16);
-                m01 *= f3_f2{fe_keep(seed, ee, cc, H, thr16, dscale), fe_keep(seed, ee, cc + 1, H, thr16, dscale)};
-                m23 *= f3_f2{fe_keep(seed, ee, cc + 2, H, thr16, dscale), fe_keep(seed, ee, cc + 3, H, thr16, dscale)};
+                const f3_f2 k01 = f3_f2{fe_keep(seed, ee, cc, H, thr16, dscale), fe_keep(seed, ee, cc + 1, H, thr16, dscale)};
+                const f3_f2 k23 = f3_f2{fe_keep(seed, ee, cc + 2, H, thr16, dscale), fe_keep(seed, ee, cc + 3, H, thr16, dscale)};
+                m01 *= k01; m23 *= k23;
+                if constexpr (SAVE) { d01 *= k01; d23 *= k23; }
             }
+            if constexpr (SAVE) f3_stq(&d2f[F3_FOFF(i, j)], f3_pack(d01), f3_pack(d23));
             uint32_t h01, l01, h23, l23;
             fe_split2(m01.x, m01.y, h01, l01);
             fe_split2(m23.x, m23.y, h23, l23);
@@ -143,6 +173,15 @@ __global__ __launch_bounds__(H, 2) void gcl_edge_fused_x3_kernel(const float* __
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
+    if constexpr (SAVE) {                                         // the hi plane = bf16(M), row-major: the weight gradient's operand
+        const __amdgpu_buffer_rsrc_t rs_m = fe_rsrc(Msave + (size_t)e0 * H, (unsigned)ne * H * 2);
+#pragma unroll
+        for (int q = tid; q < BM * CH; q += H) {
+            const int rw = q / CH, c8 = q % CH;
+            const uint4 v = *(const uint4*)&sXh[rw * H + ((c8 ^ (rw & SWZ)) * 8)];
+            __builtin_amdgcn_raw_buffer_store_b128(fe_u32x4_t{v.x, v.y, v.z, v.w}, rs_m, (int)((rw * H + c8 * 8) * 2), 0, /*aux: nt*/ 2);
+        }
+    }
 
     // ---- P2: agg[row] = sum of M (= hi + lo) over the node's edges (deterministic: fused_common.h fe_scan_runs64)
     {
@@ -165,8 +204,10 @@ __global__ __launch_bounds__(H, 2) void gcl_edge_fused_x3_kernel(const float* __
             const f3_f2 b01 = f3_f2{bq.x, bq.y}, b23 = f3_f2{bq.z, bq.w}, w01 = f3_f2{wq.x, wq.y}, w23 = f3_f2{wq.z, wq.w};
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                da[i] += f3_silu_pair(f3_f2{acc[i][j][0], acc[i][j][1]} + b01) * w01;
-                db[i] += f3_silu_pair(f3_f2{acc[i][j][2], acc[i][j][3]} + b23) * w23;
+                const f3_f2 z01 = f3_f2{acc[i][j][0], acc[i][j][1]} + b01, z23 = f3_f2{acc[i][j][2], acc[i][j][3]} + b23;
+                da[i] += f3_silu_pair(z01) * w01;
+                db[i] += f3_silu_pair(z23) * w23;
+                if constexpr (SAVE) f3_stq(&z3f[F3_FOFF(i, j)], f3_pack(z01), f3_pack(z23));
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -186,23 +227,28 @@ __global__ __launch_bounds__(H, 2) void gcl_edge_fused_x3_kernel(const float* __
         s_out[e0 + tid] = s;
     }
 #undef F3_QOFF
+#undef F3_FOFF
 }
 
 int fe_fwd3_launch(const float* AB, int ldab, int H, const int* row, const int* col, const float* rhohat, const float* w_r,
                    const void* W2ph, const void* W2pl, const float* b2, const void* Wcph, const void* Wcpl, const float* bc,
                    const float* w3, int E, float* agg, float* s_out, uint32_t thr16, float dscale, unsigned seed, float* bnd,
-                   int xcd_aware, hipStream_t stream) {
+                   int xcd_aware, hipStream_t stream, void* Msave, void* d2f, void* z3f) {
     const dim3 grid((((E + FE_BM - 1) / FE_BM + 7) / 8) * 8);
     const size_t lds = (size_t)2 * FE_BM * H * 2 + 3 * FE_BM * sizeof(int) + (size_t)(H / 64) * FE_BM * sizeof(float);
-#define F3_LAUNCH_(HH, DD)                                                                                         \
+#define F3_LAUNCH_(HH, DD, SS)                                                                                     \
     do {                                                                                                           \
         static bool set_ = false;                                                                                  \
-        if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_x3_kernel<HH, DD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
-        hipLaunchKernelGGL((gcl_edge_fused_x3_kernel<HH, DD>), grid, dim3(HH), lds, stream, AB, ldab, row, col, rhohat, w_r,  \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)gcl_edge_fused_x3_kernel<HH, DD, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        hipLaunchKernelGGL((gcl_edge_fused_x3_kernel<HH, DD, SS>), grid, dim3(HH), lds, stream, AB, ldab, row, col, rhohat, w_r,  \
                            (const bf16_t*)W2ph, (const bf16_t*)W2pl, b2, (const bf16_t*)Wcph, (const bf16_t*)Wcpl, bc, w3, E, agg, \
-                           s_out, thr16, dscale, (uint32_t)seed, bnd, xcd_aware);                                  \
+                           s_out, thr16, dscale, (uint32_t)seed, bnd, xcd_aware, (bf16_t*)Msave, (bf16_t*)d2f, (bf16_t*)z3f); \
     } while (0)
-#define F3_LAUNCH(HH) do { if (thr16) F3_LAUNCH_(HH, true); else F3_LAUNCH_(HH, false); } while (0)
+#define F3_LAUNCH(HH)                                                                                              \
+    do {                                                                                                           \
+        if (Msave) { if (thr16) F3_LAUNCH_(HH, true, true); else F3_LAUNCH_(HH, false, true); }                    \
+        else { if (thr16) F3_LAUNCH_(HH, true, false); else F3_LAUNCH_(HH, false, false); }                        \
+    } while (0)
     if (H == 512) F3_LAUNCH(512); else if (H == 256) F3_LAUNCH(256); else if (H == 128) F3_LAUNCH(128); else F3_LAUNCH(64);
 #undef F3_LAUNCH
 #undef F3_LAUNCH_

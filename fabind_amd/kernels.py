@@ -499,10 +499,18 @@ def pack_frag_split(W):
     return pack_frag(hi), pack_frag(lo)
 
 
-def gcl_edge_fused_x3(AB, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, n_rows, p_drop=0.0, seed=0, rowptr=None):
+def gcl_edge_fused_x3(AB, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, n_rows, p_drop=0.0, seed=0, rowptr=None, save=False):
     """The fused forward edge pipeline in split-bf16 arithmetic (csrc/fused_edge_fwd3.hip): AB fp32 [N, 2H], fp32 weights (split into
-    hi | lo fragment packs here) -> (agg [N,H] fp32, s [E,1] fp32).  rowptr: see gcl_edge_fused."""
+    hi | lo fragment packs here) -> (agg [N,H] fp32, s [E,1] fp32).  rowptr: see gcl_edge_fused.
+    save (training forward): also -> (M [E,H] bf16, d2f, z3f) as a third result: what gcl_edge_fused_bwd(saved=...) reads (see gcl_edge_fused)."""
     E = row.shape[0]
+    if save and E > 0:
+        nt = (E + 63) // 64
+        Msave = torch.empty((E, H), dtype=torch.bfloat16, device=AB.device)
+        d2f = torch.empty((nt * 64, H), dtype=torch.bfloat16, device=AB.device)
+        z3f = torch.empty((nt * 64, H), dtype=torch.bfloat16, device=AB.device)
+    else:
+        save = False
     assert AB.dtype == torch.float32 and AB.stride(1) == 1
     alloc = torch.zeros if (rowptr is None or E == 0) else torch.empty
     agg = alloc((n_rows, H), dtype=torch.float32, device=AB.device)
@@ -512,6 +520,15 @@ def gcl_edge_fused_x3(AB, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, n_rows, 
     bnd = torch.empty(((E + 63) // 64 * 2 + 2, H), dtype=torch.float32, device=AB.device)
     W2h, W2l = pack_frag_split(W2)
     Wch, Wcl = pack_frag_split(Wc)
+    if save:
+        _profiled("gcl_edge_fused_x3_kernel<%d> E=%d saving (gather + 2 chained H x H split-bf16 contractions + segment-sum per edge; M, silu'(pre2), pre3 kept)" % (H, E),
+                  4.0 * E * H * H,
+                  lambda: check(_lib.load().fabind_gcl_edge_fused_x3_train(ptr(AB), _ld(AB), AB.shape[0], H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
+                                                                           ptr(W2h), ptr(W2l), ptr(b2), ptr(Wch), ptr(Wcl), ptr(bc), ptr(w3), E,
+                                                                           ptr(agg), ptr(s), float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd),
+                                                                           ptr(Msave), ptr(d2f), ptr(z3f), stream()), "fabind_gcl_edge_fused_x3_train"),
+                  E * (6.0 * H + 16) + n_rows * (8.0 * H + 4.0 * H))
+        return agg, s[:E], (Msave, d2f, z3f)
     _profiled("gcl_edge_fused_x3_kernel<%d> E=%d (gather + 2 chained H x H split-bf16 contractions + segment-sum per edge)" % (H, E),
               4.0 * E * H * H,
               lambda: check(_lib.load().fabind_gcl_edge_fused_x3(ptr(AB), _ld(AB), AB.shape[0], H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),

@@ -723,19 +723,27 @@ class _FusedEdge(torch.autograd.Function):
 
 class _FusedEdgeX3(torch.autograd.Function):
     """The same pipeline in the split-bf16 mode: forward = csrc/fused_edge_fwd3.hip (fp32 AB rows, three bf16 MFMAs per product
-    term: the quantities the 1e-4 A gate is stated on); backward = the bf16 recompute kernel on bf16 copies of AB and the weights --
-    the gradients of this block carry bf16 operand rounding (like 'bf16' mode), everything upstream / downstream of it stays fp32."""
+    term: the quantities the 1e-4 A gate is stated on).  Backward, H >= EDGE_SAVE_MIN_H (round 5): the forward SAVES bf16(M),
+    silu'(pre2) x keep and pre3 -- evaluated on its split-precision accumulators -- and the two-contraction kernel of the bf16 mode
+    (csrc/fused_edge_bwd4.hip) runs on them and on a bf16 copy of AB: 3.2 instead of 5.2 ms per launch at the headline shape and no
+    recompute on bf16-rounded operands; otherwise the bf16 recompute kernel on bf16 copies of AB and the weights.  Either way the
+    gradients of this block carry bf16 operand rounding (like 'bf16' mode), everything upstream / downstream of it stays fp32."""
 
     @staticmethod
     def forward(ctx, AB, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed):
         ctx.H, ctx.g, ctx.p_drop, ctx.seed = H, g, p_drop, seed
-        ctx.save_for_backward(AB, rhohat, w_r, W2, b2, Wc, bc, w3)
-        return K.gcl_edge_fused_x3(AB, H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, AB.shape[0], p_drop, seed,
-                                   rowptr=g.rp_ctx)
+        E = g.row_ctx.shape[0]
+        save = EDGE_SAVE_FWD and X3_EDGE_SAVE_FWD and H >= EDGE_SAVE_MIN_H and E >= max(1, EDGE_SAVE_MIN_EDGES)
+        out = K.gcl_edge_fused_x3(AB, H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, AB.shape[0], p_drop, seed,
+                                  rowptr=g.rp_ctx, save=save)
+        ctx.n_saved = 3 if save else 0
+        ctx.save_for_backward(AB, rhohat, w_r, W2, b2, Wc, bc, w3, *(out[2] if save else ()))
+        return out[0], out[1]
 
     @staticmethod
     def backward(ctx, dagg, ds):
-        AB, rhohat, w_r, W2, b2, Wc, bc, w3 = ctx.saved_tensors
+        AB, rhohat, w_r, W2, b2, Wc, bc, w3 = ctx.saved_tensors[:8]
+        saved = tuple(ctx.saved_tensors[8:]) if ctx.n_saved else None
         g = ctx.g
         colptr, perm = g.ctx_by_col()
         if dagg is None:
@@ -744,8 +752,11 @@ class _FusedEdgeX3(torch.autograd.Function):
             ds = torch.zeros(g.row_ctx.shape[0], dtype=torch.float32, device=AB.device)
         dAB, drh, dwr, dW2, db2, dWc, dbc, dw3 = K.gcl_edge_fused_bwd(
             AB.to(torch.bfloat16), ctx.H, g.row_ctx, g.col_ctx, rhohat, w_r, W2, b2, Wc, bc, w3, ds.reshape(-1).float(), dagg.float(),
-            colptr, perm, ctx.p_drop, ctx.seed, dab_bf16=False, w_dtype=torch.float32, rowptr=g.rp_ctx)
+            colptr, perm, ctx.p_drop, ctx.seed, dab_bf16=False, w_dtype=torch.float32, rowptr=g.rp_ctx, saved=saved)
         return (dAB, drh, dwr, dW2, db2, dWc, dbc, dw3, None, None, None, None)
+
+
+X3_EDGE_SAVE_FWD = os.environ.get("FABIND_X3_EDGE_SAVE_FWD", "1") != "0"    # 0: 'bf16x3' keeps the recompute backward (round 3-4; A/B)
 
 
 def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop=0.0, frags=None):
@@ -1013,6 +1024,7 @@ class GradSink:
         self.buf = None
         self.pending = None          # full-size fp32 tensor deferred by deposit()
         self.rows = []               # (index64, rows) deferred by deposit_rows()
+        self.deferred = []           # (A, Wt) input-gradient GEMMs held back by gemm_into() until `_SinkOwner.backward` (DEFER_DX)
 
     def take(self, like):
         """-> (buffer, True if this call created it and must return it as the gradient)."""
@@ -1052,6 +1064,14 @@ class GradSink:
     def gemm_into(self, A, Wt, like, dtype=torch.float32):
         """d x (+)= A @ Wt^T-form GEMM (K.gemm(A, Wt)) into the shared buffer; returns the buffer if this call created it
         (the caller hands it to autograd), else None."""
+        if (DEFER_DX and A.dtype == torch.bfloat16 and Wt.dtype == torch.bfloat16 and A.dim() == 2 and A.stride(1) == 1 and A.stride(0) % 8 == 0
+                and A.shape[1] % 64 == 0 and A.shape[0] >= DEFER_DX_MIN_ROWS and A.data_ptr() % 16 == 0):
+            # held back: a tensor with two input-gradient GEMMs (first edge Linear + node MLP on h; k | v projection + Transition on the
+            # attention update; pair projections + q | k | v on the attention layer's input) gets ONE launch over the K-concatenated
+            # operands [A1 | A2] x [Wt1 | Wt2] when its last consumer has reported -- one pass over the fp32 gradient instead of a
+            # store + a read-modify-write (8 of the 12 bytes per element of the second launch), and the small-K launch disappears
+            self.deferred.append((A, Wt))
+            return None
         if self.buf is None:
             out = torch.empty(like.shape, dtype=dtype, device=like.device)      # (`like` may be the bf16 operand copy of an fp32 tensor)
             pend = self.pending
@@ -1068,6 +1088,32 @@ class GradSink:
         return None
 
 
+DEFER_DX = os.environ.get("FABIND_DEFER_DX", "1") == "1"     # 0: every input-gradient GEMM into a shared buffer is launched where it arises (round 4)
+DEFER_DX_MIN_ROWS = int(os.environ.get("FABIND_DEFER_DX_MIN_ROWS", "1024"))
+
+
+def _run_deferred(defs, out, base, accumulate):
+    """The held-back input-gradient GEMMs of one tensor: pairs as one K-concatenated launch each ([A1 | A2] x [Wt1 | Wt2]^T; the weight
+    operand is concatenated here: K_in x (N1 + N2) bf16, a parameter-sized copy).  The first launch stores `out` (+ base, the gradient
+    that already exists as a tensor, through the epilogue's residual operand) unless `accumulate`; the others accumulate."""
+    defs = sorted(defs, key=lambda d_: -d_[0].shape[1])          # largest K first: it becomes segment one of the first launch
+    first = True
+    while defs:
+        if len(defs) >= 2:
+            (A1, W1), (A2, W2) = defs[0], defs[1]
+            defs = defs[2:]
+            Wcat = torch.cat([W1, W2], 1)
+            args = dict(A2=A2)
+        else:
+            (A1, Wcat), = defs
+            defs, args = [], {}
+        if first and not accumulate:
+            K.gemm(A1, Wcat, out=out, residual=base, **args)
+        else:
+            K.gemm(A1, Wcat, out=out, accumulate=True, **args)
+        first = False
+
+
 class _SinkOwner(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t, sink):
@@ -1079,9 +1125,21 @@ class _SinkOwner(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         sink = ctx.sink
-        pend, rows = sink.pending, sink.rows
+        pend, rows, defs = sink.pending, sink.rows, sink.deferred
         owned = g is not None and g is sink.buf    # the buffer this sink allocated and returned to autograd as the one gradient
-        sink.buf, sink.pending, sink.rows = None, None, []
+        sink.buf, sink.pending, sink.rows, sink.deferred = None, None, [], []
+        if defs:                                   # the input-gradient GEMMs held back by gemm_into(): K-concatenated, one pass
+            if owned:
+                _run_deferred(defs, g, None, True)
+            else:
+                base = g
+                if pend is not None:
+                    base, pend = (pend if base is None else base + pend), None
+                if base is not None and base.dtype != ctx.meta[1] and not (base.dtype == torch.bfloat16 and ctx.meta[1] == torch.float32):
+                    base = base.to(ctx.meta[1])
+                g = torch.empty(ctx.meta[0], dtype=ctx.meta[1], device=ctx.meta[2])
+                _run_deferred(defs, g, base, False)
+                owned = True
         if pend is not None:                       # a deposit that no later GEMM folded in
             if g is None:
                 g, owned = pend, False             # `pend` may alias another node's incoming gradient (deposit() does not copy)

@@ -220,11 +220,13 @@ def condition_model_inputs(model, input_boost=300.0):
     return model
 
 
-def make_hetero_batch(sizes, seed=0, pocket_radius=20.0, feat_scale=0.1, prot_feat=1280, lig_feat=56):
+def make_hetero_batch(sizes, seed=0, pocket_radius=20.0, feat_scale=0.1, prot_feat=1280, lig_feat=56, seeds=None):
     """A collated batch with every field ``IaBNet...forward`` / ``.inference`` reads.
 
     ``sizes=[(n_prot_whole, n_lig), ...]``.  The pocket is the residues within `pocket_radius` of the
-    ligand centroid (what the reference's dataset builder does, utils/utils.py:121-144)."""
+    ligand centroid (what the reference's dataset builder does, utils/utils.py:121-144).
+    seeds (optional, one per complex): the complex's own seed instead of ``seed * 1000 + position`` -- a complex then is the same
+    whichever batch (rank shard) it is dealt to (tests/test_gpu_dp.py)."""
     data = HeteroBatch()
     acc = {k: [] for k in (
         "c_feats", "c_coords", "c_rdkit", "c_batch", "p_feats", "p_batch", "keep", "pocket_batch",
@@ -234,7 +236,7 @@ def make_hetero_batch(sizes, seed=0, pocket_radius=20.0, feat_scale=0.1, prot_fe
         "coords_center", "pocket_idx", "dis_map", "pocket_residue_center")}
     off_c = off_w = 0
     for b, (npr, nl) in enumerate(sizes):
-        c = make_complex(npr, nl, seed * 1000 + b)
+        c = make_complex(npr, nl, seed * 1000 + b if seeds is None else int(seeds[b]))
         g = c["g"]
         prot, lig_true, conf = c["prot"], c["lig"], c["conf"]
         com = lig_true.mean(0)

@@ -57,7 +57,8 @@ const char* fabind_last_error(void);
  *     cross attention: fabind_sizeof_args(4)).
  * 16 = fabind_gcl_edge_fused_train (the forward that saves M / silu'(pre2) / pre3) and FabindEdgeBwdArgs.{d2f, z3f} (the two-contraction backward).
  * 17 = round-5 retirement of knob-only kernels: fabind_gemm_set_big removed (256 x 256 GEMM tiles); fabind_gcl_edge_fused_set_variant accepts 1 only,
- *     fabind_gcl_edge_fused_bwd_set_variant 0 / 5 only, fabind_gcl_edge_fused_bwd_set_tile 64 only (their other kernels are no longer built).
+ *     fabind_gcl_edge_fused_bwd_set_variant 0 / 5 only, fabind_gcl_edge_fused_bwd_set_tile 64 only (their other kernels are no longer built);
+ *     fabind_gcl_edge_fused_x3_train added (the split-bf16 forward that saves M / silu'(pre2) / pre3 for the two-contraction backward).
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 17
 int fabind_abi_version(void);
@@ -258,6 +259,13 @@ int fabind_gcl_edge_fused_x3(const float* AB, int ldab, int n_rows, int H, const
                              const float* w_r, const void* W2ph, const void* W2pl, const float* b2, const void* Wcph,
                              const void* Wcpl, const float* bc, const float* w3, int E, float* agg, float* s_out, float p_drop,
                              unsigned seed, float* bnd, hipStream_t stream);
+/* The same for a 'bf16x3' training step (round 5): additionally leaves M [E, H] bf16 row-major (= bf16 of the split-precision messages),
+ * d2f / z3f = silu'(pre2) x keep and pre3 as bf16 in accumulator-fragment order -- exactly what fabind_gcl_edge_fused_train leaves, so the
+ * two-contraction backward (FabindEdgeBwdArgs.d2f / z3f, bf16 copy of AB) serves this mode too (reference arithmetic: egnn.py:68-128). */
+int fabind_gcl_edge_fused_x3_train(const float* AB, int ldab, int n_rows, int H, const int* row, const int* col, const float* rhohat,
+                                   const float* w_r, const void* W2ph, const void* W2pl, const float* b2, const void* Wcph,
+                                   const void* Wcpl, const float* bc, const float* w3, int E, float* agg, float* s_out, float p_drop,
+                                   unsigned seed, float* bnd, void* M, void* d2f, void* z3f, hipStream_t stream);
 
 /* Fused forward edge pipeline of MC_E_GCL (models/egnn.py:68-128) for 64-edge tiles, bf16:
  *   s_out[e] = w3 . silu( silu( silu(A[row]+Bc[col]+rhohat*w_r) W2^T + b2 ) Wc^T + bc ),  agg[row] += silu(.. W2^T + b2)

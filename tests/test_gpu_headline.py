@@ -95,10 +95,12 @@ def test_headline_shape_fp32_matches_oracle(one_complex, n_iter):
     assert herr <= 1e-4
 
 
-# bf16 ligand-RMSD gap at this shape; the asserted bound is 2x the measurement: measured
-# 7.9e-5 .. 8.4e-5 A (n_iter = 1: inside the 1e-4 A gate) and 1.48e-4 .. 1.70e-4 A (n_iter = 2: outside) over the round's runs
-# n_iter = 8 (the production loop; first measured in round 3): see DESIGN section 2
-BF16_GAP_BOUND_A = {1: 1.7e-4, 2: 3.4e-4, 8: 4e-3}
+# bf16 ligand-RMSD gap at this shape.  n_iter = 1 (the pass the headline times): the north-star GATE itself, 1e-4 A, is asserted
+# (measured 7.9e-5 .. 8.4e-5 A over rounds 2-5 -- any storage change that costs precision, e.g. a bf16 residual
+# stream at 1.35e-4 A, profiles/r05_precision_sim.txt, fails here).  n_iter = 2 / 8: the bf16 mode MISSES the gate there (1.48e-4 ..
+# 1.70e-4 A / 5.9e-4 A measured; bench.py says so next to `n_iter8`) -- bounded at 2x the measurement; `bf16x3` is the gate-meeting
+# mode for the refinement loop (test below).
+BF16_GAP_BOUND_A = {1: 1e-4, 2: 3.4e-4, 8: 4e-3}
 
 
 @pytest.mark.parametrize("n_iter", [1, 2, 8])

@@ -832,6 +832,68 @@ def test_fused_edge_split_bf16_matches_float64(H, p_drop):
     assert torch.equal(agg, agg2) and torch.equal(s, s2)                # deterministic
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.25])
+@pytest.mark.parametrize("H", [64, 256, 512])
+def test_fused_edge_split_bf16_saving_forward_feeds_the_two_contraction_backward(H, p_drop):
+    """Round 5: the SAVING form of csrc/fused_edge_fwd3.hip (fabind_gcl_edge_fused_x3_train) -- identical agg / s
+    to the plain split-bf16 forward, bf16(M) row-major, silu'(pre2) x keep and pre3 in fragment order -- and the two-contraction
+    backward of csrc/fused_edge_bwd4.hip run on what it left + a bf16 copy of AB: every gradient against fp32 torch autograd of the
+    same pipeline (bf16-grade bounds: the operands of the backward are bf16 roundings), bit-identical repeats."""
+    from fabind_amd import kernels as K
+    from helpers import fused_edge_keep_mask
+    dev = _dev()
+    g = torch.Generator().manual_seed(7 * H + 3)
+    N = 300
+    deg = torch.randint(0, 12, (N,), generator=g)
+    deg[7] = 333
+    deg[250:] = 0
+    row = torch.repeat_interleave(torch.arange(N), deg)
+    rowptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(deg, 0)]).to(torch.int32)
+    E = row.shape[0]
+    col = torch.randint(0, N, (E,), generator=g)
+    AB = torch.randn(N, 2 * H, generator=g)
+    rh = torch.rand(E, generator=g)
+    w_r, b2, bc, w3 = [torch.randn(H, generator=g) * 0.5 for _ in range(4)]
+    W2 = torch.randn(H, H, generator=g) / H ** 0.5
+    Wc = torch.randn(H, H, generator=g) / H ** 0.5
+    ds = torch.randn(E, generator=g)
+    dagg = torch.randn(N, H, generator=g)
+    silu = torch.nn.functional.silu
+    leaf = lambda t: t.clone().requires_grad_(True)
+    ABf, rhf, wrf, W2f, b2f, Wcf, bcf, w3f = map(leaf, (AB, rh, w_r, W2, b2, Wc, bc, w3))
+    seed = 4242
+    keep = fused_edge_keep_mask(seed, E, H, p_drop)
+    S1 = silu(ABf[row, :H] + ABf[col, H:] + rhf[:, None] * wrf)
+    M = silu(S1 @ W2f.T + b2f) * keep
+    agg = torch.zeros(N, H).index_add(0, row, M)
+    sv = (silu(M @ Wcf.T + bcf) * w3f).sum(1)
+    ((agg * dagg).sum() + (sv * ds).sum()).backward()
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    rp = rowptr.to(dev)
+    args = (AB.to(dev), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev), Wc.to(dev), bc.to(dev), w3.to(dev), N)
+    a0, s0 = K.gcl_edge_fused_x3(*args, p_drop=p_drop, seed=seed, rowptr=rp)
+    a1, s1, saved = K.gcl_edge_fused_x3(*args, p_drop=p_drop, seed=seed, rowptr=rp, save=True)
+    assert torch.equal(a0, a1) and torch.equal(s0, s1)                                   # the stores do not change the results
+    assert saved[0].dtype == torch.bfloat16 and saved[0].shape == (E, H) and saved[1].shape == ((E + 63) // 64 * 64, H)
+    assert (saved[0].float().cpu() - M.detach()).abs().max() <= 1e-2 * max(1.0, float(M.abs().max()))      # bf16(M), row-major
+    colsorted, perm = torch.sort(col, stable=True)
+    colptr = torch.zeros(N + 1, dtype=torch.int32)
+    colptr[1:] = torch.cumsum(torch.bincount(colsorted, minlength=N), 0)
+    bw = lambda: K.gcl_edge_fused_bwd(AB.to(dev).bfloat16(), H, i32(row), i32(col), rh.to(dev), w_r.to(dev), W2.to(dev), b2.to(dev), Wc.to(dev),
+                                      bc.to(dev), w3.to(dev), ds.to(dev), dagg.to(dev), colptr.to(dev), i32(perm), p_drop, seed,
+                                      dab_bf16=False, w_dtype=torch.float32, rowptr=rp, saved=saved)
+    out, out2 = bw(), bw()
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(out, out2))
+    names = ("dAB", "drh", "dw_r", "dW2", "db2", "dWc", "dbc", "dw3")
+    refs = (ABf.grad, rhf.grad, wrf.grad, W2f.grad, b2f.grad, Wcf.grad, bcf.grad, w3f.grad)
+    for name, got, ref in zip(names, out, refs):
+        err = (got.float().cpu() - ref).abs().max().item()
+        scale = max(1.0, ref.abs().max().item())
+        assert err <= 3e-2 * scale, (name, err, scale)
+        rel = ((got.float().cpu() - ref).norm() / ref.norm().clamp_min(1e-6)).item()
+        assert rel <= 2e-2, (name, rel)
+
+
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
 @pytest.mark.parametrize("R,C,ld", [(1000, 512, 512), (333, 1025, 1088), (77, 128, 128), (50, 36, 36), (129, 1088, 1088), (64, 96, 200),
                                     (1003, 256, 256), (333, 200, 256), (4099, 64, 64), (9001, 128, 136)])

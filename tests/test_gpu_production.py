@@ -182,6 +182,81 @@ def test_iabnet_production_size_matches_oracle(stage):
     assert g3 < 1e-4 and le3 <= 1e-5
 
 
+# bf16 gap of the whole-graph step (ligand RMSD in A, relative loss gap): asserted at 2x the first measurement (round 5)
+CONFIG3_BF16_BOUND = (2.0e-3, 2e-5)
+
+
+def test_config3_whole_graph_matches_oracle():
+    """BASELINE configs[2] READ LITERALLY: one 1500 / 40 complex whose pocket is the WHOLE protein
+    (`pocket_radius = 1e9`), full IaBNet stage 1 -- the hidden-128 pocket model AND the 4-layer hidden-512 complex model AND the
+    distance-map head over all 1500 x 40 pairs together, which no other test compares with the oracle (the production tests above use
+    the 20 A crop; the headline tests the stack alone) -- with the pocket-cls + pocket-centre + coord + both distance-map + distill
+    losses, forward and backward, n_iter = 1 as in bench.py's `config3_whole_graph` sub-object.  fp32 vs the CPU oracle: 11-tuple,
+    six loss terms to 1e-5 relative, every parameter gradient; bf16 (the sub-object's dtype): the gap printed and bounded.
+    Reference: FABind/fabind/models/model.py:82-369 (forward), main_fabind.py:398-417 (loss)."""
+    from fabind_amd import engine, synthetic
+    from fabind_amd.models.model import compute_loss
+    _threads()
+    dev = torch.device("cuda:0")
+    data0 = synthetic.make_hetero_batch([(1500, 40)], seed=12, pocket_radius=1e9)
+    m = _iabnet(n_iter=1)
+    cfg = dict(orc.DEFAULT_CFG)
+    cfg.update(mean_layers=4, n_iter=1)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    ref_out = orc.model_forward(sd, cfg, data0.clone(), stage=1)
+    ref_loss, ref_terms = orc.compute_loss(ref_out, data0)
+    ref_loss.backward()
+    ref_grads = {k: v.grad for k, v in sd.items() if v.is_floating_point()}
+    ref_out = [o.detach() if torch.is_tensor(o) else o for o in ref_out]
+    assert ref_out[9].numel() == 1500 * 40                              # the distance-map head saw every (residue, atom) pair: the whole graph
+    engine.set_precision("fp32")
+    m = m.to(dev)
+    data = data0.clone().to(dev)
+    out = m(data, stage=1, train=False)
+    init = data0["compound"].node_coords.numpy()
+    moved = rmsd(ref_out[0].numpy(), init)
+    gap = rmsd(out[0].detach().cpu().numpy(), ref_out[0].numpy())
+    print("config 3 read literally (1500 / 40, whole-protein pocket, IaBNet stage 1, n_iter 1): ligand moved %.3f A; RMSD vs oracle %.3e A" % (moved, gap))
+    assert moved > 1e-2 and gap < 1e-4
+    for i, n in TUPLE:
+        r, g = ref_out[i].numpy(), out[i].detach().cpu().numpy()
+        assert r.shape == g.shape, n
+        assert np.abs(g - r).max() <= 1e-4 * max(1.0, np.abs(r).max()), n
+    assert np.array_equal(out[5].cpu().numpy(), ref_out[5].numpy()) and np.array_equal(out[6].cpu().numpy(), ref_out[6].numpy())
+    loss, terms = compute_loss(out, data)
+    lerr = abs(float(loss.detach()) - float(ref_loss)) / abs(float(ref_loss))
+    print("    six-term loss %.6f vs oracle %.6f (rel %.2e)" % (float(loss.detach()), float(ref_loss), lerr))
+    assert lerr <= 1e-5
+    for k, v in terms.items():
+        assert abs(float(v.detach()) - float(ref_terms[k])) <= 1e-5 * max(abs(float(ref_terms[k])), 1e-2), k
+    loss.backward()
+    rows = _grad_rows(m.named_parameters(), ref_grads)
+    _print_rows("config 3 whole graph, fp32 gradients vs oracle autograd", rows)
+    assert len(rows) >= 350 and _grads_ok(rows), (len(rows), rows[0])
+    # the sub-object's dtype: forward gap and the loss; and its gradients as a whole against the oracle's (bf16-grade)
+    engine.set_precision("bf16")
+    try:
+        for p_ in m.parameters():
+            p_.grad = None
+        data = data0.clone().to(dev)
+        o16 = m(data, stage=1, train=False)
+        l16, _ = compute_loss(o16, data)
+        l16.backward()
+    finally:
+        engine.set_precision("fp32")
+    g16 = rmsd(o16[0].detach().cpu().numpy(), ref_out[0].numpy())
+    le16 = abs(float(l16.detach()) - float(ref_loss)) / abs(float(ref_loss))
+    num = sum(float(((p_.grad.detach().cpu() - ref_grads[n_]) ** 2).sum()) for n_, p_ in m.named_parameters() if p_.grad is not None and ref_grads.get(n_) is not None)
+    den = sum(float((ref_grads[n_] ** 2).sum()) for n_, p_ in m.named_parameters() if p_.grad is not None and ref_grads.get(n_) is not None)
+    print("    bf16: ligand RMSD gap %.3e A (gate 1e-4: %s), loss rel gap %.3e, whole-gradient l2 error %.3e"
+          % (g16, "met" if g16 < 1e-4 else "missed", le16, (num / den) ** 0.5))
+    assert g16 < CONFIG3_BF16_BOUND[0] and le16 < CONFIG3_BF16_BOUND[1]
+    assert (num / den) ** 0.5 < 5e-2
+
+
 def test_iabnet_production_size_inference():
     from fabind_amd import engine
     _threads()
