@@ -183,7 +183,7 @@ def test_iabnet_production_size_matches_oracle(stage):
 
 
 # bf16 gap of the whole-graph step (ligand RMSD in A, relative loss gap): asserted at 2x the first measurement (round 5)
-CONFIG3_BF16_BOUND = (2.0e-3, 2e-5)
+CONFIG3_BF16_BOUND = (1.9e-4, 1e-6)              # measured 9.43e-5 A (inside the gate) and 4.1e-7; whole-gradient l2 error 6.6e-4
 
 
 def test_config3_whole_graph_matches_oracle():
