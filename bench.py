@@ -225,6 +225,9 @@ def main():
                          "FABind+ sampling-mode inference (BASELINE configs[4]: dropout sampling, DBSCAN centre choice, "
                          "confidence head, --poses per complex); plus_train: one FABind+ training step (train mode, 7-term "
                          "loss incl. the permutation-invariant coordinate term, fwd+bwd)")
+    ap.add_argument("--whole-pocket", action="store_true",
+                    help="--mode model: unbounded pocket radius -- the complex model and the heads see the whole 1500 / 40 graph (BASELINE "
+                         "configs[2] read literally; the `config3_whole_graph` sub-object of the default line)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="run ONLY SURVEY 8(d)'s CPU-baseline protocol (oracle, B=2, >=3 warm-ups + 5 timed runs, 32 threads / torch default / 1 "
@@ -542,7 +545,7 @@ def main():
                      "algorithmic_bytes_per_launch": nbytes / cnt, "other_roofline": other})
         return out_
 
-    step, per_rank, _ = make_step(a.mode, a.n_iter)
+    step, per_rank, _ = make_step(a.mode, a.n_iter, whole_pocket=a.whole_pocket)
     dt, prof = timed(step, a.warmup, a.steps, os.environ.get("FABIND_BENCH_NO_PROFILE", "0") != "1")   # (=1: no per-launch events, A/B of their cost)
     poses = a.poses if a.mode == "plus_sampling" else 1
     value = per_rank * world * a.steps / dt * poses

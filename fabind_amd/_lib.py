@@ -107,6 +107,8 @@ SIGNATURES = {
     "fabind_pair_hadamard": [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _vp],
     "fabind_inter_attn_fwd": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
                               _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "fabind_inter_attn_fwd_rows": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp,
+                                   _vp, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fabind_layernorm_rows_bwd": [_vp, _i, _i, _vp, _vp, _i, _i, _f, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp],
     "fabind_edge_concat": [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp],
     "fabind_las_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp],
@@ -131,6 +133,8 @@ SIGNATURES = {
                                  _vp],
     "fabind_inter_attn_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i,
                               _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "fabind_inter_attn_bwd_rows": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i,
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _vp],
     "fabind_las_step_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _vp, _vp],
     "fabind_pair_bias_bwd": [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fabind_pair_bias_btcat": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _i, _vp],

@@ -153,7 +153,9 @@ class Graph:
         rp_ctx, rp_int = K.exclusive_scan(deg_ctx), K.exclusive_scan(deg_int)
         lo = lay.node_off[:-1].long()
         n_lig_rows = (rp_int[lo + lay.c_cnt.long()] - rp_int[lo]).sum()
-        E_ctx, E_int, n_half = torch.stack([rp_ctx[-1], rp_int[-1], n_lig_rows.to(rp_int.dtype)]).tolist()   # the one host sync
+        # (the two row counts of the inter-edge attention's deal-by-degree ride in the same read-back)
+        E_ctx, E_int, n_half, n_act, n_heavy = torch.stack([rp_ctx[-1], rp_int[-1], n_lig_rows.to(rp_int.dtype), (deg_int > 0).sum().to(rp_int.dtype),
+                                                            (deg_int > K.INTER_ATTN_HEAVY).sum().to(rp_int.dtype)]).tolist()   # the one host sync
         if 2 * n_half != E_int:
             # the pair bookkeeping (inter_meta) needs every ligand->protein edge mirrored; only non-finite coordinates
             # can break that -- fail loudly on the host instead of faulting on the device
@@ -173,7 +175,7 @@ class Graph:
             deg_int[u] = 1
             deg_int[v] = 1
             rp_int = K.exclusive_scan(deg_int)
-            E_int = 2
+            E_int, n_act, n_heavy = 2, 2, 0
             self.col_ctx, self.row_ctx, _, _ = K.edges_fill(x, lay.node_off, lay.c_cnt, lay.B, lay.max_n, bond_row,
                                                             bond_col, bond_off, cut_intra, -1.0, rp_ctx, rp_ctx * 0,
                                                             E_ctx, 0)
@@ -193,6 +195,9 @@ class Graph:
                   % (E_int, int(c.min()), int(c.max()), Nn, int((rr != r).sum()), nbad, bool(torch.isfinite(x).all())), flush=True)
         self.red_off, self.red_idx, self.red_c, self.red_p, self.mirror = K.inter_meta(
             lay.node_off, lay.c_cnt, lay.B, rp_int, self.col_int, self.row_int)
+        # the rows of the inter graph sorted by degree, descending (index glue: one stable sort per graph): the inter-edge attention kernels
+        # put a row with more than 8 edges on four waves and start the heavy rows first (csrc/inter_attn_rows.hip)
+        self.int_deal = (torch.argsort(deg_int, descending=True, stable=True).to(torch.int32), int(n_heavy), int(n_act))
         self._ctx_bycol = None
         self.N = lay.N
 
@@ -603,8 +608,10 @@ def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv, pdrop=0.0, pdrop_r
     qkv = ops.linear(h16, p["Wqkv"], p["bqkv"], want16=True)                           # [N,3H] (+ bf16 copy: V is the next operand)
     d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay, g.int_by_col)
     # cv = Linear(V) [N,H] (egnn.py:225) is evaluated inside inter_attn (its adjoint accumulates into dqkv in place)
+    # (h is this function's own intermediate -- the row scatter of cross_attention made it -- and with pdrop == 0 nobody reads it after
+    #  the call: a no-grad pass lets the kernel update it in place; DEBUG_CAPTURE keeps clones)
     h_new, x_new, alpha = ops.inter_attn(qkv, None, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["wcr"],
-                                         p["w3"], clampv, Wc=p["Wc"], bc=p["bc"])
+                                         p["w3"], clampv, Wc=p["Wc"], bc=p["bc"], own_h=(pdrop == 0.0))
     if pdrop > 0.0:
         h_new = h + _drop(h_new - h, pdrop)
     return h_new, x_new, alpha

@@ -400,12 +400,31 @@ def pair_hadamard(a0, b0, a1, b1, red_p, red_c, out_dtype):
     return hd
 
 
-def inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, rowptr, col, red_idx, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None, h16=None):
-    """h16 (bf16 [n_rows, H], optional): receives h_out as a bf16 operand."""
+INTER_ATTN_ROWS = os.environ.get("FABIND_INTER_ATTN_ROWS", "1") == "1"    # 0: one wave per row whatever its degree (rounds 1-4; A/B)
+INTER_ATTN_HEAVY = 8                                                      # = IA_HEAVY of csrc/inter_attn_rows.hip
+
+
+def inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, rowptr, col, red_idx, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None, h16=None, deal=None,
+                   inplace=False):
+    """h16 (bf16 [n_rows, H], optional): receives h_out as a bf16 operand.
+    deal = (order int32 [n_rows], n_heavy, n_act) (engine.Graph.int_deal): the rows dealt by degree -- heavy rows on four waves
+    (csrc/inter_attn_rows.hip); None: one wave per row.
+    inplace (needs `deal`; no-grad passes whose caller owns h): h_out IS h and h16 the caller's existing bf16 copy of h -- only the rows
+    WITH inter edges are rewritten (8 % of the rows of the headline batch; the pass-through copy of the other 92 % is 0.5 GB per call)."""
     n_rows, E = h.shape[0], col.shape[0]
-    h_out, x_out = torch.empty_like(h), torch.empty_like(x)
     alpha = torch.empty(max(E, 1), dtype=torch.float32, device=h.device)
     cvs = torch.empty(max(E, 1), dtype=torch.float32, device=h.device)
+    if deal is not None and INTER_ATTN_ROWS:
+        inplace = bool(inplace) and h.is_contiguous()
+        h_out, x_out = (h, x.clone()) if inplace else (torch.empty_like(h), torch.empty_like(x))
+        check(_lib.load().fabind_inter_attn_fwd_rows(ptr(qkv), _ld(qkv), ptr(cv), _ld(cv), H, ptr(h), _ld(h), ptr(x), ptr(d),
+                                                     ptr(rhohat), ptr(rowptr), ptr(col), ptr(red_idx), ptr(bias_part),
+                                                     bias_part.shape[1], ptr(w_rk), ptr(w_rv), ptr(wcr), ptr(w3), clampv,
+                                                     int(deal[2]) if inplace else n_rows,      # (in place: the rows without edges are not touched)
+                                                     ptr(h_out), ptr(x_out), ptr(alpha), ptr(cvs), ptr(s_ext), ptr(h16), ptr(deal[0]),
+                                                     int(deal[1]), int(deal[2]), stream()), "fabind_inter_attn_fwd_rows")
+        return h_out, x_out, alpha[:E], cvs[:E]
+    h_out, x_out = torch.empty_like(h), torch.empty_like(x)
     check(_lib.load().fabind_inter_attn_fwd(ptr(qkv), _ld(qkv), ptr(cv), _ld(cv), H, ptr(h), _ld(h), ptr(x), ptr(d),
                                             ptr(rhohat), ptr(rowptr), ptr(col), ptr(red_idx), ptr(bias_part),
                                             bias_part.shape[1], ptr(w_rk), ptr(w_rv), ptr(wcr), ptr(w3), clampv, n_rows,

@@ -1356,7 +1356,7 @@ class _InterAttn(torch.autograd.Function):
             h16 = torch.empty((h.shape[0], H), dtype=torch.bfloat16, device=h.device)
             holder.append(h16)
         h_out, x_out, alpha, cvs = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx,
-                                                    bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext, h16)
+                                                    bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext, h16, deal=getattr(g, "int_deal", None))
         ctx.g, ctx.H, ctx.clampv, ctx.np = g, H, clampv, bias_part.shape[1]
         ctx.has_ext, ctx.has_cv = s_ext is not None, Wc is not None
         ctx.sink_h = _sink_of(h)
@@ -1386,11 +1386,20 @@ class _InterAttn(torch.autograd.Function):
         #  4,096 work-groups measured 1,034 / 1,035 / 1,088 us forward + backward at the bench shape, tools/probes/inter_attn_time.py)
         nblk = min((N + 3) // 4, INTER_BWD_BLOCKS)
         wpart = torch.empty((nblk, 4 * H), **f32)                     # [block][4][H] partials of the four vector gradients
-        check(load().fabind_inter_attn_bwd(ptr(qkv), qkv.stride(0), ptr(cv), cv.stride(0), H, ptr(d), ptr(rhohat),
-                                           ptr(g.rp_int), ptr(g.col_int), ptr(g.mirror), ptr(g.red_idx), ptr(w_rk),
-                                           ptr(w_rv), ptr(wcr), ptr(w3), ptr(alpha), ptr(cvs), ctx.clampv, N, ptr(dh_out),
-                                           ptr(dx_out), ptr(dqkv), ptr(dcv), ptr(dd), ptr(drh), ptr(dbias_red), ptr(dlogit),
-                                           ptr(dcp), ptr(wpart), nblk, stream()), "fabind_inter_attn_bwd")
+        deal = getattr(g, "int_deal", None) if K.INTER_ATTN_ROWS else None
+        if deal is not None:             # the rows dealt by degree: heavy rows on four waves (csrc/inter_attn_rows.hip)
+            check(load().fabind_inter_attn_bwd_rows(ptr(qkv), qkv.stride(0), ptr(cv), cv.stride(0), H, ptr(d), ptr(rhohat),
+                                                    ptr(g.rp_int), ptr(g.col_int), ptr(g.mirror), ptr(g.red_idx), ptr(w_rk),
+                                                    ptr(w_rv), ptr(wcr), ptr(w3), ptr(alpha), ptr(cvs), ctx.clampv, N, ptr(dh_out),
+                                                    ptr(dx_out), ptr(dqkv), ptr(dcv), ptr(dd), ptr(drh), ptr(dbias_red), ptr(dlogit),
+                                                    ptr(dcp), ptr(wpart), nblk, ptr(deal[0]), int(deal[1]), int(deal[2]), stream()),
+                  "fabind_inter_attn_bwd_rows")
+        else:
+            check(load().fabind_inter_attn_bwd(ptr(qkv), qkv.stride(0), ptr(cv), cv.stride(0), H, ptr(d), ptr(rhohat),
+                                               ptr(g.rp_int), ptr(g.col_int), ptr(g.mirror), ptr(g.red_idx), ptr(w_rk),
+                                               ptr(w_rv), ptr(wcr), ptr(w3), ptr(alpha), ptr(cvs), ctx.clampv, N, ptr(dh_out),
+                                               ptr(dx_out), ptr(dqkv), ptr(dcv), ptr(dd), ptr(drh), ptr(dbias_red), ptr(dlogit),
+                                               ptr(dcp), ptr(wpart), nblk, stream()), "fabind_inter_attn_bwd")
         dw_all = K.colsum(wpart)                                      # one launch pair for all four
         dw = [dw_all[i * H:(i + 1) * H] for i in range(4)]
         dWc = dbc = None
@@ -1419,9 +1428,14 @@ class _InterAttn(torch.autograd.Function):
 INTER_BWD_BLOCKS = int(os.environ.get("FABIND_INTER_BWD_BLOCKS", "1024"))
 
 
-def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None, Wc=None, bc=None):
+INTER_ATTN_INPLACE = os.environ.get("FABIND_INTER_ATTN_INPLACE", "1") == "1"
+
+
+def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None, Wc=None, bc=None, own_h=False):
     """s_ext [E] (optional): per-edge scalar added to the coordinate-MLP value inside the kernel (FABind+ evaluates its
-    LN-MLP coord_mlp outside); differentiable.  cv=None with (Wc, bc): cv = Linear(qkv[:, 2H:]) is evaluated here."""
+    LN-MLP coord_mlp outside); differentiable.  cv=None with (Wc, bc): cv = Linear(qkv[:, 2H:]) is evaluated here.
+    own_h: the caller hands h over (a fresh intermediate nobody reads afterwards): a no-grad pass then updates it in place -- only the
+    rows with inter edges are rewritten, and the bf16 operand copy that travels with h gets the same rows."""
     assert (cv is None) != (Wc is None), "inter_attn: pass either cv or its Linear (Wc, bc)"
     w16 = _cfg.get_precision() == "bf16" and h.is_contiguous()
     if _needs_grad(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, s_ext, Wc, bc):
@@ -1431,9 +1445,16 @@ def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, c
         return _attach_b16(h_out, holder[0] if holder else None), x_out, alpha
     if cv is None:
         cv = linear(qkv[:, 2 * H:], Wc, bc)
+    deal = getattr(g, "int_deal", None)
+    if own_h and INTER_ATTN_INPLACE and deal is not None and K.INTER_ATTN_ROWS and h.is_contiguous() and h.dtype == torch.float32 and not h.requires_grad:
+        c = getattr(h, "_fab_b16", None)
+        h16 = (c[1] if (c is not None and c[0] == h._version and c[1].is_contiguous()) else h.to(torch.bfloat16)) if w16 else None
+        h_out, x_out, alpha, _ = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx, bias_part,
+                                                  w_rk, w_rv, wcr, w3, clampv, s_ext, h16, deal=deal, inplace=True)
+        return _attach_b16(h_out, h16), x_out, alpha      # (raw writes do not bump the version counter: the copy stays attached, and is current)
     h16 = torch.empty((h.shape[0], H), dtype=torch.bfloat16, device=h.device) if w16 else None
     h_out, x_out, alpha, _ = K.inter_attn_fwd(qkv, cv, H, h, x, d, rhohat, g.rp_int, g.col_int, g.red_idx, bias_part,
-                                              w_rk, w_rv, wcr, w3, clampv, s_ext, h16)
+                                              w_rk, w_rv, wcr, w3, clampv, s_ext, h16, deal=deal)
     return _attach_b16(h_out, h16), x_out, alpha
 
 

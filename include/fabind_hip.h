@@ -58,7 +58,8 @@ const char* fabind_last_error(void);
  * 16 = fabind_gcl_edge_fused_train (the forward that saves M / silu'(pre2) / pre3) and FabindEdgeBwdArgs.{d2f, z3f} (the two-contraction backward).
  * 17 = round-5 retirement of knob-only kernels: fabind_gemm_set_big removed (256 x 256 GEMM tiles); fabind_gcl_edge_fused_set_variant accepts 1 only,
  *     fabind_gcl_edge_fused_bwd_set_variant 0 / 5 only, fabind_gcl_edge_fused_bwd_set_tile 64 only (their other kernels are no longer built);
- *     fabind_gcl_edge_fused_x3_train added (the split-bf16 forward that saves M / silu'(pre2) / pre3 for the two-contraction backward).
+ *     fabind_gcl_edge_fused_x3_train added (the split-bf16 forward that saves M / silu'(pre2) / pre3 for the two-contraction backward);
+ *     fabind_inter_attn_fwd_rows / fabind_inter_attn_bwd_rows added (inter-edge attention with the rows dealt by degree: heavy rows on four waves).
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 17
 int fabind_abi_version(void);
@@ -476,6 +477,17 @@ int fabind_inter_attn_fwd(const float* qkv, int ldqkv, const float* cv, int ldcv
                                                 LN-MLP evaluated outside); its gradient is the backward's dcp[] */,
                           void* h16 /* NULL, or [n_rows, H] bf16: h_out as the next contraction's operand */,
                           hipStream_t stream);
+/* The same with the rows DEALT BY DEGREE (round 5, csrc/inter_attn_rows.hip): `order` [n_rows] int32 = the rows sorted by their number of
+ * inter edges, descending (stable); order[0 .. n_heavy) are the rows with more than 8 edges -- one work-group of four waves each, a
+ * contiguous quarter of the row's edges per wave, log-sum-exp combine in wave order --, order[n_heavy .. n_act) the other rows with edges
+ * (one wave each), order[n_act .. n_rows) the rows without edges (pass-through).  Same results up to the summation order of a heavy row;
+ * deterministic.  fabind_inter_attn_bwd_rows is the adjoint on the same deal. */
+int fabind_inter_attn_fwd_rows(const float* qkv, int ldqkv, const float* cv, int ldcv, int H, const float* h, int ldh,
+                               const float* x, const float* d, const float* rhohat, const int* rowptr, const int* col,
+                               const int* red_idx, const float* bias_red, int bias_np, const float* w_rk,
+                               const float* w_rv, const float* wcr, const float* w3, float clampv, int n_rows,
+                               float* h_out, float* x_out, float* alpha, float* cvs, const float* s_ext, void* h16,
+                               const int* order, int n_heavy, int n_act, hipStream_t stream);
 
 /* LAS geometry step (models/egnn.py:433-449): x_out = x + clamp(step * sum_{(i,j): j=node} 4(|xi-xj|^2-|x0i-x0j|^2)(xi-xj)).
  * las_off[B+1]: per-complex ranges of the (complex-contiguous) LAS edge list. */
@@ -637,6 +649,12 @@ int fabind_inter_attn_bwd(const float* qkv, int ldqkv, const float* cv, int ldcv
                           const float* cvs, float clampv, int n_rows, const float* dh_out, const float* dx_out,
                           float* dqkv, float* dcv, float* dd, float* drh, float* dbias_red, float* dlogit, float* dcp,
                           float* wpart, int nblk, hipStream_t stream);
+int fabind_inter_attn_bwd_rows(const float* qkv, int ldqkv, const float* cv, int ldcv, int H, const float* d,
+                               const float* rhohat, const int* rowptr, const int* col, const int* mirror, const int* red_idx,
+                               const float* w_rk, const float* w_rv, const float* wcr, const float* w3, const float* alpha,
+                               const float* cvs, float clampv, int n_rows, const float* dh_out, const float* dx_out,
+                               float* dqkv, float* dcv, float* dd, float* drh, float* dbias_red, float* dlogit, float* dcp,
+                               float* wpart, int nblk, const int* order, int n_heavy, int n_act, hipStream_t stream);
 int fabind_las_step_bwd(const float* x, const float* x0, const float* xo, const int* las_i, const int* las_j,
                         const int* las_off, const int* node_off, const int* c_cnt, int B, int max_n, float step,
                         float clampv, const float* dout, float* dx, hipStream_t stream);

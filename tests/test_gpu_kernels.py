@@ -1389,3 +1389,60 @@ def test_layout_ranges_is_a_lower_bound_per_complex():
         got = lay.ranges(idx)
         want = lay.ranges(idx.long())                     # int64: the torch path
         assert got.dtype == torch.int32 and torch.equal(got, want), (keep, got, want)
+
+
+@pytest.mark.parametrize("H", [64, 256, 512])
+def test_inter_attn_rows_dealt_by_degree_match_one_wave_per_row(H, monkeypatch):
+    """csrc/inter_attn_rows.hip (round 5): the inter-edge attention (egnn.py:186-252) with heavy rows split over four waves + log-sum-exp
+    combine, light rows one wave each, empty rows pass-through -- against the one-wave-per-row kernels (attn.hip / bwd.hip, themselves
+    pinned to the reference by the stack tests) on the same operands: forward outputs, every gradient of ops.inter_attn, bit-identical
+    repeats.  A compact complex (ligand atoms with > 64 edges: several 64-edge batches per quarter) next to an ordinary one and a third
+    without any inter edge."""
+    from fabind_amd import engine, kernels as K, ops, synthetic
+    dev = _dev()
+    engine.set_precision("fp32")
+    inp = synthetic.make_stack_batch([(170, 9), (230, 24), (60, 7)], 32, seed=21, snap=False)
+    pr = (inp["segment_id"] > 0.5) & ~inp["is_global"]
+    lig = (inp["segment_id"] < 0.5) & ~inp["is_global"]
+    g0 = torch.Generator().manual_seed(5)
+    sel_l, sel_p = lig & (inp["batch_id"] == 0), pr & (inp["batch_id"] == 0)
+    centre = inp["X"][sel_l].mean(0, keepdim=True)
+    inp["X"][sel_l] = centre + 0.3 * (torch.rand(int(sel_l.sum()), 1, 3, generator=g0) - 0.5)
+    inp["X"][sel_p] = centre + 1.3 * (torch.rand(int(sel_p.sum()), 1, 3, generator=g0) - 0.5) * 2 * 0.75
+    inp["X"][lig & (inp["batch_id"] == 2)] += 50.0                       # complex 2: the ligand is far away, no inter edge
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    lay = engine.Layout(t["batch_id"], t["segment_id"])
+    br, bc_ = t["compound_edge_index"][0].to(torch.int32), t["compound_edge_index"][1].to(torch.int32)
+    g = engine.Graph(lay, t["X"][:, 0].contiguous(), br, bc_, lay.ranges(br), 1.6, 2.0)
+    order, n_heavy, n_act = g.int_deal
+    deg = (g.rp_int[1:] - g.rp_int[:-1]).cpu()
+    assert n_heavy > 0 and n_act > n_heavy and n_act < lay.N and int(deg.max()) > 128
+    assert int((deg > 0).sum()) == n_act and int((deg > K.INTER_ATTN_HEAVY).sum()) == n_heavy
+    od = deg[order.cpu().long()]
+    assert bool((od[:-1] >= od[1:]).all()) and sorted(order.cpu().tolist()) == list(range(lay.N))
+    N, E = lay.N, g.col_int.shape[0]
+    gen = torch.Generator().manual_seed(H)
+    rnd = lambda *sh: torch.randn(*sh, generator=gen).to(dev)
+    qkv0, h0, x0 = rnd(N, 3 * H) * 0.3, rnd(N, H), t["X"][:, 0].contiguous().clone()
+    Wc0, bc0 = rnd(H, H) / H ** 0.5, rnd(H) * 0.1
+    w_rk0, w_rv0, wcr0, w30 = rnd(H) * 0.3, rnd(H) * 0.3, rnd(H) * 0.3, rnd(H) * 0.05
+    bias0 = rnd(E // 2, 4) * 0.5
+    co_h, co_x = rnd(N, H), rnd(N, 3)
+
+    def run(rows):
+        monkeypatch.setattr(K, "INTER_ATTN_ROWS", rows)
+        leaf = lambda v: v.clone().requires_grad_(True)
+        qkv, h, x, Wc, bc, w_rk, w_rv, w3, bias = map(leaf, (qkv0, h0, x0, Wc0, bc0, w_rk0, w_rv0, w30, bias0))
+        wcr = Wc @ w_rv
+        d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay, g.int_by_col)
+        ho, xo, al = ops.inter_attn(qkv, None, H, h, x, d, rhohat, g, bias, w_rk, w_rv, wcr, w3, 2.0, Wc=Wc, bc=bc)
+        ((ho * co_h).sum() + (xo * co_x).sum()).backward()
+        return [ho.detach(), xo.detach(), al.detach()] + [v.grad for v in (qkv, h, x, Wc, bc, w_rk, w_rv, w3, bias)]
+
+    new, new2, old = run(True), run(True), run(False)
+    names = ("h_out", "x_out", "alpha", "dqkv", "dh", "dx", "dWc", "dbc", "dw_rk", "dw_rv", "dw3", "dbias")
+    for nm, a_, b_, c_ in zip(names, new, new2, old):
+        assert torch.equal(a_, b_), nm                                   # deterministic
+        err = float((a_ - c_).abs().max()) / max(1e-6, float(c_.abs().max()))
+        assert err <= 2e-5, (nm, err)
+    assert float(new[2].sum()) > 0 and abs(float(new[2].sum()) - n_act) <= 1e-3 * n_act      # softmax rows sum to one
