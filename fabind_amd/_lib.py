@@ -38,8 +38,7 @@ class PairUpdateArgs(ctypes.Structure):
     """Mirror of FabindPairUpdateArgs (include/fabind_hip.h)."""
     _fields_ = [(n, _vp) for n in ("T", "p_node", "c_node", "z_in", "z_out", "Wop", "bo", "ln_w", "ln_b", "W1p", "b1", "W2p", "b2",
                                   "Wbp", "bb", "bias_out")] + \
-               [(n, _i) for n in ("ldt", "b_off", "n_pairs")] + [("eps", _f), ("p_drop", _f), ("seed", ctypes.c_uint)] + \
-               [(n, _vp) for n in ("save_z1", "save_y", "save_t")]
+               [(n, _i) for n in ("ldt", "b_off", "n_pairs")] + [("eps", _f), ("p_drop", _f), ("seed", ctypes.c_uint)]
 
 
 class TnJob(ctypes.Structure):

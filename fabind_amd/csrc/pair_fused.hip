@@ -11,13 +11,6 @@
 // from L2 straight into MFMA B fragments (pre-packed in fragment order), one wave owns 64 output columns.  HBM traffic
 // per pair: H bf16 in + H bf16 out + 64 B of biases, instead of the seven [pairs, H] round trips of the separate
 // Hadamard / GEMM / LayerNorm / GEMM / GEMM / GEMM launches.  Two work-groups per CU (72 KiB LDS, <= 128 VGPRs).
-//
-// SAVE (round 5: the TRAINING forward, FabindPairUpdateArgs.save_z1 / save_y / save_t): the same kernel also copies out of the LDS tile,
-// as row-major bf16 [n_pairs, H], what the adjoint chain reads -- z1 (the LayerNorm's input: its adjoint kernel recomputes the row
-// statistics from it), y (the first Linear's operand = the operand of its weight gradient) and t (the hidden activation after ReLU and
-// dropout: operand of the second weight gradient, and its zeros ARE the mask of the hidden layer's adjoint; z' does the same for the
-// output layer).  The five forward launches of the autograd chain (Hadamard, K = 64 GEMM + residual, LayerNorm, two GEMMs: seven passes
-// over [n_pairs, H]) become this one (one read, four writes).
 #include "common.h"
 #include "fabind_hip.h"
 #include "fused_common.h"
@@ -30,7 +23,7 @@ __device__ __forceinline__ float pf_rowsum16(float t) {
     return t;
 }
 
-template <int H, bool SAVE>
+template <int H>
 __global__ __launch_bounds__(H, 4) void pair_update_fused_kernel(const FabindPairUpdateArgs p) {
     constexpr int NW = H / 64;                       // waves; wave w owns output columns [64w, 64w+64)
     constexpr int CH = H / 8;                        // 16-byte chunks per row
@@ -106,7 +99,6 @@ __global__ __launch_bounds__(H, 4) void pair_update_fused_kernel(const FabindPai
                     acc[0][j][r] = v;
                     s1[r] += v;
                     s2[r] += v * v;
-                    if constexpr (SAVE) sX[rw * H + (((colj >> 3) ^ (rw & 7)) * 8) + (colj & 7)] = f32_to_bf16(v);      // z1 takes z's place (same lane, same element)
                 }
             }
             // fp32 sums of x and x^2 over the H columns: the 16 lanes of a fragment row here, the NW waves through LDS
@@ -118,7 +110,6 @@ __global__ __launch_bounds__(H, 4) void pair_update_fused_kernel(const FabindPai
             PF_ROTI(acc)
         }
         __syncthreads();
-        if constexpr (SAVE) fe_tile_store_stream<H>(sX, (bf16_t*)p.save_z1, e0, ne, tid);     // (read before the barrier below lets y overwrite the tile)
         float2* sMR = (float2*)(sStat + 2 * NW * FE_BM);          // [64] (mean, rstd) per pair row
         if (tid < FE_BM) {
             float t = 0.f, u = 0.f;
@@ -151,7 +142,6 @@ __global__ __launch_bounds__(H, 4) void pair_update_fused_kernel(const FabindPai
     }
 #undef PF_ROTI
     __syncthreads();
-    if constexpr (SAVE) fe_tile_store_stream<H>(sX, (bf16_t*)p.save_y, e0, ne, tid);
 
     // ---- phases 1, 2: the two Linear + ReLU (+ dropout) of the transition, tile -> tile through LDS
 #pragma unroll 1
@@ -182,7 +172,6 @@ __global__ __launch_bounds__(H, 4) void pair_update_fused_kernel(const FabindPai
             PF_ROT4(bj)
         }
         __syncthreads();
-        if constexpr (SAVE) { if (layer == 0) fe_tile_store_stream<H>(sX, (bf16_t*)p.save_t, e0, ne, tid); }
     }
 
     // ---- phase 3: z' -> HBM; the next layer's 16 bias columns by waves 0..3 (16 pair rows each, full K)
@@ -212,21 +201,16 @@ extern "C" int fabind_pair_update_fused(const FabindPairUpdateArgs* a, int H, hi
     FB_REQUIRE(a->p_drop >= 0.f && a->p_drop < 1.f, "fabind_pair_update_fused: p_drop in [0, 1)");
     FB_REQUIRE(a->ldt % 4 == 0 && a->b_off % 4 == 0, "fabind_pair_update_fused: ldt, b_off must be multiples of 4");
     FB_REQUIRE(a->Wbp == nullptr || (a->bb != nullptr && a->bias_out != nullptr), "fabind_pair_update_fused: bb / bias_out");
-    const bool save = a->save_z1 != nullptr || a->save_y != nullptr || a->save_t != nullptr;
-    FB_REQUIRE(!save || (a->save_z1 != nullptr && a->save_y != nullptr && a->save_t != nullptr), "fabind_pair_update_fused: save_z1, save_y, save_t come together");
-    FB_REQUIRE(!save || (a->z_out != a->z_in), "fabind_pair_update_fused: the saving forward does not run in place");
     const dim3 grid((a->n_pairs + FE_BM - 1) / FE_BM);
     const size_t lds = (size_t)FE_BM * H * 2 + FE_BM * 32 * 2 + (size_t)2 * (H / 64) * FE_BM * sizeof(float) + FE_BM * 2 * sizeof(float);
-#define PF_LAUNCH_(HH, SS)                                                                                         \
+#define PF_LAUNCH(HH)                                                                                              \
     do {                                                                                                           \
         static bool set_ = false;                                                                                  \
-        if (!set_) { (void)hipFuncSetAttribute((const void*)pair_update_fused_kernel<HH, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
-        hipLaunchKernelGGL((pair_update_fused_kernel<HH, SS>), grid, dim3(HH), lds, stream, *a);                   \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)pair_update_fused_kernel<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        hipLaunchKernelGGL((pair_update_fused_kernel<HH>), grid, dim3(HH), lds, stream, *a);                       \
     } while (0)
-#define PF_LAUNCH(HH) do { if (save) PF_LAUNCH_(HH, true); else PF_LAUNCH_(HH, false); } while (0)
     if (H == 512) PF_LAUNCH(512); else if (H == 256) PF_LAUNCH(256); else if (H == 128) PF_LAUNCH(128); else PF_LAUNCH(64);
 #undef PF_LAUNCH
-#undef PF_LAUNCH_
     FB_CHECK_LAUNCH();
     return 0;
 }

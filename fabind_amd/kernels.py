@@ -640,14 +640,12 @@ def row_stats(x, eps):
 
 
 def pair_update_fused(T, b_off, p_node, c_node, z, Wop, bo, ln_w, ln_b, eps, W1p, b1, W2p, b2, Wbp=None, bb=None, p_drop=0.0,
-                      seed=0, save=False):
+                      seed=0):
     """FABind+ pair update for a ragged pair list (csrc/pair_fused.hip): z [pairs,H] bf16 -> (z' bf16, bias' [pairs,16] fp32
-    or None).  Weights are pack_frag()-ed bf16; T = fp32 [nodes, ld] holding a32 at columns 0..31 and b32 at b_off..b_off+31.
-    save (training forward): -> (z', bias', (z1, y, t)): the three bf16 [pairs, H] tensors the adjoint chain reads."""
+    or None).  Weights are pack_frag()-ed bf16; T = fp32 [nodes, ld] holding a32 at columns 0..31 and b32 at b_off..b_off+31."""
     n, H = z.shape
     assert z.dtype == torch.bfloat16 and z.is_contiguous() and T.dtype == torch.float32
     z_out = torch.empty_like(z)
-    saved = tuple(torch.empty_like(z) for _ in range(3)) if (save and n > 0) else None
     bias_out = torch.empty((max(n, 1), 16), dtype=torch.float32, device=z.device) if Wbp is not None else None
     a = _lib.PairUpdateArgs()
     for name, t in (("T", T), ("p_node", p_node), ("c_node", c_node), ("z_in", z), ("z_out", z_out), ("Wop", Wop), ("bo", bo),
@@ -656,14 +654,9 @@ def pair_update_fused(T, b_off, p_node, c_node, z, Wop, bo, ln_w, ln_b, eps, W1p
         setattr(a, name, ptr(t))
     a.ldt, a.b_off, a.n_pairs = _ld(T), int(b_off), n
     a.eps, a.p_drop, a.seed = float(eps), float(p_drop), int(seed) & 0xFFFFFFFF
-    if saved is not None:
-        a.save_z1, a.save_y, a.save_t = ptr(saved[0]), ptr(saved[1]), ptr(saved[2])
-    _profiled("pair_update_fused_kernel<%d> pairs=%d%s (Hadamard + LN + 2 chained H x H contractions + 16 biases)" % (H, n, " saving" if saved is not None else ""),
+    _profiled("pair_update_fused_kernel<%d> pairs=%d (Hadamard + LN + 2 chained H x H contractions + 16 biases)" % (H, n),
               2.0 * n * H * (2 * H + 32 + 16),
-              lambda: check(_lib.load().fabind_pair_update_fused(ctypes.byref(a), H, stream()), "fabind_pair_update_fused"),
-              n * H * 2.0 * (5 if saved is not None else 2))
-    if save:
-        return z_out, (bias_out[:n] if bias_out is not None else None), saved
+              lambda: check(_lib.load().fabind_pair_update_fused(ctypes.byref(a), H, stream()), "fabind_pair_update_fused"))
     return z_out, (bias_out[:n] if bias_out is not None else None)
 
 

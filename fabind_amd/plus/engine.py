@@ -317,25 +317,19 @@ class _LnRows(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        from .._lib import check, dt_code, load, ptr, stream
         x, w = ctx.saved_tensors
-        dx, dw, db = _ln_rows_bwd(x, w, dy)
-        return dx, dw, db, None, None
-
-
-def _ln_rows_bwd(x, w, dy, eps=1e-5):
-    """Adjoint of the row LayerNorm y = LN(x) w + b (csrc/norm.hip: the statistics are recomputed from x) -> (dx as x.dtype, dw, db)."""
-    from .._lib import check, dt_code, load, ptr, stream
-    R, C = x.shape
-    dy = dy if dy.stride(-1) == 1 else dy.contiguous()
-    C8 = (C + 7) // 8 * 8                               # rows padded to 8 elements: the adjoint kernel's 16-byte accesses (csrc/norm.hip)
-    dx = torch.empty((R, C8), dtype=x.dtype, device=x.device)[:, :C]
-    nblk = max(1, min((R + 3) // 4, 2048))              # work-groups of four waves, rows strided over them: 8 per CU
-    dwp = torch.empty((nblk, C), dtype=torch.float32, device=x.device)
-    dbp = torch.empty((nblk, C), dtype=torch.float32, device=x.device)
-    check(load().fabind_layernorm_rows_bwd(ptr(x), dt_code(x.dtype), x.stride(0), ptr(w), ptr(dy), dt_code(dy.dtype),
-                                           dy.stride(0), float(eps), R, C, ptr(dx), dt_code(dx.dtype), C8, ptr(dwp), ptr(dbp),
-                                           nblk, stream()), "fabind_layernorm_rows_bwd")
-    return dx, K.colsum(dwp), K.colsum(dbp)
+        R, C = x.shape
+        dy = dy if dy.stride(-1) == 1 else dy.contiguous()
+        C8 = (C + 7) // 8 * 8                               # rows padded to 8 elements: the adjoint kernel's 16-byte accesses (csrc/norm.hip)
+        dx = torch.empty((R, C8), dtype=x.dtype, device=x.device)[:, :C]
+        nblk = max(1, min((R + 3) // 4, 2048))              # work-groups of four waves, rows strided over them: 8 per CU
+        dwp = torch.empty((nblk, C), dtype=torch.float32, device=x.device)
+        dbp = torch.empty((nblk, C), dtype=torch.float32, device=x.device)
+        check(load().fabind_layernorm_rows_bwd(ptr(x), dt_code(x.dtype), x.stride(0), ptr(w), ptr(dy), dt_code(dy.dtype),
+                                               dy.stride(0), 1e-5, R, C, ptr(dx), dt_code(dx.dtype), C8, ptr(dwp), ptr(dbp),
+                                               nblk, stream()), "fabind_layernorm_rows_bwd")
+        return dx, K.colsum(dwp), K.colsum(dbp), None, None
 
 
 def ln_rows(x, w, b, out_dtype, pad_to=None):
@@ -382,33 +376,29 @@ class _PairHad1(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dhd):
+        from .._lib import check, dt_code, load, ptr, stream
         T, p_node, c_node = ctx.saved_tensors
-        return _pair_had_bwd(T, ctx.Hh, p_node, c_node, ctx.lay, dhd), None, None, None, None, None
-
-
-def _pair_had_bwd(T, Hh, p_node, c_node, lay, dhd):
-    """Adjoint of hd[e] = T[p_node[e], :Hh] * T[c_node[e], Hh:2Hh] -> dT (like T)."""
-    from .._lib import check, dt_code, load, ptr, stream
-    dhd = dhd.contiguous()
-    dT = torch.zeros_like(T)
-    if (lay is not None and PAIRHAD_GRID and T.dtype == torch.float32 and p_node.shape[0] == lay.n_pairs and Hh % 4 == 0
-            and (Hh >= 256 or 256 % Hh == 0) and T.stride(0) % 4 == 0 and dhd.stride(0) % 4 == 0):
-        # the list is the batch's full protein x ligand grid: deterministic row walk instead of float atomics (csrc/bwd.hip)
-        nb = getattr(lay, "_node_b", None)
-        if nb is None:
-            nb = lay._node_b = torch.repeat_interleave(torch.arange(lay.B, dtype=torch.int32, device=T.device),
-                                                       (lay.node_off[1:] - lay.node_off[:-1]).long(), output_size=lay.N)
-        check(load().fabind_pair_hadamard_bwd_grid(ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(T), T.stride(0), Hh,
-                                                   ptr(lay.node_off), ptr(lay.c_cnt), ptr(nb), ptr(lay.desc_p), lay.N, ptr(dT),
-                                                   dT.stride(0), stream()), "fabind_pair_hadamard_bwd_grid")
-        return dT
-    a0, b0 = T[:, :Hh], T[:, Hh:2 * Hh]
-    da, db = dT[:, :Hh], dT[:, Hh:2 * Hh]
-    check(load().fabind_pair_hadamard_bwd(ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(a0), ptr(b0), T.stride(0), Hh,
-                                          ptr(a0), ptr(b0), T.stride(0), 0, ptr(p_node), ptr(c_node), p_node.shape[0], ptr(da),
-                                          ptr(db), dT.stride(0), ptr(da), ptr(db), dT.stride(0), stream()),
-          "fabind_pair_hadamard_bwd")
-    return dT
+        Hh, lay = ctx.Hh, ctx.lay
+        dhd = dhd.contiguous()
+        dT = torch.zeros_like(T)
+        if (lay is not None and PAIRHAD_GRID and T.dtype == torch.float32 and p_node.shape[0] == lay.n_pairs and Hh % 4 == 0
+                and (Hh >= 256 or 256 % Hh == 0) and T.stride(0) % 4 == 0 and dhd.stride(0) % 4 == 0):
+            # the list is the batch's full protein x ligand grid: deterministic row walk instead of float atomics (csrc/bwd.hip)
+            nb = getattr(lay, "_node_b", None)
+            if nb is None:
+                nb = lay._node_b = torch.repeat_interleave(torch.arange(lay.B, dtype=torch.int32, device=T.device),
+                                                           (lay.node_off[1:] - lay.node_off[:-1]).long(), output_size=lay.N)
+            check(load().fabind_pair_hadamard_bwd_grid(ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(T), T.stride(0), Hh,
+                                                       ptr(lay.node_off), ptr(lay.c_cnt), ptr(nb), ptr(lay.desc_p), lay.N, ptr(dT),
+                                                       dT.stride(0), stream()), "fabind_pair_hadamard_bwd_grid")
+            return dT, None, None, None, None, None
+        a0, b0 = T[:, :Hh], T[:, Hh:2 * Hh]
+        da, db = dT[:, :Hh], dT[:, Hh:2 * Hh]
+        check(load().fabind_pair_hadamard_bwd(ptr(dhd), dt_code(dhd.dtype), dhd.stride(0), ptr(a0), ptr(b0), T.stride(0), Hh,
+                                              ptr(a0), ptr(b0), T.stride(0), 0, ptr(p_node), ptr(c_node), p_node.shape[0], ptr(da),
+                                              ptr(db), dT.stride(0), ptr(da), ptr(db), dT.stride(0), stream()),
+              "fabind_pair_hadamard_bwd")
+        return dT, None, None, None, None, None
 
 
 PAIRHAD_GRID = os.environ.get("FABIND_PAIRHAD_GRID", "1") == "1"     # adjoint of the all-pairs Hadamard as a row walk (no float atomics)
@@ -419,52 +409,6 @@ def pair_had(T, Hh, p_node, c_node, out_dtype, lay=None):
     if ops.needs_grad(T):
         return _PairHad1.apply(T, Hh, p_node, c_node, out_dtype, lay)
     return _pair_hadamard_call(T, Hh, p_node, c_node, out_dtype)
-
-
-class _PairUpdateTrain(torch.autograd.Function):
-    """The pair update of one layer under autograd with the FORWARD as one kernel (csrc/pair_fused.hip, SAVE form; VERDICT r4 next 4, first
-    half): z' = drop(relu(drop(relu(LN(z + (a32 * b32) Wo^T + bo) W1^T + b1)) W2^T + b2)) (cross_att.py:42-44, model_utils.py:32-52).  The
-    kernel leaves z1 (the LayerNorm's input), y (its output) and t (the hidden activation) as bf16 [pairs, H]; the adjoint below is the
-    chain the separate autograd nodes ran -- ReLU / dropout masks from the zeros of z' and t, two weight-gradient contractions, two
-    input-gradient GEMMs (the hidden mask applied in the epilogue), the LayerNorm adjoint kernel on z1, the K = 64 tail, the Hadamard
-    adjoint -- on those tensors: the forward's five launches / seven [pairs, H] passes are one launch / five passes, the backward is
-    launch for launch what it was."""
-
-    @staticmethod
-    def forward(ctx, z, ab32, W_o32, b_o32, ln_w, ln_b, W1, b1, W2, b2, p_node, c_node, lay, pd, seed, eps):
-        with torch.no_grad():
-            Wop = K.pack_frag(W_o32[:, :32].contiguous())
-            W1p, W2p = K.pack_frag(W1), K.pack_frag(W2)
-            z_out, _, saved = K.pair_update_fused(ab32, 64, p_node, c_node, z.contiguous(), Wop, b_o32.float().contiguous(), ln_w.float().contiguous(),
-                                                  ln_b.float().contiguous(), eps, W1p, b1.float().contiguous(), W2p, b2.float().contiguous(),
-                                                  None, None, pd, seed, save=True)
-        thr = int(pd * 65536.0 + 0.5)
-        ctx.scale, ctx.lay, ctx.eps = 1.0 / (1.0 - thr / 65536.0), lay, eps
-        ctx.sink_z = ops._sink_of(z)
-        ctx.save_for_backward(z_out, saved[0], saved[1], saved[2], ab32, W_o32, ln_w, W1, W2, p_node, c_node)
-        return z_out
-
-    @staticmethod
-    def backward(ctx, dz_out):
-        z_out, z1, y, t, ab32, W_o32, ln_w, W1, W2, p_node, c_node = ctx.saved_tensors
-        bf = torch.bfloat16
-        s = ctx.scale
-        dpre2 = ops._mul_dact(dz_out.contiguous(), z_out, K.ACT_RELU, bf, s)                     # [z' > 0] / (1 - p)
-        dW2, db2 = ops._weight_grad(dpre2, t, K.ACT_NONE, None, W2.dtype, want_db=True, W=W2)
-        dpre1, _ = K.gemm(dpre2, ops._wt(W2), aux=t, dact=K.ACT_RELU, alpha=s, out_dtype=bf)      # (dpre2 W2) [t > 0] / (1 - p)
-        dW1, db1 = ops._weight_grad(dpre1, y, K.ACT_NONE, None, W1.dtype, want_db=True, W=W1)
-        dy, _ = K.gemm(dpre1, ops._wt(W1), out_dtype=bf)
-        dz1, dlnw, dlnb = _ln_rows_bwd(z1, ln_w, dy, ctx.eps)
-        dz1 = dz1.contiguous()
-        hd = _pair_hadamard_call(ab32, 64, p_node, c_node, bf)                                   # [pairs, 64] (a32 * b32 | 0)
-        dWo, dbo = ops._weight_grad(dz1, hd, K.ACT_NONE, None, W_o32.dtype, want_db=True, W=W_o32)
-        dhd, _ = K.gemm(dz1, ops._wt(W_o32), out_dtype=bf)
-        dab = _pair_had_bwd(ab32, 64, p_node, c_node, ctx.lay, dhd)
-        dz = dz1 if ctx.sink_z is None else ctx.sink_z.deposit(dz1)                              # the residual branch z1 = z + ...
-        return dz, dab, dWo, dbo, dlnw, dlnb, dW1, db1, dW2, db2, None, None, None, None, None, None
-
-
-FUSE_PAIR_TRAIN = os.environ.get("FABIND_PLUS_FUSE_PAIR_TRAIN", "1") == "1"    # 0: the pair update under autograd as separate nodes (rounds 1-4; A/B)
 
 
 class _InterView:
@@ -622,18 +566,6 @@ def cross_part(p, h, z, lay, pairs, pd=0.0, bias=None, p_next=None):
         z, bias_next = K.pair_update_fused(ab32, 64, pairs.p_node, pairs.c_node, z.contiguous(), pf["Wop"], pf["bo"], pf["ln_w"],
                                            pf["ln_b"], pf["eps"], pf["W1p"], pf["b1"], pf["W2p"], pf["b2"],
                                            nf["Wbp"] if nf else None, nf["bb"] if nf else None, pd, seed)
-    elif (FUSE_PAIR_TRAIN and FUSE_PAIR and z.dtype == torch.bfloat16 and ab32.dtype == torch.float32 and z.shape[1] in (64, 128, 256, 512)
-          and p["tr_z"]["ln_w"] is not None and p["tr_z"]["W1"].dtype == torch.bfloat16 and p["tr_z"]["W1"].shape == (z.shape[1], z.shape[1])
-          and p["tr_z"]["W2"].shape == (z.shape[1], z.shape[1]) and p["tr_z"]["b1"] is not None and p["tr_z"]["b2"] is not None
-          and z.shape[0] > 0 and ops.needs_grad(z, ab32, p["W_o32"], p["tr_z"]["W1"], p["tr_z"]["W2"])):
-        # training: the forward as ONE kernel that also leaves what the adjoint chain reads (_PairUpdateTrain)
-        tz = p["tr_z"]
-        K.tn_hook(p["W_o32"], p["b_o32"], tz["W1"], tz["b1"], tz["W2"], tz["b2"])
-        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if pd > 0.0 else 0
-        z = _PairUpdateTrain.apply(z, ab32, p["W_o32"], p["b_o32"], tz["ln_w"], tz["ln_b"], tz["W1"], tz["b1"], tz["W2"], tz["b2"],
-                                   pairs.p_node, pairs.c_node, lay, pd, seed, 1e-5)
-        if Z_SINK:
-            z = ops.shared_grad(z)
     else:
         hd32 = pair_had(ab32, 64, pairs.p_node, pairs.c_node, ad, lay)                               # [pairs, 64]
         z1 = ops.linear(hd32, p["W_o32"], p["b_o32"], residual=z, out_dtype=ad)      # (a bf16 z is added as it is: FabindGemmArgs.r_dtype)

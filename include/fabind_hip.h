@@ -59,8 +59,7 @@ const char* fabind_last_error(void);
  * 17 = round-5 retirement of knob-only kernels: fabind_gemm_set_big removed (256 x 256 GEMM tiles); fabind_gcl_edge_fused_set_variant accepts 1 only,
  *     fabind_gcl_edge_fused_bwd_set_variant 0 / 5 only, fabind_gcl_edge_fused_bwd_set_tile 64 only (their other kernels are no longer built);
  *     fabind_gcl_edge_fused_x3_train added (the split-bf16 forward that saves M / silu'(pre2) / pre3 for the two-contraction backward);
- *     fabind_inter_attn_fwd_rows / fabind_inter_attn_bwd_rows added (inter-edge attention with the rows dealt by degree: heavy rows on four waves);
- *     FabindPairUpdateArgs grew {save_z1, save_y, save_t} (FABind+ pair update: the training forward).
+ *     fabind_inter_attn_fwd_rows / fabind_inter_attn_bwd_rows added (inter-edge attention with the rows dealt by degree: heavy rows on four waves).
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 17
 int fabind_abi_version(void);
@@ -359,10 +358,6 @@ typedef struct FabindPairUpdateArgs {
     int ldt, b_off, n_pairs;
     float eps, p_drop;
     unsigned seed;
-    /* ABI 17: all NULL (inference), or three bf16 [n_pairs, H] row-major buffers the TRAINING forward leaves for the adjoint chain:
-     * z1 = z + (a32 * b32) Wo^T + bo (the LayerNorm's input), y = LayerNorm(z1) (the first Linear's operand), t = the hidden activation
-     * after ReLU and dropout (the second Linear's operand; its zeros are the hidden layer's mask).  Not in place (z_out != z_in). */
-    void* save_z1; void* save_y; void* save_t;
 } FabindPairUpdateArgs;
 int fabind_pair_update_fused(const FabindPairUpdateArgs* args, int H, hipStream_t stream);
 
