@@ -4,6 +4,7 @@ import os
 _PRECISION = {"mode": "bf16", "x3_backward": "bf16" if (os.environ.get("FABIND_X3_WGRAD", "bf16") == "bf16" and
                                                           os.environ.get("FABIND_X3_PAIRBIAS_BWD", "bf16") == "bf16") else "exact"}
 MODES = ("fp32", "bf16", "bf16x3")
+_PRECISION["split_sites"] = int(os.environ.get("FABIND_SPLIT_SITES", "1"))
 
 
 def set_precision(mode):
@@ -21,6 +22,25 @@ def set_precision(mode):
     backward stays the bf16 recompute kernel: there is no split form of it); bench.py reports both (`gate_mode`, `gate_mode_exact_bwd`)."""
     assert mode in MODES
     _PRECISION["mode"] = mode
+
+
+def set_split_sites(level):
+    """'bf16' mode only: which node-level GEMM sites run their FORWARD contraction in split precision (three bf16 MFMAs per product term on
+    the fp32 activation and the fp32 master weight, like 'bf16x3') instead of on bf16-rounded operands.  Measured at the headline shape
+    (tools/probes/precision_sites.py, precision_mixed.py; profiles/r05_precision_sites.txt): of the bf16 mode's 1.0e-4 A ligand-RMSD gap to
+    the fp32 reference, the bf16 edge pipeline carries 3.5e-6 and the bf16 attention tiles 1.3e-6; the node-level GEMM operand roundings
+    carry the rest, and three sites most of that -- the inter-edge attention's q | k | v projection (5.4e-5 alone), its coordinate-MLP
+    projection cv = Wc v (5.7e-5) and the stack's input Linear (3.2e-5).
+      0: none (rounds 1-4: every GEMM on bf16 operands);
+      1 (default): those three sites (9 of the ~50 node-level GEMMs of a pass): gap 3.3e-5 / 5.7e-5 / 2.4e-4 A at n_iter 1 / 2 / 8 instead of
+         1.0e-4 / 1.8e-4 / 6.3e-4 -- the 1e-4 A gate met with margin for one and two passes.
+    Backward passes are unchanged (bf16 operands; the gradients of a bf16-mode step are bf16-grade either way)."""
+    assert level in (0, 1)
+    _PRECISION["split_sites"] = int(level)
+
+
+def split_sites():
+    return _PRECISION["split_sites"] if _PRECISION["mode"] == "bf16" else 0
 
 
 def set_x3_backward(kind):

@@ -26,7 +26,7 @@ import torch
 from . import kernels as K
 from . import ops
 
-from .config import fp32_storage, get_precision, set_precision  # noqa: F401
+from .config import fp32_storage, get_precision, set_precision, split_sites  # noqa: F401
 from .param_pack import EagerPack, ParamPack
 
 
@@ -264,7 +264,7 @@ def cached_pack(model, builder):
     _LAST_PARAMS[:] = [weakref.ref(model), params]         # (the builders key their kept request plans on the same list: one module walk)
     if torch.is_grad_enabled() and any(p.requires_grad for p in params):
         return builder(model)
-    key = (get_precision(), tuple((p.data_ptr(), p._version) for p in params))
+    key = (get_precision(), split_sites(), tuple((p.data_ptr(), p._version) for p in params))
     ent = _PACK_CACHE.get(id(model))
     if ent is not None and ent[0] == key and ent[2]() is model:
         return ent[1]
@@ -423,7 +423,26 @@ def _build_stack_params(model):
         att_edge_composed(m, d)
         d["Wcomp1"], d["bcomp1"], d["u"] = Wc_l[i], bc_l[i], u_l[i]
     _edge_frags(P)
+    _split_site_masters(model, P)
     return P
+
+
+def _split_site_masters(model, P):
+    """fp32 master weights of the split-precision sites of the bf16 mode (config.set_split_sites), next to their bf16 pack entries: the
+    input Linear and, per attention layer, the q | k | v projection (interleaved kv split undone like `Wqkv`) and the coordinate MLP's first
+    Linear.  Detached: they are operands of the FORWARD contraction only, the gradients flow through the bf16 entries."""
+    if split_sites() < 1:
+        return
+    gnn = model.gnn
+    f32 = lambda w: w.detach().float().contiguous()
+    with torch.no_grad():
+        P["W_in32"] = f32(gnn.linear_in.weight)
+        for i in range(P["L"]):
+            m = getattr(gnn, "att_%d" % i)
+            Wkv = m.linear_kv.weight.detach()
+            d = P["att"][i]
+            d["Wqkv32"] = torch.cat([m.linear_q.weight.detach(), Wkv[0::2, 1:], Wkv[1::2, 1:]], 0).float().contiguous()
+            d["Wc32"] = f32(m.coord_mlp[0].weight)
 
 
 def _edge_frags(P):
@@ -605,13 +624,14 @@ def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv, pdrop=0.0, pdrop_r
     ab32 = ops.linear(h16, p["W_ab32"], p["b_ab32"])                                   # [N,128] (a32|0|b32|0)
     hd = ops.pair_hadamard(a0b0, H, ab32, 64, g.red_p, g.red_c, graph=g)               # [n_red, H+64]
     bias_part = ops.linear_rowdot(hd, p["Wcomp1"], p["bcomp1"], p["u"], act_epi=K.ACT_RELU)
-    qkv = ops.linear(h16, p["Wqkv"], p["bqkv"], want16=True)                           # [N,3H] (+ bf16 copy: V is the next operand)
+    # (split-precision site, config.set_split_sites: the fp32 rows of h and the fp32 master weight instead of their bf16 copies)
+    qkv = ops.linear(h if p.get("Wqkv32") is not None else h16, p["Wqkv"], p["bqkv"], want16=True, W32=p.get("Wqkv32"))   # [N,3H] (+ bf16 copy: V is the next operand)
     d, rhohat = ops.edge_geom(x, g.row_int, g.col_int, g.rp_int, lay, g.int_by_col)
     # cv = Linear(V) [N,H] (egnn.py:225) is evaluated inside inter_attn (its adjoint accumulates into dqkv in place)
     # (h is this function's own intermediate -- the row scatter of cross_attention made it -- and with pdrop == 0 nobody reads it after
     #  the call: a no-grad pass lets the kernel update it in place; DEBUG_CAPTURE keeps clones)
     h_new, x_new, alpha = ops.inter_attn(qkv, None, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["wcr"],
-                                         p["w3"], clampv, Wc=p["Wc"], bc=p["bc"], own_h=(pdrop == 0.0))
+                                         p["w3"], clampv, Wc=p["Wc"], bc=p["bc"], own_h=(pdrop == 0.0), Wc32=p.get("Wc32"))
     if pdrop > 0.0:
         h_new = h + _drop(h_new - h, pdrop)
     return h_new, x_new, alpha
@@ -621,7 +641,7 @@ def egnn_forward(P, h, x, lay, g, las, x_las, a0b0, pairbias, scale, step, drop=
     """MCAttEGNN.forward (egnn.py:392-466).  drop = dict of dropout probabilities (train mode) or None (eval)."""
     clampv = 10.0 / scale
     dp = drop or {}
-    h = _drop(ops.linear(h, P["W_in"], P["b_in"], want16=True), dp.get("gnn", 0.0))
+    h = _drop(ops.linear(h, P["W_in"], P["b_in"], want16=True, W32=P.get("W_in32")), dp.get("gnn", 0.0))
     cap = DEBUG_CAPTURE
     for i in range(P["L"]):
         h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv, dp.get("gcl", 0.0))

@@ -49,13 +49,14 @@ def _ld(t):
 def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=None, r_index=None,
          out=None, out_dtype=torch.float32, want_out=True, dotvec=None, aux=None, dact=ACT_NONE, alpha=1.0,
          accumulate=False, groups=None, n_groups=0, max_m=0, max_n=0, M=None, N=None, ldc=None, k_splits=1,
-         out2=None, groups_ext=False, p_drop=0.0, seed=0, out16=None, flops=None):
+         out2=None, groups_ext=False, p_drop=0.0, seed=0, out16=None, flops=None, force_x3=False):
     """C = epi(pro([A|A2]) @ W^T); see FabindGemmArgs.  Returns (C or None, dot_partials or None).  out16: bf16 tensor that
     receives a copy of an fp32 C (plain bias / residual epilogues only).
 
     `groups` (int32 [G,8] device tensor) selects the ragged-batched mode; then `out` must be given.
     flops: executed multiply-add flops of a ragged launch (bench.py's live roofline accounting; default 2 M N K, which for a
-    grouped launch is the padded bounding box, not the work)."""
+    grouped launch is the padded bounding box, not the work).
+    force_x3: fp32 A and fp32 W contracted as split bf16 whatever the precision mode (config.set_split_sites: single sites of the bf16 mode)."""
     lib = _lib.load()
     a = GemmArgs()
     K1 = A.shape[1]
@@ -97,7 +98,7 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     a.alpha = alpha
     a.p_drop, a.drop_seed = float(p_drop), int(seed) & 0xFFFFFFFF
     # 'bf16x3' mode: fp32 x fp32 contractions run as split bf16 (three bf16 MFMAs per product term) instead of the exact fp32 MFMA
-    x3 = A.dtype == torch.float32 and W.dtype == torch.float32 and _split3()
+    x3 = A.dtype == torch.float32 and W.dtype == torch.float32 and (_split3() or force_x3)
     a.split3 = 1 if x3 else 0
     if PROFILE is None:                                    # (the label costs more host time than the launch: formatted only when events are taken)
         check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm")

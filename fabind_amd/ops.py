@@ -246,7 +246,7 @@ def _want16(out_dtype, act_epi, want):
 
 class _Linear(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, W, b, x2, residual, act_epi, out_dtype, holder=None, p_drop=0.0, seed=0):
+    def forward(ctx, x, W, b, x2, residual, act_epi, out_dtype, holder=None, p_drop=0.0, seed=0, W32=None):
         assert act_epi in (K.ACT_NONE, K.ACT_RELU, K.ACT_SILU)
         # epilogue dropout under autograd: ReLU outputs only -- y = relu(pre) keep / (1 - p) is what is saved, its zeros ARE the dropped
         # positions (and the inactive units), so the adjoint is [y > 0] / (1 - p): no mask is stored or recomputed
@@ -266,7 +266,11 @@ class _Linear(torch.autograd.Function):
         if holder is not None:                        # the caller wants the epilogue to emit the bf16 operand copy of y as well
             y16 = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
             holder.append(y16)
-        K.gemm(xin, W, bias=b, A2=x2in, act_epi=act_epi, residual=residual, out=y, out2=D, out16=y16, p_drop=p_drop, seed=seed)
+        if W32 is not None:      # a split-precision site of the bf16 mode (config.set_split_sites): the forward contracts the fp32 activation with
+            #                      the fp32 master weight; what is saved -- and everything the backward does -- are the bf16 operands
+            K.gemm(x, W32, bias=b, A2=x2, act_epi=act_epi, residual=residual, out=y, out2=D, out16=y16, p_drop=p_drop, seed=seed, force_x3=True)
+        else:
+            K.gemm(xin, W, bias=b, A2=x2in, act_epi=act_epi, residual=residual, out=y, out2=D, out16=y16, p_drop=p_drop, seed=seed)
         ctx.act_epi, ctx.x_dtype = (K.ACT_SILU if relu_res else act_epi), x.dtype       # backward: stored derivative
         ctx.x2_dtype = x2.dtype if x2 is not None else None
         ctx.has_b, ctx.has_res, ctx.has_x2 = b is not None, residual is not None, x2 is not None
@@ -338,25 +342,39 @@ class _Linear(torch.autograd.Function):
             dres = dy if dy.dtype == ctx.res_dtype else dy.to(ctx.res_dtype)      # (a bf16 residual stream takes dy as it is)
         if dres is not None and ctx.sink_res is not None:
             dres = ctx.sink_res.deposit(dres)
-        return dx, dW, db, dx2, dres, None, None, None, None, None
+        return dx, dW, db, dx2, dres, None, None, None, None, None, None
+
+
+def _split_site_ok(x, W, W32, x2, act_pro, out_dtype, p_drop):
+    """May this Linear run as a split-precision site?  (bf16 mode, fp32 activation rows and fp32 master weight of W's shape, plain epilogue.)"""
+    return (W32 is not None and _cfg.get_precision() == "bf16" and x.dtype == torch.float32 and W32.dtype == torch.float32
+            and tuple(W32.shape) == tuple(W.shape) and W32.stride(-1) == 1 and (x2 is None or x2.dtype == torch.float32)
+            and act_pro == K.ACT_NONE and out_dtype == torch.float32 and p_drop == 0.0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
 
 
 def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, x2=None, out_dtype=torch.float32,
-           p_drop=0.0, want16=False):
+           p_drop=0.0, want16=False, W32=None):
     """p_drop > 0 (no-grad paths only): dropout on act(x W^T + b) inside the GEMM epilogue, before the residual; the mask is
-    a counter-based hash keyed by a seed drawn from torch's CPU generator."""
+    a counter-based hash keyed by a seed drawn from torch's CPU generator.
+    W32 (bf16 mode): the fp32 master of W -- the forward contraction then runs in split precision on the fp32 activation x (a
+    split-precision site, config.set_split_sites); the backward is the bf16 one either way."""
     if x.stride(-1) != 1:
         x = x.contiguous()
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
+    if not _split_site_ok(x, W, W32, x2, act_pro, out_dtype, p_drop):
+        W32 = None
     if _needs_grad(x, W, b, x2, residual):
         assert act_pro == K.ACT_NONE, "producer-side activations only under autograd"
         K.tn_hook(W, b)
         holder = [] if _want16(out_dtype, act_epi, want16) else None
-        y = _Linear.apply(x, W, b, x2, residual, act_epi, out_dtype, holder, p_drop, seed)
+        y = _Linear.apply(x, W, b, x2, residual, act_epi, out_dtype, holder, p_drop, seed, W32)
         return _attach_b16(y, holder[0] if holder else None)
     y16 = None
     if _want16(out_dtype, act_epi, want16) and act_pro == K.ACT_NONE and p_drop == 0.0:
         y16 = torch.empty((x.shape[0], W.shape[0]), dtype=torch.bfloat16, device=x.device)
+    if W32 is not None:
+        y, _ = K.gemm(x, W32, bias=b, A2=x2, act_epi=act_epi, residual=residual, out_dtype=out_dtype, out16=y16, force_x3=True)
+        return _attach_b16(y, y16)
     y, _ = K.gemm(_mm_in(x), W, bias=b, A2=_mm_in(x2), act_pro=act_pro, act_epi=act_epi, residual=residual,
                   out_dtype=out_dtype, p_drop=p_drop, seed=seed, out16=y16)
     return _attach_b16(y, y16)
@@ -1343,14 +1361,17 @@ def rows_hadamard(t, idx_a, idx_b, a_sorted=False):
 
 class _InterAttn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext=None, Wc=None, bc=None, holder=None):
+    def forward(ctx, qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext=None, Wc=None, bc=None, holder=None, Wc32=None):
         v_in = None
         if Wc is not None:
             # cv = Linear(V) (egnn.py:225) evaluated inside this node of the autograd graph: its input gradient then accumulates
             # into the V columns of dqkv in place, instead of autograd padding it to [N,3H] and adding two [N,3H] tensors
             c16 = getattr(qkv, "_fab_b16", None) if _cfg.get_precision() == "bf16" else None    # (bf16x3 attaches copies for TN operands only)
             v_in = c16[1][:, 2 * H:] if (c16 is not None and c16[0] == qkv._version) else _mm_in(qkv[:, 2 * H:])
-            cv, _ = K.gemm(v_in, Wc, bias=bc)
+            if Wc32 is not None:     # split-precision site (config.set_split_sites): fp32 v rows x the fp32 master weight; v_in / Wc serve the backward
+                cv, _ = K.gemm(qkv[:, 2 * H:], Wc32, bias=bc, force_x3=True)
+            else:
+                cv, _ = K.gemm(v_in, Wc, bias=bc)
         h16 = None
         if holder is not None:
             h16 = torch.empty((h.shape[0], H), dtype=torch.bfloat16, device=h.device)
@@ -1422,7 +1443,7 @@ class _InterAttn(torch.autograd.Function):
         if ctx.sink_h is not None and ctx.needs_input_grad[2]:
             dh_out = ctx.sink_h.deposit(dh_out)           # h_out = h + ...: the residual gradient joins h's shared buffer
         return (dqkv, dcv, dh_out, dx_out, dd[:E], drh[:E], dbias_red[:n_red, None].expand(n_red, ctx.np), dw[0], dw[1],
-                dw[2], dw[3], None, None, None, dcp[:E] if ctx.has_ext else None, dWc, dbc, None)
+                dw[2], dw[3], None, None, None, dcp[:E] if ctx.has_ext else None, dWc, dbc, None, None)
 
 
 INTER_BWD_BLOCKS = int(os.environ.get("FABIND_INTER_BWD_BLOCKS", "1024"))
@@ -1431,20 +1452,23 @@ INTER_BWD_BLOCKS = int(os.environ.get("FABIND_INTER_BWD_BLOCKS", "1024"))
 INTER_ATTN_INPLACE = os.environ.get("FABIND_INTER_ATTN_INPLACE", "1") == "1"
 
 
-def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None, Wc=None, bc=None, own_h=False):
+def inter_attn(qkv, cv, H, h, x, d, rhohat, g, bias_part, w_rk, w_rv, wcr, w3, clampv, s_ext=None, Wc=None, bc=None, own_h=False, Wc32=None):
     """s_ext [E] (optional): per-edge scalar added to the coordinate-MLP value inside the kernel (FABind+ evaluates its
     LN-MLP coord_mlp outside); differentiable.  cv=None with (Wc, bc): cv = Linear(qkv[:, 2H:]) is evaluated here.
     own_h: the caller hands h over (a fresh intermediate nobody reads afterwards): a no-grad pass then updates it in place -- only the
     rows with inter edges are rewritten, and the bf16 operand copy that travels with h gets the same rows."""
     assert (cv is None) != (Wc is None), "inter_attn: pass either cv or its Linear (Wc, bc)"
     w16 = _cfg.get_precision() == "bf16" and h.is_contiguous()
+    if Wc32 is not None and not (Wc is not None and _cfg.get_precision() == "bf16" and qkv.dtype == torch.float32 and Wc32.dtype == torch.float32
+                                 and tuple(Wc32.shape) == tuple(Wc.shape) and qkv.stride(0) % 4 == 0):
+        Wc32 = None
     if _needs_grad(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, s_ext, Wc, bc):
         K.tn_hook(Wc, bc)
         holder = [] if w16 else None
-        h_out, x_out, alpha = _InterAttn.apply(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext, Wc, bc, holder)
+        h_out, x_out, alpha = _InterAttn.apply(qkv, cv, h, x, d, rhohat, bias_part, w_rk, w_rv, wcr, w3, H, g, clampv, s_ext, Wc, bc, holder, Wc32)
         return _attach_b16(h_out, holder[0] if holder else None), x_out, alpha
     if cv is None:
-        cv = linear(qkv[:, 2 * H:], Wc, bc)
+        cv = linear(qkv[:, 2 * H:], Wc, bc, W32=Wc32)
     deal = getattr(g, "int_deal", None)
     if own_h and INTER_ATTN_INPLACE and deal is not None and K.INTER_ATTN_ROWS and h.is_contiguous() and h.dtype == torch.float32 and not h.requires_grad:
         c = getattr(h, "_fab_b16", None)
