@@ -4,7 +4,7 @@ import os
 _PRECISION = {"mode": "bf16", "x3_backward": "bf16" if (os.environ.get("FABIND_X3_WGRAD", "bf16") == "bf16" and
                                                           os.environ.get("FABIND_X3_PAIRBIAS_BWD", "bf16") == "bf16") else "exact"}
 MODES = ("fp32", "bf16", "bf16x3")
-_PRECISION["split_sites"] = int(os.environ.get("FABIND_SPLIT_SITES", "1"))
+_PRECISION["split_sites"] = int(os.environ.get("FABIND_SPLIT_SITES", "2"))
 
 
 def set_precision(mode):
@@ -31,11 +31,15 @@ def set_split_sites(level):
     the fp32 reference, the bf16 edge pipeline carries 3.5e-6 and the bf16 attention tiles 1.3e-6; the node-level GEMM operand roundings
     carry the rest, and three sites most of that -- the inter-edge attention's q | k | v projection (5.4e-5 alone), its coordinate-MLP
     projection cv = Wc v (5.7e-5) and the stack's input Linear (3.2e-5).
-      0: none (rounds 1-4: every GEMM on bf16 operands);
-      1 (default): those three sites (9 of the ~50 node-level GEMMs of a pass): gap 3.3e-5 / 5.7e-5 / 2.4e-4 A at n_iter 1 / 2 / 8 instead of
-         1.0e-4 / 1.8e-4 / 6.3e-4 -- the 1e-4 A gate met with margin for one and two passes.
+      0: none (rounds 1-4: every GEMM on bf16 operands): 1.00e-4 / 1.76e-4 / 6.26e-4 A at n_iter 1 / 2 / 8;
+      1: those three sites (9 of the ~50 node-level GEMMs of a pass): 3.84e-5 / 6.71e-5 / 2.45e-4 A; headline -1.5 %, forward only -6.6 %;
+      2 (default): + the protein-query attention block's output projection and both blocks' k | v projections (21 GEMMs of a pass):
+         2.56e-5 / 4.06e-5 / 1.58e-4 A -- the 1e-4 A gate met with margin for one and two passes; another -0.5 % / -1.7 %.
+      (Measured on MI355X: profiles/r05_precision_sites.txt.  The remaining gap sits in the GEMMs whose activation operand is a HIDDEN
+      layer -- node MLP, Transition --, which the bf16 mode stores as bf16: emulated with those in split precision too the loop reads
+      5.8e-5 A at n_iter 8; 'bf16x3' is the mode that meets the gate there.)
     Backward passes are unchanged (bf16 operands; the gradients of a bf16-mode step are bf16-grade either way)."""
-    assert level in (0, 1)
+    assert level in (0, 1, 2)
     _PRECISION["split_sites"] = int(level)
 
 

@@ -443,6 +443,11 @@ def _split_site_masters(model, P):
             d = P["att"][i]
             d["Wqkv32"] = torch.cat([m.linear_q.weight.detach(), Wkv[0::2, 1:], Wkv[1::2, 1:]], 0).float().contiguous()
             d["Wc32"] = f32(m.coord_mlp[0].weight)
+            if split_sites() >= 2:       # + the protein-query block's output projection and both blocks' k | v projections
+                cam = m.cross_attn_module
+                d["Wo_p32"] = f32(cam.p_attention_block.mha.linear_o.weight)
+                for tag, blk in (("p", cam.p_attention_block), ("c", cam.c_attention_block)):
+                    d["Wkv_%s32" % tag] = torch.cat([blk.mha.linear_k.weight.detach(), blk.mha.linear_v.weight.detach()], 0).float().contiguous()
 
 
 def _edge_frags(P):
@@ -577,17 +582,17 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
         pbt = pairbias.tensors() if isinstance(pairbias, ops.PairBias) else pairbias
         bias_p, bias_c = pbt[2 * layer], pbt[2 * layer + 1]
     qg = ops.linear(c16(h), p["Wqg_p"], p["bqg_p"])                                     # [N, 256]
-    kv = ops.linear(c16(hc), p["Wkv_p"])                                                # [sum C, 256]
+    kv = ops.linear(hc if p.get("Wkv_p32") is not None else c16(hc), p["Wkv_p"], W32=p.get("Wkv_p32"))     # [sum C, 256]
     og = ops.cross_attn_fused(qg, kv, pairbias, 2 * layer, 0, lay, scale) if fused else \
         ops.cross_attn_fused_train(qg, kv, pairbias, 2 * layer, 0, scale) if ftrain else \
         ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_pf, lay.B, lay.max_P, lay.max_C, scale)
     hp = (h + _drop(ops.linear(c16(og), p["Wo_p"], p["bo_p"]), pdrop)) if pdrop > 0.0 else \
-        ops.linear(c16(og), p["Wo_p"], p["bo_p"], residual=h, want16=True)
+        ops.linear(og if p.get("Wo_p32") is not None else c16(og), p["Wo_p"], p["bo_p"], residual=h, want16=True, W32=p.get("Wo_p32"))
     if pdrop == 0.0:
         hp = ops.shared_grad(hp)    # consumers: k / v projection of the ligand-query block, transition, its residual
     hp16 = c16(hp)
     qg = ops.linear(c16(hc), p["Wqg_c"], p["bqg_c"])
-    kv = ops.linear(hp16, p["Wkv_c"])                                                   # [N, 256], protein rows used
+    kv = ops.linear(hp if p.get("Wkv_c32") is not None else hp16, p["Wkv_c"], W32=p.get("Wkv_c32"))       # [N, 256], protein rows used
     og = ops.cross_attn_fused(qg, kv, pairbias, 2 * layer + 1, 1, lay, scale) if fused else \
         ops.cross_attn_fused_train(qg, kv, pairbias, 2 * layer + 1, 1, scale) if ftrain else \
         ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
