@@ -47,6 +47,40 @@ def split_sites():
     return _PRECISION["split_sites"] if _PRECISION["mode"] == "bf16" else 0
 
 
+_PRECISION["x3_edge"] = os.environ.get("FABIND_X3_EDGE", "bf16")
+
+
+def set_x3_edge(kind):
+    """'bf16x3' mode: the fused intra-graph edge pipeline (MC_E_GCL edge / coord model, egnn.py:68-128) as
+      'bf16'  (default since round 5): the bf16 kernels of the 'bf16' mode on a bf16 copy of the per-node projections AB -- measured at
+               the headline shape (tools/probes/precision_sources.py, profiles/r05_precision_sites.txt): with everything else in split
+               precision the bf16 edge pipeline moves the ligand by 3.5e-6 A (gate: 1e-4); its forward takes 2.2 instead of 4.9 ms per launch;
+      'split': the split-bf16 forward kernel on fp32 AB rows (round 3-4)."""
+    assert kind in ("bf16", "split")
+    _PRECISION["x3_edge"] = kind
+
+
+def x3_edge_bf16():
+    return _PRECISION["x3_edge"] == "bf16"
+
+
+_PRECISION["x3_attn"] = os.environ.get("FABIND_X3_ATTN", "bf16")
+
+
+def set_x3_attn(kind):
+    """'bf16x3' mode: the protein <-> ligand cross attention (cross_att.py:118-134) as
+      'bf16' (default since round 5): the fused MFMA kernels of the 'bf16' mode -- the pair bias recomputed on the matrix cores from the bf16
+              a0 rows and the packed ligand-side operand, bf16 score / value tiles, fp32 softmax statistics; measured with everything else in
+              split precision: 1.3e-6 A of ligand RMSD (profiles/r05_precision_sites.txt), and no [pairs, 8] bias tensors exist;
+      'fp32': the fp32 VALU kernels on [pairs, 8] bias tensors from split-precision ragged contractions (round 3-4)."""
+    assert kind in ("bf16", "fp32")
+    _PRECISION["x3_attn"] = kind
+
+
+def x3_attn_bf16():
+    return _PRECISION["x3_attn"] == "bf16"
+
+
 def set_x3_backward(kind):
     """'bf16' (default) / 'exact': see set_precision('bf16x3')."""
     assert kind in ("bf16", "exact")

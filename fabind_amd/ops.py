@@ -784,6 +784,16 @@ def fused_edge(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop=0.0, frags=No
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
     if _needs_grad(AB16, rhohat, w_r, W2, b2, Wc, bc, w3):
         K.tn_hook(W2, Wc)                    # (their gradients may be queued: kernels.gcl_edge_fused_bwd)
+    if _cfg.get_precision() == "bf16x3" and _cfg.x3_edge_bf16() and AB16.dtype == torch.float32:
+        # the bf16 kernels on a bf16 copy of AB (config.set_x3_edge: 3.5e-6 A of ligand RMSD against 2.7 ms per launch); the cast is a
+        # differentiable torch op, the weights are packed as bf16 fragments by the kernels' wrappers
+        ab = AB16.to(torch.bfloat16)
+        if _needs_grad(AB16, rhohat, w_r, W2, b2, Wc, bc, w3):
+            agg, s = _FusedEdge.apply(ab, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed, None, None)
+            return agg, s
+        out = K.gcl_edge_fused(ab, H, g.row_ctx, g.col_ctx, rhohat, w_r, K.pack_frag(W2), b2, K.pack_frag(Wc), bc, w3, ab.shape[0], p_drop, seed,
+                               want16=False, rowptr=g.rp_ctx)
+        return out[0], out[1]
     if _cfg.get_precision() == "bf16x3":
         if _needs_grad(AB16, rhohat, w_r, W2, b2, Wc, bc, w3):
             return _FusedEdgeX3.apply(AB16, rhohat, w_r, W2, b2, Wc, bc, w3, H, g, p_drop, seed)
@@ -1662,7 +1672,8 @@ class PairBias:
 
     def can_fuse(self):
         # (the kernels assume wcomp[k] rows ordered lin0..3 | gate0..3 for 4 heads of 32 channels: engine._stack_requests builds them so)
-        return (K.CROSS_ATTN_FUSED and _cfg.get_precision() == "bf16" and self.lay.max_C <= K.CROSS_ATTN_FUSED_MAX_C
+        return (K.CROSS_ATTN_FUSED and (_cfg.get_precision() == "bf16" or (_cfg.get_precision() == "bf16x3" and _cfg.x3_attn_bf16()))
+                and self.lay.max_C <= K.CROSS_ATTN_FUSED_MAX_C
                 and self.H in (64, 128, 256, 512) and tuple(self.wcomp.shape[1:]) == (8, self.H))
 
     def can_fuse_train(self):
