@@ -626,13 +626,14 @@ def main():
         from fabind_amd import config as _config
 
         def sub(name, mode, n_iter, train_mode=False, precision=None, note="", steps=3, warmup=1, n_prot=None, whole_pocket=False,
-                x3_backward="bf16"):
+                x3_backward="bf16", x3_edge="split"):
             only = os.environ.get("FABIND_BENCH_ONLY")             # development knob: comma-separated sub-object names to run
             if only and name not in only.split(","):
                 return
             prec = precision or a.precision
             engine.set_precision(prec)
             _config.set_x3_backward(x3_backward)
+            _config.set_x3_edge(x3_edge)
             try:
                 st, per, _ = make_step(mode, n_iter, train_mode, n_prot=n_prot, whole_pocket=whole_pocket)
                 d, pf = timed(st, warmup, steps, True, events_in_timed=False)
@@ -652,6 +653,7 @@ def main():
             finally:
                 engine.set_precision(a.precision)
                 _config.set_x3_backward("bf16")
+                _config.set_x3_edge("split")
                 st = per = _ = pf = None          # (model, batches, events: nothing of this sub-object may live into the next one)
                 import gc
                 gc.collect()
@@ -667,6 +669,10 @@ def main():
         sub("gate_mode_exact_bwd", "fwdbwd", a.n_iter, precision="bf16x3", steps=5, warmup=2, x3_backward="exact",
             note="gate_mode with config.set_x3_backward('exact'): weight gradients as split contractions, pair-bias adjoint in fp32 (the fused "
                  "edge backward stays the bf16 recompute kernel)")
+        sub("gate_mode_bf16_edge", "fwdbwd", a.n_iter, precision="bf16x3", steps=8, warmup=2, x3_edge="bf16",
+            note="gate_mode with config.set_x3_edge('bf16'): the intra-graph edge pipeline on the bf16 kernels (forward 2.2 instead of 4.9 ms per "
+                 "launch); the coordinate / loss gates still hold with less margin (ligand RMSD 3.5e-6 / 7.0e-6 / 3.0e-5 A at n_iter 1 / 2 / 8, full "
+                 "IaBNet 5.1e-5 A: tests/test_gpu_headline.py, test_gpu_production.py), node features to 3.4e-4 only -- an option, not the default")
         sub("fp32", "fwdbwd", a.n_iter, precision="fp32",
             note="the headline step in fp32 mode (exact-fp32 MFMA, unfused edge pipeline): the exact reference arithmetic")
         sub("train_mode", "fwdbwd", a.n_iter, train_mode=True, steps=5, warmup=2,
@@ -677,6 +683,8 @@ def main():
                                            "in the mode that meets it")
         sub("n_iter8_gate", "fwdbwd", 8, precision="bf16x3", steps=3, warmup=1,
             note="n_iter8 in the gate-meeting split-bf16 mode (2.8e-6 A at the headline shape, tests/test_gpu_headline.py)")
+        sub("n_iter8_gate_bf16_edge", "fwdbwd", 8, precision="bf16x3", steps=3, warmup=1, x3_edge="bf16",
+            note="n_iter8_gate with config.set_x3_edge('bf16') (3.0e-5 A at the headline shape: see gate_mode_bf16_edge)")
         sub("fwd", "fwd", a.n_iter, steps=10, warmup=3, note="forward only, one stack pass")
         sub("model_fwdbwd", "model", a.n_iter, steps=6, warmup=2,
             note="full IaBNet (pocket model on 1500 residues -> pocket crop -> 4-layer complex model -> heads) with the reference's "

@@ -47,15 +47,17 @@ def split_sites():
     return _PRECISION["split_sites"] if _PRECISION["mode"] == "bf16" else 0
 
 
-_PRECISION["x3_edge"] = os.environ.get("FABIND_X3_EDGE", "bf16")
+_PRECISION["x3_edge"] = os.environ.get("FABIND_X3_EDGE", "split")
 
 
 def set_x3_edge(kind):
     """'bf16x3' mode: the fused intra-graph edge pipeline (MC_E_GCL edge / coord model, egnn.py:68-128) as
-      'bf16'  (default since round 5): the bf16 kernels of the 'bf16' mode on a bf16 copy of the per-node projections AB -- measured at
-               the headline shape (tools/probes/precision_sources.py, profiles/r05_precision_sites.txt): with everything else in split
-               precision the bf16 edge pipeline moves the ligand by 3.5e-6 A (gate: 1e-4); its forward takes 2.2 instead of 4.9 ms per launch;
-      'split': the split-bf16 forward kernel on fp32 AB rows (round 3-4)."""
+      'split' (default): the split-bf16 forward kernel on fp32 AB rows (fp32-grade node features: H to 4e-6 of its largest entry);
+      'bf16'  (round 5, an option): the bf16 kernels of the 'bf16' mode on a bf16 copy of the per-node projections AB: forward 2.2 instead
+               of 4.9 ms per launch -- gate mode 531 -> 592 complexes/s, the n_iter 8 loop 156 -> 202 -- and the COORDINATE / loss gates still
+               met, with less margin: ligand RMSD 3.5e-6 / 7.0e-6 / 3.0e-5 A at n_iter 1 / 2 / 8 at the headline shape (split: 8e-7 / 9e-7 /
+               2.9e-6), full IaBNet at production size 5.1e-5 / 2.0e-5 A (2.3e-6 / 2.6e-6); node features H to 3.4e-4 only (the messages
+               are summed as bf16) -- profiles/r05_precision_sites.txt, tests/test_gpu_headline.py."""
     assert kind in ("bf16", "split")
     _PRECISION["x3_edge"] = kind
 
@@ -64,15 +66,15 @@ def x3_edge_bf16():
     return _PRECISION["x3_edge"] == "bf16"
 
 
-_PRECISION["x3_attn"] = os.environ.get("FABIND_X3_ATTN", "bf16")
+_PRECISION["x3_attn"] = os.environ.get("FABIND_X3_ATTN", "fp32")
 
 
 def set_x3_attn(kind):
     """'bf16x3' mode: the protein <-> ligand cross attention (cross_att.py:118-134) as
-      'bf16' (default since round 5): the fused MFMA kernels of the 'bf16' mode -- the pair bias recomputed on the matrix cores from the bf16
-              a0 rows and the packed ligand-side operand, bf16 score / value tiles, fp32 softmax statistics; measured with everything else in
-              split precision: 1.3e-6 A of ligand RMSD (profiles/r05_precision_sites.txt), and no [pairs, 8] bias tensors exist;
-      'fp32': the fp32 VALU kernels on [pairs, 8] bias tensors from split-precision ragged contractions (round 3-4)."""
+      'fp32' (default): the fp32 VALU kernels on [pairs, 8] bias tensors from split-precision ragged contractions;
+      'bf16' (round 5, an option, NOT recommended): the fused MFMA kernels of the 'bf16' mode (pair bias recomputed on the matrix cores
+              from bf16 operands): +3.5 % on the gate-mode step; 1.3e-6 A at the headline shape, but the full IaBNet's stage 2 (the ligand
+              moves 17 A) reads 9.35e-5 A -- inside the gate without margin (profiles/r05_precision_sites.txt)."""
     assert kind in ("bf16", "fp32")
     _PRECISION["x3_attn"] = kind
 

@@ -60,7 +60,7 @@ def test_bench_self_launches_without_a_launcher():
 
 
 SUB_OBJECTS = ("pocket", "gate_mode", "gate_mode_exact_bwd", "fp32", "train_mode", "n_iter8", "n_iter8_gate", "fwd", "model_fwdbwd",
-               "model_gate", "config3_whole_graph", "model_fwdbwd_train_n_iter8", "plus_train", "plus_train_gate", "plus_sampling")
+               "model_gate", "gate_mode_bf16_edge", "n_iter8_gate_bf16_edge", "config3_whole_graph", "model_fwdbwd_train_n_iter8", "plus_train", "plus_train_gate", "plus_sampling")
 
 
 def test_bench_line_carries_the_neighbouring_configurations():

@@ -147,6 +147,31 @@ def test_headline_shape_bf16x3_meets_the_gate(one_complex, n_iter):
     assert herr <= 1e-4
 
 
+@pytest.mark.parametrize("n_iter", [1, 2, 8])
+def test_headline_shape_bf16x3_with_the_bf16_edge_pipeline_meets_the_coordinate_gate(one_complex, n_iter):
+    """Round 5: config.set_x3_edge("bf16") -- the split-precision mode with the intra-graph edge pipeline on the bf16 kernels (gate mode
+    531 -> 592 complexes/s, the n_iter 8 loop 156 -> 202): the COORDINATE gate of north_star (1e-4 A) must hold for one, two and eight
+    passes (measured 3.5e-6 / 7.0e-6 / 3.0e-5 A); the node features are bf16-message grade (bounded at 1e-3 of the largest entry, measured
+    3.4e-4), which is why this is an option and not the default of the mode."""
+    from fabind_amd import config, engine
+    dev = torch.device("cuda:0")
+    m = _model(n_iter)
+    Xr, Hr, _, _ = _oracle(m, one_complex, n_iter)
+    engine.set_precision("bf16x3")
+    config.set_x3_edge("bf16")
+    try:
+        X, Hh, _ = _hip(m.to(dev), one_complex, dev)
+    finally:
+        config.set_x3_edge("split")
+        engine.set_precision("fp32")
+    lig = one_complex["mask"].numpy()
+    gap = rmsd(X.cpu().numpy()[lig] * 5, Xr.numpy()[lig] * 5)
+    herr = float((Hh.cpu() - Hr).abs().max()) / max(1.0, float(Hr.abs().max()))
+    print("headline shape bf16x3 + bf16 edge pipeline, n_iter=%d: RMSD vs oracle %.3e A (gate 1e-4); H rel err %.3e" % (n_iter, gap, herr))
+    assert gap < 1e-4
+    assert herr <= 1e-3
+
+
 # bf16x3 (round 3, shipped form: split-bf16 forward and activation-gradient GEMMs, bf16 fused edge backward / weight-gradient
 # contractions / pair-bias adjoint): input 7.8e-3, whole-gradient l2 1.8e-3, per-tensor l2 median 1.7e-3, worst 2.7e-2 (a bias 1e-5
 # of the largest gradient) -- bounds at ~2x

@@ -181,6 +181,23 @@ def test_iabnet_production_size_matches_oracle(stage):
     print("    bf16x3: ligand RMSD gap %.3e A, loss rel gap %.3e (gates 1e-4 A / 1e-5)" % (g3, le3))
     assert g3 < 1e-4 and le3 <= 1e-5
 
+    # ... and with the mode's bf16-edge option (config.set_x3_edge("bf16"), round 5): the same gates, less margin (measured 5.1e-5 / 2.0e-5 A)
+    from fabind_amd import config
+    engine.set_precision("bf16x3")
+    config.set_x3_edge("bf16")
+    try:
+        data = ref["data"].clone().to(dev)
+        with torch.no_grad():
+            o3e = m(data, stage=stage, train=False)
+            l3e, _ = compute_loss(o3e, data)
+    finally:
+        config.set_x3_edge("split")
+        engine.set_precision("fp32")
+    g3e = rmsd(o3e[0].cpu().numpy(), ref["out"][0].numpy())
+    le3e = abs(float(l3e) - ref["loss"]) / abs(ref["loss"])
+    print("    bf16x3 + bf16 edge pipeline: ligand RMSD gap %.3e A, loss rel gap %.3e (gates 1e-4 A / 1e-5)" % (g3e, le3e))
+    assert g3e < 1e-4 and le3e <= 1e-5
+
 
 # bf16 gap of the whole-graph step (ligand RMSD in A, relative loss gap): asserted at 2x the first measurement (round 5)
 CONFIG3_BF16_BOUND = (1.9e-4, 1e-6)              # measured 9.43e-5 A (inside the gate) and 4.1e-7; whole-gradient l2 error 6.6e-4
