@@ -862,6 +862,17 @@ def _tn_flush_hook(_g):
     tn_flush()
 
 
+_TN_HOOKED = {}            # id(tensor) -> weakref(tensor): tensors that carry the flush hook (NOT an attribute on the tensor: a Parameter that is
+#                             pickled whole -- torch.save(model), mp spawn -- would keep the attribute and lose the hook)
+
+
+def _tn_in_backward():
+    try:
+        return torch._C._current_graph_task_id() != -1
+    except Exception:
+        return True          # cannot tell: keep the queue's state
+
+
 def tn_hook(*weights):
     """Forward-time half of the queue's contract: a tensor hook on every weight (and bias) whose gradient the backward pass may
     queue.  The hook runs when autograd has that tensor's gradient complete and is about to hand it to the tensor's producer (the
@@ -871,10 +882,21 @@ def tn_hook(*weights):
     adjoint is then the one flush point of the pass.)"""
     if not TN_DEFER:
         return
+    q = _TNQ
+    if (q["armed"] or q["jobs"]) and not _tn_in_backward():
+        # forward-time call with the queue still armed / loaded: the last backward pass raised (autograd runs no final callbacks then) or
+        # was abandoned.  Its leftover jobs would write into gradients nobody will read and keep their operands alive: drop them.
+        q["jobs"], q["bytes"], q["outs"], q["armed"] = [], 0, set(), False
+    import weakref
     for W in weights:
-        if W is not None and W.requires_grad and not getattr(W, "_fab_tnq", False):
-            W.register_hook(_tn_flush_hook)
-            W._fab_tnq = True
+        if W is None or not W.requires_grad:
+            continue
+        k = id(W)
+        r = _TN_HOOKED.get(k)
+        if r is not None and r() is W:
+            continue
+        W.register_hook(_tn_flush_hook)
+        _TN_HOOKED[k] = weakref.ref(W, lambda _r, k_=k: _TN_HOOKED.pop(k_, None))
 
 
 def tn_can_queue(Y, X, key=None):

@@ -1664,6 +1664,7 @@ class PairBias:
         self._tensors, self._a16, self._bo = None, None, {}
         self._bot, self._bw = {}, None            # fused backward: Bo^T packs per block; state shared by the blocks of one backward pass
         self._n_fused = 0
+        self._fused_blocks = set()                # blocks with a differentiable fused forward whose backward has not run yet
         # a differentiable pass will come (training: the last refinement iteration) and its backward cannot recompute the bias in the
         # kernels, or nothing can be fused: build the tensors NOW, under the caller's grad mode -- a first use inside a no-grad refinement
         # iteration would cache tensors without a graph
@@ -1800,11 +1801,22 @@ class _CrossAttnFused(torch.autograd.Function):
             dw_ret = K.colsum(fin).view(nblk, NO, H)[:, inv].contiguous().to(wcomp.dtype)
             db_ret = K.colsum(bw["colpart"]).view(nblk, NO)[:, inv].contiguous()
             pb._bw = None
+            pb._fused_blocks.clear()                  # the pass is complete: the context may serve another one (_n_fused stays: a second
+            #                                           backward over a retained graph counts the same blocks down again)
         return dqg, dkv, da0b0_ret, dw_ret, db_ret, None, None, None, None
 
 
 def cross_attn_fused_train(qg, kv, pb, k_blk, mode, scale):
-    """Differentiable gated cross attention of block k_blk with the pair bias recomputed in the kernels both ways."""
+    """Differentiable gated cross attention of block k_blk with the pair bias recomputed in the kernels both ways.
+    The blocks of ONE differentiable pass share state on `pb` (the K-concatenated gradient rows, the count of blocks still to run their
+    backward): a PairBias / StackContext serves one differentiable pass at a time -- a second differentiable forward of the same block
+    before the first pass's backward has run would overwrite its slice, so it is refused here."""
+    if k_blk in pb._fused_blocks:
+        raise RuntimeError("fabind_amd: block %d of this PairBias already has a differentiable fused forward whose backward has not run -- a "
+                           "StackContext serves ONE differentiable pass at a time (build a new context, or run backward first)" % k_blk)
+    if not pb._fused_blocks:
+        pb._bw, pb._n_fused = None, 0             # a new pass starts (also drops the leftovers of a pass whose backward never completed)
+    pb._fused_blocks.add(k_blk)
     return _CrossAttnFused.apply(qg, kv, pb.a0b0, pb.wcomp, pb.bconst, pb, k_blk, mode, scale)
 
 
