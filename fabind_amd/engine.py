@@ -429,7 +429,7 @@ def _build_stack_params(model):
 
 def _split_site_masters(model, P):
     """fp32 master weights of the split-precision sites of the bf16 mode (config.set_split_sites), next to their bf16 pack entries: the
-    input Linear and, per attention layer, the q | k | v projection (interleaved kv split undone like `Wqkv`) and the coordinate MLP's first
+    input Linear and, per attention layer, the V rows of the q | k | v projection (interleaved kv split undone like `Wqkv`) and the coordinate MLP's first
     Linear.  Detached: they are operands of the FORWARD contraction only, the gradients flow through the bf16 entries."""
     if split_sites() < 1:
         return
@@ -441,7 +441,9 @@ def _split_site_masters(model, P):
             m = getattr(gnn, "att_%d" % i)
             Wkv = m.linear_kv.weight.detach()
             d = P["att"][i]
-            d["Wqkv32"] = torch.cat([m.linear_q.weight.detach(), Wkv[0::2, 1:], Wkv[1::2, 1:]], 0).float().contiguous()
+            # (of q | k | v only the v columns carry the gap: tools/probes/precision_qkv_parts.py -- the row-range form of ops.linear's W32)
+            H_ = P["H"]
+            d["Wqkv32"] = (Wkv[1::2, 1:].float().contiguous(), 2 * H_, 3 * H_)
             d["Wc32"] = f32(m.coord_mlp[0].weight)
             if split_sites() >= 2:       # + the protein-query block's output projection and both blocks' k | v projections
                 cam = m.cross_attn_module

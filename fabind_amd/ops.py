@@ -266,7 +266,9 @@ class _Linear(torch.autograd.Function):
         if holder is not None:                        # the caller wants the epilogue to emit the bf16 operand copy of y as well
             y16 = torch.empty((M, N), dtype=torch.bfloat16, device=x.device)
             holder.append(y16)
-        if W32 is not None:      # a split-precision site of the bf16 mode (config.set_split_sites): the forward contracts the fp32 activation with
+        if isinstance(W32, tuple):
+            _gemm_split_rows(x, xin, W, W32, b, y, y16)
+        elif W32 is not None:    # a split-precision site of the bf16 mode (config.set_split_sites): the forward contracts the fp32 activation with
             #                      the fp32 master weight; what is saved -- and everything the backward does -- are the bf16 operands
             K.gemm(x, W32, bias=b, A2=x2, act_epi=act_epi, residual=residual, out=y, out2=D, out16=y16, p_drop=p_drop, seed=seed, force_x3=True)
         else:
@@ -345,11 +347,29 @@ class _Linear(torch.autograd.Function):
         return dx, dW, db, dx2, dres, None, None, None, None, None, None
 
 
-def _split_site_ok(x, W, W32, x2, act_pro, out_dtype, p_drop):
-    """May this Linear run as a split-precision site?  (bf16 mode, fp32 activation rows and fp32 master weight of W's shape, plain epilogue.)"""
-    return (W32 is not None and _cfg.get_precision() == "bf16" and x.dtype == torch.float32 and W32.dtype == torch.float32
-            and tuple(W32.shape) == tuple(W.shape) and W32.stride(-1) == 1 and (x2 is None or x2.dtype == torch.float32)
-            and act_pro == K.ACT_NONE and out_dtype == torch.float32 and p_drop == 0.0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0)
+def _gemm_split_rows(x, xin, W, W32, b, y, y16):
+    """y = x W^T + b with the output columns [lo, hi) contracted in split precision (fp32 x, fp32 master rows W32p) and the others on the
+    bf16 operands: two or three launches into column ranges of the same output (and of its bf16 copy).  The inter-edge attention's
+    q | k | v projection: only the v columns carry the ligand-RMSD gap (tools/probes/precision_qkv_parts.py)."""
+    W32p, lo, hi = W32
+    N = W.shape[0]
+    for a_, b_ in ((0, lo), (hi, N)):
+        if b_ > a_:
+            K.gemm(xin, W[a_:b_], bias=b[a_:b_] if b is not None else None, out=y[:, a_:b_], out16=y16[:, a_:b_] if y16 is not None else None)
+    K.gemm(x, W32p, bias=b[lo:hi] if b is not None else None, out=y[:, lo:hi], out16=y16[:, lo:hi] if y16 is not None else None, force_x3=True)
+
+
+def _split_site_ok(x, W, W32, x2, act_pro, out_dtype, p_drop, act_epi=K.ACT_NONE, residual=None):
+    """May this Linear run as a split-precision site?  (bf16 mode, fp32 activation rows and fp32 master weight of W's shape, plain epilogue;
+    the row-range form (W32p, lo, hi): no second operand, activation or residual.)"""
+    if W32 is None or _cfg.get_precision() != "bf16" or x.dtype != torch.float32 or act_pro != K.ACT_NONE or out_dtype != torch.float32 \
+            or p_drop != 0.0 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
+        return False
+    if isinstance(W32, tuple):
+        W32p, lo, hi = W32
+        return (W32p.dtype == torch.float32 and W32p.stride(-1) == 1 and tuple(W32p.shape) == (hi - lo, W.shape[1]) and 0 <= lo < hi <= W.shape[0]
+                and lo % 128 == 0 and hi % 128 == 0 and x2 is None and act_epi == K.ACT_NONE and residual is None)
+    return (W32.dtype == torch.float32 and tuple(W32.shape) == tuple(W.shape) and W32.stride(-1) == 1 and (x2 is None or x2.dtype == torch.float32))
 
 
 def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, x2=None, out_dtype=torch.float32,
@@ -361,7 +381,7 @@ def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, 
     if x.stride(-1) != 1:
         x = x.contiguous()
     seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
-    if not _split_site_ok(x, W, W32, x2, act_pro, out_dtype, p_drop):
+    if not _split_site_ok(x, W, W32, x2, act_pro, out_dtype, p_drop, act_epi, residual):
         W32 = None
     if _needs_grad(x, W, b, x2, residual):
         assert act_pro == K.ACT_NONE, "producer-side activations only under autograd"
@@ -372,6 +392,10 @@ def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, 
     y16 = None
     if _want16(out_dtype, act_epi, want16) and act_pro == K.ACT_NONE and p_drop == 0.0:
         y16 = torch.empty((x.shape[0], W.shape[0]), dtype=torch.bfloat16, device=x.device)
+    if isinstance(W32, tuple):
+        y = torch.empty((x.shape[0], W.shape[0]), dtype=out_dtype, device=x.device)
+        _gemm_split_rows(x, _mm_in(x), W, W32, b, y, y16)
+        return _attach_b16(y, y16)
     if W32 is not None:
         y, _ = K.gemm(x, W32, bias=b, A2=x2, act_epi=act_epi, residual=residual, out_dtype=out_dtype, out16=y16, force_x3=True)
         return _attach_b16(y, y16)
