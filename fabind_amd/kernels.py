@@ -103,8 +103,10 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     if PROFILE is None:                                    # (the label costs more host time than the launch: formatted only when events are taken)
         check(lib.fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm")
         return (out if want_out else None), dot_out
-    label = "fabind_gemm <%s,%s%s> M=%d N=%d K=%d" % (str(A.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""),
-                                                      ",x3" if x3 else "", M, N, K)
+    # (the split-bf16 launches are their own family in bench.py's roofline accounting: another kernel, gemm_x3_kernel, with three MFMAs per
+    #  product term and fp32 operands)
+    label = "%s <%s,%s%s> M=%d N=%d K=%d" % ("fabind_gemm_x3" if x3 else "fabind_gemm", str(A.dtype).replace("torch.", ""),
+                                             str(W.dtype).replace("torch.", ""), ",x3" if x3 else "", M, N, K)
     if groups is not None:
         label += " (ragged, %d groups)" % n_groups
     # algorithmic HBM bytes: every operand read once, every result written once (ragged launches: not counted)

@@ -589,8 +589,8 @@ def _gemm_rowdot(x, W, b, u, act_pro, act_epi, store, p_drop=0.0, seed=0, fold=N
         a.row_mu, a.row_rs, a.col_c = ptr(fold[0]), ptr(fold[1]), ptr(fold[2])
     x3 = x.dtype == torch.float32 and W.dtype == torch.float32 and _cfg.get_precision() == "bf16x3"
     a.split3 = 1 if x3 else 0
-    label = "fabind_gemm <%s,%s%s> M=%d N=%d K=%d" % (str(x.dtype).replace("torch.", ""), str(W.dtype).replace("torch.", ""),
-                                                      ",x3" if x3 else "", M, N, Kd)
+    label = "%s <%s,%s%s> M=%d N=%d K=%d" % ("fabind_gemm_x3" if x3 else "fabind_gemm", str(x.dtype).replace("torch.", ""),
+                                             str(W.dtype).replace("torch.", ""), ",x3" if x3 else "", M, N, Kd)
     K._profiled(label, 2.0 * M * N * Kd, lambda: check(load().fabind_gemm(ctypes.byref(a), stream()), "fabind_gemm(rowdot)"))
     return z, part
 
