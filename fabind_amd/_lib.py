@@ -86,6 +86,8 @@ SIGNATURES = {
     "fabind_layernorm_rows": [_vp, _i, _i, _vp, _vp, _f, _i, _i, _vp, _i, _i, _i, _vp],
     "fabind_edge_ln_concat": [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _i, _vp, _i, _i, _i, _vp],
     "fabind_edge_lnfold": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp, _f, ctypes.c_uint, _vp],
+    "fabind_edge_lnfold_bwd_blocks": [_i],
+    "fabind_edge_lnfold_bwd": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _i, _vp],
     "fabind_inter_coord_fold": [_vp, _i, _i, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _i, _vp, _f, ctypes.c_uint, _vp],
     "fabind_post_optimize": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp],
     "fabind_multi_copy": [_vp, _i, _i, _vp],

@@ -521,6 +521,125 @@ extern "C" int fabind_edge_lnfold(const void* AB, int ldab, int Kp, int H, const
     return 0;
 }
 
+// Adjoint of fabind_edge_lnfold (round 5: the LayerNorm-folded first edge Linear under autograd, FABind_plus egnn.py:52-58).  With
+//   u_k = A[r][k] + B[c][k] + dr c_r[k] + dc c_c[k] + dq w_r[k],   out_k = drop(relu(rs u_k + dvec_k)),
+//   mu = (H (m_r + m_c) + rho) / Cn,  dr = m_r - mu,  dc = m_c - mu,  dq = rho - mu,  rs = rsqrt((Q_r + Q_c + H (dr^2 + dc^2) + dq^2) / Cn + eps)
+// and g_k = dout_k x [out_k != 0] x 1/(1-p) (the zeros of the saved output are the inactive and the dropped positions):
+//   du_k = rs g_k  -> written as bf16 [E, Kp]: the caller sums it over the receiving node (d A) and over the sending node (d B);
+//   per edge: d rs = sum_k g_k u_k, d dr = sum_k du_k c_r[k], d dc = sum_k du_k c_c[k], d dq = sum_k du_k w_r[k], folded through rs and mu into
+//             es[e] = (d m_r, d Q_r, d m_c, d Q_c, 0, 0, 0, 0), drho[e]   (the caller's segment sums over the receiving / sending node);
+//   per column: d dvec = sum_e g, d c_r = sum_e du dr, d c_c = sum_e du dc, d w_r = sum_e du dq  -> part[block][4][Kp] partials.
+// u is rebuilt from a second gather of the two projection rows (L2-resident).  One wave per edge, lane l owns the 8-column chunks
+// l, l + 64, ... (NPL of them), whose four column accumulators it keeps in registers across the wave's walk over the edges.
+template <int NPL>
+__global__ __launch_bounds__(256) void edge_lnfold_bwd_kernel(const bf16_t* __restrict__ AB, int ldab, int Kp, int H,
+                                                              const int* __restrict__ row, const int* __restrict__ col,
+                                                              const float* __restrict__ rho, const float2* __restrict__ stat, float eps,
+                                                              const float* __restrict__ w_r, const float* __restrict__ c_r,
+                                                              const float* __restrict__ c_c, const bf16_t* __restrict__ out,
+                                                              const bf16_t* __restrict__ dout, int E, float dscale, bf16_t* __restrict__ du,
+                                                              float4* __restrict__ es, float* __restrict__ drho,
+                                                              float* __restrict__ part) {
+    extern __shared__ float sred[];                                   // [4 waves][4 vectors][Kp] at the end
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nw = gridDim.x * 4, CH = Kp >> 3;
+    float a_dv[NPL][8], a_cr[NPL][8], a_cc[NPL][8], a_wr[NPL][8];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { a_dv[k][q] = 0.f; a_cr[k][q] = 0.f; a_cc[k][q] = 0.f; a_wr[k][q] = 0.f; }
+    const float Cn = (float)(2 * H + 1), Hf = (float)H;
+    for (int e = blockIdx.x * 4 + wv; e < E; e += nw) {
+        const int r = row[e], c = col[e];
+        const float rh = rho[e];
+        const float2 sr = stat[r], sc = stat[c];
+        const float mu = (Hf * (sr.x + sc.x) + rh) / Cn;
+        const float dr = sr.x - mu, dc = sc.x - mu, dq = rh - mu;
+        const float rs = rsqrtf((sr.y + sc.y + Hf * (dr * dr + dc * dc) + dq * dq) / Cn + eps);
+        const bf16_t* ar = AB + (size_t)r * ldab;
+        const bf16_t* bc = AB + (size_t)c * ldab + Kp;
+        float s_gu = 0.f, s_cr = 0.f, s_cc = 0.f, s_wr = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int ch = k * 64 + lane;
+            if (ch < CH) {
+                const uint4 ua = *(const uint4*)(ar + ch * 8), ub = *(const uint4*)(bc + ch * 8);
+                const uint4 uo = *(const uint4*)(out + (size_t)e * Kp + ch * 8), ug = *(const uint4*)(dout + (size_t)e * Kp + ch * 8);
+                const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w}, wb[4] = {ub.x, ub.y, ub.z, ub.w};
+                const uint32_t wo[4] = {uo.x, uo.y, uo.z, uo.w}, wg[4] = {ug.x, ug.y, ug.z, ug.w};
+                float d8[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int cq = ch * 8 + q;
+                    const float a = __uint_as_float((q & 1) ? (wa[q >> 1] & 0xffff0000u) : (wa[q >> 1] << 16));
+                    const float b = __uint_as_float((q & 1) ? (wb[q >> 1] & 0xffff0000u) : (wb[q >> 1] << 16));
+                    const uint32_t ob = (q & 1) ? (wo[q >> 1] & 0xffff0000u) : (wo[q >> 1] << 16);
+                    const float gy = __uint_as_float((q & 1) ? (wg[q >> 1] & 0xffff0000u) : (wg[q >> 1] << 16));
+                    const float crk = c_r[cq], cck = c_c[cq], wrk = w_r[cq];
+                    const float u = a + b + dr * crk + dc * cck + dq * wrk;
+                    const float g = (ob & 0x7fffffffu) ? gy * dscale : 0.f;
+                    const float d_ = rs * g;
+                    s_gu += g * u; s_cr += d_ * crk; s_cc += d_ * cck; s_wr += d_ * wrk;
+                    a_dv[k][q] += g; a_cr[k][q] += d_ * dr; a_cc[k][q] += d_ * dc; a_wr[k][q] += d_ * dq;
+                    d8[q] = d_;
+                }
+                uint4 o;
+                o.x = pack2_bf16(d8[0], d8[1]); o.y = pack2_bf16(d8[2], d8[3]); o.z = pack2_bf16(d8[4], d8[5]); o.w = pack2_bf16(d8[6], d8[7]);
+                *(uint4*)(du + (size_t)e * Kp + ch * 8) = o;
+            }
+        }
+        s_gu = wave_sum(s_gu); s_cr = wave_sum(s_cr); s_cc = wave_sum(s_cc); s_wr = wave_sum(s_wr);
+        if (lane == 0) {
+            // rs = (V + eps)^(-1/2), V = (Q_r + Q_c + H (dr^2 + dc^2) + dq^2) / Cn
+            const float dV = -0.5f * rs * rs * rs * s_gu;
+            const float dQ = dV / Cn;
+            const float ddr = s_cr + dV * 2.f * Hf * dr / Cn, ddc = s_cc + dV * 2.f * Hf * dc / Cn, ddq = s_wr + dV * 2.f * dq / Cn;
+            const float dmu = -(ddr + ddc + ddq);                  // dr, dc, dq = (m_r, m_c, rho) - mu
+            es[(size_t)e * 2] = make_float4(ddr + dmu * Hf / Cn, dQ, ddc + dmu * Hf / Cn, dQ);      // (d m_r, d Q_r, d m_c, d Q_c | 0 0 0 0)
+            es[(size_t)e * 2 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            drho[e] = ddq + dmu / Cn;
+        }
+    }
+    // block partials of the four column sums: waves 0 .. 3 in order
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const int ch = k * 64 + lane;
+            if (ch < CH)
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    sred[(wv * 4 + v) * Kp + ch * 8 + q] = v == 0 ? a_dv[k][q] : v == 1 ? a_cr[k][q] : v == 2 ? a_cc[k][q] : a_wr[k][q];
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * Kp; i += 256)
+        part[(size_t)blockIdx.x * 4 * Kp + i] = ((sred[i] + sred[4 * Kp + i]) + sred[8 * Kp + i]) + sred[12 * Kp + i];
+}
+extern "C" int fabind_edge_lnfold_bwd_blocks(int E) { return (int)std::min<size_t>(((size_t)E + 3) / 4, (size_t)256 * 4); }
+extern "C" int fabind_edge_lnfold_bwd(const void* AB, int ldab, int Kp, int H, const int* row, const int* col, const float* rho,
+                                      const float* stat, float eps, const float* w_r, const float* c_r, const float* c_c,
+                                      const void* out, const void* dout, int E, float p_drop, void* du, float* es,
+                                      float* drho, float* part, int n_blocks, hipStream_t stream) {
+    if (E <= 0) return 0;
+    FB_REQUIRE(Kp % 8 == 0 && ldab % 8 == 0 && ldab >= 2 * Kp && Kp <= 8 * 64 * 3, "fabind_edge_lnfold_bwd: Kp % 8, ldab % 8, ldab >= 2 Kp, Kp <= 1536");
+    FB_REQUIRE(p_drop >= 0.f && p_drop < 1.f && n_blocks > 0, "fabind_edge_lnfold_bwd: p_drop in [0, 1), n_blocks > 0");
+    const uint32_t thr = (uint32_t)(p_drop * 65536.0f + 0.5f);
+    const float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
+    const size_t lds = (size_t)16 * Kp * sizeof(float);
+    const int npl = (Kp / 8 + 63) / 64;
+#define ELB_LAUNCH(NN)                                                                                                             \
+    do {                                                                                                                           \
+        static bool set_ = false;                                                                                                  \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)edge_lnfold_bwd_kernel<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        hipLaunchKernelGGL(edge_lnfold_bwd_kernel<NN>, dim3(n_blocks), dim3(256), lds, stream, (const bf16_t*)AB, ldab, Kp, H, row, col, rho, \
+                           (const float2*)stat, eps, w_r, c_r, c_c, (const bf16_t*)out, (const bf16_t*)dout, E, dscale, (bf16_t*)du,  \
+                           (float4*)es, drho, part);                                                                                \
+    } while (0)
+    if (npl <= 1) ELB_LAUNCH(1); else if (npl == 2) ELB_LAUNCH(2); else ELB_LAUNCH(3);
+#undef ELB_LAUNCH
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
 // coord_mlp of FABind+'s inter-edge attention (egnn.py:277-300: LN -> Linear -> relu -> [dropout] -> bias-free Linear to
 // one scalar) on v_e = V[col] + rho * w_rv, with the LayerNorm folded into a per-node projection (bf16 inference):
 //   s[e] = sum_k w3[k] * drop(relu( rs_e * (P[col[e], k] + rho[e] * u[k]) + d[k] ))

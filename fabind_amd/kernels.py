@@ -621,6 +621,24 @@ def edge_lnfold(AB16, Kp, H, row, col, rho, stat, eps, w_r, c_r, c_c, dvec, p_dr
     return out
 
 
+def edge_lnfold_bwd(AB16, Kp, H, row, col, rho, stat, eps, w_r, c_r, c_c, out, dout, p_drop=0.0):
+    """Adjoint of edge_lnfold (csrc/norm.hip: edge_lnfold_bwd_kernel) -> (du bf16 [E, Kp], es fp32 [E, 8] = (d m_r, d Q_r, d m_c, d Q_c, 0...),
+    drho [E], vecs fp32 [4, Kp] = column sums d dvec, d c_r, d c_c, d w_r)."""
+    E = row.shape[0]
+    dev = AB16.device
+    lib = _lib.load()
+    nb = max(1, int(lib.fabind_edge_lnfold_bwd_blocks(E)))
+    du = torch.empty((max(E, 1), Kp), dtype=torch.bfloat16, device=dev)
+    es = torch.empty((max(E, 1), 8), dtype=torch.float32, device=dev)
+    drho = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
+    part = torch.empty((nb, 4 * Kp), dtype=torch.float32, device=dev)
+    assert AB16.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and dout.dtype == torch.bfloat16 and dout.is_contiguous() and out.is_contiguous()
+    check(lib.fabind_edge_lnfold_bwd(ptr(AB16), _ld(AB16), Kp, H, ptr(row), ptr(col), ptr(rho), ptr(stat), float(eps), ptr(w_r), ptr(c_r),
+                                     ptr(c_c), ptr(out), ptr(dout), E, float(p_drop), ptr(du), ptr(es), ptr(drho), ptr(part), nb,
+                                     stream()), "fabind_edge_lnfold_bwd")
+    return du[:E], es[:E], drho[:E], colsum(part).view(4, Kp)
+
+
 def inter_coord_fold(P16, H, col, rho, stat, q_w, eps, u, d, w3, p_drop=0.0, seed=0):
     """Per-edge coordinate scalar of FABind+'s inter-edge layer from per-node projections (csrc/norm.hip) -> fp32 [E]."""
     E = col.shape[0]

@@ -91,7 +91,8 @@ def _gcl_pack(m, H, pk=None):
         d["coord"]["foldp"] = dict(W1w=W(Wc), cvec=Wc.to(wd).float().sum(1).contiguous(), eps=float(cm.layernorm.eps),
                                    dvec=(cm.linear1.weight.float() @ cm.layernorm.bias.float() + cm.linear1.bias.float()).contiguous())
     if wd == torch.bfloat16 and infer:
-        # LayerNorm folded into per-node projections of the first edge Linear (csrc/norm.hip: edge_lnfold_kernel)
+        # LayerNorm folded into per-node projections of the first edge Linear (csrc/norm.hip: edge_lnfold_kernel); under autograd the
+        # same operands are built per call by _fold_train below
         em = m.edge_mlp
         W1w = _padded(em.linear1.weight.float() * em.layernorm.weight.float()[None, :], K8, 2 * H + 1)
         d["fold"] = dict(W_ab=W(_cat([W1w[:, :H], W1w[:, H:2 * H]])), w_r=W1w[:, 2 * H].contiguous(),
@@ -244,6 +245,8 @@ def _build_stack_params(model):
         P["gcl"] = [_gcl_pack(getattr(gnn, "gcl_%d" % i), H) for i in range(L)]
         P["out_layer"] = _gcl_pack(gnn.out_layer, H)
         P["att"] = [_att_pack(getattr(gnn, "att_%d" % i), H) for i in range(L)]
+        if torch.is_grad_enabled():
+            _fold_train(P, model)
         return P
     from .. import engine as _e
     params = _e.last_params_of(model)
@@ -256,7 +259,39 @@ def _build_stack_params(model):
         pk = ParamPack(model.inter_layer.linear_p.weight.device)
         tree = _stack_requests(model, pk)
         _PLAN_CACHE[id(model)] = (key, pk, tree, weakref.ref(model, lambda _r, k=id(model): _PLAN_CACHE.pop(k, None)))
-    return pk.resolve(tree)
+    P = pk.resolve(tree)
+    _fold_train(P, model)
+    return P
+
+
+def _fold_train(P, model):
+    """The LayerNorm-folded operands of every MC_E_GCL's first edge Linear UNDER AUTOGRAD (round 5: _EdgeLnFold), as differentiable torch
+    ops on the modules' own fp32 parameters, all layers at once (the six edge MLPs have one shape: a dozen batched launches per model call
+    each way): W_ab = [W1 diag(ln_w)]_{r|c} (bf16, rows zero-padded to the kernel's K8), w_r = its rho column, c_r / c_c = the row sums of
+    the two blocks, dvec = W1 ln_b + b1.  linear1 / LayerNorm of the edge MLPs reach the kernels ONLY through this composition in that
+    mode (their parameter-pack entries are unused and receive no gradient from the pack's adjoint)."""
+    if not (FOLD_EDGE_LN_TRAIN and FOLD_EDGE_LN and _wd() == torch.bfloat16):
+        return
+    gnn = model.gnn
+    H, L = P["H"], P["L"]
+    mods = [getattr(gnn, "gcl_%d" % i) for i in range(L)] + [gnn.out_layer]
+    C, K8 = 2 * H + 1, _pad8(2 * H + 1)
+    if K8 > 1536 or K8 % 16 != 0 or any(m.edge_mlp.linear1.weight.shape != (C, C) for m in mods):
+        return
+    F = torch.nn.functional
+    W1 = torch.stack([m.edge_mlp.linear1.weight for m in mods]).float()                      # [L + 1, C, C]
+    lw = torch.stack([m.edge_mlp.layernorm.weight for m in mods]).float()
+    lb = torch.stack([m.edge_mlp.layernorm.bias for m in mods]).float()
+    b1 = torch.stack([m.edge_mlp.linear1.bias for m in mods]).float()
+    W1w = F.pad(W1 * lw[:, None, :], (0, 0, 0, K8 - C))                                        # [L + 1, K8, C]: rows padded with zeros
+    W_ab = torch.cat([W1w[:, :, :H], W1w[:, :, H:2 * H]], 1).to(torch.bfloat16).contiguous()   # [L + 1, 2 K8, H]
+    w_r = W1w[:, :, 2 * H].contiguous()
+    c_r, c_c = W1w[:, :, :H].sum(2), W1w[:, :, H:2 * H].sum(2)
+    dvec = F.pad(torch.bmm(W1, lb[:, :, None]).squeeze(2) + b1, (0, K8 - C))
+    for i, (d_, wab, wr, cr, cc, dv) in enumerate(zip(list(P["gcl"]) + [P["out_layer"]], W_ab.unbind(0), w_r.unbind(0), c_r.unbind(0),
+                                                        c_c.unbind(0), dvec.unbind(0))):
+        d_["fold"] = dict(W_ab=wab, w_r=wr.contiguous(), c_r=cr.contiguous(), c_c=cc.contiguous(), dvec=dv.contiguous(),
+                          eps=float(mods[i].edge_mlp.layernorm.eps))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -411,6 +446,41 @@ def pair_had(T, Hh, p_node, c_node, out_dtype, lay=None):
     return _pair_hadamard_call(T, Hh, p_node, c_node, out_dtype)
 
 
+class _EdgeLnFold(torch.autograd.Function):
+    """relu(W1 LN([h_r | h_c | rho]) + b1) (+ dropout) of the edge LN-MLP from per-node projections AB and per-node statistics, under
+    autograd (round 5; FABind_plus egnn.py:52-58, model_utils.py:44-46): forward = the inference kernel (csrc/norm.hip: edge_lnfold), a
+    gather; backward = edge_lnfold_bwd (one pass over the [E, Kp] gradient: mask, rs, the four per-edge row-dots, the column sums of the
+    four vectors) + the two segment sums the concatenation's adjoint ran anyway (receiving side, sending side through the by-sender
+    permutation) + segment sums of eight floats per edge for the statistics.  The [E, 2H+1] concatenation, its LayerNorm, the
+    E x (2H+1) x (2H+1) contraction, its input-gradient GEMM and its weight-gradient contraction do not exist: the weight gradient is a
+    NODE-level contraction (autograd of AB = hcen W_ab^T)."""
+
+    @staticmethod
+    def forward(ctx, AB, stat, rhohat, w_r, c_r, c_c, dvec, g, H, Kp, eps, pd, seed):
+        t = K.edge_lnfold(AB, Kp, H, g.row_ctx, g.col_ctx, rhohat, stat, eps, w_r, c_r, c_c, dvec, pd, seed)
+        ctx.g, ctx.H, ctx.Kp, ctx.eps, ctx.pd = g, H, Kp, eps, pd
+        ctx.save_for_backward(AB, stat, rhohat, w_r, c_r, c_c, t)
+        return t
+
+    @staticmethod
+    def backward(ctx, dt):
+        AB, stat, rhohat, w_r, c_r, c_c, t = ctx.saved_tensors
+        g, H, Kp = ctx.g, ctx.H, ctx.Kp
+        N = AB.shape[0]
+        dt = dt.contiguous() if dt.dtype == torch.bfloat16 else dt.to(torch.bfloat16).contiguous()
+        du, es, drho, vecs = K.edge_lnfold_bwd(AB, Kp, H, g.row_ctx, g.col_ctx, rhohat, stat, ctx.eps, w_r, c_r, c_c, t, dt, ctx.pd)
+        colptr, perm = g.ctx_by_col()
+        dAB = torch.empty((N, 2 * Kp), dtype=torch.bfloat16, device=AB.device)
+        half = (Kp // 2 + 7) // 8 * 8                          # (the segment-sum kernel takes <= 1024 columns: two column ranges per side)
+        for lo, hi in ((0, half), (half, Kp)):
+            K.segment_sum(du[:, lo:hi], g.rp_ctx, N, out16=dAB[:, lo:hi])
+            K.segment_sum(du[:, lo:hi], colptr, N, eidx=perm, out16=dAB[:, Kp + lo:Kp + hi])
+        by_r = K.segment_sum(es, g.rp_ctx, N)                  # [N, 8]: columns 0, 1 = d (m, Q) through the edges a node RECEIVES
+        by_c = K.segment_sum(es, colptr, N, eidx=perm)         #         columns 2, 3 = through the edges it SENDS
+        dstat = torch.stack([by_r[:, 0] + by_c[:, 2], by_r[:, 1] + by_c[:, 3]], 1)
+        return dAB, dstat, drho, vecs[3], vecs[1], vecs[2], vecs[0], None, None, None, None, None, None
+
+
 class _InterView:
     """The inter graph under the attribute names ops.gcl_pre reads (row_ctx / col_ctx / rp_ctx / ctx_by_col)."""
 
@@ -495,7 +565,18 @@ def gcl_layer(p, h, x, lay, g, clampv, pd=0.0):
     H = h.shape[1]
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay, g.ctx_by_col)
     grad = ops.needs_grad(h, x, e["W1"])
-    if grad:       # the concatenation is materialised so that LayerNorm is a separate differentiable step
+    if grad and FOLD_EDGE_LN_TRAIN and FOLD_EDGE_LN and "fold" in p and ad == torch.bfloat16 and e["k_pad"] <= 1536 and e["k_pad"] % 16 == 0:
+        # training, bf16: the LayerNorm-folded first Linear under autograd (_EdgeLnFold); the node-level pieces are torch ops / ops.linear
+        f = p["fold"]
+        hf = h.float()
+        mean = hf.mean(1)
+        hcen = hf - mean[:, None]
+        stat = torch.stack([mean, (hcen * hcen).sum(1)], 1).contiguous()                            # [N, 2]
+        AB = ops.linear(hcen, f["W_ab"], None, out_dtype=torch.bfloat16)                             # [N, 2 K8]
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if pd > 0.0 else 0
+        t = _EdgeLnFold.apply(AB, stat, rhohat, f["w_r"], f["c_r"], f["c_c"], f["dvec"], g, H, e["k_pad"], f["eps"], pd, seed)
+        m = ops.linear(t, e["W2"], e["b2"], act_epi=K.ACT_RELU, out_dtype=ad, p_drop=pd)            # [E, H] messages
+    elif grad:     # the concatenation is materialised so that LayerNorm is a separate differentiable step
         cat = _EdgeConcat.apply(h, rhohat, g.row_ctx, g.col_ctx, g.rp_ctx, g.ctx_by_col, ad, e["k_pad"])
         y = ln_rows(cat[:, :2 * H + 1], e["ln_w"], e["ln_b"], ad, e["k_pad"])
         if MLP2_NODE and EPI_DROP_GRAD and y.dtype == torch.bfloat16 and e["W1"].dtype == torch.bfloat16:
@@ -531,6 +612,7 @@ def gcl_layer(p, h, x, lay, g, clampv, pd=0.0):
 
 
 FUSE_PAIR = os.environ.get("FABIND_PLUS_FUSE_PAIR", "1") == "1"
+FOLD_EDGE_LN_TRAIN = os.environ.get("FABIND_PLUS_FOLD_EDGE_LN_TRAIN", "1") == "1"     # 0: under autograd concat -> LayerNorm -> GEMM (rounds 1-4; A/B)
 FOLD_EDGE_LN = os.environ.get("FABIND_PLUS_FOLD_EDGE_LN", "1") == "1"
 
 

@@ -59,7 +59,8 @@ const char* fabind_last_error(void);
  * 17 = round-5 retirement of knob-only kernels: fabind_gemm_set_big removed (256 x 256 GEMM tiles); fabind_gcl_edge_fused_set_variant accepts 1 only,
  *     fabind_gcl_edge_fused_bwd_set_variant 0 / 5 only, fabind_gcl_edge_fused_bwd_set_tile 64 only (their other kernels are no longer built);
  *     fabind_gcl_edge_fused_x3_train added (the split-bf16 forward that saves M / silu'(pre2) / pre3 for the two-contraction backward);
- *     fabind_inter_attn_fwd_rows / fabind_inter_attn_bwd_rows added (inter-edge attention with the rows dealt by degree: heavy rows on four waves).
+ *     fabind_inter_attn_fwd_rows / fabind_inter_attn_bwd_rows added (inter-edge attention with the rows dealt by degree: heavy rows on four waves);
+ *     fabind_edge_lnfold_bwd (+ _blocks) added (FABind+: the LayerNorm-folded first edge Linear under autograd).
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 17
 int fabind_abi_version(void);
@@ -524,6 +525,16 @@ int fabind_edge_ln_concat(const float* h, int ldh, int H, const int* row, const 
 int fabind_edge_lnfold(const void* AB, int ldab, int Kp, int H, const int* row, const int* col, const float* rho,
                        const float* stat, float eps, const float* w_r, const float* c_r, const float* c_c, const float* dvec,
                        int E, void* out, float p_drop, unsigned seed, hipStream_t stream);
+/* Adjoint of fabind_edge_lnfold (round 5: the folded first edge Linear under autograd): out = what the forward wrote (its zeros are the
+ * inactive and the dropped positions), dout = its gradient (bf16 [E, Kp]).  Writes du = rs_e x dout x mask x 1/(1-p) as bf16 [E, Kp] (the
+ * caller's segment sums over the receiving / sending node give the gradient of AB's two halves), es = fp32 [E][8] = (d m_r, d Q_r, d m_c,
+ * d Q_c, 0, 0, 0, 0): the gradients of the receiving / sending node's statistics through this edge, drho [E], and part = fp32 [n_blocks][4][Kp]
+ * partial column sums (d dvec, d c_r, d c_c, d w_r); n_blocks = fabind_edge_lnfold_bwd_blocks(E).  Kp <= 1536. */
+int fabind_edge_lnfold_bwd_blocks(int E);
+int fabind_edge_lnfold_bwd(const void* AB, int ldab, int Kp, int H, const int* row, const int* col, const float* rho,
+                           const float* stat, float eps, const float* w_r, const float* c_r, const float* c_c,
+                           const void* out, const void* dout, int E, float p_drop, void* du, float* es,
+                           float* drho, float* part, int n_blocks, hipStream_t stream);
 
 /* coord_mlp of FABind+'s inter-edge attention layer (egnn.py:277-300; LN -> Linear -> relu -> dropout -> bias-free Linear)
  * on the value rows v_e = V[col] + rho * w_rv, LayerNorm folded into a per-node projection, bf16 inference:

@@ -396,3 +396,137 @@ def test_device_dbscan_labels_equal_sklearn():
         for b in range(B):
             ref = DBSCAN(eps=eps, min_samples=ms).fit(pts[b, :n[b]]).labels_
             assert np.array_equal(ref, lab[b, :n[b]]) and (lab[b, n[b]:] == -1).all(), (trial, b)
+
+
+def _fold_fixture(dev, N, H, deg, seed):
+    """A random row-sorted edge list with its by-sender permutation and one edge LN-MLP's first Linear + LayerNorm."""
+    from types import SimpleNamespace
+    gen = torch.Generator().manual_seed(seed)
+    row = torch.sort(torch.randint(0, N, (N * deg,), generator=gen)).values
+    col = torch.randint(0, N, (N * deg,), generator=gen)
+    rp = torch.zeros(N + 1, dtype=torch.int64)
+    rp[1:] = torch.cumsum(torch.bincount(row, minlength=N), 0)
+    perm = torch.argsort(col, stable=True)
+    cp = torch.zeros(N + 1, dtype=torch.int64)
+    cp[1:] = torch.cumsum(torch.bincount(col, minlength=N), 0)
+    i32 = lambda t: t.to(torch.int32).to(dev)
+    g = SimpleNamespace(row_ctx=i32(row), col_ctx=i32(col), rp_ctx=i32(rp), ctx_by_col=lambda: (i32(cp), i32(perm)))
+    C = 2 * H + 1
+    lin, ln = torch.nn.Linear(C, C), torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.2 * torch.randn(C, generator=gen))
+        ln.bias.copy_(0.1 * torch.randn(C, generator=gen))
+    mod = SimpleNamespace(edge_mlp=SimpleNamespace(linear1=lin.to(dev), layernorm=ln.to(dev)))
+    h = (0.7 + torch.randn(N, H, generator=gen)).to(dev)              # a non-zero mean: the centred form is exercised
+    rho = torch.rand(N * deg, generator=gen).to(dev)
+    cot = torch.randn(N * deg, C, generator=gen).to(dev)
+    return g, mod, h, rho, cot, row.to(dev), col.to(dev)
+
+
+@pytest.mark.parametrize("H,pd", [(64, 0.0), (512, 0.0), (128, 0.1)])
+def test_edge_lnfold_under_autograd_matches_concat_layernorm_linear(H, pd):
+    """_EdgeLnFold (round 5: the LayerNorm-folded first edge Linear of FABind+'s MC_E_GCL under autograd, egnn.py:52-58 /
+    model_utils.py:44-46) against relu(linear1(LayerNorm([h_r | h_c | rho]))) in fp32 torch: the output and the gradients of the node
+    features, rho, linear1 (weight, bias) and the LayerNorm (weight, bias).  With dropout the kernel's own mask (the zeros of its
+    output) is applied to the torch side."""
+    from types import SimpleNamespace
+    from fabind_amd import engine, ops
+    from fabind_amd.plus import engine as pe
+    dev = torch.device("cuda:0")
+    N, deg = 200, 12
+    g, mod, h, rho, cot, row, col = _fold_fixture(dev, N, H, deg, seed=H)
+    C, K8 = 2 * H + 1, pe._pad8(2 * H + 1)
+    lin, ln = mod.edge_mlp.linear1, mod.edge_mlp.layernorm
+    engine.set_precision("bf16")
+    try:
+        P = {"H": H, "L": 1, "gcl": [{}], "out_layer": {}}
+        model = SimpleNamespace(gnn=SimpleNamespace(gcl_0=mod, out_layer=mod))
+        with torch.enable_grad():
+            pe._fold_train(P, model)
+            f = P["gcl"][0]["fold"]
+            h1, rho1 = h.clone().requires_grad_(True), rho.clone().requires_grad_(True)
+            mean = h1.mean(1)
+            hcen = h1 - mean[:, None]
+            stat = torch.stack([mean, (hcen * hcen).sum(1)], 1).contiguous()
+            AB = ops.linear(hcen, f["W_ab"], None, out_dtype=torch.bfloat16)
+            t = pe._EdgeLnFold.apply(AB, stat, rho1, f["w_r"], f["c_r"], f["c_c"], f["dvec"], g, H, K8, f["eps"], pd, 1234)
+            assert t.shape == (N * deg, K8) and t.dtype == torch.bfloat16
+            assert float(t[:, C:].abs().max()) == 0.0
+            (t[:, :C].float() * cot).sum().backward()
+        got = dict(h=h1.grad, rho=rho1.grad, W=lin.weight.grad.clone(), b=lin.bias.grad.clone(), lw=ln.weight.grad.clone(),
+                   lb=ln.bias.grad.clone())
+        for p_ in (lin.weight, lin.bias, ln.weight, ln.bias):
+            p_.grad = None
+    finally:
+        engine.set_precision("fp32")
+    h2, rho2 = h.clone().requires_grad_(True), rho.clone().requires_grad_(True)
+    y = torch.relu(lin(ln(torch.cat([h2[row], h2[col], rho2[:, None]], 1))))
+    if pd > 0.0:
+        keep = (t[:, :C] != 0) | (y.detach() <= 1e-2)            # the kernel's mask where the activation is clearly positive
+        frac = 1.0 - float(((t[:, :C] != 0) & (y.detach() > 1e-2)).sum()) / float((y.detach() > 1e-2).sum())
+        assert abs(frac - pd) < 0.01, frac
+        y = y * keep / (1.0 - pd)
+    (y * cot).sum().backward()
+    ref = dict(h=h2.grad, rho=rho2.grad, W=lin.weight.grad, b=lin.bias.grad, lw=ln.weight.grad, lb=ln.bias.grad)
+    err = float((t[:, :C].float() - y.detach()).abs().max()) / float(y.detach().abs().max())
+    rows = {k: float((got[k].float() - ref[k]).norm() / ref[k].norm()) for k in ref}
+    print("edge LN-fold under autograd, H=%d p=%.1f: output max err %.2e of max; gradient relative L2 errors %s"
+          % (H, pd, err, {k: "%.1e" % v for k, v in rows.items()}))
+    assert err < 1.5e-2                                           # one bf16 rounding of the projections and of the output
+    assert all(v < 1.5e-2 for v in rows.values()), rows
+
+
+def test_plus_stack_training_with_the_folded_edge_layernorm_follows_weight_updates():
+    """The folded operands are composed from the modules' parameters on EVERY call (the parameter-pack plan is cached across steps):
+    two training-mode calls of the FABind+ stack with an update of the edge MLPs' first Linear and LayerNorm in between, the fold
+    switched on and off -- outputs and every parameter gradient agree to bf16 accuracy at both steps, and step 2 differs from step 1."""
+    from fabind_amd import engine, synthetic
+    from fabind_amd.plus import engine as pe
+    from fabind_amd.plus.models.att_model import EfficientMCAttModel
+    dev = torch.device("cuda:0")
+    hidden, layers = 128, 2
+    torch.manual_seed(0)
+    m = EfficientMCAttModel(_args(hidden, layers, 1), hidden, hidden, 1, n_layers=layers, n_iter=1, normalize_coord=lambda x: x / 5.0,
+                            unnormalize_coord=lambda x: x * 5.0).to(dev).eval()          # eval: no dropout, so the two runs are comparable
+    inp = synthetic.make_stack_batch([(150, 14), (90, 9)], hidden, seed=5)
+    t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in inp.items()}
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    cot = torch.randn(t["X"].shape, generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def two_steps(fold):
+        m.load_state_dict(sd0)
+        old = pe.FOLD_EDGE_LN_TRAIN
+        pe.FOLD_EDGE_LN_TRAIN = fold
+        engine.set_precision("bf16")
+        res = []
+        try:
+            for step in range(2):
+                for p_ in m.parameters():
+                    p_.grad = None
+                X, Hh, Z = m(t["X"].clone(), t["H"], t["batch_id"], t["segment_id"], t["mask"], t["is_global"], t["compound_edge_index"],
+                             t["LAS_edge_index"], t["coord_LAS"])
+                ((X * cot).sum() + 1e-2 * Hh.float().square().mean()).backward()
+                res.append((X.detach().clone(), Hh.detach().float().clone(), {k: p_.grad.clone() for k, p_ in m.named_parameters()
+                                                                                if p_.grad is not None}))
+                with torch.no_grad():
+                    for k, p_ in m.named_parameters():
+                        if "edge_mlp.linear1" in k or "edge_mlp.layernorm" in k:
+                            p_.mul_(0.6)
+        finally:
+            engine.set_precision("fp32")
+            pe.FOLD_EDGE_LN_TRAIN = old
+        return res
+    on, off = two_steps(True), two_steps(False)
+    for step in range(2):
+        (X1, H1, G1), (X0, H0, G0) = on[step], off[step]
+        assert float((X1 - X0).abs().max()) < 2e-2 * float(X0.abs().max())
+        assert float((H1 - H0).abs().max()) < 4e-2 * float(H0.abs().max())
+        assert set(G1) == set(G0)
+        worst = max((float((G1[k] - G0[k]).norm() / (G0[k].norm() + 1e-6 * max(1.0, float(G0[k].abs().max())))), k) for k in G0
+                    if float(G0[k].norm()) > 1e-6)
+        print("FABind+ stack, folded edge LayerNorm under autograd, step %d: worst parameter-gradient relative L2 gap vs the "
+              "concatenation path %.2e (%s)" % (step, worst[0], worst[1]))
+        assert worst[0] < 0.1, worst
+        assert any("edge_mlp.linear1.weight" in k for k in G1) and any("edge_mlp.layernorm.bias" in k for k in G1)
+    moved = float((on[1][1] - on[0][1]).abs().max()) / float(on[0][1].abs().max())
+    assert moved > 0.05, moved                                     # the second call saw the updated edge MLPs
