@@ -428,7 +428,7 @@ def test_edge_lnfold_under_autograd_matches_concat_layernorm_linear(H, pd):
     """_EdgeLnFold (round 5: the LayerNorm-folded first edge Linear of FABind+'s MC_E_GCL under autograd, egnn.py:52-58 /
     model_utils.py:44-46) against relu(linear1(LayerNorm([h_r | h_c | rho]))) in fp32 torch: the output and the gradients of the node
     features, rho, linear1 (weight, bias) and the LayerNorm (weight, bias).  With dropout the kernel's own mask (the zeros of its
-    output) is applied to the torch side."""
+    output) is applied to the torch side; without, only where the pre-activation is within bf16 rounding of zero."""
     from types import SimpleNamespace
     from fabind_amd import engine, ops
     from fabind_amd.plus import engine as pe
@@ -451,7 +451,7 @@ def test_edge_lnfold_under_autograd_matches_concat_layernorm_linear(H, pd):
             AB = ops.linear(hcen, f["W_ab"], None, out_dtype=torch.bfloat16)
             t = pe._EdgeLnFold.apply(AB, stat, rho1, f["w_r"], f["c_r"], f["c_c"], f["dvec"], g, H, K8, f["eps"], pd, 1234)
             assert t.shape == (N * deg, K8) and t.dtype == torch.bfloat16
-            assert float(t[:, C:].abs().max()) == 0.0
+            assert float(t.detach()[:, C:].abs().max()) == 0.0
             (t[:, :C].float() * cot).sum().backward()
         got = dict(h=h1.grad, rho=rho1.grad, W=lin.weight.grad.clone(), b=lin.bias.grad.clone(), lw=ln.weight.grad.clone(),
                    lb=ln.bias.grad.clone())
@@ -460,12 +460,17 @@ def test_edge_lnfold_under_autograd_matches_concat_layernorm_linear(H, pd):
     finally:
         engine.set_precision("fp32")
     h2, rho2 = h.clone().requires_grad_(True), rho.clone().requires_grad_(True)
-    y = torch.relu(lin(ln(torch.cat([h2[row], h2[col], rho2[:, None]], 1))))
+    pre = lin(ln(torch.cat([h2[row], h2[col], rho2[:, None]], 1)))
+    # relu' is taken from the kernel's own output where the pre-activation is within bf16 rounding of zero (a flipped position moves
+    # every gradient by O(1) of its term: 0.15 % of flipped positions read as a 4 % relative L2 gap); elsewhere torch's own
+    near, on = pre.detach().abs() < 2e-2, t[:, :C] != 0
+    mask = torch.where(near, on, pre.detach() > 0)
     if pd > 0.0:
-        keep = (t[:, :C] != 0) | (y.detach() <= 1e-2)            # the kernel's mask where the activation is clearly positive
-        frac = 1.0 - float(((t[:, :C] != 0) & (y.detach() > 1e-2)).sum()) / float((y.detach() > 1e-2).sum())
+        clear = (pre.detach() > 0) & ~near
+        frac = 1.0 - float((on & clear).sum()) / float(clear.sum())
         assert abs(frac - pd) < 0.01, frac
-        y = y * keep / (1.0 - pd)
+        mask = mask & (on | ~clear)                              # the kernel's dropout mask
+    y = pre * mask / (1.0 - pd)
     (y * cot).sum().backward()
     ref = dict(h=h2.grad, rho=rho2.grad, W=lin.weight.grad, b=lin.bias.grad, lw=ln.weight.grad, lb=ln.bias.grad)
     err = float((t[:, :C].float() - y.detach()).abs().max()) / float(y.detach().abs().max())
