@@ -484,7 +484,8 @@ def test_edge_lnfold_under_autograd_matches_concat_layernorm_linear(H, pd):
 def test_plus_stack_training_with_the_folded_edge_layernorm_follows_weight_updates():
     """The folded operands are composed from the modules' parameters on EVERY call (the parameter-pack plan is cached across steps):
     two training-mode calls of the FABind+ stack with an update of the edge MLPs' first Linear and LayerNorm in between, the fold
-    switched on and off -- outputs and every parameter gradient agree to bf16 accuracy at both steps, and step 2 differs from step 1."""
+    switched on and off, both against the fp32 path -- the fold's gaps (outputs, all gradients, the folded parameters' gradients) are no
+    larger than the concatenation path's at both steps, and step 2 differs from step 1."""
     from fabind_amd import engine, synthetic
     from fabind_amd.plus import engine as pe
     from fabind_amd.plus.models.att_model import EfficientMCAttModel
@@ -498,11 +499,11 @@ def test_plus_stack_training_with_the_folded_edge_layernorm_follows_weight_updat
     sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
     cot = torch.randn(t["X"].shape, generator=torch.Generator().manual_seed(1)).to(dev)
 
-    def two_steps(fold):
+    def two_steps(fold, prec="bf16"):
         m.load_state_dict(sd0)
         old = pe.FOLD_EDGE_LN_TRAIN
         pe.FOLD_EDGE_LN_TRAIN = fold
-        engine.set_precision("bf16")
+        engine.set_precision(prec)
         res = []
         try:
             for step in range(2):
@@ -521,17 +522,23 @@ def test_plus_stack_training_with_the_folded_edge_layernorm_follows_weight_updat
             engine.set_precision("fp32")
             pe.FOLD_EDGE_LN_TRAIN = old
         return res
-    on, off = two_steps(True), two_steps(False)
+    on, off, ref = two_steps(True), two_steps(False), two_steps(False, "fp32")
+
+    def gaps(G, G32, keys):
+        num = sum(float((G[k] - G32[k]).square().sum()) for k in keys)
+        return (num / sum(float(G32[k].square().sum()) for k in keys)) ** 0.5
     for step in range(2):
-        (X1, H1, G1), (X0, H0, G0) = on[step], off[step]
-        assert float((X1 - X0).abs().max()) < 2e-2 * float(X0.abs().max())
-        assert float((H1 - H0).abs().max()) < 4e-2 * float(H0.abs().max())
-        assert set(G1) == set(G0)
-        worst = max((float((G1[k] - G0[k]).norm() / (G0[k].norm() + 1e-6 * max(1.0, float(G0[k].abs().max())))), k) for k in G0
-                    if float(G0[k].norm()) > 1e-6)
-        print("FABind+ stack, folded edge LayerNorm under autograd, step %d: worst parameter-gradient relative L2 gap vs the "
-              "concatenation path %.2e (%s)" % (step, worst[0], worst[1]))
-        assert worst[0] < 0.1, worst
-        assert any("edge_mlp.linear1.weight" in k for k in G1) and any("edge_mlp.layernorm.bias" in k for k in G1)
+        (X1, H1, G1), (X0, H0, G0), (Xr, Hr, Gr) = on[step], off[step], ref[step]
+        assert set(G1) == set(G0) == set(Gr)
+        ex = [float((X - Xr).abs().max()) / float(Xr.abs().max()) for X in (X1, X0)]
+        eh = [float((Hh - Hr).abs().max()) / float(Hr.abs().max()) for Hh in (H1, H0)]
+        folded = [k for k in Gr if "edge_mlp.linear1" in k or "edge_mlp.layernorm" in k]
+        assert len(folded) == 4 * (layers + 1)
+        ga, gf = [gaps(G, Gr, list(Gr)) for G in (G1, G0)], [gaps(G, Gr, folded) for G in (G1, G0)]
+        print("FABind+ stack under autograd in bf16 vs fp32, step %d, folded edge LayerNorm / concatenation path: X %.2e / %.2e of max, "
+              "H %.2e / %.2e, all gradients (relative L2) %.2e / %.2e, the folded parameters' gradients %.2e / %.2e"
+              % (step, ex[0], ex[1], eh[0], eh[1], ga[0], ga[1], gf[0], gf[1]))
+        assert ex[0] < max(1.5 * ex[1], 5e-3) and eh[0] < max(1.5 * eh[1], 2e-2)
+        assert ga[0] < max(1.5 * ga[1], 2e-2) and gf[0] < max(1.5 * gf[1], 2e-2)
     moved = float((on[1][1] - on[0][1]).abs().max()) / float(on[0][1].abs().max())
     assert moved > 0.05, moved                                     # the second call saw the updated edge MLPs
