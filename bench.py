@@ -699,7 +699,8 @@ def main():
             note="the same with model.train() (dropout, Gumbel noise) and n_iter=8: the reference's training configuration")
         n_it8 = 8
         sub("plus_train", "plus_train", a.n_iter, steps=4, warmup=2,
-            note="one FABind+ training step (5-layer LN-MLP stack, train mode, 7-term loss with the permutation-invariant term)")
+            note="one FABind+ training step (5-layer LN-MLP stack, train mode, 7-term loss with the permutation-invariant term; round 5: the edge "
+                 "MLP's first Linear with its LayerNorm folded into per-node projections under autograd)")
         sub("plus_train_gate", "plus_train", a.n_iter, precision="bf16x3", steps=3, warmup=1,
             note="plus_train in the gate-meeting split-bf16 mode")
         sub("plus_sampling", "plus_sampling", n_it8, steps=2,
