@@ -422,7 +422,15 @@ __global__ __launch_bounds__(256) void edge_lnfold_kernel(const bf16_t* __restri
 // of the 2H leading columns with their four per-column vectors held in registers across the wave's grid-stride walk over
 // the edges (per edge and lane: 2 NPL gathered 16-B loads, NPL 16-B stores); the Kp - 2H tail columns (rho's column and
 // the zero padding) go through the first lanes.  The per-edge scalars are wave-uniform.
-template <int NPL>
+#ifndef ELF_U1
+#define ELF_U1 4   // edges in flight per wave and iteration, hidden <= 256 (one chunk per lane)
+#endif
+#ifndef ELF_U2
+#define ELF_U2 2   // hidden 512 (two chunks per lane)
+#endif
+// U edges per wave and iteration (round 5): their indices, then their statistics and gathered rows, are all requested before the first
+// is consumed -- a wave that walks one edge at a time spends its time in three dependent round trips per edge (0.6 TB/s at H = 128).
+template <int NPL, int U, bool TAIL>
 __global__ __launch_bounds__(256) void edge_lnfold_wave_kernel(const bf16_t* __restrict__ AB, int ldab, int Kp, int H,
                                                                const int* __restrict__ row, const int* __restrict__ col,
                                                                const float* __restrict__ rho, const float2* __restrict__ stat,
@@ -433,7 +441,10 @@ __global__ __launch_bounds__(256) void edge_lnfold_wave_kernel(const bf16_t* __r
     const int lane = threadIdx.x & 63;
     const int nw = gridDim.x * 4;
     float wr[NPL][8], cr[NPL][8], cc[NPL][8], dv[NPL][8];
-    const int tail0 = H >> 2, n_tail = (Kp >> 3) - tail0;            // 2H / 8 leading chunks, then rho's column + zero padding
+    // 2H / 8 leading chunks in the lanes' registers, then rho's column + zero padding through the first lanes -- unless ALL Kp / 8 chunks
+    // fit the lanes (H <= 128: 40 chunks): then one pass covers the row (a separate 8-lane tail pass cost as many issue cycles as the
+    // main pass: the kernel is VALU-bound at H = 128, 1.5 ms for 1.54 M edges)
+    const int tail0 = TAIL ? (H >> 2) : (Kp >> 3), n_tail = (Kp >> 3) - tail0;
     bool on[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
@@ -443,55 +454,70 @@ __global__ __launch_bounds__(256) void edge_lnfold_wave_kernel(const bf16_t* __r
         for (int q = 0; q < 8; ++q) { wr[k][q] = w_r[b + q]; cr[k][q] = c_r[b + q]; cc[k][q] = c_c[b + q]; dv[k][q] = dvec[b + q]; }
     }
     const float Cn = (float)(2 * H + 1), Hf = (float)H;
-    for (int e = blockIdx.x * 4 + (threadIdx.x >> 6); e < E; e += nw) {
-        const int r = row[e], c = col[e];
-        const float rh = rho[e];
-        const float2 sr = stat[r], sc = stat[c];
-        const float mu = (Hf * (sr.x + sc.x) + rh) / Cn;
-        const float dr = sr.x - mu, dc = sc.x - mu, dq = rh - mu;
-        const float rs = rsqrtf((sr.y + sc.y + Hf * (dr * dr + dc * dc) + dq * dq) / Cn + eps);
-        const bf16_t* ar = AB + (size_t)r * ldab;
-        const bf16_t* bc = AB + (size_t)c * ldab + Kp;
-        bf16_t* oe = out + (size_t)e * Kp;
-        uint4 ua[NPL], ub[NPL];
+    const bool tl = lane < n_tail;
+    const int tch = tl ? tail0 + lane : 0;
+    for (int e0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * U; e0 < E; e0 += nw * U) {
+        int r[U], c[U];
+        float rh[U];
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            const int o8 = on[k] ? (k * 64 + lane) * 8 : 0;
-            ua[k] = *(const uint4*)(ar + o8); ub[k] = *(const uint4*)(bc + o8);
+        for (int u = 0; u < U; ++u) {
+            const int e = min(e0 + u, E - 1);
+            r[u] = row[e]; c[u] = col[e]; rh[u] = rho[e];
+        }
+        float2 sr[U], sc[U];
+        uint4 ua[U][NPL], ub[U][NPL], ta[U], tb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sr[u] = stat[r[u]]; sc[u] = stat[c[u]];
+            const bf16_t* ar = AB + (size_t)r[u] * ldab;
+            const bf16_t* bc = AB + (size_t)c[u] * ldab + Kp;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const int o8 = on[k] ? (k * 64 + lane) * 8 : 0;
+                ua[u][k] = *(const uint4*)(ar + o8); ub[u][k] = *(const uint4*)(bc + o8);
+            }
+            if (TAIL) { ta[u] = *(const uint4*)(ar + tch * 8); tb[u] = *(const uint4*)(bc + tch * 8); }
         }
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            const uint32_t wa[4] = {ua[k].x, ua[k].y, ua[k].z, ua[k].w}, wb[4] = {ub[k].x, ub[k].y, ub[k].z, ub[k].w};
-            float o[8];
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u;
+            if (e >= E) break;
+            const float mu = (Hf * (sr[u].x + sc[u].x) + rh[u]) / Cn;
+            const float dr = sr[u].x - mu, dc = sc[u].x - mu, dq = rh[u] - mu;
+            const float rs = rsqrtf((sr[u].y + sc[u].y + Hf * (dr * dr + dc * dc) + dq * dq) / Cn + eps);
+            bf16_t* oe = out + (size_t)e * Kp;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const float a = __uint_as_float((q & 1) ? (wa[q >> 1] & 0xffff0000u) : (wa[q >> 1] << 16));
-                const float b = __uint_as_float((q & 1) ? (wb[q >> 1] & 0xffff0000u) : (wb[q >> 1] << 16));
-                float v = fmaxf(rs * (a + b + dr * cr[k][q] + dc * cc[k][q] + dq * wr[k][q]) + dv[k][q], 0.f);
-                if (thr) v *= ((fb_hash32(seed + (uint32_t)e * (uint32_t)Kp + (uint32_t)((k * 64 + lane) * 8 + q)) & 0xffffu) >= thr) ? dscale : 0.f;
-                o[q] = v;
-            }
-            uint4 u;
-            u.x = pack2_bf16(o[0], o[1]); u.y = pack2_bf16(o[2], o[3]); u.z = pack2_bf16(o[4], o[5]); u.w = pack2_bf16(o[6], o[7]);
-            if (on[k]) *(uint4*)(oe + (k * 64 + lane) * 8) = u;
-        }
-        if (lane < n_tail) {
-            const int ch = tail0 + lane;
-            const uint4 ta = *(const uint4*)(ar + ch * 8), tb = *(const uint4*)(bc + ch * 8);
-            const uint32_t wa[4] = {ta.x, ta.y, ta.z, ta.w}, wb[4] = {tb.x, tb.y, tb.z, tb.w};
-            float o[8];
+            for (int k = 0; k < NPL; ++k) {
+                const uint32_t wa[4] = {ua[u][k].x, ua[u][k].y, ua[u][k].z, ua[u][k].w}, wb[4] = {ub[u][k].x, ub[u][k].y, ub[u][k].z, ub[u][k].w};
+                float o[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int cq = ch * 8 + q;
-                const float a = __uint_as_float((q & 1) ? (wa[q >> 1] & 0xffff0000u) : (wa[q >> 1] << 16));
-                const float b = __uint_as_float((q & 1) ? (wb[q >> 1] & 0xffff0000u) : (wb[q >> 1] << 16));
-                float v = fmaxf(rs * (a + b + dr * c_r[cq] + dc * c_c[cq] + dq * w_r[cq]) + dvec[cq], 0.f);
-                if (thr) v *= ((fb_hash32(seed + (uint32_t)e * (uint32_t)Kp + (uint32_t)cq) & 0xffffu) >= thr) ? dscale : 0.f;
-                o[q] = v;
+                for (int q = 0; q < 8; ++q) {
+                    const float a = __uint_as_float((q & 1) ? (wa[q >> 1] & 0xffff0000u) : (wa[q >> 1] << 16));
+                    const float b = __uint_as_float((q & 1) ? (wb[q >> 1] & 0xffff0000u) : (wb[q >> 1] << 16));
+                    float v = fmaxf(rs * (a + b + dr * cr[k][q] + dc * cc[k][q] + dq * wr[k][q]) + dv[k][q], 0.f);
+                    if (thr) v *= ((fb_hash32(seed + (uint32_t)e * (uint32_t)Kp + (uint32_t)((k * 64 + lane) * 8 + q)) & 0xffffu) >= thr) ? dscale : 0.f;
+                    o[q] = v;
+                }
+                uint4 w;
+                w.x = pack2_bf16(o[0], o[1]); w.y = pack2_bf16(o[2], o[3]); w.z = pack2_bf16(o[4], o[5]); w.w = pack2_bf16(o[6], o[7]);
+                if (on[k]) *(uint4*)(oe + (k * 64 + lane) * 8) = w;
             }
-            uint4 u;
-            u.x = pack2_bf16(o[0], o[1]); u.y = pack2_bf16(o[2], o[3]); u.z = pack2_bf16(o[4], o[5]); u.w = pack2_bf16(o[6], o[7]);
-            *(uint4*)(oe + ch * 8) = u;
+            if (TAIL && tl) {
+                const uint32_t wa[4] = {ta[u].x, ta[u].y, ta[u].z, ta[u].w}, wb[4] = {tb[u].x, tb[u].y, tb[u].z, tb[u].w};
+                float o[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int cq = tch * 8 + q;
+                    const float a = __uint_as_float((q & 1) ? (wa[q >> 1] & 0xffff0000u) : (wa[q >> 1] << 16));
+                    const float b = __uint_as_float((q & 1) ? (wb[q >> 1] & 0xffff0000u) : (wb[q >> 1] << 16));
+                    float v = fmaxf(rs * (a + b + dr * c_r[cq] + dc * c_c[cq] + dq * w_r[cq]) + dvec[cq], 0.f);
+                    if (thr) v *= ((fb_hash32(seed + (uint32_t)e * (uint32_t)Kp + (uint32_t)cq) & 0xffffu) >= thr) ? dscale : 0.f;
+                    o[q] = v;
+                }
+                uint4 w;
+                w.x = pack2_bf16(o[0], o[1]); w.y = pack2_bf16(o[2], o[3]); w.z = pack2_bf16(o[4], o[5]); w.w = pack2_bf16(o[6], o[7]);
+                *(uint4*)(oe + tch * 8) = w;
+            }
         }
     }
 }
@@ -503,14 +529,18 @@ extern "C" int fabind_edge_lnfold(const void* AB, int ldab, int Kp, int H, const
     FB_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "fabind_edge_lnfold: p_drop in [0, 1)");
     const uint32_t thr = (uint32_t)(p_drop * 65536.0f + 0.5f);
     const float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
-    if (H % 4 == 0 && H <= 512 && Kp / 8 - H / 4 <= 64) {
+#ifndef ELF_WAVE_MIN_H
+#define ELF_WAVE_MIN_H 0
+#endif
+    if (H % 4 == 0 && H <= 512 && H >= ELF_WAVE_MIN_H && Kp / 8 - H / 4 <= 64) {
         const int blocks = (int)std::min<size_t>(((size_t)E + 3) / 4, (size_t)256 * 8);
-        if (H > 256)
-            hipLaunchKernelGGL(edge_lnfold_wave_kernel<2>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)AB, ldab, Kp, H, row,
-                               col, rho, (const float2*)stat, eps, w_r, c_r, c_c, dvec, E, (bf16_t*)out, thr, dscale, (uint32_t)seed);
-        else
-            hipLaunchKernelGGL(edge_lnfold_wave_kernel<1>, dim3(blocks), dim3(256), 0, stream, (const bf16_t*)AB, ldab, Kp, H, row,
-                               col, rho, (const float2*)stat, eps, w_r, c_r, c_c, dvec, E, (bf16_t*)out, thr, dscale, (uint32_t)seed);
+#define ELF_LAUNCH(NN, UU, TT)                                                                                                      \
+        hipLaunchKernelGGL((edge_lnfold_wave_kernel<NN, UU, TT>), dim3(blocks), dim3(256), 0, stream, (const bf16_t*)AB, ldab, Kp, H, row, \
+                           col, rho, (const float2*)stat, eps, w_r, c_r, c_c, dvec, E, (bf16_t*)out, thr, dscale, (uint32_t)seed)
+        if (H > 256) ELF_LAUNCH(2, ELF_U2, true);
+        else if (Kp / 8 > 64) ELF_LAUNCH(1, ELF_U1, true);
+        else ELF_LAUNCH(1, ELF_U1, false);              // every chunk of the row in one pass (H <= 128)
+#undef ELF_LAUNCH
         FB_CHECK_LAUNCH();
         return 0;
     }
@@ -531,8 +561,20 @@ extern "C" int fabind_edge_lnfold(const void* AB, int ldab, int Kp, int H, const
 //   per column: d dvec = sum_e g, d c_r = sum_e du dr, d c_c = sum_e du dc, d w_r = sum_e du dq  -> part[block][4][Kp] partials.
 // u is rebuilt from a second gather of the two projection rows (L2-resident).  One wave per edge, lane l owns the 8-column chunks
 // l, l + 64, ... (NPL of them), whose four column accumulators it keeps in registers across the wave's walk over the edges.
-template <int NPL>
-__global__ __launch_bounds__(256) void edge_lnfold_bwd_kernel(const bf16_t* __restrict__ AB, int ldab, int Kp, int H,
+#ifndef ELB_U1
+#define ELB_U1 4   // edges in flight per wave and iteration: one chunk per lane (Kp <= 512)
+#endif
+#ifndef ELB_U2
+#define ELB_U2 2   // two chunks per lane
+#endif
+#ifndef ELB_U3
+#define ELB_U3 1   // three chunks per lane (Kp = 1088, the production stack: registers)
+#endif
+#ifndef ELB_MINW
+#define ELB_MINW 1
+#endif
+template <int NPL, int U>
+__global__ __launch_bounds__(256, ELB_MINW) void edge_lnfold_bwd_kernel(const bf16_t* __restrict__ AB, int ldab, int Kp, int H,
                                                               const int* __restrict__ row, const int* __restrict__ col,
                                                               const float* __restrict__ rho, const float2* __restrict__ stat, float eps,
                                                               const float* __restrict__ w_r, const float* __restrict__ c_r,
@@ -544,60 +586,87 @@ __global__ __launch_bounds__(256) void edge_lnfold_bwd_kernel(const bf16_t* __re
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nw = gridDim.x * 4, CH = Kp >> 3;
     float a_dv[NPL][8], a_cr[NPL][8], a_cc[NPL][8], a_wr[NPL][8];
+    bool on[NPL];
 #pragma unroll
-    for (int k = 0; k < NPL; ++k)
+    for (int k = 0; k < NPL; ++k) {
+        on[k] = k * 64 + lane < CH;
 #pragma unroll
         for (int q = 0; q < 8; ++q) { a_dv[k][q] = 0.f; a_cr[k][q] = 0.f; a_cc[k][q] = 0.f; a_wr[k][q] = 0.f; }
+    }
     const float Cn = (float)(2 * H + 1), Hf = (float)H;
-    for (int e = blockIdx.x * 4 + wv; e < E; e += nw) {
-        const int r = row[e], c = col[e];
-        const float rh = rho[e];
-        const float2 sr = stat[r], sc = stat[c];
-        const float mu = (Hf * (sr.x + sc.x) + rh) / Cn;
-        const float dr = sr.x - mu, dc = sc.x - mu, dq = rh - mu;
-        const float rs = rsqrtf((sr.y + sc.y + Hf * (dr * dr + dc * dc) + dq * dq) / Cn + eps);
-        const bf16_t* ar = AB + (size_t)r * ldab;
-        const bf16_t* bc = AB + (size_t)c * ldab + Kp;
-        float s_gu = 0.f, s_cr = 0.f, s_cc = 0.f, s_wr = 0.f;
+    for (int e0 = (blockIdx.x * 4 + wv) * U; e0 < E; e0 += nw * U) {
+        int r[U], c[U];
+        float rh[U];
+        uint4 uo[U][NPL], ug[U][NPL];
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            const int ch = k * 64 + lane;
-            if (ch < CH) {
-                const uint4 ua = *(const uint4*)(ar + ch * 8), ub = *(const uint4*)(bc + ch * 8);
-                const uint4 uo = *(const uint4*)(out + (size_t)e * Kp + ch * 8), ug = *(const uint4*)(dout + (size_t)e * Kp + ch * 8);
-                const uint32_t wa[4] = {ua.x, ua.y, ua.z, ua.w}, wb[4] = {ub.x, ub.y, ub.z, ub.w};
-                const uint32_t wo[4] = {uo.x, uo.y, uo.z, uo.w}, wg[4] = {ug.x, ug.y, ug.z, ug.w};
-                float d8[8];
+        for (int u = 0; u < U; ++u) {
+            const int e = min(e0 + u, E - 1);
+            r[u] = row[e]; c[u] = col[e]; rh[u] = rho[e];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int cq = ch * 8 + q;
-                    const float a = __uint_as_float((q & 1) ? (wa[q >> 1] & 0xffff0000u) : (wa[q >> 1] << 16));
-                    const float b = __uint_as_float((q & 1) ? (wb[q >> 1] & 0xffff0000u) : (wb[q >> 1] << 16));
-                    const uint32_t ob = (q & 1) ? (wo[q >> 1] & 0xffff0000u) : (wo[q >> 1] << 16);
-                    const float gy = __uint_as_float((q & 1) ? (wg[q >> 1] & 0xffff0000u) : (wg[q >> 1] << 16));
-                    const float crk = c_r[cq], cck = c_c[cq], wrk = w_r[cq];
-                    const float u = a + b + dr * crk + dc * cck + dq * wrk;
-                    const float g = (ob & 0x7fffffffu) ? gy * dscale : 0.f;
-                    const float d_ = rs * g;
-                    s_gu += g * u; s_cr += d_ * crk; s_cc += d_ * cck; s_wr += d_ * wrk;
-                    a_dv[k][q] += g; a_cr[k][q] += d_ * dr; a_cc[k][q] += d_ * dc; a_wr[k][q] += d_ * dq;
-                    d8[q] = d_;
-                }
-                uint4 o;
-                o.x = pack2_bf16(d8[0], d8[1]); o.y = pack2_bf16(d8[2], d8[3]); o.z = pack2_bf16(d8[4], d8[5]); o.w = pack2_bf16(d8[6], d8[7]);
-                *(uint4*)(du + (size_t)e * Kp + ch * 8) = o;
+            for (int k = 0; k < NPL; ++k) {
+                const int o8 = on[k] ? (k * 64 + lane) * 8 : 0;
+                uo[u][k] = *(const uint4*)(out + (size_t)e * Kp + o8); ug[u][k] = *(const uint4*)(dout + (size_t)e * Kp + o8);
             }
         }
-        s_gu = wave_sum(s_gu); s_cr = wave_sum(s_cr); s_cc = wave_sum(s_cc); s_wr = wave_sum(s_wr);
-        if (lane == 0) {
-            // rs = (V + eps)^(-1/2), V = (Q_r + Q_c + H (dr^2 + dc^2) + dq^2) / Cn
-            const float dV = -0.5f * rs * rs * rs * s_gu;
-            const float dQ = dV / Cn;
-            const float ddr = s_cr + dV * 2.f * Hf * dr / Cn, ddc = s_cc + dV * 2.f * Hf * dc / Cn, ddq = s_wr + dV * 2.f * dq / Cn;
-            const float dmu = -(ddr + ddc + ddq);                  // dr, dc, dq = (m_r, m_c, rho) - mu
-            es[(size_t)e * 2] = make_float4(ddr + dmu * Hf / Cn, dQ, ddc + dmu * Hf / Cn, dQ);      // (d m_r, d Q_r, d m_c, d Q_c | 0 0 0 0)
-            es[(size_t)e * 2 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
-            drho[e] = ddq + dmu / Cn;
+        float2 sr[U], sc[U];
+        uint4 ua[U][NPL], ub[U][NPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sr[u] = stat[r[u]]; sc[u] = stat[c[u]];
+            const bf16_t* ar = AB + (size_t)r[u] * ldab;
+            const bf16_t* bc = AB + (size_t)c[u] * ldab + Kp;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                const int o8 = on[k] ? (k * 64 + lane) * 8 : 0;
+                ua[u][k] = *(const uint4*)(ar + o8); ub[u][k] = *(const uint4*)(bc + o8);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u;
+            if (e >= E) break;
+            const float mu = (Hf * (sr[u].x + sc[u].x) + rh[u]) / Cn;
+            const float dr = sr[u].x - mu, dc = sc[u].x - mu, dq = rh[u] - mu;
+            const float rs = rsqrtf((sr[u].y + sc[u].y + Hf * (dr * dr + dc * dc) + dq * dq) / Cn + eps);
+            float s_gu = 0.f, s_cr = 0.f, s_cc = 0.f, s_wr = 0.f;
+#pragma unroll
+            for (int k = 0; k < NPL; ++k) {
+                if (on[k]) {
+                    const int ch = k * 64 + lane;
+                    const uint32_t wa[4] = {ua[u][k].x, ua[u][k].y, ua[u][k].z, ua[u][k].w}, wb[4] = {ub[u][k].x, ub[u][k].y, ub[u][k].z, ub[u][k].w};
+                    const uint32_t wo[4] = {uo[u][k].x, uo[u][k].y, uo[u][k].z, uo[u][k].w}, wg[4] = {ug[u][k].x, ug[u][k].y, ug[u][k].z, ug[u][k].w};
+                    float d8[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int cq = ch * 8 + q;
+                        const float a = __uint_as_float((q & 1) ? (wa[q >> 1] & 0xffff0000u) : (wa[q >> 1] << 16));
+                        const float b = __uint_as_float((q & 1) ? (wb[q >> 1] & 0xffff0000u) : (wb[q >> 1] << 16));
+                        const uint32_t ob = (q & 1) ? (wo[q >> 1] & 0xffff0000u) : (wo[q >> 1] << 16);
+                        const float gy = __uint_as_float((q & 1) ? (wg[q >> 1] & 0xffff0000u) : (wg[q >> 1] << 16));
+                        const float crk = c_r[cq], cck = c_c[cq], wrk = w_r[cq];
+                        const float uu = a + b + dr * crk + dc * cck + dq * wrk;
+                        const float g = (ob & 0x7fffffffu) ? gy * dscale : 0.f;
+                        const float d_ = rs * g;
+                        s_gu += g * uu; s_cr += d_ * crk; s_cc += d_ * cck; s_wr += d_ * wrk;
+                        a_dv[k][q] += g; a_cr[k][q] += d_ * dr; a_cc[k][q] += d_ * dc; a_wr[k][q] += d_ * dq;
+                        d8[q] = d_;
+                    }
+                    uint4 o;
+                    o.x = pack2_bf16(d8[0], d8[1]); o.y = pack2_bf16(d8[2], d8[3]); o.z = pack2_bf16(d8[4], d8[5]); o.w = pack2_bf16(d8[6], d8[7]);
+                    *(uint4*)(du + (size_t)e * Kp + ch * 8) = o;
+                }
+            }
+            s_gu = wave_sum(s_gu); s_cr = wave_sum(s_cr); s_cc = wave_sum(s_cc); s_wr = wave_sum(s_wr);
+            if (lane == 0) {
+                // rs = (V + eps)^(-1/2), V = (Q_r + Q_c + H (dr^2 + dc^2) + dq^2) / Cn
+                const float dV = -0.5f * rs * rs * rs * s_gu;
+                const float dQ = dV / Cn;
+                const float ddr = s_cr + dV * 2.f * Hf * dr / Cn, ddc = s_cc + dV * 2.f * Hf * dc / Cn, ddq = s_wr + dV * 2.f * dq / Cn;
+                const float dmu = -(ddr + ddc + ddq);                  // dr, dc, dq = (m_r, m_c, rho) - mu
+                es[(size_t)e * 2] = make_float4(ddr + dmu * Hf / Cn, dQ, ddc + dmu * Hf / Cn, dQ);      // (d m_r, d Q_r, d m_c, d Q_c | 0 0 0 0)
+                es[(size_t)e * 2 + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                drho[e] = ddq + dmu / Cn;
+            }
         }
     }
     // block partials of the four column sums: waves 0 .. 3 in order
@@ -626,15 +695,15 @@ extern "C" int fabind_edge_lnfold_bwd(const void* AB, int ldab, int Kp, int H, c
     const float dscale = 1.0f / (1.0f - (float)thr / 65536.0f);
     const size_t lds = (size_t)16 * Kp * sizeof(float);
     const int npl = (Kp / 8 + 63) / 64;
-#define ELB_LAUNCH(NN)                                                                                                             \
+#define ELB_LAUNCH(NN, UU)                                                                                                             \
     do {                                                                                                                           \
         static bool set_ = false;                                                                                                  \
-        if (!set_) { (void)hipFuncSetAttribute((const void*)edge_lnfold_bwd_kernel<NN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
-        hipLaunchKernelGGL(edge_lnfold_bwd_kernel<NN>, dim3(n_blocks), dim3(256), lds, stream, (const bf16_t*)AB, ldab, Kp, H, row, col, rho, \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)edge_lnfold_bwd_kernel<NN, UU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        hipLaunchKernelGGL((edge_lnfold_bwd_kernel<NN, UU>), dim3(n_blocks), dim3(256), lds, stream, (const bf16_t*)AB, ldab, Kp, H, row, col, rho, \
                            (const float2*)stat, eps, w_r, c_r, c_c, (const bf16_t*)out, (const bf16_t*)dout, E, dscale, (bf16_t*)du,  \
                            (float4*)es, drho, part);                                                                                \
     } while (0)
-    if (npl <= 1) ELB_LAUNCH(1); else if (npl == 2) ELB_LAUNCH(2); else ELB_LAUNCH(3);
+    if (npl <= 1) ELB_LAUNCH(1, ELB_U1); else if (npl == 2) ELB_LAUNCH(2, ELB_U2); else ELB_LAUNCH(3, ELB_U3);
 #undef ELB_LAUNCH
     FB_CHECK_LAUNCH();
     return 0;

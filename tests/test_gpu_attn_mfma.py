@@ -268,3 +268,51 @@ def test_fused_attention_fwd_bwd_vs_oracle_mha():
             assert v < 2.5e-2, (k, v)
     finally:
         config.set_precision("fp32")
+
+
+def test_fused_attention_serves_one_differentiable_pass_at_a_time():
+    """the blocks of one differentiable pass share state on their PairBias.  A second differentiable forward of a block
+    whose backward has not run is refused -- also after an abandoned pass --, and a new context reproduces the first pass's gradients."""
+    from fabind_amd import config, engine, ops, synthetic
+    H = 128
+    config.set_precision("bf16")
+    old = (ops.FUSED_ATTN_TRAIN, ops.FUSED_ATTN_TRAIN_MIN_TILES)
+    try:
+        ops.FUSED_ATTN_TRAIN, ops.FUSED_ATTN_TRAIN_MIN_TILES = True, 0
+        inp = synthetic.make_stack_batch([(70, 9), (130, 33)], 8, seed=3)
+        lay = engine.Layout(inp["batch_id"].to(DEV), inp["segment_id"].to(DEV))
+        g = torch.Generator().manual_seed(11)
+        N = lay.N
+        t = {k: v.to(DEV).requires_grad_(True) for k, v in dict(
+            a0b0=torch.randn(N, 2 * H, generator=g) * 0.5, wcomp=torch.randn(2, 8, H, generator=g) / H ** 0.5, bconst=torch.randn(2, 8, generator=g),
+            qg_p=torch.randn(N, 256, generator=g), kv_p=torch.randn(lay.sumC, 256, generator=g), qg_c=torch.randn(lay.sumC, 256, generator=g),
+            kv_c=torch.randn(N, 256, generator=g)).items()}
+        scale = 1.0 / math.sqrt(32.0)
+        pb = ops.PairBias(ops.shared_grad(t["a0b0"] * 1.0), H, t["wcomp"], t["bconst"], lay)
+
+        def one_pass():
+            o_p = ops.cross_attn_fused_train(t["qg_p"], t["kv_p"], pb, 0, 0, scale)
+            o_c = ops.cross_attn_fused_train(t["qg_c"], t["kv_c"], pb, 1, 1, scale)
+            return o_p, o_c
+
+        o_p, o_c = one_pass()
+        with pytest.raises(RuntimeError, match="ONE differentiable pass"):
+            ops.cross_attn_fused_train(t["qg_p"], t["kv_p"], pb, 0, 0, scale)
+        (o_p.square().sum() + o_c.square().sum()).backward(retain_graph=False)
+        first = {k: v.grad.clone() for k, v in t.items() if k in ("wcomp", "bconst", "qg_p", "kv_c")}
+        assert all(torch.isfinite(v).all() and float(v.abs().max()) > 0 for v in first.values())
+        # an abandoned pass (forward only, graph dropped) keeps its context refused; a new context reproduces the gradients
+        pb2 = ops.PairBias(ops.shared_grad(t["a0b0"] * 1.0), H, t["wcomp"], t["bconst"], lay)
+        ops.cross_attn_fused_train(t["qg_p"], t["kv_p"], pb2, 0, 0, scale)
+        with pytest.raises(RuntimeError, match="ONE differentiable pass"):
+            ops.cross_attn_fused_train(t["qg_p"], t["kv_p"], pb2, 0, 0, scale)
+        for v in t.values():
+            v.grad = None
+        pb = ops.PairBias(ops.shared_grad(t["a0b0"] * 1.0), H, t["wcomp"], t["bconst"], lay)
+        o_p, o_c = one_pass()
+        (o_p.square().sum() + o_c.square().sum()).backward()
+        for k, v in first.items():
+            assert _rel(t[k].grad, v) < 1e-5, k
+    finally:
+        ops.FUSED_ATTN_TRAIN, ops.FUSED_ATTN_TRAIN_MIN_TILES = old
+        config.set_precision("fp32")
