@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 5: lnfold kernels (one pass per row at H <= 128, 4 edges in flight per wave): FABind+ tests + the training / sampling steps
+O=${GRAFT_REPO_ROOT:-.}/gpurun_out/r5c21; mkdir -p $O
+timeout 1200 python -m pytest tests/test_gpu_plus.py tests/test_gpu_plus_dense_api.py tests/test_gpu_attn_mfma.py -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
+timeout 1500 python -m pytest tests/test_gpu_production.py -x -q -k plus > $O/tests_prod.log 2>&1; tail -3 $O/tests_prod.log
+for i in 1 2; do python bench.py --mode plus_train --no-cpu-baseline --no-extras --steps 3 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('plus_train', round(d['value'],1), round(d['ms_per_step'],2))" | tee -a $O/speed.txt; done
+python bench.py --mode plus_sampling --no-cpu-baseline --no-extras --steps 2 --warmup 1 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('plus_sampling', round(d['value'],1), round(d['ms_per_step'],2))" | tee -a $O/speed.txt
