@@ -626,6 +626,9 @@ def edge_lnfold_bwd(AB16, Kp, H, row, col, rho, stat, eps, w_r, c_r, c_c, out, d
     drho [E], vecs fp32 [4, Kp] = column sums d dvec, d c_r, d c_c, d w_r)."""
     E = row.shape[0]
     dev = AB16.device
+    if E == 0:                                                   # (the library call is a no-op then: nothing would write the partials)
+        return (torch.zeros((0, Kp), dtype=torch.bfloat16, device=dev), torch.zeros((0, 8), dtype=torch.float32, device=dev),
+                torch.zeros(0, dtype=torch.float32, device=dev), torch.zeros((4, Kp), dtype=torch.float32, device=dev))
     lib = _lib.load()
     nb = max(1, int(lib.fabind_edge_lnfold_bwd_blocks(E)))
     du = torch.empty((max(E, 1), Kp), dtype=torch.bfloat16, device=dev)
