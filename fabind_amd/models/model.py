@@ -103,7 +103,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
     def _assemble(self, segment, is_global, c_emb, p_emb, index=None):
         """[glb_c | ligand | glb_p | protein] per complex as one gather (replaces model.py:104-115)."""
         idx, cf, pf = index if index is not None else self._assemble_index(segment, is_global, c_emb.shape[0], p_emb.shape[0])
-        return torch.cat([self.glb_c, self.glb_p, c_emb, p_emb], 0).index_select(0, idx), cf, pf
+        return ops.take_unique_rows(torch.cat([self.glb_c, self.glb_p, c_emb, p_emb], 0), idx), cf, pf
 
     @staticmethod
     def _classifier_index(data):
@@ -195,7 +195,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
             LAS_edge_index=data['complex_whole_protein', 'LAS', 'complex_whole_protein'].edge_index,
             batched_complex_coord_LAS=Xl, LAS_mask=None)
         hw = self._lin(self.embedding_enlarge, hw)
-        c_out, p_out = hw.index_select(0, cf), hw.index_select(0, pf)
+        c_out, p_out = ops.take_unique_rows(hw, cf), ops.take_unique_rows(hw, pf)
         logits_flat = self.protein_to_pocket(p_out).squeeze(-1)                      # [sum L]
         logits = torch.zeros(B, Lmax, dtype=logits_flat.dtype, device=pb.device).index_put((pb, loc), logits_flat)
         return dict(B=B, c_out=c_out, p_out=p_out, logits=logits, mask=mask, xyz=xyz, pb=pb, loc=loc, cnt=cnt,
@@ -251,7 +251,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         cb = data['compound'].batch
         B = head['B']
         pocket_xyz = data.node_xyz_whole[ix['keep']]
-        pemb = head['p_out'].index_select(0, torch.nonzero(ix['keep']).squeeze(1))
+        pemb = ops.take_unique_rows(head['p_out'], torch.nonzero(ix['keep']).squeeze(1))
         H, _, _ = self._assemble(ix['segment'], ix['is_global'], head['c_out'], pemb)
         with torch.no_grad():
             li = data['compound'].node_coords.float()
@@ -307,7 +307,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         Xo, Ho = self.complex_model(Xn, g['H'], batch_id=g['batch'], segment_id=g['segment'], mask=g['mask'],
                                     is_global=g['is_global'], compound_edge_index=g['c2c'], LAS_edge_index=g['LAS'],
                                     batched_complex_coord_LAS=Xl, LAS_mask=None)
-        coords_n = Xo.index_select(0, cidx).squeeze(-2)
+        coords_n = ops.take_unique_rows(Xo, cidx).squeeze(-2)
         return Ho, cidx, pidx, coords_n
 
     def _dist_heads(self, data, g, Ho, cidx, pidx, coords_n):
@@ -317,7 +317,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
             B = int(cb[-1].item()) + 1
             pairs = self._pair_lists(g['pocket_batch'], cb, torch.bincount(g['pocket_batch'], minlength=B), torch.bincount(cb, minlength=B))
         pi, ci = pairs
-        ln = ops.layernorm(Ho.index_select(0, torch.cat([pidx, cidx])), self.layernorm.weight, self.layernorm.bias, self.layernorm.eps)
+        ln = ops.layernorm(ops.take_unique_rows(Ho, torch.cat([pidx, cidx])), self.layernorm.weight, self.layernorm.bias, self.layernorm.eps)
         npk = pidx.shape[0]
         hd = ops.rows_hadamard(ln, pi, npk + ci, a_sorted=True)                                       # LN(p_i) * LN(c_j)
         wd = ops.mm_dtype()
@@ -356,7 +356,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
             g = self._stage2(data, head, c2)
         else:
             cx = data['complex']
-            pemb = head['p_out'].index_select(0, keep_idx if keep_idx is not None else torch.nonzero(data['pocket'].keepNode).squeeze(1))
+            pemb = ops.take_unique_rows(head['p_out'], keep_idx if keep_idx is not None else torch.nonzero(data['pocket'].keepNode).squeeze(1))
             H, _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], pemb, index=plan['asm_c'] if plan else None)
 
             g = dict(H=H, X=cx.node_coords, XL=cx.node_coords_LAS, segment=cx.segment, mask=cx.mask,

@@ -978,6 +978,29 @@ class _TakeRows(torch.autograd.Function):
         return ctx.sink.deposit_rows(idx, d_rows), None, None
 
 
+class _TakeUniqueRows(torch.autograd.Function):
+    """x[idx] for idx WITHOUT REPEATS: the adjoint is a row copy into zeros (autograd's own index_select backward is an index_add_ -- bf16
+    atomics: 1.2 ms for the 600 k x 512 pair rows of FABind+'s distance-map head, and the only float atomics of that training step)."""
+
+    @staticmethod
+    def forward(ctx, x, idx):
+        ctx.n = x.shape[0]
+        ctx.save_for_backward(idx)
+        return x.index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, d_rows):
+        idx, = ctx.saved_tensors
+        g = torch.zeros((ctx.n,) + tuple(d_rows.shape[1:]), dtype=d_rows.dtype, device=d_rows.device)
+        g.index_copy_(0, idx, d_rows)
+        return g, None
+
+
+def take_unique_rows(x, index64):
+    """Row gather with an index free of repeats (the caller's contract)."""
+    return _TakeUniqueRows.apply(x, index64) if _needs_grad(x) else x.index_select(0, index64)
+
+
 def take_rows(x, index64):
     """Row gather (pure data movement).  With a shared gradient buffer on x the adjoint is a row scatter-add into it."""
     sink = _sink_of(x)

@@ -170,7 +170,7 @@ class FABindPlus(nn.Module):
             LAS_edge_index=data['complex_whole_protein', 'LAS', 'complex_whole_protein'].edge_index,
             batched_complex_coord_LAS=Xl, LAS_mask=None, pair="none")
         hw = self._lin(self.embedding_enlarge, hw)
-        c_out, p_out = hw.index_select(0, cf), hw.index_select(0, pf)
+        c_out, p_out = ops.take_unique_rows(hw, cf), ops.take_unique_rows(hw, pf)
         csum = torch.zeros(B, c_out.shape[1], dtype=torch.float32, device=hw.device).index_add_(0, cb, c_out.float())
         radius = pengine.mlp_module(self.pocket_radius_head, csum, pdrop=self._pd()).relu()                      # [B,1]
         logits_flat = pengine.mlp_module(self.protein_to_pocket, p_out, pdrop=self._pd()).squeeze(-1)            # [sum L]
@@ -180,7 +180,7 @@ class FABindPlus(nn.Module):
     # ---- radius crop around the predicted centre, pocket-centred frame (model.py:212-330) --------------------------
     def _stage2(self, data, head, center, shift_coords):
         g = self._stage2_nograd(data, head, center, shift_coords)
-        g['H'], _, _ = self._assemble(g['segment'], g['is_global'], head['c_out'], head['p_out'].index_select(0, torch.nonzero(g.pop('keep')).squeeze(1)))
+        g['H'], _, _ = self._assemble(g['segment'], g['is_global'], head['c_out'], ops.take_unique_rows(head['p_out'], torch.nonzero(g.pop('keep')).squeeze(1)))
         return g
 
     @torch.no_grad()
@@ -244,7 +244,7 @@ class FABindPlus(nn.Module):
         with torch.no_grad():
             g = self._stage1_nograd(data, head)
         cx = data['complex']
-        g['H'], _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], head['p_out'].index_select(0, torch.nonzero(data['pocket'].keepNode).squeeze(1)))
+        g['H'], _, _ = self._assemble(cx.segment, cx.is_global, head['c_out'], ops.take_unique_rows(head['p_out'], torch.nonzero(data['pocket'].keepNode).squeeze(1)))
         return g
 
     def _stage1_nograd(self, data, head):
@@ -276,7 +276,7 @@ class FABindPlus(nn.Module):
         Xo, Ho, Z = self.complex_model(Xn, g['H'], batch_id=g['batch'], segment_id=g['segment'], mask=g['mask'],
                                        is_global=g['is_global'], compound_edge_index=g['c2c'], LAS_edge_index=g['LAS'],
                                        batched_complex_coord_LAS=Xl, LAS_mask=None, pair=pair)
-        return Ho, Z, cflag, pflag, Xo.index_select(0, cidx).squeeze(-2)
+        return Ho, Z, cflag, pflag, ops.take_unique_rows(Xo, cidx).squeeze(-2)
 
     def _dist_heads(self, data, g, Z, coords_n):
         """distmap_mlp on the threaded pair embedding without its global rows (model.py:379-388) + coordinate distances."""
@@ -287,7 +287,7 @@ class FABindPlus(nn.Module):
         n_sel = pairs.n_inner
         slot = torch.where(sel, torch.cumsum(sel, 0) - 1, torch.full_like(pairs.i, n_sel))
         idx = torch.empty(n_sel + 1, dtype=torch.int64, device=z.device).scatter_(0, slot, torch.arange(sel.shape[0], device=z.device))[:n_sel]
-        zz = z.index_select(0, idx)
+        zz = ops.take_unique_rows(z, idx)
         m = self.distmap_mlp
         wd = ops.mm_dtype()
         y = pengine.ln_rows(zz, m.layernorm.weight.float(), m.layernorm.bias.float(), ops.act_dtype())

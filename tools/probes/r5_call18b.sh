@@ -1,0 +1,8 @@
+#!/bin/bash
+# round 5: unique-index row gathers with a copy adjoint (no index_add atomics): model-level tests + the two model steps
+O=${GRAFT_REPO_ROOT:-.}/gpurun_out/r5c24; mkdir -p $O
+timeout 2400 python -m pytest tests/test_gpu_model.py tests/test_gpu_production.py tests/test_gpu_plus.py tests/test_gpu_training.py tests/test_gpu_dp.py tests/test_gpu_data.py -x -q > $O/tests.log 2>&1; tail -3 $O/tests.log
+for i in 1 2; do
+python bench.py --mode model --no-cpu-baseline --no-extras --steps 6 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('model', round(d['value'],1), round(d['ms_per_step'],2))" | tee -a $O/speed.txt
+python bench.py --mode plus_train --no-cpu-baseline --no-extras --steps 3 --warmup 2 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('plus_train', round(d['value'],1), round(d['ms_per_step'],2))" | tee -a $O/speed.txt
+done
