@@ -103,7 +103,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
     def _assemble(self, segment, is_global, c_emb, p_emb, index=None):
         """[glb_c | ligand | glb_p | protein] per complex as one gather (replaces model.py:104-115)."""
         idx, cf, pf = index if index is not None else self._assemble_index(segment, is_global, c_emb.shape[0], p_emb.shape[0])
-        return ops.take_unique_rows(torch.cat([self.glb_c, self.glb_p, c_emb, p_emb], 0), idx), cf, pf
+        return torch.cat([self.glb_c, self.glb_p, c_emb, p_emb], 0).index_select(0, idx), cf, pf
 
     @staticmethod
     def _classifier_index(data):
