@@ -467,6 +467,35 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def aten_census(step, path):
+        """Diagnostic (FABIND_BENCH_ATEN=<file>): one extra untimed step under torch.profiler; every torch (aten) op that launches something
+        itself, by shapes and issuing site (the innermost fabind_amd frame, or the autograd node for backward ops), sorted by device time."""
+        import collections
+        from torch.profiler import ProfilerActivity, profile as tprofile
+        torch.autograd.set_multithreading_enabled(False)
+        with tprofile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
+            step()
+            torch.cuda.synchronize()
+        torch.autograd.set_multithreading_enabled(True)
+        rows = collections.defaultdict(lambda: [0, 0.0])
+        for e in prof.events():
+            sdt = getattr(e, "self_device_time_total", 0) or 0
+            if not e.name.startswith("aten::") or sdt <= 0:
+                continue
+            site = "?"
+            for fr in (e.stack or []):
+                if "fabind_amd" in fr or "bench.py" in fr:
+                    site = fr.split("fabind_amd/")[-1][:80]
+                    break
+            key = (e.name, str(e.input_shapes)[:90], site)
+            rows[key][0] += 1
+            rows[key][1] += sdt
+        tot = sum(v[1] for v in rows.values())
+        with open(path, "w") as f:
+            f.write("torch (aten) ops with device time of their own in one step: %d launches, %.2f ms\n" % (sum(v[0] for v in rows.values()), tot / 1e3))
+            for (name, shapes, site), (cnt, us) in sorted(rows.items(), key=lambda kv: -kv[1][1])[:120]:
+                f.write("%9.1f us %4d x  %-28s %-90s %s\n" % (us, cnt, name, shapes, site))
+
     def timed(step, warmup, steps, profile, events_in_timed=True):
         """Timing protocol of the contract (warm-up, barrier + synchronize, exactly `steps` steps, barrier + synchronize).  Live HIP
         events for the roofline: the LAST warm-up step times every labelled launch and names the dominant kernel family; the timed
@@ -496,6 +525,9 @@ def main():
             else:
                 step()
         sync()
+        if os.environ.get("FABIND_BENCH_ATEN") and rank == 0:
+            aten_census(step, os.environ["FABIND_BENCH_ATEN"])
+            sync()
         K.PROFILE = {} if (profile and events_in_timed) else None
         K.PROFILE_BYTES.clear()
         K.PROFILE_ONLY = only

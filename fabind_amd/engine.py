@@ -73,11 +73,16 @@ class Layout:
         B = int(batch_id[-1].item()) + 1
         seg = (segment_id > 0.5) if segment_id.is_floating_point() else segment_id.bool()
         bid = batch_id.long()                               # (two read-backs in all: B above, the counts here -- no torch.bincount)
-        cnt = torch.zeros((2, B), dtype=torch.int64, device=dev)
-        cnt[0].index_add_(0, bid, torch.ones_like(bid))
-        cnt[1].index_add_(0, bid, seg.to(torch.int64))
-        cnt = cnt.cpu().numpy()
-        n, P = cnt[0].astype(np.int64), cnt[1].astype(np.int64)
+        # nodes are complex-contiguous (the layout below relies on it, like the reference's to_dense_batch): the per-complex counts are
+        # differences of the complexes' boundaries in the sorted batch vector (an index_add_ of 98,688 ones into 64 bins is 0.4 ms of
+        # contended atomics); whether the vector IS sorted rides in the same read-back
+        bound = torch.searchsorted(bid, torch.arange(B + 1, dtype=torch.int64, device=dev))
+        cs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(seg.to(torch.int64), 0)])
+        ok = (bid[1:] >= bid[:-1]).all().to(torch.int64).reshape(1) if bid.numel() > 1 else torch.ones(1, dtype=torch.int64, device=dev)
+        cnt = torch.cat([bound[1:] - bound[:-1], cs[bound[1:]] - cs[bound[:-1]], ok]).cpu().numpy()
+        if cnt[-1] != 1:
+            raise ValueError("fabind_amd: batch_id must be sorted (the nodes of a complex contiguous), as the reference's to_dense_batch requires")
+        n, P = cnt[:B].astype(np.int64), cnt[B:2 * B].astype(np.int64)
         C = n - P
         off = np.concatenate([[0], np.cumsum(n)])
         self.B, self.N = B, int(off[-1])

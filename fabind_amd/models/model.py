@@ -325,7 +325,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
                                  self.distmap_mlp[2].weight[0].contiguous(), act_epi=K.ACT_RELU)
         y_pred = (part.sum(1) + self.distmap_mlp[2].bias).sigmoid() * 10
         xp = self.normalize_coord(g['pocket_xyz']).float()
-        y_by = self.unnormalize_coord((xp[pi] - coords_n[ci]).norm(dim=-1)).clamp(0, 10)
+        y_by = self.unnormalize_coord((xp[pi] - ops.take_rows_few(coords_n, ci)).norm(dim=-1)).clamp(0, 10)
         return y_pred, y_by
 
     # ---- reference API ------------------------------------------------------------------------

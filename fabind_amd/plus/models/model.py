@@ -307,7 +307,7 @@ class FABindPlus(nn.Module):
             pairs_ = self._pair_lists(g['pocket_batch'], cb, torch.bincount(g['pocket_batch'], minlength=B), torch.bincount(cb, minlength=B))
         pi, ci = pairs_
         xp = self.normalize_coord(g['pocket_xyz']).float()
-        y_by = self.unnormalize_coord((xp[pi] - coords_n[ci]).norm(dim=-1)).clamp(0, thres)
+        y_by = self.unnormalize_coord((xp[pi] - ops.take_rows_few(coords_n, ci)).norm(dim=-1)).clamp(0, thres)
         return y_pred, y_by
 
     # ---- reference API ---------------------------------------------------------------------------------------------

@@ -1446,3 +1446,37 @@ def test_inter_attn_rows_dealt_by_degree_match_one_wave_per_row(H, monkeypatch):
         err = float((a_ - c_).abs().max()) / max(1e-6, float(c_.abs().max()))
         assert err <= 2e-5, (nm, err)
     assert float(new[2].sum()) > 0 and abs(float(new[2].sum()) - n_act) <= 1e-3 * n_act      # softmax rows sum to one
+
+
+def test_row_gathers_with_copy_and_segment_sum_adjoints_match_index_select():
+    """ops.take_unique_rows (repeat-free index: the adjoint is a row copy) and ops.take_rows_few (narrow fp32 rows gathered many times:
+    the adjoint is a stable sort + one fixed-order segment sum) against autograd's index_select -- values and gradients; the
+    many-to-few gradient is bit-identical run to run (autograd's own is an index_put with contended float atomics)."""
+    from fabind_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3000, 64, generator=g).to(dev)
+    idx = torch.randperm(3000, generator=g)[:1700].to(dev)
+    cot = torch.randn(1700, 64, generator=g).to(dev)
+    for dt in (torch.float32, torch.bfloat16):
+        a, b = x.to(dt).clone().requires_grad_(True), x.to(dt).clone().requires_grad_(True)
+        ya, yb = ops.take_unique_rows(a, idx), b.index_select(0, idx)
+        assert torch.equal(ya, yb)
+        (ya.float() * cot).sum().backward()
+        (yb.float() * cot).sum().backward()
+        assert torch.equal(a.grad, b.grad)
+    c = torch.randn(640, 3, generator=g).to(dev)
+    many = torch.randint(0, 640, (150000,), generator=g).to(dev)
+    many[:5000] = 7                                                  # one row with thousands of readers
+    cot3 = torch.randn(150000, 3, generator=g).to(dev)
+    grads = []
+    for _ in range(2):
+        a = c.clone().requires_grad_(True)
+        ya = ops.take_rows_few(a, many)
+        assert torch.equal(ya, c.index_select(0, many))
+        (ya * cot3).sum().backward()
+        grads.append(a.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    ref = torch.zeros(640, 3, dtype=torch.float64, device=dev).index_add_(0, many, cot3.double())
+    assert float((grads[0].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    assert float(grads[0][torch.bincount(many, minlength=640) == 0].abs().max() if (torch.bincount(many, minlength=640) == 0).any() else 0.0) == 0.0
