@@ -699,8 +699,9 @@ def main():
                  "product term): the FAST mode whose OUTPUTS meet the 1e-4 A parity gate at n_iter 1, 2 and 8 (tests/test_gpu_headline.py); "
                  "its weight gradients, fused edge backward and pair-bias adjoint run on bf16 roundings (bf16-grade parameter gradients)")
         sub("gate_mode_exact_bwd", "fwdbwd", a.n_iter, precision="bf16x3", steps=5, warmup=2, x3_backward="exact",
-            note="gate_mode with config.set_x3_backward('exact'): weight gradients as split contractions, pair-bias adjoint in fp32 (the fused "
-                 "edge backward stays the bf16 recompute kernel)")
+            note="gate_mode with config.set_x3_backward('exact'): weight gradients as split contractions, pair-bias adjoint in fp32, the "
+                 "intra-graph edge pipeline unfused (fp32 edge tensors, split contractions in the forward, the input gradients and the weight "
+                 "gradients): no bf16 rounding anywhere in the adjoint")
         sub("gate_mode_bf16_edge", "fwdbwd", a.n_iter, precision="bf16x3", steps=8, warmup=2, x3_edge="bf16",
             note="gate_mode with config.set_x3_edge('bf16'): the intra-graph edge pipeline on the bf16 kernels (forward 2.2 instead of 4.9 ms per "
                  "launch); the coordinate / loss gates still hold with less margin (ligand RMSD 3.5e-6 / 7.0e-6 / 3.0e-5 A at n_iter 1 / 2 / 8, full "

@@ -18,8 +18,11 @@ def set_precision(mode):
     their fp32 operands (`set_x3_backward("bf16")`, the default): the weight-gradient contractions, the fused edge backward (the bf16
     recompute kernel on bf16 copies of AB and the weights) and the pair-bias adjoint -- parameter gradients are then bf16-grade
     (whole-gradient l2 error ~2e-3, tests/test_gpu_headline.py), the outputs and losses are not affected.
-    `set_x3_backward("exact")` runs the weight gradients as split contractions and the pair-bias adjoint in fp32 (the fused edge
-    backward stays the bf16 recompute kernel: there is no split form of it); bench.py reports both (`gate_mode`, `gate_mode_exact_bwd`)."""
+    `set_x3_backward("exact")` runs the weight gradients as split contractions, the pair-bias adjoint in fp32 and -- round 5 -- a
+    differentiable pass's intra-graph edge pipeline UNFUSED (engine.gcl_layer: fp32 edge tensors, split contractions in the forward, the
+    input gradients and the weight gradients; there is no split form of the fused edge backward kernel): no bf16 rounding anywhere in the
+    adjoint, at the cost of ~3 GB of edge tensors per layer and the unfused launches; bench.py reports both (`gate_mode`,
+    `gate_mode_exact_bwd`)."""
     assert mode in MODES
     _PRECISION["mode"] = mode
 

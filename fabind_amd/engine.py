@@ -27,6 +27,7 @@ from . import kernels as K
 from . import ops
 
 from .config import fp32_storage, get_precision, set_precision, split_sites  # noqa: F401
+from .config import x3_backward_bf16 as config_x3_backward_bf16
 from .param_pack import EagerPack, ParamPack
 
 
@@ -530,7 +531,12 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
     if pdrop == 0.0:                # (train mode adds torch-side dropout consumers that do not know the shared buffer)
         h = ops.shared_grad(h)      # three consumers (first edge Linear, node MLP, residual): one gradient buffer, no autograd adds
     hin = _b16(h) if fast else h
-    if get_precision() in ("bf16", "bf16x3") and FUSED_EDGE and H in (64, 128, 256, 512):
+    # bf16x3 with config.set_x3_backward("exact"): a differentiable pass takes the UNFUSED edge pipeline below -- split contractions in the
+    # forward, the input gradients AND the weight gradients, fp32 edge tensors: no bf16 rounding anywhere in the edge path's adjoint (the
+    # fused backward kernels contract bf16 operands)
+    exact_edge = (get_precision() == "bf16x3" and not config_x3_backward_bf16() and not fast
+                  and ops.needs_grad(h, x, p["W2"], p["W_ab"]))
+    if get_precision() in ("bf16", "bf16x3") and FUSED_EDGE and H in (64, 128, 256, 512) and not exact_edge:
         # the whole edge pipeline in one kernel each way, edge tensors stay in LDS (csrc/fused_edge.hip); under
         # autograd nothing per-edge is saved, the backward kernel recomputes tile by tile.  Train-mode dropout on the
         # messages is a counter-based mask evaluated inside both kernels.

@@ -175,13 +175,21 @@ def test_headline_shape_bf16x3_with_the_bf16_edge_pipeline_meets_the_coordinate_
 # bf16x3 (round 3, shipped form: split-bf16 forward and activation-gradient GEMMs, bf16 fused edge backward / weight-gradient
 # contractions / pair-bias adjoint): input 7.8e-3, whole-gradient l2 1.8e-3, per-tensor l2 median 1.7e-3, worst 2.7e-2 (a bias 1e-5
 # of the largest gradient) -- bounds at ~2x
-@pytest.mark.parametrize("prec,tol", [("fp32", 3e-3), ("bf16x3", 1.6e-2), ("bf16", 6e-2), ("bf16+fused_attention", 6e-2)])
+@pytest.mark.parametrize("prec,tol", [("fp32", 3e-3), ("bf16x3", 1.6e-2), ("bf16x3+exact", 1.6e-2), ("bf16", 6e-2),
+                                      ("bf16+fused_attention", 6e-2)])
 def test_headline_shape_gradients_match_oracle_autograd(one_complex, prec, tol, monkeypatch):
     """(ii) d(loss)/d(input H, every parameter) through the HIP backward kernels vs autograd through the oracle.  The last case sends
     the single complex (24 row tiles, below the size dispatch) through the fused cross-attention kernels each way -- the path the
-    64-complex bench batch takes."""
-    from fabind_amd import engine, ops
+    64-complex bench batch takes.  "bf16x3+exact": config.set_x3_backward("exact") -- weight gradients as split contractions, the
+    pair-bias adjoint in fp32 and (round 5) the edge pipeline unfused with split contractions both ways: no bf16 rounding in the adjoint."""
+    from fabind_amd import config, engine, ops
     dev = torch.device("cuda:0")
+    exact = prec.endswith("+exact")
+    if exact:
+        prec = "bf16x3"
+        seen_gcl = []
+        real_pre = ops.gcl_pre
+        monkeypatch.setattr(ops, "gcl_pre", lambda *a, **k: (seen_gcl.append(1), real_pre(*a, **k))[1])
     if prec.endswith("+fused_attention"):
         prec = "bf16"
         monkeypatch.setattr(ops, "FUSED_ATTN_TRAIN_MIN_TILES", 0)
@@ -199,12 +207,17 @@ def test_headline_shape_gradients_match_oracle_autograd(one_complex, prec, tol, 
     Xr, Hr, sd, Hin_r = _oracle(m, one_complex, 1, grad=True)
     ((Xr * cotX).sum() + (Hr * cotH).sum()).backward()
     engine.set_precision(prec)
+    if exact:
+        config.set_x3_backward("exact")
     try:
         m = m.to(dev)
         X, Hh, Hin = _hip(m, one_complex, dev, grad=True)
         ((X * cotX.to(dev)).sum() + (Hh * cotH.to(dev)).sum()).backward()
     finally:
         engine.set_precision("fp32")
+        config.set_x3_backward("bf16")
+    if exact:
+        assert len(seen_gcl) == 5, seen_gcl                   # every MC_E_GCL of the pass took the unfused edge pipeline
     ref = Hin_r.grad
     e_in = float((Hin.grad.cpu() - ref).abs().max() / ref.abs().max())
     rows = []
@@ -220,7 +233,7 @@ def test_headline_shape_gradients_match_oracle_autograd(one_complex, prec, tol, 
                      float((p.grad.cpu() - r).norm() / r.norm())))
     rows.sort(reverse=True)
     print("headline shape %s gradients: input H rel err %.3e; %d parameter tensors compared; worst (max-rel, name, "
-          "|ref|max / largest, l2-rel):" % (prec, e_in, len(rows)))
+          "|ref|max / largest, l2-rel):" % (prec + ("+exact" if exact else ""), e_in, len(rows)))
     for r_ in rows[:6]:
         print("    %.3e  %s  %.2e  %.3e" % r_)
     assert len(rows) > 100
