@@ -259,7 +259,11 @@ def test_headline_shape_gradients_match_oracle_autograd(one_complex, prec, tol, 
         l2 = sorted((r_[3], r_[1]) for r_ in rows)
         print("    whole-gradient l2-rel %.3e; per-tensor l2-rel: median %.3e, worst %.3e (%s)"
               % (glob, l2[len(l2) // 2][0], l2[-1][0], l2[-1][1]))
-        if prec == "bf16x3":
+        if exact:
+            # measured at the first run: whole gradient 4.7e-4, per-tensor median 2.3e-4, worst 2.4e-3 (ReLU flips of the 2^-17 forward error
+            # remain); the default backward of the mode reads 1.8e-3 / 1.8e-3 / 2.7e-2
+            assert glob <= 1e-3 and l2[-1][0] <= 6e-3 and l2[len(l2) // 2][0] <= 6e-4, (glob, l2[-1], l2[len(l2) // 2])
+        elif prec == "bf16x3":
             assert glob <= 4e-3 and l2[-1][0] <= 6e-2 and l2[len(l2) // 2][0] <= 3.5e-3, (glob, l2[-1], l2[len(l2) // 2])
         else:
             assert glob <= tol
