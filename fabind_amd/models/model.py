@@ -43,6 +43,30 @@ def _offsets(counts):
     return torch.cumsum(counts, 0) - counts
 
 
+class _AssembleRows(torch.autograd.Function):
+    """cat([glb_c, glb_p, c_emb, p_emb])[idx] -- the per-complex [glb_c | ligand | glb_p | protein] layout -- with an adjoint free of float
+    atomics: the ligand / residue rows are read by exactly one output row each (row gathers through cf / pf), the two global rows by one
+    output row per complex (masked column sums in a fixed order).  autograd's index_select adjoint is an index_add_: the B readers of
+    each global row arrived in any order and d glb_c / d glb_p were the only gradients of a training step that changed from run to run."""
+
+    @staticmethod
+    def forward(ctx, glb_c, glb_p, c_emb, p_emb, idx, cf, pf):
+        ctx.save_for_backward(idx, cf, pf)
+        ctx.dts = (glb_c.dtype, glb_p.dtype, c_emb.dtype, p_emb.dtype)
+        return torch.cat([glb_c, glb_p, c_emb, p_emb], 0).index_select(0, idx)
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, cf, pf = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        zero = torch.zeros((), dtype=g.dtype, device=g.device)
+        d0 = torch.where((idx == 0)[:, None], g, zero).sum(0, keepdim=True).to(ctx.dts[0]) if need[0] else None
+        d1 = torch.where((idx == 1)[:, None], g, zero).sum(0, keepdim=True).to(ctx.dts[1]) if need[1] else None
+        dc = g.index_select(0, cf).to(ctx.dts[2]) if need[2] else None
+        dp = g.index_select(0, pf).to(ctx.dts[3]) if need[3] else None
+        return d0, d1, dc, dp, None, None, None
+
+
 class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
     def __init__(self, args, embedding_channels=128, pocket_pred_embedding_channels=128):
         super().__init__()
@@ -103,7 +127,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
     def _assemble(self, segment, is_global, c_emb, p_emb, index=None):
         """[glb_c | ligand | glb_p | protein] per complex as one gather (replaces model.py:104-115)."""
         idx, cf, pf = index if index is not None else self._assemble_index(segment, is_global, c_emb.shape[0], p_emb.shape[0])
-        return torch.cat([self.glb_c, self.glb_p, c_emb, p_emb], 0).index_select(0, idx), cf, pf
+        return _AssembleRows.apply(self.glb_c, self.glb_p, c_emb, p_emb, idx, cf, pf), cf, pf
 
     @staticmethod
     def _classifier_index(data):

@@ -210,3 +210,37 @@ def test_forward_with_a_stage1_plan_equals_the_plain_forward(stage):
                 assert float((a - b).abs().max()) <= 8e-3 * float(b.abs().max()) + 1e-12
     finally:
         engine.set_precision("fp32")
+
+
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+def test_full_model_step_is_bit_reproducible(prec):
+    """Two forward + backward passes of IaBNet (pocket model -> crop -> complex model -> heads, six-term loss; eval mode: no random draws)
+    from identical weights and inputs: every output and every parameter gradient bit for bit -- no float atomics anywhere in the fast modes'
+    training step, the torch glue included (round 5: the assemble gather's and the distance head's coordinate gather's adjoints)."""
+    from fabind_amd import engine, synthetic
+    from fabind_amd.models import get_model
+    from fabind_amd.models.model import compute_loss
+    dev = torch.device("cuda:0")
+    a = _args(128, 2, 1)
+    a.pocket_pred_hidden_size = 64
+    a.random_n_iter = False
+    torch.manual_seed(0)
+    engine.set_precision(prec)
+    try:
+        m = get_model(a, _Logger(), dev).to(dev).eval()
+        base = synthetic.make_hetero_batch([(300, 19), (245, 34), (410, 26), (152, 11), (333, 40), (280, 8)], seed=3).to(dev)
+        res = []
+        for _ in range(2):
+            for p_ in m.parameters():
+                p_.grad = None
+            data = base.clone()
+            out = m(data, stage=1, train=False)
+            loss, _ = compute_loss(out, data)
+            loss.backward()
+            res.append(([o.detach().clone() for o in out if torch.is_tensor(o)],
+                        {k: p_.grad.clone() for k, p_ in m.named_parameters() if p_.grad is not None}))
+    finally:
+        engine.set_precision("fp32")
+    assert all(torch.equal(x, y) for x, y in zip(res[0][0], res[1][0]))
+    bad = [k for k in res[0][1] if not torch.equal(res[0][1][k], res[1][1][k])]
+    assert len(res[0][1]) > 200 and not bad, bad
