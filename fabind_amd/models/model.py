@@ -279,8 +279,8 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         H, _, _ = self._assemble(ix['segment'], ix['is_global'], head['c_out'], pemb)
         with torch.no_grad():
             li = data['compound'].node_coords.float()
-            mean_l = torch.zeros(B, 3, device=dev).index_add_(0, cb, li) / ix['ncnt'][:, None]
-            mean_p = torch.zeros(B, 3, device=dev).index_add_(0, ix['pocket_batch'], pocket_xyz.float()) / ix['kcnt'][:, None]
+            mean_l = ops.sum_sorted_segments(li, ix['ncnt']) / ix['ncnt'][:, None]              # (fixed-order sums: stage 2 is bit-reproducible)
+            mean_p = ops.sum_sorted_segments(pocket_xyz.float(), ix['kcnt']) / ix['kcnt'][:, None]
             X = torch.zeros(ix['N'], 3, device=dev)
             X[ix['lig_pos']] = li - mean_l[cb] + mean_p[cb]
             X[ix['prot_pos']] = pocket_xyz.float()

@@ -1026,6 +1026,14 @@ def take_rows_few(x, index64):
     return x.index_select(0, index64)
 
 
+def sum_sorted_segments(x, counts):
+    """Per-segment sums of the rows of x whose segments are CONTIGUOUS (a sorted batch vector) with `counts` rows each -- one thread
+    walks a segment in order (torch.segment_reduce): no float atomics, the same bits every run.  (zeros(B, .).index_add_(0, batch, x),
+    the form the reference's scatter_mean suggests, adds in arrival order: the stage-2 input coordinates then differ in their last bits
+    from run to run, and with them everything downstream.)  Index glue on inputs: not differentiable."""
+    return torch.segment_reduce(x.detach(), "sum", lengths=counts.to(torch.int64), axis=0, unsafe=True)
+
+
 def take_unique_rows(x, index64):
     """Row gather with an index free of repeats (the caller's contract)."""
     return _TakeUniqueRows.apply(x, index64) if _needs_grad(x) else x.index_select(0, index64)

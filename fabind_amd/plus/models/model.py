@@ -215,13 +215,13 @@ class FABindPlus(nn.Module):
         mask = ~segment | is_global
         batch = torch.repeat_interleave(torch.arange(B, device=dev), n)
         pocket_xyz = data.node_xyz_whole[keep].float()
-        bias = torch.zeros(B, 3, device=dev).index_add_(0, pocket_batch, pocket_xyz) / kcnt[:, None]   # pocket centre
+        bias = ops.sum_sorted_segments(pocket_xyz, kcnt) / kcnt[:, None]   # pocket centre (fixed-order sums, like the two below)
         pocket_xyz = pocket_xyz - bias[pocket_batch]
         if shift_coords:                                            # the caller's loss reads data.coords after forward
             data.coords = data.coords - bias[cb].to(data.coords.dtype)
         li = data['compound'].node_coords.float()
-        mean_l = torch.zeros(B, 3, device=dev).index_add_(0, cb, li) / ncnt[:, None]
-        mean_p = torch.zeros(B, 3, device=dev).index_add_(0, pocket_batch, pocket_xyz) / kcnt[:, None]
+        mean_l = ops.sum_sorted_segments(li, ncnt) / ncnt[:, None]
+        mean_p = ops.sum_sorted_segments(pocket_xyz, kcnt) / kcnt[:, None]
         X = torch.zeros(N, 3, device=dev)
         X[lig_pos] = li - mean_l[cb] + mean_p[cb]
         X[prot_pos] = pocket_xyz
