@@ -26,8 +26,11 @@ def _offsets(cnt):
 
 
 def _seg_mean(x, idx, n):
-    cnt = torch.bincount(idx, minlength=n).clamp(min=1).to(x.dtype)
-    return torch.zeros(n, x.shape[1], dtype=x.dtype, device=x.device).index_add_(0, idx, x) / cnt[:, None]
+    """Per-complex mean of the rows of x; idx is a SORTED batch vector (complex-contiguous rows): the sums run in a fixed order
+    (torch.segment_reduce: one thread walks a segment), not as float atomics in arrival order -- the batches this builder emits are
+    bit-identical from run to run."""
+    cnt = torch.bincount(idx, minlength=n)
+    return torch.segment_reduce(x, "sum", lengths=cnt, axis=0, unsafe=True) / cnt.clamp(min=1).to(x.dtype)[:, None]
 
 
 _POOL = {}
