@@ -542,3 +542,43 @@ def test_plus_stack_training_with_the_folded_edge_layernorm_follows_weight_updat
         assert ga[0] < max(1.5 * ga[1], 2e-2) and gf[0] < max(1.5 * gf[1], 2e-2)
     moved = float((on[1][1] - on[0][1]).abs().max()) / float(on[0][1].abs().max())
     assert moved > 0.05, moved                                     # the second call saw the updated edge MLPs
+
+
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+def test_plus_model_step_is_bit_reproducible(prec):
+    """Two FABindPlus training steps (eval mode: no random draws; 7-term loss with the permutation-invariant term) from identical
+    weights and inputs: loss, every output and every parameter gradient bit for bit (tools/probes/plus_repeat.py)."""
+    from fabind_amd import engine, synthetic
+    from fabind_amd.plus.models import compute_loss, get_model
+    dev = torch.device("cuda:0")
+    a = _args(128, 2, 1)
+    for k, v in dict(pocket_pred_hidden_size=64, pocket_pred_layers=1, pocket_pred_n_iter=1, random_n_iter=False, use_for_radius_pred="ligand",
+                     dis_map_thres=15.0, pocket_radius_buffer=5.0, min_pocket_radius=20.0, force_fix_radius=False, use_clustering=False,
+                     gs_tau=1.0, gs_hard=False, pocket_radius=20.0, train_pred_pocket_noise=0.0, local_eval=False).items():
+        setattr(a, k, v)
+    torch.manual_seed(0)
+    engine.set_precision(prec)
+    try:
+        m = get_model(a, _Logger()).to(dev).eval()
+        sizes = [(300, 19), (245, 34), (410, 26), (152, 11), (333, 40), (280, 8)]
+        base = synthetic.make_hetero_batch(sizes, seed=3).to(dev)
+        radius = torch.tensor([6.0, 7.0, 5.0, 6.5, 6.0, 5.5], device=dev)
+        num_atoms = [s[1] for s in sizes]
+        isos = [[list(range(n)), list(reversed(range(n)))] for n in num_atoms]
+        res = []
+        for _ in range(2):
+            for p_ in m.parameters():
+                p_.grad = None
+            data = base.clone()
+            data.ligand_radius, data.num_atoms, data.isomorphisms = radius, num_atoms, isos
+            out = m(data, train=False)
+            loss, _ = compute_loss(out, data)
+            loss.backward()
+            res.append(([o.detach().clone() for o in out if torch.is_tensor(o)], float(loss.detach()),
+                        {k: p_.grad.clone() for k, p_ in m.named_parameters() if p_.grad is not None}))
+    finally:
+        engine.set_precision("fp32")
+    assert res[0][1] == res[1][1]
+    assert all(torch.equal(x, y) for x, y in zip(res[0][0], res[1][0]))
+    bad = [k for k in res[0][2] if not torch.equal(res[0][2][k], res[1][2][k])]
+    assert len(res[0][2]) >= 280 and not bad, bad
