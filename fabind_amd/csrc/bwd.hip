@@ -31,9 +31,13 @@ extern "C" int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_d
 
 // out = dy * act'(y) AND its column sums (the bias gradient) in the same pass over dy: one block = 256 columns x a
 // chunk of rows, 4 row-lanes with 4 independent row loads in flight, fixed-order combine (deterministic).
+// DROP: out = dy * mask(seed, r, c) / (1 - p) with the counter-based dropout mask of the GEMM epilogues (gemm.hip: C = R + drop(A W^T + b))
+// regenerated from its key -- the adjoint of an epilogue dropout that is followed by a residual (the zeros of the saved output do not
+// tell the mask there); `scale` = 1 / (1 - p), y is not read.
+template <bool DROP>
 __global__ __launch_bounds__(256) void mul_dact_colsum_kernel(const void* __restrict__ dy, int dy_dt, const void* __restrict__ y,
                                                               int y_dt, int act, void* __restrict__ out, int out_dt, int R, int C,
-                                                              float* scratch, int rows_per, float scale) {
+                                                              float* scratch, int rows_per, float scale, uint32_t thr, uint32_t seed) {
     __shared__ float4 part[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + lane * 4;
@@ -50,8 +54,15 @@ __global__ __launch_bounds__(256) void mul_dact_colsum_kernel(const void* __rest
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float4 o = make_float4(scale * g[u].x * apply_dact(v[u].x, act), scale * g[u].y * apply_dact(v[u].y, act),
-                                             scale * g[u].z * apply_dact(v[u].z, act), scale * g[u].w * apply_dact(v[u].w, act));
+                float4 o;
+                if (DROP) {
+                    const uint32_t k0 = seed + (uint32_t)(r + 4 * u) * (uint32_t)C + (uint32_t)c;
+                    o = make_float4(((fb_hash32(k0) & 0xffffu) >= thr) ? scale * g[u].x : 0.f, ((fb_hash32(k0 + 1u) & 0xffffu) >= thr) ? scale * g[u].y : 0.f,
+                                    ((fb_hash32(k0 + 2u) & 0xffffu) >= thr) ? scale * g[u].z : 0.f, ((fb_hash32(k0 + 3u) & 0xffffu) >= thr) ? scale * g[u].w : 0.f);
+                } else {
+                    o = make_float4(scale * g[u].x * apply_dact(v[u].x, act), scale * g[u].y * apply_dact(v[u].y, act),
+                                    scale * g[u].z * apply_dact(v[u].z, act), scale * g[u].w * apply_dact(v[u].w, act));
+                }
                 st4_any(out, out_dt, (size_t)(r + 4 * u) * C + c, o);
                 s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
             }
@@ -59,8 +70,15 @@ __global__ __launch_bounds__(256) void mul_dact_colsum_kernel(const void* __rest
         for (; r < r1; r += 4) {
             const float4 g = ld4_any(dy, dy_dt, (size_t)r * C + c);
             const float4 v = y ? ld4_any(y, y_dt, (size_t)r * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 o = make_float4(scale * g.x * apply_dact(v.x, act), scale * g.y * apply_dact(v.y, act),
-                                         scale * g.z * apply_dact(v.z, act), scale * g.w * apply_dact(v.w, act));
+            float4 o;
+            if (DROP) {
+                const uint32_t k0 = seed + (uint32_t)r * (uint32_t)C + (uint32_t)c;
+                o = make_float4(((fb_hash32(k0) & 0xffffu) >= thr) ? scale * g.x : 0.f, ((fb_hash32(k0 + 1u) & 0xffffu) >= thr) ? scale * g.y : 0.f,
+                                ((fb_hash32(k0 + 2u) & 0xffffu) >= thr) ? scale * g.z : 0.f, ((fb_hash32(k0 + 3u) & 0xffffu) >= thr) ? scale * g.w : 0.f);
+            } else {
+                o = make_float4(scale * g.x * apply_dact(v.x, act), scale * g.y * apply_dact(v.y, act),
+                                scale * g.z * apply_dact(v.z, act), scale * g.w * apply_dact(v.w, act));
+            }
             st4_any(out, out_dt, (size_t)r * C + c, o);
             s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
         }
@@ -84,8 +102,25 @@ extern "C" int fabind_mul_dact_colsum(const void* dy, int dy_dt, const void* y, 
     FB_REQUIRE(((uintptr_t)dy % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)out % 16 == 0),
                "fabind_mul_dact_colsum: 16-byte alignment");
     const int rows_per = (R + nchunk - 1) / nchunk;
-    hipLaunchKernelGGL(mul_dact_colsum_kernel, dim3((C + 255) / 256, nchunk), dim3(256), 0, stream, dy, dy_dt, y, y_dt, act, out,
-                       out_dt, R, C, scratch, rows_per, scale);
+    hipLaunchKernelGGL(mul_dact_colsum_kernel<false>, dim3((C + 255) / 256, nchunk), dim3(256), 0, stream, dy, dy_dt, y, y_dt, act, out,
+                       out_dt, R, C, scratch, rows_per, scale, 0u, 0u);
+    hipLaunchKernelGGL(sum_chunks_kernel, SUMC_GRID(C), dim3(SUMC_BLOCK), 0, stream, scratch, colsum, C, nchunk);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+// out [R, C] = dy * mask / (1 - p) (+ its column sums): the adjoint of the GEMM epilogues' dropout (fabind_gemm with p_drop > 0, key
+// seed + r * C + c), for the epilogues whose saved output does not show the mask (dropout ahead of a residual, or with no activation)
+extern "C" int fabind_mul_dropmask_colsum(const void* dy, int dy_dt, void* out, int out_dt, int R, int C, float p_drop, unsigned seed,
+                                          float* colsum, float* scratch, int nchunk, hipStream_t stream) {
+    if (R <= 0 || C <= 0) return 0;
+    FB_REQUIRE(C % 4 == 0 && nchunk >= 1, "fabind_mul_dropmask_colsum: C % 4 == 0, nchunk >= 1");
+    FB_REQUIRE(((uintptr_t)dy % 16 == 0) && ((uintptr_t)out % 16 == 0), "fabind_mul_dropmask_colsum: 16-byte alignment");
+    FB_REQUIRE(p_drop > 0.f && p_drop < 1.f, "fabind_mul_dropmask_colsum: p_drop in (0, 1)");
+    const uint32_t thr = (uint32_t)(p_drop * 65536.0f + 0.5f);
+    const float scale = 1.0f / (1.0f - (float)thr / 65536.0f);
+    const int rows_per = (R + nchunk - 1) / nchunk;
+    hipLaunchKernelGGL(mul_dact_colsum_kernel<true>, dim3((C + 255) / 256, nchunk), dim3(256), 0, stream, dy, dy_dt, nullptr, 0, FB_ACT_NONE, out,
+                       out_dt, R, C, scratch, rows_per, scale, thr, (uint32_t)seed);
     hipLaunchKernelGGL(sum_chunks_kernel, SUMC_GRID(C), dim3(SUMC_BLOCK), 0, stream, scratch, colsum, C, nchunk);
     FB_CHECK_LAUNCH();
     return 0;

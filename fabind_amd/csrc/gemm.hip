@@ -345,6 +345,10 @@ __device__ __forceinline__ void gemm_epilogue_f32(const FabindGemmArgs& p, f32x4
     const int wm = wave >> 1, wn = wave & 1, fr = lane & 15, cq = lane >> 4;
     float* C = (float*)p.C;
     const float* R = (const float*)p.R;
+    // epilogue dropout (round 5: train-mode dropout AHEAD of the residual, C = R + drop(A W^T + b)): the counter-based mask of the generic
+    // epilogue, keyed by (seed, row, col) -- the adjoint regenerates it (fabind_mul_dropmask_colsum), nothing is stored
+    const uint32_t drop_thr = (uint32_t)(p.p_drop * 65536.0f + 0.5f);
+    const float drop_scale = 1.0f / (1.0f - (float)drop_thr / 65536.0f);
     const bool vec = (ldc % 4 == 0) && (N % 4 == 0) && (((uintptr_t)C & 15) == 0) &&
                      (!HAS_R || ((p.ldr % 4 == 0) && (((uintptr_t)R & 15) == 0))) &&
                      stage_bytes >= (int)(blockDim.x / 64) * 32 * F32_SLAB_LD * 4;
@@ -361,6 +365,7 @@ __device__ __forceinline__ void gemm_epilogue_f32(const FabindGemmArgs& p, f32x4
                     const int row = m0 + wm * 64 + i * 16 + cq * 4 + r;
                     if (row < M) {
                         float v = acc[i][j][r] + bv;
+                        if (drop_thr) v *= ((fb_hash32(p.drop_seed + (uint32_t)row * (uint32_t)N + (uint32_t)col) & 0xffffu) >= drop_thr) ? drop_scale : 0.f;
                         if (HAS_R) v += R[(size_t)row * p.ldr + col];
                         C[(size_t)row * ldc + col] = v;
                         if (p.C16) ((bf16_t*)p.C16)[(size_t)row * p.ldc16 + col] = f32_to_bf16(v);
@@ -393,6 +398,13 @@ __device__ __forceinline__ void gemm_epilogue_f32(const FabindGemmArgs& p, f32x4
             const int row = m0 + wm * 64 + half * 32 + rl;
             float4 v = *(const float4*)&my[rl * F32_SLAB_LD + c4];
             if (row < M && col < N) {
+                if (drop_thr) {                          // (uniform branch)
+                    const uint32_t k0 = p.drop_seed + (uint32_t)row * (uint32_t)N + (uint32_t)col;
+                    v.x *= ((fb_hash32(k0) & 0xffffu) >= drop_thr) ? drop_scale : 0.f;
+                    v.y *= ((fb_hash32(k0 + 1u) & 0xffffu) >= drop_thr) ? drop_scale : 0.f;
+                    v.z *= ((fb_hash32(k0 + 2u) & 0xffffu) >= drop_thr) ? drop_scale : 0.f;
+                    v.w *= ((fb_hash32(k0 + 3u) & 0xffffu) >= drop_thr) ? drop_scale : 0.f;
+                }
                 if (HAS_R) {
                     const float4 q = *(const float4*)&R[(size_t)row * p.ldr + col];
                     v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
@@ -1601,9 +1613,9 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
     if (!p.R) p.r_dtype = FB_DT_F32;
     FB_REQUIRE(p.r_dtype == FB_DT_F32 || p.r_dtype == FB_DT_BF16, "fabind_gemm: r_dtype");
     const bool r32 = p.r_dtype == FB_DT_F32;
-    if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && !p.r_index && p.C != nullptr && r32 &&
+    if (!p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && !p.r_index && p.C != nullptr && r32 &&
         p.c_dtype == FB_DT_F32 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
-        p.epi_fast = p.R ? 10 : 9;
+        p.epi_fast = p.R ? 10 : 9;                /* (with or without epilogue dropout ahead of the residual) */
     } else if (!drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.aux && !p.accumulate && p.R && p.r_index && p.C && r32 &&
                p.c_dtype == FB_DT_BF16 && p.act_epi == FB_ACT_NONE && !p.dotvec && !p.C2) {
         p.epi_fast = 11;

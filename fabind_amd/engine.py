@@ -528,15 +528,16 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
     H = h.shape[1]
     ad = ops.act_dtype()
     fast = _fast(h, x, p["W2"])
-    if pdrop == 0.0:                # (train mode adds torch-side dropout consumers that do not know the shared buffer)
-        h = ops.shared_grad(h)      # three consumers (first edge Linear, node MLP, residual): one gradient buffer, no autograd adds
-    hin = _b16(h) if fast else h
     # bf16x3 with config.set_x3_backward("exact"): a differentiable pass takes the UNFUSED edge pipeline below -- split contractions in the
     # forward, the input gradients AND the weight gradients, fp32 edge tensors: no bf16 rounding anywhere in the edge path's adjoint (the
     # fused backward kernels contract bf16 operands)
     exact_edge = (get_precision() == "bf16x3" and not config_x3_backward_bf16() and not fast
                   and ops.needs_grad(h, x, p["W2"], p["W_ab"]))
-    if get_precision() in ("bf16", "bf16x3") and FUSED_EDGE and H in (64, 128, 256, 512) and not exact_edge:
+    fused_edge = get_precision() in ("bf16", "bf16x3") and FUSED_EDGE and H in (64, 128, 256, 512) and not exact_edge
+    if pdrop == 0.0 or fused_edge:  # (the unfused train-mode path has torch-side dropout consumers that do not know the shared buffer)
+        h = ops.shared_grad(h)      # three consumers (first edge Linear, node MLP, residual): one gradient buffer, no autograd adds
+    hin = _b16(h) if fast else h
+    if fused_edge:
         # the whole edge pipeline in one kernel each way, edge tensors stay in LDS (csrc/fused_edge.hip); under
         # autograd nothing per-edge is saved, the backward kernel recomputes tile by tile.  Train-mode dropout on the
         # messages is a counter-based mask evaluated inside both kernels.
@@ -545,17 +546,16 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
         agg, s = ops.fused_edge(AB, rhohat, p["w_r"], p["W2"], p["b2"], p["Wc"], p["bc"], p["w3"], H, g, pdrop,
                                 frags=p.get("_frags") if get_precision() == "bf16" else None)
         x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
-        if pdrop == 0.0 and not fast:
-            # node MLP + residual as one autograd node (activation adjoint and residual gradient inside GEMM epilogues)
-            return ops.mlp2(hin, p["Wn1"], p["bn1"], K.ACT_SILU, p["Wn2"], p["bn2"], residual=h, x2=agg, want16=True), x_new
+        if not fast:
+            # node MLP + residual as one autograd node (activation adjoint and residual gradient inside GEMM epilogues); train mode: the
+            # dropout ahead of the residual (egnn.py:106) inside the second Linear's epilogue, its mask regenerated by the adjoint
+            return ops.mlp2(hin, p["Wn1"], p["bn1"], K.ACT_SILU, p["Wn2"], p["bn2"], residual=h, x2=agg, want16=True, p_drop=pdrop), x_new
         if fast and pdrop == 0.0:
             hn = _node_chain(p, "_nc_node", p["Wn1"], p["bn1"], p["Wn2"], p["bn2"], K.ACT_SILU, 0, hin, ops._mm_in(agg), h, True)
             if hn is not None:
                 return hn, x_new
         t = ops.linear(hin, p["Wn1"], p["bn1"], x2=agg, act_epi=K.ACT_SILU, out_dtype=ad)
-        if pdrop > 0.0:
-            return h + _drop(ops.linear(t, p["Wn2"], p["bn2"]), pdrop), x_new
-        return ops.linear(t, p["Wn2"], p["bn2"], residual=h, want16=True), x_new
+        return ops.linear(t, p["Wn2"], p["bn2"], residual=h, want16=True, p_drop=pdrop), x_new      # (no-grad: epilogue dropout)
     AB = ops.linear(hin, p["W_ab"], p["b_ab"], out_dtype=ad)                           # [N,2H] node-level
     d, rhohat = ops.edge_geom(x, g.row_ctx, g.col_ctx, g.rp_ctx, lay, g.ctx_by_col)
     S1 = ops.gcl_pre(AB, H, g, rhohat, p["w_r"], act=K.ACT_SILU)                        # [E,H] silu(first edge Linear)
@@ -579,8 +579,7 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     fast = _fast(h, p["Wo_p"])
     od = ops.act_dtype()
     c16 = (lambda t: _b16(t)) if fast else (lambda t: t)
-    if pdrop == 0.0:
-        h = ops.shared_grad(h)      # consumers: ligand row gather, q / gate projection, residual of the attention update
+    h = ops.shared_grad(h)          # consumers: ligand row gather, q / gate projection, residual of the attention update
     hc = ops.take_rows(h, lay.c_index64)
     scale = 1.0 / math.sqrt(32.0)
     # forward-only bf16 passes recompute the pair bias inside the attention kernels (ops.PairBias.fused); everything else reads the
@@ -601,18 +600,18 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     og = ops.cross_attn_fused(qg, kv, pairbias, 2 * layer, 0, lay, scale) if fused else \
         ops.cross_attn_fused_train(qg, kv, pairbias, 2 * layer, 0, scale) if ftrain else \
         ops.cross_attn(qg, kv, bias_p, 0, 4, lay.desc_pf, lay.B, lay.max_P, lay.max_C, scale)
-    hp = (h + _drop(ops.linear(c16(og), p["Wo_p"], p["bo_p"]), pdrop)) if pdrop > 0.0 else \
-        ops.linear(og if p.get("Wo_p32") is not None else c16(og), p["Wo_p"], p["bo_p"], residual=h, want16=True, W32=p.get("Wo_p32"))
-    if pdrop == 0.0:
-        hp = ops.shared_grad(hp)    # consumers: k / v projection of the ligand-query block, transition, its residual
+    # (train mode: RowAttentionBlock's dropout on the attention update ahead of the residual, cross_att.py:128, inside the epilogue -- the
+    #  adjoint regenerates its mask; a split-precision site falls back to its bf16 operands then)
+    hp = ops.linear(og if p.get("Wo_p32") is not None else c16(og), p["Wo_p"], p["bo_p"], residual=h, want16=True, W32=p.get("Wo_p32"),
+                    p_drop=pdrop)
+    hp = ops.shared_grad(hp)        # consumers: k / v projection of the ligand-query block, transition, its residual
     hp16 = c16(hp)
     qg = ops.linear(c16(hc), p["Wqg_c"], p["bqg_c"])
     kv = ops.linear(hp if p.get("Wkv_c32") is not None else hp16, p["Wkv_c"], W32=p.get("Wkv_c32"))       # [N, 256], protein rows used
     og = ops.cross_attn_fused(qg, kv, pairbias, 2 * layer + 1, 1, lay, scale) if fused else \
         ops.cross_attn_fused_train(qg, kv, pairbias, 2 * layer + 1, 1, scale) if ftrain else \
         ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
-    hc = (hc + _drop(ops.linear(c16(og), p["Wo_c"], p["bo_c"]), pdrop)) if pdrop > 0.0 else \
-        ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc)
+    hc = ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc, p_drop=pdrop)
     if fast:
         hp2 = _node_chain(p, "_nc_tp", p["Wt1_p"], p["bt1_p"], p["Wt2_p"], p["bt2_p"], K.ACT_RELU, 1, hp16, None, hp, True) \
             if pdrop == 0.0 else None
@@ -661,7 +660,7 @@ def egnn_forward(P, h, x, lay, g, las, x_las, a0b0, pairbias, scale, step, drop=
     """MCAttEGNN.forward (egnn.py:392-466).  drop = dict of dropout probabilities (train mode) or None (eval)."""
     clampv = 10.0 / scale
     dp = drop or {}
-    h = _drop(ops.linear(h, P["W_in"], P["b_in"], want16=True, W32=P.get("W_in32")), dp.get("gnn", 0.0))
+    h = ops.linear(h, P["W_in"], P["b_in"], want16=True, W32=P.get("W_in32"), p_drop=dp.get("gnn", 0.0))      # (MCAttEGNN.dropout: in the epilogue)
     cap = DEBUG_CAPTURE
     for i in range(P["L"]):
         h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv, dp.get("gcl", 0.0))

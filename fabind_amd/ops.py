@@ -207,6 +207,18 @@ def _mul_dact_colsum(dy, aux, act, out_dtype, scale=1.0):
     return out, db
 
 
+def _mul_dropmask_colsum(dy, p_drop, seed, out_dtype):
+    """(dy * keep(seed, r, c) / (1 - p), its column sums): the adjoint of a GEMM epilogue's dropout with the mask regenerated from its key."""
+    R, C = dy.shape
+    out = torch.empty((R, C), dtype=out_dtype, device=dy.device)
+    nchunk = max(1, min(4096, (R + 63) // 64))
+    scratch = torch.empty((nchunk, C), dtype=torch.float32, device=dy.device)
+    db = torch.empty(C, dtype=torch.float32, device=dy.device)
+    check(load().fabind_mul_dropmask_colsum(ptr(dy), dt_code(dy.dtype), ptr(out), dt_code(out_dtype), R, C, float(p_drop), int(seed) & 0xFFFFFFFF,
+                                            ptr(db), ptr(scratch), nchunk, stream()), "fabind_mul_dropmask_colsum")
+    return out, db
+
+
 def _mm_in(x):
     """Operand as the GEMM wants it: bf16 copy of an fp32 activation in bf16 mode.  The copy is remembered on the tensor
     (keyed on its version counter, so an in-place update invalidates it): a residual-stream tensor feeds two or three
@@ -248,11 +260,17 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, W, b, x2, residual, act_epi, out_dtype, holder=None, p_drop=0.0, seed=0, W32=None):
         assert act_epi in (K.ACT_NONE, K.ACT_RELU, K.ACT_SILU)
-        # epilogue dropout under autograd: ReLU outputs only -- y = relu(pre) keep / (1 - p) is what is saved, its zeros ARE the dropped
-        # positions (and the inactive units), so the adjoint is [y > 0] / (1 - p): no mask is stored or recomputed
-        assert p_drop == 0.0 or (act_epi == K.ACT_RELU and residual is None), "epilogue dropout under autograd: ReLU, no residual"
+        # epilogue dropout under autograd.  ReLU outputs: y = relu(pre) keep / (1 - p) is what is saved, its zeros ARE the dropped
+        # positions (and the inactive units), so the adjoint is [y > 0] / (1 - p): no mask is stored or recomputed.  No activation, with
+        # or without a residual (round 5: the reference's train-mode dropouts AHEAD of `h + ...`, egnn.py:106, cross_att.py:128): fp32
+        # output through the fp32 epilogue, the adjoint regenerates the counter-based mask from (seed, row, col) -- _mul_dropmask_colsum
+        drop_regen = p_drop > 0.0 and act_epi == K.ACT_NONE
+        assert p_drop == 0.0 or (act_epi == K.ACT_RELU and residual is None) or \
+            (drop_regen and out_dtype == torch.float32 and x2 is None and W32 is None and W.shape[0] % 4 == 0), \
+            "epilogue dropout under autograd: ReLU without a residual, or no activation with an fp32 output"
         thr = int(p_drop * 65536.0 + 0.5)
         ctx.drop_scale = 1.0 / (1.0 - thr / 65536.0)
+        ctx.drop_regen = (float(p_drop), int(seed)) if drop_regen else None
         xin, x2in = _mm_in(x), _mm_in(x2)
         D = None
         M, N = x.shape[0], W.shape[0]
@@ -294,7 +312,11 @@ class _Linear(torch.autograd.Function):
         if fuse_db and ctx.needs_input_grad[1] and _db_in_tn(dy):
             fuse_db = False                                                       # ... or with the queued weight-gradient contraction
         md_op = _mul_dact_colsum if fuse_db else (lambda *a: (_mul_dact(*a), None))      # (dy, aux, act, out dtype[, scale])
-        if ctx.act_epi == K.ACT_RELU:
+        if ctx.drop_regen is not None:
+            dpre, db = _mul_dropmask_colsum(dy, ctx.drop_regen[0], ctx.drop_regen[1], md)
+            if not want_db:
+                db = None
+        elif ctx.act_epi == K.ACT_RELU:
             dpre, db = md_op(dy, y, K.ACT_RELU, md, ctx.drop_scale)
         elif ctx.act_epi == K.ACT_SILU:
             dpre, db = md_op(dy, D, K.ACT_STORED_DERIV, md)
@@ -413,8 +435,11 @@ class _MLP2(torch.autograd.Function):
         shared gradient buffer), so autograd adds nothing."""
 
     @staticmethod
-    def forward(ctx, x, x2, W1, b1, W2, b2, residual, act, holder=None):
+    def forward(ctx, x, x2, W1, b1, W2, b2, residual, act, holder=None, p_drop=0.0, seed=0):
+        # p_drop > 0 (round 5, train mode): dropout on the second Linear's output AHEAD of the residual (egnn.py:106) inside its fp32
+        # epilogue; the adjoint regenerates the mask from (seed, row, col) in the one pass that casts dy
         assert act in (K.ACT_RELU, K.ACT_SILU)
+        ctx.drop = (float(p_drop), int(seed)) if p_drop > 0.0 else None
         xin, x2in = _mm_in(x), _mm_in(x2)
         M, N1 = x.shape[0], W1.shape[0]
         ad = act_dtype()
@@ -425,7 +450,7 @@ class _MLP2(torch.autograd.Function):
         if holder is not None:
             y16 = torch.empty((M, W2.shape[0]), dtype=torch.bfloat16, device=x.device)
             holder.append(y16)
-        y, _ = K.gemm(t, W2, bias=b2, residual=residual, out_dtype=torch.float32, out16=y16)
+        y, _ = K.gemm(t, W2, bias=b2, residual=residual, out_dtype=torch.float32, out16=y16, p_drop=p_drop, seed=seed)
         ctx.act, ctx.has_x2, ctx.has_res = act, x2 is not None, residual is not None
         ctx.res_is_x = residual is x
         ctx.sink_x, ctx.sink_res = _sink_of(x), _sink_of(residual)
@@ -440,7 +465,9 @@ class _MLP2(torch.autograd.Function):
         dy = dy.contiguous()
         md = mm_dtype()
         ni = ctx.needs_input_grad
-        if dy.dtype != md and ni[4] and _db_in_tn(dy):
+        if ctx.drop is not None:
+            dy16, db2 = _mul_dropmask_colsum(dy, ctx.drop[0], ctx.drop[1], md)   # d (W2 t + b2) = dy * keep / (1 - p): mask regenerated
+        elif dy.dtype != md and ni[4] and _db_in_tn(dy):
             dy16, db2 = _mul_dact(dy, None, K.ACT_NONE, md), None           # cast only: the bias gradient rides with dW2's contraction
         elif dy.dtype != md:
             dy16, db2 = _mul_dact_colsum(dy, None, K.ACT_NONE, md)          # one pass: cast + bias gradient
@@ -477,19 +504,20 @@ class _MLP2(torch.autograd.Function):
             dres = ctx.sink_res.deposit(dres)
         if ctx.has_x2 and ni[1]:
             dx2, _ = K.gemm(dpre, W1t[K1:], out_dtype=torch.float32 if ctx.x2_dtype == torch.float32 else ctx.x2_dtype)
-        return dx, dx2, dW1, db1, dW2, (db2 if ni[5] else None), dres, None, None
+        return dx, dx2, dW1, db1, dW2, (db2 if ni[5] else None), dres, None, None, None, None
 
 
-def mlp2(x, W1, b1, act, W2, b2, residual=None, x2=None, want16=False):
+def mlp2(x, W1, b1, act, W2, b2, residual=None, x2=None, want16=False, p_drop=0.0):
     """act([x | x2] W1^T + b1) W2^T + b2 (+ residual) -> fp32.  One autograd node under autograd (see _MLP2); without
-    autograd two GEMMs with fused epilogues."""
+    autograd two GEMMs with fused epilogues.  p_drop: dropout on the second Linear's output ahead of the residual, in its epilogue."""
     if _needs_grad(x, x2, W1, b1, W2, b2, residual):
         K.tn_hook(W1, b1, W2, b2)
         holder = [] if _want16(torch.float32, K.ACT_NONE, want16) else None
-        y = _MLP2.apply(x, x2, W1, b1, W2, b2, residual, act, holder)
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
+        y = _MLP2.apply(x, x2, W1, b1, W2, b2, residual, act, holder, p_drop, seed)
         return _attach_b16(y, holder[0] if holder else None)
     t = linear(x, W1, b1, act_epi=act, x2=x2, out_dtype=act_dtype())
-    return linear(t, W2, b2, residual=residual, want16=want16)
+    return linear(t, W2, b2, residual=residual, want16=want16, p_drop=p_drop)
 
 
 class _MLP2Relu(torch.autograd.Function):

@@ -60,7 +60,8 @@ const char* fabind_last_error(void);
  *     fabind_gcl_edge_fused_bwd_set_variant 0 / 5 only, fabind_gcl_edge_fused_bwd_set_tile 64 only (their other kernels are no longer built);
  *     fabind_gcl_edge_fused_x3_train added (the split-bf16 forward that saves M / silu'(pre2) / pre3 for the two-contraction backward);
  *     fabind_inter_attn_fwd_rows / fabind_inter_attn_bwd_rows added (inter-edge attention with the rows dealt by degree: heavy rows on four waves);
- *     fabind_edge_lnfold_bwd (+ _blocks) added (FABind+: the LayerNorm-folded first edge Linear under autograd).
+ *     fabind_edge_lnfold_bwd (+ _blocks) added (FABind+: the LayerNorm-folded first edge Linear under autograd);
+ *     fabind_mul_dropmask_colsum added, fabind_gemm's fp32 (+ residual) epilogue takes p_drop (train-mode dropout ahead of a residual).
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 17
 int fabind_abi_version(void);
@@ -574,6 +575,12 @@ int fabind_mul_dact(const void* dy, int dy_dt, const void* y, int y_dt, int act,
  * so d y / d pre = [y > 0] / (1 - p) -- the dropped positions are exactly the zeros of y, no mask is stored or recomputed. */
 int fabind_mul_dact_colsum(const void* dy, int dy_dt, const void* y, int y_dt, int act, void* out, int out_dt, int R, int C,
                            float* colsum, float* scratch, int nchunk, float scale, hipStream_t stream);
+/* out [R,C] = dy * keep(seed, r, c) / (1 - p) and its column sums: the adjoint of fabind_gemm's epilogue dropout (key seed + r * C + c,
+ * C = the GEMM's N) where the saved output does not show the mask -- dropout AHEAD of a residual (the train-mode sites of the
+ * reference: nn.Dropout on the node-MLP output / the attention update before `h + ...`, FABind/fabind/models/egnn.py:106,
+ * cross_att.py:128) or without an activation.  Nothing is stored by the forward: the mask is regenerated from its key. */
+int fabind_mul_dropmask_colsum(const void* dy, int dy_dt, void* out, int out_dt, int R, int C, float p_drop, unsigned seed,
+                               float* colsum, float* scratch, int nchunk, hipStream_t stream);
 int fabind_rowdot_bwd(const void* z, int z_dt, const float* dpart, int np, const float* u, int act, int M, int N,
                       void* dz, float* du, float* scratch, int nchunk, hipStream_t stream);
 int fabind_edge_geom_bwd(const float* d, const float* rho, const float* norm, const float* dd, const float* drhohat,

@@ -1480,3 +1480,81 @@ def test_row_gathers_with_copy_and_segment_sum_adjoints_match_index_select():
     ref = torch.zeros(640, 3, dtype=torch.float64, device=dev).index_add_(0, many, cot3.double())
     assert float((grads[0].double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
     assert float(grads[0][torch.bincount(many, minlength=640) == 0].abs().max() if (torch.bincount(many, minlength=640) == 0).any() else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_linear_with_epilogue_dropout_ahead_of_the_residual_under_autograd(prec, with_res):
+    """Round 5, train mode: y = r + drop(x W^T + b) (nn.Dropout ahead of `h + ...`: FABind/fabind/models/egnn.py:106, cross_att.py:128)
+    as ONE GEMM with the counter-based mask in its fp32 epilogue; the adjoint regenerates the mask from (seed, row, col)
+    (fabind_mul_dropmask_colsum).  Checked against the explicit formula with the mask read off the forward output: values, drop rate,
+    and the gradients of x, W, b and the residual; the bf16 operand copy of y carries the same values."""
+    from fabind_amd import config, ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    M, Kd, N, pd = 3001, 256, 512, 0.1
+    x0, W0 = torch.randn(M, Kd, generator=g).to(dev), (torch.randn(N, Kd, generator=g) / Kd ** 0.5).to(dev)
+    b0, r0, cot = torch.randn(N, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev), torch.randn(M, N, generator=g).to(dev)
+    config.set_precision(prec)
+    try:
+        wd = ops.mm_dtype()
+        x, W, b, r = (t.clone().requires_grad_(True) for t in (x0, W0.to(wd), b0, r0))
+        torch.manual_seed(11)
+        y = ops.linear(x, W, b, residual=r if with_res else None, p_drop=pd, want16=True)
+        with torch.no_grad():
+            y0 = ops.linear(x0, W0.to(wd), b0)                     # no dropout, no residual
+        u = y.detach() - (r0 if with_res else 0.0)
+        keep = (u.abs() > 1e-6 * (1.0 + r0.abs() if with_res else 1.0)) | (y0.abs() < 1e-3)
+        rate = 1.0 - float(keep.float().mean())
+        assert abs(rate - pd) < 5e-3, rate
+        ref_u = y0 * keep / (1.0 - pd)
+        assert float((u - ref_u).abs().max()) <= 2e-3 * float(y0.abs().max())
+        c16 = getattr(y, "_fab_b16", None)
+        assert c16 is None or float((c16[1].float() - y.detach()).abs().max()) <= 1e-2 * float(y.detach().abs().max())
+        (y * cot).sum().backward()
+        # reference: the same mask as a constant, torch autograd in fp32 on the operands the kernels saw
+        xr, Wr, br, rr = (t.clone().float().requires_grad_(True) for t in (x0, W0.to(wd).float(), b0, r0))
+        xin = xr if prec != "bf16" else xr + (xr.detach().to(torch.bfloat16).float() - xr.detach())
+        yr = (xin @ Wr.t() + br) * keep / (1.0 - pd) + (rr if with_res else 0.0)
+        (yr * cot).sum().backward()
+    finally:
+        config.set_precision("fp32")
+    tol = 2e-2 if prec == "bf16" else 1e-2                          # (bf16: d pre is rounded to bf16 before the two contractions; bf16x3: its weight gradient contracts bf16 roundings)
+    for name, a, b_ in (("x", x.grad, xr.grad), ("W", W.grad.float(), Wr.grad), ("b", b.grad, br.grad)) + ((("r", r.grad, rr.grad),) if with_res else ()):
+        err = float((a - b_).norm() / b_.norm())
+        assert err <= tol, (name, err)
+    if with_res:
+        assert torch.equal(r.grad, cot)
+
+
+def test_mlp2_with_dropout_ahead_of_the_residual_matches_the_two_linear_form():
+    """ops.mlp2(..., p_drop): the node MLP of MC_E_GCL in train mode as one autograd node; same seeds -> the same mask as
+    linear -> linear(residual, p_drop): values bit-equal, gradients to bf16 accuracy."""
+    from fabind_amd import config, ops
+    from fabind_amd import kernels as K
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    M, H, pd = 2050, 512, 0.1
+    h0, agg0 = torch.randn(M, H, generator=g).to(dev), torch.randn(M, H, generator=g).to(dev)
+    W1, b1 = (torch.randn(H, 2 * H, generator=g) / (2 * H) ** 0.5).to(dev), torch.randn(H, generator=g).to(dev)
+    W2, b2 = (torch.randn(H, H, generator=g) / H ** 0.5).to(dev), torch.randn(H, generator=g).to(dev)
+    cot = torch.randn(M, H, generator=g).to(dev)
+    config.set_precision("bf16")
+    try:
+        res = []
+        for fused in (True, False):
+            h, agg = h0.clone().requires_grad_(True), agg0.clone().requires_grad_(True)
+            ws = [t.clone().to(torch.bfloat16).requires_grad_(True) if t.dim() == 2 else t.clone().requires_grad_(True) for t in (W1, b1, W2, b2)]
+            torch.manual_seed(5)
+            if fused:
+                y = ops.mlp2(h, ws[0], ws[1], K.ACT_SILU, ws[2], ws[3], residual=h, x2=agg, p_drop=pd)
+            else:
+                t = ops.linear(h, ws[0], ws[1], x2=agg, act_epi=K.ACT_SILU, out_dtype=torch.bfloat16)
+                y = ops.linear(t, ws[2], ws[3], residual=h, p_drop=pd)
+            (y * cot).sum().backward()
+            res.append((y.detach(), h.grad, agg.grad, [w.grad.float() for w in ws]))
+    finally:
+        config.set_precision("fp32")
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b_ in [(res[0][1], res[1][1]), (res[0][2], res[1][2])] + list(zip(res[0][3], res[1][3])):
+        assert float((a - b_).norm() / b_.norm()) <= 1e-2
