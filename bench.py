@@ -228,6 +228,7 @@ def main():
     ap.add_argument("--whole-pocket", action="store_true",
                     help="--mode model: unbounded pocket radius -- the complex model and the heads see the whole 1500 / 40 graph (BASELINE "
                          "configs[2] read literally; the `config3_whole_graph` sub-object of the default line)")
+    ap.add_argument("--train-mode", action="store_true", help="fwdbwd / model: model.train() (dropout p = 0.1 at the reference's sites)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true",
                     help="run ONLY SURVEY 8(d)'s CPU-baseline protocol (oracle, B=2, >=3 warm-ups + 5 timed runs, 32 threads / torch default / 1 "
@@ -577,7 +578,7 @@ def main():
                      "algorithmic_bytes_per_launch": nbytes / cnt, "other_roofline": other})
         return out_
 
-    step, per_rank, _ = make_step(a.mode, a.n_iter, whole_pocket=a.whole_pocket)
+    step, per_rank, _ = make_step(a.mode, a.n_iter, train_mode=a.train_mode, whole_pocket=a.whole_pocket)
     dt, prof = timed(step, a.warmup, a.steps, os.environ.get("FABIND_BENCH_NO_PROFILE", "0") != "1")   # (=1: no per-launch events, A/B of their cost)
     poses = a.poses if a.mode == "plus_sampling" else 1
     value = per_rank * world * a.steps / dt * poses
@@ -610,6 +611,7 @@ def main():
                        "+ out layer, hidden %d, n_iter=%d, %s" % (a.batch, a.batch, a.n_prot, a.n_lig, a.layers, a.hidden,
                                                                    a.n_iter, a.mode),
                        "global_batch": a.batch * world, "n_iter": a.n_iter, "pass": a.mode,
+                       **({"train_mode": True} if a.train_mode else {}),
                        **({"loss": "stack modes: a fixed quadratic of the stack's two outputs, (X*X).mean() + 1e-6 (H*H).mean() -- every parameter "
                                    "the training step reaches gets a gradient; the reference's pocket-cls + coord + distmap losses need the "
                                    "full IaBNet around the stack: that is the `config3_whole_graph` sub-object (BASELINE configs[2] read "
