@@ -535,8 +535,9 @@ def ln_mlp(m, x, last_act, residual=None, out_dtype=torch.float32, pdrop=0.0):
 
 
 def lin_drop(x, W, b, residual, pd):
-    """residual + dropout(x W^T + b): epilogue dropout without autograd, torch mask under autograd."""
-    if pd > 0.0 and ops.needs_grad(x, W, b, residual):
+    """residual + dropout(x W^T + b) with the dropout inside the GEMM's fp32 epilogue; under autograd the adjoint regenerates the
+    counter-based mask (round 5: ops._Linear) -- a torch mask only for a residual that is not fp32."""
+    if pd > 0.0 and ops.needs_grad(x, W, b, residual) and not (EPI_DROP_GRAD and residual.dtype == torch.float32 and W.shape[0] % 4 == 0):
         return residual + _drop(ops.linear(x, W, b), pd)
     return ops.linear(x, W, b, residual=residual, p_drop=pd)
 
