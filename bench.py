@@ -711,7 +711,8 @@ def main():
         sub("fp32", "fwdbwd", a.n_iter, precision="fp32",
             note="the headline step in fp32 mode (exact-fp32 MFMA, unfused edge pipeline): the exact reference arithmetic")
         sub("train_mode", "fwdbwd", a.n_iter, train_mode=True, steps=5, warmup=2,
-            note="the headline step with model.train(): dropout p=0.1 at the reference's six sites")
+            note="the headline step with model.train(): dropout p=0.1 at the reference's six sites (per-edge: in the fused edge kernels; "
+                 "ahead of the residuals and after the input Linear: in the GEMM epilogues, masks regenerated by the adjoint)")
         sub("n_iter8", "fwdbwd", 8, note="production refinement loop: 8 stack passes, gradient on the last one.  GATE MISSED in this dtype: the "
                                            "bf16 ligand-RMSD gap to the fp32 oracle is 1.9e-4 A at n_iter 8 (4.7e-5 at 2 and 3.1e-5 at 1 = the "
                                            "headline's pass: inside the 1e-4 A gate; tests/test_gpu_headline.py) -- `n_iter8_gate` is the loop "
