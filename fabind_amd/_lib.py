@@ -118,6 +118,8 @@ SIGNATURES = {
     "fabind_add": [_vp, _vp, _vp, _l, _vp],
     "fabind_mul_dact": [_vp, _i, _vp, _i, _i, _vp, _i, _l, _f, _vp],
     "fabind_mul_dact_colsum": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _f, _vp],
+    "fabind_drop_mix": [_vp, _vp, _vp, _l, _f, ctypes.c_uint, _vp],
+    "fabind_drop_mix_bwd": [_vp, _vp, _vp, _l, _f, ctypes.c_uint, _vp],
     "fabind_mul_dropmask_colsum": [_vp, _i, _vp, _i, _i, _i, _f, ctypes.c_uint, _vp, _vp, _i, _vp],
     "fabind_rowdot_bwd": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "fabind_edge_geom_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],

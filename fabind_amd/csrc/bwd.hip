@@ -127,6 +127,61 @@ extern "C" int fabind_mul_dropmask_colsum(const void* dy, int dy_dt, void* out, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// out = h + drop(hn - h) and its adjoint (train mode: nn.Dropout on the aggregated inter-edge attention message ahead of the residual,
+// FABind/fabind/models/egnn.py:236) -- one pass each way with the counter-based mask of the GEMM epilogues keyed by (seed, linear index);
+// torch ran sub -> native_dropout -> add and their three adjoints over the [N, H] fp32 tensors.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void drop_mix_kernel(const float4* __restrict__ h, const float4* __restrict__ hn, float4* __restrict__ out,
+                                                       long n4, uint32_t thr, float scale, uint32_t seed) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 a = h[i], b = hn[i];
+    const uint32_t k0 = seed + (uint32_t)(i * 4);
+    float4 o;
+    o.x = a.x + (((fb_hash32(k0) & 0xffffu) >= thr) ? scale * (b.x - a.x) : 0.f);
+    o.y = a.y + (((fb_hash32(k0 + 1u) & 0xffffu) >= thr) ? scale * (b.y - a.y) : 0.f);
+    o.z = a.z + (((fb_hash32(k0 + 2u) & 0xffffu) >= thr) ? scale * (b.z - a.z) : 0.f);
+    o.w = a.w + (((fb_hash32(k0 + 3u) & 0xffffu) >= thr) ? scale * (b.w - a.w) : 0.f);
+    out[i] = o;
+}
+__global__ __launch_bounds__(256) void drop_mix_bwd_kernel(const float4* __restrict__ g, float4* __restrict__ dhn, float4* __restrict__ dh,
+                                                           long n4, uint32_t thr, float scale, uint32_t seed) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 a = g[i];
+    const uint32_t k0 = seed + (uint32_t)(i * 4);
+    float4 d;
+    d.x = ((fb_hash32(k0) & 0xffffu) >= thr) ? scale * a.x : 0.f;
+    d.y = ((fb_hash32(k0 + 1u) & 0xffffu) >= thr) ? scale * a.y : 0.f;
+    d.z = ((fb_hash32(k0 + 2u) & 0xffffu) >= thr) ? scale * a.z : 0.f;
+    d.w = ((fb_hash32(k0 + 3u) & 0xffffu) >= thr) ? scale * a.w : 0.f;
+    dhn[i] = d;
+    dh[i] = make_float4(a.x - d.x, a.y - d.y, a.z - d.z, a.w - d.w);
+}
+extern "C" int fabind_drop_mix(const float* h, const float* hn, float* out, long n, float p_drop, unsigned seed, hipStream_t stream) {
+    if (n <= 0) return 0;
+    FB_REQUIRE(n % 4 == 0 && ((((uintptr_t)h | (uintptr_t)hn | (uintptr_t)out) & 15) == 0), "fabind_drop_mix: n % 4 == 0, 16-byte aligned buffers");
+    FB_REQUIRE(p_drop > 0.f && p_drop < 1.f, "fabind_drop_mix: p_drop in (0, 1)");
+    const uint32_t thr = (uint32_t)(p_drop * 65536.0f + 0.5f);
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(drop_mix_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float4*)h, (const float4*)hn,
+                       (float4*)out, n4, thr, 1.0f / (1.0f - (float)thr / 65536.0f), (uint32_t)seed);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int fabind_drop_mix_bwd(const float* g, float* dhn, float* dh, long n, float p_drop, unsigned seed, hipStream_t stream) {
+    if (n <= 0) return 0;
+    FB_REQUIRE(n % 4 == 0 && ((((uintptr_t)g | (uintptr_t)dhn | (uintptr_t)dh) & 15) == 0), "fabind_drop_mix_bwd: n % 4 == 0, 16-byte aligned buffers");
+    FB_REQUIRE(p_drop > 0.f && p_drop < 1.f, "fabind_drop_mix_bwd: p_drop in (0, 1)");
+    const uint32_t thr = (uint32_t)(p_drop * 65536.0f + 0.5f);
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(drop_mix_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const float4*)g, (float4*)dhn,
+                       (float4*)dh, n4, thr, 1.0f / (1.0f - (float)thr / 65536.0f), (uint32_t)seed);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // adjoint of the row-dot epilogue:  part[m,t] = sum_{n in tile t} act(z[m,n]) u[n]
 //   dz[m,n] = dpart[m, n/128] * u[n] * act'(z[m,n]);   du[n] = sum_m dpart[m, n/128] * act(z[m,n])
 // ------------------------------------------------------------------------------------------------

@@ -652,7 +652,7 @@ def att_layer(p, h, x, lay, g, a0b0, pairbias, layer, clampv, pdrop=0.0, pdrop_r
     h_new, x_new, alpha = ops.inter_attn(qkv, None, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["wcr"],
                                          p["w3"], clampv, Wc=p["Wc"], bc=p["bc"], own_h=(pdrop == 0.0), Wc32=p.get("Wc32"))
     if pdrop > 0.0:
-        h_new = h + _drop(h_new - h, pdrop)
+        h_new = ops.drop_mix(h, h_new, pdrop)          # h + dropout(h_new - h): one pass each way, the mask regenerated by the adjoint
     return h_new, x_new, alpha
 
 

@@ -1054,6 +1054,40 @@ def take_rows_few(x, index64):
     return x.index_select(0, index64)
 
 
+class _DropMix(torch.autograd.Function):
+    """h + dropout(hn - h) as one pass each way (csrc/bwd.hip: drop_mix_kernel); the mask is keyed by (seed, element) and regenerated in
+    the adjoint."""
+
+    @staticmethod
+    def forward(ctx, h, hn, p_drop, seed):
+        out = torch.empty_like(h)
+        check(load().fabind_drop_mix(ptr(h), ptr(hn), ptr(out), h.numel(), float(p_drop), int(seed) & 0xFFFFFFFF, stream()), "fabind_drop_mix")
+        ctx.pd, ctx.seed = float(p_drop), int(seed)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        dhn, dh = torch.empty_like(g), torch.empty_like(g)
+        check(load().fabind_drop_mix_bwd(ptr(g), ptr(dhn), ptr(dh), g.numel(), ctx.pd, ctx.seed & 0xFFFFFFFF, stream()), "fabind_drop_mix_bwd")
+        return dh, dhn, None, None
+
+
+def drop_mix(h, hn, p_drop):
+    """h + nn.Dropout(p)(hn - h) (train mode; egnn.py:236).  fp32, contiguous, numel % 4 == 0: one kernel; else torch ops."""
+    if p_drop <= 0.0:
+        return hn
+    if (h.dtype == torch.float32 and hn.dtype == torch.float32 and h.is_contiguous() and hn.is_contiguous() and h.shape == hn.shape
+            and h.numel() % 4 == 0 and h.is_cuda):
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        if _needs_grad(h, hn):
+            return _DropMix.apply(h, hn, p_drop, seed)
+        out = torch.empty_like(h)
+        check(load().fabind_drop_mix(ptr(h), ptr(hn), ptr(out), h.numel(), float(p_drop), seed, stream()), "fabind_drop_mix")
+        return out
+    return h + torch.nn.functional.dropout(hn - h, p_drop, True)
+
+
 def sum_sorted_segments(x, counts):
     """Per-segment sums of the rows of x whose segments are CONTIGUOUS (a sorted batch vector) with `counts` rows each -- one thread
     walks a segment in order (torch.segment_reduce): no float atomics, the same bits every run.  (zeros(B, .).index_add_(0, batch, x),

@@ -61,7 +61,8 @@ const char* fabind_last_error(void);
  *     fabind_gcl_edge_fused_x3_train added (the split-bf16 forward that saves M / silu'(pre2) / pre3 for the two-contraction backward);
  *     fabind_inter_attn_fwd_rows / fabind_inter_attn_bwd_rows added (inter-edge attention with the rows dealt by degree: heavy rows on four waves);
  *     fabind_edge_lnfold_bwd (+ _blocks) added (FABind+: the LayerNorm-folded first edge Linear under autograd);
- *     fabind_mul_dropmask_colsum added, fabind_gemm's fp32 (+ residual) epilogue takes p_drop (train-mode dropout ahead of a residual).
+ *     fabind_mul_dropmask_colsum, fabind_drop_mix (+ _bwd) added, fabind_gemm's fp32 (+ residual) epilogue takes p_drop (train-mode dropout
+ *     ahead of a residual).
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 17
 int fabind_abi_version(void);
@@ -581,6 +582,11 @@ int fabind_mul_dact_colsum(const void* dy, int dy_dt, const void* y, int y_dt, i
  * cross_att.py:128) or without an activation.  Nothing is stored by the forward: the mask is regenerated from its key. */
 int fabind_mul_dropmask_colsum(const void* dy, int dy_dt, void* out, int out_dt, int R, int C, float p_drop, unsigned seed,
                                float* colsum, float* scratch, int nchunk, hipStream_t stream);
+/* out = h + drop(hn - h) over n fp32 elements (nn.Dropout on the aggregated inter-edge attention message ahead of the residual,
+ * FABind/fabind/models/egnn.py:236) and its adjoint (d hn = g keep / (1 - p), d h = g - d hn): the counter-based mask of the GEMM
+ * epilogues keyed by (seed, linear index), regenerated by the adjoint. */
+int fabind_drop_mix(const float* h, const float* hn, float* out, long n, float p_drop, unsigned seed, hipStream_t stream);
+int fabind_drop_mix_bwd(const float* g, float* dhn, float* dh, long n, float p_drop, unsigned seed, hipStream_t stream);
 int fabind_rowdot_bwd(const void* z, int z_dt, const float* dpart, int np, const float* u, int act, int M, int N,
                       void* dz, float* du, float* scratch, int nchunk, hipStream_t stream);
 int fabind_edge_geom_bwd(const float* d, const float* rho, const float* norm, const float* dd, const float* drhohat,

@@ -1558,3 +1558,26 @@ def test_mlp2_with_dropout_ahead_of_the_residual_matches_the_two_linear_form():
     assert torch.equal(res[0][0], res[1][0])
     for a, b_ in [(res[0][1], res[1][1]), (res[0][2], res[1][2])] + list(zip(res[0][3], res[1][3])):
         assert float((a - b_).norm() / b_.norm()) <= 1e-2
+
+
+def test_drop_mix_is_h_plus_dropout_of_the_difference():
+    """ops.drop_mix: h + nn.Dropout(p)(hn - h) as one pass each way with a regenerated counter-based mask (train mode, egnn.py:236)."""
+    from fabind_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    h0, hn0, cot = (torch.randn(1001, 512, generator=g).to(dev) for _ in range(3))
+    pd = 0.1
+    h, hn = h0.clone().requires_grad_(True), hn0.clone().requires_grad_(True)
+    torch.manual_seed(2)
+    out = ops.drop_mix(h, hn, pd)
+    keep = out.detach() != h0
+    assert abs(1.0 - float(keep.float().mean()) - pd) < 5e-3
+    ref = h0 + (hn0 - h0) * keep / (1.0 - pd)
+    assert float((out.detach() - ref).abs().max()) <= 1e-5
+    (out * cot).sum().backward()
+    dhn = cot * keep / (1.0 - pd)
+    assert float((hn.grad - dhn).abs().max()) <= 1e-5 and float((h.grad - (cot - dhn)).abs().max()) <= 1e-5
+    torch.manual_seed(2)
+    with torch.no_grad():
+        assert torch.equal(ops.drop_mix(h0, hn0, pd), out.detach())      # the no-grad form draws the same mask from the same seed
+    assert ops.drop_mix(h0, hn0, 0.0) is hn0
