@@ -686,14 +686,13 @@ def att_layer(p, h, x, z, lay, g, pairs, batch_id, clampv, pd=0.0, bias=None, p_
     h_new, x_new, alpha = ops.inter_attn(qkv, zero_cv, H, h, x, d, rhohat, g, bias_part, p["w_rk"], p["w_rv"], p["zeroH"],
                                          p["zeroH"], clampv, s_ext=s_ext.contiguous())
     if pd > 0.0:
-        h_new = h + _drop(h_new - h, pd)                                                             # egnn.py:207 dropout(agg)
+        h_new = ops.drop_mix(h, h_new, pd)                                                           # egnn.py:207 dropout(agg): h + drop(h_new - h)
     return h_new, x_new, alpha, z, bias_next
 
 
 def egnn_forward(P, h, x, z0, lay, g, las, x_las, pairs, batch_id, scale, step, capture=None, pd=0.0):
     clampv = 10.0 / scale
-    h = _drop(ops.linear(h, P["W_in"], P["b_in"]), pd) if (pd > 0.0 and ops.needs_grad(h, P["W_in"])) else \
-        ops.linear(h, P["W_in"], P["b_in"], p_drop=pd)
+    h = ops.linear(h, P["W_in"], P["b_in"], p_drop=pd)      # (dropout in the fp32 epilogue; under autograd the adjoint regenerates the mask)
     z, bias = (ops.shared_grad(z0) if Z_SINK else z0), None
     for i in range(P["L"]):
         h, x = gcl_layer(P["gcl"][i], h, x, lay, g, clampv, pd)
