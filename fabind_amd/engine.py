@@ -613,15 +613,13 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
         ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
     hc = ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc, p_drop=pdrop)
     if fast:
-        hp2 = _node_chain(p, "_nc_tp", p["Wt1_p"], p["bt1_p"], p["Wt2_p"], p["bt2_p"], K.ACT_RELU, 1, hp16, None, hp, True) \
-            if pdrop == 0.0 else None
+        hp2 = _node_chain(p, "_nc_tp", p["Wt1_p"], p["bt1_p"], p["Wt2_p"], p["bt2_p"], K.ACT_RELU, 1, hp16, None, hp, True)
         if hp2 is None:
             t = ops.linear(hp16, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU, out_dtype=od)
             hp2 = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True)
         hp = hp2
         hc16 = c16(hc)
-        hc2 = _node_chain(p, "_nc_tc", p["Wt1_c"], p["bt1_c"], p["Wt2_c"], p["bt2_c"], K.ACT_RELU, 1, hc16, None, hc, False) \
-            if pdrop == 0.0 else None
+        hc2 = _node_chain(p, "_nc_tc", p["Wt1_c"], p["bt1_c"], p["Wt2_c"], p["bt2_c"], K.ACT_RELU, 1, hc16, None, hc, False)
         if hc2 is None:
             t = ops.linear(hc16, p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU, out_dtype=od)
             hc2 = ops.linear(t, p["Wt2_c"], p["bt2_c"], residual=hc)

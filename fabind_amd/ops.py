@@ -412,8 +412,8 @@ def linear(x, W, b=None, act_pro=K.ACT_NONE, act_epi=K.ACT_NONE, residual=None, 
         y = _Linear.apply(x, W, b, x2, residual, act_epi, out_dtype, holder, p_drop, seed, W32)
         return _attach_b16(y, holder[0] if holder else None)
     y16 = None
-    if _want16(out_dtype, act_epi, want16) and act_pro == K.ACT_NONE and p_drop == 0.0:
-        y16 = torch.empty((x.shape[0], W.shape[0]), dtype=torch.bfloat16, device=x.device)
+    if _want16(out_dtype, act_epi, want16) and act_pro == K.ACT_NONE and (p_drop == 0.0 or (act_epi == K.ACT_NONE and x2 is None and W.shape[0] % 4 == 0)):
+        y16 = torch.empty((x.shape[0], W.shape[0]), dtype=torch.bfloat16, device=x.device)      # (with epilogue dropout: the plain fp32 epilogues only)
     if isinstance(W32, tuple):
         y = torch.empty((x.shape[0], W.shape[0]), dtype=out_dtype, device=x.device)
         _gemm_split_rows(x, _mm_in(x), W, W32, b, y, y16)
