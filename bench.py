@@ -716,16 +716,16 @@ def main():
         sub("n_iter8", "fwdbwd", 8, note="production refinement loop: 8 stack passes, gradient on the last one.  GATE MISSED in this dtype: the "
                                            "bf16 ligand-RMSD gap to the fp32 oracle is 1.9e-4 A at n_iter 8 (4.7e-5 at 2 and 3.1e-5 at 1 = the "
                                            "headline's pass: inside the 1e-4 A gate; tests/test_gpu_headline.py) -- `n_iter8_gate` is the loop "
-                                           "in the mode that meets it")
+                                           "in the mode that meets it", steps=5, warmup=1)
         sub("n_iter8_gate", "fwdbwd", 8, precision="bf16x3", steps=3, warmup=1,
             note="n_iter8 in the gate-meeting split-bf16 mode (2.8e-6 A at the headline shape, tests/test_gpu_headline.py)")
         sub("n_iter8_gate_bf16_edge", "fwdbwd", 8, precision="bf16x3", steps=3, warmup=1, x3_edge="bf16",
             note="n_iter8_gate with config.set_x3_edge('bf16') (3.0e-5 A at the headline shape: see gate_mode_bf16_edge)")
         sub("fwd", "fwd", a.n_iter, steps=10, warmup=3, note="forward only, one stack pass")
-        sub("model_fwdbwd", "model", a.n_iter, steps=6, warmup=2,
+        sub("model_fwdbwd", "model", a.n_iter, steps=12, warmup=3,
             note="full IaBNet (pocket model on 1500 residues -> pocket crop -> 4-layer complex model -> heads) with the reference's "
                  "six-term loss (pocket-cls + pocket-centre + contact x2 + distill + coord), eval mode")
-        sub("model_gate", "model", a.n_iter, precision="bf16x3", steps=6, warmup=2,
+        sub("model_gate", "model", a.n_iter, precision="bf16x3", steps=10, warmup=2,
             note="model_fwdbwd in the gate-meeting split-bf16 mode (production-size parity: tests/test_gpu_production.py)")
         sub("config3_whole_graph", "model", a.n_iter, steps=10, warmup=2, whole_pocket=True,
             note="BASELINE configs[2] read literally: the same synthetic batch with an unbounded pocket radius, so the 4-layer hidden-512 "
@@ -734,7 +734,7 @@ def main():
         sub("model_fwdbwd_train_n_iter8", "model", 8, train_mode=True,
             note="the same with model.train() (dropout, Gumbel noise) and n_iter=8: the reference's training configuration")
         n_it8 = 8
-        sub("plus_train", "plus_train", a.n_iter, steps=4, warmup=2,
+        sub("plus_train", "plus_train", a.n_iter, steps=6, warmup=2,
             note="one FABind+ training step (5-layer LN-MLP stack, train mode, 7-term loss with the permutation-invariant term; round 5: the edge "
                  "MLP's first Linear with its LayerNorm folded into per-node projections under autograd)")
         sub("plus_train_gate", "plus_train", a.n_iter, precision="bf16x3", steps=3, warmup=1,
