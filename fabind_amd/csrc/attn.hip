@@ -405,7 +405,17 @@ __global__ __launch_bounds__(256) void las_step_kernel(const float* __restrict__
         float ex = x0[i * 3] - hx, ey = x0[i * 3 + 1] - hy, ez = x0[i * 3 + 2] - hz;
         float cur = dx * dx + dy * dy + dz * dz, tru = ex * ex + ey * ey + ez * ez;
         float f = 2.f * (cur - tru);
-        fx += f * (2.f * dx); fy += f * (2.f * dy); fz += f * (2.f * dz);
+        // The three accumulations stay SCALAR FMAs (the empty asm statements stop the SLP vectoriser from pairing fy / fz into one
+        // `v_pk_fma_f32 ... op_sel:[0,1,0]`).  With the packed form, the y sum of lanes 48-63 was LOST in 1-3 % of the launches when
+        // several processes shared the device (tests/test_gpu_dp.py: three processes on one GPU) -- one coordinate of one atom off by
+        // the missing terms, never single-process, never with scalar FMAs (tools/probes/model_repeat3.py: 13 of 414 contended passes
+        // against 0 of 414; the dumped cases show exactly the upper row's terms of the y component missing).
+        fx = __builtin_fmaf(f, 2.f * dx, fx);
+        asm volatile("" : "+v"(fx));
+        fy = __builtin_fmaf(f, 2.f * dy, fy);
+        asm volatile("" : "+v"(fy));
+        fz = __builtin_fmaf(f, 2.f * dz, fz);
+        asm volatile("" : "+v"(fz));
     }
     fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
     if (lane == 0) {

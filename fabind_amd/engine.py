@@ -546,6 +546,10 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
         agg, s = ops.fused_edge(AB, rhohat, p["w_r"], p["W2"], p["b2"], p["Wc"], p["bc"], p["w3"], H, g, pdrop,
                                 frags=p.get("_frags") if get_precision() == "bf16" else None)
         x_new = ops.coord_update(x, d, s, g.rp_ctx, mean=True, clampv=clampv)
+        if DEBUG_CAPTURE is not None:              # (tools/probes/model_repeat3.py: the pieces of the coordinate update)
+            k_ = "gcl_dbg_%d" % sum(1 for q in DEBUG_CAPTURE if q.startswith("gcl_dbg_") and q.endswith(".s"))
+            DEBUG_CAPTURE[k_ + ".xin"], DEBUG_CAPTURE[k_ + ".d"], DEBUG_CAPTURE[k_ + ".rhohat"] = x.detach().clone(), d.detach().clone(), rhohat.detach().clone()
+            DEBUG_CAPTURE[k_ + ".agg"], DEBUG_CAPTURE[k_ + ".s"] = agg.detach().clone(), s.detach().clone()
         if not fast:
             # node MLP + residual as one autograd node (activation adjoint and residual gradient inside GEMM epilogues); train mode: the
             # dropout ahead of the residual (egnn.py:106) inside the second Linear's epilogue, its mask regenerated by the adjoint
@@ -668,6 +672,8 @@ def egnn_forward(P, h, x, lay, g, las, x_las, a0b0, pairbias, scale, step, drop=
         if cap is not None:
             cap["att_%d.h" % i], cap["att_%d.x" % i], cap["att_%d.alpha" % i] = h.detach().clone(), x.detach().clone(), alpha.detach().clone()
         x = ops.las_step(x, x_las, las, lay, step, 15.0 / scale)
+        if cap is not None:
+            cap["las_%d.xout" % i] = x.detach().clone()
     h, x = gcl_layer(P["out_layer"], h, x, lay, g, clampv, dp.get("out", 0.0))
     return ops.linear(_drop(h, dp.get("gnn", 0.0)), P["W_out"], P["b_out"]), x
 

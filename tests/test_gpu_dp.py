@@ -122,6 +122,7 @@ def test_two_rank_training_of_ragged_pocket_batches_equals_mean_of_shard_gradien
             parallel.clip_grad_norm_(params, 1.0)
             opt.step()
         want = [p.detach().float().cpu().numpy() for p in params]
+        names = [n for n, p in m.named_parameters() if p.requires_grad]
     finally:
         engine.set_precision("fp32")
     res = sorted([q.get(timeout=900) for _ in range(WORLD)], key=lambda t: t[0])
@@ -131,7 +132,10 @@ def test_two_rank_training_of_ragged_pocket_batches_equals_mean_of_shard_gradien
     for rank, idx, losses, early, got in res:
         assert idx == [int(i) for i in shards[rank][0]]
         assert np.allclose(losses, ref_losses[rank], rtol=1e-5), (rank, losses, ref_losses[rank])
-        worst = max(float(np.abs(g - w).max()) / max(1e-6, float(np.abs(w).max())) for g, w in zip(got, want))
+        gaps = sorted(((float(np.abs(g - w).max()) / max(1e-6, float(np.abs(w).max())), n) for g, w, n in zip(got, want, names)), reverse=True)
+        worst = gaps[0][0]
+        if worst > 1e-5:
+            print("rank %d: parameters that differ from the emulation:" % rank, [(n, "%.2e" % v) for v, n in gaps[:8] if v > 0])
         print("rank %d: 3 DP steps, losses %s; parameters vs single-process mean-of-shards emulation: worst relative gap %.2e; "
               "buckets on the wire before the end of the last backward: %d" % (rank, ["%.5f" % v for v in losses], worst, early))
         assert worst <= 1e-5
