@@ -1413,8 +1413,14 @@ __global__ __launch_bounds__(256) void las_step_bwd_kernel(const float* __restri
         const float dg = dx_ * gF[0] + dy_ * gF[1] + dz_ * gF[2];
         const float vx = 4.f * (diff * gF[0] + 2.f * dx_ * dg), vy = 4.f * (diff * gF[1] + 2.f * dy_ * dg),
                     vz = 4.f * (diff * gF[2] + 2.f * dz_ * dg);
-        if (i == gu) { ax += vx; ay += vy; az += vz; }
-        if (j == gu) { ax -= vx; ay -= vy; az -= vz; }
+        // (scalar accumulations, not paired into v_pk_fma_f32: see las_step_kernel in attn.hip)
+        const float sg = (i == gu ? 1.f : 0.f) - (j == gu ? 1.f : 0.f);
+        ax = __builtin_fmaf(sg, vx, ax);
+        asm volatile("" : "+v"(ax));
+        ay = __builtin_fmaf(sg, vy, ay);
+        asm volatile("" : "+v"(ay));
+        az = __builtin_fmaf(sg, vz, az);
+        asm volatile("" : "+v"(az));
     }
     ax = wave_sum(ax); ay = wave_sum(ay); az = wave_sum(az);
     if (lane == 0) {
