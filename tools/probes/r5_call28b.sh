@@ -1,9 +1,9 @@
 #!/bin/bash
 # round 5, final evidence on the final tree: GPU suite, smoke, r5_final.sh (traces, launch groups, PMC), plus_train trace, default bench line
-O=$GRAFT_REPO_ROOT/gpurun_out/r5fin5; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r5fin6; mkdir -p $O
 timeout 3000 python -m pytest tests -m gpu -x -q > $O/tests_gpu.log 2>&1; tail -3 $O/tests_gpu.log
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.log 2>&1; tail -2 $O/smoke.log
-bash tools/probes/r5_final.sh r5fin5 > $O/final.log 2>&1; tail -3 $O/final.log
+bash tools/probes/r5_final.sh r5fin6 > $O/final.log 2>&1; tail -3 $O/final.log
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/profpt -o pt -- python3 $GRAFT_REPO_ROOT/bench.py --mode plus_train --no-cpu-baseline --no-extras --steps 3 --warmup 2 > $O/bench_profpt.log 2>&1
 cd $GRAFT_REPO_ROOT
