@@ -376,7 +376,15 @@ extern "C" int fabind_inter_attn_fwd(const float* qkv, int ldqkv, const float* c
 // Ligand atoms (1 <= u < C): ONE WAVE per atom, lanes stride over the complex's LAS edges (154 at 40 atoms), fixed-order wave sum;
 // every other node is a copy, one thread each (blocks [0, nb_copy)).  (Round 3: one THREAD per atom walking all edges serially --
 // 37 us per call for 2,560 atoms, latency of 154 dependent index loads.)
-__global__ __launch_bounds__(256) void las_step_kernel(const float* __restrict__ x, const float* __restrict__ x0,
+// NO PACKED fp32 MATH in this kernel (`target("no-packed-fp32-ops")`, checked on the built code object by tools/isa_lint.py).  Round 5:
+// with the fy / fz accumulations paired into one `v_pk_fma_f32 ... op_sel:[0,1,0]`, the y sum of lanes 48-63 was LOST in 1-3 % of the
+// full-model passes when several processes shared the device (profiles/r05_contention.txt: 13 of 414 contended passes; the dumped cases
+// show exactly the upper row's y terms missing; 0 of 414 with scalar FMAs; never single-process).  Unlike the weight-gradient
+// contraction's mismatch (an inline-asm hazard, gemm.hip) the compiler-generated waits of this kernel are complete (the lint covers
+// them) and the kernel has no LDS traffic of its own: the cause is NOT established.  Round 6 replaces the empty-asm trick that kept the
+// SLP vectoriser from pairing the accumulations (it depended on the optimiser's mood) by switching packed fp32 off for the function,
+// and keeps the kernel in the device-sharing stress test (tests/test_gpu_contention.py).
+__global__ __launch_bounds__(256) __attribute__((target("no-packed-fp32-ops"))) void las_step_kernel(const float* __restrict__ x, const float* __restrict__ x0,
                                                        const int* las_i, const int* las_j, const int* las_off,
                                                        const int* node_off, const int* c_cnt, float step, float clampv,
                                                        float* x_out, int nb_copy) {
@@ -405,17 +413,9 @@ __global__ __launch_bounds__(256) void las_step_kernel(const float* __restrict__
         float ex = x0[i * 3] - hx, ey = x0[i * 3 + 1] - hy, ez = x0[i * 3 + 2] - hz;
         float cur = dx * dx + dy * dy + dz * dz, tru = ex * ex + ey * ey + ez * ez;
         float f = 2.f * (cur - tru);
-        // The three accumulations stay SCALAR FMAs (the empty asm statements stop the SLP vectoriser from pairing fy / fz into one
-        // `v_pk_fma_f32 ... op_sel:[0,1,0]`).  With the packed form, the y sum of lanes 48-63 was LOST in 1-3 % of the launches when
-        // several processes shared the device (tests/test_gpu_dp.py: three processes on one GPU) -- one coordinate of one atom off by
-        // the missing terms, never single-process, never with scalar FMAs (tools/probes/model_repeat3.py: 13 of 414 contended passes
-        // against 0 of 414; the dumped cases show exactly the upper row's terms of the y component missing).
         fx = __builtin_fmaf(f, 2.f * dx, fx);
-        asm volatile("" : "+v"(fx));
         fy = __builtin_fmaf(f, 2.f * dy, fy);
-        asm volatile("" : "+v"(fy));
         fz = __builtin_fmaf(f, 2.f * dz, fz);
-        asm volatile("" : "+v"(fz));
     }
     fx = wave_sum(fx); fy = wave_sum(fy); fz = wave_sum(fz);
     if (lane == 0) {

@@ -1378,7 +1378,7 @@ extern "C" int fabind_inter_attn_bwd(const float* qkv, int ldqkv, const float* c
 // ------------------------------------------------------------------------------------------------
 // (one wave per ligand atom, lanes over the complex's LAS edges, fixed-order wave sums; other nodes: a copy, one thread each -- the
 //  thread-per-atom form walked all 154 edges serially: 76 us per call at 2,560 atoms)
-__global__ __launch_bounds__(256) void las_step_bwd_kernel(const float* __restrict__ x, const float* __restrict__ x0,
+__global__ __launch_bounds__(256) __attribute__((target("no-packed-fp32-ops"))) void las_step_bwd_kernel(const float* __restrict__ x, const float* __restrict__ x0,
                                                            const float* __restrict__ xo, const int* las_i,
                                                            const int* las_j, const int* las_off, const int* node_off,
                                                            const int* c_cnt, float step, float clampv,
@@ -1413,14 +1413,11 @@ __global__ __launch_bounds__(256) void las_step_bwd_kernel(const float* __restri
         const float dg = dx_ * gF[0] + dy_ * gF[1] + dz_ * gF[2];
         const float vx = 4.f * (diff * gF[0] + 2.f * dx_ * dg), vy = 4.f * (diff * gF[1] + 2.f * dy_ * dg),
                     vz = 4.f * (diff * gF[2] + 2.f * dz_ * dg);
-        // (scalar accumulations, not paired into v_pk_fma_f32: see las_step_kernel in attn.hip)
+        // (no packed fp32 math in this kernel: see las_step_kernel in attn.hip)
         const float sg = (i == gu ? 1.f : 0.f) - (j == gu ? 1.f : 0.f);
         ax = __builtin_fmaf(sg, vx, ax);
-        asm volatile("" : "+v"(ax));
         ay = __builtin_fmaf(sg, vy, ay);
-        asm volatile("" : "+v"(ay));
         az = __builtin_fmaf(sg, vz, az);
-        asm volatile("" : "+v"(az));
     }
     ax = wave_sum(ax); ay = wave_sum(ay); az = wave_sum(az);
     if (lane == 0) {

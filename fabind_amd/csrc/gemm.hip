@@ -1089,42 +1089,72 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __r
     for (int i = 0; i < 4; ++i) offX[i] = lds0 + X_BYTES0 + (unsigned)(r1 * TN_ + (((wn * 4 + i) ^ z1) * 16) + co) * 2u;
     // Schedule of one k-step (round 2 -- the previous loop read all fragments, waited, then ran all MFMAs: its LDS latency,
     // its barrier and its operand wait added up instead of overlapping, 34 % of the MFMA peak):
-    //   top:  issue the reads of the SECOND half of the Y granules of stage kt; wait for the first half (+ X), issued one phase ago
+    //   top:  the first half of the Y granules (+ X) of stage kt is IN REGISTERS; issue the reads of the SECOND half
     //   A:    MFMAs of the first half
     //   mid:  second half landed in registers -> this wave is done with stage kt in LDS; wait for this wave's pieces of stage kt+1;
     //         barrier (every wave done with stage kt, all of stage kt+1 landed); refill the slot of stage kt with stage kt+NSTAGE; issue the
-    //         reads of the first half (+ X) of stage kt+1
-    //   B:    MFMAs of the second half
+    //         reads of the first half (+ X) of stage kt+1 into the OTHER register set
+    //   B:    MFMAs of the second half; then the wait for the reads just issued
     // so every LDS read has half a k-step of MFMAs (16 x 16 cycles) to land under, and operand loads have NSTAGE - 1 k-steps.
+    //
+    // ROUND 6 -- the root cause of the weight-gradient mismatches under device sharing (profiles/r05_contention.txt).  Every LDS read
+    // here is inline asm whose result lands ASYNCHRONOUSLY; the compiler believes an asm output is valid the moment the statement has
+    // issued.  Rounds 2-5 kept ONE set of first-half registers: the reads of stage kt+1 were issued in iteration kt and waited for at
+    // the top of iteration kt+1.  The old values were still live (phase B), so the new ones landed in other registers and the register
+    // allocator resolved the loop-carried value with copies at the back-edge -- `v_mov_b64 v[162:163], v[204:205]` AHEAD of the
+    // `s_waitcnt lgkmcnt` that guarded v[204:205].  Whenever the LDS answered later than the phase-B MFMAs took to issue (another
+    // process's waves on the CU), the copy took the PREVIOUS stage's fragments: 2-12 % of the passes with 16 MFMAs of cover (the
+    // 256-row-per-wave layouts), every pass with 8 (the 8-wave 128-column layout); never on an otherwise idle device.  A wait tied to
+    // the registers ("+v") does not help by itself: the tie makes the allocator place the same copy in front of the wait.  The loop is
+    // now unrolled by two over PING-PONG register sets: a set is read, waited for and consumed without ever meeting a live older value
+    // of itself, so no copy is needed, and the wait sits in the same straight-line block as the read, ahead of the back-edge.  The
+    // code object is checked for this at build time (tools/isa_lint.py, tests/test_isa_lint.py): no instruction may touch the
+    // destination of an LDS read that the LGKM counter still covers.
     typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     constexpr int HALF = MI / 2;
-    u32x2 ya[MI], yb[MI], xa[4], xb[4];
-    auto read_first = [&](unsigned sb) {
+    struct Frag { u32x2 xa[4], xb[4], ya[HALF], yb[HALF]; };     // first-half fragments of one stage: X (4 granules) + Y granules [0, HALF)
+    Frag fA, fB;
+    u32x2 y2a[MI - HALF], y2b[MI - HALF];                        // second-half Y granules: read, waited for and consumed inside one k-step
+    auto read_first = [&](unsigned sb, Frag& f) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(xa[i]) : "v"(offX[i] + sb) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(xb[i]) : "v"(offX[i] + sb), "n"(4 * TN_ * 2) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.xa[i]) : "v"(offX[i] + sb) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.xb[i]) : "v"(offX[i] + sb), "n"(4 * TN_ * 2) : "memory");
         }
 #pragma unroll
         for (int i = 0; i < HALF; ++i) {
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ya[i]) : "v"(offY[i] + sb) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yb[i]) : "v"(offY[i] + sb), "n"(4 * TM * 2) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f.ya[i]) : "v"(offY[i] + sb) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f.yb[i]) : "v"(offY[i] + sb), "n"(4 * TM * 2) : "memory");
+        }
+    };
+    auto wait_first = [&](Frag& f) {
+        if constexpr (MI == 8) {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f.ya[0]), "+v"(f.ya[1]), "+v"(f.ya[2]), "+v"(f.ya[3]), "+v"(f.yb[0]), "+v"(f.yb[1]), "+v"(f.yb[2]), "+v"(f.yb[3]),
+                           "+v"(f.xa[0]), "+v"(f.xa[1]), "+v"(f.xa[2]), "+v"(f.xa[3]), "+v"(f.xb[0]), "+v"(f.xb[1]), "+v"(f.xb[2]), "+v"(f.xb[3])
+                         :: "memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f.ya[0]), "+v"(f.ya[1]), "+v"(f.yb[0]), "+v"(f.yb[1]),
+                           "+v"(f.xa[0]), "+v"(f.xa[1]), "+v"(f.xa[2]), "+v"(f.xa[3]), "+v"(f.xb[0]), "+v"(f.xb[1]), "+v"(f.xb[2]), "+v"(f.xb[3])
+                         :: "memory");
         }
     };
     auto read_second = [&](unsigned sb) {
 #pragma unroll
         for (int i = HALF; i < MI; ++i) {
-            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(ya[i]) : "v"(offY[i] + sb) : "memory");
-            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(yb[i]) : "v"(offY[i] + sb), "n"(4 * TM * 2) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(y2a[i - HALF]) : "v"(offY[i] + sb) : "memory");
+            asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(y2b[i - HALF]) : "v"(offY[i] + sb), "n"(4 * TM * 2) : "memory");
         }
     };
-    {   // stage 0 landed for everyone -> first-half reads of stage 0
+    {   // stage 0 landed for everyone -> first-half reads of stage 0 (nk == 0: the reads return whatever the slot holds, never used)
         int fl = min(nk, NSTAGE) - 1;                              // stages still in flight behind stage 0
         if constexpr (NSTAGE == 5) { if (fl >= 4) wait_vmcnt<4 * PPW>(); else wait_vmcnt_upto<PPW>(fl); }
         else wait_vmcnt_upto<PPW>(fl);
         __builtin_amdgcn_s_barrier();
-        if (nk > 0) read_first(0u);
+        read_first(0u, fA);
+        wait_first(fA);
     }
     unsigned s_cur = 0, s_nxt = STAGE_BYTES;                       // byte offsets of the slots of stage kt and stage kt + 1
     // cs: the column sums of Y (= the bias gradient dY^T 1 of the Linear whose weight gradient this contraction is) ride along: the WN
@@ -1139,28 +1169,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __r
         return (__uint_as_float(lo[0] << 16) + __uint_as_float(lo[0] & 0xffff0000u)) + (__uint_as_float(lo[1] << 16) + __uint_as_float(lo[1] & 0xffff0000u)) +
                (__uint_as_float(hi[0] << 16) + __uint_as_float(hi[0] & 0xffff0000u)) + (__uint_as_float(hi[1] << 16) + __uint_as_float(hi[1] & 0xffff0000u));
     };
-    for (int kt = 0; kt < nk; ++kt) {
-        if (!((xf & 2) && kt)) read_second(s_cur);
-        if constexpr (MI == 8) {
-            asm volatile("s_waitcnt lgkmcnt(8)"
-                         : "+v"(ya[0]), "+v"(ya[1]), "+v"(ya[2]), "+v"(ya[3]), "+v"(yb[0]), "+v"(yb[1]), "+v"(yb[2]), "+v"(yb[3]),
-                           "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])
-                         :: "memory");
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(4)"
-                         : "+v"(ya[0]), "+v"(ya[1]), "+v"(yb[0]), "+v"(yb[1]),
-                           "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]), "+v"(xb[0]), "+v"(xb[1]), "+v"(xb[2]), "+v"(xb[3])
-                         :: "memory");
-        }
+    // one k-step: consumes the landed set `c` (stage kt), leaves the set `n` landed (stage kt + 1)
+    auto k_step = [&](Frag& c, Frag& n, const int kt) {
+        read_second(s_cur);
         bf16x8_t bfr[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const u32x4 rb = {xa[i][0], xa[i][1], xb[i][0], xb[i][1]};
+            const u32x4 rb = {c.xa[i][0], c.xa[i][1], c.xb[i][0], c.xb[i][1]};
             bfr[i] = __builtin_bit_cast(bf16x8_t, rb);
         }
 #pragma unroll
         for (int i = 0; i < HALF; ++i) {
-            const u32x4 ra = {ya[i][0], ya[i][1], yb[i][0], yb[i][1]};
+            const u32x4 ra = {c.ya[i][0], c.ya[i][1], c.yb[i][0], c.yb[i][1]};
             const bf16x8_t af = __builtin_bit_cast(bf16x8_t, ra);
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
@@ -1169,14 +1189,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __r
         bf16x8_t af2[MI - HALF];
         if constexpr (MI == 8) {
             asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(ya[4]), "+v"(ya[5]), "+v"(ya[6]), "+v"(ya[7]), "+v"(yb[4]), "+v"(yb[5]), "+v"(yb[6]), "+v"(yb[7])
+                         : "+v"(y2a[0]), "+v"(y2a[1]), "+v"(y2a[2]), "+v"(y2a[3]), "+v"(y2b[0]), "+v"(y2b[1]), "+v"(y2b[2]), "+v"(y2b[3])
                          :: "memory");
         } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ya[2]), "+v"(ya[3]), "+v"(yb[2]), "+v"(yb[3]) :: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y2a[0]), "+v"(y2a[1]), "+v"(y2b[0]), "+v"(y2b[1]) :: "memory");
         }
 #pragma unroll
         for (int i = HALF; i < MI; ++i) {
-            const u32x4 ra = {ya[i][0], ya[i][1], yb[i][0], yb[i][1]};
+            const u32x4 ra = {y2a[i - HALF][0], y2a[i - HALF][1], y2b[i - HALF][0], y2b[i - HALF][1]};
             af2[i - HALF] = __builtin_bit_cast(bf16x8_t, ra);
         }
         if (do_cs) {                                              // all MI fragments of stage kt are in registers here
@@ -1184,24 +1204,35 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __r
             for (int w_ = 0; w_ < WN; ++w_)
                 if (wn == w_) {
 #pragma unroll
-                    for (int g_ = 0; g_ < GPW; ++g_) csum[g_] += sum8(ya[w_ + g_ * WN], yb[w_ + g_ * WN]);
+                    for (int g_ = 0; g_ < GPW; ++g_) {
+                        const int gi = w_ + g_ * WN;              // compile-time after unrolling
+                        csum[g_] += gi < HALF ? sum8(c.ya[gi < HALF ? gi : 0], c.yb[gi < HALF ? gi : 0])
+                                              : sum8(y2a[gi >= HALF ? gi - HALF : 0], y2b[gi >= HALF ? gi - HALF : 0]);
+                    }
                 }
         }
         if (kt + 1 < nk) {
             wait_vmcnt_upto<PPW>(min(NSTAGE - 2, nk - kt - 2));  // stages kt+2 .. kt+NSTAGE-1 may stay in flight
             __builtin_amdgcn_s_barrier();
             if (kt + NSTAGE < nk && !(xf & 1)) stage(s_cur);       // xf: probe knobs (fabind_gemm_tn_set_exp), 0 in production
-            if (!(xf & 2)) read_first(s_nxt);
         }
+        // first-half reads of stage kt+1 -- UNCONDITIONAL (in the last k-step they return the slot's old content, unused), so that the
+        // reads, the phase-B MFMAs they hide under and their wait are one straight-line block with no join in between
+        read_first(s_nxt, n);
         __builtin_amdgcn_sched_barrier(0);
-        // B operand fragments of THIS k-step were consumed into bfr above; the reads just issued overwrite xa / xb only when they land
 #pragma unroll
         for (int i = HALF; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af2[i - HALF], bfr[j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+        wait_first(n);                                            // nothing asynchronous crosses the end of a k-step
         s_cur = s_nxt;
         s_nxt = (s_nxt + STAGE_BYTES == NSTAGE * STAGE_BYTES) ? 0u : s_nxt + STAGE_BYTES;
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        k_step(fA, fB, kt);
+        if (kt + 1 >= nk) break;
+        k_step(fB, fA, kt + 1);
     }
     float* Cs = C + c_goff + (size_t)split * ((size_t)M * N + (cs ? M : 0));
     const int fr = lane & 15, cq = lane >> 4;
@@ -1228,7 +1259,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_tn_bf16_kernel(const bf16_t* __r
 
 static int g_tn_waves = 16;  // work-group layout of the TN kernel (see the kernel): 16 = 256x256 tile, 8 waves, 4-stage ring (default);
                              // 4 = 256x128, 4 waves, two work-groups per CU (round 1's default); 8 = 256x128, 8 waves
-static int g_tn_exp = 0;     // probe knobs: 1 = no operand loads after the pipeline fill, 2 = no fragment reads after the first k-step,
+static int g_tn_exp = 0;     // probe knobs: 1 = no operand loads after the pipeline fill (2: retired in round 6 -- fragment reads are unconditional),
                              // 4 = operand loads re-read the first rows of the range (cache hits instead of HBM)
 extern "C" void fabind_gemm_tn_set_exp(int x) { g_tn_exp = x; }
 extern "C" void fabind_gemm_tn_set_waves(int w) { g_tn_waves = (w == 8 || w == 4 || w == 20) ? w : 16; }

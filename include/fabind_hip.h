@@ -701,7 +701,7 @@ void fabind_gemm_set_x3_tile(int wm); /* development knob: tile height of the sp
 void fabind_gemm_set_small_m(int tiles); /* development knob: fabind_gemm launches with fewer 256x128 tiles than this use 128x128 tiles (default 100; 0 = never); results are bitwise equal */
 void fabind_gemm_tn_set_waves(int waves); /* development knob: work-group layout of fabind_gemm_tn: 16 (default) = 256x256 tile, 8 waves, 4-stage ring; 20 = the same with 5 stages; 4 = 256x128 tile, 4 waves, two work-groups per CU; 8 = 256x128, 8 waves.  Results are bitwise equal for equal `splits` */
 int fabind_gemm_tn_tile_n(void);          /* 256 or 128: columns of an output tile under the current layout (the host sizes `splits` from the tile count) */
-void fabind_gemm_tn_set_exp(int mask);    /* probe knob (tools/probes/gemm_tn_bench.py): 1 = no operand loads after the pipeline fill, 2 = no fragment reads after the first k-step, 4 = operand loads re-read the first rows (cache hits); 0 in production */
+void fabind_gemm_tn_set_exp(int mask);    /* probe knob (tools/probes/gemm_tn_bench.py): 1 = no operand loads after the pipeline fill, 4 = operand loads re-read the first rows (cache hits); 2 is retired (ignored); 0 in production */
 
 #ifdef __cplusplus
 }
