@@ -6,9 +6,12 @@ python bench.py --gpus N --steps K --warmup W
     as a child, relays rank 0's JSON line and exits with the child's code.  Under a launcher (the driver's way) the
     ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
-A "step" = one pass of the hot path (EfficientMCAttModel: 4 FABind layers + out layer, hidden 512,
-refinement iterations = --n-iter) over one resident synthetic batch of --batch complexes of
-1500 protein / 40 ligand nodes per GPU (BASELINE.json configs[1]/[2]).  Prints ONE JSON line on rank 0.
+A "step" (default mode `config3` = BASELINE.json configs[2] read literally) = forward + backward of the full IaBNet -- pocket model,
+4 FABind layers + out layer at hidden 512 on ALL 1500 protein / 40 ligand nodes of every complex (unbounded pocket radius), distance-map
+head over all 60,000 pairs per complex -- with the reference's six-term loss (pocket-cls + pocket-centre + coord + two distance-map terms
++ distill, main_fabind.py:398-417), over one synthetic batch of --batch complexes per GPU resident in HBM, a fresh batch object per
+step.  `--mode fwdbwd` / `fwd`: the layer stack alone (rounds 1-5's headline, now the `stack_fwdbwd` sub-object).  Prints ONE JSON line
+on rank 0.
 """
 import argparse
 import json
@@ -27,14 +30,33 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3.0}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 
 
-def price_against_rooflines(flops, nbytes, ms, precision):
-    """(binding, other) roofline objects of a set of launches: `flops` executed and `nbytes` algorithmic HBM bytes in `ms` milliseconds.
-    The binding one is the roofline the launches sit closer to (the larger fraction of its peak)."""
+# which roofline a kernel is REPORTED against is a property of the operation, not of whichever fraction happens to be larger
+# (rounds 3-5 picked max(frac) over this design's own tile traffic, and the label flipped mfma -> hbm without the kernel becoming
+# byte-minimal).  Dense contractions -- the fused GCL edge pipeline both ways (8(d): "intensity ~ 15 kFLOP/B => MFMA-bound; report that
+# kernel against the MFMA roofline"), the pair path, the attention blocks, every GEMM -- are priced on EXECUTED flops against the dense
+# matrix-core peak of the dtype; stand-alone gather / scatter / softmax / edge-build kernels on their 8(d) bytes against HBM.
+MFMA_FAMILIES = ("gcl_edge_fused", "cross_attn", "pair_update_fused", "fabind_gemm", "fabind_node_chain")
+
+
+def bound_of(label):
+    return "mfma" if label.startswith(MFMA_FAMILIES) else "hbm"
+
+
+def price_against_rooflines(flops, algo_bytes, ms, precision, bound, design_bytes=None):
+    """Roofline object of a set of launches that ran `ms` milliseconds: `flops` executed, `algo_bytes` = SURVEY 8(d)'s compulsory bytes of
+    the operation, `design_bytes` = what this design's launches read + write once (>= algo_bytes when tiles are materialised).
+    `bound` ("mfma" | "hbm") comes from 8(d)'s classification (bound_of), never from comparing the two fractions; the other view rides along."""
     tf = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    gb = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    gb = algo_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     mfma = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS[precision], "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS[precision]}
     hbm = {"bound": "hbm", "achieved": gb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gb / HBM_PEAK_GBS}
-    return (hbm, mfma) if hbm["frac"] > mfma["frac"] else (mfma, hbm)
+    out = dict(mfma if bound == "mfma" else hbm)
+    out["other_roofline"] = hbm if bound == "mfma" else mfma
+    if design_bytes is not None:
+        dg = design_bytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out["design_traffic"] = {"achieved": dg, "unit": "GB/s", "frac_of_hbm_peak": dg / HBM_PEAK_GBS,
+                                 "note": "this design's own materialised tiles per launch over the launch time: a cost of the design, not the kernel's roofline"}
+    return out
 
 
 def stack_args(hidden, layers, n_iter):
@@ -142,6 +164,51 @@ def cpu_baseline(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, backward=
     return out
 
 
+def cpu_baseline_config3(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, batch=1):
+    """The headline's workload on the host: the oracle's full IaBNet (`oracle/fabind_oracle.py::model_forward`, pocket radius unbounded)
+    + the six-term loss + backward to every parameter through autograd, `batch` complexes of n_prot / n_lig nodes, fp32, 32 threads
+    (the best setting of tools/probes/cpu_threads.py).  Bounded sample: one warm-up, then as many timed runs as fit `budget_s`."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fabind_oracle as orc
+    from fabind_amd import synthetic
+    from fabind_amd.models import get_model
+
+    class _Log:
+        def log_message(self, m):
+            pass
+    default_threads = torch.get_num_threads()
+    torch.set_num_threads(min(default_threads, 32))
+    torch.manual_seed(0)
+    m = synthetic.condition_for_large_graphs(get_model(stack_args(hidden, layers, n_iter), _Log(), None))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for v in sd.values():
+        if v.is_floating_point():
+            v.requires_grad_(True)
+    cfg = dict(orc.DEFAULT_CFG)
+    cfg.update(mean_layers=layers, n_iter=n_iter)
+    data = synthetic.make_hetero_batch([(n_prot, n_lig)] * batch, seed=0, pocket_radius=1e9)
+
+    def run():
+        for v in sd.values():
+            v.grad = None
+        out = orc.model_forward(sd, cfg, data.clone(), stage=1)
+        loss, _ = orc.compute_loss(out, data)
+        loss.backward()
+    t0 = time.time()
+    run()
+    first = time.time() - t0
+    reps = max(1, min(5, int(budget_s / max(first, 1e-3)) - 1))
+    t0 = time.time()
+    for _ in range(reps):
+        run()
+    dt = (time.time() - t0) / reps
+    cores = torch.get_num_threads()
+    torch.set_num_threads(default_threads)
+    return dict(value=batch / dt, unit="complexes/s", cores=cores, kind="port",
+                sample="oracle full IaBNet (whole-protein pocket) + six-term loss, forward + backward, B=%d, %d/%d nodes, hidden %d, %d layers, "
+                       "n_iter=%d, fp32, %d timed run(s) after one warm-up" % (batch, n_prot, n_lig, hidden, layers, n_iter, reps))
+
+
 def cpu_baseline_full(hidden, layers, n_lig, warmups=3, runs=5, batch=2, slow_run_s=40.0, skip_run_s=150.0):
     """SURVEY 8(d)'s CPU-baseline protocol: the oracle at B = 2, fp32, eval: torch.set_num_threads(k) for k = the best many-thread
     setting (32; torch's default of half the host's CPUs is measured next to it on the stack pass) and k = 1; >= 3 warm-ups + 5 timed
@@ -218,8 +285,10 @@ def main():
                     help="bf16: the dtype BASELINE configs[1..2] name; fp32: exact-fp32 MFMA; bf16x3: fp32 storage with split-bf16 "
                          "contractions (three bf16 MFMAs per product term) -- the fast mode that meets the 1e-4 A parity gate")
     ap.add_argument("--poses", type=int, default=20, help="plus_sampling: poses sampled per complex and step")
-    ap.add_argument("--mode", default="fwdbwd", choices=["fwd", "fwdbwd", "model", "plus_sampling", "plus_train"],
-                    help="fwd / fwdbwd: the layer stack on the whole graph (SURVEY 8(d), the headline); model: the full "
+    ap.add_argument("--mode", default="config3", choices=["config3", "fwd", "fwdbwd", "model", "plus_sampling", "plus_train"],
+                    help="config3 (default, the headline): BASELINE configs[2] read literally = `model --whole-pocket`: the full IaBNet with "
+                         "the complex model and the distance-map head on ALL 1500 / 40 nodes, six-term loss, fwd+bwd; "
+                         "fwd / fwdbwd: the layer stack alone on the whole graph (SURVEY 8(d); rounds 1-5's headline); model: the full "
                          "IaBNet (pocket model on the whole protein -> pocket crop -> complex model -> heads) with the "
                          "pocket-cls + coord + distmap losses, fwd+bwd (BASELINE configs[2] read literally); plus_sampling: "
                          "FABind+ sampling-mode inference (BASELINE configs[4]: dropout sampling, DBSCAN centre choice, "
@@ -242,6 +311,9 @@ def main():
     if a.cpu_baseline_full:
         print(json.dumps(cpu_baseline_full(a.hidden, a.layers, a.n_lig)))
         return
+    headline_config3 = a.mode == "config3"
+    if headline_config3:
+        a.mode, a.whole_pocket = "model", True
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         sys.exit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -506,7 +578,7 @@ def main():
         events_in_timed=False (the sub-objects, several of which are host-bound): the timed region carries NO events at all; the returned
         profile is the fully timed warm-up step (every labelled launch of ONE step)."""
         probe = profile and not os.environ.get("FABIND_BENCH_DUMP_PROFILE")      # (the same on every rank: sync() holds a barrier)
-        probe_prof, probe_bytes = None, {}
+        probe_prof, probe_bytes, probe_algo = None, {}, {}
         profile = profile and rank == 0
         only = None
         for w in range(warmup):
@@ -514,12 +586,13 @@ def main():
                 sync()
                 K.PROFILE, K.PROFILE_ONLY = ({} if profile else None), None
                 K.PROFILE_BYTES.clear()
+                K.PROFILE_ALGO.clear()
                 step()
                 sync()
                 fams = {}
                 for label, evs in (K.PROFILE or {}).items():
                     fams[family(label)] = fams.get(family(label), 0.0) + sum(s_.elapsed_time(e_) for s_, e_, _ in evs)
-                probe_prof, probe_bytes = K.PROFILE, dict(K.PROFILE_BYTES)
+                probe_prof, probe_bytes, probe_algo = K.PROFILE, dict(K.PROFILE_BYTES), dict(K.PROFILE_ALGO)
                 K.PROFILE = None
                 if fams:
                     only = max(fams.items(), key=lambda kv: kv[1])[0].split(" ")[0]
@@ -531,6 +604,7 @@ def main():
             sync()
         K.PROFILE = {} if (profile and events_in_timed) else None
         K.PROFILE_BYTES.clear()
+        K.PROFILE_ALGO.clear()
         K.PROFILE_ONLY = only
         t0 = time.time()
         for _ in range(steps):
@@ -543,6 +617,8 @@ def main():
             prof = probe_prof
             K.PROFILE_BYTES.clear()
             K.PROFILE_BYTES.update(probe_bytes)
+            K.PROFILE_ALGO.clear()
+            K.PROFILE_ALGO.update(probe_algo)
         if world > 1:
             tt = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -558,24 +634,27 @@ def main():
         return name
 
     def roofline_of(prof, dt, precision):
-        """Dominant MFMA kernel FAMILY of the timed region from live HIP-event timing of every launch (kernels._profiled):
-        achieved = (sum of the executed flops of the family's launches) / (sum of their durations); a ragged launch carries the
-        flops of its actual group sizes."""
+        """Dominant kernel FAMILY of the timed region from live HIP-event timing of every launch (kernels._profiled), priced as SURVEY 8(d)
+        prescribes: `bound` from the operation's classification (bound_of), `achieved` = (executed flops | 8(d) compulsory bytes of the
+        family's launches) / (sum of their durations); a ragged launch carries the flops of its actual group sizes."""
         fams = {}
         for label, evs in prof.items():
-            f = fams.setdefault(family(label), [0.0, 0, 0.0, label, 0.0])
+            f = fams.setdefault(family(label), [0.0, 0, 0.0, label, 0.0, 0.0])
             for s_, e_, fl in evs:
                 f[0] += s_.elapsed_time(e_)
                 f[1] += 1
                 f[2] += fl
             f[4] += K.PROFILE_BYTES.get(label, 0.0)
-        name, (ms, cnt, flops, label, nbytes) = max(fams.items(), key=lambda kv: kv[1][0])
-        binding, other = price_against_rooflines(flops, nbytes, ms, precision)
-        out_ = dict(binding)
+            f[5] += K.PROFILE_ALGO.get(label, 0.0)
+        name, (ms, cnt, flops, label, nbytes, algo) = max(fams.items(), key=lambda kv: kv[1][0])
+        out_ = price_against_rooflines(flops, algo, ms, precision, bound_of(name), design_bytes=nbytes)
         out_.update({"traffic": None,
                      "kernel": label if len([1 for l_ in prof if family(l_) == name]) == 1 else name + " (all shapes of the step)",
                      "flop_per_launch": flops / cnt, "launches": cnt, "avg_us": 1e3 * ms / cnt, "share_of_step": ms / (1e3 * dt),
-                     "algorithmic_bytes_per_launch": nbytes / cnt, "other_roofline": other})
+                     "algorithmic_bytes_per_launch": algo / cnt, "design_bytes_per_launch": nbytes / cnt,
+                     "classification": "SURVEY 8(d): %s" % ("dense contraction, reported against the matrix-core peak on executed flops"
+                                                            if bound_of(name) == "mfma" else
+                                                            "stand-alone gather / scatter / reduction, reported against HBM on its compulsory bytes")})
         return out_
 
     step, per_rank, _ = make_step(a.mode, a.n_iter, train_mode=a.train_mode, whole_pocket=a.whole_pocket)
@@ -587,6 +666,9 @@ def main():
         out = {
             "metric": ("poses/sec, FABind+ sampling-mode inference (dropout sampling + DBSCAN centre + confidence head)"
                        if a.mode == "plus_sampling" else
+                       "complexes/sec fwd+bwd (1500p/40l nodes), full IaBNet on the whole graph (pocket model + 4-layer complex model + "
+                       "distance-map head on all nodes / pairs) with the pocket-cls + pocket-centre + coord + distmap + distmap-by-coords + "
+                       "distill losses (BASELINE configs[2] read literally)" if (a.mode == "model" and a.whole_pocket) else
                        "complexes/sec fwd+bwd, full IaBNet (pocket model + pocket crop + complex model + heads) with "
                        "pocket-cls + coord + distmap losses" if a.mode == "model" else
                        "complexes/sec, one FABind+ training step (train mode, 7-term loss with the permutation-invariant "
@@ -607,6 +689,12 @@ def main():
                        "synthetic batch=%d/GPU, %d protein / %d ligand nodes, FABind+ model (5-layer LN-MLP stack, hidden %d, "
                        "n_iter=%d), training step" % (a.batch, a.n_prot, a.n_lig, a.hidden, a.n_iter)
                        if a.mode == "plus_train" else
+                       "BASELINE configs[2]: synthetic batch=%d/GPU (%d distinct seeded geometries), %d protein / %d ligand nodes, full IaBNet "
+                       "(hidden-128 pocket model + %d-layer hidden-%d FABind stack + out layer + distance-map head), %s, n_iter=%d, "
+                       "six-term loss, fwd+bwd" % (a.batch, a.batch, a.n_prot, a.n_lig, a.layers, a.hidden,
+                                                   "pocket = the whole protein (radius unbounded): every node and all %d pairs per complex"
+                                                   % (a.n_prot * a.n_lig) if a.whole_pocket else "20 A pocket crop", a.n_iter)
+                       if a.mode == "model" else
                        "synthetic batch=%d/GPU (%d distinct seeded geometries), %d protein / %d ligand nodes, %d-layer FABind stack "
                        "+ out layer, hidden %d, n_iter=%d, %s" % (a.batch, a.batch, a.n_prot, a.n_lig, a.layers, a.hidden,
                                                                    a.n_iter, a.mode),
@@ -619,7 +707,14 @@ def main():
                                    "pocket crop)",
                            "config3": "config3_whole_graph sub-object of this line (parity: tests/test_gpu_production.py::"
                                       "test_config3_whole_graph_matches_oracle)"} if a.mode in ("fwd", "fwdbwd") else {}),
-                       "batch_arrival": ("fresh index tensors per step; layout + input-coordinate graph of step k+1 built on a "
+                       **({"loss": "the reference's six-term training loss (main_fabind.py:398-417; fabind_amd.models.model.compute_loss)",
+                           "parity": "tests/test_gpu_production.py::test_config3_whole_graph_matches_oracle (fp32 vs the CPU oracle: 11-tuple, six "
+                                     "loss terms, 351 gradients; the bench dtype asserted at the 1e-4 A gate)",
+                           "stack_only": "`stack_fwdbwd` sub-object = rounds 1-5's headline (the layer stack with a quadratic loss)"}
+                          if (a.mode == "model" and a.whole_pocket) else {}),
+                       "batch_arrival": ("a fresh batch object per step; its stage-1 plan (gather indices, pair lists, both stacks' layouts and "
+                                         "input graphs) built on a feeder stream during the previous step (model.plan_stage1)") if a.mode == "model" else
+                                        ("fresh index tensors per step; layout + input-coordinate graph of step k+1 built on a "
                                          "feeder stream during step k (engine.prefetch)") if prefetching[0]
                        else ("ONE resident batch re-served (round 2's protocol, FABIND_BENCH_REUSE_BATCH=1)" if REUSE_BATCH else
                              "fresh index tensors per step, layout built at the start of the step")},
@@ -652,7 +747,7 @@ def main():
                     break
 
     # ---- the same JSON line also says what the neighbouring configurations cost (N=1, default workload only)
-    if a.mode == "fwdbwd" and world == 1 and not a.no_extras:
+    if (a.mode == "fwdbwd" or headline_config3) and world == 1 and not a.no_extras:
         extras = {}
         del step
         torch.cuda.empty_cache()
@@ -693,6 +788,10 @@ def main():
                 gc.collect()
                 torch.cuda.synchronize()
                 torch.cuda.empty_cache()
+        if headline_config3:
+            sub("stack_fwdbwd", "fwdbwd", a.n_iter, steps=10, warmup=3,
+                note="rounds 1-5's headline: the layer stack ALONE (4 FABind layers + out layer, hidden 512) on the same 1500 / 40 batch, "
+                     "forward + backward of (X*X).mean() + 1e-6 (H*H).mean(), fresh batch per step")
         sub("pocket", "fwdbwd", a.n_iter, steps=30, warmup=5, n_prot=100,
             note="the headline step at the size the 4-layer stack sees in production (SURVEY 0.4 / 8(d): the 20 A pocket, 100 protein / 40 "
                  "ligand nodes per complex), fresh batch per step")
@@ -727,10 +826,14 @@ def main():
                  "six-term loss (pocket-cls + pocket-centre + contact x2 + distill + coord), eval mode")
         sub("model_gate", "model", a.n_iter, precision="bf16x3", steps=10, warmup=2,
             note="model_fwdbwd in the gate-meeting split-bf16 mode (production-size parity: tests/test_gpu_production.py)")
-        sub("config3_whole_graph", "model", a.n_iter, steps=10, warmup=2, whole_pocket=True,
-            note="BASELINE configs[2] read literally: the same synthetic batch with an unbounded pocket radius, so the 4-layer hidden-512 "
-                 "complex model AND the heads run on all 1500 protein / 40 ligand nodes -- pocket-cls + pocket-centre + coord + both "
-                 "distance-map losses + distill (the reference's six-term loss) -- fwd+bwd, eval mode")
+        if not headline_config3:
+            sub("config3_whole_graph", "model", a.n_iter, steps=10, warmup=2, whole_pocket=True,
+                note="BASELINE configs[2] read literally: the same synthetic batch with an unbounded pocket radius, so the 4-layer hidden-512 "
+                     "complex model AND the heads run on all 1500 protein / 40 ligand nodes -- pocket-cls + pocket-centre + coord + both "
+                     "distance-map losses + distill (the reference's six-term loss) -- fwd+bwd, eval mode")
+        else:
+            sub("config3_gate", "model", a.n_iter, precision="bf16x3", steps=6, warmup=2, whole_pocket=True,
+                note="the headline step in the split-bf16 mode (fp32 storage, three bf16 MFMAs per product term)")
         sub("model_fwdbwd_train_n_iter8", "model", 8, train_mode=True,
             note="the same with model.train() (dropout, Gumbel noise) and n_iter=8: the reference's training configuration")
         n_it8 = 8
@@ -754,6 +857,8 @@ def main():
     # FABind+ sampling modes would otherwise carry a baseline of a different workload)
     if not a.no_cpu_baseline and world == 1 and a.mode in ("fwd", "fwdbwd"):
         out["cpu_baseline"] = cpu_baseline(a.hidden, a.layers, a.n_iter, a.n_prot, a.n_lig, backward=(a.mode == "fwdbwd"))
+    if not a.no_cpu_baseline and world == 1 and headline_config3:
+        out["cpu_baseline"] = cpu_baseline_config3(a.hidden, a.layers, a.n_iter, a.n_prot, a.n_lig)
     print(json.dumps(out))
 
 

@@ -19,10 +19,13 @@ PROFILE = None  # dict: label -> list of (start_event, end_event, flops) around 
 PROFILE_ONLY = None
 
 
-PROFILE_BYTES = {}        # label -> ALGORITHMIC HBM bytes of the launches timed under that label (operands read once + results written once)
+PROFILE_BYTES = {}        # label -> DESIGN HBM bytes of the launches timed under that label (the tensors this design's launch reads once + writes once)
+PROFILE_ALGO = {}         # label -> ALGORITHMIC bytes in the sense of SURVEY 8(d): the compulsory traffic of the reference operation the launch replaces
+#                           (fused edge kernels: per-node rows + indices only -- the [E, H] tiles this design materialises are NOT in it); a launch that
+#                           names no figure of its own is priced at its design bytes
 
 
-def _profiled(label, flops, fn, nbytes=0.0):
+def _profiled(label, flops, fn, nbytes=0.0, algo=None):
     # PROFILE_ONLY: name prefix of the one kernel family to time (bench.py: the dominant family, found in a fully timed warm-up step --
     # two events around each of the ~300 labelled launches of a step cost the host 1.7-2.6 ms of a 100 ms step, 2-3 ms of a 26 ms one)
     if PROFILE is None or (PROFILE_ONLY is not None and not label.startswith(PROFILE_ONLY)):
@@ -33,6 +36,7 @@ def _profiled(label, flops, fn, nbytes=0.0):
     e1.record()
     PROFILE.setdefault(label, []).append((e0, e1, flops))
     PROFILE_BYTES[label] = PROFILE_BYTES.get(label, 0.0) + float(nbytes)
+    PROFILE_ALGO[label] = PROFILE_ALGO.get(label, 0.0) + float(nbytes if algo is None else algo)
     return r
 
 
@@ -549,14 +553,16 @@ def gcl_edge_fused_x3(AB, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, n_rows, 
                                                                            ptr(W2h), ptr(W2l), ptr(b2), ptr(Wch), ptr(Wcl), ptr(bc), ptr(w3), E,
                                                                            ptr(agg), ptr(s), float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd),
                                                                            ptr(Msave), ptr(d2f), ptr(z3f), stream()), "fabind_gcl_edge_fused_x3_train"),
-                  E * (6.0 * H + 16) + n_rows * (8.0 * H + 4.0 * H))
+                  E * (6.0 * H + 16) + n_rows * (8.0 * H + 4.0 * H),
+                  algo=2.0 * n_rows * H * 4 + E * 8.0 + n_rows * 24.0)        # 2 N H s + E 8 + N 24 (s = 4: fp32 rows)
         return agg, s[:E], (Msave, d2f, z3f)
     _profiled("gcl_edge_fused_x3_kernel<%d> E=%d (gather + 2 chained H x H split-bf16 contractions + segment-sum per edge)" % (H, E),
               4.0 * E * H * H,
               lambda: check(_lib.load().fabind_gcl_edge_fused_x3(ptr(AB), _ld(AB), AB.shape[0], H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
                                                                  ptr(W2h), ptr(W2l), ptr(b2), ptr(Wch), ptr(Wcl), ptr(bc), ptr(w3), E,
                                                                  ptr(agg), ptr(s), float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd),
-                                                                 stream()), "fabind_gcl_edge_fused_x3"))
+                                                                 stream()), "fabind_gcl_edge_fused_x3"),
+              E * 16.0 + n_rows * (8.0 * H + 4.0 * H), algo=2.0 * n_rows * H * 4 + E * 8.0 + n_rows * 24.0)
     return agg, s[:E]
 
 
@@ -598,14 +604,16 @@ def gcl_edge_fused(AB16, H, row, col, rhohat, w_r, W2p, b2, Wcp, bc, w3, n_rows,
                                                                         ptr(Msave), ptr(d2f), ptr(z3f), stream()),
                                 "fabind_gcl_edge_fused_train"),
                   # per edge: 3 saved bf16 rows + row / col / rhohat / s; per node: the AB row once + agg fp32 (+ bf16)
-                  E * (6.0 * H + 16) + n_rows * (4.0 * H + 4.0 * H + (2.0 * H if want16 else 0.0)))
+                  E * (6.0 * H + 16) + n_rows * (4.0 * H + 4.0 * H + (2.0 * H if want16 else 0.0)),
+                  algo=2.0 * n_rows * H * 2 + E * 8.0 + n_rows * 24.0)        # 2 N H s + E 8 + N 24 (s = 2: bf16)
     else:
         _profiled("gcl_edge_fused_kernel<%d> E=%d (gather + 2 chained H x H contractions + segment-sum per edge)" % (H, E), 4.0 * E * H * H,
                   lambda: check(_lib.load().fabind_gcl_edge_fused(ptr(AB16), _ld(AB16), H, ptr(row), ptr(col), ptr(rhohat), ptr(w_r),
                                                                   ptr(W2p), ptr(b2), ptr(Wcp), ptr(bc), ptr(w3), E, ptr(agg), ptr(s),
                                                                   float(p_drop), int(seed) & 0xFFFFFFFF, ptr(bnd), ptr(agg16), stream()),
                                 "fabind_gcl_edge_fused"),
-                  E * 16.0 + n_rows * (4.0 * H + 4.0 * H + (2.0 * H if want16 else 0.0)))
+                  E * 16.0 + n_rows * (4.0 * H + 4.0 * H + (2.0 * H if want16 else 0.0)),
+                  algo=2.0 * n_rows * H * 2 + E * 8.0 + n_rows * 24.0)
     out = (agg, s[:E], agg16) if want16 else (agg, s[:E])
     return out + ((Msave, d2f, z3f),) if save else out
 
@@ -760,7 +768,10 @@ def gcl_edge_fused_bwd(AB16, H, row, col, rhohat, w_r, W2, b2, Wc, bc, w3, ds, d
                             "fabind_gcl_edge_fused_bwd"),
               # per edge: the [E,H] bf16 tiles read (saved form: silu'(pre2), pre3) and written (S1, dT, dP2, dP1; recompute form: + M) +
               # row / col / rhohat / ds / drh; per node: the AB row and dagg once, dAB's receiving half
-              E * ((12.0 if variant == 6 else 10.0) * H + 20) + N * (4.0 * H + 4.0 * H + (2.0 if dab_bf16 else 4.0) * H))
+              E * ((12.0 if variant == 6 else 10.0) * H + 20) + N * (4.0 * H + 4.0 * H + (2.0 if dab_bf16 else 4.0) * H),
+              # SURVEY 8(d) names the forward's compulsory bytes only; the adjoint's, by the same rule (nothing of size [E, H] counts):
+              # per node the AB row (2H bf16), the incoming d agg row (H fp32) and the outgoing d AB row (2H), per edge 20 B of indices / scalars
+              algo=N * (2.0 * H * 2 + 4.0 * H + 2.0 * H * (2.0 if dab_bf16 else 4.0)) + E * 20.0)
     del keep
     if E > 0:
         if dab_bf16:

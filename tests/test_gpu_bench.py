@@ -35,6 +35,10 @@ def test_bench_json_contract_single_rank():
     assert abs(r["value"] - 3 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]
     rf = r["roofline"]
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    # the fraction is reproducible from the line itself -- executed flops (or compulsory bytes) per launch / average launch time / peak
+    per = rf["flop_per_launch"] / 1e12 if rf["bound"] == "mfma" else rf["algorithmic_bytes_per_launch"] / 1e9
+    assert abs(rf["achieved"] - per / (rf["avg_us"] * 1e-6)) <= 1e-6 * max(rf["achieved"], 1e-9)
+    assert rf["design_bytes_per_launch"] >= 0 and rf["other_roofline"]["bound"] != rf["bound"]
 
 
 def test_bench_two_ranks_control_flow():
@@ -60,7 +64,7 @@ def test_bench_self_launches_without_a_launcher():
 
 
 SUB_OBJECTS = ("pocket", "gate_mode", "gate_mode_exact_bwd", "fp32", "train_mode", "n_iter8", "n_iter8_gate", "fwd", "model_fwdbwd",
-               "model_gate", "gate_mode_bf16_edge", "n_iter8_gate_bf16_edge", "config3_whole_graph", "model_fwdbwd_train_n_iter8", "plus_train", "plus_train_gate", "plus_sampling")
+               "model_gate", "gate_mode_bf16_edge", "n_iter8_gate_bf16_edge", "stack_fwdbwd", "config3_gate", "model_fwdbwd_train_n_iter8", "plus_train", "plus_train_gate", "plus_sampling")
 
 
 def test_bench_line_carries_the_neighbouring_configurations():
@@ -75,7 +79,9 @@ def test_bench_line_carries_the_neighbouring_configurations():
     for k in ("gate_mode", "gate_mode_exact_bwd", "n_iter8_gate", "model_gate", "plus_train_gate"):
         assert r[k]["dtype"] == "bf16x3", k
     assert r["pocket"]["nodes"].startswith("100 protein") and r["pocket"]["pass"] == "fwdbwd"
-    assert r["config3_whole_graph"]["pass"] == "model"
+    assert r["stack_fwdbwd"]["pass"] == "fwdbwd" and r["config3_gate"]["pass"] == "model" and r["config3_gate"]["dtype"] == "bf16x3"
+    # the headline is BASELINE configs[2] read literally and says so: the full model on the whole graph, the six losses named
+    assert r["config"]["pass"] == "model" and all(w in r["metric"] for w in ("pocket-cls", "pocket-centre", "coord", "distmap", "distill"))
     # nothing else in the line is an unreported failure either
     assert not [k for k, v in r.items() if isinstance(v, dict) and "error" in v]
 

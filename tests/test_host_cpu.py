@@ -410,16 +410,26 @@ def test_rows_hadamard_csr_lists_every_pair_under_both_rows():
     assert int(rp[36]) == int(rp[37])                      # rows 35, 36 have no pair
 
 
-def test_bench_prices_a_family_against_both_rooflines():
-    """bench.py: the dominant family's launches are priced against the MFMA and the HBM roofline; the one they sit closer to binds."""
+def test_bench_reports_rooflines_by_the_survey_classification():
+    """bench.py (round 6): WHICH roofline a kernel family is reported against follows SURVEY 8(d)'s classification of the
+    operation (bound_of), not whichever fraction is larger; the fraction is reproducible from flops (or 8(d) compulsory bytes), launch
+    time and the peak; this design's own tile traffic rides along as `design_traffic`."""
     import bench
-    # the node-level GEMM family of the round-4 headline: 50.3 GFLOP and 312 MB per launch in 119 us -> HBM-shaped
-    b, o = bench.price_against_rooflines(50.3e9 * 755, 312e6 * 755, 0.119 * 755, "bf16")
-    assert b["bound"] == "hbm" and o["bound"] == "mfma" and abs(b["achieved"] - 2621.8) < 5 and abs(o["achieved"] - 422.7) < 2
-    assert abs(b["frac"] - b["achieved"] / 8000.0) < 1e-12 and abs(o["frac"] - o["achieved"] / 2500.0) < 1e-12
-    # the fused edge forward: 1.61 TFLOP and 0.4 GB in 1.83 ms -> MFMA-shaped
-    b, o = bench.price_against_rooflines(1.61e12, 0.4e9, 1.83, "bf16")
-    assert b["bound"] == "mfma" and 0.34 < b["frac"] < 0.36 and o["frac"] < 0.05
+    assert bench.bound_of("gcl_edge_fused_bwd4_kernel<512> E=1539196") == "mfma" and bench.bound_of("fabind_gemm M=98688") == "mfma"
+    assert bench.bound_of("cross_attn_fused_fwd mode=0") == "mfma" and bench.bound_of("fabind_gemm_tn M=512") == "mfma"
+    assert bench.bound_of("segment_sum rows=98688") == "hbm" and bench.bound_of("inter_attn_fwd_rows") == "hbm"
+    # the edge backward of the round-5 headline: 4 E H^2 = 1.614 TFLOP per launch in 3,267.5 us; 8(d)-style compulsory bytes 0.64 GB,
+    # design tiles 9.98 GB.  Reported against the matrix cores: 0.494 PFLOP/s = 0.198 of 2.5 PFLOP/s -- NOT "hbm 0.38" as rounds 4-5 printed
+    E, H, N = 1539196, 512, 98688
+    r = bench.price_against_rooflines(4.0 * E * H * H, N * 6.0 * H * 2 + E * 20.0, 3.2675, "bf16", "mfma", design_bytes=9.98e9)
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["achieved"] - 494.0) < 1.0 and abs(r["frac"] - 0.1976) < 5e-4
+    assert r["other_roofline"]["bound"] == "hbm" and r["other_roofline"]["frac"] < 0.03          # the compulsory bytes: 2 % of HBM
+    assert abs(r["design_traffic"]["achieved"] - 3054.0) < 5.0 and abs(r["design_traffic"]["frac_of_hbm_peak"] - 0.382) < 2e-3
+    # a stand-alone segment sum: 8(d): E H s + E 4 + N H s bytes against HBM
+    nb = E * H * 2 + E * 4 + N * H * 2
+    r = bench.price_against_rooflines(0.0, nb, 0.6, "bf16", "hbm")
+    assert r["bound"] == "hbm" and abs(r["achieved"] - nb / 0.6e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert "design_traffic" not in r
     # no time measured: zeros, not a division error; the split-bf16 mode is priced at a third of the bf16 peak
-    b, o = bench.price_against_rooflines(1e12, 1e9, 0.0, "bf16x3")
-    assert b["achieved"] == 0.0 and o["achieved"] == 0.0 and {b["peak"], o["peak"]} == {8000.0, 2500.0 / 3.0}
+    r = bench.price_against_rooflines(1e12, 1e9, 0.0, "bf16x3", "mfma")
+    assert r["achieved"] == 0.0 and r["other_roofline"]["achieved"] == 0.0 and r["peak"] == 2500.0 / 3.0
