@@ -10,7 +10,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FABIND_LIB") or os.path.join(_HERE, "libfabind_hip.so")      # FABIND_LIB: an A/B build (tools/probes)
 
-ABI_VERSION = 17         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
+ABI_VERSION = 18         # FABIND_ABI_VERSION of include/fabind_hip.h this binding mirrors
 DT_F32, DT_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_RELU, ACT_SIGMOID, ACT_STORED_DERIV = 0, 1, 2, 3, 4
 
@@ -146,6 +146,11 @@ SIGNATURES = {
     "fabind_pair_bias_finish": [_vp, _vp, _i, _i, _vp, _vp, _i, _vp, _vp, _l, _vp],
     "fabind_pack_frag_multi": [_vp, _vp, _i, _vp],
     "fabind_lower_bound": [_vp, _i, _vp, _i, _vp, _vp],
+    "fabind_pocket_center_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp],
+    "fabind_pocket_center_bwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "fabind_loss_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
+    "fabind_loss_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _l, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp,
+                        _vp, _vp, _vp, _vp, _vp, _vp],
     "fabind_layernorm_fwd": [_vp, _vp, _vp, _f, _i, _i, _vp, _vp, _vp, _vp],
     "fabind_layernorm_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
 }
@@ -175,6 +180,7 @@ def load():
     lib.fabind_cross_attn_fused_bwd_scratch.argtypes, lib.fabind_cross_attn_fused_bwd_scratch.restype = [_i, _i, _i, _i, _i], ctypes.c_long
     lib.fabind_cross_attn_fused_bwd_parts.argtypes, lib.fabind_cross_attn_fused_bwd_parts.restype = [_i, _i], ctypes.c_int
     lib.fabind_pair_bias_finish_parts.argtypes, lib.fabind_pair_bias_finish_parts.restype = [_i], ctypes.c_int
+    lib.fabind_loss_blocks.argtypes, lib.fabind_loss_blocks.restype = [_l, _l, _l], ctypes.c_int
     for which, mirror in enumerate((GemmArgs, EdgeBwdArgs, PairUpdateArgs, TnJob, AttnFusedBwdArgs)):
         if lib.fabind_sizeof_args(which) != ctypes.sizeof(mirror):
             raise RuntimeError("fabind_amd: ctypes mirror %s is %d bytes, the library's struct is %d -- _lib.py and "

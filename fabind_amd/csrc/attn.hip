@@ -384,7 +384,7 @@ extern "C" int fabind_inter_attn_fwd(const float* qkv, int ldqkv, const float* c
 // them) and the kernel has no LDS traffic of its own: the cause is NOT established.  Round 6 replaces the empty-asm trick that kept the
 // SLP vectoriser from pairing the accumulations (it depended on the optimiser's mood) by switching packed fp32 off for the function,
 // and keeps the kernel in the device-sharing stress test (tests/test_gpu_contention.py).
-__global__ __launch_bounds__(256) __attribute__((target("no-packed-fp32-ops"))) void las_step_kernel(const float* __restrict__ x, const float* __restrict__ x0,
+__global__ __launch_bounds__(256) FB_NO_PACKED_F32 void las_step_kernel(const float* __restrict__ x, const float* __restrict__ x0,
                                                        const int* las_i, const int* las_j, const int* las_off,
                                                        const int* node_off, const int* c_cnt, float step, float clampv,
                                                        float* x_out, int nb_copy) {

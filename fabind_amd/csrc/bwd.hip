@@ -1378,7 +1378,7 @@ extern "C" int fabind_inter_attn_bwd(const float* qkv, int ldqkv, const float* c
 // ------------------------------------------------------------------------------------------------
 // (one wave per ligand atom, lanes over the complex's LAS edges, fixed-order wave sums; other nodes: a copy, one thread each -- the
 //  thread-per-atom form walked all 154 edges serially: 76 us per call at 2,560 atoms)
-__global__ __launch_bounds__(256) __attribute__((target("no-packed-fp32-ops"))) void las_step_bwd_kernel(const float* __restrict__ x, const float* __restrict__ x0,
+__global__ __launch_bounds__(256) FB_NO_PACKED_F32 void las_step_bwd_kernel(const float* __restrict__ x, const float* __restrict__ x0,
                                                            const float* __restrict__ xo, const int* las_i,
                                                            const int* las_j, const int* las_off, const int* node_off,
                                                            const int* c_cnt, float step, float clampv,

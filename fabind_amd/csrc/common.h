@@ -12,6 +12,14 @@
 #define FB_ACT_SIGMOID 3
 #define FB_ACT_STORED_DERIV 4  // "derivative" operand already holds act'(pre): apply_dact(x) = x
 
+// Function attribute: no packed fp32 math (v_pk_*_f32) in this kernel (the LAS step: attn.hip).  A subtarget feature of the DEVICE pass; the host
+// pass of the same source does not know it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FB_NO_PACKED_F32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define FB_NO_PACKED_F32
+#endif
+
 typedef uint16_t bf16_t;  // raw bfloat16 storage
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;

@@ -226,15 +226,12 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
                     logits_flat=logits_flat)
 
     def _soft_center(self, logits, mask, xyz, noise):
-        pt = logits.sigmoid().unsqueeze(-1)
-        prob = torch.clamp(torch.cat([1. - pt, pt], dim=-1), min=1e-6, max=1 - 1e-6)
-        logp = torch.log(prob)
+        """Gumbel-softmax pocket centre (reference model.py:146-158) as ONE kernel each way (ops.pocket_center, csrc/heads.hip).  Train
+        mode draws the Gumbel samples exactly as F.gumbel_softmax does (same generator calls), the kernel adds them."""
+        gn = None
         if noise:
-            y = F.gumbel_softmax(logp, tau=self.args.gs_tau, hard=self.args.gs_hard)
-        else:
-            y = gumbel_softmax_no_random(logp, tau=self.args.gs_tau, hard=self.args.gs_hard)
-        wgt = (y[:, :, 1] * mask).unsqueeze(-1)
-        return (wgt * xyz).sum(dim=1) / wgt.sum(dim=1)
+            gn = -torch.empty((logits.shape[0], logits.shape[1], 2), dtype=torch.float32, device=logits.device).exponential_().log()
+        return ops.pocket_center(logits, mask, xyz, tau=self.args.gs_tau, hard=self.args.gs_hard, noise=gn)
 
     @torch.no_grad()
     def _stage2_indices(self, data, head, center):
@@ -427,16 +424,14 @@ def get_model(args, logger, device=None):
 def compute_loss(out, data, args=None):
     """The reference's train-step loss (main_fabind.py:398-417) as a function of the forward's 11-tuple.
 
-    Returns (loss, dict of the six terms).  Small vector reductions: plain torch on the device."""
+    Returns (loss, dict of the six terms: pocket_cls, pocket_center, contact, contact_by_pred, distill, coord)."""
     w = dict(coord=1.0, pair=1.0, distill=1.0, cls=1.0, center=0.05, delta=3.0)
     if args is not None:
         w.update(coord=args.coord_loss_weight, pair=args.pair_distance_loss_weight,
                  distill=args.pair_distance_distill_loss_weight, cls=args.pocket_cls_loss_weight,
                  center=args.pocket_distance_loss_weight, delta=args.pocket_coord_huber_delta)
     coords, cb, y_pred, y_by, logits, pocket_cls, p_mask, _, center, dis_map, _ = out
-    terms = dict(
-        pocket_cls=w['cls'] * F.binary_cross_entropy_with_logits(logits, pocket_cls.float()) * (p_mask.numel() / p_mask.sum()),
-        pocket_center=w['center'] * F.huber_loss(center, data.coords_center, delta=w['delta']),
-        contact=w['pair'] * F.mse_loss(y_pred, dis_map), contact_by_pred=w['pair'] * F.mse_loss(y_by, dis_map),
-        distill=w['distill'] * F.mse_loss(y_by, y_pred), coord=w['coord'] * F.smooth_l1_loss(coords, data.coords))
-    return sum(terms.values()), terms
+    if coords.is_cuda:
+        # one launch for the six terms and their sum, one for the five gradient seeds (ops.six_term_loss, csrc/heads.hip: SURVEY K20)
+        return ops.six_term_loss(coords, y_pred, y_by, logits, center, data.coords, dis_map, pocket_cls, p_mask, data.coords_center, w)
+    raise RuntimeError("fabind_amd.compute_loss: the model's outputs are HIP tensors; got %s" % coords.device)

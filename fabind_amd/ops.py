@@ -2006,3 +2006,95 @@ class _LayerNorm(torch.autograd.Function):
 
 def layernorm(x, w, b, eps=1e-5):
     return _LayerNorm.apply(x.float().contiguous(), w, b, eps)
+
+
+# ------------------------------------------------------------------------------------------------
+# Heads (round 6; csrc/heads.hip): the Gumbel-softmax pocket centre and the six-term training loss with its gradient
+# seeds -- one launch each way instead of chains of element-wise torch ops
+# ------------------------------------------------------------------------------------------------
+class _PocketCenter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, mask_u8, xyz, noise, tau, hard):
+        B, L = logits.shape
+        center = torch.empty((B, 3), dtype=torch.float32, device=logits.device)
+        wsum = torch.empty(B, dtype=torch.float32, device=logits.device)
+        check(load().fabind_pocket_center_fwd(ptr(logits), ptr(mask_u8), ptr(xyz), ptr(noise), B, L, float(tau), int(bool(hard)),
+                                              ptr(center), ptr(wsum), stream()), "fabind_pocket_center_fwd")
+        ctx.save_for_backward(logits, mask_u8, xyz, noise if noise is not None else logits.new_empty(0), center, wsum)
+        ctx.tau, ctx.has_noise = float(tau), noise is not None
+        return center
+
+    @staticmethod
+    def backward(ctx, dcenter):
+        logits, mask_u8, xyz, noise, center, wsum = ctx.saved_tensors
+        B, L = logits.shape
+        dlogits = torch.empty_like(logits)
+        check(load().fabind_pocket_center_bwd(ptr(logits), ptr(mask_u8), ptr(xyz), ptr(noise) if ctx.has_noise else None, B, L, ctx.tau,
+                                              ptr(center), ptr(wsum), ptr(dcenter.contiguous().float()), ptr(dlogits), stream()),
+              "fabind_pocket_center_bwd")
+        return dlogits, None, None, None, None, None
+
+
+def pocket_center(logits, mask, xyz, tau=1.0, hard=False, noise=None):
+    """center [B, 3] of the reference's Gumbel-softmax pocket head (models/model.py:146-158): logits / mask [B, L], xyz [B, L, 3];
+    noise: the Gumbel samples [B, L, 2] of train mode (None: gumbel_softmax_no_random).  One kernel forward, one backward."""
+    lg = logits.float().contiguous()
+    m8 = mask.contiguous().view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8).contiguous()
+    return _PocketCenter.apply(lg, m8, xyz.float().contiguous(), None if noise is None else noise.float().contiguous(), tau, hard)
+
+
+_LOSS_TICKET = {}
+_CLS_DT = {torch.float32: 0, torch.int64: 1, torch.int32: 2, torch.uint8: 3, torch.bool: 3}
+LOSS_TERM_NAMES = ("pocket_cls", "pocket_center", "contact", "contact_by_pred", "distill", "coord")
+
+
+class _SixTermLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, coords, y_pred, y_by, logits, center, coords_true, dis_map, cls, mask_u8, center_true, w):
+        dev = coords.device
+        tk = _LOSS_TICKET.get(dev)
+        if tk is None:
+            tk = _LOSS_TICKET[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+        n_pair, n_coord, n_cls, n_center = y_pred.numel(), coords.numel(), logits.numel(), center.numel()
+        nblk = load().fabind_loss_blocks(n_pair, n_coord, n_cls)
+        part = torch.empty((nblk, 8), dtype=torch.float32, device=dev)
+        out = torch.empty(8, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        terms = torch.empty(6, dtype=torch.float32, device=dev)
+        cls_dt = _CLS_DT[cls.dtype]
+        check(load().fabind_loss_fwd(ptr(coords), ptr(coords_true), n_coord, ptr(y_pred), ptr(y_by), ptr(dis_map), n_pair, ptr(logits),
+                                     ptr(cls), cls_dt, ptr(mask_u8), n_cls, ptr(center), ptr(center_true), n_center, w['coord'], w['pair'],
+                                     w['distill'], w['cls'], w['center'], w['delta'], ptr(part), ptr(tk), ptr(out), ptr(loss), ptr(terms),
+                                     stream()), "fabind_loss_fwd")
+        ctx.save_for_backward(coords, y_pred, y_by, logits, center, coords_true, dis_map, cls, center_true, out)
+        ctx.w, ctx.cls_dt = w, cls_dt
+        return loss, terms
+
+    @staticmethod
+    def backward(ctx, g_loss, g_terms):
+        coords, y_pred, y_by, logits, center, coords_true, dis_map, cls, center_true, out = ctx.saved_tensors
+        w = ctx.w
+        need = ctx.needs_input_grad
+        d = [torch.empty_like(t) if need[i] else None for i, t in enumerate((coords, y_pred, y_by, logits, center))]
+        gl = None if g_loss is None else g_loss.contiguous().float()
+        gt = None if g_terms is None else g_terms.contiguous().float()
+        check(load().fabind_loss_bwd(ptr(coords), ptr(coords_true), coords.numel(), ptr(y_pred), ptr(y_by), ptr(dis_map), y_pred.numel(),
+                                     ptr(logits), ptr(cls), ctx.cls_dt, logits.numel(), ptr(center), ptr(center_true), center.numel(),
+                                     w['coord'], w['pair'], w['distill'], w['cls'], w['center'], w['delta'], ptr(out), ptr(gl), ptr(gt),
+                                     ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), stream()), "fabind_loss_bwd")
+        return d[0], d[1], d[2], d[3], d[4], None, None, None, None, None, None
+
+
+def six_term_loss(coords, y_pred, y_by, logits, center, coords_true, dis_map, pocket_cls, p_mask, center_true, w):
+    """The reference's train-step loss (main_fabind.py:398-417) -> (loss, {name: term}); ONE launch for the six terms and their sum, ONE for
+    the five gradient seeds.  w: dict(coord, pair, distill, cls, center, delta)."""
+    f = lambda t: t.float().contiguous()
+    cls = pocket_cls.contiguous()
+    if cls.dtype not in _CLS_DT:
+        cls = cls.float()
+    m8 = p_mask.contiguous().view(torch.uint8) if p_mask.dtype == torch.bool else p_mask.to(torch.uint8).contiguous()
+    w = {k: float(v) for k, v in w.items()}
+    loss, terms = _SixTermLoss.apply(f(coords), f(y_pred), f(y_by), f(logits), f(center), f(coords_true), f(dis_map), cls, m8,
+                                     f(center_true), w)
+    tt = terms.unbind(0)
+    return loss, {n: tt[i] for i, n in enumerate(LOSS_TERM_NAMES)}

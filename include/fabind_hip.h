@@ -63,8 +63,10 @@ const char* fabind_last_error(void);
  *     fabind_edge_lnfold_bwd (+ _blocks) added (FABind+: the LayerNorm-folded first edge Linear under autograd);
  *     fabind_mul_dropmask_colsum, fabind_drop_mix (+ _bwd) added, fabind_gemm's fp32 (+ residual) epilogue takes p_drop (train-mode dropout
  *     ahead of a residual).
+ * 18 = round 6: fabind_loss_fwd / fabind_loss_bwd / fabind_loss_blocks (the six-term training loss and its gradient seeds, one launch each way),
+ *     fabind_pocket_center_fwd / _bwd (the Gumbel-softmax pocket centre, one launch each way); fabind_gemm_tn_set_exp ignores bit 2.
  * A binding must refuse a library whose version differs from the header it was written against. */
-#define FABIND_ABI_VERSION 17
+#define FABIND_ABI_VERSION 18
 int fabind_abi_version(void);
 /* sizeof() of an argument struct as this library was compiled: which = 0 FabindGemmArgs, 1 FabindEdgeBwdArgs,
  * 2 FabindPairUpdateArgs, 3 FabindTnJob (-1 for an unknown index).  Lets a foreign-language mirror of the struct verify its layout. */
@@ -497,6 +499,40 @@ int fabind_inter_attn_fwd_rows(const float* qkv, int ldqkv, const float* cv, int
 int fabind_las_step(const float* x, const float* x0, const int* las_i, const int* las_j, const int* las_off,
                     const int* node_off, const int* c_cnt, int B, int max_n, float step, float clampv, float* x_out,
                     hipStream_t stream);
+
+/* Pocket centre (models/model.py:146-158): per complex b over its L (padded) residues
+ *   s = sigmoid(logit); p = clamp([1 - s, s], 1e-6, 1 - 1e-6); y = softmax((log p + noise) / tau) over the two classes
+ *   (noise: the Gumbel samples of F.gumbel_softmax in train mode, [B, L, 2], NULL in eval = utils/utils.py:687-699 gumbel_softmax_no_random);
+ *   hard != 0: the straight-through one-hot; w = y[..., 1] * mask; center[b] = sum_l w_l xyz[b, l] / sum_l w_l; wsum[b] = sum_l w_l.
+ * logits / mask: [B, L] (fp32 / uint8), xyz [B, L, 3].  _bwd: dlogits [B, L] from dcenter [B, 3] (the soft path's gradient; 0 at masked
+ * positions).  One launch each; fixed-order sums. */
+int fabind_pocket_center_fwd(const float* logits, const uint8_t* mask, const float* xyz, const float* noise, int B, int L,
+                             float tau, int hard, float* center, float* wsum, hipStream_t stream);
+int fabind_pocket_center_bwd(const float* logits, const uint8_t* mask, const float* xyz, const float* noise, int B, int L,
+                             float tau, const float* center, const float* wsum, const float* dcenter, float* dlogits,
+                             hipStream_t stream);
+
+/* Training loss (main_fabind.py:398-417), all six terms and their sum in ONE launch:
+ *   out[0] pocket_cls      = w_cls * BCEWithLogits(logits, cls) (mean over all n_cls = B * Lmax positions, padding included) * n_cls / sum(mask)
+ *   out[1] pocket_center   = w_center * Huber_delta(center, center_true)                (mean over n_center = 3 B)
+ *   out[2] contact         = w_pair * MSE(y_pred, dis_map)      out[3] contact_by_pred = w_pair * MSE(y_by, dis_map)
+ *   out[4] distill         = w_distill * MSE(y_by, y_pred)      out[5] coord = w_coord * SmoothL1(coords, coords_true)   (n_coord = 3 * atoms)
+ *   out[6] = their sum (in this order), out[7] = sum(mask); loss_out[1] / terms_out[6] (either may be NULL): copies of out[6] / out[0..5].
+ * cls_dt: dtype of `cls`: 0 fp32, 1 int64, 2 int32, 3 uint8.  part: fp32 scratch [fabind_loss_blocks(n_pair, n_coord, n_cls)][8];
+ * ticket: one uint32 that is ZERO before the first launch (the kernel re-arms it).  Deterministic (block partials summed in block order).
+ * fabind_loss_bwd: the gradient seeds d_coords / d_y_pred / d_y_by / d_logits / d_center (any may be NULL) for the upstream gradients
+ * g_loss (scalar, of out[6]) and g_terms[6] (of out[0..5]); either may be NULL (= 0).  fwd_out = the forward's out[8]. */
+int fabind_loss_blocks(long n_pair, long n_coord, long n_cls);
+int fabind_loss_fwd(const float* coords, const float* coords_true, long n_coord, const float* y_pred, const float* y_by,
+                    const float* dis_map, long n_pair, const float* logits, const void* cls, int cls_dt, const uint8_t* mask,
+                    long n_cls, const float* center, const float* center_true, long n_center, float w_coord, float w_pair,
+                    float w_distill, float w_cls, float w_center, float delta, float* part, unsigned* ticket, float* out,
+                    float* loss_out, float* terms_out, hipStream_t stream);
+int fabind_loss_bwd(const float* coords, const float* coords_true, long n_coord, const float* y_pred, const float* y_by,
+                    const float* dis_map, long n_pair, const float* logits, const void* cls, int cls_dt, long n_cls,
+                    const float* center, const float* center_true, long n_center, float w_coord, float w_pair, float w_distill,
+                    float w_cls, float w_center, float delta, const float* fwd_out, const float* g_loss, const float* g_terms,
+                    float* d_coords, float* d_y_pred, float* d_y_by, float* d_logits, float* d_center, hipStream_t stream);
 
 /* x_out[i] = mask[i] ? z[i] : x[i]   (X[mask] = Z[mask], models/att_model.py:236,245) */
 int fabind_select_rows(const float* x, const float* z, const uint8_t* mask, int n, int width, float* x_out,

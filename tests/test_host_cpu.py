@@ -50,7 +50,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()                                        # loads without a GPU (HIP initialises lazily)
     from fabind_amd import _lib as L
     import ctypes
-    assert lib.fabind_abi_version() == L.ABI_VERSION == 17
+    assert lib.fabind_abi_version() == L.ABI_VERSION == 18
     # the ctypes mirrors have the library's struct sizes (load() refuses a mismatch; checked again here explicitly)
     for which, mirror in enumerate((L.GemmArgs, L.EdgeBwdArgs, L.PairUpdateArgs, L.TnJob, L.AttnFusedBwdArgs)):
         assert lib.fabind_sizeof_args(which) == ctypes.sizeof(mirror)
@@ -197,7 +197,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fabind_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     protos = dict(re.findall(r"\bint\s+(fabind_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S))
-    special = {"fabind_abi_version", "fabind_sizeof_args", "fabind_gemm_set_config", "fabind_gemm_set_persistent", "fabind_gemm_tn_tile_n",
+    special = {"fabind_abi_version", "fabind_sizeof_args", "fabind_loss_blocks", "fabind_gemm_set_config", "fabind_gemm_set_persistent", "fabind_gemm_tn_tile_n",
                "fabind_gemm_x3_occupancy", "fabind_cross_attn_fused_occupancy"}
     protos.update(dict(re.findall(r"\blong\s+(fabind_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)))
     special.update({"fabind_cross_attn_bwd_scratch", "fabind_pair_bias_cat_parts", "fabind_pair_bias_finish_parts", "fabind_cross_attn_fused_bwd_scratch",
