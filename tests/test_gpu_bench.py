@@ -49,6 +49,17 @@ def test_bench_two_ranks_control_flow():
     assert abs(r["value"] - 6 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]      # whole-job aggregate over both ranks
 
 
+def test_bench_eight_ranks_control_flow():
+    """`--gpus 8` at a tiny shape, eight ranks on ONE device over gloo (the driver's 8-GPU run must not be the first
+    time this control flow executes): per-rank batches, GradReducer through the full model's 33 never-used tensors, barrier + MAX timing,
+    whole-job aggregate."""
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+              "--master-port", "29537", "bench.py", "--gpus", "8"] + SMALL,
+             env={"FABIND_BENCH_DEVICE": "0", "FABIND_BENCH_BACKEND": "gloo"})
+    assert r["n_gpus"] == 8 and r["config"]["global_batch"] == 24 and r["scaling"] == "weak"
+    assert abs(r["value"] - 24 * 1000.0 / r["ms_per_step"]) < 1e-6 * r["value"]
+
+
 def test_bench_self_launches_without_a_launcher():
     """`python bench.py --gpus 2` with no torch.distributed.run around it: the parent spawns the ranks before touching the GPU,
     relays rank 0's line and exit code (it used to die on an assert)."""
