@@ -678,9 +678,11 @@ def main():
             "value": value, "unit": "poses/s" if a.mode == "plus_sampling" else "complexes/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-            **({"dtype_note": "bf16 MFMA operands, fp32 accumulation and residual stream; 21 of the ~50 node-level GEMMs of a pass (input Linear, inter-edge "
-                              "v and coordinate projections, attention k|v and output projections) contract in split bf16 (3 MFMAs per product "
-                              "term) in the FORWARD pass: config.set_split_sites(2), ligand RMSD 3.1e-5 A from the fp32 reference at this shape"}
+            **({"dtype_note": "bf16 MFMA operands, fp32 accumulation and residual stream; the edge pipeline, the attention tiles and every backward "
+                              "contraction on bf16 operands; ~40 of the ~50 node-level GEMMs of a FORWARD pass (input Linear, inter-edge v and "
+                              "coordinate projections, attention k|v and output projections, both Linears of every node MLP / Transition with an "
+                              "fp32 hidden layer) contract in split bf16 (3 MFMAs per product term): config.set_split_sites(3).  Ligand RMSD from "
+                              "the fp32 oracle: 1.6e-5 A on this workload (config 3), 1.4e-5 / 7.8e-5 A for the stack at n_iter 1 / 8"}
                if a.precision == "bf16" else {}),
             "config": {"workload": ("synthetic batch=%d/GPU, %d protein / %d ligand nodes, FABind+ model (5-layer LN-MLP stack, hidden "
                                     "%d, n_iter=%d), %d poses per complex and step" % (a.batch, a.n_prot, a.n_lig, a.hidden,
@@ -812,10 +814,10 @@ def main():
         sub("train_mode", "fwdbwd", a.n_iter, train_mode=True, steps=5, warmup=2,
             note="the headline step with model.train(): dropout p=0.1 at the reference's six sites (per-edge: in the fused edge kernels; "
                  "ahead of the residuals and after the input Linear: in the GEMM epilogues, masks regenerated by the adjoint)")
-        sub("n_iter8", "fwdbwd", 8, note="production refinement loop: 8 stack passes, gradient on the last one.  GATE MISSED in this dtype: the "
-                                           "bf16 ligand-RMSD gap to the fp32 oracle is 1.9e-4 A at n_iter 8 (4.7e-5 at 2 and 3.1e-5 at 1 = the "
-                                           "headline's pass: inside the 1e-4 A gate; tests/test_gpu_headline.py) -- `n_iter8_gate` is the loop "
-                                           "in the mode that meets it", steps=5, warmup=1)
+        sub("n_iter8", "fwdbwd", 8, note="production refinement loop: 8 stack passes, gradient on the last one; bf16 with split-precision sites "
+                                           "level 3: 7.8e-5 A from the fp32 oracle at this shape -- the 1e-4 A gate is met and asserted "
+                                           "(tests/test_gpu_headline.py); round 5 (level 2: 1.9e-4 A, gate missed) ran this loop at 276 /s",
+            steps=5, warmup=1)
         sub("n_iter8_gate", "fwdbwd", 8, precision="bf16x3", steps=3, warmup=1,
             note="n_iter8 in the gate-meeting split-bf16 mode (2.8e-6 A at the headline shape, tests/test_gpu_headline.py)")
         sub("n_iter8_gate_bf16_edge", "fwdbwd", 8, precision="bf16x3", steps=3, warmup=1, x3_edge="bf16",
@@ -834,8 +836,12 @@ def main():
         else:
             sub("config3_gate", "model", a.n_iter, precision="bf16x3", steps=6, warmup=2, whole_pocket=True,
                 note="the headline step in the split-bf16 mode (fp32 storage, three bf16 MFMAs per product term)")
-        sub("model_fwdbwd_train_n_iter8", "model", 8, train_mode=True,
-            note="the same with model.train() (dropout, Gumbel noise) and n_iter=8: the reference's training configuration")
+        sub("model_fwdbwd_train_n_iter8", "model", 8, train_mode=True, precision="bf16x3",
+            note="full IaBNet with model.train() (dropout, Gumbel noise) and n_iter=8: the reference's training configuration, in the "
+                 "gate-meeting split-bf16 mode (production-size parity at n_iter 8: 2.3e-6 / 2.6e-6 A, tests/test_gpu_production.py)")
+        sub("model_fwdbwd_train_n_iter8_bf16", "model", 8, train_mode=True,
+            note="the same in bf16 (split sites level 3): production-size parity at n_iter 8 9.1e-5 A in stage 1 (gate met) but 1.3e-4 A in "
+                 "stage 2 (gate MISSED by 1.3x) -- reported, not the creditable number")
         n_it8 = 8
         sub("plus_train", "plus_train", a.n_iter, steps=6, warmup=2,
             note="one FABind+ training step (5-layer LN-MLP stack, train mode, 7-term loss with the permutation-invariant term; round 5: the edge "

@@ -4,7 +4,7 @@ import os
 _PRECISION = {"mode": "bf16", "x3_backward": "bf16" if (os.environ.get("FABIND_X3_WGRAD", "bf16") == "bf16" and
                                                           os.environ.get("FABIND_X3_PAIRBIAS_BWD", "bf16") == "bf16") else "exact"}
 MODES = ("fp32", "bf16", "bf16x3")
-_PRECISION["split_sites"] = int(os.environ.get("FABIND_SPLIT_SITES", "2"))
+_PRECISION["split_sites"] = int(os.environ.get("FABIND_SPLIT_SITES", "3"))
 
 
 def set_precision(mode):
@@ -36,14 +36,22 @@ def set_split_sites(level):
     projection cv = Wc v (5.7e-5) and the stack's input Linear (3.2e-5).
       0: none (rounds 1-4: every GEMM on bf16 operands): 1.00e-4 / 1.76e-4 / 6.26e-4 A at n_iter 1 / 2 / 8;
       1: those three sites (9 of the ~50 node-level GEMMs of a pass): 3.84e-5 / 6.71e-5 / 2.45e-4 A (q | k | v fully split);
-      2 (default): + the protein-query attention block's output projection and both blocks' k | v projections (21 GEMMs of a pass), and of
+      2 (round 5's default): + the protein-query attention block's output projection and both blocks' k | v projections (21 GEMMs of a pass), and of
          q | k | v only the V columns (the q and k columns do not carry the gap: tools/probes/precision_qkv_parts.py):
          3.07e-5 / 4.66e-5 / 1.90e-4 A -- the 1e-4 A gate met with margin for one and two passes; headline -2.4 %, forward only -5 %.
       (Measured on MI355X: profiles/r05_precision_sites.txt.  The remaining gap sits in the GEMMs whose activation operand is a HIDDEN
       layer -- node MLP, Transition --, which the bf16 mode stores as bf16: emulated with those in split precision too the loop reads
       5.8e-5 A at n_iter 8; 'bf16x3' is the mode that meets the gate there.)
+      3 (round 6, default): + both Linears of every node MLP (egnn.py:89-109) and of both Transitions (model_utils.py:162-175), with the
+         hidden layer kept in fp32 between them (no-grad passes: two split-precision launches instead of the one-kernel bf16 node chain;
+         under autograd the bf16 roundings of the hidden activation / its derivative are saved for the unchanged backward), the
+         ligand-query block's output projection, and the full model's embedding Linears around the two stacks (models/model.py `_lin`):
+         1.37e-5 / 2.73e-5 / 7.76e-5 A at n_iter 1 / 2 / 8 -- the 1e-4 A gate met in the production loop at the headline shape; config 3 read
+         literally 1.6e-5 A (level 2: 5.6e-5); full IaBNet at production size, n_iter 8: stage 1 9.1e-5 A (met), stage 2 -- the ligand moves
+         17 A -- 1.3e-4 A (missed; 'bf16x3' is the mode for that loop).  Cost, same box (profiles/r06_split_sites.txt): stack step -6.5 %,
+         config-3 step -4 %, n_iter 8 -12 % (the four MLP contractions of a layer cost three MFMAs per product term and fp32 operands).
     Backward passes are unchanged (bf16 operands; the gradients of a bf16-mode step are bf16-grade either way)."""
-    assert level in (0, 1, 2)
+    assert level in (0, 1, 2, 3)
     _PRECISION["split_sites"] = int(level)
 
 

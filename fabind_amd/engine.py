@@ -456,6 +456,17 @@ def _split_site_masters(model, P):
                 d["Wo_p32"] = f32(cam.p_attention_block.mha.linear_o.weight)
                 for tag, blk in (("p", cam.p_attention_block), ("c", cam.c_attention_block)):
                     d["Wkv_%s32" % tag] = torch.cat([blk.mha.linear_k.weight.detach(), blk.mha.linear_v.weight.detach()], 0).float().contiguous()
+            if split_sites() >= 3:       # + both Linears of the protein-side Transition (the hidden layer stays fp32 between them)
+                cam = m.cross_attn_module
+                d["Wt_p32"] = (f32(cam.p_transition.linear_1.weight), f32(cam.p_transition.linear_2.weight))
+                # ... and the ligand side's (2,600 rows at B = 64: free): its Transition and its attention block's output projection
+                d["Wt_c32"] = (f32(cam.c_transition.linear_1.weight), f32(cam.c_transition.linear_2.weight))
+                d["Wo_c32"] = f32(cam.c_attention_block.mha.linear_o.weight)
+        if split_sites() >= 3:           # + both Linears of every node MLP
+            for i in range(P["L"] + 1):
+                m = getattr(gnn, "gcl_%d" % i) if i < P["L"] else gnn.out_layer
+                d = P["gcl"][i] if i < P["L"] else P["out_layer"]
+                d["Wn_32"] = (f32(m.node_mlp[0].weight), f32(m.node_mlp[2].weight))
 
 
 def _edge_frags(P):
@@ -553,7 +564,10 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
         if not fast:
             # node MLP + residual as one autograd node (activation adjoint and residual gradient inside GEMM epilogues); train mode: the
             # dropout ahead of the residual (egnn.py:106) inside the second Linear's epilogue, its mask regenerated by the adjoint
-            return ops.mlp2(hin, p["Wn1"], p["bn1"], K.ACT_SILU, p["Wn2"], p["bn2"], residual=h, x2=agg, want16=True, p_drop=pdrop), x_new
+            return ops.mlp2(hin, p["Wn1"], p["bn1"], K.ACT_SILU, p["Wn2"], p["bn2"], residual=h, x2=agg, want16=True, p_drop=pdrop,
+                            W32=p.get("Wn_32")), x_new
+        if fast and pdrop == 0.0 and p.get("Wn_32") is not None:     # split-precision site (level 3): two launches, fp32 hidden layer
+            return ops.mlp2(h, p["Wn1"], p["bn1"], K.ACT_SILU, p["Wn2"], p["bn2"], residual=h, x2=agg, want16=True, W32=p["Wn_32"]), x_new
         if fast and pdrop == 0.0:
             hn = _node_chain(p, "_nc_node", p["Wn1"], p["bn1"], p["Wn2"], p["bn2"], K.ACT_SILU, 0, hin, ops._mm_in(agg), h, True)
             if hn is not None:
@@ -615,22 +629,29 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     og = ops.cross_attn_fused(qg, kv, pairbias, 2 * layer + 1, 1, lay, scale) if fused else \
         ops.cross_attn_fused_train(qg, kv, pairbias, 2 * layer + 1, 1, scale) if ftrain else \
         ops.cross_attn(qg, kv, bias_c, 0, 4, lay.desc_cf, lay.B, lay.max_C, lay.max_P, scale)
-    hc = ops.linear(c16(og), p["Wo_c"], p["bo_c"], residual=hc, p_drop=pdrop)
+    hc = ops.linear(og if p.get("Wo_c32") is not None else c16(og), p["Wo_c"], p["bo_c"], residual=hc, p_drop=pdrop, W32=p.get("Wo_c32"))
     if fast:
-        hp2 = _node_chain(p, "_nc_tp", p["Wt1_p"], p["bt1_p"], p["Wt2_p"], p["bt2_p"], K.ACT_RELU, 1, hp16, None, hp, True)
+        hp2 = None
+        if p.get("Wt_p32") is not None:                              # split-precision site (level 3)
+            hp2 = ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True, W32=p["Wt_p32"])
+        else:
+            hp2 = _node_chain(p, "_nc_tp", p["Wt1_p"], p["bt1_p"], p["Wt2_p"], p["bt2_p"], K.ACT_RELU, 1, hp16, None, hp, True)
         if hp2 is None:
             t = ops.linear(hp16, p["Wt1_p"], p["bt1_p"], act_epi=K.ACT_RELU, out_dtype=od)
             hp2 = ops.linear(t, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True)
         hp = hp2
         hc16 = c16(hc)
-        hc2 = _node_chain(p, "_nc_tc", p["Wt1_c"], p["bt1_c"], p["Wt2_c"], p["bt2_c"], K.ACT_RELU, 1, hc16, None, hc, False)
+        if p.get("Wt_c32") is not None:
+            hc2 = ops.mlp2(hc, p["Wt1_c"], p["bt1_c"], K.ACT_RELU, p["Wt2_c"], p["bt2_c"], residual=hc, W32=p["Wt_c32"])
+        else:
+            hc2 = _node_chain(p, "_nc_tc", p["Wt1_c"], p["bt1_c"], p["Wt2_c"], p["bt2_c"], K.ACT_RELU, 1, hc16, None, hc, False)
         if hc2 is None:
             t = ops.linear(hc16, p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU, out_dtype=od)
             hc2 = ops.linear(t, p["Wt2_c"], p["bt2_c"], residual=hc)
         hc = hc2
     else:   # Transition + residual (cross_att.py:48-49) as one autograd node each
-        hp = ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True)
-        hc = ops.mlp2(hc, p["Wt1_c"], p["bt1_c"], K.ACT_RELU, p["Wt2_c"], p["bt2_c"], residual=hc)
+        hp = ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True, W32=p.get("Wt_p32"))
+        hc = ops.mlp2(hc, p["Wt1_c"], p["bt1_c"], K.ACT_RELU, p["Wt2_c"], p["bt2_c"], residual=hc, W32=p.get("Wt_c32"))
     return ops.put_rows(hp, hc, lay.c_index64)
 
 

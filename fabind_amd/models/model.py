@@ -104,7 +104,11 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
 
     # ---- helpers ------------------------------------------------------------------------------
     def _lin(self, lin, x, **kw):
-        return ops.linear(x.float().contiguous(), lin.weight.to(ops.mm_dtype()), lin.bias, **kw)
+        # bf16 mode, config.set_split_sites(3): the embedding Linears around the two stacks contract in split precision on the fp32 master
+        # weight (node-level, K = 1280 / 512 / 128: cheap), like the stacks' own split-precision sites; the backward is the bf16 one
+        from ..config import split_sites
+        W32 = lin.weight.detach() if (split_sites() >= 3 and lin.weight.dtype == torch.float32 and lin.weight.shape[1] % 32 == 0) else None
+        return ops.linear(x.float().contiguous(), lin.weight.to(ops.mm_dtype()), lin.bias, W32=W32, **kw)
 
     @staticmethod
     def _assemble_index(segment, is_global, n_c, n_p):

@@ -435,7 +435,7 @@ class _MLP2(torch.autograd.Function):
         shared gradient buffer), so autograd adds nothing."""
 
     @staticmethod
-    def forward(ctx, x, x2, W1, b1, W2, b2, residual, act, holder=None, p_drop=0.0, seed=0):
+    def forward(ctx, x, x2, W1, b1, W2, b2, residual, act, holder=None, p_drop=0.0, seed=0, W32=None):
         # p_drop > 0 (round 5, train mode): dropout on the second Linear's output AHEAD of the residual (egnn.py:106) inside its fp32
         # epilogue; the adjoint regenerates the mask from (seed, row, col) in the one pass that casts dy
         assert act in (K.ACT_RELU, K.ACT_SILU)
@@ -443,14 +443,26 @@ class _MLP2(torch.autograd.Function):
         xin, x2in = _mm_in(x), _mm_in(x2)
         M, N1 = x.shape[0], W1.shape[0]
         ad = act_dtype()
-        t = torch.empty((M, N1), dtype=ad, device=x.device)
-        D = torch.empty((M, N1), dtype=ad, device=x.device) if act == K.ACT_SILU else None
-        K.gemm(xin, W1, bias=b1, A2=x2in, act_epi=act, out=t, out2=D)
         y16 = None
         if holder is not None:
             y16 = torch.empty((M, W2.shape[0]), dtype=torch.bfloat16, device=x.device)
             holder.append(y16)
-        y, _ = K.gemm(t, W2, bias=b2, residual=residual, out_dtype=torch.float32, out16=y16, p_drop=p_drop, seed=seed)
+        if W32 is not None and ctx.drop is None and _split_site_ok(x, W1, W32[0], x2, K.ACT_NONE, torch.float32, 0.0, act, None):
+            # round 6, config.set_split_sites(3): BOTH contractions of the forward in split precision -- the hidden layer stays fp32 between them
+            # (what the bf16 mode's remaining gap at n_iter 8 sat in: profiles/r05_precision_sites.txt).  Saved for the backward, which is
+            # unchanged: the bf16 roundings of x, of the hidden activation and of its stored derivative.
+            t32 = torch.empty((M, N1), dtype=torch.float32, device=x.device)
+            D32 = torch.empty((M, N1), dtype=torch.float32, device=x.device) if act == K.ACT_SILU else None
+            K.gemm(x, W32[0], bias=b1, A2=x2, act_epi=act, out=t32, out2=D32, force_x3=True)
+            y, _ = K.gemm(t32, W32[1], bias=b2, residual=residual, out_dtype=torch.float32, out16=y16, force_x3=True)
+            t = t32.to(ad)
+            D = D32.to(ad) if D32 is not None else None
+            del t32, D32
+        else:
+            t = torch.empty((M, N1), dtype=ad, device=x.device)
+            D = torch.empty((M, N1), dtype=ad, device=x.device) if act == K.ACT_SILU else None
+            K.gemm(xin, W1, bias=b1, A2=x2in, act_epi=act, out=t, out2=D)
+            y, _ = K.gemm(t, W2, bias=b2, residual=residual, out_dtype=torch.float32, out16=y16, p_drop=p_drop, seed=seed)
         ctx.act, ctx.has_x2, ctx.has_res = act, x2 is not None, residual is not None
         ctx.res_is_x = residual is x
         ctx.sink_x, ctx.sink_res = _sink_of(x), _sink_of(residual)
@@ -504,18 +516,25 @@ class _MLP2(torch.autograd.Function):
             dres = ctx.sink_res.deposit(dres)
         if ctx.has_x2 and ni[1]:
             dx2, _ = K.gemm(dpre, W1t[K1:], out_dtype=torch.float32 if ctx.x2_dtype == torch.float32 else ctx.x2_dtype)
-        return dx, dx2, dW1, db1, dW2, (db2 if ni[5] else None), dres, None, None, None, None
+        return dx, dx2, dW1, db1, dW2, (db2 if ni[5] else None), dres, None, None, None, None, None
 
 
-def mlp2(x, W1, b1, act, W2, b2, residual=None, x2=None, want16=False, p_drop=0.0):
+def mlp2(x, W1, b1, act, W2, b2, residual=None, x2=None, want16=False, p_drop=0.0, W32=None):
     """act([x | x2] W1^T + b1) W2^T + b2 (+ residual) -> fp32.  One autograd node under autograd (see _MLP2); without
-    autograd two GEMMs with fused epilogues.  p_drop: dropout on the second Linear's output ahead of the residual, in its epilogue."""
+    autograd two GEMMs with fused epilogues.  p_drop: dropout on the second Linear's output ahead of the residual, in its epilogue.
+    W32 = (W1_32, W2_32) (bf16 mode, config.set_split_sites(3)): the fp32 masters -- both forward contractions then run in split precision
+    on fp32 operands with an fp32 hidden layer; the backward is the bf16 one either way."""
+    if W32 is not None and (W32[0] is None or W32[1] is None or p_drop != 0.0 or _cfg.get_precision() != "bf16"):
+        W32 = None
     if _needs_grad(x, x2, W1, b1, W2, b2, residual):
         K.tn_hook(W1, b1, W2, b2)
         holder = [] if _want16(torch.float32, K.ACT_NONE, want16) else None
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
-        y = _MLP2.apply(x, x2, W1, b1, W2, b2, residual, act, holder, p_drop, seed)
+        y = _MLP2.apply(x, x2, W1, b1, W2, b2, residual, act, holder, p_drop, seed, W32)
         return _attach_b16(y, holder[0] if holder else None)
+    if W32 is not None:
+        t = linear(x, W1, b1, act_epi=act, x2=x2, out_dtype=torch.float32, W32=W32[0])
+        return linear(t, W2, b2, residual=residual, want16=want16, W32=W32[1])
     t = linear(x, W1, b1, act_epi=act, x2=x2, out_dtype=act_dtype())
     return linear(t, W2, b2, residual=residual, want16=want16, p_drop=p_drop)
 

@@ -75,7 +75,7 @@ def test_bench_self_launches_without_a_launcher():
 
 
 SUB_OBJECTS = ("pocket", "gate_mode", "gate_mode_exact_bwd", "fp32", "train_mode", "n_iter8", "n_iter8_gate", "fwd", "model_fwdbwd",
-               "model_gate", "gate_mode_bf16_edge", "n_iter8_gate_bf16_edge", "stack_fwdbwd", "config3_gate", "model_fwdbwd_train_n_iter8", "plus_train", "plus_train_gate", "plus_sampling")
+               "model_gate", "gate_mode_bf16_edge", "n_iter8_gate_bf16_edge", "stack_fwdbwd", "config3_gate", "model_fwdbwd_train_n_iter8", "model_fwdbwd_train_n_iter8_bf16", "plus_train", "plus_train_gate", "plus_sampling")
 
 
 def test_bench_line_carries_the_neighbouring_configurations():
@@ -87,7 +87,7 @@ def test_bench_line_carries_the_neighbouring_configurations():
         assert r[k]["value"] > 0 and r[k]["unit"] == ("poses/s" if k == "plus_sampling" else "complexes/s")
         assert r[k]["steps"] >= 1 and r[k]["ms_per_step"] > 0
     assert r["fp32"]["dtype"] == "fp32" and r["train_mode"]["train_mode"] is True and r["n_iter8"]["n_iter"] == 8
-    for k in ("gate_mode", "gate_mode_exact_bwd", "n_iter8_gate", "model_gate", "plus_train_gate"):
+    for k in ("gate_mode", "gate_mode_exact_bwd", "n_iter8_gate", "model_gate", "plus_train_gate", "model_fwdbwd_train_n_iter8"):
         assert r[k]["dtype"] == "bf16x3", k
     assert r["pocket"]["nodes"].startswith("100 protein") and r["pocket"]["pass"] == "fwdbwd"
     assert r["stack_fwdbwd"]["pass"] == "fwdbwd" and r["config3_gate"]["pass"] == "model" and r["config3_gate"]["dtype"] == "bf16x3"

@@ -114,8 +114,10 @@ def _iabnet_oracle(stage):
 
 
 TUPLE = ((2, "y_pred"), (3, "y_pred_by_coords"), (4, "pocket_cls_pred"), (8, "pred_pocket_center"), (9, "dis_map"))
-# bf16 gaps measured at the first run of this file (ligand RMSD in A / relative loss gap); asserted at 2x
-IAB_BF16_BOUND = {1: (1.2e-3, 1e-5), 2: (1.3e-3, 1e-5)}     # measured 5.9e-4 / 6.4e-4 A, loss 2.4e-6 / 6.9e-8
+# bf16 (split-precision sites level 3, round 6) at production size and n_iter 8: stage 1 is asserted AT THE GATE (1e-4 A; measured 9.1e-5);
+# stage 2 -- the ligand travels 17 A from the predicted pocket centre -- reads 1.3e-4 A: the gate is missed by 1.3x there, bounded at 2x the
+# measurement; 'bf16x3' (asserted at the gate below) is the mode bench.py quotes for that loop.  (Round 5, level 2: 5.9e-4 / 6.4e-4 A.)
+IAB_BF16_BOUND = {1: (1e-4, 1e-5), 2: (2.7e-4, 1e-5)}
 
 
 @pytest.mark.parametrize("stage", [1, 2])
@@ -199,8 +201,8 @@ def test_iabnet_production_size_matches_oracle(stage):
     assert g3e < 1e-4 and le3e <= 1e-5
 
 
-# bf16 gap of the whole-graph step (ligand RMSD in A, relative loss gap): asserted at 2x the first measurement (round 5)
-CONFIG3_BF16_BOUND = (1.9e-4, 1e-6)              # measured 9.43e-5 A (inside the gate) and 4.1e-7; whole-gradient l2 error 6.6e-4
+# bf16 gap of the whole-graph step = bench.py's HEADLINE (ligand RMSD in A, relative loss gap): the north-star gates themselves
+CONFIG3_BF16_BOUND = (1e-4, 1e-5)                # measured 1.6e-5 A and 2.0e-7 (round 5, split sites level 2: 9.4e-5 / 5.6e-5 A); whole-gradient l2 error 6.7e-4
 
 
 def test_config3_whole_graph_matches_oracle():
