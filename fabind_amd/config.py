@@ -78,21 +78,8 @@ def x3_edge_bf16():
     return _PRECISION["x3_edge"] == "bf16"
 
 
-_PRECISION["x3_attn"] = os.environ.get("FABIND_X3_ATTN", "fp32")
-
-
-def set_x3_attn(kind):
-    """'bf16x3' mode: the protein <-> ligand cross attention (cross_att.py:118-134) as
-      'fp32' (default): the fp32 VALU kernels on [pairs, 8] bias tensors from split-precision ragged contractions;
-      'bf16' (round 5, an option, NOT recommended): the fused MFMA kernels of the 'bf16' mode (pair bias recomputed on the matrix cores
-              from bf16 operands): +3.5 % on the gate-mode step; 1.3e-6 A at the headline shape, but the full IaBNet's stage 2 (the ligand
-              moves 17 A) reads 9.35e-5 A -- inside the gate without margin (profiles/r05_precision_sites.txt)."""
-    assert kind in ("bf16", "fp32")
-    _PRECISION["x3_attn"] = kind
-
-
-def x3_attn_bf16():
-    return _PRECISION["x3_attn"] == "bf16"
+# (round 6: `set_x3_attn("bf16")` -- the bf16 fused attention kernels inside the 'bf16x3' mode, +3.5 % -- is RETIRED: the full IaBNet's stage 2
+#  read 9.35e-5 A with it, inside the 1e-4 A gate without margin; a switch whose on-state cannot be asserted at the gate does not ship.)
 
 
 def set_x3_backward(kind):

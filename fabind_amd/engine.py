@@ -604,7 +604,6 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     # [pairs, 8] bias tensors
     # (when the bias tensors exist anyway -- a training call builds them for its differentiable pass -- the no-grad refinement
     #  iterations read them too: recomputing the contraction per iteration measured 8 % slower at n_iter = 8)
-    # ('bf16x3' with config.set_x3_attn("bf16"): the same fused kernels on the fp32 q | gate and k | v rows -- 1.3e-6 A of ligand RMSD)
     nograd = fast or (get_precision() == "bf16x3" and not ops.needs_grad(h, p["Wo_p"], getattr(pairbias, "a0b0", None)))
     fused = nograd and isinstance(pairbias, ops.PairBias) and pairbias.can_fuse() and not pairbias.has_tensors()
     # the differentiable pass in bf16 mode: the same recomputation in the forward AND the backward kernels (ops._CrossAttnFused)

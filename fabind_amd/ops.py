@@ -1839,7 +1839,7 @@ class PairBias:
 
     def can_fuse(self):
         # (the kernels assume wcomp[k] rows ordered lin0..3 | gate0..3 for 4 heads of 32 channels: engine._stack_requests builds them so)
-        return (K.CROSS_ATTN_FUSED and (_cfg.get_precision() == "bf16" or (_cfg.get_precision() == "bf16x3" and _cfg.x3_attn_bf16()))
+        return (K.CROSS_ATTN_FUSED and _cfg.get_precision() == "bf16"
                 and self.lay.max_C <= K.CROSS_ATTN_FUSED_MAX_C
                 and self.H in (64, 128, 256, 512) and tuple(self.wcomp.shape[1:]) == (8, self.H))
 
