@@ -148,6 +148,9 @@ SIGNATURES = {
     "fabind_lower_bound": [_vp, _i, _vp, _i, _vp, _vp],
     "fabind_pocket_center_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp],
     "fabind_pocket_center_bwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "fabind_pair_dist_fwd": [_vp, _i, _i, _vp, _vp, _f, _f, _f, _vp, _vp],
+    "fabind_pair_dist_bwd": [_vp, _i, _i, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp],
+    "fabind_block_hadamard_bwd": [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp],
     "fabind_loss_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "fabind_loss_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _l, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp,
                         _vp, _vp, _vp, _vp, _vp, _vp],
@@ -181,6 +184,8 @@ def load():
     lib.fabind_cross_attn_fused_bwd_parts.argtypes, lib.fabind_cross_attn_fused_bwd_parts.restype = [_i, _i], ctypes.c_int
     lib.fabind_pair_bias_finish_parts.argtypes, lib.fabind_pair_bias_finish_parts.restype = [_i], ctypes.c_int
     lib.fabind_loss_blocks.argtypes, lib.fabind_loss_blocks.restype = [_l, _l, _l], ctypes.c_int
+    for nm in ("fabind_pair_block_tile", "fabind_pair_block_chunk"):
+        getattr(lib, nm).argtypes, getattr(lib, nm).restype = [], ctypes.c_int
     for which, mirror in enumerate((GemmArgs, EdgeBwdArgs, PairUpdateArgs, TnJob, AttnFusedBwdArgs)):
         if lib.fabind_sizeof_args(which) != ctypes.sizeof(mirror):
             raise RuntimeError("fabind_amd: ctypes mirror %s is %d bytes, the library's struct is %d -- _lib.py and "

@@ -209,7 +209,214 @@ __global__ __launch_bounds__(256) void pocket_center_bwd_kernel(const float* __r
     dlogits[i] = dw * ds;
 }
 
+
+// ---- K19 glue: the distance-map head's pair operations on per-complex BLOCK descriptors ------------------------------------------------
+// The valid (pocket residue, ligand atom) pairs of complex b are the dense block [P_b x C_b], protein-major, at pairs pair_off[b] + i * C_b + j
+// (reference model.py:352-361: z[z_mask] of the padded [B, P, C] tensors).  desc[b] = {pair_off, P_b, C_b, p_row0, c_row0, tile0}: rows of the
+// pocket / ligand operands and the first of the complex's ceil(P_b / TP) protein tiles.  Rounds 1-5 described the same pairs by two index lists
+// and, for the adjoints, built a CSR per call (two stable sorts of 3.84 M keys at the headline shape) and walked it one wave per row.
+constexpr int PB_TP = 128;             // proteins per tile
+constexpr int PB_CH = 20;              // ligand atoms per register chunk of the Hadamard adjoint (20 x W fp32 in LDS: four work-groups per CU at W = 512)
+
+struct PairBlock { long pair_off; int P, C, p_row0, c_row0, tile0, pad; };
+
+__device__ __forceinline__ int pb_find(const PairBlock* __restrict__ desc, int B, int tile) {   // the complex that owns `tile` (tile0 is increasing)
+    int lo = 0, hi = B - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].tile0 <= tile) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// y[pair] = clamp(scale * |xp[p_row0 + i] - xc[c_row0 + j]|, lo, hi)                      (torch.cdist -> mask -> unnormalize -> clamp)
+__global__ __launch_bounds__(256) void pair_dist_fwd_kernel(const PairBlock* __restrict__ desc, int B, const float* __restrict__ xp,
+                                                            const float* __restrict__ xc, float scale, float lo, float hi, float* y) {
+    const int b = pb_find(desc, B, blockIdx.x);
+    const PairBlock d = desc[b];
+    const int i0 = (blockIdx.x - d.tile0) * PB_TP, i1 = min(d.P, i0 + PB_TP);
+    if (i0 >= d.P) return;
+    const long n = (long)(i1 - i0) * d.C;
+    for (long k = threadIdx.x; k < n; k += 256) {
+        const int i = i0 + (int)(k / d.C), j = (int)(k % d.C);
+        const float* a = xp + (size_t)(d.p_row0 + i) * 3;
+        const float* c = xc + (size_t)(d.c_row0 + j) * 3;
+        const float dx = a[0] - c[0], dy = a[1] - c[1], dz = a[2] - c[2];
+        const float v = scale * sqrtf(dx * dx + dy * dy + dz * dz);
+        y[d.pair_off + (long)i0 * d.C + k] = fminf(fmaxf(v, lo), hi);
+    }
+}
+
+// d xc[c_row0 + j] = sum_i dy[pair(i, j)] * scale * (xc_j - xp_i) / |xc_j - xp_i|  where the clamp is inactive (and the distance non-zero).
+// One work-group per (complex, one of 8 protein strides): thread (il, j) walks its proteins for ONE atom -- consecutive threads read consecutive
+// pairs --, the il lanes meet through LDS in lane order -> part[b][s][j][3]; pair_dist_bwd_reduce adds the 8 strides in order.
+__global__ __launch_bounds__(256) void pair_dist_bwd_kernel(const PairBlock* __restrict__ desc, const float* __restrict__ xp,
+                                                            const float* __restrict__ xc, const float* __restrict__ dy, float scale,
+                                                            float lo, float hi, int max_C, float* part) {
+    const int b = blockIdx.x, s = blockIdx.y;
+    const PairBlock d = desc[b];
+    __shared__ float sh[256][3];
+    for (int j0 = 0; j0 < d.C; j0 += 256) {
+        const int cw = min(256, d.C - j0);                 // atoms of this chunk; lanes = 256 / cw proteins in flight per atom
+        const int nl = 256 / cw, il = threadIdx.x / cw, j = j0 + threadIdx.x % cw;
+        float ax = 0.f, ay = 0.f, az = 0.f;
+        if (il < nl) {
+            const float* c = xc + (size_t)(d.c_row0 + j) * 3;
+            const float cx = c[0], cy = c[1], cz = c[2];
+            for (int i = s + 8 * il; i < d.P; i += 8 * nl) {
+                const float* a = xp + (size_t)(d.p_row0 + i) * 3;
+                const float dx = cx - a[0], dyv = cy - a[1], dz = cz - a[2];
+                const float r = sqrtf(dx * dx + dyv * dyv + dz * dz), v = scale * r;
+                const float g = (r > 0.f && v >= lo && v <= hi) ? dy[d.pair_off + (long)i * d.C + j] * scale / r : 0.f;
+                ax += g * dx; ay += g * dyv; az += g * dz;
+            }
+        }
+        sh[threadIdx.x][0] = ax; sh[threadIdx.x][1] = ay; sh[threadIdx.x][2] = az;
+        __syncthreads();
+        if (threadIdx.x < cw) {
+            float tx = 0.f, ty = 0.f, tz = 0.f;
+            for (int l = 0; l < nl; ++l) { tx += sh[l * cw + threadIdx.x][0]; ty += sh[l * cw + threadIdx.x][1]; tz += sh[l * cw + threadIdx.x][2]; }
+            float* o = part + (((size_t)b * 8 + s) * max_C + j0 + threadIdx.x) * 3;
+            o[0] = tx; o[1] = ty; o[2] = tz;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void pair_dist_bwd_reduce_kernel(const PairBlock* __restrict__ desc, int B, int max_C,
+                                                                   const float* __restrict__ part, float* dxc) {
+    const int b = blockIdx.x;
+    const PairBlock d = desc[b];
+    for (int k = threadIdx.x; k < d.C * 3; k += 256) {
+        float v = 0.f;
+        for (int s = 0; s < 8; ++s) v += part[(((size_t)b * 8 + s) * max_C) * 3 + k];
+        dxc[(size_t)d.c_row0 * 3 + k] = v;
+    }
+}
+
+// Adjoint of out[pair(i, j), :] = tp[p_row0 + i, :] * tc[c_row0 + j, :] (einsum 'bik,bjk->bijk' on the valid pairs, model.py:355):
+//   d tp[i] = sum_j dout[pair] * tc[j]  (complete inside the tile: written here),   d tc[j] = sum_i dout[pair] * tp[i]  (the tile's share -> part).
+// A thread owns TWO columns and, for the current chunk of <= 20 atoms, the 20 x 2 accumulators of d tc in registers; W / 2 threads span a row
+// (one 1 KiB row of dout per pair at W = 512, read once, non-temporal), 256 / (W / 2) proteins run side by side and meet through LDS in lane order.
+template <int W>
+__global__ __launch_bounds__(256) void block_hadamard_bwd_kernel(const PairBlock* __restrict__ desc, int B, const bf16_t* __restrict__ dout,
+                                                                 int ldo, const float* __restrict__ tp, int ldtp,
+                                                                 const float* __restrict__ tc, int ldtc, float* dtp, int lddp,
+                                                                 int nchunk_max, float* part) {
+    constexpr int CT = W / 2, NL = 256 / CT;              // column threads per row, protein lanes
+    const int b = pb_find(desc, B, blockIdx.x);
+    const PairBlock d = desc[b];
+    const int i0 = (blockIdx.x - d.tile0) * PB_TP, i1 = min(d.P, i0 + PB_TP);
+    if (i0 >= d.P) return;
+    const int ct = threadIdx.x % CT, il = threadIdx.x / CT, c2 = ct * 2;
+    extern __shared__ float sm[];                          // [PB_CH][W] tc rows of the chunk, then [NL][PB_CH][W] for the lane reduction (NL > 1)
+    float* s_tc = sm;
+    float* s_red = sm + PB_CH * W;
+    for (int j0 = 0, ch = 0; j0 < d.C; j0 += PB_CH, ++ch) {
+        const int cw = min(PB_CH, d.C - j0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < cw * W; k += 256) s_tc[k] = tc[(size_t)(d.c_row0 + j0 + k / W) * ldtc + k % W];
+        __syncthreads();
+        float acc[PB_CH][2];
+#pragma unroll
+        for (int j = 0; j < PB_CH; ++j) acc[j][0] = acc[j][1] = 0.f;
+        for (int i = i0 + il; i < i1; i += NL) {
+            const float2 p = *(const float2*)(tp + (size_t)(d.p_row0 + i) * ldtp + c2);
+            const bf16_t* row = dout + (size_t)(d.pair_off + (long)i * d.C + j0) * ldo + c2;
+            float ax = 0.f, ay = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < PB_CH; ++j) {
+                if (j < cw) {
+                    const uint32_t u = __builtin_nontemporal_load((const uint32_t*)(row + (size_t)j * ldo));
+                    const float dx = __uint_as_float(u << 16), dy = __uint_as_float(u & 0xffff0000u);
+                    const float2 c = *(const float2*)(s_tc + j * W + c2);
+                    ax += dx * c.x; ay += dy * c.y;
+                    acc[j][0] += dx * p.x; acc[j][1] += dy * p.y;
+                }
+            }
+            float* o = dtp + (size_t)(d.p_row0 + i) * lddp + c2;
+            if (ch == 0) { o[0] = ax; o[1] = ay; } else { o[0] += ax; o[1] += ay; }      // (this work-group owns the row)
+        }
+        float* po = part + ((size_t)blockIdx.x * nchunk_max + ch) * PB_CH * W;
+        if (NL == 1) {
+#pragma unroll
+            for (int j = 0; j < PB_CH; ++j)
+                if (j < cw) *(float2*)(po + j * W + c2) = make_float2(acc[j][0], acc[j][1]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < PB_CH; ++j)
+                if (j < cw) *(float2*)(s_red + ((size_t)il * PB_CH + j) * W + c2) = make_float2(acc[j][0], acc[j][1]);
+            __syncthreads();
+            for (int k = threadIdx.x; k < cw * W; k += 256) {
+                float v = 0.f;
+                for (int l = 0; l < NL; ++l) v += s_red[(size_t)l * PB_CH * W + k];
+                po[k] = v;
+            }
+        }
+    }
+}
+// d tc[c_row0 + j, :] = sum over the complex's tiles (in tile order) of part[tile][chunk of j][j % 20][:]
+__global__ __launch_bounds__(256) void block_hadamard_bwd_reduce_kernel(const PairBlock* __restrict__ desc, int B, const int* __restrict__ row_b,
+                                                                        int W, int nchunk_max, const float* __restrict__ part, float* dtc,
+                                                                        int lddc) {
+    const int r = blockIdx.x, b = row_b[r];                // r: ligand row (global index into the ligand operand), b its complex
+    const PairBlock d = desc[b];
+    const int j = r - d.c_row0, ch = j / PB_CH, jj = j % PB_CH;
+    const int nt = (d.P + PB_TP - 1) / PB_TP;
+    for (int c = threadIdx.x; c < W; c += 256) {
+        float v = 0.f;
+        for (int t = 0; t < nt; ++t) v += part[(((size_t)(d.tile0 + t) * nchunk_max + ch) * PB_CH + jj) * W + c];
+        dtc[(size_t)r * lddc + c] = v;
+    }
+}
+
 }  // namespace
+
+extern "C" int fabind_pair_block_tile(void) { return PB_TP; }
+extern "C" int fabind_pair_block_chunk(void) { return PB_CH; }
+
+extern "C" int fabind_pair_dist_fwd(const void* desc, int B, int n_tiles, const float* xp, const float* xc, float scale, float lo, float hi,
+                                    float* y, hipStream_t stream) {
+    if (B <= 0 || n_tiles <= 0) return 0;
+    hipLaunchKernelGGL(pair_dist_fwd_kernel, dim3(n_tiles), dim3(256), 0, stream, (const PairBlock*)desc, B, xp, xc, scale, lo, hi, y);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int fabind_pair_dist_bwd(const void* desc, int B, int max_C, const float* xp, const float* xc, const float* dy, float scale,
+                                    float lo, float hi, float* part, float* dxc, hipStream_t stream) {
+    if (B <= 0) return 0;
+    FB_REQUIRE(part && dxc && max_C > 0, "fabind_pair_dist_bwd: scratch [B][8][max_C][3] and the output are required");
+    hipLaunchKernelGGL(pair_dist_bwd_kernel, dim3(B, 8), dim3(256), 0, stream, (const PairBlock*)desc, xp, xc, dy, scale, lo, hi, max_C, part);
+    FB_CHECK_LAUNCH();
+    hipLaunchKernelGGL(pair_dist_bwd_reduce_kernel, dim3(B), dim3(256), 0, stream, (const PairBlock*)desc, B, max_C, part, dxc);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int fabind_block_hadamard_bwd(const void* desc, int B, int n_tiles, const void* dout, int ldo, const float* tp, int ldtp,
+                                         const float* tc, int ldtc, int W, const int* row_b, int n_crows, int nchunk_max, float* part,
+                                         float* dtp, int lddp, float* dtc, int lddc, hipStream_t stream) {
+    FB_REQUIRE(W == 64 || W == 128 || W == 256 || W == 512, "fabind_block_hadamard_bwd: W in {64, 128, 256, 512}");
+    FB_REQUIRE(ldo % 2 == 0 && ldtp % 2 == 0 && lddp % 2 == 0 && ((((uintptr_t)dout) & 3) == 0) && ((((uintptr_t)tp | (uintptr_t)dtp | (uintptr_t)part) & 7) == 0),
+               "fabind_block_hadamard_bwd: alignment (bf16 pairs / float2)");
+    if (B <= 0 || n_tiles <= 0) return 0;
+#define BH_LAUNCH(WW)                                                                                                              \
+    do {                                                                                                                           \
+        constexpr int NL_ = 256 / (WW / 2);                                                                                        \
+        const size_t lds = (size_t)PB_CH * WW * 4 * (NL_ > 1 ? 1 + NL_ : 1);                                                      \
+        static bool set_ = false;                                                                                                  \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)block_hadamard_bwd_kernel<WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        hipLaunchKernelGGL((block_hadamard_bwd_kernel<WW>), dim3(n_tiles), dim3(256), lds, stream, (const PairBlock*)desc, B,      \
+                           (const bf16_t*)dout, ldo, tp, ldtp, tc, ldtc, dtp, lddp, nchunk_max, part);                             \
+    } while (0)
+    if (W == 512) BH_LAUNCH(512); else if (W == 256) BH_LAUNCH(256); else if (W == 128) BH_LAUNCH(128); else BH_LAUNCH(64);
+#undef BH_LAUNCH
+    FB_CHECK_LAUNCH();
+    if (n_crows > 0) {
+        hipLaunchKernelGGL(block_hadamard_bwd_reduce_kernel, dim3(n_crows), dim3(256), 0, stream, (const PairBlock*)desc, B, row_b, W,
+                           nchunk_max, part, dtc, lddc);
+        FB_CHECK_LAUNCH();
+    }
+    return 0;
+}
 
 extern "C" int fabind_loss_blocks(long n_pair, long n_coord, long n_cls) {
     const long n = n_pair > n_coord ? (n_pair > n_cls ? n_pair : n_cls) : (n_coord > n_cls ? n_coord : n_cls);

@@ -201,6 +201,8 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
             elif isinstance(v, (tuple, list)):
                 for u in v:
                     rec(u)
+                if hasattr(v, 'blocks'):
+                    rec(v.blocks.tensors())
         rec({k: v for k, v in plan.items() if k != 'event'})
         plan['_adopted'] = True
 
@@ -294,7 +296,8 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
             c2c = (el.x + ix['off'][el.batch][:, None]).t().contiguous().long()
             las = (ll.x + ix['off'][ll.batch][:, None]).t().contiguous().long()
             # distance map against the INITIAL ligand pose (model.py:286-287), protein-major per complex
-            pi, ci = self._pair_lists(ix['pocket_batch'], cb, ix['kcnt'], ix['ncnt'])
+            pairs = self._pair_lists(ix['pocket_batch'], cb, ix['kcnt'], ix['ncnt'])
+            pi, ci = pairs
             dis_map = (pocket_xyz.float()[pi] - li[ci]).norm(dim=-1).clamp(max=10.0)
         # the reference overwrites the batch's `complex` stores (model.py:291-300)
         cx = data['complex']
@@ -303,7 +306,7 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         data['complex', 'LAS', 'complex'].edge_index = las
         return dict(H=H, X=X, XL=XL, segment=ix['segment'], mask=ix['mask'], is_global=ix['is_global'], batch=ix['batch'],
                     c2c=c2c, LAS=las, pocket_xyz=pocket_xyz, pocket_batch=ix['pocket_batch'], dis_map=dis_map,
-                    less5=ix['less5'], pairs=(pi, ci))
+                    less5=ix['less5'], pairs=pairs)
 
     @staticmethod
     def _pair_lists(pocket_batch, cb, kcnt, ncnt):
@@ -314,7 +317,9 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         start = _offsets(reps)
         j = torch.arange(pi.shape[0], device=dev) - start[pi]
         ci = _offsets(ncnt)[pocket_batch][pi] + j
-        return pi, ci
+        # the same pairs as dense per-complex blocks (ops.PairBlocks): the distance head's adjoints walk them without index glue
+        kn = torch.stack([kcnt, ncnt]).tolist()
+        return _Pairs(pi, ci, ops.PairBlocks(kn[0], kn[1], dev))
 
     def _complex_and_heads(self, data, g, plan=None):
         scale = self.coordinate_scale
@@ -344,13 +349,18 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         pi, ci = pairs
         ln = ops.layernorm(ops.take_unique_rows(Ho, torch.cat([pidx, cidx])), self.layernorm.weight, self.layernorm.bias, self.layernorm.eps)
         npk = pidx.shape[0]
-        hd = ops.rows_hadamard(ln, pi, npk + ci, a_sorted=True)                                       # LN(p_i) * LN(c_j)
+        blocks = getattr(pairs, 'blocks', None)
+        hd = ops.rows_hadamard(ln, pi, npk + ci, a_sorted=True, blocks=blocks, n_a=npk)               # LN(p_i) * LN(c_j)
         wd = ops.mm_dtype()
         part = ops.linear_rowdot(hd, self.distmap_mlp[0].weight.to(wd), self.distmap_mlp[0].bias,
                                  self.distmap_mlp[2].weight[0].contiguous(), act_epi=K.ACT_RELU)
         y_pred = (part.sum(1) + self.distmap_mlp[2].bias).sigmoid() * 10
         xp = self.normalize_coord(g['pocket_xyz']).float()
-        y_by = self.unnormalize_coord((xp[pi] - ops.take_rows_few(coords_n, ci)).norm(dim=-1)).clamp(0, 10)
+        if blocks is not None and coords_n.is_cuda:
+            # cdist -> valid pairs -> unnormalize -> clamp as ONE kernel each way over the pair blocks (ops.pair_dist, csrc/heads.hip)
+            y_by = ops.pair_dist(xp, coords_n, blocks, scale=self.coordinate_scale, lo=0.0, hi=10.0)
+        else:
+            y_by = self.unnormalize_coord((xp[pi] - ops.take_rows_few(coords_n, ci)).norm(dim=-1)).clamp(0, 10)
         return y_pred, y_by
 
     # ---- reference API ------------------------------------------------------------------------
@@ -416,6 +426,15 @@ class IaBNet_mean_and_pocket_prediction_cls_coords_dependent(nn.Module):
         data['complex'].batch = g['batch']
         _, _, _, coords_n = self._complex_and_heads(data, g)
         return self.unnormalize_coord(coords_n), data['compound'].batch
+
+
+class _Pairs(tuple):
+    """(pi, ci) -- what `_pair_lists` always returned -- with the block descriptors of the same pairs riding along."""
+
+    def __new__(cls, pi, ci, blocks):
+        t = super().__new__(cls, (pi, ci))
+        t.blocks = blocks
+        return t
 
 
 def get_model(args, logger, device=None):

@@ -7,6 +7,7 @@ import ctypes
 
 import os
 
+import numpy as np
 import torch
 
 from . import config as _cfg
@@ -1467,9 +1468,9 @@ class _RowsHadamard(torch.autograd.Function):
     """out[e,:] = t[ia[e],:] * t[ib[e],:]"""
 
     @staticmethod
-    def forward(ctx, t, ia, ib, a_sorted=False):
+    def forward(ctx, t, ia, ib, a_sorted=False, blocks=None, n_a=0):
         ctx.save_for_backward(t, ia, ib)
-        ctx.a_sorted = a_sorted
+        ctx.a_sorted, ctx.blocks, ctx.n_a = a_sorted, blocks, n_a
         dummy = t[:, :0]
         return K.pair_hadamard(t, t, dummy, dummy, ia, ib, act_dtype())
 
@@ -1478,6 +1479,17 @@ class _RowsHadamard(torch.autograd.Function):
         t, ia, ib = ctx.saved_tensors
         dout = dout.contiguous()
         W = t.shape[1]
+        bl = ctx.blocks
+        if bl is not None and dout.dtype == torch.bfloat16 and t.dtype == torch.float32 and W in (64, 128, 256, 512) and t.stride(0) % 2 == 0 \
+                and ctx.n_a == bl.n_prows and t.shape[0] == bl.n_prows + bl.n_crows and dout.shape[0] == bl.n_pairs:
+            # round 6: the pairs are dense per-complex blocks -> one pass over dout (read once), d t rows written once each, no per-call CSR
+            dt_ = torch.empty_like(t)
+            part = torch.empty((bl.n_tiles, bl.nchunk_max, bl.chunk, W), dtype=torch.float32, device=t.device)
+            tc, dtc = t[ctx.n_a:], dt_[ctx.n_a:]
+            check(load().fabind_block_hadamard_bwd(bl.desc_ptr, bl.B, bl.n_tiles, ptr(dout), dout.stride(0), ptr(t), t.stride(0), ptr(tc),
+                                                   t.stride(0), W, bl.row_b_ptr, bl.n_crows, bl.nchunk_max, ptr(part), ptr(dt_),
+                                                   dt_.stride(0), ptr(dtc), dt_.stride(0), stream()), "fabind_block_hadamard_bwd")
+            return dt_, None, None, None, None, None
         if ROWS_HADAMARD_WALK and t.dtype == torch.float32 and W % 4 == 0 and W <= 1024 and t.stride(0) % 4 == 0 and dout.stride(0) % 4 == 0:
             # every row of t gets its pairs as a CSR: as first factor (the pairs sorted by ia) and as second factor (sorted by ib);
             # one wave per row sums them -- no float atomics, fixed order (index glue: two stable sorts and two histograms per call)
@@ -1487,12 +1499,12 @@ class _RowsHadamard(torch.autograd.Function):
             check(load().fabind_rows_hadamard_bwd(ptr(dout), dt_code(dout.dtype), dout.stride(0), ptr(t), t.stride(0), W,
                                                   ptr(rowptr), ptr(pair_idx), ptr(partner), n, ptr(dt_), dt_.stride(0),
                                                   stream()), "fabind_rows_hadamard_bwd")
-            return dt_, None, None, None
+            return dt_, None, None, None, None, None
         dt_ = torch.zeros_like(t)
         check(load().fabind_pair_hadamard_bwd(ptr(dout), dt_code(dout.dtype), dout.stride(0), ptr(t), ptr(t), t.stride(0), W,
                                               None, None, 0, 0, ptr(ia), ptr(ib), ia.shape[0], ptr(dt_), ptr(dt_),
                                               dt_.stride(0), None, None, 0, stream()), "fabind_pair_hadamard_bwd")
-        return dt_, None, None, None
+        return dt_, None, None, None, None, None
 
 
 def _rows_hadamard_csr(ia, ib, n, a_sorted=False):
@@ -1525,12 +1537,13 @@ def _rows_hadamard_csr(ia, ib, n, a_sorted=False):
 ROWS_HADAMARD_WALK = os.environ.get("FABIND_ROWS_HADAMARD_WALK", "1") == "1"      # adjoint of rows_hadamard as a row walk (0: float atomics)
 
 
-def rows_hadamard(t, idx_a, idx_b, a_sorted=False):
+def rows_hadamard(t, idx_a, idx_b, a_sorted=False, blocks=None, n_a=0):
     """einsum('bik,bjk->bijk') restricted to the valid pairs (reference model.py:355).  a_sorted: idx_a is non-decreasing (a
-    protein-major pair list) -- the adjoint's index glue skips one sort."""
+    protein-major pair list) -- the adjoint's index glue skips one sort.  blocks (PairBlocks) + n_a: the same pairs as dense per-complex
+    blocks over t = [n_a pocket rows | ligand rows]: the adjoint then needs no index glue at all (csrc/heads.hip)."""
     ia, ib = idx_a.to(torch.int32).contiguous(), idx_b.to(torch.int32).contiguous()
     if _needs_grad(t):
-        return _RowsHadamard.apply(t, ia, ib, a_sorted)
+        return _RowsHadamard.apply(t, ia, ib, a_sorted, blocks, n_a)
     dummy = t[:, :0]
     return K.pair_hadamard(t, t, dummy, dummy, ia, ib, act_dtype())
 
@@ -2117,3 +2130,77 @@ def six_term_loss(coords, y_pred, y_by, logits, center, coords_true, dis_map, po
                                      f(center_true), w)
     tt = terms.unbind(0)
     return loss, {n: tt[i] for i, n in enumerate(LOSS_TERM_NAMES)}
+
+
+# ------------------------------------------------------------------------------------------------
+# Distance-map head on per-complex pair blocks (round 6; csrc/heads.hip): the valid (pocket residue, ligand atom) pairs of a complex are a
+# dense P_b x C_b block, protein-major -- the adjoints no longer sort 3.84 M pair keys into a CSR per step
+# ------------------------------------------------------------------------------------------------
+_PAIRBLOCK = np.dtype([("pair_off", np.int64), ("P", np.int32), ("C", np.int32), ("p_row0", np.int32), ("c_row0", np.int32),
+                       ("tile0", np.int32), ("pad", np.int32)])          # = struct PairBlock of csrc/heads.hip
+
+
+class PairBlocks:
+    """Block descriptors of the pair lists `IaBNet._pair_lists` builds: kcnt[b] pocket residues x ncnt[b] ligand atoms per complex (host
+    lists).  Pocket rows and ligand rows are complex-contiguous in their own arrays."""
+
+    def __init__(self, kcnt, ncnt, dev):
+        from .param_pack import _upload
+        kc, nc = np.asarray(kcnt, dtype=np.int64), np.asarray(ncnt, dtype=np.int64)
+        B = kc.shape[0]
+        tp, ch = load().fabind_pair_block_tile(), load().fabind_pair_block_chunk()
+        tiles = (kc + tp - 1) // tp
+        d = np.zeros(B, dtype=_PAIRBLOCK)
+        d["pair_off"] = np.cumsum(kc * nc) - kc * nc
+        d["P"], d["C"] = kc, nc
+        d["p_row0"], d["c_row0"] = np.cumsum(kc) - kc, np.cumsum(nc) - nc
+        d["tile0"] = np.cumsum(tiles) - tiles
+        self.B, self.n_tiles, self.n_pairs = int(B), int(tiles.sum()), int((kc * nc).sum())
+        self.max_C, self.n_prows, self.n_crows = int(nc.max()) if B else 0, int(kc.sum()), int(nc.sum())
+        self.nchunk_max = (self.max_C + ch - 1) // ch
+        self.chunk = ch
+        row_b = np.repeat(np.arange(B, dtype=np.int32), nc)
+        raw = np.concatenate([d.view(np.uint8), row_b.view(np.uint8)]) if B else np.zeros(0, dtype=np.uint8)
+        self.buf = _upload(raw, dev) if raw.shape[0] else None            # one host-to-device copy: descriptors, then row_b
+        self.desc_bytes = d.view(np.uint8).shape[0]
+
+    def tensors(self):
+        return [self.buf] if self.buf is not None else []
+
+    @property
+    def desc_ptr(self):
+        return self.buf.data_ptr()
+
+    @property
+    def row_b_ptr(self):
+        return self.buf.data_ptr() + self.desc_bytes
+
+
+class _PairDist(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xp, xc, blocks, scale, lo, hi):
+        y = torch.empty(blocks.n_pairs, dtype=torch.float32, device=xc.device)
+        check(load().fabind_pair_dist_fwd(blocks.desc_ptr, blocks.B, blocks.n_tiles, ptr(xp), ptr(xc), scale, lo, hi, ptr(y), stream()),
+              "fabind_pair_dist_fwd")
+        ctx.save_for_backward(xp, xc)
+        ctx.blocks, ctx.k = blocks, (scale, lo, hi)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, xc = ctx.saved_tensors
+        bl = ctx.blocks
+        part = torch.empty((bl.B, 8, bl.max_C, 3), dtype=torch.float32, device=xc.device)
+        dxc = torch.empty_like(xc)
+        check(load().fabind_pair_dist_bwd(bl.desc_ptr, bl.B, bl.max_C, ptr(xp), ptr(xc), ptr(dy.contiguous().float()), ctx.k[0], ctx.k[1],
+                                          ctx.k[2], ptr(part), ptr(dxc), stream()), "fabind_pair_dist_bwd")
+        return None, dxc, None, None, None, None
+
+
+def pair_dist(xp, xc, blocks, scale=1.0, lo=0.0, hi=10.0):
+    """clamp(scale * |xp_i - xc_j|, lo, hi) over the valid pairs of every complex (reference model.py:349,363-365: cdist -> [z_mask] ->
+    unnormalize -> clamp).  xp [sum P, 3] (data: no gradient), xc [sum C, 3]; the adjoint to xc is a fixed-order sum."""
+    assert not xp.requires_grad, "pair_dist: the pocket coordinates are data"
+    xp, xc = xp.float().contiguous(), xc.float().contiguous()
+    assert xp.shape[0] == blocks.n_prows and xc.shape[0] == blocks.n_crows
+    return _PairDist.apply(xp, xc, blocks, float(scale), float(lo), float(hi))

@@ -64,7 +64,8 @@ const char* fabind_last_error(void);
  *     fabind_mul_dropmask_colsum, fabind_drop_mix (+ _bwd) added, fabind_gemm's fp32 (+ residual) epilogue takes p_drop (train-mode dropout
  *     ahead of a residual).
  * 18 = round 6: fabind_loss_fwd / fabind_loss_bwd / fabind_loss_blocks (the six-term training loss and its gradient seeds, one launch each way),
- *     fabind_pocket_center_fwd / _bwd (the Gumbel-softmax pocket centre, one launch each way); fabind_gemm_tn_set_exp ignores bit 2.
+ *     fabind_pocket_center_fwd / _bwd (the Gumbel-softmax pocket centre, one launch each way); fabind_gemm_tn_set_exp ignores bit 2;
+ *     fabind_pair_dist_fwd / _bwd, fabind_block_hadamard_bwd (+ fabind_pair_block_tile / _chunk): the distance head's pair operations on block descriptors.
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 18
 int fabind_abi_version(void);
@@ -533,6 +534,27 @@ int fabind_loss_bwd(const float* coords, const float* coords_true, long n_coord,
                     const float* center, const float* center_true, long n_center, float w_coord, float w_pair, float w_distill,
                     float w_cls, float w_center, float delta, const float* fwd_out, const float* g_loss, const float* g_terms,
                     float* d_coords, float* d_y_pred, float* d_y_by, float* d_logits, float* d_center, hipStream_t stream);
+
+/* Pair operations of the distance-map head (models/model.py:344-365; SURVEY K19 glue) on per-complex BLOCK descriptors: the valid
+ * (pocket residue i, ligand atom j) pairs of complex b are the dense block P_b x C_b, protein-major, at pair index pair_off + i * C_b + j
+ * (z[z_mask] of the reference's padded [B, P, C] tensors).  desc: device array of B records
+ *   struct { int64 pair_off; int32 P, C, p_row0, c_row0, tile0, pad; }      (32 bytes; tile0 = first of the complex's ceil(P / TP) tiles,
+ *   TP = fabind_pair_block_tile()), n_tiles = sum_b ceil(P_b / TP).
+ * fabind_pair_dist_fwd: y[pair] = clamp(scale * |xp[p_row0 + i] - xc[c_row0 + j]|, lo, hi)   (torch.cdist -> [z_mask] -> unnormalize -> clamp,
+ *   model.py:349,363-365).  _bwd: dxc[c_row0 + j] (rows of every complex's atoms; fixed-order sums); part: fp32 scratch [B][8][max_C][3].
+ * fabind_block_hadamard_bwd: adjoint of out[pair, :] = tp[p_row0 + i, :] * tc[c_row0 + j, :] (einsum 'bik,bjk->bijk' on the valid pairs,
+ *   model.py:355) for a bf16 dout [pairs, W] (W in {64, 128, 256, 512}): dtp / dtc rows written once each, no atomics;
+ *   row_b[n_crows]: complex of every row of tc; nchunk_max = ceil(max_b C_b / fabind_pair_block_chunk());
+ *   part: fp32 scratch [n_tiles][nchunk_max][chunk][W]. */
+int fabind_pair_block_tile(void);
+int fabind_pair_block_chunk(void);
+int fabind_pair_dist_fwd(const void* desc, int B, int n_tiles, const float* xp, const float* xc, float scale, float lo, float hi,
+                         float* y, hipStream_t stream);
+int fabind_pair_dist_bwd(const void* desc, int B, int max_C, const float* xp, const float* xc, const float* dy, float scale, float lo,
+                         float hi, float* part, float* dxc, hipStream_t stream);
+int fabind_block_hadamard_bwd(const void* desc, int B, int n_tiles, const void* dout, int ldo, const float* tp, int ldtp,
+                              const float* tc, int ldtc, int W, const int* row_b, int n_crows, int nchunk_max, float* part,
+                              float* dtp, int lddp, float* dtc, int lddc, hipStream_t stream);
 
 /* x_out[i] = mask[i] ? z[i] : x[i]   (X[mask] = Z[mask], models/att_model.py:236,245) */
 int fabind_select_rows(const float* x, const float* z, const uint8_t* mask, int n, int width, float* x_out,

@@ -143,3 +143,73 @@ def test_six_term_loss_is_bit_repeatable_and_rearms_its_ticket():
         b, tb = ops.six_term_loss(*t, W)
         assert torch.equal(a, b) and all(torch.equal(ta[k], tb[k]) for k in ta)
     assert int(ops._LOSS_TICKET[t[0].device].item()) == 0
+
+
+# ---- the distance head's pair operations on per-complex blocks (csrc/heads.hip) -------------------------------------------------------
+def _blocks(kcnt, ncnt):
+    from fabind_amd import ops
+    bl = ops.PairBlocks(kcnt, ncnt, torch.device(DEV))
+    pi, ci = [], []
+    p0 = c0 = 0
+    for P, C in zip(kcnt, ncnt):
+        for i in range(P):
+            pi += [p0 + i] * C
+            ci += list(range(c0, c0 + C))
+        p0, c0 = p0 + P, c0 + C
+    return bl, torch.tensor(pi, device=DEV), torch.tensor(ci, device=DEV)
+
+
+@pytest.mark.parametrize("kcnt,ncnt", [([5], [3]), ([130, 7, 260], [9, 41, 2]), ([300, 129], [300, 5]), ([1500] * 3, [40] * 3)])
+def test_pair_dist_matches_cdist_clamp_and_its_autograd(kcnt, ncnt):
+    """y_pred_by_coords of reference model.py:349,363-365: clamp(5 * |xp_i / 5 - x_j|, 0, 10) over the valid pairs, and its gradient to the
+    ligand coordinates (clamp active on both sides, a zero distance)."""
+    from fabind_amd import ops
+    bl, pi, ci = _blocks(kcnt, ncnt)
+    g = torch.Generator().manual_seed(sum(kcnt))
+    xp = (torch.randn(sum(kcnt), 3, generator=g) * 1.2).to(DEV)                    # normalised coordinates: distances 0 ... ~4 (x 5 A: clamp at 10 bites)
+    xc = (torch.randn(sum(ncnt), 3, generator=g) * 0.6).to(DEV)
+    xc[0] = xp[0]                                                                  # a zero distance: gradient 0, not NaN
+    a, b = xc.clone().requires_grad_(True), xc.clone().requires_grad_(True)
+    ref = (5.0 * (xp[pi] - a[ci]).norm(dim=-1)).clamp(0, 10)
+    got = ops.pair_dist(xp, b, bl, scale=5.0, lo=0.0, hi=10.0)
+    assert got.shape == ref.shape and float((got - ref).abs().max()) < 2e-5
+    assert float((ref >= 10).float().mean()) > 0.01                                # the clamp is exercised
+    dy = torch.randn(ref.shape, generator=g).to(DEV)
+    (ref * dy).sum().backward()
+    (got * dy).sum().backward()
+    assert bool(torch.isfinite(b.grad).all())
+    err = float((a.grad.nan_to_num() - b.grad).abs().max()) / float(a.grad.nan_to_num().abs().max())
+    assert err < 2e-5, err
+    got2 = ops.pair_dist(xp, b.detach().requires_grad_(True), bl, scale=5.0)
+    assert torch.equal(got2, got)
+
+
+@pytest.mark.parametrize("W", [64, 128, 512])
+@pytest.mark.parametrize("kcnt,ncnt", [([5], [3]), ([130, 7, 260], [9, 41, 2]), ([200, 129], [45, 5])])
+def test_rows_hadamard_block_adjoint_matches_autograd(W, kcnt, ncnt):
+    """einsum('bik,bjk->bijk')[z_mask] (reference model.py:355) under autograd: the block-descriptor adjoint against torch's, and against
+    the CSR-walk adjoint of rounds 4-5 (same dout, bf16)."""
+    from fabind_amd import engine, ops
+    engine.set_precision("bf16")
+    try:
+        bl, pi, ci = _blocks(kcnt, ncnt)
+        npk = sum(kcnt)
+        g = torch.Generator().manual_seed(W + npk)
+        t0 = torch.randn(npk + sum(ncnt), W, generator=g).to(DEV)
+        dout = torch.randn(bl.n_pairs, W, generator=g).to(DEV).to(torch.bfloat16)
+        t1 = t0.clone().requires_grad_(True)
+        hd = ops.rows_hadamard(t1, pi, npk + ci, a_sorted=True, blocks=bl, n_a=npk)
+        assert hd.dtype == torch.bfloat16
+        hd.backward(dout)
+        t2 = t0.clone().requires_grad_(True)
+        (t2[pi] * t2[npk + ci]).backward(dout.float())
+        err = float((t1.grad - t2.grad).abs().max()) / float(t2.grad.abs().max())
+        assert err < 1e-5, err
+        t3 = t0.clone().requires_grad_(True)
+        ops.rows_hadamard(t3, pi, npk + ci, a_sorted=True).backward(dout)            # the CSR walk
+        assert float((t1.grad - t3.grad).abs().max()) / float(t3.grad.abs().max()) < 1e-5
+        t4 = t0.clone().requires_grad_(True)
+        ops.rows_hadamard(t4, pi, npk + ci, a_sorted=True, blocks=bl, n_a=npk).backward(dout)
+        assert torch.equal(t4.grad, t1.grad)                                         # bit-repeatable
+    finally:
+        engine.set_precision("fp32")

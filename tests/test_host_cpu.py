@@ -197,7 +197,7 @@ def test_ctypes_signatures_match_the_header_prototypes():
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "fabind_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     protos = dict(re.findall(r"\bint\s+(fabind_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S))
-    special = {"fabind_abi_version", "fabind_sizeof_args", "fabind_loss_blocks", "fabind_gemm_set_config", "fabind_gemm_set_persistent", "fabind_gemm_tn_tile_n",
+    special = {"fabind_abi_version", "fabind_sizeof_args", "fabind_loss_blocks", "fabind_pair_block_tile", "fabind_pair_block_chunk", "fabind_gemm_set_config", "fabind_gemm_set_persistent", "fabind_gemm_tn_tile_n",
                "fabind_gemm_x3_occupancy", "fabind_cross_attn_fused_occupancy"}
     protos.update(dict(re.findall(r"\blong\s+(fabind_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)))
     special.update({"fabind_cross_attn_bwd_scratch", "fabind_pair_bias_cat_parts", "fabind_pair_bias_finish_parts", "fabind_cross_attn_fused_bwd_scratch",
