@@ -23,7 +23,7 @@ class GemmArgs(ctypes.Structure):
                                   "a_dtype", "w_dtype", "c_dtype", "aux_dtype", "act_pro", "act_epi", "dact_epi",
                                   "accumulate", "store_preact", "n_groups", "max_m", "max_n", "groups_ext", "epi_fast", "k_splits")] + \
                [("alpha", _f), ("p_drop", _f), ("drop_seed", ctypes.c_uint)] + \
-               [(n, _vp) for n in ("row_mu", "row_rs", "col_c", "C16")] + [("ldc16", _i), ("split3", _i), ("r_dtype", _i)]
+               [(n, _vp) for n in ("row_mu", "row_rs", "col_c", "C16")] + [("ldc16", _i), ("split3", _i), ("r_dtype", _i), ("c2_bf16", _i)]
 
 
 class EdgeBwdArgs(ctypes.Structure):

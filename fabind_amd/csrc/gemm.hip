@@ -117,7 +117,7 @@ __device__ __forceinline__ void gemm_epilogue(const FabindGemmArgs& p, f32x4_t (
                         long rr = p.r_index ? (long)p.r_index[a_row0 + row] : (a_row0 + row);
                         v += ld_any(p.R, p.r_dtype, (size_t)rr * p.ldr + col);
                     }
-                    if (p.C2) st_any(p.C2, p.c_dtype, (size_t)c_off + (size_t)row * ldc + col, apply_dact(vpre, p.act_epi));
+                    if (p.C2) st_any(p.C2, p.c2_bf16 ? FB_DT_BF16 : p.c_dtype, (size_t)c_off + (size_t)row * ldc + col, apply_dact(vpre, p.act_epi));
                     if (staged) {
                         sOut[rowl * OUT_LD + coll] = f32_to_bf16(p.store_preact ? vpre : v);
                     } else if (p.C) {
@@ -465,11 +465,15 @@ __device__ __forceinline__ bool gemm_epilogue_f32x(const FabindGemmArgs& p, f32x
                     for (int e = 0; e < 4; ++e) o[e] *= (AUXD == 1) ? (av[e] > 0.f ? 1.f : 0.f) : av[e];
                 }
                 if (HAS_C2) {
-                    *(float4*)&C2[(size_t)row * ldc + col] = make_float4(fast_dact<ACT>(o[0]), fast_dact<ACT>(o[1]), fast_dact<ACT>(o[2]),
-                                                                         fast_dact<ACT>(o[3]));
+                    const float d0 = fast_dact<ACT>(o[0]), d1 = fast_dact<ACT>(o[1]), d2 = fast_dact<ACT>(o[2]), d3 = fast_dact<ACT>(o[3]);
+                    if (p.c2_bf16) *(uint2*)((bf16_t*)p.C2 + (size_t)row * ldc + col) = make_uint2(pack2_bf16(d0, d1), pack2_bf16(d2, d3));
+                    else *(float4*)&C2[(size_t)row * ldc + col] = make_float4(d0, d1, d2, d3);
                 }
-                *(float4*)&C[(size_t)row * ldc + col] = make_float4(fast_act<ACT>(o[0]), fast_act<ACT>(o[1]), fast_act<ACT>(o[2]),
-                                                                    fast_act<ACT>(o[3]));
+                const float a0 = fast_act<ACT>(o[0]), a1 = fast_act<ACT>(o[1]), a2 = fast_act<ACT>(o[2]), a3 = fast_act<ACT>(o[3]);
+                *(float4*)&C[(size_t)row * ldc + col] = make_float4(a0, a1, a2, a3);
+                // (round 6) the bf16 operand copy of the activated tile next to it: the hidden layer of a split-precision MLP stays fp32 for
+                // the second contraction while the backward keeps its bf16 operands -- no cast pass
+                if (p.C16) *(uint2*)((bf16_t*)p.C16 + (size_t)row * p.ldc16 + col) = make_uint2(pack2_bf16(a0, a1), pack2_bf16(a2, a3));
             }
         }
     }
@@ -1674,7 +1678,7 @@ extern "C" int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream) {
         else if (p.act_epi == FB_ACT_RELU && hc && !hc2 && hd && !pre) p.epi_fast = 15;
     }
     if (p.epi_fast == 0 && !drop && !p.groups && p.k_splits <= 1 && p.alpha == 1.0f && !p.accumulate && !p.r_index && !p.R && p.C != nullptr &&
-        p.c_dtype == FB_DT_F32 && !p.dotvec && !p.store_preact && !p.C16 && !foldq) {
+        p.c_dtype == FB_DT_F32 && !p.dotvec && !p.store_preact && (!p.C16 || !p.aux) && !foldq) {
         /* fp32 C with an activation (+ stored derivative) or with the activation adjoint through an fp32 aux tile */
         if (p.aux && p.aux_dtype == FB_DT_F32 && p.act_epi == FB_ACT_NONE && !p.C2 && (p.dact_epi == FB_ACT_RELU || p.dact_epi == FB_ACT_STORED_DERIV))
             p.epi_fast = p.dact_epi == FB_ACT_RELU ? 20 : 21;

@@ -81,6 +81,7 @@ def gemm(A, W, bias=None, A2=None, act_pro=ACT_NONE, act_epi=ACT_NONE, residual=
     a.bias, a.R, a.r_index = ptr(bias), ptr(residual), ptr(r_index)
     a.dotvec, a.dot_out, a.aux, a.groups = ptr(dotvec), ptr(dot_out), ptr(aux), ptr(groups)
     a.C2 = ptr(out2)
+    a.c2_bf16 = 1 if (out2 is not None and want_out and out2.dtype == torch.bfloat16 and out.dtype == torch.float32) else 0
     if out16 is not None:
         a.C16, a.ldc16 = ptr(out16), _ld(out16)
     a.M, a.N, a.K, a.K1 = M, N, K, K1

@@ -452,13 +452,13 @@ class _MLP2(torch.autograd.Function):
             # round 6, config.set_split_sites(3): BOTH contractions of the forward in split precision -- the hidden layer stays fp32 between them
             # (what the bf16 mode's remaining gap at n_iter 8 sat in: profiles/r05_precision_sites.txt).  Saved for the backward, which is
             # unchanged: the bf16 roundings of x, of the hidden activation and of its stored derivative.
+            # (the first launch's epilogue writes the fp32 hidden tile, its bf16 copy and the bf16 derivative: FabindGemmArgs.c2_bf16)
             t32 = torch.empty((M, N1), dtype=torch.float32, device=x.device)
-            D32 = torch.empty((M, N1), dtype=torch.float32, device=x.device) if act == K.ACT_SILU else None
-            K.gemm(x, W32[0], bias=b1, A2=x2, act_epi=act, out=t32, out2=D32, force_x3=True)
+            t = torch.empty((M, N1), dtype=ad, device=x.device)
+            D = torch.empty((M, N1), dtype=ad, device=x.device) if act == K.ACT_SILU else None
+            K.gemm(x, W32[0], bias=b1, A2=x2, act_epi=act, out=t32, out2=D, out16=t, force_x3=True)
             y, _ = K.gemm(t32, W32[1], bias=b2, residual=residual, out_dtype=torch.float32, out16=y16, force_x3=True)
-            t = t32.to(ad)
-            D = D32.to(ad) if D32 is not None else None
-            del t32, D32
+            del t32
         else:
             t = torch.empty((M, N1), dtype=ad, device=x.device)
             D = torch.empty((M, N1), dtype=ad, device=x.device) if act == K.ACT_SILU else None

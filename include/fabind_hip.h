@@ -127,6 +127,8 @@ typedef struct FabindGemmArgs {
     /* dtype of R (FB_DT_F32 = 0: the default; FB_DT_BF16: a bf16 residual stream -- the FABind+ pair embedding, cross_att.py:41-46 --
        is added without a converted copy; row-contiguous 16-byte reads when C is bf16 with no activation, no r_index) */
     int r_dtype;
+    int c2_bf16;       /* round 6: != 0: C2 (the stored activation derivative) is written as bf16 although C is fp32 (fp32 hidden layer for a
+                          split-precision second Linear, bf16 derivative for the unchanged backward); C16 then carries bf16(act(pre)) */
 } FabindGemmArgs;
 
 int fabind_gemm(const FabindGemmArgs* args, hipStream_t stream);
