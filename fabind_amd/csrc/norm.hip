@@ -697,8 +697,15 @@ extern "C" int fabind_edge_lnfold_bwd(const void* AB, int ldab, int Kp, int H, c
     const int npl = (Kp / 8 + 63) / 64;
 #define ELB_LAUNCH(NN, UU)                                                                                                             \
     do {                                                                                                                           \
-        static bool set_ = false;                                                                                                  \
-        if (!set_) { (void)hipFuncSetAttribute((const void*)edge_lnfold_bwd_kernel<NN, UU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        /* the attribute is per DEVICE and must cover the instantiation's LARGEST request (NN x 512 columns: 16 x NN x 512 x 4 bytes), not the \
+           first call's (a later call with a larger Kp, or a second device, launched beyond the allowance) */                  \
+        static unsigned long long set_ = 0ull;                                                                                     \
+        int dev_ = 0;                                                                                                              \
+        (void)hipGetDevice(&dev_);                                                                                                 \
+        if (!((set_ >> (dev_ & 63)) & 1ull)) {                                                                                     \
+            (void)hipFuncSetAttribute((const void*)edge_lnfold_bwd_kernel<NN, UU>, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * NN * 512 * 4); \
+            set_ |= 1ull << (dev_ & 63);                                                                                           \
+        }                                                                                                                          \
         hipLaunchKernelGGL((edge_lnfold_bwd_kernel<NN, UU>), dim3(n_blocks), dim3(256), lds, stream, (const bf16_t*)AB, ldab, Kp, H, row, col, rho, \
                            (const float2*)stat, eps, w_r, c_r, c_c, (const bf16_t*)out, (const bf16_t*)dout, E, dscale, (bf16_t*)du,  \
                            (float4*)es, drho, part);                                                                                \

@@ -30,7 +30,11 @@ def _seg_mean(x, idx, n):
     (torch.segment_reduce: one thread walks a segment), not as float atomics in arrival order -- the batches this builder emits are
     bit-identical from run to run."""
     cnt = torch.bincount(idx, minlength=n)
-    return torch.segment_reduce(x, "sum", lengths=cnt, axis=0, unsafe=True) / cnt.clamp(min=1).to(x.dtype)[:, None]
+    # (the builder reads sizes back anyway: the sortedness of idx and -- inside segment_reduce, unsafe=False -- the lengths are CHECKED;
+    #  an unsorted or filtered batch vector raises instead of giving wrong centres, ADVICE r5)
+    if idx.numel() > 1 and not bool((idx[1:] >= idx[:-1]).all()):
+        raise ValueError("fabind_amd.data: the batch vector must be sorted (complex-contiguous rows)")
+    return torch.segment_reduce(x, "sum", lengths=cnt, axis=0) / cnt.clamp(min=1).to(x.dtype)[:, None]
 
 
 _POOL = {}

@@ -1112,8 +1112,10 @@ def sum_sorted_segments(x, counts):
     """Per-segment sums of the rows of x whose segments are CONTIGUOUS (a sorted batch vector) with `counts` rows each -- one thread
     walks a segment in order (torch.segment_reduce): no float atomics, the same bits every run.  (zeros(B, .).index_add_(0, batch, x),
     the form the reference's scatter_mean suggests, adds in arrival order: the stage-2 input coordinates then differ in their last bits
-    from run to run, and with them everything downstream.)  Index glue on inputs: not differentiable."""
-    return torch.segment_reduce(x.detach(), "sum", lengths=counts.to(torch.int64), axis=0, unsafe=True)
+    from run to run, and with them everything downstream.)  Index glue on inputs: not differentiable.
+    The lengths are validated (segment_reduce without `unsafe`: they must be non-negative and sum to the row count -- one small read-back on
+    a path, stage 2, that reads sizes back anyway)."""
+    return torch.segment_reduce(x.detach(), "sum", lengths=counts.to(torch.int64), axis=0)
 
 
 def take_unique_rows(x, index64):
