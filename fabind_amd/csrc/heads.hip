@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void pocket_center_bwd_kernel(const float* __r
 // pocket / ligand operands and the first of the complex's ceil(P_b / TP) protein tiles.  Rounds 1-5 described the same pairs by two index lists
 // and, for the adjoints, built a CSR per call (two stable sorts of 3.84 M keys at the headline shape) and walked it one wave per row.
 constexpr int PB_TP = 128;             // proteins per tile
-constexpr int PB_CH = 20;              // ligand atoms per register chunk of the Hadamard adjoint (20 x W fp32 in LDS: four work-groups per CU at W = 512)
+constexpr int PB_CH = 20;              // ligand atoms per register chunk of the Hadamard adjoint (20 tc pairs + 20 accumulator pairs + 20 loads per thread)
 
 struct PairBlock { long pair_off; int P, C, p_row0, c_row0, tile0, pad; };
 
@@ -307,48 +307,55 @@ __global__ __launch_bounds__(256) void block_hadamard_bwd_kernel(const PairBlock
     const PairBlock d = desc[b];
     const int i0 = (blockIdx.x - d.tile0) * PB_TP, i1 = min(d.P, i0 + PB_TP);
     if (i0 >= d.P) return;
-    const int ct = threadIdx.x % CT, il = threadIdx.x / CT, c2 = ct * 2;
-    extern __shared__ float sm[];                          // [PB_CH][W] tc rows of the chunk, then [NL][PB_CH][W] for the lane reduction (NL > 1)
-    float* s_tc = sm;
-    float* s_red = sm + PB_CH * W;
+    // (NL == 1, W = 512: every thread of the work-group walks the SAME protein -- row bases are wave-uniform: scalar registers + one lane offset)
+    const int ct = (NL == 1) ? (int)threadIdx.x : (int)threadIdx.x % CT, il = (NL == 1) ? 0 : (int)threadIdx.x / CT, c2 = ct * 2;
+    extern __shared__ float sm[];                          // [NL][PB_CH][W] for the lane reduction (NL > 1 only)
     for (int j0 = 0, ch = 0; j0 < d.C; j0 += PB_CH, ++ch) {
         const int cw = min(PB_CH, d.C - j0);
-        __syncthreads();
-        for (int k = threadIdx.x; k < cw * W; k += 256) s_tc[k] = tc[(size_t)(d.c_row0 + j0 + k / W) * ldtc + k % W];
-        __syncthreads();
-        float acc[PB_CH][2];
+        // this thread's two columns of the chunk's tc rows and of its d tc accumulators: registers (rows past the chunk: zeros)
+        float2 c[PB_CH], acc[PB_CH];
 #pragma unroll
-        for (int j = 0; j < PB_CH; ++j) acc[j][0] = acc[j][1] = 0.f;
+        for (int j = 0; j < PB_CH; ++j) {
+            c[j] = j < cw ? *(const float2*)(tc + (size_t)(d.c_row0 + j0 + j) * ldtc + c2) : make_float2(0.f, 0.f);
+            acc[j] = make_float2(0.f, 0.f);
+        }
         for (int i = i0 + il; i < i1; i += NL) {
             const float2 p = *(const float2*)(tp + (size_t)(d.p_row0 + i) * ldtp + c2);
-            const bf16_t* row = dout + (size_t)(d.pair_off + (long)i * d.C + j0) * ldo + c2;
+            const bf16_t* row = dout + (size_t)(d.pair_off + (long)i * d.C + j0) * ldo;      // + c2 per lane below
+            // ALL loads of the protein's chunk rows first (read once: non-temporal), then the arithmetic: 20 x 256 B per wave in flight
+            uint32_t u[PB_CH];
+            if (cw == PB_CH) {
+#pragma unroll
+                for (int j = 0; j < PB_CH; ++j) u[j] = __builtin_nontemporal_load((const uint32_t*)(row + (size_t)j * ldo) + ct);
+            } else {
+#pragma unroll
+                for (int j = 0; j < PB_CH; ++j) u[j] = j < cw ? __builtin_nontemporal_load((const uint32_t*)(row + (size_t)j * ldo) + ct) : 0u;
+            }
             float ax = 0.f, ay = 0.f;
-#pragma unroll 8
+#pragma unroll
             for (int j = 0; j < PB_CH; ++j) {
-                if (j < cw) {
-                    const uint32_t u = __builtin_nontemporal_load((const uint32_t*)(row + (size_t)j * ldo));
-                    const float dx = __uint_as_float(u << 16), dy = __uint_as_float(u & 0xffff0000u);
-                    const float2 c = *(const float2*)(s_tc + j * W + c2);
-                    ax += dx * c.x; ay += dy * c.y;
-                    acc[j][0] += dx * p.x; acc[j][1] += dy * p.y;
-                }
+                const float dx = __uint_as_float(u[j] << 16), dy = __uint_as_float(u[j] & 0xffff0000u);
+                ax += dx * c[j].x; ay += dy * c[j].y;
+                acc[j].x += dx * p.x; acc[j].y += dy * p.y;
             }
             float* o = dtp + (size_t)(d.p_row0 + i) * lddp + c2;
-            if (ch == 0) { o[0] = ax; o[1] = ay; } else { o[0] += ax; o[1] += ay; }      // (this work-group owns the row)
+            if (ch == 0) *(float2*)o = make_float2(ax, ay);                       // (this work-group owns the row)
+            else { const float2 q = *(const float2*)o; *(float2*)o = make_float2(q.x + ax, q.y + ay); }
         }
         float* po = part + ((size_t)blockIdx.x * nchunk_max + ch) * PB_CH * W;
         if (NL == 1) {
 #pragma unroll
             for (int j = 0; j < PB_CH; ++j)
-                if (j < cw) *(float2*)(po + j * W + c2) = make_float2(acc[j][0], acc[j][1]);
+                if (j < cw) *(float2*)(po + j * W + c2) = acc[j];
         } else {
+            __syncthreads();                               // (the previous chunk's readers are done with the buffer)
 #pragma unroll
             for (int j = 0; j < PB_CH; ++j)
-                if (j < cw) *(float2*)(s_red + ((size_t)il * PB_CH + j) * W + c2) = make_float2(acc[j][0], acc[j][1]);
+                if (j < cw) *(float2*)(sm + ((size_t)il * PB_CH + j) * W + c2) = acc[j];
             __syncthreads();
             for (int k = threadIdx.x; k < cw * W; k += 256) {
                 float v = 0.f;
-                for (int l = 0; l < NL; ++l) v += s_red[(size_t)l * PB_CH * W + k];
+                for (int l = 0; l < NL; ++l) v += sm[(size_t)l * PB_CH * W + k];
                 po[k] = v;
             }
         }
@@ -401,7 +408,7 @@ extern "C" int fabind_block_hadamard_bwd(const void* desc, int B, int n_tiles, c
 #define BH_LAUNCH(WW)                                                                                                              \
     do {                                                                                                                           \
         constexpr int NL_ = 256 / (WW / 2);                                                                                        \
-        const size_t lds = (size_t)PB_CH * WW * 4 * (NL_ > 1 ? 1 + NL_ : 1);                                                      \
+        const size_t lds = NL_ > 1 ? (size_t)PB_CH * WW * 4 * NL_ : 0;                                                            \
         static bool set_ = false;                                                                                                  \
         if (!set_) { (void)hipFuncSetAttribute((const void*)block_hadamard_bwd_kernel<WW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
         hipLaunchKernelGGL((block_hadamard_bwd_kernel<WW>), dim3(n_tiles), dim3(256), lds, stream, (const PairBlock*)desc, B,      \
