@@ -191,3 +191,200 @@ extern "C" int fabind_node_chain_fwd(const void* X1, int ld1, const void* X2, in
     FB_CHECK_LAUNCH();
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// Round 6: the SPLIT-PRECISION form of the chain (bf16 mode, config.set_split_sites(3): both Linears of a node MLP / Transition contract
+// fp32 activations with fp32 master weights as split bf16, three MFMAs per product term, and the hidden layer never gets rounded to
+// bf16).  fp32 X rows are split while they are staged into TWO swizzled [64][H] bf16 planes (hi = bf16(x), lo = bf16(x - hi)), the
+// weights arrive as hi | lo fragment packs (kernels.pack_frag_split), fe_gemm_x3 (fused_common.h) contracts, the fp32 hidden accumulators
+// get bias + activation and are split back into the planes in place.  One work-group of H / 64 waves per 64 rows, 2 x 64 x H x 2 bytes of
+// LDS (128 KiB at H = 512: one work-group per CU).  As two gemm_x3 launches the fp32 hidden layer travels through HBM (404 MB each way for
+// the Transition at 98,688 rows) and every k-tile of both operands is split in every work-group.
+// ------------------------------------------------------------------------------------------------------------------------------------------
+struct NodeChainX3Args {
+    const float* X1; int ld1;
+    const float* X2; int ld2;
+    const bf16_t* W1ah; const bf16_t* W1al; const bf16_t* W1bh; const bf16_t* W1bl; const float* b1;
+    const bf16_t* W2ah; const bf16_t* W2al; const bf16_t* W2bh; const bf16_t* W2bl; const float* b2;
+    const float* R; int ldr;
+    float* out; int ldo;
+    bf16_t* out16; int ldo16;
+    int M;
+};
+
+__device__ __forceinline__ void nc_split4(const float4 x, uint2& hi, uint2& lo) {
+    const uint32_t h0 = pack2_bf16(x.x, x.y), h1 = pack2_bf16(x.z, x.w);
+    hi = make_uint2(h0, h1);
+    lo = make_uint2(pack2_bf16(x.x - __uint_as_float(h0 << 16), x.y - __uint_as_float(h0 & 0xffff0000u)),
+                    pack2_bf16(x.z - __uint_as_float(h1 << 16), x.w - __uint_as_float(h1 & 0xffff0000u)));
+}
+
+template <int H, int KIND, int ACT>
+__global__ __launch_bounds__(H, 1) void node_chain_x3_kernel(const NodeChainX3Args p) {
+    constexpr int BM = 64, MI = BM / 16, CH = H / 8;
+    constexpr int SWZ = (H >= 128) ? 15 : 7;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16_t* sXh = (bf16_t*)smem;                                  // [64][H] swizzled, hi plane
+    bf16_t* sXl = sXh + BM * H;                                   // lo plane
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, cq = lane >> 4;
+    const int m0 = blockIdx.x * BM;
+    const int nr = min(BM, p.M - m0);
+    const int cx = (wave * 8 + (cq >> 1)) ^ (fr & SWZ);
+    const int lbase = fr * H + (cq & 1) * 4;
+#define NC_QOFF(i, j) (lbase + (i) * 16 * H + ((cx ^ ((j) * 2)) * 8))
+    const int fcol = wave * 64 + cq * 4;
+
+    constexpr int NLD = BM * CH / H;                              // 8-element chunks per thread and tile (= 8): two float4 loads each
+    auto stage = [&](const float* X, int ld) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                    // two rounds of four chunks: 8 float4 loads in flight per thread
+            float4 v[NLD / 2][2];
+#pragma unroll
+            for (int u = 0; u < NLD / 2; ++u) {
+                const int q = tid + (half * (NLD / 2) + u) * H, rw = q / CH, ch = q % CH;
+                v[u][0] = v[u][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rw < nr) {
+                    const float* src = X + (size_t)(m0 + rw) * ld + ch * 8;
+                    v[u][0] = *(const float4*)src;
+                    v[u][1] = *(const float4*)(src + 4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NLD / 2; ++u) {
+                const int q = tid + (half * (NLD / 2) + u) * H, rw = q / CH, ch = q % CH;
+                uint2 h0, l0, h1, l1;
+                nc_split4(v[u][0], h0, l0);
+                nc_split4(v[u][1], h1, l1);
+                const int o = rw * H + ((ch ^ (rw & SWZ)) * 8);
+                *(uint4*)&sXh[o] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+                *(uint4*)&sXl[o] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
+        }
+    };
+    auto hidden_to_tile = [&](f32x4_t (&acc)[MI][4], const float* bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 bq = *(const float4*)(bias + fcol + j * 16);
+            const nc_f2 b01 = nc_f2{bq.x, bq.y}, b23 = nc_f2{bq.z, bq.w};
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const nc_f2 t01 = nc_act_pair<ACT>(nc_f2{acc[i][j][0], acc[i][j][1]} + b01);
+                const nc_f2 t23 = nc_act_pair<ACT>(nc_f2{acc[i][j][2], acc[i][j][3]} + b23);
+                uint2 hi, lo;
+                nc_split4(make_float4(t01.x, t01.y, t23.x, t23.y), hi, lo);
+                *(uint2*)&sXh[NC_QOFF(i, j)] = hi;
+                *(uint2*)&sXl[NC_QOFF(i, j)] = lo;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    f32x4_t acc[MI][4], out[MI][4];
+    fe_zero(out);
+    stage(p.X1, p.ld1);
+    __syncthreads();
+    if constexpr (KIND == 0) {
+        fe_zero(acc);
+        fe_gemm_x3<H, MI, SWZ>(sXh, sXl, p.W1ah, p.W1al, wave, lane, acc);
+        __syncthreads();
+        stage(p.X2, p.ld2);
+        __syncthreads();
+        fe_gemm_x3<H, MI, SWZ>(sXh, sXl, p.W1bh, p.W1bl, wave, lane, acc);
+        __syncthreads();
+        hidden_to_tile(acc, p.b1);
+        __syncthreads();
+        fe_gemm_x3<H, MI, SWZ>(sXh, sXl, p.W2ah, p.W2al, wave, lane, out);
+    } else {
+#pragma unroll 1
+        for (int c = 0; c < 2; ++c) {
+            if (c) {
+                __syncthreads();
+                stage(p.X1, p.ld1);
+                __syncthreads();
+            }
+            fe_zero(acc);
+            fe_gemm_x3<H, MI, SWZ>(sXh, sXl, c ? p.W1bh : p.W1ah, c ? p.W1bl : p.W1al, wave, lane, acc);
+            __syncthreads();
+            hidden_to_tile(acc, p.b1 + c * H);
+            __syncthreads();
+            fe_gemm_x3<H, MI, SWZ>(sXh, sXl, c ? p.W2bh : p.W2ah, c ? p.W2bl : p.W2al, wave, lane, out);
+        }
+    }
+    {   // out = acc + b2 (+ R): as in node_chain_fwd_kernel, through the (dead) planes in two column halves, whole rows out
+        float* sO = (float*)smem;
+        constexpr int HW = H / 2;
+        constexpr int WPH = (H / 64) / 2;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if (wave / WPH == half) {
+                const int lc = (wave % WPH) * 64 + cq * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 bq = *(const float4*)(p.b2 + fcol + j * 16);
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        *(float4*)&sO[(i * 16 + fr) * HW + lc + j * 16] =
+                            make_float4(out[i][j][0] + bq.x, out[i][j][1] + bq.y, out[i][j][2] + bq.z, out[i][j][3] + bq.w);
+                }
+            }
+            __syncthreads();
+            constexpr int C4 = HW / 4;
+            for (int q = tid; q < BM * C4; q += H) {
+                const int rw = q / C4, c4 = q % C4;
+                if (rw >= nr) continue;
+                const size_t row = (size_t)(m0 + rw);
+                const int col = half * HW + c4 * 4;
+                float4 o = *(const float4*)&sO[rw * HW + c4 * 4];
+                if (p.R) {
+                    const float4 r = *(const float4*)(p.R + row * p.ldr + col);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                *(float4*)(p.out + row * p.ldo + col) = o;
+                if (p.out16) *(uint2*)(p.out16 + row * p.ldo16 + col) = make_uint2(pack2_bf16(o.x, o.y), pack2_bf16(o.z, o.w));
+            }
+        }
+    }
+#undef NC_QOFF
+}
+
+extern "C" int fabind_node_chain_x3_fwd(const float* X1, int ld1, const float* X2, int ld2, const void* W1ah, const void* W1al,
+                                        const void* W1bh, const void* W1bl, const float* b1, const void* W2ah, const void* W2al,
+                                        const void* W2bh, const void* W2bl, const float* b2, int act, int kind, const float* R, int ldr,
+                                        float* out, int ldo, void* out16, int ldo16, int M, int H, hipStream_t stream) {
+    if (M <= 0) return 0;
+    FB_REQUIRE(H == 512 || H == 256 || H == 128, "fabind_node_chain_x3_fwd: H in {128, 256, 512}");
+    FB_REQUIRE(kind == 0 || kind == 1, "fabind_node_chain_x3_fwd: kind 0 (K = 2H, hidden H) or 1 (K = H, hidden 2H)");
+    FB_REQUIRE(act == FB_ACT_SILU || act == FB_ACT_RELU, "fabind_node_chain_x3_fwd: silu or relu");
+    FB_REQUIRE(X1 && W1ah && W1al && W1bh && W1bl && W2ah && W2al && b1 && b2 && out && (kind == 0 ? X2 != nullptr : (W2bh && W2bl)),
+               "fabind_node_chain_x3_fwd: operands");
+    FB_REQUIRE(ld1 % 4 == 0 && (kind == 1 || ld2 % 4 == 0) && ldo % 4 == 0 && (!R || ldr % 4 == 0) && (!out16 || ldo16 % 4 == 0),
+               "fabind_node_chain_x3_fwd: leading dimensions % 4");
+    FB_REQUIRE((((uintptr_t)X1 | (uintptr_t)X2 | (uintptr_t)out | (uintptr_t)R | (uintptr_t)out16 | (uintptr_t)b1 | (uintptr_t)b2) & 15) == 0,
+               "fabind_node_chain_x3_fwd: 16-byte aligned buffers");
+    NodeChainX3Args a;
+    a.X1 = X1; a.ld1 = ld1; a.X2 = X2; a.ld2 = ld2;
+    a.W1ah = (const bf16_t*)W1ah; a.W1al = (const bf16_t*)W1al; a.W1bh = (const bf16_t*)W1bh; a.W1bl = (const bf16_t*)W1bl; a.b1 = b1;
+    a.W2ah = (const bf16_t*)W2ah; a.W2al = (const bf16_t*)W2al; a.W2bh = (const bf16_t*)W2bh; a.W2bl = (const bf16_t*)W2bl; a.b2 = b2;
+    a.R = R; a.ldr = ldr; a.out = out; a.ldo = ldo; a.out16 = (bf16_t*)out16; a.ldo16 = ldo16; a.M = M;
+    const dim3 grid((M + 63) / 64);
+#define NCX_LAUNCH_(HH, KK, AA)                                                                                                 \
+    do {                                                                                                                        \
+        const size_t lds = (size_t)2 * 64 * HH * 2;                                                                             \
+        static bool set_ = false;                                                                                               \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)node_chain_x3_kernel<HH, KK, AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        hipLaunchKernelGGL((node_chain_x3_kernel<HH, KK, AA>), grid, dim3(HH), lds, stream, a);                                  \
+    } while (0)
+#define NCX_LAUNCH(HH)                                                                                                          \
+    do {                                                                                                                        \
+        if (kind == 0) { if (act == FB_ACT_SILU) NCX_LAUNCH_(HH, 0, FB_ACT_SILU); else NCX_LAUNCH_(HH, 0, FB_ACT_RELU); }        \
+        else { if (act == FB_ACT_SILU) NCX_LAUNCH_(HH, 1, FB_ACT_SILU); else NCX_LAUNCH_(HH, 1, FB_ACT_RELU); }                  \
+    } while (0)
+    if (H == 512) NCX_LAUNCH(512); else if (H == 256) NCX_LAUNCH(256); else NCX_LAUNCH(128);
+#undef NCX_LAUNCH
+#undef NCX_LAUNCH_
+    FB_CHECK_LAUNCH();
+    return 0;
+}

@@ -529,6 +529,26 @@ def _node_chain(p, key, W1, b1, W2, b2, act, kind, x1, x2, residual, want16):
     return ops._attach_b16(out, out16)
 
 
+def _node_chain_x3(p, key, W32, b1, b2, act, kind, x1, x2, residual, want16):
+    """The same chain in split precision (config.set_split_sites(3), no-grad passes): fp32 rows, fp32 master weights W32 = (W1_32, W2_32)
+    as hi | lo fragment packs (kept in the cached parameter pack under `key`); None when the shapes do not fit."""
+    H = W32[1].shape[0]
+    ok = lambda t: t is not None and t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == H and t.stride(1) == 1 and t.stride(0) % 4 == 0 \
+        and t.data_ptr() % 16 == 0
+    if not (NODE_CHAIN and NODE_CHAIN_X3 and H in (128, 256, 512) and b1 is not None and b2 is not None and ok(x1) and ok(residual)
+            and (kind == 1 or ok(x2)) and tuple(W32[0].shape) == ((H, 2 * H) if kind == 0 else (2 * H, H))
+            and tuple(W32[1].shape) == ((H, H) if kind == 0 else (H, 2 * H))):
+        return None
+    packs = p.get(key)
+    if packs is None:
+        packs = p[key] = K.node_chain_x3_pack(W32[0], W32[1], kind)
+    out, out16 = K.node_chain_x3_fwd(x1, x2 if kind == 0 else None, packs, b1.float(), b2.float(), act, kind, residual=residual, want16=want16)
+    return ops._attach_b16(out, out16)
+
+
+NODE_CHAIN_X3 = os.environ.get("FABIND_NODE_CHAIN_X3", "1") == "1"     # 0: the split-precision MLPs of no-grad passes as two gemm_x3 launches (A/B)
+
+
 def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
     """MC_E_GCL.forward (egnn.py:130-144): edge -> coord -> node, all from the layer's input h, x.
 
@@ -566,7 +586,10 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
             # dropout ahead of the residual (egnn.py:106) inside the second Linear's epilogue, its mask regenerated by the adjoint
             return ops.mlp2(hin, p["Wn1"], p["bn1"], K.ACT_SILU, p["Wn2"], p["bn2"], residual=h, x2=agg, want16=True, p_drop=pdrop,
                             W32=p.get("Wn_32")), x_new
-        if fast and pdrop == 0.0 and p.get("Wn_32") is not None:     # split-precision site (level 3): two launches, fp32 hidden layer
+        if fast and pdrop == 0.0 and p.get("Wn_32") is not None:     # split-precision site (level 3): one kernel, the hidden layer on chip
+            hn = _node_chain_x3(p, "_ncx_node", p["Wn_32"], p["bn1"], p["bn2"], K.ACT_SILU, 0, h, agg, h, True)
+            if hn is not None:
+                return hn, x_new
             return ops.mlp2(h, p["Wn1"], p["bn1"], K.ACT_SILU, p["Wn2"], p["bn2"], residual=h, x2=agg, want16=True, W32=p["Wn_32"]), x_new
         if fast and pdrop == 0.0:
             hn = _node_chain(p, "_nc_node", p["Wn1"], p["bn1"], p["Wn2"], p["bn2"], K.ACT_SILU, 0, hin, ops._mm_in(agg), h, True)
@@ -632,7 +655,9 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
     if fast:
         hp2 = None
         if p.get("Wt_p32") is not None:                              # split-precision site (level 3)
-            hp2 = ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True, W32=p["Wt_p32"])
+            hp2 = _node_chain_x3(p, "_ncx_tp", p["Wt_p32"], p["bt1_p"], p["bt2_p"], K.ACT_RELU, 1, hp, None, hp, True)
+            if hp2 is None:
+                hp2 = ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True, W32=p["Wt_p32"])
         else:
             hp2 = _node_chain(p, "_nc_tp", p["Wt1_p"], p["bt1_p"], p["Wt2_p"], p["bt2_p"], K.ACT_RELU, 1, hp16, None, hp, True)
         if hp2 is None:

@@ -519,6 +519,38 @@ def node_chain_fwd(X1, X2, packs, b1, b2, act, kind, residual=None, want16=False
     return out, out16
 
 
+def node_chain_x3_pack(W1, W2, kind):
+    """hi | lo fragment packs of the H x H blocks of a chain's two fp32 master weights (node_chain_x3_fwd): 8 packs in the order
+    (W1a hi, lo, W1b hi, lo, W2a hi, lo, W2b hi, lo); kind as in node_chain_pack."""
+    H = W2.shape[0]
+    if kind == 0:
+        assert W1.shape == (H, 2 * H) and W2.shape == (H, H)
+        blocks = (W1[:, :H], W1[:, H:], W2, None)
+    else:
+        assert W1.shape == (2 * H, H) and W2.shape == (H, 2 * H)
+        blocks = (W1[:H], W1[H:], W2[:, :H], W2[:, H:])
+    out = []
+    for b_ in blocks:
+        out.extend(pack_frag_split(b_.contiguous()) if b_ is not None else (None, None))
+    return tuple(out)
+
+
+def node_chain_x3_fwd(X1, X2, packs, b1, b2, act, kind, residual=None, want16=False):
+    """out = act([X1 | X2] W1^T + b1) W2^T + b2 (+ residual) in split precision with the hidden layer on chip (csrc/node_chain.hip,
+    forward only): fp32 X rows, packs from node_chain_x3_pack.  -> (out fp32 [M, H], bf16 copy or None)."""
+    M, H = X1.shape
+    assert X1.dtype == torch.float32 and (X2 is None or X2.dtype == torch.float32)
+    out = torch.empty((M, H), dtype=torch.float32, device=X1.device)
+    out16 = torch.empty((M, H), dtype=torch.bfloat16, device=X1.device) if want16 else None
+    hidden = H if kind == 0 else 2 * H
+    _profiled("fabind_node_chain_x3_fwd kind=%d M=%d H=%d" % (kind, M, H), 2.0 * M * (2 * H * hidden),
+              lambda: check(_lib.load().fabind_node_chain_x3_fwd(
+                  ptr(X1), _ld(X1), ptr(X2), _ld(X2) if X2 is not None else 0, *[ptr(t_) for t_ in packs[:4]], ptr(b1),
+                  *[ptr(t_) for t_ in packs[4:]], ptr(b2), act, kind, ptr(residual), _ld(residual) if residual is not None else 0,
+                  ptr(out), _ld(out), ptr(out16), H if want16 else 0, M, H, stream()), "fabind_node_chain_x3_fwd"))
+    return out, out16
+
+
 def pack_frag_split(W):
     """fp32 [N,K] weight -> (hi, lo) bf16 fragment packs of the split-bf16 kernels: hi = bf16(W), lo = bf16(W - hi)."""
     hi = W.to(torch.bfloat16)

@@ -65,7 +65,8 @@ const char* fabind_last_error(void);
  *     ahead of a residual).
  * 18 = round 6: fabind_loss_fwd / fabind_loss_bwd / fabind_loss_blocks (the six-term training loss and its gradient seeds, one launch each way),
  *     fabind_pocket_center_fwd / _bwd (the Gumbel-softmax pocket centre, one launch each way); fabind_gemm_tn_set_exp ignores bit 2;
- *     fabind_pair_dist_fwd / _bwd, fabind_block_hadamard_bwd (+ fabind_pair_block_tile / _chunk): the distance head's pair operations on block descriptors.
+ *     fabind_pair_dist_fwd / _bwd, fabind_block_hadamard_bwd (+ fabind_pair_block_tile / _chunk): the distance head's pair operations on block descriptors;
+ *     FabindGemmArgs.c2_bf16; fabind_node_chain_x3_fwd (node MLP / Transition as one split-precision kernel).
  * A binding must refuse a library whose version differs from the header it was written against. */
 #define FABIND_ABI_VERSION 18
 int fabind_abi_version(void);
@@ -715,6 +716,13 @@ int fabind_pair_hadamard_bwd_grid(const void* dhd, int dt, int ldh, const float*
 int fabind_node_chain_fwd(const void* X1, int ld1, const void* X2, int ld2, const void* W1a, const void* W1b, const float* b1,
                           const void* W2a, const void* W2b, const float* b2, int act, int kind, const float* R, int ldr, float* out,
                           int ldo, void* out16, int ldo16, int M, int H, hipStream_t stream);
+/* The same chains in SPLIT PRECISION (round 6; bf16 mode with config.set_split_sites(3)): fp32 X rows and fp32 master weights given as
+ * hi | lo bf16 fragment packs (hi = bf16(W), lo = bf16(W - hi), each in the layout of fabind_node_chain_fwd's packs); every product term
+ * is three MFMAs, the hidden layer is never rounded to bf16.  X1 / X2 / R / out: fp32 rows (ld % 4 == 0, 16-byte aligned). */
+int fabind_node_chain_x3_fwd(const float* X1, int ld1, const float* X2, int ld2, const void* W1ah, const void* W1al, const void* W1bh,
+                             const void* W1bl, const float* b1, const void* W2ah, const void* W2al, const void* W2bh, const void* W2bl,
+                             const float* b2, int act, int kind, const float* R, int ldr, float* out, int ldo, void* out16, int ldo16,
+                             int M, int H, hipStream_t stream);
 /* Adjoint of out[e, :] = t[ia[e], :] * t[ib[e], :] (the distance-map head's LN(p_i) * LN(c_j) over every pocket residue x ligand atom
  * pair, FABind/fabind/models/model.py:355) without float atomics: the pairs of every row of t are given as a CSR (rowptr [n_rows + 1];
  * per entry the pair's row of dout and the partner's row of t); one wave per row, dT[n, :] = sum_e dout[pair_idx[e], :] * t[partner[e], :]

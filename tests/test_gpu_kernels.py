@@ -1244,6 +1244,43 @@ def test_node_chain_forward_matches_two_linears(H, kind, act):
     assert none16 is None and float((out_nr.cpu() - (ref - R)).abs().max() / ref.abs().max()) <= 5e-3
 
 
+@pytest.mark.parametrize("H", [512, 128])
+@pytest.mark.parametrize("kind,act", [(0, "silu"), (1, "relu"), (0, "relu"), (1, "silu")])
+def test_node_chain_x3_forward_matches_float64(H, kind, act):
+    """csrc/node_chain.hip, split-precision form (round 6: the node MLP / Transition of a no-grad pass in the bf16 mode's split-precision
+    sites level 3): fp32 rows, fp32 master weights as hi | lo packs, hidden layer never rounded to bf16 -- against float64 of the same
+    fp32 operands: fp32-grade (the two-launch bf16 chain above is 5e-3), and equal to the two gemm_x3 launches it replaces to 1e-5."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(7 * H + kind)
+    M = 1000 + 37
+    hid = H if kind == 0 else 2 * H
+    kin = 2 * H if kind == 0 else H
+    X = torch.randn(M, kin, generator=g)
+    W1 = torch.randn(hid, kin, generator=g) / kin ** 0.5
+    W2 = torch.randn(H, hid, generator=g) / hid ** 0.5
+    b1, b2 = torch.randn(hid, generator=g) * 0.3, torch.randn(H, generator=g) * 0.3
+    R = torch.randn(M, H, generator=g)
+    fa = torch.nn.functional.silu if act == "silu" else torch.relu
+    ref = (fa(X.double() @ W1.double().T + b1.double()) @ W2.double().T + b2.double() + R.double())
+    code = K.ACT_SILU if act == "silu" else K.ACT_RELU
+    packs = K.node_chain_x3_pack(W1.to(dev), W2.to(dev), kind)
+    assert len(packs) == 8 and (packs[6] is None) == (kind == 0)
+    Xd = X.to(dev)
+    X1, X2 = (Xd[:, :H].contiguous(), Xd[:, H:].contiguous()) if kind == 0 else (Xd, None)
+    out, out16 = K.node_chain_x3_fwd(X1, X2, packs, b1.to(dev), b2.to(dev), code, kind, residual=R.to(dev), want16=True)
+    err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-5, err
+    assert torch.equal(out16.float().cpu(), out.cpu().bfloat16().float())
+    # the two split-precision GEMM launches of the same chain
+    t, _ = K.gemm(X1, W1.to(dev), bias=b1.to(dev), A2=X2, act_epi=code, force_x3=True)
+    two, _ = K.gemm(t, W2.to(dev), bias=b2.to(dev), residual=R.to(dev), force_x3=True)
+    assert float((out - two).abs().max() / two.abs().max()) <= 1e-5
+    out_nr, none16 = K.node_chain_x3_fwd(X1, X2, packs, b1.to(dev), b2.to(dev), code, kind)
+    assert none16 is None and float((out_nr.double().cpu() - (ref - R.double())).abs().max() / ref.abs().max()) <= 2e-5
+    assert torch.equal(K.node_chain_x3_fwd(X1, X2, packs, b1.to(dev), b2.to(dev), code, kind)[0], out_nr)          # bit-repeatable
+
+
 def test_gemm_tn_multi_matches_single_launches():
     """fabind_gemm_tn_multi: many weight-gradient contractions as one launch + one reduction (kernels.gemm_tn_queued / tn_flush).  Every
     job against the single-launch result of the same operands (same kernel code path; split counts differ, so fp32 sums are compared
