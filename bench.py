@@ -733,7 +733,7 @@ def main():
             out["roofline"] = roofline_of(prof, dt, a.precision)
             # HBM traffic of the dominant kernel: NOT measured in this run -- the per-launch figure of the committed PMC passes
             # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, corrected per MI355X_MICROARCH.md "HBM"); the source is named
-            for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
+            for name in ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json", "r01_pmc.json"):
                 pmc = os.path.join(ROOT, "profiles", name)
                 if not os.path.exists(pmc):
                     continue
