@@ -131,7 +131,8 @@ SIGNATURES = {
     "fabind_pair_bias_cat": [_vp, _i, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp],
     "fabind_batched_transpose_pad": [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp],
     "fabind_node_chain_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
-    "fabind_node_chain_x3_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp],
+    "fabind_node_chain_x3_fwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i,
+                                 _i, _i, _vp],
     "fabind_rows_hadamard_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "fabind_pair_hadamard_bwd_grid": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp],
     "fabind_pair_hadamard_bwd_rows": [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],

@@ -410,6 +410,11 @@ __global__ __launch_bounds__(256) void pack_frag_multi_kernel(const FabindPackSe
             } else {
                 a = ((const float*)sg.src)[i0];
                 b = ((const float*)sg.src)[i1];
+                if (sg.src_dt == 2) {          // round 6: the LO plane of a split-bf16 operand: bf16(w - bf16(w)) of an fp32 source
+                    const uint32_t h = pack2_bf16(a, b);
+                    a -= __uint_as_float(h << 16);
+                    b -= __uint_as_float(h & 0xffff0000u);
+                }
             }
             w[j] = pack2_bf16(a, b);
         }
@@ -423,7 +428,7 @@ extern "C" int fabind_pack_frag_multi(const FabindPackSeg* segs_dev, const Fabin
     for (int i = 0; i < n_segs; ++i) {
         const FabindPackSeg& g = segs_host[i];
         FB_REQUIRE(g.src && g.dst && g.N > 0 && g.K > 0 && g.N % 16 == 0 && g.K % 32 == 0 && ((uintptr_t)g.dst % 16 == 0) &&
-                   (g.src_dt == FB_DT_F32 || g.src_dt == FB_DT_BF16), "fabind_pack_frag_multi: N % 16 == 0, K % 32 == 0, 16-byte aligned dst");
+                   (g.src_dt == FB_DT_F32 || g.src_dt == FB_DT_BF16 || g.src_dt == 2), "fabind_pack_frag_multi: N % 16 == 0, K % 32 == 0, 16-byte aligned dst");
         const long nv = (long)g.N * g.K / 8;
         big = nv > big ? nv : big;
     }

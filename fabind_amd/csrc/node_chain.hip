@@ -211,6 +211,8 @@ struct NodeChainX3Args {
     float* out; int ldo;
     bf16_t* out16; int ldo16;
     int M;
+    bf16_t* T16; int ldt;             // SAVE (training forward): bf16 of the activated hidden layer [M, hidden] ...
+    bf16_t* D16; int ldd;             // ... and of the activation derivative (SiLU only; NULL for ReLU): the operands of the unchanged bf16 backward
 };
 
 __device__ __forceinline__ void nc_split4(const float4 x, uint2& hi, uint2& lo) {
@@ -220,7 +222,14 @@ __device__ __forceinline__ void nc_split4(const float4 x, uint2& hi, uint2& lo) 
                     pack2_bf16(x.z - __uint_as_float(h1 << 16), x.w - __uint_as_float(h1 & 0xffff0000u)));
 }
 
-template <int H, int KIND, int ACT>
+template <int ACT> __device__ __forceinline__ nc_f2 nc_dact_pair(const nc_f2 z) {     // act'(z), SiLU: s (1 + z (1 - s))
+    const nc_f2 t = z * -1.44269504f;
+    const nc_f2 o = nc_f2{__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)} + 1.0f;
+    const nc_f2 sg = nc_f2{__builtin_amdgcn_rcpf(o.x), __builtin_amdgcn_rcpf(o.y)};
+    return sg * (1.0f + z * (1.0f - sg));
+}
+
+template <int H, int KIND, int ACT, bool SAVE = false>
 __global__ __launch_bounds__(H, 1) void node_chain_x3_kernel(const NodeChainX3Args p) {
     constexpr int BM = 64, MI = BM / 16, CH = H / 8;
     constexpr int SWZ = (H >= 128) ? 15 : 7;
@@ -263,21 +272,38 @@ __global__ __launch_bounds__(H, 1) void node_chain_x3_kernel(const NodeChainX3Ar
             }
         }
     };
-    auto hidden_to_tile = [&](f32x4_t (&acc)[MI][4], const float* bias) {
+    auto hidden_to_tile = [&](f32x4_t (&acc)[MI][4], const float* bias, int hcol0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 bq = *(const float4*)(bias + fcol + j * 16);
             const nc_f2 b01 = nc_f2{bq.x, bq.y}, b23 = nc_f2{bq.z, bq.w};
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const nc_f2 t01 = nc_act_pair<ACT>(nc_f2{acc[i][j][0], acc[i][j][1]} + b01);
-                const nc_f2 t23 = nc_act_pair<ACT>(nc_f2{acc[i][j][2], acc[i][j][3]} + b23);
+                const nc_f2 z01 = nc_f2{acc[i][j][0], acc[i][j][1]} + b01, z23 = nc_f2{acc[i][j][2], acc[i][j][3]} + b23;
+                const nc_f2 t01 = nc_act_pair<ACT>(z01);
+                const nc_f2 t23 = nc_act_pair<ACT>(z23);
                 uint2 hi, lo;
                 nc_split4(make_float4(t01.x, t01.y, t23.x, t23.y), hi, lo);
                 *(uint2*)&sXh[NC_QOFF(i, j)] = hi;
                 *(uint2*)&sXl[NC_QOFF(i, j)] = lo;
+                if constexpr (SAVE && ACT == FB_ACT_SILU) {       // the stored derivative of the backward's activation adjoint: four columns of one row
+                    const int rw = i * 16 + fr;
+                    if (rw < nr && p.D16) {
+                        const nc_f2 d01 = nc_dact_pair<ACT>(z01), d23 = nc_dact_pair<ACT>(z23);
+                        *(uint2*)(p.D16 + (size_t)(m0 + rw) * p.ldd + hcol0 + fcol + j * 16) = make_uint2(pack2_bf16(d01.x, d01.y), pack2_bf16(d23.x, d23.y));
+                    }
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // SAVE: the hi plane IS bf16(hidden) -- copied out as whole rows (un-swizzled) once every wave has written its columns
+    auto flush_hidden = [&](int hcol0) {
+        if constexpr (SAVE) {
+            for (int q = tid; q < BM * CH; q += H) {
+                const int rw = q / CH, ch = q % CH;
+                if (rw < nr) *(uint4*)(p.T16 + (size_t)(m0 + rw) * p.ldt + hcol0 + ch * 8) = *(const uint4*)&sXh[rw * H + ((ch ^ (rw & SWZ)) * 8)];
+            }
         }
     };
 
@@ -293,8 +319,9 @@ __global__ __launch_bounds__(H, 1) void node_chain_x3_kernel(const NodeChainX3Ar
         __syncthreads();
         fe_gemm_x3<H, MI, SWZ>(sXh, sXl, p.W1bh, p.W1bl, wave, lane, acc);
         __syncthreads();
-        hidden_to_tile(acc, p.b1);
+        hidden_to_tile(acc, p.b1, 0);
         __syncthreads();
+        flush_hidden(0);
         fe_gemm_x3<H, MI, SWZ>(sXh, sXl, p.W2ah, p.W2al, wave, lane, out);
     } else {
 #pragma unroll 1
@@ -307,8 +334,9 @@ __global__ __launch_bounds__(H, 1) void node_chain_x3_kernel(const NodeChainX3Ar
             fe_zero(acc);
             fe_gemm_x3<H, MI, SWZ>(sXh, sXl, c ? p.W1bh : p.W1ah, c ? p.W1bl : p.W1al, wave, lane, acc);
             __syncthreads();
-            hidden_to_tile(acc, p.b1 + c * H);
+            hidden_to_tile(acc, p.b1 + c * H, c * H);
             __syncthreads();
+            flush_hidden(c * H);
             fe_gemm_x3<H, MI, SWZ>(sXh, sXl, c ? p.W2bh : p.W2ah, c ? p.W2bl : p.W2al, wave, lane, out);
         }
     }
@@ -353,9 +381,13 @@ __global__ __launch_bounds__(H, 1) void node_chain_x3_kernel(const NodeChainX3Ar
 extern "C" int fabind_node_chain_x3_fwd(const float* X1, int ld1, const float* X2, int ld2, const void* W1ah, const void* W1al,
                                         const void* W1bh, const void* W1bl, const float* b1, const void* W2ah, const void* W2al,
                                         const void* W2bh, const void* W2bl, const float* b2, int act, int kind, const float* R, int ldr,
-                                        float* out, int ldo, void* out16, int ldo16, int M, int H, hipStream_t stream) {
+                                        float* out, int ldo, void* out16, int ldo16, void* t16, int ldt, void* d16, int ldd, int M, int H,
+                                        hipStream_t stream) {
     if (M <= 0) return 0;
     FB_REQUIRE(H == 512 || H == 256 || H == 128, "fabind_node_chain_x3_fwd: H in {128, 256, 512}");
+    FB_REQUIRE(!t16 || (ldt % 8 == 0 && ((uintptr_t)t16 & 15) == 0 && (!d16 || (ldd % 4 == 0 && ((uintptr_t)d16 & 7) == 0))),
+               "fabind_node_chain_x3_fwd: saved hidden tile: ldt % 8, 16-byte aligned; derivative tile: ldd % 4, 8-byte aligned");
+    FB_REQUIRE(!d16 || (t16 && act == FB_ACT_SILU), "fabind_node_chain_x3_fwd: the derivative tile goes with a saved SiLU hidden tile");
     FB_REQUIRE(kind == 0 || kind == 1, "fabind_node_chain_x3_fwd: kind 0 (K = 2H, hidden H) or 1 (K = H, hidden 2H)");
     FB_REQUIRE(act == FB_ACT_SILU || act == FB_ACT_RELU, "fabind_node_chain_x3_fwd: silu or relu");
     FB_REQUIRE(X1 && W1ah && W1al && W1bh && W1bl && W2ah && W2al && b1 && b2 && out && (kind == 0 ? X2 != nullptr : (W2bh && W2bl)),
@@ -369,14 +401,16 @@ extern "C" int fabind_node_chain_x3_fwd(const float* X1, int ld1, const float* X
     a.W1ah = (const bf16_t*)W1ah; a.W1al = (const bf16_t*)W1al; a.W1bh = (const bf16_t*)W1bh; a.W1bl = (const bf16_t*)W1bl; a.b1 = b1;
     a.W2ah = (const bf16_t*)W2ah; a.W2al = (const bf16_t*)W2al; a.W2bh = (const bf16_t*)W2bh; a.W2bl = (const bf16_t*)W2bl; a.b2 = b2;
     a.R = R; a.ldr = ldr; a.out = out; a.ldo = ldo; a.out16 = (bf16_t*)out16; a.ldo16 = ldo16; a.M = M;
+    a.T16 = (bf16_t*)t16; a.ldt = ldt; a.D16 = (bf16_t*)d16; a.ldd = ldd;
     const dim3 grid((M + 63) / 64);
-#define NCX_LAUNCH_(HH, KK, AA)                                                                                                 \
+#define NCX_LAUNCH__(HH, KK, AA, SS)                                                                                            \
     do {                                                                                                                        \
         const size_t lds = (size_t)2 * 64 * HH * 2;                                                                             \
         static bool set_ = false;                                                                                               \
-        if (!set_) { (void)hipFuncSetAttribute((const void*)node_chain_x3_kernel<HH, KK, AA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
-        hipLaunchKernelGGL((node_chain_x3_kernel<HH, KK, AA>), grid, dim3(HH), lds, stream, a);                                  \
+        if (!set_) { (void)hipFuncSetAttribute((const void*)node_chain_x3_kernel<HH, KK, AA, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); set_ = true; } \
+        hipLaunchKernelGGL((node_chain_x3_kernel<HH, KK, AA, SS>), grid, dim3(HH), lds, stream, a);                              \
     } while (0)
+#define NCX_LAUNCH_(HH, KK, AA) do { if (t16) NCX_LAUNCH__(HH, KK, AA, true); else NCX_LAUNCH__(HH, KK, AA, false); } while (0)
 #define NCX_LAUNCH(HH)                                                                                                          \
     do {                                                                                                                        \
         if (kind == 0) { if (act == FB_ACT_SILU) NCX_LAUNCH_(HH, 0, FB_ACT_SILU); else NCX_LAUNCH_(HH, 0, FB_ACT_RELU); }        \
@@ -385,6 +419,7 @@ extern "C" int fabind_node_chain_x3_fwd(const float* X1, int ld1, const float* X
     if (H == 512) NCX_LAUNCH(512); else if (H == 256) NCX_LAUNCH(256); else NCX_LAUNCH(128);
 #undef NCX_LAUNCH
 #undef NCX_LAUNCH_
+#undef NCX_LAUNCH__
     FB_CHECK_LAUNCH();
     return 0;
 }

@@ -467,6 +467,18 @@ def _split_site_masters(model, P):
                 m = getattr(gnn, "gcl_%d" % i) if i < P["L"] else gnn.out_layer
                 d = P["gcl"][i] if i < P["L"] else P["out_layer"]
                 d["Wn_32"] = (f32(m.node_mlp[0].weight), f32(m.node_mlp[2].weight))
+            # the hi | lo fragment packs of every split-precision chain (node MLPs, both Transitions) of the model: ONE launch
+            if NODE_CHAIN and NODE_CHAIN_X3 and P["H"] in (128, 256, 512):
+                chains, where = [], []
+                for i in range(P["L"] + 1):
+                    d = P["gcl"][i] if i < P["L"] else P["out_layer"]
+                    chains.append(d["Wn_32"] + (0,)); where.append((d, "_ncx_node"))
+                for i in range(P["L"]):
+                    d = P["att"][i]
+                    chains.append(d["Wt_p32"] + (1,)); where.append((d, "_ncx_tp"))
+                    chains.append(d["Wt_c32"] + (1,)); where.append((d, "_ncx_tc"))
+                for (d, key), packs in zip(where, K.node_chain_x3_pack_many(chains)):
+                    d[key] = packs
 
 
 def _edge_frags(P):
@@ -585,7 +597,7 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
             # node MLP + residual as one autograd node (activation adjoint and residual gradient inside GEMM epilogues); train mode: the
             # dropout ahead of the residual (egnn.py:106) inside the second Linear's epilogue, its mask regenerated by the adjoint
             return ops.mlp2(hin, p["Wn1"], p["bn1"], K.ACT_SILU, p["Wn2"], p["bn2"], residual=h, x2=agg, want16=True, p_drop=pdrop,
-                            W32=p.get("Wn_32")), x_new
+                            W32=p.get("Wn_32"), chain=p.get("_ncx_node")), x_new
         if fast and pdrop == 0.0 and p.get("Wn_32") is not None:     # split-precision site (level 3): one kernel, the hidden layer on chip
             hn = _node_chain_x3(p, "_ncx_node", p["Wn_32"], p["bn1"], p["bn2"], K.ACT_SILU, 0, h, agg, h, True)
             if hn is not None:
@@ -666,7 +678,9 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
         hp = hp2
         hc16 = c16(hc)
         if p.get("Wt_c32") is not None:
-            hc2 = ops.mlp2(hc, p["Wt1_c"], p["bt1_c"], K.ACT_RELU, p["Wt2_c"], p["bt2_c"], residual=hc, W32=p["Wt_c32"])
+            hc2 = _node_chain_x3(p, "_ncx_tc", p["Wt_c32"], p["bt1_c"], p["bt2_c"], K.ACT_RELU, 1, hc, None, hc, False)
+            if hc2 is None:
+                hc2 = ops.mlp2(hc, p["Wt1_c"], p["bt1_c"], K.ACT_RELU, p["Wt2_c"], p["bt2_c"], residual=hc, W32=p["Wt_c32"])
         else:
             hc2 = _node_chain(p, "_nc_tc", p["Wt1_c"], p["bt1_c"], p["Wt2_c"], p["bt2_c"], K.ACT_RELU, 1, hc16, None, hc, False)
         if hc2 is None:
@@ -674,8 +688,9 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
             hc2 = ops.linear(t, p["Wt2_c"], p["bt2_c"], residual=hc)
         hc = hc2
     else:   # Transition + residual (cross_att.py:48-49) as one autograd node each
-        hp = ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True, W32=p.get("Wt_p32"))
-        hc = ops.mlp2(hc, p["Wt1_c"], p["bt1_c"], K.ACT_RELU, p["Wt2_c"], p["bt2_c"], residual=hc, W32=p.get("Wt_c32"))
+        hp = ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True, W32=p.get("Wt_p32"),
+                      chain=p.get("_ncx_tp"))
+        hc = ops.mlp2(hc, p["Wt1_c"], p["bt1_c"], K.ACT_RELU, p["Wt2_c"], p["bt2_c"], residual=hc, W32=p.get("Wt_c32"), chain=p.get("_ncx_tc"))
     return ops.put_rows(hp, hc, lay.c_index64)
 
 

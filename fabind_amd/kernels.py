@@ -465,9 +465,10 @@ _PACKSEG = np.dtype([("src", np.uint64), ("dst", np.uint64), ("src_sr", np.int64
                      ("src_dt", np.int32), ("pad_", np.int32)])          # = FabindPackSeg
 
 
-def pack_frag_multi(weights):
+def pack_frag_multi(weights, lo=None):
     """pack_frag of MANY [N, K] weights (any 2-D views: a transposed view is a stride swap) in one launch (csrc/gcl.hip) -> list of
-    bf16 tensors in fragment order [K/32][N/16][4][16][8]."""
+    bf16 tensors in fragment order [K/32][N/16][4][16][8].  lo: optional list of flags, True = pack the LO plane bf16(w - bf16(w)) of an
+    fp32 weight (with the plain pack of the same weight: the hi | lo operand of the split-precision kernels)."""
     from .param_pack import _upload
     n = len(weights)
     if n == 0:
@@ -482,6 +483,9 @@ def pack_frag_multi(weights):
     tab["src_sr"], tab["src_sc"] = [W.stride(0) for W in weights], [W.stride(1) for W in weights]
     tab["N"], tab["K"] = [W.shape[0] for W in weights], [W.shape[1] for W in weights]
     tab["src_dt"] = [dt_code(W.dtype) for W in weights]
+    if lo is not None:
+        assert len(lo) == n and all(W.dtype == torch.float32 for W, f_ in zip(weights, lo) if f_)
+        tab["src_dt"] = [2 if f_ else int(c_) for c_, f_ in zip(tab["src_dt"], lo)]
     tdev = _upload(tab, dev)
     check(_lib.load().fabind_pack_frag_multi(tdev.data_ptr(), tab.ctypes.data, n, stream()), "fabind_pack_frag_multi")
     outs = []
@@ -519,6 +523,34 @@ def node_chain_fwd(X1, X2, packs, b1, b2, act, kind, residual=None, want16=False
     return out, out16
 
 
+def node_chain_x3_blocks(W1, W2, kind):
+    """The H x H blocks (strided VIEWS, None for an absent one) of a chain's two fp32 master weights in pack order W1a, W1b, W2a, W2b."""
+    H = W2.shape[0]
+    if kind == 0:
+        assert W1.shape == (H, 2 * H) and W2.shape == (H, H)
+        return [W1[:, :H], W1[:, H:], W2, None]
+    assert W1.shape == (2 * H, H) and W2.shape == (H, 2 * H)
+    return [W1[:H], W1[H:], W2[:, :H], W2[:, H:]]
+
+
+def node_chain_x3_pack_many(chains):
+    """hi | lo fragment packs of MANY chains in ONE launch: chains = [(W1_32, W2_32, kind), ...] -> list of 8-tuples (node_chain_x3_fwd's
+    `packs`).  (Under autograd the packs are functions of the current weights: built once per step for the whole model.)"""
+    ws, lo, slots = [], [], []
+    for ci, (W1, W2, kind) in enumerate(chains):
+        for bi, b_ in enumerate(node_chain_x3_blocks(W1, W2, kind)):
+            if b_ is None:
+                continue
+            ws += [b_, b_]
+            lo += [False, True]
+            slots.append((ci, bi))
+    packs = pack_frag_multi(ws, lo)
+    out = [[None] * 8 for _ in chains]
+    for k, (ci, bi) in enumerate(slots):
+        out[ci][2 * bi], out[ci][2 * bi + 1] = packs[2 * k], packs[2 * k + 1]
+    return [tuple(o) for o in out]
+
+
 def node_chain_x3_pack(W1, W2, kind):
     """hi | lo fragment packs of the H x H blocks of a chain's two fp32 master weights (node_chain_x3_fwd): 8 packs in the order
     (W1a hi, lo, W1b hi, lo, W2a hi, lo, W2b hi, lo); kind as in node_chain_pack."""
@@ -535,20 +567,24 @@ def node_chain_x3_pack(W1, W2, kind):
     return tuple(out)
 
 
-def node_chain_x3_fwd(X1, X2, packs, b1, b2, act, kind, residual=None, want16=False):
-    """out = act([X1 | X2] W1^T + b1) W2^T + b2 (+ residual) in split precision with the hidden layer on chip (csrc/node_chain.hip,
-    forward only): fp32 X rows, packs from node_chain_x3_pack.  -> (out fp32 [M, H], bf16 copy or None)."""
+def node_chain_x3_fwd(X1, X2, packs, b1, b2, act, kind, residual=None, want16=False, save=False):
+    """out = act([X1 | X2] W1^T + b1) W2^T + b2 (+ residual) in split precision with the hidden layer on chip (csrc/node_chain.hip):
+    fp32 X rows, packs from node_chain_x3_pack.  -> (out fp32 [M, H], bf16 copy or None); save (training forward): + (t16, d16): bf16 of
+    the activated hidden layer [M, hidden] and (SiLU) of its derivative, what the bf16 backward of ops._MLP2 reads."""
     M, H = X1.shape
     assert X1.dtype == torch.float32 and (X2 is None or X2.dtype == torch.float32)
     out = torch.empty((M, H), dtype=torch.float32, device=X1.device)
     out16 = torch.empty((M, H), dtype=torch.bfloat16, device=X1.device) if want16 else None
     hidden = H if kind == 0 else 2 * H
+    t16 = torch.empty((M, hidden), dtype=torch.bfloat16, device=X1.device) if save else None
+    d16 = torch.empty((M, hidden), dtype=torch.bfloat16, device=X1.device) if (save and act == ACT_SILU) else None
     _profiled("fabind_node_chain_x3_fwd kind=%d M=%d H=%d" % (kind, M, H), 2.0 * M * (2 * H * hidden),
               lambda: check(_lib.load().fabind_node_chain_x3_fwd(
                   ptr(X1), _ld(X1), ptr(X2), _ld(X2) if X2 is not None else 0, *[ptr(t_) for t_ in packs[:4]], ptr(b1),
                   *[ptr(t_) for t_ in packs[4:]], ptr(b2), act, kind, ptr(residual), _ld(residual) if residual is not None else 0,
-                  ptr(out), _ld(out), ptr(out16), H if want16 else 0, M, H, stream()), "fabind_node_chain_x3_fwd"))
-    return out, out16
+                  ptr(out), _ld(out), ptr(out16), H if want16 else 0, ptr(t16), hidden if save else 0, ptr(d16), hidden if d16 is not None else 0,
+                  M, H, stream()), "fabind_node_chain_x3_fwd"))
+    return (out, out16, t16, d16) if save else (out, out16)
 
 
 def pack_frag_split(W):

@@ -436,7 +436,7 @@ class _MLP2(torch.autograd.Function):
         shared gradient buffer), so autograd adds nothing."""
 
     @staticmethod
-    def forward(ctx, x, x2, W1, b1, W2, b2, residual, act, holder=None, p_drop=0.0, seed=0, W32=None):
+    def forward(ctx, x, x2, W1, b1, W2, b2, residual, act, holder=None, p_drop=0.0, seed=0, W32=None, chain=None):
         # p_drop > 0 (round 5, train mode): dropout on the second Linear's output AHEAD of the residual (egnn.py:106) inside its fp32
         # epilogue; the adjoint regenerates the mask from (seed, row, col) in the one pass that casts dy
         assert act in (K.ACT_RELU, K.ACT_SILU)
@@ -445,10 +445,25 @@ class _MLP2(torch.autograd.Function):
         M, N1 = x.shape[0], W1.shape[0]
         ad = act_dtype()
         y16 = None
+        split_ok = W32 is not None and ctx.drop is None and _split_site_ok(x, W1, W32[0], x2, K.ACT_NONE, torch.float32, 0.0, act, None)
+        if split_ok and chain is not None and _chain_ok(x, x2, residual, W1, W2):
+            # round 6: the whole forward of the MLP as ONE split-precision kernel (csrc/node_chain.hip): the fp32 hidden layer never leaves the
+            # CU; what the (unchanged, bf16) backward needs -- bf16(hidden) and, for SiLU, bf16 of its derivative -- is written on the way
+            y, y16, t, D = K.node_chain_x3_fwd(x, x2, chain, b1.float(), b2.float(), act, 0 if x2 is not None else 1, residual=residual,
+                                               want16=holder is not None, save=True)
+            if holder is not None:
+                holder.append(y16)
+            ctx.act, ctx.has_x2, ctx.has_res = act, x2 is not None, residual is not None
+            ctx.res_is_x = residual is x
+            ctx.sink_x, ctx.sink_res = _sink_of(x), _sink_of(residual)
+            ctx.x2_dtype = x2.dtype if x2 is not None else None
+            ctx.save_for_backward(xin, x2in, W1, W2, t, D)
+            ctx.W1t, ctx.W2t = getattr(W1, "_fab_T", None), getattr(W2, "_fab_T", None)
+            return y
         if holder is not None:
             y16 = torch.empty((M, W2.shape[0]), dtype=torch.bfloat16, device=x.device)
             holder.append(y16)
-        if W32 is not None and ctx.drop is None and _split_site_ok(x, W1, W32[0], x2, K.ACT_NONE, torch.float32, 0.0, act, None):
+        if split_ok:
             # round 6, config.set_split_sites(3): BOTH contractions of the forward in split precision -- the hidden layer stays fp32 between them
             # (what the bf16 mode's remaining gap at n_iter 8 sat in: profiles/r05_precision_sites.txt).  Saved for the backward, which is
             # unchanged: the bf16 roundings of x, of the hidden activation and of its stored derivative.
@@ -517,10 +532,21 @@ class _MLP2(torch.autograd.Function):
             dres = ctx.sink_res.deposit(dres)
         if ctx.has_x2 and ni[1]:
             dx2, _ = K.gemm(dpre, W1t[K1:], out_dtype=torch.float32 if ctx.x2_dtype == torch.float32 else ctx.x2_dtype)
-        return dx, dx2, dW1, db1, dW2, (db2 if ni[5] else None), dres, None, None, None, None, None
+        return dx, dx2, dW1, db1, dW2, (db2 if ni[5] else None), dres, None, None, None, None, None, None
 
 
-def mlp2(x, W1, b1, act, W2, b2, residual=None, x2=None, want16=False, p_drop=0.0, W32=None):
+MLP2_CHAIN = os.environ.get("FABIND_MLP2_CHAIN", "1") == "1"       # 0: the split-precision MLPs under autograd as two gemm_x3 launches (A/B)
+
+
+def _chain_ok(x, x2, residual, W1, W2):
+    H = W2.shape[0]
+    ok = lambda t: t.dtype == torch.float32 and t.dim() == 2 and t.shape[1] == H and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+    kind0 = x2 is not None
+    return (MLP2_CHAIN and H in (128, 256, 512) and ok(x) and (x2 is None or ok(x2)) and (residual is None or ok(residual))
+            and tuple(W1.shape) == ((H, 2 * H) if kind0 else (2 * H, H)) and tuple(W2.shape) == ((H, H) if kind0 else (H, 2 * H)))
+
+
+def mlp2(x, W1, b1, act, W2, b2, residual=None, x2=None, want16=False, p_drop=0.0, W32=None, chain=None):
     """act([x | x2] W1^T + b1) W2^T + b2 (+ residual) -> fp32.  One autograd node under autograd (see _MLP2); without
     autograd two GEMMs with fused epilogues.  p_drop: dropout on the second Linear's output ahead of the residual, in its epilogue.
     W32 = (W1_32, W2_32) (bf16 mode, config.set_split_sites(3)): the fp32 masters -- both forward contractions then run in split precision
@@ -531,7 +557,7 @@ def mlp2(x, W1, b1, act, W2, b2, residual=None, x2=None, want16=False, p_drop=0.
         K.tn_hook(W1, b1, W2, b2)
         holder = [] if _want16(torch.float32, K.ACT_NONE, want16) else None
         seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if p_drop > 0.0 else 0
-        y = _MLP2.apply(x, x2, W1, b1, W2, b2, residual, act, holder, p_drop, seed, W32)
+        y = _MLP2.apply(x, x2, W1, b1, W2, b2, residual, act, holder, p_drop, seed, W32, chain if W32 is not None else None)
         return _attach_b16(y, holder[0] if holder else None)
     if W32 is not None:
         t = linear(x, W1, b1, act_epi=act, x2=x2, out_dtype=torch.float32, W32=W32[0])

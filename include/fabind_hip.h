@@ -179,7 +179,9 @@ typedef struct FabindCopySeg {
     int vec4, pad_;
 } FabindCopySeg;
 int fabind_multi_copy(const FabindCopySeg* segs_dev, int n_segs, int blocks_per_seg, hipStream_t stream);
-/* Many [N, K] weights (fp32 or bf16; element (n, k) at src[n * src_sr + k * src_sc], so a transposed source is a stride swap) into the
+/* (round 6: src_dt = 2 = an fp32 source whose LO plane is packed, bf16(w - bf16(w)): with src_dt = 0 of the same source the hi | lo
+ * fragment packs of the split-precision kernels.)
+ * Many [N, K] weights (fp32 or bf16; element (n, k) at src[n * src_sr + k * src_sc], so a transposed source is a stride swap) into the
  * bf16 MFMA-fragment order [K/32][N/16][4][16][8] the fused edge / pair kernels take (fabind_gcl_edge_fused: W2p, Wcp; FabindEdgeBwdArgs:
  * W2p, Wcp, W2Tp, WcTp), one launch for all.  segs_dev: the table in DEVICE memory, segs_host: the same table on the host (validated). */
 typedef struct FabindPackSeg {
@@ -718,11 +720,13 @@ int fabind_node_chain_fwd(const void* X1, int ld1, const void* X2, int ld2, cons
                           int ldo, void* out16, int ldo16, int M, int H, hipStream_t stream);
 /* The same chains in SPLIT PRECISION (round 6; bf16 mode with config.set_split_sites(3)): fp32 X rows and fp32 master weights given as
  * hi | lo bf16 fragment packs (hi = bf16(W), lo = bf16(W - hi), each in the layout of fabind_node_chain_fwd's packs); every product term
- * is three MFMAs, the hidden layer is never rounded to bf16.  X1 / X2 / R / out: fp32 rows (ld % 4 == 0, 16-byte aligned). */
+ * is three MFMAs, the hidden layer is never rounded to bf16.  X1 / X2 / R / out: fp32 rows (ld % 4 == 0, 16-byte aligned).
+ * t16 (training forward; NULL otherwise): bf16 [M, hidden] of the activated hidden layer, d16 (SiLU only): bf16 of its derivative -- the
+ * operands of the bf16 backward (weight gradient of the second Linear, activation adjoint inside the input-gradient GEMM). */
 int fabind_node_chain_x3_fwd(const float* X1, int ld1, const float* X2, int ld2, const void* W1ah, const void* W1al, const void* W1bh,
                              const void* W1bl, const float* b1, const void* W2ah, const void* W2al, const void* W2bh, const void* W2bl,
                              const float* b2, int act, int kind, const float* R, int ldr, float* out, int ldo, void* out16, int ldo16,
-                             int M, int H, hipStream_t stream);
+                             void* t16, int ldt, void* d16, int ldd, int M, int H, hipStream_t stream);
 /* Adjoint of out[e, :] = t[ia[e], :] * t[ib[e], :] (the distance-map head's LN(p_i) * LN(c_j) over every pocket residue x ligand atom
  * pair, FABind/fabind/models/model.py:355) without float atomics: the pairs of every row of t are given as a CSR (rowptr [n_rows + 1];
  * per entry the pair's row of dout and the partner's row of t); one wave per row, dT[n, :] = sum_e dout[pair_idx[e], :] * t[partner[e], :]

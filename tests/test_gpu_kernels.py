@@ -1281,6 +1281,46 @@ def test_node_chain_x3_forward_matches_float64(H, kind, act):
     assert torch.equal(K.node_chain_x3_fwd(X1, X2, packs, b1.to(dev), b2.to(dev), code, kind)[0], out_nr)          # bit-repeatable
 
 
+@pytest.mark.parametrize("H", [512, 128])
+@pytest.mark.parametrize("kind,act", [(0, "silu"), (1, "relu")])
+def test_node_chain_x3_training_forward_saves_the_backward_operands(H, kind, act):
+    """The SAVE form of the split-precision chain (ops._MLP2 under autograd at split-precision sites level 3): besides the output it leaves
+    bf16(hidden) and, for SiLU, bf16(silu'(pre)) -- the operands of the unchanged bf16 backward -- and the packs of MANY chains come from
+    one launch (kernels.node_chain_x3_pack_many == node_chain_x3_pack per chain)."""
+    from fabind_amd import kernels as K
+    dev = _dev()
+    g = torch.Generator().manual_seed(11 * H + kind)
+    M = 700 + 13
+    hid = H if kind == 0 else 2 * H
+    kin = 2 * H if kind == 0 else H
+    X = torch.randn(M, kin, generator=g)
+    W1 = (torch.randn(hid, kin, generator=g) / kin ** 0.5).to(dev)
+    W2 = (torch.randn(H, hid, generator=g) / hid ** 0.5).to(dev)
+    b1, b2 = torch.randn(hid, generator=g) * 0.3, torch.randn(H, generator=g) * 0.3
+    R = torch.randn(M, H, generator=g)
+    pre = X.double() @ W1.double().cpu().T + b1.double()
+    hidden = torch.nn.functional.silu(pre) if act == "silu" else torch.relu(pre)
+    ref = hidden @ W2.double().cpu().T + b2.double() + R.double()
+    code = K.ACT_SILU if act == "silu" else K.ACT_RELU
+    many = K.node_chain_x3_pack_many([(W1, W2, kind), (W1 * 2.0, W2, kind)])
+    one = K.node_chain_x3_pack(W1, W2, kind)
+    for a_, b_ in zip(many[0], one):
+        assert (a_ is None) == (b_ is None) and (a_ is None or torch.equal(a_.reshape(-1), b_.reshape(-1)))
+    Xd = X.to(dev)
+    X1, X2 = (Xd[:, :H].contiguous(), Xd[:, H:].contiguous()) if kind == 0 else (Xd, None)
+    out, out16, t16, d16 = K.node_chain_x3_fwd(X1, X2, many[0], b1.to(dev), b2.to(dev), code, kind, residual=R.to(dev), want16=True, save=True)
+    assert float((out.double().cpu() - ref).abs().max() / ref.abs().max()) <= 2e-5
+    assert t16.shape == (M, hid) and float((t16.double().cpu() - hidden).abs().max()) <= 2.0 ** -8 * float(hidden.abs().max())
+    if act == "silu":
+        sg = torch.sigmoid(pre)
+        dref = sg * (1 + pre * (1 - sg))
+        assert d16 is not None and float((d16.double().cpu() - dref).abs().max()) <= 6e-3          # bf16 rounding + v_exp / v_rcp
+    else:
+        assert d16 is None
+    plain, _ = K.node_chain_x3_fwd(X1, X2, many[0], b1.to(dev), b2.to(dev), code, kind, residual=R.to(dev))
+    assert torch.equal(plain, out)                                                                 # saving does not change the result
+
+
 def test_gemm_tn_multi_matches_single_launches():
     """fabind_gemm_tn_multi: many weight-gradient contractions as one launch + one reduction (kernels.gemm_tn_queued / tn_flush).  Every
     job against the single-launch result of the same operands (same kernel code path; split counts differ, so fp32 sums are compared
