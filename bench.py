@@ -164,10 +164,30 @@ def cpu_baseline(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, backward=
     return out
 
 
-def cpu_baseline_config3(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, batch=1):
-    """The headline's workload on the host: the oracle's full IaBNet (`oracle/fabind_oracle.py::model_forward`, pocket radius unbounded)
-    + the six-term loss + backward to every parameter through autograd, `batch` complexes of n_prot / n_lig nodes, fp32, 32 threads
-    (the best setting of tools/probes/cpu_threads.py).  Bounded sample: one warm-up, then as many timed runs as fit `budget_s`."""
+def cpu_baseline_config3_full(hidden, layers, n_lig, warmups=3, runs=5):
+    """SURVEY 8(d)'s CPU-baseline protocol for the HEADLINE workload of round 6 (the full IaBNet + six-term loss, forward + backward through the
+    oracle's autograd): B = 1, fp32, eval; 32 threads (>= 3 warm-ups + 5 timed runs) and 1 thread (1 warm-up + 2 runs) at 1500 / 40 with the
+    whole-protein pocket (config 3 read literally, n_iter 1); the production configuration (20 A pocket crop, n_iter 8) at 32 threads."""
+    rows = []
+    for threads, n_prot, n_iter, radius, w, r in ((32, 1500, 1, 1e9, warmups, runs), (1, 1500, 1, 1e9, 1, 2), (32, 1500, 8, 20.0, warmups, runs)):
+        run, _ = _config3_run_fn(hidden, layers, n_iter, n_prot, n_lig, 1, threads, radius)
+        for _ in range(w):
+            run()
+        ts = []
+        for _ in range(r):
+            t0 = time.time()
+            run()
+            ts.append(time.time() - t0)
+        ts.sort()
+        rows.append(dict(threads=threads, n_iter=n_iter, nodes="%d/%d" % (n_prot, n_lig), pocket="whole protein" if radius > 1e6 else "20 A crop",
+                         workload="oracle full IaBNet + six-term loss, forward + backward", batch=1,
+                         complexes_per_s=1.0 / (sum(ts) / len(ts)), best_run_s=ts[0], worst_run_s=ts[-1],
+                         protocol="%d warm-up(s) + %d timed runs" % (w, r)))
+        print(json.dumps(rows[-1]), file=sys.stderr, flush=True)
+    return dict(kind="port", host_cpus=os.cpu_count(), rows=rows)
+
+
+def _config3_run_fn(hidden, layers, n_iter, n_prot, n_lig, batch, threads, pocket_radius=1e9):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fabind_oracle as orc
     from fabind_amd import synthetic
@@ -176,8 +196,7 @@ def cpu_baseline_config3(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, b
     class _Log:
         def log_message(self, m):
             pass
-    default_threads = torch.get_num_threads()
-    torch.set_num_threads(min(default_threads, 32))
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     m = synthetic.condition_for_large_graphs(get_model(stack_args(hidden, layers, n_iter), _Log(), None))
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
@@ -186,7 +205,7 @@ def cpu_baseline_config3(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, b
             v.requires_grad_(True)
     cfg = dict(orc.DEFAULT_CFG)
     cfg.update(mean_layers=layers, n_iter=n_iter)
-    data = synthetic.make_hetero_batch([(n_prot, n_lig)] * batch, seed=0, pocket_radius=1e9)
+    data = synthetic.make_hetero_batch([(n_prot, n_lig)] * batch, seed=0, pocket_radius=pocket_radius)
 
     def run():
         for v in sd.values():
@@ -194,6 +213,15 @@ def cpu_baseline_config3(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, b
         out = orc.model_forward(sd, cfg, data.clone(), stage=1)
         loss, _ = orc.compute_loss(out, data)
         loss.backward()
+    return run, sd
+
+
+def cpu_baseline_config3(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, batch=1):
+    """The headline's workload on the host: the oracle's full IaBNet (`oracle/fabind_oracle.py::model_forward`, pocket radius unbounded)
+    + the six-term loss + backward to every parameter through autograd, `batch` complexes of n_prot / n_lig nodes, fp32, 32 threads
+    (the best setting of tools/probes/cpu_threads.py).  Bounded sample: one warm-up, then as many timed runs as fit `budget_s`."""
+    default_threads = torch.get_num_threads()
+    run, _ = _config3_run_fn(hidden, layers, n_iter, n_prot, n_lig, batch, min(default_threads, 32))
     t0 = time.time()
     run()
     first = time.time() - t0
@@ -204,9 +232,16 @@ def cpu_baseline_config3(hidden, layers, n_iter, n_prot, n_lig, budget_s=25.0, b
     dt = (time.time() - t0) / reps
     cores = torch.get_num_threads()
     torch.set_num_threads(default_threads)
-    return dict(value=batch / dt, unit="complexes/s", cores=cores, kind="port",
-                sample="oracle full IaBNet (whole-protein pocket) + six-term loss, forward + backward, B=%d, %d/%d nodes, hidden %d, %d layers, "
-                       "n_iter=%d, fp32, %d timed run(s) after one warm-up" % (batch, n_prot, n_lig, hidden, layers, n_iter, reps))
+    out = dict(value=batch / dt, unit="complexes/s", cores=cores, kind="port",
+               sample="oracle full IaBNet (whole-protein pocket) + six-term loss, forward + backward, B=%d, %d/%d nodes, hidden %d, %d layers, "
+                      "n_iter=%d, fp32, %d timed run(s) after one warm-up" % (batch, n_prot, n_lig, hidden, layers, n_iter, reps))
+    full = os.path.join(ROOT, "profiles", "r06_cpu_baseline.json")
+    if os.path.exists(full):
+        try:
+            out["protocol_8d"] = dict(json.load(open(full)), source="profiles/r06_cpu_baseline.json (committed run of `bench.py --cpu-baseline-full` on a GPU box's host, not this run)")
+        except Exception:
+            pass
+    return out
 
 
 def cpu_baseline_full(hidden, layers, n_lig, warmups=3, runs=5, batch=2, slow_run_s=40.0, skip_run_s=150.0):
@@ -309,7 +344,10 @@ def main():
     a = ap.parse_args()
 
     if a.cpu_baseline_full:
-        print(json.dumps(cpu_baseline_full(a.hidden, a.layers, a.n_lig)))
+        res = cpu_baseline_config3_full(a.hidden, a.layers, a.n_lig)
+        if os.environ.get("FABIND_CPU_BASELINE_STACK", "0") == "1":          # + the stack-only protocol of rounds 4-5 (tens of minutes)
+            res["stack_protocol"] = cpu_baseline_full(a.hidden, a.layers, a.n_lig)
+        print(json.dumps(res))
         return
     headline_config3 = a.mode == "config3"
     if headline_config3:
