@@ -285,6 +285,31 @@ def cpu_baseline_full(hidden, layers, n_lig, warmups=3, runs=5, batch=2, slow_ru
     return dict(kind="port", host_cpus=os.cpu_count(), torch_default_threads=default_threads, rows=rows)
 
 
+def north_star_targets(value, world):
+    """BASELINE.json's north_star targets next to where this build stands, said plainly.  The utilisation / bandwidth
+    figures are NOT measured in this run: they are the committed rocprofv3 PMC / kernel-trace numbers of the same command
+    (profiles/r06_pmc_util.txt, r06_pmc.json, r06_fwdbwd_kernel_stats.txt)."""
+    return {
+        "fwd_bwd_complexes_per_s_8gpu": {"target": 2000.0, "this_run": value, "n_gpus": world,
+                                         "note": "target quoted for 8 x MI355X; %s" % ("this run is one GPU: 8 x this value = %.0f if scaling were perfect (no 8-GPU "
+                                                                                      "node was available to measure it)" % (8.0 * value) if world == 1 else "measured here")},
+        "mfma_util_cross_attention": {"target": 0.30, "measured_fwd": 0.165, "measured_bwd": 0.08, "met": False,
+                                      "why": "the fused kernels' matrix-core busy time is bounded by the block's node-level I/O: per 64-row protein tile 22 MFLOP "
+                                             "against 160 KiB of fp32 q|gate rows, bf16 a0 tile and output -- 25 % at a perfect HBM floor, 17 % with the "
+                                             "projections inside (DESIGN 6.3); the backward recomputes the bias contraction twice",
+                                      "source": "profiles/r06_pmc_util.txt (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES, cross_attn_fused_*_kernel<512>)"},
+        "hbm_frac_message_passing": {"target": 0.40,
+                                     "measured": {"segment_sum (sending-side aggregation, 1.60 GB / 475 us)": 0.42,
+                                                  "block_hadamard_bwd (3.93 GB / 0.95 ms)": 0.52, "rowdot_bwd (7.86 GB / 1.76 ms)": 0.56,
+                                                  "pair_hadamard forward (3.93 GB written / 1.72 ms)": 0.29},
+                                     "met": "for the reductions; the fused edge kernels are dense contractions (SURVEY 8(d): MFMA-bound class) at 0.20 (backward) / "
+                                            "0.31 (forward) of the bf16 peak",
+                                     "source": "profiles/r06_pmc.json, r06_fwdbwd_kernel_stats.txt"},
+        "parity": {"target": "ligand RMSD <= 1e-4 A, losses <= 1e-5 relative vs the reference CPU path",
+                   "this_dtype": "1.6e-5 A / 2.0e-7 on this workload (tests/test_gpu_production.py::test_config3_whole_graph_matches_oracle, asserted at the gates)"},
+    }
+
+
 def self_launch(n):
     """--gpus N with no launcher: spawn the N ranks as a child process group (one process per GPU over RCCL) BEFORE anything in
     this process initialises the GPU; relay the child's output and exit code.  (Never re-exec a GPU-initialised process.)"""
@@ -903,6 +928,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a.hidden, a.layers, a.n_iter, a.n_prot, a.n_lig, backward=(a.mode == "fwdbwd"))
     if not a.no_cpu_baseline and world == 1 and headline_config3:
         out["cpu_baseline"] = cpu_baseline_config3(a.hidden, a.layers, a.n_iter, a.n_prot, a.n_lig)
+    if headline_config3:
+        out["north_star_targets"] = north_star_targets(out["value"], world)
     print(json.dumps(out))
 
 
