@@ -285,7 +285,7 @@ def cpu_baseline_full(hidden, layers, n_lig, warmups=3, runs=5, batch=2, slow_ru
     return dict(kind="port", host_cpus=os.cpu_count(), torch_default_threads=default_threads, rows=rows)
 
 
-def north_star_targets(value, world):
+def north_star_targets(value, world, fwd_value=None, stack_value=None):
     """BASELINE.json's north_star targets next to where this build stands, said plainly.  The utilisation / bandwidth
     figures are NOT measured in this run: they are the committed rocprofv3 PMC / kernel-trace numbers of the same command
     (profiles/r06_pmc_util.txt, r06_pmc.json, r06_fwdbwd_kernel_stats.txt)."""
@@ -293,6 +293,9 @@ def north_star_targets(value, world):
         "fwd_bwd_complexes_per_s_8gpu": {"target": 2000.0, "this_run": value, "n_gpus": world,
                                          "note": "target quoted for 8 x MI355X; %s" % ("this run is one GPU: 8 x this value = %.0f if scaling were perfect (no 8-GPU "
                                                                                       "node was available to measure it)" % (8.0 * value) if world == 1 else "measured here")},
+        "fwd_complexes_per_s_8gpu": {"target": 10000.0, "this_run_stack_forward_one_gpu": fwd_value,
+                                     "note": "north_star's forward target is only reachable for one stack pass per complex (SURVEY 8(d)); the `fwd` sub-object is that "
+                                             "pass on one GPU; the stack-only fwd+bwd step (`stack_fwdbwd`) reads %s on one GPU" % (("%.0f /s" % stack_value) if stack_value else "n/a")},
         "mfma_util_cross_attention": {"target": 0.30, "measured_fwd": 0.165, "measured_bwd": 0.08, "met": False,
                                       "why": "the fused kernels' matrix-core busy time is bounded by the block's node-level I/O: per 64-row protein tile 22 MFLOP "
                                              "against 160 KiB of fp32 q|gate rows, bf16 a0 tile and output -- 25 % at a perfect HBM floor, 17 % with the "
@@ -929,7 +932,7 @@ def main():
     if not a.no_cpu_baseline and world == 1 and headline_config3:
         out["cpu_baseline"] = cpu_baseline_config3(a.hidden, a.layers, a.n_iter, a.n_prot, a.n_lig)
     if headline_config3:
-        out["north_star_targets"] = north_star_targets(out["value"], world)
+        out["north_star_targets"] = north_star_targets(out["value"], world, out.get("fwd", {}).get("value"), out.get("stack_fwdbwd", {}).get("value"))
     print(json.dumps(out))
 
 
