@@ -2112,9 +2112,10 @@ class _SixTermLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, coords, y_pred, y_by, logits, center, coords_true, dis_map, cls, mask_u8, center_true, w):
         dev = coords.device
-        tk = _LOSS_TICKET.get(dev)
+        key = (dev, stream())                      # (one arrival counter per device AND stream: two streams must not share it)
+        tk = _LOSS_TICKET.get(key)
         if tk is None:
-            tk = _LOSS_TICKET[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+            tk = _LOSS_TICKET[key] = torch.zeros(1, dtype=torch.int32, device=dev)
         n_pair, n_coord, n_cls, n_center = y_pred.numel(), coords.numel(), logits.numel(), center.numel()
         nblk = load().fabind_loss_blocks(n_pair, n_coord, n_cls)
         part = torch.empty((nblk, 8), dtype=torch.float32, device=dev)
