@@ -799,6 +799,10 @@ EDGE_SAVE_MIN_EDGES = int(os.environ.get("FABIND_EDGE_SAVE_MIN_EDGES", "0"))
 #  FABIND_EDGE_SAVE_MIN_H=128, but the full-model step is host-bound there: 1,234 / 1,301 / 1,351 against 1,308 / 1,313 / 1,304 complexes/s in
 #  three interleaved pairs (profiles/r04_ab_same_box.txt) -- the default stays 256, which keeps 1.2 GB per pocket-model layer free)
 EDGE_SAVE_MIN_H = int(os.environ.get("FABIND_EDGE_SAVE_MIN_H", "256"))
+# (round 6, measured and NOT enabled: the saving form for large graphs at hidden 128 -- E >= EDGE_SAVE_BIG_EDGES edges -- reads 539 / 538 against
+#  543 / 547 complexes/s on the config-3 headline and 1,371 / 1,342 against 1,326 / 1,335 on the production-shape model step, two interleaved
+#  pairs each (profiles/r06_ab_same_box.txt): the default keeps it off)
+EDGE_SAVE_BIG_EDGES = int(os.environ.get("FABIND_EDGE_SAVE_BIG_EDGES", "2000000000"))
 
 
 class _FusedEdge(torch.autograd.Function):
@@ -811,7 +815,7 @@ class _FusedEdge(torch.autograd.Function):
         ctx.H, ctx.g, ctx.p_drop, ctx.seed, ctx.frags = H, g, p_drop, seed, frags
         W2p, Wcp = (frags[0], frags[1]) if frags is not None else (K.pack_frag(W2), K.pack_frag(Wc))
         E = g.row_ctx.shape[0]
-        save = EDGE_SAVE_FWD and H >= EDGE_SAVE_MIN_H and E >= max(1, EDGE_SAVE_MIN_EDGES) and AB16.dtype == torch.bfloat16
+        save = EDGE_SAVE_FWD and (H >= EDGE_SAVE_MIN_H or (H >= 128 and E >= EDGE_SAVE_BIG_EDGES)) and E >= max(1, EDGE_SAVE_MIN_EDGES) and AB16.dtype == torch.bfloat16
         out = K.gcl_edge_fused(AB16, H, g.row_ctx, g.col_ctx, rhohat, w_r, W2p, b2, Wcp, bc, w3,
                                AB16.shape[0], p_drop, seed, want16=holder is not None, rowptr=g.rp_ctx, save=save)
         ctx.n_saved = 3 if save else 0
