@@ -152,6 +152,7 @@ SIGNATURES = {
     "fabind_pocket_center_bwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "fabind_pair_dist_fwd": [_vp, _i, _i, _vp, _vp, _f, _f, _f, _vp, _vp],
     "fabind_pair_dist_bwd": [_vp, _i, _i, _vp, _vp, _vp, _f, _f, _f, _vp, _vp, _vp],
+    "fabind_block_hadamard_fwd": [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp, _i, _vp],
     "fabind_block_hadamard_bwd": [_vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _vp],
     "fabind_loss_fwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _vp, _l, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp],
     "fabind_loss_bwd": [_vp, _vp, _l, _vp, _vp, _vp, _l, _vp, _vp, _i, _l, _vp, _vp, _l, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp,

@@ -361,6 +361,32 @@ __global__ __launch_bounds__(256) void block_hadamard_bwd_kernel(const PairBlock
         }
     }
 }
+// Forward of the same product on the block descriptors: out[pair(i, j), :] = bf16(tp[p_row0 + i, :] * tc[c_row0 + j, :]).  A thread owns 8
+// columns (one 16-byte bf16 store per pair), W / 8 threads span a row, 256 / (W / 8) atoms j run side by side; the protein row stays in
+// registers across its C_b pairs, the complex's ligand rows come from L1 / L2 (40 x 2 KiB at the headline shape).
+template <int W>
+__global__ __launch_bounds__(256) void block_hadamard_fwd_kernel(const PairBlock* __restrict__ desc, int B, const float* __restrict__ tp,
+                                                                 int ldtp, const float* __restrict__ tc, int ldtc, bf16_t* out, int ldo) {
+    constexpr int CT = W / 8, RP = 256 / CT;               // column threads per row, rows (atoms) in parallel
+    const int b = pb_find(desc, B, blockIdx.x);
+    const PairBlock d = desc[b];
+    const int i0 = (blockIdx.x - d.tile0) * PB_TP, i1 = min(d.P, i0 + PB_TP);
+    if (i0 >= d.P) return;
+    const int ct = threadIdx.x % CT, rg = threadIdx.x / CT, c8 = ct * 8;
+    for (int i = i0; i < i1; ++i) {
+        const float4 p0 = *(const float4*)(tp + (size_t)(d.p_row0 + i) * ldtp + c8), p1 = *(const float4*)(tp + (size_t)(d.p_row0 + i) * ldtp + c8 + 4);
+        bf16_t* orow = out + (size_t)(d.pair_off + (long)i * d.C) * ldo + c8;
+        for (int j = rg; j < d.C; j += RP) {
+            const float* c = tc + (size_t)(d.c_row0 + j) * ldtc + c8;
+            const float4 q0 = *(const float4*)c, q1 = *(const float4*)(c + 4);
+            typedef __attribute__((ext_vector_type(4))) unsigned int nc_u4;
+            const nc_u4 v = {pack2_bf16(p0.x * q0.x, p0.y * q0.y), pack2_bf16(p0.z * q0.z, p0.w * q0.w),
+                             pack2_bf16(p1.x * q1.x, p1.y * q1.y), pack2_bf16(p1.z * q1.z, p1.w * q1.w)};
+            __builtin_nontemporal_store(v, (nc_u4*)(orow + (size_t)j * ldo));
+        }
+    }
+}
+
 // d tc[c_row0 + j, :] = sum over the complex's tiles (in tile order) of part[tile][chunk of j][j % 20][:]
 __global__ __launch_bounds__(256) void block_hadamard_bwd_reduce_kernel(const PairBlock* __restrict__ desc, int B, const int* __restrict__ row_b,
                                                                         int W, int nchunk_max, const float* __restrict__ part, float* dtc,
@@ -395,6 +421,21 @@ extern "C" int fabind_pair_dist_bwd(const void* desc, int B, int max_C, const fl
     hipLaunchKernelGGL(pair_dist_bwd_kernel, dim3(B, 8), dim3(256), 0, stream, (const PairBlock*)desc, xp, xc, dy, scale, lo, hi, max_C, part);
     FB_CHECK_LAUNCH();
     hipLaunchKernelGGL(pair_dist_bwd_reduce_kernel, dim3(B), dim3(256), 0, stream, (const PairBlock*)desc, B, max_C, part, dxc);
+    FB_CHECK_LAUNCH();
+    return 0;
+}
+extern "C" int fabind_block_hadamard_fwd(const void* desc, int B, int n_tiles, const float* tp, int ldtp, const float* tc, int ldtc, int W,
+                                         void* out, int ldo, hipStream_t stream) {
+    FB_REQUIRE(W == 64 || W == 128 || W == 256 || W == 512, "fabind_block_hadamard_fwd: W in {64, 128, 256, 512}");
+    FB_REQUIRE(ldtp % 4 == 0 && ldtc % 4 == 0 && ldo % 8 == 0 && ((((uintptr_t)tp | (uintptr_t)tc | (uintptr_t)out) & 15) == 0),
+               "fabind_block_hadamard_fwd: 16-byte aligned rows");
+    if (B <= 0 || n_tiles <= 0) return 0;
+    const PairBlock* dd = (const PairBlock*)desc;
+    bf16_t* o = (bf16_t*)out;
+    if (W == 512) hipLaunchKernelGGL((block_hadamard_fwd_kernel<512>), dim3(n_tiles), dim3(256), 0, stream, dd, B, tp, ldtp, tc, ldtc, o, ldo);
+    else if (W == 256) hipLaunchKernelGGL((block_hadamard_fwd_kernel<256>), dim3(n_tiles), dim3(256), 0, stream, dd, B, tp, ldtp, tc, ldtc, o, ldo);
+    else if (W == 128) hipLaunchKernelGGL((block_hadamard_fwd_kernel<128>), dim3(n_tiles), dim3(256), 0, stream, dd, B, tp, ldtp, tc, ldtc, o, ldo);
+    else hipLaunchKernelGGL((block_hadamard_fwd_kernel<64>), dim3(n_tiles), dim3(256), 0, stream, dd, B, tp, ldtp, tc, ldtc, o, ldo);
     FB_CHECK_LAUNCH();
     return 0;
 }

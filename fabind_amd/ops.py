@@ -1503,6 +1503,9 @@ class _RowsHadamard(torch.autograd.Function):
     def forward(ctx, t, ia, ib, a_sorted=False, blocks=None, n_a=0):
         ctx.save_for_backward(t, ia, ib)
         ctx.a_sorted, ctx.blocks, ctx.n_a = a_sorted, blocks, n_a
+        fwd = _block_hadamard_fwd(t, blocks, n_a)
+        if fwd is not None:
+            return fwd
         dummy = t[:, :0]
         return K.pair_hadamard(t, t, dummy, dummy, ia, ib, act_dtype())
 
@@ -1569,6 +1572,18 @@ def _rows_hadamard_csr(ia, ib, n, a_sorted=False):
 ROWS_HADAMARD_WALK = os.environ.get("FABIND_ROWS_HADAMARD_WALK", "1") == "1"      # adjoint of rows_hadamard as a row walk (0: float atomics)
 
 
+def _block_hadamard_fwd(t, bl, n_a):
+    """The forward on the block descriptors (bf16 result, W in {64 .. 512}); None when the shapes do not fit."""
+    W = t.shape[1]
+    if not (bl is not None and act_dtype() == torch.bfloat16 and t.dtype == torch.float32 and W in (64, 128, 256, 512) and t.stride(1) == 1
+            and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and n_a == bl.n_prows and t.shape[0] == bl.n_prows + bl.n_crows and n_a % 4 == 0):
+        return None
+    out = torch.empty((bl.n_pairs, W), dtype=torch.bfloat16, device=t.device)
+    check(load().fabind_block_hadamard_fwd(bl.desc_ptr, bl.B, bl.n_tiles, ptr(t), t.stride(0), ptr(t[n_a:]), t.stride(0), W, ptr(out), W,
+                                           stream()), "fabind_block_hadamard_fwd")
+    return out
+
+
 def rows_hadamard(t, idx_a, idx_b, a_sorted=False, blocks=None, n_a=0):
     """einsum('bik,bjk->bijk') restricted to the valid pairs (reference model.py:355).  a_sorted: idx_a is non-decreasing (a
     protein-major pair list) -- the adjoint's index glue skips one sort.  blocks (PairBlocks) + n_a: the same pairs as dense per-complex
@@ -1576,6 +1591,9 @@ def rows_hadamard(t, idx_a, idx_b, a_sorted=False, blocks=None, n_a=0):
     ia, ib = idx_a.to(torch.int32).contiguous(), idx_b.to(torch.int32).contiguous()
     if _needs_grad(t):
         return _RowsHadamard.apply(t, ia, ib, a_sorted, blocks, n_a)
+    fwd = _block_hadamard_fwd(t, blocks, n_a)
+    if fwd is not None:
+        return fwd
     dummy = t[:, :0]
     return K.pair_hadamard(t, t, dummy, dummy, ia, ib, act_dtype())
 

@@ -557,6 +557,8 @@ int fabind_pair_dist_fwd(const void* desc, int B, int n_tiles, const float* xp, 
                          float* y, hipStream_t stream);
 int fabind_pair_dist_bwd(const void* desc, int B, int max_C, const float* xp, const float* xc, const float* dy, float scale, float lo,
                          float hi, float* part, float* dxc, hipStream_t stream);
+int fabind_block_hadamard_fwd(const void* desc, int B, int n_tiles, const float* tp, int ldtp, const float* tc, int ldtc, int W, void* out,
+                              int ldo, hipStream_t stream);      /* out[pair, :] = bf16(tp[p_row0 + i, :] * tc[c_row0 + j, :]) */
 int fabind_block_hadamard_bwd(const void* desc, int B, int n_tiles, const void* dout, int ldo, const float* tp, int ldtp,
                               const float* tc, int ldtc, int W, const int* row_b, int n_crows, int nchunk_max, float* part,
                               float* dtp, int lddp, float* dtc, int lddc, hipStream_t stream);
