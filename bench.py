@@ -302,9 +302,9 @@ def north_star_targets(value, world, fwd_value=None, stack_value=None):
                                              "projections inside (DESIGN 6.3); the backward recomputes the bias contraction twice",
                                       "source": "profiles/r06_pmc_util.txt (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES, cross_attn_fused_*_kernel<512>)"},
         "hbm_frac_message_passing": {"target": 0.40,
-                                     "measured": {"segment_sum (sending-side aggregation, 1.60 GB / 475 us)": 0.42,
-                                                  "block_hadamard_bwd (3.93 GB / 0.95 ms)": 0.52, "rowdot_bwd (7.86 GB / 1.76 ms)": 0.56,
-                                                  "pair_hadamard forward (3.93 GB written / 1.72 ms)": 0.29},
+                                     "measured": {"segment_sum (sending-side aggregation, 1.60 GB / 483 us)": 0.41,
+                                                  "block_hadamard_bwd (3.93 GB / 0.92 ms)": 0.53, "rowdot_bwd (7.86 GB / 1.74 ms)": 0.56,
+                                                  "block_hadamard_fwd (3.93 GB written / 1.24 ms)": 0.40},
                                      "met": "for the reductions; the fused edge kernels are dense contractions (SURVEY 8(d): MFMA-bound class) at 0.20 (backward) / "
                                             "0.31 (forward) of the bf16 peak",
                                      "source": "profiles/r06_pmc.json, r06_fwdbwd_kernel_stats.txt"},
