@@ -93,6 +93,10 @@ def test_bench_line_carries_the_neighbouring_configurations():
     assert r["stack_fwdbwd"]["pass"] == "fwdbwd" and r["config3_gate"]["pass"] == "model" and r["config3_gate"]["dtype"] == "bf16x3"
     # the headline is BASELINE configs[2] read literally and says so: the full model on the whole graph, the six losses named
     assert r["config"]["pass"] == "model" and all(w in r["metric"] for w in ("pocket-cls", "pocket-centre", "coord", "distmap", "distill"))
+    # north_star's targets ride in the line with where this build stands, said plainly (the 30 % matrix-core bar of the cross attention is NOT met)
+    ns = r["north_star_targets"]
+    assert ns["mfma_util_cross_attention"]["met"] is False and ns["mfma_util_cross_attention"]["target"] == 0.30
+    assert ns["fwd_bwd_complexes_per_s_8gpu"]["target"] == 2000.0 and ns["fwd_complexes_per_s_8gpu"]["this_run_stack_forward_one_gpu"] == r["fwd"]["value"]
     # nothing else in the line is an unreported failure either
     assert not [k for k, v in r.items() if isinstance(v, dict) and "error" in v]
 
