@@ -553,11 +553,13 @@ def _node_chain_x3(p, key, W32, b1, b2, act, kind, x1, x2, residual, want16):
         return None
     packs = p.get(key)
     if packs is None:
-        packs = p[key] = K.node_chain_x3_pack(W32[0], W32[1], kind)
+        with torch.no_grad():
+            packs = p[key] = K.node_chain_x3_pack_many([(W32[0].detach(), W32[1].detach(), kind)])[0]      # (one launch)
     out, out16 = K.node_chain_x3_fwd(x1, x2 if kind == 0 else None, packs, b1.float(), b2.float(), act, kind, residual=residual, want16=want16)
     return ops._attach_b16(out, out16)
 
 
+X3_NOGRAD_CHAIN = os.environ.get("FABIND_X3_NOGRAD_CHAIN", "1") == "1"   # 0: no-grad passes of 'bf16x3' run their MLPs as two gemm_x3 launches (A/B)
 NODE_CHAIN_X3 = os.environ.get("FABIND_NODE_CHAIN_X3", "1") == "1"     # 0: the split-precision MLPs of no-grad passes as two gemm_x3 launches (A/B)
 
 
@@ -593,6 +595,13 @@ def gcl_layer(p, h, x, lay, g, clampv, pdrop=0.0):
             k_ = "gcl_dbg_%d" % sum(1 for q in DEBUG_CAPTURE if q.startswith("gcl_dbg_") and q.endswith(".s"))
             DEBUG_CAPTURE[k_ + ".xin"], DEBUG_CAPTURE[k_ + ".d"], DEBUG_CAPTURE[k_ + ".rhohat"] = x.detach().clone(), d.detach().clone(), rhohat.detach().clone()
             DEBUG_CAPTURE[k_ + ".agg"], DEBUG_CAPTURE[k_ + ".s"] = agg.detach().clone(), s.detach().clone()
+        if (get_precision() == "bf16x3" and X3_NOGRAD_CHAIN and pdrop == 0.0 and p["Wn1"].dtype == torch.float32
+                and not ops.needs_grad(h, agg, p["Wn1"], p["Wn2"])):
+            # round 6: a no-grad pass of the 'bf16x3' mode takes the same split-precision chain kernel (fp32 weights -> hi | lo packs, cached
+            # with the no-grad parameter pack): no fp32 hidden layer in HBM
+            hn = _node_chain_x3(p, "_ncx3_node", (p["Wn1"], p["Wn2"]), p["bn1"], p["bn2"], K.ACT_SILU, 0, h, agg, h, True)
+            if hn is not None:
+                return hn, x_new
         if not fast:
             # node MLP + residual as one autograd node (activation adjoint and residual gradient inside GEMM epilogues); train mode: the
             # dropout ahead of the residual (egnn.py:106) inside the second Linear's epilogue, its mask regenerated by the adjoint
@@ -687,6 +696,12 @@ def cross_attention(p, h, lay, pairbias, layer, pdrop=0.0):
             t = ops.linear(hc16, p["Wt1_c"], p["bt1_c"], act_epi=K.ACT_RELU, out_dtype=od)
             hc2 = ops.linear(t, p["Wt2_c"], p["bt2_c"], residual=hc)
         hc = hc2
+    elif (get_precision() == "bf16x3" and X3_NOGRAD_CHAIN and p["Wt1_p"].dtype == torch.float32
+          and not ops.needs_grad(hp, hc, p["Wt1_p"], p["Wt2_p"], p["Wt1_c"], p["Wt2_c"])):
+        hp2 = _node_chain_x3(p, "_ncx3_tp", (p["Wt1_p"], p["Wt2_p"]), p["bt1_p"], p["bt2_p"], K.ACT_RELU, 1, hp, None, hp, True)
+        hp = hp2 if hp2 is not None else ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True)
+        hc2 = _node_chain_x3(p, "_ncx3_tc", (p["Wt1_c"], p["Wt2_c"]), p["bt1_c"], p["bt2_c"], K.ACT_RELU, 1, hc, None, hc, False)
+        hc = hc2 if hc2 is not None else ops.mlp2(hc, p["Wt1_c"], p["bt1_c"], K.ACT_RELU, p["Wt2_c"], p["bt2_c"], residual=hc)
     else:   # Transition + residual (cross_att.py:48-49) as one autograd node each
         hp = ops.mlp2(hp, p["Wt1_p"], p["bt1_p"], K.ACT_RELU, p["Wt2_p"], p["bt2_p"], residual=hp, want16=True, W32=p.get("Wt_p32"),
                       chain=p.get("_ncx_tp"))
